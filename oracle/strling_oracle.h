@@ -1,0 +1,172 @@
+/*
+ * strling_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A literal, single-threaded, plain-C restatement of the STRling (v0.6.0)
+ * extract + cluster hot path, used as the parity checker for the HIP path and
+ * as the `cpu_baseline` leg of bench.py.  Nothing under strling_amd/ may
+ * include, link or call this file.
+ *
+ * PARITY STATUS: pinned against every known-answer test the reference holds
+ * for this path (tests/test_strling.nim, test_utils.nim, test_extract.nim,
+ * test_cluster.nim -- transcribed in tests/golden/reference_kats.json).  The
+ * real Nim binary cannot be built in this image (no nim / htslib / nimble
+ * packages), so behaviours that no reference test pins -- the kmer module's
+ * base->2bit table for non-ACGT symbols, msgpack4nim integer widths and Nim
+ * 1.6 Table/CountTable slot order -- are "parity unpinned" and each lives
+ * behind one small function here.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the STRling repository root).
+ */
+#ifndef STRLING_ORACLE_H
+#define STRLING_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Soft enum, src/strpkg/cluster.nim:14-20 ---- */
+enum { ORC_SOFT_LEFT = 0, ORC_SOFT_RIGHT = 1, ORC_SOFT_BOTH = 2, ORC_SOFT_NONE = 3,
+       ORC_SOFT_NONE_RIGHT = 4, ORC_SOFT_NONE_LEFT = 5 };
+
+/* ---- tread, src/strpkg/cluster.nim:23-32 ---- */
+typedef struct {
+  int32_t  tid;
+  uint32_t position;
+  char     repeat[6];
+  uint16_t flag;
+  uint8_t  split;
+  uint8_t  mapping_quality;
+  uint8_t  repeat_count;
+  uint8_t  align_length;
+  int64_t  qname_id;   /* index of the record whose qname this tread carries, or (merge) the sample index */
+  int64_t  src;        /* bookkeeping: record index that produced it (not part of the reference type) */
+} orc_tread;
+
+/* ---- Options, src/strpkg/utils.nim:119-127 ---- */
+typedef struct {
+  int     median_fragment_length;
+  double  proportion_repeat;
+  uint8_t min_mapq;
+} orc_opts;
+
+/* ---- a batch of BAM records, fields as hts-nim exposes them to extract.nim ---- */
+typedef struct {
+  int64_t n;
+  const int32_t  *tid, *pos, *mtid, *mpos;
+  const uint16_t *flag;
+  const uint8_t  *mapq;
+  const uint32_t *cigar_off;   /* n+1 */
+  const uint32_t *cigar;       /* BAM encoding: len<<4 | op */
+  const uint64_t *seq_off;     /* n, byte offset of each record's 4-bit packed SEQ */
+  const int32_t  *l_seq;       /* n */
+  const uint8_t  *seq4;        /* BAM nibble packing, high nibble first */
+  const uint64_t *qname_off;   /* n+1 */
+  const char     *qnames;
+} orc_records;
+
+/* genome STR intervals (ref.fasta.str), grouped per tid; iv_off[tid]..iv_off[tid+1];
+ * has_chrom[tid] != 0 iff the chromosome name is a key of the table (read_bed.nim:30-50) */
+typedef struct {
+  int32_t n_tid;
+  const uint8_t *has_chrom;
+  const int64_t *iv_off;      /* n_tid+1 */
+  const int32_t *iv_start, *iv_stop;
+} orc_genome_str;
+
+/* kmer module (brentp/nim-kmer, not vendored): base -> 2-bit code and back. */
+unsigned orc_kmer_code(char c);
+char     orc_kmer_base(unsigned code);
+
+/* utils.nim:10-34 */
+int  orc_slide_by(const char *s, int len, int k, uint64_t *out);
+/* utils.nim:236-271 */
+void orc_get_repeat(const char *read, int len, double proportion_repeat, char rep[6], int *repeat_count);
+/* utils.nim:220-233 */
+int  orc_reduce_repeat(char rep[6]);
+/* utils.nim:61-80 */
+void orc_min_rev_complement(char rep[6]);
+/* utils.nim:304-310 */
+void orc_canonical_repeat(const char in[6], char out[6]);
+/* utils.nim:139-146 */
+int  orc_median(const uint32_t frag[4096], double pct);
+/* extract.nim:56-58 */
+double orc_p_repeat(const orc_tread *t);
+/* extract.nim:141-179 */
+int  orc_adjust_by(orc_tread *A, const orc_tread *B, const orc_opts *o, uint32_t B_position);
+/* extract.nim:182-190 */
+int  orc_unplaced_pair(const orc_tread *A, const orc_tread *B, const orc_opts *o);
+
+/* extract.nim:20-40 + 63-87 (to_tread) for record i; also returns the decoded whole-read result */
+void orc_to_tread(const orc_records *r, int64_t i, const orc_genome_str *g, const orc_opts *o, orc_tread *out);
+
+/* extract.nim:93-132: soft-clip scan of record i with the (already lowered) proportion p.
+ * Writes 0..2 treads to out, returns how many. */
+int  orc_add_soft(const orc_records *r, int64_t i, const orc_opts *o, double p, const char read_repeat[6], orc_tread out[2]);
+
+/* extract.nim:192-248 + 308-329: the whole extract loop over `r` (records already filtered to
+ * what `for aln in ibam` yields, in file order); n_tail = number of trailing records that
+ * `ibam.query("*")` would revisit (tid == -1 block at the end).  Returns number of treads written
+ * (at most cap); *n_needed gets the total. */
+int64_t orc_extract(const orc_records *r, int64_t n_tail, const orc_genome_str *g, const orc_opts *o,
+                    orc_tread *out, int64_t cap, int64_t *n_needed);
+
+/* per-record scorer outputs, for kernel parity (whole read + both soft ends under both lowered
+ * thresholds).  Each result = unit (6 chars) + count (after reduce_repeat) + align_length. */
+typedef struct { char rep[6]; int32_t count; int32_t align_length; } orc_seg_result;
+void orc_score_record(const orc_records *r, int64_t i, const orc_genome_str *g, const orc_opts *o,
+                      orc_seg_result *whole, orc_seg_result soft[4] /* L-first, L-after, R-first, R-after */,
+                      int *skipped);
+
+/* ---- clustering ---- */
+typedef struct {
+  int32_t  tid;
+  uint32_t left, left_most, right, right_most, center_mass;
+  uint16_t n_left, n_right, n_total;
+  char     repeat[7];
+} orc_bounds;
+
+/* cluster.nim:175-250; reads must be the cluster's reads in order; left_most/right_most = Cluster fields */
+void orc_bounds_of(const orc_tread *reads, int64_t n, uint32_t cl_left_most, uint32_t cl_right_most,
+                   uint16_t max_clip_dist, orc_bounds *b);
+
+/* One emitted cluster: [first, first+n) indexes into the *sorted group array* handed to the callback. */
+typedef void (*orc_cluster_cb)(void *ud, const orc_tread *reads, int64_t n, uint32_t left_most, uint32_t right_most);
+/* cluster.nim:323-374 (cluster -> trcluster -> split_cluster) on one (tid, repeat) group sorted by position */
+void orc_cluster_group(const orc_tread *reps, int64_t n, uint32_t max_dist, int min_supporting_reads,
+                       orc_cluster_cb cb, void *ud);
+
+/* merge.nim:91-187 / call.nim:118-130,221-262 restricted to the bounds they derive from treads:
+ * groups by (tid, repeat) in Nim Table slot order, stable sort by position, cluster, gate through
+ * callclusters.nim:52-66.  mode 0 = merge (drops tid<0 on load, has_per_sample_reads with
+ * qname_id = sample), mode 1 = call (unplaced groups are reported in unplaced[] instead).
+ * Returns number of bounds (at most cap).  */
+typedef struct { char repeat[7]; int64_t count; } orc_unplaced;
+int64_t orc_call_bounds(const orc_tread *treads, int64_t n, int mode, uint32_t window, int min_support,
+                        uint16_t min_clip, uint16_t min_clip_total, uint16_t max_clip_dist,
+                        orc_bounds *out, int64_t cap, orc_unplaced *unpl, int64_t unpl_cap, int64_t *n_unpl);
+
+/* ---- Nim 1.6 stdlib emulation (hashes.nim / tables.nim) ---- */
+uint64_t orc_nim_hash_int(uint64_t x);                 /* hashWangYi1 */
+uint64_t orc_nim_hash_bytes(const uint8_t *p, int n);  /* murmurHash */
+uint64_t orc_nim_hash_tidrep(int32_t tid, const char rep[6]);
+/* CountTable[uint32] built by inc() in the given order; returns key/val of `largest` */
+void orc_counttable_largest(const uint32_t *keys, int64_t n, int initial_size, uint32_t *key, int64_t *val, int64_t *n_distinct);
+
+/* ---- .bin (extract.nim:336-346, cluster.nim:38-50, unpack.nim:36-133) ---- */
+/* writes header+records to buf (cap bytes); returns bytes needed. qname via callback-free arrays */
+int64_t orc_bin_write(uint8_t *buf, int64_t cap, float proportion_repeat, uint8_t min_mapq,
+                      const uint32_t frag[4096], const char *sam_header, int32_t hdr_len,
+                      const orc_tread *treads, int64_t n, const uint64_t *qname_off, const char *qnames);
+/* msgpack one tread (returns bytes written) */
+int orc_pack_tread(uint8_t *buf, const orc_tread *t, const char *qname, uint32_t qlen);
+
+/* text row, cluster.nim:262-266 */
+int orc_bounds_row(char *buf, int cap, const orc_bounds *b, const char *chrom);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
