@@ -1,0 +1,168 @@
+#!/usr/bin/env python
+"""bench.py -- reads/s through the extract hot path on N MI355X (one process per GPU).
+
+A "step" = one pass of the device hot path (classify -> score -> soft-clip scan kernels, the
+whole `strl_score_reads` entry point) over one HBM-resident batch of synthetic 150 bp paired-end
+WGS records (input S1).  Reads shard by record, so with N > 1 every rank scores
+its own batch and no collective sits on the data path (weak scaling); the only collectives are
+the barrier + MAX of the elapsed time the contract asks for.
+
+Prints ONE JSON line on rank 0 (see the task contract): value = reads of ALL ranks / max-rank time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads-per-gpu", type=int, default=2 ** 25, help="reads resident per GPU (2^24 pairs, SURVEY S1)")
+    ap.add_argument("--base-pairs", type=int, default=2 ** 18, help="unique synthetic pairs generated on the host, tiled in HBM")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline budget (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from strling_amd import api, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+
+    # ---- synthetic S1 base sample on the host, tiled into HBM -------------------------------------
+    rec, g = synth.synth_wgs(args.base_pairs, seed=1234 + rank, with_qnames=False)
+    soa = api.Soa(rec)
+    n_base = soa.n
+    tiles = max(1, args.reads_per_gpu // n_base)
+    n = n_base * tiles
+    stride16 = int(soa.seq_off[1] - soa.seq_off[0]) if n_base > 1 else 5
+    seq_bytes_base = n_base * stride16 * 16
+
+    def tile(a, dt):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev).view(dt).repeat(tiles)
+
+    d = dict(tid=tile(soa.tid, torch.int32), pos=tile(soa.pos, torch.int32), end=tile(soa.end, torch.int32),
+             l_seq=tile(soa.l_seq.view(np.int16), torch.int16), clip_l=tile(soa.clip_l.view(np.int16), torch.int16),
+             clip_r=tile(soa.clip_r.view(np.int16), torch.int16), mapq=tile(soa.mapq, torch.uint8), cig=tile(soa.cig, torch.uint8))
+    so = torch.from_numpy(soa.seq_off.astype(np.int64)).to(dev)
+    d["seq_off"] = (so[None, :] + (torch.arange(tiles, device=dev, dtype=torch.int64) * (seq_bytes_base // 16))[:, None]).reshape(-1).to(torch.int32)
+    seq_base = torch.from_numpy(soa.seq4[:seq_bytes_base]).to(dev)
+    d["seq4"] = torch.cat([seq_base.repeat(tiles), torch.zeros(64, dtype=torch.uint8, device=dev)])
+    whole = torch.zeros(n, dtype=torch.int32, device=dev)
+    soft_cap = max(1024, n // 8)
+    soft = torch.zeros((soft_cap, 4), dtype=torch.int32, device=dev)
+    cs = api.CReadSoa(n, d["tid"].data_ptr(), d["pos"].data_ptr(), d["end"].data_ptr(), d["seq_off"].data_ptr(), d["l_seq"].data_ptr(),
+                      d["clip_l"].data_ptr(), d["clip_r"].data_ptr(), d["mapq"].data_ptr(), d["cig"].data_ptr(), d["seq4"].data_ptr(),
+                      d["seq4"].numel(), soa.max_l_seq, api.MEM_DEVICE)
+    torch.cuda.synchronize()
+
+    ctx = api.Context(local)
+    med = api.frag_median(synth.frag_hist(rec))
+    ctx.set_opts(0.8, 40, med)      # reference defaults: -p 0.8 -q 40 (extract.nim:255-256)
+    ctx.set_genome(g)
+
+    # one synchronous pass for the unit counts of each kernel
+    n_soft, st = ctx.score_device(cs, whole.data_ptr(), soft.data_ptr(), soft_cap, sync=True)
+    for _ in range(args.warmup):
+        ctx.score_device(cs, whole.data_ptr(), soft.data_ptr(), soft_cap)
+    ctx.sync()
+    ctx.enable_timing(True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.score_device(cs, whole.data_ptr(), soft.data_ptr(), soft_cap)
+    ctx.sync()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    (ms_classify, ms_score, ms_soft), launches = ctx.kernel_times()
+    ctx.enable_timing(False)
+
+    # ---- roofline of the dominant kernel (HIP-event durations on the kernels' own stream) ----------
+    launches = max(1, launches)
+    L = int(soa.max_l_seq)
+    seq_b = (L + 1) // 2
+    kernels = {
+        # algorithmic bytes per launch (DESIGN.md "Kernels"): classify streams 13 B of coordinates per read and writes a
+        # 4 B result word or a 4 B queue entry; score reads 4 B queue + 12 B metadata + ceil(L/2) B SEQ and writes 4 B;
+        # soft reads 4 B queue + 8 B metadata + the clipped bases (<= ceil(L/2) B, counted as ceil(L/4) on average) and writes 16 B.
+        "classify_kernel": (ms_classify / launches, 17.0 * n),
+        "score_kernel<whole>": (ms_score / launches, (20.0 + seq_b) * st.n_scored),
+        "score_kernel<soft>": (ms_soft / launches, (28.0 + (L + 3) // 4) * st.n_soft_items),
+    }
+    dom = max(kernels, key=lambda k: kernels[k][0])
+    dom_ms, dom_bytes = kernels[dom]
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                "kernel_ms": {k: round(v[0], 4) for k, v in kernels.items()},
+                "kernel_alg_bytes": {k: int(v[1]) for k, v in kernels.items()},
+                "pipeline_alg_GBps": round(sum(v[1] for v in kernels.values()) / (el / args.steps) / 1e9, 2),
+                "survey_115B_per_read_GBps": round(115.0 * n / (el / args.steps) / 1e9, 2)}
+
+    # ---- CPU baseline: the oracle ("port" of the reference algorithm), 1 thread, bounded sample ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        sample_pairs = min(args.base_pairs, 2 ** 17)
+        srec, sg = synth.synth_wgs(sample_pairs, seed=1234)
+        opts = O.make_opts(med, 0.8, 40)
+        reads_done, t_cpu = 0, 0.0
+        while t_cpu < args.cpu_seconds:
+            t1 = time.perf_counter()
+            O.extract(srec, sg, opts)
+            t_cpu += time.perf_counter() - t1
+            reads_done += srec.n
+        cpu = {"value": round(reads_done / t_cpu, 1), "unit": "reads/s", "cores": 1, "kind": "port",
+               "sample": f"oracle extract loop (skip predicate + get_repeat + add_soft + pair logic) over the S1 mix, "
+                         f"{srec.n} reads x {reads_done // srec.n} passes, {t_cpu:.1f} s, single thread like the reference (threads=0)"}
+
+    if rank == 0:
+        total_reads = n * world * args.steps
+        out = {
+            "metric": "reads/sec through extract+cluster, 30x 150 bp WGS; 1/2/4/8 MI355X + CPU ref",
+            "value": round(total_reads / el, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/u32 integer", "data": "synthetic",
+            "config": {"workload": "1xMI355X: 30x 150 bp PE synthetic WGS, k=2-6 repeat-unit scorer + soft-clip scan, single-GPU extract (BASELINE.json configs[1])",
+                       "reads_per_gpu": n, "read_len": L, "unique_reads_per_gpu": n_base, "tiles": tiles,
+                       "skipped_frac": round(st.n_skipped / n, 4), "scored_reads": int(st.n_scored), "soft_items": int(st.n_soft_items),
+                       "timed_region": "classify + score + soft-clip kernels on HBM-resident SoA batches; BAM decode, PCIe and host pair logic excluded",
+                       "parallelism": f"records sharded over {world} GPU(s), no data-path collective"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

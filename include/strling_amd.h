@@ -1,0 +1,233 @@
+/*
+ * strling_amd.h -- C ABI of the MI355X-native STRling extract + cluster hot path.
+ *
+ * The reference (quinlan-lab/STRling v0.6.0) is a single statically linked Nim program with no
+ * plugin / FFI seam; its drop-in contract is CLI + files (.bin, -bounds.txt).  This header is the
+ * seam a Nim (or any) host binds instead of the reference's in-process procs: each entry point
+ * names the reference code it replaces (paths relative to the STRling repository root).  Plain
+ * pointers and sizes only; no C++ or torch types.  All functions return 0 (STRL_OK) or a negative
+ * status; strl_last_error() gives the message (thread-local).  The library has NO CPU fallback:
+ * every compute entry point needs a HIP device and fails with STRL_ERR_NO_DEVICE without one.
+ */
+#ifndef STRLING_AMD_H
+#define STRLING_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STRL_OK 0
+#define STRL_ERR_NO_DEVICE (-1)
+#define STRL_ERR_HIP (-2)
+#define STRL_ERR_ARG (-3)
+#define STRL_ERR_CAPACITY (-4)
+#define STRL_ERR_IO (-5)
+#define STRL_ERR_FORMAT (-6)
+#define STRL_ERR_ASSERT (-7) /* a doAssert of the reference would have fired (e.g. extract.nim:72) */
+
+#define STRL_MEM_HOST 0
+#define STRL_MEM_DEVICE 1
+
+/* longest read the scorer accepts (uint8 histogram counters of utils.nim:113-117 would wrap beyond it) */
+#define STRL_MAX_READ_LEN 510
+
+typedef struct strl_ctx strl_ctx;
+
+int strl_version(void);
+const char *strl_last_error(void);
+int strl_device_count(void);
+
+/* One context per GPU / stream (re-entrant per handle; the reference is single-threaded). */
+int strl_ctx_create(int device_ordinal, strl_ctx **ctx);
+void strl_ctx_destroy(strl_ctx *ctx);
+/* The HIP stream (hipStream_t) all kernels of this context are launched on. */
+void *strl_ctx_stream(strl_ctx *ctx);
+int strl_ctx_sync(strl_ctx *ctx);
+
+/* ---- Options (utils.nim:119-127; extract.nim:255-256,299-300) ---- */
+typedef struct {
+  int32_t median_fragment_length; /* frag_dist.median, extract.nim:283 */
+  double proportion_repeat;       /* -p, default 0.8 */
+  uint8_t min_mapq;               /* -q, default 40 */
+} strl_opts;
+int strl_ctx_set_opts(strl_ctx *ctx, const strl_opts *opts);
+
+/* ---- genome STR intervals: the table genome_repeats() returns (genome_strs.nim:107-141,
+ * read_bed.nim:30-50), flattened per BAM tid.  has_chrom[tid] != 0 iff the chromosome is a key of
+ * the table (extract.nim:30 `aln.chrom in genome_str`).  Intervals need not be sorted. ---- */
+typedef struct {
+  int32_t n_tid;
+  const uint8_t *has_chrom; /* [n_tid] */
+  const int64_t *iv_off;    /* [n_tid+1] */
+  const int32_t *iv_start;  /* [iv_off[n_tid]] */
+  const int32_t *iv_stop;
+} strl_genome_str;
+int strl_ctx_set_genome(strl_ctx *ctx, const strl_genome_str *g); /* g == NULL: empty table */
+
+/* ---- BAM records as hts-nim hands them to extract.nim (tid/start/mate_*, flag, mapq, cigar,
+ * 4-bit SEQ, qname).  seq_off is a byte offset and must be a multiple of 16; seq4 must have 32
+ * readable bytes of slack after the last record. ---- */
+typedef struct {
+  int64_t n;
+  const int32_t *tid, *pos, *mtid, *mpos;
+  const uint16_t *flag;
+  const uint8_t *mapq;
+  const uint32_t *cigar_off; /* [n+1] */
+  const uint32_t *cigar;     /* BAM encoding len<<4|op */
+  const uint64_t *seq_off;   /* [n] */
+  const int32_t *l_seq;      /* [n] */
+  const uint8_t *seq4;
+  const uint64_t *qname_off; /* [n+1] */
+  const char *qnames;
+} strl_records;
+
+/* ---- structure-of-arrays read batch the kernels consume (24 B of metadata per read + SEQ) ---- */
+#define STRL_CIG_SINGLE_M 1u /* n_cigar == 1 and op == M          (extract.nim:30) */
+#define STRL_CIG_FIRST_S 2u  /* n_cigar >= 1 and cigar[0] is S     (extract.nim:98,104) */
+#define STRL_CIG_LAST_S 4u   /* n_cigar >= 1 and cigar[last] is S */
+#define STRL_CIG_ONE_OP 8u   /* n_cigar == 1 */
+#define STRL_CIG_NONE 16u    /* n_cigar == 0 */
+typedef struct {
+  uint64_t n;
+  const int32_t *tid;      /* [n] */
+  const int32_t *pos;      /* [n] aln.start */
+  const int32_t *end;      /* [n] aln.stop (bam_endpos) */
+  const uint32_t *seq_off; /* [n] offset of the read's 4-bit SEQ in 16-byte units */
+  const uint16_t *l_seq;   /* [n] */
+  const uint16_t *clip_l;  /* [n] length of cigar[0] if it is S else 0 */
+  const uint16_t *clip_r;  /* [n] length of cigar[last] if it is S else 0 */
+  const uint8_t *mapq;     /* [n] */
+  const uint8_t *cig;      /* [n] STRL_CIG_* bits */
+  const uint8_t *seq4;     /* BAM nibble packing; every read starts 16-byte aligned */
+  uint64_t seq4_bytes;     /* including >= 32 bytes of slack */
+  uint32_t max_l_seq;
+  int32_t mem;             /* STRL_MEM_HOST or STRL_MEM_DEVICE: where ALL pointers above live */
+} strl_read_soa;
+
+/* Host: derive the SoA metadata arrays from BAM-native records (replaces the hts-nim accessors
+ * used at extract.nim:30-38,83-87,98-119: cigar ops, aln.stop, clip lengths).  Caller provides the
+ * output arrays ([n] each); SEQ is shared with `rec` (seq_off/16). */
+int strl_soa_from_records(const strl_records *rec, int32_t *end, uint32_t *seq_off16, uint16_t *l_seq, uint16_t *clip_l,
+                          uint16_t *clip_r, uint8_t *cig, uint32_t *max_l_seq);
+
+/* ---- scorer results ----
+ * packed unit/count word:  bits 0-11 unit code (kmer 2-bit "CATG" code, first base in the high bits),
+ * bits 12-14 unit length (0 = empty), bit 15 = read removed by the skip predicate (extract.nim:30-34),
+ * bits 16-31 repeat_count (after reduce_repeat, utils.nim:271). */
+#define STRL_RES_SKIPPED 0x8000u
+#define STRL_RES_K(w) (((w) >> 12) & 7u)
+#define STRL_RES_CODE(w) ((w) & 0xfffu)
+#define STRL_RES_COUNT(w) ((w) >> 16)
+typedef struct {
+  uint32_t read_side; /* read index << 1 | side (0 = left clip / cigar[0], 1 = right clip / cigar[last]) */
+  uint32_t res_first; /* get_repeat(soft_seq) with p - 0.07      (first-seen branch, extract.nim:241-244) */
+  uint32_t res_after; /* get_repeat(soft_seq) with min(p, 0.6)   (after-mate branch,  extract.nim:207-211) */
+  uint32_t seg_len;   /* c.len: number of soft-clipped bases scored */
+} strl_soft_rec;
+
+typedef struct {
+  uint64_t n_reads, n_skipped, n_scored, n_soft_items;
+  float ms_classify, ms_score, ms_soft; /* HIP-event kernel times on the context stream (0 if timing off) */
+} strl_score_stats;
+
+/* Score a batch: per read the skip predicate + utils.get_repeat on the whole read
+ * (extract.nim:20-40 via to_tread :66), and the soft-clip repeat scan of add_soft
+ * (extract.nim:93-116) for every clipped end that add_soft would look at, under both lowered
+ * thresholds.  whole[n] and soft[soft_cap] live where soa->mem says.  Soft records come back in
+ * unspecified order when mem == DEVICE and sorted by read_side when mem == HOST.
+ * Requires strl_ctx_set_opts (and optionally strl_ctx_set_genome) first. */
+int strl_score_reads(strl_ctx *ctx, const strl_read_soa *soa, uint32_t *whole, strl_soft_rec *soft, uint64_t soft_cap,
+                     uint64_t *n_soft, strl_score_stats *stats);
+/* Kernel timing with HIP events recorded on the context stream around every kernel of
+ * strl_score_reads (a ring of 256 launches).  enable_timing(ctx, 1) resets the ring;
+ * strl_ctx_kernel_times synchronises the stream and returns the SUM of the classify / score / soft
+ * kernel durations (ms) over the launches recorded since then. */
+int strl_ctx_enable_timing(strl_ctx *ctx, int on);
+int strl_ctx_kernel_times(strl_ctx *ctx, double ms_sum[3], uint64_t *n_launches);
+
+/* ---- tread (cluster.nim:23-32); qname is carried as an index (record index in extract, sample
+ * index in merge -- merge.nim:118-125 overwrites qname with the sample number) ---- */
+#define STRL_SOFT_LEFT 0
+#define STRL_SOFT_RIGHT 1
+#define STRL_SOFT_BOTH 2
+#define STRL_SOFT_NONE 3
+#define STRL_SOFT_NONE_RIGHT 4
+#define STRL_SOFT_NONE_LEFT 5
+typedef struct {
+  int32_t tid;
+  uint32_t position;
+  char repeat[6];
+  uint16_t flag;
+  uint8_t split;
+  uint8_t mapping_quality;
+  uint8_t repeat_count;
+  uint8_t align_length;
+  int64_t qname_id;
+} strl_tread;
+
+/* Host pair logic: Cache.add over the record stream (extract.nim:192-248 driven by :308-329,
+ * including the second visit of the unmapped tail by ibam.query("*")), fed by the scorer outputs.
+ * soft must be sorted by read_side.  Writes at most cap treads; *n_out gets the total produced. */
+int strl_pair_reads(const strl_records *rec, const strl_opts *opts, const uint32_t *whole, const strl_soft_rec *soft,
+                    uint64_t n_soft, int64_t n_tail, strl_tread *out, uint64_t cap, uint64_t *n_out);
+
+/* The extract hot loop end to end on one batch: SoA derivation + device scoring + pair logic
+ * (replaces extract.nim:308-329). */
+int strl_extract(strl_ctx *ctx, const strl_records *rec, int64_t n_tail, strl_tread *out, uint64_t cap, uint64_t *n_out,
+                 strl_score_stats *stats);
+
+/* ---- clustering (cluster.nim:323-374 + :175-250, callclusters.nim:52-66) ---- */
+typedef struct {
+  int32_t tid;
+  uint32_t left, left_most, right, right_most, center_mass;
+  uint16_t n_left, n_right, n_total;
+  char repeat[7];
+} strl_bounds;
+typedef struct {
+  char repeat[7];
+  int64_t count;
+} strl_unplaced;
+typedef struct {
+  uint64_t n_treads, n_groups, n_clusters, n_bounds, n_tie_fixups;
+  float ms_sort, ms_sweep, ms_bounds;
+} strl_cluster_stats;
+
+#define STRL_MODE_MERGE 0 /* merge.nim:172-187: tid<0 dropped on load, has_per_sample_reads gate, qname_id = sample */
+#define STRL_MODE_CALL 1  /* call.nim:223-235: unplaced groups reported, no per-sample gate */
+/* Group treads by (tid, repeat), stable-sort by position (call.nim:118-130 / merge.nim:121-135),
+ * cluster every group and derive the gated Bounds.  Output order = the reference's order (Nim Table
+ * slot order of the groups, clusters in position order within a group).  treads/out are host arrays. */
+int strl_cluster(strl_ctx *ctx, const strl_tread *treads, uint64_t n, int mode, uint32_t window, int32_t min_support,
+                 uint16_t min_clip, uint16_t min_clip_total, uint16_t max_clip_dist, strl_bounds *out, uint64_t cap,
+                 uint64_t *n_out, strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced,
+                 strl_cluster_stats *stats);
+
+/* ---- fragment-length statistics (utils.nim:139-146) ---- */
+int strl_frag_median(const uint32_t frag[4096], double pct);
+
+/* ---- files ---- */
+/* .bin writer (extract.nim:332-348 + cluster.nim:38-50).  qname_off/qnames index by tread.qname_id. */
+int strl_bin_write(const char *path, float proportion_repeat, uint8_t min_mapq, const uint32_t frag[4096],
+                   const char *sam_header, int32_t header_len, const strl_tread *treads, uint64_t n,
+                   const uint64_t *qname_off, const char *qnames);
+/* .bin reader (unpack.nim:58-133).  Two-call protocol: with treads == NULL only the counts/sizes are
+ * returned.  qname bytes are concatenated into qnames with offsets in qname_off ([n+1]). */
+typedef struct {
+  float proportion_repeat;
+  uint8_t min_mapq;
+  uint32_t frag[4096];
+  int32_t header_len;
+  int32_t n_reads;
+  uint64_t qnames_bytes;
+} strl_bin_info;
+int strl_bin_read(const char *path, strl_bin_info *info, char *sam_header, strl_tread *treads, uint64_t *qname_off,
+                  char *qnames);
+/* one -bounds.txt row (cluster.nim:262-266), without newline; returns length or <0 */
+int strl_bounds_row(char *buf, int cap, const strl_bounds *b, const char *chrom);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -46,7 +46,7 @@ class Records(C.Structure):
 
 class GenomeStr(C.Structure):
     _fields_ = [("n_tid", C.c_int32), ("has_chrom", C.c_void_p), ("iv_off", C.c_void_p), ("iv_start", C.c_void_p),
-                ("iv_stop", C.c_void_p)]
+                ("iv_stop", C.c_void_p), ("max_len", C.c_void_p)]
 
 
 class SegResult(C.Structure):
@@ -200,11 +200,21 @@ class RecordsView:
 class GenomeView:
     def __init__(self, g):
         # g: object with n_tid, has_chrom(u8[n_tid]), iv_off(i64[n_tid+1]), iv_start(i32), iv_stop(i32)
-        self.keep = dict(has=np.ascontiguousarray(g.has_chrom, np.uint8), off=np.ascontiguousarray(g.iv_off, np.int64),
-                         st=np.ascontiguousarray(g.iv_start, np.int32), en=np.ascontiguousarray(g.iv_stop, np.int32))
+        off = np.ascontiguousarray(g.iv_off, np.int64)
+        st = np.array(g.iv_start, np.int32)
+        en = np.array(g.iv_stop, np.int32)
+        mx = np.zeros(int(g.n_tid), np.int32)
+        for t in range(int(g.n_tid)):          # lapify(): sort by start, remember the longest interval
+            a, b = int(off[t]), int(off[t + 1])
+            if b > a:
+                o = np.argsort(st[a:b], kind="stable")
+                st[a:b], en[a:b] = st[a:b][o], en[a:b][o]
+                mx[t] = int((en[a:b] - st[a:b]).max())
+        self.keep = dict(has=np.ascontiguousarray(g.has_chrom, np.uint8), off=off, st=st, en=en, mx=mx)
         k = self.keep
         self.c = GenomeStr(int(g.n_tid), k["has"].ctypes.data, k["off"].ctypes.data,
-                           k["st"].ctypes.data if k["st"].size else None, k["en"].ctypes.data if k["en"].size else None)
+                           k["st"].ctypes.data if k["st"].size else None, k["en"].ctypes.data if k["en"].size else None,
+                           k["mx"].ctypes.data)
 
 
 def extract(rec, genome, opts, n_tail=-1):

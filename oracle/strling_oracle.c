@@ -280,9 +280,20 @@ static int64_t rec_stop(const orc_records *r, int64_t i) {
   return (int64_t)r->pos[i] + rlen;
 }
 /* lapper find(): any interval with iv.start < stop and iv.stop > start (brentp/nim-lapper) */
+/* Lapper.find (nim-lapper src/lapper.nim): intervals sorted by start, lowerBound(start - max_len), then a forward
+ * scan that stops at the first interval starting at or after `stop`.  Callers hand the intervals over sorted by
+ * start per tid (lapify sorts them, read_bed.nim:45-47); max_len[tid] = longest interval. */
 static int genome_find(const orc_genome_str *g, int32_t tid, int64_t start, int64_t stop) {
-  for (int64_t j = g->iv_off[tid]; j < g->iv_off[tid + 1]; j++)
+  int64_t lo = g->iv_off[tid], hi = g->iv_off[tid + 1];
+  const int64_t end = hi, key = start - (int64_t)g->max_len[tid];
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)g->iv_start[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  for (int64_t j = lo; j < end; j++) {
     if ((int64_t)g->iv_start[j] < stop && (int64_t)g->iv_stop[j] > start) return 1;
+    else if ((int64_t)g->iv_start[j] >= stop) break;
+  }
   return 0;
 }
 

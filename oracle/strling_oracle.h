@@ -73,7 +73,8 @@ typedef struct {
   int32_t n_tid;
   const uint8_t *has_chrom;
   const int64_t *iv_off;      /* n_tid+1 */
-  const int32_t *iv_start, *iv_stop;
+  const int32_t *iv_start, *iv_stop; /* sorted by start within each tid */
+  const int32_t *max_len;            /* [n_tid] longest interval of the tid (Lapper.max_len) */
 } orc_genome_str;
 
 /* kmer module (brentp/nim-kmer, not vendored): base -> 2-bit code and back. */

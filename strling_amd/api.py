@@ -1,0 +1,327 @@
+"""Python host mirror of the C ABI (include/strling_amd.h) via ctypes.
+
+This is plumbing for tests, bench.py and scripting: every compute call goes through
+libstrling_amd.so into the HIP kernels.  There is no CPU fallback -- if the library is missing or
+no HIP device is present the calls raise.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+from . import build as _build
+from .records import RecordBatch, GenomeStr
+
+_LIB = None
+
+
+class StrlingError(RuntimeError):
+    pass
+
+
+class Opts(C.Structure):
+    _fields_ = [("median_fragment_length", C.c_int32), ("proportion_repeat", C.c_double), ("min_mapq", C.c_uint8)]
+
+
+class CGenomeStr(C.Structure):
+    _fields_ = [("n_tid", C.c_int32), ("has_chrom", C.c_void_p), ("iv_off", C.c_void_p), ("iv_start", C.c_void_p),
+                ("iv_stop", C.c_void_p)]
+
+
+class CRecords(C.Structure):
+    _fields_ = [("n", C.c_int64), ("tid", C.c_void_p), ("pos", C.c_void_p), ("mtid", C.c_void_p), ("mpos", C.c_void_p),
+                ("flag", C.c_void_p), ("mapq", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
+                ("seq_off", C.c_void_p), ("l_seq", C.c_void_p), ("seq4", C.c_void_p), ("qname_off", C.c_void_p),
+                ("qnames", C.c_void_p)]
+
+
+class CReadSoa(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("tid", C.c_void_p), ("pos", C.c_void_p), ("end", C.c_void_p), ("seq_off", C.c_void_p),
+                ("l_seq", C.c_void_p), ("clip_l", C.c_void_p), ("clip_r", C.c_void_p), ("mapq", C.c_void_p),
+                ("cig", C.c_void_p), ("seq4", C.c_void_p), ("seq4_bytes", C.c_uint64), ("max_l_seq", C.c_uint32),
+                ("mem", C.c_int32)]
+
+
+class ScoreStats(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_skipped", C.c_uint64), ("n_scored", C.c_uint64), ("n_soft_items", C.c_uint64),
+                ("ms_classify", C.c_float), ("ms_score", C.c_float), ("ms_soft", C.c_float)]
+
+
+class ClusterStats(C.Structure):
+    _fields_ = [("n_treads", C.c_uint64), ("n_groups", C.c_uint64), ("n_clusters", C.c_uint64), ("n_bounds", C.c_uint64),
+                ("n_tie_fixups", C.c_uint64), ("ms_sort", C.c_float), ("ms_sweep", C.c_float), ("ms_bounds", C.c_float)]
+
+
+class BinInfo(C.Structure):
+    _fields_ = [("proportion_repeat", C.c_float), ("min_mapq", C.c_uint8), ("frag", C.c_uint32 * 4096),
+                ("header_len", C.c_int32), ("n_reads", C.c_int32), ("qnames_bytes", C.c_uint64)]
+
+
+SOFT_DTYPE = np.dtype([("read_side", "<u4"), ("res_first", "<u4"), ("res_after", "<u4"), ("seg_len", "<u4")])
+TREAD_DTYPE = np.dtype([("tid", "<i4"), ("position", "<u4"), ("repeat", "S6"), ("flag", "<u2"), ("split", "u1"),
+                        ("mapping_quality", "u1"), ("repeat_count", "u1"), ("align_length", "u1"), ("qname_id", "<i8")],
+                       align=True)
+BOUNDS_DTYPE = np.dtype([("tid", "<i4"), ("left", "<u4"), ("left_most", "<u4"), ("right", "<u4"), ("right_most", "<u4"),
+                         ("center_mass", "<u4"), ("n_left", "<u2"), ("n_right", "<u2"), ("n_total", "<u2"),
+                         ("repeat", "S7")], align=True)
+UNPLACED_DTYPE = np.dtype([("repeat", "S7"), ("count", "<i8")], align=True)
+assert TREAD_DTYPE.itemsize == 32 and BOUNDS_DTYPE.itemsize == 40 and UNPLACED_DTYPE.itemsize == 16
+
+MEM_HOST, MEM_DEVICE = 0, 1
+MODE_MERGE, MODE_CALL = 0, 1
+
+# every symbol include/strling_amd.h declares
+EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_create", "strl_ctx_destroy", "strl_ctx_stream",
+           "strl_ctx_sync", "strl_ctx_set_opts", "strl_ctx_set_genome", "strl_soa_from_records", "strl_score_reads",
+           "strl_ctx_enable_timing", "strl_ctx_kernel_times", "strl_pair_reads", "strl_extract", "strl_cluster", "strl_frag_median",
+           "strl_bin_write", "strl_bin_read", "strl_bounds_row"]
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """dlopen the in-tree library (building it with hipcc when missing). Raises when impossible."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise StrlingError(f"{path} is missing: build it with `python -m strling_amd.build` (no CPU fallback)")
+        _build.build()
+    L = C.CDLL(path)
+    L.strl_last_error.restype = C.c_char_p
+    L.strl_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.strl_ctx_destroy.argtypes = [C.c_void_p]
+    L.strl_ctx_stream.argtypes = [C.c_void_p]
+    L.strl_ctx_stream.restype = C.c_void_p
+    L.strl_ctx_sync.argtypes = [C.c_void_p]
+    L.strl_ctx_set_opts.argtypes = [C.c_void_p, C.POINTER(Opts)]
+    L.strl_ctx_set_genome.argtypes = [C.c_void_p, C.POINTER(CGenomeStr)]
+    L.strl_ctx_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    L.strl_ctx_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 3), C.POINTER(C.c_uint64)]
+    L.strl_soa_from_records.argtypes = [C.POINTER(CRecords)] + [C.c_void_p] * 6 + [C.POINTER(C.c_uint32)]
+    L.strl_score_reads.argtypes = [C.c_void_p, C.POINTER(CReadSoa), C.c_void_p, C.c_void_p, C.c_uint64,
+                                   C.POINTER(C.c_uint64), C.POINTER(ScoreStats)]
+    L.strl_pair_reads.argtypes = [C.POINTER(CRecords), C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64,
+                                  C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.strl_extract.argtypes = [C.c_void_p, C.POINTER(CRecords), C.c_int64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                               C.POINTER(ScoreStats)]
+    L.strl_cluster.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_int32, C.c_uint16, C.c_uint16,
+                               C.c_uint16, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64,
+                               C.POINTER(C.c_uint64), C.POINTER(ClusterStats)]
+    L.strl_frag_median.argtypes = [C.c_void_p, C.c_double]
+    L.strl_bin_write.argtypes = [C.c_char_p, C.c_float, C.c_uint8, C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_uint64,
+                                 C.c_void_p, C.c_char_p]
+    L.strl_bin_read.argtypes = [C.c_char_p, C.POINTER(BinInfo), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.strl_bounds_row.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_char_p]
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise StrlingError(f"strling_amd error {rc}: {load().strl_last_error().decode()}")
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None and a.size else None
+
+
+class _RecView:
+    def __init__(self, rec: RecordBatch):
+        k = dict(tid=np.ascontiguousarray(rec.tid, np.int32), pos=np.ascontiguousarray(rec.pos, np.int32),
+                 mtid=np.ascontiguousarray(rec.mtid, np.int32), mpos=np.ascontiguousarray(rec.mpos, np.int32),
+                 flag=np.ascontiguousarray(rec.flag, np.uint16), mapq=np.ascontiguousarray(rec.mapq, np.uint8),
+                 cigar_off=np.ascontiguousarray(rec.cigar_off, np.uint32),
+                 cigar=np.ascontiguousarray(np.append(rec.cigar, 0), np.uint32),
+                 seq_off=np.ascontiguousarray(rec.seq_off, np.uint64), l_seq=np.ascontiguousarray(rec.l_seq, np.int32),
+                 seq4=np.ascontiguousarray(rec.seq4, np.uint8), qname_off=np.ascontiguousarray(rec.qname_off, np.uint64),
+                 qnames=np.frombuffer(bytes(rec.qnames) + b"\0", dtype=np.uint8))
+        self.keep = k
+        self.n = int(k["tid"].size)
+        self.c = CRecords(self.n, *[k[f].ctypes.data for f in ("tid", "pos", "mtid", "mpos", "flag", "mapq", "cigar_off",
+                                                               "cigar", "seq_off", "l_seq", "seq4", "qname_off", "qnames")])
+
+
+class Soa:
+    """Host numpy SoA batch (the layout the kernels consume)."""
+
+    def __init__(self, rec: RecordBatch):
+        L = load()
+        rv = _RecView(rec)
+        n = rv.n
+        self.rv = rv
+        self.n = n
+        self.end = np.zeros(n, np.int32)
+        self.seq_off = np.zeros(n, np.uint32)
+        self.l_seq = np.zeros(n, np.uint16)
+        self.clip_l = np.zeros(n, np.uint16)
+        self.clip_r = np.zeros(n, np.uint16)
+        self.cig = np.zeros(n, np.uint8)
+        mx = C.c_uint32(0)
+        _check(L.strl_soa_from_records(C.byref(rv.c), self.end.ctypes.data, self.seq_off.ctypes.data, self.l_seq.ctypes.data,
+                                       self.clip_l.ctypes.data, self.clip_r.ctypes.data, self.cig.ctypes.data, C.byref(mx)))
+        self.max_l_seq = mx.value
+        self.tid, self.pos, self.mapq, self.seq4 = rv.keep["tid"], rv.keep["pos"], rv.keep["mapq"], rv.keep["seq4"]
+
+    def c_struct(self):
+        return CReadSoa(self.n, _ptr(self.tid), _ptr(self.pos), _ptr(self.end), _ptr(self.seq_off), _ptr(self.l_seq),
+                        _ptr(self.clip_l), _ptr(self.clip_r), _ptr(self.mapq), _ptr(self.cig), self.seq4.ctypes.data,
+                        self.seq4.size, self.max_l_seq, MEM_HOST)
+
+
+class Context:
+    """One context per GPU (strl_ctx)."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        _check(self.L.strl_ctx_create(device, C.byref(h)))
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.strl_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return self.L.strl_ctx_stream(self.h)
+
+    def sync(self):
+        _check(self.L.strl_ctx_sync(self.h))
+
+    def enable_timing(self, on=True):
+        _check(self.L.strl_ctx_enable_timing(self.h, int(on)))
+
+    def kernel_times(self):
+        """-> ((ms_classify, ms_score, ms_soft) summed, n_launches) since enable_timing(True)"""
+        ms = (C.c_double * 3)()
+        n = C.c_uint64(0)
+        _check(self.L.strl_ctx_kernel_times(self.h, C.byref(ms), C.byref(n)))
+        return tuple(ms), n.value
+
+    def set_opts(self, proportion_repeat=0.8, min_mapq=40, median_fragment_length=0):
+        self.opts = Opts(median_fragment_length, proportion_repeat, min_mapq)
+        _check(self.L.strl_ctx_set_opts(self.h, C.byref(self.opts)))
+
+    def set_genome(self, g: GenomeStr):
+        if g is None:
+            _check(self.L.strl_ctx_set_genome(self.h, None))
+            return
+        has = np.ascontiguousarray(g.has_chrom, np.uint8)
+        off = np.ascontiguousarray(g.iv_off, np.int64)
+        st = np.ascontiguousarray(g.iv_start, np.int32)
+        en = np.ascontiguousarray(g.iv_stop, np.int32)
+        cg = CGenomeStr(int(g.n_tid), has.ctypes.data, off.ctypes.data, _ptr(st), _ptr(en))
+        _check(self.L.strl_ctx_set_genome(self.h, C.byref(cg)))
+
+    # ---- scorer --------------------------------------------------------------------------------
+    def score_reads(self, rec_or_soa):
+        """-> (whole uint32[n], soft SOFT_DTYPE[m] sorted by read_side, ScoreStats)"""
+        soa = rec_or_soa if isinstance(rec_or_soa, Soa) else Soa(rec_or_soa)
+        n = soa.n
+        whole = np.zeros(max(n, 1), np.uint32)
+        soft = np.zeros(2 * n + 1, SOFT_DTYPE)
+        ns = C.c_uint64(0)
+        st = ScoreStats()
+        cs = soa.c_struct()
+        _check(self.L.strl_score_reads(self.h, C.byref(cs), whole.ctypes.data, soft.ctypes.data, 2 * n, C.byref(ns), C.byref(st)))
+        return whole[:n], soft[:ns.value].copy(), st
+
+    def score_device(self, cs: CReadSoa, whole_ptr, soft_ptr, soft_cap, sync=False):
+        """Device-resident batch (pointers from torch tensors). Asynchronous unless sync."""
+        if sync:
+            ns = C.c_uint64(0)
+            st = ScoreStats()
+            _check(self.L.strl_score_reads(self.h, C.byref(cs), whole_ptr, soft_ptr, soft_cap, C.byref(ns), C.byref(st)))
+            return ns.value, st
+        _check(self.L.strl_score_reads(self.h, C.byref(cs), whole_ptr, soft_ptr, soft_cap, None, None))
+        return None
+
+    # ---- extract (score + pair) -----------------------------------------------------------------
+    def extract(self, rec: RecordBatch, n_tail=-1):
+        rv = _RecView(rec)
+        cap = max(1024, rv.n // 4)
+        while True:
+            out = np.zeros(cap, TREAD_DTYPE)
+            no = C.c_uint64(0)
+            st = ScoreStats()
+            rc = self.L.strl_extract(self.h, C.byref(rv.c), n_tail, out.ctypes.data, cap, C.byref(no), C.byref(st))
+            if rc == -4 and no.value > cap:
+                cap = int(no.value)
+                continue
+            _check(rc)
+            return out[:no.value].copy(), st
+
+    def pair_reads(self, rec: RecordBatch, whole, soft, n_tail=-1):
+        rv = _RecView(rec)
+        whole = np.ascontiguousarray(whole, np.uint32)
+        soft = np.ascontiguousarray(soft, SOFT_DTYPE)
+        cap = max(1024, rv.n // 4)
+        while True:
+            out = np.zeros(cap, TREAD_DTYPE)
+            no = C.c_uint64(0)
+            rc = self.L.strl_pair_reads(C.byref(rv.c), C.byref(self.opts), whole.ctypes.data, _ptr(soft), soft.size, n_tail,
+                                        out.ctypes.data, cap, C.byref(no))
+            if rc == -4 and no.value > cap:
+                cap = int(no.value)
+                continue
+            _check(rc)
+            return out[:no.value].copy()
+
+    # ---- cluster --------------------------------------------------------------------------------
+    def cluster(self, treads, mode, window, min_support=5, min_clip=0, min_clip_total=0, max_clip_dist=200):
+        t = np.ascontiguousarray(treads, TREAD_DTYPE)
+        cap = max(64, t.size)
+        out = np.zeros(cap, BOUNDS_DTYPE)
+        unpl = np.zeros(8192, UNPLACED_DTYPE)
+        no, nu = C.c_uint64(0), C.c_uint64(0)
+        st = ClusterStats()
+        _check(self.L.strl_cluster(self.h, _ptr(t), t.size, mode, window, min_support, min_clip, min_clip_total, max_clip_dist,
+                                   out.ctypes.data, cap, C.byref(no), unpl.ctypes.data, unpl.size, C.byref(nu), C.byref(st)))
+        return out[:no.value].copy(), unpl[:nu.value].copy(), st
+
+
+def frag_median(frag, pct=0.5):
+    frag = np.ascontiguousarray(frag, np.uint32)
+    return load().strl_frag_median(frag.ctypes.data, pct)
+
+
+def bounds_row(b, chrom):
+    buf = C.create_string_buffer(512)
+    bb = np.ascontiguousarray(b, BOUNDS_DTYPE).reshape(1)
+    load().strl_bounds_row(buf, 512, bb.ctypes.data, chrom.encode())
+    return buf.value.decode()
+
+
+def bin_write(path, proportion_repeat, min_mapq, frag, sam_header, treads, qname_off, qnames):
+    t = np.ascontiguousarray(treads, TREAD_DTYPE)
+    frag = np.ascontiguousarray(frag, np.uint32)
+    qo = np.ascontiguousarray(qname_off, np.uint64)
+    hdr = sam_header.encode() if isinstance(sam_header, str) else sam_header
+    _check(load().strl_bin_write(path.encode(), proportion_repeat, min_mapq, frag.ctypes.data, hdr, len(hdr), _ptr(t), t.size,
+                                 qo.ctypes.data, bytes(qnames) + b"\0"))
+
+
+def bin_read(path):
+    L = load()
+    info = BinInfo()
+    _check(L.strl_bin_read(path.encode(), C.byref(info), None, None, None, None))
+    hdr = C.create_string_buffer(max(1, info.header_len))
+    t = np.zeros(max(1, info.n_reads), TREAD_DTYPE)
+    qo = np.zeros(info.n_reads + 1, np.uint64)
+    qn = C.create_string_buffer(max(1, int(info.qnames_bytes)))
+    _check(L.strl_bin_read(path.encode(), C.byref(info), hdr, t.ctypes.data, qo.ctypes.data, qn))
+    return dict(proportion_repeat=info.proportion_repeat, min_mapq=info.min_mapq, frag=np.array(info.frag, np.uint32),
+                header=hdr.raw[:info.header_len].decode(), treads=t[:info.n_reads].copy(), qname_off=qo,
+                qnames=qn.raw[:int(info.qnames_bytes)])

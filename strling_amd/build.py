@@ -1,0 +1,54 @@
+"""Builds libstrling_amd.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs on the CPU-only build box as well; the built
+.so travels to the GPU box with the repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libstrling_amd.so")
+CLI = os.path.join(LIBDIR, "strling")
+SOURCES = ["score.hip", "cluster.hip", "host_logic.cpp", "nim_tables.cpp"]
+CLI_SOURCES = ["cli/main.cpp", "cli/bam_reader.cpp"]
+HEADERS = ["common.h", "score_core.h", "score_tables.h", "nim_tables.h", "cli/bam_reader.h", "../../include/strling_amd.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built (there is no CPU fallback)")
+
+
+def _stale(target, srcs):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in srcs)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
+    if force or _stale(LIB, deps):
+        cmd = [_hipcc()] + FLAGS + ["-shared", "-o", LIB] + srcs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+    cli_srcs = [os.path.join(CSRC, s) for s in CLI_SOURCES]
+    if all(os.path.exists(s) for s in cli_srcs) and (force or _stale(CLI, cli_srcs + deps + [LIB])):
+        cmd = [_hipcc()] + FLAGS + ["-o", CLI] + cli_srcs + ["-L" + LIBDIR, "-lstrling_amd", "-lz", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,455 @@
+// cluster.hip -- STR-read clustering on the GPU (call.nim:118-130,223-235; merge.nim:121-187;
+// cluster.nim:175-374; callclusters.nim:52-66), gfx950.
+//
+// The reference groups treads in a hash table keyed by (tid, repeat), merge-sorts every group by
+// position and sweeps each group sequentially.  Here the whole tread set is ONE keyed stable
+// radix sort (position pass, then (tid, unit) pass), after which
+//   ends_kernel   : one tread per lane computes where the cluster that STARTS at it would end --
+//                   the reference's growth rule depends only on the start: <= 9 warm-up steps of
+//                   the running median-of-first-9, then a binary search for pos > posmed+max_dist+100,
+//   walk_kernel   : one lane per group follows start -> end links and flags the cluster heads,
+//   bounds_kernel : one lane per cluster: trim, anchor/support gate, split_cluster, bounds() and
+//                   the callclusters gate, with Nim CountTable.largest slot-order tie-breaks
+//                   reproduced on the device (nim_tables.h).
+// HBM-bound integer work; sizes are ~1e6 treads per 30x sample (5e7 for a 50-sample merge).
+#include <hipcub/hipcub.hpp>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "common.h"
+#include "nim_tables.h"
+
+namespace nim { std::vector<int64_t> table_slot_order(const std::vector<uint64_t> &hcodes, uint64_t initial_size); }
+
+namespace strl {
+
+struct RawBounds {  // one candidate row per (cluster, half)
+  uint32_t valid;   // 1 = passes every gate
+  uint32_t first;   // sorted index of the first read (diagnostics / ordering)
+  uint32_t left, left_most, right, right_most, center_mass;
+  uint16_t n_left, n_right, n_total, pad;
+};
+
+struct ClusterParams {
+  uint32_t n;
+  const uint32_t *pos;      // sorted
+  const uint8_t *split;     // sorted
+  const uint32_t *sample;   // sorted (qname_id)
+  const uint32_t *gid;      // group index of each sorted tread
+  const uint32_t *gstart;   // [n_groups+1]
+  const uint8_t *gplaced;   // [n_groups] 1 if tid >= 0
+  uint32_t n_groups;
+  uint32_t *ends;           // e(s)
+  uint32_t *is_start;       // cluster-head flags
+  const uint32_t *cl_start; // [n_clusters] compacted heads
+  const uint32_t *n_clusters;
+  uint32_t *scratch;        // 4 * (16 * n_clusters + 3 * n) dwords
+  RawBounds *out;           // [2 * n_clusters]
+  uint32_t max_dist;
+  int32_t min_support;
+  uint32_t min_clip, min_clip_total, max_clip_dist;
+  int32_t mode;
+};
+
+__device__ __forceinline__ uint32_t posmed_at(const uint32_t *pos, uint32_t s, uint32_t n) {
+  const uint32_t m = n < 9u ? n : 9u;         // cluster.nim:59-62: reads[int(min(9, n) / 2 - 0.5)]
+  return pos[s + ((m - 1u) >> 1)];
+}
+
+__global__ __launch_bounds__(256) void ends_kernel(ClusterParams P) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= P.n) return;
+  const uint32_t g = P.gid[s];
+  const uint32_t ge = P.gstart[g + 1];
+  const uint32_t add = P.max_dist + 100u;     // uint32 arithmetic as in cluster.nim:336
+  uint32_t n = 1, j = s + 1;
+  bool open = true;
+  while (j < ge && n < 9u) {                  // warm-up: the median still moves
+    if (P.pos[j] <= posmed_at(P.pos, s, n) + add) { ++n; ++j; }
+    else { open = false; break; }
+  }
+  if (open && j < ge) {                       // n == 9: median fixed at pos[s+4]
+    const uint32_t limit = P.pos[s + 4] + add;
+    uint32_t lo = j, hi = ge;
+    while (lo < hi) {                         // first index with pos > limit
+      const uint32_t mid = (lo + hi) >> 1;
+      if (P.pos[mid] <= limit) lo = mid + 1; else hi = mid;
+    }
+    j = lo;
+  }
+  P.ends[s] = j;
+}
+
+__global__ __launch_bounds__(64) void walk_kernel(ClusterParams P) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P.n_groups || !P.gplaced[g]) return;
+  uint32_t s = P.gstart[g];
+  const uint32_t ge = P.gstart[g + 1];
+  while (s < ge) {                            // trcluster: the next cluster starts at the first rejected read
+    P.is_start[s] = 1u;
+    s = P.ends[s];
+  }
+}
+
+// CountTable over the clip positions of one kind in [a, b) (sorted by position => equal keys adjacent).
+template <bool FILTER>
+__device__ void clip_table(const ClusterParams &P, uint32_t a, uint32_t b, uint8_t kind, int32_t cm, nim::CountTable &ct,
+                           uint32_t *scratch, uint32_t cap, uint32_t &n_reads, uint32_t &n_distinct) {
+  ct.init(scratch, cap);
+  n_reads = 0;
+  n_distinct = 0;
+  uint32_t run_key = 0, run = 0;
+  for (uint32_t i = a; i < b; ++i) {
+    if (P.split[i] != kind) continue;
+    const uint32_t p = P.pos[i];
+    if (FILTER) {                              // cluster.nim:193,197
+      if (kind == STRL_SOFT_LEFT && !((int32_t)p < cm + (int32_t)P.max_clip_dist)) continue;
+      if (kind == STRL_SOFT_RIGHT && !((int32_t)p > cm - (int32_t)P.max_clip_dist)) continue;
+    }
+    ++n_reads;
+    if (run && p == run_key) { ++run; continue; }
+    if (run) { ct.insert_new(run_key, run); ++n_distinct; }
+    run_key = p;
+    run = 1;
+  }
+  if (run) { ct.insert_new(run_key, run); ++n_distinct; }
+}
+
+// bounds() (cluster.nim:175-250) + gate (callclusters.nim:52-66) for reads [a, b)
+__device__ void emit_bounds(const ClusterParams &P, uint32_t a, uint32_t b, uint32_t cl_left_most, uint32_t cl_right_most,
+                            uint32_t *scratch, uint32_t cap, RawBounds &o) {
+  o.valid = 0;
+  o.first = a;
+  const uint32_t n = b - a;
+  if (P.mode == STRL_MODE_MERGE) {            // has_per_sample_reads, merge.nim:18-25: small open-addressing count table
+    uint32_t tl = 16;
+    while (tl < 2 * n) tl <<= 1;              // <= 4n <= scratch region (4 * (16 + 3n) dwords)
+    uint32_t *k = scratch, *v = scratch + tl;
+    for (uint32_t i = 0; i < tl; ++i) v[i] = 0;
+    uint32_t best = 0;
+    for (uint32_t i = a; i < b; ++i) {
+      const uint32_t sm = P.sample[i];
+      uint32_t h = (sm * 0x9E3779B1u) & (tl - 1);
+      while (v[h] && k[h] != sm) h = (h + 1) & (tl - 1);
+      k[h] = sm;
+      const uint32_t c = ++v[h];
+      best = c > best ? c : best;
+    }
+    if ((int32_t)best < P.min_support) return;
+  }
+  if (n >= 65535u) return;                    // callclusters.nim:53-55
+  const uint32_t center = P.pos[a + (n >> 1)];
+  const int32_t cm = (int32_t)center;
+  nim::CountTable ct;
+  uint32_t nl, nr, dl, dr, left = 0, right = 0, key, val;
+  clip_table<true>(P, a, b, STRL_SOFT_LEFT, cm, ct, scratch, cap, nl, dl);
+  if (dl) { ct.largest(key, val); if (val > 1) left = key; }          // cluster.nim:204-207
+  clip_table<true>(P, a, b, STRL_SOFT_RIGHT, cm, ct, scratch, cap, nr, dr);
+  if (dr) { ct.largest(key, val); if (val > 1) right = key; }         // :208-211
+  if (left == 0) left = center;                                       // :214-217
+  if (right == 0) right = left + 1;
+  if (left >= right) {                                                // :227-231
+    if (nl > 0 && nr > 0) { const uint32_t t = left; left = right; right = t; }
+    else left = right - 1;
+  }
+  uint32_t lm = cl_left_most > 0 ? cl_left_most : P.pos[a];           // :234-241 (posns sorted: min/max are the ends)
+  uint32_t rm = cl_right_most > 0 ? cl_right_most : P.pos[b - 1];
+  if (lm > left) lm = left;                                           // :244-247
+  if (rm < right) rm = right;
+  if (right - left > 1000u) return;                                   // callclusters.nim:57-59
+  if (nl < P.min_clip) return;                                        // :62-65
+  if (nr < P.min_clip) return;
+  if (((nl + nr) & 0xffffu) < P.min_clip_total) return;
+  o.left = left; o.right = right; o.left_most = lm; o.right_most = rm; o.center_mass = center;
+  o.n_left = (uint16_t)nl; o.n_right = (uint16_t)nr; o.n_total = (uint16_t)n; o.pad = 0;
+  o.valid = 1;
+}
+
+__global__ __launch_bounds__(64) void bounds_kernel(ClusterParams P) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nc = *P.n_clusters;
+  if (c >= nc) return;
+  RawBounds *o = P.out + 2 * (uint64_t)c;
+  o[0].valid = 0; o[1].valid = 0;
+  uint32_t s = P.cl_start[c];
+  const uint32_t e = P.ends[s];
+  uint32_t n = e - s;
+  const uint32_t cap = 16u + 3u * n;
+  uint32_t *scratch = P.scratch + 4ull * (16ull * c + 3ull * s);
+  // trim(max_dist + 100), cluster.nim:252-257 -- `lo` is computed once
+  {
+    const uint32_t md = P.max_dist + 100u;
+    const int64_t lo64 = (int64_t)posmed_at(P.pos, s, n) - (int64_t)md;
+    const uint32_t lo = lo64 < 0 ? 0u : (uint32_t)lo64;
+    while (n > 1 && P.pos[s] < lo) { ++s; --n; }
+  }
+  const uint32_t pm = posmed_at(P.pos, s, n);
+  const uint32_t last = P.pos[e - 1], firstp = P.pos[s];
+  const uint32_t right_most = last > pm + P.max_dist ? last : pm + P.max_dist;      // :343
+  const uint32_t left_most = firstp < pm - P.max_dist ? firstp : pm - P.max_dist;   // :344 (uint32 wrap kept)
+  if ((int64_t)n < (int64_t)P.min_support) return;                                  // :346
+  bool anchor = false;
+  for (uint32_t i = s; i < e && !anchor; ++i) anchor = P.split[i] == STRL_SOFT_NONE; // has_anchor :275-281
+  if (!anchor) return;
+  // split_cluster, cluster.nim:283-320
+  nim::CountTable ct;
+  uint32_t nl, nr, dl, dr, llk = 0, llv = 0, rlk = 0, rlv = 0;
+  clip_table<false>(P, s, e, STRL_SOFT_RIGHT, 0, ct, scratch, cap, nr, dr);
+  if (dr) ct.largest(rlk, rlv);
+  clip_table<false>(P, s, e, STRL_SOFT_LEFT, 0, ct, scratch, cap, nl, dl);
+  if (dl) ct.largest(llk, llv);
+  if (dr && dl && rlk < llk && (int64_t)rlv >= P.min_support && (int64_t)llv >= P.min_support &&
+      (double)llv / (double)dl > 0.5 && (double)rlv / (double)dr > 0.5) {
+    const uint32_t mid = (uint32_t)(0.5 + ((double)rlk + (double)llk) / 2.0);
+    uint32_t m = s;
+    while (m < e && P.pos[m] < mid) ++m;
+    emit_bounds(P, s, m, 0u, mid - 1u, scratch, cap, o[0]);                         // :313
+    emit_bounds(P, m, e, mid, 0u, scratch, cap, o[1]);                              // :314
+  } else {
+    emit_bounds(P, s, e, left_most, right_most, scratch, cap, o[0]);
+  }
+}
+
+__global__ void heads_kernel(const uint64_t *gkey, uint32_t n, uint32_t *head) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) head[i] = (i == 0 || gkey[i] != gkey[i - 1]) ? 1u : 0u;
+}
+__global__ void gather_kernel(uint32_t n, const uint32_t *perm, const uint32_t *pos_in, const uint8_t *split_in, const uint32_t *sample_in,
+                              const uint32_t *head, const uint32_t *gid_incl, const uint64_t *gkey_sorted, uint32_t *pos, uint8_t *split,
+                              uint32_t *sample, uint32_t *gid, uint32_t *gstart, uint32_t *gfirst, uint64_t *gkeys, uint8_t *gplaced) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t src = perm[i];
+  pos[i] = pos_in[src];
+  split[i] = split_in[src];
+  sample[i] = sample_in[src];
+  const uint32_t g = gid_incl[i] - 1u;
+  gid[i] = g;
+  if (head[i]) { gstart[g] = i; gkeys[g] = gkey_sorted[i]; gplaced[g] = (gkey_sorted[i] >> 15) != 0; }
+  atomicMin(&gfirst[g], src);                  // first appearance in input order => Nim Table insertion order
+  if (i == n - 1) gstart[g + 1] = n;
+}
+__global__ void scatter_starts_kernel(uint32_t n, const uint32_t *is_start, const uint32_t *excl, uint32_t *cl_start, uint32_t *n_clusters) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (is_start[i]) cl_start[excl[i]] = i;
+  if (i == n - 1) *n_clusters = excl[i] + is_start[i];
+}
+__global__ void iota_kernel(uint32_t n, uint32_t *v) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+__global__ void gather_key_kernel(uint32_t n, const uint32_t *perm, const uint64_t *in, uint64_t *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[perm[i]];
+}
+
+static inline uint32_t base_code(char b, bool &ok) {
+  switch (b) { case 'C': return 0; case 'A': return 1; case 'T': return 2; case 'G': return 3; default: ok = false; return 0; }
+}
+
+}  // namespace strl
+
+using namespace strl;
+
+extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in, int mode, uint32_t window, int32_t min_support,
+                            uint16_t min_clip, uint16_t min_clip_total, uint16_t max_clip_dist, strl_bounds *out, uint64_t cap,
+                            uint64_t *n_out, strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced,
+                            strl_cluster_stats *stats) {
+  if (!c || (!treads && n_in) || (!out && cap)) { set_error("null argument"); return STRL_ERR_ARG; }
+  if (n_out) *n_out = 0;
+  if (n_unplaced) *n_unplaced = 0;
+  if (stats) memset(stats, 0, sizeof *stats);
+  STRL_HIP(hipSetDevice(c->device));
+  // ---- host: keys -------------------------------------------------------------------------------
+  std::vector<uint32_t> h_pos, h_sample;
+  std::vector<uint8_t> h_split;
+  std::vector<uint64_t> h_key;
+  h_pos.reserve(n_in); h_sample.reserve(n_in); h_split.reserve(n_in); h_key.reserve(n_in);
+  for (uint64_t i = 0; i < n_in; ++i) {
+    const strl_tread &t = treads[i];
+    if (mode == STRL_MODE_MERGE && t.tid < 0) continue;           // unpack_file(drop_unplaced=true), merge.nim:101
+    if (t.tid < -1) { set_error("tread %llu: tid %d", (unsigned long long)i, t.tid); return STRL_ERR_ARG; }
+    bool ok = true;
+    uint32_t len = 0, code = 0;
+    while (len < 6 && t.repeat[len]) { code = (code << 2) | base_code(t.repeat[len], ok); ++len; }
+    for (uint32_t j = len; j < 6; ++j) if (t.repeat[j]) ok = false;
+    if (!ok) { set_error("tread %llu: repeat unit is not a NUL-padded ACGT string", (unsigned long long)i); return STRL_ERR_ARG; }
+    h_key.push_back(((uint64_t)(uint32_t)(t.tid + 1) << 15) | ((uint64_t)len << 12) | code);
+    h_pos.push_back(t.position);
+    h_split.push_back(t.split);
+    h_sample.push_back((uint32_t)t.qname_id);
+  }
+  const uint64_t n64 = h_pos.size();
+  if (n64 > 0x7ffffff0ull) { set_error("too many treads"); return STRL_ERR_ARG; }
+  const uint32_t n = (uint32_t)n64;
+  if (stats) stats->n_treads = n;
+  if (n == 0) return STRL_OK;
+
+  // ---- device buffers ----------------------------------------------------------------------------
+  enum { B_POSIN, B_SPLITIN, B_SAMPLEIN, B_KEYIN, B_PERM0, B_PERM1, B_POSK, B_KEYG, B_KEYS, B_TMP, B_A, B_B, B_C, B_D, B_E, B_F };
+  strl::DevBuf *B = c->c_buf;
+  int rc;
+  auto need = [&](int i, size_t bytes) { return B[i].reserve(std::max<size_t>(bytes, 256)); };
+  if ((rc = need(B_POSIN, (size_t)n * 4)) || (rc = need(B_SPLITIN, n)) || (rc = need(B_SAMPLEIN, (size_t)n * 4)) ||
+      (rc = need(B_KEYIN, (size_t)n * 8)) || (rc = need(B_PERM0, (size_t)n * 4)) || (rc = need(B_PERM1, (size_t)n * 4)) ||
+      (rc = need(B_POSK, (size_t)n * 4)) || (rc = need(B_KEYG, (size_t)n * 8)) || (rc = need(B_KEYS, (size_t)n * 8)))
+    return rc;
+  hipStream_t st = c->stream;
+  STRL_HIP(hipMemcpyAsync(B[B_POSIN].p, h_pos.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  STRL_HIP(hipMemcpyAsync(B[B_SPLITIN].p, h_split.data(), n, hipMemcpyHostToDevice, st));
+  STRL_HIP(hipMemcpyAsync(B[B_SAMPLEIN].p, h_sample.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  STRL_HIP(hipMemcpyAsync(B[B_KEYIN].p, h_key.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+  const int TB = 256;
+  const uint32_t nb = (n + TB - 1) / TB;
+  if (c->timing) STRL_HIP(hipEventRecord(c->ev[4], st));
+  // stable sort by position, then stable sort by (tid, unit)  ==  group + algorithm.sort by position
+  hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM0].as<uint32_t>());
+  size_t tmp1 = 0, tmp2 = 0, tmp3 = 0;
+  STRL_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, B[B_POSIN].as<uint32_t>(), B[B_POSK].as<uint32_t>(), B[B_PERM0].as<uint32_t>(),
+                                             B[B_PERM1].as<uint32_t>(), (int)n, 0, 32, st));
+  uint64_t maxkey = 0;
+  for (uint64_t k : h_key) maxkey = std::max(maxkey, k);
+  int kbits = 1;
+  while (kbits < 64 && (maxkey >> kbits)) ++kbits;
+  STRL_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, B[B_KEYG].as<uint64_t>(), B[B_KEYS].as<uint64_t>(), B[B_PERM1].as<uint32_t>(),
+                                             B[B_PERM0].as<uint32_t>(), (int)n, 0, kbits, st));
+  STRL_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp3, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, st));
+  const size_t tmpb = std::max(tmp1, std::max(tmp2, tmp3)) + 256;
+  if ((rc = need(B_TMP, tmpb))) return rc;
+  size_t t = tmpb;
+  STRL_HIP(hipcub::DeviceRadixSort::SortPairs(B[B_TMP].p, t, B[B_POSIN].as<uint32_t>(), B[B_POSK].as<uint32_t>(), B[B_PERM0].as<uint32_t>(),
+                                             B[B_PERM1].as<uint32_t>(), (int)n, 0, 32, st));
+  hipLaunchKernelGGL(gather_key_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM1].as<uint32_t>(), B[B_KEYIN].as<uint64_t>(), B[B_KEYG].as<uint64_t>());
+  t = tmpb;
+  STRL_HIP(hipcub::DeviceRadixSort::SortPairs(B[B_TMP].p, t, B[B_KEYG].as<uint64_t>(), B[B_KEYS].as<uint64_t>(), B[B_PERM1].as<uint32_t>(),
+                                             B[B_PERM0].as<uint32_t>(), (int)n, 0, kbits, st));
+  // B_PERM0 = final permutation (sorted index -> input index), B_KEYS = sorted group keys
+  // group heads -> group ids
+  if ((rc = need(B_A, (size_t)n * 4)) || (rc = need(B_B, (size_t)n * 4))) return rc;   // A: head flags / is_start, B: scans
+  uint32_t *d_head = B[B_A].as<uint32_t>(), *d_scan = B[B_B].as<uint32_t>();
+  hipLaunchKernelGGL(heads_kernel, dim3(nb), dim3(TB), 0, st, B[B_KEYS].as<uint64_t>(), n, d_head);
+  t = tmpb;
+  STRL_HIP(hipcub::DeviceScan::InclusiveSum(B[B_TMP].p, t, d_head, d_scan, (int)n, st));
+  uint32_t n_groups = 0;
+  STRL_HIP(hipMemcpyAsync(&n_groups, d_scan + (n - 1), 4, hipMemcpyDeviceToHost, st));
+  STRL_HIP(hipStreamSynchronize(st));
+  // sorted payload + per-group tables.  Layout of B_C: pos | sample | gid | ends ; B_D: split ; B_E: group tables
+  if ((rc = need(B_C, (size_t)n * 16)) || (rc = need(B_D, n))) return rc;
+  const size_t gt_bytes = (size_t)(n_groups + 1) * 4 + (size_t)n_groups * 4 + (size_t)n_groups * 8 + (size_t)n_groups + 64;
+  if ((rc = need(B_E, gt_bytes))) return rc;
+  uint32_t *d_pos = B[B_C].as<uint32_t>(), *d_sample = d_pos + n, *d_gid = d_sample + n, *d_ends = d_gid + n;
+  uint8_t *d_split = B[B_D].as<uint8_t>();
+  uint64_t *d_gkeys = B[B_E].as<uint64_t>();
+  uint32_t *d_gstart = reinterpret_cast<uint32_t *>(d_gkeys + n_groups);
+  uint32_t *d_gfirst = d_gstart + (n_groups + 1);
+  uint8_t *d_gplaced = reinterpret_cast<uint8_t *>(d_gfirst + n_groups);
+  STRL_HIP(hipMemsetAsync(d_gfirst, 0xff, (size_t)n_groups * 4, st));
+  hipLaunchKernelGGL(gather_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM0].as<uint32_t>(), B[B_POSIN].as<uint32_t>(), B[B_SPLITIN].as<uint8_t>(),
+                     B[B_SAMPLEIN].as<uint32_t>(), d_head, d_scan, B[B_KEYS].as<uint64_t>(), d_pos, d_split, d_sample, d_gid, d_gstart, d_gfirst,
+                     d_gkeys, d_gplaced);
+  if (c->timing) STRL_HIP(hipEventRecord(c->ev[5], st));
+  // ---- sweep ---------------------------------------------------------------------------------------
+  ClusterParams P{};
+  P.n = n; P.pos = d_pos; P.split = d_split; P.sample = d_sample; P.gid = d_gid; P.gstart = d_gstart; P.gplaced = d_gplaced;
+  P.n_groups = n_groups; P.ends = d_ends; P.is_start = d_head; P.max_dist = window; P.min_support = min_support;
+  P.min_clip = min_clip; P.min_clip_total = min_clip_total; P.max_clip_dist = max_clip_dist; P.mode = mode;
+  STRL_HIP(hipMemsetAsync(d_head, 0, (size_t)n * 4, st));
+  hipLaunchKernelGGL(ends_kernel, dim3(nb), dim3(TB), 0, st, P);
+  hipLaunchKernelGGL(walk_kernel, dim3((n_groups + 63) / 64), dim3(64), 0, st, P);
+  t = tmpb;
+  STRL_HIP(hipcub::DeviceScan::ExclusiveSum(B[B_TMP].p, t, d_head, d_scan, (int)n, st));
+  if ((rc = need(B_F, (size_t)n * 4 + 64))) return rc;
+  uint32_t *d_cl_start = B[B_F].as<uint32_t>(), *d_ncl = d_cl_start + n;
+  hipLaunchKernelGGL(scatter_starts_kernel, dim3(nb), dim3(TB), 0, st, n, d_head, d_scan, d_cl_start, d_ncl);
+  uint32_t n_clusters = 0;
+  STRL_HIP(hipMemcpyAsync(&n_clusters, d_ncl, 4, hipMemcpyDeviceToHost, st));
+  STRL_HIP(hipStreamSynchronize(st));
+  if (c->timing) STRL_HIP(hipEventRecord(c->ev[6], st));
+  // ---- bounds ---------------------------------------------------------------------------------------
+  std::vector<RawBounds> raw((size_t)2 * n_clusters);
+  if (n_clusters) {
+    const size_t scratch_dw = 4ull * (16ull * n_clusters + 3ull * n) + 64;
+    if ((rc = c->soft_tmp.reserve(scratch_dw * 4))) return rc;
+    if ((rc = need(B_KEYG, std::max((size_t)n * 8, (size_t)2 * n_clusters * sizeof(RawBounds))))) return rc;   // reuse as output
+    P.cl_start = d_cl_start; P.n_clusters = d_ncl; P.scratch = c->soft_tmp.as<uint32_t>(); P.out = B[B_KEYG].as<RawBounds>();
+    hipLaunchKernelGGL(bounds_kernel, dim3((n_clusters + 63) / 64), dim3(64), 0, st, P);
+    STRL_HIP(hipGetLastError());
+    STRL_HIP(hipMemcpyAsync(raw.data(), P.out, raw.size() * sizeof(RawBounds), hipMemcpyDeviceToHost, st));
+  }
+  if (c->timing) STRL_HIP(hipEventRecord(c->ev[7], st));
+  std::vector<uint64_t> g_keys(n_groups);
+  std::vector<uint32_t> g_start(n_groups + 1), g_first(n_groups), cl_start(n_clusters);
+  STRL_HIP(hipMemcpyAsync(g_keys.data(), d_gkeys, (size_t)n_groups * 8, hipMemcpyDeviceToHost, st));
+  STRL_HIP(hipMemcpyAsync(g_start.data(), d_gstart, (size_t)(n_groups + 1) * 4, hipMemcpyDeviceToHost, st));
+  STRL_HIP(hipMemcpyAsync(g_first.data(), d_gfirst, (size_t)n_groups * 4, hipMemcpyDeviceToHost, st));
+  if (n_clusters) STRL_HIP(hipMemcpyAsync(cl_start.data(), d_cl_start, (size_t)n_clusters * 4, hipMemcpyDeviceToHost, st));
+  STRL_HIP(hipStreamSynchronize(st));
+
+  // ---- host: reference row order = Nim Table slot order of the groups (insertion = first appearance) ----
+  std::vector<uint32_t> by_first(n_groups);
+  for (uint32_t g = 0; g < n_groups; ++g) by_first[g] = g;
+  std::sort(by_first.begin(), by_first.end(), [&](uint32_t a, uint32_t b) { return g_first[a] < g_first[b]; });
+  auto key_unit = [](uint64_t key, char rep[7]) {
+    const uint32_t len = (uint32_t)(key >> 12) & 7u, code = (uint32_t)key & 0xfffu;
+    memset(rep, 0, 7);
+    for (uint32_t j = 0; j < len; ++j) rep[j] = "CATG"[(code >> (2 * (len - 1 - j))) & 3u];
+  };
+  std::vector<uint64_t> hcodes(n_groups);
+  for (uint32_t q = 0; q < n_groups; ++q) {
+    const uint64_t key = g_keys[by_first[q]];
+    char rep[7];
+    key_unit(key, rep);
+    hcodes[q] = nim::hash_tid_rep((int32_t)(key >> 15) - 1, rep);
+  }
+  const std::vector<int64_t> order = nim::table_slot_order(hcodes, 8192);           // newTable(8192): call.nim:118, merge.nim:92
+  // clusters are in sorted order => grouped; index them per group
+  std::vector<uint32_t> cl_lo(n_groups + 1, 0);
+  {
+    uint32_t ci = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+      cl_lo[g] = ci;
+      while (ci < n_clusters && cl_start[ci] < g_start[g + 1]) ++ci;
+    }
+    cl_lo[n_groups] = ci;
+  }
+  uint64_t no = 0, nu = 0;
+  for (int64_t q : order) {
+    const uint32_t g = by_first[(size_t)q];
+    const uint64_t key = g_keys[g];
+    const int32_t tid = (int32_t)(key >> 15) - 1;
+    char rep[7];
+    key_unit(key, rep);
+    if (tid < 0) {                                                                    // call.nim:226-228
+      if (mode == STRL_MODE_CALL) {
+        if (unplaced && nu < unplaced_cap) { memcpy(unplaced[nu].repeat, rep, 7); unplaced[nu].count = (int64_t)(g_start[g + 1] - g_start[g]); }
+        ++nu;
+      }
+      continue;
+    }
+    for (uint32_t ci = cl_lo[g]; ci < cl_lo[g + 1]; ++ci)
+      for (int half = 0; half < 2; ++half) {
+        const RawBounds &r = raw[(size_t)2 * ci + half];
+        if (!r.valid) continue;
+        if (no < cap) {
+          strl_bounds &b = out[no];
+          b.tid = tid; b.left = r.left; b.left_most = r.left_most; b.right = r.right; b.right_most = r.right_most;
+          b.center_mass = r.center_mass; b.n_left = r.n_left; b.n_right = r.n_right; b.n_total = r.n_total;
+          memcpy(b.repeat, rep, 7);
+        }
+        ++no;
+      }
+  }
+  if (n_out) *n_out = no;
+  if (n_unplaced) *n_unplaced = nu;
+  if (stats) {
+    stats->n_groups = n_groups; stats->n_clusters = n_clusters; stats->n_bounds = no;
+    if (c->timing) {
+      (void)hipEventElapsedTime(&stats->ms_sort, c->ev[4], c->ev[5]);
+      (void)hipEventElapsedTime(&stats->ms_sweep, c->ev[5], c->ev[6]);
+      (void)hipEventElapsedTime(&stats->ms_bounds, c->ev[6], c->ev[7]);
+    }
+  }
+  if (no > cap) { set_error("bounds capacity %llu too small, need %llu", (unsigned long long)cap, (unsigned long long)no); return STRL_ERR_CAPACITY; }
+  return STRL_OK;
+}

@@ -1,0 +1,56 @@
+// common.h -- internal declarations shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/strling_amd.h"
+
+namespace strl {
+
+void set_error(const char *fmt, ...);
+
+#define STRL_HIP(call)                                                                              \
+  do {                                                                                              \
+    hipError_t e__ = (call);                                                                        \
+    if (e__ != hipSuccess) {                                                                        \
+      strl::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__);  \
+      return STRL_ERR_HIP;                                                                          \
+    }                                                                                               \
+  } while (0)
+
+// growable device buffer
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes);
+  void release();
+  template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+}  // namespace strl
+
+struct strl_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool timing = false;
+  hipEvent_t ev[8] = {};
+  std::vector<hipEvent_t> ring;   // 4 events per recorded strl_score_reads launch
+  uint64_t ring_pos = 0;
+  // options / tables
+  bool have_opts = false;
+  strl_opts opts{};
+  strl::DevBuf lut;  // uint16[LUT_ENTRIES]
+  strl::DevBuf thr;  // uint16[4][5][512]
+  // genome STR intervals, per tid sorted by start, with prefix max of stop
+  int32_t n_tid = 0;
+  uint64_t n_iv = 0;
+  strl::DevBuf g_has, g_off, g_start, g_pmax;
+  // scratch
+  strl::DevBuf queue, soft_queue, counters, soft_tmp;
+  // staging for host-memory batches
+  strl::DevBuf st_tid, st_pos, st_end, st_seqoff, st_lseq, st_clipl, st_clipr, st_mapq, st_cig, st_seq4, st_whole, st_soft;
+  // clustering scratch
+  strl::DevBuf c_buf[16];
+};

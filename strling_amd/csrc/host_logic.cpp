@@ -1,0 +1,525 @@
+// host_logic.cpp -- host side of the C ABI that needs no device: SoA derivation from BAM-native
+// records, the mate-pairing state machine of extract (Cache.add), fragment statistics, the .bin
+// reader/writer and the -bounds.txt row formatter.  Everything here consumes the packed results the
+// HIP kernels produced; none of it scores reads.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+#include "common.h"
+
+using strl::set_error;
+
+namespace {
+
+constexpr uint16_t F_PROPER = 0x2, F_UNMAP = 0x4, F_REVERSE = 0x10, F_MREVERSE = 0x20, F_SECONDARY = 0x100, F_SUPPL = 0x800;
+constexpr int OP_M = 0, OP_S = 4;
+
+// kmer module alphabet (brentp/nim-kmer): 2-bit code -> base.  See DESIGN.md "kmer code order".
+inline char code_base(uint32_t c) { return "CATG"[c & 3u]; }
+inline uint32_t base_code(char b) {
+  switch (b) { case 'C': return 0; case 'A': return 1; case 'T': return 2; case 'G': return 3; default: return 1; }
+}
+
+struct Unit {
+  char s[6];
+  int len;
+};
+
+inline Unit unpack_unit(uint32_t w) {
+  Unit u{};
+  u.len = (int)STRL_RES_K(w);
+  const uint32_t code = STRL_RES_CODE(w);
+  for (int j = 0; j < u.len; ++j) u.s[j] = code_base(code >> (2 * (u.len - 1 - j)));
+  return u;
+}
+
+inline int unit_len(const char r[6]) {
+  int l = 0;
+  while (l < 6 && r[l]) ++l;
+  return l;
+}
+
+// p_repeat template, extract.nim:56-58 (uint8 product)
+inline double p_repeat(const strl_tread &t) {
+  const uint8_t prod = (uint8_t)(t.repeat_count * (uint8_t)unit_len(t.repeat));
+  const uint8_t al = t.align_length ? t.align_length : 1;
+  return (double)prod / (double)al;
+}
+
+// minimum rotation of the reverse complement (utils.nim:61-80), on 2-bit codes:
+// complement of a "CATG" code c is 3 - c.
+void min_rev_complement(char rep[6]) {
+  const int l = unit_len(rep);
+  if (l == 0) return;
+  uint32_t c = 0;
+  for (int i = l - 1; i >= 0; --i) c = (c << 2) | (3u - base_code(rep[i]));  // only ACGT reach here (decoded units)
+  const uint32_t mask = (1u << (2 * l)) - 1u;
+  uint32_t best = c, f = c;
+  for (int j = 0; j < l; ++j) {
+    f = ((f << 2) | (f >> (2 * (l - 1)))) & mask;
+    best = std::min(best, f);
+  }
+  for (int j = 0; j < l; ++j) rep[j] = code_base(best >> (2 * (l - 1 - j)));
+}
+
+// canonical_repeat, utils.nim:291-310: the rev-comp rotation minimum if it is ASCII-smaller
+void canonical_repeat(char rep[6]) {
+  char r[6];
+  memcpy(r, rep, 6);
+  min_rev_complement(r);
+  if (memcmp(r, rep, 6) < 0) memcpy(rep, r, 6);
+}
+
+inline bool should_reverse(uint16_t f) {  // extract.nim:134-139
+  bool r = !(f & F_MREVERSE);
+  return (f & F_REVERSE) ? !r : r;
+}
+
+// adjust_by, extract.nim:141-179
+bool adjust_by(strl_tread &A, const strl_tread &B, const strl_opts &o, uint32_t B_position) {
+  if (A.repeat_count == 0) return false;
+  const uint32_t half = (uint32_t)((double)A.align_length / 2.0 + 0.5);
+  if (B.mapping_quality > o.min_mapq &&
+      ((p_repeat(A) > o.proportion_repeat && p_repeat(B) < 0.2) || (!(A.flag & F_PROPER) && A.mapping_quality < o.min_mapq))) {
+    if (B.flag & F_REVERSE) {
+      A.position = B_position - (uint32_t)o.median_fragment_length + B.align_length + half;
+      if (B.split == STRL_SOFT_NONE_LEFT) A.position = B_position;
+    } else {
+      A.position = B_position + (uint32_t)o.median_fragment_length - half;
+      if (B.split == STRL_SOFT_NONE_RIGHT) A.position = B_position + (uint32_t)B.align_length;
+    }
+    A.split = STRL_SOFT_NONE;
+    A.tid = B.tid;
+    A.mapping_quality = std::max(A.mapping_quality, B.mapping_quality);
+    if (should_reverse(A.flag)) min_rev_complement(A.repeat);
+  } else if (A.mapping_quality >= o.min_mapq || (A.flag & F_PROPER)) {
+    A.position += half;
+    A.mapping_quality = std::max(A.mapping_quality, B.mapping_quality);
+  }
+  return true;
+}
+
+bool unplaced_pair(const strl_tread &A, const strl_tread &B, const strl_opts &o) {  // extract.nim:182-190
+  if (p_repeat(A) > o.proportion_repeat && p_repeat(B) > o.proportion_repeat) return true;
+  if (p_repeat(A) > o.proportion_repeat && B.mapping_quality < o.min_mapq) return true;
+  if (p_repeat(B) > o.proportion_repeat && A.mapping_quality < o.min_mapq) return true;
+  return false;
+}
+
+struct RecView {
+  const strl_records *r;
+  int ncig(int64_t i) const { return (int)(r->cigar_off[i + 1] - r->cigar_off[i]); }
+  int op(int64_t i, int j) const { return (int)(r->cigar[r->cigar_off[i] + j] & 0xf); }
+  int len(int64_t i, int j) const { return (int)(r->cigar[r->cigar_off[i] + j] >> 4); }
+  int64_t stop(int64_t i) const {  // htslib bam_endpos
+    int64_t rl = 0;
+    if (!(r->flag[i] & F_UNMAP)) {
+      const int n = ncig(i);
+      for (int j = 0; j < n; ++j) {
+        const int o = op(i, j);
+        if (o == 0 || o == 2 || o == 3 || o == 7 || o == 8) rl += len(i, j);
+      }
+    }
+    return (int64_t)r->pos[i] + (rl ? rl : 1);
+  }
+  std::string_view qname(int64_t i) const {
+    return std::string_view(r->qnames + r->qname_off[i], (size_t)(r->qname_off[i + 1] - r->qname_off[i]));
+  }
+};
+
+struct Pairer {
+  RecView rv;
+  const strl_opts *o;
+  const uint32_t *whole;
+  const strl_soft_rec *soft;
+  uint64_t n_soft;
+  strl_tread *out;
+  uint64_t cap, n_out = 0;
+  int err = 0;
+  std::unordered_map<std::string_view, strl_tread> tbl;
+
+  void push(const strl_tread &t) {
+    if (n_out < cap) out[n_out] = t;
+    ++n_out;
+  }
+  const strl_soft_rec *find_soft(int64_t i, int side) const {
+    const uint32_t key = ((uint32_t)i << 1) | (uint32_t)side;
+    const strl_soft_rec *e = soft + n_soft;
+    const strl_soft_rec *it = std::lower_bound(soft, e, key, [](const strl_soft_rec &a, uint32_t k) { return a.read_side < k; });
+    return (it != e && it->read_side == key) ? it : nullptr;
+  }
+  // to_tread, extract.nim:63-87, from the packed scorer word
+  strl_tread to_tread(int64_t i) {
+    const strl_records *r = rv.r;
+    const uint32_t w = whole[i];
+    strl_tread t{};
+    const Unit u = unpack_unit(w);
+    memcpy(t.repeat, u.s, 6);
+    const uint32_t cnt = STRL_RES_COUNT(w);
+    if (cnt >= 256) { err = STRL_ERR_ASSERT; set_error("repeat_count %u >= 256 for record %lld (doAssert extract.nim:72)", cnt, (long long)i); }
+    const int align_length = (w & STRL_RES_SKIPPED) ? rv.len(i, 0) : r->l_seq[i];  // extract.nim:33 / :38
+    t.tid = r->tid[i];
+    t.position = (uint32_t)std::max(0, r->pos[i]);
+    t.flag = r->flag[i];
+    t.repeat_count = (uint8_t)cnt;
+    t.align_length = (uint8_t)align_length;
+    t.split = STRL_SOFT_NONE;
+    t.mapping_quality = r->mapq[i];
+    t.qname_id = i;
+    const int L = rv.ncig(i);
+    if (L > 1 && rv.op(i, 0) == OP_S && rv.len(i, 0) > 16) t.split = STRL_SOFT_NONE_LEFT;
+    if (L > 1 && rv.op(i, L - 1) == OP_S && rv.len(i, L - 1) > 16) t.split = STRL_SOFT_NONE_RIGHT;
+    return t;
+  }
+  // add_soft, extract.nim:93-132, consuming the device's soft-clip records
+  void add_soft(int64_t i, bool first_seen, const char read_repeat[6]) {
+    const strl_records *r = rv.r;
+    if (r->mapq[i] < o->min_mapq) return;
+    const int L = rv.ncig(i);
+    if (L == 0 || (rv.op(i, 0) != OP_S && rv.op(i, L - 1) != OP_S)) return;
+    const int idxs[2] = {0, L - 1};
+    for (int q = 0; q < 2; ++q) {
+      const int ci = idxs[q];
+      if (rv.op(i, ci) != OP_S) continue;
+      const int clen = rv.len(i, ci);
+      if (read_repeat[0] == 0 && clen <= 16) continue;
+      const int side = (ci == 0) ? 0 : 1;
+      const strl_soft_rec *s = find_soft(i, side);
+      if (!s) { err = STRL_ERR_ARG; set_error("missing soft-clip result for record %lld side %d", (long long)i, side); return; }
+      const uint32_t w = first_seen ? s->res_first : s->res_after;
+      const uint32_t cnt = STRL_RES_COUNT(w);
+      if (cnt == 0) continue;
+      if (cnt >= 256) { err = STRL_ERR_ASSERT; set_error("soft repeat_count %u >= 256 for record %lld", cnt, (long long)i); }
+      strl_tread t{};
+      const Unit u = unpack_unit(w);
+      memcpy(t.repeat, u.s, 6);
+      t.tid = r->tid[i];
+      const int64_t p = (ci == 0) ? (int64_t)r->pos[i] : rv.stop(i);
+      t.position = (uint32_t)std::max<int64_t>(0, p);
+      t.flag = r->flag[i];
+      t.repeat_count = (uint8_t)cnt;
+      t.align_length = (uint8_t)clen;
+      t.split = (ci == 0) ? STRL_SOFT_LEFT : STRL_SOFT_RIGHT;
+      t.mapping_quality = r->mapq[i];
+      t.qname_id = i;
+      if (p_repeat(t) < 0.9) continue;
+      push(t);
+    }
+  }
+  // Cache.add, extract.nim:192-248
+  void add(int64_t i) {
+    const strl_records *r = rv.r;
+    const std::string_view qn = rv.qname(i);
+    auto it = tbl.find(qn);
+    const int32_t tid = r->tid[i], mtid = r->mtid[i], start = r->pos[i], mpos = r->mpos[i];
+    const bool after_mate = tid > mtid || (tid == mtid && (start > mpos || (start == mpos && it != tbl.end())));
+    if (after_mate) {
+      if (it == tbl.end()) return;
+      strl_tread mate = it->second;
+      tbl.erase(it);
+      strl_tread self = to_tread(i);
+      add_soft(i, false, self.repeat);
+      if (mate.repeat_count == 0 && self.repeat_count == 0) return;
+      if (unplaced_pair(self, mate, *o)) {
+        if (self.repeat[0] == 0 || mate.repeat[0] == 0) return;
+        canonical_repeat(self.repeat);
+        self.position = 0;
+        self.tid = -1;
+        canonical_repeat(mate.repeat);
+        mate.position = 0;
+        mate.tid = -1;
+        push(self);
+        push(mate);
+        return;
+      }
+      const uint32_t mp = mate.position;
+      if (adjust_by(mate, self, *o, self.position)) push(mate);
+      if (adjust_by(self, mate, *o, mp)) push(self);
+    } else {
+      strl_tread tr = to_tread(i);
+      add_soft(i, true, tr.repeat);
+      if (it != tbl.end()) tbl.erase(it);  // hasKeyOrPut hit: warn + take, the new tread is not stored (:245-248)
+      else tbl.emplace(qn, tr);
+    }
+  }
+};
+
+inline uint64_t hash_bytes(std::string_view s) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (unsigned char c : s) { h ^= c; h *= 0x100000001b3ull; }
+  return h ^ (h >> 29);
+}
+
+}  // namespace
+
+extern "C" {
+
+int strl_soa_from_records(const strl_records *rec, int32_t *end, uint32_t *seq_off16, uint16_t *l_seq, uint16_t *clip_l,
+                          uint16_t *clip_r, uint8_t *cig, uint32_t *max_l_seq) {
+  if (!rec || !end || !seq_off16 || !l_seq || !clip_l || !clip_r || !cig) { set_error("null argument"); return STRL_ERR_ARG; }
+  RecView rv{rec};
+  uint32_t mx = 0;
+  for (int64_t i = 0; i < rec->n; ++i) {
+    const int L = rv.ncig(i);
+    uint8_t c = 0;
+    uint32_t cl = 0, cr = 0;
+    if (L == 0) c |= STRL_CIG_NONE;
+    else {
+      if (L == 1) c |= STRL_CIG_ONE_OP;
+      if (L == 1 && rv.op(i, 0) == OP_M) c |= STRL_CIG_SINGLE_M;
+      if (rv.op(i, 0) == OP_S) { c |= STRL_CIG_FIRST_S; cl = (uint32_t)rv.len(i, 0); }
+      if (rv.op(i, L - 1) == OP_S) { c |= STRL_CIG_LAST_S; cr = (uint32_t)rv.len(i, L - 1); }
+    }
+    const int32_t ls = rec->l_seq[i];
+    if (ls < 0 || ls > STRL_MAX_READ_LEN) { set_error("record %lld: l_seq %d outside [0, %d]", (long long)i, ls, STRL_MAX_READ_LEN); return STRL_ERR_ARG; }
+    if (rec->seq_off[i] & 15u) { set_error("record %lld: seq_off not 16-byte aligned", (long long)i); return STRL_ERR_ARG; }
+    if ((rec->seq_off[i] >> 4) > 0xffffffffull) { set_error("SEQ buffer exceeds 64 GiB"); return STRL_ERR_ARG; }
+    cig[i] = c;
+    clip_l[i] = (uint16_t)std::min<uint32_t>(cl, 65535u);
+    clip_r[i] = (uint16_t)std::min<uint32_t>(cr, 65535u);
+    l_seq[i] = (uint16_t)ls;
+    seq_off16[i] = (uint32_t)(rec->seq_off[i] >> 4);
+    const int64_t e = rv.stop(i);
+    end[i] = (int32_t)e;
+    mx = std::max(mx, (uint32_t)ls);
+  }
+  if (max_l_seq) *max_l_seq = mx;
+  return STRL_OK;
+}
+
+int strl_pair_reads(const strl_records *rec, const strl_opts *opts, const uint32_t *whole, const strl_soft_rec *soft,
+                    uint64_t n_soft, int64_t n_tail, strl_tread *out, uint64_t cap, uint64_t *n_out) {
+  if (!rec || !opts || (!whole && rec->n) || (!out && cap)) { set_error("null argument"); return STRL_ERR_ARG; }
+  Pairer P{RecView{rec}, opts, whole, soft, n_soft, out, cap};
+  const int64_t n = rec->n;
+  // Qname groups never interact (the table is keyed by qname), and a group none of whose records
+  // carries a repeat produces no output: only replay Cache.add for the groups that can emit.
+  std::vector<uint8_t> hot((size_t)n, 0);
+  for (int64_t i = 0; i < n; ++i) hot[(size_t)i] = STRL_RES_COUNT(whole[i]) != 0;
+  for (uint64_t s = 0; s < n_soft; ++s)
+    if (STRL_RES_COUNT(soft[s].res_first) || STRL_RES_COUNT(soft[s].res_after)) hot[soft[s].read_side >> 1] = 1;
+  std::unordered_set<uint64_t> hot_names;
+  for (int64_t i = 0; i < n; ++i) if (hot[(size_t)i]) hot_names.insert(hash_bytes(P.rv.qname(i)));
+  std::vector<uint8_t> sel((size_t)n, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    if (rec->flag[i] & (F_SECONDARY | F_SUPPL)) continue;  // extract.nim:309
+    sel[(size_t)i] = hot[(size_t)i] || hot_names.count(hash_bytes(P.rv.qname(i)));
+  }
+  for (int64_t i = 0; i < n; ++i) if (sel[(size_t)i]) P.add(i);                      // extract.nim:308-322
+  if (n_tail < 0) { n_tail = 0; while (n_tail < n && rec->tid[n - 1 - n_tail] < 0) ++n_tail; }
+  for (int64_t i = n - n_tail; i < n; ++i) if (sel[(size_t)i]) P.add(i);             // extract.nim:326-329 (tail revisited)
+  if (n_out) *n_out = P.n_out;
+  if (P.err) return P.err;
+  if (P.n_out > cap) { set_error("tread capacity %llu too small, need %llu", (unsigned long long)cap, (unsigned long long)P.n_out); return STRL_ERR_CAPACITY; }
+  return STRL_OK;
+}
+
+int strl_extract(strl_ctx *ctx, const strl_records *rec, int64_t n_tail, strl_tread *out, uint64_t cap, uint64_t *n_out,
+                 strl_score_stats *stats) {
+  if (!ctx || !rec) { set_error("null argument"); return STRL_ERR_ARG; }
+  const size_t n = (size_t)rec->n;
+  std::vector<int32_t> end(n);
+  std::vector<uint32_t> so(n), whole(n);
+  std::vector<uint16_t> ls(n), cl(n), cr(n);
+  std::vector<uint8_t> cig(n);
+  uint32_t mx = 0;
+  int rc = strl_soa_from_records(rec, end.data(), so.data(), ls.data(), cl.data(), cr.data(), cig.data(), &mx);
+  if (rc) return rc;
+  uint64_t seq_bytes = 32;
+  for (size_t i = 0; i < n; ++i) seq_bytes = std::max<uint64_t>(seq_bytes, rec->seq_off[i] + (uint64_t)((rec->l_seq[i] + 1) / 2) + 32);
+  strl_read_soa soa{};
+  soa.n = n; soa.tid = rec->tid; soa.pos = rec->pos; soa.end = end.data(); soa.seq_off = so.data(); soa.l_seq = ls.data();
+  soa.clip_l = cl.data(); soa.clip_r = cr.data(); soa.mapq = rec->mapq; soa.cig = cig.data(); soa.seq4 = rec->seq4;
+  soa.seq4_bytes = seq_bytes; soa.max_l_seq = mx; soa.mem = STRL_MEM_HOST;
+  std::vector<strl_soft_rec> soft(2 * n + 1);
+  uint64_t ns = 0;
+  rc = strl_score_reads(ctx, &soa, whole.data(), soft.data(), 2 * n, &ns, stats);
+  if (rc) return rc;
+  return strl_pair_reads(rec, &ctx->opts, whole.data(), soft.data(), ns, n_tail, out, cap, n_out);
+}
+
+int strl_frag_median(const uint32_t frag[4096], double pct) {  // utils.nim:139-146
+  uint32_t n = 0;
+  for (int i = 0; i < 4096; ++i) n += frag[i];
+  const uint32_t want = (uint32_t)(0.5 + (double)n / (1.0 / pct));
+  uint32_t c = 0;
+  for (int i = 0; i < 4096; ++i) {
+    c += frag[i];
+    if (c >= want) return i;
+  }
+  return 4096;
+}
+
+// ---- msgpack subset used by the .bin records (msgpack4nim picks the smallest encoding) ----------
+static void mp_uint(std::string &b, uint64_t v) {
+  if (v < 128) b.push_back((char)v);
+  else if (v < 256) { b.push_back((char)0xcc); b.push_back((char)v); }
+  else if (v < 65536) { b.push_back((char)0xcd); b.push_back((char)(v >> 8)); b.push_back((char)v); }
+  else { b.push_back((char)0xce); for (int s = 24; s >= 0; s -= 8) b.push_back((char)(v >> s)); }
+}
+static void mp_int(std::string &b, int32_t v) {
+  if (v >= 0) { mp_uint(b, (uint64_t)v); return; }
+  if (v >= -32) b.push_back((char)v);
+  else if (v >= -128) { b.push_back((char)0xd0); b.push_back((char)v); }
+  else if (v >= -32768) { b.push_back((char)0xd1); b.push_back((char)((uint16_t)v >> 8)); b.push_back((char)v); }
+  else { b.push_back((char)0xd2); const uint32_t u = (uint32_t)v; for (int s = 24; s >= 0; s -= 8) b.push_back((char)(u >> s)); }
+}
+static void mp_str(std::string &b, const char *p, size_t l) {
+  if (l < 32) b.push_back((char)(0xa0 | l));
+  else if (l < 256) { b.push_back((char)0xd9); b.push_back((char)l); }
+  else if (l < 65536) { b.push_back((char)0xda); b.push_back((char)(l >> 8)); b.push_back((char)l); }
+  else { b.push_back((char)0xdb); for (int s = 24; s >= 0; s -= 8) b.push_back((char)(l >> s)); }
+  b.append(p, l);
+}
+
+int strl_bin_write(const char *path, float proportion_repeat, uint8_t min_mapq, const uint32_t frag[4096], const char *sam_header,
+                   int32_t header_len, const strl_tread *treads, uint64_t n, const uint64_t *qname_off, const char *qnames) {
+  FILE *f = fopen(path, "wb");
+  if (!f) { set_error("[strling] couldnt open binary output file %s", path); return STRL_ERR_IO; }
+  std::string b;
+  b.reserve(1 << 20);
+  b.append("STR", 3);                                       // extract.nim:336
+  const int16_t fmt = 0;                                    // version.nim:4
+  b.append((const char *)&fmt, 2);
+  char ver[9] = {0};
+  memcpy(ver, "0.6.0", 5);                                  // version.nim:1
+  b.append(ver, 9);
+  b.append((const char *)&proportion_repeat, 4);
+  b.push_back((char)min_mapq);
+  b.append((const char *)frag, 4096 * 4);
+  b.append((const char *)&header_len, 4);
+  b.append(sam_header, (size_t)header_len);
+  const int32_t n32 = (int32_t)n;
+  b.append((const char *)&n32, 4);
+  for (uint64_t i = 0; i < n; ++i) {                        // pack_type, cluster.nim:38-50
+    const strl_tread &t = treads[i];
+    mp_int(b, t.tid);
+    mp_uint(b, t.position);
+    b.push_back((char)0x96);
+    for (int j = 0; j < 6; ++j) mp_uint(b, (uint8_t)t.repeat[j]);
+    mp_uint(b, t.flag);
+    mp_uint(b, t.split);
+    mp_uint(b, t.mapping_quality);
+    mp_uint(b, t.repeat_count);
+    mp_uint(b, t.align_length);
+    const uint64_t q0 = qname_off[t.qname_id], q1 = qname_off[t.qname_id + 1];
+    mp_uint(b, q1 - q0);
+    mp_str(b, qnames + q0, (size_t)(q1 - q0));
+    if (b.size() > (1u << 20)) { if (fwrite(b.data(), 1, b.size(), f) != b.size()) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; } b.clear(); }
+  }
+  if (fwrite(b.data(), 1, b.size(), f) != b.size()) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; }
+  fclose(f);
+  return STRL_OK;
+}
+
+namespace {
+struct Rd {
+  const uint8_t *p, *e;
+  bool ok = true;
+  uint64_t be(int n) { uint64_t v = 0; for (int i = 0; i < n; ++i) { if (p >= e) { ok = false; return 0; } v = (v << 8) | *p++; } return v; }
+  int64_t integer() {
+    if (p >= e) { ok = false; return 0; }
+    const uint8_t t = *p++;
+    if (t < 0x80) return t;
+    if (t >= 0xe0) return (int8_t)t;
+    switch (t) {
+      case 0xcc: return (int64_t)be(1);
+      case 0xcd: return (int64_t)be(2);
+      case 0xce: return (int64_t)be(4);
+      case 0xcf: return (int64_t)be(8);
+      case 0xd0: return (int8_t)be(1);
+      case 0xd1: return (int16_t)be(2);
+      case 0xd2: return (int32_t)be(4);
+      case 0xd3: return (int64_t)be(8);
+      default: ok = false; return 0;
+    }
+  }
+  size_t strhdr() {
+    if (p >= e) { ok = false; return 0; }
+    const uint8_t t = *p++;
+    if ((t & 0xe0) == 0xa0) return t & 0x1f;
+    if (t == 0xd9) return (size_t)be(1);
+    if (t == 0xda) return (size_t)be(2);
+    if (t == 0xdb) return (size_t)be(4);
+    ok = false;
+    return 0;
+  }
+};
+}  // namespace
+
+int strl_bin_read(const char *path, strl_bin_info *info, char *sam_header, strl_tread *treads, uint64_t *qname_off, char *qnames) {
+  if (!path || !info) { set_error("null argument"); return STRL_ERR_ARG; }
+  FILE *f = fopen(path, "rb");
+  if (!f) { set_error("[strling] unable to open %s for reading. please check path", path); return STRL_ERR_IO; }
+  std::vector<uint8_t> buf;
+  fseek(f, 0, SEEK_END);
+  const long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  buf.resize((size_t)std::max(0L, sz));
+  if (sz > 0 && fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); set_error("short read from %s", path); return STRL_ERR_IO; }
+  fclose(f);
+  const size_t fixed = 3 + 2 + 9 + 4 + 1 + 4096 * 4 + 4;
+  if (buf.size() < fixed + 4 || memcmp(buf.data(), "STR", 3) != 0) {                // unpack.nim:61-62
+    set_error("[strling] expected bin file to start with \"STR\"");
+    return STRL_ERR_FORMAT;
+  }
+  int16_t fmt;
+  memcpy(&fmt, buf.data() + 3, 2);
+  if (fmt != 0) { set_error("[strling] this bin file was generated using a different format"); return STRL_ERR_FORMAT; }   // :64-66
+  size_t o = 3 + 2 + 9;
+  memcpy(&info->proportion_repeat, buf.data() + o, 4); o += 4;
+  info->min_mapq = buf[o++];
+  memcpy(info->frag, buf.data() + o, 4096 * 4); o += 4096 * 4;
+  memcpy(&info->header_len, buf.data() + o, 4); o += 4;
+  if (info->header_len < 0 || o + (size_t)info->header_len + 4 > buf.size()) { set_error("truncated bin header"); return STRL_ERR_FORMAT; }
+  if (sam_header) memcpy(sam_header, buf.data() + o, (size_t)info->header_len);
+  o += (size_t)info->header_len;
+  memcpy(&info->n_reads, buf.data() + o, 4); o += 4;
+  Rd rd{buf.data() + o, buf.data() + buf.size()};
+  uint64_t qbytes = 0;
+  int64_t i = 0;
+  while (rd.p < rd.e) {                                                              // unpack_type, unpack.nim:36-55
+    strl_tread t{};
+    t.tid = (int32_t)rd.integer();
+    t.position = (uint32_t)rd.integer();
+    if (rd.p >= rd.e || *rd.p++ != 0x96) { rd.ok = false; break; }
+    for (int j = 0; j < 6; ++j) t.repeat[j] = (char)rd.integer();
+    t.flag = (uint16_t)rd.integer();
+    t.split = (uint8_t)rd.integer();
+    t.mapping_quality = (uint8_t)rd.integer();
+    t.repeat_count = (uint8_t)rd.integer();
+    t.align_length = (uint8_t)rd.integer();
+    const uint64_t L = (uint64_t)rd.integer();
+    size_t sl = 0;
+    if (L > 0) {                                                                     // :51-54 (qname read only when L > 0)
+      sl = rd.strhdr();
+      if (!rd.ok || rd.p + sl > rd.e) { rd.ok = false; break; }
+      if (qnames) memcpy(qnames + qbytes, rd.p, sl);
+      rd.p += sl;
+    }
+    if (!rd.ok) break;
+    t.qname_id = i;
+    if (treads) treads[i] = t;
+    if (qname_off) qname_off[i] = qbytes;
+    qbytes += sl;
+    ++i;
+  }
+  if (!rd.ok) { set_error("malformed msgpack record %lld in %s", (long long)i, path); return STRL_ERR_FORMAT; }
+  if (qname_off) qname_off[i] = qbytes;
+  if (i != info->n_reads) { set_error("[strling] expected %d got %lld", info->n_reads, (long long)i); return STRL_ERR_FORMAT; }   // :130-131
+  info->qnames_bytes = qbytes;
+  return STRL_OK;
+}
+
+int strl_bounds_row(char *buf, int cap, const strl_bounds *b, const char *chrom) {   // cluster.nim:262-266
+  return snprintf(buf, (size_t)cap, "%s\t%u\t%u\t%s\t\t%u\t%u\t%u\t%u\t%u\t%u", chrom, b->left, b->right, b->repeat, b->left_most,
+                  b->right_most, b->center_mass, (unsigned)b->n_left, (unsigned)b->n_right, (unsigned)b->n_total);
+}
+
+}  // extern "C"

@@ -1,0 +1,298 @@
+// score_core.h -- per-lane repeat-unit scorer for one read segment (CDNA4 / gfx950).
+//
+// What it computes: utils.get_repeat (src/strpkg/utils.nim:236-271) of the reference, i.e. for
+// k = 2..6 the most frequent minimum-rotation k-mer over NON-overlapping windows
+// (slide_by utils.nim:10-34, count :205-211 with the running-argmax tie rule of inc :192-195),
+// the greedy literal recount (strutils.count, utils.nim:254), the score/threshold ladder
+// (:250-263) and reduce_repeat (:220-233, :271).  It is written from the algorithm for a
+// 64-wide wavefront with ONE READ PER LANE:
+//   * the read lives in registers as a 2-bit stream (kmer "CATG" code, base i at bits 2i..2i+1
+//     of word i/16) plus a same-layout invalid-base stream,
+//   * window -> canonical (min-rotation) code is one LDS table lookup,
+//   * per-lane uint8 histograms (k <= 4) / open-addressing tables (k = 5,6) live in LDS in a
+//     [row][lane] layout, so every lane hits its own bank: no conflicts, no atomics between lanes,
+//   * the literal recount is bit-parallel (XOR against the replicated unit, 16 bases per op),
+//   * the k loop is wave-uniform (lanes that `break` just go idle), so table clears are
+//     cooperative 16-byte stores.
+// The same source compiles for the host (STRL_EMU, one "lane", LANES = 1) purely so that the
+// CPU-only test-suite can exercise the device logic; the product never runs that build.
+#pragma once
+#include <stdint.h>
+
+#ifdef STRL_EMU
+#define STRL_DEV inline
+#define STRL_LANES 1
+static inline uint32_t strl_funnel_r(uint32_t lo, uint32_t hi, uint32_t s) {
+  return s == 0 ? lo : (uint32_t)(((((uint64_t)hi) << 32) | lo) >> s);
+}
+static inline int strl_ffs(uint32_t x) { return __builtin_ffs((int)x); }
+static inline int strl_popc(uint32_t x) { return __builtin_popcount(x); }
+static inline bool strl_any(bool p) { return p; }
+static inline uint32_t strl_lds_add(uint32_t *a, uint32_t v) { uint32_t o = *a; *a = o + v; return o; }
+#else
+#include <hip/hip_runtime.h>
+#define STRL_DEV __device__ __forceinline__
+#define STRL_LANES 64
+STRL_DEV uint32_t strl_funnel_r(uint32_t lo, uint32_t hi, uint32_t s) { return __funnelshift_r(lo, hi, s); }
+STRL_DEV int strl_ffs(uint32_t x) { return __ffs((int)x); }
+STRL_DEV int strl_popc(uint32_t x) { return __popc(x); }
+STRL_DEV bool strl_any(bool p) { return __any(p) != 0; }
+STRL_DEV uint32_t strl_lds_add(uint32_t *a, uint32_t v) { return atomicAdd(a, v); }  // lane-private: ds_add_rtn_u32
+#endif
+
+namespace strl {
+
+// canonical-code lookup tables, indexed by the window value as it comes out of the LSB-first
+// 2-bit stream (first base in the LOW bits); entries are the reference's code (first base HIGH).
+constexpr int LUT_OFF2 = 0, LUT_OFF3 = 16, LUT_OFF4 = 80, LUT_OFF5 = 336, LUT_OFF6 = 1360, LUT_ENTRIES = 5456;
+template <int K> struct LutOff;
+template <> struct LutOff<2> { static constexpr int v = LUT_OFF2; };
+template <> struct LutOff<3> { static constexpr int v = LUT_OFF3; };
+template <> struct LutOff<4> { static constexpr int v = LUT_OFF4; };
+template <> struct LutOff<5> { static constexpr int v = LUT_OFF5; };
+template <> struct LutOff<6> { static constexpr int v = LUT_OFF6; };
+
+// threshold tables (host-computed with the reference's float64 expressions, so the device does
+// no floating point at all): thr[row][k-2][L], rows: 0 = int(L*0.12/k) (utils.nim:251),
+// 1 = int(L*p/k), 2 = int(L*(p-0.07)/k), 3 = int(L*min(p,0.6)/k)  (utils.nim:259, extract.nim:208,242)
+constexpr int THR_LMAX = 512;
+constexpr int THR_ROW = 5 * THR_LMAX;
+
+// ---- BAM 4-bit -> 2-bit -----------------------------------------------------------------------
+// squeeze the two low bits of each nibble of z into 16 contiguous bits, in base order
+// (BAM stores base 2m in the HIGH nibble of byte m).
+STRL_DEV uint32_t squeeze8(uint32_t z) {
+  z = ((z >> 4) & 0x03030303u) | ((z & 0x03030303u) << 2);
+  z = (z | (z >> 4)) & 0x00FF00FFu;
+  z = (z | (z >> 8)) & 0x0000FFFFu;
+  return z;
+}
+// 8 BAM-packed bases -> 8 code pairs (A=1 C=0 G=3 T=2, anything else 1 like the kmer module's
+// lookup) and 8 flag pairs (bit 2j: base j is not ACGT, bit 2j+1: base j is 'N').
+STRL_DEV void conv8(uint32_t x, uint32_t &pairs, uint32_t &flags) {
+  uint32_t b0 = x & 0x11111111u, b1 = (x >> 1) & 0x11111111u, b2 = (x >> 2) & 0x11111111u, b3 = (x >> 3) & 0x11111111u;
+  uint32_t sum = b0 + b1 + b2 + b3;  // per-nibble popcount
+  uint32_t t = sum ^ 0x11111111u;
+  uint32_t inv = (t | (t >> 1) | (t >> 2)) & 0x11111111u;  // popcount != 1
+  uint32_t l = (b0 | b2) | inv;
+  uint32_t h = (b3 | b2) & ~inv;
+  pairs = squeeze8(l | (h << 1));
+  flags = 0;
+  if (inv) {
+    uint32_t isn = (sum >> 2) & 0x11111111u;  // popcount == 4 <=> 'N'
+    flags = squeeze8(inv | (isn << 1));
+  }
+}
+
+// One segment in registers.
+template <int NW> struct Seg {
+  uint32_t seq[NW];  // 2-bit codes, 16 bases per word, zero beyond len
+  uint32_t inv[NW];  // bit 2i set: base i is not ACGT (never matches a literal unit)
+  int len;
+  int n_N;
+  bool has_inv;
+};
+
+// Build a Seg from raw BAM-packed dwords staged in this lane's LDS column (`raw[i * STRL_LANES]`
+// is dword i of the staged chunk), starting at base `s0` (< 32) of the chunk.
+template <int NW> STRL_DEV void seg_from_raw(const uint32_t *raw, int s0, int len, Seg<NW> &sg) {
+  const int dw0 = s0 >> 3, sh = s0 & 7;
+  uint32_t p, f;
+  conv8(raw[dw0 * STRL_LANES], p, f);
+  uint32_t cur = p >> (2 * sh), curf = f >> (2 * sh);
+  const int fill = 16 - 2 * sh;
+  uint32_t any_f = 0;
+  int nn = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    uint32_t sw = 0, fw = 0;
+    if (16 * w < len) {
+      uint32_t pa, fa, pb, fb;
+      conv8(raw[(dw0 + 1 + 2 * w) * STRL_LANES], pa, fa);
+      conv8(raw[(dw0 + 2 + 2 * w) * STRL_LANES], pb, fb);
+      uint64_t buf = (uint64_t)cur | ((uint64_t)pa << fill) | ((uint64_t)pb << (fill + 16));
+      uint64_t bf = (uint64_t)curf | ((uint64_t)fa << fill) | ((uint64_t)fb << (fill + 16));
+      sw = (uint32_t)buf;
+      fw = (uint32_t)bf;
+      cur = (uint32_t)(buf >> 32);
+      curf = (uint32_t)(bf >> 32);
+      const int nv = len - 16 * w;
+      if (nv < 16) {
+        const uint32_t m = (1u << (2 * nv)) - 1u;
+        sw &= m;
+        fw &= m;
+      }
+    }
+    sg.seq[w] = sw;
+    sg.inv[w] = fw & 0x55555555u;
+    any_f |= fw;
+    nn += strl_popc(fw & 0xAAAAAAAAu);
+  }
+  sg.len = len;
+  sg.n_N = nn;
+  sg.has_inv = (any_f & 0x55555555u) != 0;
+}
+
+// ---- per-k histogram pass (utils.nim:205-211) ---------------------------------------------------
+// tab: this lane's LDS column (row stride STRL_LANES dwords), already zeroed for this k.
+// Returns count (A[imax]) and the winning code (4^K-1 when there is no window: decode of -1).
+template <int K, int NW, int SLOTS>
+STRL_DEV void hist_pass(const Seg<NW> &sg, bool active, uint32_t *tab, const uint16_t *lut, int &cmax, uint32_t &imax) {
+  constexpr uint32_t MASK = (1u << (2 * K)) - 1u;
+  const uint16_t *lk = lut + LutOff<K>::v;
+  const int nwin = active ? sg.len / K : 0;
+  cmax = 0;
+  imax = MASK;
+  uint64_t buf = 0;
+  int avail = 0, wi = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    if (wi < nwin) {
+      buf |= (uint64_t)sg.seq[w] << avail;
+      avail += 32;
+    }
+    while (avail >= 2 * K && wi < nwin) {
+      const uint32_t v = (uint32_t)buf & MASK;
+      buf >>= 2 * K;
+      avail -= 2 * K;
+      ++wi;
+      const uint32_t code = lk[v];
+      int newc;
+      if (K <= 4) {  // direct uint8 bins, 4 per dword
+        const uint32_t shift = (code & 3u) * 8u;
+        const uint32_t old = strl_lds_add(tab + (code >> 2) * STRL_LANES, 1u << shift);
+        newc = (int)((old >> shift) & 0xffu) + 1;
+      } else {  // open addressing, entry = (code+1) << 8 | count
+        uint32_t hsh = ((code * 0x9E3779B1u) >> 16) & (uint32_t)(SLOTS - 1);
+        for (;;) {
+          const uint32_t e = tab[hsh * STRL_LANES];
+          if (e == 0) { tab[hsh * STRL_LANES] = ((code + 1u) << 8) | 1u; newc = 1; break; }
+          if ((e >> 8) == code + 1u) { tab[hsh * STRL_LANES] = e + 1u; newc = (int)(e & 0xffu) + 1; break; }
+          hsh = (hsh + 1u) & (uint32_t)(SLOTS - 1);
+        }
+      }
+      if (newc > cmax) { cmax = newc; imax = code; }  // inc(): first code to reach the final maximum wins
+    }
+  }
+}
+
+// ---- greedy non-overlapping literal count of the decoded unit (strutils.count, utils.nim:254) ----
+template <int K, int NW> STRL_DEV int recount(const Seg<NW> &sg, uint32_t code) {
+  uint32_t acc[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) acc[w] = 0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const uint32_t pat = ((code >> (2 * (K - 1 - j))) & 3u) * 0x55555555u;  // unit base j replicated
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t lo = sg.seq[w], hi = (w + 1 < NW) ? sg.seq[w + 1] : 0u;
+      acc[w] |= strl_funnel_r(lo, hi, 2 * j) ^ pat;
+    }
+  }
+  if (sg.has_inv) {  // rare: a non-ACGT base inside the window kills the match
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const uint32_t lo = sg.inv[w], hi = (w + 1 < NW) ? sg.inv[w + 1] : 0u;
+        acc[w] |= strl_funnel_r(lo, hi, 2 * j);
+      }
+    }
+  }
+  const int limit = sg.len - K + 1;  // number of start positions
+  int cnt = 0, skip = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    uint32_t m = ~(acc[w] | (acc[w] >> 1)) & 0x55555555u;
+    const int nv = limit - 16 * w;
+    if (nv < 16) m &= (nv <= 0) ? 0u : ((1u << (2 * nv)) - 1u);
+    m &= ~((1u << (2 * skip)) - 1u);
+    skip = 0;
+    while (m) {
+      const int i = (strl_ffs(m) - 1) >> 1;
+      ++cnt;
+      const int nx = i + K;
+      if (nx >= 16) { skip = nx - 16; m = 0; }
+      else m &= ~((1u << (2 * nx)) - 1u);
+    }
+  }
+  return cnt;
+}
+
+// cooperative zeroing of `rows` rows ([row][lane] dwords) of this wave's table region
+STRL_DEV void clear_rows(uint32_t *wave_tab, int lane, int rows) {
+#ifdef STRL_EMU
+  for (int i = 0; i < rows; ++i) wave_tab[i] = 0;
+  (void)lane;
+#else
+  uint4 z = make_uint4(0, 0, 0, 0);
+  uint4 *p = reinterpret_cast<uint4 *>(wave_tab);
+  const int n16 = rows * (STRL_LANES / 4);  // 16-byte units
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < n16; i += STRL_LANES) p[i] = z;
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
+
+struct ScoreState {
+  int best;
+  bool alive;
+  uint32_t res0, res1;  // packed results for the two threshold rows
+};
+
+template <int K, int NW, int SLOTS>
+STRL_DEV void score_k(const Seg<NW> &sg, ScoreState &st, uint32_t *wave_tab, int lane, const uint16_t *lut,
+                      const uint16_t *thr, int row0, int row1) {
+  if (!strl_any(st.alive)) return;  // wave-uniform
+  constexpr int ROWS = (K == 2) ? 4 : (K == 3) ? 16 : (K == 4) ? 64 : SLOTS;
+  clear_rows(wave_tab, lane, ROWS);
+  int c;
+  uint32_t code;
+  hist_pass<K, NW, SLOTS>(sg, st.alive, wave_tab + lane, lut, c, code);
+  if (st.alive) {
+    int score = c * K;
+    const int L = sg.len;
+    if (score <= st.best) {  // utils.nim:250-253
+      if (c < (int)thr[0 * THR_ROW + (K - 2) * THR_LMAX + L]) st.alive = false;  // break
+    } else {
+      c = recount<K, NW>(sg, code);  // utils.nim:254
+      score = c * K;
+      if (score >= st.best) {  // :256
+        st.best = score;
+        const uint32_t packed = code | ((uint32_t)K << 12) | ((uint32_t)c << 16);
+        if (c > (int)thr[row0 * THR_ROW + (K - 2) * THR_LMAX + L]) st.res0 = packed;  // :259-263
+        if (c > (int)thr[row1 * THR_ROW + (K - 2) * THR_LMAX + L]) st.res1 = packed;
+      }
+    }
+  }
+}
+
+// reduce_repeat (utils.nim:220-233) + the final multiply (:271) on a packed result
+STRL_DEV uint32_t reduce_packed(uint32_t r) {
+  const uint32_t k = (r >> 12) & 7u;
+  if (k == 0) return 0;
+  const uint32_t code = r & 0xfffu, b = code & 3u;
+  const uint32_t rep = b * (((1u << (2 * k)) - 1u) / 3u);
+  if (code != rep) return r;
+  return b | (1u << 12) | (((r >> 16) * k) << 16);
+}
+
+// Whole ladder for one segment.  Wave-uniform call; `active` lanes own a segment.
+template <int NW, int SLOTS>
+STRL_DEV void score_segment(const Seg<NW> &sg, bool active, uint32_t *wave_tab, int lane, const uint16_t *lut,
+                            const uint16_t *thr, int row0, int row1, uint32_t &out0, uint32_t &out1) {
+  ScoreState st;
+  st.best = -1;
+  st.alive = active && sg.n_N <= 20;  // utils.nim:238
+  st.res0 = st.res1 = 0;
+  score_k<2, NW, SLOTS>(sg, st, wave_tab, lane, lut, thr, row0, row1);
+  score_k<3, NW, SLOTS>(sg, st, wave_tab, lane, lut, thr, row0, row1);
+  score_k<4, NW, SLOTS>(sg, st, wave_tab, lane, lut, thr, row0, row1);
+  score_k<5, NW, SLOTS>(sg, st, wave_tab, lane, lut, thr, row0, row1);
+  score_k<6, NW, SLOTS>(sg, st, wave_tab, lane, lut, thr, row0, row1);
+  out0 = reduce_packed(st.res0);
+  out1 = reduce_packed(st.res1);
+}
+
+}  // namespace strl

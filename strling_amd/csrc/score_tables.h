@@ -1,0 +1,43 @@
+// score_tables.h -- host-side builders of the two small device tables the scorer reads:
+// the window -> minimum-rotation code LUT (slide_by, utils.nim:10-34) and the integer thresholds
+// of the score ladder (utils.nim:251,259 with the float64 expressions of the reference).
+#pragma once
+#include <algorithm>
+#include <vector>
+#include "score_core.h"
+#include "../../include/strling_amd.h"
+
+namespace strl {
+
+inline void build_lut(std::vector<uint16_t> &lut) {
+  lut.assign(LUT_ENTRIES, 0);
+  const int off[7] = {0, 0, LUT_OFF2, LUT_OFF3, LUT_OFF4, LUT_OFF5, LUT_OFF6};
+  for (int k = 2; k <= 6; ++k) {
+    const uint32_t mask = (1u << (2 * k)) - 1u;
+    for (uint32_t v = 0; v <= mask; ++v) {
+      uint32_t c = 0;  // reference orientation: first base in the high bits
+      for (int j = 0; j < k; ++j) c |= ((v >> (2 * j)) & 3u) << (2 * (k - 1 - j));
+      uint32_t best = c, f = c;
+      for (int j = 0; j < k; ++j) {  // slide_by: rotate, keep the minimum (utils.nim:17-20)
+        f = ((f << 2) | (f >> (2 * (k - 1)))) & mask;
+        best = std::min(best, f);
+      }
+      lut[off[k] + v] = (uint16_t)best;
+    }
+  }
+}
+
+inline void build_thr(const strl_opts &o, std::vector<uint16_t> &thr) {
+  thr.assign(4 * THR_ROW, 0);
+  const double p = o.proportion_repeat;
+  const double ps[4] = {0.12, p, p - 0.07, std::min(p, 0.6)};  // utils.nim:251,259; extract.nim:242,208
+  for (int row = 0; row < 4; ++row)
+    for (int k = 2; k <= 6; ++k)
+      for (int L = 0; L < THR_LMAX; ++L) {
+        int v = (int)((double)L * ps[row] / (double)k);
+        thr[row * THR_ROW + (k - 2) * THR_LMAX + L] = (uint16_t)std::max(0, std::min(v, 65535));
+      }
+}
+
+
+}  // namespace strl

@@ -1,0 +1,246 @@
+"""Synthetic inputs: S1 = 30x 150 bp paired-end WGS-like record batches with the
+read-class mix the extract hot path sees, S2 = multi-sample tread sets for the clustering path.
+All randomness comes from numpy's counter-based Philox generator, so the CPU oracle and the GPU
+path regenerate identical inputs from (seed, sizes).  No reference code or data is involved.
+"""
+import numpy as np
+
+from .records import RecordBatch, GenomeStr, pack_codes4, CIGAR_OPS
+
+NIB = {"A": 1, "C": 2, "G": 4, "T": 8, "N": 15}
+_ACGT_NIB = np.array([1, 2, 4, 8], np.uint8)
+OP = {c: i for i, c in enumerate(CIGAR_OPS)}
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.Philox(seed))
+
+
+def synth_genome_str(rng, n_contigs, contig_len, overlap_frac=0.03, read_len=150):
+    """Reference STR intervals (what `strling index` writes to ref.fasta.str): lengths 30-300 bp, density
+    chosen so that ~overlap_frac of 150 bp reads overlap one."""
+    mean_len = 165.0
+    dens = overlap_frac / (read_len + mean_len)
+    per = int(contig_len * dens)
+    ivs = {}
+    for t in range(n_contigs):
+        st = np.sort(rng.integers(0, contig_len - 400, size=per))
+        ln = rng.integers(30, 301, size=per)
+        ivs[t] = list(zip(st.tolist(), (st + ln).tolist()))
+    return GenomeStr.from_lists(n_contigs, ivs)
+
+
+def synth_wgs(n_pairs, seed=1234, read_len=150, n_contigs=25, contig_len=10_000_000, str_frac=0.01, soft_frac=0.03,
+              indel_frac=0.01, unmapped_frac=0.005, interchrom_frac=0.01, genome_overlap=0.03, with_qnames=True):
+    """-> (RecordBatch sorted like a coordinate-sorted BAM with the unmapped tail last, GenomeStr)."""
+    rng = _rng(seed)
+    L = read_len
+    n = 2 * n_pairs
+    g = synth_genome_str(rng, n_contigs, contig_len, genome_overlap, L)
+    # ---- pair placement ----
+    tid1 = rng.integers(0, n_contigs, size=n_pairs).astype(np.int32)
+    frag = np.clip(np.rint(rng.normal(350, 120, size=n_pairs)), L, 4095).astype(np.int32)
+    pos1 = rng.integers(0, contig_len - 5000, size=n_pairs).astype(np.int32)
+    pos2 = pos1 + frag - L
+    tid2 = tid1.copy()
+    u = rng.random(n_pairs)
+    inter = u < interchrom_frac
+    tid2[inter] = (tid1[inter] + 1 + rng.integers(0, n_contigs - 1, size=int(inter.sum()))) % n_contigs
+    pos2[inter] = rng.integers(0, contig_len - 5000, size=int(inter.sum()))
+    unm = (u >= interchrom_frac) & (u < interchrom_frac + unmapped_frac)
+    proper = ~inter & ~unm & (rng.random(n_pairs) < 0.99)
+    # per read arrays, read 2i = first in pair, 2i+1 = second
+    tid = np.empty(n, np.int32); pos = np.empty(n, np.int32)
+    tid[0::2], tid[1::2] = tid1, tid2
+    pos[0::2], pos[1::2] = pos1, pos2
+    isize = np.zeros(n, np.int32)
+    isize[0::2] = np.where(proper, frag, 0)
+    isize[1::2] = np.where(proper, -frag, 0)
+    flag = np.empty(n, np.uint16)
+    flag[0::2] = 0x1 | 0x40 | 0x20 | np.where(proper, 0x2, 0)
+    flag[1::2] = 0x1 | 0x80 | 0x10 | np.where(proper, 0x2, 0)
+    um = np.repeat(unm, 2)
+    mq_u = rng.random(n)
+    mapq = np.where(mq_u < 0.90, 60, np.where(mq_u < 0.95, 0, rng.integers(1, 60, size=n))).astype(np.uint8)
+    # ---- read classes ----
+    cls_u = rng.random(n)
+    is_str = cls_u < str_frac
+    is_str |= np.repeat(unm & (rng.random(n_pairs) < 0.3), 2)   # both-unmapped STR pairs (the tail extract visits twice)
+    is_soft = (cls_u >= str_frac) & (cls_u < str_frac + soft_frac) & ~um
+    is_indel = (cls_u >= str_frac + soft_frac) & (cls_u < str_frac + soft_frac + indel_frac) & ~um
+    # STR-rich reads as an aligner leaves them: 40% sit on a reference STR (so the skip predicate keeps them),
+    # 30% are partly soft-clipped, 30% are unmapped but placed at their mate (flag 0x4, no cigar).
+    sub = rng.random(n)
+    str_on_ref = is_str & ~um & (sub < 0.4)
+    str_clip = is_str & ~um & (sub >= 0.4) & (sub < 0.7)
+    str_unmapped = is_str & ~um & (sub >= 0.7)
+    partner = np.arange(n) ^ 1
+    str_unmapped &= ~str_unmapped[partner] | (np.arange(n) % 2 == 0)   # at most one mate of a pair is placed-unmapped
+    str_unmapped &= ~(str_unmapped[partner] & (np.arange(n) % 2 == 1))
+    r_idx = np.nonzero(str_on_ref)[0]
+    if r_idx.size:
+        t_ = tid[r_idx]
+        lo, hi = g.iv_off[t_], g.iv_off[t_ + 1]
+        j = lo + (rng.random(r_idx.size) * (hi - lo)).astype(np.int64)
+        pos[r_idx] = np.maximum(0, g.iv_start[j] - rng.integers(0, 100, size=r_idx.size)).astype(np.int32)
+    is_soft |= str_clip
+    u_idx = np.nonzero(str_unmapped)[0]
+    tid[u_idx] = tid[partner[u_idx]]
+    pos[u_idx] = pos[partner[u_idx]]
+    flag[u_idx] = (flag[u_idx] & ~np.uint16(0x2)) | 0x4
+    flag[partner[u_idx]] = (flag[partner[u_idx]] & ~np.uint16(0x2)) | 0x8
+    mapq[u_idx] = 0
+    nocig = um | str_unmapped
+    tid[um] = -1; pos[um] = -1
+    flag[um] = (flag[um] & ~np.uint16(0x32)) | 0x4 | 0x8
+    mapq[um] = 0
+    mtid = tid[partner].copy()
+    mpos = pos[partner].copy()
+    # ---- sequences (nibble codes) ----
+    codes = _ACGT_NIB[rng.integers(0, 4, size=(n, L))]
+    idx = np.nonzero(is_str)[0]
+    if idx.size:
+        k = rng.integers(1, 7, size=idx.size)
+        unit = _ACGT_NIB[rng.integers(0, 4, size=(idx.size, 6))]
+        phase = rng.integers(0, 6, size=idx.size)
+        j = (np.arange(L)[None, :] + phase[:, None]) % k[:, None]
+        rep = np.take_along_axis(unit, j, axis=1)
+        purity = rng.choice(np.array([1.0, 0.97, 0.93, 0.9, 0.85]), size=idx.size)
+        keep = rng.random((idx.size, L)) < purity[:, None]
+        codes[idx] = np.where(keep, rep, codes[idx])
+    # soft clips: clip length 1-100 on one end (10% both); 40% of clipped tails are repeats
+    clip_l = np.zeros(n, np.int32); clip_r = np.zeros(n, np.int32)
+    sidx = np.nonzero(is_soft)[0]
+    if sidx.size:
+        both = rng.random(sidx.size) < 0.10
+        left = rng.random(sidx.size) < 0.5
+        cl = rng.integers(1, 101, size=sidx.size)
+        cr = rng.integers(1, min(101, L - 100), size=sidx.size)
+        clip_l[sidx] = np.where(both | left, cl, 0)
+        clip_r[sidx] = np.where(both | ~left, np.where(both, cr, cl), 0)
+        rep_tail = rng.random(sidx.size) < 0.4
+        k = rng.integers(2, 7, size=sidx.size)
+        unit = _ACGT_NIB[rng.integers(0, 4, size=(sidx.size, 6))]
+        j = np.arange(L)[None, :] % k[:, None]
+        rep = np.take_along_axis(unit, j, axis=1)
+        col = np.arange(L)[None, :]
+        in_clip = (col < clip_l[sidx][:, None]) | (col >= (L - clip_r[sidx])[:, None])
+        codes[sidx] = np.where(in_clip & rep_tail[:, None], rep, codes[sidx])
+        mapq[sidx] = np.where(rng.random(sidx.size) < 0.8, 60, mapq[sidx])
+    # N bases: 0.1% of bases, and 0.2% of reads with > 20 N
+    nmask = rng.random((n, L)) < 0.001
+    many = np.nonzero(rng.random(n) < 0.002)[0]
+    if many.size:
+        nmask[many[:, None], rng.integers(0, L, size=(many.size, 40))] = True
+    codes[nmask] = 15
+    l_seq = np.full(n, L, np.int32)
+    # ---- cigars ----
+    ncig = np.ones(n, np.int64)
+    ncig[nocig] = 0
+    ncig[is_soft] = 1 + (clip_l[is_soft] > 0) + (clip_r[is_soft] > 0)
+    ncig[is_indel] = 3
+    cig_off = np.zeros(n + 1, np.uint32)
+    cig_off[1:] = np.cumsum(ncig)
+    cigar = np.zeros(int(cig_off[-1]), np.uint32)
+    is_soft &= ~nocig
+    is_indel &= ~nocig & ~is_soft
+    plain = ~nocig & ~is_soft & ~is_indel
+    cigar[cig_off[:-1][plain]] = (L << 4) | OP["M"]
+    ii = np.nonzero(is_indel)[0]
+    if ii.size:
+        ins = rng.random(ii.size) < 0.5
+        a = rng.integers(20, L - 40, size=ii.size)
+        d = rng.integers(1, 6, size=ii.size)
+        o = cig_off[:-1][ii]
+        cigar[o] = (a << 4) | OP["M"]
+        cigar[o + 1] = (d << 4) | np.where(ins, OP["I"], OP["D"])
+        cigar[o + 2] = ((L - a - np.where(ins, d, 0)) << 4) | OP["M"]
+    if sidx.size:
+        o = cig_off[:-1][sidx].astype(np.int64)
+        hasl = clip_l[sidx] > 0
+        cigar[o[hasl]] = (clip_l[sidx][hasl] << 4) | OP["S"]
+        o2 = o + hasl
+        cigar[o2] = ((L - clip_l[sidx] - clip_r[sidx]) << 4) | OP["M"]
+        hasr = clip_r[sidx] > 0
+        cigar[(o2 + 1)[hasr]] = (clip_r[sidx][hasr] << 4) | OP["S"]
+    # ---- coordinate sort (unmapped last), keep mate order for equal keys ----
+    key = np.where(tid < 0, np.int64(1) << 40, tid.astype(np.int64) << 32) + np.maximum(pos, 0).astype(np.int64)
+    order = np.argsort(key, kind="stable")
+    pair_id = (np.arange(n) // 2)[order]
+    new_off = np.zeros(n + 1, np.uint32)
+    new_off[1:] = np.cumsum(ncig[order])
+    src = np.repeat(cig_off[:-1][order].astype(np.int64), ncig[order]) + (np.arange(int(new_off[-1])) - np.repeat(new_off[:-1].astype(np.int64), ncig[order]))
+    cigar = cigar[src]
+    seq4, seq_off = pack_codes4(codes[order], l_seq[order])
+    if with_qnames:
+        names = np.char.add("q", pair_id.astype(str)).astype("S")
+        qlen = np.char.str_len(names)
+        qoff = np.zeros(n + 1, np.uint64)
+        qoff[1:] = np.cumsum(qlen)
+        qnames = b"".join(names.tolist())
+    else:
+        qoff = np.zeros(n + 1, np.uint64)
+        qnames = b""
+    rec = RecordBatch(tid[order], pos[order], mtid[order], mpos[order], flag[order], mapq[order], new_off, cigar, seq_off,
+                      l_seq[order], seq4, qoff, qnames, isize[order],
+                      [(f"chr{i + 1}", contig_len) for i in range(n_contigs)])
+    return rec, g
+
+
+def frag_hist(rec):
+    """utils.fragment_length_distribution (utils.nim:86-111) on an in-memory batch, without the 100k-record
+    skip (the batch IS the sample): histogram of isize in [0, 4095] over proper-pair primary records."""
+    f = rec.flag
+    ok = ((f & 0x2) != 0) & ((f & 0x900) == 0) & (rec.isize >= 0) & (rec.isize <= 4095)
+    return np.bincount(rec.isize[ok], minlength=4096).astype(np.uint32)
+
+
+def synth_treads(n_samples=4, n_loci=400, seed=1000, n_contigs=25, contig_len=10_000_000, background=0.3, dtype=None):
+    """S2: per sample every locus present w.p. 0.3 with 5-60 reads: anchors (Soft.none) within +-400 bp, left/right
+    clips at the locus boundary +-{0,1}; plus background singletons.  Returns one structured array in
+    "sample order then .bin order" with qname_id = sample index (merge.nim:118-125)."""
+    from .api import TREAD_DTYPE
+    dtype = dtype or TREAD_DTYPE
+    rng = _rng(seed)
+    units = []
+    bases = "ACGT"
+    while len(units) < 60:
+        k = int(rng.integers(1, 7))
+        u = "".join(bases[int(b)] for b in rng.integers(0, 4, size=k))
+        units.append(u)
+    zipf = 1.0 / np.arange(1, len(units) + 1)
+    zipf /= zipf.sum()
+    loc_tid = rng.integers(0, n_contigs, size=n_loci)
+    loc_pos = rng.integers(1000, contig_len - 1000, size=n_loci)
+    loc_len = rng.integers(0, 120, size=n_loci)
+    loc_unit = rng.choice(len(units), size=n_loci, p=zipf)
+    out = []
+    for s in range(n_samples):
+        present = rng.random(n_loci) < 0.3
+        rows = []
+        for li in np.nonzero(present)[0]:
+            nr = int(rng.integers(5, 61))
+            kind = rng.random(nr)
+            left_b, right_b = int(loc_pos[li]), int(loc_pos[li] + loc_len[li])
+            for kd in kind:
+                if kd < 0.5:
+                    rows.append((loc_tid[li], max(0, left_b + int(rng.integers(-400, 401))), loc_unit[li], 3))
+                elif kd < 0.75:   # right-clipped reads end at the left boundary of the repeat
+                    rows.append((loc_tid[li], left_b + int(rng.integers(0, 2)), loc_unit[li], 1))
+                else:             # left-clipped reads start at its right boundary
+                    rows.append((loc_tid[li], right_b + int(rng.integers(0, 2)), loc_unit[li], 0))
+        nb = int(len(rows) * background)
+        for _ in range(nb):
+            rows.append((int(rng.integers(0, n_contigs)), int(rng.integers(0, contig_len)), int(rng.choice(len(units), p=zipf)),
+                         int(rng.choice([0, 1, 3, 3]))))
+        perm = rng.permutation(len(rows))
+        t = np.zeros(len(rows), dtype)
+        for j, pi in enumerate(perm):
+            r = rows[pi]
+            t[j]["tid"] = r[0]; t[j]["position"] = r[1]; t[j]["repeat"] = units[r[2]].encode(); t[j]["split"] = r[3]
+        t["qname_id"] = s
+        t["mapping_quality"] = 60
+        t["repeat_count"] = 40
+        t["align_length"] = 150
+        out.append(t)
+    return np.concatenate(out)

@@ -1,0 +1,41 @@
+// score_emu.cpp -- TEST-ONLY host build of the device scorer (strling_amd/csrc/score_core.h with
+// STRL_EMU: one lane, "LDS" in a plain array).  It lets the CPU test-suite exercise the exact
+// device logic (bit packing, LUT, tie rule, bit-parallel recount, threshold ladder) against the
+// oracle without a GPU.  The product never links this file.
+#define STRL_EMU 1
+#include "../../strling_amd/csrc/score_core.h"
+#include "../../strling_amd/csrc/score_tables.h"
+#include <string.h>
+
+using namespace strl;
+
+static std::vector<uint16_t> g_lut, g_thr;
+
+template <int NW, int SLOTS>
+static void run(const uint8_t *seq4, int s0, int len, int row0, int row1, uint32_t *o0, uint32_t *o1) {
+  static uint32_t tab[SLOTS + 8];
+  constexpr int MAXCH = (16 * NW + 62) / 32;
+  const int s0l = s0 & 31;
+  const int nch = (s0l + len + 31) >> 5;
+  const uint8_t *src = seq4 + (size_t)(s0 >> 5) * 16;
+  for (int c = 0; c < MAXCH && c < nch; ++c) memcpy(&tab[4 * c], src + 16 * c, 16);
+  Seg<NW> sg;
+  seg_from_raw<NW>(tab, s0l, len, sg);
+  score_segment<NW, SLOTS>(sg, true, tab, 0, g_lut.data(), g_thr.data(), row0, row1, *o0, *o1);
+}
+
+extern "C" {
+void emu_set_p(double p) {
+  strl_opts o{};
+  o.proportion_repeat = p;
+  build_lut(g_lut);
+  build_thr(o, g_thr);
+}
+// mode 0: whole read (threshold p); mode 1: soft clip (p-0.07 / min(p,0.6)).  seq4 must have 32 B slack.
+void emu_score(const uint8_t *seq4, int s0, int len, int mode, int klass, uint32_t *o0, uint32_t *o1) {
+  const int r0 = mode == 0 ? 1 : 2, r1 = mode == 0 ? 1 : 3;
+  if (klass == 0) run<10, 64>(seq4, s0, len, r0, r1, o0, o1);
+  else if (klass == 1) run<16, 128>(seq4, s0, len, r0, r1, o0, o1);
+  else run<32, 256>(seq4, s0, len, r0, r1, o0, o1);
+}
+}

@@ -1,0 +1,59 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import numpy as np
+
+CODE = {"C": 0, "A": 1, "T": 2, "G": 3}
+
+
+def pack_word(unit, count, skipped=False):
+    """(unit str, count) -> packed scorer word of include/strling_amd.h"""
+    if isinstance(unit, bytes):
+        unit = unit.decode()
+    k = len(unit)
+    code = 0
+    for ch in unit:
+        code = (code << 2) | CODE[ch]
+    return (code | (k << 12) | (int(count) << 16) | (0x8000 if skipped else 0)) & 0xFFFFFFFF
+
+
+def oracle_words(O, rec, g, opts):
+    """Oracle scorer outputs in the packed layout the device produces: (whole u32[n], dict (read,side)->(first,after))."""
+    sk, wu, wc, su, sc = O.score_records_packed(rec, g, opts)
+    whole = np.array([pack_word(wu[i], wc[i], sk[i]) for i in range(rec.n)], dtype=np.uint32)
+    soft = {}
+    for i in range(rec.n):
+        for side in (0, 1):
+            soft[(i, side)] = (pack_word(su[i, 2 * side], sc[i, 2 * side]), pack_word(su[i, 2 * side + 1], sc[i, 2 * side + 1]))
+    return whole, soft
+
+
+def soft_items_expected(rec, whole, min_mapq):
+    """Which (read, side) items add_soft would look at (extract.nim:97-106), given the whole-read words."""
+    items = []
+    for i in range(rec.n):
+        a, b = int(rec.cigar_off[i]), int(rec.cigar_off[i + 1])
+        L = b - a
+        if L == 0 or rec.mapq[i] < min_mapq or (whole[i] & 0x8000):
+            continue
+        first_s = (int(rec.cigar[a]) & 0xF) == 4
+        last_s = (int(rec.cigar[b - 1]) & 0xF) == 4
+        has_unit = ((int(whole[i]) >> 12) & 7) != 0
+        if first_s and (has_unit or (int(rec.cigar[a]) >> 4) > 16):
+            items.append((i, 0))
+        if last_s and L > 1 and (has_unit or (int(rec.cigar[b - 1]) >> 4) > 16):
+            items.append((i, 1))
+    return items
+
+
+def treads_equal(a, b, fields=("tid", "position", "repeat", "flag", "split", "mapping_quality", "repeat_count", "align_length",
+                               "qname_id")):
+    if len(a) != len(b):
+        return False, f"length {len(a)} != {len(b)}"
+    for f in fields:
+        if not np.array_equal(np.asarray(a[f]), np.asarray(b[f])):
+            bad = np.nonzero(np.asarray(a[f]) != np.asarray(b[f]))[0][:5]
+            return False, f"field {f} differs at {bad.tolist()}: {a[f][bad].tolist()} vs {b[f][bad].tolist()}"
+    return True, ""
+
+
+def bounds_rows(bounds, targets, row_fn):
+    return [row_fn(b, targets[int(b["tid"])][0]) for b in bounds]

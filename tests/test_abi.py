@@ -1,0 +1,159 @@
+"""C-ABI library: loads, exports every symbol include/strling_amd.h declares, fails loudly without
+a device, and its host-only entry points (SoA derivation, pair logic, .bin, bounds rows, fragment
+statistics) agree with the oracle.  CPU only -- no compute kernels are launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from strling_amd import api, synth
+from strling_amd.records import RecordBatch
+from helpers import oracle_words, soft_items_expected, treads_equal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_every_declared_symbol():
+    L = api.load()
+    hdr = open(os.path.join(ROOT, "include", "strling_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(strl_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/strling_amd.h but not exported"
+    assert sorted(api.EXPORTS) == declared
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = api.load()
+    h = C.c_void_p()
+    rc = L.strl_ctx_create(0, C.byref(h))
+    assert rc == -1 and not h.value
+    assert b"no CPU fallback" in L.strl_last_error()
+    with pytest.raises(api.StrlingError):
+        api.Context(0)
+
+
+@pytest.fixture(scope="module")
+def batch():
+    rec, g = synth.synth_wgs(6000, seed=99, contig_len=1_000_000)
+    return rec, g
+
+
+def test_soa_from_records(batch, oracle):
+    rec, g = batch
+    soa = api.Soa(rec)
+    assert soa.max_l_seq == 150
+    for i in range(0, rec.n, 37):
+        a, b = int(rec.cigar_off[i]), int(rec.cigar_off[i + 1])
+        ops = [(int(c) & 15, int(c) >> 4) for c in rec.cigar[a:b]]
+        ref_len = sum(l for o, l in ops if o in (0, 2, 3, 7, 8)) if not (rec.flag[i] & 4) else 0
+        assert soa.end[i] == rec.pos[i] + (ref_len or 1)
+        assert soa.clip_l[i] == (ops[0][1] if ops and ops[0][0] == 4 else 0)
+        assert soa.clip_r[i] == (ops[-1][1] if ops and ops[-1][0] == 4 else 0)
+        assert bool(soa.cig[i] & 1) == (len(ops) == 1 and ops[0][0] == 0)
+        assert bool(soa.cig[i] & 16) == (len(ops) == 0)
+        assert soa.seq_off[i] * 16 == rec.seq_off[i]
+
+
+@pytest.mark.parametrize("p,q", [(0.8, 40), (0.6, 20)])
+def test_pair_logic_matches_oracle(batch, oracle, p, q):
+    """strl_pair_reads (host state machine of extract.nim:192-248) fed with scorer words == oracle extract."""
+    rec, g = batch
+    med = oracle.median(synth.frag_hist(rec))
+    opts = oracle.make_opts(med, p, q)
+    whole, softd = oracle_words(oracle, rec, g, opts)
+    items = soft_items_expected(rec, whole, q)
+    soft = np.zeros(len(items), api.SOFT_DTYPE)
+    for j, (i, side) in enumerate(items):
+        soft[j] = ((i << 1) | side, softd[(i, side)][0], softd[(i, side)][1], 0)
+    exp = oracle.extract(rec, g, opts)
+    L = api.load()
+    rv = api._RecView(rec)
+    o = api.Opts(med, p, q)
+    out = np.zeros(len(exp) + 16, api.TREAD_DTYPE)
+    no = C.c_uint64(0)
+    rc = L.strl_pair_reads(C.byref(rv.c), C.byref(o), whole.ctypes.data, soft.ctypes.data, soft.size, -1, out.ctypes.data, out.size,
+                           C.byref(no))
+    assert rc == 0, L.strl_last_error()
+    assert len(exp) > 100
+    ok, why = treads_equal(out[:no.value], exp)
+    assert ok, why
+
+
+def test_unmapped_tail_is_replayed(oracle):
+    """extract.nim:308 reads to EOF (tail included) and :326 query("*") visits the tail again: a both-STR
+    unmapped pair is emitted twice."""
+    seq = "CAG" * 50
+    rec = RecordBatch.from_fields(tid=[-1, -1], pos=[-1, -1], mtid=[-1, -1], mpos=[-1, -1], flag=[77, 141], mapq=[0, 0],
+                                  cigars=["*", "*"], seqs=[seq, seq], qnames=["x", "x"])
+    opts = oracle.make_opts(350, 0.8, 40)
+    t = oracle.extract(rec, None, opts)
+    assert len(t) == 4 and set(t["tid"]) == {-1}
+    assert set(t["repeat"]) == {oracle.canonical_repeat(oracle.get_repeat(seq, 0.8)[0]).encode()}
+
+
+def test_frag_median(oracle):
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        f = rng.integers(0, 50, 4096).astype(np.uint32)
+        f[rng.integers(0, 4096, 300)] += rng.integers(0, 10000, 300).astype(np.uint32)
+        for pct in (0.5, 0.1, 0.9, 0.98, 0.99):
+            assert api.frag_median(f, pct) == oracle.median(f, pct)
+
+
+def test_bin_roundtrip_and_bytes(tmp_path, batch, oracle):
+    import msgpack
+    rec, g = batch
+    opts = oracle.make_opts(350, 0.8, 40)
+    exp = oracle.extract(rec, g, opts)
+    frag = synth.frag_hist(rec)
+    hdr = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in rec.targets)
+    t = np.zeros(len(exp), api.TREAD_DTYPE)
+    for f in t.dtype.names:
+        t[f] = exp[f]
+    path = str(tmp_path / "s.bin")
+    api.bin_write(path, 0.8, 40, frag, hdr, t, rec.qname_off, rec.qnames)
+    raw = open(path, "rb").read()
+    assert raw == oracle.bin_write(0.8, 40, frag, hdr, exp, rec.qname_off, rec.qnames)      # byte-identical writers
+    # header layout of extract.nim:336-344
+    assert raw[:3] == b"STR" and raw[3:5] == b"\0\0" and raw[5:14] == b"0.6.0\0\0\0\0"
+    assert np.frombuffer(raw[14:18], "<f4")[0] == np.float32(0.8) and raw[18] == 40
+    o = 19 + 4096 * 4
+    hl = int(np.frombuffer(raw[o:o + 4], "<i4")[0])
+    assert raw[o + 4:o + 4 + hl].decode() == hdr
+    n = int(np.frombuffer(raw[o + 4 + hl:o + 8 + hl], "<i4")[0])
+    assert n == len(exp)
+    # the records are plain msgpack values in pack_type order (cluster.nim:38-50)
+    up = msgpack.Unpacker(raw=True)
+    up.feed(raw[o + 8 + hl:])
+    vals = list(up)
+    assert len(vals) == 10 * n
+    for i in (0, n // 2, n - 1):
+        v = vals[10 * i:10 * i + 10]
+        assert v[0] == exp["tid"][i] and v[1] == exp["position"][i] and bytes(v[2]).rstrip(b"\0") == exp["repeat"][i]
+        assert v[3] == exp["flag"][i] and v[4] == exp["split"][i] and v[8] == len(v[9]) and v[9] == rec.qname(int(exp["qname_id"][i]))
+    back = api.bin_read(path)
+    assert back["header"] == hdr and back["min_mapq"] == 40 and np.array_equal(back["frag"], frag)
+    ok, why = treads_equal(back["treads"], t, fields=("tid", "position", "repeat", "flag", "split", "mapping_quality", "repeat_count",
+                                                      "align_length"))
+    assert ok, why
+    qn = [back["qnames"][int(back["qname_off"][i]):int(back["qname_off"][i + 1])] for i in range(n)]
+    assert qn == [rec.qname(int(i)) for i in exp["qname_id"]]
+
+
+def test_bounds_row(oracle):
+    b = np.zeros(1, api.BOUNDS_DTYPE)
+    b["tid"], b["left"], b["right"], b["left_most"], b["right_most"], b["center_mass"] = 0, 990, 1010, 500, 1500, 1000
+    b["n_left"], b["n_right"], b["n_total"], b["repeat"] = 3, 1, 50, b"CAG"
+    row = api.bounds_row(b[0], "chr1")
+    assert row == "chr1\t990\t1010\tCAG\t\t500\t1500\t1000\t3\t1\t50"      # tests/test_cluster.nim:171 line layout
+    ob = np.zeros(1, oracle.BOUNDS_DTYPE)
+    for f in b.dtype.names:
+        ob[f] = b[f]
+    assert oracle.bounds_row(ob[0], "chr1") == row
+    assert len(row.split("\t")) == 11                                    # parse_boundsline requires 11 fields (cluster.nim:146)

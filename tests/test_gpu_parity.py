@@ -1,0 +1,201 @@
+"""Parity of the HIP path against the oracle, through the C ABI.  Needs a real MI355X (-m gpu)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from strling_amd import api, synth
+from strling_amd.records import RecordBatch, unpack_result
+from helpers import oracle_words, soft_items_expected, treads_equal
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = json.load(open(os.path.join(HERE, "golden", "reference_kats.json")))
+
+
+def _as_api_treads(t):
+    out = np.zeros(len(t), api.TREAD_DTYPE)
+    for f in out.dtype.names:
+        out[f] = t[f]
+    return out
+
+
+def test_native_library_is_loaded(ctx):
+    maps = open("/proc/self/maps").read()
+    assert "libstrling_amd.so" in maps
+
+
+@pytest.mark.parametrize("k", KATS["get_repeat"], ids=lambda k: k["source"])
+def test_reference_kats_through_the_kernels(ctx, k):
+    rec = RecordBatch.from_sam(k["sam_header"], [k["sam"]])
+    ctx.set_opts(k["proportion_repeat"], k["min_mapq"], 500)
+    ctx.set_genome(None)
+    whole, soft, st = ctx.score_reads(rec)
+    unit, count, skipped = unpack_result(whole[0])
+    assert (unit, count, skipped) == (k["expect_unit"], k["expect_count"], False)
+
+
+@pytest.mark.parametrize("n_pairs,seed,p,q", [(30000, 1234, 0.8, 40), (8000, 7, 0.6, 20), (8000, 11, 0.9, 0)])
+def test_score_reads_matches_oracle(ctx, oracle, n_pairs, seed, p, q):
+    rec, g = synth.synth_wgs(n_pairs, seed=seed, contig_len=3_000_000)
+    opts = oracle.make_opts(350, p, q)
+    ctx.set_opts(p, q, 350)
+    ctx.set_genome(g)
+    whole, soft, st = ctx.score_reads(rec)
+    exp_whole, exp_soft = oracle_words(oracle, rec, g, opts)
+    assert np.array_equal(whole, exp_whole), np.nonzero(whole != exp_whole)[0][:10]
+    items = soft_items_expected(rec, exp_whole, q)
+    assert soft["read_side"].tolist() == [(i << 1) | s for i, s in items]
+    assert soft["res_first"].tolist() == [exp_soft[it][0] for it in items]
+    assert soft["res_after"].tolist() == [exp_soft[it][1] for it in items]
+    assert st.n_reads == rec.n and st.n_skipped == int(((exp_whole & 0x8000) != 0).sum())
+    assert st.n_scored + st.n_skipped == rec.n
+
+
+def test_ragged_lengths_and_edge_cases(ctx, oracle):
+    rng = np.random.default_rng(5)
+    seqs, cig = [], []
+    for L in [0, 1, 2, 3, 5, 6, 7, 15, 16, 17, 31, 32, 33, 64, 100, 149, 150, 151, 160, 161, 200, 250, 255, 256, 257, 300, 400, 510]:
+        for kind in range(4):
+            if kind == 0:
+                s = "".join(rng.choice(list("ACGT"), L))
+            elif kind == 1:
+                u = "".join(rng.choice(list("ACGT"), int(rng.integers(1, 7))))
+                s = (u * (L + 6))[:L]
+            elif kind == 2:
+                s = "".join(rng.choice(list("ACGTN"), L))
+            else:
+                s = "N" * L
+            seqs.append(s)
+            if L >= 40 and kind < 2:
+                c = int(rng.integers(1, L // 2))
+                cig.append(f"{c}S{L - c}M" if rng.random() < 0.5 else f"{L - c}M{c}S")
+            elif L > 0:
+                cig.append(f"{L}M")
+            else:
+                cig.append("*")
+    n = len(seqs)
+    rec = RecordBatch.from_fields(tid=[0] * n, pos=list(range(100, 100 + n)), mtid=[0] * n, mpos=[5] * n, flag=[99] * n,
+                                  mapq=[60] * n, cigars=cig, seqs=seqs, qnames=[f"r{i}" for i in range(n)])
+    opts = oracle.make_opts(350, 0.8, 40)
+    ctx.set_opts(0.8, 40, 350)
+    ctx.set_genome(None)
+    whole, soft, st = ctx.score_reads(rec)
+    exp_whole, exp_soft = oracle_words(oracle, rec, None, opts)
+    assert np.array_equal(whole, exp_whole), [(seqs[i], unpack_result(whole[i]), unpack_result(exp_whole[i])) for i in np.nonzero(whole != exp_whole)[0][:5]]
+    items = soft_items_expected(rec, exp_whole, 40)
+    assert soft["read_side"].tolist() == [(i << 1) | s for i, s in items]
+    assert soft["res_first"].tolist() == [exp_soft[it][0] for it in items]
+    assert soft["res_after"].tolist() == [exp_soft[it][1] for it in items]
+
+
+def test_empty_batch(ctx):
+    rec = RecordBatch.from_fields([], [], [], [], [], [], [], [], [])
+    ctx.set_opts(0.8, 40, 350)
+    whole, soft, st = ctx.score_reads(rec)
+    assert whole.size == 0 and soft.size == 0 and st.n_reads == 0
+    b, u, cs = ctx.cluster(np.zeros(0, api.TREAD_DTYPE), api.MODE_MERGE, 500)
+    assert b.size == 0
+
+
+def test_read_longer_than_limit_is_refused(ctx):
+    rec = RecordBatch.from_fields([0], [1], [0], [1], [99], [60], ["600M"], ["A" * 600], ["x"])
+    with pytest.raises(api.StrlingError):
+        ctx.score_reads(rec)
+
+
+@pytest.mark.parametrize("n_pairs,seed,p,q", [(30000, 4321, 0.8, 40), (10000, 3, 0.7, 30)])
+def test_extract_matches_oracle(ctx, oracle, n_pairs, seed, p, q):
+    """tread records identical to the oracle's extract (extract.nim:308-329), same order."""
+    rec, g = synth.synth_wgs(n_pairs, seed=seed, contig_len=3_000_000)
+    med = oracle.median(synth.frag_hist(rec))
+    ctx.set_opts(p, q, med)
+    ctx.set_genome(g)
+    got, st = ctx.extract(rec)
+    exp = oracle.extract(rec, g, oracle.make_opts(med, p, q))
+    assert len(exp) > 300
+    ok, why = treads_equal(got, exp)
+    assert ok, why
+
+
+@pytest.mark.parametrize("k", KATS["cluster"], ids=lambda k: k["source"])
+def test_cluster_kats_through_the_kernels(ctx, oracle, k):
+    t = np.zeros(len(k["positions"]), api.TREAD_DTYPE)
+    t["tid"] = k["tid"]
+    t["repeat"] = k["repeat"].encode() or b"A"
+    t["position"] = k["positions"]
+    t["split"] = k["splits"]
+    b, u, st = ctx.cluster(t, api.MODE_CALL, k["max_dist"], min_support=k["min_supporting_reads"])
+    assert st.n_clusters == (1 if len(k["expect"]) == 1 else 1)      # one swept cluster; the 2nd KAT splits it in two
+    assert [int(x) for x in b["n_total"]] == [e["n"] for e in k["expect"]]
+
+
+@pytest.mark.parametrize("k", KATS["bounds"], ids=lambda k: k["source"])
+def test_bounds_kats_through_the_kernels(ctx, k):
+    t = np.zeros(len(k["positions"]), api.TREAD_DTYPE)
+    t["tid"] = 1
+    t["repeat"] = b"ATG"
+    t["position"] = k["positions"]
+    t["split"] = k["splits"]
+    # one cluster holding every read: window larger than the span, min_support 1
+    b, u, st = ctx.cluster(t, api.MODE_CALL, 2_000_000, min_support=1, max_clip_dist=k["max_clip_dist"])
+    assert len(b) == 1
+    for f, v in k.get("expect", {}).items():
+        if f in ("left_most", "right_most"):
+            continue     # Cluster.left_most/right_most come from the sweep here, not from a bare Cluster literal
+        assert int(b[f][0]) == v, f
+    assert b["left"][0] < b["right"][0]
+
+
+@pytest.mark.parametrize("mode,n_samples,n_loci,seed,min_support", [(api.MODE_MERGE, 6, 500, 1000, 5), (api.MODE_CALL, 1, 800, 2000, 3),
+                                                                     (api.MODE_MERGE, 3, 300, 5, 2)])
+def test_cluster_matches_oracle(ctx, oracle, mode, n_samples, n_loci, seed, min_support):
+    """-bounds rows identical to the oracle's merge/call clustering, same row order."""
+    t = synth.synth_treads(n_samples=n_samples, n_loci=n_loci, seed=seed, contig_len=2_000_000)
+    if mode == api.MODE_CALL:   # add unplaced groups
+        t["tid"][::97] = -1
+        t["position"][::97] = 0
+    ot = np.zeros(len(t), oracle.TREAD_DTYPE)
+    for f in t.dtype.names:
+        ot[f] = t[f]
+    exp_b, exp_u = oracle.call_bounds(ot, mode, 560, min_support=min_support, max_clip_dist=175)
+    b, u, st = ctx.cluster(t, mode, 560, min_support=min_support, max_clip_dist=175)
+    assert len(exp_b) > 20
+    rows = [api.bounds_row(x, f"chr{int(x['tid']) + 1}") for x in b]
+    exp_rows = [oracle.bounds_row(x, f"chr{int(x['tid']) + 1}") for x in exp_b]
+    assert sorted(rows) == sorted(exp_rows)          # same set of loci
+    assert rows == exp_rows                          # and the reference's row order (Nim Table slot order)
+    assert [(x["repeat"].decode(), int(x["count"])) for x in u] == exp_u
+
+
+def test_cluster_large_positions_and_ties(ctx, oracle):
+    """uint32 wrap in left_most (cluster.nim:344), ties between modal clip positions (CountTable.largest slot order)."""
+    rng = np.random.default_rng(17)
+    rows = []
+    for locus in range(300):
+        base = int(rng.integers(0, 400)) if locus % 3 == 0 else int(rng.integers(1000, 4_000_000_000))
+        k = int(rng.integers(2, 5))
+        for j in range(k):   # k tied left-clip positions and k tied right-clip positions
+            for _ in range(3):
+                rows.append((base + 40 + j, 0))
+                rows.append((base + j, 1))
+        for _ in range(6):
+            rows.append((max(0, base + int(rng.integers(-300, 300))), 3))
+    t = np.zeros(len(rows), api.TREAD_DTYPE)
+    perm = rng.permutation(len(rows))
+    t["position"] = np.array([r[0] for r in rows], np.uint64)[perm].astype(np.uint32)
+    t["split"] = np.array([r[1] for r in rows])[perm]
+    t["tid"] = 2
+    t["repeat"] = b"AC"
+    t["qname_id"] = rng.integers(0, 3, len(rows))
+    ot = np.zeros(len(t), oracle.TREAD_DTYPE)
+    for f in t.dtype.names:
+        ot[f] = t[f]
+    for mode in (api.MODE_MERGE, api.MODE_CALL):
+        exp_b, _ = oracle.call_bounds(ot, mode, 500, min_support=3, max_clip_dist=200)
+        b, _, _ = ctx.cluster(t, mode, 500, min_support=3, max_clip_dist=200)
+        assert len(exp_b) > 100
+        for f in ("left", "right", "left_most", "right_most", "center_mass", "n_left", "n_right", "n_total"):
+            assert np.array_equal(b[f], exp_b[f]), f
