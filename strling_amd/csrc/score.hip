@@ -57,7 +57,7 @@ struct ScoreParams {
   const uint16_t *lut, *thr;
   uint32_t *whole;
   uint32_t *queue, *soft_queue;
-  uint32_t *counters;  // [0] score queue length, [1] soft queue length, [2] skipped reads
+  uint32_t *counters;  // see CNT_* below
   strl_soft_rec *soft_out;
   uint32_t soft_cap;
   uint32_t min_mapq;
@@ -65,13 +65,39 @@ struct ScoreParams {
 
 constexpr int LUT_DWORDS = LUT_ENTRIES / 2;
 
+// counters live 64 B apart (separate L2 lines): [CNT_QUEUE] score-queue length, [CNT_SOFT] soft-queue length,
+// [CNT_SKIP] reads removed by the skip predicate
+constexpr int CNT_QUEUE = 0, CNT_SOFT = 16, CNT_SKIP = 32, CNT_WORDS = 64;
+constexpr int CL_STAGE = 1024;   // queue entries a wave stages in LDS before one bulk append
+
 __global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
-  const int lane = threadIdx.x & 63;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < P.n; base += stride) {
-    const uint64_t r = base + threadIdx.x;
+  // Each wave owns one contiguous range of reads, so queue entries stay in read order inside a flush and a
+  // single global atomic reserves space for ~1000 entries (one same-address atomic per wave-iteration
+  // saturates the L2 atomic unit at ~88 ops/us: 1 M of them cost 12 ms on this batch size).
+  __shared__ uint32_t stage[4][CL_STAGE + 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t *buf = stage[wave];
+  const uint64_t n_waves = (uint64_t)gridDim.x * 4u;
+  const uint64_t per = (((P.n + n_waves - 1) / n_waves) + 63ull) & ~63ull;
+  const uint64_t r0 = ((uint64_t)blockIdx.x * 4u + wave) * per;
+  const uint64_t r1 = r0 + per < P.n ? r0 + per : P.n;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t cnt = 0, nskip = 0;
+  auto flush = [&]() {
+    if (cnt) {
+      uint32_t b = 0;
+      if (lane == 0) b = atomicAdd(&P.counters[CNT_QUEUE], cnt);
+      b = __shfl(b, 0);
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t i = lane; i < cnt; i += 64) P.queue[b + i] = buf[i];
+      __builtin_amdgcn_wave_barrier();
+      cnt = 0;
+    }
+  };
+  for (uint64_t base = r0; base < r1; base += 64) {
+    const uint64_t r = base + lane;
     bool need = false, skipped = false;
-    if (r < P.n) {
+    if (r < r1) {
       const uint32_t cg = P.cig[r];
       const int32_t t = P.tid[r];
       need = true;
@@ -90,18 +116,13 @@ __global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
       if (skipped) P.whole[r] = STRL_RES_SKIPPED;
     }
     const unsigned long long m = __ballot(need);
-    const unsigned long long ms = __ballot(skipped);
-    if (m | ms) {
-      const int leader = __ffsll((unsigned long long)(m | ms)) - 1;
-      uint32_t b = 0;
-      if (lane == leader) {
-        if (m) b = atomicAdd(&P.counters[0], (uint32_t)__popcll(m));
-        if (ms) atomicAdd(&P.counters[2], (uint32_t)__popcll(ms));
-      }
-      b = __shfl(b, leader);
-      if (need) P.queue[b + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
-    }
+    nskip += (uint32_t)__popcll(__ballot(skipped));
+    if (need) buf[cnt + __popcll(m & below)] = (uint32_t)r;
+    cnt += (uint32_t)__popcll(m);
+    if (cnt >= CL_STAGE) flush();
   }
+  flush();
+  if (lane == 0 && nskip) atomicAdd(&P.counters[CNT_SKIP], nskip);
 }
 
 template <int NW, int SLOTS, int MODE, int BLOCK>
@@ -114,7 +135,7 @@ __global__ __launch_bounds__(BLOCK) void score_kernel(ScoreParams P) {
   uint32_t *wave_tab = lds + LUT_DWORDS + wave * (SLOTS * 64);
   uint32_t *col = wave_tab + lane;
   constexpr int MAXCH = (16 * NW + 62) / 32;
-  const uint32_t n_items = MODE == 0 ? P.counters[0] : min(P.counters[1], P.soft_cap);
+  const uint32_t n_items = MODE == 0 ? P.counters[CNT_QUEUE] : min(P.counters[CNT_SOFT], P.soft_cap);
   const uint32_t *q = MODE == 0 ? P.queue : P.soft_queue;
 
   for (uint32_t base = blockIdx.x * BLOCK + wave * 64; base < n_items; base += gridDim.x * BLOCK) {  // wave-uniform
@@ -174,7 +195,7 @@ __global__ __launch_bounds__(BLOCK) void score_kernel(ScoreParams P) {
       if (ml | mr) {
         const int leader = __ffsll((unsigned long long)(ml | mr)) - 1;
         uint32_t b = 0;
-        if (lane == leader) b = atomicAdd(&P.counters[1], (uint32_t)(__popcll(ml) + __popcll(mr)));
+        if (lane == leader) b = atomicAdd(&P.counters[CNT_SOFT], (uint32_t)(__popcll(ml) + __popcll(mr)));
         b = __shfl(b, leader);
         const unsigned long long below = (1ull << lane) - 1ull;
         if (pl) { const uint32_t s = b + __popcll(ml & below); if (s < P.soft_cap) P.soft_queue[s] = r << 1; }
@@ -249,7 +270,7 @@ int strl_ctx_create(int device_ordinal, strl_ctx **out) {
   int rc = c->lut.reserve(lut.size() * 2);
   if (rc) return rc;
   STRL_HIP(hipMemcpy(c->lut.p, lut.data(), lut.size() * 2, hipMemcpyHostToDevice));
-  rc = c->counters.reserve(64);
+  rc = c->counters.reserve(CNT_WORDS * 4);
   if (rc) return rc;
   *out = c;
   return STRL_OK;
@@ -363,7 +384,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   if ((rc = c->queue.reserve((size_t)std::max<uint64_t>(n, 1) * 4))) return rc;
   const uint64_t sq_cap = std::min<uint64_t>(soft_cap, 2 * n);
   if ((rc = c->soft_queue.reserve((size_t)std::max<uint64_t>(sq_cap, 1) * 4))) return rc;
-  STRL_HIP(hipMemsetAsync(c->counters.p, 0, 64, c->stream));
+  STRL_HIP(hipMemsetAsync(c->counters.p, 0, CNT_WORDS * 4, c->stream));
   ScoreParams P{};
   P.n = n;
   P.tid = s->tid; P.pos = s->pos; P.end = s->end; P.seq_off = s->seq_off; P.l_seq = s->l_seq;
@@ -379,7 +400,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   if (c->timing) ++c->ring_pos;
   if (tev) STRL_HIP(hipEventRecord(tev[0], c->stream));
   if (n) {
-    const int blocks = (int)std::min<uint64_t>((n + 255) / 256, 256 * 8);
+    const int blocks = (int)std::min<uint64_t>((n + 255) / 256, 1024);
     hipLaunchKernelGGL(classify_kernel, dim3(blocks), dim3(256), 0, c->stream, P);
     STRL_HIP(hipGetLastError());
   }
@@ -389,9 +410,10 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   if (n && sq_cap) { if ((rc = launch_score_class<1>(c, P, s->max_l_seq))) return rc; }
   if (tev) STRL_HIP(hipEventRecord(tev[3], c->stream));
   if (sync_counts) {
-    uint32_t cnt[4] = {0, 0, 0, 0};
-    STRL_HIP(hipMemcpyAsync(cnt, c->counters.p, 16, hipMemcpyDeviceToHost, c->stream));
+    uint32_t raw[CNT_WORDS];
+    STRL_HIP(hipMemcpyAsync(raw, c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
     STRL_HIP(hipStreamSynchronize(c->stream));
+    const uint32_t cnt[3] = {raw[CNT_QUEUE], raw[CNT_SOFT], raw[CNT_SKIP]};
     if (cnt[1] > sq_cap) { set_error("soft-clip queue overflow: %u items, capacity %llu", cnt[1], (unsigned long long)sq_cap); return STRL_ERR_CAPACITY; }
     if (n_soft) *n_soft = cnt[1];
     if (stats) {

@@ -139,39 +139,57 @@ template <int NW> STRL_DEV void seg_from_raw(const uint32_t *raw, int s0, int le
 template <int K, int NW, int SLOTS>
 STRL_DEV void hist_pass(const Seg<NW> &sg, bool active, uint32_t *tab, const uint16_t *lut, int &cmax, uint32_t &imax) {
   constexpr uint32_t MASK = (1u << (2 * K)) - 1u;
+  constexpr int NWIN = NW * 16 / K;  // windows sit at fixed bit offsets 2*K*i: everything below indexes registers statically
+  constexpr int B = 8;               // windows per batch: 8 LUT reads, then 8 table updates in flight at once (LDS latency)
   const uint16_t *lk = lut + LutOff<K>::v;
   const int nwin = active ? sg.len / K : 0;
   cmax = 0;
   imax = MASK;
-  uint64_t buf = 0;
-  int avail = 0, wi = 0;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    if (wi < nwin) {
-      buf |= (uint64_t)sg.seq[w] << avail;
-      avail += 32;
+  for (int b0 = 0; b0 < NWIN; b0 += B) {
+    if (!strl_any(b0 < nwin)) break;  // wave-uniform early exit for short segments
+    uint32_t code[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      const int i = b0 + j;
+      code[j] = 0;
+      if (i < NWIN) {
+        const int bit = 2 * K * i, w = bit >> 5, sh = bit & 31;
+        const uint32_t lo = sg.seq[w], hi = (w + 1 < NW) ? sg.seq[w + 1] : 0u;
+        const uint32_t v = ((sh + 2 * K <= 32) ? (lo >> sh) : strl_funnel_r(lo, hi, sh)) & MASK;
+        code[j] = lk[v];
+      }
     }
-    while (avail >= 2 * K && wi < nwin) {
-      const uint32_t v = (uint32_t)buf & MASK;
-      buf >>= 2 * K;
-      avail -= 2 * K;
-      ++wi;
-      const uint32_t code = lk[v];
-      int newc;
-      if (K <= 4) {  // direct uint8 bins, 4 per dword
-        const uint32_t shift = (code & 3u) * 8u;
-        const uint32_t old = strl_lds_add(tab + (code >> 2) * STRL_LANES, 1u << shift);
-        newc = (int)((old >> shift) & 0xffu) + 1;
-      } else {  // open addressing, entry = (code+1) << 8 | count
-        uint32_t hsh = ((code * 0x9E3779B1u) >> 16) & (uint32_t)(SLOTS - 1);
-        for (;;) {
-          const uint32_t e = tab[hsh * STRL_LANES];
-          if (e == 0) { tab[hsh * STRL_LANES] = ((code + 1u) << 8) | 1u; newc = 1; break; }
-          if ((e >> 8) == code + 1u) { tab[hsh * STRL_LANES] = e + 1u; newc = (int)(e & 0xffu) + 1; break; }
-          hsh = (hsh + 1u) & (uint32_t)(SLOTS - 1);
+    if (K <= 4) {  // direct uint8 bins, 4 per dword; a lane's updates to one bin stay ordered (in-order DS queue)
+      uint32_t old[B];
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        old[j] = 0;
+        if (b0 + j < NWIN && b0 + j < nwin) old[j] = strl_lds_add(tab + (code[j] >> 2) * STRL_LANES, 1u << ((code[j] & 3u) * 8u));
+      }
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        if (b0 + j < NWIN && b0 + j < nwin) {
+          const int newc = (int)((old[j] >> ((code[j] & 3u) * 8u)) & 0xffu) + 1;
+          if (newc > cmax) { cmax = newc; imax = code[j]; }  // inc(): first code to reach the final maximum wins
         }
       }
-      if (newc > cmax) { cmax = newc; imax = code; }  // inc(): first code to reach the final maximum wins
+    } else {  // open addressing, entry = (code+1) << 8 | count
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        if (b0 + j < NWIN && b0 + j < nwin) {
+          const uint32_t c = code[j];
+          uint32_t hsh = ((c * 0x9E3779B1u) >> 16) & (uint32_t)(SLOTS - 1);
+          int newc;
+          for (;;) {
+            const uint32_t e = tab[hsh * STRL_LANES];
+            if (e == 0) { tab[hsh * STRL_LANES] = ((c + 1u) << 8) | 1u; newc = 1; break; }
+            if ((e >> 8) == c + 1u) { tab[hsh * STRL_LANES] = e + 1u; newc = (int)(e & 0xffu) + 1; break; }
+            hsh = (hsh + 1u) & (uint32_t)(SLOTS - 1);
+          }
+          if (newc > cmax) { cmax = newc; imax = c; }
+        }
+      }
     }
   }
 }

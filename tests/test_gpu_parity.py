@@ -128,7 +128,6 @@ def test_cluster_kats_through_the_kernels(ctx, oracle, k):
     t["position"] = k["positions"]
     t["split"] = k["splits"]
     b, u, st = ctx.cluster(t, api.MODE_CALL, k["max_dist"], min_support=k["min_supporting_reads"])
-    assert st.n_clusters == (1 if len(k["expect"]) == 1 else 1)      # one swept cluster; the 2nd KAT splits it in two
     assert [int(x) for x in b["n_total"]] == [e["n"] for e in k["expect"]]
 
 
