@@ -85,7 +85,7 @@ def load(build_if_missing=True):
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = _build.LIB
+    path = os.environ.get("STRL_LIB", _build.LIB)   # STRL_LIB: A/B a differently built copy of the same library
     if not os.path.exists(path):
         if not build_if_missing:
             raise StrlingError(f"{path} is missing: build it with `python -m strling_amd.build` (no CPU fallback)")

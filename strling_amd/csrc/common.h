@@ -46,7 +46,7 @@ struct strl_ctx {
   // genome STR intervals, per tid sorted by start, with prefix max of stop
   int32_t n_tid = 0;
   uint64_t n_iv = 0;
-  strl::DevBuf g_has, g_off, g_start, g_pmax;
+  strl::DevBuf g_tid, g_bins, g_start, g_pmax;
   // scratch
   strl::DevBuf queue, soft_queue, counters, soft_tmp;
   // staging for host-memory batches

@@ -43,6 +43,28 @@ void DevBuf::release() {
   cap = 0;
 }
 
+// per-tid view of the genome STR table (32 B, one or two cache lines for a whole genome's contigs)
+struct TidInfo {
+  int64_t iv_off;    // first interval of the tid in g_start / g_pmax
+  int64_t bin_off;   // first bin of the tid in g_bins
+  int32_t n_iv;      // intervals of the tid
+  int32_t n_bins;    // bins of the tid (bin b covers starts in [b << BIN_SHIFT, (b+1) << BIN_SHIFT))
+  int32_t has;       // chromosome is a key of the table (extract.nim:30)
+  int32_t pad;
+};
+constexpr int BIN_SHIFT = 12;
+
+// Number of sub-queues.  Measured on MI355X (2^25 reads): 64 statically partitioned sub-queues made the scorer 4x
+// SLOWER (5.07 vs 1.29 ms) because scored-read density is very uneven along the coordinate-sorted input (the
+// unmapped tail is 100 % scored), while the LDS-staged appends already keep the single counter far below the
+// L2 atomic limit (8192 atomics per launch).  One queue, blocks stride over it => balanced by construction.
+#ifndef STRL_NQ
+#define STRL_NQ 1
+#endif
+constexpr int NQ = STRL_NQ;
+constexpr int CNT_STRIDE = 16;   // counters 64 B apart
+constexpr int CNT_QUEUE = 0, CNT_SOFT = NQ * CNT_STRIDE, CNT_SKIP = 2 * NQ * CNT_STRIDE, CNT_WORDS = 2 * NQ * CNT_STRIDE + 16;
+
 struct ScoreParams {
   uint64_t n;
   const int32_t *tid, *pos, *end;
@@ -50,75 +72,97 @@ struct ScoreParams {
   const uint16_t *l_seq, *clip_l, *clip_r;
   const uint8_t *mapq, *cig;
   const uint8_t *seq4;
-  const uint8_t *g_has;
-  const int64_t *g_off;
+  const TidInfo *g_tid;
   const int32_t *g_start, *g_pmax;
+  const uint32_t *g_bins;
   int32_t n_tid;
   const uint16_t *lut, *thr;
   uint32_t *whole;
-  uint32_t *queue, *soft_queue;
-  uint32_t *counters;  // see CNT_* below
+  uint32_t *queue, *soft_queue;  // NQ regions of qcap / scap entries
+  uint32_t qcap, scap;
+  uint32_t *counters;            // CNT_* layout
   strl_soft_rec *soft_out;
   uint32_t soft_cap;
   uint32_t min_mapq;
 };
 
 constexpr int LUT_DWORDS = LUT_ENTRIES / 2;
-
-// counters live 64 B apart (separate L2 lines): [CNT_QUEUE] score-queue length, [CNT_SOFT] soft-queue length,
-// [CNT_SKIP] reads removed by the skip predicate
-constexpr int CNT_QUEUE = 0, CNT_SOFT = 16, CNT_SKIP = 32, CNT_WORDS = 64;
 constexpr int CL_STAGE = 1024;   // queue entries a wave stages in LDS before one bulk append
+constexpr int CL_ILP = 4;        // reads per lane per iteration (independent lookup chains in flight)
+
+// extract.nim:30-34: single-M cigar, chromosome in the table, no interval overlapping [start, stop)
+__device__ __forceinline__ bool skip_predicate(const ScoreParams &P, uint32_t cg, int32_t t, int32_t start, int32_t stop) {
+  if (!(cg & STRL_CIG_SINGLE_M) || t < 0 || t >= P.n_tid) return false;
+  const TidInfo ti = P.g_tid[t];
+  if (!ti.has) return false;
+  // lapper.find(start, stop) <=> any interval with iv.start < stop and iv.stop > start.
+  // idx = number of intervals with iv.start < stop: bin directory, then a short scan inside the bin
+  int32_t idx;
+  const int32_t b = stop > 0 ? (stop >> BIN_SHIFT) : 0;
+  if (b >= ti.n_bins) idx = ti.n_iv;
+  else {
+    const uint32_t *bins = P.g_bins + ti.bin_off + b;
+    idx = (int32_t)bins[0];
+    const int32_t hi = (int32_t)bins[1];
+    while (idx < hi && P.g_start[ti.iv_off + idx] < stop) ++idx;
+  }
+  const bool overlap = idx > 0 && P.g_pmax[ti.iv_off + idx - 1] > start;
+  return !overlap;
+}
 
 __global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
-  // Each wave owns one contiguous range of reads, so queue entries stay in read order inside a flush and a
-  // single global atomic reserves space for ~1000 entries (one same-address atomic per wave-iteration
-  // saturates the L2 atomic unit at ~88 ops/us: 1 M of them cost 12 ms on this batch size).
-  __shared__ uint32_t stage[4][CL_STAGE + 64];
+  // Each wave owns one contiguous range of reads; queue entries are staged in LDS and appended to the
+  // wave's sub-queue with one atomic per ~1000 entries (one same-address atomic per wave-iteration ran into
+  // the ~88 ops/us limit of the L2 atomic unit: 12 ms per 2^25 reads).
+  __shared__ uint32_t stage[4][CL_STAGE + 64 * CL_ILP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t *buf = stage[wave];
   const uint64_t n_waves = (uint64_t)gridDim.x * 4u;
+  const uint64_t gw = (uint64_t)blockIdx.x * 4u + wave;
   const uint64_t per = (((P.n + n_waves - 1) / n_waves) + 63ull) & ~63ull;
-  const uint64_t r0 = ((uint64_t)blockIdx.x * 4u + wave) * per;
+  const uint64_t r0 = gw * per;
   const uint64_t r1 = r0 + per < P.n ? r0 + per : P.n;
+  const uint32_t q = (uint32_t)(gw % NQ);
+  uint32_t *qbase = P.queue + (uint64_t)q * P.qcap;
   const unsigned long long below = (1ull << lane) - 1ull;
   uint32_t cnt = 0, nskip = 0;
   auto flush = [&]() {
     if (cnt) {
       uint32_t b = 0;
-      if (lane == 0) b = atomicAdd(&P.counters[CNT_QUEUE], cnt);
+      if (lane == 0) b = atomicAdd(&P.counters[CNT_QUEUE + q * CNT_STRIDE], cnt);
       b = __shfl(b, 0);
       __builtin_amdgcn_wave_barrier();
-      for (uint32_t i = lane; i < cnt; i += 64) P.queue[b + i] = buf[i];
+      for (uint32_t i = lane; i < cnt; i += 64) qbase[b + i] = buf[i];
       __builtin_amdgcn_wave_barrier();
       cnt = 0;
     }
   };
-  for (uint64_t base = r0; base < r1; base += 64) {
-    const uint64_t r = base + lane;
-    bool need = false, skipped = false;
-    if (r < r1) {
-      const uint32_t cg = P.cig[r];
-      const int32_t t = P.tid[r];
-      need = true;
-      if ((cg & STRL_CIG_SINGLE_M) && t >= 0 && t < P.n_tid && P.g_has[t]) {
-        // lapper.find(start, stop): any interval with iv.start < stop and iv.stop > start
-        const int32_t start = P.pos[r], stop = P.end[r];
-        int64_t lo = P.g_off[t], hi = P.g_off[t + 1];
-        const int64_t first = lo;
-        while (lo < hi) {  // number of intervals with iv.start < stop
-          const int64_t mid = (lo + hi) >> 1;
-          if (P.g_start[mid] < stop) lo = mid + 1; else hi = mid;
-        }
-        const bool overlap = lo > first && P.g_pmax[lo - 1] > start;
-        if (!overlap) { need = false; skipped = true; }
-      }
-      if (skipped) P.whole[r] = STRL_RES_SKIPPED;
+  for (uint64_t base = r0; base < r1; base += 64 * CL_ILP) {
+    bool need[CL_ILP], skipped[CL_ILP];
+    uint32_t cg[CL_ILP];
+    int32_t t[CL_ILP], st[CL_ILP], en[CL_ILP];
+#pragma unroll
+    for (int j = 0; j < CL_ILP; ++j) {
+      const uint64_t r = base + 64 * j + lane;
+      const bool in = r < r1;
+      cg[j] = in ? P.cig[r] : 0u;
+      t[j] = in ? P.tid[r] : -1;
+      st[j] = in ? P.pos[r] : 0;
+      en[j] = in ? P.end[r] : 0;
+      need[j] = in;
     }
-    const unsigned long long m = __ballot(need);
-    nskip += (uint32_t)__popcll(__ballot(skipped));
-    if (need) buf[cnt + __popcll(m & below)] = (uint32_t)r;
-    cnt += (uint32_t)__popcll(m);
+#pragma unroll
+    for (int j = 0; j < CL_ILP; ++j) {
+      skipped[j] = need[j] && skip_predicate(P, cg[j], t[j], st[j], en[j]);
+      if (skipped[j]) { P.whole[base + 64 * j + lane] = STRL_RES_SKIPPED; need[j] = false; }
+    }
+#pragma unroll
+    for (int j = 0; j < CL_ILP; ++j) {
+      const unsigned long long m = __ballot(need[j]);
+      nskip += (uint32_t)__popcll(__ballot(skipped[j]));
+      if (need[j]) buf[cnt + __popcll(m & below)] = (uint32_t)(base + 64 * j + lane);
+      cnt += (uint32_t)__popcll(m);
+    }
     if (cnt >= CL_STAGE) flush();
   }
   flush();
@@ -135,10 +179,21 @@ __global__ __launch_bounds__(BLOCK) void score_kernel(ScoreParams P) {
   uint32_t *wave_tab = lds + LUT_DWORDS + wave * (SLOTS * 64);
   uint32_t *col = wave_tab + lane;
   constexpr int MAXCH = (16 * NW + 62) / 32;
-  const uint32_t n_items = MODE == 0 ? P.counters[CNT_QUEUE] : min(P.counters[CNT_SOFT], P.soft_cap);
-  const uint32_t *q = MODE == 0 ? P.queue : P.soft_queue;
+  // block b works on sub-queue b % NQ (gridDim.x is a multiple of NQ)
+  const uint32_t sq = blockIdx.x % NQ, bq = blockIdx.x / NQ, nbq = gridDim.x / NQ;
+  uint32_t n_items, out_base = 0;
+  const uint32_t *q;
+  if (MODE == 0) {
+    n_items = P.counters[CNT_QUEUE + sq * CNT_STRIDE];
+    q = P.queue + (uint64_t)sq * P.qcap;
+  } else {
+    n_items = min(P.counters[CNT_SOFT + sq * CNT_STRIDE], P.scap);
+    q = P.soft_queue + (uint64_t)sq * P.scap;
+    for (uint32_t i = 0; i < sq; ++i) out_base += min(P.counters[CNT_SOFT + i * CNT_STRIDE], P.scap);  // compact output
+  }
+  uint32_t *softq = P.soft_queue + (uint64_t)sq * P.scap;
 
-  for (uint32_t base = blockIdx.x * BLOCK + wave * 64; base < n_items; base += gridDim.x * BLOCK) {  // wave-uniform
+  for (uint32_t base = bq * BLOCK + wave * 64; base < n_items; base += nbq * BLOCK) {  // wave-uniform
     const uint32_t item = base + lane;
     const bool act = item < n_items;
     uint32_t qv = 0, r = 0;
@@ -195,20 +250,20 @@ __global__ __launch_bounds__(BLOCK) void score_kernel(ScoreParams P) {
       if (ml | mr) {
         const int leader = __ffsll((unsigned long long)(ml | mr)) - 1;
         uint32_t b = 0;
-        if (lane == leader) b = atomicAdd(&P.counters[CNT_SOFT], (uint32_t)(__popcll(ml) + __popcll(mr)));
+        if (lane == leader) b = atomicAdd(&P.counters[CNT_SOFT + sq * CNT_STRIDE], (uint32_t)(__popcll(ml) + __popcll(mr)));
         b = __shfl(b, leader);
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (pl) { const uint32_t s = b + __popcll(ml & below); if (s < P.soft_cap) P.soft_queue[s] = r << 1; }
-        if (pr) { const uint32_t s = b + __popcll(ml) + __popcll(mr & below); if (s < P.soft_cap) P.soft_queue[s] = (r << 1) | 1u; }
+        if (pl) { const uint32_t s = b + __popcll(ml & below); if (s < P.scap) softq[s] = r << 1; }
+        if (pr) { const uint32_t s = b + __popcll(ml) + __popcll(mr & below); if (s < P.scap) softq[s] = (r << 1) | 1u; }
       }
     } else {
-      if (act) {
+      if (act && out_base + item < P.soft_cap) {
         strl_soft_rec o;
         o.read_side = qv;
         o.res_first = o0;
         o.res_after = o1;
         o.seg_len = (uint32_t)len;
-        P.soft_out[item] = o;
+        P.soft_out[out_base + item] = o;
       }
     }
   }
@@ -280,7 +335,7 @@ void strl_ctx_destroy(strl_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  strl::DevBuf *bufs[] = {&c->lut, &c->thr, &c->g_has, &c->g_off, &c->g_start, &c->g_pmax, &c->queue, &c->soft_queue, &c->counters,
+  strl::DevBuf *bufs[] = {&c->lut, &c->thr, &c->g_tid, &c->g_bins, &c->g_start, &c->g_pmax, &c->queue, &c->soft_queue, &c->counters,
                           &c->soft_tmp, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
                           &c->st_mapq, &c->st_cig, &c->st_seq4, &c->st_whole, &c->st_soft};
   for (auto *b : bufs) b->release();
@@ -347,27 +402,46 @@ int strl_ctx_set_genome(strl_ctx *c, const strl_genome_str *g) {
   const int32_t nt = g->n_tid;
   const int64_t niv = g->iv_off[nt];
   std::vector<int32_t> st((size_t)std::max<int64_t>(niv, 1)), pm((size_t)std::max<int64_t>(niv, 1));
+  std::vector<TidInfo> ti((size_t)nt);
+  std::vector<uint32_t> bins;
   std::vector<int64_t> idx;
   for (int32_t t = 0; t < nt; ++t) {
     const int64_t a = g->iv_off[t], b = g->iv_off[t + 1];
+    if (b - a > 0x7ffffff0ll) { set_error("too many intervals on tid %d", t); return STRL_ERR_ARG; }
     idx.resize((size_t)(b - a));
     for (int64_t i = a; i < b; ++i) idx[(size_t)(i - a)] = i;
     std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) { return g->iv_start[x] < g->iv_start[y]; });
     int32_t run = INT32_MIN;
-    for (int64_t i = a; i < b; ++i) {
+    for (int64_t i = a; i < b; ++i) {          // sorted starts + running maximum of stops
       const int64_t s = idx[(size_t)(i - a)];
       st[(size_t)i] = g->iv_start[s];
       run = std::max(run, g->iv_stop[s]);
       pm[(size_t)i] = run;
     }
+    TidInfo &x = ti[(size_t)t];
+    x.iv_off = a;
+    x.n_iv = (int32_t)(b - a);
+    x.has = g->has_chrom[t] ? 1 : 0;
+    x.pad = 0;
+    x.bin_off = (int64_t)bins.size();
+    // bins[k] = number of intervals with start < (k << BIN_SHIFT); one extra entry closes the last bin
+    const int32_t max_start = b > a ? std::max(0, st[(size_t)(b - 1)]) : 0;
+    x.n_bins = b > a ? (max_start >> BIN_SHIFT) + 1 : 0;
+    int64_t j = a;
+    for (int32_t k = 0; k <= x.n_bins; ++k) {
+      const int64_t lim = (int64_t)k << BIN_SHIFT;
+      while (j < b && (int64_t)st[(size_t)j] < lim) ++j;
+      bins.push_back((uint32_t)(j - a));
+    }
   }
+  if (bins.empty()) bins.push_back(0);
   int rc;
-  if ((rc = c->g_has.reserve((size_t)nt))) return rc;
-  if ((rc = c->g_off.reserve((size_t)(nt + 1) * 8))) return rc;
+  if ((rc = c->g_tid.reserve(ti.size() * sizeof(TidInfo)))) return rc;
+  if ((rc = c->g_bins.reserve(bins.size() * 4))) return rc;
   if ((rc = c->g_start.reserve(st.size() * 4))) return rc;
   if ((rc = c->g_pmax.reserve(pm.size() * 4))) return rc;
-  STRL_HIP(hipMemcpy(c->g_has.p, g->has_chrom, (size_t)nt, hipMemcpyHostToDevice));
-  STRL_HIP(hipMemcpy(c->g_off.p, g->iv_off, (size_t)(nt + 1) * 8, hipMemcpyHostToDevice));
+  STRL_HIP(hipMemcpy(c->g_tid.p, ti.data(), ti.size() * sizeof(TidInfo), hipMemcpyHostToDevice));
+  STRL_HIP(hipMemcpy(c->g_bins.p, bins.data(), bins.size() * 4, hipMemcpyHostToDevice));
   STRL_HIP(hipMemcpy(c->g_start.p, st.data(), st.size() * 4, hipMemcpyHostToDevice));
   STRL_HIP(hipMemcpy(c->g_pmax.p, pm.data(), pm.size() * 4, hipMemcpyHostToDevice));
   c->n_tid = nt;
@@ -381,44 +455,56 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   if (n > 0x7fffffffull) { set_error("batch too large (%llu reads; limit 2^31-1)", (unsigned long long)n); return STRL_ERR_ARG; }
   if (s->max_l_seq > STRL_MAX_READ_LEN) { set_error("read of %u bases exceeds STRL_MAX_READ_LEN=%d", s->max_l_seq, STRL_MAX_READ_LEN); return STRL_ERR_ARG; }
   int rc;
-  if ((rc = c->queue.reserve((size_t)std::max<uint64_t>(n, 1) * 4))) return rc;
-  const uint64_t sq_cap = std::min<uint64_t>(soft_cap, 2 * n);
-  if ((rc = c->soft_queue.reserve((size_t)std::max<uint64_t>(sq_cap, 1) * 4))) return rc;
+  // classify grid: a multiple of 16 blocks (64 waves) so every sub-queue gets the same number of wave ranges
+  int cblocks = (int)std::min<uint64_t>((n + 255) / 256, 2048);
+  cblocks = std::max(16, (cblocks + 15) & ~15);
+  const uint64_t n_waves = (uint64_t)cblocks * 4;
+  const uint64_t per = (((n + n_waves - 1) / n_waves) + 63ull) & ~63ull;
+  const uint64_t qcap = (n_waves / NQ) * per;                                  // reads routed to one sub-queue
+  const uint64_t scap = std::min<uint64_t>((soft_cap + NQ - 1) / NQ, 2 * qcap); // soft items of one sub-queue
+  if ((rc = c->queue.reserve((size_t)std::max<uint64_t>(NQ * qcap, 1) * 4))) return rc;
+  if ((rc = c->soft_queue.reserve((size_t)std::max<uint64_t>(NQ * scap, 1) * 4))) return rc;
   STRL_HIP(hipMemsetAsync(c->counters.p, 0, CNT_WORDS * 4, c->stream));
   ScoreParams P{};
   P.n = n;
   P.tid = s->tid; P.pos = s->pos; P.end = s->end; P.seq_off = s->seq_off; P.l_seq = s->l_seq;
   P.clip_l = s->clip_l; P.clip_r = s->clip_r; P.mapq = s->mapq; P.cig = s->cig; P.seq4 = s->seq4;
-  P.g_has = c->g_has.as<uint8_t>(); P.g_off = c->g_off.as<int64_t>(); P.g_start = c->g_start.as<int32_t>();
+  P.g_tid = c->g_tid.as<TidInfo>(); P.g_bins = c->g_bins.as<uint32_t>(); P.g_start = c->g_start.as<int32_t>();
   P.g_pmax = c->g_pmax.as<int32_t>(); P.n_tid = c->n_tid;
   P.lut = c->lut.as<uint16_t>(); P.thr = c->thr.as<uint16_t>();
   P.whole = whole; P.queue = c->queue.as<uint32_t>(); P.soft_queue = c->soft_queue.as<uint32_t>();
+  P.qcap = (uint32_t)qcap; P.scap = (uint32_t)scap;
   P.counters = c->counters.as<uint32_t>(); P.soft_out = soft;
-  P.soft_cap = (uint32_t)std::min<uint64_t>(sq_cap, 0xffffffffull);
+  P.soft_cap = (uint32_t)std::min<uint64_t>(soft_cap, 0xffffffffull);
   P.min_mapq = c->opts.min_mapq;
   hipEvent_t *tev = c->timing ? &c->ring[(c->ring_pos % RING) * 4] : nullptr;
   if (c->timing) ++c->ring_pos;
   if (tev) STRL_HIP(hipEventRecord(tev[0], c->stream));
   if (n) {
-    const int blocks = (int)std::min<uint64_t>((n + 255) / 256, 1024);
-    hipLaunchKernelGGL(classify_kernel, dim3(blocks), dim3(256), 0, c->stream, P);
+    hipLaunchKernelGGL(classify_kernel, dim3(cblocks), dim3(256), 0, c->stream, P);
     STRL_HIP(hipGetLastError());
   }
   if (tev) STRL_HIP(hipEventRecord(tev[1], c->stream));
   if (n) { if ((rc = launch_score_class<0>(c, P, s->max_l_seq))) return rc; }
   if (tev) STRL_HIP(hipEventRecord(tev[2], c->stream));
-  if (n && sq_cap) { if ((rc = launch_score_class<1>(c, P, s->max_l_seq))) return rc; }
+  if (n && scap) { if ((rc = launch_score_class<1>(c, P, s->max_l_seq))) return rc; }
   if (tev) STRL_HIP(hipEventRecord(tev[3], c->stream));
   if (sync_counts) {
-    uint32_t raw[CNT_WORDS];
-    STRL_HIP(hipMemcpyAsync(raw, c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint32_t> raw(CNT_WORDS);
+    STRL_HIP(hipMemcpyAsync(raw.data(), c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
     STRL_HIP(hipStreamSynchronize(c->stream));
-    const uint32_t cnt[3] = {raw[CNT_QUEUE], raw[CNT_SOFT], raw[CNT_SKIP]};
-    if (cnt[1] > sq_cap) { set_error("soft-clip queue overflow: %u items, capacity %llu", cnt[1], (unsigned long long)sq_cap); return STRL_ERR_CAPACITY; }
-    if (n_soft) *n_soft = cnt[1];
+    uint64_t scored = 0, softs = 0;
+    for (int q = 0; q < NQ; ++q) {
+      scored += raw[CNT_QUEUE + q * CNT_STRIDE];
+      const uint32_t sc = raw[CNT_SOFT + q * CNT_STRIDE];
+      if (sc > scap) { set_error("soft-clip queue overflow: sub-queue %d has %u items, capacity %llu (soft_cap %llu)", q, sc, (unsigned long long)scap, (unsigned long long)soft_cap); return STRL_ERR_CAPACITY; }
+      softs += sc;
+    }
+    if (softs > soft_cap) { set_error("soft-clip output overflow: %llu items, capacity %llu", (unsigned long long)softs, (unsigned long long)soft_cap); return STRL_ERR_CAPACITY; }
+    if (n_soft) *n_soft = softs;
     if (stats) {
       memset(stats, 0, sizeof *stats);
-      stats->n_reads = n; stats->n_skipped = cnt[2]; stats->n_scored = cnt[0]; stats->n_soft_items = cnt[1];
+      stats->n_reads = n; stats->n_skipped = raw[CNT_SKIP]; stats->n_scored = scored; stats->n_soft_items = softs;
       if (tev) {
         (void)hipEventElapsedTime(&stats->ms_classify, tev[0], tev[1]);
         (void)hipEventElapsedTime(&stats->ms_score, tev[1], tev[2]);
@@ -455,12 +541,13 @@ int strl_score_reads(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, strl_
   }
   d.mem = STRL_MEM_DEVICE;
   if ((rc = c->st_whole.reserve((size_t)std::max<uint64_t>(n, 1) * 4))) return rc;
-  const uint64_t dcap = std::min<uint64_t>(soft_cap, 2 * n);
+  const uint64_t dcap = 4 * n + 65536;   // >= NQ * (worst case of one sub-queue): no overflow possible in host mode
   if ((rc = c->st_soft.reserve((size_t)std::max<uint64_t>(dcap, 1) * sizeof(strl_soft_rec)))) return rc;
   uint64_t ns = 0;
   strl_score_stats st{};
   rc = score_device(c, &d, c->st_whole.as<uint32_t>(), c->st_soft.as<strl_soft_rec>(), dcap, &ns, &st, true);
   if (rc) return rc;
+  if (ns > soft_cap) { set_error("soft capacity %llu too small, need %llu", (unsigned long long)soft_cap, (unsigned long long)ns); return STRL_ERR_CAPACITY; }
   if (n) STRL_HIP(hipMemcpyAsync(whole, c->st_whole.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
   if (ns && soft) STRL_HIP(hipMemcpyAsync(soft, c->st_soft.p, (size_t)ns * sizeof(strl_soft_rec), hipMemcpyDeviceToHost, c->stream));
   STRL_HIP(hipStreamSynchronize(c->stream));
