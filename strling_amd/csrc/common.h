@@ -48,7 +48,7 @@ struct strl_ctx {
   uint64_t n_iv = 0;
   strl::DevBuf g_tid, g_bins, g_start, g_pmax;
   // scratch
-  strl::DevBuf queue, soft_queue, counters, soft_tmp;
+  strl::DevBuf queue, soft_queue, counters, soft_tmp, sb_whole, sb_soft, soft_dense, sb_state_w, sb_state_s, queue_r;
   // staging for host-memory batches
   strl::DevBuf st_tid, st_pos, st_end, st_seqoff, st_lseq, st_clipl, st_clipr, st_mapq, st_cig, st_seq4, st_whole, st_soft;
   // clustering scratch

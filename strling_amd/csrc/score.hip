@@ -54,16 +54,13 @@ struct TidInfo {
 };
 constexpr int BIN_SHIFT = 12;
 
-// Number of sub-queues.  Measured on MI355X (2^25 reads): 64 statically partitioned sub-queues made the scorer 4x
-// SLOWER (5.07 vs 1.29 ms) because scored-read density is very uneven along the coordinate-sorted input (the
-// unmapped tail is 100 % scored), while the LDS-staged appends already keep the single counter far below the
-// L2 atomic limit (8192 atomics per launch).  One queue, blocks stride over it => balanced by construction.
-#ifndef STRL_NQ
-#define STRL_NQ 1
-#endif
-constexpr int NQ = STRL_NQ;
+// Work items are self-contained 16-byte queue entries, so the scorer never chases metadata pointers:
+//   whole read : id = read index            | seq_off | l_seq | clip_l << 16 | clip_r | cig << 16 | mapq << 24
+//   soft clip  : id = read index << 1 | side | seq_off | l_seq | clip_len << 16 | 0
+// Stage-B items are 32 bytes: the entry + {slot, best, res0, res1}.
+constexpr uint32_t EMPTY = 0xffffffffu;
 constexpr int CNT_STRIDE = 16;   // counters 64 B apart
-constexpr int CNT_QUEUE = 0, CNT_SOFT = NQ * CNT_STRIDE, CNT_SKIP = 2 * NQ * CNT_STRIDE, CNT_WORDS = 2 * NQ * CNT_STRIDE + 16;
+constexpr int CNT_QUEUE = 0, CNT_SOFT = 16, CNT_SKIP = 32, CNT_SBW = 48, CNT_SBS = 64, CNT_WORDS = 80;
 
 struct ScoreParams {
   uint64_t n;
@@ -73,20 +70,27 @@ struct ScoreParams {
   const uint8_t *mapq, *cig;
   const uint8_t *seq4;
   const TidInfo *g_tid;
-  const int32_t *g_start, *g_pmax;
+  const int2 *g_iv;         // per tid, sorted by start: {start, running max of stop}
   const uint32_t *g_bins;
   int32_t n_tid;
-  const uint16_t *lut, *thr;
+  const uint16_t *lut;
+  const uint64_t *thr;
   uint32_t *whole;
-  uint32_t *queue, *soft_queue;  // NQ regions of qcap / scap entries
-  uint32_t qcap, scap;
-  uint32_t *counters;            // CNT_* layout
+  uint32_t *queue_r;   // [n]      read indices the skip predicate kept (classify)
+  uint4 *queue;        // [n]      scoring queue entries built from queue_r (entries_kernel)
+  uint4 *soft_dense;   // [2n]     two slots per scored read (left / right clip) or EMPTY
+  uint4 *soft_queue;   // [scap]   compacted soft-clip items
+  uint4 *sb_state[2];  // dense hand-over of stage A: {best | EMPTY, res0, res1, -} per item
+  uint4 *sb_queue[2];  // compacted stage-B items (2 x uint4 each)
+  uint32_t scap;
+  uint32_t *counters;  // CNT_* layout
   strl_soft_rec *soft_out;
   uint32_t soft_cap;
   uint32_t min_mapq;
 };
 
 constexpr int LUT_DWORDS = LUT_ENTRIES / 2;
+constexpr int LUT_A_DWORDS = LUT_OFF5 / 2;   // stage A only looks up k <= 4
 constexpr int CL_STAGE = 1024;   // queue entries a wave stages in LDS before one bulk append
 constexpr int CL_ILP = 4;        // reads per lane per iteration (independent lookup chains in flight)
 
@@ -97,23 +101,30 @@ __device__ __forceinline__ bool skip_predicate(const ScoreParams &P, uint32_t cg
   if (!ti.has) return false;
   // lapper.find(start, stop) <=> any interval with iv.start < stop and iv.stop > start.
   // idx = number of intervals with iv.start < stop: bin directory, then a short scan inside the bin
-  int32_t idx;
   const int32_t b = stop > 0 ? (stop >> BIN_SHIFT) : 0;
-  if (b >= ti.n_bins) idx = ti.n_iv;
-  else {
+  int32_t idx = ti.n_iv, hi = ti.n_iv;
+  if (b < ti.n_bins) {
     const uint32_t *bins = P.g_bins + ti.bin_off + b;
     idx = (int32_t)bins[0];
-    const int32_t hi = (int32_t)bins[1];
-    while (idx < hi && P.g_start[ti.iv_off + idx] < stop) ++idx;
+    hi = (int32_t)bins[1];
   }
-  const bool overlap = idx > 0 && P.g_pmax[ti.iv_off + idx - 1] > start;
+  const int2 *iv = P.g_iv + ti.iv_off;
+  // both candidates are requested together; the scan below almost never needs a third element
+  int32_t pm = idx > 0 ? iv[idx - 1].y : INT32_MIN;
+  int2 c = idx < hi ? iv[idx] : make_int2(INT32_MAX, 0);
+  while (c.x < stop) {
+    pm = c.y;
+    ++idx;
+    c = idx < hi ? iv[idx] : make_int2(INT32_MAX, 0);
+  }
+  const bool overlap = idx > 0 && pm > start;
   return !overlap;
 }
 
 __global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
-  // Each wave owns one contiguous range of reads; queue entries are staged in LDS and appended to the
-  // wave's sub-queue with one atomic per ~1000 entries (one same-address atomic per wave-iteration ran into
-  // the ~88 ops/us limit of the L2 atomic unit: 12 ms per 2^25 reads).
+  // Each wave owns one contiguous range of reads; queue entries are staged in LDS and appended with one atomic
+  // per flush (one same-address atomic per wave-iteration ran into the ~88 ops/us limit of the L2 atomic unit:
+  // 12 ms per 2^25 reads).
   __shared__ uint32_t stage[4][CL_STAGE + 64 * CL_ILP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t *buf = stage[wave];
@@ -122,17 +133,15 @@ __global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
   const uint64_t per = (((P.n + n_waves - 1) / n_waves) + 63ull) & ~63ull;
   const uint64_t r0 = gw * per;
   const uint64_t r1 = r0 + per < P.n ? r0 + per : P.n;
-  const uint32_t q = (uint32_t)(gw % NQ);
-  uint32_t *qbase = P.queue + (uint64_t)q * P.qcap;
   const unsigned long long below = (1ull << lane) - 1ull;
   uint32_t cnt = 0, nskip = 0;
   auto flush = [&]() {
     if (cnt) {
       uint32_t b = 0;
-      if (lane == 0) b = atomicAdd(&P.counters[CNT_QUEUE + q * CNT_STRIDE], cnt);
+      if (lane == 0) b = atomicAdd(&P.counters[CNT_QUEUE], cnt);
       b = __shfl(b, 0);
       __builtin_amdgcn_wave_barrier();
-      for (uint32_t i = lane; i < cnt; i += 64) qbase[b + i] = buf[i];
+      for (uint32_t i = lane; i < cnt; i += 64) P.queue_r[b + i] = buf[i];
       __builtin_amdgcn_wave_barrier();
       cnt = 0;
     }
@@ -169,110 +178,210 @@ __global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
   if (lane == 0 && nskip) atomicAdd(&P.counters[CNT_SKIP], nskip);
 }
 
-template <int NW, int SLOTS, int MODE, int BLOCK>
+// Builds the self-contained 16-byte work items of the kept reads (scattered metadata gathers; full occupancy,
+// nothing downstream of them in this kernel, so their latency is free).
+__global__ __launch_bounds__(256) void entries_kernel(ScoreParams P) {
+  const uint32_t nq = P.counters[CNT_QUEUE];
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nq; i += gridDim.x * 256u) {
+    const uint32_t r = P.queue_r[i];
+    uint4 e;
+    e.x = r;
+    e.y = P.seq_off[r];
+    e.z = (uint32_t)P.l_seq[r] | ((uint32_t)P.clip_l[r] << 16);
+    e.w = (uint32_t)P.clip_r[r] | ((uint32_t)P.cig[r] << 16) | ((uint32_t)P.mapq[r] << 24);
+    P.queue[i] = e;
+  }
+}
+
+// Order-preserving-within-block compaction of a dense array with EMPTY holes into a queue: one global atomic
+// per 1024 slots, issued by a kernel that has nothing else to wait for (the scorers themselves never wait on
+// an atomic).  KIND 0: soft-clip slots -> soft queue.  KIND 1: stage-A survivors -> 32-byte stage-B items.
+template <int KIND, int MODE>
+__global__ __launch_bounds__(1024) void compact_kernel(ScoreParams P) {
+  __shared__ uint32_t wcnt[16];
+  __shared__ uint32_t base_sh;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t n_src, cap, cnt_idx;
+  const uint4 *src;
+  const uint4 *ent = nullptr;
+  uint4 *dst;
+  if (KIND == 0) { n_src = 2u * P.counters[CNT_QUEUE]; src = P.soft_dense; dst = P.soft_queue; cap = P.scap; cnt_idx = CNT_SOFT; }
+  else {
+    n_src = MODE == 0 ? P.counters[CNT_QUEUE] : min(P.counters[CNT_SOFT], P.scap);
+    src = P.sb_state[MODE]; ent = MODE == 0 ? P.queue : P.soft_queue; dst = P.sb_queue[MODE];
+    cap = 0xffffffffu; cnt_idx = MODE == 0 ? CNT_SBW : CNT_SBS;
+  }
+  for (uint32_t b0 = blockIdx.x * 1024u; b0 < n_src; b0 += gridDim.x * 1024u) {
+    const uint32_t i = b0 + threadIdx.x;
+    uint4 v = make_uint4(EMPTY, 0, 0, 0);
+    if (i < n_src) v = src[i];
+    const bool keep = v.x != EMPTY;
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t tot = 0;
+      for (int w = 0; w < 16; ++w) { const uint32_t c = wcnt[w]; wcnt[w] = tot; tot += c; }
+      base_sh = tot ? atomicAdd(&P.counters[cnt_idx], tot) : 0u;
+    }
+    __syncthreads();
+    if (keep) {
+      const uint32_t d = base_sh + wcnt[wave] + (uint32_t)__popcll(m & below);
+      if (KIND == 0) { if (d < cap) dst[d] = v; }
+      else {
+        dst[2 * (uint64_t)d] = ent[i];
+        dst[2 * (uint64_t)d + 1] = make_uint4(i, v.x, v.y, v.z);   // slot, best, res0, res1
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// rows ([row][lane] dwords) of a wave's LDS region: raw SEQ staging, k = 2/3 bins + dummy row, long-read hash slots
+template <int NW, int SLOTS, int STAGE> constexpr int table_rows() {
+  constexpr int raw = 4 * ((16 * NW + 62) / 32);
+  constexpr int need = STAGE == 0 ? 65 : (NW <= 10 ? 0 : SLOTS);
+  return raw > need ? raw : need;
+}
+
+template <int MODE, int STAGE> struct Item {
+  uint32_t id, seq_off, slot;
+  int L, len, s0;
+  uint32_t cl, cr, cg, mq;
+  int best;
+  uint32_t res0, res1;
+  bool act;
+};
+
+// STAGE 0: k = 2..4 on queued items; a lane whose ladder goes on leaves (best, res0, res1) in the dense
+//          hand-over array.  STAGE 1: k = 5, 6 on the compacted survivors.  Whoever finishes an item writes its
+//          result and the item's two soft-clip slots.  The loop is software-pipelined: while item i runs
+//          the ladder, the SEQ chunks and thresholds of item i+1 and the queue entry of item i+2 are in flight.
+template <int NW, int SLOTS, int MODE, int STAGE, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void score_kernel(ScoreParams P) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  for (int i = threadIdx.x; i < LUT_DWORDS; i += BLOCK) lds[i] = reinterpret_cast<const uint32_t *>(P.lut)[i];
+  constexpr int LUTW = STAGE == 0 ? LUT_A_DWORDS : LUT_DWORDS;
+  for (int i = threadIdx.x; i < LUTW; i += BLOCK) lds[i] = reinterpret_cast<const uint32_t *>(P.lut)[i];
   __syncthreads();
   const uint16_t *lut = reinterpret_cast<const uint16_t *>(lds);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t *wave_tab = lds + LUT_DWORDS + wave * (SLOTS * 64);
+  uint32_t *wave_tab = lds + LUTW + wave * (table_rows<NW, SLOTS, STAGE>() * 64);
   uint32_t *col = wave_tab + lane;
   constexpr int MAXCH = (16 * NW + 62) / 32;
-  // block b works on sub-queue b % NQ (gridDim.x is a multiple of NQ)
-  const uint32_t sq = blockIdx.x % NQ, bq = blockIdx.x / NQ, nbq = gridDim.x / NQ;
-  uint32_t n_items, out_base = 0;
-  const uint32_t *q;
-  if (MODE == 0) {
-    n_items = P.counters[CNT_QUEUE + sq * CNT_STRIDE];
-    q = P.queue + (uint64_t)sq * P.qcap;
-  } else {
-    n_items = min(P.counters[CNT_SOFT + sq * CNT_STRIDE], P.scap);
-    q = P.soft_queue + (uint64_t)sq * P.scap;
-    for (uint32_t i = 0; i < sq; ++i) out_base += min(P.counters[CNT_SOFT + i * CNT_STRIDE], P.scap);  // compact output
-  }
-  uint32_t *softq = P.soft_queue + (uint64_t)sq * P.scap;
+  constexpr int ROW0 = MODE == 0 ? 1 : 2, ROW1 = MODE == 0 ? 1 : 3;
+  uint32_t n_items;
+  const uint4 *q;
+  if (STAGE == 1) { n_items = P.counters[MODE == 0 ? CNT_SBW : CNT_SBS]; q = P.sb_queue[MODE]; }
+  else if (MODE == 0) { n_items = P.counters[CNT_QUEUE]; q = P.queue; }
+  else { n_items = min(P.counters[CNT_SOFT], P.scap); q = P.soft_queue; }
+  const uint32_t stride = gridDim.x * BLOCK;
 
-  for (uint32_t base = bq * BLOCK + wave * 64; base < n_items; base += nbq * BLOCK) {  // wave-uniform
-    const uint32_t item = base + lane;
-    const bool act = item < n_items;
-    uint32_t qv = 0, r = 0;
-    int s0 = 0, len = 0;
-    if (act) {
-      qv = q[item];
-      if (MODE == 0) {
-        r = qv;
-        len = P.l_seq[r];
-      } else {
-        r = qv >> 1;
-        const int L = P.l_seq[r];
-        len = (qv & 1u) ? P.clip_r[r] : P.clip_l[r];
-        if (len > L) len = L;
-        s0 = (qv & 1u) ? L - len : 0;
-      }
-      if (len > 16 * NW) len = 16 * NW;  // host picks NW from max_l_seq; never taken
+  auto fetch = [&](uint32_t item) {
+    Item<MODE, STAGE> it;
+    it.act = item < n_items;
+    uint4 e = make_uint4(0, 0, 0, 0), x = make_uint4(0, 0, 0, 0);
+    if (it.act) {
+      if (STAGE == 0) e = q[item];
+      else { e = q[2 * (uint64_t)item]; x = q[2 * (uint64_t)item + 1]; }
     }
-    // stage the BAM-packed bases that cover [s0, s0+len) into this lane's LDS column
-    const int s0l = s0 & 31;
-    const int nch = act ? (s0l + len + 31) >> 5 : 0;
-    const uint4 *src = reinterpret_cast<const uint4 *>(P.seq4 + (uint64_t)P.seq_off[r] * 16u) + (s0 >> 5);
+    it.id = e.x; it.seq_off = e.y;
+    it.L = (int)(e.z & 0xffffu);
+    it.slot = STAGE == 0 ? item : x.x;
+    it.best = STAGE == 0 ? -1 : (int)x.y;
+    it.res0 = x.z; it.res1 = x.w;
+    if (MODE == 0) {
+      it.cl = e.z >> 16; it.cr = e.w & 0xffffu; it.cg = (e.w >> 16) & 0xffu; it.mq = e.w >> 24;
+      it.len = it.L; it.s0 = 0;
+    } else {
+      it.cl = it.cr = it.cg = it.mq = 0;
+      int len = (int)(e.z >> 16);
+      if (len > it.L) len = it.L;
+      it.len = len;
+      it.s0 = (e.x & 1u) ? it.L - len : 0;
+    }
+    if (it.len > 16 * NW) it.len = 16 * NW;  // host picks NW from max_l_seq; never taken
+    if (!it.act) { it.len = 0; it.s0 = 0; }
+    return it;
+  };
+  struct Pre { uint4 s[MAXCH]; LaneThr t; };
+  auto prefetch = [&](const Item<MODE, STAGE> &it, Pre &p) {
+    const int nch = it.act ? ((it.s0 & 31) + it.len + 31) >> 5 : 0;
+    const uint4 *src = reinterpret_cast<const uint4 *>(P.seq4 + (uint64_t)it.seq_off * 16u) + (it.s0 >> 5);
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) p.s[c] = (c < nch) ? src[c] : make_uint4(0, 0, 0, 0);
+    load_thr(P.thr, ROW0, ROW1, it.len, p.t);
+  };
+
+  uint32_t base = blockIdx.x * BLOCK + wave * 64;
+  Item<MODE, STAGE> cur = fetch(base + lane), nxt = fetch(base + stride + lane);
+  Pre pc, pn;
+  prefetch(cur, pc);
+  for (; base < n_items; base += stride) {  // wave-uniform
+    const Item<MODE, STAGE> nn = fetch(base + 2 * stride + lane);
+    prefetch(nxt, pn);
+    // ---- run item `cur` ----
+    ScoreState st;
+    st.best = cur.best; st.alive = STAGE == 1 && cur.act; st.res0 = cur.res0; st.res1 = cur.res1;
+    st.ph_t = __builtin_readcyclecounter();
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
-      if (c < nch) {
-        const uint4 v = src[c];
-        col[(4 * c + 0) * 64] = v.x;
-        col[(4 * c + 1) * 64] = v.y;
-        col[(4 * c + 2) * 64] = v.z;
-        col[(4 * c + 3) * 64] = v.w;
-      }
+    for (int c = 0; c < MAXCH; ++c) {   // rows a lane does not need just receive zeros
+      col[(4 * c + 0) * 64] = pc.s[c].x;
+      col[(4 * c + 1) * 64] = pc.s[c].y;
+      col[(4 * c + 2) * 64] = pc.s[c].z;
+      col[(4 * c + 3) * 64] = pc.s[c].w;
     }
     __builtin_amdgcn_wave_barrier();
+    STRL_PH(st, 0);
     Seg<NW> sg;
-    seg_from_raw<NW>(col, s0l, len, sg);
-    uint32_t o0, o1;
-    score_segment<NW, SLOTS>(sg, act, wave_tab, lane, lut, P.thr, MODE == 0 ? 1 : 2, MODE == 0 ? 1 : 3, o0, o1);
+    seg_from_raw<NW>(col, cur.s0 & 31, cur.len, sg);
+    STRL_PH(st, 1);
+    if (STAGE == 0) score_stage_a<NW, SLOTS>(sg, cur.act, wave_tab, lane, lut, pc.t, st);
+    else score_stage_b<NW, SLOTS>(sg, wave_tab, lane, lut, pc.t, st);
 
+    const bool fwd = STAGE == 0 && cur.act && st.alive;
+    const bool fin = cur.act && !fwd;
+    const uint32_t o0 = reduce_packed(st.res0), o1 = reduce_packed(st.res1);
+    if (STAGE == 0 && cur.act)
+      P.sb_state[MODE][cur.slot] = fwd ? make_uint4((uint32_t)st.best, st.res0, st.res1, 0u) : make_uint4(EMPTY, 0u, 0u, 0u);
     if (MODE == 0) {
-      bool pl = false, pr = false;
-      if (act) {
-        P.whole[r] = o0;
-        // add_soft gates, extract.nim:97-106
-        const uint32_t cg = P.cig[r];
-        if (P.mapq[r] >= P.min_mapq && (cg & (STRL_CIG_FIRST_S | STRL_CIG_LAST_S))) {
-          const bool has_unit = STRL_RES_K(o0) != 0;
-          pl = (cg & STRL_CIG_FIRST_S) && (has_unit || P.clip_l[r] > 16);
-          // with a single cigar op both loop iterations are cig_index == 0 (the host replays the duplicate)
-          pr = (cg & STRL_CIG_LAST_S) && !(cg & STRL_CIG_ONE_OP) && (has_unit || P.clip_r[r] > 16);
+      if (cur.act) {
+        uint4 sl = make_uint4(EMPTY, 0, 0, 0), sr = make_uint4(EMPTY, 0, 0, 0);
+        if (fin) {
+          P.whole[cur.id] = o0;
+          // add_soft gates, extract.nim:97-106
+          if (cur.mq >= P.min_mapq && (cur.cg & (STRL_CIG_FIRST_S | STRL_CIG_LAST_S))) {
+            const bool has_unit = STRL_RES_K(o0) != 0;
+            if ((cur.cg & STRL_CIG_FIRST_S) && (has_unit || cur.cl > 16))
+              sl = make_uint4(cur.id << 1, cur.seq_off, (uint32_t)cur.L | (cur.cl << 16), 0u);
+            // with a single cigar op both loop iterations are cig_index == 0 (the host replays the duplicate)
+            if ((cur.cg & STRL_CIG_LAST_S) && !(cur.cg & STRL_CIG_ONE_OP) && (has_unit || cur.cr > 16))
+              sr = make_uint4((cur.id << 1) | 1u, cur.seq_off, (uint32_t)cur.L | (cur.cr << 16), 0u);
+          }
         }
-      }
-      const unsigned long long ml = __ballot(pl), mr = __ballot(pr);
-      if (ml | mr) {
-        const int leader = __ffsll((unsigned long long)(ml | mr)) - 1;
-        uint32_t b = 0;
-        if (lane == leader) b = atomicAdd(&P.counters[CNT_SOFT + sq * CNT_STRIDE], (uint32_t)(__popcll(ml) + __popcll(mr)));
-        b = __shfl(b, leader);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (pl) { const uint32_t s = b + __popcll(ml & below); if (s < P.scap) softq[s] = r << 1; }
-        if (pr) { const uint32_t s = b + __popcll(ml) + __popcll(mr & below); if (s < P.scap) softq[s] = (r << 1) | 1u; }
+        P.soft_dense[2 * (uint64_t)cur.slot] = sl;       // forwarded items leave EMPTY; stage B overwrites
+        P.soft_dense[2 * (uint64_t)cur.slot + 1] = sr;
       }
     } else {
-      if (act && out_base + item < P.soft_cap) {
+      if (fin && cur.slot < P.soft_cap) {
         strl_soft_rec o;
-        o.read_side = qv;
+        o.read_side = cur.id;
         o.res_first = o0;
         o.res_after = o1;
-        o.seg_len = (uint32_t)len;
-        P.soft_out[out_base + item] = o;
+        o.seg_len = (uint32_t)cur.len;
+        P.soft_out[cur.slot] = o;
       }
     }
+    STRL_PH(st, 12);
+    cur = nxt; pc = pn; nxt = nn;
   }
 }
 
 // ---- host side of this translation unit -------------------------------------------------------
-template <int NW, int SLOTS, int MODE, int BLOCK> static int launch_score(strl_ctx *ctx, const ScoreParams &P, int blocks) {
-  auto kfn = score_kernel<NW, SLOTS, MODE, BLOCK>;
-  const size_t shmem = (size_t)LUT_DWORDS * 4 + (size_t)(BLOCK / 64) * SLOTS * 64 * 4;
+template <int NW, int SLOTS, int MODE, int STAGE, int BLOCK> static int launch_score(strl_ctx *ctx, const ScoreParams &P, int blocks) {
+  auto kfn = score_kernel<NW, SLOTS, MODE, STAGE, BLOCK>;
+  const size_t shmem = (size_t)(STAGE == 0 ? LUT_A_DWORDS : LUT_DWORDS) * 4 + (size_t)(BLOCK / 64) * table_rows<NW, SLOTS, STAGE>() * 64 * 4;
   static bool attr_done = false;
   if (!attr_done) {
     STRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -283,10 +392,18 @@ template <int NW, int SLOTS, int MODE, int BLOCK> static int launch_score(strl_c
   return STRL_OK;
 }
 
+// stage A -> compaction of the survivors -> stage B of one MODE, kernel class picked by the longest read
 template <int MODE> static int launch_score_class(strl_ctx *ctx, const ScoreParams &P, uint32_t max_l) {
-  if (max_l <= 160) return launch_score<10, 64, MODE, 256>(ctx, P, 512);
-  if (max_l <= 256) return launch_score<16, 128, MODE, 256>(ctx, P, 256);
-  return launch_score<32, 256, MODE, 64>(ctx, P, 512);
+  int rc;
+  if (max_l <= 160) rc = launch_score<10, 64, MODE, 0, 256>(ctx, P, 512);
+  else if (max_l <= 256) rc = launch_score<16, 128, MODE, 0, 256>(ctx, P, 256);
+  else rc = launch_score<32, 256, MODE, 0, 64>(ctx, P, 512);
+  if (rc) return rc;
+  hipLaunchKernelGGL((compact_kernel<1, MODE>), dim3(512), dim3(1024), 0, ctx->stream, P);
+  STRL_HIP(hipGetLastError());
+  if (max_l <= 160) return launch_score<10, 64, MODE, 1, 256>(ctx, P, 512);
+  if (max_l <= 256) return launch_score<16, 128, MODE, 1, 256>(ctx, P, 256);
+  return launch_score<32, 256, MODE, 1, 64>(ctx, P, 512);
 }
 
 }  // namespace strl
@@ -296,6 +413,14 @@ using namespace strl;
 static constexpr uint64_t RING = 256;
 
 extern "C" {
+
+#ifdef STRL_PHASE_TIMING
+int strl_debug_phase(unsigned long long *out, int reset) {   // debug builds only (not part of the ABI)
+  if (out) { if (hipMemcpyFromSymbol(out, HIP_SYMBOL(strl::g_phase), 32 * 8) != hipSuccess) return -1; }
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(strl::g_phase), z, 32 * 8) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 int strl_version(void) { return 100; }
 const char *strl_last_error(void) { return strl::g_err; }
@@ -336,7 +461,7 @@ void strl_ctx_destroy(strl_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   strl::DevBuf *bufs[] = {&c->lut, &c->thr, &c->g_tid, &c->g_bins, &c->g_start, &c->g_pmax, &c->queue, &c->soft_queue, &c->counters,
-                          &c->soft_tmp, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
+                          &c->soft_tmp, &c->sb_whole, &c->sb_soft, &c->queue_r, &c->soft_dense, &c->sb_state_w, &c->sb_state_s, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
                           &c->st_mapq, &c->st_cig, &c->st_seq4, &c->st_whole, &c->st_soft};
   for (auto *b : bufs) b->release();
   for (auto &b : c->c_buf) b.release();
@@ -385,11 +510,11 @@ int strl_ctx_set_opts(strl_ctx *c, const strl_opts *o) {
   if (!c || !o) { set_error("null argument"); return STRL_ERR_ARG; }
   STRL_HIP(hipSetDevice(c->device));
   c->opts = *o;
-  std::vector<uint16_t> thr;
+  std::vector<uint64_t> thr;
   build_thr(*o, thr);
-  int rc = c->thr.reserve(thr.size() * 2);
+  int rc = c->thr.reserve(thr.size() * 8);
   if (rc) return rc;
-  STRL_HIP(hipMemcpyAsync(c->thr.p, thr.data(), thr.size() * 2, hipMemcpyHostToDevice, c->stream));
+  STRL_HIP(hipMemcpyAsync(c->thr.p, thr.data(), thr.size() * 8, hipMemcpyHostToDevice, c->stream));
   STRL_HIP(hipStreamSynchronize(c->stream));
   c->have_opts = true;
   return STRL_OK;
@@ -402,6 +527,7 @@ int strl_ctx_set_genome(strl_ctx *c, const strl_genome_str *g) {
   const int32_t nt = g->n_tid;
   const int64_t niv = g->iv_off[nt];
   std::vector<int32_t> st((size_t)std::max<int64_t>(niv, 1)), pm((size_t)std::max<int64_t>(niv, 1));
+  std::vector<int2> ivs((size_t)std::max<int64_t>(niv, 1));
   std::vector<TidInfo> ti((size_t)nt);
   std::vector<uint32_t> bins;
   std::vector<int64_t> idx;
@@ -417,6 +543,7 @@ int strl_ctx_set_genome(strl_ctx *c, const strl_genome_str *g) {
       st[(size_t)i] = g->iv_start[s];
       run = std::max(run, g->iv_stop[s]);
       pm[(size_t)i] = run;
+      ivs[(size_t)i] = make_int2(st[(size_t)i], run);
     }
     TidInfo &x = ti[(size_t)t];
     x.iv_off = a;
@@ -438,12 +565,10 @@ int strl_ctx_set_genome(strl_ctx *c, const strl_genome_str *g) {
   int rc;
   if ((rc = c->g_tid.reserve(ti.size() * sizeof(TidInfo)))) return rc;
   if ((rc = c->g_bins.reserve(bins.size() * 4))) return rc;
-  if ((rc = c->g_start.reserve(st.size() * 4))) return rc;
-  if ((rc = c->g_pmax.reserve(pm.size() * 4))) return rc;
+  if ((rc = c->g_start.reserve(ivs.size() * 8))) return rc;
   STRL_HIP(hipMemcpy(c->g_tid.p, ti.data(), ti.size() * sizeof(TidInfo), hipMemcpyHostToDevice));
   STRL_HIP(hipMemcpy(c->g_bins.p, bins.data(), bins.size() * 4, hipMemcpyHostToDevice));
-  STRL_HIP(hipMemcpy(c->g_start.p, st.data(), st.size() * 4, hipMemcpyHostToDevice));
-  STRL_HIP(hipMemcpy(c->g_pmax.p, pm.data(), pm.size() * 4, hipMemcpyHostToDevice));
+  STRL_HIP(hipMemcpy(c->g_start.p, ivs.data(), ivs.size() * 8, hipMemcpyHostToDevice));
   c->n_tid = nt;
   c->n_iv = (uint64_t)niv;
   return STRL_OK;
@@ -452,28 +577,32 @@ int strl_ctx_set_genome(strl_ctx *c, const strl_genome_str *g) {
 static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, strl_soft_rec *soft, uint64_t soft_cap,
                         uint64_t *n_soft, strl_score_stats *stats, bool sync_counts) {
   const uint64_t n = s->n;
-  if (n > 0x7fffffffull) { set_error("batch too large (%llu reads; limit 2^31-1)", (unsigned long long)n); return STRL_ERR_ARG; }
+  if (n > 0x3fffffffull) { set_error("batch too large (%llu reads; limit 2^30-1)", (unsigned long long)n); return STRL_ERR_ARG; }
   if (s->max_l_seq > STRL_MAX_READ_LEN) { set_error("read of %u bases exceeds STRL_MAX_READ_LEN=%d", s->max_l_seq, STRL_MAX_READ_LEN); return STRL_ERR_ARG; }
   int rc;
-  // classify grid: a multiple of 16 blocks (64 waves) so every sub-queue gets the same number of wave ranges
-  int cblocks = (int)std::min<uint64_t>((n + 255) / 256, 2048);
-  cblocks = std::max(16, (cblocks + 15) & ~15);
-  const uint64_t n_waves = (uint64_t)cblocks * 4;
-  const uint64_t per = (((n + n_waves - 1) / n_waves) + 63ull) & ~63ull;
-  const uint64_t qcap = (n_waves / NQ) * per;                                  // reads routed to one sub-queue
-  const uint64_t scap = std::min<uint64_t>((soft_cap + NQ - 1) / NQ, 2 * qcap); // soft items of one sub-queue
-  if ((rc = c->queue.reserve((size_t)std::max<uint64_t>(NQ * qcap, 1) * 4))) return rc;
-  if ((rc = c->soft_queue.reserve((size_t)std::max<uint64_t>(NQ * scap, 1) * 4))) return rc;
+  const uint64_t n1 = std::max<uint64_t>(n, 1);
+  const uint64_t scap = std::max<uint64_t>(std::min<uint64_t>(soft_cap, 2 * n), 1);
+  if ((rc = c->queue.reserve((size_t)n1 * 16))) return rc;
+  if ((rc = c->queue_r.reserve((size_t)n1 * 4))) return rc;
+  if ((rc = c->soft_dense.reserve((size_t)n1 * 32))) return rc;
+  if ((rc = c->soft_queue.reserve((size_t)scap * 16))) return rc;
+  if ((rc = c->sb_state_w.reserve((size_t)n1 * 16))) return rc;
+  if ((rc = c->sb_state_s.reserve((size_t)scap * 16))) return rc;
+  if ((rc = c->sb_whole.reserve((size_t)n1 * 32))) return rc;
+  if ((rc = c->sb_soft.reserve((size_t)scap * 32))) return rc;
   STRL_HIP(hipMemsetAsync(c->counters.p, 0, CNT_WORDS * 4, c->stream));
   ScoreParams P{};
   P.n = n;
   P.tid = s->tid; P.pos = s->pos; P.end = s->end; P.seq_off = s->seq_off; P.l_seq = s->l_seq;
   P.clip_l = s->clip_l; P.clip_r = s->clip_r; P.mapq = s->mapq; P.cig = s->cig; P.seq4 = s->seq4;
-  P.g_tid = c->g_tid.as<TidInfo>(); P.g_bins = c->g_bins.as<uint32_t>(); P.g_start = c->g_start.as<int32_t>();
-  P.g_pmax = c->g_pmax.as<int32_t>(); P.n_tid = c->n_tid;
-  P.lut = c->lut.as<uint16_t>(); P.thr = c->thr.as<uint16_t>();
-  P.whole = whole; P.queue = c->queue.as<uint32_t>(); P.soft_queue = c->soft_queue.as<uint32_t>();
-  P.qcap = (uint32_t)qcap; P.scap = (uint32_t)scap;
+  P.g_tid = c->g_tid.as<TidInfo>(); P.g_bins = c->g_bins.as<uint32_t>(); P.g_iv = c->g_start.as<int2>();
+  P.n_tid = c->n_tid;
+  P.lut = c->lut.as<uint16_t>(); P.thr = c->thr.as<uint64_t>();
+  P.whole = whole; P.queue = c->queue.as<uint4>(); P.queue_r = c->queue_r.as<uint32_t>(); P.soft_dense = c->soft_dense.as<uint4>();
+  P.soft_queue = c->soft_queue.as<uint4>();
+  P.sb_state[0] = c->sb_state_w.as<uint4>(); P.sb_state[1] = c->sb_state_s.as<uint4>();
+  P.sb_queue[0] = c->sb_whole.as<uint4>(); P.sb_queue[1] = c->sb_soft.as<uint4>();
+  P.scap = (uint32_t)scap;
   P.counters = c->counters.as<uint32_t>(); P.soft_out = soft;
   P.soft_cap = (uint32_t)std::min<uint64_t>(soft_cap, 0xffffffffull);
   P.min_mapq = c->opts.min_mapq;
@@ -481,30 +610,30 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   if (c->timing) ++c->ring_pos;
   if (tev) STRL_HIP(hipEventRecord(tev[0], c->stream));
   if (n) {
+    const int cblocks = (int)std::min<uint64_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(classify_kernel, dim3(cblocks), dim3(256), 0, c->stream, P);
+    hipLaunchKernelGGL(entries_kernel, dim3(1024), dim3(256), 0, c->stream, P);
     STRL_HIP(hipGetLastError());
   }
   if (tev) STRL_HIP(hipEventRecord(tev[1], c->stream));
   if (n) { if ((rc = launch_score_class<0>(c, P, s->max_l_seq))) return rc; }
   if (tev) STRL_HIP(hipEventRecord(tev[2], c->stream));
-  if (n && scap) { if ((rc = launch_score_class<1>(c, P, s->max_l_seq))) return rc; }
+  if (n && soft_cap) {
+    hipLaunchKernelGGL((compact_kernel<0, 0>), dim3(1024), dim3(1024), 0, c->stream, P);
+    STRL_HIP(hipGetLastError());
+    if ((rc = launch_score_class<1>(c, P, s->max_l_seq))) return rc;
+  }
   if (tev) STRL_HIP(hipEventRecord(tev[3], c->stream));
   if (sync_counts) {
-    std::vector<uint32_t> raw(CNT_WORDS);
-    STRL_HIP(hipMemcpyAsync(raw.data(), c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
+    uint32_t raw[CNT_WORDS];
+    STRL_HIP(hipMemcpyAsync(raw, c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
     STRL_HIP(hipStreamSynchronize(c->stream));
-    uint64_t scored = 0, softs = 0;
-    for (int q = 0; q < NQ; ++q) {
-      scored += raw[CNT_QUEUE + q * CNT_STRIDE];
-      const uint32_t sc = raw[CNT_SOFT + q * CNT_STRIDE];
-      if (sc > scap) { set_error("soft-clip queue overflow: sub-queue %d has %u items, capacity %llu (soft_cap %llu)", q, sc, (unsigned long long)scap, (unsigned long long)soft_cap); return STRL_ERR_CAPACITY; }
-      softs += sc;
-    }
-    if (softs > soft_cap) { set_error("soft-clip output overflow: %llu items, capacity %llu", (unsigned long long)softs, (unsigned long long)soft_cap); return STRL_ERR_CAPACITY; }
+    const uint64_t softs = soft_cap ? raw[CNT_SOFT] : 0;
+    if (softs > scap || softs > soft_cap) { set_error("soft-clip queue overflow: %llu items, capacity %llu", (unsigned long long)softs, (unsigned long long)std::min(scap, soft_cap)); return STRL_ERR_CAPACITY; }
     if (n_soft) *n_soft = softs;
     if (stats) {
       memset(stats, 0, sizeof *stats);
-      stats->n_reads = n; stats->n_skipped = raw[CNT_SKIP]; stats->n_scored = scored; stats->n_soft_items = softs;
+      stats->n_reads = n; stats->n_skipped = raw[CNT_SKIP]; stats->n_scored = raw[CNT_QUEUE]; stats->n_soft_items = softs;
       if (tev) {
         (void)hipEventElapsedTime(&stats->ms_classify, tev[0], tev[1]);
         (void)hipEventElapsedTime(&stats->ms_score, tev[1], tev[2]);
@@ -541,7 +670,7 @@ int strl_score_reads(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, strl_
   }
   d.mem = STRL_MEM_DEVICE;
   if ((rc = c->st_whole.reserve((size_t)std::max<uint64_t>(n, 1) * 4))) return rc;
-  const uint64_t dcap = 4 * n + 65536;   // >= NQ * (worst case of one sub-queue): no overflow possible in host mode
+  const uint64_t dcap = 2 * n + 2;   // at most two clipped ends per read
   if ((rc = c->st_soft.reserve((size_t)std::max<uint64_t>(dcap, 1) * sizeof(strl_soft_rec)))) return rc;
   uint64_t ns = 0;
   strl_score_stats st{};

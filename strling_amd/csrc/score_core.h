@@ -42,6 +42,19 @@ STRL_DEV uint32_t strl_lds_add(uint32_t *a, uint32_t v) { return atomicAdd(a, v)
 
 namespace strl {
 
+// Optional per-phase cycle accounting (debug builds with -DSTRL_PHASE_TIMING only; see tools/phase_timing.py)
+#if defined(STRL_PHASE_TIMING) && !defined(STRL_EMU)
+__device__ unsigned long long g_phase[32];
+#define STRL_PH(st, i)                                                                   \
+  do {                                                                                   \
+    const unsigned long long now__ = __builtin_readcyclecounter();                       \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_phase[i], now__ - (st).ph_t);              \
+    (st).ph_t = now__;                                                                   \
+  } while (0)
+#else
+#define STRL_PH(st, i) do { } while (0)
+#endif
+
 // canonical-code lookup tables, indexed by the window value as it comes out of the LSB-first
 // 2-bit stream (first base in the LOW bits); entries are the reference's code (first base HIGH).
 constexpr int LUT_OFF2 = 0, LUT_OFF3 = 16, LUT_OFF4 = 80, LUT_OFF5 = 336, LUT_OFF6 = 1360, LUT_ENTRIES = 5456;
@@ -53,10 +66,9 @@ template <> struct LutOff<5> { static constexpr int v = LUT_OFF5; };
 template <> struct LutOff<6> { static constexpr int v = LUT_OFF6; };
 
 // threshold tables (host-computed with the reference's float64 expressions, so the device does
-// no floating point at all): thr[row][k-2][L], rows: 0 = int(L*0.12/k) (utils.nim:251),
+// no floating point at all): thr[row][L] = five bytes, byte k-2 = the value for k; rows: 0 = int(L*0.12/k) (utils.nim:251),
 // 1 = int(L*p/k), 2 = int(L*(p-0.07)/k), 3 = int(L*min(p,0.6)/k)  (utils.nim:259, extract.nim:208,242)
 constexpr int THR_LMAX = 512;
-constexpr int THR_ROW = 5 * THR_LMAX;
 
 // ---- BAM 4-bit -> 2-bit -----------------------------------------------------------------------
 // squeeze the two low bits of each nibble of z into 16 contiguous bits, in base order
@@ -136,45 +148,89 @@ template <int NW> STRL_DEV void seg_from_raw(const uint32_t *raw, int s0, int le
 // ---- per-k histogram pass (utils.nim:205-211) ---------------------------------------------------
 // tab: this lane's LDS column (row stride STRL_LANES dwords), already zeroed for this k.
 // Returns count (A[imax]) and the winning code (4^K-1 when there is no window: decode of -1).
+// Window i of a k pass sits at the fixed bit offset 2*k*i of the stream, so everything indexes registers statically.
+template <int K, int NW> STRL_DEV uint32_t window_code(const Seg<NW> &sg, const uint16_t *lk, int i) {
+  constexpr uint32_t MASK = (1u << (2 * K)) - 1u;
+  const int bit = 2 * K * i, w = bit >> 5, sh = bit & 31;
+  const uint32_t lo = sg.seq[w], hi = (w + 1 < NW) ? sg.seq[w + 1] : 0u;
+  const uint32_t v = ((sh + 2 * K <= 32) ? (lo >> sh) : strl_funnel_r(lo, hi, sh)) & MASK;
+  return lk[v];
+}
+
+// The count of a k pass is the running count inc() (utils.nim:192-195) would have seen at each window:
+//   newc_i = 1 + #{j < i : code_j == code_i};  count = max_i newc_i;  winner = code at the first i reaching it.
+// Four interchangeable ways to get newc_i, picked per k by what is cheapest on CDNA4:
+//   k = 2,3 : 32-bit bins in LDS ([bin][lane], ds_add_rtn returns the old count), 16 / 64 rows
+//   k = 4   : 256 uint8 bins packed 4 per dword in LDS, 64 rows.  (Counting k = 4 in registers with byte-parallel
+//             equality was tried: 2.6x the VALU instructions of the LDS bins, and integer VALU is the binding
+//             resource of this kernel -- 4 cycles per wave64 op, ~90 % busy -- so it lost.)
+//   k = 5,6 : in registers, one code per VGPR (<= 32 windows for reads <= 160 bases); longer reads fall back to a
+//             per-lane open-addressing table in LDS.
 template <int K, int NW, int SLOTS>
 STRL_DEV void hist_pass(const Seg<NW> &sg, bool active, uint32_t *tab, const uint16_t *lut, int &cmax, uint32_t &imax) {
   constexpr uint32_t MASK = (1u << (2 * K)) - 1u;
-  constexpr int NWIN = NW * 16 / K;  // windows sit at fixed bit offsets 2*K*i: everything below indexes registers statically
-  constexpr int B = 8;               // windows per batch: 8 LUT reads, then 8 table updates in flight at once (LDS latency)
+  constexpr int NWIN = NW * 16 / K;
+  constexpr int B = 8;  // windows per batch: 8 LUT reads, then 8 table updates in flight at once (LDS latency)
   const uint16_t *lk = lut + LutOff<K>::v;
   const int nwin = active ? sg.len / K : 0;
   cmax = 0;
   imax = MASK;
+  if (K >= 5 && NW <= 10) {
+    uint32_t code[NWIN];
+#pragma unroll
+    for (int i = 0; i < NWIN; ++i) code[i] = window_code<K, NW>(sg, lk, i);
+#pragma unroll
+    for (int i = 0; i < NWIN; ++i) {
+      uint32_t ne = 0;  // earlier windows that differ (pure VALU: xor, min, add -- no compare-to-SGPR round trips)
+#pragma unroll
+      for (int j = 0; j < i; ++j) {
+        const uint32_t x = code[j] ^ code[i];
+        ne += x < 1u ? x : 1u;
+      }
+      const int newc = 1 + i - (int)ne;
+      if (i < nwin && newc > cmax) { cmax = newc; imax = code[i]; }
+    }
+    return;
+  }
 #pragma unroll
   for (int b0 = 0; b0 < NWIN; b0 += B) {
     if (!strl_any(b0 < nwin)) break;  // wave-uniform early exit for short segments
     uint32_t code[B];
 #pragma unroll
-    for (int j = 0; j < B; ++j) {
-      const int i = b0 + j;
-      code[j] = 0;
-      if (i < NWIN) {
-        const int bit = 2 * K * i, w = bit >> 5, sh = bit & 31;
-        const uint32_t lo = sg.seq[w], hi = (w + 1 < NW) ? sg.seq[w + 1] : 0u;
-        const uint32_t v = ((sh + 2 * K <= 32) ? (lo >> sh) : strl_funnel_r(lo, hi, sh)) & MASK;
-        code[j] = lk[v];
-      }
-    }
-    if (K <= 4) {  // direct uint8 bins, 4 per dword; a lane's updates to one bin stay ordered (in-order DS queue)
+    for (int j = 0; j < B; ++j) code[j] = (b0 + j < NWIN) ? window_code<K, NW>(sg, lk, b0 + j) : 0u;
+    if (K <= 3) {  // 16 / 64 x 32-bit bins.  Branch-free: windows past this lane's end hit a dummy row and count 0.
+      constexpr uint32_t DUMMY = (K == 2) ? 16u : 64u;
       uint32_t old[B];
 #pragma unroll
       for (int j = 0; j < B; ++j) {
         old[j] = 0;
-        if (b0 + j < NWIN && b0 + j < nwin) old[j] = strl_lds_add(tab + (code[j] >> 2) * STRL_LANES, 1u << ((code[j] & 3u) * 8u));
+        if (b0 + j < NWIN) old[j] = strl_lds_add(tab + ((b0 + j < nwin) ? code[j] : DUMMY) * STRL_LANES, 1u);
       }
 #pragma unroll
       for (int j = 0; j < B; ++j) {
-        if (b0 + j < NWIN && b0 + j < nwin) {
-          const int newc = (int)((old[j] >> ((code[j] & 3u) * 8u)) & 0xffu) + 1;
+        if (b0 + j < NWIN) {
+          const int newc = (b0 + j < nwin) ? (int)old[j] + 1 : 0;
           if (newc > cmax) { cmax = newc; imax = code[j]; }  // inc(): first code to reach the final maximum wins
         }
       }
-    } else {  // open addressing, entry = (code+1) << 8 | count
+    } else if (K == 4) {  // 256 uint8 bins packed 4 per dword (64 rows + dummy); a lane's updates to one bin stay ordered
+      uint32_t old[B];
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        old[j] = 0;
+        if (b0 + j < NWIN) {
+          const uint32_t row = (b0 + j < nwin) ? (code[j] >> 2) : 64u;
+          old[j] = strl_lds_add(tab + row * STRL_LANES, 1u << ((code[j] & 3u) * 8u));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        if (b0 + j < NWIN) {
+          const int newc = (b0 + j < nwin) ? (int)((old[j] >> ((code[j] & 3u) * 8u)) & 0xffu) + 1 : 0;
+          if (newc > cmax) { cmax = newc; imax = code[j]; }
+        }
+      }
+    } else {  // k = 5, 6 on long reads: open addressing, entry = (code+1) << 8 | count
 #pragma unroll
       for (int j = 0; j < B; ++j) {
         if (b0 + j < NWIN && b0 + j < nwin) {
@@ -219,20 +275,54 @@ template <int K, int NW> STRL_DEV int recount(const Seg<NW> &sg, uint32_t code) 
     }
   }
   const int limit = sg.len - K + 1;  // number of start positions
-  int cnt = 0, skip = 0;
+  uint32_t m[NW];                    // bit 2i of m[w] set <=> the unit matches at base 16w + i
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
-    uint32_t m = ~(acc[w] | (acc[w] >> 1)) & 0x55555555u;
+    uint32_t x = ~(acc[w] | (acc[w] >> 1)) & 0x55555555u;
     const int nv = limit - 16 * w;
-    if (nv < 16) m &= (nv <= 0) ? 0u : ((1u << (2 * nv)) - 1u);
-    m &= ~((1u << (2 * skip)) - 1u);
-    skip = 0;
-    while (m) {
-      const int i = (strl_ffs(m) - 1) >> 1;
-      ++cnt;
-      const int nx = i + K;
-      if (nx >= 16) { skip = nx - 16; m = 0; }
-      else m &= ~((1u << (2 * nx)) - 1u);
+    if (nv < 16) x &= (nv <= 0) ? 0u : ((1u << (2 * nv)) - 1u);
+    m[w] = x;
+  }
+  int cnt = 0;
+  if (K == 2) {
+    // Two matches collide only when adjacent (homodimer unit), and greedy left-to-right then keeps every other
+    // match of a run.  Runs are resolved with one multi-word addition: adding a run's start bit to the run
+    // (both bits of every pair filled) carries through exactly that run, which tells every pair the parity of
+    // its run's start.  Exact for hetero-dimers too (their runs have length 1).
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t prev = w ? m[w - 1] : 0u;
+      const uint32_t start = m[w] & ~((m[w] << 2) | (prev >> 30));   // first match of a run
+      const uint32_t fill = m[w] | (m[w] << 1);                        // runs as solid bit strings
+      const uint64_t t = (uint64_t)fill + (start & 0x11111111u) + carry;  // only runs starting on an even pair
+      carry = (uint32_t)(t >> 32);
+      const uint32_t even_runs = fill & ~(uint32_t)t;                  // bits those runs lost to the carry
+      const uint32_t sel = (m[w] & even_runs & 0x11111111u) | (m[w] & ~even_runs & 0x44444444u);
+      cnt += strl_popc(sel);
+    }
+  } else {
+    // does the unit overlap a shifted copy of itself (s[0..K-d) == s[d..K))?  Only then can matches collide.
+    bool border = false;
+#pragma unroll
+    for (int d = 1; d < K; ++d) border |= (code >> (2 * d)) == (code & ((1u << (2 * (K - d))) - 1u));
+    if (!strl_any(border)) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) cnt += strl_popc(m[w]);
+    } else {  // rare (periodic units whose shorter period did not already win): literal greedy walk
+      int skip = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        uint32_t x = m[w] & ~((1u << (2 * skip)) - 1u);
+        skip = 0;
+        while (x) {
+          const int i = (strl_ffs(x) - 1) >> 1;
+          ++cnt;
+          const int nx = i + K;
+          if (nx >= 16) { skip = nx - 16; x = 0; }
+          else x &= ~((1u << (2 * nx)) - 1u);
+        }
+      }
     }
   }
   return cnt;
@@ -257,33 +347,51 @@ struct ScoreState {
   int best;
   bool alive;
   uint32_t res0, res1;  // packed results for the two threshold rows
+  unsigned long long ph_t;  // phase clock (debug builds)
 };
 
+// rows of the wave's table region a k pass touches (direct bins + the dummy row, or the hash slots)
+template <int K, int SLOTS> struct KRows { static constexpr int v = (K == 2) ? 17 : (K <= 4) ? 65 : SLOTS; };
+
+// The lane's thresholds for its segment length.  The host packs the five k-values of one (row, L) into one
+// 64-bit word (one byte each; L <= 510 and p <= 1 keep them <= 255), so an item needs THREE loads, issued with
+// the rest of its global traffic.  (Loading thresholds at the decision points -- which is also where the
+// compiler sinks scalarised loads to -- put a global round trip on the critical path of every k: the
+// "decide" phases were 38 % of all wave cycles.)
+struct LaneThr {
+  uint64_t w12, w0, w1;
+};
+STRL_DEV void load_thr(const uint64_t *thr, int row0, int row1, int L, LaneThr &t) {
+  t.w12 = thr[0 * THR_LMAX + L];
+  t.w0 = thr[row0 * THR_LMAX + L];
+  t.w1 = (row1 == row0) ? t.w0 : thr[row1 * THR_LMAX + L];
+}
+template <int K> STRL_DEV int thr_get(uint64_t w) { return (int)((w >> (8 * (K - 2))) & 0xffu); }
+
 template <int K, int NW, int SLOTS>
-STRL_DEV void score_k(const Seg<NW> &sg, ScoreState &st, uint32_t *wave_tab, int lane, const uint16_t *lut,
-                      const uint16_t *thr, int row0, int row1) {
+STRL_DEV void score_k(const Seg<NW> &sg, ScoreState &st, uint32_t *wave_tab, int lane, const uint16_t *lut, const LaneThr &t) {
   if (!strl_any(st.alive)) return;  // wave-uniform
-  constexpr int ROWS = (K == 2) ? 4 : (K == 3) ? 16 : (K == 4) ? 64 : SLOTS;
-  clear_rows(wave_tab, lane, ROWS);
+  if (K <= 4 || NW > 10) clear_rows(wave_tab, lane, KRows<K, SLOTS>::v);   // k = 5,6 of short reads count in registers
   int c;
   uint32_t code;
   hist_pass<K, NW, SLOTS>(sg, st.alive, wave_tab + lane, lut, c, code);
+  STRL_PH(st, 2 + 2 * (K - 2));
   if (st.alive) {
     int score = c * K;
-    const int L = sg.len;
     if (score <= st.best) {  // utils.nim:250-253
-      if (c < (int)thr[0 * THR_ROW + (K - 2) * THR_LMAX + L]) st.alive = false;  // break
+      if (c < thr_get<K>(t.w12)) st.alive = false;  // break
     } else {
       c = recount<K, NW>(sg, code);  // utils.nim:254
       score = c * K;
       if (score >= st.best) {  // :256
         st.best = score;
         const uint32_t packed = code | ((uint32_t)K << 12) | ((uint32_t)c << 16);
-        if (c > (int)thr[row0 * THR_ROW + (K - 2) * THR_LMAX + L]) st.res0 = packed;  // :259-263
-        if (c > (int)thr[row1 * THR_ROW + (K - 2) * THR_LMAX + L]) st.res1 = packed;
+        if (c > thr_get<K>(t.w0)) st.res0 = packed;  // :259-263
+        if (c > thr_get<K>(t.w1)) st.res1 = packed;
       }
     }
   }
+  STRL_PH(st, 3 + 2 * (K - 2));
 }
 
 // reduce_repeat (utils.nim:220-233) + the final multiply (:271) on a packed result
@@ -296,21 +404,25 @@ STRL_DEV uint32_t reduce_packed(uint32_t r) {
   return b | (1u << 12) | (((r >> 16) * k) << 16);
 }
 
-// Whole ladder for one segment.  Wave-uniform call; `active` lanes own a segment.
+// The ladder is cut in two so that the expensive, rarely reached k = 4..6 passes run on a dense
+// set of survivors instead of dragging every wave through them for one or two live lanes:
+//   stage A: N filter (utils.nim:238), k = 2, 3, 4.   st.alive afterwards <=> the loop reaches k = 5
+//            (~12 % of scored 150 bp reads in the S1 mix; 60 % would survive a cut after k = 3).
+//   stage B: k = 5, 6 from a carried (best, res0, res1).
 template <int NW, int SLOTS>
-STRL_DEV void score_segment(const Seg<NW> &sg, bool active, uint32_t *wave_tab, int lane, const uint16_t *lut,
-                            const uint16_t *thr, int row0, int row1, uint32_t &out0, uint32_t &out1) {
-  ScoreState st;
+STRL_DEV void score_stage_a(const Seg<NW> &sg, bool active, uint32_t *wave_tab, int lane, const uint16_t *lut, const LaneThr &t,
+                            ScoreState &st) {
   st.best = -1;
-  st.alive = active && sg.n_N <= 20;  // utils.nim:238
+  st.alive = active && sg.n_N <= 20;
   st.res0 = st.res1 = 0;
-  score_k<2, NW, SLOTS>(sg, st, wave_tab, lane, lut, thr, row0, row1);
-  score_k<3, NW, SLOTS>(sg, st, wave_tab, lane, lut, thr, row0, row1);
-  score_k<4, NW, SLOTS>(sg, st, wave_tab, lane, lut, thr, row0, row1);
-  score_k<5, NW, SLOTS>(sg, st, wave_tab, lane, lut, thr, row0, row1);
-  score_k<6, NW, SLOTS>(sg, st, wave_tab, lane, lut, thr, row0, row1);
-  out0 = reduce_packed(st.res0);
-  out1 = reduce_packed(st.res1);
+  score_k<2, NW, SLOTS>(sg, st, wave_tab, lane, lut, t);
+  score_k<3, NW, SLOTS>(sg, st, wave_tab, lane, lut, t);
+  score_k<4, NW, SLOTS>(sg, st, wave_tab, lane, lut, t);
+}
+template <int NW, int SLOTS>
+STRL_DEV void score_stage_b(const Seg<NW> &sg, uint32_t *wave_tab, int lane, const uint16_t *lut, const LaneThr &t, ScoreState &st) {
+  score_k<5, NW, SLOTS>(sg, st, wave_tab, lane, lut, t);
+  score_k<6, NW, SLOTS>(sg, st, wave_tab, lane, lut, t);
 }
 
 }  // namespace strl

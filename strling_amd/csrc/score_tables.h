@@ -27,17 +27,20 @@ inline void build_lut(std::vector<uint16_t> &lut) {
   }
 }
 
-inline void build_thr(const strl_opts &o, std::vector<uint16_t> &thr) {
-  thr.assign(4 * THR_ROW, 0);
+inline void build_thr(const strl_opts &o, std::vector<uint64_t> &thr) {
+  thr.assign(4 * THR_LMAX, 0);
   const double p = o.proportion_repeat;
   const double ps[4] = {0.12, p, p - 0.07, std::min(p, 0.6)};  // utils.nim:251,259; extract.nim:242,208
   for (int row = 0; row < 4; ++row)
-    for (int k = 2; k <= 6; ++k)
-      for (int L = 0; L < THR_LMAX; ++L) {
+    for (int L = 0; L < THR_LMAX; ++L) {
+      uint64_t w = 0;
+      for (int k = 2; k <= 6; ++k) {
         int v = (int)((double)L * ps[row] / (double)k);
-        thr[row * THR_ROW + (k - 2) * THR_LMAX + L] = (uint16_t)std::max(0, std::min(v, 65535));
+        v = std::max(0, std::min(v, 255));   // L <= 510: only p > 1 could exceed a byte, and then nothing passes anyway
+        w |= (uint64_t)v << (8 * (k - 2));
       }
+      thr[row * THR_LMAX + L] = w;
+    }
 }
-
 
 }  // namespace strl

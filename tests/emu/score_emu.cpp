@@ -9,11 +9,13 @@
 
 using namespace strl;
 
-static std::vector<uint16_t> g_lut, g_thr;
+static std::vector<uint16_t> g_lut;
+static std::vector<uint64_t> g_thr;
+static bool g_last_alive = false;
 
 template <int NW, int SLOTS>
 static void run(const uint8_t *seq4, int s0, int len, int row0, int row1, uint32_t *o0, uint32_t *o1) {
-  static uint32_t tab[SLOTS + 8];
+  static uint32_t tab[SLOTS + 8];   // SLOTS rows + the dummy row
   constexpr int MAXCH = (16 * NW + 62) / 32;
   const int s0l = s0 & 31;
   const int nch = (s0l + len + 31) >> 5;
@@ -21,10 +23,24 @@ static void run(const uint8_t *seq4, int s0, int len, int row0, int row1, uint32
   for (int c = 0; c < MAXCH && c < nch; ++c) memcpy(&tab[4 * c], src + 16 * c, 16);
   Seg<NW> sg;
   seg_from_raw<NW>(tab, s0l, len, sg);
-  score_segment<NW, SLOTS>(sg, true, tab, 0, g_lut.data(), g_thr.data(), row0, row1, *o0, *o1);
+  // run the two stages the way the kernels do: stage A, hand the state over, re-stage the bases, stage B
+  ScoreState st;
+  LaneThr lt;
+  load_thr(g_thr.data(), row0, row1, len, lt);
+  score_stage_a<NW, SLOTS>(sg, true, tab, 0, g_lut.data(), lt, st);
+  g_last_alive = st.alive;
+  if (st.alive) {
+    for (int c = 0; c < MAXCH && c < nch; ++c) memcpy(&tab[4 * c], src + 16 * c, 16);
+    Seg<NW> sg2;
+    seg_from_raw<NW>(tab, s0l, len, sg2);
+    score_stage_b<NW, SLOTS>(sg2, tab, 0, g_lut.data(), lt, st);
+  }
+  *o0 = reduce_packed(st.res0);
+  *o1 = reduce_packed(st.res1);
 }
 
 extern "C" {
+int emu_last_alive() { return g_last_alive ? 1 : 0; }
 void emu_set_p(double p) {
   strl_opts o{};
   o.proportion_repeat = p;
