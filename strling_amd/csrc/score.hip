@@ -76,8 +76,7 @@ struct ScoreParams {
   const uint16_t *lut;
   const uint64_t *thr;
   uint32_t *whole;
-  uint32_t *queue_r;   // [n]      read indices the skip predicate kept (classify)
-  uint4 *queue;        // [n]      scoring queue entries built from queue_r (entries_kernel)
+  uint4 *queue;        // [n]      scoring queue (classify -> stage A, whole reads)
   uint4 *soft_dense;   // [2n]     two slots per scored read (left / right clip) or EMPTY
   uint4 *soft_queue;   // [scap]   compacted soft-clip items
   uint4 *sb_state[2];  // dense hand-over of stage A: {best | EMPTY, res0, res1, -} per item
@@ -92,7 +91,7 @@ struct ScoreParams {
 constexpr int LUT_DWORDS = LUT_ENTRIES / 2;
 constexpr int LUT_A_DWORDS = LUT_OFF5 / 2;   // stage A only looks up k <= 4
 constexpr int CL_STAGE = 1024;   // queue entries a wave stages in LDS before one bulk append
-constexpr int CL_ILP = 4;        // reads per lane per iteration (independent lookup chains in flight)
+constexpr int CL_ILP = 8;        // reads per lane per iteration (independent lookup chains in flight)
 
 // extract.nim:30-34: single-M cigar, chromosome in the table, no interval overlapping [start, stop)
 __device__ __forceinline__ bool skip_predicate(const ScoreParams &P, uint32_t cg, int32_t t, int32_t start, int32_t stop) {
@@ -122,9 +121,9 @@ __device__ __forceinline__ bool skip_predicate(const ScoreParams &P, uint32_t cg
 }
 
 __global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
-  // Each wave owns one contiguous range of reads; queue entries are staged in LDS and appended with one atomic
-  // per flush (one same-address atomic per wave-iteration ran into the ~88 ops/us limit of the L2 atomic unit:
-  // 12 ms per 2^25 reads).
+  // Each wave owns one contiguous range of reads.  Kept read indices are staged in LDS; a flush reserves queue
+  // space with ONE global atomic (one same-address atomic per wave-iteration ran into the ~88 ops/us limit of
+  // the L2 atomic unit: 12 ms per 2^25 reads) and gathers the reads' metadata into self-contained 16-byte items.
   __shared__ uint32_t stage[4][CL_STAGE + 64 * CL_ILP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t *buf = stage[wave];
@@ -141,29 +140,42 @@ __global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
       if (lane == 0) b = atomicAdd(&P.counters[CNT_QUEUE], cnt);
       b = __shfl(b, 0);
       __builtin_amdgcn_wave_barrier();
-      for (uint32_t i = lane; i < cnt; i += 64) P.queue_r[b + i] = buf[i];
+      for (uint32_t i = lane; i < cnt; i += 64) {
+        const uint32_t r = buf[i];
+        uint4 e;
+        e.x = r;
+        e.y = P.seq_off[r];
+        e.z = (uint32_t)P.l_seq[r] | ((uint32_t)P.clip_l[r] << 16);
+        e.w = (uint32_t)P.clip_r[r] | ((uint32_t)P.cig[r] << 16) | ((uint32_t)P.mapq[r] << 24);
+        P.queue[b + i] = e;
+      }
       __builtin_amdgcn_wave_barrier();
       cnt = 0;
     }
   };
-  for (uint64_t base = r0; base < r1; base += 64 * CL_ILP) {
-    bool need[CL_ILP], skipped[CL_ILP];
-    uint32_t cg[CL_ILP];
-    int32_t t[CL_ILP], st[CL_ILP], en[CL_ILP];
+  struct In { uint32_t cg; int32_t t, st, en; };
+  auto load = [&](uint64_t base, In (&x)[CL_ILP]) {
 #pragma unroll
     for (int j = 0; j < CL_ILP; ++j) {
       const uint64_t r = base + 64 * j + lane;
       const bool in = r < r1;
-      cg[j] = in ? P.cig[r] : 0u;
-      t[j] = in ? P.tid[r] : -1;
-      st[j] = in ? P.pos[r] : 0;
-      en[j] = in ? P.end[r] : 0;
-      need[j] = in;
+      x[j].cg = in ? P.cig[r] : 0u;
+      x[j].t = in ? P.tid[r] : -1;
+      x[j].st = in ? P.pos[r] : 0;
+      x[j].en = in ? P.end[r] : 0;
     }
+  };
+  In cur[CL_ILP], nxt[CL_ILP];
+  load(r0, cur);
+  for (uint64_t base = r0; base < r1; base += 64 * CL_ILP) {
+    load(base + 64 * CL_ILP, nxt);   // next iteration's streaming loads fly while this one chases the interval table
+    bool need[CL_ILP], skipped[CL_ILP];
 #pragma unroll
     for (int j = 0; j < CL_ILP; ++j) {
-      skipped[j] = need[j] && skip_predicate(P, cg[j], t[j], st[j], en[j]);
-      if (skipped[j]) { P.whole[base + 64 * j + lane] = STRL_RES_SKIPPED; need[j] = false; }
+      const bool in = base + 64 * j + lane < r1;
+      skipped[j] = in && skip_predicate(P, cur[j].cg, cur[j].t, cur[j].st, cur[j].en);
+      need[j] = in && !skipped[j];
+      if (skipped[j]) P.whole[base + 64 * j + lane] = STRL_RES_SKIPPED;
     }
 #pragma unroll
     for (int j = 0; j < CL_ILP; ++j) {
@@ -173,24 +185,11 @@ __global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
       cnt += (uint32_t)__popcll(m);
     }
     if (cnt >= CL_STAGE) flush();
+#pragma unroll
+    for (int j = 0; j < CL_ILP; ++j) cur[j] = nxt[j];
   }
   flush();
   if (lane == 0 && nskip) atomicAdd(&P.counters[CNT_SKIP], nskip);
-}
-
-// Builds the self-contained 16-byte work items of the kept reads (scattered metadata gathers; full occupancy,
-// nothing downstream of them in this kernel, so their latency is free).
-__global__ __launch_bounds__(256) void entries_kernel(ScoreParams P) {
-  const uint32_t nq = P.counters[CNT_QUEUE];
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nq; i += gridDim.x * 256u) {
-    const uint32_t r = P.queue_r[i];
-    uint4 e;
-    e.x = r;
-    e.y = P.seq_off[r];
-    e.z = (uint32_t)P.l_seq[r] | ((uint32_t)P.clip_l[r] << 16);
-    e.w = (uint32_t)P.clip_r[r] | ((uint32_t)P.cig[r] << 16) | ((uint32_t)P.mapq[r] << 24);
-    P.queue[i] = e;
-  }
 }
 
 // Order-preserving-within-block compaction of a dense array with EMPTY holes into a queue: one global atomic
@@ -583,7 +582,6 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   const uint64_t n1 = std::max<uint64_t>(n, 1);
   const uint64_t scap = std::max<uint64_t>(std::min<uint64_t>(soft_cap, 2 * n), 1);
   if ((rc = c->queue.reserve((size_t)n1 * 16))) return rc;
-  if ((rc = c->queue_r.reserve((size_t)n1 * 4))) return rc;
   if ((rc = c->soft_dense.reserve((size_t)n1 * 32))) return rc;
   if ((rc = c->soft_queue.reserve((size_t)scap * 16))) return rc;
   if ((rc = c->sb_state_w.reserve((size_t)n1 * 16))) return rc;
@@ -598,7 +596,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   P.g_tid = c->g_tid.as<TidInfo>(); P.g_bins = c->g_bins.as<uint32_t>(); P.g_iv = c->g_start.as<int2>();
   P.n_tid = c->n_tid;
   P.lut = c->lut.as<uint16_t>(); P.thr = c->thr.as<uint64_t>();
-  P.whole = whole; P.queue = c->queue.as<uint4>(); P.queue_r = c->queue_r.as<uint32_t>(); P.soft_dense = c->soft_dense.as<uint4>();
+  P.whole = whole; P.queue = c->queue.as<uint4>(); P.soft_dense = c->soft_dense.as<uint4>();
   P.soft_queue = c->soft_queue.as<uint4>();
   P.sb_state[0] = c->sb_state_w.as<uint4>(); P.sb_state[1] = c->sb_state_s.as<uint4>();
   P.sb_queue[0] = c->sb_whole.as<uint4>(); P.sb_queue[1] = c->sb_soft.as<uint4>();
@@ -612,7 +610,6 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   if (n) {
     const int cblocks = (int)std::min<uint64_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(classify_kernel, dim3(cblocks), dim3(256), 0, c->stream, P);
-    hipLaunchKernelGGL(entries_kernel, dim3(1024), dim3(256), 0, c->stream, P);
     STRL_HIP(hipGetLastError());
   }
   if (tev) STRL_HIP(hipEventRecord(tev[1], c->stream));
