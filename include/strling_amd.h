@@ -173,6 +173,16 @@ typedef struct {
 int strl_pair_reads(const strl_records *rec, const strl_opts *opts, const uint32_t *whole, const strl_soft_rec *soft,
                     uint64_t n_soft, int64_t n_tail, strl_tread *out, uint64_t cap, uint64_t *n_out);
 
+/* Streaming form of the pair logic: the reference's Cache (extract.nim:89-91,298) kept alive across batches fed in
+ * file order.  Emitted treads accumulate inside the pairer; their qname_id indexes the pairer's own qname arena.
+ * The caller replays the unmapped tail a second time itself (extract.nim:326-329). */
+typedef struct strl_pairer strl_pairer;
+int strl_pairer_create(const strl_opts *opts, strl_pairer **pairer);
+void strl_pairer_destroy(strl_pairer *pairer);
+int strl_pairer_add(strl_pairer *pairer, const strl_records *rec, const uint32_t *whole, const strl_soft_rec *soft, uint64_t n_soft);
+int strl_pairer_result(strl_pairer *pairer, const strl_tread **treads, uint64_t *n, const uint64_t **qname_off,
+                       const char **qnames, uint64_t *n_pending);
+
 /* The extract hot loop end to end on one batch: SoA derivation + device scoring + pair logic
  * (replaces extract.nim:308-329). */
 int strl_extract(strl_ctx *ctx, const strl_records *rec, int64_t n_tail, strl_tread *out, uint64_t cap, uint64_t *n_out,

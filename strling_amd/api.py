@@ -72,7 +72,8 @@ MODE_MERGE, MODE_CALL = 0, 1
 # every symbol include/strling_amd.h declares
 EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_create", "strl_ctx_destroy", "strl_ctx_stream",
            "strl_ctx_sync", "strl_ctx_set_opts", "strl_ctx_set_genome", "strl_soa_from_records", "strl_score_reads",
-           "strl_ctx_enable_timing", "strl_ctx_kernel_times", "strl_pair_reads", "strl_extract", "strl_cluster", "strl_frag_median",
+           "strl_ctx_enable_timing", "strl_ctx_kernel_times", "strl_pair_reads", "strl_pairer_create", "strl_pairer_destroy", "strl_pairer_add",
+           "strl_pairer_result", "strl_extract", "strl_cluster", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row"]
 
 

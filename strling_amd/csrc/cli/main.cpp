@@ -1,0 +1,406 @@
+// strling -- command-line front end over libstrling_amd.so, keeping the reference's CLI surface and files:
+//   strling extract [-f FASTA] [-g STR.bed] [-p 0.8] [-q 40] [-v] BAM BIN      (src/strpkg/extract.nim:250-350)
+//   strling merge   [-w -1] [-m 5] [-c 0] [-t 0] [-q 40] [-o PREFIX] [-v] BIN...  (src/strpkg/merge.nim:47-191)
+// The BAM is decoded on the host (own BGZF/BAM reader), batches go through the C ABI into the HIP kernels,
+// the pair logic runs in the streaming pairer, and the .bin / -bounds.txt writers are byte-compatible with the
+// reference's.  Not in this build (SURVEY.md section 8f "next"): CRAM input, building the genome STR index when -g
+// does not exist (`strling index`), `strling call` (needs the spanning-read evidence of collect.nim), -l/--bed loci.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <chrono>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../../include/strling_amd.h"
+#include "bam_reader.h"
+
+using namespace strl;
+
+[[noreturn]] static void quit(const char *fmt, ...) {   // Nim `quit msg`: message on stderr, exit code 1
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(stderr, fmt, ap);
+  va_end(ap);
+  fputc('\n', stderr);
+  exit(1);
+}
+#define CHECK(call)                                                        \
+  do {                                                                     \
+    const int rc__ = (call);                                               \
+    if (rc__ != 0) quit("[strling] %s (status %d)", strl_last_error(), rc__); \
+  } while (0)
+
+struct Args {
+  std::map<std::string, std::string> opt;
+  std::vector<std::string> pos;
+  bool flag(const char *k) const { return opt.count(k) != 0; }
+  std::string get(const char *k, const char *dflt) const { auto it = opt.find(k); return it == opt.end() ? dflt : it->second; }
+};
+
+// long name -> (short name, takes value)
+struct OptSpec { const char *longn; char shortn; bool value; };
+
+static Args parse(int argc, char **argv, int first, const std::vector<OptSpec> &specs, const char *usage) {
+  Args a;
+  for (int i = first; i < argc; ++i) {
+    std::string s = argv[i];
+    if (s == "-h" || s == "--help") { fputs(usage, stdout); exit(0); }
+    const OptSpec *sp = nullptr;
+    if (s.size() > 2 && s[0] == '-' && s[1] == '-') {
+      for (auto &x : specs) if (s.substr(2) == x.longn) sp = &x;
+      if (!sp) quit("unknown option %s\n%s", s.c_str(), usage);
+    } else if (s.size() == 2 && s[0] == '-' && s[1] != '-') {
+      for (auto &x : specs) if (s[1] == x.shortn) sp = &x;
+      if (!sp) quit("unknown option %s\n%s", s.c_str(), usage);
+    }
+    if (!sp) { a.pos.push_back(s); continue; }
+    if (sp->value) {
+      if (i + 1 >= argc) quit("option %s needs a value", s.c_str());
+      a.opt[sp->longn] = argv[++i];
+    } else a.opt[sp->longn] = "1";
+  }
+  return a;
+}
+
+static std::vector<BamTarget> targets_from_header(const std::string &text) {
+  std::vector<BamTarget> t;
+  size_t p = 0;
+  while (p < text.size()) {
+    size_t e = text.find('\n', p);
+    if (e == std::string::npos) e = text.size();
+    const std::string line = text.substr(p, e - p);
+    if (line.rfind("@SQ", 0) == 0) {
+      BamTarget bt{"", 0};
+      size_t q = 0;
+      while (q < line.size()) {
+        size_t f = line.find('\t', q);
+        if (f == std::string::npos) f = line.size();
+        const std::string fld = line.substr(q, f - q);
+        if (fld.rfind("SN:", 0) == 0) bt.name = fld.substr(3);
+        if (fld.rfind("LN:", 0) == 0) bt.length = (uint32_t)strtoul(fld.c_str() + 3, nullptr, 10);
+        q = f + 1;
+      }
+      t.push_back(bt);
+    }
+    p = e + 1;
+  }
+  return t;
+}
+
+static void append_record(RecordBatch &dst, const RecordBatch &src, size_t i) {
+  dst.tid.push_back(src.tid[i]); dst.pos.push_back(src.pos[i]); dst.mtid.push_back(src.mtid[i]); dst.mpos.push_back(src.mpos[i]);
+  dst.isize.push_back(src.isize[i]); dst.l_seq.push_back(src.l_seq[i]); dst.flag.push_back(src.flag[i]); dst.mapq.push_back(src.mapq[i]);
+  for (uint32_t c = src.cigar_off[i]; c < src.cigar_off[i + 1]; ++c) dst.cigar.push_back(src.cigar[c]);
+  dst.cigar_off.push_back((uint32_t)dst.cigar.size());
+  dst.qnames.append(src.qnames, src.qname_off[i], src.qname_off[i + 1] - src.qname_off[i]);
+  dst.qname_off.push_back(dst.qnames.size());
+  const size_t so = (dst.seq4.size() + 15) & ~(size_t)15, sb = (size_t)(src.l_seq[i] + 1) / 2;
+  dst.seq4.resize(so + sb, 0);
+  memcpy(dst.seq4.data() + so, src.seq4.data() + src.seq_off[i], sb);
+  dst.seq_off.push_back(so);
+}
+
+// utils.nim:86-111
+static void fragment_length_distribution(const std::string &bam, uint32_t frag[4096]) {
+  const int64_t n_reads = 2000000, skip_reads = 100000;
+  memset(frag, 0, 4096 * sizeof(uint32_t));
+  BamReader rd;
+  std::string err;
+  if (!rd.open(bam, err)) quit("couldn't open bam");
+  RecordBatch b;
+  std::vector<int32_t> skipped;
+  int64_t i = -1, counted = 0;
+  bool done = false;
+  while (!done) {
+    b.clear();
+    const int64_t got = rd.read(b, 1 << 16, err);
+    if (got < 0) quit("[strling] error reading %s: %s", bam.c_str(), err.c_str());
+    if (got == 0) break;
+    for (int64_t k = 0; k < got; ++k) {
+      ++i;
+      const uint16_t f = b.flag[(size_t)k];
+      if (!(f & 0x2)) continue;
+      if (f & (0x800 | 0x100)) continue;
+      const int32_t is = b.isize[(size_t)k];
+      if (is < 0 || is > 4095) continue;
+      if (i < skip_reads) { skipped.push_back(is); continue; }
+      skipped.clear();
+      frag[is]++;
+      if (++counted > n_reads) { done = true; break; }
+    }
+  }
+  uint64_t sum = 0;
+  for (int k = 0; k < 4096; ++k) sum += frag[k];
+  if ((uint32_t)sum == 0) {
+    fprintf(stderr, "using first reads in fragment_length_distribution calculation as there were not enough\n");
+    for (int32_t is : skipped) frag[is]++;
+  }
+}
+
+// read_bed.nim:18-50 + genome_strs.nim:107-135 (existing file only), flattened per BAM tid
+struct Genome {
+  std::vector<uint8_t> has;
+  std::vector<int64_t> off;
+  std::vector<int32_t> st, en;
+};
+static Genome read_genome_bed(const std::string &path, const std::vector<BamTarget> &targets) {
+  FILE *f = fopen(path.c_str(), "r");
+  if (!f) quit("[strling] genome repeats file %s does not exist; building it (`strling index`) is not part of this build -- supply an existing file with -g", path.c_str());
+  std::map<std::string, int> tid;
+  for (size_t i = 0; i < targets.size(); ++i) tid[targets[i].name] = (int)i;
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> per(targets.size());
+  Genome g;
+  g.has.assign(targets.size(), 0);
+  char line[1 << 16];
+  while (fgets(line, sizeof line, f)) {
+    if (line[0] == '#' || strncmp(line, "track ", 6) == 0) continue;
+    char chrom[4096];
+    long a, b;
+    if (sscanf(line, "%4095[^\t]\t%ld\t%ld", chrom, &a, &b) != 3) { fprintf(stderr, "[slivar] skipping bad bed line:%s", line); continue; }
+    auto it = tid.find(chrom);
+    if (it == tid.end()) continue;
+    g.has[(size_t)it->second] = 1;
+    per[(size_t)it->second].push_back({(int32_t)a, (int32_t)b});
+  }
+  fclose(f);
+  g.off.assign(targets.size() + 1, 0);
+  for (size_t t = 0; t < targets.size(); ++t) {
+    for (auto &iv : per[t]) { g.st.push_back(iv.first); g.en.push_back(iv.second); }
+    g.off[t + 1] = (int64_t)g.st.size();
+  }
+  return g;
+}
+
+static int extract_main(int argc, char **argv) {
+  const char *usage =
+      "strling extract\n\nUsage:\n  strling extract [options] bam bin\n\nArguments:\n  bam              path to bam file\n"
+      "  bin              path bin to output bin file to be created\n\nOptions:\n  -f, --fasta=FASTA          path to fasta file (required for CRAM)\n"
+      "  -g, --genome-repeats=GENOME_REPEATS\n                             path to genome repeats file (must exist in this build)\n"
+      "  -p, --proportion-repeat=PROPORTION_REPEAT\n                             proportion of read that is repetitive to be considered as STR (default: 0.8)\n"
+      "  -q, --min-mapq=MIN_MAPQ    minimum mapping quality (does not apply to STR reads) (default: 40)\n  -v, --verbose\n  -h, --help                 Show this help\n";
+  if (argc <= 2) { fputs(usage, stdout); return 0; }
+  const Args a = parse(argc, argv, 2, {{"fasta", 'f', true}, {"genome-repeats", 'g', true}, {"proportion-repeat", 'p', true},
+                                       {"min-mapq", 'q', true}, {"verbose", 'v', false}, {"batch", 'B', true}}, usage);
+  if (a.pos.size() != 2) quit("expected 2 arguments (bam, bin)\n%s", usage);
+  const std::string bam = a.pos[0], bin = a.pos[1];
+  const double p = atof(a.get("proportion-repeat", "0.8").c_str());
+  const uint8_t min_mapq = (uint8_t)atoi(a.get("min-mapq", "40").c_str());
+  const bool verbose = a.flag("verbose");
+  const int64_t batch = atoll(a.get("batch", "2097152").c_str());
+
+  uint32_t frag[4096];
+  fragment_length_distribution(bam, frag);                                        // extract.nim:281
+  const int frag_median = strl_frag_median(frag, 0.5);
+  if (verbose) {
+    fprintf(stderr, "Calculated median fragment length:%d\n", frag_median);
+    fprintf(stderr, "10th, 90th percentile of fragment length:%d %d\n", strl_frag_median(frag, 0.1), strl_frag_median(frag, 0.9));
+  }
+  BamReader rd;
+  std::string err;
+  if (!rd.open(bam, err)) quit("couldn't open bam");
+  if (!a.flag("genome-repeats")) quit("[strling] -g/--genome-repeats is required in this build (building the genome STR index is not implemented)");
+  const Genome g = read_genome_bed(a.get("genome-repeats", ""), rd.targets());
+  fprintf(stderr, "[strling] using existing file %s for genome repeats\n", a.get("genome-repeats", "").c_str());
+
+  strl_ctx *ctx = nullptr;
+  CHECK(strl_ctx_create(0, &ctx));
+  strl_opts opts{frag_median, p, min_mapq};
+  CHECK(strl_ctx_set_opts(ctx, &opts));
+  strl_genome_str gs{(int32_t)rd.targets().size(), g.has.data(), g.off.data(), g.st.data(), g.en.data()};
+  CHECK(strl_ctx_set_genome(ctx, &gs));
+  strl_pairer *pairer = nullptr;
+  CHECK(strl_pairer_create(&opts, &pairer));
+
+  std::vector<int32_t> end;
+  std::vector<uint32_t> so, whole;
+  std::vector<uint16_t> ls, cl, cr;
+  std::vector<uint8_t> cig;
+  std::vector<strl_soft_rec> soft;
+  auto run_batch = [&](RecordBatch &b) {
+    const size_t n = b.size();
+    if (!n) return;
+    strl_records rec = b.view();
+    end.resize(n); so.resize(n); whole.resize(n); ls.resize(n); cl.resize(n); cr.resize(n); cig.resize(n); soft.resize(2 * n + 2);
+    uint32_t mx = 0;
+    CHECK(strl_soa_from_records(&rec, end.data(), so.data(), ls.data(), cl.data(), cr.data(), cig.data(), &mx));
+    strl_read_soa soa{};
+    soa.n = n; soa.tid = rec.tid; soa.pos = rec.pos; soa.end = end.data(); soa.seq_off = so.data(); soa.l_seq = ls.data();
+    soa.clip_l = cl.data(); soa.clip_r = cr.data(); soa.mapq = rec.mapq; soa.cig = cig.data(); soa.seq4 = rec.seq4;
+    soa.seq4_bytes = b.seq4.size(); soa.max_l_seq = mx; soa.mem = STRL_MEM_HOST;
+    uint64_t ns = 0;
+    CHECK(strl_score_reads(ctx, &soa, whole.data(), soft.data(), 2 * n, &ns, nullptr));
+    CHECK(strl_pairer_add(pairer, &rec, whole.data(), soft.data(), ns));
+  };
+
+  fprintf(stderr, "[strling] collecting str-like reads\n");
+  const auto t0 = std::chrono::steady_clock::now();
+  RecordBatch b, tail;
+  int64_t nreads = 0, last_tid = -1;
+  for (;;) {
+    b.clear();
+    const int64_t got = rd.read(b, batch, err);
+    if (got < 0) quit("[strling] error reading %s: %s", bam.c_str(), err.c_str());
+    if (got == 0) break;
+    for (size_t i = 0; i < (size_t)got; ++i) {
+      const uint16_t f = b.flag[i];
+      if (b.tid[i] >= 0) tail.clear(); else append_record(tail, b, i);            // the "*" region: unplaced records at the end
+      if (f & (0x100 | 0x800)) continue;
+      if (b.tid[i] != last_tid && b.tid[i] >= 0) {
+        if (rd.targets()[(size_t)b.tid[i]].length > 2000000u) fprintf(stderr, "[strling] extracting chromosome:%s\n", rd.targets()[(size_t)b.tid[i]].name.c_str());
+        last_tid = b.tid[i];
+      }
+      ++nreads;
+    }
+    run_batch(b);
+    if (verbose) {
+      const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      fprintf(stderr, "%lld %.1f reads/sec\n", (long long)nreads, (double)nreads / std::max(s, 1e-9));
+    }
+  }
+  fprintf(stderr, "[strling] extracting unmapped reads\n");
+  for (size_t i = 0; i < tail.size(); ++i) if (!(tail.flag[i] & (0x100 | 0x800))) ++nreads;
+  run_batch(tail);                                                                // extract.nim:326-329
+
+  const strl_tread *treads;
+  const uint64_t *qoff;
+  const char *qn;
+  uint64_t nt = 0, pending = 0;
+  CHECK(strl_pairer_result(pairer, &treads, &nt, &qoff, &qn, &pending));
+  fprintf(stderr, "[strling] writing binary file:%s\n", bin.c_str());
+  CHECK(strl_bin_write(bin.c_str(), (float)p, min_mapq, frag, rd.header_text().data(), (int32_t)rd.header_text().size(), treads, nt, qoff, qn));
+  fprintf(stderr, "[strling] finished extraction\n");
+  if (verbose) fprintf(stderr, "[strling] %lld reads, %llu STR reads, %llu reads still waiting for a mate\n", (long long)nreads, (unsigned long long)nt, (unsigned long long)pending);
+  strl_pairer_destroy(pairer);
+  strl_ctx_destroy(ctx);
+  return 0;
+}
+
+static int merge_main(int argc, char **argv) {
+  const char *usage =
+      "strling merge\n\nUsage:\n  strling merge [options] [bin ...]\n\nOptions:\n  -w, --window=WINDOW        Number of bp within which to search for reads supporting the other side of a bound. "
+      "Estimated from the insert size distribution by default. (default: -1)\n  -m, --min-support=MIN_SUPPORT\n"
+      "                             minimum number of supporting reads required in at least one individual for a locus to be reported (default: 5)\n"
+      "  -c, --min-clip=MIN_CLIP    minimum number of supporting clipped reads for each side of a locus (default: 0)\n"
+      "  -t, --min-clip-total=MIN_CLIP_TOTAL\n                             minimum total number of supporting clipped reads for a locus (default: 0)\n"
+      "  -q, --min-mapq=MIN_MAPQ    minimum mapping quality (does not apply to STR reads) (default: 40)\n"
+      "  -o, --output-prefix=OUTPUT_PREFIX\n                             prefix for output files. Suffix will be -bounds.txt (default: strling)\n  -v, --verbose\n  -h, --help                 Show this help\n";
+  if (argc <= 2) { fputs(usage, stdout); return 0; }
+  const Args a = parse(argc, argv, 2, {{"fasta", 'f', true}, {"window", 'w', true}, {"min-support", 'm', true}, {"chromosome", 'C', true},
+                                       {"min-clip", 'c', true}, {"min-clip-total", 't', true}, {"min-mapq", 'q', true}, {"bed", 'l', true},
+                                       {"output-prefix", 'o', true}, {"diff-refs", 'd', false}, {"verbose", 'v', false}}, usage);
+  if (a.flag("bed")) quit("[strling] -l/--bed is not supported by this build");
+  if (a.flag("chromosome")) quit("[strling] --chromosome is not supported by this build");
+  int window = atoi(a.get("window", "-1").c_str());
+  const int min_support = atoi(a.get("min-support", "5").c_str());
+  const uint16_t min_clip = (uint16_t)atoi(a.get("min-clip", "0").c_str());
+  const uint16_t min_clip_total = (uint16_t)atoi(a.get("min-clip-total", "0").c_str());
+  const bool verbose = a.flag("verbose");
+  const std::string prefix = a.get("output-prefix", "strling");
+
+  uint32_t frag[4096] = {0};
+  std::vector<strl_tread> all;
+  std::string header0;
+  std::vector<BamTarget> targets;
+  for (size_t si = 0; si < a.pos.size(); ++si) {
+    const std::string &path = a.pos[si];
+    if (verbose) fprintf(stderr, "[strling] reading bin file: %s\n", path.c_str());
+    strl_bin_info info;
+    CHECK(strl_bin_read(path.c_str(), &info, nullptr, nullptr, nullptr, nullptr));
+    std::string hdr((size_t)info.header_len, '\0');
+    std::vector<strl_tread> t((size_t)std::max(1, info.n_reads));
+    std::vector<uint64_t> qo((size_t)info.n_reads + 1);
+    std::vector<char> qn((size_t)info.qnames_bytes + 1);
+    CHECK(strl_bin_read(path.c_str(), &info, &hdr[0], t.data(), qo.data(), qn.data()));
+    const std::vector<BamTarget> tg = targets_from_header(hdr);
+    if (si == 0) { header0 = hdr; targets = tg; }
+    else {
+      bool same = tg.size() == targets.size();
+      for (size_t k = 0; same && k < tg.size(); ++k) same = tg[k].name == targets[k].name && tg[k].length == targets[k].length;
+      if (!same && !a.flag("diff-refs")) quit("[strling] Error: inconsistent bam header for %s. Were all samples run on the same reference genome?", path.c_str());
+    }
+    for (int k = 0; k < 4096; ++k) {                                               // merge.nim:112-115
+      const uint32_t before = frag[k];
+      frag[k] += info.frag[k];
+      if (frag[k] < before) quit("overflow");
+    }
+    uint64_t kept = 0;
+    for (int32_t k = 0; k < info.n_reads; ++k) {
+      if (t[(size_t)k].tid < 0) continue;                                          // unpack_file(drop_unplaced=true)
+      t[(size_t)k].qname_id = (int64_t)si;                                         // merge.nim:118-125: qname := sample index
+      all.push_back(t[(size_t)k]);
+      ++kept;
+    }
+    fprintf(stderr, "[strling] read %llu STR reads from file: %s\n", (unsigned long long)kept, path.c_str());
+  }
+  if (verbose) {
+    fprintf(stderr, "[strling] read %llu STR reads across all samples.\n", (unsigned long long)all.size());
+    fprintf(stderr, "[strling] Calculated median fragment length accross all samples:%d\n", strl_frag_median(frag, 0.5));
+    fprintf(stderr, "[strling] 10th, 90th percentile of fragment length:%d %d\n", strl_frag_median(frag, 0.1), strl_frag_median(frag, 0.9));
+  }
+  if (window < 0) window = strl_frag_median(frag, 0.98);                           // merge.nim:151-152
+  const uint16_t max_clip_dist = (uint16_t)(0.5 * (double)strl_frag_median(frag, 0.5));   // merge.nim:181
+
+  strl_ctx *ctx = nullptr;
+  CHECK(strl_ctx_create(0, &ctx));
+  std::vector<strl_bounds> bounds(std::max<size_t>(all.size(), 16));
+  uint64_t nb = 0, nu = 0;
+  CHECK(strl_cluster(ctx, all.data(), all.size(), STRL_MODE_MERGE, (uint32_t)window, min_support, min_clip, min_clip_total, max_clip_dist,
+                     bounds.data(), bounds.size(), &nb, nullptr, 0, &nu, nullptr));
+  const std::string outp = prefix + "-bounds.txt";
+  FILE *fo = fopen(outp.c_str(), "w");
+  if (!fo) quit("couldn't open output file");
+  fputs("#chrom\tleft\tright\trepeat\tname\tleft_most\tright_most\tcenter_mass\tn_left\tn_right\tn_total\n", fo);   // cluster.nim:89
+  char row[1024];
+  for (uint64_t k = 0; k < nb; ++k) {
+    const strl_bounds &b = bounds[(size_t)k];
+    strl_bounds_row(row, sizeof row, &b, targets[(size_t)b.tid].name.c_str());
+    fputs(row, fo);
+    fputc('\n', fo);
+  }
+  fclose(fo);
+  if (verbose) fprintf(stderr, "[strling] Wrote merged str bounds to %s\n", outp.c_str());
+  strl_ctx_destroy(ctx);
+  return 0;
+}
+
+// `strling _dump BAM`: SAM-like text of every record as the reader decoded it (reader self-check; needs no GPU)
+static int dump_main(int argc, char **argv) {
+  if (argc < 3) quit("usage: strling _dump BAM");
+  BamReader rd;
+  std::string err;
+  if (!rd.open(argv[2], err)) quit("couldn't open bam");
+  fputs(rd.header_text().c_str(), stdout);
+  RecordBatch b;
+  for (;;) {
+    b.clear();
+    const int64_t got = rd.read(b, 4096, err);
+    if (got < 0) quit("[strling] error reading %s: %s", argv[2], err.c_str());
+    if (got == 0) break;
+    for (size_t i = 0; i < (size_t)got; ++i) {
+      std::string cig, seq;
+      for (uint32_t c = b.cigar_off[i]; c < b.cigar_off[i + 1]; ++c) cig += std::to_string(b.cigar[c] >> 4) + "MIDNSHP=X"[b.cigar[c] & 15];
+      for (int j = 0; j < b.l_seq[i]; ++j) seq += "=ACMGRSVTWYHKDBN"[(b.seq4[b.seq_off[i] + (size_t)(j >> 1)] >> ((~j & 1) << 2)) & 15];
+      printf("%s\t%u\t%d\t%d\t%u\t%s\t%d\t%d\t%d\t%s\n", b.qnames.substr(b.qname_off[i], b.qname_off[i + 1] - b.qname_off[i]).c_str(), b.flag[i],
+             b.tid[i], b.pos[i], b.mapq[i], cig.empty() ? "*" : cig.c_str(), b.mtid[i], b.mpos[i], b.isize[i], seq.empty() ? "*" : seq.c_str());
+    }
+  }
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  const char *top =
+      "strling version: 0.6.0 (MI355X-native hot path)\n\nCommands:\n  extract  :   extract informative STR reads from a BAM (CRAM is not supported by this build).\n"
+      "  merge    :   merge putitive STR loci from multiple samples.\n  call     :   (not in this build) call STRs.\n  index    :   (not in this build) identify large STRs in the reference genome.\n";
+  if (argc < 2) { fputs(top, stdout); return 1; }
+  const std::string cmd = argv[1];
+  if (cmd == "extract") return extract_main(argc, argv);
+  if (cmd == "merge") return merge_main(argc, argv);
+  if (cmd == "_dump") return dump_main(argc, argv);
+  if (cmd == "call" || cmd == "index" || cmd == "pull_region")
+    quit("[strling] `%s` is not part of this build (the MI355X path covers extract and merge; see DESIGN.md section 9)", cmd.c_str());
+  fputs(top, stdout);
+  return 1;
+}

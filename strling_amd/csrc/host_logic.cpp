@@ -133,21 +133,46 @@ struct RecView {
   }
 };
 
-struct Pairer {
+// Where first-seen treads wait for their mate and where emitted treads go.
+//  BatchStore : one batch is the whole input; keys are views into the batch's qname buffer, emitted treads keep
+//               qname_id = record index.
+//  StreamStore: batches arrive one after another (the CLI); keys and emitted qnames are owned copies, emitted
+//               treads get qname_id = index into the store's own qname arena.
+struct BatchStore {
+  std::unordered_map<std::string_view, strl_tread> tbl;
+  strl_tread *out = nullptr;
+  uint64_t cap = 0, n_out = 0;
+  strl_tread *find(std::string_view q) { auto it = tbl.find(q); return it == tbl.end() ? nullptr : &it->second; }
+  void erase(std::string_view q) { tbl.erase(q); }
+  void insert(std::string_view q, const strl_tread &t) { tbl.emplace(q, t); }
+  void emit(strl_tread t, std::string_view) { if (n_out < cap) out[n_out] = t; ++n_out; }
+};
+struct StreamStore {
+  std::unordered_map<std::string, strl_tread> tbl;
+  std::vector<strl_tread> out;
+  std::vector<uint64_t> qoff{0};
+  std::string qnames;
+  std::string key;
+  strl_tread *find(std::string_view q) { key.assign(q); auto it = tbl.find(key); return it == tbl.end() ? nullptr : &it->second; }
+  void erase(std::string_view q) { key.assign(q); tbl.erase(key); }
+  void insert(std::string_view q, const strl_tread &t) { tbl.emplace(std::string(q), t); }
+  void emit(strl_tread t, std::string_view q) {
+    t.qname_id = (int64_t)out.size();
+    out.push_back(t);
+    qnames.append(q);
+    qoff.push_back(qnames.size());
+  }
+};
+
+template <class Store> struct Pairer {
   RecView rv;
   const strl_opts *o;
   const uint32_t *whole;
   const strl_soft_rec *soft;
   uint64_t n_soft;
-  strl_tread *out;
-  uint64_t cap, n_out = 0;
+  Store &S;
   int err = 0;
-  std::unordered_map<std::string_view, strl_tread> tbl;
 
-  void push(const strl_tread &t) {
-    if (n_out < cap) out[n_out] = t;
-    ++n_out;
-  }
   const strl_soft_rec *find_soft(int64_t i, int side) const {
     const uint32_t key = ((uint32_t)i << 1) | (uint32_t)side;
     const strl_soft_rec *e = soft + n_soft;
@@ -178,7 +203,7 @@ struct Pairer {
     return t;
   }
   // add_soft, extract.nim:93-132, consuming the device's soft-clip records
-  void add_soft(int64_t i, bool first_seen, const char read_repeat[6]) {
+  void add_soft(int64_t i, bool first_seen, const char read_repeat[6], std::string_view qn) {
     const strl_records *r = rv.r;
     if (r->mapq[i] < o->min_mapq) return;
     const int L = rv.ncig(i);
@@ -209,22 +234,22 @@ struct Pairer {
       t.mapping_quality = r->mapq[i];
       t.qname_id = i;
       if (p_repeat(t) < 0.9) continue;
-      push(t);
+      S.emit(t, qn);
     }
   }
   // Cache.add, extract.nim:192-248
   void add(int64_t i) {
     const strl_records *r = rv.r;
     const std::string_view qn = rv.qname(i);
-    auto it = tbl.find(qn);
+    strl_tread *stored = S.find(qn);
     const int32_t tid = r->tid[i], mtid = r->mtid[i], start = r->pos[i], mpos = r->mpos[i];
-    const bool after_mate = tid > mtid || (tid == mtid && (start > mpos || (start == mpos && it != tbl.end())));
+    const bool after_mate = tid > mtid || (tid == mtid && (start > mpos || (start == mpos && stored != nullptr)));
     if (after_mate) {
-      if (it == tbl.end()) return;
-      strl_tread mate = it->second;
-      tbl.erase(it);
+      if (!stored) return;
+      strl_tread mate = *stored;
+      S.erase(qn);
       strl_tread self = to_tread(i);
-      add_soft(i, false, self.repeat);
+      add_soft(i, false, self.repeat, qn);
       if (mate.repeat_count == 0 && self.repeat_count == 0) return;
       if (unplaced_pair(self, mate, *o)) {
         if (self.repeat[0] == 0 || mate.repeat[0] == 0) return;
@@ -234,18 +259,18 @@ struct Pairer {
         canonical_repeat(mate.repeat);
         mate.position = 0;
         mate.tid = -1;
-        push(self);
-        push(mate);
+        S.emit(self, qn);
+        S.emit(mate, qn);
         return;
       }
       const uint32_t mp = mate.position;
-      if (adjust_by(mate, self, *o, self.position)) push(mate);
-      if (adjust_by(self, mate, *o, mp)) push(self);
+      if (adjust_by(mate, self, *o, self.position)) S.emit(mate, qn);
+      if (adjust_by(self, mate, *o, mp)) S.emit(self, qn);
     } else {
       strl_tread tr = to_tread(i);
-      add_soft(i, true, tr.repeat);
-      if (it != tbl.end()) tbl.erase(it);  // hasKeyOrPut hit: warn + take, the new tread is not stored (:245-248)
-      else tbl.emplace(qn, tr);
+      add_soft(i, true, tr.repeat, qn);
+      if (stored) S.erase(qn);  // hasKeyOrPut hit: warn + take, the new tread is not stored (:245-248)
+      else S.insert(qn, tr);
     }
   }
 };
@@ -296,7 +321,10 @@ int strl_soa_from_records(const strl_records *rec, int32_t *end, uint32_t *seq_o
 int strl_pair_reads(const strl_records *rec, const strl_opts *opts, const uint32_t *whole, const strl_soft_rec *soft,
                     uint64_t n_soft, int64_t n_tail, strl_tread *out, uint64_t cap, uint64_t *n_out) {
   if (!rec || !opts || (!whole && rec->n) || (!out && cap)) { set_error("null argument"); return STRL_ERR_ARG; }
-  Pairer P{RecView{rec}, opts, whole, soft, n_soft, out, cap};
+  BatchStore store;
+  store.out = out;
+  store.cap = cap;
+  Pairer<BatchStore> P{RecView{rec}, opts, whole, soft, n_soft, store};
   const int64_t n = rec->n;
   // Qname groups never interact (the table is keyed by qname), and a group none of whose records
   // carries a repeat produces no output: only replay Cache.add for the groups that can emit.
@@ -314,9 +342,43 @@ int strl_pair_reads(const strl_records *rec, const strl_opts *opts, const uint32
   for (int64_t i = 0; i < n; ++i) if (sel[(size_t)i]) P.add(i);                      // extract.nim:308-322
   if (n_tail < 0) { n_tail = 0; while (n_tail < n && rec->tid[n - 1 - n_tail] < 0) ++n_tail; }
   for (int64_t i = n - n_tail; i < n; ++i) if (sel[(size_t)i]) P.add(i);             // extract.nim:326-329 (tail revisited)
-  if (n_out) *n_out = P.n_out;
+  if (n_out) *n_out = store.n_out;
   if (P.err) return P.err;
-  if (P.n_out > cap) { set_error("tread capacity %llu too small, need %llu", (unsigned long long)cap, (unsigned long long)P.n_out); return STRL_ERR_CAPACITY; }
+  if (store.n_out > cap) { set_error("tread capacity %llu too small, need %llu", (unsigned long long)cap, (unsigned long long)store.n_out); return STRL_ERR_CAPACITY; }
+  return STRL_OK;
+}
+
+// ---- streaming pairer: the Cache of extract.nim:298 kept alive across batches (what the CLI drives) ----
+struct strl_pairer {
+  strl_opts opts;
+  StreamStore store;
+};
+
+int strl_pairer_create(const strl_opts *opts, strl_pairer **out) {
+  if (!opts || !out) { set_error("null argument"); return STRL_ERR_ARG; }
+  *out = new strl_pairer{*opts, {}};
+  return STRL_OK;
+}
+void strl_pairer_destroy(strl_pairer *p) { delete p; }
+
+int strl_pairer_add(strl_pairer *p, const strl_records *rec, const uint32_t *whole, const strl_soft_rec *soft, uint64_t n_soft) {
+  if (!p || !rec || (!whole && rec->n)) { set_error("null argument"); return STRL_ERR_ARG; }
+  Pairer<StreamStore> P{RecView{rec}, &p->opts, whole, soft, n_soft, p->store};
+  for (int64_t i = 0; i < rec->n; ++i) {
+    if (rec->flag[i] & (F_SECONDARY | F_SUPPL)) continue;   // extract.nim:309,327
+    P.add(i);
+  }
+  return P.err;
+}
+
+int strl_pairer_result(strl_pairer *p, const strl_tread **treads, uint64_t *n, const uint64_t **qname_off, const char **qnames,
+                       uint64_t *n_pending) {
+  if (!p) return STRL_ERR_ARG;
+  if (treads) *treads = p->store.out.data();
+  if (n) *n = p->store.out.size();
+  if (qname_off) *qname_off = p->store.qoff.data();
+  if (qnames) *qnames = p->store.qnames.data();
+  if (n_pending) *n_pending = p->store.tbl.size();
   return STRL_OK;
 }
 

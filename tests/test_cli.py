@@ -1,0 +1,102 @@
+"""The `strling` CLI: BGZF/BAM reader round trip (CPU) and extract/merge end to end against the oracle (GPU)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from strling_amd import api, bamio, build, synth
+from strling_amd.records import CIGAR_OPS
+
+CLI = build.CLI
+
+
+def _run(args, **kw):
+    return subprocess.run([CLI] + args, capture_output=True, text=True, **kw)
+
+
+@pytest.fixture(scope="module")
+def sample(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cli")
+    rec, g = synth.synth_wgs(6000, seed=21, contig_len=800_000)
+    bam = str(d / "s.bam")
+    hdr = bamio.write_bam(bam, rec)
+    bed = str(d / "ref.fa.str")
+    bamio.write_genome_bed(bed, g, rec.targets)
+    return dict(dir=d, rec=rec, g=g, bam=bam, bed=bed, hdr=hdr)
+
+
+def test_cli_exists_and_help():
+    assert os.path.exists(CLI), "strling CLI not built (python -m strling_amd.build)"
+    r = _run(["extract"])
+    assert r.returncode == 0 and "strling extract" in r.stdout
+    r = _run(["call", "x", "y"])
+    assert r.returncode == 1 and "not part of this build" in r.stderr
+
+
+def test_bam_reader_roundtrip(sample):
+    """own BGZF/BAM decoder == what the Python writer put in (every field extract.nim reads through hts-nim)"""
+    rec = sample["rec"]
+    r = _run(["_dump", sample["bam"]])
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split("\n")
+    nh = len(sample["hdr"].rstrip("\n").split("\n"))
+    assert "\n".join(lines[:nh]) + "\n" == sample["hdr"]
+    body = [l for l in lines[nh:] if l]
+    assert len(body) == rec.n
+    for i in list(range(0, rec.n, 97)) + [rec.n - 1]:
+        f = body[i].split("\t")
+        c0, c1 = int(rec.cigar_off[i]), int(rec.cigar_off[i + 1])
+        cig = "".join(f"{int(c) >> 4}{CIGAR_OPS[int(c) & 15]}" for c in rec.cigar[c0:c1]) or "*"
+        assert f[0] == rec.qname(i).decode() and int(f[1]) == rec.flag[i] and int(f[2]) == rec.tid[i] and int(f[3]) == rec.pos[i]
+        assert int(f[4]) == rec.mapq[i] and f[5] == cig and int(f[6]) == rec.mtid[i] and int(f[7]) == rec.mpos[i]
+        assert int(f[8]) == rec.isize[i] and f[9] == rec.sequence(i)
+
+
+@pytest.mark.gpu
+def test_extract_bin_is_byte_identical_to_oracle(sample, oracle):
+    """strling extract BAM BIN  ==  the oracle's extract + .bin writer, byte for byte (several GPU batches)."""
+    rec, g = sample["rec"], sample["g"]
+    out = str(sample["dir"] / "s.bin")
+    r = _run(["extract", "-g", sample["bed"], "-v", "--batch", "5000", sample["bam"], out])
+    assert r.returncode == 0, r.stderr
+    assert "[strling] collecting str-like reads" in r.stderr and "[strling] finished extraction" in r.stderr
+    frag = synth.frag_hist(rec)              # < 100k records: the reference falls back to the skipped reads (utils.nim:105-111)
+    med = oracle.median(frag)
+    exp_t = oracle.extract(rec, g, oracle.make_opts(med, 0.8, 40))
+    assert len(exp_t) > 100
+    exp = oracle.bin_write(0.8, 40, frag, sample["hdr"].rstrip("\0"), exp_t, rec.qname_off, rec.qnames)
+    assert open(out, "rb").read() == exp
+
+
+@pytest.mark.gpu
+def test_merge_bounds_match_oracle(sample, oracle, tmp_path):
+    """strling merge BIN... -> -bounds.txt identical (rows and row order) to the oracle's merge clustering."""
+    bins, all_t, frag_sum = [], [], np.zeros(4096, np.uint64)
+    for s in range(3):
+        rec, g = synth.synth_wgs(5000, seed=100 + s, contig_len=300_000, str_frac=0.05)
+        frag = synth.frag_hist(rec)
+        med = oracle.median(frag)
+        t = oracle.extract(rec, g, oracle.make_opts(med, 0.8, 40))
+        p = str(tmp_path / f"s{s}.bin")
+        tt = np.zeros(len(t), api.TREAD_DTYPE)
+        for f in tt.dtype.names:
+            tt[f] = t[f]
+        api.bin_write(p, 0.8, 40, frag, bamio.sam_header(rec.targets), tt, rec.qname_off, rec.qnames)
+        bins.append(p)
+        keep = t[t["tid"] >= 0].copy()
+        keep["qname_id"] = s
+        all_t.append(keep)
+        frag_sum += frag
+    frag_sum = frag_sum.astype(np.uint32)
+    prefix = str(tmp_path / "joint")
+    r = _run(["merge", "-m", "2", "-o", prefix] + bins)
+    assert r.returncode == 0, r.stderr
+    window = oracle.median(frag_sum, 0.98)
+    mcd = int(0.5 * oracle.median(frag_sum, 0.5))
+    exp_b, _ = oracle.call_bounds(np.concatenate(all_t), 0, window, min_support=2, max_clip_dist=mcd)
+    exp = ["#chrom\tleft\tright\trepeat\tname\tleft_most\tright_most\tcenter_mass\tn_left\tn_right\tn_total"]
+    exp += [oracle.bounds_row(b, rec.targets[int(b["tid"])][0]) for b in exp_b]
+    got = open(prefix + "-bounds.txt").read().rstrip("\n").split("\n")
+    assert len(exp) > 3
+    assert got == exp
