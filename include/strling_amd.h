@@ -183,6 +183,10 @@ int strl_pairer_add(strl_pairer *pairer, const strl_records *rec, const uint32_t
 int strl_pairer_result(strl_pairer *pairer, const strl_tread **treads, uint64_t *n, const uint64_t **qname_off,
                        const char **qnames, uint64_t *n_pending);
 
+/* 64-bit hash of every record's qname (out[n]).  Qname groups never interact in the pair logic, so a multi-GPU
+ * run only has to bring together the records whose hash belongs to a group that can emit (strling_amd/dist.py). */
+int strl_qname_hash(const strl_records *rec, uint64_t *out);
+
 /* The extract hot loop end to end on one batch: SoA derivation + device scoring + pair logic
  * (replaces extract.nim:308-329). */
 int strl_extract(strl_ctx *ctx, const strl_records *rec, int64_t n_tail, strl_tread *out, uint64_t cap, uint64_t *n_out,

@@ -73,7 +73,7 @@ MODE_MERGE, MODE_CALL = 0, 1
 EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_create", "strl_ctx_destroy", "strl_ctx_stream",
            "strl_ctx_sync", "strl_ctx_set_opts", "strl_ctx_set_genome", "strl_soa_from_records", "strl_score_reads",
            "strl_ctx_enable_timing", "strl_ctx_kernel_times", "strl_pair_reads", "strl_pairer_create", "strl_pairer_destroy", "strl_pairer_add",
-           "strl_pairer_result", "strl_extract", "strl_cluster", "strl_frag_median",
+           "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row"]
 
 
@@ -107,6 +107,7 @@ def load(build_if_missing=True):
                                    C.POINTER(C.c_uint64), C.POINTER(ScoreStats)]
     L.strl_pair_reads.argtypes = [C.POINTER(CRecords), C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64,
                                   C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.strl_qname_hash.argtypes = [C.POINTER(CRecords), C.c_void_p]
     L.strl_extract.argtypes = [C.c_void_p, C.POINTER(CRecords), C.c_int64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                C.POINTER(ScoreStats)]
     L.strl_cluster.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_int32, C.c_uint16, C.c_uint16,
@@ -291,6 +292,33 @@ class Context:
         _check(self.L.strl_cluster(self.h, _ptr(t), t.size, mode, window, min_support, min_clip, min_clip_total, max_clip_dist,
                                    out.ctypes.data, cap, C.byref(no), unpl.ctypes.data, unpl.size, C.byref(nu), C.byref(st)))
         return out[:no.value].copy(), unpl[:nu.value].copy(), st
+
+
+def qname_hash(rec):
+    """uint64 hash of every record's qname (strl_qname_hash)"""
+    rv = _RecView(rec)
+    out = np.zeros(max(rv.n, 1), np.uint64)
+    _check(load().strl_qname_hash(C.byref(rv.c), out.ctypes.data))
+    return out[:rv.n]
+
+
+def pair_reads(rec, opts, whole, soft, n_tail=-1):
+    """strl_pair_reads without a device context (host state machine only). opts = (p, min_mapq, median_fragment_length)"""
+    L = load()
+    rv = _RecView(rec)
+    o = Opts(int(opts[2]), float(opts[0]), int(opts[1]))
+    whole = np.ascontiguousarray(whole, np.uint32)
+    soft = np.ascontiguousarray(soft, SOFT_DTYPE)
+    cap = max(1024, rv.n // 4)
+    while True:
+        out = np.zeros(cap, TREAD_DTYPE)
+        no = C.c_uint64(0)
+        rc = L.strl_pair_reads(C.byref(rv.c), C.byref(o), _ptr(whole), _ptr(soft), soft.size, n_tail, out.ctypes.data, cap, C.byref(no))
+        if rc == -4 and no.value > cap:
+            cap = int(no.value)
+            continue
+        _check(rc)
+        return out[:no.value].copy()
 
 
 def frag_median(frag, pct=0.5):

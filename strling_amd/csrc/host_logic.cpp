@@ -406,6 +406,13 @@ int strl_extract(strl_ctx *ctx, const strl_records *rec, int64_t n_tail, strl_tr
   return strl_pair_reads(rec, &ctx->opts, whole.data(), soft.data(), ns, n_tail, out, cap, n_out);
 }
 
+int strl_qname_hash(const strl_records *rec, uint64_t *out) {
+  if (!rec || (!out && rec->n)) { set_error("null argument"); return STRL_ERR_ARG; }
+  RecView rv{rec};
+  for (int64_t i = 0; i < rec->n; ++i) out[i] = hash_bytes(rv.qname(i));
+  return STRL_OK;
+}
+
 int strl_frag_median(const uint32_t frag[4096], double pct) {  // utils.nim:139-146
   uint32_t n = 0;
   for (int i = 0; i < 4096; ++i) n += frag[i];

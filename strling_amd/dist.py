@@ -1,0 +1,107 @@
+"""Multi-GPU extract: reads shard by record, one process per GPU (torch.distributed: "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in the CPU tests).
+
+Scoring needs no communication.  The pair logic (extract.nim:192-248) is keyed by qname, qname groups never
+interact, and a group none of whose records carries a repeat emits nothing -- so the only exchange the path needs
+is small:
+  1. all-gather of the qname hashes of each rank's "hot" records (whole-read or soft-clip count > 0; ~2 % of reads);
+  2. all-gather of the compact records (coordinates, flag, mapq, cigar, qname, scorer words -- no SEQ) whose hash is
+     in the union, i.e. the hot groups with their mates wherever those were scored.
+Every rank then replays Cache.add over the merged records in global file order and obtains the same treads as a
+single-GPU run; clustering follows on the gathered treads.  Payload ~ a few % of the records, tens of MB per 30x
+sample: latency-bound on xGMI, so one fused all-gather per step.
+"""
+import numpy as np
+import torch.distributed as dist
+
+from . import api
+from .records import RecordBatch
+
+
+def shard_bounds(n, world):
+    """contiguous record ranges [lo, hi) per rank"""
+    step = (n + world - 1) // world
+    return [(min(r * step, n), min((r + 1) * step, n)) for r in range(world)]
+
+
+def slice_records(rec, lo, hi):
+    """sub-batch [lo, hi) of a RecordBatch (keeps SEQ so the shard can be scored)"""
+    c0, c1 = int(rec.cigar_off[lo]), int(rec.cigar_off[hi])
+    q0, q1 = int(rec.qname_off[lo]), int(rec.qname_off[hi])
+    s0 = int(rec.seq_off[lo]) if hi > lo else 0
+    s1 = int(rec.seq_off[hi - 1]) + (int(rec.l_seq[hi - 1]) + 1) // 2 if hi > lo else 0
+    seq4 = np.concatenate([rec.seq4[s0:s1], np.zeros(32, np.uint8)])
+    return RecordBatch(rec.tid[lo:hi], rec.pos[lo:hi], rec.mtid[lo:hi], rec.mpos[lo:hi], rec.flag[lo:hi], rec.mapq[lo:hi],
+                       (rec.cigar_off[lo:hi + 1] - c0).astype(np.uint32), rec.cigar[c0:c1], (rec.seq_off[lo:hi] - np.uint64(s0)),
+                       rec.l_seq[lo:hi], seq4, (rec.qname_off[lo:hi + 1] - np.uint64(q0)), rec.qnames[q0:q1],
+                       None if rec.isize is None else rec.isize[lo:hi], rec.targets)
+
+
+def _compact(rec, idx, whole, soft):
+    """SEQ-free payload of the selected records (local indices idx, ascending)"""
+    clen = (rec.cigar_off[idx + 1] - rec.cigar_off[idx]).astype(np.int64)
+    cig = np.concatenate([rec.cigar[int(rec.cigar_off[i]):int(rec.cigar_off[i + 1])] for i in idx]) if idx.size else np.zeros(0, np.uint32)
+    qn = [rec.qname(int(i)) for i in idx]
+    side = soft["read_side"] & 1
+    sread = (soft["read_side"] >> 1).astype(np.int64)
+    keep = np.isin(sread, idx)
+    return dict(idx=idx, tid=rec.tid[idx], pos=rec.pos[idx], mtid=rec.mtid[idx], mpos=rec.mpos[idx], flag=rec.flag[idx], mapq=rec.mapq[idx],
+                l_seq=rec.l_seq[idx], clen=clen, cigar=cig, qnames=qn, whole=whole[idx],
+                soft_read=sread[keep], soft_side=side[keep], soft_first=soft["res_first"][keep], soft_after=soft["res_after"][keep],
+                soft_len=soft["seg_len"][keep])
+
+
+def exchange_hot_groups(rec, whole, soft, global_offset, group=None):
+    """Steps 1+2 of the module docstring.  rec/whole/soft are this rank's shard and its scorer outputs (soft sorted by
+    read_side, local indices).  Returns (merged RecordBatch in global file order, whole words, soft records re-indexed
+    to the merged batch, global index of every merged record)."""
+    world = dist.get_world_size(group)
+    n = rec.n
+    h = api.qname_hash(rec)
+    hot = (whole >> 16) != 0
+    if soft.size:
+        nz = ((soft["res_first"] >> 16) != 0) | ((soft["res_after"] >> 16) != 0)
+        hot[(soft["read_side"][nz] >> 1).astype(np.int64)] = True
+    gathered = [None] * world
+    dist.all_gather_object(gathered, np.unique(h[hot]), group=group)
+    hot_all = np.unique(np.concatenate(gathered)) if gathered else np.zeros(0, np.uint64)
+    primary = (rec.flag & 0x900) == 0
+    idx = np.nonzero(np.isin(h, hot_all) & primary)[0]
+    payload = _compact(rec, idx, whole, soft)
+    payload["goff"] = int(global_offset)
+    parts = [None] * world
+    dist.all_gather_object(parts, payload, group=group)
+    parts.sort(key=lambda p: p["goff"])
+    # ---- merge in global order ----
+    gidx = np.concatenate([p["idx"] + p["goff"] for p in parts]).astype(np.int64)
+    cat = lambda k, dt: np.concatenate([np.asarray(p[k], dt) for p in parts])
+    clen = cat("clen", np.int64)
+    cig_off = np.zeros(gidx.size + 1, np.uint32)
+    cig_off[1:] = np.cumsum(clen)
+    qn = [q for p in parts for q in p["qnames"]]
+    qoff = np.zeros(gidx.size + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(q) for q in qn])
+    merged = RecordBatch(cat("tid", np.int32), cat("pos", np.int32), cat("mtid", np.int32), cat("mpos", np.int32), cat("flag", np.uint16),
+                         cat("mapq", np.uint8), cig_off, cat("cigar", np.uint32), np.zeros(gidx.size, np.uint64), cat("l_seq", np.int32),
+                         np.zeros(64, np.uint8), qoff, b"".join(qn), None, rec.targets)
+    whole_m = cat("whole", np.uint32)
+    sread = np.concatenate([p["soft_read"] + p["goff"] for p in parts]).astype(np.int64)
+    pos_of = np.searchsorted(gidx, sread)
+    soft_m = np.zeros(sread.size, api.SOFT_DTYPE)
+    soft_m["read_side"] = (pos_of.astype(np.uint32) << 1) | cat("soft_side", np.uint32)
+    soft_m["res_first"], soft_m["res_after"], soft_m["seg_len"] = cat("soft_first", np.uint32), cat("soft_after", np.uint32), cat("soft_len", np.uint32)
+    soft_m.sort(order="read_side")
+    return merged, whole_m, soft_m, gidx
+
+
+def extract_sharded(score_fn, rec, global_offset, n_total, tail_start, opts, group=None):
+    """One rank's part of a multi-GPU extract.
+    score_fn(rec_shard) -> (whole, soft)   (api.Context.score_reads on the GPU box)
+    tail_start = global index of the first record of the unplaced tail the reference visits twice (extract.nim:326).
+    Returns the treads of the WHOLE input (identical on every rank), qname_id = global record index."""
+    whole, soft = score_fn(rec)[:2]
+    merged, whole_m, soft_m, gidx = exchange_hot_groups(rec, whole, soft, global_offset, group)
+    n_tail = int((gidx >= tail_start).sum())
+    t = api.pair_reads(merged, opts, whole_m, soft_m, n_tail=n_tail)
+    t["qname_id"] = gidx[t["qname_id"]]
+    return t
