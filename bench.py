@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """bench.py -- reads/s through the extract hot path on N MI355X (one process per GPU).
 
-A "step" = one pass of the device hot path (classify -> score -> soft-clip scan kernels, the
-whole `strl_score_reads` entry point) over one HBM-resident batch of synthetic 150 bp paired-end
-WGS records (input S1).  Reads shard by record, so with N > 1 every rank scores
+A "step" = one pass of the device hot path over one HBM-resident batch of synthetic 150 bp paired-end WGS
+records (input S1): the extract kernels (classify -> score -> soft-clip scan, the whole
+`strl_score_reads` entry point) followed by the clustering pass (stable radix sorts -> sweep -> bounds,
+`strl_cluster_replay`) over the STR reads such a batch yields.  Reads shard by record, so with N > 1 every rank scores
 its own batch and no collective sits on the data path (weak scaling); the only collectives are
 the barrier + MAX of the elapsed time the contract asks for.
 
@@ -49,7 +50,7 @@ def main():
     dev = torch.device("cuda", local)
 
     # ---- synthetic S1 base sample on the host, tiled into HBM -------------------------------------
-    rec, g = synth.synth_wgs(args.base_pairs, seed=1234 + rank, with_qnames=False)
+    rec, g = synth.synth_wgs(args.base_pairs, seed=1234 + rank)
     soa = api.Soa(rec)
     n_base = soa.n
     tiles = max(1, args.reads_per_gpu // n_base)
@@ -80,11 +81,34 @@ def main():
     ctx.set_opts(0.8, 40, med)      # reference defaults: -p 0.8 -q 40 (extract.nim:255-256)
     ctx.set_genome(g)
 
+    # the STR reads of the batch: extract the unique sample through the full path (GPU scoring + host pair logic) and
+    # give every tile its own contigs, as if the genome were `tiles` times larger (no artificial pile-ups)
+    base_treads, _ = ctx.extract(rec)
+    treads = np.tile(base_treads, tiles)
+    n_contigs = len(rec.targets)
+    placed = treads["tid"] >= 0
+    treads["tid"] = np.where(placed, treads["tid"] + np.repeat(np.arange(tiles, dtype=np.int32) * n_contigs, base_treads.size), -1)
+    frag = synth.frag_hist(rec)
+    window = api.frag_median(frag, 0.99)                     # call.nim:114
+    max_clip_dist = int(0.5 * api.frag_median(frag, 0.5))    # call.nim:232
+    bounds, unplaced, cst = ctx.cluster(treads, api.MODE_CALL, window, min_support=5, max_clip_dist=max_clip_dist)
+
     # one synchronous pass for the unit counts of each kernel
     n_soft, st = ctx.score_device(cs, whole.data_ptr(), soft.data_ptr(), soft_cap, sync=True)
     for _ in range(args.warmup):
         ctx.score_device(cs, whole.data_ptr(), soft.data_ptr(), soft_cap)
+        ctx.cluster_replay()
     ctx.sync()
+    # clustering pass alone, HIP events on the context stream
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    cstream = torch.cuda.ExternalStream(ctx.stream)
+    with torch.cuda.stream(cstream):
+        ev0.record()
+        for _ in range(5):
+            ctx.cluster_replay()
+        ev1.record()
+    ctx.sync()
+    ms_cluster = ev0.elapsed_time(ev1) / 5
     ctx.enable_timing(True)
 
     def barrier():
@@ -96,6 +120,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctx.score_device(cs, whole.data_ptr(), soft.data_ptr(), soft_cap)
+        ctx.cluster_replay()
     ctx.sync()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
@@ -117,6 +142,8 @@ def main():
         "classify_kernel": (ms_classify / launches, 17.0 * n),
         "score_kernel<whole>": (ms_score / launches, (20.0 + seq_b) * st.n_scored),
         "score_kernel<soft>": (ms_soft / launches, (28.0 + (L + 3) // 4) * st.n_soft_items),
+        # clustering: 2 radix-sort passes over (key, value) pairs + 24 B per tread for the sweep + 44 B per emitted row
+        "cluster_pass": (ms_cluster, (2 * (4 + 4) * 2 + 2 * (8 + 4) * 2 + 24.0) * treads.size + 44.0 * len(bounds)),
     }
     dom = max(kernels, key=lambda k: kernels[k][0])
     dom_ms, dom_bytes = kernels[dom]
@@ -152,10 +179,11 @@ def main():
             "value": round(total_reads / el, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32 integer", "data": "synthetic",
-            "config": {"workload": "1xMI355X: 30x 150 bp PE synthetic WGS, k=2-6 repeat-unit scorer + soft-clip scan, single-GPU extract (BASELINE.json configs[1])",
+            "config": {"workload": "1xMI355X: 30x 150 bp PE synthetic WGS, k=2-6 repeat-unit scorer + soft-clip scan + on-GPU radix-sort/segmented clustering (BASELINE.json configs[1]+[2])",
                        "reads_per_gpu": n, "read_len": L, "unique_reads_per_gpu": n_base, "tiles": tiles,
                        "skipped_frac": round(st.n_skipped / n, 4), "scored_reads": int(st.n_scored), "soft_items": int(st.n_soft_items),
-                       "timed_region": "classify + score + soft-clip kernels on HBM-resident SoA batches; BAM decode, PCIe and host pair logic excluded",
+                       "str_reads_clustered": int(treads.size), "clusters": int(cst.n_clusters), "bounds": int(len(bounds)),
+                       "timed_region": "classify + score + soft-clip kernels, then radix-sort + sweep + bounds clustering kernels, all on HBM-resident data; BAM decode, PCIe and the host pair logic between the two are excluded",
                        "parallelism": f"records sharded over {world} GPU(s), no data-path collective"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

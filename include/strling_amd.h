@@ -218,6 +218,10 @@ int strl_cluster(strl_ctx *ctx, const strl_tread *treads, uint64_t n, int mode, 
                  uint64_t *n_out, strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced,
                  strl_cluster_stats *stats);
 
+/* Re-run the device side of the last strl_cluster call (sorts, sweep, bounds) over the treads still resident on
+ * the device, asynchronously on the context stream and without host synchronisation.  For timing. */
+int strl_cluster_replay(strl_ctx *ctx);
+
 /* ---- fragment-length statistics (utils.nim:139-146) ---- */
 int strl_frag_median(const uint32_t frag[4096], double pct);
 

@@ -73,7 +73,7 @@ MODE_MERGE, MODE_CALL = 0, 1
 EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_create", "strl_ctx_destroy", "strl_ctx_stream",
            "strl_ctx_sync", "strl_ctx_set_opts", "strl_ctx_set_genome", "strl_soa_from_records", "strl_score_reads",
            "strl_ctx_enable_timing", "strl_ctx_kernel_times", "strl_pair_reads", "strl_pairer_create", "strl_pairer_destroy", "strl_pairer_add",
-           "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_frag_median",
+           "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row"]
 
 
@@ -113,6 +113,7 @@ def load(build_if_missing=True):
     L.strl_cluster.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_int32, C.c_uint16, C.c_uint16,
                                C.c_uint16, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64,
                                C.POINTER(C.c_uint64), C.POINTER(ClusterStats)]
+    L.strl_cluster_replay.argtypes = [C.c_void_p]
     L.strl_frag_median.argtypes = [C.c_void_p, C.c_double]
     L.strl_bin_write.argtypes = [C.c_char_p, C.c_float, C.c_uint8, C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_uint64,
                                  C.c_void_p, C.c_char_p]
@@ -293,6 +294,10 @@ class Context:
                                    out.ctypes.data, cap, C.byref(no), unpl.ctypes.data, unpl.size, C.byref(nu), C.byref(st)))
         return out[:no.value].copy(), unpl[:nu.value].copy(), st
 
+    def cluster_replay(self):
+        """device side of the last cluster() call again, asynchronously (bench)"""
+        _check(self.L.strl_cluster_replay(self.h))
+
 
 def qname_hash(rec):
     """uint64 hash of every record's qname (strl_qname_hash)"""
@@ -319,6 +324,10 @@ def pair_reads(rec, opts, whole, soft, n_tail=-1):
             continue
         _check(rc)
         return out[:no.value].copy()
+
+
+def _noop():
+    pass
 
 
 def frag_median(frag, pct=0.5):

@@ -252,6 +252,114 @@ static inline uint32_t base_code(char b, bool &ok) {
 
 using namespace strl;
 
+enum { B_POSIN, B_SPLITIN, B_SAMPLEIN, B_KEYIN, B_PERM0, B_PERM1, B_POSK, B_KEYG, B_KEYS, B_TMP, B_A, B_B, B_C, B_D, B_E, B_F };
+
+// The whole device side of strl_cluster over the tread arrays resident in the context (B_POSIN, B_SPLITIN,
+// B_SAMPLEIN, B_KEYIN): two stable radix sorts, group tables, ends/walk sweep, cluster compaction, bounds.
+// First pass (replay = false): sizes buffers as it goes and learns n_groups / n_clusters (two host syncs).
+// Replay (strl_cluster_replay): same data => same sizes, so it runs without any host synchronisation; this is what
+// bench.py times as the clustering part of a step.
+static int cluster_device_pass(strl_ctx *c, bool replay) {
+  ClusterRun &R = c->cl_run;
+  const uint32_t n = R.n;
+  strl::DevBuf *B = c->c_buf;
+  hipStream_t st = c->stream;
+  int rc;
+  auto need = [&](int i, size_t bytes) { return replay ? STRL_OK : B[i].reserve(std::max<size_t>(bytes, 256)); };
+  if ((rc = need(B_PERM0, (size_t)n * 4)) || (rc = need(B_PERM1, (size_t)n * 4)) || (rc = need(B_POSK, (size_t)n * 4)) ||
+      (rc = need(B_KEYG, (size_t)n * 8)) || (rc = need(B_KEYS, (size_t)n * 8)))
+    return rc;
+  const int TB = 256;
+  const uint32_t nb = (n + TB - 1) / TB;
+  if (c->timing) STRL_HIP(hipEventRecord(c->ev[4], st));
+  // stable sort by position, then stable sort by (tid, unit)  ==  group + algorithm.sort by position
+  hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM0].as<uint32_t>());
+  if (!replay) {
+    size_t tmp1 = 0, tmp2 = 0, tmp3 = 0;
+    STRL_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, B[B_POSIN].as<uint32_t>(), B[B_POSK].as<uint32_t>(), B[B_PERM0].as<uint32_t>(),
+                                               B[B_PERM1].as<uint32_t>(), (int)n, 0, 32, st));
+    STRL_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, B[B_KEYG].as<uint64_t>(), B[B_KEYS].as<uint64_t>(), B[B_PERM1].as<uint32_t>(),
+                                               B[B_PERM0].as<uint32_t>(), (int)n, 0, R.kbits, st));
+    STRL_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp3, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, st));
+    R.tmpb = std::max(tmp1, std::max(tmp2, tmp3)) + 256;
+    if ((rc = need(B_TMP, R.tmpb))) return rc;
+  }
+  const size_t tmpb = R.tmpb;
+  size_t t = tmpb;
+  STRL_HIP(hipcub::DeviceRadixSort::SortPairs(B[B_TMP].p, t, B[B_POSIN].as<uint32_t>(), B[B_POSK].as<uint32_t>(), B[B_PERM0].as<uint32_t>(),
+                                             B[B_PERM1].as<uint32_t>(), (int)n, 0, 32, st));
+  hipLaunchKernelGGL(gather_key_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM1].as<uint32_t>(), B[B_KEYIN].as<uint64_t>(), B[B_KEYG].as<uint64_t>());
+  t = tmpb;
+  STRL_HIP(hipcub::DeviceRadixSort::SortPairs(B[B_TMP].p, t, B[B_KEYG].as<uint64_t>(), B[B_KEYS].as<uint64_t>(), B[B_PERM1].as<uint32_t>(),
+                                             B[B_PERM0].as<uint32_t>(), (int)n, 0, R.kbits, st));
+  // B_PERM0 = final permutation (sorted index -> input index), B_KEYS = sorted group keys; group heads -> group ids
+  if ((rc = need(B_A, (size_t)n * 4)) || (rc = need(B_B, (size_t)n * 4))) return rc;   // A: head flags / is_start, B: scans
+  uint32_t *d_head = B[B_A].as<uint32_t>(), *d_scan = B[B_B].as<uint32_t>();
+  hipLaunchKernelGGL(heads_kernel, dim3(nb), dim3(TB), 0, st, B[B_KEYS].as<uint64_t>(), n, d_head);
+  t = tmpb;
+  STRL_HIP(hipcub::DeviceScan::InclusiveSum(B[B_TMP].p, t, d_head, d_scan, (int)n, st));
+  if (!replay) {
+    STRL_HIP(hipMemcpyAsync(&R.n_groups, d_scan + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    STRL_HIP(hipStreamSynchronize(st));
+  }
+  const uint32_t n_groups = R.n_groups;
+  // sorted payload + per-group tables.  Layout of B_C: pos | sample | gid | ends ; B_D: split ; B_E: group tables
+  if ((rc = need(B_C, (size_t)n * 16)) || (rc = need(B_D, n))) return rc;
+  const size_t gt_bytes = (size_t)(n_groups + 1) * 4 + (size_t)n_groups * 4 + (size_t)n_groups * 8 + (size_t)n_groups + 64;
+  if ((rc = need(B_E, gt_bytes))) return rc;
+  uint32_t *d_pos = B[B_C].as<uint32_t>(), *d_sample = d_pos + n, *d_gid = d_sample + n, *d_ends = d_gid + n;
+  uint8_t *d_split = B[B_D].as<uint8_t>();
+  uint64_t *d_gkeys = B[B_E].as<uint64_t>();
+  uint32_t *d_gstart = reinterpret_cast<uint32_t *>(d_gkeys + n_groups);
+  uint32_t *d_gfirst = d_gstart + (n_groups + 1);
+  uint8_t *d_gplaced = reinterpret_cast<uint8_t *>(d_gfirst + n_groups);
+  STRL_HIP(hipMemsetAsync(d_gfirst, 0xff, (size_t)n_groups * 4, st));
+  hipLaunchKernelGGL(gather_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM0].as<uint32_t>(), B[B_POSIN].as<uint32_t>(), B[B_SPLITIN].as<uint8_t>(),
+                     B[B_SAMPLEIN].as<uint32_t>(), d_head, d_scan, B[B_KEYS].as<uint64_t>(), d_pos, d_split, d_sample, d_gid, d_gstart, d_gfirst,
+                     d_gkeys, d_gplaced);
+  if (c->timing) STRL_HIP(hipEventRecord(c->ev[5], st));
+  // ---- sweep ---------------------------------------------------------------------------------------
+  ClusterParams P{};
+  P.n = n; P.pos = d_pos; P.split = d_split; P.sample = d_sample; P.gid = d_gid; P.gstart = d_gstart; P.gplaced = d_gplaced;
+  P.n_groups = n_groups; P.ends = d_ends; P.is_start = d_head; P.max_dist = R.window; P.min_support = R.min_support;
+  P.min_clip = R.min_clip; P.min_clip_total = R.min_clip_total; P.max_clip_dist = R.max_clip_dist; P.mode = R.mode;
+  STRL_HIP(hipMemsetAsync(d_head, 0, (size_t)n * 4, st));
+  hipLaunchKernelGGL(ends_kernel, dim3(nb), dim3(TB), 0, st, P);
+  hipLaunchKernelGGL(walk_kernel, dim3((n_groups + 63) / 64), dim3(64), 0, st, P);
+  t = tmpb;
+  STRL_HIP(hipcub::DeviceScan::ExclusiveSum(B[B_TMP].p, t, d_head, d_scan, (int)n, st));
+  if ((rc = need(B_F, (size_t)n * 4 + 64))) return rc;
+  uint32_t *d_cl_start = B[B_F].as<uint32_t>(), *d_ncl = d_cl_start + n;
+  hipLaunchKernelGGL(scatter_starts_kernel, dim3(nb), dim3(TB), 0, st, n, d_head, d_scan, d_cl_start, d_ncl);
+  if (!replay) {
+    STRL_HIP(hipMemcpyAsync(&R.n_clusters, d_ncl, 4, hipMemcpyDeviceToHost, st));
+    STRL_HIP(hipStreamSynchronize(st));
+  }
+  const uint32_t n_clusters = R.n_clusters;
+  if (c->timing) STRL_HIP(hipEventRecord(c->ev[6], st));
+  // ---- bounds ---------------------------------------------------------------------------------------
+  if (n_clusters) {
+    const size_t scratch_dw = 4ull * (16ull * n_clusters + 3ull * n) + 64;
+    if (!replay) {
+      if ((rc = c->soft_tmp.reserve(scratch_dw * 4))) return rc;
+      if ((rc = need(B_KEYG, std::max((size_t)n * 8, (size_t)2 * n_clusters * sizeof(RawBounds))))) return rc;   // reused as output
+    }
+    P.cl_start = d_cl_start; P.n_clusters = d_ncl; P.scratch = c->soft_tmp.as<uint32_t>(); P.out = B[B_KEYG].as<RawBounds>();
+    hipLaunchKernelGGL(bounds_kernel, dim3((n_clusters + 63) / 64), dim3(64), 0, st, P);
+    STRL_HIP(hipGetLastError());
+  }
+  if (c->timing) STRL_HIP(hipEventRecord(c->ev[7], st));
+  return STRL_OK;
+}
+
+// Re-run the device side of the last strl_cluster call on the same resident treads, asynchronously.
+extern "C" int strl_cluster_replay(strl_ctx *c) {
+  if (!c) return STRL_ERR_ARG;
+  if (c->cl_run.n == 0) { set_error("strl_cluster_replay: no previous strl_cluster call on this context"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  return cluster_device_pass(c, true);
+}
+
 extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in, int mode, uint32_t window, int32_t min_support,
                             uint16_t min_clip, uint16_t min_clip_total, uint16_t max_clip_dist, strl_bounds *out, uint64_t cap,
                             uint64_t *n_out, strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced,
@@ -286,105 +394,43 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
   if (stats) stats->n_treads = n;
   if (n == 0) return STRL_OK;
 
-  // ---- device buffers ----------------------------------------------------------------------------
-  enum { B_POSIN, B_SPLITIN, B_SAMPLEIN, B_KEYIN, B_PERM0, B_PERM1, B_POSK, B_KEYG, B_KEYS, B_TMP, B_A, B_B, B_C, B_D, B_E, B_F };
+  // ---- upload, then one device pass ------------------------------------------------------------------
   strl::DevBuf *B = c->c_buf;
   int rc;
   auto need = [&](int i, size_t bytes) { return B[i].reserve(std::max<size_t>(bytes, 256)); };
   if ((rc = need(B_POSIN, (size_t)n * 4)) || (rc = need(B_SPLITIN, n)) || (rc = need(B_SAMPLEIN, (size_t)n * 4)) ||
-      (rc = need(B_KEYIN, (size_t)n * 8)) || (rc = need(B_PERM0, (size_t)n * 4)) || (rc = need(B_PERM1, (size_t)n * 4)) ||
-      (rc = need(B_POSK, (size_t)n * 4)) || (rc = need(B_KEYG, (size_t)n * 8)) || (rc = need(B_KEYS, (size_t)n * 8)))
+      (rc = need(B_KEYIN, (size_t)n * 8)))
     return rc;
   hipStream_t st = c->stream;
   STRL_HIP(hipMemcpyAsync(B[B_POSIN].p, h_pos.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
   STRL_HIP(hipMemcpyAsync(B[B_SPLITIN].p, h_split.data(), n, hipMemcpyHostToDevice, st));
   STRL_HIP(hipMemcpyAsync(B[B_SAMPLEIN].p, h_sample.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
   STRL_HIP(hipMemcpyAsync(B[B_KEYIN].p, h_key.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-  const int TB = 256;
-  const uint32_t nb = (n + TB - 1) / TB;
-  if (c->timing) STRL_HIP(hipEventRecord(c->ev[4], st));
-  // stable sort by position, then stable sort by (tid, unit)  ==  group + algorithm.sort by position
-  hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM0].as<uint32_t>());
-  size_t tmp1 = 0, tmp2 = 0, tmp3 = 0;
-  STRL_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, B[B_POSIN].as<uint32_t>(), B[B_POSK].as<uint32_t>(), B[B_PERM0].as<uint32_t>(),
-                                             B[B_PERM1].as<uint32_t>(), (int)n, 0, 32, st));
   uint64_t maxkey = 0;
   for (uint64_t k : h_key) maxkey = std::max(maxkey, k);
   int kbits = 1;
   while (kbits < 64 && (maxkey >> kbits)) ++kbits;
-  STRL_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, B[B_KEYG].as<uint64_t>(), B[B_KEYS].as<uint64_t>(), B[B_PERM1].as<uint32_t>(),
-                                             B[B_PERM0].as<uint32_t>(), (int)n, 0, kbits, st));
-  STRL_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp3, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, st));
-  const size_t tmpb = std::max(tmp1, std::max(tmp2, tmp3)) + 256;
-  if ((rc = need(B_TMP, tmpb))) return rc;
-  size_t t = tmpb;
-  STRL_HIP(hipcub::DeviceRadixSort::SortPairs(B[B_TMP].p, t, B[B_POSIN].as<uint32_t>(), B[B_POSK].as<uint32_t>(), B[B_PERM0].as<uint32_t>(),
-                                             B[B_PERM1].as<uint32_t>(), (int)n, 0, 32, st));
-  hipLaunchKernelGGL(gather_key_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM1].as<uint32_t>(), B[B_KEYIN].as<uint64_t>(), B[B_KEYG].as<uint64_t>());
-  t = tmpb;
-  STRL_HIP(hipcub::DeviceRadixSort::SortPairs(B[B_TMP].p, t, B[B_KEYG].as<uint64_t>(), B[B_KEYS].as<uint64_t>(), B[B_PERM1].as<uint32_t>(),
-                                             B[B_PERM0].as<uint32_t>(), (int)n, 0, kbits, st));
-  // B_PERM0 = final permutation (sorted index -> input index), B_KEYS = sorted group keys
-  // group heads -> group ids
-  if ((rc = need(B_A, (size_t)n * 4)) || (rc = need(B_B, (size_t)n * 4))) return rc;   // A: head flags / is_start, B: scans
-  uint32_t *d_head = B[B_A].as<uint32_t>(), *d_scan = B[B_B].as<uint32_t>();
-  hipLaunchKernelGGL(heads_kernel, dim3(nb), dim3(TB), 0, st, B[B_KEYS].as<uint64_t>(), n, d_head);
-  t = tmpb;
-  STRL_HIP(hipcub::DeviceScan::InclusiveSum(B[B_TMP].p, t, d_head, d_scan, (int)n, st));
-  uint32_t n_groups = 0;
-  STRL_HIP(hipMemcpyAsync(&n_groups, d_scan + (n - 1), 4, hipMemcpyDeviceToHost, st));
-  STRL_HIP(hipStreamSynchronize(st));
-  // sorted payload + per-group tables.  Layout of B_C: pos | sample | gid | ends ; B_D: split ; B_E: group tables
-  if ((rc = need(B_C, (size_t)n * 16)) || (rc = need(B_D, n))) return rc;
-  const size_t gt_bytes = (size_t)(n_groups + 1) * 4 + (size_t)n_groups * 4 + (size_t)n_groups * 8 + (size_t)n_groups + 64;
-  if ((rc = need(B_E, gt_bytes))) return rc;
-  uint32_t *d_pos = B[B_C].as<uint32_t>(), *d_sample = d_pos + n, *d_gid = d_sample + n, *d_ends = d_gid + n;
-  uint8_t *d_split = B[B_D].as<uint8_t>();
-  uint64_t *d_gkeys = B[B_E].as<uint64_t>();
-  uint32_t *d_gstart = reinterpret_cast<uint32_t *>(d_gkeys + n_groups);
-  uint32_t *d_gfirst = d_gstart + (n_groups + 1);
-  uint8_t *d_gplaced = reinterpret_cast<uint8_t *>(d_gfirst + n_groups);
-  STRL_HIP(hipMemsetAsync(d_gfirst, 0xff, (size_t)n_groups * 4, st));
-  hipLaunchKernelGGL(gather_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM0].as<uint32_t>(), B[B_POSIN].as<uint32_t>(), B[B_SPLITIN].as<uint8_t>(),
-                     B[B_SAMPLEIN].as<uint32_t>(), d_head, d_scan, B[B_KEYS].as<uint64_t>(), d_pos, d_split, d_sample, d_gid, d_gstart, d_gfirst,
-                     d_gkeys, d_gplaced);
-  if (c->timing) STRL_HIP(hipEventRecord(c->ev[5], st));
-  // ---- sweep ---------------------------------------------------------------------------------------
-  ClusterParams P{};
-  P.n = n; P.pos = d_pos; P.split = d_split; P.sample = d_sample; P.gid = d_gid; P.gstart = d_gstart; P.gplaced = d_gplaced;
-  P.n_groups = n_groups; P.ends = d_ends; P.is_start = d_head; P.max_dist = window; P.min_support = min_support;
-  P.min_clip = min_clip; P.min_clip_total = min_clip_total; P.max_clip_dist = max_clip_dist; P.mode = mode;
-  STRL_HIP(hipMemsetAsync(d_head, 0, (size_t)n * 4, st));
-  hipLaunchKernelGGL(ends_kernel, dim3(nb), dim3(TB), 0, st, P);
-  hipLaunchKernelGGL(walk_kernel, dim3((n_groups + 63) / 64), dim3(64), 0, st, P);
-  t = tmpb;
-  STRL_HIP(hipcub::DeviceScan::ExclusiveSum(B[B_TMP].p, t, d_head, d_scan, (int)n, st));
-  if ((rc = need(B_F, (size_t)n * 4 + 64))) return rc;
-  uint32_t *d_cl_start = B[B_F].as<uint32_t>(), *d_ncl = d_cl_start + n;
-  hipLaunchKernelGGL(scatter_starts_kernel, dim3(nb), dim3(TB), 0, st, n, d_head, d_scan, d_cl_start, d_ncl);
-  uint32_t n_clusters = 0;
-  STRL_HIP(hipMemcpyAsync(&n_clusters, d_ncl, 4, hipMemcpyDeviceToHost, st));
-  STRL_HIP(hipStreamSynchronize(st));
-  if (c->timing) STRL_HIP(hipEventRecord(c->ev[6], st));
-  // ---- bounds ---------------------------------------------------------------------------------------
+  ClusterRun &R = c->cl_run;
+  R = ClusterRun{};
+  R.n = n; R.kbits = kbits; R.mode = mode; R.window = window; R.min_support = min_support; R.min_clip = min_clip;
+  R.min_clip_total = min_clip_total; R.max_clip_dist = max_clip_dist;
+  if ((rc = cluster_device_pass(c, false))) return rc;
+  const uint32_t n_groups = R.n_groups, n_clusters = R.n_clusters;
+  // ---- results back ------------------------------------------------------------------------------------
   std::vector<RawBounds> raw((size_t)2 * n_clusters);
-  if (n_clusters) {
-    const size_t scratch_dw = 4ull * (16ull * n_clusters + 3ull * n) + 64;
-    if ((rc = c->soft_tmp.reserve(scratch_dw * 4))) return rc;
-    if ((rc = need(B_KEYG, std::max((size_t)n * 8, (size_t)2 * n_clusters * sizeof(RawBounds))))) return rc;   // reuse as output
-    P.cl_start = d_cl_start; P.n_clusters = d_ncl; P.scratch = c->soft_tmp.as<uint32_t>(); P.out = B[B_KEYG].as<RawBounds>();
-    hipLaunchKernelGGL(bounds_kernel, dim3((n_clusters + 63) / 64), dim3(64), 0, st, P);
-    STRL_HIP(hipGetLastError());
-    STRL_HIP(hipMemcpyAsync(raw.data(), P.out, raw.size() * sizeof(RawBounds), hipMemcpyDeviceToHost, st));
-  }
-  if (c->timing) STRL_HIP(hipEventRecord(c->ev[7], st));
   std::vector<uint64_t> g_keys(n_groups);
   std::vector<uint32_t> g_start(n_groups + 1), g_first(n_groups), cl_start(n_clusters);
-  STRL_HIP(hipMemcpyAsync(g_keys.data(), d_gkeys, (size_t)n_groups * 8, hipMemcpyDeviceToHost, st));
-  STRL_HIP(hipMemcpyAsync(g_start.data(), d_gstart, (size_t)(n_groups + 1) * 4, hipMemcpyDeviceToHost, st));
-  STRL_HIP(hipMemcpyAsync(g_first.data(), d_gfirst, (size_t)n_groups * 4, hipMemcpyDeviceToHost, st));
-  if (n_clusters) STRL_HIP(hipMemcpyAsync(cl_start.data(), d_cl_start, (size_t)n_clusters * 4, hipMemcpyDeviceToHost, st));
-  STRL_HIP(hipStreamSynchronize(st));
+  {
+    uint64_t *d_gkeys = B[B_E].as<uint64_t>();
+    uint32_t *d_gstart = reinterpret_cast<uint32_t *>(d_gkeys + n_groups);
+    uint32_t *d_gfirst = d_gstart + (n_groups + 1);
+    if (n_clusters) STRL_HIP(hipMemcpyAsync(raw.data(), B[B_KEYG].p, raw.size() * sizeof(RawBounds), hipMemcpyDeviceToHost, st));
+    STRL_HIP(hipMemcpyAsync(g_keys.data(), d_gkeys, (size_t)n_groups * 8, hipMemcpyDeviceToHost, st));
+    STRL_HIP(hipMemcpyAsync(g_start.data(), d_gstart, (size_t)(n_groups + 1) * 4, hipMemcpyDeviceToHost, st));
+    STRL_HIP(hipMemcpyAsync(g_first.data(), d_gfirst, (size_t)n_groups * 4, hipMemcpyDeviceToHost, st));
+    if (n_clusters) STRL_HIP(hipMemcpyAsync(cl_start.data(), B[B_F].p, (size_t)n_clusters * 4, hipMemcpyDeviceToHost, st));
+    STRL_HIP(hipStreamSynchronize(st));
+  }
 
   // ---- host: reference row order = Nim Table slot order of the groups (insertion = first appearance) ----
   std::vector<uint32_t> by_first(n_groups);

@@ -31,6 +31,16 @@ struct DevBuf {
 
 }  // namespace strl
 
+// what strl_cluster_replay needs to re-run the device side of the last strl_cluster call
+struct ClusterRun {
+  uint32_t n = 0, n_groups = 0, n_clusters = 0;
+  int kbits = 0, mode = 0;
+  uint32_t window = 0;
+  int32_t min_support = 0;
+  uint32_t min_clip = 0, min_clip_total = 0, max_clip_dist = 0;
+  size_t tmpb = 0;
+};
+
 struct strl_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -53,4 +63,5 @@ struct strl_ctx {
   strl::DevBuf st_tid, st_pos, st_end, st_seqoff, st_lseq, st_clipl, st_clipr, st_mapq, st_cig, st_seq4, st_whole, st_soft;
   // clustering scratch
   strl::DevBuf c_buf[16];
+  ClusterRun cl_run;
 };

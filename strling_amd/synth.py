@@ -31,7 +31,7 @@ def synth_genome_str(rng, n_contigs, contig_len, overlap_frac=0.03, read_len=150
 
 
 def synth_wgs(n_pairs, seed=1234, read_len=150, n_contigs=25, contig_len=10_000_000, str_frac=0.01, soft_frac=0.03,
-              indel_frac=0.01, unmapped_frac=0.005, interchrom_frac=0.01, genome_overlap=0.03, with_qnames=True):
+              indel_frac=0.01, unmapped_frac=0.005, interchrom_frac=0.01, genome_overlap=0.03, with_qnames=True, hot_loci=2):
     """-> (RecordBatch sorted like a coordinate-sorted BAM with the unmapped tail last, GenomeStr)."""
     rng = _rng(seed)
     L = read_len
@@ -77,13 +77,32 @@ def synth_wgs(n_pairs, seed=1234, read_len=150, n_contigs=25, contig_len=10_000_
     partner = np.arange(n) ^ 1
     str_unmapped &= ~str_unmapped[partner] | (np.arange(n) % 2 == 0)   # at most one mate of a pair is placed-unmapped
     str_unmapped &= ~(str_unmapped[partner] & (np.arange(n) % 2 == 1))
+    # Expanded loci: a few reference STR intervals per contig attract the STR-rich reads, so that they pile up into
+    # clusters the way reads around a real expansion do.  Every locus has its own repeat unit.  Reads of the
+    # "on_ref" kind lie on the locus (150M, kept by the skip predicate); reads of the "clip" kind straddle one of its
+    # boundaries and are soft-clipped exactly there (xMyS ending at iv.start, or ySxM starting at iv.stop).
+    H = hot_loci
+    n_iv = (g.iv_off[1:] - g.iv_off[:-1]).astype(np.int64)
+    hot_iv = g.iv_off[:-1, None] + (rng.random((n_contigs, H)) * n_iv[:, None]).astype(np.int64)
+    hot_k = rng.integers(2, 7, size=(n_contigs, H))
+    hot_unit = _ACGT_NIB[rng.integers(0, 4, size=(n_contigs, H, 6))]
+    loc = rng.integers(0, H, size=n)
+    tsafe = np.clip(tid, 0, n_contigs - 1)
+    liv = hot_iv[tsafe, loc]
     r_idx = np.nonzero(str_on_ref)[0]
-    if r_idx.size:
-        t_ = tid[r_idx]
-        lo, hi = g.iv_off[t_], g.iv_off[t_ + 1]
-        j = lo + (rng.random(r_idx.size) * (hi - lo)).astype(np.int64)
-        pos[r_idx] = np.maximum(0, g.iv_start[j] - rng.integers(0, 100, size=r_idx.size)).astype(np.int32)
-    is_soft |= str_clip
+    pos[r_idx] = np.maximum(0, g.iv_start[liv[r_idx]] - rng.integers(0, 100, size=r_idx.size)).astype(np.int32)
+    c_idx = np.nonzero(str_clip)[0]
+    loc_clip = rng.integers(30, 101, size=n)
+    loc_right = rng.random(n) < 0.5           # True: xMyS (clip on the right, read ends inside the repeat)
+    pos[c_idx] = np.where(loc_right[c_idx], g.iv_start[liv[c_idx]] - (L - loc_clip[c_idx]), g.iv_stop[liv[c_idx]]).astype(np.int32)
+    pos[c_idx] = np.maximum(pos[c_idx], 0)
+    mapq[c_idx] = 60
+    mapq[r_idx] = np.where(rng.random(r_idx.size) < 0.7, 60, mapq[r_idx])
+    # the mate follows its read to the locus (same fragment length, same orientation)
+    mv = np.concatenate([r_idx, c_idx])
+    mv = mv[(tid[mv] == tid[partner[mv]]) & ~um[mv]]
+    fr = np.repeat(frag, 2)[mv] - L
+    pos[partner[mv]] = np.maximum(0, np.where(mv % 2 == 0, pos[mv] + fr, pos[mv] - fr)).astype(np.int32)
     u_idx = np.nonzero(str_unmapped)[0]
     tid[u_idx] = tid[partner[u_idx]]
     pos[u_idx] = pos[partner[u_idx]]
@@ -108,8 +127,25 @@ def synth_wgs(n_pairs, seed=1234, read_len=150, n_contigs=25, contig_len=10_000_
         purity = rng.choice(np.array([1.0, 0.97, 0.93, 0.9, 0.85]), size=idx.size)
         keep = rng.random((idx.size, L)) < purity[:, None]
         codes[idx] = np.where(keep, rep, codes[idx])
+    # reads at expanded loci carry the locus' unit: all of the read (on_ref) or its clipped part (clip)
+    lidx = np.nonzero(str_on_ref | str_clip)[0]
+    if lidx.size:
+        k = hot_k[tsafe[lidx], loc[lidx]]
+        unit = hot_unit[tsafe[lidx], loc[lidx]]
+        phase = rng.integers(0, 6, size=lidx.size)
+        j = (np.arange(L)[None, :] + phase[:, None]) % k[:, None]
+        rep = np.take_along_axis(unit, j, axis=1)
+        purity = rng.choice(np.array([1.0, 0.98, 0.95, 0.92]), size=lidx.size)
+        keep = rng.random((lidx.size, L)) < purity[:, None]
+        col = np.arange(L)[None, :]
+        inrep = np.where(str_clip[lidx][:, None],
+                         np.where(loc_right[lidx][:, None], col >= (L - loc_clip[lidx])[:, None], col < loc_clip[lidx][:, None]), True)
+        flank = _ACGT_NIB[rng.integers(0, 4, size=(lidx.size, L))]
+        codes[lidx] = np.where(inrep, np.where(keep, rep, flank), flank)
     # soft clips: clip length 1-100 on one end (10% both); 40% of clipped tails are repeats
     clip_l = np.zeros(n, np.int32); clip_r = np.zeros(n, np.int32)
+    clip_r[c_idx] = np.where(loc_right[c_idx], loc_clip[c_idx], 0)
+    clip_l[c_idx] = np.where(loc_right[c_idx], 0, loc_clip[c_idx])
     sidx = np.nonzero(is_soft)[0]
     if sidx.size:
         both = rng.random(sidx.size) < 0.10
@@ -127,6 +163,7 @@ def synth_wgs(n_pairs, seed=1234, read_len=150, n_contigs=25, contig_len=10_000_
         in_clip = (col < clip_l[sidx][:, None]) | (col >= (L - clip_r[sidx])[:, None])
         codes[sidx] = np.where(in_clip & rep_tail[:, None], rep, codes[sidx])
         mapq[sidx] = np.where(rng.random(sidx.size) < 0.8, 60, mapq[sidx])
+    is_soft = is_soft | str_clip
     # N bases: 0.1% of bases, and 0.2% of reads with > 20 N
     nmask = rng.random((n, L)) < 0.001
     many = np.nonzero(rng.random(n) < 0.002)[0]
@@ -145,6 +182,7 @@ def synth_wgs(n_pairs, seed=1234, read_len=150, n_contigs=25, contig_len=10_000_
     is_soft &= ~nocig
     is_indel &= ~nocig & ~is_soft
     plain = ~nocig & ~is_soft & ~is_indel
+    sidx = np.nonzero(is_soft)[0]          # includes the reads clipped at an expanded locus
     cigar[cig_off[:-1][plain]] = (L << 4) | OP["M"]
     ii = np.nonzero(is_indel)[0]
     if ii.size:
