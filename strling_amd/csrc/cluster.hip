@@ -210,24 +210,39 @@ __global__ __launch_bounds__(64) void bounds_kernel(ClusterParams P) {
   }
 }
 
-__global__ void heads_kernel(const uint64_t *gkey, uint32_t n, uint32_t *head) {
+__global__ void heads_kernel(const uint64_t *gkey, uint32_t n, uint32_t *head, uint32_t shift) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) head[i] = (i == 0 || gkey[i] != gkey[i - 1]) ? 1u : 0u;
+  if (i < n) head[i] = (i == 0 || (gkey[i] >> shift) != (gkey[i - 1] >> shift)) ? 1u : 0u;
 }
 __global__ void gather_kernel(uint32_t n, const uint32_t *perm, const uint32_t *pos_in, const uint8_t *split_in, const uint32_t *sample_in,
                               const uint32_t *head, const uint32_t *gid_incl, const uint64_t *gkey_sorted, uint32_t *pos, uint8_t *split,
-                              uint32_t *sample, uint32_t *gid, uint32_t *gstart, uint32_t *gfirst, uint64_t *gkeys, uint8_t *gplaced) {
+                              uint32_t *sample, uint32_t *gid, uint32_t *gstart, uint32_t *gfirst, uint64_t *gkeys, uint8_t *gplaced,
+                              uint32_t shift) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t src = perm[i];
-  pos[i] = pos_in[src];
-  split[i] = split_in[src];
-  sample[i] = sample_in[src];
-  const uint32_t g = gid_incl[i] - 1u;
-  gid[i] = g;
-  if (head[i]) { gstart[g] = i; gkeys[g] = gkey_sorted[i]; gplaced[g] = (gkey_sorted[i] >> 15) != 0; }
-  atomicMin(&gfirst[g], src);                  // first appearance in input order => Nim Table insertion order
-  if (i == n - 1) gstart[g + 1] = n;
+  const int lane = threadIdx.x & 63;
+  const bool in = i < n;
+  uint32_t src = 0xffffffffu, g = 0xffffffffu;
+  if (in) {
+    src = perm[i];
+    pos[i] = pos_in[src];
+    split[i] = split_in[src];
+    sample[i] = sample_in[src];
+    g = gid_incl[i] - 1u;
+    gid[i] = g;
+    if (head[i]) { const uint64_t k = gkey_sorted[i] >> shift; gstart[g] = i; gkeys[g] = k; gplaced[g] = (k >> 15) != 0; }
+    if (i == n - 1) gstart[g + 1] = n;
+  }
+  // First appearance in input order (=> Nim Table insertion order) = min of `src` per group.  Group ids are
+  // non-decreasing along the wave, so a segmented suffix-min leaves each run's minimum in its first lane and only
+  // that lane touches memory (one atomic per (wave, group) instead of one per tread on a handful of hot addresses).
+  uint32_t v = src;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t ov = __shfl_down(v, d), og = __shfl_down(g, d);
+    if (lane + d < 64 && og == g) v = v < ov ? v : ov;
+  }
+  const uint32_t pg = __shfl_up(g, 1);
+  if (in && (lane == 0 || pg != g)) atomicMin(&gfirst[g], v);
 }
 __global__ void scatter_starts_kernel(uint32_t n, const uint32_t *is_start, const uint32_t *excl, uint32_t *cl_start, uint32_t *n_clusters) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -272,30 +287,41 @@ static int cluster_device_pass(strl_ctx *c, bool replay) {
   const int TB = 256;
   const uint32_t nb = (n + TB - 1) / TB;
   if (c->timing) STRL_HIP(hipEventRecord(c->ev[4], st));
-  // stable sort by position, then stable sort by (tid, unit)  ==  group + algorithm.sort by position
-  hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM0].as<uint32_t>());
+  // stable sort by position, then stable sort by (tid, unit)  ==  group + algorithm.sort by position.
+  // When the group key fits 32 bits both collapse into ONE stable sort of the composite key (group << 32 | position),
+  // which the host uploads in B_KEYIN (the sorts are launch-bound at ~10^6 treads: 36 small kernels each).
+  hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM1].as<uint32_t>());
+  const uint32_t shift = R.composite ? 32u : 0u;
   if (!replay) {
     size_t tmp1 = 0, tmp2 = 0, tmp3 = 0;
-    STRL_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, B[B_POSIN].as<uint32_t>(), B[B_POSK].as<uint32_t>(), B[B_PERM0].as<uint32_t>(),
-                                               B[B_PERM1].as<uint32_t>(), (int)n, 0, 32, st));
+    STRL_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, B[B_POSIN].as<uint32_t>(), B[B_POSK].as<uint32_t>(), B[B_PERM1].as<uint32_t>(),
+                                               B[B_PERM0].as<uint32_t>(), (int)n, 0, 32, st));
     STRL_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, B[B_KEYG].as<uint64_t>(), B[B_KEYS].as<uint64_t>(), B[B_PERM1].as<uint32_t>(),
-                                               B[B_PERM0].as<uint32_t>(), (int)n, 0, R.kbits, st));
+                                               B[B_PERM0].as<uint32_t>(), (int)n, 0, 64, st));
     STRL_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp3, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, st));
     R.tmpb = std::max(tmp1, std::max(tmp2, tmp3)) + 256;
     if ((rc = need(B_TMP, R.tmpb))) return rc;
   }
   const size_t tmpb = R.tmpb;
   size_t t = tmpb;
-  STRL_HIP(hipcub::DeviceRadixSort::SortPairs(B[B_TMP].p, t, B[B_POSIN].as<uint32_t>(), B[B_POSK].as<uint32_t>(), B[B_PERM0].as<uint32_t>(),
-                                             B[B_PERM1].as<uint32_t>(), (int)n, 0, 32, st));
-  hipLaunchKernelGGL(gather_key_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM1].as<uint32_t>(), B[B_KEYIN].as<uint64_t>(), B[B_KEYG].as<uint64_t>());
-  t = tmpb;
-  STRL_HIP(hipcub::DeviceRadixSort::SortPairs(B[B_TMP].p, t, B[B_KEYG].as<uint64_t>(), B[B_KEYS].as<uint64_t>(), B[B_PERM1].as<uint32_t>(),
-                                             B[B_PERM0].as<uint32_t>(), (int)n, 0, R.kbits, st));
+  if (R.composite) {
+    STRL_HIP(hipcub::DeviceRadixSort::SortPairs(B[B_TMP].p, t, B[B_KEYIN].as<uint64_t>(), B[B_KEYS].as<uint64_t>(), B[B_PERM1].as<uint32_t>(),
+                                               B[B_PERM0].as<uint32_t>(), (int)n, 0, 32 + R.kbits, st));
+  } else {
+    STRL_HIP(hipcub::DeviceRadixSort::SortPairs(B[B_TMP].p, t, B[B_POSIN].as<uint32_t>(), B[B_POSK].as<uint32_t>(), B[B_PERM1].as<uint32_t>(),
+                                               B[B_PERM0].as<uint32_t>(), (int)n, 0, 32, st));
+    hipLaunchKernelGGL(gather_key_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM0].as<uint32_t>(), B[B_KEYIN].as<uint64_t>(), B[B_KEYG].as<uint64_t>());
+    hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM1].as<uint32_t>());   // reused below as scratch values
+    t = tmpb;
+    // second pass carries the first pass' permutation as its values
+    STRL_HIP(hipcub::DeviceRadixSort::SortPairs(B[B_TMP].p, t, B[B_KEYG].as<uint64_t>(), B[B_KEYS].as<uint64_t>(), B[B_PERM0].as<uint32_t>(),
+                                               B[B_PERM1].as<uint32_t>(), (int)n, 0, R.kbits, st));
+    STRL_HIP(hipMemcpyAsync(B[B_PERM0].p, B[B_PERM1].p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+  }
   // B_PERM0 = final permutation (sorted index -> input index), B_KEYS = sorted group keys; group heads -> group ids
   if ((rc = need(B_A, (size_t)n * 4)) || (rc = need(B_B, (size_t)n * 4))) return rc;   // A: head flags / is_start, B: scans
   uint32_t *d_head = B[B_A].as<uint32_t>(), *d_scan = B[B_B].as<uint32_t>();
-  hipLaunchKernelGGL(heads_kernel, dim3(nb), dim3(TB), 0, st, B[B_KEYS].as<uint64_t>(), n, d_head);
+  hipLaunchKernelGGL(heads_kernel, dim3(nb), dim3(TB), 0, st, B[B_KEYS].as<uint64_t>(), n, d_head, shift);
   t = tmpb;
   STRL_HIP(hipcub::DeviceScan::InclusiveSum(B[B_TMP].p, t, d_head, d_scan, (int)n, st));
   if (!replay) {
@@ -316,7 +342,7 @@ static int cluster_device_pass(strl_ctx *c, bool replay) {
   STRL_HIP(hipMemsetAsync(d_gfirst, 0xff, (size_t)n_groups * 4, st));
   hipLaunchKernelGGL(gather_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM0].as<uint32_t>(), B[B_POSIN].as<uint32_t>(), B[B_SPLITIN].as<uint8_t>(),
                      B[B_SAMPLEIN].as<uint32_t>(), d_head, d_scan, B[B_KEYS].as<uint64_t>(), d_pos, d_split, d_sample, d_gid, d_gstart, d_gfirst,
-                     d_gkeys, d_gplaced);
+                     d_gkeys, d_gplaced, shift);
   if (c->timing) STRL_HIP(hipEventRecord(c->ev[5], st));
   // ---- sweep ---------------------------------------------------------------------------------------
   ClusterParams P{};
@@ -405,14 +431,16 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
   STRL_HIP(hipMemcpyAsync(B[B_POSIN].p, h_pos.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
   STRL_HIP(hipMemcpyAsync(B[B_SPLITIN].p, h_split.data(), n, hipMemcpyHostToDevice, st));
   STRL_HIP(hipMemcpyAsync(B[B_SAMPLEIN].p, h_sample.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-  STRL_HIP(hipMemcpyAsync(B[B_KEYIN].p, h_key.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
   uint64_t maxkey = 0;
   for (uint64_t k : h_key) maxkey = std::max(maxkey, k);
   int kbits = 1;
   while (kbits < 64 && (maxkey >> kbits)) ++kbits;
+  const bool composite = kbits <= 32;
+  if (composite) for (uint32_t i = 0; i < n; ++i) h_key[i] = (h_key[i] << 32) | h_pos[i];
+  STRL_HIP(hipMemcpyAsync(B[B_KEYIN].p, h_key.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
   ClusterRun &R = c->cl_run;
   R = ClusterRun{};
-  R.n = n; R.kbits = kbits; R.mode = mode; R.window = window; R.min_support = min_support; R.min_clip = min_clip;
+  R.n = n; R.kbits = kbits; R.composite = composite; R.mode = mode; R.window = window; R.min_support = min_support; R.min_clip = min_clip;
   R.min_clip_total = min_clip_total; R.max_clip_dist = max_clip_dist;
   if ((rc = cluster_device_pass(c, false))) return rc;
   const uint32_t n_groups = R.n_groups, n_clusters = R.n_clusters;

@@ -35,6 +35,7 @@ struct DevBuf {
 struct ClusterRun {
   uint32_t n = 0, n_groups = 0, n_clusters = 0;
   int kbits = 0, mode = 0;
+  bool composite = false;
   uint32_t window = 0;
   int32_t min_support = 0;
   uint32_t min_clip = 0, min_clip_total = 0, max_clip_dist = 0;

@@ -198,3 +198,18 @@ def test_cluster_large_positions_and_ties(ctx, oracle):
         assert len(exp_b) > 100
         for f in ("left", "right", "left_most", "right_most", "center_mass", "n_left", "n_right", "n_total"):
             assert np.array_equal(b[f], exp_b[f]), f
+
+
+def test_cluster_many_contigs_two_pass_sort(ctx, oracle):
+    """tid >= 2^17 makes the (tid, unit) key wider than 32 bits: the composite single sort is replaced by the
+    position sort + stable group sort; rows must not change."""
+    t = synth.synth_treads(n_samples=2, n_loci=200, seed=9, contig_len=1_000_000)
+    t["tid"] = t["tid"] + 140000
+    ot = np.zeros(len(t), oracle.TREAD_DTYPE)
+    for f in t.dtype.names:
+        ot[f] = t[f]
+    exp_b, _ = oracle.call_bounds(ot, api.MODE_MERGE, 560, min_support=3, max_clip_dist=175)
+    b, _, st = ctx.cluster(t, api.MODE_MERGE, 560, min_support=3, max_clip_dist=175)
+    assert len(exp_b) > 10
+    for f in ("tid", "left", "right", "left_most", "right_most", "center_mass", "n_left", "n_right", "n_total", "repeat"):
+        assert np.array_equal(b[f], exp_b[f]), f
