@@ -145,11 +145,25 @@ def main():
         # clustering: 2 radix-sort passes over (key, value) pairs + 24 B per tread for the sweep + 44 B per emitted row
         "cluster_pass": (ms_cluster, (2 * (4 + 4) * 2 + 2 * (8 + 4) * 2 + 24.0) * treads.size + 44.0 * len(bounds)),
     }
+    # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs of tools/prof_run.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null if absent
+    traffic = {}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "c_traffic.json")))["kernels"]
+        pick = {"classify_kernel": ["classify_kernel"], "score_kernel<whole>": ["<10, 64, 0, 0", "compact_kernel<1, 0>", "<10, 64, 0, 1"],
+                "score_kernel<soft>": ["compact_kernel<0, 0>", "<10, 64, 1, 0", "compact_kernel<1, 1>", "<10, 64, 1, 1"],
+                "cluster_pass": ["iota_kernel", "heads_kernel", "gather_kernel", "ends_kernel", "walk_kernel", "scatter_starts", "bounds_kernel"]}
+        for k, pats in pick.items():
+            traffic[k] = sum(v["hbm_bytes_corrected"] for name, v in tj.items() if any(p in name for p in pats))
+    except Exception:
+        traffic = {}
     dom = max(kernels, key=lambda k: kernels[k][0])
     dom_ms, dom_bytes = kernels[dom]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                "traffic": traffic.get(dom) if (n == 2 ** 25 and L == 150) else None,
+                "traffic_note": "HBM bytes per launch of the dominant kernel group from profiles/r01/c_traffic.json (PMC, same workload); cluster_pass excludes the rocprim sort kernels",
                 "kernel_ms": {k: round(v[0], 4) for k, v in kernels.items()},
                 "kernel_alg_bytes": {k: int(v[1]) for k, v in kernels.items()},
                 "pipeline_alg_GBps": round(sum(v[1] for v in kernels.values()) / (el / args.steps) / 1e9, 2),
