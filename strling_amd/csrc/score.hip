@@ -70,8 +70,8 @@ struct ScoreParams {
   const uint8_t *mapq, *cig;
   const uint8_t *seq4;
   const TidInfo *g_tid;
-  const int2 *g_iv;         // per tid, sorted by start: {start, running max of stop}
-  const uint32_t *g_bins;
+  const int2 *g_iv;         // per tid, sorted by start: {start_i, max stop of the earlier intervals} + sentinel
+  const uint2 *g_bins;      // per tid and 4 KiB bin: {#starts below the bin, #starts below the next bin}
   int32_t n_tid;
   const uint16_t *lut;
   const uint64_t *thr;
@@ -90,36 +90,67 @@ struct ScoreParams {
 
 constexpr int LUT_DWORDS = LUT_ENTRIES / 2;
 constexpr int LUT_A_DWORDS = LUT_OFF5 / 2;   // stage A only looks up k <= 4
-constexpr int CL_STAGE = 1024;   // queue entries a wave stages in LDS before one bulk append
+constexpr int CL_STAGE = 512;    // queue entries a wave stages in LDS before one bulk append (16 KB per block: 8 blocks per CU)
 constexpr int CL_ILP = 8;        // reads per lane per iteration (independent lookup chains in flight)
 
 // extract.nim:30-34: single-M cigar, chromosome in the table, no interval overlapping [start, stop)
-__device__ __forceinline__ bool skip_predicate(const ScoreParams &P, uint32_t cg, int32_t t, int32_t start, int32_t stop) {
-  if (!(cg & STRL_CIG_SINGLE_M) || t < 0 || t >= P.n_tid) return false;
-  const TidInfo ti = P.g_tid[t];
-  if (!ti.has) return false;
+// The predicate for N independent reads of one lane, written as straight-line PHASES (all directory loads, then all
+// bin loads, then all interval loads) so that the N lookup chains are in flight together: N separately inlined
+// while-loops serialise their chains, and the kernel is bound by exactly that latency.
+template <int N>
+__device__ __forceinline__ void skip_predicate_n(const ScoreParams &P, const uint32_t (&cg)[N], const int32_t (&t)[N], const int32_t (&start)[N],
+                                                 const int32_t (&stop)[N], const bool (&in)[N], bool (&skip)[N]) {
+  bool cand[N];
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    cand[j] = in[j] && (cg[j] & STRL_CIG_SINGLE_M) && t[j] >= 0 && t[j] < P.n_tid;
+    any |= cand[j];
+  }
+  // A coordinate-sorted wave almost always sits on ONE contig: fetch its directory entry once (uniform address).
+  int32_t t0 = 0;
+#pragma unroll
+  for (int j = N - 1; j >= 0; --j) if (cand[j]) t0 = t[j];
+  t0 = __builtin_amdgcn_readfirstlane(any ? t0 : __builtin_amdgcn_readfirstlane(0));
+  bool same = true;
+#pragma unroll
+  for (int j = 0; j < N; ++j) same = same && (!cand[j] || t[j] == t0);
+  const bool uniform = __all(same) && __any(any);
+  TidInfo ti[N];
+  if (uniform) {
+    const TidInfo tu = P.g_tid[__builtin_amdgcn_readfirstlane(t0 < 0 ? 0 : (t0 < P.n_tid ? t0 : 0))];
+#pragma unroll
+    for (int j = 0; j < N; ++j) ti[j] = tu;
+  } else {
+#pragma unroll
+    for (int j = 0; j < N; ++j) ti[j] = P.g_tid[cand[j] ? t[j] : 0];
+  }
   // lapper.find(start, stop) <=> any interval with iv.start < stop and iv.stop > start.
-  // idx = number of intervals with iv.start < stop: bin directory, then a short scan inside the bin
-  const int32_t b = stop > 0 ? (stop >> BIN_SHIFT) : 0;
-  int32_t idx = ti.n_iv, hi = ti.n_iv;
-  if (b < ti.n_bins) {
-    const uint32_t *bins = P.g_bins + ti.bin_off + b;
-    idx = (int32_t)bins[0];
-    hi = (int32_t)bins[1];
+  // idx = number of intervals with iv.start < stop: bin directory, then a short scan inside the bin.
+  int32_t idx[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    cand[j] = cand[j] && ti[j].has;
+    const int32_t b = stop[j] > 0 ? (stop[j] >> BIN_SHIFT) : 0;
+    idx[j] = ti[j].n_iv;
+    if (cand[j] && b < ti[j].n_bins) idx[j] = (int32_t)P.g_bins[ti[j].bin_off + b].x;
   }
-  const int2 *iv = P.g_iv + ti.iv_off;
-  // both candidates are requested together; the scan below almost never needs a third element
-  int32_t pm = idx > 0 ? iv[idx - 1].y : INT32_MIN;
-  int2 c = idx < hi ? iv[idx] : make_int2(INT32_MAX, 0);
-  while (c.x < stop) {
-    pm = c.y;
-    ++idx;
-    c = idx < hi ? iv[idx] : make_int2(INT32_MAX, 0);
+  int2 c[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) c[j] = cand[j] ? P.g_iv[ti[j].iv_off + idx[j]] : make_int2(INT32_MAX, INT32_MIN);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    while (c[j].x < stop[j]) {   // a start inside the bin below `stop`: rare, and the sentinel ends it
+      ++idx[j];
+      c[j] = P.g_iv[ti[j].iv_off + idx[j]];
+    }
+    skip[j] = cand[j] && !(c[j].y > start[j]);   // c.y = longest reach of the intervals starting before `stop`
   }
-  const bool overlap = idx > 0 && pm > start;
-  return !overlap;
 }
 
+// VEC: a lane owns 4 consecutive reads per group and fetches their coordinates with 16-byte loads (needs 16-byte aligned
+// arrays; the host picks the scalar variant otherwise).
+template <bool VEC>
 __global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
   // Each wave owns one contiguous range of reads.  Kept read indices are staged in LDS; a flush reserves queue
   // space with ONE global atomic (one same-address atomic per wave-iteration ran into the ~88 ops/us limit of
@@ -129,25 +160,37 @@ __global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
   uint32_t *buf = stage[wave];
   const uint64_t n_waves = (uint64_t)gridDim.x * 4u;
   const uint64_t gw = (uint64_t)blockIdx.x * 4u + wave;
-  const uint64_t per = (((P.n + n_waves - 1) / n_waves) + 63ull) & ~63ull;
+  const uint64_t per = (((P.n + n_waves - 1) / n_waves) + 255ull) & ~255ull;
   const uint64_t r0 = gw * per;
   const uint64_t r1 = r0 + per < P.n ? r0 + per : P.n;
   const unsigned long long below = (1ull << lane) - 1ull;
   uint32_t cnt = 0, nskip = 0;
+  // read handled by this lane as sub-item j of the iteration starting at `base`
+  auto ridx = [&](uint64_t base, int j) -> uint64_t {
+    return VEC ? base + 256ull * (uint64_t)(j >> 2) + 4ull * (uint64_t)lane + (uint64_t)(j & 3) : base + 64ull * (uint64_t)j + (uint64_t)lane;
+  };
   auto flush = [&]() {
     if (cnt) {
       uint32_t b = 0;
       if (lane == 0) b = atomicAdd(&P.counters[CNT_QUEUE], cnt);
       b = __shfl(b, 0);
       __builtin_amdgcn_wave_barrier();
-      for (uint32_t i = lane; i < cnt; i += 64) {
-        const uint32_t r = buf[i];
-        uint4 e;
-        e.x = r;
-        e.y = P.seq_off[r];
-        e.z = (uint32_t)P.l_seq[r] | ((uint32_t)P.clip_l[r] << 16);
-        e.w = (uint32_t)P.clip_r[r] | ((uint32_t)P.cig[r] << 16) | ((uint32_t)P.mapq[r] << 24);
-        P.queue[b + i] = e;
+      for (uint32_t i0 = lane; i0 < cnt; i0 += 64 * 4) {   // 4 entries per lane per round: 24 gathers in flight, then 4 stores
+        uint4 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t i = i0 + 64u * u;
+          const uint32_t r = i < cnt ? buf[i] : 0u;
+          e[u].x = r;
+          e[u].y = P.seq_off[r];
+          e[u].z = (uint32_t)P.l_seq[r] | ((uint32_t)P.clip_l[r] << 16);
+          e[u].w = (uint32_t)P.clip_r[r] | ((uint32_t)P.cig[r] << 16) | ((uint32_t)P.mapq[r] << 24);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t i = i0 + 64u * u;
+          if (i < cnt) P.queue[b + i] = e[u];
+        }
       }
       __builtin_amdgcn_wave_barrier();
       cnt = 0;
@@ -155,33 +198,75 @@ __global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
   };
   struct In { uint32_t cg; int32_t t, st, en; };
   auto load = [&](uint64_t base, In (&x)[CL_ILP]) {
+    if (VEC) {
 #pragma unroll
-    for (int j = 0; j < CL_ILP; ++j) {
-      const uint64_t r = base + 64 * j + lane;
-      const bool in = r < r1;
-      x[j].cg = in ? P.cig[r] : 0u;
-      x[j].t = in ? P.tid[r] : -1;
-      x[j].st = in ? P.pos[r] : 0;
-      x[j].en = in ? P.end[r] : 0;
+      for (int gq = 0; gq < CL_ILP / 4; ++gq) {
+        const uint64_t r = base + 256ull * gq + 4ull * lane;
+        if (r + 3 < r1) {
+          const int4 t4 = reinterpret_cast<const int4 *>(P.tid)[r >> 2];
+          const int4 s4 = reinterpret_cast<const int4 *>(P.pos)[r >> 2];
+          const int4 e4 = reinterpret_cast<const int4 *>(P.end)[r >> 2];
+          const uint32_t c4 = reinterpret_cast<const uint32_t *>(P.cig)[r >> 2];
+          x[4 * gq + 0] = In{c4 & 0xffu, t4.x, s4.x, e4.x};
+          x[4 * gq + 1] = In{(c4 >> 8) & 0xffu, t4.y, s4.y, e4.y};
+          x[4 * gq + 2] = In{(c4 >> 16) & 0xffu, t4.z, s4.z, e4.z};
+          x[4 * gq + 3] = In{c4 >> 24, t4.w, s4.w, e4.w};
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool in = r + q < r1;
+            x[4 * gq + q] = In{in ? (uint32_t)P.cig[r + q] : 0u, in ? P.tid[r + q] : -1, in ? P.pos[r + q] : 0, in ? P.end[r + q] : 0};
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CL_ILP; ++j) {
+        const uint64_t r = base + 64 * j + lane;
+        const bool in = r < r1;
+        x[j].cg = in ? P.cig[r] : 0u;
+        x[j].t = in ? P.tid[r] : -1;
+        x[j].st = in ? P.pos[r] : 0;
+        x[j].en = in ? P.end[r] : 0;
+      }
     }
   };
   In cur[CL_ILP], nxt[CL_ILP];
   load(r0, cur);
   for (uint64_t base = r0; base < r1; base += 64 * CL_ILP) {
     load(base + 64 * CL_ILP, nxt);   // next iteration's streaming loads fly while this one chases the interval table
-    bool need[CL_ILP], skipped[CL_ILP];
+    bool need[CL_ILP], skipped[CL_ILP], inr[CL_ILP];
+    uint32_t cgs[CL_ILP];
+    int32_t ts[CL_ILP], sts[CL_ILP], ens[CL_ILP];
 #pragma unroll
     for (int j = 0; j < CL_ILP; ++j) {
-      const bool in = base + 64 * j + lane < r1;
-      skipped[j] = in && skip_predicate(P, cur[j].cg, cur[j].t, cur[j].st, cur[j].en);
-      need[j] = in && !skipped[j];
-      if (skipped[j]) P.whole[base + 64 * j + lane] = STRL_RES_SKIPPED;
+      inr[j] = ridx(base, j) < r1;
+      cgs[j] = cur[j].cg; ts[j] = cur[j].t; sts[j] = cur[j].st; ens[j] = cur[j].en;
+    }
+    skip_predicate_n<CL_ILP>(P, cgs, ts, sts, ens, inr, skipped);
+#pragma unroll
+    for (int j = 0; j < CL_ILP; ++j) {
+      need[j] = inr[j] && !skipped[j];
+      if (!VEC && skipped[j]) P.whole[ridx(base, j)] = STRL_RES_SKIPPED;
+    }
+    if (VEC) {   // one 16-byte store per group; kept reads get 0 here and their real word from the scorer later
+#pragma unroll
+      for (int gq = 0; gq < CL_ILP / 4; ++gq) {
+        const uint64_t r = base + 256ull * gq + 4ull * lane;
+        if (r + 3 < r1) {
+          reinterpret_cast<uint4 *>(P.whole)[r >> 2] = make_uint4(skipped[4 * gq] ? STRL_RES_SKIPPED : 0u, skipped[4 * gq + 1] ? STRL_RES_SKIPPED : 0u,
+                                                                 skipped[4 * gq + 2] ? STRL_RES_SKIPPED : 0u, skipped[4 * gq + 3] ? STRL_RES_SKIPPED : 0u);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (skipped[4 * gq + q]) P.whole[r + q] = STRL_RES_SKIPPED;
+        }
+      }
     }
 #pragma unroll
     for (int j = 0; j < CL_ILP; ++j) {
       const unsigned long long m = __ballot(need[j]);
       nskip += (uint32_t)__popcll(__ballot(skipped[j]));
-      if (need[j]) buf[cnt + __popcll(m & below)] = (uint32_t)(base + 64 * j + lane);
+      if (need[j]) buf[cnt + __popcll(m & below)] = (uint32_t)ridx(base, j);
       cnt += (uint32_t)__popcll(m);
     }
     if (cnt >= CL_STAGE) flush();
@@ -525,10 +610,14 @@ int strl_ctx_set_genome(strl_ctx *c, const strl_genome_str *g) {
   if (!g || g->n_tid <= 0) { c->n_tid = 0; c->n_iv = 0; return STRL_OK; }
   const int32_t nt = g->n_tid;
   const int64_t niv = g->iv_off[nt];
-  std::vector<int32_t> st((size_t)std::max<int64_t>(niv, 1)), pm((size_t)std::max<int64_t>(niv, 1));
-  std::vector<int2> ivs((size_t)std::max<int64_t>(niv, 1));
+  std::vector<int32_t> st((size_t)std::max<int64_t>(niv, 1));
+  // per tid, n_iv + 1 elements sorted by start: element i = {start_i, max(stop_0..stop_{i-1})}; the last one is the
+  // sentinel {INT32_MAX, max of all stops}.  One 8-byte load answers "does a start lie here" AND "does an earlier
+  // interval reach past my start".
+  std::vector<int2> ivs;
+  ivs.reserve((size_t)niv + (size_t)nt);
   std::vector<TidInfo> ti((size_t)nt);
-  std::vector<uint32_t> bins;
+  std::vector<uint2> bins;   // bins[k] = {#starts < k << BIN_SHIFT, #starts < (k+1) << BIN_SHIFT}
   std::vector<int64_t> idx;
   for (int32_t t = 0; t < nt; ++t) {
     const int64_t a = g->iv_off[t], b = g->iv_off[t + 1];
@@ -536,37 +625,39 @@ int strl_ctx_set_genome(strl_ctx *c, const strl_genome_str *g) {
     idx.resize((size_t)(b - a));
     for (int64_t i = a; i < b; ++i) idx[(size_t)(i - a)] = i;
     std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) { return g->iv_start[x] < g->iv_start[y]; });
+    TidInfo &x = ti[(size_t)t];
+    x.iv_off = (int64_t)ivs.size();
     int32_t run = INT32_MIN;
-    for (int64_t i = a; i < b; ++i) {          // sorted starts + running maximum of stops
+    for (int64_t i = a; i < b; ++i) {
       const int64_t s = idx[(size_t)(i - a)];
       st[(size_t)i] = g->iv_start[s];
+      ivs.push_back(make_int2(g->iv_start[s], run));
       run = std::max(run, g->iv_stop[s]);
-      pm[(size_t)i] = run;
-      ivs[(size_t)i] = make_int2(st[(size_t)i], run);
     }
-    TidInfo &x = ti[(size_t)t];
-    x.iv_off = a;
+    ivs.push_back(make_int2(INT32_MAX, run));
     x.n_iv = (int32_t)(b - a);
     x.has = g->has_chrom[t] ? 1 : 0;
     x.pad = 0;
     x.bin_off = (int64_t)bins.size();
-    // bins[k] = number of intervals with start < (k << BIN_SHIFT); one extra entry closes the last bin
     const int32_t max_start = b > a ? std::max(0, st[(size_t)(b - 1)]) : 0;
     x.n_bins = b > a ? (max_start >> BIN_SHIFT) + 1 : 0;
     int64_t j = a;
+    uint32_t prev = 0;
     for (int32_t k = 0; k <= x.n_bins; ++k) {
       const int64_t lim = (int64_t)k << BIN_SHIFT;
       while (j < b && (int64_t)st[(size_t)j] < lim) ++j;
-      bins.push_back((uint32_t)(j - a));
+      const uint32_t cntk = (uint32_t)(j - a);
+      if (k > 0) bins.push_back(make_uint2(prev, cntk));
+      prev = cntk;
     }
   }
-  if (bins.empty()) bins.push_back(0);
+  if (bins.empty()) bins.push_back(make_uint2(0, 0));
   int rc;
   if ((rc = c->g_tid.reserve(ti.size() * sizeof(TidInfo)))) return rc;
-  if ((rc = c->g_bins.reserve(bins.size() * 4))) return rc;
+  if ((rc = c->g_bins.reserve(bins.size() * 8))) return rc;
   if ((rc = c->g_start.reserve(ivs.size() * 8))) return rc;
   STRL_HIP(hipMemcpy(c->g_tid.p, ti.data(), ti.size() * sizeof(TidInfo), hipMemcpyHostToDevice));
-  STRL_HIP(hipMemcpy(c->g_bins.p, bins.data(), bins.size() * 4, hipMemcpyHostToDevice));
+  STRL_HIP(hipMemcpy(c->g_bins.p, bins.data(), bins.size() * 8, hipMemcpyHostToDevice));
   STRL_HIP(hipMemcpy(c->g_start.p, ivs.data(), ivs.size() * 8, hipMemcpyHostToDevice));
   c->n_tid = nt;
   c->n_iv = (uint64_t)niv;
@@ -593,7 +684,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   P.n = n;
   P.tid = s->tid; P.pos = s->pos; P.end = s->end; P.seq_off = s->seq_off; P.l_seq = s->l_seq;
   P.clip_l = s->clip_l; P.clip_r = s->clip_r; P.mapq = s->mapq; P.cig = s->cig; P.seq4 = s->seq4;
-  P.g_tid = c->g_tid.as<TidInfo>(); P.g_bins = c->g_bins.as<uint32_t>(); P.g_iv = c->g_start.as<int2>();
+  P.g_tid = c->g_tid.as<TidInfo>(); P.g_bins = c->g_bins.as<uint2>(); P.g_iv = c->g_start.as<int2>();
   P.n_tid = c->n_tid;
   P.lut = c->lut.as<uint16_t>(); P.thr = c->thr.as<uint64_t>();
   P.whole = whole; P.queue = c->queue.as<uint4>(); P.soft_dense = c->soft_dense.as<uint4>();
@@ -609,7 +700,9 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   if (tev) STRL_HIP(hipEventRecord(tev[0], c->stream));
   if (n) {
     const int cblocks = (int)std::min<uint64_t>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(classify_kernel, dim3(cblocks), dim3(256), 0, c->stream, P);
+    const bool vec = (((uintptr_t)P.tid | (uintptr_t)P.pos | (uintptr_t)P.end | (uintptr_t)P.whole) & 15u) == 0 && ((uintptr_t)P.cig & 3u) == 0;
+    if (vec) hipLaunchKernelGGL(classify_kernel<true>, dim3(cblocks), dim3(256), 0, c->stream, P);
+    else hipLaunchKernelGGL(classify_kernel<false>, dim3(cblocks), dim3(256), 0, c->stream, P);
     STRL_HIP(hipGetLastError());
   }
   if (tev) STRL_HIP(hipEventRecord(tev[1], c->stream));
