@@ -345,10 +345,13 @@ template <int MODE, int STAGE> struct Item {
 template <int NW, int SLOTS, int MODE, int STAGE, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void score_kernel(ScoreParams P) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  constexpr int LUTW = STAGE == 0 ? LUT_A_DWORDS : LUT_DWORDS;
-  for (int i = threadIdx.x; i < LUTW; i += BLOCK) lds[i] = reinterpret_cast<const uint32_t *>(P.lut)[i];
+  constexpr int LUTK = STAGE == 0 ? LUT_A_DWORDS : LUT_DWORDS;   // k-mer tables this stage looks up
+  constexpr int LUTW = LUTK + 256;                                  // + the byte -> 2-bit conversion table
+  for (int i = threadIdx.x; i < LUTK; i += BLOCK) lds[i] = reinterpret_cast<const uint32_t *>(P.lut)[i];
+  for (int i = threadIdx.x; i < 256; i += BLOCK) lds[LUTK + i] = reinterpret_cast<const uint32_t *>(P.lut)[LUT_DWORDS + i];
   __syncthreads();
   const uint16_t *lut = reinterpret_cast<const uint16_t *>(lds);
+  const uint32_t *clut = lds + LUTK;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t *wave_tab = lds + LUTW + wave * (table_rows<NW, SLOTS, STAGE>() * 64);
   uint32_t *col = wave_tab + lane;
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(BLOCK) void score_kernel(ScoreParams P) {
     __builtin_amdgcn_wave_barrier();
     STRL_PH(st, 0);
     Seg<NW> sg;
-    seg_from_raw<NW>(col, cur.s0 & 31, cur.len, sg);
+    seg_from_raw<NW>(col, clut, cur.s0 & 31, cur.len, sg);
     STRL_PH(st, 1);
     if (STAGE == 0) score_stage_a<NW, SLOTS>(sg, cur.act, wave_tab, lane, lut, pc.t, st);
     else score_stage_b<NW, SLOTS>(sg, wave_tab, lane, lut, pc.t, st);
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(BLOCK) void score_kernel(ScoreParams P) {
 // ---- host side of this translation unit -------------------------------------------------------
 template <int NW, int SLOTS, int MODE, int STAGE, int BLOCK> static int launch_score(strl_ctx *ctx, const ScoreParams &P, int blocks) {
   auto kfn = score_kernel<NW, SLOTS, MODE, STAGE, BLOCK>;
-  const size_t shmem = (size_t)(STAGE == 0 ? LUT_A_DWORDS : LUT_DWORDS) * 4 + (size_t)(BLOCK / 64) * table_rows<NW, SLOTS, STAGE>() * 64 * 4;
+  const size_t shmem = (size_t)((STAGE == 0 ? LUT_A_DWORDS : LUT_DWORDS) + 256) * 4 + (size_t)(BLOCK / 64) * table_rows<NW, SLOTS, STAGE>() * 64 * 4;
   static bool attr_done = false;
   if (!attr_done) {
     STRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -531,9 +534,12 @@ int strl_ctx_create(int device_ordinal, strl_ctx **out) {
   for (auto &e : c->ev) STRL_HIP(hipEventCreate(&e));
   std::vector<uint16_t> lut;
   build_lut(lut);
-  int rc = c->lut.reserve(lut.size() * 2);
+  std::vector<uint32_t> clut;
+  build_conv_lut(clut);
+  int rc = c->lut.reserve(lut.size() * 2 + clut.size() * 4);
   if (rc) return rc;
   STRL_HIP(hipMemcpy(c->lut.p, lut.data(), lut.size() * 2, hipMemcpyHostToDevice));
+  STRL_HIP(hipMemcpy(static_cast<char *>(c->lut.p) + lut.size() * 2, clut.data(), clut.size() * 4, hipMemcpyHostToDevice));
   rc = c->counters.reserve(CNT_WORDS * 4);
   if (rc) return rc;
   *out = c;

@@ -21,6 +21,7 @@
 
 #ifdef STRL_EMU
 #define STRL_DEV inline
+#define STRL_HD inline
 #define STRL_LANES 1
 static inline uint32_t strl_funnel_r(uint32_t lo, uint32_t hi, uint32_t s) {
   return s == 0 ? lo : (uint32_t)(((((uint64_t)hi) << 32) | lo) >> s);
@@ -32,6 +33,7 @@ static inline uint32_t strl_lds_add(uint32_t *a, uint32_t v) { uint32_t o = *a; 
 #else
 #include <hip/hip_runtime.h>
 #define STRL_DEV __device__ __forceinline__
+#define STRL_HD __host__ __device__ __forceinline__
 #define STRL_LANES 64
 STRL_DEV uint32_t strl_funnel_r(uint32_t lo, uint32_t hi, uint32_t s) { return __funnelshift_r(lo, hi, s); }
 STRL_DEV int strl_ffs(uint32_t x) { return __ffs((int)x); }
@@ -73,7 +75,7 @@ constexpr int THR_LMAX = 512;
 // ---- BAM 4-bit -> 2-bit -----------------------------------------------------------------------
 // squeeze the two low bits of each nibble of z into 16 contiguous bits, in base order
 // (BAM stores base 2m in the HIGH nibble of byte m).
-STRL_DEV uint32_t squeeze8(uint32_t z) {
+STRL_HD uint32_t squeeze8(uint32_t z) {
   z = ((z >> 4) & 0x03030303u) | ((z & 0x03030303u) << 2);
   z = (z | (z >> 4)) & 0x00FF00FFu;
   z = (z | (z >> 8)) & 0x0000FFFFu;
@@ -81,7 +83,7 @@ STRL_DEV uint32_t squeeze8(uint32_t z) {
 }
 // 8 BAM-packed bases -> 8 code pairs (A=1 C=0 G=3 T=2, anything else 1 like the kmer module's
 // lookup) and 8 flag pairs (bit 2j: base j is not ACGT, bit 2j+1: base j is 'N').
-STRL_DEV void conv8(uint32_t x, uint32_t &pairs, uint32_t &flags) {
+STRL_HD void conv8(uint32_t x, uint32_t &pairs, uint32_t &flags) {
   uint32_t b0 = x & 0x11111111u, b1 = (x >> 1) & 0x11111111u, b2 = (x >> 2) & 0x11111111u, b3 = (x >> 3) & 0x11111111u;
   uint32_t sum = b0 + b1 + b2 + b3;  // per-nibble popcount
   uint32_t t = sum ^ 0x11111111u;
@@ -96,6 +98,15 @@ STRL_DEV void conv8(uint32_t x, uint32_t &pairs, uint32_t &flags) {
   }
 }
 
+// Same conversion through a 256-entry table indexed by one BAM byte (two bases): entry bits 0-3 = the two 2-bit
+// codes, bits 16-19 = their flag pairs.  Four lookups + three shift-ors replace ~35 bit-trick ops per dword, and
+// the integer VALU is the binding resource of the scorer.  (conv8 above stays as the table's specification.)
+STRL_DEV void conv8_lut(uint32_t x, const uint32_t *clut, uint32_t &pairs, uint32_t &flags) {
+  const uint32_t r = clut[x & 0xffu] | (clut[(x >> 8) & 0xffu] << 4) | (clut[(x >> 16) & 0xffu] << 8) | (clut[x >> 24] << 12);
+  pairs = r & 0xffffu;
+  flags = r >> 16;
+}
+
 // One segment in registers.
 template <int NW> struct Seg {
   uint32_t seq[NW];  // 2-bit codes, 16 bases per word, zero beyond len
@@ -107,10 +118,10 @@ template <int NW> struct Seg {
 
 // Build a Seg from raw BAM-packed dwords staged in this lane's LDS column (`raw[i * STRL_LANES]`
 // is dword i of the staged chunk), starting at base `s0` (< 32) of the chunk.
-template <int NW> STRL_DEV void seg_from_raw(const uint32_t *raw, int s0, int len, Seg<NW> &sg) {
+template <int NW> STRL_DEV void seg_from_raw(const uint32_t *raw, const uint32_t *clut, int s0, int len, Seg<NW> &sg) {
   const int dw0 = s0 >> 3, sh = s0 & 7;
   uint32_t p, f;
-  conv8(raw[dw0 * STRL_LANES], p, f);
+  conv8_lut(raw[dw0 * STRL_LANES], clut, p, f);
   uint32_t cur = p >> (2 * sh), curf = f >> (2 * sh);
   const int fill = 16 - 2 * sh;
   uint32_t any_f = 0;
@@ -120,8 +131,8 @@ template <int NW> STRL_DEV void seg_from_raw(const uint32_t *raw, int s0, int le
     uint32_t sw = 0, fw = 0;
     if (16 * w < len) {
       uint32_t pa, fa, pb, fb;
-      conv8(raw[(dw0 + 1 + 2 * w) * STRL_LANES], pa, fa);
-      conv8(raw[(dw0 + 2 + 2 * w) * STRL_LANES], pb, fb);
+      conv8_lut(raw[(dw0 + 1 + 2 * w) * STRL_LANES], clut, pa, fa);
+      conv8_lut(raw[(dw0 + 2 + 2 * w) * STRL_LANES], clut, pb, fb);
       uint64_t buf = (uint64_t)cur | ((uint64_t)pa << fill) | ((uint64_t)pb << (fill + 16));
       uint64_t bf = (uint64_t)curf | ((uint64_t)fa << fill) | ((uint64_t)fb << (fill + 16));
       sw = (uint32_t)buf;

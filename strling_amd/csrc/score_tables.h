@@ -43,4 +43,15 @@ inline void build_thr(const strl_opts &o, std::vector<uint64_t> &thr) {
     }
 }
 
+// conv8_lut's table: one BAM byte (base 2m in the high nibble, base 2m+1 in the low nibble) -> codes | flags << 16.
+// Built FROM conv8 so that the two can never disagree.
+inline void build_conv_lut(std::vector<uint32_t> &t) {
+  t.assign(256, 0);
+  for (uint32_t b = 0; b < 256; ++b) {
+    uint32_t pairs, flags;
+    conv8(b, pairs, flags);          // the byte sits in the low byte of the dword: bases 0 and 1
+    t[b] = (pairs & 0xfu) | ((flags & 0xfu) << 16);
+  }
+}
+
 }  // namespace strl

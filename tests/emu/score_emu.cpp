@@ -11,6 +11,7 @@ using namespace strl;
 
 static std::vector<uint16_t> g_lut;
 static std::vector<uint64_t> g_thr;
+static std::vector<uint32_t> g_clut;
 static bool g_last_alive = false;
 
 template <int NW, int SLOTS>
@@ -22,7 +23,7 @@ static void run(const uint8_t *seq4, int s0, int len, int row0, int row1, uint32
   const uint8_t *src = seq4 + (size_t)(s0 >> 5) * 16;
   for (int c = 0; c < MAXCH && c < nch; ++c) memcpy(&tab[4 * c], src + 16 * c, 16);
   Seg<NW> sg;
-  seg_from_raw<NW>(tab, s0l, len, sg);
+  seg_from_raw<NW>(tab, g_clut.data(), s0l, len, sg);
   // run the two stages the way the kernels do: stage A, hand the state over, re-stage the bases, stage B
   ScoreState st;
   LaneThr lt;
@@ -32,7 +33,7 @@ static void run(const uint8_t *seq4, int s0, int len, int row0, int row1, uint32
   if (st.alive) {
     for (int c = 0; c < MAXCH && c < nch; ++c) memcpy(&tab[4 * c], src + 16 * c, 16);
     Seg<NW> sg2;
-    seg_from_raw<NW>(tab, s0l, len, sg2);
+    seg_from_raw<NW>(tab, g_clut.data(), s0l, len, sg2);
     score_stage_b<NW, SLOTS>(sg2, tab, 0, g_lut.data(), lt, st);
   }
   *o0 = reduce_packed(st.res0);
@@ -46,6 +47,7 @@ void emu_set_p(double p) {
   o.proportion_repeat = p;
   build_lut(g_lut);
   build_thr(o, g_thr);
+  build_conv_lut(g_clut);
 }
 // mode 0: whole read (threshold p); mode 1: soft clip (p-0.07 / min(p,0.6)).  seq4 must have 32 B slack.
 void emu_score(const uint8_t *seq4, int s0, int len, int mode, int klass, uint32_t *o0, uint32_t *o1) {
