@@ -140,6 +140,20 @@ typedef struct {
  * Requires strl_ctx_set_opts (and optionally strl_ctx_set_genome) first. */
 int strl_score_reads(strl_ctx *ctx, const strl_read_soa *soa, uint32_t *whole, strl_soft_rec *soft, uint64_t soft_cap,
                      uint64_t *n_soft, strl_score_stats *stats);
+/* `strling index` scoring (genome_strs.nim:61-92): utils.get_repeat on every window [i*step, min(n, i*step+window))
+ * of one chromosome (ASCII, any case; hts-nim fai.get + toUpperAscii), with the context's proportion_repeat.
+ * words[n_windows] receives the packed unit/count word of each window (host array; pass NULL to only get
+ * *n_windows = ceil(n_bases / step)).  window <= 160. */
+int strl_index_chrom(strl_ctx *ctx, const char *seq, uint64_t n_bases, uint32_t window, uint32_t step, uint32_t *words,
+                     uint64_t *n_windows);
+/* The sequential half of `strling index` (host): merge consecutive windows that carry the same unit (allowing one
+ * skipped window), pad by one window on both sides and trim to the first/last unit-sized step that is a rotation of
+ * the unit -- repeat_windows genome_strs.nim:76-91 and trim :22-59.  One BED row of <fasta>.str per region
+ * (genome_strs.nim:137: chrom, start, stop, unit).  STRL_ERR_ASSERT where trim's doAssert would fire. */
+typedef struct { uint64_t start, stop; char unit[8]; } strl_region;
+int strl_index_regions(const char *seq, uint64_t n_bases, const uint32_t *words, uint64_t n_windows, uint32_t window,
+                       uint32_t step, strl_region *out, uint64_t cap, uint64_t *n_out);
+
 /* Kernel timing with HIP events recorded on the context stream around every kernel of
  * strl_score_reads (a ring of 256 launches).  enable_timing(ctx, 1) resets the ring;
  * strl_ctx_kernel_times synchronises the stream and returns the SUM of the classify / score / soft

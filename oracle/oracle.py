@@ -111,6 +111,8 @@ def lib():
         L.orc_bin_write.restype = C.c_int64
         L.orc_bounds_row.argtypes = [C.c_char_p, C.c_int, C.POINTER(Bounds), C.c_char_p]
         L.orc_bounds_row.restype = C.c_int
+        L.orc_index_chrom.argtypes = [C.c_char_p, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.orc_index_chrom.restype = C.c_int64
         L.orc_cluster_group.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
     return _LIB
 
@@ -309,6 +311,20 @@ def cluster_group(treads, max_dist, min_supporting_reads):
 
     lib().orc_cluster_group(t.ctypes.data, t.size, max_dist, min_supporting_reads, _CB(cb), None)
     return res
+
+
+def index_chrom(seq, p=0.8, window=100, step=60):
+    """genome_strs.nim:61-92 on one (upper-cased) chromosome -> [(start, stop, unit)]"""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    cap = max(16, len(seq) // step + 2)
+    st = np.zeros(cap, np.int64)
+    en = np.zeros(cap, np.int64)
+    un = np.zeros(cap, "S7")
+    n = lib().orc_index_chrom(seq, len(seq), p, window, step, st.ctypes.data, en.ctypes.data, un.ctypes.data, cap)
+    if n < 0:
+        raise AssertionError("doAssert of genome_strs.trim would fire")
+    return [(int(st[i]), int(en[i]), un[i].decode()) for i in range(n)]
 
 
 def bounds_row(b, chrom):

@@ -510,6 +510,65 @@ int64_t orc_extract(const orc_records *r, int64_t n_tail, const orc_genome_str *
 }
 
 /* ==========================================================================================
+ * strling index: src/strpkg/genome_strs.nim:22-92 (one chromosome; seq already upper-cased like fai.get().toUpperAscii)
+ * ======================================================================================== */
+typedef struct { int64_t start, stop; char repeat[7]; int valid; } idx_window;
+
+/* genome_strs.nim:22-59; returns 0 when one of its doAsserts would fire */
+static int window_trim(idx_window *w, const char *dna, int64_t dlen) {
+  int k = (int)strlen(w->repeat);
+  uint64_t *codes = (uint64_t *)malloc(((size_t)dlen + 2) * sizeof(uint64_t));
+  uint64_t expected = 0, one[8];
+  if (orc_slide_by(w->repeat, k, k, one) > 0) expected = one[0];
+  int n = orc_slide_by(dna, (int)dlen, k, codes);                    /* trim left */
+  for (int i = 0; i < n; i++) { if (expected != codes[i]) w->start += k; else break; }
+  if (!(w->start < w->stop)) { free(codes); return 0; }
+  char *dnar = (char *)malloc((size_t)dlen + 1), rep[8];
+  for (int64_t i = 0; i < dlen; i++) dnar[dlen - 1 - i] = dna[i];
+  for (int i = 0; i < k; i++) rep[k - 1 - i] = w->repeat[i];
+  if (orc_slide_by(rep, k, k, one) > 0) expected = one[0];
+  n = orc_slide_by(dnar, (int)dlen, k, codes);                       /* trim right */
+  for (int i = 0; i < n; i++) { if (expected != codes[i]) w->stop -= k; else break; }
+  free(dnar);
+  free(codes);
+  return w->start < w->stop;
+}
+
+/* genome_strs.nim:61-92 for one chromosome.  out: (start, stop, unit) triples; returns count or -1 on a doAssert */
+int64_t orc_index_chrom(const char *seq, int64_t L, double p, int window_size, int step, int64_t *starts, int64_t *stops,
+                        char (*units)[7], int64_t cap) {
+  int64_t n_out = 0;
+  idx_window last; memset(&last, 0, sizeof last); last.stop = -1;
+#define YIELD_LAST()                                                                                   \
+  do {                                                                                                 \
+    if (last.stop != -1 && last.stop - last.start >= (window_size - step)) {                           \
+      last.start = last.start - window_size < 0 ? 0 : last.start - window_size;                        \
+      last.stop = last.stop + window_size < L ? last.stop + window_size : L;                           \
+      idx_window t = last;                                                                             \
+      if (!window_trim(&t, seq + last.start, last.stop - last.start)) return -1;                       \
+      if (n_out < cap) { starts[n_out] = t.start; stops[n_out] = t.stop; memcpy(units[n_out], t.repeat, 7); } \
+      n_out++;                                                                                         \
+    }                                                                                                  \
+  } while (0)
+  for (int64_t start = 0; start < L; start += step) {
+    int64_t dl = start + window_size <= L ? window_size : L - start;
+    char rep[6]; int rc;
+    orc_get_repeat(seq + start, (int)dl, p, rep, &rc);
+    if (rc > 0) {
+      idx_window w; memset(&w, 0, sizeof w);
+      w.start = start; w.stop = start + dl; memcpy(w.repeat, rep, 6);
+      if (strcmp(last.repeat, w.repeat) != 0 || w.start > last.stop + (window_size - step)) {
+        YIELD_LAST();
+        last = w;
+      } else last.stop = w.stop;
+    }
+  }
+  YIELD_LAST();
+#undef YIELD_LAST
+  return n_out;
+}
+
+/* ==========================================================================================
  * Nim 1.6 stdlib emulation: lib/pure/hashes.nim, lib/pure/collections/{tables,tableimpl,hashcommon}.nim
  * (Nim 1.6.10 is what the reference CI pins: .github/workflows/ci.yml:11).  Unpinned by any
  * reference test; isolated here.

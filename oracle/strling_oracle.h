@@ -149,6 +149,10 @@ int64_t orc_call_bounds(const orc_tread *treads, int64_t n, int mode, uint32_t w
                         uint16_t min_clip, uint16_t min_clip_total, uint16_t max_clip_dist,
                         orc_bounds *out, int64_t cap, orc_unplaced *unpl, int64_t unpl_cap, int64_t *n_unpl);
 
+/* ---- strling index for one chromosome (genome_strs.nim:22-92); -1 if a doAssert of trim() would fire ---- */
+int64_t orc_index_chrom(const char *seq, int64_t L, double p, int window_size, int step, int64_t *starts, int64_t *stops,
+                        char (*units)[7], int64_t cap);
+
 /* ---- Nim 1.6 stdlib emulation (hashes.nim / tables.nim) ---- */
 uint64_t orc_nim_hash_int(uint64_t x);                 /* hashWangYi1 */
 uint64_t orc_nim_hash_bytes(const uint8_t *p, int n);  /* murmurHash */

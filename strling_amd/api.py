@@ -71,7 +71,7 @@ MODE_MERGE, MODE_CALL = 0, 1
 
 # every symbol include/strling_amd.h declares
 EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_create", "strl_ctx_destroy", "strl_ctx_stream",
-           "strl_ctx_sync", "strl_ctx_set_opts", "strl_ctx_set_genome", "strl_soa_from_records", "strl_score_reads",
+           "strl_ctx_sync", "strl_ctx_set_opts", "strl_ctx_set_genome", "strl_soa_from_records", "strl_score_reads", "strl_index_chrom", "strl_index_regions",
            "strl_ctx_enable_timing", "strl_ctx_kernel_times", "strl_pair_reads", "strl_pairer_create", "strl_pairer_destroy", "strl_pairer_add",
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row"]
@@ -105,6 +105,9 @@ def load(build_if_missing=True):
     L.strl_soa_from_records.argtypes = [C.POINTER(CRecords)] + [C.c_void_p] * 6 + [C.POINTER(C.c_uint32)]
     L.strl_score_reads.argtypes = [C.c_void_p, C.POINTER(CReadSoa), C.c_void_p, C.c_void_p, C.c_uint64,
                                    C.POINTER(C.c_uint64), C.POINTER(ScoreStats)]
+    L.strl_index_chrom.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.strl_index_regions.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
+                                     C.POINTER(C.c_uint64)]
     L.strl_pair_reads.argtypes = [C.POINTER(CRecords), C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64,
                                   C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.strl_qname_hash.argtypes = [C.POINTER(CRecords), C.c_void_p]
@@ -121,6 +124,20 @@ def load(build_if_missing=True):
     L.strl_bounds_row.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_char_p]
     _LIB = L
     return L
+
+
+REGION_DTYPE = np.dtype([("start", "<u8"), ("stop", "<u8"), ("unit", "S8")])
+
+
+def index_regions(seq, words, window=100, step=60):
+    """host half of strling index: merge + trim the scored windows (strl_index_regions)"""
+    L = load()
+    words = np.ascontiguousarray(words, np.uint32)
+    cap = len(words) + 1
+    out = np.zeros(cap, REGION_DTYPE)
+    n = C.c_uint64(0)
+    _check(L.strl_index_regions(seq, len(seq), words.ctypes.data, len(words), window, step, out.ctypes.data, cap, C.byref(n)))
+    return [(int(r["start"]), int(r["stop"]), r["unit"].decode()) for r in out[:n.value]]
 
 
 def _check(rc):
@@ -250,6 +267,22 @@ class Context:
             return ns.value, st
         _check(self.L.strl_score_reads(self.h, C.byref(cs), whole_ptr, soft_ptr, soft_cap, None, None))
         return None
+
+    def index_chrom(self, seq, window=100, step=60):
+        """packed get_repeat word of every window of a chromosome (strling index, genome_strs.nim:61-92)"""
+        if isinstance(seq, str):
+            seq = seq.encode()
+        nw = C.c_uint64(0)
+        _check(self.L.strl_index_chrom(self.h, seq, len(seq), window, step, None, C.byref(nw)))
+        words = np.zeros(max(1, nw.value), np.uint32)
+        _check(self.L.strl_index_chrom(self.h, seq, len(seq), window, step, words.ctypes.data, C.byref(nw)))
+        return words[:nw.value]
+
+    def index_regions(self, seq, window=100, step=60):
+        """the (start, stop, unit) rows `strling index` writes for one chromosome (genome_strs.nim:61-92, :137)"""
+        if isinstance(seq, str):
+            seq = seq.encode()
+        return index_regions(seq, self.index_chrom(seq, window, step), window, step)
 
     # ---- extract (score + pair) -----------------------------------------------------------------
     def extract(self, rec: RecordBatch, n_tail=-1):

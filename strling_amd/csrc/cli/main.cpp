@@ -3,12 +3,15 @@
 //   strling merge   [-w -1] [-m 5] [-c 0] [-t 0] [-q 40] [-o PREFIX] [-v] BIN...  (src/strpkg/merge.nim:47-191)
 // The BAM is decoded on the host (own BGZF/BAM reader), batches go through the C ABI into the HIP kernels,
 // the pair logic runs in the streaming pairer, and the .bin / -bounds.txt writers are byte-compatible with the
-// reference's.  Not in this build (SURVEY.md section 8f "next"): CRAM input, building the genome STR index when -g
-// does not exist (`strling index`), `strling call` (needs the spanning-read evidence of collect.nim), -l/--bed loci.
+//   strling index   [-g STR.bed] [-p 0.8] FASTA                                  (src/strpkg/genome_strs.nim:61-135,175-205)
+// reference's.  Not in this build (SURVEY.md section 8f "next"): CRAM input, `strling call` (needs the
+// spanning-read evidence of collect.nim), -l/--bed loci.
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
+#include <zlib.h>
 #include <algorithm>
 #include <chrono>
 #include <map>
@@ -140,7 +143,65 @@ static void fragment_length_distribution(const std::string &bam, uint32_t frag[4
   }
 }
 
-// read_bed.nim:18-50 + genome_strs.nim:107-135 (existing file only), flattened per BAM tid
+
+// ---- genome STR index: repeat_windows + genome_repeats' writer (genome_strs.nim:61-92, :116-137) -------------------
+// The FASTA is read front to back with zlib (plain, gzip or bgzip), one contig in memory at a time, in file order --
+// the order hts-nim's Fai enumerates.  Windows are scored on the device (strl_index_chrom); merging + trimming is
+// strl_index_regions.  Returns the number of rows written.
+static bool file_exists(const std::string &p) { return access(p.c_str(), F_OK) == 0; }
+
+static uint64_t build_genome_index(strl_ctx *ctx, const std::string &fasta, const std::string &bed_path) {
+  gzFile in = gzopen(fasta.c_str(), "rb");
+  if (!in) quit("[strling] couldn't open fasta %s make sure file is present and has a .fai index", fasta.c_str());
+  gzbuffer(in, 1 << 20);
+  FILE *fh = fopen(bed_path.c_str(), "w");
+  if (!fh) quit("[strling] couldn't open bed file: %s for writing", bed_path.c_str());
+  uint64_t n_rows = 0;
+  std::string name, seq;
+  std::vector<uint32_t> words;
+  std::vector<strl_region> regions;
+  bool have = false;
+  const uint32_t window_size = 100, step = 60;                                     // genome_strs.nim:131-132
+  auto finish = [&]() {
+    if (!have) return;
+    if (seq.size() > 2000000) fprintf(stderr, "[strling] finding STR regions on reference chromosome: %s\n", name.c_str());
+    uint64_t nw = 0, nr = 0;
+    CHECK(strl_index_chrom(ctx, seq.data(), seq.size(), window_size, step, nullptr, &nw));
+    words.assign((size_t)nw + 1, 0);
+    CHECK(strl_index_chrom(ctx, seq.data(), seq.size(), window_size, step, words.data(), &nw));
+    regions.resize((size_t)nw + 1);
+    CHECK(strl_index_regions(seq.data(), seq.size(), words.data(), nw, window_size, step, regions.data(), regions.size(), &nr));
+    for (uint64_t i = 0; i < nr; ++i)
+      fprintf(fh, "%s\t%llu\t%llu\t%s\n", name.c_str(), (unsigned long long)regions[(size_t)i].start, (unsigned long long)regions[(size_t)i].stop, regions[(size_t)i].unit);
+    n_rows += nr;
+  };
+  std::vector<char> line(1 << 16);
+  bool in_header = false;   // a header line longer than the buffer continues on the next gzgets
+  while (gzgets(in, line.data(), (int)line.size())) {
+    size_t len = strlen(line.data());
+    const bool complete = len && line[len - 1] == '\n';
+    while (len && (line[len - 1] == '\n' || line[len - 1] == '\r')) --len;
+    if (in_header) { in_header = !complete; continue; }
+    if (len && line[0] == '>') {
+      finish();
+      have = true;
+      seq.clear();
+      size_t e = 1;
+      while (e < len && line[e] != ' ' && line[e] != '\t') ++e;
+      name.assign(line.data() + 1, e - 1);
+      in_header = !complete;
+      continue;
+    }
+    if (have) seq.append(line.data(), len);
+  }
+  finish();
+  gzclose(in);
+  fclose(fh);
+  fprintf(stderr, "[strling] found %llu STR-like regions in the genome\n", (unsigned long long)n_rows);
+  return n_rows;
+}
+
+// read_bed.nim:18-50, flattened per BAM tid
 struct Genome {
   std::vector<uint8_t> has;
   std::vector<int64_t> off;
@@ -148,7 +209,7 @@ struct Genome {
 };
 static Genome read_genome_bed(const std::string &path, const std::vector<BamTarget> &targets) {
   FILE *f = fopen(path.c_str(), "r");
-  if (!f) quit("[strling] genome repeats file %s does not exist; building it (`strling index`) is not part of this build -- supply an existing file with -g", path.c_str());
+  if (!f) quit("[strling] couldn't open bed file: %s", path.c_str());
   std::map<std::string, int> tid;
   for (size_t i = 0; i < targets.size(); ++i) tid[targets[i].name] = (int)i;
   std::vector<std::vector<std::pair<int32_t, int32_t>>> per(targets.size());
@@ -178,7 +239,7 @@ static int extract_main(int argc, char **argv) {
   const char *usage =
       "strling extract\n\nUsage:\n  strling extract [options] bam bin\n\nArguments:\n  bam              path to bam file\n"
       "  bin              path bin to output bin file to be created\n\nOptions:\n  -f, --fasta=FASTA          path to fasta file (required for CRAM)\n"
-      "  -g, --genome-repeats=GENOME_REPEATS\n                             path to genome repeats file (must exist in this build)\n"
+      "  -g, --genome-repeats=GENOME_REPEATS\n                             optional path to genome repeats file. if it does not exist, it will be created\n"
       "  -p, --proportion-repeat=PROPORTION_REPEAT\n                             proportion of read that is repetitive to be considered as STR (default: 0.8)\n"
       "  -q, --min-mapq=MIN_MAPQ    minimum mapping quality (does not apply to STR reads) (default: 40)\n  -v, --verbose\n  -h, --help                 Show this help\n";
   if (argc <= 2) { fputs(usage, stdout); return 0; }
@@ -201,14 +262,27 @@ static int extract_main(int argc, char **argv) {
   BamReader rd;
   std::string err;
   if (!rd.open(bam, err)) quit("couldn't open bam");
-  if (!a.flag("genome-repeats")) quit("[strling] -g/--genome-repeats is required in this build (building the genome STR index is not implemented)");
-  const Genome g = read_genome_bed(a.get("genome-repeats", ""), rd.targets());
-  fprintf(stderr, "[strling] using existing file %s for genome repeats\n", a.get("genome-repeats", "").c_str());
-
   strl_ctx *ctx = nullptr;
   CHECK(strl_ctx_create(0, &ctx));
   strl_opts opts{frag_median, p, min_mapq};
   CHECK(strl_ctx_set_opts(ctx, &opts));
+  // genome_repeats, genome_strs.nim:107-146: existing file, or build it from the FASTA (into a temporary file when
+  // no -g was given).  An existing -g is accepted without -f here; the reference insists on opening the FASTA first.
+  std::string bed_path = a.get("genome-repeats", "");
+  const bool is_tmp = bed_path.empty();
+  if (is_tmp) {
+    const char *td = getenv("TMPDIR");
+    bed_path = std::string(td ? td : "/tmp") + "/strling." + std::to_string((long)getpid()) + ".bed";
+  }
+  if (is_tmp || !file_exists(bed_path)) {
+    if (!a.flag("fasta")) quit("[strling] couldn't open fasta %s make sure file is present and has a .fai index", a.get("fasta", "").c_str());
+    build_genome_index(ctx, a.get("fasta", ""), bed_path);
+  } else {
+    fprintf(stderr, "[strling] using existing file %s for genome repeats\n", bed_path.c_str());
+  }
+  const Genome g = read_genome_bed(bed_path, rd.targets());
+  fprintf(stderr, "[strling] got STR repeats from genome into an interval tree\n");
+  if (is_tmp) remove(bed_path.c_str());
   strl_genome_str gs{(int32_t)rd.targets().size(), g.has.data(), g.off.data(), g.st.data(), g.en.data()};
   CHECK(strl_ctx_set_genome(ctx, &gs));
   strl_pairer *pairer = nullptr;
@@ -390,17 +464,48 @@ static int dump_main(int argc, char **argv) {
   return 0;
 }
 
+// genome_strs.nim:175-205
+static int index_main(int argc, char **argv) {
+  const char *usage =
+      "str index\n\nUsage:\n  str index [options] fasta\n\nArguments:\n  fasta            path to fasta file\n\nOptions:\n"
+      "  -g, --genome-repeats=GENOME_REPEATS\n                             optional path to output genome repeats file. if it does not exist, it will be created (default: ./<FASTA>.str)\n"
+      "  -p, --proportion-repeat=PROPORTION_REPEAT\n                             proportion of read that is repetitive to be considered as STR (default: 0.8)\n  -h, --help                 Show this help\n";
+  if (argc <= 2) { fputs(usage, stdout); return 0; }
+  const Args a = parse(argc, argv, 2, {{"genome-repeats", 'g', true}, {"proportion-repeat", 'p', true}}, usage);
+  if (a.pos.size() != 1) quit("expected 1 argument (fasta)\n%s", usage);
+  const std::string fasta = a.pos[0];
+  std::string out = a.get("genome-repeats", "");
+  if (out.empty()) {                                                               // lastPathPart(fasta) & ".str"
+    const size_t sl = fasta.find_last_of('/');
+    out = (sl == std::string::npos ? fasta : fasta.substr(sl + 1)) + ".str";
+  }
+  if (!file_exists(fasta)) quit("[strling] couldn't open fasta %s make sure file is present and has a .fai index", fasta.c_str());
+  fprintf(stderr, "Writing genome str index to: %s\n", out.c_str());
+  if (file_exists(out)) {                                                          // genome_strs.nim:139-140
+    fprintf(stderr, "[strling] using existing file %s for genome repeats\n", out.c_str());
+    return 0;
+  }
+  strl_ctx *ctx = nullptr;
+  CHECK(strl_ctx_create(0, &ctx));
+  strl_opts opts{0, atof(a.get("proportion-repeat", "0.8").c_str()), 0};
+  CHECK(strl_ctx_set_opts(ctx, &opts));
+  build_genome_index(ctx, fasta, out);
+  strl_ctx_destroy(ctx);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const char *top =
       "strling version: 0.6.0 (MI355X-native hot path)\n\nCommands:\n  extract  :   extract informative STR reads from a BAM (CRAM is not supported by this build).\n"
-      "  merge    :   merge putitive STR loci from multiple samples.\n  call     :   (not in this build) call STRs.\n  index    :   (not in this build) identify large STRs in the reference genome.\n";
+      "  merge    :   merge putitive STR loci from multiple samples.\n  call     :   (not in this build) call STRs.\n  index    :   identify large STRs in the reference genome.\n";
   if (argc < 2) { fputs(top, stdout); return 1; }
   const std::string cmd = argv[1];
   if (cmd == "extract") return extract_main(argc, argv);
   if (cmd == "merge") return merge_main(argc, argv);
+  if (cmd == "index") return index_main(argc, argv);
   if (cmd == "_dump") return dump_main(argc, argv);
-  if (cmd == "call" || cmd == "index" || cmd == "pull_region")
-    quit("[strling] `%s` is not part of this build (the MI355X path covers extract and merge; see DESIGN.md section 9)", cmd.c_str());
+  if (cmd == "call" || cmd == "pull_region")
+    quit("[strling] `%s` is not part of this build (the MI355X path covers index, extract and merge; see DESIGN.md section 9)", cmd.c_str());
   fputs(top, stdout);
   return 1;
 }

@@ -592,3 +592,70 @@ int strl_bounds_row(char *buf, int cap, const strl_bounds *b, const char *chrom)
 }
 
 }  // extern "C"
+
+// ---- strling index: window merge + trim, genome_strs.nim:22-92 ------------------------------------------------
+namespace {
+inline uint32_t base_code_ci(char ch) {   // after toUpperAscii (genome_strs.nim:71); anything not ACGT counts as 'A'
+  switch (ch) { case 'C': case 'c': return 0; case 'T': case 't': return 2; case 'G': case 'g': return 3; default: return 1; }
+}
+// minimum rotation of the k-mer at s[0..k) (utils.nim:10-34, one window)
+inline uint32_t min_rot(const char *s, int k, bool reversed) {
+  uint32_t f = 0;
+  for (int j = 0; j < k; ++j) f = (f << 2) | base_code_ci(reversed ? s[-j] : s[j]);
+  const uint32_t mask = (1u << (2 * k)) - 1u;
+  uint32_t best = f;
+  for (int j = 1; j < k; ++j) { f = ((f << 2) | (f >> (2 * k - 2))) & mask; best = std::min(best, f); }
+  return best;
+}
+// trim, genome_strs.nim:22-59: walk k-sized steps in from both ends until a step is a rotation of the unit
+bool trim_region(const char *seq, const Unit &u, uint64_t &start, uint64_t &stop) {
+  const int k = u.len;
+  const uint64_t len = stop - start, nwin = len / (uint64_t)k;
+  const uint32_t fwd = min_rot(u.s, k, false);
+  const uint32_t rev = min_rot(u.s + k - 1, k, true);
+  const char *dna = seq + start;
+  for (uint64_t i = 0; i < nwin; ++i) { if (min_rot(dna + i * k, k, false) != fwd) start += k; else break; }
+  if (!(start < stop)) return false;
+  const char *last = dna + len - 1;
+  for (uint64_t i = 0; i < nwin; ++i) { if (min_rot(last - i * k, k, true) != rev) stop -= k; else break; }
+  return start < stop;
+}
+}  // namespace
+
+extern "C" int strl_index_regions(const char *seq, uint64_t n_bases, const uint32_t *words, uint64_t n_windows, uint32_t window,
+                                  uint32_t step, strl_region *out, uint64_t cap, uint64_t *n_out) {
+  if ((!seq && n_bases) || (!words && n_windows) || !n_out || !window || !step || step > window) { set_error("bad argument"); return STRL_ERR_ARG; }
+  uint64_t n = 0;
+  int err = STRL_OK;
+  const uint64_t slack = window - step;
+  bool have = false;
+  uint64_t l_start = 0, l_stop = 0;
+  uint32_t l_word = 0;
+  auto flush = [&]() {     // genome_strs.nim:79-82 / :88-91
+    if (!have || l_stop - l_start < slack) return;
+    uint64_t a = l_start >= window ? l_start - window : 0, b = std::min<uint64_t>(l_stop + window, n_bases);
+    const Unit u = unpack_unit(l_word);
+    if (!trim_region(seq, u, a, b)) {
+      if (!err) set_error("repeat %.6s not found in expected region %llu-%llu (doAssert genome_strs.nim:39/57)", u.s, (unsigned long long)l_start, (unsigned long long)l_stop);
+      err = STRL_ERR_ASSERT;
+      return;
+    }
+    if (n < cap && out) { out[n].start = a; out[n].stop = b; memset(out[n].unit, 0, sizeof out[n].unit); memcpy(out[n].unit, u.s, 6); }
+    ++n;
+  };
+  for (uint64_t i = 0; i < n_windows; ++i) {
+    const uint32_t w = words[i];
+    if (STRL_RES_COUNT(w) == 0) continue;                       // :75
+    const uint64_t start = i * step, stop = std::min<uint64_t>(start + window, n_bases);
+    const uint32_t unit_bits = w & 0x7fffu;                     // code + k identify the unit string
+    if (!have || unit_bits != (l_word & 0x7fffu) || start > l_stop + slack) {   // :78
+      flush();
+      have = true; l_start = start; l_stop = stop; l_word = w;
+    } else l_stop = stop;
+  }
+  flush();
+  *n_out = n;
+  if (err) return err;
+  if (n > cap && out) { set_error("region buffer too small: %llu needed", (unsigned long long)n); return STRL_ERR_CAPACITY; }
+  return STRL_OK;
+}

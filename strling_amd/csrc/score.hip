@@ -56,7 +56,7 @@ constexpr int BIN_SHIFT = 12;
 
 // Work items are self-contained 16-byte queue entries, so the scorer never chases metadata pointers:
 //   whole read : id = read index            | seq_off | l_seq | clip_l << 16 | clip_r | cig << 16 | mapq << 24
-//   soft clip  : id = read index << 1 | side | seq_off | l_seq | clip_len << 16 | 0
+//   segment    : id (read index << 1 | side, or a window index) | seq_off | first base | length
 // Stage-B items are 32 bytes: the entry + {slot, best, res0, res1}.
 constexpr uint32_t EMPTY = 0xffffffffu;
 constexpr int CNT_STRIDE = 16;   // counters 64 B apart
@@ -86,6 +86,7 @@ struct ScoreParams {
   strl_soft_rec *soft_out;
   uint32_t soft_cap;
   uint32_t min_mapq;
+  int32_t seg_row0, seg_row1;   // threshold rows of the segment scorer: (2,3) for soft clips, (1,1) for genome windows
 };
 
 constexpr int LUT_DWORDS = LUT_ENTRIES / 2;
@@ -329,6 +330,16 @@ template <int NW, int SLOTS, int STAGE> constexpr int table_rows() {
   return raw > need ? raw : need;
 }
 
+// `strling index`: the scorer over fixed windows of a chromosome (genome_strs.nim:61-92: window 100, step 60)
+__global__ void window_items_kernel(ScoreParams P, uint32_t n_win, uint32_t window, uint32_t step, uint64_t n_bases) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) P.counters[CNT_SOFT] = n_win;
+  if (i >= n_win) return;
+  const uint64_t s0 = (uint64_t)i * step;
+  const uint64_t len = s0 + window <= n_bases ? window : n_bases - s0;
+  P.soft_queue[i] = make_uint4(i, 0u, (uint32_t)s0, (uint32_t)len);
+}
+
 template <int MODE, int STAGE> struct Item {
   uint32_t id, seq_off, slot;
   int L, len, s0;
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(BLOCK) void score_kernel(ScoreParams P) {
   uint32_t *wave_tab = lds + LUTW + wave * (table_rows<NW, SLOTS, STAGE>() * 64);
   uint32_t *col = wave_tab + lane;
   constexpr int MAXCH = (16 * NW + 62) / 32;
-  constexpr int ROW0 = MODE == 0 ? 1 : 2, ROW1 = MODE == 0 ? 1 : 3;
+  const int ROW0 = MODE == 0 ? 1 : P.seg_row0, ROW1 = MODE == 0 ? 1 : P.seg_row1;
   uint32_t n_items;
   const uint4 *q;
   if (STAGE == 1) { n_items = P.counters[MODE == 0 ? CNT_SBW : CNT_SBS]; q = P.sb_queue[MODE]; }
@@ -382,10 +393,9 @@ __global__ __launch_bounds__(BLOCK) void score_kernel(ScoreParams P) {
       it.len = it.L; it.s0 = 0;
     } else {
       it.cl = it.cr = it.cg = it.mq = 0;
-      int len = (int)(e.z >> 16);
-      if (len > it.L) len = it.L;
-      it.len = len;
-      it.s0 = (e.x & 1u) ? it.L - len : 0;
+      it.s0 = (int)e.z;
+      it.len = (int)e.w;
+      it.L = it.len;
     }
     if (it.len > 16 * NW) it.len = 16 * NW;  // host picks NW from max_l_seq; never taken
     if (!it.act) { it.len = 0; it.s0 = 0; }
@@ -441,10 +451,11 @@ __global__ __launch_bounds__(BLOCK) void score_kernel(ScoreParams P) {
           if (cur.mq >= P.min_mapq && (cur.cg & (STRL_CIG_FIRST_S | STRL_CIG_LAST_S))) {
             const bool has_unit = STRL_RES_K(o0) != 0;
             if ((cur.cg & STRL_CIG_FIRST_S) && (has_unit || cur.cl > 16))
-              sl = make_uint4(cur.id << 1, cur.seq_off, (uint32_t)cur.L | (cur.cl << 16), 0u);
+              sl = make_uint4(cur.id << 1, cur.seq_off, 0u, cur.cl < (uint32_t)cur.L ? cur.cl : (uint32_t)cur.L);
             // with a single cigar op both loop iterations are cig_index == 0 (the host replays the duplicate)
             if ((cur.cg & STRL_CIG_LAST_S) && !(cur.cg & STRL_CIG_ONE_OP) && (has_unit || cur.cr > 16))
-              sr = make_uint4((cur.id << 1) | 1u, cur.seq_off, (uint32_t)cur.L | (cur.cr << 16), 0u);
+              { const uint32_t cl2 = cur.cr < (uint32_t)cur.L ? cur.cr : (uint32_t)cur.L;
+                sr = make_uint4((cur.id << 1) | 1u, cur.seq_off, (uint32_t)cur.L - cl2, cl2); }
           }
         }
         P.soft_dense[2 * (uint64_t)cur.slot] = sl;       // forwarded items leave EMPTY; stage B overwrites
@@ -701,6 +712,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   P.counters = c->counters.as<uint32_t>(); P.soft_out = soft;
   P.soft_cap = (uint32_t)std::min<uint64_t>(soft_cap, 0xffffffffull);
   P.min_mapq = c->opts.min_mapq;
+  P.seg_row0 = 2; P.seg_row1 = 3;
   hipEvent_t *tev = c->timing ? &c->ring[(c->ring_pos % RING) * 4] : nullptr;
   if (c->timing) ++c->ring_pos;
   if (tev) STRL_HIP(hipEventRecord(tev[0], c->stream));
@@ -737,6 +749,50 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
       }
     }
   }
+  return STRL_OK;
+}
+
+int strl_index_chrom(strl_ctx *c, const char *seq, uint64_t n_bases, uint32_t window, uint32_t step, uint32_t *words, uint64_t *n_windows) {
+  if (!c || (!seq && n_bases) || !window || !step) { set_error("bad argument"); return STRL_ERR_ARG; }
+  if (!c->have_opts) { set_error("strl_ctx_set_opts must be called before scoring"); return STRL_ERR_ARG; }
+  if (window > 160) { set_error("window %u too long (<= 160)", window); return STRL_ERR_ARG; }
+  if (n_bases >= (1ull << 31)) { set_error("sequence too long (< 2^31 bases)"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  const uint64_t nw = n_bases ? (n_bases + step - 1) / step : 0;
+  if (n_windows) *n_windows = nw;
+  if (!nw || !words) return STRL_OK;
+  // hts-nim's fai.get + toUpperAscii, then the BAM nibble code of every base (anything that is not an IUPAC letter
+  // becomes '=' : never 'N', never a match)
+  static const char nt16[] = "=ACMGRSVTWYHKDBN";
+  uint8_t code[256];
+  memset(code, 0, sizeof code);
+  for (int i = 0; i < 16; ++i) { code[(unsigned char)nt16[i]] = (uint8_t)i; code[(unsigned char)(nt16[i] | 0x20)] = (uint8_t)i; }
+  code[(unsigned char)'='] = 0;
+  std::vector<uint8_t> packed((size_t)(n_bases + 1) / 2 + 64, 0);
+  for (uint64_t i = 0; i + 1 < n_bases; i += 2) packed[(size_t)(i >> 1)] = (uint8_t)((code[(unsigned char)seq[i]] << 4) | code[(unsigned char)seq[i + 1]]);
+  if (n_bases & 1) packed[(size_t)(n_bases >> 1)] = (uint8_t)(code[(unsigned char)seq[n_bases - 1]] << 4);
+  int rc;
+  if ((rc = c->st_seq4.reserve(packed.size()))) return rc;
+  if ((rc = c->soft_queue.reserve((size_t)nw * 16))) return rc;
+  if ((rc = c->sb_state_s.reserve((size_t)nw * 16))) return rc;
+  if ((rc = c->sb_soft.reserve((size_t)nw * 32))) return rc;
+  if ((rc = c->st_soft.reserve((size_t)nw * sizeof(strl_soft_rec)))) return rc;
+  STRL_HIP(hipMemcpyAsync(c->st_seq4.p, packed.data(), packed.size(), hipMemcpyHostToDevice, c->stream));
+  STRL_HIP(hipMemsetAsync(c->counters.p, 0, CNT_WORDS * 4, c->stream));
+  ScoreParams P{};
+  P.n = nw; P.seq4 = c->st_seq4.as<uint8_t>();
+  P.lut = c->lut.as<uint16_t>(); P.thr = c->thr.as<uint64_t>();
+  P.soft_queue = c->soft_queue.as<uint4>(); P.scap = (uint32_t)nw;
+  P.sb_state[1] = c->sb_state_s.as<uint4>(); P.sb_queue[1] = c->sb_soft.as<uint4>();
+  P.counters = c->counters.as<uint32_t>(); P.soft_out = c->st_soft.as<strl_soft_rec>(); P.soft_cap = (uint32_t)nw;
+  P.seg_row0 = 1; P.seg_row1 = 1;                       // genome windows are scored with the plain -p threshold (genome_strs.nim:74)
+  hipLaunchKernelGGL(window_items_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, c->stream, P, (uint32_t)nw, window, step, n_bases);
+  STRL_HIP(hipGetLastError());
+  if ((rc = launch_score_class<1>(c, P, window))) return rc;
+  std::vector<strl_soft_rec> out((size_t)nw);
+  STRL_HIP(hipMemcpyAsync(out.data(), c->st_soft.p, (size_t)nw * sizeof(strl_soft_rec), hipMemcpyDeviceToHost, c->stream));
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  for (uint64_t i = 0; i < nw; ++i) words[out[(size_t)i].read_side] = out[(size_t)i].res_first;
   return STRL_OK;
 }
 

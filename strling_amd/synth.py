@@ -282,3 +282,40 @@ def synth_treads(n_samples=4, n_loci=400, seed=1000, n_contigs=25, contig_len=10
         t["align_length"] = 150
         out.append(t)
     return np.concatenate(out)
+
+
+def synth_chrom(n_bases, seed=1, n_str=None, soft_mask=True):
+    """One reference chromosome for `strling index`: random ACGT with embedded STR arrays (pure and interrupted,
+    units of 1-6 bases, some spanning many 100-base windows, some touching the chromosome ends, adjacent arrays
+    with different units), N gaps, IUPAC letters and lower-case (soft-masked) stretches."""
+    rng = _rng(seed)
+    seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), n_bases).copy()
+    if n_str is None:
+        n_str = max(4, n_bases // 4000)
+    spots = np.sort(rng.integers(0, max(1, n_bases - 50), n_str))
+    for j, at in enumerate(spots):
+        k = int(rng.integers(1, 7))
+        unit = rng.choice(np.frombuffer(b"ACGT", np.uint8), k)
+        ln = int(rng.choice([40, 70, 100, 130, 200, 400, 1500]))
+        arr = np.resize(unit, ln).copy()
+        nerr = int(ln * rng.choice([0.0, 0.0, 0.02, 0.08, 0.2]))
+        if nerr:
+            arr[rng.integers(0, ln, nerr)] = rng.choice(np.frombuffer(b"ACGT", np.uint8), nerr)
+        if j == 0:
+            at = 0
+        if j == n_str - 1:
+            at = max(0, n_bases - ln)
+        ln = min(ln, n_bases - at)
+        seq[at:at + ln] = arr[:ln]
+        if j % 5 == 4 and at + ln + 120 < n_bases:          # a second array right behind, different unit
+            u2 = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(rng.integers(2, 7)))
+            seq[at + ln:at + ln + 120] = np.resize(u2, 120)
+    for _ in range(max(1, n_bases // 20000)):               # N gaps and stray IUPAC letters
+        at = int(rng.integers(0, n_bases))
+        seq[at:at + int(rng.choice([5, 25, 300]))] = ord("N")
+        seq[int(rng.integers(0, n_bases))] = int(rng.choice(np.frombuffer(b"RYKMSWn", np.uint8)))
+    if soft_mask:
+        for _ in range(max(1, n_bases // 10000)):
+            at = int(rng.integers(0, n_bases))
+            seq[at:at + 500] |= 0x20
+    return seq.tobytes()

@@ -100,3 +100,69 @@ def test_merge_bounds_match_oracle(sample, oracle, tmp_path):
     got = open(prefix + "-bounds.txt").read().rstrip("\n").split("\n")
     assert len(exp) > 3
     assert got == exp
+
+
+def _write_fasta(path, contigs, width=70, gz=False):
+    import gzip
+    op = gzip.open if gz else open
+    with op(path, "wb") as f:
+        for name, seq in contigs:
+            f.write(b">" + name.encode() + b" some description\n")
+            for i in range(0, len(seq), width):
+                f.write(seq[i:i + width] + b"\n")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gz", [False, True])
+def test_index_bed_is_identical_to_oracle(oracle, tmp_path, gz):
+    """strling index FASTA -> <FASTA>.str rows == the oracle's repeat_windows/trim rows (genome_strs.nim:61-137)"""
+    contigs = [("chr1", synth.synth_chrom(300_000, 31)), ("chrEmpty", b""), ("chr2", synth.synth_chrom(70_001, 32)), ("tiny", b"ACGTACGTAC")]
+    fa = str(tmp_path / ("ref.fa.gz" if gz else "ref.fa"))
+    _write_fasta(fa, contigs, gz=gz)
+    out = str(tmp_path / "ref.str")
+    r = _run(["index", "-g", out, fa])
+    assert r.returncode == 0, r.stderr
+    assert f"Writing genome str index to: {out}" in r.stderr and "STR-like regions in the genome" in r.stderr
+    exp = "".join(f"{name}\t{a}\t{b}\t{u}\n" for name, seq in contigs for a, b, u in oracle.index_chrom(seq.upper(), 0.8))
+    assert exp.count("\n") > 50
+    assert open(out).read() == exp
+    # an existing file is left alone (genome_strs.nim:139-140), default output name is ./<FASTA>.str
+    open(out, "w").write("untouched\n")
+    r = _run(["index", "-g", out, "-p", "0.7", fa])
+    assert r.returncode == 0 and "using existing file" in r.stderr and open(out).read() == "untouched\n"
+    r = _run(["index", "-p", "0.7", fa], cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    exp7 = "".join(f"{name}\t{a}\t{b}\t{u}\n" for name, seq in contigs for a, b, u in oracle.index_chrom(seq.upper(), 0.7))
+    assert open(str(tmp_path / (os.path.basename(fa) + ".str"))).read() == exp7
+
+
+@pytest.mark.gpu
+def test_extract_builds_missing_genome_index(oracle, tmp_path):
+    """extract -f FASTA -g MISSING creates the index first (genome_strs.nim:124-138) and then uses it."""
+    n_contigs, clen = 3, 200_000
+    contigs = [(f"chr{i + 1}", synth.synth_chrom(clen, 40 + i)) for i in range(n_contigs)]
+    fa = str(tmp_path / "ref.fa")
+    _write_fasta(fa, contigs)
+    rec, _ = synth.synth_wgs(4000, seed=77, n_contigs=n_contigs, contig_len=clen)
+    bam = str(tmp_path / "s.bam")
+    hdr = bamio.write_bam(bam, rec)
+    bed = str(tmp_path / "made.str")
+    out = str(tmp_path / "s.bin")
+    r = _run(["extract", "-f", fa, "-g", bed, bam, out])
+    assert r.returncode == 0, r.stderr
+    rows = [(name, a, b) for name, seq in contigs for a, b, u in oracle.index_chrom(seq.upper(), 0.8)]
+    assert [tuple(l.split("\t")[:3]) for l in open(bed).read().splitlines()] == [(n, str(a), str(b)) for n, a, b in rows]
+    from strling_amd.records import GenomeStr
+    per = {i: [(a, b) for n, a, b in rows if n == name] for i, (name, _) in enumerate(contigs) if any(n == name for n, _, _ in rows)}
+    g = GenomeStr.from_lists(n_contigs, per)
+    frag = synth.frag_hist(rec)
+    exp_t = oracle.extract(rec, g, oracle.make_opts(oracle.median(frag), 0.8, 40))
+    exp = oracle.bin_write(0.8, 40, frag, hdr.rstrip("\0"), exp_t, rec.qname_off, rec.qnames)
+    assert open(out, "rb").read() == exp
+    # without -g the index goes to a temporary file that is removed again; without -f and -g it cannot be built
+    out2 = str(tmp_path / "s2.bin")
+    r = _run(["extract", "-f", fa, bam, out2])
+    assert r.returncode == 0, r.stderr
+    assert open(out2, "rb").read() == exp
+    r = _run(["extract", bam, out2])
+    assert r.returncode == 1 and "couldn't open fasta" in r.stderr

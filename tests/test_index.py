@@ -1,0 +1,57 @@
+"""`strling index` (genome_strs.nim:22-92): window scoring on the device, merge + trim on the host."""
+import numpy as np
+import pytest
+
+from strling_amd import api, synth
+from helpers import pack_word
+
+
+def oracle_window_words(O, seq, p, window=100, step=60):
+    up = seq.upper()
+    return np.array([pack_word(*O.get_repeat(up[s:s + window], p)) for s in range(0, len(up), step)], np.uint32)
+
+
+def test_reference_regression_window_fires_trims_doassert(oracle):
+    """genome_strs.nim:203-206 (the commented-out `bug` case): no unit-sized step counted from the right end of that
+    window is a rotation of CACGAT, so trim's second doAssert (:57) fires.  Both the oracle and the host logic must
+    report it instead of returning a region."""
+    dna = "ATAACACTTGGGGGTAGCTAAAGTGAACTGTATCCGACATCTGGTTCCTACTTCAGGGTCATAAAGCCTAAATAGCCCACACGTTCCCCTTAAATAAGACATCACGATG"
+    assert len(dna) == 16569 - 16460
+    words = np.array([pack_word("CACGAT", 15)], np.uint32)
+    with pytest.raises(api.StrlingError, match="genome_strs.nim"):
+        api.index_regions(dna.encode(), words, window=len(dna), step=len(dna) - 1)
+    # the same window with the unit present at both ends trims cleanly to the outermost full units
+    ok = "GG" + "CACGAT" * 17 + "TTTTT"
+    (start, stop, unit), = api.index_regions(ok.encode(), np.array([pack_word("CACGAT", 17)], np.uint32), window=len(ok), step=len(ok) - 1)
+    assert (unit, start % 6, stop) == ("CACGAT", 0, len(ok) - 6) and start <= 6
+
+
+@pytest.mark.parametrize("n_bases,seed,p", [(60_000, 1, 0.8), (25_000, 2, 0.6), (9_999, 3, 0.9), (130, 4, 0.8), (59, 5, 0.8), (0, 6, 0.8)])
+def test_host_merge_trim_matches_oracle(oracle, n_bases, seed, p):
+    seq = synth.synth_chrom(n_bases, seed) if n_bases else b""
+    exp = oracle.index_chrom(seq.upper(), p)
+    words = oracle_window_words(oracle, seq, p)
+    got = api.index_regions(seq, words)
+    assert got == exp
+    if n_bases >= 9_999:
+        assert len(exp) >= 2
+
+
+def test_one_skipped_window_still_merges(oracle):
+    rng = np.random.default_rng(0)
+    rnd = lambda n: "".join(rng.choice(list("ACGT"), n))
+    seq = (rnd(500) + "CAG" * 40 + rnd(70) + "CAG" * 40 + rnd(500) + "AT" * 100 + "GGC" * 60 + rnd(300)).encode()
+    exp = oracle.index_chrom(seq, 0.8)
+    assert api.index_regions(seq, oracle_window_words(oracle, seq, 0.8)) == exp
+    assert [u for _, _, u in exp] == ["CAG", "AT", "CGG"] or len(exp) >= 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_bases,seed,p", [(400_000, 11, 0.8), (50_001, 12, 0.6), (61, 13, 0.8)])
+def test_index_windows_and_regions_match_oracle(ctx, oracle, n_bases, seed, p):
+    seq = synth.synth_chrom(n_bases, seed)
+    ctx.set_opts(p, 40, 350)
+    words = ctx.index_chrom(seq)
+    exp_words = oracle_window_words(oracle, seq.decode(), p)
+    assert np.array_equal(words, exp_words), np.nonzero(words != exp_words)[0][:10]
+    assert ctx.index_regions(seq) == oracle.index_chrom(seq.upper(), p)
