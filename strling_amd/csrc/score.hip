@@ -340,6 +340,40 @@ __global__ void window_items_kernel(ScoreParams P, uint32_t n_win, uint32_t wind
   P.soft_queue[i] = make_uint4(i, 0u, (uint32_t)s0, (uint32_t)len);
 }
 
+// chromosome text -> BAM nibble packing (what the scorer reads), 8 bases per lane per round.  Letters are folded to
+// upper case (genome_strs.nim:71 toUpperAscii); anything that is not an IUPAC letter becomes '=' (code 0): not 'N',
+// never a match -- the same thing the kmer table makes of it.
+__device__ inline uint32_t nt16_code(uint32_t ch) {
+  switch (ch & ~0x20u) {
+    case 'A': return 1; case 'C': return 2; case 'M': return 3; case 'G': return 4; case 'R': return 5; case 'S': return 6;
+    case 'V': return 7; case 'T': return 8; case 'W': return 9; case 'Y': return 10; case 'H': return 11; case 'K': return 12;
+    case 'D': return 13; case 'B': return 14; case 'N': return 15; default: return 0;
+  }
+}
+__global__ __launch_bounds__(256) void pack_text_kernel(const uint8_t *__restrict__ text, uint32_t *__restrict__ seq4, uint64_t n_bases, uint64_t n_dwords) {
+  __shared__ uint8_t tbl[256];
+  tbl[threadIdx.x] = (uint8_t)nt16_code(threadIdx.x);
+  __syncthreads();
+  for (uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x; d < n_dwords; d += (uint64_t)gridDim.x * 256) {
+    uint32_t out = 0;
+    if (8 * d + 8 <= n_bases) {
+      const uint2 t = *reinterpret_cast<const uint2 *>(text + 8 * d);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t w = j < 2 ? t.x >> (16 * j) : t.y >> (16 * (j - 2));
+        out |= (((uint32_t)tbl[w & 0xffu] << 4) | tbl[(w >> 8) & 0xffu]) << (8 * j);
+      }
+    } else {
+      for (int b = 0; b < 8; ++b) {
+        const uint64_t i = 8 * d + b;
+        const uint32_t cde = i < n_bases ? tbl[text[i]] : 0u;
+        out |= cde << (8 * (b >> 1) + ((b & 1) ? 0 : 4));
+      }
+    }
+    seq4[d] = out;
+  }
+}
+
 template <int MODE, int STAGE> struct Item {
   uint32_t id, seq_off, slot;
   int L, len, s0;
@@ -761,23 +795,18 @@ int strl_index_chrom(strl_ctx *c, const char *seq, uint64_t n_bases, uint32_t wi
   const uint64_t nw = n_bases ? (n_bases + step - 1) / step : 0;
   if (n_windows) *n_windows = nw;
   if (!nw || !words) return STRL_OK;
-  // hts-nim's fai.get + toUpperAscii, then the BAM nibble code of every base (anything that is not an IUPAC letter
-  // becomes '=' : never 'N', never a match)
-  static const char nt16[] = "=ACMGRSVTWYHKDBN";
-  uint8_t code[256];
-  memset(code, 0, sizeof code);
-  for (int i = 0; i < 16; ++i) { code[(unsigned char)nt16[i]] = (uint8_t)i; code[(unsigned char)(nt16[i] | 0x20)] = (uint8_t)i; }
-  code[(unsigned char)'='] = 0;
-  std::vector<uint8_t> packed((size_t)(n_bases + 1) / 2 + 64, 0);
-  for (uint64_t i = 0; i + 1 < n_bases; i += 2) packed[(size_t)(i >> 1)] = (uint8_t)((code[(unsigned char)seq[i]] << 4) | code[(unsigned char)seq[i + 1]]);
-  if (n_bases & 1) packed[(size_t)(n_bases >> 1)] = (uint8_t)(code[(unsigned char)seq[n_bases - 1]] << 4);
+  const uint64_t n_dwords = (n_bases + 7) / 8 + 16;       // 64 bytes of zero slack behind the last base
   int rc;
-  if ((rc = c->st_seq4.reserve(packed.size()))) return rc;
+  if ((rc = c->st_text.reserve((size_t)n_bases + 8))) return rc;
+  if ((rc = c->st_seq4.reserve((size_t)n_dwords * 4))) return rc;
   if ((rc = c->soft_queue.reserve((size_t)nw * 16))) return rc;
   if ((rc = c->sb_state_s.reserve((size_t)nw * 16))) return rc;
   if ((rc = c->sb_soft.reserve((size_t)nw * 32))) return rc;
   if ((rc = c->st_soft.reserve((size_t)nw * sizeof(strl_soft_rec)))) return rc;
-  STRL_HIP(hipMemcpyAsync(c->st_seq4.p, packed.data(), packed.size(), hipMemcpyHostToDevice, c->stream));
+  STRL_HIP(hipMemcpyAsync(c->st_text.p, seq, (size_t)n_bases, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(pack_text_kernel, dim3((unsigned)std::min<uint64_t>((n_dwords + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                     c->st_text.as<uint8_t>(), c->st_seq4.as<uint32_t>(), n_bases, n_dwords);
+  STRL_HIP(hipGetLastError());
   STRL_HIP(hipMemsetAsync(c->counters.p, 0, CNT_WORDS * 4, c->stream));
   ScoreParams P{};
   P.n = nw; P.seq4 = c->st_seq4.as<uint8_t>();
