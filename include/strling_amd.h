@@ -232,9 +232,66 @@ int strl_cluster(strl_ctx *ctx, const strl_tread *treads, uint64_t n, int mode, 
                  uint64_t *n_out, strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced,
                  strl_cluster_stats *stats);
 
+/* The reads of every bound the last strl_cluster call on this context returned, in cluster order (position-sorted,
+ * stable): bound j holds treads[members[member_off[j]]] .. treads[members[member_off[j+1] - 1]] (indices into the
+ * array given to strl_cluster; c.reads of call.nim:246).  member_off is [n_bounds + 1]. */
+int strl_cluster_members(strl_ctx *ctx, uint64_t *member_off, uint32_t *members, uint64_t cap, uint64_t *n_members);
+
 /* Re-run the device side of the last strl_cluster call (sorts, sweep, bounds) over the treads still resident on
  * the device, asynchronously on the context stream and without host synchronisation.  For timing. */
 int strl_cluster_replay(strl_ctx *ctx);
+
+/* ---- `strling call` evidence around one bound and the genotype record (host; collect.nim, spanning.nim,
+ * genotyper.nim).  The caller performs the indexed BAM read (hts-nim `b.query(tid, start, stop)`, collect.nim:141)
+ * and hands the records over; `isize` is aln.isize of each record. ---- */
+#define STRL_SPANNING_FRAGMENT 0 /* collect.nim:10-13 SupportType */
+#define STRL_SPANNING_READ 1
+#define STRL_OVERLAPPING_READ 2
+typedef struct { /* collect.nim:15-31 Support; repeat = the bound's unit, qname = qname of record `rec` */
+  uint8_t type, repeat_count, cigar_ins, cigar_del;
+  uint32_t fragment_length;
+  double fragment_percentile;
+  int64_t rec;
+} strl_support;
+typedef struct {
+  int32_t median_depth;    /* -1: more than 20 000 read pairs in the window (collect.nim:171-174) */
+  float expected_spanners;
+  uint64_t n_support;
+} strl_span_summary;
+/* spanners(), collect.nim:132-182: out receives the Support list in the reference's order; records outside the
+ * queried region [max(0, left - window), right + window) are ignored, so `r` may be a superset of the query result. */
+int strl_spanners(const strl_records *r, const int32_t *isize, const strl_bounds *b, int32_t window, const uint32_t frag[4096],
+                  uint8_t min_mapq, strl_support *out, uint64_t cap, strl_span_summary *sum);
+
+typedef struct { /* the Options fields genotype() reads (utils.nim:119-127, call.nim:106-110) */
+  int32_t median_fragment_length;
+  int32_t min_support;
+  uint16_t min_clip, min_clip_total;
+} strl_call_opts;
+typedef struct { /* genotyper.nim:29-52 Call */
+  int32_t tid;
+  uint32_t start, stop;
+  char repeat[7];
+  double allele1, allele2;
+  uint32_t overlapping_reads, anchored_reads, spanning_reads, spanning_pairs, left_clips, right_clips, sum_str_counts;
+  float expected_spanning_fragments, spanning_fragments_oe_percentile;
+  int32_t unplaced_reads;
+  double depth;
+  int32_t is_large;
+} strl_call;
+/* genotype(), genotyper.nim:150-199 */
+int strl_genotype(const strl_bounds *b, const strl_tread *members, uint64_t n_members, const uint64_t *qname_off, const char *qnames,
+                  const strl_support *spanners, uint64_t n_spanners, const strl_call_opts *opts, double depth, strl_call *call);
+/* After every bound: add_percentile (call.nim:38-48), the single-large-expansion refinement (:264-276) and the row
+ * order of -genotype.txt (Table[string, seq[Call]] by canonical unit).  calls in the order they were made;
+ * order[n] receives the indices in output order. */
+int strl_calls_finish(strl_call *calls, uint64_t n, const strl_unplaced *unplaced, uint64_t n_unplaced, uint64_t *order);
+/* Row order of -unplaced.txt (CountTable[string], call.nim:280-281) for the unplaced list strl_cluster returned */
+int strl_unplaced_order(const strl_unplaced *unplaced, uint64_t n, uint64_t *order);
+/* one -genotype.txt row (genotyper.nim:54-57), without newline */
+int strl_call_row(char *buf, int cap, const strl_call *call, const char *chrom);
+/* canonical_repeat, utils.nim:304-316 */
+void strl_canonical_repeat(const char in[6], char out[6]);
 
 /* ---- fragment-length statistics (utils.nim:139-146) ---- */
 int strl_frag_median(const uint32_t frag[4096], double pct);

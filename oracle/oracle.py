@@ -65,6 +65,25 @@ BOUNDS_DTYPE = np.dtype([("tid", "<i4"), ("left", "<u4"), ("left_most", "<u4"), 
 assert BOUNDS_DTYPE.itemsize == C.sizeof(Bounds), (BOUNDS_DTYPE.itemsize, C.sizeof(Bounds))
 
 
+class Support(C.Structure):
+    _fields_ = [("type", C.c_uint8), ("repeat_count", C.c_uint8), ("cigar_ins", C.c_uint8), ("cigar_del", C.c_uint8),
+                ("frag_len", C.c_uint32), ("frag_pct", C.c_double), ("rec", C.c_int64)]
+
+
+SUPPORT_DTYPE = np.dtype([("type", "u1"), ("repeat_count", "u1"), ("cigar_ins", "u1"), ("cigar_del", "u1"), ("frag_len", "<u4"),
+                          ("frag_pct", "<f8"), ("rec", "<i8")], align=True)
+assert SUPPORT_DTYPE.itemsize == C.sizeof(Support)
+SUPPORT_TYPES = ["SpanningFragment", "SpanningRead", "OverlappingRead"]
+
+
+class Gt(C.Structure):
+    _fields_ = [("tid", C.c_int32), ("start", C.c_uint32), ("stop", C.c_uint32), ("repeat", C.c_char * 7), ("allele1", C.c_double),
+                ("allele2", C.c_double), ("overlapping_reads", C.c_uint32), ("anchored_reads", C.c_uint32), ("spanning_reads", C.c_uint32),
+                ("spanning_pairs", C.c_uint32), ("left_clips", C.c_uint32), ("right_clips", C.c_uint32), ("sum_str_counts", C.c_uint32),
+                ("expected_spanning_fragments", C.c_float), ("pctile", C.c_float), ("unplaced_reads", C.c_int32), ("depth", C.c_double),
+                ("is_large", C.c_int)]
+
+
 class Unplaced(C.Structure):
     _fields_ = [("repeat", C.c_char * 7), ("count", C.c_int64)]
 
@@ -113,6 +132,27 @@ def lib():
         L.orc_bounds_row.restype = C.c_int
         L.orc_index_chrom.argtypes = [C.c_char_p, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.orc_index_chrom.restype = C.c_int64
+        L.orc_cumulative.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_expected_spanning_probability.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int64]
+        L.orc_expected_spanning_probability.restype = C.c_double
+        L.orc_percentile.argtypes = [C.c_void_p, C.c_int64]
+        L.orc_percentile.restype = C.c_double
+        L.orc_median_depth.argtypes = [C.c_void_p, C.c_int64]
+        L.orc_overlapping_read.argtypes = [C.POINTER(Records), C.c_int64, C.POINTER(Bounds), C.POINTER(Support)]
+        L.orc_spanning_fragment.argtypes = [C.POINTER(Records), C.c_void_p, C.c_int64, C.c_int64, C.POINTER(Bounds), C.POINTER(Support), C.c_void_p]
+        L.orc_spanners.argtypes = [C.POINTER(Records), C.c_void_p, C.POINTER(Bounds), C.c_int, C.c_void_p, C.c_uint8, C.c_void_p, C.c_int64,
+                                   C.POINTER(C.c_int), C.POINTER(C.c_float)]
+        L.orc_spanners.restype = C.c_int64
+        L.orc_spanning_read_est.argtypes = [C.c_void_p, C.c_int64] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_uint32)]
+        L.orc_genotype.argtypes = [C.POINTER(Bounds), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint16,
+                                   C.c_uint16, C.c_int, C.c_double, C.POINTER(Gt)]
+        L.orc_call_row.argtypes = [C.c_char_p, C.c_int, C.POINTER(Gt), C.c_char_p]
+        L.orc_call.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(Records), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                               C.c_uint16, C.c_uint16, C.c_uint8, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                               C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.orc_call_members.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_uint16, C.c_uint16, C.c_uint16, C.c_void_p, C.c_void_p,
+                                       C.c_int64, C.POINTER(C.c_int64)]
+        L.orc_call_members.restype = C.c_int64
         L.orc_cluster_group.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
     return _LIB
 
@@ -325,6 +365,88 @@ def index_chrom(seq, p=0.8, window=100, step=60):
     if n < 0:
         raise AssertionError("doAssert of genome_strs.trim would fire")
     return [(int(st[i]), int(en[i]), un[i].decode()) for i in range(n)]
+
+
+def make_bounds(tid, left, right, repeat, **kw):
+    b = Bounds()
+    b.tid, b.left, b.right, b.repeat = tid, left, right, repeat.encode()
+    for k, v in kw.items():
+        setattr(b, k, v)
+    return b
+
+
+def _as_bounds(b):
+    return Bounds.from_buffer_copy(b.tobytes()) if isinstance(b, np.void) else b
+
+
+def median_depth(depths):
+    d = np.ascontiguousarray(depths, np.int64)
+    return lib().orc_median_depth(d.ctypes.data, d.size)
+
+
+def overlapping_read(rec, i, b):
+    """collect.nim:97-119 -> None or Support"""
+    rv = RecordsView(rec)
+    s = Support()
+    return s if lib().orc_overlapping_read(C.byref(rv.c), i, C.byref(_as_bounds(b)), C.byref(s)) else None
+
+
+def spanning_fragment(rec, l, r, b, frag):
+    rv = RecordsView(rec)
+    s = Support()
+    frag = np.ascontiguousarray(frag, np.uint32)
+    isz = np.ascontiguousarray(rec.isize if rec.isize is not None else np.zeros(rec.n), np.int32)
+    ok = lib().orc_spanning_fragment(C.byref(rv.c), isz.ctypes.data, l, r, C.byref(_as_bounds(b)), C.byref(s), frag.ctypes.data)
+    return s if ok else None
+
+
+def spanners(rec, b, window, frag, min_mapq=20):
+    """collect.nim:132-182 over all records of `rec` -> (support array, median_depth, expected_spanners)"""
+    rv = RecordsView(rec)
+    frag = np.ascontiguousarray(frag, np.uint32)
+    isz = np.ascontiguousarray(rec.isize if rec.isize is not None else np.zeros(rec.n), np.int32)
+    cap = 2 * rec.n + 16
+    out = np.zeros(cap, SUPPORT_DTYPE)
+    md, es = C.c_int(0), C.c_float(0)
+    n = lib().orc_spanners(C.byref(rv.c), isz.ctypes.data, C.byref(_as_bounds(b)), window, frag.ctypes.data, min_mapq, out.ctypes.data, cap,
+                           C.byref(md), C.byref(es))
+    return out[:n].copy(), md.value, es.value
+
+
+def spanning_read_est(supports):
+    s = np.ascontiguousarray(supports, SUPPORT_DTYPE)
+    v = [C.c_double(0) for _ in range(4)]
+    sup = C.c_uint32(0)
+    lib().orc_spanning_read_est(s.ctypes.data, s.size, *[C.byref(x) for x in v], C.byref(sup))
+    return dict(allele1_bp=v[0].value, allele2_bp=v[1].value, allele1_ru=v[2].value, allele2_ru=v[3].value, supporting_reads=sup.value)
+
+
+def call(treads, rec, frag, min_support=5, min_clip=0, min_clip_total=0, min_mapq=40):
+    """call.nim:111-285 (no -l/-b): (bounds.txt, genotype.txt, unplaced.txt) texts.  tread.qname_id indexes rec's qnames."""
+    t = np.ascontiguousarray(treads, dtype=TREAD_DTYPE)
+    rv = RecordsView(rec)
+    frag = np.ascontiguousarray(frag, np.uint32)
+    isz = np.ascontiguousarray(rec.isize if rec.isize is not None else np.zeros(rec.n), np.int32)
+    names = (C.c_char_p * len(rec.targets))(*[n.encode() for n, _ in rec.targets])
+    caps = [1 << 22, 1 << 22, 1 << 16]
+    bufs = [C.create_string_buffer(c) for c in caps]
+    ns = [C.c_int64(0) for _ in range(3)]
+    lib().orc_call(t.ctypes.data, t.size, rv.keep["qname_off"].ctypes.data, rv.keep["qnames"].ctypes.data, C.byref(rv.c), isz.ctypes.data,
+                   frag.ctypes.data, names, min_support, min_clip, min_clip_total, min_mapq, bufs[0], caps[0], bufs[1], caps[1], bufs[2], caps[2],
+                   C.byref(ns[0]), C.byref(ns[1]), C.byref(ns[2]))
+    assert all(n.value < c for n, c in zip(ns, caps))
+    return tuple(b.raw[:n.value].decode() for b, n in zip(bufs, ns))
+
+
+def cluster_members_call(treads, window, min_support=5, max_clip_dist=200, min_clip=0, min_clip_total=0):
+    """per bound of call_bounds(mode 1): index array into treads (c.reads, call.nim:246)"""
+    t = np.ascontiguousarray(treads, dtype=TREAD_DTYPE)
+    off = np.zeros(t.size + 2, np.int64)
+    mem = np.zeros(t.size + 1, np.int64)
+    nm = C.c_int64(0)
+    nb = lib().orc_call_members(t.ctypes.data, t.size, window, min_support, min_clip, min_clip_total, max_clip_dist, off.ctypes.data,
+                                mem.ctypes.data, mem.size, C.byref(nm))
+    return [mem[off[j]:off[j + 1]].copy() for j in range(nb)]
 
 
 def bounds_row(b, chrom):

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include <math.h>
 
 /* ------------------------------------------------------------------------------------------
  * kmer module (brentp/nim-kmer >= 0.2.2; strling.nimble:20 -- third party, NOT in the tree).
@@ -775,6 +776,8 @@ typedef struct {
   int mode; int min_support; uint16_t min_clip, min_clip_total, max_clip_dist;
   orc_bounds *out; int64_t cap, n;
   orc_unplaced *unpl; int64_t unpl_cap, n_unpl;
+  int (*on_bound)(void *ud, orc_bounds *b, const orc_tread *reads, int64_t n);   /* call.nim:237-255; 0 = bound dropped */
+  void *hook_ud;
 } drv;
 
 /* merge.nim:18-25 */
@@ -811,6 +814,7 @@ static void on_cluster(void *ud, const orc_tread *reads, int64_t n, uint32_t lef
   if (b.n_left < d->min_clip) return;
   if (b.n_right < d->min_clip) return;
   if ((uint16_t)(b.n_right + b.n_left) < d->min_clip_total) return;
+  if (d->on_bound && !d->on_bound(d->hook_ud, &b, reads, n)) return;
   if (d->n < d->cap) d->out[d->n] = b;
   d->n++;
 }
@@ -824,9 +828,19 @@ static int cmp_pos_stable(const void *a, const void *b) {
   return x < y ? -1 : (x > y ? 1 : 0);        /* algorithm.sort is a stable merge sort */
 }
 
+static int64_t call_bounds_impl(const orc_tread *treads, int64_t n, int mode, uint32_t window, int min_support,
+                        uint16_t min_clip, uint16_t min_clip_total, uint16_t max_clip_dist,
+                        orc_bounds *out, int64_t cap, orc_unplaced *unpl, int64_t unpl_cap, int64_t *n_unpl,
+                        int (*on_bound)(void *, orc_bounds *, const orc_tread *, int64_t), void *hook_ud);
 int64_t orc_call_bounds(const orc_tread *treads, int64_t n, int mode, uint32_t window, int min_support,
                         uint16_t min_clip, uint16_t min_clip_total, uint16_t max_clip_dist,
                         orc_bounds *out, int64_t cap, orc_unplaced *unpl, int64_t unpl_cap, int64_t *n_unpl) {
+  return call_bounds_impl(treads, n, mode, window, min_support, min_clip, min_clip_total, max_clip_dist, out, cap, unpl, unpl_cap, n_unpl, NULL, NULL);
+}
+static int64_t call_bounds_impl(const orc_tread *treads, int64_t n, int mode, uint32_t window, int min_support,
+                        uint16_t min_clip, uint16_t min_clip_total, uint16_t max_clip_dist,
+                        orc_bounds *out, int64_t cap, orc_unplaced *unpl, int64_t unpl_cap, int64_t *n_unpl,
+                        int (*on_bound)(void *, orc_bounds *, const orc_tread *, int64_t), void *hook_ud) {
   int64_t len = slots_needed(8192), counter = 0;
   tslot *tb = (tslot *)calloc((size_t)len, sizeof(tslot));
   int64_t *gid_of = (int64_t *)malloc((size_t)(n ? n : 1) * 8);
@@ -868,7 +882,7 @@ int64_t orc_call_bounds(const orc_tread *treads, int64_t n, int mode, uint32_t w
   int64_t *fill = (int64_t *)malloc((size_t)(ngroups + 1) * 8);
   memcpy(fill, gcount, (size_t)(ngroups + 1) * 8);
   for (int64_t q = 0; q < n; q++) if (gid_of[q] >= 0) ptr[fill[gid_of[q]]++] = &treads[q];
-  drv d = {mode, min_support, min_clip, min_clip_total, max_clip_dist, out, cap, 0, unpl, unpl_cap, 0};
+  drv d = {mode, min_support, min_clip, min_clip_total, max_clip_dist, out, cap, 0, unpl, unpl_cap, 0, on_bound, hook_ud};
   orc_tread *buf = (orc_tread *)malloc((size_t)(n ? n : 1) * sizeof(orc_tread));
   for (int64_t h = 0; h < len; h++) {                                      /* mpairs: slot order */
     if (tb[h].hcode == 0) continue;
@@ -948,4 +962,490 @@ int64_t orc_bin_write(uint8_t *buf, int64_t cap, float proportion_repeat, uint8_
 int orc_bounds_row(char *buf, int cap, const orc_bounds *b, const char *chrom) {
   return snprintf(buf, (size_t)cap, "%s\t%u\t%u\t%s\t%s\t%u\t%u\t%u\t%u\t%u\t%u", chrom, b->left, b->right, b->repeat, "",
                   b->left_most, b->right_most, b->center_mass, (unsigned)b->n_left, (unsigned)b->n_right, (unsigned)b->n_total);
+}
+
+/* ==========================================================================================
+ * strling call: evidence around one bound (collect.nim, spanning.nim), genotype (genotyper.nim),
+ * driver (call.nim:111-285).  Literal and slow: every region query is a scan over the whole
+ * in-memory record set with htslib's iterator filter (tid equal, pos < end, bam_endpos > beg).
+ * PARITY: the reference's own KATs for this part (tests/test_collect.nim, test_genotyper.nim,
+ * test_utils.nim:10-13,29-35) are transcribed in tests/golden/reference_kats.json; Nim stdlib
+ * behaviours that leak into the text (Table/CountTable slot order for string, uint16 and int16
+ * keys, CountTable.sort = stable merge sort of the slot array, C printf of NaN) are unpinned.
+ * ======================================================================================== */
+/* generic Nim 1.6 Table/CountTable slot bookkeeping over pre-hashed distinct keys ------------- */
+typedef struct { int64_t len, counter; uint64_t *hc; int64_t *id; } nim_slots;
+static void ns_init(nim_slots *t, int64_t initial_size) {
+  t->len = slots_needed(initial_size); t->counter = 0;
+  t->hc = (uint64_t *)calloc((size_t)t->len, 8); t->id = (int64_t *)malloc((size_t)t->len * 8);
+  for (int64_t i = 0; i < t->len; i++) t->id[i] = -1;
+}
+static void ns_free(nim_slots *t) { free(t->hc); free(t->id); }
+/* insert a key known to be absent; hc = its hash (already remapped 0 -> 314159265 for Table) */
+static void ns_insert(nim_slots *t, uint64_t hc, int64_t id) {
+  if (must_rehash(t->len, t->counter)) {
+    int64_t nl = t->len * 2;
+    uint64_t *nh = (uint64_t *)calloc((size_t)nl, 8); int64_t *ni = (int64_t *)malloc((size_t)nl * 8);
+    for (int64_t i = 0; i < nl; i++) ni[i] = -1;
+    for (int64_t i = 0; i < t->len; i++) if (t->id[i] >= 0) {
+      int64_t j = (int64_t)(t->hc[i] & (uint64_t)(nl - 1));
+      while (ni[j] >= 0) j = (j + 1) & (nl - 1);
+      nh[j] = t->hc[i]; ni[j] = t->id[i];
+    }
+    free(t->hc); free(t->id); t->hc = nh; t->id = ni; t->len = nl;
+  }
+  int64_t h = (int64_t)(hc & (uint64_t)(t->len - 1));
+  while (t->id[h] >= 0) h = (h + 1) & (t->len - 1);
+  t->hc[h] = hc; t->id[h] = id; t->counter++;
+}
+static uint64_t str_hash(const char *s, int n) { return orc_nim_hash_bytes((const uint8_t *)s, n); }
+
+/* spanning.nim:7-20 */
+void orc_cumulative(const uint32_t frag[4096], float cd[4096]) {
+  for (int i = 0; i < 4096; i++) {
+    cd[i] = 0;
+    int lo = i - 11 < 0 ? 0 : i - 11, hi = i + 11 > 4095 ? 4095 : i + 11;
+    for (int j = lo; j <= hi; j++) cd[i] += (float)frag[j];
+  }
+  for (int i = 1; i < 4096; i++) cd[i] = cd[i] + cd[i - 1];          /* math.cumsum */
+  float fmax = cd[4095];
+  for (int i = 0; i < 4096; i++) cd[i] = cd[i] / fmax;
+}
+/* spanning.nim:22-49 */
+double orc_expected_spanning_probability(const float cd[4096], int64_t start, int64_t stop, int reverse, int64_t event_start,
+                                         int64_t event_stop) {
+  const int64_t min_spanning_bases = 20;
+  int64_t dist;
+  if (start < event_stop - min_spanning_bases) {
+    if (reverse) return 0;
+    dist = event_start - start;
+    if (dist < 0) return 0;
+    if (dist + (event_stop - event_start) < min_spanning_bases) return 0;
+  } else {
+    if (!reverse) return 0;
+    dist = stop - event_stop;
+    if (dist < 0) return 0;
+    if (dist + (event_stop - event_start) < min_spanning_bases) return 0;
+  }
+  dist += min_spanning_bases;
+  dist += (event_stop - event_start);
+  if (dist < 0 || dist > 4095) return 0;
+  return (double)(1.0f - cd[dist]);
+}
+/* utils.nim:129-137 */
+double orc_percentile(const uint32_t frag[4096], int64_t fragment_length) {
+  uint32_t total = 0;
+  for (int i = 0; i < 4096; i++) total += frag[i];
+  int64_t s = 0;
+  for (int i = 0; i < 4096; i++) { s += frag[i]; if (i >= fragment_length) break; }
+  return (double)s / (double)(total > 1 ? total : 1);
+}
+/* utils.nim:148-158 */
+int orc_median_depth(const int64_t *D, int64_t n) {
+  int64_t H[1048];
+  memset(H, 0, sizeof H);
+  for (int64_t i = 0; i < n; i++) H[D[i] < 1047 ? D[i] : 1047] += 1;
+  int64_t s = 0;
+  for (int i = 0; i < 1048; i++) { s += H[i]; if ((double)s > (double)n / 2.0) return i; }
+  return 0;
+}
+
+static int cig_consumes_query(int op) { return op == 0 || op == 1 || op == 4 || op == 7 || op == 8; }
+static int cig_consumes_ref(int op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+/* collect.nim:50-72 */
+static int64_t find_read_position(const orc_records *r, int64_t i, int64_t position) {
+  int64_t r_off = r->pos[i], q_off = 0;
+  int n = cig_n(r, i);
+  for (int j = 0; j < n; j++) {
+    if (r_off > position) return -1;
+    int op = cig_op(r, i, j), len = cig_len(r, i, j);
+    if (cig_consumes_query(op)) q_off += len;
+    if (cig_consumes_ref(op)) r_off += len;
+    if (r_off < position) continue;
+    int64_t over = r_off - position;
+    if (over > q_off) return -1;
+    if (!cig_consumes_query(op)) return -1;
+    return q_off - over;
+  }
+  return -1;
+}
+/* collect.nim:75-93 */
+static int count_in_bounds(const orc_records *r, int64_t i, const orc_bounds *b) {
+  if (b->right < b->left) return 0;
+  static char dna[1 << 16];
+  int dlen = rec_sequence(r, i, dna);
+  int64_t read_left = find_read_position(r, i, (int64_t)b->left);
+  int64_t read_right = find_read_position(r, i, (int64_t)b->right);
+  if (read_left >= 0 && read_right < 0) read_right = dlen;
+  if (read_left < 0 && read_right < 0) return 0;
+  if (read_left < 0) read_left = 0;
+  int64_t slen = read_right - read_left;
+  if (slen < 0) slen = 0;
+  int k = (int)strlen(b->repeat);
+  int result = str_count(dna + read_left, (int)slen, b->repeat, k);
+  if (result < (int)((double)slen * 0.7 / (double)k)) result = 0;
+  return result;
+}
+static void bound_slop(const orc_bounds *b, int64_t *slop) {
+  int64_t bound_width = (int64_t)b->right - (int64_t)b->left;
+  *slop = (int64_t)strlen(b->repeat) - 1;
+  if (bound_width < 5) *slop += (5 - bound_width);
+}
+/* collect.nim:97-119; record overlap: cluster.nim:104-108 */
+int orc_overlapping_read(const orc_records *r, int64_t i, const orc_bounds *b, orc_support *s) {
+  int64_t slop; bound_slop(b, &slop);
+  int64_t start = r->pos[i], stop = rec_stop(r, i);
+  if (r->tid[i] != b->tid) return 0;
+  int64_t ileft = start > (int64_t)b->left ? start : (int64_t)b->left, iright = stop < (int64_t)b->right ? stop : (int64_t)b->right;
+  if (!(ileft <= iright)) return 0;
+  s->type = ORC_OVERLAPPING_READ;
+  s->repeat_count = (uint8_t)count_in_bounds(r, i, b);
+  s->rec = i;
+  if (start < ((int64_t)b->left - slop) && stop > ((int64_t)b->right + slop)) {
+    s->type = ORC_SPANNING_READ;
+    int n = cig_n(r, i);
+    for (int j = 0; j < n; j++) {
+      if (cig_op(r, i, j) == 1) s->cigar_ins = (uint8_t)(s->cigar_ins + (uint8_t)cig_len(r, i, j));
+      if (cig_op(r, i, j) == 2) s->cigar_del = (uint8_t)(s->cigar_del + (uint8_t)cig_len(r, i, j));
+    }
+  }
+  return 1;
+}
+/* collect.nim:36-48 */
+int orc_spanning_fragment(const orc_records *r, const int32_t *isize, int64_t L, int64_t R, const orc_bounds *b, orc_support *s,
+                          const uint32_t frag[4096]) {
+  if (!(r->pos[L] <= r->pos[R])) { fprintf(stderr, "oracle: doAssert L.start <= R.start (collect.nim:37)\n"); abort(); }
+  int64_t slop; bound_slop(b, &slop);
+  if (r->pos[L] < ((int64_t)b->left - slop) && rec_stop(r, R) > ((int64_t)b->right + slop)) {
+    s->type = ORC_SPANNING_FRAGMENT;
+    int64_t a = isize[L] < 0 ? -(int64_t)isize[L] : isize[L];
+    s->frag_len = (uint32_t)a > 1u ? (uint32_t)a : 1u;
+    s->frag_pct = orc_percentile(frag, (int64_t)s->frag_len);
+    s->rec = L;
+    return 1;
+  }
+  return 0;
+}
+
+/* collect.nim:132-182.  out gets the Support list in the reference's order (overlapping reads in file order, then
+ * spanning fragments in Table[string, seq[Record]] slot order); returns the number (also when > cap). */
+int64_t orc_spanners(const orc_records *r, const int32_t *isize, const orc_bounds *b, int window, const uint32_t frag[4096],
+                     uint8_t min_mapq, orc_support *out, int64_t cap, int *median_depth, float *expected_spanners) {
+  const int max_size = 5000;
+  int64_t window_left = (int64_t)b->left - window, window_right = (int64_t)b->right + window;
+  static float cd[4096];
+  orc_cumulative(frag, cd);
+  int64_t nd = window_right - window_left;
+  int64_t *depths = (int64_t *)calloc((size_t)nd, 8);
+  int64_t beg = window_left > 0 ? window_left : 0, end = window_right;
+  int64_t n_out = 0;
+  /* distinct qnames seen: id -> first record; both tables hold qname strings */
+  nim_slots exp_t, pair_t;
+  ns_init(&exp_t, 32); ns_init(&pair_t, 32);
+  int64_t cap_q = 1024, nq_exp = 0, nq_pair = 0;
+  int64_t *exp_rec = (int64_t *)malloc((size_t)cap_q * 8); double *exp_val = (double *)malloc((size_t)cap_q * 8);
+  int64_t *pair_rec = (int64_t *)malloc((size_t)cap_q * 8), *pair_n = (int64_t *)malloc((size_t)cap_q * 8), *pair_second = (int64_t *)malloc((size_t)cap_q * 8);
+  int early = 0;
+  for (int64_t i = 0; i < r->n && !early; i++) {
+    if (r->tid[i] != b->tid) continue;                                   /* hts iterator: region filter */
+    int64_t start = r->pos[i], stop = rec_stop(r, i);
+    if (!(start < end && stop > beg)) continue;
+    uint16_t f = r->flag[i];
+    if ((f & 0x100) || (f & 0x800) || (f & 0x400)) continue;             /* :142 */
+    if (r->mapq[i] < min_mapq) continue;
+    double prob = orc_expected_spanning_probability(cd, start, stop, (f & 0x10) != 0, (int64_t)b->left, (int64_t)b->right);
+    const char *qn = r->qnames + r->qname_off[i];
+    int qlen = (int)(r->qname_off[i + 1] - r->qname_off[i]);
+    if (prob > 0) {
+      int64_t id = -1;
+      for (int64_t k = 0; k < nq_exp; k++) {
+        int64_t rr = exp_rec[k];
+        if ((int)(r->qname_off[rr + 1] - r->qname_off[rr]) == qlen && memcmp(r->qnames + r->qname_off[rr], qn, (size_t)qlen) == 0) { id = k; break; }
+      }
+      if (id >= 0) exp_val[id] = 0.5 * (exp_val[id] + prob);
+      else {
+        if (nq_exp == cap_q) { cap_q *= 2; exp_rec = realloc(exp_rec, (size_t)cap_q * 8); exp_val = realloc(exp_val, (size_t)cap_q * 8);
+                               pair_rec = realloc(pair_rec, (size_t)cap_q * 8); pair_n = realloc(pair_n, (size_t)cap_q * 8); pair_second = realloc(pair_second, (size_t)cap_q * 8); }
+        uint64_t hc = str_hash(qn, qlen); if (hc == 0) hc = 314159265;
+        ns_insert(&exp_t, hc, nq_exp);
+        exp_rec[nq_exp] = i; exp_val[nq_exp] = prob; nq_exp++;
+      }
+    }
+    { int64_t a = start - window_left - 1; if (a < 0) a = 0; depths[a] += 1;
+      int64_t z = stop - window_left - 1; if (z > nd - 1) z = nd - 1; depths[z] -= 1; }
+    orc_support s; memset(&s, 0, sizeof s);
+    if (orc_overlapping_read(r, i, b, &s)) { if (n_out < cap) out[n_out] = s; n_out++; }
+    if (r->tid[i] != r->mtid[i]) continue;
+    { int64_t a = isize[i] < 0 ? -(int64_t)isize[i] : isize[i]; if (a > max_size) continue; }
+    int64_t id = -1;
+    for (int64_t k = 0; k < nq_pair; k++) {
+      int64_t rr = pair_rec[k];
+      if ((int)(r->qname_off[rr + 1] - r->qname_off[rr]) == qlen && memcmp(r->qnames + r->qname_off[rr], qn, (size_t)qlen) == 0) { id = k; break; }
+    }
+    if (id >= 0) { if (pair_n[id] == 1) pair_second[id] = i; pair_n[id]++; }
+    else {
+      if (nq_pair == cap_q) { cap_q *= 2; exp_rec = realloc(exp_rec, (size_t)cap_q * 8); exp_val = realloc(exp_val, (size_t)cap_q * 8);
+                              pair_rec = realloc(pair_rec, (size_t)cap_q * 8); pair_n = realloc(pair_n, (size_t)cap_q * 8); pair_second = realloc(pair_second, (size_t)cap_q * 8); }
+      uint64_t hc = str_hash(qn, qlen); if (hc == 0) hc = 314159265;
+      ns_insert(&pair_t, hc, nq_pair);
+      pair_rec[nq_pair] = i; pair_n[nq_pair] = 1; pair_second[nq_pair] = -1; nq_pair++;
+    }
+    if (nq_pair > 20000) early = 1;                                       /* :171-174 */
+  }
+  if (early) { n_out = 0; *median_depth = -1; *expected_spanners = 0; }
+  else {
+    float es = 0;
+    for (int64_t h = 0; h < exp_t.len; h++) if (exp_t.id[h] >= 0) es += (float)exp_val[exp_t.id[h]];   /* :176-177, values in slot order */
+    *expected_spanners = es;
+    for (int64_t h = 0; h < pair_t.len; h++) {                            /* :179-183 */
+      int64_t id = pair_t.id[h];
+      if (id < 0 || pair_n[id] != 2) continue;
+      orc_support s; memset(&s, 0, sizeof s);
+      if (orc_spanning_fragment(r, isize, pair_rec[id], pair_second[id], b, &s, frag)) { if (n_out < cap) out[n_out] = s; n_out++; }
+    }
+    for (int64_t i = 1; i < nd; i++) depths[i] += depths[i - 1];
+    *median_depth = orc_median_depth(depths, nd);
+  }
+  free(depths); free(exp_rec); free(exp_val); free(pair_rec); free(pair_n); free(pair_second); ns_free(&exp_t); ns_free(&pair_t);
+  return n_out;
+}
+
+/* ---- genotyper.nim ---- */
+/* CountTable over small integer keys: keys[] in inc() order -> distinct keys in SLOT order with their counts */
+static int64_t count_table_slots(const int64_t *keys, int64_t n, int64_t *okeys, int64_t *ovals) {
+  nim_slots t; ns_init(&t, 32);                       /* `var x: CountTable[T]` -> initImpl(defaultInitialSize = 32) on first inc */
+  int64_t nd = 0;
+  int64_t *dk = (int64_t *)malloc((size_t)(n ? n : 1) * 8), *dv = (int64_t *)malloc((size_t)(n ? n : 1) * 8);
+  for (int64_t i = 0; i < n; i++) {
+    int64_t id = -1;
+    for (int64_t k = 0; k < nd; k++) if (dk[k] == keys[i]) { id = k; break; }
+    if (id >= 0) { dv[id]++; continue; }
+    ns_insert(&t, orc_nim_hash_int((uint64_t)keys[i]), nd);
+    dk[nd] = keys[i]; dv[nd] = 1; nd++;
+  }
+  int64_t m = 0;
+  for (int64_t h = 0; h < t.len; h++) if (t.id[h] >= 0) { okeys[m] = dk[t.id[h]]; ovals[m] = dv[t.id[h]]; m++; }
+  free(dk); free(dv); ns_free(&t);
+  return m;
+}
+/* utils.nim:165-177 most_frequent(2) = CountTable.sort (stable, descending) then the first two keys; `largest` = first
+ * maximum in slot order.  a1/a2 receive NaN when absent. */
+static void top_two(const int64_t *keys, int64_t n, double *a1, double *a2) {
+  *a1 = NAN; *a2 = NAN;
+  if (n == 0) return;
+  int64_t *k = (int64_t *)malloc((size_t)n * 8), *v = (int64_t *)malloc((size_t)n * 8);
+  int64_t m = count_table_slots(keys, n, k, v);
+  if (m >= 2) {
+    for (int64_t i = 1; i < m; i++) {                 /* stable insertion sort, descending by count */
+      int64_t kk = k[i], vv = v[i], j = i - 1;
+      while (j >= 0 && v[j] < vv) { k[j + 1] = k[j]; v[j + 1] = v[j]; j--; }
+      k[j + 1] = kk; v[j + 1] = vv;
+    }
+    *a1 = (double)k[0]; *a2 = (double)k[1];
+  } else if (m == 1) *a1 = (double)k[0];
+  free(k); free(v);
+}
+/* genotyper.nim:61-98 */
+void orc_spanning_read_est(const orc_support *reads, int64_t n, double *allele1_bp, double *allele2_bp, double *allele1_ru,
+                           double *allele2_ru, uint32_t *supporting) {
+  int64_t *rc = (int64_t *)malloc((size_t)(n ? n : 1) * 8), *ind = (int64_t *)malloc((size_t)(n ? n : 1) * 8), m = 0;
+  for (int64_t i = 0; i < n; i++) if (reads[i].type == ORC_SPANNING_READ) {
+    rc[m] = (uint16_t)reads[i].repeat_count;
+    ind[m] = (int16_t)((int16_t)reads[i].cigar_ins - (int16_t)reads[i].cigar_del);
+    m++;
+  }
+  *supporting = (uint32_t)m;
+  top_two(rc, m, allele1_ru, allele2_ru);
+  top_two(ind, m, allele1_bp, allele2_bp);
+  free(rc); free(ind);
+}
+/* genotyper.nim:122-130 */
+static double anchored_lm(uint64_t sum_str_counts, double depth) {
+  if (sum_str_counts == 0) return NAN;
+  const double intercept = 4.3558142, cofficient = 0.7565329;
+  double y = log2((double)sum_str_counts / (depth > 1.0 ? depth : 1.0) + 1) * cofficient + intercept;
+  return pow(2, y);
+}
+/* genotyper.nim:150-199; tq_off/tqnames resolve tread.qname_id to its qname string */
+void orc_genotype(const orc_bounds *b, const orc_tread *tandems, int64_t nt, const uint64_t *tq_off, const char *tqnames,
+                  const orc_support *spanners, int64_t ns, int min_support, uint16_t min_clip, uint16_t min_clip_total,
+                  int median_fragment_length, double depth, orc_gt *c) {
+  memset(c, 0, sizeof *c);
+  c->tid = b->tid; c->start = b->left; c->stop = b->right; c->left_clips = b->n_left; c->right_clips = b->n_right;
+  memcpy(c->repeat, b->repeat, 7);
+  c->depth = depth;
+  int RUlen = (int)strlen(c->repeat);
+  if (ns == 0) c->allele1 = NAN;
+  else {
+    double a1bp, a2bp, a1ru, a2ru; uint32_t sup;
+    orc_spanning_read_est(spanners, ns, &a1bp, &a2bp, &a1ru, &a2ru, &sup);
+    if (!isnan(a1bp)) c->allele1 = a1bp / (double)(RUlen > 1 ? RUlen : 1);
+    c->spanning_reads = sup;
+    uint32_t sp = 0;
+    for (int64_t i = 0; i < ns; i++) sp += (spanners[i].type == ORC_SPANNING_FRAGMENT);
+    c->spanning_pairs = sp;
+  }
+  c->is_large = (uint16_t)b->n_left >= min_clip && (uint16_t)b->n_right >= min_clip && (uint16_t)(b->n_left + b->n_right) >= min_clip_total &&
+                nt >= min_support && c->allele2 > (double)median_fragment_length;        /* allele2 is still 0.0 here (:175) */
+  uint64_t sum = 0;
+  for (int64_t i = 0; i < nt; i++) sum += tandems[i].repeat_count;
+  c->overlapping_reads = (uint32_t)nt;
+  c->sum_str_counts = (uint32_t)sum;
+  c->allele2 = anchored_lm(sum, depth) / (double)(RUlen > 1 ? RUlen : 1);
+  uint32_t distinct = 0;                                                               /* :187-191 */
+  for (int64_t i = 0; i < nt; i++) {
+    if (tandems[i].split != ORC_SOFT_NONE) continue;
+    int dup = 0;
+    const char *qi = tqnames + tq_off[tandems[i].qname_id]; uint64_t li = tq_off[tandems[i].qname_id + 1] - tq_off[tandems[i].qname_id];
+    for (int64_t j = 0; j < i && !dup; j++) {
+      if (tandems[j].split != ORC_SOFT_NONE) continue;
+      const char *qj = tqnames + tq_off[tandems[j].qname_id]; uint64_t lj = tq_off[tandems[j].qname_id + 1] - tq_off[tandems[j].qname_id];
+      dup = (li == lj && memcmp(qi, qj, (size_t)li) == 0);
+    }
+    distinct += !dup;
+  }
+  c->anchored_reads = distinct;
+}
+/* Nim `$float` for the values that occur here */
+static int nim_float_str(char *buf, int cap, double v) {
+  if (isnan(v)) return snprintf(buf, (size_t)cap, "nan");
+  int n = snprintf(buf, (size_t)cap, "%.16g", v);
+  if (!strpbrk(buf, ".eEn")) n += snprintf(buf + n, (size_t)(cap - n), ".0");
+  return n;
+}
+/* genotyper.nim:56-57 */
+int orc_call_row(char *buf, int cap, const orc_gt *c, const char *chrom) {
+  char d[64];
+  nim_float_str(d, sizeof d, c->depth);
+  return snprintf(buf, (size_t)cap, "%s\t%u\t%u\t%s\t%.2f\t%.2f\t%u\t%u\t%u\t%.2f\t%.2f\t%u\t%u\t%d\t%s\t%u", chrom, c->start, c->stop, c->repeat,
+                  c->allele1, c->allele2, c->anchored_reads, c->spanning_reads, c->spanning_pairs, (double)c->expected_spanning_fragments,
+                  (double)c->pctile, c->left_clips, c->right_clips, c->unplaced_reads, d, c->sum_str_counts);
+}
+
+/* ---- call.nim:111-285 without -l/-b ---- */
+typedef struct { char *p; int64_t cap, n; } sbuf;
+static void sb_add(sbuf *s, const char *line) {
+  int64_t l = (int64_t)strlen(line);
+  if (s->n + l + 1 < s->cap) { memcpy(s->p + s->n, line, (size_t)l); s->p[s->n + l] = '\n'; }
+  s->n += l + 1;
+}
+typedef struct {
+  const orc_records *r; const int32_t *isize; const uint32_t *frag; const uint64_t *tq_off; const char *tqnames; const char *const *targets;
+  int window, min_support, frag_median; uint16_t min_clip, min_clip_total; uint8_t min_mapq;
+  orc_gt *calls; int64_t ncalls, ccap; char (*canon)[7];
+  sbuf *bounds;
+} call_ctx;
+static int call_on_bound(void *ud, orc_bounds *b, const orc_tread *reads, int64_t n) {
+  call_ctx *c = (call_ctx *)ud;
+  int64_t cap = 1 << 16;
+  orc_support *sp = (orc_support *)malloc((size_t)cap * sizeof(orc_support));
+  int md; float es;
+  int64_t ns = orc_spanners(c->r, c->isize, b, c->window, c->frag, c->min_mapq, sp, cap, &md, &es);
+  if (ns > 5000 || md == -1) { free(sp); return 0; }                                   /* call.nim:239-244 */
+  if (c->ncalls == c->ccap) { c->ccap *= 2; c->calls = realloc(c->calls, (size_t)c->ccap * sizeof(orc_gt)); c->canon = realloc(c->canon, (size_t)c->ccap * 7); }
+  orc_gt *gt = &c->calls[c->ncalls];
+  orc_genotype(b, reads, n, c->tq_off, c->tqnames, sp, ns, c->min_support, c->min_clip, c->min_clip_total, c->frag_median, (double)md, gt);
+  gt->expected_spanning_fragments = es;
+  char in6[6] = {0}, out6[6];
+  memcpy(in6, b->repeat, strlen(b->repeat));
+  orc_canonical_repeat(in6, out6);
+  memset(c->canon[c->ncalls], 0, 7); memcpy(c->canon[c->ncalls], out6, 6);
+  c->ncalls++;
+  char row[512], line[600];
+  orc_bounds_row(row, sizeof row, b, c->targets[b->tid]);
+  snprintf(line, sizeof line, "%s\t%d", row, md);
+  sb_add(c->bounds, line);
+  free(sp);
+  return 1;
+}
+static int cmp_f32(const void *a, const void *b) { float x = *(const float *)a, y = *(const float *)b; return x < y ? -1 : (x > y ? 1 : 0); }
+
+int orc_call(const orc_tread *treads, int64_t n, const uint64_t *tq_off, const char *tqnames, const orc_records *r, const int32_t *isize,
+             const uint32_t frag[4096], const char *const *target_names, int min_support, uint16_t min_clip, uint16_t min_clip_total,
+             uint8_t min_mapq, char *bounds_buf, int64_t bcap, char *gt_buf, int64_t gcap, char *unpl_buf, int64_t ucap,
+             int64_t *bn, int64_t *gn, int64_t *un) {
+  sbuf sb = {bounds_buf, bcap, 0}, sg = {gt_buf, gcap, 0}, su = {unpl_buf, ucap, 0};
+  sb_add(&sb, "#chrom\tleft\tright\trepeat\tname\tleft_most\tright_most\tcenter_mass\tn_left\tn_right\tn_total\tdepth");
+  sb_add(&sg, "#chrom\tleft\tright\trepeatunit\tallele1_est\tallele2_est\tanchored_reads\tspanning_reads\tspanning_pairs\texpected_spanning_pairs\tspanning_pairs_pctl\tleft_clips\tright_clips\tunplaced_pairs\tdepth\tsum_str_counts");
+  call_ctx c; memset(&c, 0, sizeof c);
+  c.r = r; c.isize = isize; c.frag = frag; c.tq_off = tq_off; c.tqnames = tqnames; c.targets = target_names;
+  c.frag_median = orc_median(frag, 0.5); c.window = orc_median(frag, 0.99);
+  c.min_support = min_support; c.min_clip = min_clip; c.min_clip_total = min_clip_total; c.min_mapq = min_mapq;
+  c.ccap = 256; c.calls = malloc((size_t)c.ccap * sizeof(orc_gt)); c.canon = malloc((size_t)c.ccap * 7); c.bounds = &sb;
+  uint16_t max_clip_dist = (uint16_t)(0.5 * (double)orc_median(frag, 0.5));
+  int64_t ucap_n = n + 1, nu = 0;
+  orc_unplaced *unpl = (orc_unplaced *)calloc((size_t)ucap_n, sizeof(orc_unplaced));
+  orc_bounds *tmp = (orc_bounds *)malloc((size_t)(n + 1) * sizeof(orc_bounds));
+  call_bounds_impl(treads, n, 1, (uint32_t)c.window, min_support, min_clip, min_clip_total, max_clip_dist, tmp, n + 1, unpl, ucap_n, &nu, call_on_bound, &c);
+  free(tmp);
+  /* add_percentile, call.nim:38-48 */
+  float *oes = (float *)malloc((size_t)(c.ncalls ? c.ncalls : 1) * sizeof(float));
+  for (int64_t i = 0; i < c.ncalls; i++) {
+    float obs = (float)c.calls[i].spanning_pairs, ex = c.calls[i].expected_spanning_fragments;
+    oes[i] = (1.0f + obs - ex) / (ex + 1.0f);
+  }
+  float *sorted = (float *)malloc((size_t)(c.ncalls ? c.ncalls : 1) * sizeof(float));
+  memcpy(sorted, oes, (size_t)c.ncalls * sizeof(float));
+  qsort(sorted, (size_t)c.ncalls, sizeof(float), cmp_f32);
+  for (int64_t i = 0; i < c.ncalls; i++) {
+    int64_t lb = 0;
+    while (lb < c.ncalls && sorted[lb] < oes[i]) lb++;
+    volatile float num = (float)lb, den = (float)(c.ncalls - 1);
+    c.calls[i].pctile = num / den;
+  }
+  /* unplaced_counts: CountTable[string], `[]=` in group order; file in slot order (call.nim:280-281) */
+  nim_slots ut; ns_init(&ut, 32);
+  for (int64_t i = 0; i < nu; i++) ns_insert(&ut, str_hash(unpl[i].repeat, (int)strlen(unpl[i].repeat)), i);
+  /* genotypes_by_repeat: Table[string, seq[Call]] keyed by the canonical unit; rows in slot order, insertion order inside */
+  nim_slots gt; ns_init(&gt, 32);
+  int64_t *first_of = (int64_t *)malloc((size_t)(c.ncalls ? c.ncalls : 1) * 8), ng = 0;
+  for (int64_t i = 0; i < c.ncalls; i++) {
+    int seen = 0;
+    for (int64_t k = 0; k < ng && !seen; k++) seen = strcmp(c.canon[first_of[k]], c.canon[i]) == 0;
+    if (seen) continue;
+    uint64_t hc = str_hash(c.canon[i], (int)strlen(c.canon[i])); if (hc == 0) hc = 314159265;
+    ns_insert(&gt, hc, i);
+    first_of[ng++] = i;
+  }
+  for (int64_t h = 0; h < gt.len; h++) {
+    if (gt.id[h] < 0) continue;
+    const char *key = c.canon[gt.id[h]];
+    /* is_large is always false (see orc_genotype), so update_genotype never runs: call.nim:267-276 */
+    for (int64_t i = 0; i < c.ncalls; i++) {
+      if (strcmp(c.canon[i], key) != 0) continue;
+      char row[1024];
+      orc_call_row(row, sizeof row, &c.calls[i], target_names[c.calls[i].tid]);
+      sb_add(&sg, row);
+    }
+  }
+  for (int64_t h = 0; h < ut.len; h++) {
+    if (ut.id[h] < 0) continue;
+    char row[64];
+    snprintf(row, sizeof row, "%s\t%lld", unpl[ut.id[h]].repeat, (long long)unpl[ut.id[h]].count);
+    sb_add(&su, row);
+  }
+  *bn = sb.n; *gn = sg.n; *un = su.n;
+  ns_free(&ut); ns_free(&gt); free(first_of); free(oes); free(sorted); free(unpl); free(c.calls); free(c.canon);
+  return 0;
+}
+
+/* the reads (indices into treads) of every bound orc_call_bounds(mode 1) returns, cluster order */
+typedef struct { int64_t *off, *mem, cap, nb, nm; } mem_ctx;
+static int members_on_bound(void *ud, orc_bounds *b, const orc_tread *reads, int64_t n) {
+  mem_ctx *m = (mem_ctx *)ud;
+  m->off[m->nb++] = m->nm;
+  for (int64_t i = 0; i < n; i++) { if (m->nm < m->cap) m->mem[m->nm] = reads[i].src; m->nm++; }
+  return 1;
+}
+int64_t orc_call_members(const orc_tread *treads, int64_t n, uint32_t window, int min_support, uint16_t min_clip, uint16_t min_clip_total,
+                         uint16_t max_clip_dist, int64_t *member_off, int64_t *members, int64_t cap, int64_t *n_members) {
+  orc_tread *cp = (orc_tread *)malloc((size_t)(n ? n : 1) * sizeof(orc_tread));
+  for (int64_t i = 0; i < n; i++) { cp[i] = treads[i]; cp[i].src = i; }
+  orc_bounds *tmp = (orc_bounds *)malloc((size_t)(n + 1) * sizeof(orc_bounds));
+  mem_ctx m = {member_off, members, cap, 0, 0};
+  int64_t nb = call_bounds_impl(cp, n, 1, window, min_support, min_clip, min_clip_total, max_clip_dist, tmp, n + 1, NULL, 0, NULL, members_on_bound, &m);
+  member_off[nb] = m.nm;
+  *n_members = m.nm;
+  free(tmp); free(cp);
+  return nb;
 }

@@ -153,6 +153,49 @@ int64_t orc_call_bounds(const orc_tread *treads, int64_t n, int mode, uint32_t w
 int64_t orc_index_chrom(const char *seq, int64_t L, double p, int window_size, int step, int64_t *starts, int64_t *stops,
                         char (*units)[7], int64_t cap);
 
+/* ---- strling call evidence + genotype (collect.nim, spanning.nim, genotyper.nim, call.nim) ---- */
+enum { ORC_SPANNING_FRAGMENT = 0, ORC_SPANNING_READ = 1, ORC_OVERLAPPING_READ = 2 };   /* collect.nim:10-13 */
+typedef struct {                       /* collect.nim:15-31; repeat = bounds.repeat, qname = qname of record `rec` */
+  uint8_t  type, repeat_count, cigar_ins, cigar_del;
+  uint32_t frag_len;
+  double   frag_pct;
+  int64_t  rec;
+} orc_support;
+typedef struct {                       /* genotyper.nim:29-52 */
+  int32_t tid; uint32_t start, stop; char repeat[7];
+  double allele1, allele2;
+  uint32_t overlapping_reads, anchored_reads, spanning_reads, spanning_pairs, left_clips, right_clips, sum_str_counts;
+  float expected_spanning_fragments, pctile;
+  int32_t unplaced_reads;
+  double depth;
+  int is_large;
+} orc_gt;
+void   orc_cumulative(const uint32_t frag[4096], float cd[4096]);                                     /* spanning.nim:7-20 */
+double orc_expected_spanning_probability(const float cd[4096], int64_t start, int64_t stop, int reverse, int64_t event_start,
+                                         int64_t event_stop);                                         /* spanning.nim:22-49 */
+double orc_percentile(const uint32_t frag[4096], int64_t fragment_length);                            /* utils.nim:129-137 */
+int    orc_median_depth(const int64_t *D, int64_t n);                                                 /* utils.nim:148-158 */
+int    orc_overlapping_read(const orc_records *r, int64_t i, const orc_bounds *b, orc_support *s);    /* collect.nim:97-119 */
+int    orc_spanning_fragment(const orc_records *r, const int32_t *isize, int64_t L, int64_t R, const orc_bounds *b, orc_support *s,
+                             const uint32_t frag[4096]);                                              /* collect.nim:36-48 */
+int64_t orc_spanners(const orc_records *r, const int32_t *isize, const orc_bounds *b, int window, const uint32_t frag[4096],
+                     uint8_t min_mapq, orc_support *out, int64_t cap, int *median_depth, float *expected_spanners);   /* collect.nim:132-182 */
+void   orc_spanning_read_est(const orc_support *reads, int64_t n, double *allele1_bp, double *allele2_bp, double *allele1_ru,
+                             double *allele2_ru, uint32_t *supporting);                               /* genotyper.nim:61-98 */
+void   orc_genotype(const orc_bounds *b, const orc_tread *tandems, int64_t nt, const uint64_t *tq_off, const char *tqnames,
+                    const orc_support *spanners, int64_t ns, int min_support, uint16_t min_clip, uint16_t min_clip_total,
+                    int median_fragment_length, double depth, orc_gt *c);                           /* genotyper.nim:150-199 */
+int    orc_call_row(char *buf, int cap, const orc_gt *c, const char *chrom);                        /* genotyper.nim:56-57 */
+/* call.nim:111-285 without -l/-b: the three output files as text (returns 0; bn/gn/un receive the bytes needed) */
+int    orc_call(const orc_tread *treads, int64_t n, const uint64_t *tq_off, const char *tqnames, const orc_records *r, const int32_t *isize,
+                const uint32_t frag[4096], const char *const *target_names, int min_support, uint16_t min_clip, uint16_t min_clip_total,
+                uint8_t min_mapq, char *bounds_buf, int64_t bcap, char *gt_buf, int64_t gcap, char *unpl_buf, int64_t ucap,
+                int64_t *bn, int64_t *gn, int64_t *un);
+
+/* reads (indices into treads) of every bound orc_call_bounds(mode 1) returns, in cluster order; member_off is [nb + 1] */
+int64_t orc_call_members(const orc_tread *treads, int64_t n, uint32_t window, int min_support, uint16_t min_clip, uint16_t min_clip_total,
+                         uint16_t max_clip_dist, int64_t *member_off, int64_t *members, int64_t cap, int64_t *n_members);
+
 /* ---- Nim 1.6 stdlib emulation (hashes.nim / tables.nim) ---- */
 uint64_t orc_nim_hash_int(uint64_t x);                 /* hashWangYi1 */
 uint64_t orc_nim_hash_bytes(const uint8_t *p, int n);  /* murmurHash */

@@ -66,6 +66,25 @@ BOUNDS_DTYPE = np.dtype([("tid", "<i4"), ("left", "<u4"), ("left_most", "<u4"), 
 UNPLACED_DTYPE = np.dtype([("repeat", "S7"), ("count", "<i8")], align=True)
 assert TREAD_DTYPE.itemsize == 32 and BOUNDS_DTYPE.itemsize == 40 and UNPLACED_DTYPE.itemsize == 16
 
+SUPPORT_DTYPE = np.dtype([("type", "u1"), ("repeat_count", "u1"), ("cigar_ins", "u1"), ("cigar_del", "u1"), ("fragment_length", "<u4"),
+                          ("fragment_percentile", "<f8"), ("rec", "<i8")], align=True)
+CALL_DTYPE = np.dtype([("tid", "<i4"), ("start", "<u4"), ("stop", "<u4"), ("repeat", "S7"), ("allele1", "<f8"), ("allele2", "<f8"),
+                       ("overlapping_reads", "<u4"), ("anchored_reads", "<u4"), ("spanning_reads", "<u4"), ("spanning_pairs", "<u4"),
+                       ("left_clips", "<u4"), ("right_clips", "<u4"), ("sum_str_counts", "<u4"), ("expected_spanning_fragments", "<f4"),
+                       ("spanning_fragments_oe_percentile", "<f4"), ("unplaced_reads", "<i4"), ("depth", "<f8"), ("is_large", "<i4")],
+                      align=True)
+assert SUPPORT_DTYPE.itemsize == 24 and CALL_DTYPE.itemsize == 96, (SUPPORT_DTYPE.itemsize, CALL_DTYPE.itemsize)
+SUPPORT_TYPES = ["SpanningFragment", "SpanningRead", "OverlappingRead"]
+
+
+class SpanSummary(C.Structure):
+    _fields_ = [("median_depth", C.c_int32), ("expected_spanners", C.c_float), ("n_support", C.c_uint64)]
+
+
+class CallOpts(C.Structure):
+    _fields_ = [("median_fragment_length", C.c_int32), ("min_support", C.c_int32), ("min_clip", C.c_uint16), ("min_clip_total", C.c_uint16)]
+
+
 MEM_HOST, MEM_DEVICE = 0, 1
 MODE_MERGE, MODE_CALL = 0, 1
 
@@ -74,7 +93,8 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_ctx_sync", "strl_ctx_set_opts", "strl_ctx_set_genome", "strl_soa_from_records", "strl_score_reads", "strl_index_chrom", "strl_index_regions",
            "strl_ctx_enable_timing", "strl_ctx_kernel_times", "strl_pair_reads", "strl_pairer_create", "strl_pairer_destroy", "strl_pairer_add",
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
-           "strl_bin_write", "strl_bin_read", "strl_bounds_row"]
+           "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
+           "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat"]
 
 
 def lib_path():
@@ -122,6 +142,16 @@ def load(build_if_missing=True):
                                  C.c_void_p, C.c_char_p]
     L.strl_bin_read.argtypes = [C.c_char_p, C.POINTER(BinInfo), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.strl_bounds_row.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_char_p]
+    L.strl_cluster_members.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.strl_spanners.argtypes = [C.POINTER(CRecords), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint8, C.c_void_p, C.c_uint64,
+                                C.POINTER(SpanSummary)]
+    L.strl_genotype.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(CallOpts),
+                                C.c_double, C.c_void_p]
+    L.strl_calls_finish.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.strl_unplaced_order.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.strl_call_row.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_char_p]
+    L.strl_canonical_repeat.argtypes = [C.c_char_p, C.c_char_p]
+    L.strl_canonical_repeat.restype = None
     _LIB = L
     return L
 
@@ -327,6 +357,15 @@ class Context:
                                    out.ctypes.data, cap, C.byref(no), unpl.ctypes.data, unpl.size, C.byref(nu), C.byref(st)))
         return out[:no.value].copy(), unpl[:nu.value].copy(), st
 
+    def cluster_members(self, n_bounds):
+        """indices (into the tread array of the last cluster() call) of every returned bound's reads, cluster order"""
+        off = np.zeros(n_bounds + 1, np.uint64)
+        nm = C.c_uint64(0)
+        _check(self.L.strl_cluster_members(self.h, off.ctypes.data, None, 0, C.byref(nm)))
+        mem = np.zeros(max(1, nm.value), np.uint32)
+        _check(self.L.strl_cluster_members(self.h, off.ctypes.data, mem.ctypes.data, mem.size, C.byref(nm)))
+        return off, mem[:nm.value]
+
     def cluster_replay(self):
         """device side of the last cluster() call again, asynchronously (bench)"""
         _check(self.L.strl_cluster_replay(self.h))
@@ -366,6 +405,51 @@ def _noop():
 def frag_median(frag, pct=0.5):
     frag = np.ascontiguousarray(frag, np.uint32)
     return load().strl_frag_median(frag.ctypes.data, pct)
+
+
+def spanners(rec: RecordBatch, bound, window, frag, min_mapq=20):
+    """collect.nim:132-182 over the records of `rec` -> (support array, median_depth, expected_spanners)"""
+    L = load()
+    rv = _RecView(rec)
+    isz = np.ascontiguousarray(rec.isize if rec.isize is not None else np.zeros(rec.n), np.int32)
+    frag = np.ascontiguousarray(frag, np.uint32)
+    bb = np.ascontiguousarray(bound, BOUNDS_DTYPE).reshape(1)
+    cap = 2 * rv.n + 16
+    out = np.zeros(cap, SUPPORT_DTYPE)
+    sm = SpanSummary()
+    _check(L.strl_spanners(C.byref(rv.c), isz.ctypes.data, bb.ctypes.data, window, frag.ctypes.data, min_mapq, out.ctypes.data, cap, C.byref(sm)))
+    return out[:sm.n_support].copy(), sm.median_depth, sm.expected_spanners
+
+
+def genotype(bound, members, qname_off, qnames, supports, depth, median_fragment_length, min_support=5, min_clip=0, min_clip_total=0):
+    L = load()
+    bb = np.ascontiguousarray(bound, BOUNDS_DTYPE).reshape(1)
+    m = np.ascontiguousarray(members, TREAD_DTYPE)
+    sp = np.ascontiguousarray(supports, SUPPORT_DTYPE)
+    qo = np.ascontiguousarray(qname_off, np.uint64)
+    qn = np.frombuffer(bytes(qnames) + b"\0", dtype=np.uint8)
+    out = np.zeros(1, CALL_DTYPE)
+    o = CallOpts(median_fragment_length, min_support, min_clip, min_clip_total)
+    _check(L.strl_genotype(bb.ctypes.data, m.ctypes.data, m.size, qo.ctypes.data, qn.ctypes.data, sp.ctypes.data, sp.size, C.byref(o), float(depth),
+                           out.ctypes.data))
+    return out[0]
+
+
+def calls_finish(calls, unplaced):
+    """percentiles + output order (call.nim:38-48,264-276) -> (calls, order)"""
+    L = load()
+    c = np.ascontiguousarray(calls, CALL_DTYPE).copy()
+    u = np.ascontiguousarray(unplaced, UNPLACED_DTYPE)
+    order = np.zeros(max(1, c.size), np.uint64)
+    _check(L.strl_calls_finish(c.ctypes.data, c.size, u.ctypes.data, u.size, order.ctypes.data))
+    return c, order[:c.size]
+
+
+def call_row(call, chrom):
+    buf = C.create_string_buffer(1024)
+    cc = np.ascontiguousarray(call, CALL_DTYPE).reshape(1)
+    load().strl_call_row(buf, 1024, cc.ctypes.data, chrom.encode())
+    return buf.value.decode()
 
 
 def bounds_row(b, chrom):

@@ -1,8 +1,8 @@
 """Synthetic BAM / BED writers for tests and examples (pure Python + zlib; htslib/samtools are not available).
 
 Writes spec-conformant BGZF-compressed BAM (SAM spec sections 4.1-4.2) from a records.RecordBatch so that the
-`strling` CLI's own BGZF/BAM reader can be exercised end to end.  No index is written: the CLI revisits the
-unmapped tail by itself (it does not need `query("*")`).
+`strling` CLI's own BGZF/BAM reader can be exercised end to end, plus the matching .bai (SAM spec 5.2: binning
+index + 16 KiB linear index) that `strling call` needs for its region reads.
 """
 import struct
 import zlib
@@ -24,7 +24,7 @@ def sam_header(targets, sort_order="coordinate"):
     return f"@HD\tVN:1.6\tSO:{sort_order}\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in targets)
 
 
-def write_bam(path, rec, header_text=None, level=1, block=0xFF00):
+def write_bam(path, rec, header_text=None, level=1, block=0xFF00, index=True):
     targets = rec.targets
     text = (header_text if header_text is not None else sam_header(targets)).encode()
     out = bytearray()
@@ -33,7 +33,9 @@ def write_bam(path, rec, header_text=None, level=1, block=0xFF00):
         nb = name.encode() + b"\0"
         out += struct.pack("<i", len(nb)) + nb + struct.pack("<i", length)
     isize = rec.isize if rec.isize is not None else np.zeros(rec.n, np.int32)
+    rec_off = []
     for i in range(rec.n):
+        rec_off.append(len(out))
         qn = rec.qname(i) + b"\0"
         c0, c1 = int(rec.cigar_off[i]), int(rec.cigar_off[i + 1])
         l_seq = int(rec.l_seq[i])
@@ -46,11 +48,78 @@ def write_bam(path, rec, header_text=None, level=1, block=0xFF00):
         body = struct.pack("<iiBBHHHiiii", int(rec.tid[i]), int(rec.pos[i]), len(qn), int(rec.mapq[i]), 4680, c1 - c0,
                            int(rec.flag[i]), l_seq, int(rec.mtid[i]), int(rec.mpos[i]), int(isize[i])) + qn + cig + seq + qual
         out += struct.pack("<i", len(body)) + body
+    rec_off.append(len(out))
+    block_off = []
     with open(path, "wb") as f:
         for o in range(0, len(out), block):
+            block_off.append(f.tell())
             f.write(_bgzf_block(bytes(out[o:o + block]), level))
+        block_off.append(f.tell())
         f.write(_EOF)
+    if index:
+        write_bai(path + ".bai", rec, rec_off, block_off, block)
     return text.decode()
+
+
+def _reg2bin(beg, end):
+    end -= 1
+    if beg >> 14 == end >> 14:
+        return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17:
+        return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20:
+        return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23:
+        return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26:
+        return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+def _ref_len(rec, i):
+    if int(rec.flag[i]) & 4:
+        return 1
+    c0, c1 = int(rec.cigar_off[i]), int(rec.cigar_off[i + 1])
+    rl = sum(int(c) >> 4 for c in rec.cigar[c0:c1] if (int(c) & 15) in (0, 2, 3, 7, 8))
+    return rl or 1
+
+
+def write_bai(path, rec, rec_off, block_off, block):
+    """rec_off[i] = offset of record i in the uncompressed stream (rec_off[n] = its end); block_off[k] = file offset of
+    BGZF block k (uncompressed stream cut every `block` bytes)"""
+    def voff(u):
+        k = u // block                       # block_off has one entry more than there are data blocks (the EOF block)
+        return (block_off[k] << 16) | (u - k * block)
+    n_ref = len(rec.targets)
+    bins = [dict() for _ in range(n_ref)]
+    lin = [dict() for _ in range(n_ref)]
+    for i in range(rec.n):
+        t = int(rec.tid[i])
+        if t < 0:
+            continue
+        beg = int(rec.pos[i])
+        end = beg + _ref_len(rec, i)
+        v0, v1 = voff(rec_off[i]), voff(rec_off[i + 1])
+        ch = bins[t].setdefault(_reg2bin(beg, end), [])
+        if ch and ch[-1][1] == v0:
+            ch[-1][1] = v1
+        else:
+            ch.append([v0, v1])
+        for w in range(beg >> 14, ((end - 1) >> 14) + 1):
+            lin[t].setdefault(w, v0)
+    out = bytearray(b"BAI\1" + struct.pack("<i", n_ref))
+    for t in range(n_ref):
+        out += struct.pack("<i", len(bins[t]))
+        for b, chunks in sorted(bins[t].items()):
+            out += struct.pack("<Ii", b, len(chunks))
+            for v0, v1 in chunks:
+                out += struct.pack("<QQ", v0, v1)
+        n_intv = (max(lin[t]) + 1) if lin[t] else 0
+        out += struct.pack("<i", n_intv)
+        for w in range(n_intv):
+            out += struct.pack("<Q", lin[t].get(w, 0))       # empty windows stay 0, as in files written by older tools
+    with open(path, "wb") as f:
+        f.write(out)
 
 
 def write_genome_bed(path, genome, targets, unit="AC"):

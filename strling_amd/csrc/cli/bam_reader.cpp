@@ -3,6 +3,7 @@
 #include "bam_reader.h"
 #include <string.h>
 #include <zlib.h>
+#include <algorithm>
 
 namespace strl {
 
@@ -115,7 +116,60 @@ bool BamReader::seek(Pos p, std::string &err) {
   return true;
 }
 
-int64_t BamReader::read(RecordBatch &b, int64_t max_records, std::string &err) {
+// BAI (SAM spec 5.2): magic, n_ref, per reference { n_bin, { bin, n_chunk, { beg, end } }, n_intv, ioffset[] }
+bool BamReader::load_index(const std::string &bam_path, std::string &err) {
+  FILE *f = fopen((bam_path + ".bai").c_str(), "rb");
+  if (!f && bam_path.size() > 4) f = fopen((bam_path.substr(0, bam_path.size() - 4) + ".bai").c_str(), "rb");
+  if (!f) { err = "no .bai index next to " + bam_path; return false; }
+  auto rd = [&](void *p, size_t n) { return fread(p, 1, n, f) == n; };
+  char magic[4];
+  int32_t n_ref = 0;
+  bool ok = rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && n_ref >= 0;
+  lin_.assign((size_t)std::max(n_ref, 0), {});
+  ref_beg_.assign((size_t)std::max(n_ref, 0), 0);
+  for (int32_t r = 0; ok && r < n_ref; ++r) {
+    int32_t n_bin = 0;
+    ok = rd(&n_bin, 4);
+    uint64_t first = 0;
+    for (int32_t k = 0; ok && k < n_bin; ++k) {
+      uint32_t bin = 0;
+      int32_t n_chunk = 0;
+      ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0;
+      for (int32_t c = 0; ok && c < n_chunk; ++c) {
+        uint64_t be[2];
+        ok = rd(be, 16);
+        if (ok && bin != 37450 && (first == 0 || be[0] < first)) first = be[0];   // 37450: the metadata pseudo-bin
+      }
+    }
+    int32_t n_intv = 0;
+    ok = ok && rd(&n_intv, 4) && n_intv >= 0;
+    if (ok) {
+      lin_[(size_t)r].resize((size_t)n_intv);
+      ok = n_intv == 0 || rd(lin_[(size_t)r].data(), (size_t)n_intv * 8);
+      ref_beg_[(size_t)r] = first;
+    }
+  }
+  fclose(f);
+  if (!ok) { lin_.clear(); err = "corrupt .bai index"; return false; }
+  if (lin_.empty()) lin_.push_back({});   // has_index() for a BAM without references
+  return true;
+}
+
+int64_t BamReader::read_region(RecordBatch &b, int32_t tid, int64_t beg, int64_t end, std::string &err) {
+  if (tid < 0 || (size_t)tid >= ref_beg_.size() || ref_beg_[(size_t)tid] == 0 || end <= beg) return 0;
+  const std::vector<uint64_t> &lin = lin_[(size_t)tid];
+  // smallest offset of a record overlapping the 16 KiB window of `beg`; empty windows (0) fall back to the nearest
+  // earlier filled one, windows beyond the last record-bearing one hold nothing that can overlap
+  uint64_t off = 0;
+  int64_t w = beg >> 14;
+  if (w >= (int64_t)lin.size()) w = (int64_t)lin.size() - 1;
+  for (; w >= 0 && off == 0; --w) off = lin[(size_t)w];
+  if (off == 0) off = ref_beg_[(size_t)tid];
+  if (!seek(Pos{off >> 16, (uint32_t)(off & 0xffff)}, err)) return -1;
+  return read_until(b, INT64_MAX, tid, (int32_t)std::min<int64_t>(end, INT32_MAX), err);
+}
+
+int64_t BamReader::read_until(RecordBatch &b, int64_t max_records, int32_t stop_tid, int32_t stop_pos, std::string &err) {
   int64_t n = 0;
   std::vector<uint8_t> rec;
   while (n < max_records) {
@@ -138,6 +192,7 @@ int64_t BamReader::read(RecordBatch &b, int64_t max_records, std::string &err) {
     memcpy(&next_ref, p + 20, 4); memcpy(&next_pos, p + 24, 4); memcpy(&tlen, p + 28, 4);
     const size_t need = 32 + (size_t)l_read_name + 4u * n_cigar + (size_t)(l_seq + 1) / 2;
     if (l_seq < 0 || need > (size_t)bs) { err = "corrupt BAM record"; return -1; }
+    if (stop_tid != INT32_MIN && (refID != stop_tid || pos >= stop_pos)) break;
     b.tid.push_back(refID); b.pos.push_back(pos); b.mtid.push_back(next_ref); b.mpos.push_back(next_pos);
     b.isize.push_back(tlen); b.l_seq.push_back(l_seq); b.flag.push_back(flag); b.mapq.push_back(mapq);
     const char *qn = reinterpret_cast<const char *>(p + 32);

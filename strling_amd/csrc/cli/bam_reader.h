@@ -3,6 +3,7 @@
 // hts-nim: header text + targets, and per record tid/pos/mapq/flag/mate tid+pos/isize/cigar/4-bit SEQ/qname,
 // written straight into the structure-of-arrays batch layout of include/strling_amd.h (SEQ 16-byte aligned).
 #pragma once
+#include <limits.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
@@ -39,7 +40,15 @@ class BamReader {
   const std::vector<BamTarget> &targets() const { return targets_; }
   // Appends up to max_records records to `b`.  Returns number appended (0 at EOF), -1 on error.
   // keep_secondary = false drops secondary/supplementary records (extract.nim:309) before they are batched.
-  int64_t read(RecordBatch &b, int64_t max_records, std::string &err);
+  int64_t read(RecordBatch &b, int64_t max_records, std::string &err) { return read_until(b, max_records, INT32_MIN, 0, err); }
+  // Same, but stops (without appending) at the first record that is not on stop_tid or starts at/after stop_pos.
+  int64_t read_until(RecordBatch &b, int64_t max_records, int32_t stop_tid, int32_t stop_pos, std::string &err);
+  // Region read through the .bai linear index (hts-nim `b.query(tid, beg, end)`, collect.nim:141): appends every record
+  // of `tid` from the first one that can overlap [beg, end) up to the first one starting at or after `end`, in file
+  // order.  Records ending before `beg` may be included; consumers apply the overlap filter (strl_spanners does).
+  bool load_index(const std::string &bam_path, std::string &err);
+  bool has_index() const { return !lin_.empty(); }
+  int64_t read_region(RecordBatch &b, int32_t tid, int64_t beg, int64_t end, std::string &err);
   // position of the NEXT record, to come back to it later (used to revisit the unmapped tail)
   struct Pos { uint64_t block_off; uint32_t in_block; };
   Pos tell() const { return Pos{block_start_, (uint32_t)upos_}; }
@@ -55,6 +64,8 @@ class BamReader {
   bool eof_ = false;
   std::string text_;
   std::vector<BamTarget> targets_;
+  std::vector<std::vector<uint64_t>> lin_;   // per reference: linear index (virtual offset per 16 KiB window)
+  std::vector<uint64_t> ref_beg_;            // per reference: smallest chunk start of any bin (0 = no records)
 };
 
 }  // namespace strl

@@ -4,8 +4,8 @@
 // The BAM is decoded on the host (own BGZF/BAM reader), batches go through the C ABI into the HIP kernels,
 // the pair logic runs in the streaming pairer, and the .bin / -bounds.txt writers are byte-compatible with the
 //   strling index   [-g STR.bed] [-p 0.8] FASTA                                  (src/strpkg/genome_strs.nim:61-135,175-205)
-// reference's.  Not in this build (SURVEY.md section 8f "next"): CRAM input, `strling call` (needs the
-// spanning-read evidence of collect.nim), -l/--bed loci.
+//   strling call    [-m 5] [-c 0] [-t 0] [-q 40] [-o PREFIX] [-v] BAM BIN              (src/strpkg/call.nim:51-285)
+// reference's.  Not in this build (SURVEY.md section 8f "next"): CRAM input, -l/--loci and -b/--bounds.
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -440,6 +440,128 @@ static int merge_main(int argc, char **argv) {
   return 0;
 }
 
+// call.nim:51-285.  -l/--loci and -b/--bounds (assign_reads_locus, callclusters.nim:14-50) are not in this build.
+static int call_main(int argc, char **argv) {
+  const char *usage =
+      "strling call\n\nUsage:\n  strling call [options] bam bin\n\nArguments:\n  bam              path to bam file\n"
+      "  bin              bin file previously created by `strling extract`\n\nOptions:\n  -f, --fasta=FASTA          path to fasta file\n"
+      "  -m, --min-support=MIN_SUPPORT\n                             minimum number of supporting reads for a locus to be reported (default: 5)\n"
+      "  -c, --min-clip=MIN_CLIP    minimum number of supporting clipped reads for each side of a locus (default: 0)\n"
+      "  -t, --min-clip-total=MIN_CLIP_TOTAL\n                             minimum total number of supporting clipped reads for a locus (default: 0)\n"
+      "  -q, --min-mapq=MIN_MAPQ    minimum mapping quality (does not apply to STR reads) (default: 40)\n"
+      "  -l, --loci=LOCI            (not in this build) annotated bed file specifying additional STR loci to genotype\n"
+      "  -b, --bounds=BOUNDS        (not in this build) STRling -bounds.txt file specifying additional STR loci to genotype\n"
+      "  -o, --output-prefix=OUTPUT_PREFIX\n                             prefix for output files (default: strling)\n  -v, --verbose\n  -h, --help                 Show this help\n";
+  if (argc <= 2) { fputs(usage, stdout); return 0; }
+  const Args a = parse(argc, argv, 2, {{"fasta", 'f', true}, {"min-support", 'm', true}, {"min-clip", 'c', true}, {"min-clip-total", 't', true},
+                                       {"min-mapq", 'q', true}, {"loci", 'l', true}, {"bounds", 'b', true}, {"output-prefix", 'o', true},
+                                       {"verbose", 'v', false}}, usage);
+  if (a.pos.size() != 2) quit("expected 2 arguments (bam, bin)\n%s", usage);
+  if (a.flag("loci") || a.flag("bounds")) quit("[strling] -l/--loci and -b/--bounds are not supported by this build (DESIGN.md section 9)");
+  const std::string bam = a.pos[0], bin = a.pos[1], prefix = a.get("output-prefix", "strling");
+  const int min_support = atoi(a.get("min-support", "5").c_str());
+  const uint16_t min_clip = (uint16_t)atoi(a.get("min-clip", "0").c_str());
+  const uint16_t min_clip_total = (uint16_t)atoi(a.get("min-clip-total", "0").c_str());
+  const uint8_t min_mapq = (uint8_t)atoi(a.get("min-mapq", "40").c_str());
+  const bool verbose = a.flag("verbose");
+
+  uint32_t frag[4096];
+  fragment_length_distribution(bam, frag);                                          // call.nim:92
+  const int frag_median = strl_frag_median(frag, 0.5);
+  if (verbose) {
+    fprintf(stderr, "Calculated median fragment length:%d\n", frag_median);
+    fprintf(stderr, "10th, 90th percentile of fragment length:%d %d\n", strl_frag_median(frag, 0.1), strl_frag_median(frag, 0.9));
+  }
+  BamReader rd;
+  std::string err;
+  if (!rd.open(bam, err) || !rd.load_index(bam, err)) quit("couldn't open bam");    // index=true, call.nim:101-102
+  const int window = strl_frag_median(frag, 0.99);                                  // call.nim:109
+  const strl_call_opts copts{frag_median, min_support, min_clip, min_clip_total};
+
+  // the .bin of extract (call.nim:118-123)
+  strl_bin_info info;
+  CHECK(strl_bin_read(bin.c_str(), &info, nullptr, nullptr, nullptr, nullptr));
+  std::string hdr((size_t)info.header_len, '\0');
+  std::vector<strl_tread> treads((size_t)std::max(1, info.n_reads));
+  std::vector<uint64_t> qoff((size_t)info.n_reads + 1);
+  std::vector<char> qnames((size_t)info.qnames_bytes + 1);
+  CHECK(strl_bin_read(bin.c_str(), &info, &hdr[0], treads.data(), qoff.data(), qnames.data()));
+  {
+    const std::vector<BamTarget> tg = targets_from_header(hdr);
+    bool same = tg.size() == rd.targets().size();
+    for (size_t k = 0; same && k < tg.size(); ++k) same = tg[k].name == rd.targets()[k].name && tg[k].length == rd.targets()[k].length;
+    if (!same) quit("[strling] the bin file and the bam do not have the same reference sequences (doAssert call.nim:121)");
+  }
+  const std::string pb = prefix + "-bounds.txt", pg = prefix + "-genotype.txt", pu = prefix + "-unplaced.txt";
+  FILE *gt_fh = fopen(pg.c_str(), "w"), *bounds_fh = fopen(pb.c_str(), "w"), *unplaced_fh = fopen(pu.c_str(), "w");
+  if (!gt_fh || !bounds_fh || !unplaced_fh) quit("couldn't open output file");
+  fputs("#chrom\tleft\tright\trepeat\tname\tleft_most\tright_most\tcenter_mass\tn_left\tn_right\tn_total\tdepth\n", bounds_fh);   // call.nim:145
+  fputs("#chrom\tleft\tright\trepeatunit\tallele1_est\tallele2_est\tanchored_reads\tspanning_reads\tspanning_pairs\texpected_spanning_pairs\t"
+        "spanning_pairs_pctl\tleft_clips\tright_clips\tunplaced_pairs\tdepth\tsum_str_counts\n", gt_fh);                          // genotyper.nim:54
+
+  // discovery: group, sort, cluster, bounds on the device (call.nim:118-130,221-235)
+  strl_ctx *ctx = nullptr;
+  CHECK(strl_ctx_create(0, &ctx));
+  const uint16_t max_clip_dist = (uint16_t)(0.5 * (double)frag_median);             // call.nim:232
+  const uint64_t nt = (uint64_t)info.n_reads;
+  std::vector<strl_bounds> bounds(std::max<size_t>((size_t)nt, 16));
+  std::vector<strl_unplaced> unplaced(std::max<size_t>((size_t)nt, 16));
+  uint64_t nb = 0, nu = 0;
+  CHECK(strl_cluster(ctx, treads.data(), nt, STRL_MODE_CALL, (uint32_t)window, min_support, min_clip, min_clip_total, max_clip_dist, bounds.data(),
+                     bounds.size(), &nb, unplaced.data(), unplaced.size(), &nu, nullptr));
+  std::vector<uint64_t> moff((size_t)nb + 1);
+  uint64_t nm = 0;
+  CHECK(strl_cluster_members(ctx, moff.data(), nullptr, 0, &nm));
+  std::vector<uint32_t> members((size_t)std::max<uint64_t>(nm, 1));
+  CHECK(strl_cluster_members(ctx, moff.data(), members.data(), members.size(), &nm));
+
+  // evidence + genotype per bound (call.nim:237-255): indexed region read, spanners(), genotype()
+  std::vector<strl_call> calls;
+  std::vector<strl_support> sup;
+  std::vector<strl_tread> cl;
+  RecordBatch region;
+  char row[2048];
+  for (uint64_t j = 0; j < nb; ++j) {
+    const strl_bounds &b = bounds[(size_t)j];
+    region.clear();
+    const int64_t wl = (int64_t)b.left - window, wr = (int64_t)b.right + window;
+    if (rd.read_region(region, b.tid, std::max<int64_t>(0, wl), wr, err) < 0) quit("[strling] error reading %s: %s", bam.c_str(), err.c_str());
+    const strl_records rv = region.view();
+    sup.resize(2 * region.size() + 16);
+    strl_span_summary sm{};
+    CHECK(strl_spanners(&rv, region.isize.data(), &b, window, frag, min_mapq, sup.data(), sup.size(), &sm));
+    if (sm.n_support > 5000) continue;                                              // call.nim:239-242
+    if (sm.median_depth == -1) continue;                                            // :243-244
+    cl.clear();
+    for (uint64_t k = moff[(size_t)j]; k < moff[(size_t)j + 1]; ++k) cl.push_back(treads[members[(size_t)k]]);
+    strl_call c{};
+    CHECK(strl_genotype(&b, cl.data(), cl.size(), qoff.data(), qnames.data(), sup.data(), sm.n_support, &copts, (double)sm.median_depth, &c));
+    c.expected_spanning_fragments = sm.expected_spanners;                           // :247
+    calls.push_back(c);
+    strl_bounds_row(row, sizeof row, &b, rd.targets()[(size_t)b.tid].name.c_str());
+    fprintf(bounds_fh, "%s\t%d\n", row, sm.median_depth);                           // :255
+  }
+  std::vector<uint64_t> order(std::max<size_t>(calls.size(), 1)), uorder(std::max<size_t>((size_t)nu, 1));
+  CHECK(strl_calls_finish(calls.data(), calls.size(), unplaced.data(), nu, order.data()));   // :264-278
+  for (size_t k = 0; k < calls.size(); ++k) {
+    const strl_call &c = calls[(size_t)order[k]];
+    strl_call_row(row, sizeof row, &c, rd.targets()[(size_t)c.tid].name.c_str());
+    fprintf(gt_fh, "%s\n", row);
+  }
+  CHECK(strl_unplaced_order(unplaced.data(), nu, uorder.data()));                   // :280-281
+  for (uint64_t k = 0; k < nu; ++k) fprintf(unplaced_fh, "%s\t%lld\n", unplaced[(size_t)uorder[k]].repeat, (long long)unplaced[(size_t)uorder[k]].count);
+  fclose(gt_fh); fclose(bounds_fh); fclose(unplaced_fh);
+  if (verbose) {
+    fprintf(stderr, "Supporting evidence used to make the genotype calls:\n");
+    fprintf(stderr, "wrote putative str bounds to %s\n", pb.c_str());
+    fprintf(stderr, "wrote counts of unplaced reads with STR content to %s\n", pu.c_str());
+    fprintf(stderr, "Main results file:\n");
+    fprintf(stderr, "wrote genotypes to %s\n", pg.c_str());
+  }
+  strl_ctx_destroy(ctx);
+  return 0;
+}
+
 // `strling _dump BAM`: SAM-like text of every record as the reader decoded it (reader self-check; needs no GPU)
 static int dump_main(int argc, char **argv) {
   if (argc < 3) quit("usage: strling _dump BAM");
@@ -461,6 +583,31 @@ static int dump_main(int argc, char **argv) {
              b.tid[i], b.pos[i], b.mapq[i], cig.empty() ? "*" : cig.c_str(), b.mtid[i], b.mpos[i], b.isize[i], seq.empty() ? "*" : seq.c_str());
     }
   }
+  return 0;
+}
+
+// `strling _region BAM TID BEG END`: qname and start of every record the indexed region read returns that passes htslib's
+// iterator filter (reader self-check; needs no GPU)
+static int region_main(int argc, char **argv) {
+  if (argc < 6) quit("usage: strling _region BAM TID BEG END");
+  BamReader rd;
+  std::string err;
+  if (!rd.open(argv[2], err) || !rd.load_index(argv[2], err)) quit("couldn't open bam: %s", err.c_str());
+  const int32_t tid = atoi(argv[3]);
+  const int64_t beg = atoll(argv[4]), end = atoll(argv[5]);
+  RecordBatch b;
+  const int64_t got = rd.read_region(b, tid, beg, end, err);
+  if (got < 0) quit("[strling] error reading %s: %s", argv[2], err.c_str());
+  int64_t kept = 0;
+  for (size_t i = 0; i < b.size(); ++i) {
+    int64_t rl = 0;
+    if (!(b.flag[i] & 4)) for (uint32_t c = b.cigar_off[i]; c < b.cigar_off[i + 1]; ++c) { const uint32_t op = b.cigar[c] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += b.cigar[c] >> 4; }
+    const int64_t stop = b.pos[i] + (rl ? rl : 1);
+    if (!(b.tid[i] == tid && b.pos[i] < end && stop > beg)) continue;
+    printf("%s\t%d\t%u\n", b.qnames.substr(b.qname_off[i], b.qname_off[i + 1] - b.qname_off[i]).c_str(), b.pos[i], b.flag[i]);
+    ++kept;
+  }
+  fprintf(stderr, "read %lld records, %lld in region\n", (long long)got, (long long)kept);
   return 0;
 }
 
@@ -497,15 +644,17 @@ static int index_main(int argc, char **argv) {
 int main(int argc, char **argv) {
   const char *top =
       "strling version: 0.6.0 (MI355X-native hot path)\n\nCommands:\n  extract  :   extract informative STR reads from a BAM (CRAM is not supported by this build).\n"
-      "  merge    :   merge putitive STR loci from multiple samples.\n  call     :   (not in this build) call STRs.\n  index    :   identify large STRs in the reference genome.\n";
+      "  merge    :   merge putitive STR loci from multiple samples.\n  call     :   call STRs.\n  index    :   identify large STRs in the reference genome.\n";
   if (argc < 2) { fputs(top, stdout); return 1; }
   const std::string cmd = argv[1];
   if (cmd == "extract") return extract_main(argc, argv);
   if (cmd == "merge") return merge_main(argc, argv);
   if (cmd == "index") return index_main(argc, argv);
+  if (cmd == "call") return call_main(argc, argv);
   if (cmd == "_dump") return dump_main(argc, argv);
-  if (cmd == "call" || cmd == "pull_region")
-    quit("[strling] `%s` is not part of this build (the MI355X path covers index, extract and merge; see DESIGN.md section 9)", cmd.c_str());
+  if (cmd == "_region") return region_main(argc, argv);
+  if (cmd == "pull_region")
+    quit("[strling] `%s` is not part of this build (the MI355X path covers index, extract, merge and call; see DESIGN.md section 9)", cmd.c_str());
   fputs(top, stdout);
   return 1;
 }

@@ -378,6 +378,30 @@ static int cluster_device_pass(strl_ctx *c, bool replay) {
   return STRL_OK;
 }
 
+// c.reads of every returned bound: the sorted permutation is still resident (B_PERM0)
+extern "C" int strl_cluster_members(strl_ctx *c, uint64_t *member_off, uint32_t *members, uint64_t cap, uint64_t *n_members) {
+  if (!c || !member_off || !n_members) { set_error("null argument"); return STRL_ERR_ARG; }
+  const ClusterRun &R = c->cl_run;
+  uint64_t tot = 0;
+  for (size_t j = 0; j < R.b_first.size(); ++j) { member_off[j] = tot; tot += R.b_count[j]; }
+  member_off[R.b_first.size()] = tot;
+  *n_members = tot;
+  if (!members) return STRL_OK;
+  if (tot > cap) { set_error("member capacity %llu too small, need %llu", (unsigned long long)cap, (unsigned long long)tot); return STRL_ERR_CAPACITY; }
+  if (!tot) return STRL_OK;
+  STRL_HIP(hipSetDevice(c->device));
+  std::vector<uint32_t> perm(R.n);
+  STRL_HIP(hipMemcpyAsync(perm.data(), c->c_buf[B_PERM0].p, (size_t)R.n * 4, hipMemcpyDeviceToHost, c->stream));
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  uint64_t k = 0;
+  for (size_t j = 0; j < R.b_first.size(); ++j)
+    for (uint32_t q = 0; q < R.b_count[j]; ++q) {
+      const uint32_t src = perm[R.b_first[j] + q];
+      members[k++] = R.kept.empty() ? src : R.kept[src];
+    }
+  return STRL_OK;
+}
+
 // Re-run the device side of the last strl_cluster call on the same resident treads, asynchronously.
 extern "C" int strl_cluster_replay(strl_ctx *c) {
   if (!c) return STRL_ERR_ARG;
@@ -399,6 +423,7 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
   std::vector<uint32_t> h_pos, h_sample;
   std::vector<uint8_t> h_split;
   std::vector<uint64_t> h_key;
+  std::vector<uint32_t> kept;
   h_pos.reserve(n_in); h_sample.reserve(n_in); h_split.reserve(n_in); h_key.reserve(n_in);
   for (uint64_t i = 0; i < n_in; ++i) {
     const strl_tread &t = treads[i];
@@ -413,6 +438,7 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
     h_pos.push_back(t.position);
     h_split.push_back(t.split);
     h_sample.push_back((uint32_t)t.qname_id);
+    if (mode == STRL_MODE_MERGE) kept.push_back((uint32_t)i);
   }
   const uint64_t n64 = h_pos.size();
   if (n64 > 0x7ffffff0ull) { set_error("too many treads"); return STRL_ERR_ARG; }
@@ -442,6 +468,7 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
   R = ClusterRun{};
   R.n = n; R.kbits = kbits; R.composite = composite; R.mode = mode; R.window = window; R.min_support = min_support; R.min_clip = min_clip;
   R.min_clip_total = min_clip_total; R.max_clip_dist = max_clip_dist;
+  R.kept.swap(kept);
   if ((rc = cluster_device_pass(c, false))) return rc;
   const uint32_t n_groups = R.n_groups, n_clusters = R.n_clusters;
   // ---- results back ------------------------------------------------------------------------------------
@@ -510,6 +537,7 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
           b.tid = tid; b.left = r.left; b.left_most = r.left_most; b.right = r.right; b.right_most = r.right_most;
           b.center_mass = r.center_mass; b.n_left = r.n_left; b.n_right = r.n_right; b.n_total = r.n_total;
           memcpy(b.repeat, rep, 7);
+          R.b_first.push_back(r.first); R.b_count.push_back(r.n_total);
         }
         ++no;
       }

@@ -40,6 +40,9 @@ struct ClusterRun {
   int32_t min_support = 0;
   uint32_t min_clip = 0, min_clip_total = 0, max_clip_dist = 0;
   size_t tmpb = 0;
+  // members of the bounds the last strl_cluster returned: [first, first + count) in sorted order; `kept` maps the
+  // uploaded (filtered) treads back to the caller's indices when merge mode dropped unplaced ones
+  std::vector<uint32_t> b_first, b_count, kept;
 };
 
 struct strl_ctx {

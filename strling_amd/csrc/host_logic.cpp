@@ -586,6 +586,11 @@ int strl_bin_read(const char *path, strl_bin_info *info, char *sam_header, strl_
   return STRL_OK;
 }
 
+void strl_canonical_repeat(const char in[6], char out[6]) {   // utils.nim:304-316
+  memcpy(out, in, 6);
+  canonical_repeat(out);
+}
+
 int strl_bounds_row(char *buf, int cap, const strl_bounds *b, const char *chrom) {   // cluster.nim:262-266
   return snprintf(buf, (size_t)cap, "%s\t%u\t%u\t%s\t\t%u\t%u\t%u\t%u\t%u\t%u", chrom, b->left, b->right, b->repeat, b->left_most,
                   b->right_most, b->center_mass, (unsigned)b->n_left, (unsigned)b->n_right, (unsigned)b->n_total);

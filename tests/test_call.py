@@ -1,0 +1,159 @@
+"""`strling call`: evidence around a bound (collect.nim / spanning.nim), genotype (genotyper.nim) and the CLI end to end."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from strling_amd import api, bamio, build, synth
+
+CLI = build.CLI
+
+
+def _sample(n_pairs=6000, seed=5, n_contigs=2, contig_len=30_000, **kw):
+    rec, g = synth.synth_wgs(n_pairs, seed=seed, n_contigs=n_contigs, contig_len=contig_len, **kw)
+    return rec, g
+
+
+def _oracle_bounds(oracle, rec, g, min_support=5):
+    frag = synth.frag_hist(rec)
+    med = oracle.median(frag)
+    t = oracle.extract(rec, g, oracle.make_opts(med, 0.8, 40))
+    window = oracle.median(frag, 0.99)
+    b, u = oracle.call_bounds(t, 1, window, min_support=min_support, max_clip_dist=int(0.5 * med))
+    return frag, med, window, t, b, u
+
+
+def _to_api_bounds(b):
+    out = np.zeros(len(b), api.BOUNDS_DTYPE)
+    for f in out.dtype.names:
+        out[f] = b[f]
+    return out
+
+
+@pytest.mark.parametrize("seed,min_mapq", [(5, 40), (6, 0), (7, 20)])
+def test_spanners_match_oracle(oracle, seed, min_mapq):
+    rec, g = _sample(seed=seed)
+    frag, med, window, t, b, u = _oracle_bounds(oracle, rec, g)
+    assert len(b) >= 2
+    ab = _to_api_bounds(b)
+    n_frag = n_span = 0
+    for j in range(len(b)):
+        es, emd, eexp = oracle.spanners(rec, b[j], window, frag, min_mapq)
+        gs, gmd, gexp = api.spanners(rec, ab[j], window, frag, min_mapq)
+        assert (gmd, np.float32(gexp)) == (emd, np.float32(eexp))
+        assert len(gs) == len(es)
+        for fa, fo in (("type", "type"), ("repeat_count", "repeat_count"), ("cigar_ins", "cigar_ins"), ("cigar_del", "cigar_del"),
+                       ("fragment_length", "frag_len"), ("fragment_percentile", "frag_pct"), ("rec", "rec")):
+            assert np.array_equal(gs[fa], es[fo]), (j, fa)
+        n_frag += int((es["type"] == 0).sum())
+        n_span += int((es["type"] == 1).sum())
+    assert n_frag > 0 and n_span > 0
+
+
+def test_spanners_edges(oracle):
+    """bound at the contig start (window_left < 0), bound wider than any read, unit of 6, tiny bound with extra slop,
+    a region with more than 20 000 pairs (median_depth -1)"""
+    rec, g = _sample(seed=11)
+    frag = synth.frag_hist(rec)
+    window = oracle.median(frag, 0.99)
+    cases = [dict(tid=0, left=3, right=40, repeat="AC"), dict(tid=1, left=12_000, right=12_900, repeat="AAGGGC"),
+             dict(tid=0, left=15_000, right=15_001, repeat="CAG"), dict(tid=1, left=29_900, right=29_990, repeat="A")]
+    for c in cases:
+        ob = oracle.make_bounds(**c)
+        ab = np.zeros(1, api.BOUNDS_DTYPE)
+        ab["tid"], ab["left"], ab["right"], ab["repeat"] = c["tid"], c["left"], c["right"], c["repeat"].encode()
+        es, emd, eexp = oracle.spanners(rec, ob, window, frag, 20)
+        gs, gmd, gexp = api.spanners(rec, ab[0], window, frag, 20)
+        assert (gmd, np.float32(gexp), len(gs)) == (emd, np.float32(eexp), len(es)), c
+        assert np.array_equal(gs["type"], es["type"]) and np.array_equal(gs["rec"], es["rec"]) and np.array_equal(gs["repeat_count"], es["repeat_count"])
+
+
+def test_genotype_and_rows_match_oracle(oracle):
+    rec, g = _sample(seed=5)
+    frag, med, window, t, b, u = _oracle_bounds(oracle, rec, g)
+    exp_b, exp_g, exp_u = oracle.call(t, rec, frag)
+    assert exp_b.count("\n") >= 3 and exp_g.count("\n") == exp_b.count("\n")
+    # product pieces driven from Python exactly like the CLI drives them (bounds + members from the oracle here: CPU only)
+    at = np.zeros(len(t), api.TREAD_DTYPE)
+    for f in at.dtype.names:
+        at[f] = t[f]
+    ab = _to_api_bounds(b)
+    members = oracle.cluster_members_call(t, window, 5, int(0.5 * med))
+    assert len(members) == len(b)
+    calls, rows_b = [], []
+    for j in range(len(b)):
+        sp, md, ex = api.spanners(rec, ab[j], window, frag, 40)
+        if len(sp) > 5000 or md == -1:
+            continue
+        c = api.genotype(ab[j], at[members[j]], rec.qname_off, rec.qnames, sp, md, med)
+        c["expected_spanning_fragments"] = ex
+        calls.append(c)
+        rows_b.append(api.bounds_row(ab[j], rec.targets[int(ab[j]["tid"])][0]) + f"\t{md}")
+    uu = np.zeros(len(u), api.UNPLACED_DTYPE)
+    uu["repeat"] = [x[0].encode() for x in u]
+    uu["count"] = [x[1] for x in u]
+    fin, order = api.calls_finish(np.array(calls, api.CALL_DTYPE), uu)
+    rows_g = [api.call_row(fin[int(i)], rec.targets[int(fin[int(i)]["tid"])][0]) for i in order]
+    assert "\n".join(exp_b.splitlines()[1:]) == "\n".join(rows_b)
+    assert "\n".join(exp_g.splitlines()[1:]) == "\n".join(rows_g)
+
+
+def _run(args, **kw):
+    return subprocess.run([CLI] + args, capture_output=True, text=True, **kw)
+
+
+@pytest.mark.gpu
+def test_cluster_members_match_oracle(ctx, oracle):
+    rec, g = _sample(seed=5)
+    frag, med, window, t, b, u = _oracle_bounds(oracle, rec, g)
+    at = np.zeros(len(t), api.TREAD_DTYPE)
+    for f in at.dtype.names:
+        at[f] = t[f]
+    gb, gu, st = ctx.cluster(at, api.MODE_CALL, window, min_support=5, max_clip_dist=int(0.5 * med))
+    off, mem = ctx.cluster_members(len(gb))
+    exp = oracle.cluster_members_call(t, window, 5, int(0.5 * med))
+    assert len(gb) == len(exp) >= 2
+    for j in range(len(gb)):
+        assert mem[int(off[j]):int(off[j + 1])].tolist() == exp[j].tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_pairs,extra", [(5, 6000, []), (21, 9000, ["-m", "3", "-q", "20"]), (33, 6000, ["-c", "1", "-t", "2"])])
+def test_call_outputs_identical_to_oracle(oracle, tmp_path, seed, n_pairs, extra):
+    """extract -> call on a synthetic BAM: -bounds.txt (with depth), -genotype.txt and -unplaced.txt byte-identical to the
+    oracle's restatement of call.nim (evidence from indexed region reads of the BAM)"""
+    rec, g = _sample(n_pairs=n_pairs, seed=seed, n_contigs=3, contig_len=40_000)
+    bam, bed, binp = str(tmp_path / "s.bam"), str(tmp_path / "ref.str"), str(tmp_path / "s.bin")
+    bamio.write_bam(bam, rec)
+    bamio.write_genome_bed(bed, g, rec.targets)
+    r = _run(["extract", "-g", bed, bam, binp])
+    assert r.returncode == 0, r.stderr
+    prefix = str(tmp_path / "out")
+    r = _run(["call", "-v", "-o", prefix] + extra + [bam, binp])
+    assert r.returncode == 0, r.stderr
+    assert "wrote genotypes to" in r.stderr
+    frag = synth.frag_hist(rec)
+    med = oracle.median(frag)
+    t = oracle.extract(rec, g, oracle.make_opts(med, 0.8, 40))
+    kw = dict(min_support=5, min_clip=0, min_clip_total=0, min_mapq=40)
+    for flag, key in (("-m", "min_support"), ("-q", "min_mapq"), ("-c", "min_clip"), ("-t", "min_clip_total")):
+        if flag in extra:
+            kw[key] = int(extra[extra.index(flag) + 1])
+    exp_b, exp_g, exp_u = oracle.call(t, rec, frag, **kw)
+    assert exp_b.count("\n") >= 3
+    assert open(prefix + "-bounds.txt").read() == exp_b
+    assert open(prefix + "-genotype.txt").read() == exp_g
+    assert open(prefix + "-unplaced.txt").read() == exp_u
+
+
+@pytest.mark.gpu
+def test_call_requires_index_and_matching_bin(oracle, tmp_path):
+    rec, g = _sample(n_pairs=1500, seed=2)
+    bam, bed, binp = str(tmp_path / "s.bam"), str(tmp_path / "ref.str"), str(tmp_path / "s.bin")
+    bamio.write_bam(bam, rec)
+    bamio.write_genome_bed(bed, g, rec.targets)
+    assert _run(["extract", "-g", bed, bam, binp]).returncode == 0
+    os.remove(bam + ".bai")
+    r = _run(["call", "-o", str(tmp_path / "x"), bam, binp])
+    assert r.returncode == 1 and "couldn't open bam" in r.stderr

@@ -30,7 +30,7 @@ def test_cli_exists_and_help():
     assert os.path.exists(CLI), "strling CLI not built (python -m strling_amd.build)"
     r = _run(["extract"])
     assert r.returncode == 0 and "strling extract" in r.stdout
-    r = _run(["call", "x", "y"])
+    r = _run(["pull_region", "x", "y"])
     assert r.returncode == 1 and "not part of this build" in r.stderr
 
 
@@ -51,6 +51,26 @@ def test_bam_reader_roundtrip(sample):
         assert f[0] == rec.qname(i).decode() and int(f[1]) == rec.flag[i] and int(f[2]) == rec.tid[i] and int(f[3]) == rec.pos[i]
         assert int(f[4]) == rec.mapq[i] and f[5] == cig and int(f[6]) == rec.mtid[i] and int(f[7]) == rec.mpos[i]
         assert int(f[8]) == rec.isize[i] and f[9] == rec.sequence(i)
+
+
+def test_indexed_region_reads(tmp_path):
+    """.bai linear index + region read == a scan of all records with htslib's iterator filter (tid, pos < end, endpos > beg)"""
+    rec, _ = synth.synth_wgs(5000, seed=3, n_contigs=3, contig_len=200_000)
+    bam = str(tmp_path / "r.bam")
+    bamio.write_bam(bam, rec)
+    assert os.path.exists(bam + ".bai")
+    stop = np.array([int(rec.pos[i]) + bamio._ref_len(rec, i) for i in range(rec.n)])
+    rng = np.random.default_rng(1)
+    regions = [(0, 0, 500), (2, 199_000, 200_500), (1, 16_300, 16_400), (1, 150_000, 150_001), (0, 100_000, 140_000), (2, 0, 1)]
+    regions += [(int(rng.integers(0, 3)), int(a), int(a) + int(rng.integers(1, 3000))) for a in rng.integers(0, 199_000, 20)]
+    for tid, beg, end in regions:
+        r = _run(["_region", bam, str(tid), str(beg), str(end)])
+        assert r.returncode == 0, r.stderr
+        got = [tuple(l.split("\t")) for l in r.stdout.splitlines()]
+        sel = np.nonzero((rec.tid == tid) & (rec.pos < end) & (stop > beg))[0]
+        exp = [(rec.qname(i).decode(), str(int(rec.pos[i])), str(int(rec.flag[i]))) for i in sel]
+        assert got == exp, (tid, beg, end)
+    assert sum(1 for t, b, e in regions if np.any((rec.tid == t) & (rec.pos < e) & (stop > b))) > 15
 
 
 @pytest.mark.gpu

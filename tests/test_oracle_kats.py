@@ -119,3 +119,37 @@ def test_counttable_largest_first_max_in_slot_order(oracle):
         else:
             exp = a if sa < sb else b
         assert (key.value, val.value, nd.value) == (exp, 2, 2)
+
+
+# ---- strling call evidence (collect.nim / genotyper.nim / utils.nim) ----
+@pytest.mark.parametrize("k", KATS["overlapping_read"], ids=lambda k: k["source"])
+def test_overlapping_read_kats(oracle, k):
+    rec = RecordBatch.from_sam(k["sam_header"], [k["sam"]])
+    s = oracle.overlapping_read(rec, 0, oracle.make_bounds(**k["bounds"]))
+    assert (s is not None) == k["expect"]
+    if "type" in k:
+        assert oracle.SUPPORT_TYPES[s.type] == k["type"]
+
+
+@pytest.mark.parametrize("k", KATS["spanning_fragment"], ids=lambda k: k["source"])
+def test_spanning_fragment_kats(oracle, k):
+    rec = RecordBatch.from_sam(k["sam_header"], k["sam"])
+    s = oracle.spanning_fragment(rec, 0, 1, oracle.make_bounds(**k["bounds"]), np.zeros(4096, np.uint32))
+    assert (s is not None) == k["expect"]
+
+
+@pytest.mark.parametrize("k", KATS["spanning_read_est"], ids=lambda k: k["source"])
+def test_spanning_read_est_kat(oracle, k):
+    s = np.zeros(len(k["reads"]), oracle.SUPPORT_DTYPE)
+    s["type"] = 1
+    s["repeat_count"] = [r["repeat_count"] for r in k["reads"]]
+    s["cigar_ins"] = [r["ins"] for r in k["reads"]]
+    s["cigar_del"] = [r["del"] for r in k["reads"]]
+    est = oracle.spanning_read_est(s)
+    for f, v in k["expect"].items():
+        assert est[f] == v, f
+
+
+@pytest.mark.parametrize("k", KATS["median_depth"], ids=lambda k: k["source"])
+def test_median_depth_kats(oracle, k):
+    assert oracle.median_depth(k["depths"]) == k["expect"]
