@@ -169,6 +169,7 @@ int strl_ctx_kernel_times(strl_ctx *ctx, double ms_sum[3], uint64_t *n_launches)
 #define STRL_SOFT_NONE 3
 #define STRL_SOFT_NONE_RIGHT 4
 #define STRL_SOFT_NONE_LEFT 5
+#define STRL_SOFT_TAKEN 255 /* not a Soft value: a tread strl_assign_reads_loci took out of the table (see there) */
 typedef struct {
   int32_t tid;
   uint32_t position;
@@ -236,6 +237,19 @@ int strl_cluster(strl_ctx *ctx, const strl_tread *treads, uint64_t n, int mode, 
  * stable): bound j holds treads[members[member_off[j]]] .. treads[members[member_off[j+1] - 1]] (indices into the
  * array given to strl_cluster; c.reads of call.nim:246).  member_off is [n_bounds + 1]. */
 int strl_cluster_members(strl_ctx *ctx, uint64_t *member_off, uint32_t *members, uint64_t cap, uint64_t *n_members);
+
+/* Loci given on the command line (-l BED / -b BOUNDS) take their reads before clustering: assign_reads_locus,
+ * callclusters.nim:14-50, for every locus in order.  The reads of the locus' (tid, unit) group whose position lies in
+ * [left_most - 1, right_most] go to the locus (assigned[assigned_off[j] .. assigned_off[j+1]), position order), the read
+ * right behind that range is lost like in the reference (:34-36), n_total/n_left/n_right of the locus are recounted.
+ * Taken and lost treads get split = STRL_SOFT_TAKEN in place: strl_cluster then ignores them as reads but still
+ * counts them as keys of the reference's Table, which keeps its row order.  mode as for strl_cluster. */
+typedef struct {
+  strl_bounds b;
+  char name[128]; /* Bounds.name, column 5 of -bounds.txt */
+} strl_locus;
+int strl_assign_reads_loci(strl_tread *treads, uint64_t n, int mode, strl_locus *loci, uint64_t n_loci, uint64_t *assigned_off,
+                           uint32_t *assigned, uint64_t cap);
 
 /* Re-run the device side of the last strl_cluster call (sorts, sweep, bounds) over the treads still resident on
  * the device, asynchronously on the context stream and without host synchronisation.  For timing. */

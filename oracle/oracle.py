@@ -84,6 +84,10 @@ class Gt(C.Structure):
                 ("is_large", C.c_int)]
 
 
+class Locus(C.Structure):
+    _fields_ = [("b", Bounds), ("name", C.c_char * 128)]
+
+
 class Unplaced(C.Structure):
     _fields_ = [("repeat", C.c_char * 7), ("count", C.c_int64)]
 
@@ -149,10 +153,16 @@ def lib():
         L.orc_call_row.argtypes = [C.c_char_p, C.c_int, C.POINTER(Gt), C.c_char_p]
         L.orc_call.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(Records), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                C.c_uint16, C.c_uint16, C.c_uint8, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
-                               C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+                               C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_char_p, C.c_char_p, C.c_void_p, C.c_int]
         L.orc_call_members.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_uint16, C.c_uint16, C.c_uint16, C.c_void_p, C.c_void_p,
                                        C.c_int64, C.POINTER(C.c_int64)]
         L.orc_call_members.restype = C.c_int64
+        L.orc_parse_bed.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int64]
+        L.orc_parse_bed.restype = C.c_int64
+        L.orc_parse_bounds.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+        L.orc_parse_bounds.restype = C.c_int64
+        L.orc_merge_text.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_uint16, C.c_uint16, C.c_uint16, C.c_char_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.orc_cluster_group.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
     return _LIB
 
@@ -421,19 +431,57 @@ def spanning_read_est(supports):
     return dict(allele1_bp=v[0].value, allele2_bp=v[1].value, allele1_ru=v[2].value, allele2_ru=v[3].value, supporting_reads=sup.value)
 
 
-def call(treads, rec, frag, min_support=5, min_clip=0, min_clip_total=0, min_mapq=40):
-    """call.nim:111-285 (no -l/-b): (bounds.txt, genotype.txt, unplaced.txt) texts.  tread.qname_id indexes rec's qnames."""
+def _targets(targets):
+    names = (C.c_char_p * len(targets))(*[n.encode() for n, _ in targets])
+    lens = np.array([l for _, l in targets], np.uint32)
+    return names, lens
+
+
+def parse_bed(text, targets, window):
+    names, lens = _targets(targets)
+    out = (Locus * 4096)()
+    n = lib().orc_parse_bed(text.encode(), names, lens.ctypes.data, len(targets), window, out, 4096)
+    if n < 0:
+        raise ValueError("parse_bed: the reference quits on this input")
+    return [out[i] for i in range(n)]
+
+
+def parse_bounds(text, targets):
+    names, lens = _targets(targets)
+    out = (Locus * 4096)()
+    n = lib().orc_parse_bounds(text.encode(), names, len(targets), out, 4096)
+    if n < 0:
+        raise ValueError("parse_bounds: the reference quits on this input")
+    return [out[i] for i in range(n)]
+
+
+def merge_text(treads, window, targets, min_support=5, min_clip=0, min_clip_total=0, max_clip_dist=200, loci_text=None):
+    """merge.nim:154-187 -> text of -bounds.txt (qname_id = sample index), with optional -l loci"""
+    t = np.ascontiguousarray(treads, dtype=TREAD_DTYPE)
+    names, lens = _targets(targets)
+    cap = 1 << 22
+    buf = C.create_string_buffer(cap)
+    need = C.c_int64(0)
+    rc = lib().orc_merge_text(t.ctypes.data, t.size, window, min_support, min_clip, min_clip_total, max_clip_dist,
+                              loci_text.encode() if loci_text is not None else None, names, lens.ctypes.data, len(targets), buf, cap, C.byref(need))
+    assert rc == 0 and need.value < cap
+    return buf.raw[:need.value].decode()
+
+
+def call(treads, rec, frag, min_support=5, min_clip=0, min_clip_total=0, min_mapq=40, loci_text=None, bounds_text=None):
+    """call.nim:111-285: (bounds.txt, genotype.txt, unplaced.txt) texts.  tread.qname_id indexes rec's qnames."""
     t = np.ascontiguousarray(treads, dtype=TREAD_DTYPE)
     rv = RecordsView(rec)
     frag = np.ascontiguousarray(frag, np.uint32)
     isz = np.ascontiguousarray(rec.isize if rec.isize is not None else np.zeros(rec.n), np.int32)
-    names = (C.c_char_p * len(rec.targets))(*[n.encode() for n, _ in rec.targets])
+    names, lens = _targets(rec.targets)
     caps = [1 << 22, 1 << 22, 1 << 16]
     bufs = [C.create_string_buffer(c) for c in caps]
     ns = [C.c_int64(0) for _ in range(3)]
     lib().orc_call(t.ctypes.data, t.size, rv.keep["qname_off"].ctypes.data, rv.keep["qnames"].ctypes.data, C.byref(rv.c), isz.ctypes.data,
                    frag.ctypes.data, names, min_support, min_clip, min_clip_total, min_mapq, bufs[0], caps[0], bufs[1], caps[1], bufs[2], caps[2],
-                   C.byref(ns[0]), C.byref(ns[1]), C.byref(ns[2]))
+                   C.byref(ns[0]), C.byref(ns[1]), C.byref(ns[2]), loci_text.encode() if loci_text is not None else None,
+                   bounds_text.encode() if bounds_text is not None else None, lens.ctypes.data, len(rec.targets))
     assert all(n.value < c for n, c in zip(ns, caps))
     return tuple(b.raw[:n.value].decode() for b, n in zip(bufs, ns))
 

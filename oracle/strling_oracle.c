@@ -828,6 +828,11 @@ static int cmp_pos_stable(const void *a, const void *b) {
   return x < y ? -1 : (x > y ? 1 : 0);        /* algorithm.sort is a stable merge sort */
 }
 
+/* loci handed to call/merge on the command line (-l / -b); set by the drivers around call_bounds_impl */
+static orc_locus *g_loci = NULL;
+static int64_t g_n_loci = 0;
+static void (*g_on_locus)(void *ud, orc_locus *L, const orc_tread *reads, int64_t n) = NULL;
+static void *g_locus_ud = NULL;
 static int64_t call_bounds_impl(const orc_tread *treads, int64_t n, int mode, uint32_t window, int min_support,
                         uint16_t min_clip, uint16_t min_clip_total, uint16_t max_clip_dist,
                         orc_bounds *out, int64_t cap, orc_unplaced *unpl, int64_t unpl_cap, int64_t *n_unpl,
@@ -884,13 +889,54 @@ static int64_t call_bounds_impl(const orc_tread *treads, int64_t n, int mode, ui
   for (int64_t q = 0; q < n; q++) if (gid_of[q] >= 0) ptr[fill[gid_of[q]]++] = &treads[q];
   drv d = {mode, min_support, min_clip, min_clip_total, max_clip_dist, out, cap, 0, unpl, unpl_cap, 0, on_bound, hook_ud};
   orc_tread *buf = (orc_tread *)malloc((size_t)(n ? n : 1) * sizeof(orc_tread));
+  int64_t *glen = (int64_t *)malloc((size_t)(ngroups + 1) * 8);
+  for (int64_t gi = 0; gi < ngroups; gi++) {                              /* call.nim:127-130 / merge.nim:132-135 */
+    glen[gi] = gcount[gi + 1] - gcount[gi];
+    qsort(ptr + gcount[gi], (size_t)glen[gi], sizeof(void *), cmp_pos_stable);
+  }
+  /* loci given on the command line take their reads out of the table first (callclusters.nim:14-50) */
+  for (int64_t li = 0; li < g_n_loci; li++) {
+    orc_locus *L = &g_loci[li];
+    char rep6[6] = {0};
+    memcpy(rep6, L->b.repeat, strlen(L->b.repeat));
+    uint64_t hc = orc_nim_hash_tidrep(L->b.tid, rep6);
+    if (hc == 0) hc = 314159265;
+    int64_t h = (int64_t)(hc & (uint64_t)(len - 1)), gi = -1;
+    while (tb[h].hcode != 0) {
+      if (tb[h].hcode == hc && tb[h].tid == L->b.tid && memcmp(tb[h].rep, rep6, 6) == 0) { gi = tb[h].gid; break; }
+      h = (h + 1) & (len - 1);
+    }
+    int64_t nres = 0;
+    if (gi >= 0 && glen[gi] > 0) {
+      const orc_tread **trs = ptr + gcount[gi];
+      int64_t tl = glen[gi];
+      uint32_t left_most = L->b.left_most == 0 ? 0u : L->b.left_most - 1u;
+      int64_t lo = 0, ri = 0;
+      while (lo < tl && trs[lo]->position < left_most) lo++;               /* lowerBound */
+      while (ri < tl && trs[ri]->position <= L->b.right_most) ri++;          /* upperBound */
+      if (ri < lo) ri = lo;
+      nres = ri - lo;
+      for (int64_t j = 0; j < nres; j++) buf[j] = *trs[lo + j];
+      /* table[key] = trs[0..<li] & (if ri < trs.high: trs[ri+1..high]): trs[ri] itself is lost */
+      int64_t w = lo;
+      if (ri < tl - 1) for (int64_t j = ri + 1; j < tl; j++) trs[w++] = trs[j];
+      glen[gi] = w;
+    }
+    L->b.n_total = 0; L->b.n_left = 0; L->b.n_right = 0;
+    for (int64_t j = 0; j < nres; j++) {
+      L->b.n_total++;
+      if (buf[j].split == ORC_SOFT_RIGHT) L->b.n_right++;
+      else if (buf[j].split == ORC_SOFT_LEFT) L->b.n_left++;
+    }
+    if (g_on_locus) g_on_locus(g_locus_ud, L, buf, nres);
+  }
   for (int64_t h = 0; h < len; h++) {                                      /* mpairs: slot order */
     if (tb[h].hcode == 0) continue;
-    int64_t gi = tb[h].gid, a = gcount[gi], e = gcount[gi + 1];
-    qsort(ptr + a, (size_t)(e - a), sizeof(void *), cmp_pos_stable);
+    int64_t gi = tb[h].gid, a = gcount[gi], e = a + glen[gi];
     for (int64_t j = a; j < e; j++) buf[j - a] = *ptr[j];
     orc_cluster_group(buf, e - a, window, min_support, on_cluster, &d);
   }
+  free(glen);
   free(buf); free(fill); free(ptr); free(gcount); free(gid_of); free(tb);
   if (n_unpl) *n_unpl = d.n_unpl;
   return d.n < cap ? d.n : cap;
@@ -1358,12 +1404,143 @@ static int call_on_bound(void *ud, orc_bounds *b, const orc_tread *reads, int64_
   free(sp);
   return 1;
 }
+/* cluster.nim:262-266 with the name column filled */
+static int locus_row(char *buf, int cap, const orc_locus *L, const char *chrom) {
+  const orc_bounds *b = &L->b;
+  return snprintf(buf, (size_t)cap, "%s\t%u\t%u\t%s\t%s\t%u\t%u\t%u\t%u\t%u\t%u", chrom, b->left, b->right, b->repeat, L->name, b->left_most,
+                  b->right_most, b->center_mass, (unsigned)b->n_left, (unsigned)b->n_right, (unsigned)b->n_total);
+}
+/* call.nim:190-218: a bound given with -l/-b, after assign_reads_locus took its reads */
+static void call_on_locus(void *ud, orc_locus *L, const orc_tread *reads, int64_t n) {
+  call_ctx *c = (call_ctx *)ud;
+  orc_bounds *b = &L->b;
+  if (b->right - b->left > 1000u) return;                                             /* :193-195 */
+  int64_t cap = 1 << 16;
+  orc_support *sp = (orc_support *)malloc((size_t)cap * sizeof(orc_support));
+  int md; float es;
+  int64_t ns = orc_spanners(c->r, c->isize, b, c->window, c->frag, c->min_mapq, sp, cap, &md, &es);
+  if (ns > 5000 || md == -1) { free(sp); return; }
+  if (c->ncalls == c->ccap) { c->ccap *= 2; c->calls = realloc(c->calls, (size_t)c->ccap * sizeof(orc_gt)); c->canon = realloc(c->canon, (size_t)c->ccap * 7); }
+  orc_gt *gt = &c->calls[c->ncalls];
+  orc_genotype(b, reads, n, c->tq_off, c->tqnames, sp, ns, c->min_support, c->min_clip, c->min_clip_total, c->frag_median, (double)md, gt);
+  gt->expected_spanning_fragments = es;
+  char in6[6] = {0}, out6[6];
+  memcpy(in6, b->repeat, strlen(b->repeat));
+  orc_canonical_repeat(in6, out6);
+  memset(c->canon[c->ncalls], 0, 7); memcpy(c->canon[c->ncalls], out6, 6);
+  c->ncalls++;
+  char row[768], line[800];
+  locus_row(row, sizeof row, L, c->targets[b->tid]);
+  snprintf(line, sizeof line, "%s\t%d", row, md);
+  sb_add(c->bounds, line);
+  free(sp);
+}
+
+static int get_tid(const char *name, int nlen, const char *const *names, int n_targets) {   /* utils.nim:214-218 */
+  for (int t = 0; t < n_targets; t++) if ((int)strlen(names[t]) == nlen && memcmp(names[t], name, (size_t)nlen) == 0) return t;
+  return -1;
+}
+/* cluster.nim:111-141 parse_bed: whitespace separated chrom start stop unit [name]; returns count or -1 where the reference quits */
+int64_t orc_parse_bed(const char *text, const char *const *names, const uint32_t *lengths, int n_targets, uint32_t window, orc_locus *out, int64_t cap) {
+  int64_t n = 0;
+  const char *p = text;
+  while (*p) {
+    const char *e = strchr(p, '\n'); if (!e) e = p + strlen(p);
+    const char *f[8]; int fl[8], nf = 0;
+    const char *q = p;
+    while (q < e) {
+      while (q < e && (*q == ' ' || *q == '\t' || *q == '\r')) q++;
+      if (q >= e) break;
+      const char *s0 = q;
+      while (q < e && !(*q == ' ' || *q == '\t' || *q == '\r')) q++;
+      if (nf < 8) { f[nf] = s0; fl[nf] = (int)(q - s0); }
+      nf++;
+    }
+    if (nf != 4 && nf != 5) return -1;
+    orc_locus L; memset(&L, 0, sizeof L);
+    if (nf == 5) memcpy(L.name, f[4], (size_t)(fl[4] < 127 ? fl[4] : 127));
+    L.b.tid = get_tid(f[0], fl[0], names, n_targets);
+    L.b.left = (uint32_t)strtoll(f[1], NULL, 10); L.b.right = (uint32_t)strtoll(f[2], NULL, 10);
+    if (fl[3] > 6 || L.b.tid < 0) return -1;
+    memcpy(L.b.repeat, f[3], (size_t)fl[3]);
+    int32_t lm = (int32_t)L.b.left - (int32_t)window;
+    L.b.left_most = (uint32_t)(lm > 0 ? lm : 0);
+    L.b.right_most = L.b.right + window < lengths[L.b.tid] ? L.b.right + window : lengths[L.b.tid];
+    for (int i = 0; i < fl[3]; i++) if (!strchr("ATCG", f[3][i])) return -1;
+    if (!(L.b.left <= L.b.right) || !(L.b.left_most <= L.b.right_most)) return -1;
+    if (n < cap) out[n] = L;
+    n++;
+    p = *e ? e + 1 : e;
+  }
+  return n;
+}
+/* cluster.nim:143-169 parse_bounds: exactly 11 tab separated fields, '#' lines skipped */
+int64_t orc_parse_bounds(const char *text, const char *const *names, int n_targets, orc_locus *out, int64_t cap) {
+  int64_t n = 0;
+  const char *p = text;
+  while (*p) {
+    const char *e = strchr(p, '\n'); if (!e) e = p + strlen(p);
+    if (*p != '#') {
+      const char *f[12]; int fl[12], nf = 0;
+      const char *q = p;
+      for (;;) {
+        const char *t = q;
+        while (t < e && *t != '\t') t++;
+        if (nf < 12) { f[nf] = q; fl[nf] = (int)(t - q); }
+        nf++;
+        if (t >= e) break;
+        q = t + 1;
+      }
+      if (nf != 11) return -1;
+      orc_locus L; memset(&L, 0, sizeof L);
+      L.b.tid = get_tid(f[0], fl[0], names, n_targets);
+      if (L.b.tid < 0 || fl[3] > 6) return -1;
+      L.b.left = (uint32_t)strtoll(f[1], NULL, 10); L.b.right = (uint32_t)strtoll(f[2], NULL, 10);
+      memcpy(L.b.repeat, f[3], (size_t)fl[3]);
+      memcpy(L.name, f[4], (size_t)(fl[4] < 127 ? fl[4] : 127));
+      L.b.left_most = (uint32_t)strtoll(f[5], NULL, 10); L.b.right_most = (uint32_t)strtoll(f[6], NULL, 10);
+      L.b.center_mass = (uint32_t)strtoll(f[7], NULL, 10);
+      L.b.n_left = (uint16_t)strtoll(f[8], NULL, 10); L.b.n_right = (uint16_t)strtoll(f[9], NULL, 10); L.b.n_total = (uint16_t)strtoll(f[10], NULL, 10);
+      for (int i = 0; i < fl[3]; i++) if (!strchr("ATCG", f[3][i])) return -1;
+      if (!(L.b.left <= L.b.right) || !(L.b.left_most <= L.b.right_most)) return -1;
+      if (n < cap) out[n] = L;
+      n++;
+    }
+    p = *e ? e + 1 : e;
+  }
+  return n;
+}
+static int loci_overlap(const orc_bounds *a, const orc_bounds *b) {                    /* cluster.nim:96-100 */
+  if (a->tid == b->tid && strcmp(a->repeat, b->repeat) == 0) {
+    uint32_t il = a->left > b->left ? a->left : b->left, ir = a->right < b->right ? a->right : b->right;
+    return il <= ir;
+  }
+  return 0;
+}
+/* call.nim:160-183: bounds first (loci overwrite the bound they overlap and are then removed with seq.del, which moves the
+ * last element into the hole), then the loci that are left.  Returns the merged list length. */
+int64_t orc_merge_loci_bounds(orc_locus *bounds, int64_t nb, orc_locus *loci, int64_t nl, orc_locus *out) {
+  for (int64_t i = 0; i < nb; i++) {
+    for (int64_t j = 0; j < nl; j++) {
+      if (loci_overlap(&loci[j].b, &bounds[i].b)) {
+        memcpy(bounds[i].name, loci[j].name, sizeof bounds[i].name);
+        bounds[i].b.left = loci[j].b.left; bounds[i].b.right = loci[j].b.right;
+        loci[j] = loci[nl - 1]; nl--;                                               /* loci.del(i) */
+        break;
+      }
+    }
+    out[i] = bounds[i];
+  }
+  for (int64_t j = 0; j < nl; j++) out[nb + j] = loci[j];
+  return nb + nl;
+}
+
 static int cmp_f32(const void *a, const void *b) { float x = *(const float *)a, y = *(const float *)b; return x < y ? -1 : (x > y ? 1 : 0); }
 
 int orc_call(const orc_tread *treads, int64_t n, const uint64_t *tq_off, const char *tqnames, const orc_records *r, const int32_t *isize,
              const uint32_t frag[4096], const char *const *target_names, int min_support, uint16_t min_clip, uint16_t min_clip_total,
              uint8_t min_mapq, char *bounds_buf, int64_t bcap, char *gt_buf, int64_t gcap, char *unpl_buf, int64_t ucap,
-             int64_t *bn, int64_t *gn, int64_t *un) {
+             int64_t *bn, int64_t *gn, int64_t *un, const char *loci_text, const char *bounds_text, const uint32_t *target_lengths, int n_targets) {
   sbuf sb = {bounds_buf, bcap, 0}, sg = {gt_buf, gcap, 0}, su = {unpl_buf, ucap, 0};
   sb_add(&sb, "#chrom\tleft\tright\trepeat\tname\tleft_most\tright_most\tcenter_mass\tn_left\tn_right\tn_total\tdepth");
   sb_add(&sg, "#chrom\tleft\tright\trepeatunit\tallele1_est\tallele2_est\tanchored_reads\tspanning_reads\tspanning_pairs\texpected_spanning_pairs\tspanning_pairs_pctl\tleft_clips\tright_clips\tunplaced_pairs\tdepth\tsum_str_counts");
@@ -1376,8 +1553,17 @@ int orc_call(const orc_tread *treads, int64_t n, const uint64_t *tq_off, const c
   int64_t ucap_n = n + 1, nu = 0;
   orc_unplaced *unpl = (orc_unplaced *)calloc((size_t)ucap_n, sizeof(orc_unplaced));
   orc_bounds *tmp = (orc_bounds *)malloc((size_t)(n + 1) * sizeof(orc_bounds));
+  int64_t lcap = 1 << 16, nl = 0, nbd = 0;
+  orc_locus *loci = (orc_locus *)malloc((size_t)lcap * sizeof(orc_locus)), *bnds = (orc_locus *)malloc((size_t)lcap * sizeof(orc_locus));
+  orc_locus *merged = (orc_locus *)malloc((size_t)2 * lcap * sizeof(orc_locus));
+  if (loci_text) nl = orc_parse_bed(loci_text, target_names, target_lengths, n_targets, (uint32_t)c.window, loci, lcap);
+  if (bounds_text) nbd = orc_parse_bounds(bounds_text, target_names, n_targets, bnds, lcap);
+  if (nl < 0 || nbd < 0) return -1;
+  g_n_loci = orc_merge_loci_bounds(bnds, nbd, loci, nl, merged);
+  g_loci = merged; g_on_locus = call_on_locus; g_locus_ud = &c;
   call_bounds_impl(treads, n, 1, (uint32_t)c.window, min_support, min_clip, min_clip_total, max_clip_dist, tmp, n + 1, unpl, ucap_n, &nu, call_on_bound, &c);
-  free(tmp);
+  g_loci = NULL; g_n_loci = 0; g_on_locus = NULL; g_locus_ud = NULL;
+  free(tmp); free(loci); free(bnds); free(merged);
   /* add_percentile, call.nim:38-48 */
   float *oes = (float *)malloc((size_t)(c.ncalls ? c.ncalls : 1) * sizeof(float));
   for (int64_t i = 0; i < c.ncalls; i++) {
@@ -1448,4 +1634,36 @@ int64_t orc_call_members(const orc_tread *treads, int64_t n, uint32_t window, in
   *n_members = m.nm;
   free(tmp); free(cp);
   return nb;
+}
+
+/* merge.nim:154-187 as text: header, one row per -l locus (ungated, after assign_reads_locus), then the clustered bounds */
+static void merge_on_locus(void *ud, orc_locus *L, const orc_tread *reads, int64_t n) {
+  call_ctx *c = (call_ctx *)ud;
+  char row[768];
+  locus_row(row, sizeof row, L, c->targets[L->b.tid]);
+  sb_add(c->bounds, row);
+}
+int orc_merge_text(const orc_tread *treads, int64_t n, uint32_t window, int min_support, uint16_t min_clip, uint16_t min_clip_total,
+                   uint16_t max_clip_dist, const char *loci_text, const char *const *target_names, const uint32_t *target_lengths, int n_targets,
+                   char *buf, int64_t cap, int64_t *need) {
+  sbuf sb = {buf, cap, 0};
+  sb_add(&sb, "#chrom\tleft\tright\trepeat\tname\tleft_most\tright_most\tcenter_mass\tn_left\tn_right\tn_total");
+  call_ctx c; memset(&c, 0, sizeof c);
+  c.targets = target_names; c.bounds = &sb;
+  int64_t lcap = 1 << 16, nl = 0;
+  orc_locus *loci = (orc_locus *)malloc((size_t)lcap * sizeof(orc_locus));
+  if (loci_text) nl = orc_parse_bed(loci_text, target_names, target_lengths, n_targets, window, loci, lcap);
+  if (nl < 0) return -1;
+  g_loci = loci; g_n_loci = nl; g_on_locus = merge_on_locus; g_locus_ud = &c;
+  orc_bounds *tmp = (orc_bounds *)malloc((size_t)(n + 1) * sizeof(orc_bounds));
+  int64_t nb = call_bounds_impl(treads, n, 0, window, min_support, min_clip, min_clip_total, max_clip_dist, tmp, n + 1, NULL, 0, NULL, NULL, NULL);
+  g_loci = NULL; g_n_loci = 0; g_on_locus = NULL; g_locus_ud = NULL;
+  for (int64_t i = 0; i < nb; i++) {
+    char row[768];
+    orc_bounds_row(row, sizeof row, &tmp[i], target_names[tmp[i].tid]);
+    sb_add(&sb, row);
+  }
+  free(tmp); free(loci);
+  *need = sb.n;
+  return 0;
 }

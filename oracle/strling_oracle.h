@@ -133,6 +133,9 @@ typedef struct {
 void orc_bounds_of(const orc_tread *reads, int64_t n, uint32_t cl_left_most, uint32_t cl_right_most,
                    uint16_t max_clip_dist, orc_bounds *b);
 
+/* a locus read from a file: Bounds with its name column (cluster.nim:75-87) */
+typedef struct { orc_bounds b; char name[128]; } orc_locus;
+
 /* One emitted cluster: [first, first+n) indexes into the *sorted group array* handed to the callback. */
 typedef void (*orc_cluster_cb)(void *ud, const orc_tread *reads, int64_t n, uint32_t left_most, uint32_t right_most);
 /* cluster.nim:323-374 (cluster -> trcluster -> split_cluster) on one (tid, repeat) group sorted by position */
@@ -186,11 +189,20 @@ void   orc_genotype(const orc_bounds *b, const orc_tread *tandems, int64_t nt, c
                     const orc_support *spanners, int64_t ns, int min_support, uint16_t min_clip, uint16_t min_clip_total,
                     int median_fragment_length, double depth, orc_gt *c);                           /* genotyper.nim:150-199 */
 int    orc_call_row(char *buf, int cap, const orc_gt *c, const char *chrom);                        /* genotyper.nim:56-57 */
-/* call.nim:111-285 without -l/-b: the three output files as text (returns 0; bn/gn/un receive the bytes needed) */
+/* call.nim:111-285 the three output files as text (returns 0; bn/gn/un receive the bytes needed) */
 int    orc_call(const orc_tread *treads, int64_t n, const uint64_t *tq_off, const char *tqnames, const orc_records *r, const int32_t *isize,
                 const uint32_t frag[4096], const char *const *target_names, int min_support, uint16_t min_clip, uint16_t min_clip_total,
                 uint8_t min_mapq, char *bounds_buf, int64_t bcap, char *gt_buf, int64_t gcap, char *unpl_buf, int64_t ucap,
-                int64_t *bn, int64_t *gn, int64_t *un);
+                int64_t *bn, int64_t *gn, int64_t *un, const char *loci_text /* -l, or NULL */, const char *bounds_text /* -b, or NULL */,
+                const uint32_t *target_lengths, int n_targets);
+/* cluster.nim:111-169 (-1 where the reference quits) and the merge of -b bounds with -l loci, call.nim:160-183 */
+int64_t orc_parse_bed(const char *text, const char *const *names, const uint32_t *lengths, int n_targets, uint32_t window, orc_locus *out, int64_t cap);
+int64_t orc_parse_bounds(const char *text, const char *const *names, int n_targets, orc_locus *out, int64_t cap);
+int64_t orc_merge_loci_bounds(orc_locus *bounds, int64_t nb, orc_locus *loci, int64_t nl, orc_locus *out);
+/* merge.nim:154-187 as the text of -bounds.txt, with optional -l loci */
+int    orc_merge_text(const orc_tread *treads, int64_t n, uint32_t window, int min_support, uint16_t min_clip, uint16_t min_clip_total,
+                      uint16_t max_clip_dist, const char *loci_text, const char *const *target_names, const uint32_t *target_lengths, int n_targets,
+                      char *buf, int64_t cap, int64_t *need);
 
 /* reads (indices into treads) of every bound orc_call_bounds(mode 1) returns, in cluster order; member_off is [nb + 1] */
 int64_t orc_call_members(const orc_tread *treads, int64_t n, uint32_t window, int min_support, uint16_t min_clip, uint16_t min_clip_total,

@@ -85,6 +85,9 @@ class CallOpts(C.Structure):
     _fields_ = [("median_fragment_length", C.c_int32), ("min_support", C.c_int32), ("min_clip", C.c_uint16), ("min_clip_total", C.c_uint16)]
 
 
+LOCUS_DTYPE = np.dtype([("b", BOUNDS_DTYPE), ("name", "S128")], align=True)
+assert LOCUS_DTYPE.itemsize == 168, LOCUS_DTYPE.itemsize
+SOFT_TAKEN = 255
 MEM_HOST, MEM_DEVICE = 0, 1
 MODE_MERGE, MODE_CALL = 0, 1
 
@@ -94,7 +97,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_ctx_enable_timing", "strl_ctx_kernel_times", "strl_pair_reads", "strl_pairer_create", "strl_pairer_destroy", "strl_pairer_add",
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
-           "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat"]
+           "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci"]
 
 
 def lib_path():
@@ -152,6 +155,7 @@ def load(build_if_missing=True):
     L.strl_call_row.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_char_p]
     L.strl_canonical_repeat.argtypes = [C.c_char_p, C.c_char_p]
     L.strl_canonical_repeat.restype = None
+    L.strl_assign_reads_loci.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
     _LIB = L
     return L
 
@@ -405,6 +409,18 @@ def _noop():
 def frag_median(frag, pct=0.5):
     frag = np.ascontiguousarray(frag, np.uint32)
     return load().strl_frag_median(frag.ctypes.data, pct)
+
+
+def assign_reads_loci(treads, loci, mode):
+    """assign_reads_locus (callclusters.nim:14-50) for every locus in order.  Returns (treads with taken ones marked,
+    loci with recounted reads, [index arrays of the reads each locus received])."""
+    L = load()
+    t = np.ascontiguousarray(treads, TREAD_DTYPE).copy()
+    lo = np.ascontiguousarray(loci, LOCUS_DTYPE).copy()
+    off = np.zeros(lo.size + 1, np.uint64)
+    idx = np.zeros(max(1, t.size), np.uint32)
+    _check(L.strl_assign_reads_loci(t.ctypes.data, t.size, mode, lo.ctypes.data, lo.size, off.ctypes.data, idx.ctypes.data, idx.size))
+    return t, lo, [idx[int(off[j]):int(off[j + 1])].copy() for j in range(lo.size)]
 
 
 def spanners(rec: RecordBatch, bound, window, frag, min_mapq=20):

@@ -374,6 +374,57 @@ int strl_unplaced_order(const strl_unplaced *unplaced, uint64_t n, uint64_t *ord
   return STRL_OK;
 }
 
+// assign_reads_locus (callclusters.nim:14-50) for every locus in order
+int strl_assign_reads_loci(strl_tread *treads, uint64_t n, int mode, strl_locus *loci, uint64_t n_loci, uint64_t *assigned_off,
+                           uint32_t *assigned, uint64_t cap) {
+  if ((n && !treads) || (n_loci && (!loci || !assigned_off))) { set_error("null argument"); return STRL_ERR_ARG; }
+  struct Key { int32_t tid; char rep[6]; bool operator==(const Key &o) const { return tid == o.tid && memcmp(rep, o.rep, 6) == 0; } };
+  struct KeyHash { size_t operator()(const Key &k) const { return (size_t)nim::hash_tid_rep(k.tid, k.rep); } };
+  std::unordered_map<Key, std::vector<uint32_t>, KeyHash> groups;                 // Table[tid_rep, seq[tread]], each sorted by position
+  for (uint64_t i = 0; i < n; ++i) {
+    if (treads[i].split == STRL_SOFT_TAKEN) continue;
+    if (mode == STRL_MODE_MERGE && treads[i].tid < 0) continue;
+    Key k{treads[i].tid, {0}};
+    memcpy(k.rep, treads[i].repeat, 6);
+    groups[k].push_back((uint32_t)i);
+  }
+  for (auto &g : groups)
+    std::stable_sort(g.second.begin(), g.second.end(), [&](uint32_t a, uint32_t b) { return treads[a].position < treads[b].position; });
+  uint64_t tot = 0;
+  for (uint64_t j = 0; j < n_loci; ++j) {
+    strl_bounds &L = loci[j].b;
+    assigned_off[j] = tot;
+    Key k{L.tid, {0}};
+    memcpy(k.rep, L.repeat, strnlen(L.repeat, 6));
+    L.n_total = 0; L.n_left = 0; L.n_right = 0;
+    auto it = groups.find(k);
+    if (it == groups.end() || it->second.empty()) continue;
+    std::vector<uint32_t> &trs = it->second;
+    const uint32_t left_most = L.left_most == 0 ? 0u : L.left_most - 1u;
+    size_t li = 0, ri = 0;
+    while (li < trs.size() && treads[trs[li]].position < left_most) ++li;          // lowerBound
+    while (ri < trs.size() && treads[trs[ri]].position <= L.right_most) ++ri;      // upperBound
+    if (ri < li) ri = li;
+    for (size_t q = li; q < ri; ++q) {
+      const strl_tread &t = treads[trs[q]];
+      ++L.n_total;
+      if (t.split == STRL_SOFT_RIGHT) ++L.n_right;
+      else if (t.split == STRL_SOFT_LEFT) ++L.n_left;
+      if (assigned && tot < cap) assigned[tot] = trs[q];
+      ++tot;
+    }
+    // table[key] = trs[0..<li] & (if ri < trs.high: trs[ri+1..high]) -- trs[ri] is dropped with the assigned ones
+    const size_t drop_end = std::min(trs.size(), ri + 1);
+    if (ri > li || ri < trs.size()) {
+      for (size_t q = li; q < drop_end; ++q) treads[trs[q]].split = STRL_SOFT_TAKEN;
+      trs.erase(trs.begin() + (long)li, trs.begin() + (long)drop_end);
+    }
+  }
+  if (n_loci) assigned_off[n_loci] = tot;
+  if (assigned && tot > cap) { set_error("assigned capacity %llu too small, need %llu", (unsigned long long)cap, (unsigned long long)tot); return STRL_ERR_CAPACITY; }
+  return STRL_OK;
+}
+
 // genotyper.nim:54-57
 int strl_call_row(char *buf, int cap, const strl_call *c, const char *chrom) {
   const std::string d = nim_float(c->depth);

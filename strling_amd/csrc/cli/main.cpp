@@ -352,6 +352,86 @@ static int extract_main(int argc, char **argv) {
   return 0;
 }
 
+// ---- loci given on the command line: cluster.nim:96-169, call.nim:160-183 --------------------------------------------------------
+static int get_tid(const std::string &name, const std::vector<BamTarget> &targets) {      // utils.nim:214-218
+  for (size_t t = 0; t < targets.size(); ++t) if (targets[t].name == name) return (int)t;
+  return -1;
+}
+static void check_unit(const std::string &rep, const std::string &line) {
+  for (char x : rep) if (!strchr("ATCG", x)) quit("Error reading loci bed file. Expected DNA (ATCG only) in the 4th field, and got an unexpected character on line: %s", line.c_str());
+}
+static std::vector<std::string> read_lines(const std::string &path) {
+  std::vector<std::string> out;
+  FILE *f = fopen(path.c_str(), "r");
+  if (!f) return out;
+  std::string cur;
+  int ch;
+  while ((ch = fgetc(f)) != EOF) { if (ch == '\n') { if (!cur.empty() && cur.back() == '\r') cur.pop_back(); out.push_back(cur); cur.clear(); } else cur.push_back((char)ch); }
+  if (!cur.empty()) out.push_back(cur);
+  fclose(f);
+  return out;
+}
+static strl_locus make_locus(const std::vector<std::string> &f, const std::vector<BamTarget> &targets, const std::string &line) {
+  strl_locus L;
+  memset(&L, 0, sizeof L);
+  L.b.tid = get_tid(f[0], targets);
+  if (L.b.tid < 0) quit("[strling] chromosome %s of a locus is not in the bam header: %s", f[0].c_str(), line.c_str());
+  L.b.left = (uint32_t)atoll(f[1].c_str());
+  L.b.right = (uint32_t)atoll(f[2].c_str());
+  if (f[3].size() > 6) quit("ERROR: STRling currently only supports 1-6 bp repeat units. Input bed contains repeat unit length %zu\n%s", f[3].size(), line.c_str());
+  memcpy(L.b.repeat, f[3].data(), f[3].size());
+  check_unit(f[3], line);
+  return L;
+}
+// parse_bed, cluster.nim:111-141
+static std::vector<strl_locus> parse_bed(const std::string &path, const std::vector<BamTarget> &targets, uint32_t window) {
+  std::vector<strl_locus> out;
+  for (const std::string &line : read_lines(path)) {
+    std::vector<std::string> f;
+    for (size_t i = 0; i < line.size();) {
+      while (i < line.size() && isspace((unsigned char)line[i])) ++i;
+      size_t j = i;
+      while (j < line.size() && !isspace((unsigned char)line[j])) ++j;
+      if (j > i) f.push_back(line.substr(i, j - i));
+      i = j;
+    }
+    if (f.size() != 4 && f.size() != 5) quit("Error reading loci bed file. Expected 4 or 5 fields and got %zu on line: %s", f.size(), line.c_str());
+    strl_locus L = make_locus(f, targets, line);
+    if (f.size() == 5) snprintf(L.name, sizeof L.name, "%s", f[4].c_str());
+    L.b.left_most = (uint32_t)std::max<int32_t>((int32_t)L.b.left - (int32_t)window, 0);
+    L.b.right_most = std::min<uint32_t>(L.b.right + window, targets[(size_t)L.b.tid].length);
+    if (!(L.b.left <= L.b.right) || !(L.b.left_most <= L.b.right_most)) quit("[strling] inverted locus (doAssert cluster.nim:133-134): %s", line.c_str());
+    out.push_back(L);
+  }
+  return out;
+}
+// parse_bounds, cluster.nim:143-169
+static std::vector<strl_locus> parse_bounds(const std::string &path, const std::vector<BamTarget> &targets) {
+  std::vector<strl_locus> out;
+  for (const std::string &line : read_lines(path)) {
+    if (!line.empty() && line[0] == '#') continue;
+    std::vector<std::string> f;
+    size_t i = 0;
+    for (;;) { const size_t j = line.find('\t', i); f.push_back(line.substr(i, j == std::string::npos ? std::string::npos : j - i)); if (j == std::string::npos) break; i = j + 1; }
+    if (f.size() != 11) quit("Error reading loci bed file. Expected 11 fields and got %zu on line: %s", f.size(), line.c_str());
+    strl_locus L = make_locus(f, targets, line);
+    snprintf(L.name, sizeof L.name, "%s", f[4].c_str());
+    L.b.left_most = (uint32_t)atoll(f[5].c_str()); L.b.right_most = (uint32_t)atoll(f[6].c_str()); L.b.center_mass = (uint32_t)atoll(f[7].c_str());
+    L.b.n_left = (uint16_t)atoll(f[8].c_str()); L.b.n_right = (uint16_t)atoll(f[9].c_str()); L.b.n_total = (uint16_t)atoll(f[10].c_str());
+    if (!(L.b.left <= L.b.right) || !(L.b.left_most <= L.b.right_most)) quit("[strling] inverted bounds (doAssert cluster.nim:162-163): %s", line.c_str());
+    out.push_back(L);
+  }
+  return out;
+}
+static bool loci_overlap(const strl_bounds &a, const strl_bounds &b) {                 // cluster.nim:96-100
+  return a.tid == b.tid && strncmp(a.repeat, b.repeat, 7) == 0 && std::max(a.left, b.left) <= std::min(a.right, b.right);
+}
+static int locus_row(char *buf, int cap, const strl_locus &L, const char *chrom) {     // cluster.nim:262-266 with a name
+  const strl_bounds &b = L.b;
+  return snprintf(buf, (size_t)cap, "%s\t%u\t%u\t%s\t%s\t%u\t%u\t%u\t%u\t%u\t%u", chrom, b.left, b.right, b.repeat, L.name, b.left_most, b.right_most,
+                  b.center_mass, (unsigned)b.n_left, (unsigned)b.n_right, (unsigned)b.n_total);
+}
+
 static int merge_main(int argc, char **argv) {
   const char *usage =
       "strling merge\n\nUsage:\n  strling merge [options] [bin ...]\n\nOptions:\n  -w, --window=WINDOW        Number of bp within which to search for reads supporting the other side of a bound. "
@@ -365,7 +445,7 @@ static int merge_main(int argc, char **argv) {
   const Args a = parse(argc, argv, 2, {{"fasta", 'f', true}, {"window", 'w', true}, {"min-support", 'm', true}, {"chromosome", 'C', true},
                                        {"min-clip", 'c', true}, {"min-clip-total", 't', true}, {"min-mapq", 'q', true}, {"bed", 'l', true},
                                        {"output-prefix", 'o', true}, {"diff-refs", 'd', false}, {"verbose", 'v', false}}, usage);
-  if (a.flag("bed")) quit("[strling] -l/--bed is not supported by this build");
+  if (a.flag("bed") && !file_exists(a.get("bed", ""))) quit("couldn't open bed file");     // merge.nim:80-82
   if (a.flag("chromosome")) quit("[strling] --chromosome is not supported by this build");
   int window = atoi(a.get("window", "-1").c_str());
   const int min_support = atoi(a.get("min-support", "5").c_str());
@@ -417,6 +497,13 @@ static int merge_main(int argc, char **argv) {
   if (window < 0) window = strl_frag_median(frag, 0.98);                           // merge.nim:151-152
   const uint16_t max_clip_dist = (uint16_t)(0.5 * (double)strl_frag_median(frag, 0.5));   // merge.nim:181
 
+  // -l BED: those loci take their reads first (merge.nim:154-167)
+  std::vector<strl_locus> loci;
+  if (a.flag("bed")) {
+    loci = parse_bed(a.get("bed", ""), targets, (uint32_t)window);
+    std::vector<uint64_t> aoff(loci.size() + 1);
+    CHECK(strl_assign_reads_loci(all.data(), all.size(), STRL_MODE_MERGE, loci.data(), loci.size(), aoff.data(), nullptr, 0));
+  }
   strl_ctx *ctx = nullptr;
   CHECK(strl_ctx_create(0, &ctx));
   std::vector<strl_bounds> bounds(std::max<size_t>(all.size(), 16));
@@ -428,6 +515,11 @@ static int merge_main(int argc, char **argv) {
   if (!fo) quit("couldn't open output file");
   fputs("#chrom\tleft\tright\trepeat\tname\tleft_most\tright_most\tcenter_mass\tn_left\tn_right\tn_total\n", fo);   // cluster.nim:89
   char row[1024];
+  for (const strl_locus &L : loci) {                                                 // merge.nim:165-167: reported as they are
+    locus_row(row, sizeof row, L, targets[(size_t)L.b.tid].name.c_str());
+    fputs(row, fo);
+    fputc('\n', fo);
+  }
   for (uint64_t k = 0; k < nb; ++k) {
     const strl_bounds &b = bounds[(size_t)k];
     strl_bounds_row(row, sizeof row, &b, targets[(size_t)b.tid].name.c_str());
@@ -440,7 +532,7 @@ static int merge_main(int argc, char **argv) {
   return 0;
 }
 
-// call.nim:51-285.  -l/--loci and -b/--bounds (assign_reads_locus, callclusters.nim:14-50) are not in this build.
+// call.nim:51-285
 static int call_main(int argc, char **argv) {
   const char *usage =
       "strling call\n\nUsage:\n  strling call [options] bam bin\n\nArguments:\n  bam              path to bam file\n"
@@ -449,15 +541,16 @@ static int call_main(int argc, char **argv) {
       "  -c, --min-clip=MIN_CLIP    minimum number of supporting clipped reads for each side of a locus (default: 0)\n"
       "  -t, --min-clip-total=MIN_CLIP_TOTAL\n                             minimum total number of supporting clipped reads for a locus (default: 0)\n"
       "  -q, --min-mapq=MIN_MAPQ    minimum mapping quality (does not apply to STR reads) (default: 40)\n"
-      "  -l, --loci=LOCI            (not in this build) annotated bed file specifying additional STR loci to genotype\n"
-      "  -b, --bounds=BOUNDS        (not in this build) STRling -bounds.txt file specifying additional STR loci to genotype\n"
+      "  -l, --loci=LOCI            Annoated bed file specifying additional STR loci to genotype. Format is: chr start stop repeatunit [name]\n"
+      "  -b, --bounds=BOUNDS        STRling -bounds.txt file (usually produced by strling merge) specifying additional STR loci to genotype.\n"
       "  -o, --output-prefix=OUTPUT_PREFIX\n                             prefix for output files (default: strling)\n  -v, --verbose\n  -h, --help                 Show this help\n";
   if (argc <= 2) { fputs(usage, stdout); return 0; }
   const Args a = parse(argc, argv, 2, {{"fasta", 'f', true}, {"min-support", 'm', true}, {"min-clip", 'c', true}, {"min-clip-total", 't', true},
                                        {"min-mapq", 'q', true}, {"loci", 'l', true}, {"bounds", 'b', true}, {"output-prefix", 'o', true},
                                        {"verbose", 'v', false}}, usage);
   if (a.pos.size() != 2) quit("expected 2 arguments (bam, bin)\n%s", usage);
-  if (a.flag("loci") || a.flag("bounds")) quit("[strling] -l/--loci and -b/--bounds are not supported by this build (DESIGN.md section 9)");
+  if (a.flag("loci") && !file_exists(a.get("loci", ""))) quit("couldn't open loci file");          // call.nim:81-87
+  if (a.flag("bounds") && !file_exists(a.get("bounds", ""))) quit("couldn't open bounds file");
   const std::string bam = a.pos[0], bin = a.pos[1], prefix = a.get("output-prefix", "strling");
   const int min_support = atoi(a.get("min-support", "5").c_str());
   const uint16_t min_clip = (uint16_t)atoi(a.get("min-clip", "0").c_str());
@@ -499,11 +592,68 @@ static int call_main(int argc, char **argv) {
   fputs("#chrom\tleft\tright\trepeatunit\tallele1_est\tallele2_est\tanchored_reads\tspanning_reads\tspanning_pairs\texpected_spanning_pairs\t"
         "spanning_pairs_pctl\tleft_clips\tright_clips\tunplaced_pairs\tdepth\tsum_str_counts\n", gt_fh);                          // genotyper.nim:54
 
+  // evidence + genotype of one bound (call.nim:196-218 / :237-255): indexed region read, spanners(), genotype(), one row
+  std::vector<strl_call> calls;
+  std::vector<strl_support> sup;
+  RecordBatch region;
+  char row[2048];
+  auto evidence = [&](const strl_bounds &b, const char *name, const strl_tread *reads, uint64_t n_reads) {
+    region.clear();
+    const int64_t wl = (int64_t)b.left - window, wr = (int64_t)b.right + window;
+    if (rd.read_region(region, b.tid, std::max<int64_t>(0, wl), wr, err) < 0) quit("[strling] error reading %s: %s", bam.c_str(), err.c_str());
+    const strl_records rv = region.view();
+    sup.resize(2 * region.size() + 16);
+    strl_span_summary sm{};
+    CHECK(strl_spanners(&rv, region.isize.data(), &b, window, frag, min_mapq, sup.data(), sup.size(), &sm));
+    if (sm.n_support > 5000) return;                                                // spans.len > 5_000
+    if (sm.median_depth == -1) return;
+    strl_call c{};
+    CHECK(strl_genotype(&b, reads, n_reads, qoff.data(), qnames.data(), sup.data(), sm.n_support, &copts, (double)sm.median_depth, &c));
+    c.expected_spanning_fragments = sm.expected_spanners;
+    calls.push_back(c);
+    strl_locus L{};
+    L.b = b;
+    if (name) snprintf(L.name, sizeof L.name, "%s", name);
+    locus_row(row, sizeof row, L, rd.targets()[(size_t)b.tid].name.c_str());
+    fprintf(bounds_fh, "%s\t%d\n", row, sm.median_depth);
+  };
+  const uint64_t nt = (uint64_t)info.n_reads;
+  std::vector<strl_tread> cl;
+  const std::vector<strl_tread> taken_copy = treads;   // assigned reads are genotyped with the split they came with
+
+  // loci handed in with -l / -b are genotyped first and take their reads out of the table (call.nim:150-218)
+  {
+    std::vector<strl_locus> loci, given;
+    if (a.flag("loci")) { loci = parse_bed(a.get("loci", ""), rd.targets(), (uint32_t)window); fprintf(stderr, "Read %zu loci from %s\n", loci.size(), a.get("loci", "").c_str()); }
+    if (a.flag("bounds")) { given = parse_bounds(a.get("bounds", ""), rd.targets()); fprintf(stderr, "Read %zu bounds from %s\n", given.size(), a.get("bounds", "").c_str()); }
+    for (strl_locus &bound : given)                                                  // loci overwrite the bound they overlap (:160-169)
+      for (size_t i = 0; i < loci.size(); ++i)
+        if (loci_overlap(loci[i].b, bound.b)) {
+          memcpy(bound.name, loci[i].name, sizeof bound.name);
+          bound.b.left = loci[i].b.left; bound.b.right = loci[i].b.right;
+          loci[i] = loci.back(); loci.pop_back();                                    // seq.del: the last element fills the hole
+          break;
+        }
+    for (const strl_locus &l : loci) given.push_back(l);
+    if (!given.empty()) {
+      std::vector<uint64_t> aoff(given.size() + 1);
+      std::vector<uint32_t> assigned((size_t)std::max<uint64_t>(nt, 1));
+      CHECK(strl_assign_reads_loci(treads.data(), nt, STRL_MODE_CALL, given.data(), given.size(), aoff.data(), assigned.data(), assigned.size()));
+      // the reads keep the split they had: strl_assign_reads_loci only re-marks its own copies in `treads`
+      for (size_t j = 0; j < given.size(); ++j) {
+        const strl_locus &L = given[j];
+        if (L.b.right - L.b.left > 1000u) { fprintf(stderr, "large bounds: %s:%u-%u skipping\n", rd.targets()[(size_t)L.b.tid].name.c_str(), L.b.left, L.b.right); continue; }
+        cl.clear();
+        for (uint64_t k = aoff[j]; k < aoff[j + 1]; ++k) cl.push_back(taken_copy[assigned[(size_t)k]]);
+        evidence(L.b, L.name, cl.data(), cl.size());
+      }
+    }
+  }
+
   // discovery: group, sort, cluster, bounds on the device (call.nim:118-130,221-235)
   strl_ctx *ctx = nullptr;
   CHECK(strl_ctx_create(0, &ctx));
   const uint16_t max_clip_dist = (uint16_t)(0.5 * (double)frag_median);             // call.nim:232
-  const uint64_t nt = (uint64_t)info.n_reads;
   std::vector<strl_bounds> bounds(std::max<size_t>((size_t)nt, 16));
   std::vector<strl_unplaced> unplaced(std::max<size_t>((size_t)nt, 16));
   uint64_t nb = 0, nu = 0;
@@ -514,32 +664,10 @@ static int call_main(int argc, char **argv) {
   CHECK(strl_cluster_members(ctx, moff.data(), nullptr, 0, &nm));
   std::vector<uint32_t> members((size_t)std::max<uint64_t>(nm, 1));
   CHECK(strl_cluster_members(ctx, moff.data(), members.data(), members.size(), &nm));
-
-  // evidence + genotype per bound (call.nim:237-255): indexed region read, spanners(), genotype()
-  std::vector<strl_call> calls;
-  std::vector<strl_support> sup;
-  std::vector<strl_tread> cl;
-  RecordBatch region;
-  char row[2048];
   for (uint64_t j = 0; j < nb; ++j) {
-    const strl_bounds &b = bounds[(size_t)j];
-    region.clear();
-    const int64_t wl = (int64_t)b.left - window, wr = (int64_t)b.right + window;
-    if (rd.read_region(region, b.tid, std::max<int64_t>(0, wl), wr, err) < 0) quit("[strling] error reading %s: %s", bam.c_str(), err.c_str());
-    const strl_records rv = region.view();
-    sup.resize(2 * region.size() + 16);
-    strl_span_summary sm{};
-    CHECK(strl_spanners(&rv, region.isize.data(), &b, window, frag, min_mapq, sup.data(), sup.size(), &sm));
-    if (sm.n_support > 5000) continue;                                              // call.nim:239-242
-    if (sm.median_depth == -1) continue;                                            // :243-244
     cl.clear();
     for (uint64_t k = moff[(size_t)j]; k < moff[(size_t)j + 1]; ++k) cl.push_back(treads[members[(size_t)k]]);
-    strl_call c{};
-    CHECK(strl_genotype(&b, cl.data(), cl.size(), qoff.data(), qnames.data(), sup.data(), sm.n_support, &copts, (double)sm.median_depth, &c));
-    c.expected_spanning_fragments = sm.expected_spanners;                           // :247
-    calls.push_back(c);
-    strl_bounds_row(row, sizeof row, &b, rd.targets()[(size_t)b.tid].name.c_str());
-    fprintf(bounds_fh, "%s\t%d\n", row, sm.median_depth);                           // :255
+    evidence(bounds[(size_t)j], nullptr, cl.data(), cl.size());
   }
   std::vector<uint64_t> order(std::max<size_t>(calls.size(), 1)), uorder(std::max<size_t>((size_t)nu, 1));
   CHECK(strl_calls_finish(calls.data(), calls.size(), unplaced.data(), nu, order.data()));   // :264-278

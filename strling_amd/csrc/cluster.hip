@@ -424,27 +424,34 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
   std::vector<uint8_t> h_split;
   std::vector<uint64_t> h_key;
   std::vector<uint32_t> kept;
+  std::vector<std::pair<uint64_t, uint32_t>> ghosts;   // (group key, index) of treads that only hold their group's place
+  bool any_skipped = mode == STRL_MODE_MERGE;
   h_pos.reserve(n_in); h_sample.reserve(n_in); h_split.reserve(n_in); h_key.reserve(n_in);
   for (uint64_t i = 0; i < n_in; ++i) {
     const strl_tread &t = treads[i];
     if (mode == STRL_MODE_MERGE && t.tid < 0) continue;           // unpack_file(drop_unplaced=true), merge.nim:101
     if (t.tid < -1) { set_error("tread %llu: tid %d", (unsigned long long)i, t.tid); return STRL_ERR_ARG; }
+    const bool ghost = t.split == STRL_SOFT_TAKEN;   // given to a -l/-b locus: still a key of the table, no longer a read
+    any_skipped |= ghost;
     bool ok = true;
     uint32_t len = 0, code = 0;
     while (len < 6 && t.repeat[len]) { code = (code << 2) | base_code(t.repeat[len], ok); ++len; }
     for (uint32_t j = len; j < 6; ++j) if (t.repeat[j]) ok = false;
     if (!ok) { set_error("tread %llu: repeat unit is not a NUL-padded ACGT string", (unsigned long long)i); return STRL_ERR_ARG; }
-    h_key.push_back(((uint64_t)(uint32_t)(t.tid + 1) << 15) | ((uint64_t)len << 12) | code);
+    const uint64_t gkey = ((uint64_t)(uint32_t)(t.tid + 1) << 15) | ((uint64_t)len << 12) | code;
+    if (ghost) { ghosts.push_back({gkey, (uint32_t)i}); continue; }
+    h_key.push_back(gkey);
     h_pos.push_back(t.position);
     h_split.push_back(t.split);
     h_sample.push_back((uint32_t)t.qname_id);
-    if (mode == STRL_MODE_MERGE) kept.push_back((uint32_t)i);
+    kept.push_back((uint32_t)i);
   }
+  if (!any_skipped) kept.clear();                     // identity
   const uint64_t n64 = h_pos.size();
   if (n64 > 0x7ffffff0ull) { set_error("too many treads"); return STRL_ERR_ARG; }
   const uint32_t n = (uint32_t)n64;
   if (stats) stats->n_treads = n;
-  if (n == 0) return STRL_OK;
+  if (n == 0) return STRL_OK;                        // (only ghosts left: nothing to cluster, nothing to report)
 
   // ---- upload, then one device pass ------------------------------------------------------------------
   strl::DevBuf *B = c->c_buf;
@@ -488,20 +495,33 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
   }
 
   // ---- host: reference row order = Nim Table slot order of the groups (insertion = first appearance) ----
-  std::vector<uint32_t> by_first(n_groups);
-  for (uint32_t g = 0; g < n_groups; ++g) by_first[g] = g;
-  std::sort(by_first.begin(), by_first.end(), [&](uint32_t a, uint32_t b) { return g_first[a] < g_first[b]; });
+  // Table keys in insertion order = first appearance in the caller's array, counting the place-holding treads too
+  struct KeyEnt { uint64_t key; uint32_t first; int32_t g; };
+  std::vector<KeyEnt> ents;
+  ents.reserve(n_groups + ghosts.size());
+  for (uint32_t g = 0; g < n_groups; ++g) ents.push_back(KeyEnt{g_keys[g], R.kept.empty() ? g_first[g] : R.kept[g_first[g]], (int32_t)g});
+  if (!ghosts.empty()) {
+    std::sort(ghosts.begin(), ghosts.end());
+    std::vector<KeyEnt> real = ents;
+    std::sort(real.begin(), real.end(), [](const KeyEnt &a, const KeyEnt &b) { return a.key < b.key; });
+    for (size_t q = 0; q < ghosts.size(); ++q) {
+      if (q && ghosts[q].first == ghosts[q - 1].first) continue;       // first (smallest index) ghost of each key
+      auto it = std::lower_bound(real.begin(), real.end(), ghosts[q].first, [](const KeyEnt &a, uint64_t k) { return a.key < k; });
+      if (it != real.end() && it->key == ghosts[q].first) { KeyEnt &e = ents[(size_t)it->g]; e.first = std::min(e.first, ghosts[q].second); }
+      else ents.push_back(KeyEnt{ghosts[q].first, ghosts[q].second, -1});
+    }
+  }
+  std::sort(ents.begin(), ents.end(), [](const KeyEnt &a, const KeyEnt &b) { return a.first < b.first; });
   auto key_unit = [](uint64_t key, char rep[7]) {
     const uint32_t len = (uint32_t)(key >> 12) & 7u, code = (uint32_t)key & 0xfffu;
     memset(rep, 0, 7);
     for (uint32_t j = 0; j < len; ++j) rep[j] = "CATG"[(code >> (2 * (len - 1 - j))) & 3u];
   };
-  std::vector<uint64_t> hcodes(n_groups);
-  for (uint32_t q = 0; q < n_groups; ++q) {
-    const uint64_t key = g_keys[by_first[q]];
+  std::vector<uint64_t> hcodes(ents.size());
+  for (size_t q = 0; q < ents.size(); ++q) {
     char rep[7];
-    key_unit(key, rep);
-    hcodes[q] = nim::hash_tid_rep((int32_t)(key >> 15) - 1, rep);
+    key_unit(ents[q].key, rep);
+    hcodes[q] = nim::hash_tid_rep((int32_t)(ents[q].key >> 15) - 1, rep);
   }
   const std::vector<int64_t> order = nim::table_slot_order(hcodes, 8192);           // newTable(8192): call.nim:118, merge.nim:92
   // clusters are in sorted order => grouped; index them per group
@@ -516,7 +536,8 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
   }
   uint64_t no = 0, nu = 0;
   for (int64_t q : order) {
-    const uint32_t g = by_first[(size_t)q];
+    if (ents[(size_t)q].g < 0) continue;                                              // every read of the group went to a locus
+    const uint32_t g = (uint32_t)ents[(size_t)q].g;
     const uint64_t key = g_keys[g];
     const int32_t tid = (int32_t)(key >> 15) - 1;
     char rep[7];

@@ -157,3 +157,112 @@ def test_call_requires_index_and_matching_bin(oracle, tmp_path):
     os.remove(bam + ".bai")
     r = _run(["call", "-o", str(tmp_path / "x"), bam, binp])
     assert r.returncode == 1 and "couldn't open bam" in r.stderr
+
+
+def _loci_from_bounds(rows, targets, rng, extra=()):
+    """a BED of loci: some overlap existing bounds (same unit), some sit elsewhere, one is wider than 1000 bp"""
+    out = []
+    for k, r in enumerate(rows):
+        f = r.split("\t")
+        if k % 2 == 0:
+            out.append(f"{f[0]}\t{max(0, int(f[1]) - 3)}\t{int(f[2]) + 5}\t{f[3]}\tlocus{k}")
+        elif k % 3 == 0:
+            out.append(f"{f[0]} {int(f[1]) + 2000} {int(f[1]) + 2040} {f[3]}")
+    out.append(f"{targets[0][0]}\t100\t1500\tAC\twide")
+    out.append(f"{targets[-1][0]}\t5000\t5030\tAAAAAG")
+    out.extend(extra)
+    return "\n".join(out) + "\n"
+
+
+def test_assign_reads_loci_matches_oracle(oracle):
+    """callclusters.nim:14-50 incl. the read lost behind every assigned range; loci rows of merge.nim:165-167"""
+    t = synth.synth_treads(n_samples=3, n_loci=300, seed=4, n_contigs=4, contig_len=400_000)
+    targets = [(f"chr{i + 1}", 400_000) for i in range(4)]
+    ot = np.zeros(len(t), oracle.TREAD_DTYPE)
+    for f in t.dtype.names:
+        ot[f] = t[f]
+    base = oracle.merge_text(ot, 560, targets, min_support=3, max_clip_dist=175).splitlines()[1:]
+    assert len(base) > 20
+    rng = np.random.default_rng(0)
+    bed = _loci_from_bounds(base, targets, rng, extra=[base[0].split("\t")[0] + "\t0\t399999\t" + base[0].split("\t")[3] + "\teverything"])
+    exp = oracle.merge_text(ot, 560, targets, min_support=3, max_clip_dist=175, loci_text=bed).splitlines()[1:]
+    loci = oracle.parse_bed(bed, targets, 560)
+    lo = np.zeros(len(loci), api.LOCUS_DTYPE)
+    for j, L in enumerate(loci):
+        for f in api.BOUNDS_DTYPE.names:
+            lo["b"][f][j] = getattr(L.b, f)
+        lo["name"][j] = L.name
+    t2, lo2, taken = api.assign_reads_loci(t, lo, api.MODE_MERGE)
+    rows = []
+    for j in range(len(lo2)):
+        b = lo2["b"][j]
+        rows.append("\t".join([targets[int(b["tid"])][0], str(int(b["left"])), str(int(b["right"])), b["repeat"].decode(), lo2["name"][j].decode(),
+                               str(int(b["left_most"])), str(int(b["right_most"])), str(int(b["center_mass"])), str(int(b["n_left"])),
+                               str(int(b["n_right"])), str(int(b["n_total"]))]))
+    assert rows == exp[:len(rows)]
+    assert sum(len(x) for x in taken) > 50
+    n_marked = int((t2["split"] == api.SOFT_TAKEN).sum())
+    assert n_marked >= sum(len(x) for x in taken)        # assigned + the ones lost behind each range
+
+
+@pytest.mark.gpu
+def test_merge_with_loci_matches_oracle(oracle, tmp_path):
+    """strling merge -l BED: locus rows first, then the clusters of what is left, in the reference's table order"""
+    bins, all_t = [], []
+    targets = None
+    for s_i in range(3):
+        rec, g = synth.synth_wgs(5000, seed=200 + s_i, n_contigs=3, contig_len=300_000, str_frac=0.05)
+        targets = rec.targets
+        frag = synth.frag_hist(rec)
+        t = oracle.extract(rec, g, oracle.make_opts(oracle.median(frag), 0.8, 40))
+        path = str(tmp_path / f"s{s_i}.bin")
+        open(path, "wb").write(oracle.bin_write(0.8, 40, frag, bamio.sam_header(rec.targets), t, rec.qname_off, rec.qnames))
+        bins.append(path)
+        t = t[t["tid"] >= 0].copy()
+        t["qname_id"] = s_i
+        all_t.append((t, frag))
+    merged = np.concatenate([x[0] for x in all_t])
+    frag = np.sum([x[1] for x in all_t], axis=0).astype(np.uint32)
+    window, mcd = oracle.median(frag, 0.98), int(0.5 * oracle.median(frag, 0.5))
+    base = oracle.merge_text(merged, window, targets, min_support=2, max_clip_dist=mcd).splitlines()[1:]
+    assert len(base) >= 4
+    f0 = base[0].split("\t")     # plus one locus that swallows a whole (chrom, unit) group: the group stays a key of the table
+    bed = _loci_from_bounds(base, targets, np.random.default_rng(1), extra=[f"{f0[0]}\t0\t299999\t{f0[3]}\tall"])
+    bedp = str(tmp_path / "loci.bed")
+    open(bedp, "w").write(bed)
+    exp = oracle.merge_text(merged, window, targets, min_support=2, max_clip_dist=mcd, loci_text=bed)
+    r = _run(["merge", "-m", "2", "-l", bedp, "-o", str(tmp_path / "joint")] + bins)
+    assert r.returncode == 0, r.stderr
+    assert open(str(tmp_path / "joint-bounds.txt")).read() == exp
+    assert exp != "\n".join(["x"] + base) and exp.count("locus") >= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use", ["both", "bounds", "loci"])
+def test_call_with_loci_and_bounds_matches_oracle(oracle, tmp_path, use):
+    """the joint-calling flow: call -b joint-bounds.txt [-l loci.bed] genotypes the given loci first (call.nim:150-218)"""
+    rec, g = _sample(n_pairs=9000, seed=21, n_contigs=3, contig_len=40_000)
+    bam, bedg, binp = str(tmp_path / "s.bam"), str(tmp_path / "ref.str"), str(tmp_path / "s.bin")
+    bamio.write_bam(bam, rec)
+    bamio.write_genome_bed(bedg, g, rec.targets)
+    assert _run(["extract", "-g", bedg, bam, binp]).returncode == 0
+    frag = synth.frag_hist(rec)
+    t = oracle.extract(rec, g, oracle.make_opts(oracle.median(frag), 0.8, 40))
+    base_b, _, _ = oracle.call(t, rec, frag, min_support=3)
+    rows = ["\t".join(l.split("\t")[:11]) for l in base_b.splitlines()[1:]]
+    assert len(rows) >= 4
+    bounds_text = "#header line\n" + "\n".join(rows[:-1]) + "\n"
+    loci_text = _loci_from_bounds(rows, rec.targets, np.random.default_rng(2))
+    args, kw = [], {}
+    if use in ("both", "bounds"):
+        p = str(tmp_path / "in-bounds.txt"); open(p, "w").write(bounds_text); args += ["-b", p]; kw["bounds_text"] = bounds_text
+    if use in ("both", "loci"):
+        p = str(tmp_path / "loci.bed"); open(p, "w").write(loci_text); args += ["-l", p]; kw["loci_text"] = loci_text
+    prefix = str(tmp_path / "out")
+    r = _run(["call", "-m", "3", "-o", prefix] + args + [bam, binp])
+    assert r.returncode == 0, r.stderr
+    exp_b, exp_g, exp_u = oracle.call(t, rec, frag, min_support=3, **kw)
+    assert open(prefix + "-bounds.txt").read() == exp_b
+    assert open(prefix + "-genotype.txt").read() == exp_g
+    assert open(prefix + "-unplaced.txt").read() == exp_u
+    assert exp_b != base_b

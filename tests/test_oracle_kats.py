@@ -153,3 +153,23 @@ def test_spanning_read_est_kat(oracle, k):
 @pytest.mark.parametrize("k", KATS["median_depth"], ids=lambda k: k["source"])
 def test_median_depth_kats(oracle, k):
     assert oracle.median_depth(k["depths"]) == k["expect"]
+
+
+@pytest.mark.parametrize("k", KATS["parse_bed"], ids=lambda k: k["source"])
+def test_parse_bed_kats(oracle, k):
+    loci = oracle.parse_bed(k["text"], [tuple(t) for t in k["targets"]], k["window"])
+    assert len(loci) == len(k["expect"])
+    for L, e in zip(loci, k["expect"]):
+        for f, v in e.items():
+            got = getattr(L.b, f)
+            assert (got.decode() if isinstance(got, bytes) else got) == v, f
+
+
+@pytest.mark.parametrize("k", KATS["parse_bounds"], ids=lambda k: k["source"])
+def test_parse_bounds_kats(oracle, k):
+    loci = oracle.parse_bounds(k["text"], [tuple(t) for t in k["targets"]])
+    assert len(loci) == len(k["expect"])
+    for L, e in zip(loci, k["expect"]):
+        for f, v in e.items():
+            got = getattr(L.b, f)
+            assert (got.decode() if isinstance(got, bytes) else got) == v, f
