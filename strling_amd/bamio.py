@@ -24,7 +24,9 @@ def sam_header(targets, sort_order="coordinate"):
     return f"@HD\tVN:1.6\tSO:{sort_order}\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in targets)
 
 
-def write_bam(path, rec, header_text=None, level=1, block=0xFF00, index=True):
+def write_bam(path, rec, header_text=None, level=1, block=0xFF00, index=True, repeat=1):
+    """repeat > 1 (benchmarks only): the header gets its own BGZF blocks and the record blocks are written `repeat` times;
+    such a file is not coordinate sorted and gets no index."""
     targets = rec.targets
     text = (header_text if header_text is not None else sam_header(targets)).encode()
     out = bytearray()
@@ -49,6 +51,16 @@ def write_bam(path, rec, header_text=None, level=1, block=0xFF00, index=True):
                            int(rec.flag[i]), l_seq, int(rec.mtid[i]), int(rec.mpos[i]), int(isize[i])) + qn + cig + seq + qual
         out += struct.pack("<i", len(body)) + body
     rec_off.append(len(out))
+    if repeat > 1:
+        n_hdr = rec_off[0]
+        with open(path, "wb") as f:
+            for o in range(0, n_hdr, block):
+                f.write(_bgzf_block(bytes(out[o:min(n_hdr, o + block)]), level))
+            body = b"".join(_bgzf_block(bytes(out[o:o + block]), level) for o in range(n_hdr, len(out), block))
+            for _ in range(repeat):
+                f.write(body)
+            f.write(_EOF)
+        return text.decode()
     block_off = []
     with open(path, "wb") as f:
         for o in range(0, len(out), block):

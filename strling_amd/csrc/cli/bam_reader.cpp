@@ -1,9 +1,19 @@
 // bam_reader.cpp -- see bam_reader.h.  BGZF = concatenated gzip members with a BC extra field carrying the
 // compressed block size (SAM spec 4.1); each is inflated with raw zlib into a <= 64 KiB buffer.
 #include "bam_reader.h"
+#include <fcntl.h>
+#include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 #include <zlib.h>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 namespace strl {
 
@@ -207,6 +217,269 @@ int64_t BamReader::read_until(RecordBatch &b, int64_t max_records, int32_t stop_
     memcpy(b.seq4.data() + so, cg + 4u * n_cigar, sb);
     b.seq_off.push_back(so);
     ++n;
+  }
+  return n;
+}
+
+
+// ---- ThreadPool ---------------------------------------------------------------------------------------------------------
+struct ThreadPool::Impl {
+  std::vector<std::thread> workers;
+  std::mutex m;
+  std::condition_variable cv_start, cv_done;
+  const std::function<void(size_t)> *fn = nullptr;
+  size_t n = 0;
+  std::atomic<size_t> next{0};
+  uint64_t generation = 0;
+  int active = 0;
+  bool stop = false;
+  void work() {
+    for (;;) {
+      const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= n) break;
+      (*fn)(i);
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_start.wait(lk, [&] { return stop || generation != seen; });
+        if (stop) return;
+        seen = generation;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (--active == 0) cv_done.notify_one();
+      }
+    }
+  }
+};
+ThreadPool::ThreadPool(int threads) : impl_(new Impl), n_threads_(std::max(1, threads)) {
+  for (int t = 1; t < n_threads_; ++t) impl_->workers.emplace_back([this] { impl_->loop(); });
+}
+ThreadPool::~ThreadPool() {
+  { std::lock_guard<std::mutex> lk(impl_->m); impl_->stop = true; }
+  impl_->cv_start.notify_all();
+  for (auto &w : impl_->workers) w.join();
+  delete impl_;
+}
+void ThreadPool::parallel_for(size_t n, const std::function<void(size_t)> &fn) {
+  if (n == 0) return;
+  if (n_threads_ == 1 || n == 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+  {
+    std::lock_guard<std::mutex> lk(impl_->m);
+    impl_->fn = &fn; impl_->n = n; impl_->next.store(0); impl_->active = (int)impl_->workers.size(); ++impl_->generation;
+  }
+  impl_->cv_start.notify_all();
+  impl_->work();
+  std::unique_lock<std::mutex> lk(impl_->m);
+  impl_->cv_done.wait(lk, [&] { return impl_->active == 0; });
+}
+
+// ---- BamStream ----------------------------------------------------------------------------------------------------------
+namespace {
+struct DecodeClock {   // STRL_DECODE_TIMING=1: where the reader's time goes, printed when the stream closes
+  double walk = 0, inflate = 0, scan = 0, parse = 0;
+  bool on = getenv("STRL_DECODE_TIMING") != nullptr;
+  static double now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+} g_clk;
+}  // namespace
+BamStream::~BamStream() { close(); }
+void BamStream::close() {
+  if (g_clk.on && map_) fprintf(stderr, "[strling] decode seconds: walk+carry %.3f inflate %.3f record scan %.3f parse %.3f\n", g_clk.walk, g_clk.inflate, g_clk.scan, g_clk.parse);
+  if (map_) munmap(const_cast<uint8_t *>(map_), map_len_);
+  map_ = nullptr; map_len_ = 0;
+  delete pool_;
+  pool_ = nullptr;
+}
+
+bool BamStream::open(const std::string &path, int threads, std::string &err) {
+  close();
+  {   // header text + targets with the plain reader; it also tells where the first record starts
+    BamReader hdr;
+    if (!hdr.open(path, err)) return false;
+    text_ = hdr.header_text();
+    targets_ = hdr.targets();
+    const BamReader::Pos p = hdr.tell();
+    cpos_ = (size_t)p.block_off;
+    skip_ = p.in_block;
+  }
+  const int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) { err = "couldn't open bam"; return false; }
+  struct stat st;
+  if (fstat(fd, &st) != 0) { ::close(fd); err = "couldn't stat bam"; return false; }
+  map_len_ = (size_t)st.st_size;
+  void *m = map_len_ ? mmap(nullptr, map_len_, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+  ::close(fd);
+  if (map_len_ && m == MAP_FAILED) { map_len_ = 0; err = "couldn't map bam"; return false; }
+  map_ = static_cast<const uint8_t *>(m);
+  if (map_len_) madvise(const_cast<uint8_t *>(map_), map_len_, MADV_SEQUENTIAL);
+  pool_ = new ThreadPool(threads);
+  eof_ = false; rec_next_ = 0; recs_.clear(); u_.clear(); prev_.clear();
+  return true;
+}
+
+// Next superchunk: [leftover bytes of the previous one][blocks inflated in parallel] -> record table
+bool BamStream::load_chunk(std::string &err) {
+  struct Blk { const uint8_t *c; uint32_t clen, isize; size_t out; };
+  static const char *env_blocks = getenv("STRL_CHUNK_BLOCKS");   // tests: tiny superchunks to exercise the carry path
+  const size_t max_blocks = env_blocks && atoi(env_blocks) > 0 ? (size_t)atoi(env_blocks) : 64 * (size_t)pool_->size() + 64, max_bytes = (size_t)96 << 20;
+  std::vector<Blk> blks;
+  const double t0 = DecodeClock::now();
+  // bytes behind the last complete record of the previous superchunk
+  size_t carry = 0;
+  if (!u_.empty()) {
+    const size_t done = recs_.empty() ? skip_ : (size_t)(recs_.back().off + 4 + [&] { uint32_t bs; memcpy(&bs, u_.data() + recs_.back().off, 4); return bs; }());
+    carry = u_.size() - done;
+    prev_.assign(u_.begin() + (long)done, u_.end());
+    skip_ = 0;
+  }
+  size_t total = carry;
+  while (cpos_ < map_len_ && blks.size() < max_blocks && total < max_bytes) {
+    if (cpos_ + 18 > map_len_) { err = "truncated BGZF header"; return false; }
+    const uint8_t *h = map_ + cpos_;
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF block"; return false; }
+    const uint32_t xlen = h[10] | (h[11] << 8);
+    if (cpos_ + 12 + xlen > map_len_) { err = "truncated BGZF header"; return false; }
+    uint32_t bsize = 0;
+    for (uint32_t o = 0; o + 4 <= xlen;) {
+      const uint8_t *x = h + 12 + o;
+      const uint32_t sl = x[2] | (x[3] << 8);
+      if (x[0] == 'B' && x[1] == 'C' && sl == 2) bsize = (x[4] | (x[5] << 8)) + 1u;
+      o += 4 + sl;
+    }
+    if (!bsize || bsize < 12 + xlen + 8) { err = "BGZF block without BC field"; return false; }
+    if (cpos_ + bsize > map_len_) { err = "truncated BGZF block"; return false; }
+    const uint8_t *f = h + bsize - 4;
+    const uint32_t isz = f[0] | (f[1] << 8) | (f[2] << 16) | ((uint32_t)f[3] << 24);
+    if (isz) { blks.push_back(Blk{h + 12 + xlen, bsize - 12 - xlen - 8, isz, total}); total += isz; }
+    cpos_ += bsize;
+  }
+  if (cpos_ >= map_len_) eof_ = true;
+  u_.resize(total);
+  if (carry) memcpy(u_.data(), prev_.data(), carry);
+  std::atomic<bool> bad{false};
+  const double t1 = DecodeClock::now();
+  // Each task inflates one block and then walks the block_size chain through it -- while the data is still in that
+  // core's cache -- starting where the previous block's walk stopped (start[k], published by task k - 1; tasks are
+  // claimed in increasing order, so the task a walk waits for is always already running).  A record whose fixed
+  // 36-byte part is not complete inside the blocks done so far is handed on to the next block.
+  const size_t nb = blks.size(), total_n = u_.size();
+  struct alignas(64) Link { std::atomic<int64_t> v{-1}; int64_t load(std::memory_order o = std::memory_order_seq_cst) const { return v.load(o); }
+                            void store(int64_t x, std::memory_order o = std::memory_order_seq_cst) { v.store(x, o); } };
+  std::vector<Link> start(nb + 1);                       // one cache line each: every link has one writer and one spinning reader
+  start[0].store((int64_t)skip_, std::memory_order_release);
+  std::vector<std::vector<RecMeta>> found(nb);
+  pool_->parallel_for(nb, [&](size_t k) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    bool ok = inflateInit2(&zs, -15) == Z_OK;
+    if (ok) {
+      zs.next_in = const_cast<uint8_t *>(blks[k].c); zs.avail_in = blks[k].clen;
+      zs.next_out = u_.data() + blks[k].out; zs.avail_out = blks[k].isize;
+      const int rc = inflate(&zs, Z_FINISH);
+      ok = rc == Z_STREAM_END && zs.total_out == blks[k].isize;
+      inflateEnd(&zs);
+    }
+    if (!ok) bad = true;
+    int64_t p;
+    for (unsigned spins = 0; (p = start[k].load(std::memory_order_acquire)) < 0; ++spins) {
+      if (bad) { start[k + 1].store(0, std::memory_order_release); return; }
+      if (spins < 4096) __builtin_ia32_pause(); else std::this_thread::yield();
+    }
+    const size_t end_k = blks[k].out + blks[k].isize;
+    std::vector<RecMeta> &out = found[k];
+    out.reserve(blks[k].isize / 128 + 4);
+    size_t q = (size_t)p;
+    while (ok && q + 36 <= end_k) {
+      uint32_t bs;
+      memcpy(&bs, u_.data() + q, 4);
+      const uint8_t *r = u_.data() + q + 4;
+      RecMeta m;
+      m.off = q;
+      m.l_qname = r[8];
+      memcpy(&m.n_cigar, r + 12, 2);
+      memcpy(&m.l_seq, r + 16, 4);
+      if (bs < 32 || m.l_seq < 0 || 32 + (size_t)m.l_qname + 4u * m.n_cigar + (size_t)(m.l_seq + 1) / 2 > bs) { bad = true; ok = false; break; }
+      out.push_back(m);
+      q += 4 + (size_t)bs;
+    }
+    start[k + 1].store((int64_t)q, std::memory_order_release);
+  });
+  if (bad) { err = "BGZF inflate failed or corrupt BAM record"; return false; }
+  const double t2 = DecodeClock::now();
+  // record table of the superchunk: the per-block lists in order, minus the records that are not complete yet
+  recs_.clear();
+  rec_next_ = 0;
+  for (size_t k = 0; k < nb; ++k) recs_.insert(recs_.end(), found[k].begin(), found[k].end());
+  const size_t n = total_n;
+  auto rec_end = [&](const RecMeta &m) { uint32_t bs; memcpy(&bs, u_.data() + m.off, 4); return (size_t)m.off + 4 + (size_t)bs; };
+  if (!recs_.empty() && rec_end(recs_.back()) > n) recs_.pop_back();   // only the last one can reach past the superchunk
+  const size_t p = recs_.empty() ? skip_ : rec_end(recs_.back());      // what lies behind it is carried into the next superchunk
+  if (eof_ && p != n) { err = "truncated BAM record at end of file"; return false; }
+  const double t3 = DecodeClock::now();
+  g_clk.walk += t1 - t0; g_clk.inflate += t2 - t1; g_clk.scan += t3 - t2;
+  return true;
+}
+
+int64_t BamStream::read(RecordBatch &b, int64_t max_records, std::string &err) {
+  int64_t n = 0;
+  while (n < max_records) {
+    if (rec_next_ == recs_.size()) {
+      if (eof_) break;
+      if (!load_chunk(err)) return -1;
+      if (recs_.empty()) { if (eof_) break; continue; }
+    }
+    const size_t m = (size_t)std::min<int64_t>(max_records - n, (int64_t)(recs_.size() - rec_next_));
+    const double tp0 = DecodeClock::now();
+    const RecMeta *rm = recs_.data() + rec_next_;
+    // output offsets of this part
+    const size_t base = b.tid.size();
+    std::vector<uint32_t> cig_at(m + 1);
+    std::vector<uint64_t> qn_at(m + 1), seq_at(m + 1);
+    cig_at[0] = b.cigar_off.back();
+    qn_at[0] = b.qname_off.back();
+    size_t so = b.seq4.size();
+    for (size_t i = 0; i < m; ++i) {
+      cig_at[i + 1] = cig_at[i] + rm[i].n_cigar;
+      qn_at[i + 1] = qn_at[i] + (rm[i].l_qname ? rm[i].l_qname - 1u : 0u);
+      so = (so + 15) & ~(size_t)15;
+      seq_at[i] = so;
+      so += (size_t)(rm[i].l_seq + 1) / 2;
+    }
+    seq_at[m] = so;
+    b.tid.resize(base + m); b.pos.resize(base + m); b.mtid.resize(base + m); b.mpos.resize(base + m); b.isize.resize(base + m);
+    b.l_seq.resize(base + m); b.flag.resize(base + m); b.mapq.resize(base + m); b.seq_off.resize(base + m);
+    b.cigar_off.resize(base + m + 1); b.qname_off.resize(base + m + 1);
+    b.cigar.resize(cig_at[m]); b.qnames.resize(qn_at[m]); b.seq4.resize(so);
+    const size_t parts = std::min<size_t>(m, (size_t)pool_->size() * 4);
+    pool_->parallel_for(parts, [&](size_t part) {
+      const size_t i0 = m * part / parts, i1 = m * (part + 1) / parts;
+      for (size_t i = i0; i < i1; ++i) {
+        const uint8_t *p = u_.data() + rm[i].off + 4;
+        const size_t o = base + i;
+        memcpy(&b.tid[o], p, 4); memcpy(&b.pos[o], p + 4, 4);
+        b.mapq[o] = p[9];
+        memcpy(&b.flag[o], p + 14, 2);
+        b.l_seq[o] = rm[i].l_seq;
+        memcpy(&b.mtid[o], p + 20, 4); memcpy(&b.mpos[o], p + 24, 4); memcpy(&b.isize[o], p + 28, 4);
+        const size_t ql = rm[i].l_qname ? rm[i].l_qname - 1u : 0u;
+        if (ql) memcpy(&b.qnames[qn_at[i]], p + 32, ql);
+        b.qname_off[o + 1] = qn_at[i + 1];
+        const uint8_t *cg = p + 32 + rm[i].l_qname;
+        if (rm[i].n_cigar) memcpy(&b.cigar[cig_at[i]], cg, 4u * rm[i].n_cigar);
+        b.cigar_off[o + 1] = cig_at[i + 1];
+        const size_t sb = (size_t)(rm[i].l_seq + 1) / 2;
+        if (sb) memcpy(b.seq4.data() + seq_at[i], cg + 4u * rm[i].n_cigar, sb);
+        b.seq_off[o] = seq_at[i];
+      }
+    });
+    rec_next_ += m;
+    n += (int64_t)m;
+    g_clk.parse += DecodeClock::now() - tp0;
   }
   return n;
 }

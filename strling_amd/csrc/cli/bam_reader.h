@@ -6,6 +6,10 @@
 #include <limits.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <functional>
+#include <memory>
+#include <type_traits>
+#include <utility>
 #include <string>
 #include <vector>
 #include "../../../include/strling_amd.h"
@@ -17,14 +21,24 @@ struct BamTarget {
   uint32_t length;
 };
 
+// std::vector whose resize() leaves new trivially-constructible elements uninitialised: the batch arrays are hundreds of
+// megabytes that the parser overwrites completely, value-initialising them first would cost a second pass over memory.
+template <class T> struct default_init_allocator : std::allocator<T> {
+  template <class U> struct rebind { using other = default_init_allocator<U>; };
+  using std::allocator<T>::allocator;
+  template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+  template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using rvec = std::vector<T, default_init_allocator<T>>;
+
 // One batch of records in the strl_records layout (owning storage).
 struct RecordBatch {
-  std::vector<int32_t> tid, pos, mtid, mpos, isize, l_seq;
-  std::vector<uint16_t> flag;
-  std::vector<uint8_t> mapq;
-  std::vector<uint32_t> cigar_off{0}, cigar;
-  std::vector<uint64_t> seq_off, qname_off{0};
-  std::vector<uint8_t> seq4;
+  rvec<int32_t> tid, pos, mtid, mpos, isize, l_seq;
+  rvec<uint16_t> flag;
+  rvec<uint8_t> mapq;
+  rvec<uint32_t> cigar_off{0}, cigar;
+  rvec<uint64_t> seq_off, qname_off{0};
+  rvec<uint8_t> seq4;
   std::string qnames;
   void clear();
   size_t size() const { return tid.size(); }
@@ -66,6 +80,47 @@ class BamReader {
   std::vector<BamTarget> targets_;
   std::vector<std::vector<uint64_t>> lin_;   // per reference: linear index (virtual offset per 16 KiB window)
   std::vector<uint64_t> ref_beg_;            // per reference: smallest chunk start of any bin (0 = no records)
+};
+
+// Minimal fork-join pool: parallel_for(n, fn) runs fn(i) for every i in [0, n) on `threads` threads (the caller is one).
+class ThreadPool {
+ public:
+  explicit ThreadPool(int threads);
+  ~ThreadPool();
+  int size() const { return n_threads_; }
+  void parallel_for(size_t n, const std::function<void(size_t)> &fn);
+
+ private:
+  struct Impl;
+  Impl *impl_;
+  int n_threads_;
+};
+
+// Whole-file sequential BAM reader for `extract` and the fragment-length pass: the file is
+// mapped, BGZF blocks are inflated in parallel a superchunk (a few hundred blocks) at a time, record boundaries are
+// found in one light sequential scan, and the records of a batch are parsed into the SoA layout in parallel.
+// Same batch contract as BamReader::read.  htslib in the reference decodes on one thread (threads=0, extract.nim:275).
+class BamStream {
+ public:
+  ~BamStream();
+  bool open(const std::string &path, int threads, std::string &err);
+  void close();
+  const std::string &header_text() const { return text_; }
+  const std::vector<BamTarget> &targets() const { return targets_; }
+  int64_t read(RecordBatch &b, int64_t max_records, std::string &err);
+
+ private:
+  struct RecMeta { uint64_t off; int32_t l_seq; uint16_t n_cigar; uint8_t l_qname; };
+  bool load_chunk(std::string &err);
+  const uint8_t *map_ = nullptr;
+  size_t map_len_ = 0, cpos_ = 0;
+  rvec<uint8_t> u_, prev_;            // decompressed superchunk (leftover of the previous one in front)
+  std::vector<RecMeta> recs_;         // complete records of the current superchunk
+  size_t rec_next_ = 0, skip_ = 0;
+  bool eof_ = false;
+  ThreadPool *pool_ = nullptr;
+  std::string text_;
+  std::vector<BamTarget> targets_;
 };
 
 }  // namespace strl

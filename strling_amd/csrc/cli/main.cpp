@@ -14,8 +14,11 @@
 #include <zlib.h>
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../../include/strling_amd.h"
 #include "bam_reader.h"
@@ -107,12 +110,19 @@ static void append_record(RecordBatch &dst, const RecordBatch &src, size_t i) {
 }
 
 // utils.nim:86-111
+// decode threads: STRL_THREADS, else what the machine has, at most 32 (the reference decodes on one: threads=0, extract.nim:275)
+static int decode_threads() {
+  const char *e = getenv("STRL_THREADS");
+  if (e && atoi(e) > 0) return atoi(e);
+  return (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+}
+
 static void fragment_length_distribution(const std::string &bam, uint32_t frag[4096]) {
   const int64_t n_reads = 2000000, skip_reads = 100000;
   memset(frag, 0, 4096 * sizeof(uint32_t));
-  BamReader rd;
+  BamStream rd;
   std::string err;
-  if (!rd.open(bam, err)) quit("couldn't open bam");
+  if (!rd.open(bam, decode_threads(), err)) quit("couldn't open bam");
   RecordBatch b;
   std::vector<int32_t> skipped;
   int64_t i = -1, counted = 0;
@@ -250,7 +260,7 @@ static int extract_main(int argc, char **argv) {
   const double p = atof(a.get("proportion-repeat", "0.8").c_str());
   const uint8_t min_mapq = (uint8_t)atoi(a.get("min-mapq", "40").c_str());
   const bool verbose = a.flag("verbose");
-  const int64_t batch = atoll(a.get("batch", "2097152").c_str());
+  const int64_t batch = atoll(a.get("batch", "1048576").c_str());
 
   uint32_t frag[4096];
   fragment_length_distribution(bam, frag);                                        // extract.nim:281
@@ -259,9 +269,9 @@ static int extract_main(int argc, char **argv) {
     fprintf(stderr, "Calculated median fragment length:%d\n", frag_median);
     fprintf(stderr, "10th, 90th percentile of fragment length:%d %d\n", strl_frag_median(frag, 0.1), strl_frag_median(frag, 0.9));
   }
-  BamReader rd;
+  BamStream rd;
   std::string err;
-  if (!rd.open(bam, err)) quit("couldn't open bam");
+  if (!rd.open(bam, decode_threads(), err)) quit("couldn't open bam");
   strl_ctx *ctx = nullptr;
   CHECK(strl_ctx_create(0, &ctx));
   strl_opts opts{frag_median, p, min_mapq};
@@ -293,9 +303,13 @@ static int extract_main(int argc, char **argv) {
   std::vector<uint16_t> ls, cl, cr;
   std::vector<uint8_t> cig;
   std::vector<strl_soft_rec> soft;
+  double t_read = 0, t_soa = 0, t_score = 0, t_pair = 0;   // -v: where the wall time of the loop goes
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   auto run_batch = [&](RecordBatch &b) {
     const size_t n = b.size();
     if (!n) return;
+    const auto ta = now();
     strl_records rec = b.view();
     end.resize(n); so.resize(n); whole.resize(n); ls.resize(n); cl.resize(n); cr.resize(n); cig.resize(n); soft.resize(2 * n + 2);
     uint32_t mx = 0;
@@ -305,22 +319,57 @@ static int extract_main(int argc, char **argv) {
     soa.clip_l = cl.data(); soa.clip_r = cr.data(); soa.mapq = rec.mapq; soa.cig = cig.data(); soa.seq4 = rec.seq4;
     soa.seq4_bytes = b.seq4.size(); soa.max_l_seq = mx; soa.mem = STRL_MEM_HOST;
     uint64_t ns = 0;
+    const auto tb = now();
     CHECK(strl_score_reads(ctx, &soa, whole.data(), soft.data(), 2 * n, &ns, nullptr));
+    const auto tc = now();
     CHECK(strl_pairer_add(pairer, &rec, whole.data(), soft.data(), ns));
+    const auto td = now();
+    t_soa += secs(ta, tb); t_score += secs(tb, tc); t_pair += secs(tc, td);
   };
 
   fprintf(stderr, "[strling] collecting str-like reads\n");
   const auto t0 = std::chrono::steady_clock::now();
-  RecordBatch b, tail;
+  // the decoder runs one batch ahead of scoring + pairing (two slots)
+  struct Slot { RecordBatch b; int64_t got = 0; std::string err; };
+  Slot slots[2];
+  std::mutex mu;
+  std::condition_variable cv;
+  int filled = 0;
+  bool stop = false;
+  std::thread producer([&] {
+    for (int w = 0;; w ^= 1) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return filled < 2 || stop; });
+        if (stop) return;
+      }
+      Slot &sl = slots[w];
+      sl.b.clear();
+      sl.got = rd.read(sl.b, batch, sl.err);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        ++filled;
+      }
+      cv.notify_all();
+      if (sl.got <= 0) return;
+    }
+  });
+  RecordBatch tail;
   int64_t nreads = 0, last_tid = -1;
-  for (;;) {
-    b.clear();
-    const int64_t got = rd.read(b, batch, err);
-    if (got < 0) quit("[strling] error reading %s: %s", bam.c_str(), err.c_str());
+  for (int r = 0;; r ^= 1) {
+    const auto tr0 = now();
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return filled > 0; });
+    }
+    t_read += secs(tr0, now());
+    RecordBatch &b = slots[r].b;
+    const int64_t got = slots[r].got;
+    if (got < 0) { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); producer.join(); quit("[strling] error reading %s: %s", bam.c_str(), slots[r].err.c_str()); }
     if (got == 0) break;
     for (size_t i = 0; i < (size_t)got; ++i) {
       const uint16_t f = b.flag[i];
-      if (b.tid[i] >= 0) tail.clear(); else append_record(tail, b, i);            // the "*" region: unplaced records at the end
+      if (b.tid[i] >= 0) { if (tail.size()) tail.clear(); } else append_record(tail, b, i);            // the "*" region: unplaced records at the end
       if (f & (0x100 | 0x800)) continue;
       if (b.tid[i] != last_tid && b.tid[i] >= 0) {
         if (rd.targets()[(size_t)b.tid[i]].length > 2000000u) fprintf(stderr, "[strling] extracting chromosome:%s\n", rd.targets()[(size_t)b.tid[i]].name.c_str());
@@ -329,11 +378,17 @@ static int extract_main(int argc, char **argv) {
       ++nreads;
     }
     run_batch(b);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      --filled;
+    }
+    cv.notify_all();
     if (verbose) {
       const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       fprintf(stderr, "%lld %.1f reads/sec\n", (long long)nreads, (double)nreads / std::max(s, 1e-9));
     }
   }
+  producer.join();
   fprintf(stderr, "[strling] extracting unmapped reads\n");
   for (size_t i = 0; i < tail.size(); ++i) if (!(tail.flag[i] & (0x100 | 0x800))) ++nreads;
   run_batch(tail);                                                                // extract.nim:326-329
@@ -346,7 +401,11 @@ static int extract_main(int argc, char **argv) {
   fprintf(stderr, "[strling] writing binary file:%s\n", bin.c_str());
   CHECK(strl_bin_write(bin.c_str(), (float)p, min_mapq, frag, rd.header_text().data(), (int32_t)rd.header_text().size(), treads, nt, qoff, qn));
   fprintf(stderr, "[strling] finished extraction\n");
-  if (verbose) fprintf(stderr, "[strling] %lld reads, %llu STR reads, %llu reads still waiting for a mate\n", (long long)nreads, (unsigned long long)nt, (unsigned long long)pending);
+  if (verbose) {
+    fprintf(stderr, "[strling] %lld reads, %llu STR reads, %llu reads still waiting for a mate\n", (long long)nreads, (unsigned long long)nt, (unsigned long long)pending);
+    fprintf(stderr, "[strling] seconds: total %.3f  waiting for the decoder %.3f  soa %.3f  device scoring (incl. copies) %.3f  pair logic %.3f\n",
+            secs(t0, now()), t_read, t_soa, t_score, t_pair);
+  }
   strl_pairer_destroy(pairer);
   strl_ctx_destroy(ctx);
   return 0;
@@ -692,15 +751,18 @@ static int call_main(int argc, char **argv) {
 
 // `strling _dump BAM`: SAM-like text of every record as the reader decoded it (reader self-check; needs no GPU)
 static int dump_main(int argc, char **argv) {
-  if (argc < 3) quit("usage: strling _dump BAM");
+  if (argc < 3) quit("usage: strling _dump BAM [stream [BATCH]]");
+  const bool stream = argc > 3 && std::string(argv[3]) == "stream";   // the multi-threaded whole-file reader instead of the plain one
+  const int64_t batch = argc > 4 ? atoll(argv[4]) : 4096;
   BamReader rd;
+  BamStream rs;
   std::string err;
-  if (!rd.open(argv[2], err)) quit("couldn't open bam");
-  fputs(rd.header_text().c_str(), stdout);
+  if (stream ? !rs.open(argv[2], decode_threads(), err) : !rd.open(argv[2], err)) quit("couldn't open bam");
+  fputs((stream ? rs.header_text() : rd.header_text()).c_str(), stdout);
   RecordBatch b;
   for (;;) {
     b.clear();
-    const int64_t got = rd.read(b, 4096, err);
+    const int64_t got = stream ? rs.read(b, batch, err) : rd.read(b, batch, err);
     if (got < 0) quit("[strling] error reading %s: %s", argv[2], err.c_str());
     if (got == 0) break;
     for (size_t i = 0; i < (size_t)got; ++i) {

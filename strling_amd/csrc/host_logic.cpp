@@ -6,6 +6,11 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <string_view>
 #include <unordered_map>
@@ -349,36 +354,169 @@ int strl_pair_reads(const strl_records *rec, const strl_opts *opts, const uint32
 }
 
 // ---- streaming pairer: the Cache of extract.nim:298 kept alive across batches (what the CLI drives) ----
-struct strl_pairer {
-  strl_opts opts;
-  StreamStore store;
+// Qname groups never interact in Cache.add (the table is keyed by qname and every emission happens while the record
+// that triggers it is processed), so the table is split into shards by qname hash and the shards of a batch run on
+// their own threads.  Every emission carries (batch, record index); merging the shards by that key -- stable within a
+// shard -- gives exactly the order a single sequential pass produces.
+struct alignas(256) ShardStore {   // own cache lines: `cur` is written for every record by the shard's thread
+  std::unordered_map<std::string, strl_tread> tbl;
+  std::vector<strl_tread> out;
+  std::vector<uint64_t> key;       // batch << 32 | record index of the record being processed at emission time
+  std::vector<uint64_t> qoff{0};
+  std::string qnames;
+  std::string tmp;
+  uint64_t cur = 0;
+  strl_tread *find(std::string_view q) { tmp.assign(q); auto it = tbl.find(tmp); return it == tbl.end() ? nullptr : &it->second; }
+  void erase(std::string_view q) { tmp.assign(q); tbl.erase(tmp); }
+  void insert(std::string_view q, const strl_tread &t) { tbl.emplace(std::string(q), t); }
+  void emit(strl_tread t, std::string_view q) {
+    out.push_back(t);
+    key.push_back(cur);
+    qnames.append(q);
+    qoff.push_back(qnames.size());
+  }
 };
 
+// Fixed team of threads: run(fn) executes fn(t) on thread t of the team (t = 0 is the caller).  The mapping is fixed so
+// that shard t of the pairer is always touched by the same OS thread (its allocations stay in one malloc arena).
+struct Team {
+  int n;
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv_go, cv_done;
+  const std::function<void(int)> *fn = nullptr;
+  uint64_t gen = 0;
+  int left = 0;
+  bool stop = false;
+  explicit Team(int n_) : n(n_) {
+    for (int t = 1; t < n; ++t)
+      th.emplace_back([this, t] {
+        uint64_t seen = 0;
+        for (;;) {
+          const std::function<void(int)> *f;
+          {
+            std::unique_lock<std::mutex> lk(m);
+            cv_go.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            f = fn;
+          }
+          (*f)(t);
+          {
+            std::lock_guard<std::mutex> lk(m);
+            if (--left == 0) cv_done.notify_one();
+          }
+        }
+      });
+  }
+  ~Team() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    cv_go.notify_all();
+    for (auto &x : th) x.join();
+  }
+  void run(const std::function<void(int)> &f) {
+    if (n == 1) { f(0); return; }
+    { std::lock_guard<std::mutex> lk(m); fn = &f; left = n - 1; ++gen; }
+    cv_go.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return left == 0; });
+  }
+};
+
+struct strl_pairer {
+  strl_opts opts;
+  std::vector<ShardStore> shards;
+  uint64_t batch_no = 0;
+  std::unique_ptr<Team> team;
+  // merged view, rebuilt by strl_pairer_result
+  std::vector<strl_tread> out;
+  std::vector<uint64_t> qoff;
+  std::string qnames;
+};
+
+static int pair_threads() {
+  const char *e = getenv("STRL_PAIR_THREADS");
+  if (e && atoi(e) > 0) return std::min(atoi(e), 64);
+  return (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+}
 int strl_pairer_create(const strl_opts *opts, strl_pairer **out) {
   if (!opts || !out) { set_error("null argument"); return STRL_ERR_ARG; }
-  *out = new strl_pairer{*opts, {}};
+  strl_pairer *p = new strl_pairer;
+  p->opts = *opts;
+  p->shards.resize((size_t)pair_threads());
+  p->team.reset(new Team((int)p->shards.size()));
+  *out = p;
   return STRL_OK;
 }
 void strl_pairer_destroy(strl_pairer *p) { delete p; }
 
 int strl_pairer_add(strl_pairer *p, const strl_records *rec, const uint32_t *whole, const strl_soft_rec *soft, uint64_t n_soft) {
   if (!p || !rec || (!whole && rec->n)) { set_error("null argument"); return STRL_ERR_ARG; }
-  Pairer<StreamStore> P{RecView{rec}, &p->opts, whole, soft, n_soft, p->store};
-  for (int64_t i = 0; i < rec->n; ++i) {
-    if (rec->flag[i] & (F_SECONDARY | F_SUPPL)) continue;   // extract.nim:309,327
-    P.add(i);
+  if (rec->n >= (1ll << 32)) { set_error("batch too large"); return STRL_ERR_ARG; }
+  const int P = (int)p->shards.size();
+  const int64_t n = rec->n;
+  const uint64_t batch = p->batch_no++;
+  std::vector<int> errs((size_t)P, 0);
+  if (P == 1) {
+    ShardStore &S = p->shards[0];
+    Pairer<ShardStore> pr{RecView{rec}, &p->opts, whole, soft, n_soft, S};
+    for (int64_t i = 0; i < n; ++i) {
+      if (rec->flag[i] & (F_SECONDARY | F_SUPPL)) continue;   // extract.nim:309,327
+      S.cur = (batch << 32) | (uint64_t)i;
+      pr.add(i);
+    }
+    return pr.err;
   }
-  return P.err;
+  std::vector<uint8_t> owner((size_t)n);
+  const RecView rv{rec};
+  p->team->run([&](int t) {                                     // who owns which record
+    const int64_t i0 = n * t / P, i1 = n * (t + 1) / P;
+    for (int64_t i = i0; i < i1; ++i) owner[(size_t)i] = (uint8_t)(hash_bytes(rv.qname(i)) % (uint64_t)P);
+  });
+  p->team->run([&](int t) {
+    ShardStore &S = p->shards[(size_t)t];
+    Pairer<ShardStore> pr{RecView{rec}, &p->opts, whole, soft, n_soft, S};
+    for (int64_t i = 0; i < n; ++i) {
+      if (owner[(size_t)i] != (uint8_t)t) continue;
+      if (rec->flag[i] & (F_SECONDARY | F_SUPPL)) continue;   // extract.nim:309,327
+      S.cur = (batch << 32) | (uint64_t)i;
+      pr.add(i);
+    }
+    errs[(size_t)t] = pr.err;
+  });
+  for (int e : errs) if (e) return e;
+  return STRL_OK;
 }
 
 int strl_pairer_result(strl_pairer *p, const strl_tread **treads, uint64_t *n, const uint64_t **qname_off, const char **qnames,
                        uint64_t *n_pending) {
   if (!p) return STRL_ERR_ARG;
-  if (treads) *treads = p->store.out.data();
-  if (n) *n = p->store.out.size();
-  if (qname_off) *qname_off = p->store.qoff.data();
-  if (qnames) *qnames = p->store.qnames.data();
-  if (n_pending) *n_pending = p->store.tbl.size();
+  // k-way merge of the shards' emissions by (batch, record); each shard is already in that order
+  struct Ref { uint64_t key; uint32_t shard, idx; };
+  std::vector<Ref> refs;
+  uint64_t pending = 0;
+  for (size_t sh = 0; sh < p->shards.size(); ++sh) {
+    const ShardStore &S = p->shards[sh];
+    pending += S.tbl.size();
+    for (size_t k = 0; k < S.out.size(); ++k) refs.push_back(Ref{S.key[k], (uint32_t)sh, (uint32_t)k});
+  }
+  std::stable_sort(refs.begin(), refs.end(), [](const Ref &a, const Ref &b) { return a.key < b.key; });
+  p->out.clear(); p->qoff.assign(1, 0); p->qnames.clear();
+  p->out.reserve(refs.size());
+  for (const Ref &r : refs) {
+    const ShardStore &S = p->shards[r.shard];
+    strl_tread t = S.out[r.idx];
+    t.qname_id = (int64_t)p->out.size();
+    p->out.push_back(t);
+    p->qnames.append(S.qnames, S.qoff[r.idx], S.qoff[r.idx + 1] - S.qoff[r.idx]);
+    p->qoff.push_back(p->qnames.size());
+  }
+  if (treads) *treads = p->out.data();
+  if (n) *n = p->out.size();
+  if (qname_off) *qname_off = p->qoff.data();
+  if (qnames) *qnames = p->qnames.data();
+  if (n_pending) *n_pending = pending;
   return STRL_OK;
 }
 

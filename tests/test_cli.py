@@ -53,6 +53,16 @@ def test_bam_reader_roundtrip(sample):
         assert int(f[8]) == rec.isize[i] and f[9] == rec.sequence(i)
 
 
+@pytest.mark.parametrize("threads,blocks,batch", [("1", "0", "4096"), ("4", "3", "1000"), ("7", "1", "77"), ("3", "0", "100000")])
+def test_parallel_stream_reader_equals_plain_reader(sample, threads, blocks, batch):
+    """the multi-threaded whole-file reader (parallel inflate + parallel parse, superchunk carry) yields the same records"""
+    a = _run(["_dump", sample["bam"]])
+    env = dict(os.environ, STRL_THREADS=threads, STRL_CHUNK_BLOCKS=blocks)
+    b = _run(["_dump", sample["bam"], "stream", batch], env=env)
+    assert a.returncode == 0 and b.returncode == 0, b.stderr
+    assert a.stdout == b.stdout and a.stdout.count("\n") > sample["rec"].n
+
+
 def test_indexed_region_reads(tmp_path):
     """.bai linear index + region read == a scan of all records with htslib's iterator filter (tid, pos < end, endpos > beg)"""
     rec, _ = synth.synth_wgs(5000, seed=3, n_contigs=3, contig_len=200_000)
