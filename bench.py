@@ -93,15 +93,42 @@ def main():
     max_clip_dist = int(0.5 * api.frag_median(frag, 0.5))    # call.nim:232
     bounds, unplaced, cst = ctx.cluster(treads, api.MODE_CALL, window, min_support=5, max_clip_dist=max_clip_dist)
 
+    # N > 1: the exchange step of SURVEY section 8(e) -- one RCCL all-gather of the compact tread arrays (32 B per STR read)
+    # before clustering, after which every rank clusters an equal share of the (tid, unit) groups.  The synthetic ranks
+    # hold equally sized tread sets, so the share a rank clusters is as large as its own set: the replayed pass.
+    exchange = None
+    cstream = torch.cuda.ExternalStream(ctx.stream)
+    if world > 1:
+        try:
+            t_local = torch.from_numpy(np.ascontiguousarray(treads).view(np.uint8).copy()).to(dev)
+            t_all = torch.empty(world * t_local.numel(), dtype=torch.uint8, device=dev)
+            gather_done = torch.cuda.Event()
+
+            def exchange():
+                dist.all_gather_into_tensor(t_all, t_local)
+                gather_done.record()
+                cstream.wait_event(gather_done)      # the clustering kernels of this step start after the gather
+
+            exchange()
+            torch.cuda.synchronize()
+        except Exception as e:                        # keep the shard-only measurement if the collective is unavailable
+            print(f"[bench] rank {rank}: tread all-gather disabled: {e}", file=sys.stderr)
+            exchange = None
+        ok = torch.tensor([1 if exchange is not None else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)     # all ranks must agree, or the collective would hang
+        if int(ok.item()) == 0:
+            exchange = None
+
     # one synchronous pass for the unit counts of each kernel
     n_soft, st = ctx.score_device(cs, whole.data_ptr(), soft.data_ptr(), soft_cap, sync=True)
     for _ in range(args.warmup):
         ctx.score_device(cs, whole.data_ptr(), soft.data_ptr(), soft_cap)
+        if exchange:
+            exchange()
         ctx.cluster_replay()
     ctx.sync()
     # clustering pass alone, HIP events on the context stream
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    cstream = torch.cuda.ExternalStream(ctx.stream)
     with torch.cuda.stream(cstream):
         ev0.record()
         for _ in range(5):
@@ -120,9 +147,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctx.score_device(cs, whole.data_ptr(), soft.data_ptr(), soft_cap)
+        if exchange:
+            exchange()
         ctx.cluster_replay()
     ctx.sync()
-    torch.cuda.synchronize()
+    barrier()
     el = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
@@ -198,7 +227,9 @@ def main():
                        "skipped_frac": round(st.n_skipped / n, 4), "scored_reads": int(st.n_scored), "soft_items": int(st.n_soft_items),
                        "str_reads_clustered": int(treads.size), "clusters": int(cst.n_clusters), "bounds": int(len(bounds)),
                        "timed_region": "classify + score + soft-clip kernels, then radix-sort + sweep + bounds clustering kernels, all on HBM-resident data; BAM decode, PCIe and the host pair logic between the two are excluded",
-                       "parallelism": f"records sharded over {world} GPU(s), no data-path collective"},
+                       "parallelism": (f"records sharded over {world} GPU(s), no data-path collective" if exchange is None else
+                                       f"records sharded over {world} GPUs; per step one RCCL all-gather of the compact tread arrays "
+                                       f"({treads.size * 32} B per rank) before clustering, every rank clusters an equal share of the groups")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -319,3 +319,80 @@ def synth_chrom(n_bases, seed=1, n_str=None, soft_mask=True):
             at = int(rng.integers(0, n_bases))
             seq[at:at + 500] |= 0x20
     return seq.tobytes()
+
+
+def synth_htt(n_pairs=5000, seed=7, contig_len=200_000, tract_at=100_000, ref_units=19, extra_units=100, read_len=150):
+    """SURVEY section 8(d) input S0 (BASELINE.json configs[0], cf. sim/htt_locus.bed): one contig "4" of iid ACGT (seed 42)
+    with a (CAG)x19 tract, two haplotypes (reference and +100 CAG units), paired reads with fragment length
+    ~ N(350, 120), records synthesised without an aligner:
+      * flank reads: 150M, mapq 60, proper pair;
+      * reads that run from a flank into the expansion: the part beyond the reference tract is soft-clipped (xMyS / xSyM);
+      * reads wholly inside the expansion: unmapped (flag 0x4), mapq 0, placed at the mate's position; when both mates
+        are inside, both unmapped with tid -1 at the end of the file.
+    -> (RecordBatch, reference sequence bytes)"""
+    from .records import RecordBatch
+    g = np.random.Generator(np.random.Philox(42))
+    ref = g.choice(np.frombuffer(b"ACGT", np.uint8), contig_len)
+    tract = np.resize(np.frombuffer(b"CAG", np.uint8), 3 * ref_units)
+    ref[tract_at:tract_at + tract.size] = tract
+    T0, T1 = tract_at, tract_at + tract.size                          # reference tract [T0, T1)
+    ins = 3 * extra_units
+    alt = np.concatenate([ref[:T1], np.resize(np.frombuffer(b"CAG", np.uint8), ins), ref[T1:]])   # expansion appended behind the tract
+    rng = _rng(seed)
+    L = read_len
+    comp = np.zeros(256, np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    tids, poss, mtids, mposs, flags, mapqs, cigs, seqs, qn, isz = [], [], [], [], [], [], [], [], [], []
+
+    def place(h, a):
+        """read covering haplotype coordinates [a, a+L) -> (tid, pos, cigar string, mapq, unmapped)"""
+        b = a + L
+        if h == 0 or b <= T1:                                         # reference haplotype, or left of the expansion
+            return 0, a, f"{L}M", 60, False
+        e0, e1 = T1, T1 + ins                                         # expansion in haplotype coordinates
+        if a >= e1:                                                   # right flank: shift back
+            return 0, a - ins, f"{L}M", 60, False
+        if a >= e0 - 0 and b <= e1 + 0 and a >= e0 and b <= e1:       # wholly inside the expansion
+            return -1, 0, "*", 0, True
+        if a < e0:                                                    # enters the expansion from the left
+            m = e0 - a
+            if b <= e1:
+                return 0, a, f"{m}M{L - m}S", 60, False
+            return 0, a, f"{m}M{ins}I{b - e1}M", 60, False             # spans the whole expansion (only if ins < L)
+        m = b - e1                                                    # leaves the expansion to the right
+        return 0, T1, f"{L - m}S{m}M", 60, False
+
+    for i in range(n_pairs):
+        h = int(rng.integers(0, 2))
+        hap = alt if h else ref
+        frag = int(np.clip(np.rint(rng.normal(350, 120)), L, 4095))
+        a = int(rng.integers(0, hap.size - frag))
+        r1 = place(h, a)
+        r2 = place(h, a + frag - L)
+        s1 = bytes(hap[a:a + L])
+        s2 = bytes(hap[a + frag - L:a + frag])                         # SEQ is stored on the forward strand for the reverse mate
+        both_un = r1[4] and r2[4]
+        for k, (r, s, other) in enumerate(((r1, s1, r2), (r2, s2, r1))):
+            tid, pos, cig, mq, un = r
+            f = 0x1 | (0x40 if k == 0 else 0x80) | (0x10 if k == 1 else 0x20)
+            if un:
+                f |= 0x4
+                if not both_un:
+                    tid, pos = other[0], other[1]                      # unmapped mate sits at its mate's position
+            if other[4]:
+                f |= 0x8
+            mt, mp = (other[0], other[1]) if not other[4] else ((tid, pos) if not both_un else (-1, -1))
+            if both_un:
+                tid, pos, mt, mp = -1, -1, -1, -1
+            proper = not un and not other[4]
+            if proper:
+                f |= 0x2
+            tids.append(tid); poss.append(pos); mtids.append(mt); mposs.append(mp); flags.append(f); mapqs.append(mq); cigs.append(cig)
+            seqs.append(s.decode()); qn.append(f"htt{i}")
+            span = (r2[1] + L) - r1[1] if proper else 0
+            isz.append((span if k == 0 else -span) if proper else 0)
+    order = sorted(range(len(tids)), key=lambda j: ((1 << 40) if tids[j] < 0 else (tids[j] << 32) + max(poss[j], 0), j))
+    pick = lambda x: [x[j] for j in order]
+    rec = RecordBatch.from_fields(pick(tids), pick(poss), pick(mtids), pick(mposs), pick(flags), pick(mapqs), pick(cigs), pick(seqs), pick(qn),
+                                  isize=pick(isz), targets=[("4", contig_len)])
+    return rec, ref.tobytes()

@@ -266,3 +266,34 @@ def test_call_with_loci_and_bounds_matches_oracle(oracle, tmp_path, use):
     assert open(prefix + "-genotype.txt").read() == exp_g
     assert open(prefix + "-unplaced.txt").read() == exp_u
     assert exp_b != base_b
+
+
+@pytest.mark.gpu
+def test_htt_simulation_end_to_end(oracle, tmp_path):
+    """BASELINE.json configs[0] (S0, cf. sim/htt_locus.bed): 10 000 simulated reads around a (CAG)x19 tract with a
+    +100 unit expansion on one haplotype.  index (built by extract from the FASTA) -> extract -> call; every file is
+    byte-identical to the oracle's, and the expansion is called at the tract."""
+    rec, ref = synth.synth_htt()
+    fa, bam, bed, binp, prefix = (str(tmp_path / x) for x in ("ref.fa", "s.bam", "ref.fa.str", "s.bin", "htt"))
+    with open(fa, "wb") as f:
+        f.write(b">4 synthetic\n")
+        for i in range(0, len(ref), 60):
+            f.write(ref[i:i + 60] + b"\n")
+    bamio.write_bam(bam, rec)
+    r = _run(["extract", "-f", fa, "-g", bed, bam, binp])
+    assert r.returncode == 0, r.stderr
+    regions = oracle.index_chrom(ref, 0.8)
+    assert open(bed).read() == "".join(f"4\t{a}\t{b}\t{u}\n" for a, b, u in regions)     # the 57 bp reference tract is below index's radar
+    from strling_amd.records import GenomeStr
+    g = GenomeStr.from_lists(1, {0: [(a, b) for a, b, u in regions]} if regions else {})
+    frag = synth.frag_hist(rec)
+    t = oracle.extract(rec, g, oracle.make_opts(oracle.median(frag), 0.8, 40))
+    assert open(binp, "rb").read() == oracle.bin_write(0.8, 40, frag, bamio.sam_header(rec.targets), t, rec.qname_off, rec.qnames)
+    r = _run(["call", "-o", prefix, bam, binp])
+    assert r.returncode == 0, r.stderr
+    exp_b, exp_g, exp_u = oracle.call(t, rec, frag)
+    assert open(prefix + "-bounds.txt").read() == exp_b
+    assert open(prefix + "-genotype.txt").read() == exp_g
+    assert open(prefix + "-unplaced.txt").read() == exp_u
+    rows = [l.split("\t") for l in exp_b.splitlines()[1:]]
+    assert any(r[0] == "4" and r[3] == "CAG" and abs(int(r[1]) - 100_057) <= 60 for r in rows)
