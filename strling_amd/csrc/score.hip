@@ -323,10 +323,10 @@ __global__ __launch_bounds__(1024) void compact_kernel(ScoreParams P) {
   }
 }
 
-// rows ([row][lane] dwords) of a wave's LDS region: raw SEQ staging, k = 2/3 bins + dummy row, long-read hash slots
+// rows ([row][lane] dwords) of a wave's LDS region: raw SEQ staging, the class bins of k <= 4 + dummy row (24 + 1 for k = 3), long-read hash slots
 template <int NW, int SLOTS, int STAGE> constexpr int table_rows() {
   constexpr int raw = 4 * ((16 * NW + 62) / 32);
-  constexpr int need = STAGE == 0 ? 65 : (NW <= 10 ? 0 : SLOTS);
+  constexpr int need = STAGE == 0 ? 25 : (NW <= 10 ? 0 : SLOTS);
   return raw > need ? raw : need;
 }
 
@@ -388,7 +388,7 @@ template <int MODE, int STAGE> struct Item {
 //          result and the item's two soft-clip slots.  The loop is software-pipelined: while item i runs
 //          the ladder, the SEQ chunks and thresholds of item i+1 and the queue entry of item i+2 are in flight.
 template <int NW, int SLOTS, int MODE, int STAGE, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void score_kernel(ScoreParams P) {
+__global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? 4 : 1) void score_kernel(ScoreParams P) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr int LUTK = STAGE == 0 ? LUT_A_DWORDS : LUT_DWORDS;   // k-mer tables this stage looks up
   constexpr int LUTW = LUTK + 256;                                  // + the byte -> 2-bit conversion table
@@ -527,15 +527,23 @@ template <int NW, int SLOTS, int MODE, int STAGE, int BLOCK> static int launch_s
 // stage A -> compaction of the survivors -> stage B of one MODE, kernel class picked by the longest read
 template <int MODE> static int launch_score_class(strl_ctx *ctx, const ScoreParams &P, uint32_t max_l) {
   int rc;
-  if (max_l <= 160) rc = launch_score<10, 64, MODE, 0, 256>(ctx, P, 512);
-  else if (max_l <= 256) rc = launch_score<16, 128, MODE, 0, 256>(ctx, P, 256);
-  else rc = launch_score<32, 256, MODE, 0, 64>(ctx, P, 512);
+  // Grid: the kernels stride over the queue, so any grid works; measured on 2^25-read batches the time keeps falling
+  // until ~8192 blocks for stage A and ~4096 for stage B (1.51 -> 1.29 ms per step against 512 blocks = two resident
+  // blocks per CU): surplus blocks are what lets the hardware even out the very uneven cost of the items.  The queue
+  // length lives on the device; the host knows an upper bound (reads of the batch / capacity of the segment queue).
+  const uint64_t upper = MODE == 0 ? P.n : (uint64_t)P.scap;
+  static const int env_a = getenv("STRL_GRID_A") ? atoi(getenv("STRL_GRID_A")) : 0, env_b = getenv("STRL_GRID_B") ? atoi(getenv("STRL_GRID_B")) : 0;
+  const int ga = env_a > 0 ? env_a : (int)std::min<uint64_t>(8192, std::max<uint64_t>(256, (upper + 255) / 256));
+  const int gb = env_b > 0 ? env_b : std::max(256, ga / 2);
+  if (max_l <= 160) rc = launch_score<10, 64, MODE, 0, 256>(ctx, P, ga);
+  else if (max_l <= 256) rc = launch_score<16, 128, MODE, 0, 256>(ctx, P, std::max(256, ga / 4));
+  else rc = launch_score<32, 256, MODE, 0, 64>(ctx, P, std::max(512, ga / 2));
   if (rc) return rc;
   hipLaunchKernelGGL((compact_kernel<1, MODE>), dim3(512), dim3(1024), 0, ctx->stream, P);
   STRL_HIP(hipGetLastError());
-  if (max_l <= 160) return launch_score<10, 64, MODE, 1, 256>(ctx, P, 512);
-  if (max_l <= 256) return launch_score<16, 128, MODE, 1, 256>(ctx, P, 256);
-  return launch_score<32, 256, MODE, 1, 64>(ctx, P, 512);
+  if (max_l <= 160) return launch_score<10, 64, MODE, 1, 256>(ctx, P, gb);
+  if (max_l <= 256) return launch_score<16, 128, MODE, 1, 256>(ctx, P, std::max(256, gb / 4));
+  return launch_score<32, 256, MODE, 1, 64>(ctx, P, std::max(512, gb / 2));
 }
 
 }  // namespace strl

@@ -29,6 +29,9 @@ static inline uint32_t strl_funnel_r(uint32_t lo, uint32_t hi, uint32_t s) {
 static inline int strl_ffs(uint32_t x) { return __builtin_ffs((int)x); }
 static inline int strl_popc(uint32_t x) { return __builtin_popcount(x); }
 static inline bool strl_any(bool p) { return p; }
+static inline int strl_wave_min(int v) { return v; }
+static inline uint32_t strl_max3(uint32_t a, uint32_t b, uint32_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+static inline uint32_t strl_bfe(uint32_t x, uint32_t off, uint32_t w) { return (x >> off) & ((1u << w) - 1u); }
 static inline uint32_t strl_lds_add(uint32_t *a, uint32_t v) { uint32_t o = *a; *a = o + v; return o; }
 #else
 #include <hip/hip_runtime.h>
@@ -39,6 +42,13 @@ STRL_DEV uint32_t strl_funnel_r(uint32_t lo, uint32_t hi, uint32_t s) { return _
 STRL_DEV int strl_ffs(uint32_t x) { return __ffs((int)x); }
 STRL_DEV int strl_popc(uint32_t x) { return __popc(x); }
 STRL_DEV bool strl_any(bool p) { return __any(p) != 0; }
+STRL_DEV int strl_wave_min(int v) {   // wave-uniform minimum (butterfly; once per k pass)
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o < v ? o : v; }
+  return __builtin_amdgcn_readfirstlane(v);
+}
+STRL_DEV uint32_t strl_max3(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }   // v_max3_u32
+STRL_DEV uint32_t strl_bfe(uint32_t x, uint32_t off, uint32_t w) { return __builtin_amdgcn_ubfe(x, off, w); }
 STRL_DEV uint32_t strl_lds_add(uint32_t *a, uint32_t v) { return atomicAdd(a, v); }  // lane-private: ds_add_rtn_u32
 #endif
 
@@ -58,8 +68,13 @@ __device__ unsigned long long g_phase[32];
 #endif
 
 // canonical-code lookup tables, indexed by the window value as it comes out of the LSB-first
-// 2-bit stream (first base in the LOW bits); entries are the reference's code (first base HIGH).
-constexpr int LUT_OFF2 = 0, LUT_OFF3 = 16, LUT_OFF4 = 80, LUT_OFF5 = 336, LUT_OFF6 = 1360, LUT_ENTRIES = 5456;
+// 2-bit stream (first base in the LOW bits).  For k = 5, 6 an entry is the reference's code (first base HIGH).  For
+// k <= 4 it is the dense CLASS ID of that code -- its rank among the 10 / 24 / 70 minimum-rotation codes -- so that a
+// k pass needs 10 / 24 / 18 rows of LDS bins instead of 16 / 64 / 64 (the histogram rows are what limits how many
+// waves fit a CU); LUT_C<k>[id] turns the winning id back into the code once per pass.
+constexpr int LUT_OFF2 = 0, LUT_OFF3 = 16, LUT_OFF4 = 80, LUT_C2 = 336, LUT_C3 = 346, LUT_C4 = 370, LUT_OFF5 = 440, LUT_OFF6 = 1464,
+              LUT_ENTRIES = 5560;
+template <int K> struct LutCls { static constexpr int off = K == 2 ? LUT_C2 : K == 3 ? LUT_C3 : LUT_C4, n = K == 2 ? 10 : K == 3 ? 24 : 70; };
 template <int K> struct LutOff;
 template <> struct LutOff<2> { static constexpr int v = LUT_OFF2; };
 template <> struct LutOff<3> { static constexpr int v = LUT_OFF3; };
@@ -203,45 +218,82 @@ STRL_DEV void hist_pass(const Seg<NW> &sg, bool active, uint32_t *tab, const uin
     }
     return;
   }
+  if (K <= 4) {
+    // Running argmax without compare/select chains: inside a batch of 8 windows key = newc << 15 | (7 - j) << 12 | code and
+    // one unsigned max picks the largest running count and, among equals, the earliest window; across batches an earlier
+    // batch keeps the lead unless a later one has a strictly larger count -- together the code inc() (utils.nim:192-195)
+    // would have kept.  (A single key with the global window index needs ~170 distinct constants, which the compiler
+    // parks in VGPRs for the whole kernel.)  Batches that lie below the shortest live segment of the wave (`umin`,
+    // wave-uniform) need no per-window bounds masks at all: idle lanes count into their own bins, their result is ignored.
+    static_assert(B == 8, "three tie-break bits");
+    const int umin = strl_wave_min(active ? nwin : 0x7fffffff);
+    uint32_t best = 0;
+#pragma unroll
+    for (int b0 = 0; b0 < NWIN; b0 += B) {
+      if (!strl_any(b0 < nwin)) break;  // wave-uniform early exit for short segments
+      uint32_t code[B], key[B], kc[B];
+#pragma unroll
+      for (int j = 0; j < B; ++j) code[j] = (b0 + j < NWIN) ? window_code<K, NW>(sg, lk, b0 + j) : 0u;
+#pragma unroll
+      for (int j = 0; j < B; ++j) kc[j] = (1u << 15) | ((7u - (uint32_t)j) << 12);
+      const bool full = b0 + B <= umin && b0 + B <= NWIN;      // wave-uniform
+      if (K <= 3) {  // 10 / 24 x 32-bit bins (one per class); windows past a lane's end hit a dummy row and get key 0
+        constexpr uint32_t DUMMY = (uint32_t)LutCls<K>::n;
+        uint32_t old[B];
+        if (full) {
+#pragma unroll
+          for (int j = 0; j < B; ++j) old[j] = strl_lds_add(tab + code[j] * STRL_LANES, 1u);
+#pragma unroll
+          for (int j = 0; j < B; ++j) key[j] = ((old[j] << 15) + kc[j]) | code[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < B; ++j) {
+            old[j] = 0;
+            if (b0 + j < NWIN) old[j] = strl_lds_add(tab + ((b0 + j < nwin) ? code[j] : DUMMY) * STRL_LANES, 1u);
+          }
+#pragma unroll
+          for (int j = 0; j < B; ++j) {
+            const uint32_t k = ((old[j] << 15) + kc[j]) | code[j];
+            key[j] = (b0 + j < NWIN && b0 + j < nwin) ? k : 0u;
+          }
+        }
+      } else {  // K == 4: 70 uint8 bins packed 4 per dword (18 rows + dummy); a lane's updates to one bin stay ordered
+        uint32_t old[B], sh[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) sh[j] = (code[j] & 3u) * 8u;
+        if (full) {
+#pragma unroll
+          for (int j = 0; j < B; ++j) old[j] = strl_lds_add(tab + (code[j] >> 2) * STRL_LANES, 1u << sh[j]);
+#pragma unroll
+          for (int j = 0; j < B; ++j) key[j] = ((strl_bfe(old[j], sh[j], 8) << 15) + kc[j]) | code[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < B; ++j) {
+            old[j] = 0;
+            if (b0 + j < NWIN) old[j] = strl_lds_add(tab + ((b0 + j < nwin) ? (code[j] >> 2) : 18u) * STRL_LANES, 1u << sh[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < B; ++j) {
+            const uint32_t k = ((strl_bfe(old[j], sh[j], 8) << 15) + kc[j]) | code[j];
+            key[j] = (b0 + j < NWIN && b0 + j < nwin) ? k : 0u;
+          }
+        }
+      }
+      uint32_t bb = key[0] > key[1] ? key[0] : key[1];
+#pragma unroll
+      for (int j = 2; j + 1 < B; j += 2) bb = strl_max3(bb, key[j], key[j + 1]);
+      if (bb > (best | 0x7fffu)) best = bb;      // strictly larger count only
+    }
+    if (best) { cmax = (int)(best >> 15); imax = lut[LutCls<K>::off + (best & 0xfffu)]; }   // no window at all: count 0, code "all ones" (utils.nim:197-198)
+    return;
+  }
 #pragma unroll
   for (int b0 = 0; b0 < NWIN; b0 += B) {
     if (!strl_any(b0 < nwin)) break;  // wave-uniform early exit for short segments
     uint32_t code[B];
 #pragma unroll
     for (int j = 0; j < B; ++j) code[j] = (b0 + j < NWIN) ? window_code<K, NW>(sg, lk, b0 + j) : 0u;
-    if (K <= 3) {  // 16 / 64 x 32-bit bins.  Branch-free: windows past this lane's end hit a dummy row and count 0.
-      constexpr uint32_t DUMMY = (K == 2) ? 16u : 64u;
-      uint32_t old[B];
-#pragma unroll
-      for (int j = 0; j < B; ++j) {
-        old[j] = 0;
-        if (b0 + j < NWIN) old[j] = strl_lds_add(tab + ((b0 + j < nwin) ? code[j] : DUMMY) * STRL_LANES, 1u);
-      }
-#pragma unroll
-      for (int j = 0; j < B; ++j) {
-        if (b0 + j < NWIN) {
-          const int newc = (b0 + j < nwin) ? (int)old[j] + 1 : 0;
-          if (newc > cmax) { cmax = newc; imax = code[j]; }  // inc(): first code to reach the final maximum wins
-        }
-      }
-    } else if (K == 4) {  // 256 uint8 bins packed 4 per dword (64 rows + dummy); a lane's updates to one bin stay ordered
-      uint32_t old[B];
-#pragma unroll
-      for (int j = 0; j < B; ++j) {
-        old[j] = 0;
-        if (b0 + j < NWIN) {
-          const uint32_t row = (b0 + j < nwin) ? (code[j] >> 2) : 64u;
-          old[j] = strl_lds_add(tab + row * STRL_LANES, 1u << ((code[j] & 3u) * 8u));
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < B; ++j) {
-        if (b0 + j < NWIN) {
-          const int newc = (b0 + j < nwin) ? (int)((old[j] >> ((code[j] & 3u) * 8u)) & 0xffu) + 1 : 0;
-          if (newc > cmax) { cmax = newc; imax = code[j]; }
-        }
-      }
-    } else {  // k = 5, 6 on long reads: open addressing, entry = (code+1) << 8 | count
+    {  // k = 5, 6 on long reads: open addressing, entry = (code+1) << 8 | count
 #pragma unroll
       for (int j = 0; j < B; ++j) {
         if (b0 + j < NWIN && b0 + j < nwin) {
@@ -362,7 +414,7 @@ struct ScoreState {
 };
 
 // rows of the wave's table region a k pass touches (direct bins + the dummy row, or the hash slots)
-template <int K, int SLOTS> struct KRows { static constexpr int v = (K == 2) ? 17 : (K <= 4) ? 65 : SLOTS; };
+template <int K, int SLOTS> struct KRows { static constexpr int v = (K == 2) ? 11 : (K == 3) ? 25 : (K == 4) ? 19 : SLOTS; };
 
 // The lane's thresholds for its segment length.  The host packs the five k-values of one (row, L) into one
 // 64-bit word (one byte each; L <= 510 and p <= 1 keep them <= 255), so an item needs THREE loads, issued with

@@ -2,6 +2,7 @@
 // the window -> minimum-rotation code LUT (slide_by, utils.nim:10-34) and the integer thresholds
 // of the score ladder (utils.nim:251,259 with the float64 expressions of the reference).
 #pragma once
+#include <stdlib.h>
 #include <algorithm>
 #include <vector>
 #include "score_core.h"
@@ -23,6 +24,16 @@ inline void build_lut(std::vector<uint16_t> &lut) {
         best = std::min(best, f);
       }
       lut[off[k] + v] = (uint16_t)best;
+    }
+    if (k <= 4) {   // canonical code -> dense class id (rank), and the way back
+      const int coff = k == 2 ? LUT_C2 : k == 3 ? LUT_C3 : LUT_C4;
+      std::vector<uint16_t> codes(lut.begin() + off[k], lut.begin() + off[k] + mask + 1);
+      std::sort(codes.begin(), codes.end());
+      codes.erase(std::unique(codes.begin(), codes.end()), codes.end());
+      if (codes.size() != (k == 2 ? 10u : k == 3 ? 24u : 70u)) abort();   // necklaces of length k over 4 letters
+      for (size_t id = 0; id < codes.size(); ++id) lut[coff + (int)id] = codes[id];
+      for (uint32_t v = 0; v <= mask; ++v)
+        lut[off[k] + v] = (uint16_t)(std::lower_bound(codes.begin(), codes.end(), lut[off[k] + v]) - codes.begin());
     }
   }
 }
