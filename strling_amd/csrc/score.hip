@@ -279,11 +279,11 @@ __global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
 }
 
 // Order-preserving-within-block compaction of a dense array with EMPTY holes into a queue: one global atomic
-// per 1024 slots, issued by a kernel that has nothing else to wait for (the scorers themselves never wait on
+// per 8192 slots, issued by a kernel that has nothing else to wait for (the scorers themselves never wait on
 // an atomic).  KIND 0: soft-clip slots -> soft queue.  KIND 1: stage-A survivors -> 32-byte stage-B items.
 template <int KIND, int MODE>
 __global__ __launch_bounds__(1024) void compact_kernel(ScoreParams P) {
-  __shared__ uint32_t wcnt[16];
+  __shared__ uint32_t wcnt[128];
   __shared__ uint32_t base_sh;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long below = (1ull << lane) - 1ull;
@@ -297,26 +297,40 @@ __global__ __launch_bounds__(1024) void compact_kernel(ScoreParams P) {
     src = P.sb_state[MODE]; ent = MODE == 0 ? P.queue : P.soft_queue; dst = P.sb_queue[MODE];
     cap = 0xffffffffu; cnt_idx = MODE == 0 ? CNT_SBW : CNT_SBS;
   }
-  for (uint32_t b0 = blockIdx.x * 1024u; b0 < n_src; b0 += gridDim.x * 1024u) {
-    const uint32_t i = b0 + threadIdx.x;
-    uint4 v = make_uint4(EMPTY, 0, 0, 0);
-    if (i < n_src) v = src[i];
-    const bool keep = v.x != EMPTY;
-    const unsigned long long m = __ballot(keep);
-    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
+  // U slots per thread and round: the same-address atomic that reserves queue space is what bounds this kernel
+  // (~88 per microsecond on the L2 atomic unit), so a round covers 8192 slots, not 1024.
+  constexpr int U = 8;
+  for (uint32_t b0 = blockIdx.x * (1024u * U); b0 < n_src; b0 += gridDim.x * (1024u * U)) {
+    uint4 v[U];
+    unsigned long long m[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = b0 + 1024u * u + threadIdx.x;
+      v[u] = make_uint4(EMPTY, 0, 0, 0);
+      if (i < n_src) v[u] = src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      m[u] = __ballot(v[u].x != EMPTY);
+      if (lane == 0) wcnt[u * 16 + wave] = (uint32_t)__popcll(m[u]);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
       uint32_t tot = 0;
-      for (int w = 0; w < 16; ++w) { const uint32_t c = wcnt[w]; wcnt[w] = tot; tot += c; }
+      for (int w = 0; w < 16 * U; ++w) { const uint32_t c = wcnt[w]; wcnt[w] = tot; tot += c; }
       base_sh = tot ? atomicAdd(&P.counters[cnt_idx], tot) : 0u;
     }
     __syncthreads();
-    if (keep) {
-      const uint32_t d = base_sh + wcnt[wave] + (uint32_t)__popcll(m & below);
-      if (KIND == 0) { if (d < cap) dst[d] = v; }
-      else {
-        dst[2 * (uint64_t)d] = ent[i];
-        dst[2 * (uint64_t)d + 1] = make_uint4(i, v.x, v.y, v.z);   // slot, best, res0, res1
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (v[u].x != EMPTY) {
+        const uint32_t i = b0 + 1024u * u + threadIdx.x;
+        const uint32_t d = base_sh + wcnt[u * 16 + wave] + (uint32_t)__popcll(m[u] & below);
+        if (KIND == 0) { if (d < cap) dst[d] = v[u]; }
+        else {
+          dst[2 * (uint64_t)d] = ent[i];
+          dst[2 * (uint64_t)d + 1] = make_uint4(i, v[u].x, v[u].y, v[u].z);   // slot, best, res0, res1
+        }
       }
     }
     __syncthreads();
@@ -666,7 +680,20 @@ int strl_ctx_set_opts(strl_ctx *c, const strl_opts *o) {
 int strl_ctx_set_genome(strl_ctx *c, const strl_genome_str *g) {
   if (!c) return STRL_ERR_ARG;
   STRL_HIP(hipSetDevice(c->device));
-  if (!g || g->n_tid <= 0) { c->n_tid = 0; c->n_iv = 0; return STRL_OK; }
+  if (!g || g->n_tid <= 0) {
+    // empty table: no chromosome is a key, nothing is skipped.  The kernels still dereference entry 0 of each array for
+    // lanes without a candidate read, so the arrays must exist.
+    const TidInfo t0{};
+    const int2 iv0 = make_int2(INT32_MAX, INT32_MIN);
+    const uint2 b0 = make_uint2(0, 0);
+    int rc0;
+    if ((rc0 = c->g_tid.reserve(sizeof t0)) || (rc0 = c->g_bins.reserve(sizeof b0)) || (rc0 = c->g_start.reserve(sizeof iv0))) return rc0;
+    STRL_HIP(hipMemcpy(c->g_tid.p, &t0, sizeof t0, hipMemcpyHostToDevice));
+    STRL_HIP(hipMemcpy(c->g_bins.p, &b0, sizeof b0, hipMemcpyHostToDevice));
+    STRL_HIP(hipMemcpy(c->g_start.p, &iv0, sizeof iv0, hipMemcpyHostToDevice));
+    c->n_tid = 0; c->n_iv = 0;
+    return STRL_OK;
+  }
   const int32_t nt = g->n_tid;
   const int64_t niv = g->iv_off[nt];
   std::vector<int32_t> st((size_t)std::max<int64_t>(niv, 1));
@@ -743,6 +770,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   P.n = n;
   P.tid = s->tid; P.pos = s->pos; P.end = s->end; P.seq_off = s->seq_off; P.l_seq = s->l_seq;
   P.clip_l = s->clip_l; P.clip_r = s->clip_r; P.mapq = s->mapq; P.cig = s->cig; P.seq4 = s->seq4;
+  if (!c->g_tid.p && (rc = strl_ctx_set_genome(c, nullptr))) return rc;   // never set: the empty table
   P.g_tid = c->g_tid.as<TidInfo>(); P.g_bins = c->g_bins.as<uint2>(); P.g_iv = c->g_start.as<int2>();
   P.n_tid = c->n_tid;
   P.lut = c->lut.as<uint16_t>(); P.thr = c->thr.as<uint64_t>();
@@ -759,7 +787,8 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   if (c->timing) ++c->ring_pos;
   if (tev) STRL_HIP(hipEventRecord(tev[0], c->stream));
   if (n) {
-    const int cblocks = (int)std::min<uint64_t>((n + 255) / 256, 2048);
+    static const int env_c = getenv("STRL_GRID_C") ? atoi(getenv("STRL_GRID_C")) : 0;
+    const int cblocks = (int)std::min<uint64_t>((n + 255) / 256, env_c > 0 ? (uint64_t)env_c : 1536);   // 2 x (256 CUs x 3 resident blocks at 164 VGPRs); measured 768..16384
     const bool vec = (((uintptr_t)P.tid | (uintptr_t)P.pos | (uintptr_t)P.end | (uintptr_t)P.whole) & 15u) == 0 && ((uintptr_t)P.cig & 3u) == 0;
     if (vec) hipLaunchKernelGGL(classify_kernel<true>, dim3(cblocks), dim3(256), 0, c->stream, P);
     else hipLaunchKernelGGL(classify_kernel<false>, dim3(cblocks), dim3(256), 0, c->stream, P);

@@ -91,6 +91,20 @@ def test_ragged_lengths_and_edge_cases(ctx, oracle):
     assert soft["res_after"].tolist() == [exp_soft[it][1] for it in items]
 
 
+def test_fresh_context_without_genome(oracle):
+    """no strl_ctx_set_genome at all, and an explicit empty table, on a context that never held one: nothing is skipped"""
+    rec, _ = synth.synth_wgs(300, seed=3, contig_len=100_000, n_contigs=2)
+    opts = oracle.make_opts(350, 0.8, 40)
+    exp_whole, _ = oracle_words(oracle, rec, None, opts)
+    for explicit in (False, True):
+        c = api.Context(0)
+        c.set_opts(0.8, 40, 350)
+        if explicit:
+            c.set_genome(None)
+        whole, soft, st = c.score_reads(rec)
+        assert np.array_equal(whole, exp_whole) and st.n_skipped == 0
+
+
 def test_empty_batch(ctx):
     rec = RecordBatch.from_fields([], [], [], [], [], [], [], [], [])
     ctx.set_opts(0.8, 40, 350)
