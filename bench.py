@@ -178,7 +178,7 @@ def main():
     # separate runs of tools/prof_run.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null if absent
     traffic = {}
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "e_traffic.json")))["kernels"]
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "f_traffic.json")))["kernels"]
         pick = {"classify_kernel": ["classify_kernel"], "score_kernel<whole>": ["<10, 64, 0, 0", "compact_kernel<1, 0>", "<10, 64, 0, 1"],
                 "score_kernel<soft>": ["compact_kernel<0, 0>", "<10, 64, 1, 0", "compact_kernel<1, 1>", "<10, 64, 1, 1"],
                 "cluster_pass": ["iota_kernel", "heads_kernel", "gather_kernel", "ends_kernel", "walk_kernel", "scatter_starts", "bounds_kernel"]}
@@ -192,7 +192,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic.get(dom) if (n == 2 ** 25 and L == 150) else None,
-                "traffic_note": "HBM bytes per launch of the dominant kernel group from profiles/r01/e_traffic.json (PMC, same workload); cluster_pass excludes the rocprim sort kernels",
+                "traffic_note": "HBM bytes per launch of the dominant kernel group from profiles/r01/f_traffic.json (PMC, same workload); cluster_pass excludes the rocprim sort kernels",
                 "kernel_ms": {k: round(v[0], 4) for k, v in kernels.items()},
                 "kernel_alg_bytes": {k: int(v[1]) for k, v in kernels.items()},
                 "pipeline_alg_GBps": round(sum(v[1] for v in kernels.values()) / (el / args.steps) / 1e9, 2),
