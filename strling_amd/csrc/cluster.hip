@@ -8,7 +8,7 @@
 //                   the reference's growth rule depends only on the start: <= 9 warm-up steps of
 //                   the running median-of-first-9, then a binary search for pos > posmed+max_dist+100,
 //   walk_kernel   : one lane per group follows start -> end links and flags the cluster heads,
-//   bounds_kernel : one lane per cluster: trim, anchor/support gate, split_cluster, bounds() and
+//   bounds_filter_kernel / bounds_rows_kernel : trim + support gate per cluster, then anchor gate, split_cluster, bounds() and
 //                   the callclusters gate, with Nim CountTable.largest slot-order tie-breaks
 //                   reproduced on the device (nim_tables.h).
 // HBM-bound integer work; sizes are ~1e6 treads per 30x sample (5e7 for a 50-sample merge).
@@ -44,6 +44,8 @@ struct ClusterParams {
   const uint32_t *cl_start; // [n_clusters] compacted heads
   const uint32_t *n_clusters;
   uint32_t *scratch;        // 4 * (16 * n_clusters + 3 * n) dwords
+  uint4 *cand;              // [n_clusters] clusters that pass the support gate: {cluster, first read after trim, end}
+  uint32_t *n_cand;
   RawBounds *out;           // [2 * n_clusters]
   uint32_t max_dist;
   int32_t min_support;
@@ -91,17 +93,32 @@ __global__ __launch_bounds__(64) void walk_kernel(ClusterParams P) {
   }
 }
 
+// Where the sorted reads of the cluster being worked on live: the global arrays, or a copy the wave staged in LDS
+// (indices stay the global sorted indices).
+struct GlobalView {
+  const uint32_t *p; const uint8_t *sp; const uint32_t *sm;
+  __device__ uint32_t pos(uint32_t i) const { return p[i]; }
+  __device__ uint8_t split(uint32_t i) const { return sp[i]; }
+  __device__ uint32_t sample(uint32_t i) const { return sm[i]; }
+};
+struct LdsView {
+  const uint32_t *p; const uint8_t *sp; const uint32_t *sm; uint32_t base;
+  __device__ uint32_t pos(uint32_t i) const { return p[i - base]; }
+  __device__ uint8_t split(uint32_t i) const { return sp[i - base]; }
+  __device__ uint32_t sample(uint32_t i) const { return sm[i - base]; }
+};
+
 // CountTable over the clip positions of one kind in [a, b) (sorted by position => equal keys adjacent).
-template <bool FILTER>
-__device__ void clip_table(const ClusterParams &P, uint32_t a, uint32_t b, uint8_t kind, int32_t cm, nim::CountTable &ct,
+template <bool FILTER, class V>
+__device__ void clip_table(const ClusterParams &P, const V &R, uint32_t a, uint32_t b, uint8_t kind, int32_t cm, nim::CountTable &ct,
                            uint32_t *scratch, uint32_t cap, uint32_t &n_reads, uint32_t &n_distinct) {
   ct.init(scratch, cap);
   n_reads = 0;
   n_distinct = 0;
   uint32_t run_key = 0, run = 0;
   for (uint32_t i = a; i < b; ++i) {
-    if (P.split[i] != kind) continue;
-    const uint32_t p = P.pos[i];
+    if (R.split(i) != kind) continue;
+    const uint32_t p = R.pos(i);
     if (FILTER) {                              // cluster.nim:193,197
       if (kind == STRL_SOFT_LEFT && !((int32_t)p < cm + (int32_t)P.max_clip_dist)) continue;
       if (kind == STRL_SOFT_RIGHT && !((int32_t)p > cm - (int32_t)P.max_clip_dist)) continue;
@@ -116,7 +133,8 @@ __device__ void clip_table(const ClusterParams &P, uint32_t a, uint32_t b, uint8
 }
 
 // bounds() (cluster.nim:175-250) + gate (callclusters.nim:52-66) for reads [a, b)
-__device__ void emit_bounds(const ClusterParams &P, uint32_t a, uint32_t b, uint32_t cl_left_most, uint32_t cl_right_most,
+template <class V>
+__device__ void emit_bounds(const ClusterParams &P, const V &R, uint32_t a, uint32_t b, uint32_t cl_left_most, uint32_t cl_right_most,
                             uint32_t *scratch, uint32_t cap, RawBounds &o) {
   o.valid = 0;
   o.first = a;
@@ -128,7 +146,7 @@ __device__ void emit_bounds(const ClusterParams &P, uint32_t a, uint32_t b, uint
     for (uint32_t i = 0; i < tl; ++i) v[i] = 0;
     uint32_t best = 0;
     for (uint32_t i = a; i < b; ++i) {
-      const uint32_t sm = P.sample[i];
+      const uint32_t sm = R.sample(i);
       uint32_t h = (sm * 0x9E3779B1u) & (tl - 1);
       while (v[h] && k[h] != sm) h = (h + 1) & (tl - 1);
       k[h] = sm;
@@ -138,13 +156,13 @@ __device__ void emit_bounds(const ClusterParams &P, uint32_t a, uint32_t b, uint
     if ((int32_t)best < P.min_support) return;
   }
   if (n >= 65535u) return;                    // callclusters.nim:53-55
-  const uint32_t center = P.pos[a + (n >> 1)];
+  const uint32_t center = R.pos(a + (n >> 1));
   const int32_t cm = (int32_t)center;
   nim::CountTable ct;
   uint32_t nl, nr, dl, dr, left = 0, right = 0, key, val;
-  clip_table<true>(P, a, b, STRL_SOFT_LEFT, cm, ct, scratch, cap, nl, dl);
+  clip_table<true>(P, R, a, b, STRL_SOFT_LEFT, cm, ct, scratch, cap, nl, dl);
   if (dl) { ct.largest(key, val); if (val > 1) left = key; }          // cluster.nim:204-207
-  clip_table<true>(P, a, b, STRL_SOFT_RIGHT, cm, ct, scratch, cap, nr, dr);
+  clip_table<true>(P, R, a, b, STRL_SOFT_RIGHT, cm, ct, scratch, cap, nr, dr);
   if (dr) { ct.largest(key, val); if (val > 1) right = key; }         // :208-211
   if (left == 0) left = center;                                       // :214-217
   if (right == 0) right = left + 1;
@@ -152,8 +170,8 @@ __device__ void emit_bounds(const ClusterParams &P, uint32_t a, uint32_t b, uint
     if (nl > 0 && nr > 0) { const uint32_t t = left; left = right; right = t; }
     else left = right - 1;
   }
-  uint32_t lm = cl_left_most > 0 ? cl_left_most : P.pos[a];           // :234-241 (posns sorted: min/max are the ends)
-  uint32_t rm = cl_right_most > 0 ? cl_right_most : P.pos[b - 1];
+  uint32_t lm = cl_left_most > 0 ? cl_left_most : R.pos(a);           // :234-241 (posns sorted: min/max are the ends)
+  uint32_t rm = cl_right_most > 0 ? cl_right_most : R.pos(b - 1);
   if (lm > left) lm = left;                                           // :244-247
   if (rm < right) rm = right;
   if (right - left > 1000u) return;                                   // callclusters.nim:57-59
@@ -165,48 +183,105 @@ __device__ void emit_bounds(const ClusterParams &P, uint32_t a, uint32_t b, uint
   o.valid = 1;
 }
 
-__global__ __launch_bounds__(64) void bounds_kernel(ClusterParams P) {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t nc = *P.n_clusters;
-  if (c >= nc) return;
-  RawBounds *o = P.out + 2 * (uint64_t)c;
-  o[0].valid = 0; o[1].valid = 0;
-  uint32_t s = P.cl_start[c];
-  const uint32_t e = P.ends[s];
-  uint32_t n = e - s;
-  const uint32_t cap = 16u + 3u * n;
-  uint32_t *scratch = P.scratch + 4ull * (16ull * c + 3ull * s);
-  // trim(max_dist + 100), cluster.nim:252-257 -- `lo` is computed once
-  {
-    const uint32_t md = P.max_dist + 100u;
-    const int64_t lo64 = (int64_t)posmed_at(P.pos, s, n) - (int64_t)md;
-    const uint32_t lo = lo64 < 0 ? 0u : (uint32_t)lo64;
-    while (n > 1 && P.pos[s] < lo) { ++s; --n; }
-  }
-  const uint32_t pm = posmed_at(P.pos, s, n);
-  const uint32_t last = P.pos[e - 1], firstp = P.pos[s];
-  const uint32_t right_most = last > pm + P.max_dist ? last : pm + P.max_dist;      // :343
-  const uint32_t left_most = firstp < pm - P.max_dist ? firstp : pm - P.max_dist;   // :344 (uint32 wrap kept)
-  if ((int64_t)n < (int64_t)P.min_support) return;                                  // :346
+// has_anchor, split_cluster and bounds() of one cluster that passed the support gate (reads [s, e) after trim)
+template <class V>
+__device__ void cluster_rows(const ClusterParams &P, const V &R, uint32_t s, uint32_t e, uint32_t left_most, uint32_t right_most,
+                             uint32_t *scratch, uint32_t cap, RawBounds *o) {
   bool anchor = false;
-  for (uint32_t i = s; i < e && !anchor; ++i) anchor = P.split[i] == STRL_SOFT_NONE; // has_anchor :275-281
+  for (uint32_t i = s; i < e && !anchor; ++i) anchor = R.split(i) == STRL_SOFT_NONE; // has_anchor :275-281
   if (!anchor) return;
   // split_cluster, cluster.nim:283-320
   nim::CountTable ct;
   uint32_t nl, nr, dl, dr, llk = 0, llv = 0, rlk = 0, rlv = 0;
-  clip_table<false>(P, s, e, STRL_SOFT_RIGHT, 0, ct, scratch, cap, nr, dr);
+  clip_table<false>(P, R, s, e, STRL_SOFT_RIGHT, 0, ct, scratch, cap, nr, dr);
   if (dr) ct.largest(rlk, rlv);
-  clip_table<false>(P, s, e, STRL_SOFT_LEFT, 0, ct, scratch, cap, nl, dl);
+  clip_table<false>(P, R, s, e, STRL_SOFT_LEFT, 0, ct, scratch, cap, nl, dl);
   if (dl) ct.largest(llk, llv);
   if (dr && dl && rlk < llk && (int64_t)rlv >= P.min_support && (int64_t)llv >= P.min_support &&
       (double)llv / (double)dl > 0.5 && (double)rlv / (double)dr > 0.5) {
     const uint32_t mid = (uint32_t)(0.5 + ((double)rlk + (double)llk) / 2.0);
     uint32_t m = s;
-    while (m < e && P.pos[m] < mid) ++m;
-    emit_bounds(P, s, m, 0u, mid - 1u, scratch, cap, o[0]);                         // :313
-    emit_bounds(P, m, e, mid, 0u, scratch, cap, o[1]);                              // :314
+    while (m < e && R.pos(m) < mid) ++m;
+    emit_bounds(P, R, s, m, 0u, mid - 1u, scratch, cap, o[0]);                      // :313
+    emit_bounds(P, R, m, e, mid, 0u, scratch, cap, o[1]);                           // :314
   } else {
-    emit_bounds(P, s, e, left_most, right_most, scratch, cap, o[0]);
+    emit_bounds(P, R, s, e, left_most, right_most, scratch, cap, o[0]);
+  }
+}
+
+// bounds in two launches.  bounds_filter_kernel: one lane per cluster for the cheap part (trim, support gate: 98 % of the
+// clusters of a WGS sample end there); survivors are appended to a candidate list with one atomic per 1024 clusters.
+// bounds_rows_kernel: one WAVE per candidate -- all lanes copy the cluster's reads into LDS in one coalesced round trip,
+// then one lane runs the sequential CountTable logic out of LDS (its tables live there too).  With one lane per cluster
+// and every read and table access a dependent global load, the single kernel took 80 us for 5x10^5 treads, all latency.
+constexpr uint32_t BK_LIM = 256;   // reads of a cluster staged in LDS; larger clusters use the global arrays
+__global__ __launch_bounds__(1024) void bounds_filter_kernel(ClusterParams P) {
+  __shared__ uint32_t wcnt[16];
+  __shared__ uint32_t base_sh;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nc = *P.n_clusters;
+  uint32_t s = 0, e = 0;
+  bool cand = false;
+  if (c < nc) {
+    RawBounds *o = P.out + 2 * (uint64_t)c;
+    o[0].valid = 0; o[1].valid = 0;
+    s = P.cl_start[c];
+    e = P.ends[s];
+    uint32_t n = e - s;
+    // trim(max_dist + 100), cluster.nim:252-257 -- `lo` is computed once
+    const uint32_t md = P.max_dist + 100u;
+    const int64_t lo64 = (int64_t)posmed_at(P.pos, s, n) - (int64_t)md;
+    const uint32_t lo = lo64 < 0 ? 0u : (uint32_t)lo64;
+    while (n > 1 && P.pos[s] < lo) { ++s; --n; }
+    cand = (int64_t)n >= (int64_t)P.min_support;                                      // :346
+  }
+  const unsigned long long m = __ballot(cand);
+  if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int w = 0; w < 16; ++w) { const uint32_t x = wcnt[w]; wcnt[w] = tot; tot += x; }
+    base_sh = tot ? atomicAdd(P.n_cand, tot) : 0u;
+  }
+  __syncthreads();
+  if (cand) P.cand[base_sh + wcnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint4(c, s, e, 0u);
+}
+
+__global__ __launch_bounds__(64) void bounds_rows_kernel(ClusterParams P) {
+  __shared__ uint32_t l_pos[BK_LIM], l_sample[BK_LIM];
+  __shared__ uint8_t l_split[BK_LIM];
+  __shared__ uint32_t l_scratch[4 * (16 + 3 * BK_LIM)];
+  const int lane = threadIdx.x;
+  const uint32_t n_cand = *P.n_cand;
+  for (uint32_t k = blockIdx.x; k < n_cand; k += gridDim.x) {
+    const uint4 cd = P.cand[k];
+    const uint32_t cc = cd.x, cs = cd.y, ce = cd.z, cn = ce - cs;
+    RawBounds *o = P.out + 2 * (uint64_t)cc;
+    const bool in_lds = cn <= BK_LIM;
+    if (in_lds) {
+      for (uint32_t i = lane; i < cn; i += 64) {
+        l_pos[i] = P.pos[cs + i];
+        l_split[i] = P.split[cs + i];
+        l_sample[i] = P.sample[cs + i];
+      }
+      __syncthreads();
+    }
+    if (lane == 0) {
+      const uint32_t n = cn;
+      const uint32_t pm = in_lds ? l_pos[((n < 9u ? n : 9u) - 1u) >> 1] : posmed_at(P.pos, cs, n);
+      const uint32_t last = in_lds ? l_pos[n - 1] : P.pos[ce - 1], firstp = in_lds ? l_pos[0] : P.pos[cs];
+      const uint32_t right_most = last > pm + P.max_dist ? last : pm + P.max_dist;    // :343
+      const uint32_t left_most = firstp < pm - P.max_dist ? firstp : pm - P.max_dist; // :344 (uint32 wrap kept)
+      if (in_lds) cluster_rows(P, LdsView{l_pos, l_split, l_sample, cs}, cs, ce, left_most, right_most, l_scratch, 16u + 3u * cn, o);
+      else {
+        // scratch of the global path: the region of the ORIGINAL cluster start is as large as this cluster needs
+        const uint32_t s0 = P.cl_start[cc];
+        cluster_rows(P, GlobalView{P.pos, P.split, P.sample}, cs, ce, left_most, right_most, P.scratch + 4ull * (16ull * cc + 3ull * s0),
+                     16u + 3u * (ce - s0), o);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -354,7 +429,7 @@ static int cluster_device_pass(strl_ctx *c, bool replay) {
   hipLaunchKernelGGL(walk_kernel, dim3((n_groups + 63) / 64), dim3(64), 0, st, P);
   t = tmpb;
   STRL_HIP(hipcub::DeviceScan::ExclusiveSum(B[B_TMP].p, t, d_head, d_scan, (int)n, st));
-  if ((rc = need(B_F, (size_t)n * 4 + 64))) return rc;
+  if ((rc = need(B_F, (size_t)n * 4 + 96 + (size_t)n * 16))) return rc;   // cluster starts, two counters, candidate list
   uint32_t *d_cl_start = B[B_F].as<uint32_t>(), *d_ncl = d_cl_start + n;
   hipLaunchKernelGGL(scatter_starts_kernel, dim3(nb), dim3(TB), 0, st, n, d_head, d_scan, d_cl_start, d_ncl);
   if (!replay) {
@@ -371,7 +446,11 @@ static int cluster_device_pass(strl_ctx *c, bool replay) {
       if ((rc = need(B_KEYG, std::max((size_t)n * 8, (size_t)2 * n_clusters * sizeof(RawBounds))))) return rc;   // reused as output
     }
     P.cl_start = d_cl_start; P.n_clusters = d_ncl; P.scratch = c->soft_tmp.as<uint32_t>(); P.out = B[B_KEYG].as<RawBounds>();
-    hipLaunchKernelGGL(bounds_kernel, dim3((n_clusters + 63) / 64), dim3(64), 0, st, P);
+    P.n_cand = d_ncl + 1;
+    P.cand = reinterpret_cast<uint4 *>(B[B_F].as<uint8_t>() + (((size_t)n * 4 + 64 + 15) & ~(size_t)15));
+    STRL_HIP(hipMemsetAsync(P.n_cand, 0, 4, st));
+    hipLaunchKernelGGL(bounds_filter_kernel, dim3((n_clusters + 1023) / 1024), dim3(1024), 0, st, P);
+    hipLaunchKernelGGL(bounds_rows_kernel, dim3(std::min<uint32_t>(n_clusters, 32768u)), dim3(64), 0, st, P);
     STRL_HIP(hipGetLastError());
   }
   if (c->timing) STRL_HIP(hipEventRecord(c->ev[7], st));

@@ -63,6 +63,25 @@ def test_parallel_stream_reader_equals_plain_reader(sample, threads, blocks, bat
     assert a.stdout == b.stdout and a.stdout.count("\n") > sample["rec"].n
 
 
+@pytest.mark.parametrize("block,threads,chunk", [(61, "5", "7"), (100, "3", "1"), (333, "8", "2"), (4096, "2", "0")])
+def test_stream_reader_with_tiny_bgzf_blocks(tmp_path, block, threads, chunk):
+    """records (and their fixed 36-byte part) straddle many BGZF blocks and superchunks; also an empty BAM"""
+    rec, _ = synth.synth_wgs(150, seed=8, n_contigs=2, contig_len=50_000, read_len=151)
+    bam = str(tmp_path / "tiny.bam")
+    bamio.write_bam(bam, rec, block=block, index=False)
+    a = _run(["_dump", bam])
+    b = _run(["_dump", bam, "stream", "37"], env=dict(os.environ, STRL_THREADS=threads, STRL_CHUNK_BLOCKS=chunk))
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+    assert a.stdout == b.stdout and a.stdout.count("\n") >= rec.n
+    empty = synth.synth_wgs(150, seed=8, n_contigs=2, contig_len=50_000)[0]
+    from strling_amd.records import RecordBatch
+    none = RecordBatch.from_fields([], [], [], [], [], [], [], [], [], targets=empty.targets)
+    bam0 = str(tmp_path / "empty.bam")
+    bamio.write_bam(bam0, none, index=False)
+    c = _run(["_dump", bam0, "stream"], env=dict(os.environ, STRL_THREADS=threads))
+    assert c.returncode == 0 and c.stdout == _run(["_dump", bam0]).stdout and c.stdout.count("\n") == 3
+
+
 def test_indexed_region_reads(tmp_path):
     """.bai linear index + region read == a scan of all records with htslib's iterator filter (tid, pos < end, endpos > beg)"""
     rec, _ = synth.synth_wgs(5000, seed=3, n_contigs=3, contig_len=200_000)
