@@ -44,9 +44,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    local = local % torch.cuda.device_count()       # (a 2-rank dry run on a 1-GPU box maps both ranks to cuda:0)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("BENCH_BACKEND", "nccl")   # nccl == RCCL on ROCm; gloo only for dry runs of the N > 1 path
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local)
 
     # ---- synthetic S1 base sample on the host, tiled into HBM -------------------------------------
@@ -100,7 +105,11 @@ def main():
     cstream = torch.cuda.ExternalStream(ctx.stream)
     if world > 1:
         try:
-            t_local = torch.from_numpy(np.ascontiguousarray(treads).view(np.uint8).copy()).to(dev)
+            t_mine = torch.from_numpy(np.ascontiguousarray(treads).view(np.uint8).copy()).to(dev)
+            n_max = torch.tensor([t_mine.numel()], dtype=torch.int64, device=dev)
+            dist.all_reduce(n_max, op=dist.ReduceOp.MAX)      # ranks hold different samples: pad to the largest tread array
+            t_local = torch.zeros(int(n_max.item()), dtype=torch.uint8, device=dev)
+            t_local[:t_mine.numel()] = t_mine
             t_all = torch.empty(world * t_local.numel(), dtype=torch.uint8, device=dev)
             gather_done = torch.cuda.Event()
 
@@ -222,7 +231,7 @@ def main():
             "value": round(total_reads / el, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32 integer", "data": "synthetic",
-            "config": {"workload": "1xMI355X: 30x 150 bp PE synthetic WGS, k=2-6 repeat-unit scorer + soft-clip scan + on-GPU radix-sort/segmented clustering (BASELINE.json configs[1]+[2])",
+            "config": {"workload": f"{world}xMI355X: 30x 150 bp PE synthetic WGS, k=2-6 repeat-unit scorer + soft-clip scan + on-GPU radix-sort/segmented clustering (BASELINE.json configs[1]+[2])",
                        "reads_per_gpu": n, "read_len": L, "unique_reads_per_gpu": n_base, "tiles": tiles,
                        "skipped_frac": round(st.n_skipped / n, 4), "scored_reads": int(st.n_scored), "soft_items": int(st.n_soft_items),
                        "str_reads_clustered": int(treads.size), "clusters": int(cst.n_clusters), "bounds": int(len(bounds)),
