@@ -1,0 +1,110 @@
+"""Randomised end-to-end sweep of the CLI (extract -> call [-l/-b], extract x3 -> merge [-l]) against the oracle.
+usage: python tools/fuzz_call.py [seconds]     (GPU box)"""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+from strling_amd import bamio, build, synth
+from oracle import oracle as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(77)
+CLI = build.CLI
+
+
+def run(args):
+    r = subprocess.run([CLI] + args, capture_output=True, text=True)
+    assert r.returncode == 0, (args, r.stderr[-600:])
+    return r
+
+
+def loci_bed(rows, targets, k0):
+    """loci the reference accepts (parse_bed asserts left_most <= right_most, i.e. the locus must start inside its contig)"""
+    length = dict(targets)
+    out = []
+    for k, r in enumerate(rows):
+        f = r.split("\t")
+        if (k + k0) % 2 == 0:
+            out.append(f"{f[0]}\t{max(0, int(f[1]) - 3)}\t{int(f[2]) + 5}\t{f[3]}\tlocus{k}")
+        elif (k + k0) % 3 == 0 and int(f[1]) + 1540 < length[f[0]]:
+            out.append(f"{f[0]} {int(f[1]) + 1500} {int(f[1]) + 1540} {f[3]}")
+    out.append(f"{targets[0][0]}\t100\t1500\tAC\twide")
+    return "\n".join(out) + "\n"
+
+
+t0 = time.time()
+n_call = n_merge = n_rows = 0
+with tempfile.TemporaryDirectory() as d:
+    while time.time() - t0 < budget:
+        seed = int(rng.integers(1, 1 << 30))
+        nc = int(rng.choice([2, 3, 5]))
+        kw = dict(n_contigs=nc, contig_len=int(rng.choice([20_000, 40_000, 80_000])), str_frac=float(rng.choice([0.01, 0.05, 0.15])),
+                  soft_frac=float(rng.choice([0.03, 0.15])), unmapped_frac=float(rng.choice([0.005, 0.03])))
+        n_pairs = int(rng.choice([3000, 6000, 12000]))
+        m, q = int(rng.choice([2, 3, 5])), int(rng.choice([0, 20, 40]))
+        c, t = int(rng.choice([0, 0, 1])), int(rng.choice([0, 0, 2]))
+        tag = f"seed={seed} pairs={n_pairs} m={m} q={q} c={c} t={t} {kw}"
+        if rng.random() < 0.7:          # ---- extract -> call ----
+            rec, g = synth.synth_wgs(n_pairs, seed=seed, **kw)
+            bam, bed, binp, pre = (os.path.join(d, x) for x in ("s.bam", "g.str", "s.bin", "o"))
+            bamio.write_bam(bam, rec)
+            bamio.write_genome_bed(bed, g, rec.targets)
+            run(["extract", "-g", bed, "-q", str(q), bam, binp])
+            frag = synth.frag_hist(rec)
+            tr = O.extract(rec, g, O.make_opts(O.median(frag), 0.8, q))
+            kwc = dict(min_support=m, min_mapq=q, min_clip=c, min_clip_total=t)
+            eb, eg, eu = O.call(tr, rec, frag, **kwc)
+            args = ["call", "-m", str(m), "-q", str(q), "-c", str(c), "-t", str(t), "-o", pre]
+            extra = {}
+            rows = ["\t".join(l.split("\t")[:11]) for l in eb.splitlines()[1:]]
+            if rows and rng.random() < 0.5:
+                bt = "#h\n" + "\n".join(rows[: max(1, len(rows) - 1)]) + "\n"
+                open(os.path.join(d, "b.txt"), "w").write(bt)
+                args += ["-b", os.path.join(d, "b.txt")]
+                extra["bounds_text"] = bt
+            if rows and rng.random() < 0.5:
+                lt = loci_bed(rows, rec.targets, int(rng.integers(0, 3)))
+                open(os.path.join(d, "l.bed"), "w").write(lt)
+                args += ["-l", os.path.join(d, "l.bed")]
+                extra["loci_text"] = lt
+            if extra:
+                eb, eg, eu = O.call(tr, rec, frag, **kwc, **extra)
+            run(args + [bam, binp])
+            for suf, exp in (("-bounds.txt", eb), ("-genotype.txt", eg), ("-unplaced.txt", eu)):
+                assert open(pre + suf).read() == exp, (suf, tag, extra.keys())
+            n_call += 1
+            n_rows += eb.count("\n") - 1
+        else:                            # ---- three samples -> merge ----
+            bins, parts, frags, targets = [], [], [], None
+            for s_i in range(3):
+                rec, g = synth.synth_wgs(n_pairs // 2, seed=seed + s_i, **kw)
+                targets = rec.targets
+                frag = synth.frag_hist(rec)
+                tr = O.extract(rec, g, O.make_opts(O.median(frag), 0.8, 40))
+                p = os.path.join(d, f"m{s_i}.bin")
+                open(p, "wb").write(O.bin_write(0.8, 40, frag, bamio.sam_header(rec.targets), tr, rec.qname_off, rec.qnames))
+                bins.append(p)
+                tr = tr[tr["tid"] >= 0].copy()
+                tr["qname_id"] = s_i
+                parts.append(tr)
+                frags.append(frag)
+            merged = np.concatenate(parts)
+            frag = np.sum(frags, axis=0).astype(np.uint32)
+            window, mcd = O.median(frag, 0.98), int(0.5 * O.median(frag, 0.5))
+            exp = O.merge_text(merged, window, targets, min_support=m, min_clip=c, min_clip_total=t, max_clip_dist=mcd)
+            args = ["merge", "-m", str(m), "-c", str(c), "-t", str(t), "-o", os.path.join(d, "j")]
+            rows = exp.splitlines()[1:]
+            if rows and rng.random() < 0.5:
+                lt = loci_bed(rows, targets, int(rng.integers(0, 3)))
+                open(os.path.join(d, "ml.bed"), "w").write(lt)
+                args += ["-l", os.path.join(d, "ml.bed")]
+                exp = O.merge_text(merged, window, targets, min_support=m, min_clip=c, min_clip_total=t, max_clip_dist=mcd, loci_text=lt)
+            run(args + bins)
+            assert open(os.path.join(d, "j-bounds.txt")).read() == exp, ("merge", tag)
+            n_merge += 1
+            n_rows += exp.count("\n") - 1
+print(f"fuzz_call ok: {n_call} extract->call runs, {n_merge} merges, {n_rows} bounds rows identical to the oracle in {time.time() - t0:.0f} s")
