@@ -77,7 +77,7 @@ struct ScoreParams {
   const uint64_t *thr;
   uint32_t *whole;
   uint4 *queue;        // [n]      scoring queue (classify -> stage A, whole reads)
-  uint4 *soft_dense;   // [2n]     two slots per scored read (left / right clip) or EMPTY
+  uint8_t *soft_flag;  // [n]      per scored read: bit 0 / 1 = its left / right clip has to be scored (add_soft gates)
   uint4 *soft_queue;   // [scap]   compacted soft-clip items
   uint4 *sb_state[2];  // dense hand-over of stage A: {best | EMPTY, res0, res1, -} per item
   uint4 *sb_queue[2];  // compacted stage-B items (2 x uint4 each)
@@ -291,8 +291,8 @@ __global__ __launch_bounds__(1024) void compact_kernel(ScoreParams P) {
   const uint4 *src;
   const uint4 *ent = nullptr;
   uint4 *dst;
-  if (KIND == 0) { n_src = 2u * P.counters[CNT_QUEUE]; src = P.soft_dense; dst = P.soft_queue; cap = P.scap; cnt_idx = CNT_SOFT; }
-  else {
+  static_assert(KIND == 1, "soft items have their own compaction kernel");
+  {
     n_src = MODE == 0 ? P.counters[CNT_QUEUE] : min(P.counters[CNT_SOFT], P.scap);
     src = P.sb_state[MODE]; ent = MODE == 0 ? P.queue : P.soft_queue; dst = P.sb_queue[MODE];
     cap = 0xffffffffu; cnt_idx = MODE == 0 ? CNT_SBW : CNT_SBS;
@@ -331,6 +331,52 @@ __global__ __launch_bounds__(1024) void compact_kernel(ScoreParams P) {
           dst[2 * (uint64_t)d] = ent[i];
           dst[2 * (uint64_t)d + 1] = make_uint4(i, v[u].x, v[u].y, v[u].z);   // slot, best, res0, res1
         }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Soft-clip items of the scored reads: flag byte + the read's queue entry -> segment items {id << 1 | side, seq_off, first
+// base, length} in the soft queue (left clip before right clip, reads in queue order within a block round).  One
+// queue-space atomic per 8192 reads.
+__global__ __launch_bounds__(1024) void soft_compact_kernel(ScoreParams P) {
+  __shared__ uint32_t wcnt[128];
+  __shared__ uint32_t base_sh;
+  constexpr int U = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const uint32_t n_src = P.counters[CNT_QUEUE];
+  for (uint32_t b0 = blockIdx.x * (1024u * U); b0 < n_src; b0 += gridDim.x * (1024u * U)) {
+    uint32_t f[U];
+    unsigned long long m0[U], m1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = b0 + 1024u * u + threadIdx.x;
+      f[u] = i < n_src ? (uint32_t)P.soft_flag[i] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      m0[u] = __ballot((f[u] & 1u) != 0);
+      m1[u] = __ballot((f[u] & 2u) != 0);
+      if (lane == 0) wcnt[u * 16 + wave] = (uint32_t)(__popcll(m0[u]) + __popcll(m1[u]));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t tot = 0;
+      for (int w = 0; w < 16 * U; ++w) { const uint32_t c = wcnt[w]; wcnt[w] = tot; tot += c; }
+      base_sh = tot ? atomicAdd(&P.counters[CNT_SOFT], tot) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (f[u]) {
+        const uint32_t i = b0 + 1024u * u + threadIdx.x;
+        const uint4 e = P.queue[i];
+        const uint32_t L = e.z & 0xffffu, cl = e.z >> 16, cr = e.w & 0xffffu;
+        uint32_t d = base_sh + wcnt[u * 16 + wave] + (uint32_t)(__popcll(m0[u] & below) + __popcll(m1[u] & below));
+        if (f[u] & 1u) { if (d < P.scap) P.soft_queue[d] = make_uint4(e.x << 1, e.y, 0u, cl < L ? cl : L); ++d; }
+        if (f[u] & 2u) { const uint32_t c2 = cr < L ? cr : L; if (d < P.scap) P.soft_queue[d] = make_uint4((e.x << 1) | 1u, e.y, L - c2, c2); }
       }
     }
     __syncthreads();
@@ -492,22 +538,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? 4 : 1) void sco
       P.sb_state[MODE][cur.slot] = fwd ? make_uint4((uint32_t)st.best, st.res0, st.res1, 0u) : make_uint4(EMPTY, 0u, 0u, 0u);
     if (MODE == 0) {
       if (cur.act) {
-        uint4 sl = make_uint4(EMPTY, 0, 0, 0), sr = make_uint4(EMPTY, 0, 0, 0);
+        uint32_t flag = 0;
         if (fin) {
           P.whole[cur.id] = o0;
           // add_soft gates, extract.nim:97-106
           if (cur.mq >= P.min_mapq && (cur.cg & (STRL_CIG_FIRST_S | STRL_CIG_LAST_S))) {
             const bool has_unit = STRL_RES_K(o0) != 0;
-            if ((cur.cg & STRL_CIG_FIRST_S) && (has_unit || cur.cl > 16))
-              sl = make_uint4(cur.id << 1, cur.seq_off, 0u, cur.cl < (uint32_t)cur.L ? cur.cl : (uint32_t)cur.L);
+            if ((cur.cg & STRL_CIG_FIRST_S) && (has_unit || cur.cl > 16)) flag |= 1u;
             // with a single cigar op both loop iterations are cig_index == 0 (the host replays the duplicate)
-            if ((cur.cg & STRL_CIG_LAST_S) && !(cur.cg & STRL_CIG_ONE_OP) && (has_unit || cur.cr > 16))
-              { const uint32_t cl2 = cur.cr < (uint32_t)cur.L ? cur.cr : (uint32_t)cur.L;
-                sr = make_uint4((cur.id << 1) | 1u, cur.seq_off, (uint32_t)cur.L - cl2, cl2); }
+            if ((cur.cg & STRL_CIG_LAST_S) && !(cur.cg & STRL_CIG_ONE_OP) && (has_unit || cur.cr > 16)) flag |= 2u;
           }
         }
-        P.soft_dense[2 * (uint64_t)cur.slot] = sl;       // forwarded items leave EMPTY; stage B overwrites
-        P.soft_dense[2 * (uint64_t)cur.slot + 1] = sr;
+        P.soft_flag[cur.slot] = (uint8_t)flag;           // forwarded items leave 0; stage B overwrites
       }
     } else {
       if (fin && cur.slot < P.soft_cap) {
@@ -759,7 +801,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   const uint64_t n1 = std::max<uint64_t>(n, 1);
   const uint64_t scap = std::max<uint64_t>(std::min<uint64_t>(soft_cap, 2 * n), 1);
   if ((rc = c->queue.reserve((size_t)n1 * 16))) return rc;
-  if ((rc = c->soft_dense.reserve((size_t)n1 * 32))) return rc;
+  if ((rc = c->soft_dense.reserve((size_t)n1 + 64))) return rc;
   if ((rc = c->soft_queue.reserve((size_t)scap * 16))) return rc;
   if ((rc = c->sb_state_w.reserve((size_t)n1 * 16))) return rc;
   if ((rc = c->sb_state_s.reserve((size_t)scap * 16))) return rc;
@@ -774,7 +816,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   P.g_tid = c->g_tid.as<TidInfo>(); P.g_bins = c->g_bins.as<uint2>(); P.g_iv = c->g_start.as<int2>();
   P.n_tid = c->n_tid;
   P.lut = c->lut.as<uint16_t>(); P.thr = c->thr.as<uint64_t>();
-  P.whole = whole; P.queue = c->queue.as<uint4>(); P.soft_dense = c->soft_dense.as<uint4>();
+  P.whole = whole; P.queue = c->queue.as<uint4>(); P.soft_flag = c->soft_dense.as<uint8_t>();
   P.soft_queue = c->soft_queue.as<uint4>();
   P.sb_state[0] = c->sb_state_w.as<uint4>(); P.sb_state[1] = c->sb_state_s.as<uint4>();
   P.sb_queue[0] = c->sb_whole.as<uint4>(); P.sb_queue[1] = c->sb_soft.as<uint4>();
@@ -798,7 +840,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   if (n) { if ((rc = launch_score_class<0>(c, P, s->max_l_seq))) return rc; }
   if (tev) STRL_HIP(hipEventRecord(tev[2], c->stream));
   if (n && soft_cap) {
-    hipLaunchKernelGGL((compact_kernel<0, 0>), dim3(1024), dim3(1024), 0, c->stream, P);
+    hipLaunchKernelGGL(soft_compact_kernel, dim3(1024), dim3(1024), 0, c->stream, P);
     STRL_HIP(hipGetLastError());
     if ((rc = launch_score_class<1>(c, P, s->max_l_seq))) return rc;
   }
