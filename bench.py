@@ -189,7 +189,7 @@ def main():
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "f_traffic.json")))["kernels"]
         pick = {"classify_kernel": ["classify_kernel"], "score_kernel<whole>": ["<10, 64, 0, 0", "compact_kernel<1, 0>", "<10, 64, 0, 1"],
-                "score_kernel<soft>": ["compact_kernel<0, 0>", "<10, 64, 1, 0", "compact_kernel<1, 1>", "<10, 64, 1, 1"],
+                "score_kernel<soft>": ["soft_compact_kernel", "<10, 64, 1, 0", "compact_kernel<1, 1>", "<10, 64, 1, 1"],
                 "cluster_pass": ["iota_kernel", "heads_kernel", "gather_kernel", "ends_kernel", "walk_kernel", "scatter_starts", "bounds_filter_kernel", "bounds_rows_kernel"]}
         for k, pats in pick.items():
             traffic[k] = sum(v["hbm_bytes_corrected"] for name, v in tj.items() if any(p in name for p in pats))
