@@ -166,33 +166,49 @@ def main():
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    (ms_classify, ms_score, ms_soft), launches = ctx.kernel_times()
+    detail, launches = ctx.kernel_times_detail()
     ctx.enable_timing(False)
 
     # ---- roofline of the dominant kernel (HIP-event durations on the kernels' own stream) ----------
+    # One entry per kernel LAUNCH of a scoring pass; algorithmic bytes per launch as in DESIGN.md "Kernels":
+    #   classify   13 B of coordinates read + 4 B written (result word or queue slot) per read
+    #   stage A    16 B queue entry + ceil(L/2) B SEQ read + 4 B result written per item
+    #   stage B    32 B item + ceil(L/2) B SEQ + 4 B result per item that reaches k = 5
+    #   segments   16 B item + the clipped bases (counted as ceil(L/4) B on average) + 16 B result record
+    #   compaction 16 B state read per slot + 32 B item written per survivor; soft items: 1 B flag per slot, 16 B entry
+    #              read + 16 B item written per clipped end
     launches = max(1, launches)
     L = int(soa.max_l_seq)
     seq_b = (L + 1) // 2
-    kernels = {
-        # algorithmic bytes per launch (DESIGN.md "Kernels"): classify streams 13 B of coordinates per read and writes a
-        # 4 B result word or a 4 B queue entry; score reads 4 B queue + 12 B metadata + ceil(L/2) B SEQ and writes 4 B;
-        # soft reads 4 B queue + 8 B metadata + the clipped bases (<= ceil(L/2) B, counted as ceil(L/4) on average) and writes 16 B.
-        "classify_kernel": (ms_classify / launches, 17.0 * n),
-        "score_kernel<whole>": (ms_score / launches, (20.0 + seq_b) * st.n_scored),
-        "score_kernel<soft>": (ms_soft / launches, (28.0 + (L + 3) // 4) * st.n_soft_items),
-        # clustering: 2 radix-sort passes over (key, value) pairs + 24 B per tread for the sweep + 44 B per emitted row
-        "cluster_pass": (ms_cluster, (2 * (4 + 4) * 2 + 2 * (8 + 4) * 2 + 24.0) * treads.size + 44.0 * len(bounds)),
+    ms = {k: v / launches for k, v in detail.items()}
+    nbw, nbs = int(st.n_stage_b_whole), int(st.n_stage_b_soft)
+    alg = {
+        "classify_kernel": 17.0 * n,
+        "score_kernel<whole,A>": (20.0 + seq_b) * st.n_scored,
+        "compact_kernel<whole>": 16.0 * st.n_scored + 32.0 * nbw,
+        "score_kernel<whole,B>": (36.0 + seq_b) * nbw,
+        "soft_compact_kernel": 1.0 * st.n_scored + 32.0 * st.n_soft_items,
+        "score_kernel<segment,A>": (32.0 + (L + 3) // 4) * st.n_soft_items,
+        "compact_kernel<segment>": 16.0 * st.n_soft_items + 32.0 * nbs,
+        "score_kernel<segment,B>": (48.0 + (L + 3) // 4) * nbs,
     }
+    kernels = {k: (ms[k], alg[k]) for k in ms}
+    groups = {"classify_kernel": ms["classify_kernel"],
+              "score_kernel<whole>": ms["score_kernel<whole,A>"] + ms["compact_kernel<whole>"] + ms["score_kernel<whole,B>"],
+              "score_kernel<soft>": ms["soft_compact_kernel"] + ms["score_kernel<segment,A>"] + ms["compact_kernel<segment>"] + ms["score_kernel<segment,B>"],
+              # clustering: 36 small launches (merge sort of the composite key, scans, sweep, bounds); reported as one pass
+              "cluster_pass": ms_cluster}
+    cluster_alg = (2 * (4 + 4) * 2 + 2 * (8 + 4) * 2 + 24.0) * treads.size + 44.0 * len(bounds)
     # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate runs of tools/prof_run.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null if absent
     traffic = {}
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "f_traffic.json")))["kernels"]
-        pick = {"classify_kernel": ["classify_kernel"], "score_kernel<whole>": ["<10, 64, 0, 0", "compact_kernel<1, 0>", "<10, 64, 0, 1"],
-                "score_kernel<soft>": ["soft_compact_kernel", "<10, 64, 1, 0", "compact_kernel<1, 1>", "<10, 64, 1, 1"],
-                "cluster_pass": ["iota_kernel", "heads_kernel", "gather_kernel", "ends_kernel", "walk_kernel", "scatter_starts", "bounds_filter_kernel", "bounds_rows_kernel"]}
-        for k, pats in pick.items():
-            traffic[k] = sum(v["hbm_bytes_corrected"] for name, v in tj.items() if any(p in name for p in pats))
+        pick = {"classify_kernel": "classify_kernel", "score_kernel<whole,A>": "<10, 64, 0, 0", "compact_kernel<whole>": "compact_kernel<1, 0>",
+                "score_kernel<whole,B>": "<10, 64, 0, 1", "soft_compact_kernel": "soft_compact_kernel", "score_kernel<segment,A>": "<10, 64, 1, 0",
+                "compact_kernel<segment>": "compact_kernel<1, 1>", "score_kernel<segment,B>": "<10, 64, 1, 1"}
+        for k, pat in pick.items():
+            traffic[k] = sum(v["hbm_bytes_corrected"] for name, v in tj.items() if pat in name)
     except Exception:
         traffic = {}
     dom = max(kernels, key=lambda k: kernels[k][0])
@@ -201,10 +217,12 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic.get(dom) if (n == 2 ** 25 and L == 150) else None,
-                "traffic_note": "HBM bytes per launch of the dominant kernel group from profiles/r01/f_traffic.json (PMC, same workload); cluster_pass excludes the rocprim sort kernels",
+                "traffic_note": "HBM bytes per launch of that kernel from profiles/r01/f_traffic.json (PMC, same workload)",
                 "kernel_ms": {k: round(v[0], 4) for k, v in kernels.items()},
                 "kernel_alg_bytes": {k: int(v[1]) for k, v in kernels.items()},
-                "pipeline_alg_GBps": round(sum(v[1] for v in kernels.values()) / (el / args.steps) / 1e9, 2),
+                "kernel_alg_GBps": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0.0 for k, v in kernels.items()},
+                "group_ms": {k: round(v, 4) for k, v in groups.items()},
+                "pipeline_alg_GBps": round((sum(v[1] for v in kernels.values()) + cluster_alg) / (el / args.steps) / 1e9, 2),
                 "survey_115B_per_read_GBps": round(115.0 * n / (el / args.steps) / 1e9, 2)}
 
     # ---- CPU baseline: the oracle ("port" of the reference algorithm), 1 thread, bounded sample ----

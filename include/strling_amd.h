@@ -130,6 +130,7 @@ typedef struct {
 typedef struct {
   uint64_t n_reads, n_skipped, n_scored, n_soft_items;
   float ms_classify, ms_score, ms_soft; /* HIP-event kernel times on the context stream (0 if timing off) */
+  uint32_t n_stage_b_whole, n_stage_b_soft; /* items whose ladder reaches k = 5 (second scorer launch) */
 } strl_score_stats;
 
 /* Score a batch: per read the skip predicate + utils.get_repeat on the whole read
@@ -160,6 +161,9 @@ int strl_index_regions(const char *seq, uint64_t n_bases, const uint32_t *words,
  * kernel durations (ms) over the launches recorded since then. */
 int strl_ctx_enable_timing(strl_ctx *ctx, int on);
 int strl_ctx_kernel_times(strl_ctx *ctx, double ms_sum[3], uint64_t *n_launches);
+/* The same per launch of a kernel: classify | stage A, survivor compaction, stage B of the whole reads | soft-item
+ * compaction | stage A, compaction, stage B of the segments. */
+int strl_ctx_kernel_times_detail(strl_ctx *ctx, double ms_sum[8], uint64_t *n_launches);
 
 /* ---- tread (cluster.nim:23-32); qname is carried as an index (record index in extract, sample
  * index in merge -- merge.nim:118-125 overwrites qname with the sample number) ---- */

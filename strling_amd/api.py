@@ -43,7 +43,8 @@ class CReadSoa(C.Structure):
 
 class ScoreStats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_skipped", C.c_uint64), ("n_scored", C.c_uint64), ("n_soft_items", C.c_uint64),
-                ("ms_classify", C.c_float), ("ms_score", C.c_float), ("ms_soft", C.c_float)]
+                ("ms_classify", C.c_float), ("ms_score", C.c_float), ("ms_soft", C.c_float), ("n_stage_b_whole", C.c_uint32),
+                ("n_stage_b_soft", C.c_uint32)]
 
 
 class ClusterStats(C.Structure):
@@ -94,7 +95,7 @@ MODE_MERGE, MODE_CALL = 0, 1
 # every symbol include/strling_amd.h declares
 EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_create", "strl_ctx_destroy", "strl_ctx_stream",
            "strl_ctx_sync", "strl_ctx_set_opts", "strl_ctx_set_genome", "strl_soa_from_records", "strl_score_reads", "strl_index_chrom", "strl_index_regions",
-           "strl_ctx_enable_timing", "strl_ctx_kernel_times", "strl_pair_reads", "strl_pairer_create", "strl_pairer_destroy", "strl_pairer_add",
+           "strl_ctx_enable_timing", "strl_ctx_kernel_times", "strl_ctx_kernel_times_detail", "strl_pair_reads", "strl_pairer_create", "strl_pairer_destroy", "strl_pairer_add",
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
            "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci"]
@@ -125,6 +126,7 @@ def load(build_if_missing=True):
     L.strl_ctx_set_genome.argtypes = [C.c_void_p, C.POINTER(CGenomeStr)]
     L.strl_ctx_enable_timing.argtypes = [C.c_void_p, C.c_int]
     L.strl_ctx_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 3), C.POINTER(C.c_uint64)]
+    L.strl_ctx_kernel_times_detail.argtypes = [C.c_void_p, C.POINTER(C.c_double * 8), C.POINTER(C.c_uint64)]
     L.strl_soa_from_records.argtypes = [C.POINTER(CRecords)] + [C.c_void_p] * 6 + [C.POINTER(C.c_uint32)]
     L.strl_score_reads.argtypes = [C.c_void_p, C.POINTER(CReadSoa), C.c_void_p, C.c_void_p, C.c_uint64,
                                    C.POINTER(C.c_uint64), C.POINTER(ScoreStats)]
@@ -263,6 +265,16 @@ class Context:
         n = C.c_uint64(0)
         _check(self.L.strl_ctx_kernel_times(self.h, C.byref(ms), C.byref(n)))
         return tuple(ms), n.value
+
+    KERNEL_NAMES = ["classify_kernel", "score_kernel<whole,A>", "compact_kernel<whole>", "score_kernel<whole,B>", "soft_compact_kernel",
+                    "score_kernel<segment,A>", "compact_kernel<segment>", "score_kernel<segment,B>"]
+
+    def kernel_times_detail(self):
+        """-> ({launch name: ms summed}, n) since enable_timing(True): one entry per kernel launch of a scoring pass"""
+        ms = (C.c_double * 8)()
+        n = C.c_uint64(0)
+        _check(self.L.strl_ctx_kernel_times_detail(self.h, C.byref(ms), C.byref(n)))
+        return dict(zip(self.KERNEL_NAMES, list(ms))), n.value
 
     def set_opts(self, proportion_repeat=0.8, min_mapq=40, median_fragment_length=0):
         self.opts = Opts(median_fragment_length, proportion_repeat, min_mapq)

@@ -581,7 +581,8 @@ template <int NW, int SLOTS, int MODE, int STAGE, int BLOCK> static int launch_s
 }
 
 // stage A -> compaction of the survivors -> stage B of one MODE, kernel class picked by the longest read
-template <int MODE> static int launch_score_class(strl_ctx *ctx, const ScoreParams &P, uint32_t max_l) {
+// ev (optional): two events, recorded behind stage A and behind the compaction
+template <int MODE> static int launch_score_class(strl_ctx *ctx, const ScoreParams &P, uint32_t max_l, hipEvent_t *ev = nullptr) {
   int rc;
   // Grid: the kernels stride over the queue, so any grid works; measured on 2^25-read batches the time keeps falling
   // until ~8192 blocks for stage A and ~4096 for stage B (1.51 -> 1.29 ms per step against 512 blocks = two resident
@@ -595,8 +596,10 @@ template <int MODE> static int launch_score_class(strl_ctx *ctx, const ScorePara
   else if (max_l <= 256) rc = launch_score<16, 128, MODE, 0, 256>(ctx, P, std::max(256, ga / 4));
   else rc = launch_score<32, 256, MODE, 0, 64>(ctx, P, std::max(512, ga / 2));
   if (rc) return rc;
+  if (ev) STRL_HIP(hipEventRecord(ev[0], ctx->stream));
   hipLaunchKernelGGL((compact_kernel<1, MODE>), dim3(512), dim3(1024), 0, ctx->stream, P);
   STRL_HIP(hipGetLastError());
+  if (ev) STRL_HIP(hipEventRecord(ev[1], ctx->stream));
   if (max_l <= 160) return launch_score<10, 64, MODE, 1, 256>(ctx, P, gb);
   if (max_l <= 256) return launch_score<16, 128, MODE, 1, 256>(ctx, P, std::max(256, gb / 4));
   return launch_score<32, 256, MODE, 1, 64>(ctx, P, std::max(512, gb / 2));
@@ -607,6 +610,9 @@ template <int MODE> static int launch_score_class(strl_ctx *ctx, const ScorePara
 using namespace strl;
 
 static constexpr uint64_t RING = 256;
+// events per recorded strl_score_reads call: start | classify | stage A, compaction, stage B (whole reads) | soft-item
+// compaction | stage A, compaction, stage B (segments)
+static constexpr int EV_PER = 9;
 
 extern "C" {
 
@@ -682,26 +688,37 @@ int strl_ctx_enable_timing(strl_ctx *c, int on) {
   c->timing = on != 0;
   c->ring_pos = 0;
   if (c->timing && c->ring.empty()) {
-    c->ring.resize(RING * 4);
+    c->ring.resize(RING * EV_PER);
     for (auto &e : c->ring) STRL_HIP(hipEventCreate(&e));
   }
   return STRL_OK;
 }
-int strl_ctx_kernel_times(strl_ctx *c, double ms_sum[3], uint64_t *n_launches) {
+int strl_ctx_kernel_times_detail(strl_ctx *c, double ms_sum[8], uint64_t *n_launches) {
   if (!c || !ms_sum) return STRL_ERR_ARG;
   STRL_HIP(hipSetDevice(c->device));
   STRL_HIP(hipStreamSynchronize(c->stream));
-  ms_sum[0] = ms_sum[1] = ms_sum[2] = 0.0;
+  for (int k = 0; k < EV_PER - 1; ++k) ms_sum[k] = 0.0;
   const uint64_t n = std::min<uint64_t>(c->ring_pos, RING);
   for (uint64_t q = 0; q < n; ++q) {
-    hipEvent_t *e = &c->ring[q * 4];
-    for (int k = 0; k < 3; ++k) {
+    hipEvent_t *e = &c->ring[q * EV_PER];
+    for (int k = 0; k < EV_PER - 1; ++k) {
       float ms = 0.f;
       STRL_HIP(hipEventElapsedTime(&ms, e[k], e[k + 1]));
       ms_sum[k] += ms;
     }
   }
   if (n_launches) *n_launches = n;
+  return STRL_OK;
+}
+
+int strl_ctx_kernel_times(strl_ctx *c, double ms_sum[3], uint64_t *n_launches) {
+  if (!c || !ms_sum) return STRL_ERR_ARG;
+  double d[EV_PER - 1];
+  const int rc = strl_ctx_kernel_times_detail(c, d, n_launches);
+  if (rc) return rc;
+  ms_sum[0] = d[0];
+  ms_sum[1] = d[1] + d[2] + d[3];
+  ms_sum[2] = d[4] + d[5] + d[6] + d[7];
   return STRL_OK;
 }
 
@@ -825,7 +842,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   P.soft_cap = (uint32_t)std::min<uint64_t>(soft_cap, 0xffffffffull);
   P.min_mapq = c->opts.min_mapq;
   P.seg_row0 = 2; P.seg_row1 = 3;
-  hipEvent_t *tev = c->timing ? &c->ring[(c->ring_pos % RING) * 4] : nullptr;
+  hipEvent_t *tev = c->timing ? &c->ring[(c->ring_pos % RING) * EV_PER] : nullptr;
   if (c->timing) ++c->ring_pos;
   if (tev) STRL_HIP(hipEventRecord(tev[0], c->stream));
   if (n) {
@@ -837,14 +854,16 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
     STRL_HIP(hipGetLastError());
   }
   if (tev) STRL_HIP(hipEventRecord(tev[1], c->stream));
-  if (n) { if ((rc = launch_score_class<0>(c, P, s->max_l_seq))) return rc; }
-  if (tev) STRL_HIP(hipEventRecord(tev[2], c->stream));
+  if (n) { if ((rc = launch_score_class<0>(c, P, s->max_l_seq, tev ? tev + 2 : nullptr))) return rc; }
+  else if (tev) { STRL_HIP(hipEventRecord(tev[2], c->stream)); STRL_HIP(hipEventRecord(tev[3], c->stream)); }
+  if (tev) STRL_HIP(hipEventRecord(tev[4], c->stream));
   if (n && soft_cap) {
     hipLaunchKernelGGL(soft_compact_kernel, dim3(1024), dim3(1024), 0, c->stream, P);
     STRL_HIP(hipGetLastError());
-    if ((rc = launch_score_class<1>(c, P, s->max_l_seq))) return rc;
-  }
-  if (tev) STRL_HIP(hipEventRecord(tev[3], c->stream));
+    if (tev) STRL_HIP(hipEventRecord(tev[5], c->stream));
+    if ((rc = launch_score_class<1>(c, P, s->max_l_seq, tev ? tev + 6 : nullptr))) return rc;
+  } else if (tev) { for (int k = 5; k <= 7; ++k) STRL_HIP(hipEventRecord(tev[k], c->stream)); }
+  if (tev) STRL_HIP(hipEventRecord(tev[8], c->stream));
   if (sync_counts) {
     uint32_t raw[CNT_WORDS];
     STRL_HIP(hipMemcpyAsync(raw, c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
@@ -855,10 +874,11 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
     if (stats) {
       memset(stats, 0, sizeof *stats);
       stats->n_reads = n; stats->n_skipped = raw[CNT_SKIP]; stats->n_scored = raw[CNT_QUEUE]; stats->n_soft_items = softs;
+      stats->n_stage_b_whole = raw[CNT_SBW]; stats->n_stage_b_soft = soft_cap ? raw[CNT_SBS] : 0;
       if (tev) {
         (void)hipEventElapsedTime(&stats->ms_classify, tev[0], tev[1]);
-        (void)hipEventElapsedTime(&stats->ms_score, tev[1], tev[2]);
-        (void)hipEventElapsedTime(&stats->ms_soft, tev[2], tev[3]);
+        (void)hipEventElapsedTime(&stats->ms_score, tev[1], tev[4]);
+        (void)hipEventElapsedTime(&stats->ms_soft, tev[4], tev[8]);
       }
     }
   }
