@@ -90,3 +90,34 @@ def test_full_size_batch_is_tilewise_identical_to_the_oracle(oracle):
     assert len(per_tile) == tiles and all(sorted(v) == exp_keys for v in per_tile.values())
     # unplaced reads of all tiles fall into the same (tid = -1, unit) groups
     assert sorted((x["repeat"].decode(), int(x["count"])) for x in u) == sorted((r, c * tiles) for r, c in exp_u)
+
+
+def test_joint_merge_at_s2_scale(ctx, oracle):
+    """BASELINE.json configs[4] (S2: 50 samples, ~5x10^7 STR reads through `strling merge` semantics): 64 tiles of a
+    50-sample base set on their own contigs; every tile must give the oracle's rows for the base set, in the
+    reference's row order within the tile's groups.  19 200 (tid, unit) groups also push the emulated Nim table
+    through its enlarge path (8192 initial slots)."""
+    import time
+    base = synth.synth_treads(n_samples=50, n_loci=1200, seed=77, n_contigs=5, contig_len=2_000_000)
+    tiles, n_contigs = 64, 5
+    ot = np.zeros(len(base), oracle.TREAD_DTYPE)
+    for f in base.dtype.names:
+        ot[f] = base[f]
+    exp_b, _ = oracle.call_bounds(ot, api.MODE_MERGE, 560, min_support=5, max_clip_dist=175)
+    assert len(exp_b) > 1000
+    t = np.tile(base, tiles)
+    t["tid"] += np.repeat(np.arange(tiles, dtype=np.int32) * n_contigs, len(base))
+    assert len(t) > 4.5e7
+    t0 = time.time()
+    b, u, st = ctx.cluster(t, api.MODE_MERGE, 560, min_support=5, max_clip_dist=175)
+    dt = time.time() - t0
+    assert len(b) == tiles * len(exp_b) and st.n_groups == tiles * len({(int(x["tid"]), bytes(x["repeat"])) for x in base})
+    fields = ("left", "right", "left_most", "right_most", "center_mass", "n_left", "n_right", "n_total", "repeat")
+    tile_of = b["tid"] // n_contigs
+    exp_sorted = np.sort(np.array([tuple([int(x["tid"])] + [x[f] for f in fields]) for x in exp_b],
+                                  dtype=[("tid", "i8")] + [(f, exp_b.dtype[f]) for f in fields]))
+    for k in range(tiles):
+        bk = b[tile_of == k]
+        got = np.sort(np.array([tuple([int(x["tid"]) - k * n_contigs] + [x[f] for f in fields]) for x in bk], dtype=exp_sorted.dtype))
+        assert np.array_equal(got, exp_sorted), k
+    print(f"S2 scale: {len(t)} treads, {st.n_groups} groups, {st.n_clusters} clusters, {len(b)} bounds in {dt:.2f} s (host keys + device pass + row order)")
