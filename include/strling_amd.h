@@ -237,6 +237,15 @@ int strl_cluster(strl_ctx *ctx, const strl_tread *treads, uint64_t n, int mode, 
                  uint64_t *n_out, strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced,
                  strl_cluster_stats *stats);
 
+/* The (tid, unit) groups of `treads` in the order the reference iterates its Table (call.nim:223, merge.nim:172) -- the
+ * order strl_cluster emits the groups' rows in.  Host only.  A multi-GPU run that clusters disjoint sets of groups on
+ * different ranks puts the gathered rows back into the reference's order with it (strling_amd/dist.py). */
+typedef struct {
+  int32_t tid;
+  char repeat[8];
+} strl_group_key;
+int strl_group_order(const strl_tread *treads, uint64_t n, int mode, strl_group_key *out, uint64_t cap, uint64_t *n_groups);
+
 /* The reads of every bound the last strl_cluster call on this context returned, in cluster order (position-sorted,
  * stable): bound j holds treads[members[member_off[j]]] .. treads[members[member_off[j+1] - 1]] (indices into the
  * array given to strl_cluster; c.reads of call.nim:246).  member_off is [n_bounds + 1]. */

@@ -98,7 +98,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_ctx_enable_timing", "strl_ctx_kernel_times", "strl_ctx_kernel_times_detail", "strl_pair_reads", "strl_pairer_create", "strl_pairer_destroy", "strl_pairer_add",
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
-           "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci"]
+           "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order"]
 
 
 def lib_path():
@@ -157,6 +157,7 @@ def load(build_if_missing=True):
     L.strl_call_row.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_char_p]
     L.strl_canonical_repeat.argtypes = [C.c_char_p, C.c_char_p]
     L.strl_canonical_repeat.restype = None
+    L.strl_group_order.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.strl_assign_reads_loci.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
     _LIB = L
     return L
@@ -421,6 +422,20 @@ def _noop():
 def frag_median(frag, pct=0.5):
     frag = np.ascontiguousarray(frag, np.uint32)
     return load().strl_frag_median(frag.ctypes.data, pct)
+
+
+GROUP_KEY_DTYPE = np.dtype([("tid", "<i4"), ("repeat", "S8")])
+
+
+def group_order(treads, mode):
+    """[(tid, unit bytes)] of the (tid, unit) groups in the reference's Table iteration order (strl_group_order)"""
+    L = load()
+    t = np.ascontiguousarray(treads, TREAD_DTYPE)
+    ng = C.c_uint64(0)
+    _check(L.strl_group_order(_ptr(t), t.size, mode, None, 0, C.byref(ng)))
+    out = np.zeros(max(1, ng.value), GROUP_KEY_DTYPE)
+    _check(L.strl_group_order(_ptr(t), t.size, mode, out.ctypes.data, out.size, C.byref(ng)))
+    return [(int(k["tid"]), bytes(k["repeat"])) for k in out[:ng.value]]
 
 
 def assign_reads_loci(treads, loci, mode):

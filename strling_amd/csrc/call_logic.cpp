@@ -425,6 +425,33 @@ int strl_assign_reads_loci(strl_tread *treads, uint64_t n, int mode, strl_locus 
   return STRL_OK;
 }
 
+// Table[(tid, repeat), seq[tread]] iteration order: keys in first-appearance order -> slot order (8192 initial slots)
+int strl_group_order(const strl_tread *treads, uint64_t n, int mode, strl_group_key *out, uint64_t cap, uint64_t *n_groups) {
+  if ((n && !treads) || !n_groups) { set_error("null argument"); return STRL_ERR_ARG; }
+  struct Key { int32_t tid; char rep[6]; bool operator==(const Key &o) const { return tid == o.tid && memcmp(rep, o.rep, 6) == 0; } };
+  struct KeyHash { size_t operator()(const Key &k) const { return (size_t)nim::hash_tid_rep(k.tid, k.rep); } };
+  std::unordered_map<Key, size_t, KeyHash> seen;
+  std::vector<Key> keys;
+  std::vector<uint64_t> hc;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (mode == STRL_MODE_MERGE && treads[i].tid < 0) continue;
+    Key k{treads[i].tid, {0}};
+    memcpy(k.rep, treads[i].repeat, 6);
+    if (seen.emplace(k, keys.size()).second) { keys.push_back(k); hc.push_back(nim::hash_tid_rep(k.tid, k.rep)); }
+  }
+  *n_groups = keys.size();
+  if (!out) return STRL_OK;
+  if (keys.size() > cap) { set_error("group capacity %llu too small, need %llu", (unsigned long long)cap, (unsigned long long)keys.size()); return STRL_ERR_CAPACITY; }
+  uint64_t q = 0;
+  for (int64_t id : nim::table_slot_order(hc, 8192)) {
+    out[q].tid = keys[(size_t)id].tid;
+    memset(out[q].repeat, 0, sizeof out[q].repeat);
+    memcpy(out[q].repeat, keys[(size_t)id].rep, 6);
+    ++q;
+  }
+  return STRL_OK;
+}
+
 // genotyper.nim:54-57
 int strl_call_row(char *buf, int cap, const strl_call *c, const char *chrom) {
   const std::string d = nim_float(c->depth);

@@ -105,3 +105,36 @@ def extract_sharded(score_fn, rec, global_offset, n_total, tail_start, opts, gro
     t = api.pair_reads(merged, opts, whole_m, soft_m, n_tail=n_tail)
     t["qname_id"] = gidx[t["qname_id"]]
     return t
+
+
+def group_owner(treads, world):
+    """rank that clusters each tread's (tid, unit) group: any function of the key works, groups never interact"""
+    rep = np.ascontiguousarray(treads["repeat"]).view(np.uint8).reshape(-1, 6).astype(np.uint64)
+    h = treads["tid"].astype(np.int64).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    for j in range(6):
+        h = (h ^ rep[:, j]) * np.uint64(0x100000001B3)
+    return ((h >> np.uint64(17)) % np.uint64(world)).astype(np.int64)
+
+
+def cluster_sharded(cluster_fn, treads_local, mode, group=None):
+    """Multi-GPU clustering: all-gather the compact tread arrays (32 B per STR read), every rank
+    clusters the (tid, unit) groups it owns, the rows are gathered and put back into the reference's row order.
+    cluster_fn(treads) -> (bounds, unplaced)   (api.Context.cluster on the GPU box; rows of one group in position order)
+    treads_local: this rank's treads; ranks are concatenated in rank order (= sample order for merge, file order for call).
+    Returns (bounds, unplaced) of the whole input, identical on every rank."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    parts = [None] * world
+    dist.all_gather_object(parts, np.ascontiguousarray(treads_local), group=group)
+    all_t = np.concatenate(parts)
+    mine = group_owner(all_t, world) == rank
+    b, u = cluster_fn(all_t[mine])[:2]
+    rows = [None] * world
+    dist.all_gather_object(rows, (b, u), group=group)
+    order = {k: i for i, k in enumerate(api.group_order(all_t, mode))}
+    bs = np.concatenate([r[0] for r in rows])
+    us = np.concatenate([r[1] for r in rows])
+    # numpy hands out the NUL-padded unit fields without their padding, on both sides
+    key_b = np.array([order[(int(x["tid"]), bytes(x["repeat"]))] for x in bs], np.int64) if len(bs) else np.zeros(0, np.int64)
+    key_u = np.array([order[(-1, bytes(x["repeat"]))] for x in us], np.int64) if len(us) else np.zeros(0, np.int64)
+    return bs[np.argsort(key_b, kind="stable")], us[np.argsort(key_u, kind="stable")]

@@ -59,3 +59,74 @@ def test_sharded_extract_matches_single_process():
     assert sorted(r[0] for r in res) == [0, 1]
     for rank, ok, n, ne in res:
         assert ok and n == ne and n > 100, (rank, ok, n, ne)
+
+
+def _cluster_worker(rank, world, port, q, use_gpu):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from strling_amd import api, dist as sdist, synth
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        for mode, seed in ((api.MODE_MERGE, 31), (api.MODE_CALL, 32)):
+            t = synth.synth_treads(n_samples=4, n_loci=300, seed=seed, n_contigs=6, contig_len=500_000)
+            if mode == api.MODE_CALL:
+                t["tid"][::53] = -1
+                t["position"][::53] = 0
+
+            def to_oracle(x):
+                o = np.zeros(len(x), O.TREAD_DTYPE)
+                for f in x.dtype.names:
+                    o[f] = x[f]
+                return o
+
+            if use_gpu:
+                ctx = api.Context(0)
+                fn = lambda x: ctx.cluster(x, mode, 560, min_support=3, max_clip_dist=175)
+            else:     # the oracle stands in for the device clustering of a rank's groups (same row layout)
+                def fn(x):
+                    b, u = O.call_bounds(to_oracle(x), mode, 560, min_support=3, max_clip_dist=175)
+                    bb = np.zeros(len(b), api.BOUNDS_DTYPE)
+                    for f in bb.dtype.names:
+                        bb[f] = b[f]
+                    uu = np.zeros(len(u), api.UNPLACED_DTYPE)
+                    uu["repeat"] = [r.encode() for r, _ in u]
+                    uu["count"] = [c for _, c in u]
+                    return bb, uu
+            lo, hi = sdist.shard_bounds(len(t), world)[rank]
+            b, u = sdist.cluster_sharded(fn, t[lo:hi], mode)
+            eb, eu = O.call_bounds(to_oracle(t), mode, 560, min_support=3, max_clip_dist=175)
+            rows = [api.bounds_row(x, f"chr{int(x['tid']) + 1}") for x in b]
+            exp_rows = [O.bounds_row(x, f"chr{int(x['tid']) + 1}") for x in eb]
+            ok = ok and rows == exp_rows and len(rows) > 20
+            ok = ok and [(x["repeat"].decode(), int(x["count"])) for x in u] == eu
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_cluster(use_gpu):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_cluster_worker, args=(r, 2, port, q, use_gpu)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)], res
+
+
+def test_sharded_clustering_row_order_matches_single_process():
+    """two ranks cluster disjoint sets of (tid, unit) groups; the gathered rows come back in the reference's order"""
+    _run_cluster(False)
+
+
+@pytest.mark.gpu
+def test_sharded_clustering_on_the_device():
+    _run_cluster(True)
