@@ -1,12 +1,12 @@
 """Randomised end-to-end sweep of the CLI (extract -> call [-l/-b], extract x3 -> merge [-l]) against the oracle.
-usage: python tools/fuzz_call.py [seconds]     (GPU box)"""
+usage: python tests/fuzz/fuzz_call.py [seconds]     (test infrastructure: uses the oracle; GPU box)"""
 import os
 import subprocess
 import sys
 import tempfile
 import time
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 from strling_amd import bamio, build, synth
 from oracle import oracle as O

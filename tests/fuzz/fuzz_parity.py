@@ -1,11 +1,11 @@
 """Randomised parity sweep of the HIP path against the oracle (longer than the test suite allows).
-usage: python tools/fuzz_parity.py [seconds]     (GPU box)"""
+usage: python tests/fuzz/fuzz_parity.py [seconds]     (test infrastructure: uses the oracle; GPU box)"""
 import os
 import sys
 import time
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
 from strling_amd import api, synth
 from oracle import oracle as O

@@ -1,11 +1,11 @@
 """`strling index` throughput: device window scoring + host merge/trim vs the oracle, on a synthetic chromosome.
-usage: python tools/index_bench.py [n_bases]   (GPU box; the oracle leg runs on a 4 Mbp prefix)"""
+usage: python tests/fuzz/index_bench.py [n_bases]   (test infrastructure: uses the oracle; GPU box; the oracle leg runs on a 4 Mbp prefix)"""
 import json
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 from strling_amd import api, synth
 from oracle import oracle as O

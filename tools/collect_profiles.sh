@@ -13,7 +13,7 @@ run fetch --pmc FETCH_SIZE
 run write --pmc WRITE_SIZE
 run pmc1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU
 run pmc2 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/idx -o run -- python $R/tools/index_bench.py 100000000 > $O/index_bench.json 2> $O/idx.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/idx -o run -- python $R/tests/fuzz/index_bench.py 100000000 > $O/index_bench.json 2> $O/idx.log
 find $O -name '*agent_info*' -delete; find $O -name '*.log' -size +200k -delete
 # keep only the per-kernel averages of the big counter CSVs
 python $R/tools/summarise_profiles.py $O
