@@ -96,7 +96,8 @@ typedef struct {
   const int32_t *end;      /* [n] aln.stop (bam_endpos) */
   const uint32_t *seq_off; /* [n] offset of the read's 4-bit SEQ in 16-byte units */
   const uint16_t *l_seq;   /* [n] */
-  const uint16_t *clip_l;  /* [n] length of cigar[0] if it is S else 0 */
+  const uint16_t *clip_l;  /* [n] length of cigar[0] if it is S, or if the cigar is one single M op (the align_length of a read the
+                            * skip predicate removes, extract.nim:33); else 0 */
   const uint16_t *clip_r;  /* [n] length of cigar[last] if it is S else 0 */
   const uint8_t *mapq;     /* [n] */
   const uint8_t *cig;      /* [n] STRL_CIG_* bits */
@@ -105,6 +106,15 @@ typedef struct {
   uint32_t max_l_seq;
   int32_t mem;             /* STRL_MEM_HOST or STRL_MEM_DEVICE: where ALL pointers above live */
 } strl_read_soa;
+
+/* The per-read fields the pair logic (Cache.add, extract.nim:192-248) needs on top of strl_read_soa; same `mem` as the
+ * read batch they belong to. */
+typedef struct {
+  const int32_t *mtid;   /* [n] aln.mate_chrom tid */
+  const int32_t *mpos;   /* [n] aln.mate_pos */
+  const uint16_t *flag;  /* [n] aln.flag */
+  const uint64_t *qhash; /* [n] 64-bit hash of aln.qname (strl_qname_hash); the Cache is keyed by it */
+} strl_pair_soa;
 
 /* Host: derive the SoA metadata arrays from BAM-native records (replaces the hts-nim accessors
  * used at extract.nim:30-38,83-87,98-119: cigar ops, aln.stop, clip lengths).  Caller provides the
@@ -201,6 +211,31 @@ void strl_pairer_destroy(strl_pairer *pairer);
 int strl_pairer_add(strl_pairer *pairer, const strl_records *rec, const uint32_t *whole, const strl_soft_rec *soft, uint64_t n_soft);
 int strl_pairer_result(strl_pairer *pairer, const strl_tread **treads, uint64_t *n, const uint64_t **qname_off,
                        const char **qnames, uint64_t *n_pending);
+
+/* ---- the extract hot loop on the device, end to end (replaces extract.nim:308-329 for one batch that is the whole input):
+ * skip predicate + scorer + soft-clip scan (strl_score_reads) and the pair logic (Cache.add with to_tread, add_soft,
+ * adjust_by, unplaced_pair; the second visit of the last n_tail records, extract.nim:326-329), all as kernels on the context
+ * stream.  Asynchronous when soa->mem == STRL_MEM_DEVICE: nothing is copied to the host, the treads stay resident in the
+ * context in the order of the reference's .bin file (qname_id = record index) for strl_treads_fetch / strl_cluster_resident.
+ * item_cap bounds the records that take part in the join (reads of qname groups with a repeat + their soft-clip records),
+ * tread_cap the treads; 0 = defaults from n.  Exceeding either is reported by strl_treads_fetch (STRL_ERR_CAPACITY).
+ * Qname groups are keyed by the 64-bit hash alone (two different qnames with equal hashes would be treated as one group). */
+int strl_extract_device(strl_ctx *ctx, const strl_read_soa *soa, const strl_pair_soa *pair, int64_t n_tail, uint64_t item_cap,
+                        uint64_t tread_cap);
+/* Wait for the last strl_extract_device call and copy its treads to the host (out may be NULL to only get the count).
+ * STRL_ERR_CAPACITY: a capacity was exceeded (n_out = treads needed when known); STRL_ERR_ASSERT: the reference's
+ * doAssert repeat_count < 256 (extract.nim:72) would have fired; STRL_ERR_FORMAT: more than 12 records share one qname
+ * hash (malformed input -- use the host pair logic, strl_pair_reads). */
+int strl_treads_fetch(strl_ctx *ctx, strl_tread *out, uint64_t cap, uint64_t *n_out, strl_score_stats *stats);
+/* HIP-event times (ms) of the last strl_extract_device call when timing is enabled: mark + probe | join sort | replay |
+ * order sort + gather. */
+int strl_ctx_pair_times(strl_ctx *ctx, double ms[4]);
+
+/* Stable LSD radix sort of (key, value) pairs by key bits [bit_lo, bit_lo + bits) on the device (the sort of the
+ * clustering and pairing paths: call.nim:127-130 / merge.nim:132-135 `sort` by position inside a (tid, repeat) group
+ * becomes one stable keyed sort).  Host arrays in, sorted in place; n_max >= n sizes the launch like a pipeline that
+ * only knows an upper bound of the count would. */
+int strl_sort_pairs(strl_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t n, uint64_t n_max, int bit_lo, int bits);
 
 /* 64-bit hash of every record's qname (out[n]).  Qname groups never interact in the pair logic, so a multi-GPU
  * run only has to bring together the records whose hash belongs to a group that can emit (strling_amd/dist.py). */

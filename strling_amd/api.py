@@ -41,6 +41,10 @@ class CReadSoa(C.Structure):
                 ("mem", C.c_int32)]
 
 
+class CPairSoa(C.Structure):
+    _fields_ = [("mtid", C.c_void_p), ("mpos", C.c_void_p), ("flag", C.c_void_p), ("qhash", C.c_void_p)]
+
+
 class ScoreStats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_skipped", C.c_uint64), ("n_scored", C.c_uint64), ("n_soft_items", C.c_uint64),
                 ("ms_classify", C.c_float), ("ms_score", C.c_float), ("ms_soft", C.c_float), ("n_stage_b_whole", C.c_uint32),
@@ -98,7 +102,8 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_ctx_enable_timing", "strl_ctx_kernel_times", "strl_ctx_kernel_times_detail", "strl_pair_reads", "strl_pairer_create", "strl_pairer_destroy", "strl_pairer_add",
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
-           "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order"]
+           "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order",
+           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs"]
 
 
 def lib_path():
@@ -159,6 +164,10 @@ def load(build_if_missing=True):
     L.strl_canonical_repeat.restype = None
     L.strl_group_order.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.strl_assign_reads_loci.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.strl_extract_device.argtypes = [C.c_void_p, C.POINTER(CReadSoa), C.POINTER(CPairSoa), C.c_int64, C.c_uint64, C.c_uint64]
+    L.strl_treads_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(ScoreStats)]
+    L.strl_ctx_pair_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 4)]
+    L.strl_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
     _LIB = L
     return L
 
@@ -330,6 +339,32 @@ class Context:
         if isinstance(seq, str):
             seq = seq.encode()
         return index_regions(seq, self.index_chrom(seq, window, step), window, step)
+
+    def sort_pairs(self, keys, vals, bit_lo=0, bits=64, n_max=None):
+        """stable LSD radix sort of (uint64 key, uint32 value) pairs on the device (strl_sort_pairs) -> (keys, vals)"""
+        k = np.ascontiguousarray(keys, np.uint64).copy()
+        v = np.ascontiguousarray(vals, np.uint32).copy()
+        _check(self.L.strl_sort_pairs(self.h, _ptr(k), _ptr(v), k.size, n_max or k.size, bit_lo, bits))
+        return k, v
+
+    def extract_device(self, cs: CReadSoa, cp: CPairSoa, n_tail, item_cap=0, tread_cap=0):
+        """scoring + pair logic of one batch, asynchronous for device-resident batches (strl_extract_device)"""
+        _check(self.L.strl_extract_device(self.h, C.byref(cs), C.byref(cp), n_tail, item_cap, tread_cap))
+
+    def treads_fetch(self, want=True):
+        """-> (treads of the last extract_device call in .bin order, ScoreStats)"""
+        no = C.c_uint64(0)
+        st = ScoreStats()
+        _check(self.L.strl_treads_fetch(self.h, None, 0, C.byref(no), C.byref(st)))
+        out = np.zeros(max(1, no.value), TREAD_DTYPE)
+        if want and no.value:
+            _check(self.L.strl_treads_fetch(self.h, out.ctypes.data, out.size, C.byref(no), None))
+        return out[:no.value], st
+
+    def pair_times(self):
+        ms = (C.c_double * 4)()
+        _check(self.L.strl_ctx_pair_times(self.h, C.byref(ms)))
+        return dict(zip(["pair_mark_probe", "pair_join_sort", "pair_replay", "pair_order"], list(ms)))
 
     # ---- extract (score + pair) -----------------------------------------------------------------
     def extract(self, rec: RecordBatch, n_tail=-1):

@@ -29,6 +29,19 @@ struct DevBuf {
   template <typename T> T *as() { return static_cast<T *>(p); }
 };
 
+// counters of one scoring pass (strl_ctx::counters), 64 B apart
+constexpr int CNT_STRIDE = 16;
+constexpr int CNT_QUEUE = 0, CNT_SOFT = 16, CNT_SKIP = 32, CNT_SBW = 48, CNT_SBS = 64, CNT_WORDS = 80;
+// counters of the device pair logic (strl_ctx::pair_cnt)
+constexpr int PC_ITEMS = 0, PC_EMIT = 16, PC_ERR = 32, PC_WORDS = 48;
+constexpr uint32_t PAIR_ERR_RUN = 1u, PAIR_ERR_ASSERT = 2u, PAIR_ERR_ITEMS = 4u, PAIR_ERR_EMIT = 8u, PAIR_ERR_LOCAL = 16u;
+
+// murmur3 finaliser: a bijection on 64-bit words, so equality of mixed hashes == equality of hashes
+__host__ __device__ inline uint64_t fmix64(uint64_t h) {
+  h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
+  return h;
+}
+
 }  // namespace strl
 
 // what strl_cluster_replay needs to re-run the device side of the last strl_cluster call
@@ -68,4 +81,19 @@ struct strl_ctx {
   // clustering scratch
   strl::DevBuf c_buf[16];
   ClusterRun cl_run;
+  // device pair logic (pair.hip): join items / emission keys (ping-pong), emitted treads, Bloom bitmap, counters
+  strl::DevBuf p_key0, p_key1, p_val0, p_val1, p_emit, sort_scratch, pair_cnt, bloom;
+  uint32_t bloom_mask = 0;
+  // the treads the last strl_extract_device call produced, in .bin order: treads[0, *n_treads_dev)
+  strl::DevBuf treads;
+  uint32_t *n_treads_dev = nullptr;
+  uint32_t tread_cap = 0, pair_item_cap = 0;
+  uint64_t ex_n = 0, ex_soft_cap = 0;
+  hipEvent_t pev[6] = {};
+  // staging of the pairing arrays for host-memory batches
+  strl::DevBuf st_mtid, st_mpos, st_flag, st_qhash;
 };
+
+// pair.hip: enqueue the device pair logic behind a scoring pass of the same batch
+int strl_pair_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *pp, const uint32_t *whole, const strl_soft_rec *soft,
+                     uint64_t soft_cap, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap);

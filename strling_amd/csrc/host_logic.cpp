@@ -302,7 +302,7 @@ int strl_soa_from_records(const strl_records *rec, int32_t *end, uint32_t *seq_o
     if (L == 0) c |= STRL_CIG_NONE;
     else {
       if (L == 1) c |= STRL_CIG_ONE_OP;
-      if (L == 1 && rv.op(i, 0) == OP_M) c |= STRL_CIG_SINGLE_M;
+      if (L == 1 && rv.op(i, 0) == OP_M) { c |= STRL_CIG_SINGLE_M; cl = (uint32_t)rv.len(i, 0); }   // extract.nim:33 align_length
       if (rv.op(i, 0) == OP_S) { c |= STRL_CIG_FIRST_S; cl = (uint32_t)rv.len(i, 0); }
       if (rv.op(i, L - 1) == OP_S) { c |= STRL_CIG_LAST_S; cr = (uint32_t)rv.len(i, L - 1); }
     }
@@ -525,18 +525,36 @@ int strl_extract(strl_ctx *ctx, const strl_records *rec, int64_t n_tail, strl_tr
   if (!ctx || !rec) { set_error("null argument"); return STRL_ERR_ARG; }
   const size_t n = (size_t)rec->n;
   std::vector<int32_t> end(n);
-  std::vector<uint32_t> so(n), whole(n);
+  std::vector<uint32_t> so(n);
   std::vector<uint16_t> ls(n), cl(n), cr(n);
   std::vector<uint8_t> cig(n);
+  std::vector<uint64_t> qh(n);
   uint32_t mx = 0;
   int rc = strl_soa_from_records(rec, end.data(), so.data(), ls.data(), cl.data(), cr.data(), cig.data(), &mx);
   if (rc) return rc;
+  if ((rc = strl_qname_hash(rec, qh.data()))) return rc;
   uint64_t seq_bytes = 32;
   for (size_t i = 0; i < n; ++i) seq_bytes = std::max<uint64_t>(seq_bytes, rec->seq_off[i] + (uint64_t)((rec->l_seq[i] + 1) / 2) + 32);
   strl_read_soa soa{};
   soa.n = n; soa.tid = rec->tid; soa.pos = rec->pos; soa.end = end.data(); soa.seq_off = so.data(); soa.l_seq = ls.data();
   soa.clip_l = cl.data(); soa.clip_r = cr.data(); soa.mapq = rec->mapq; soa.cig = cig.data(); soa.seq4 = rec->seq4;
   soa.seq4_bytes = seq_bytes; soa.max_l_seq = mx; soa.mem = STRL_MEM_HOST;
+  strl_pair_soa pp{rec->mtid, rec->mpos, rec->flag, qh.data()};
+  if (n_tail < 0) { n_tail = 0; while ((size_t)n_tail < n && rec->tid[n - 1 - (size_t)n_tail] < 0) ++n_tail; }
+  // scoring + pair logic on the device; capacities first from the defaults, then from the hard bounds
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const uint64_t icap = attempt ? 3 * (uint64_t)n + 16 : 0, tcap = attempt ? 8 * (uint64_t)n + 16 : 0;
+    if ((rc = strl_extract_device(ctx, &soa, &pp, n_tail, icap, tcap))) return rc;
+    uint64_t need = 0;
+    rc = strl_treads_fetch(ctx, nullptr, 0, &need, stats);
+    if (rc == STRL_ERR_CAPACITY && attempt == 0) continue;
+    if (rc == STRL_ERR_FORMAT) break;                 // > 12 records under one qname hash: the host pair logic takes it
+    if (rc) return rc;
+    if (n_out) *n_out = need;
+    if (need > cap) { set_error("tread capacity %llu too small, need %llu", (unsigned long long)cap, (unsigned long long)need); return STRL_ERR_CAPACITY; }
+    return strl_treads_fetch(ctx, out, cap, n_out, nullptr);
+  }
+  std::vector<uint32_t> whole(n);
   std::vector<strl_soft_rec> soft(2 * n + 1);
   uint64_t ns = 0;
   rc = strl_score_reads(ctx, &soa, whole.data(), soft.data(), 2 * n, &ns, stats);

@@ -1,0 +1,552 @@
+// pair.hip -- the mate-pairing logic of `strling extract` (Cache.add, extract.nim:192-248, with to_tread :63-87,
+// add_soft :93-132, adjust_by :141-179, unplaced_pair :182-190, canonical_repeat utils.nim:304-316) on the GPU, gfx950.
+//
+// The reference keeps a qname-keyed hash table of first-seen reads and walks the BAM sequentially.  Two facts make the
+// walk data-parallel:
+//   1. qname groups never interact (the table is keyed by qname; every emission happens while a record of the group is
+//      being processed), and
+//   2. a group none of whose records carries a repeat (whole-read count 0 and no soft-clip result) emits nothing.
+// So the device joins only the HOT groups -- a few per cent of the reads:
+//   mark   : every scored read / soft-clip record with a non-zero count sets two bits of a Bloom bitmap keyed by the
+//            64-bit qname hash (whole reads: inside score_kernel; soft-clip records: pair_soft_items_kernel, which also
+//            turns each such record into a join item),
+//   probe  : one streaming pass over the qname hashes of ALL reads (8 B per read -- the only full pass the pair logic
+//            adds) tests the bitmap (2 MB, L2 resident) and turns the hits into join items,
+//   join   : the items are radix-sorted by hash (sort.hip); a run of equal hashes = one qname group (reads + its hot
+//            soft-clip records),
+//   replay : one lane per run replays Cache.add over the group's records in file order -- first pass over all records,
+//            second pass over the unmapped tail (extract.nim:326-329) -- with the reference's uint8 / uint32 / float64
+//            arithmetic, and buffers what the group emits,
+//   order  : every emitted tread carries (pass, record index, sequence number) = the position of its emission in the
+//            reference's sequential walk; one more radix sort puts the treads into exactly the order of the .bin file.
+// Bloom false positives only add groups that emit nothing.
+#include <string.h>
+#include <algorithm>
+#include "common.h"
+#include "device_util.h"
+#include "sort.h"
+
+namespace strl {
+
+constexpr uint16_t F_PROPER = 0x2, F_REVERSE = 0x10, F_MREVERSE = 0x20, F_SECONDARY = 0x100, F_SUPPL = 0x800;
+constexpr int PAIR_MAXM = 12;   // items (reads + hot soft-clip records) of one hash run a lane can replay
+constexpr int PAIR_MAXE = 12;   // treads one run may emit
+
+struct PairParams {
+  uint32_t n;               // reads of the batch
+  uint32_t tail_start;      // first record of the unmapped tail visited a second time (n if none)
+  const int32_t *tid, *pos, *end, *mtid, *mpos;
+  const uint16_t *flag, *l_seq, *clip_l, *clip_r;
+  const uint8_t *mapq, *cig;
+  const uint64_t *qhash;
+  const uint32_t *whole;
+  const strl_soft_rec *soft;
+  const uint32_t *score_cnt;   // CNT_* counters of the scoring pass
+  uint32_t scap;
+  uint32_t *bloom;
+  uint32_t bloom_mask;         // bits - 1
+  uint64_t *item_key;
+  uint32_t *item_val;          // read index, or 0x80000000 | soft record index
+  uint32_t item_cap;
+  uint32_t *pc;                // PC_* counters
+  strl_tread *emit;
+  uint64_t *emit_key;
+  uint32_t *emit_val;
+  uint32_t emit_cap;
+  double p;
+  uint32_t min_mapq;
+  int32_t frag_median;
+};
+
+// Soft-clip records with a result under either threshold: mark their read's qname group and make them join items.
+// One queue-space atomic per 8192 records (the same-address atomic rate of the L2 is ~88 per microsecond).
+__global__ __launch_bounds__(1024) void pair_soft_items_kernel(PairParams P) {
+  __shared__ uint32_t wcnt[128];
+  __shared__ uint32_t base_sh;
+  constexpr int U = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t n_src = P.score_cnt[CNT_SOFT];
+  if (n_src > P.scap) n_src = P.scap;
+  for (uint32_t b0 = blockIdx.x * (1024u * U); b0 < n_src; b0 += gridDim.x * (1024u * U)) {
+    uint64_t m[U];
+    bool hot[U];
+    unsigned long long bal[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t j = b0 + 1024u * u + threadIdx.x;
+      hot[u] = false;
+      m[u] = 0;
+      if (j < n_src) {
+        const strl_soft_rec s = P.soft[j];
+        hot[u] = (STRL_RES_COUNT(s.res_first) | STRL_RES_COUNT(s.res_after)) != 0;
+        if (hot[u]) {
+          m[u] = fmix64(P.qhash[s.read_side >> 1]);
+          bloom_set(P.bloom, P.bloom_mask, m[u]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bal[u] = __ballot(hot[u]);
+      if (lane == 0) wcnt[u * 16 + wave] = (uint32_t)__popcll(bal[u]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t tot = 0;
+      for (int w = 0; w < 16 * U; ++w) { const uint32_t c = wcnt[w]; wcnt[w] = tot; tot += c; }
+      base_sh = tot ? atomicAdd(&P.pc[PC_ITEMS], tot) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (hot[u]) {
+        const uint32_t d = base_sh + wcnt[u * 16 + wave] + (uint32_t)__popcll(bal[u] & below);
+        if (d < P.item_cap) { P.item_key[d] = m[u]; P.item_val[d] = 0x80000000u | (b0 + 1024u * u + threadIdx.x); }
+        else atomicOr(&P.pc[PC_ERR], PAIR_ERR_ITEMS);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// The one full pass of the pair logic: qname hash of every read against the bitmap.  Each wave owns a contiguous range
+// of reads and stages its hits in LDS; a flush reserves item space with one atomic per ~512 hits (classify_kernel's
+// scheme) and gathers the hashes of the staged reads again.
+constexpr int PR_STAGE = 512, PR_ILP = 8;
+__global__ __launch_bounds__(256) void pair_probe_kernel(PairParams P) {
+  __shared__ uint32_t stage[4][PR_STAGE + 64 * PR_ILP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t *buf = stage[wave];
+  const uint64_t n_waves = (uint64_t)gridDim.x * 4u;
+  const uint64_t gw = (uint64_t)blockIdx.x * 4u + wave;
+  const uint64_t per = (((P.n + n_waves - 1) / n_waves) + 63ull) & ~63ull;
+  const uint64_t r0 = gw * per;
+  const uint64_t r1 = r0 + per < P.n ? r0 + per : P.n;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t cnt = 0;
+  auto flush = [&]() {
+    if (cnt) {
+      uint32_t b = 0;
+      if (lane == 0) b = atomicAdd(&P.pc[PC_ITEMS], cnt);
+      b = __shfl(b, 0);
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t i = lane; i < cnt; i += 64) {
+        const uint32_t r = buf[i];
+        const uint32_t d = b + i;
+        if (d < P.item_cap) { P.item_key[d] = fmix64(P.qhash[r]); P.item_val[d] = r; }
+        else atomicOr(&P.pc[PC_ERR], PAIR_ERR_ITEMS);
+      }
+      __builtin_amdgcn_wave_barrier();
+      cnt = 0;
+    }
+  };
+  uint64_t cur[PR_ILP], nxt[PR_ILP];
+  auto load = [&](uint64_t base, uint64_t (&x)[PR_ILP]) {
+#pragma unroll
+    for (int j = 0; j < PR_ILP; ++j) {
+      const uint64_t r = base + 64ull * j + lane;
+      x[j] = r < r1 ? P.qhash[r] : 0ull;
+    }
+  };
+  load(r0, cur);
+  for (uint64_t base = r0; base < r1; base += 64 * PR_ILP) {
+    load(base + 64 * PR_ILP, nxt);
+    bool hit[PR_ILP];
+#pragma unroll
+    for (int j = 0; j < PR_ILP; ++j) {
+      const uint64_t r = base + 64ull * j + lane;
+      hit[j] = r < r1 && bloom_test(P.bloom, P.bloom_mask, fmix64(cur[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < PR_ILP; ++j) {
+      const unsigned long long mk = __ballot(hit[j]);
+      if (hit[j]) buf[cnt + __popcll(mk & below)] = (uint32_t)(base + 64ull * j + lane);
+      cnt += (uint32_t)__popcll(mk);
+    }
+    if (cnt >= PR_STAGE) flush();
+#pragma unroll
+    for (int j = 0; j < PR_ILP; ++j) cur[j] = nxt[j];
+  }
+  flush();
+}
+
+// ---- the replay of Cache.add for one qname group ------------------------------------------------------------------
+struct DTread {   // tread (cluster.nim:23-32) with the unit as (length, kmer code)
+  int32_t tid;
+  uint32_t position;
+  uint32_t k, code;
+  uint16_t flag;
+  uint8_t split, mapq, count, align_length;
+  uint32_t qid;
+};
+
+__device__ __forceinline__ double p_repeat(const DTread &t) {   // extract.nim:56-58 (uint8 product)
+  const uint8_t prod = (uint8_t)(t.count * (uint8_t)t.k);
+  const uint8_t al = t.align_length ? t.align_length : 1;
+  return (double)prod / (double)al;
+}
+// minimum rotation of the reverse complement (utils.nim:61-80) on 2-bit "CATG" codes: complement of c is 3 - c
+__device__ inline uint32_t min_rev_complement(uint32_t code, uint32_t k) {
+  if (k == 0) return code;
+  uint32_t c = 0;
+  for (int i = (int)k - 1; i >= 0; --i) c = (c << 2) | (3u - ((code >> (2 * (k - 1 - i))) & 3u));
+  const uint32_t mask = (1u << (2 * k)) - 1u;
+  uint32_t best = c, f = c;
+  for (uint32_t j = 0; j < k; ++j) {
+    f = ((f << 2) | (f >> (2 * (k - 1)))) & mask;
+    best = f < best ? f : best;
+  }
+  return best;
+}
+// canonical_repeat, utils.nim:291-316: the rev-comp rotation minimum if it is ASCII-smaller (A < C < G < T)
+__device__ inline uint32_t canonical_repeat(uint32_t code, uint32_t k) {
+  const uint32_t r = min_rev_complement(code, k);
+  for (uint32_t j = 0; j < k; ++j) {
+    const uint32_t a = (r >> (2 * (k - 1 - j))) & 3u, b = (code >> (2 * (k - 1 - j))) & 3u;
+    // code -> ASCII rank: C(0) -> 1, A(1) -> 0, T(2) -> 3, G(3) -> 2
+    const uint32_t ra = a ^ 1u, rb = b ^ 1u;
+    if (ra != rb) return ra < rb ? r : code;
+  }
+  return code;
+}
+__device__ __forceinline__ bool should_reverse(uint16_t f) {   // extract.nim:134-139
+  const bool r = !(f & F_MREVERSE);
+  return (f & F_REVERSE) ? !r : r;
+}
+// adjust_by, extract.nim:141-179
+__device__ inline bool adjust_by(DTread &A, const DTread &B, const PairParams &P, uint32_t B_position) {
+  if (A.count == 0) return false;
+  const uint32_t half = (uint32_t)((double)A.align_length / 2.0 + 0.5);
+  if (B.mapq > P.min_mapq && ((p_repeat(A) > P.p && p_repeat(B) < 0.2) || (!(A.flag & F_PROPER) && A.mapq < P.min_mapq))) {
+    if (B.flag & F_REVERSE) {
+      A.position = B_position - (uint32_t)P.frag_median + B.align_length + half;
+      if (B.split == STRL_SOFT_NONE_LEFT) A.position = B_position;
+    } else {
+      A.position = B_position + (uint32_t)P.frag_median - half;
+      if (B.split == STRL_SOFT_NONE_RIGHT) A.position = B_position + (uint32_t)B.align_length;
+    }
+    A.split = STRL_SOFT_NONE;
+    A.tid = B.tid;
+    A.mapq = A.mapq > B.mapq ? A.mapq : B.mapq;
+    if (should_reverse(A.flag)) A.code = min_rev_complement(A.code, A.k);
+  } else if (A.mapq >= P.min_mapq || (A.flag & F_PROPER)) {
+    A.position += half;
+    A.mapq = A.mapq > B.mapq ? A.mapq : B.mapq;
+  }
+  return true;
+}
+__device__ inline bool unplaced_pair(const DTread &A, const DTread &B, const PairParams &P) {   // extract.nim:182-190
+  if (p_repeat(A) > P.p && p_repeat(B) > P.p) return true;
+  if (p_repeat(A) > P.p && B.mapq < P.min_mapq) return true;
+  if (p_repeat(B) > P.p && A.mapq < P.min_mapq) return true;
+  return false;
+}
+
+struct Emit {   // what one run emits, buffered until the block reserves output space
+  strl_tread t[PAIR_MAXE];
+  uint64_t key[PAIR_MAXE];
+  int n;
+  bool overflow;
+};
+__device__ inline void emit(Emit &E, const DTread &d, uint64_t vidx, uint32_t &seq) {
+  if (E.n >= PAIR_MAXE) { E.overflow = true; return; }
+  strl_tread &t = E.t[E.n];
+  t.tid = d.tid;
+  t.position = d.position;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) t.repeat[j] = (uint32_t)j < d.k ? "CATG"[(d.code >> (2 * (d.k - 1 - j))) & 3u] : (char)0;
+  t.flag = d.flag;
+  t.split = d.split;
+  t.mapping_quality = d.mapq;
+  t.repeat_count = d.count;
+  t.align_length = d.align_length;
+  t.qname_id = (int64_t)d.qid;
+  E.key[E.n] = (vidx << 2) | (uint64_t)(seq & 3u);
+  ++seq;
+  ++E.n;
+}
+
+struct GroupCtx {
+  const PairParams &P;
+  const uint32_t *vals;   // sorted values of the (sub)group's items
+  int i0, i1;             // [i0, i1) reads then soft records
+  uint32_t *err;
+};
+
+// to_tread, extract.nim:63-87, from the packed scorer word and the SoA metadata
+__device__ inline DTread to_tread(const PairParams &P, uint32_t r, uint32_t &err) {
+  const uint32_t w = P.whole[r];
+  DTread t;
+  t.k = STRL_RES_K(w);
+  t.code = STRL_RES_CODE(w);
+  const uint32_t cnt = STRL_RES_COUNT(w);
+  if (cnt >= 256) err |= PAIR_ERR_ASSERT;   // doAssert extract.nim:72
+  const uint32_t cg = P.cig[r];
+  // extract.nim:33 / :38: the M length of a skipped read (clip_l carries it for single-M cigars), else len(read)
+  const uint32_t al = (w & STRL_RES_SKIPPED) ? (uint32_t)P.clip_l[r] : (uint32_t)P.l_seq[r];
+  t.tid = P.tid[r];
+  const int32_t ps = P.pos[r];
+  t.position = (uint32_t)(ps > 0 ? ps : 0);
+  t.flag = P.flag[r];
+  t.count = (uint8_t)cnt;
+  t.align_length = (uint8_t)al;
+  t.split = STRL_SOFT_NONE;
+  t.mapq = P.mapq[r];
+  t.qid = r;
+  const bool multi = !(cg & (STRL_CIG_ONE_OP | STRL_CIG_NONE));
+  if (multi && (cg & STRL_CIG_FIRST_S) && P.clip_l[r] > 16) t.split = STRL_SOFT_NONE_LEFT;
+  if (multi && (cg & STRL_CIG_LAST_S) && P.clip_r[r] > 16) t.split = STRL_SOFT_NONE_RIGHT;
+  return t;
+}
+
+// add_soft, extract.nim:93-132, consuming the soft-clip records that joined the group (records without a result
+// under either threshold never joined: they could only `continue` at :117)
+__device__ inline void add_soft(const GroupCtx &G, uint32_t r, bool first_seen, uint32_t read_k, Emit &E, uint64_t vidx, uint32_t &seq) {
+  const PairParams &P = G.P;
+  if (P.mapq[r] < P.min_mapq) return;
+  const uint32_t cg = P.cig[r];
+  if ((cg & STRL_CIG_NONE) || !(cg & (STRL_CIG_FIRST_S | STRL_CIG_LAST_S))) return;
+  for (int q = 0; q < 2; ++q) {
+    // cig_index in [0, L-1]: with a single op both iterations look at op 0
+    const int side = (q == 0 || (cg & STRL_CIG_ONE_OP)) ? 0 : 1;
+    if (!(cg & (side == 0 ? STRL_CIG_FIRST_S : STRL_CIG_LAST_S))) continue;
+    const uint32_t clen = side == 0 ? P.clip_l[r] : P.clip_r[r];
+    if (read_k == 0 && clen <= 16) continue;
+    uint32_t w = 0;
+    const uint32_t want = (r << 1) | (uint32_t)side;
+    for (int j = G.i0; j < G.i1; ++j) {
+      const uint32_t v = G.vals[j];
+      if (!(v & 0x80000000u)) continue;
+      const strl_soft_rec s = P.soft[v & 0x7fffffffu];
+      if (s.read_side == want) { w = first_seen ? s.res_first : s.res_after; break; }
+    }
+    const uint32_t cnt = STRL_RES_COUNT(w);
+    if (cnt == 0) continue;
+    if (cnt >= 256) *G.err |= PAIR_ERR_ASSERT;
+    DTread t;
+    t.k = STRL_RES_K(w);
+    t.code = STRL_RES_CODE(w);
+    t.tid = P.tid[r];
+    const int32_t p = side == 0 ? P.pos[r] : P.end[r];
+    t.position = (uint32_t)(p > 0 ? p : 0);
+    t.flag = P.flag[r];
+    t.count = (uint8_t)cnt;
+    t.align_length = (uint8_t)clen;
+    t.split = side == 0 ? STRL_SOFT_LEFT : STRL_SOFT_RIGHT;
+    t.mapq = P.mapq[r];
+    t.qid = r;
+    if (p_repeat(t) < 0.9) continue;
+    emit(E, t, vidx, seq);
+  }
+}
+
+// Cache.add, extract.nim:192-248, for record r of the group
+__device__ inline void cache_add(const GroupCtx &G, uint32_t r, uint64_t vidx, bool &stored, DTread &S, Emit &E) {
+  const PairParams &P = G.P;
+  const uint16_t fl = P.flag[r];
+  if (fl & (F_SECONDARY | F_SUPPL)) return;   // extract.nim:309,327
+  const int32_t tid = P.tid[r], mtid = P.mtid[r], start = P.pos[r], mpos = P.mpos[r];
+  const bool after_mate = tid > mtid || (tid == mtid && (start > mpos || (start == mpos && stored)));
+  uint32_t seq = 0;
+  if (after_mate) {
+    if (!stored) return;
+    DTread mate = S;
+    stored = false;
+    DTread self = to_tread(P, r, *G.err);
+    add_soft(G, r, false, self.k, E, vidx, seq);
+    if (mate.count == 0 && self.count == 0) return;
+    if (unplaced_pair(self, mate, P)) {
+      if (self.k == 0 || mate.k == 0) return;
+      self.code = canonical_repeat(self.code, self.k);
+      self.position = 0;
+      self.tid = -1;
+      mate.code = canonical_repeat(mate.code, mate.k);
+      mate.position = 0;
+      mate.tid = -1;
+      emit(E, self, vidx, seq);
+      emit(E, mate, vidx, seq);
+      return;
+    }
+    const uint32_t mp = mate.position;
+    if (adjust_by(mate, self, P, self.position)) emit(E, mate, vidx, seq);
+    if (adjust_by(self, mate, P, mp)) emit(E, self, vidx, seq);
+  } else {
+    const DTread tr = to_tread(P, r, *G.err);
+    add_soft(G, r, true, tr.k, E, vidx, seq);
+    if (stored) stored = false;   // hasKeyOrPut hit: warn + take, the new tread is not stored (:245-248)
+    else { S = tr; stored = true; }
+  }
+}
+
+// One lane per run of items with equal low 32 hash bits (the sorted key); lanes that do not start a run idle.
+__global__ __launch_bounds__(1024) void pair_groups_kernel(PairParams P) {
+  __shared__ uint32_t wtot[16];
+  __shared__ uint32_t base_sh;
+  uint32_t n_items = P.pc[PC_ITEMS];
+  if (n_items > P.item_cap) n_items = P.item_cap;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t b0 = blockIdx.x * 1024u; b0 < n_items; b0 += gridDim.x * 1024u) {
+    const uint32_t i = b0 + threadIdx.x;
+    Emit E;
+    E.n = 0;
+    E.overflow = false;
+    uint32_t err = 0;
+    if (i < n_items) {
+      const uint32_t lo = (uint32_t)P.item_key[i];
+      const bool head = i == 0 || (uint32_t)P.item_key[i - 1] != lo;
+      if (head) {
+        uint64_t hk[PAIR_MAXM];
+        uint32_t hv[PAIR_MAXM];
+        int m = 0;
+        bool too_long = false;
+        for (uint32_t j = i; j < n_items; ++j) {
+          const uint64_t k = P.item_key[j];
+          if ((uint32_t)k != lo) break;
+          if (m == PAIR_MAXM) { too_long = true; break; }
+          // insertion by (hash, value): reads (ascending record index) before the soft-clip records of the same hash
+          const uint32_t v = P.item_val[j];
+          int q = m;
+          while (q > 0 && (hk[q - 1] > k || (hk[q - 1] == k && hv[q - 1] > v))) { hk[q] = hk[q - 1]; hv[q] = hv[q - 1]; --q; }
+          hk[q] = k; hv[q] = v;
+          ++m;
+        }
+        if (too_long) err |= PAIR_ERR_RUN;
+        else {
+          int a = 0;
+          while (a < m) {
+            int b = a + 1;
+            while (b < m && hk[b] == hk[a]) ++b;
+            GroupCtx G{P, hv, a, b, &err};
+            bool stored = false;
+            DTread S{};
+            for (int j = a; j < b; ++j) {            // extract.nim:308-322
+              if (hv[j] & 0x80000000u) break;
+              cache_add(G, hv[j], (uint64_t)hv[j], stored, S, E);
+            }
+            for (int j = a; j < b; ++j) {            // extract.nim:326-329: the unmapped tail once more
+              if (hv[j] & 0x80000000u) break;
+              if (hv[j] >= P.tail_start) cache_add(G, hv[j], (uint64_t)P.n + (uint64_t)(hv[j] - P.tail_start), stored, S, E);
+            }
+            a = b;
+          }
+        }
+      }
+    }
+    if (E.overflow) err |= PAIR_ERR_LOCAL;
+    if (err) atomicOr(&P.pc[PC_ERR], err);
+    // block-wide reservation of output space: one atomic per 1024 items
+    uint32_t inc = (uint32_t)E.n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t tot = 0;
+      for (int w = 0; w < 16; ++w) { const uint32_t c = wtot[w]; wtot[w] = tot; tot += c; }
+      base_sh = tot ? atomicAdd(&P.pc[PC_EMIT], tot) : 0u;
+    }
+    __syncthreads();
+    const uint32_t at = base_sh + wtot[wave] + inc - (uint32_t)E.n;
+    for (int e = 0; e < E.n; ++e) {
+      const uint32_t d = at + (uint32_t)e;
+      if (d < P.emit_cap) { P.emit[d] = E.t[e]; P.emit_key[d] = E.key[e]; P.emit_val[d] = d; }
+      else atomicOr(&P.pc[PC_ERR], PAIR_ERR_EMIT);
+    }
+    __syncthreads();
+  }
+}
+
+// treads in the order of the reference's .bin file
+__global__ __launch_bounds__(256) void pair_order_kernel(const uint32_t *pc, uint32_t emit_cap, const strl_tread *emit, const uint32_t *perm,
+                                                         strl_tread *out, uint32_t *n_out) {
+  uint32_t n = pc[PC_EMIT];
+  if (n > emit_cap) n = emit_cap;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i == 0) *n_out = n;
+  if (i >= n) return;
+  const uint4 *src = reinterpret_cast<const uint4 *>(emit + perm[i]);
+  uint4 *dst = reinterpret_cast<uint4 *>(out + i);
+  dst[0] = src[0];
+  dst[1] = src[1];
+}
+
+}  // namespace strl
+
+using namespace strl;
+
+// Enqueue the pair logic behind a scoring pass of the same batch (score_device has run on c->stream with the pairing
+// arrays given, so the whole-read marks are in the bitmap).  Everything is asynchronous; results stay on the device:
+// c->treads[0, *c->n_treads).
+int strl_pair_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *pp, const uint32_t *whole, const strl_soft_rec *soft,
+                     uint64_t soft_cap, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap) {
+  const uint64_t n = s->n;
+  if (n_tail < 0 || (uint64_t)n_tail > n) { set_error("strl_pair_device: n_tail must be in [0, n]"); return STRL_ERR_ARG; }
+  if (item_cap > 0x7ffffff0ull || tread_cap > 0x7ffffff0ull) { set_error("pair capacities too large"); return STRL_ERR_ARG; }
+  hipStream_t st = c->stream;
+  int rc;
+  const uint32_t icap = (uint32_t)std::max<uint64_t>(item_cap, 1024), ecap = (uint32_t)std::max<uint64_t>(tread_cap, 1024);
+  int ebits = 3;   // emission key: (virtual record index < 2n) << 2 | sequence number
+  while (ebits < 40 && ((2 * n) >> (ebits - 2))) ++ebits;
+  const size_t sb = std::max(radix_sort_scratch_bytes(icap, 32), radix_sort_scratch_bytes(ecap, ebits));
+  if ((rc = c->p_key0.reserve((size_t)std::max(icap, ecap) * 8)) || (rc = c->p_key1.reserve((size_t)std::max(icap, ecap) * 8)) ||
+      (rc = c->p_val0.reserve((size_t)std::max(icap, ecap) * 4)) || (rc = c->p_val1.reserve((size_t)std::max(icap, ecap) * 4)) ||
+      (rc = c->p_emit.reserve((size_t)ecap * sizeof(strl_tread))) || (rc = c->treads.reserve((size_t)ecap * sizeof(strl_tread) + 64)) ||
+      (rc = c->sort_scratch.reserve(sb)) || (rc = c->pair_cnt.reserve(PC_WORDS * 4 + 64)))
+    return rc;
+  STRL_HIP(hipMemsetAsync(c->pair_cnt.p, 0, PC_WORDS * 4 + 64, st));
+  PairParams P{};
+  P.n = (uint32_t)n;
+  P.tail_start = (uint32_t)(n - (uint64_t)n_tail);
+  P.tid = s->tid; P.pos = s->pos; P.end = s->end; P.mtid = pp->mtid; P.mpos = pp->mpos; P.flag = pp->flag;
+  P.l_seq = s->l_seq; P.clip_l = s->clip_l; P.clip_r = s->clip_r; P.mapq = s->mapq; P.cig = s->cig; P.qhash = pp->qhash;
+  P.whole = whole; P.soft = soft; P.score_cnt = c->counters.as<uint32_t>();
+  P.scap = (uint32_t)std::max<uint64_t>(std::min<uint64_t>(soft_cap, 2 * n), 1);
+  P.bloom = c->bloom.as<uint32_t>(); P.bloom_mask = c->bloom_mask;
+  P.item_key = c->p_key0.as<uint64_t>(); P.item_val = c->p_val0.as<uint32_t>(); P.item_cap = icap;
+  P.pc = c->pair_cnt.as<uint32_t>();
+  P.emit = c->p_emit.as<strl_tread>(); P.emit_key = c->p_key0.as<uint64_t>(); P.emit_val = c->p_val0.as<uint32_t>(); P.emit_cap = ecap;
+  P.p = c->opts.proportion_repeat; P.min_mapq = c->opts.min_mapq; P.frag_median = c->opts.median_fragment_length;
+  hipEvent_t *ev = c->timing ? c->pev : nullptr;
+  if (ev) STRL_HIP(hipEventRecord(ev[0], st));
+  if (n) {
+    hipLaunchKernelGGL(pair_soft_items_kernel, dim3(256), dim3(1024), 0, st, P);
+    const int pblocks = (int)std::min<uint64_t>((n + 2047) / 2048, 2048);
+    hipLaunchKernelGGL(pair_probe_kernel, dim3(pblocks), dim3(256), 0, st, P);
+    STRL_HIP(hipGetLastError());
+  }
+  if (ev) STRL_HIP(hipEventRecord(ev[1], st));
+  // join: sort the items by the low 32 bits of the (mixed) hash; runs are disambiguated by the full hash in the replay
+  uint64_t *ik = nullptr;
+  uint32_t *iv = nullptr;
+  int e = radix_sort_pairs(st, P.pc + PC_ITEMS, icap, c->p_key0.as<uint64_t>(), c->p_val0.as<uint32_t>(), c->p_key1.as<uint64_t>(),
+                           c->p_val1.as<uint32_t>(), c->sort_scratch.p, c->sort_scratch.cap, 0, 32, &ik, &iv);
+  if (e) { set_error("radix_sort_pairs failed: %s", hipGetErrorString((hipError_t)e)); return STRL_ERR_HIP; }
+  if (ev) STRL_HIP(hipEventRecord(ev[2], st));
+  // the sorted items sit in (ik, iv); the emission keys go to the other pair of buffers
+  P.item_key = ik; P.item_val = iv;
+  const bool in0 = ik == c->p_key0.as<uint64_t>();
+  uint64_t *ek = in0 ? c->p_key1.as<uint64_t>() : c->p_key0.as<uint64_t>();
+  uint32_t *evl = in0 ? c->p_val1.as<uint32_t>() : c->p_val0.as<uint32_t>();
+  P.emit_key = ek; P.emit_val = evl;
+  if (n) {
+    hipLaunchKernelGGL(pair_groups_kernel, dim3((unsigned)std::min<uint32_t>((icap + 1023) / 1024, 4096)), dim3(1024), 0, st, P);
+    STRL_HIP(hipGetLastError());
+  }
+  if (ev) STRL_HIP(hipEventRecord(ev[3], st));
+  // the items are consumed: their buffers are the sort's second pair now
+  uint64_t *ok = nullptr;
+  uint32_t *ov = nullptr;
+  e = radix_sort_pairs(st, P.pc + PC_EMIT, ecap, ek, evl, ik, iv, c->sort_scratch.p, c->sort_scratch.cap, 0, ebits, &ok, &ov);
+  if (e) { set_error("radix_sort_pairs failed: %s", hipGetErrorString((hipError_t)e)); return STRL_ERR_HIP; }
+  c->n_treads_dev = reinterpret_cast<uint32_t *>(c->treads.as<uint8_t>() + (size_t)ecap * sizeof(strl_tread));
+  hipLaunchKernelGGL(pair_order_kernel, dim3((ecap + 255) / 256), dim3(256), 0, st, P.pc, ecap, P.emit, ov, c->treads.as<strl_tread>(), c->n_treads_dev);
+  STRL_HIP(hipGetLastError());
+  if (ev) STRL_HIP(hipEventRecord(ev[4], st));
+  c->tread_cap = ecap;
+  c->pair_item_cap = icap;
+  return STRL_OK;
+}

@@ -14,6 +14,7 @@
 #include <string.h>
 #include <algorithm>
 #include "common.h"
+#include "device_util.h"
 #include "score_core.h"
 #include "score_tables.h"
 
@@ -59,8 +60,6 @@ constexpr int BIN_SHIFT = 12;
 //   segment    : id (read index << 1 | side, or a window index) | seq_off | first base | length
 // Stage-B items are 32 bytes: the entry + {slot, best, res0, res1}.
 constexpr uint32_t EMPTY = 0xffffffffu;
-constexpr int CNT_STRIDE = 16;   // counters 64 B apart
-constexpr int CNT_QUEUE = 0, CNT_SOFT = 16, CNT_SKIP = 32, CNT_SBW = 48, CNT_SBS = 64, CNT_WORDS = 80;
 
 struct ScoreParams {
   uint64_t n;
@@ -87,6 +86,10 @@ struct ScoreParams {
   uint32_t soft_cap;
   uint32_t min_mapq;
   int32_t seg_row0, seg_row1;   // threshold rows of the segment scorer: (2,3) for soft clips, (1,1) for genome windows
+  // pair logic (pair.hip): a whole read with a repeat marks its qname group in the Bloom bitmap; nullptr = no pairing
+  const uint64_t *qhash;
+  uint32_t *bloom;
+  uint32_t bloom_mask;
 };
 
 constexpr int LUT_DWORDS = LUT_ENTRIES / 2;
@@ -541,6 +544,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? 4 : 1) void sco
         uint32_t flag = 0;
         if (fin) {
           P.whole[cur.id] = o0;
+          if (P.bloom && STRL_RES_COUNT(o0)) bloom_set(P.bloom, P.bloom_mask, fmix64(P.qhash[cur.id]));
           // add_soft gates, extract.nim:97-106
           if (cur.mq >= P.min_mapq && (cur.cg & (STRL_CIG_FIRST_S | STRL_CIG_LAST_S))) {
             const bool has_unit = STRL_RES_K(o0) != 0;
@@ -647,6 +651,7 @@ int strl_ctx_create(int device_ordinal, strl_ctx **out) {
   c->device = device_ordinal;
   STRL_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (auto &e : c->ev) STRL_HIP(hipEventCreate(&e));
+  for (auto &e : c->pev) STRL_HIP(hipEventCreate(&e));
   std::vector<uint16_t> lut;
   build_lut(lut);
   std::vector<uint32_t> clut;
@@ -667,10 +672,13 @@ void strl_ctx_destroy(strl_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   strl::DevBuf *bufs[] = {&c->lut, &c->thr, &c->g_tid, &c->g_bins, &c->g_start, &c->g_pmax, &c->queue, &c->soft_queue, &c->counters,
                           &c->soft_tmp, &c->sb_whole, &c->sb_soft, &c->queue_r, &c->soft_dense, &c->sb_state_w, &c->sb_state_s, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
-                          &c->st_mapq, &c->st_cig, &c->st_seq4, &c->st_whole, &c->st_soft};
+                          &c->st_mapq, &c->st_cig, &c->st_seq4, &c->st_whole, &c->st_soft, &c->st_text,
+                          &c->p_key0, &c->p_key1, &c->p_val0, &c->p_val1, &c->p_emit, &c->sort_scratch, &c->pair_cnt, &c->bloom, &c->treads,
+                          &c->st_mtid, &c->st_mpos, &c->st_flag, &c->st_qhash};
   for (auto *b : bufs) b->release();
   for (auto &b : c->c_buf) b.release();
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+  for (auto &e : c->pev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->ring) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -810,7 +818,7 @@ int strl_ctx_set_genome(strl_ctx *c, const strl_genome_str *g) {
 }
 
 static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, strl_soft_rec *soft, uint64_t soft_cap,
-                        uint64_t *n_soft, strl_score_stats *stats, bool sync_counts) {
+                        uint64_t *n_soft, strl_score_stats *stats, bool sync_counts, const strl_pair_soa *pp = nullptr) {
   const uint64_t n = s->n;
   if (n > 0x3fffffffull) { set_error("batch too large (%llu reads; limit 2^30-1)", (unsigned long long)n); return STRL_ERR_ARG; }
   if (s->max_l_seq > STRL_MAX_READ_LEN) { set_error("read of %u bases exceeds STRL_MAX_READ_LEN=%d", s->max_l_seq, STRL_MAX_READ_LEN); return STRL_ERR_ARG; }
@@ -842,6 +850,15 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   P.soft_cap = (uint32_t)std::min<uint64_t>(soft_cap, 0xffffffffull);
   P.min_mapq = c->opts.min_mapq;
   P.seg_row0 = 2; P.seg_row1 = 3;
+  if (pp) {
+    // Bloom bitmap of the hot qname groups: ~n/2 bits (2 MB for 2^25 reads: L2 resident), two bits per key
+    uint64_t bits = 1ull << 16;
+    while (bits < n / 2 && bits < (1ull << 27)) bits <<= 1;
+    if ((rc = c->bloom.reserve((size_t)(bits / 8)))) return rc;
+    STRL_HIP(hipMemsetAsync(c->bloom.p, 0, (size_t)(bits / 8), c->stream));
+    c->bloom_mask = (uint32_t)(bits - 1);
+    P.qhash = pp->qhash; P.bloom = c->bloom.as<uint32_t>(); P.bloom_mask = c->bloom_mask;
+  }
   hipEvent_t *tev = c->timing ? &c->ring[(c->ring_pos % RING) * EV_PER] : nullptr;
   if (c->timing) ++c->ring_pos;
   if (tev) STRL_HIP(hipEventRecord(tev[0], c->stream));
@@ -880,6 +897,36 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
         (void)hipEventElapsedTime(&stats->ms_score, tev[1], tev[4]);
         (void)hipEventElapsedTime(&stats->ms_soft, tev[4], tev[8]);
       }
+    }
+  }
+  return STRL_OK;
+}
+
+// host-memory batch -> staging buffers in HBM (asynchronous copies on the context stream)
+static int stage_batch(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *pp, strl_read_soa *d, strl_pair_soa *dpp) {
+  const uint64_t n = s->n;
+  *d = *s;
+  int rc;
+  struct { strl::DevBuf *b; const void *src; size_t bytes; const void **dst; } cp[] = {
+      {&c->st_tid, s->tid, (size_t)n * 4, (const void **)&d->tid},         {&c->st_pos, s->pos, (size_t)n * 4, (const void **)&d->pos},
+      {&c->st_end, s->end, (size_t)n * 4, (const void **)&d->end},         {&c->st_seqoff, s->seq_off, (size_t)n * 4, (const void **)&d->seq_off},
+      {&c->st_lseq, s->l_seq, (size_t)n * 2, (const void **)&d->l_seq},    {&c->st_clipl, s->clip_l, (size_t)n * 2, (const void **)&d->clip_l},
+      {&c->st_clipr, s->clip_r, (size_t)n * 2, (const void **)&d->clip_r}, {&c->st_mapq, s->mapq, (size_t)n, (const void **)&d->mapq},
+      {&c->st_cig, s->cig, (size_t)n, (const void **)&d->cig},             {&c->st_seq4, s->seq4, (size_t)s->seq4_bytes, (const void **)&d->seq4}};
+  for (auto &x : cp) {
+    if ((rc = x.b->reserve(std::max<size_t>(x.bytes, 64)))) return rc;
+    if (x.bytes) STRL_HIP(hipMemcpyAsync(x.b->p, x.src, x.bytes, hipMemcpyHostToDevice, c->stream));
+    *x.dst = x.b->p;
+  }
+  d->mem = STRL_MEM_DEVICE;
+  if (pp) {
+    struct { strl::DevBuf *b; const void *src; size_t bytes; const void **dst; } cq[] = {
+        {&c->st_mtid, pp->mtid, (size_t)n * 4, (const void **)&dpp->mtid}, {&c->st_mpos, pp->mpos, (size_t)n * 4, (const void **)&dpp->mpos},
+        {&c->st_flag, pp->flag, (size_t)n * 2, (const void **)&dpp->flag}, {&c->st_qhash, pp->qhash, (size_t)n * 8, (const void **)&dpp->qhash}};
+    for (auto &x : cq) {
+      if ((rc = x.b->reserve(std::max<size_t>(x.bytes, 64)))) return rc;
+      if (x.bytes) STRL_HIP(hipMemcpyAsync(x.b->p, x.src, x.bytes, hipMemcpyHostToDevice, c->stream));
+      *x.dst = x.b->p;
     }
   }
   return STRL_OK;
@@ -935,20 +982,9 @@ int strl_score_reads(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, strl_
   }
   // host batch: stage to HBM, run, copy results back
   const uint64_t n = s->n;
-  strl_read_soa d = *s;
+  strl_read_soa d;
   int rc;
-  struct { strl::DevBuf *b; const void *src; size_t bytes; const void **dst; } cp[] = {
-      {&c->st_tid, s->tid, (size_t)n * 4, (const void **)&d.tid},         {&c->st_pos, s->pos, (size_t)n * 4, (const void **)&d.pos},
-      {&c->st_end, s->end, (size_t)n * 4, (const void **)&d.end},         {&c->st_seqoff, s->seq_off, (size_t)n * 4, (const void **)&d.seq_off},
-      {&c->st_lseq, s->l_seq, (size_t)n * 2, (const void **)&d.l_seq},    {&c->st_clipl, s->clip_l, (size_t)n * 2, (const void **)&d.clip_l},
-      {&c->st_clipr, s->clip_r, (size_t)n * 2, (const void **)&d.clip_r}, {&c->st_mapq, s->mapq, (size_t)n, (const void **)&d.mapq},
-      {&c->st_cig, s->cig, (size_t)n, (const void **)&d.cig},             {&c->st_seq4, s->seq4, (size_t)s->seq4_bytes, (const void **)&d.seq4}};
-  for (auto &x : cp) {
-    if ((rc = x.b->reserve(std::max<size_t>(x.bytes, 64)))) return rc;
-    if (x.bytes) STRL_HIP(hipMemcpyAsync(x.b->p, x.src, x.bytes, hipMemcpyHostToDevice, c->stream));
-    *x.dst = x.b->p;
-  }
-  d.mem = STRL_MEM_DEVICE;
+  if ((rc = stage_batch(c, s, nullptr, &d, nullptr))) return rc;
   if ((rc = c->st_whole.reserve((size_t)std::max<uint64_t>(n, 1) * 4))) return rc;
   const uint64_t dcap = 2 * n + 2;   // at most two clipped ends per read
   if ((rc = c->st_soft.reserve((size_t)std::max<uint64_t>(dcap, 1) * sizeof(strl_soft_rec)))) return rc;
@@ -963,6 +999,69 @@ int strl_score_reads(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, strl_
   if (soft && ns) std::sort(soft, soft + ns, [](const strl_soft_rec &a, const strl_soft_rec &b) { return a.read_side < b.read_side; });
   if (n_soft) *n_soft = ns;
   if (stats) *stats = st;
+  return STRL_OK;
+}
+
+int strl_extract_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *pp, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap) {
+  if (!c || !s || !pp) { set_error("null argument"); return STRL_ERR_ARG; }
+  if (!c->have_opts) { set_error("strl_ctx_set_opts must be called before scoring"); return STRL_ERR_ARG; }
+  if (s->n && (!pp->mtid || !pp->mpos || !pp->flag || !pp->qhash)) { set_error("strl_extract_device: incomplete strl_pair_soa"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  const uint64_t n = s->n;
+  if (n_tail < 0 || (uint64_t)n_tail > n) { set_error("strl_extract_device: n_tail must be in [0, n]"); return STRL_ERR_ARG; }
+  if (!item_cap) item_cap = n / 8 + 65536;
+  if (!tread_cap) tread_cap = n / 16 + 65536;
+  item_cap = std::min<uint64_t>(item_cap, 3 * n + 16);    // every read and both of its clipped ends
+  tread_cap = std::min<uint64_t>(tread_cap, 8 * n + 16);
+  strl_read_soa d = *s;
+  strl_pair_soa dp = *pp;
+  int rc;
+  if (s->mem != STRL_MEM_DEVICE && (rc = stage_batch(c, s, pp, &d, &dp))) return rc;
+  const uint64_t soft_cap = std::min<uint64_t>(item_cap, 2 * n + 2);
+  if ((rc = c->st_whole.reserve((size_t)std::max<uint64_t>(n, 1) * 4))) return rc;
+  if ((rc = c->st_soft.reserve((size_t)std::max<uint64_t>(soft_cap, 1) * sizeof(strl_soft_rec)))) return rc;
+  c->ex_n = n; c->ex_soft_cap = soft_cap;
+  if ((rc = score_device(c, &d, c->st_whole.as<uint32_t>(), c->st_soft.as<strl_soft_rec>(), soft_cap, nullptr, nullptr, false, &dp))) return rc;
+  return strl_pair_device(c, &d, &dp, c->st_whole.as<uint32_t>(), c->st_soft.as<strl_soft_rec>(), soft_cap, n_tail, item_cap, tread_cap);
+}
+
+int strl_treads_fetch(strl_ctx *c, strl_tread *out, uint64_t cap, uint64_t *n_out, strl_score_stats *stats) {
+  if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
+  if (!c->n_treads_dev) { set_error("strl_treads_fetch: no strl_extract_device call on this context"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  uint32_t raw[CNT_WORDS], pc[PC_WORDS];
+  STRL_HIP(hipMemcpyAsync(raw, c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
+  STRL_HIP(hipMemcpyAsync(pc, c->pair_cnt.p, PC_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  if (stats) {
+    memset(stats, 0, sizeof *stats);
+    stats->n_reads = c->ex_n; stats->n_skipped = raw[CNT_SKIP]; stats->n_scored = raw[CNT_QUEUE]; stats->n_soft_items = raw[CNT_SOFT];
+    stats->n_stage_b_whole = raw[CNT_SBW]; stats->n_stage_b_soft = raw[CNT_SBS];
+  }
+  if (n_out) *n_out = pc[PC_EMIT];
+  if (raw[CNT_SOFT] > c->ex_soft_cap) { set_error("soft-clip queue overflow: %u items, capacity %llu (raise item_cap)", raw[CNT_SOFT], (unsigned long long)c->ex_soft_cap); return STRL_ERR_CAPACITY; }
+  const uint32_t err = pc[PC_ERR];
+  if (err & PAIR_ERR_ITEMS) { set_error("pair logic: %u join items, capacity %u (raise item_cap)", pc[PC_ITEMS], c->pair_item_cap); return STRL_ERR_CAPACITY; }
+  if (err & PAIR_ERR_EMIT) { set_error("pair logic: %u treads, capacity %u (raise tread_cap)", pc[PC_EMIT], c->tread_cap); return STRL_ERR_CAPACITY; }
+  if (err & (PAIR_ERR_RUN | PAIR_ERR_LOCAL)) { set_error("pair logic: more than 12 records / emissions under one qname hash"); return STRL_ERR_FORMAT; }
+  if (err & PAIR_ERR_ASSERT) { set_error("repeat_count >= 256 (doAssert extract.nim:72)"); return STRL_ERR_ASSERT; }
+  const uint64_t n = pc[PC_EMIT];
+  if (out) {
+    if (n > cap) { set_error("tread capacity %llu too small, need %llu", (unsigned long long)cap, (unsigned long long)n); return STRL_ERR_CAPACITY; }
+    if (n) STRL_HIP(hipMemcpy(out, c->treads.p, (size_t)n * sizeof(strl_tread), hipMemcpyDeviceToHost));
+  }
+  return STRL_OK;
+}
+
+int strl_ctx_pair_times(strl_ctx *c, double ms[4]) {
+  if (!c || !ms) return STRL_ERR_ARG;
+  STRL_HIP(hipSetDevice(c->device));
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 4; ++k) {
+    float f = 0.f;
+    if (c->timing) (void)hipEventElapsedTime(&f, c->pev[k], c->pev[k + 1]);
+    ms[k] = f;
+  }
   return STRL_OK;
 }
 
