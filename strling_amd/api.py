@@ -103,7 +103,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
            "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order",
-           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs"]
+           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident"]
 
 
 def lib_path():
@@ -167,6 +167,9 @@ def load(build_if_missing=True):
     L.strl_extract_device.argtypes = [C.c_void_p, C.POINTER(CReadSoa), C.POINTER(CPairSoa), C.c_int64, C.c_uint64, C.c_uint64]
     L.strl_treads_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(ScoreStats)]
     L.strl_ctx_pair_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 4)]
+    L.strl_cluster_resident.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int, C.c_uint32, C.c_int32, C.c_uint16, C.c_uint16, C.c_uint16,
+                                        C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                        C.POINTER(ClusterStats)]
     L.strl_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
     _LIB = L
     return L
@@ -408,6 +411,29 @@ class Context:
         _check(self.L.strl_cluster(self.h, _ptr(t), t.size, mode, window, min_support, min_clip, min_clip_total, max_clip_dist,
                                    out.ctypes.data, cap, C.byref(no), unpl.ctypes.data, unpl.size, C.byref(nu), C.byref(st)))
         return out[:no.value].copy(), unpl[:nu.value].copy(), st
+
+    def cluster_resident(self, n_tid, window, min_support=5, min_clip=0, min_clip_total=0, max_clip_dist=200, pos_bits=0, fetch=True,
+                         cap=None):
+        """cluster the treads the last extract_device call left on the device (strl_cluster_resident, call mode).
+        fetch=False only enqueues the kernels."""
+        if not fetch:
+            _check(self.L.strl_cluster_resident(self.h, MODE_CALL, n_tid, pos_bits, window, min_support, min_clip, min_clip_total,
+                                                max_clip_dist, None, 0, None, None, 0, None, None))
+            return None
+        cap = cap or 1 << 16
+        while True:
+            out = np.zeros(cap, BOUNDS_DTYPE)
+            unpl = np.zeros(8192, UNPLACED_DTYPE)
+            no, nu = C.c_uint64(0), C.c_uint64(0)
+            st = ClusterStats()
+            rc = self.L.strl_cluster_resident(self.h, MODE_CALL, n_tid, pos_bits, window, min_support, min_clip, min_clip_total,
+                                              max_clip_dist, out.ctypes.data, cap, C.byref(no), unpl.ctypes.data, unpl.size,
+                                              C.byref(nu), C.byref(st))
+            if rc == -4 and no.value > cap:
+                cap = int(no.value)
+                continue
+            _check(rc)
+            return out[:no.value].copy(), unpl[:nu.value].copy(), st
 
     def cluster_members(self, n_bounds):
         """indices (into the tread array of the last cluster() call) of every returned bound's reads, cluster order"""

@@ -2,56 +2,74 @@
 // cluster.nim:175-374; callclusters.nim:52-66), gfx950.
 //
 // The reference groups treads in a hash table keyed by (tid, repeat), merge-sorts every group by
-// position and sweeps each group sequentially.  Here the whole tread set is ONE keyed stable
-// radix sort (position pass, then (tid, unit) pass), after which
-//   ends_kernel   : one tread per lane computes where the cluster that STARTS at it would end --
-//                   the reference's growth rule depends only on the start: <= 9 warm-up steps of
-//                   the running median-of-first-9, then a binary search for pos > posmed+max_dist+100,
-//   walk_kernel   : one lane per group follows start -> end links and flags the cluster heads,
-//   bounds_filter_kernel / bounds_rows_kernel : trim + support gate per cluster, then anchor gate, split_cluster, bounds() and
-//                   the callclusters gate, with Nim CountTable.largest slot-order tie-breaks
-//                   reproduced on the device (nim_tables.h).
-// HBM-bound integer work; sizes are ~1e6 treads per 30x sample (5e7 for a 50-sample merge).
-#include <hipcub/hipcub.hpp>
+// position and sweeps each group sequentially.  Here the whole tread set -- a host array, or the treads the device
+// pair logic left resident in the context -- goes through
+//   tread_keys_kernel : tread -> composite key (tid, unit) << pos_bits | position,
+//   radix sort        : ONE stable LSD sort of the composite key (sort.hip; two sorts when the key needs > 64 bits),
+//   heads / gather    : group heads counted per tile, then group ids, the sorted payload and the per-group tables in one
+//                       launch (a tile sums the head counts of the tiles before it: no scan kernel),
+//   ends_kernel       : one tread per lane computes where the cluster that STARTS at it would end -- the reference's
+//                       growth rule depends only on the start: <= 9 warm-up steps of the running median-of-first-9,
+//                       then a binary search for pos > posmed + max_dist + 100,
+//   walk_kernel       : one lane per group follows start -> end links and flags the cluster heads,
+//   bounds_filter_kernel / bounds_rows_kernel : trim + support gate per cluster head, then anchor gate, split_cluster,
+//                       bounds() and the callclusters gate, with Nim CountTable.largest slot-order tie-breaks
+//                       reproduced on the device (nim_tables.h).
+// Every count (treads, groups, candidates) lives on the device; launches are sized by host-known upper bounds, so the
+// whole pass is enqueued without a host round trip (12 + number-of-sort-passes launches).
+// HBM-bound integer work in principle; at ~1e6 treads per 30x sample it is bound by launch boundaries and dependent-load
+// latency (5e7 treads for a 50-sample merge).
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
 #include "common.h"
 #include "nim_tables.h"
+#include "sort.h"
 
 namespace nim { std::vector<int64_t> table_slot_order(const std::vector<uint64_t> &hcodes, uint64_t initial_size); }
 
 namespace strl {
 
-struct RawBounds {  // one candidate row per (cluster, half)
+struct RawBounds {  // one candidate row per (candidate cluster, half)
   uint32_t valid;   // 1 = passes every gate
-  uint32_t first;   // sorted index of the first read (diagnostics / ordering)
+  uint32_t first;   // sorted index of the first read
+  uint32_t gid;     // group of the cluster
   uint32_t left, left_most, right, right_most, center_mass;
   uint16_t n_left, n_right, n_total, pad;
 };
 
+// device-side counters of one clustering pass
+constexpr int CC_N = 0, CC_NGROUPS = 1, CC_NCAND = 2, CC_NCLUSTERS = 3, CC_BIG = 4, CC_ERR = 5, CC_WORDS = 16;
+constexpr uint32_t CERR_UNIT = 1u, CERR_TID = 2u, CERR_POS = 4u, CERR_CAND = 8u, CERR_BIG = 16u;
+
 struct ClusterParams {
-  uint32_t n;
+  const uint32_t *d_n;      // number of treads (device)
+  uint32_t n_max;
   const uint32_t *pos;      // sorted
   const uint8_t *split;     // sorted
   const uint32_t *sample;   // sorted (qname_id)
   const uint32_t *gid;      // group index of each sorted tread
   const uint32_t *gstart;   // [n_groups+1]
   const uint8_t *gplaced;   // [n_groups] 1 if tid >= 0
-  uint32_t n_groups;
   uint32_t *ends;           // e(s)
   uint32_t *is_start;       // cluster-head flags
-  const uint32_t *cl_start; // [n_clusters] compacted heads
-  const uint32_t *n_clusters;
-  uint32_t *scratch;        // 4 * (16 * n_clusters + 3 * n) dwords
-  uint4 *cand;              // [n_clusters] clusters that pass the support gate: {cluster, first read after trim, end}
-  uint32_t *n_cand;
-  RawBounds *out;           // [2 * n_clusters]
+  uint32_t *cnt;            // CC_* counters
+  uint32_t *big;            // scratch of clusters too large for LDS, handed out with a bump cursor
+  uint32_t big_words;
+  uint4 *cand;              // clusters that pass the support gate: {cluster start, first read after trim, end, group}
+  uint32_t cand_cap;
+  RawBounds *out;           // [2 * cand_cap]
   uint32_t max_dist;
   int32_t min_support;
   uint32_t min_clip, min_clip_total, max_clip_dist;
   int32_t mode;
 };
+
+__device__ __forceinline__ uint32_t n_of(const ClusterParams &P) {
+  const uint32_t n = *P.d_n;
+  return n < P.n_max ? n : P.n_max;
+}
 
 __device__ __forceinline__ uint32_t posmed_at(const uint32_t *pos, uint32_t s, uint32_t n) {
   const uint32_t m = n < 9u ? n : 9u;         // cluster.nim:59-62: reads[int(min(9, n) / 2 - 0.5)]
@@ -60,7 +78,8 @@ __device__ __forceinline__ uint32_t posmed_at(const uint32_t *pos, uint32_t s, u
 
 __global__ __launch_bounds__(256) void ends_kernel(ClusterParams P) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= P.n) return;
+  if (s >= n_of(P)) return;
+  P.is_start[s] = 0u;
   const uint32_t g = P.gid[s];
   const uint32_t ge = P.gstart[g + 1];
   const uint32_t add = P.max_dist + 100u;     // uint32 arithmetic as in cluster.nim:336
@@ -84,13 +103,19 @@ __global__ __launch_bounds__(256) void ends_kernel(ClusterParams P) {
 
 __global__ __launch_bounds__(64) void walk_kernel(ClusterParams P) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= P.n_groups || !P.gplaced[g]) return;
-  uint32_t s = P.gstart[g];
-  const uint32_t ge = P.gstart[g + 1];
-  while (s < ge) {                            // trcluster: the next cluster starts at the first rejected read
-    P.is_start[s] = 1u;
-    s = P.ends[s];
+  uint32_t nc = 0;
+  if (g < P.cnt[CC_NGROUPS] && P.gplaced[g]) {
+    uint32_t s = P.gstart[g];
+    const uint32_t ge = P.gstart[g + 1];
+    while (s < ge) {                          // trcluster: the next cluster starts at the first rejected read
+      P.is_start[s] = 1u;
+      s = P.ends[s];
+      ++nc;
+    }
   }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) nc += __shfl_down(nc, d);
+  if (threadIdx.x == 0 && nc) atomicAdd(&P.cnt[CC_NCLUSTERS], nc);
 }
 
 // Where the sorted reads of the cluster being worked on live: the global arrays, or a copy the wave staged in LDS
@@ -209,25 +234,22 @@ __device__ void cluster_rows(const ClusterParams &P, const V &R, uint32_t s, uin
   }
 }
 
-// bounds in two launches.  bounds_filter_kernel: one lane per cluster for the cheap part (trim, support gate: 98 % of the
-// clusters of a WGS sample end there); survivors are appended to a candidate list with one atomic per 1024 clusters.
-// bounds_rows_kernel: one WAVE per candidate -- all lanes copy the cluster's reads into LDS in one coalesced round trip,
-// then one lane runs the sequential CountTable logic out of LDS (its tables live there too).  With one lane per cluster
-// and every read and table access a dependent global load, the single kernel took 80 us for 5x10^5 treads, all latency.
+// bounds in two launches.  bounds_filter_kernel: one lane per sorted tread; a lane whose tread starts a cluster does the
+// cheap part (trim, support gate: 98 % of the clusters of a WGS sample end there); survivors are appended to a candidate
+// list with one atomic per 1024 treads.  bounds_rows_kernel: one WAVE per candidate -- all lanes copy the cluster's
+// reads into LDS in one coalesced round trip, then one lane runs the sequential CountTable logic out of LDS (its
+// tables live there too).
 constexpr uint32_t BK_LIM = 256;   // reads of a cluster staged in LDS; larger clusters use the global arrays
 __global__ __launch_bounds__(1024) void bounds_filter_kernel(ClusterParams P) {
   __shared__ uint32_t wcnt[16];
   __shared__ uint32_t base_sh;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t nc = *P.n_clusters;
-  uint32_t s = 0, e = 0;
+  const uint32_t s0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nn = n_of(P);
+  uint32_t s = s0, e = 0;
   bool cand = false;
-  if (c < nc) {
-    RawBounds *o = P.out + 2 * (uint64_t)c;
-    o[0].valid = 0; o[1].valid = 0;
-    s = P.cl_start[c];
-    e = P.ends[s];
+  if (s0 < nn && P.is_start[s0]) {
+    e = P.ends[s0];
     uint32_t n = e - s;
     // trim(max_dist + 100), cluster.nim:252-257 -- `lo` is computed once
     const uint32_t md = P.max_dist + 100u;
@@ -242,10 +264,14 @@ __global__ __launch_bounds__(1024) void bounds_filter_kernel(ClusterParams P) {
   if (threadIdx.x == 0) {
     uint32_t tot = 0;
     for (int w = 0; w < 16; ++w) { const uint32_t x = wcnt[w]; wcnt[w] = tot; tot += x; }
-    base_sh = tot ? atomicAdd(P.n_cand, tot) : 0u;
+    base_sh = tot ? atomicAdd(&P.cnt[CC_NCAND], tot) : 0u;
   }
   __syncthreads();
-  if (cand) P.cand[base_sh + wcnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint4(c, s, e, 0u);
+  if (cand) {
+    const uint32_t d = base_sh + wcnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (d < P.cand_cap) P.cand[d] = make_uint4(s0, s, e, P.gid[s0]);
+    else atomicOr(&P.cnt[CC_ERR], CERR_CAND);
+  }
 }
 
 __global__ __launch_bounds__(64) void bounds_rows_kernel(ClusterParams P) {
@@ -253,11 +279,12 @@ __global__ __launch_bounds__(64) void bounds_rows_kernel(ClusterParams P) {
   __shared__ uint8_t l_split[BK_LIM];
   __shared__ uint32_t l_scratch[4 * (16 + 3 * BK_LIM)];
   const int lane = threadIdx.x;
-  const uint32_t n_cand = *P.n_cand;
+  uint32_t n_cand = P.cnt[CC_NCAND];
+  if (n_cand > P.cand_cap) n_cand = P.cand_cap;
   for (uint32_t k = blockIdx.x; k < n_cand; k += gridDim.x) {
     const uint4 cd = P.cand[k];
-    const uint32_t cc = cd.x, cs = cd.y, ce = cd.z, cn = ce - cs;
-    RawBounds *o = P.out + 2 * (uint64_t)cc;
+    const uint32_t cs = cd.y, ce = cd.z, cn = ce - cs;
+    RawBounds *o = P.out + 2 * (uint64_t)k;
     const bool in_lds = cn <= BK_LIM;
     if (in_lds) {
       for (uint32_t i = lane; i < cn; i += 64) {
@@ -268,6 +295,9 @@ __global__ __launch_bounds__(64) void bounds_rows_kernel(ClusterParams P) {
       __syncthreads();
     }
     if (lane == 0) {
+      o[0].valid = 0; o[1].valid = 0;
+      o[0].gid = cd.w; o[1].gid = cd.w;
+      o[0].first = cs; o[1].first = cs;
       const uint32_t n = cn;
       const uint32_t pm = in_lds ? l_pos[((n < 9u ? n : 9u) - 1u) >> 1] : posmed_at(P.pos, cs, n);
       const uint32_t last = in_lds ? l_pos[n - 1] : P.pos[ce - 1], firstp = in_lds ? l_pos[0] : P.pos[cs];
@@ -275,63 +305,212 @@ __global__ __launch_bounds__(64) void bounds_rows_kernel(ClusterParams P) {
       const uint32_t left_most = firstp < pm - P.max_dist ? firstp : pm - P.max_dist; // :344 (uint32 wrap kept)
       if (in_lds) cluster_rows(P, LdsView{l_pos, l_split, l_sample, cs}, cs, ce, left_most, right_most, l_scratch, 16u + 3u * cn, o);
       else {
-        // scratch of the global path: the region of the ORIGINAL cluster start is as large as this cluster needs
-        const uint32_t s0 = P.cl_start[cc];
-        cluster_rows(P, GlobalView{P.pos, P.split, P.sample}, cs, ce, left_most, right_most, P.scratch + 4ull * (16ull * cc + 3ull * s0),
-                     16u + 3u * (ce - s0), o);
+        // large cluster: its tables come from the global scratch (bump cursor; at most n / 256 such clusters)
+        const uint32_t need = 4u * (16u + 3u * cn);
+        const uint32_t at = atomicAdd(&P.cnt[CC_BIG], need);
+        if (at + need <= P.big_words) cluster_rows(P, GlobalView{P.pos, P.split, P.sample}, cs, ce, left_most, right_most, P.big + at, 16u + 3u * cn, o);
+        else atomicOr(&P.cnt[CC_ERR], CERR_BIG);
       }
     }
     __syncthreads();
   }
 }
 
-__global__ void heads_kernel(const uint64_t *gkey, uint32_t n, uint32_t *head, uint32_t shift) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) head[i] = (i == 0 || (gkey[i] >> shift) != (gkey[i - 1] >> shift)) ? 1u : 0u;
-}
-__global__ void gather_kernel(uint32_t n, const uint32_t *perm, const uint32_t *pos_in, const uint8_t *split_in, const uint32_t *sample_in,
-                              const uint32_t *head, const uint32_t *gid_incl, const uint64_t *gkey_sorted, uint32_t *pos, uint8_t *split,
-                              uint32_t *sample, uint32_t *gid, uint32_t *gstart, uint32_t *gfirst, uint64_t *gkeys, uint8_t *gplaced,
-                              uint32_t shift) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const bool in = i < n;
-  uint32_t src = 0xffffffffu, g = 0xffffffffu;
-  if (in) {
-    src = perm[i];
-    pos[i] = pos_in[src];
-    split[i] = split_in[src];
-    sample[i] = sample_in[src];
-    g = gid_incl[i] - 1u;
-    gid[i] = g;
-    if (head[i]) { const uint64_t k = gkey_sorted[i] >> shift; gstart[g] = i; gkeys[g] = k; gplaced[g] = (k >> 15) != 0; }
-    if (i == n - 1) gstart[g + 1] = n;
-  }
-  // First appearance in input order (=> Nim Table insertion order) = min of `src` per group.  Group ids are
-  // non-decreasing along the wave, so a segmented suffix-min leaves each run's minimum in its first lane and only
-  // that lane touches memory (one atomic per (wave, group) instead of one per tread on a handful of hot addresses).
-  uint32_t v = src;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t ov = __shfl_down(v, d), og = __shfl_down(g, d);
-    if (lane + d < 64 && og == g) v = v < ov ? v : ov;
-  }
-  const uint32_t pg = __shfl_up(g, 1);
-  if (in && (lane == 0 || pg != g)) atomicMin(&gfirst[g], v);
-}
-__global__ void scatter_starts_kernel(uint32_t n, const uint32_t *is_start, const uint32_t *excl, uint32_t *cl_start, uint32_t *n_clusters) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// tread -> sort key + the payload the sweep needs.  composite: key = (tid + 1, unit) << pos_bits | position, one sort;
+// else key = position and the group key goes to gkey_in for the second sort.
+struct KeyParams {
+  const uint32_t *d_n;
+  uint32_t n_max;
+  const strl_tread *treads;
+  uint64_t *key;
+  uint32_t *val;
+  uint32_t *pos_in, *sample_in;
+  uint8_t *split_in;
+  uint64_t *gkey_in;
+  uint32_t *cnt;
+  int composite, pos_bits;
+  int32_t n_tid;    // tids must be < n_tid
+};
+__global__ __launch_bounds__(256) void tread_keys_kernel(KeyParams K) {
+  uint32_t n = *K.d_n;
+  if (n > K.n_max) n = K.n_max;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
-  if (is_start[i]) cl_start[excl[i]] = i;
-  if (i == n - 1) *n_clusters = excl[i] + is_start[i];
+  const uint4 *src = reinterpret_cast<const uint4 *>(K.treads + i);
+  union { uint4 q[2]; strl_tread t; } u;
+  u.q[0] = src[0];
+  u.q[1] = src[1];
+  const strl_tread &t = u.t;
+  uint32_t len = 0, code = 0, err = 0;
+  bool ended = false;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const char ch = t.repeat[j];
+    if (ch == 0) { ended = true; continue; }
+    if (ended) { err |= CERR_UNIT; continue; }
+    uint32_t cd = 0;
+    switch (ch) { case 'C': cd = 0; break; case 'A': cd = 1; break; case 'T': cd = 2; break; case 'G': cd = 3; break; default: err |= CERR_UNIT; }
+    code = (code << 2) | cd;
+    ++len;
+  }
+  if (t.tid < -1 || t.tid >= K.n_tid) err |= CERR_TID;
+  const uint64_t gkey = ((uint64_t)(uint32_t)(t.tid + 1) << 15) | ((uint64_t)len << 12) | code;
+  K.pos_in[i] = t.position;
+  K.split_in[i] = t.split;
+  K.sample_in[i] = (uint32_t)t.qname_id;
+  K.val[i] = i;
+  if (K.composite) {
+    if (K.pos_bits < 32 && (t.position >> K.pos_bits)) err |= CERR_POS;
+    K.key[i] = (gkey << K.pos_bits) | t.position;
+  } else {
+    K.key[i] = t.position;
+    K.gkey_in[i] = gkey;
+  }
+  if (err) atomicOr(&K.cnt[CC_ERR], err);
 }
-__global__ void iota_kernel(uint32_t n, uint32_t *v) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) v[i] = i;
-}
-__global__ void gather_key_kernel(uint32_t n, const uint32_t *perm, const uint64_t *in, uint64_t *out) {
+__global__ void regather_key_kernel(const uint32_t *d_n, uint32_t n_max, const uint32_t *perm, const uint64_t *in, uint64_t *out) {
+  uint32_t n = *d_n;
+  if (n > n_max) n = n_max;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[perm[i]];
+}
+
+// ---- group heads, ids and tables from the sorted keys ----------------------------------------------------------------
+constexpr uint32_t GT_TILE = 2048;   // 4 waves x 8 rounds of 64 consecutive keys
+struct GatherParams {
+  const uint32_t *d_n;
+  uint32_t n_max;
+  const uint64_t *key;      // sorted
+  const uint32_t *perm;     // sorted index -> input index
+  int shift;                // group key = key >> shift
+  const uint32_t *pos_in, *sample_in;
+  const uint8_t *split_in;
+  uint32_t *tile_heads;     // [tiles] heads per tile (exclusive prefix when `scanned`)
+  int scanned;
+  uint32_t *pos, *sample, *gid;
+  uint8_t *split;
+  uint32_t *gstart, *gfirst;
+  uint64_t *gkeys;
+  uint8_t *gplaced;
+  uint32_t *cnt;
+};
+__device__ __forceinline__ bool is_head(const GatherParams &G, uint32_t j, uint64_t k) {
+  return j == 0 || (G.key[j - 1] >> G.shift) != (k >> G.shift);
+}
+__global__ __launch_bounds__(256) void heads_kernel(GatherParams G) {
+  __shared__ uint32_t wsum[4];
+  uint32_t n = *G.d_n;
+  if (n > G.n_max) n = G.n_max;
+  const uint32_t t = blockIdx.x;
+  if ((uint64_t)t * GT_TILE >= n) return;
+  uint32_t c = 0;
+#pragma unroll
+  for (uint32_t r = 0; r < 8; ++r) {
+    const uint32_t j = t * GT_TILE + r * 256u + threadIdx.x;
+    if (j < n) {
+      G.gfirst[j] = 0xffffffffu;          // (n_groups <= n) first appearance, filled by atomicMin in gather_kernel
+      c += is_head(G, j, G.key[j]) ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) G.tile_heads[t] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+// more than 1024 tiles: exclusive scan of the tile counts by one block (in place)
+__global__ __launch_bounds__(1024) void tile_scan_kernel(GatherParams G) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry_sh;
+  uint32_t n = *G.d_n;
+  if (n > G.n_max) n = G.n_max;
+  const uint32_t ntiles = (n + GT_TILE - 1) / GT_TILE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_sh = 0;
+  __syncthreads();
+  for (uint32_t b = 0; b < ntiles; b += 1024) {
+    const uint32_t i = b + threadIdx.x;
+    const uint32_t v = i < ntiles ? G.tile_heads[i] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = carry_sh;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    if (i < ntiles) G.tile_heads[i] = base + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_sh = base + inc;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void gather_kernel(GatherParams G) {
+  __shared__ uint32_t wsum[4], wheads[4];
+  uint32_t n = *G.d_n;
+  if (n > G.n_max) n = G.n_max;
+  const uint32_t t = blockIdx.x;
+  if ((uint64_t)t * GT_TILE >= n) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // groups that start in earlier tiles
+  uint32_t prefix = 0;
+  if (G.scanned) prefix = G.tile_heads[t];
+  else {
+    uint32_t c = 0;
+    for (uint32_t i = threadIdx.x; i < t; i += 256) c += G.tile_heads[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+    if (lane == 0) wsum[wave] = c;
+    __syncthreads();
+    prefix = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  }
+  // wave w owns the 512 consecutive keys [w * 512, (w + 1) * 512) of the tile, 64 per round
+  const uint32_t j0 = t * GT_TILE + (uint32_t)wave * 512u + (uint32_t)lane;
+  uint64_t key[8];
+  unsigned long long hm[8];
+  uint32_t wtot = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint32_t j = j0 + 64u * r;
+    key[r] = j < n ? G.key[j] : 0ull;
+    hm[r] = __ballot(j < n && is_head(G, j, key[r]));
+    wtot += (uint32_t)__popcll(hm[r]);
+  }
+  if (lane == 0) wheads[wave] = wtot;
+  __syncthreads();
+  uint32_t run = prefix;
+  for (int w = 0; w < wave; ++w) run += wheads[w];
+  const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint32_t j = j0 + 64u * r;
+    const bool in = j < n;
+    uint32_t src = 0xffffffffu, g = 0xffffffffu;
+    if (in) {
+      g = run + (uint32_t)__popcll(hm[r] & le) - 1u;
+      src = G.perm[j];
+      G.pos[j] = G.pos_in[src];
+      G.split[j] = G.split_in[src];
+      G.sample[j] = G.sample_in[src];
+      G.gid[j] = g;
+      if ((hm[r] >> lane) & 1ull) {
+        const uint64_t k = key[r] >> G.shift;
+        G.gstart[g] = j; G.gkeys[g] = k; G.gplaced[g] = (k >> 15) != 0;
+      }
+      if (j == n - 1) { G.gstart[g + 1] = n; G.cnt[CC_NGROUPS] = g + 1; }
+    }
+    run += (uint32_t)__popcll(hm[r]);
+    // First appearance in input order (=> Nim Table insertion order) = min of `src` per group.  Group ids are
+    // non-decreasing along the wave, so a segmented suffix-min leaves each run's minimum in its first lane and only
+    // that lane touches memory (one atomic per (wave-round, group) instead of one per tread on a handful of hot addresses).
+    uint32_t v = src;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t ov = __shfl_down(v, d), og = __shfl_down(g, d);
+      if (lane + d < 64 && og == g) v = v < ov ? v : ov;
+    }
+    const uint32_t pg = __shfl_up(g, 1);
+    if (in && (lane == 0 || pg != g)) atomicMin(&G.gfirst[g], v);
+  }
 }
 
 static inline uint32_t base_code(char b, bool &ok) {
@@ -342,122 +521,96 @@ static inline uint32_t base_code(char b, bool &ok) {
 
 using namespace strl;
 
-enum { B_POSIN, B_SPLITIN, B_SAMPLEIN, B_KEYIN, B_PERM0, B_PERM1, B_POSK, B_KEYG, B_KEYS, B_TMP, B_A, B_B, B_C, B_D, B_E, B_F };
+enum { B_TREADS, B_KEY0, B_KEY1, B_VAL0, B_VAL1, B_SORT, B_IN, B_SORTED, B_TILES, B_GROUPS, B_CAND, B_OUT, B_BIG, B_CNT, B_GKEY };
 
-// The whole device side of strl_cluster over the tread arrays resident in the context (B_POSIN, B_SPLITIN,
-// B_SAMPLEIN, B_KEYIN): two stable radix sorts, group tables, ends/walk sweep, cluster compaction, bounds.
-// First pass (replay = false): sizes buffers as it goes and learns n_groups / n_clusters (two host syncs).
-// Replay (strl_cluster_replay): same data => same sizes, so it runs without any host synchronisation; this is what
-// bench.py times as the clustering part of a step.
-static int cluster_device_pass(strl_ctx *c, bool replay) {
+// The whole device side of a clustering pass over `treads` (device memory; count at d_n, at most n_max): keys, sort,
+// group tables, ends/walk sweep, bounds.  Asynchronous: no host synchronisation, every launch is sized by n_max.
+static int cluster_device_pass(strl_ctx *c, const strl_tread *treads, const uint32_t *d_n) {
   ClusterRun &R = c->cl_run;
-  const uint32_t n = R.n;
+  const uint32_t n_max = R.n_max;
   strl::DevBuf *B = c->c_buf;
   hipStream_t st = c->stream;
   int rc;
-  auto need = [&](int i, size_t bytes) { return replay ? STRL_OK : B[i].reserve(std::max<size_t>(bytes, 256)); };
-  if ((rc = need(B_PERM0, (size_t)n * 4)) || (rc = need(B_PERM1, (size_t)n * 4)) || (rc = need(B_POSK, (size_t)n * 4)) ||
-      (rc = need(B_KEYG, (size_t)n * 8)) || (rc = need(B_KEYS, (size_t)n * 8)))
+  const size_t n1 = std::max<size_t>(n_max, 1);
+  const uint32_t cand_cap = (uint32_t)(n1 / (size_t)std::max(1, R.min_support) + 1);
+  const uint32_t big_words = (uint32_t)std::min<size_t>(13 * n1 + 1024, 0xfffffff0u);
+  const int sort_bits = R.composite ? R.pos_bits + R.kbits : std::max(32, R.kbits);
+  const size_t sb = radix_sort_scratch_bytes(n_max, sort_bits);
+  const uint32_t ntiles = (uint32_t)((n1 + GT_TILE - 1) / GT_TILE);
+  auto need = [&](int i, size_t bytes) { return B[i].reserve(std::max<size_t>(bytes, 256)); };
+  if ((rc = need(B_KEY0, n1 * 8)) || (rc = need(B_KEY1, n1 * 8)) || (rc = need(B_VAL0, n1 * 4)) || (rc = need(B_VAL1, n1 * 4)) ||
+      (rc = need(B_SORT, sb)) || (rc = need(B_IN, n1 * 9 + 64)) || (rc = need(B_SORTED, n1 * 21 + 64)) || (rc = need(B_TILES, (size_t)ntiles * 4)) ||
+      (rc = need(B_GROUPS, n1 * 17 + 64)) || (rc = need(B_CAND, (size_t)cand_cap * 16)) || (rc = need(B_OUT, (size_t)cand_cap * 2 * sizeof(RawBounds))) ||
+      (rc = need(B_BIG, (size_t)big_words * 4)) || (rc = need(B_CNT, CC_WORDS * 4)) || (!R.composite && (rc = need(B_GKEY, n1 * 8))))
     return rc;
+  uint32_t *cnt = B[B_CNT].as<uint32_t>();
+  STRL_HIP(hipMemsetAsync(cnt + 1, 0, (CC_WORDS - 1) * 4, st));   // CC_N stays (host path stores n there)
   const int TB = 256;
-  const uint32_t nb = (n + TB - 1) / TB;
+  const uint32_t nb = (uint32_t)((n1 + TB - 1) / TB);
   if (c->timing) STRL_HIP(hipEventRecord(c->ev[4], st));
-  // stable sort by position, then stable sort by (tid, unit)  ==  group + algorithm.sort by position.
-  // When the group key fits 32 bits both collapse into ONE stable sort of the composite key (group << 32 | position),
-  // which the host uploads in B_KEYIN (the sorts are launch-bound at ~10^6 treads: 36 small kernels each).
-  hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM1].as<uint32_t>());
-  const uint32_t shift = R.composite ? 32u : 0u;
-  if (!replay) {
-    size_t tmp1 = 0, tmp2 = 0, tmp3 = 0;
-    STRL_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, B[B_POSIN].as<uint32_t>(), B[B_POSK].as<uint32_t>(), B[B_PERM1].as<uint32_t>(),
-                                               B[B_PERM0].as<uint32_t>(), (int)n, 0, 32, st));
-    STRL_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, B[B_KEYG].as<uint64_t>(), B[B_KEYS].as<uint64_t>(), B[B_PERM1].as<uint32_t>(),
-                                               B[B_PERM0].as<uint32_t>(), (int)n, 0, 64, st));
-    STRL_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp3, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, st));
-    R.tmpb = std::max(tmp1, std::max(tmp2, tmp3)) + 256;
-    if ((rc = need(B_TMP, R.tmpb))) return rc;
-  }
-  const size_t tmpb = R.tmpb;
-  size_t t = tmpb;
+  // ---- keys + sort ------------------------------------------------------------------------------------
+  uint32_t *d_posin = B[B_IN].as<uint32_t>(), *d_samplein = d_posin + n1;
+  uint8_t *d_splitin = reinterpret_cast<uint8_t *>(d_samplein + n1);
+  KeyParams K{};
+  K.d_n = d_n; K.n_max = n_max; K.treads = treads; K.key = B[B_KEY0].as<uint64_t>(); K.val = B[B_VAL0].as<uint32_t>();
+  K.pos_in = d_posin; K.sample_in = d_samplein; K.split_in = d_splitin; K.gkey_in = R.composite ? nullptr : B[B_GKEY].as<uint64_t>();
+  K.cnt = cnt; K.composite = R.composite ? 1 : 0; K.pos_bits = R.pos_bits; K.n_tid = R.n_tid;
+  hipLaunchKernelGGL(tread_keys_kernel, dim3(nb), dim3(TB), 0, st, K);
+  uint64_t *sk = nullptr;
+  uint32_t *sv = nullptr;
+  int e;
   if (R.composite) {
-    STRL_HIP(hipcub::DeviceRadixSort::SortPairs(B[B_TMP].p, t, B[B_KEYIN].as<uint64_t>(), B[B_KEYS].as<uint64_t>(), B[B_PERM1].as<uint32_t>(),
-                                               B[B_PERM0].as<uint32_t>(), (int)n, 0, 32 + R.kbits, st));
+    e = radix_sort_pairs(st, d_n, n_max, B[B_KEY0].as<uint64_t>(), B[B_VAL0].as<uint32_t>(), B[B_KEY1].as<uint64_t>(), B[B_VAL1].as<uint32_t>(),
+                         B[B_SORT].p, B[B_SORT].cap, 0, R.pos_bits + R.kbits, &sk, &sv);
   } else {
-    STRL_HIP(hipcub::DeviceRadixSort::SortPairs(B[B_TMP].p, t, B[B_POSIN].as<uint32_t>(), B[B_POSK].as<uint32_t>(), B[B_PERM1].as<uint32_t>(),
-                                               B[B_PERM0].as<uint32_t>(), (int)n, 0, 32, st));
-    hipLaunchKernelGGL(gather_key_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM0].as<uint32_t>(), B[B_KEYIN].as<uint64_t>(), B[B_KEYG].as<uint64_t>());
-    hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM1].as<uint32_t>());   // reused below as scratch values
-    t = tmpb;
-    // second pass carries the first pass' permutation as its values
-    STRL_HIP(hipcub::DeviceRadixSort::SortPairs(B[B_TMP].p, t, B[B_KEYG].as<uint64_t>(), B[B_KEYS].as<uint64_t>(), B[B_PERM0].as<uint32_t>(),
-                                               B[B_PERM1].as<uint32_t>(), (int)n, 0, R.kbits, st));
-    STRL_HIP(hipMemcpyAsync(B[B_PERM0].p, B[B_PERM1].p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    // stable sort by position, then stable sort by (tid, unit)  ==  group + algorithm.sort by position
+    e = radix_sort_pairs(st, d_n, n_max, B[B_KEY0].as<uint64_t>(), B[B_VAL0].as<uint32_t>(), B[B_KEY1].as<uint64_t>(), B[B_VAL1].as<uint32_t>(),
+                         B[B_SORT].p, B[B_SORT].cap, 0, 32, &sk, &sv);
+    if (!e) {
+      uint64_t *ok = sk == B[B_KEY0].as<uint64_t>() ? B[B_KEY1].as<uint64_t>() : B[B_KEY0].as<uint64_t>();
+      uint32_t *ov = sv == B[B_VAL0].as<uint32_t>() ? B[B_VAL1].as<uint32_t>() : B[B_VAL0].as<uint32_t>();
+      hipLaunchKernelGGL(regather_key_kernel, dim3(nb), dim3(TB), 0, st, d_n, n_max, sv, B[B_GKEY].as<uint64_t>(), sk);
+      e = radix_sort_pairs(st, d_n, n_max, sk, sv, ok, ov, B[B_SORT].p, B[B_SORT].cap, 0, R.kbits, &sk, &sv);
+    }
   }
-  // B_PERM0 = final permutation (sorted index -> input index), B_KEYS = sorted group keys; group heads -> group ids
-  if ((rc = need(B_A, (size_t)n * 4)) || (rc = need(B_B, (size_t)n * 4))) return rc;   // A: head flags / is_start, B: scans
-  uint32_t *d_head = B[B_A].as<uint32_t>(), *d_scan = B[B_B].as<uint32_t>();
-  hipLaunchKernelGGL(heads_kernel, dim3(nb), dim3(TB), 0, st, B[B_KEYS].as<uint64_t>(), n, d_head, shift);
-  t = tmpb;
-  STRL_HIP(hipcub::DeviceScan::InclusiveSum(B[B_TMP].p, t, d_head, d_scan, (int)n, st));
-  if (!replay) {
-    STRL_HIP(hipMemcpyAsync(&R.n_groups, d_scan + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    STRL_HIP(hipStreamSynchronize(st));
-  }
-  const uint32_t n_groups = R.n_groups;
-  // sorted payload + per-group tables.  Layout of B_C: pos | sample | gid | ends ; B_D: split ; B_E: group tables
-  if ((rc = need(B_C, (size_t)n * 16)) || (rc = need(B_D, n))) return rc;
-  const size_t gt_bytes = (size_t)(n_groups + 1) * 4 + (size_t)n_groups * 4 + (size_t)n_groups * 8 + (size_t)n_groups + 64;
-  if ((rc = need(B_E, gt_bytes))) return rc;
-  uint32_t *d_pos = B[B_C].as<uint32_t>(), *d_sample = d_pos + n, *d_gid = d_sample + n, *d_ends = d_gid + n;
-  uint8_t *d_split = B[B_D].as<uint8_t>();
-  uint64_t *d_gkeys = B[B_E].as<uint64_t>();
-  uint32_t *d_gstart = reinterpret_cast<uint32_t *>(d_gkeys + n_groups);
-  uint32_t *d_gfirst = d_gstart + (n_groups + 1);
-  uint8_t *d_gplaced = reinterpret_cast<uint8_t *>(d_gfirst + n_groups);
-  STRL_HIP(hipMemsetAsync(d_gfirst, 0xff, (size_t)n_groups * 4, st));
-  hipLaunchKernelGGL(gather_kernel, dim3(nb), dim3(TB), 0, st, n, B[B_PERM0].as<uint32_t>(), B[B_POSIN].as<uint32_t>(), B[B_SPLITIN].as<uint8_t>(),
-                     B[B_SAMPLEIN].as<uint32_t>(), d_head, d_scan, B[B_KEYS].as<uint64_t>(), d_pos, d_split, d_sample, d_gid, d_gstart, d_gfirst,
-                     d_gkeys, d_gplaced, shift);
+  if (e) { set_error("radix_sort_pairs failed: %s", hipGetErrorString((hipError_t)e)); return STRL_ERR_HIP; }
+  R.perm = sv;
+  // ---- group heads -> ids, sorted payload, per-group tables ---------------------------------------------------
+  uint32_t *d_pos = B[B_SORTED].as<uint32_t>(), *d_sample = d_pos + n1, *d_gid = d_sample + n1, *d_ends = d_gid + n1, *d_isstart = d_ends + n1;
+  uint8_t *d_split = reinterpret_cast<uint8_t *>(d_isstart + n1);
+  uint64_t *d_gkeys = B[B_GROUPS].as<uint64_t>();
+  uint32_t *d_gstart = reinterpret_cast<uint32_t *>(d_gkeys + n1);
+  uint32_t *d_gfirst = d_gstart + (n1 + 1);
+  uint8_t *d_gplaced = reinterpret_cast<uint8_t *>(d_gfirst + n1);
+  GatherParams G{};
+  G.d_n = d_n; G.n_max = n_max; G.key = sk; G.perm = sv; G.shift = R.composite ? R.pos_bits : 0;
+  G.pos_in = d_posin; G.sample_in = d_samplein; G.split_in = d_splitin; G.tile_heads = B[B_TILES].as<uint32_t>();
+  G.scanned = ntiles > 1024 ? 1 : 0;
+  G.pos = d_pos; G.sample = d_sample; G.gid = d_gid; G.split = d_split; G.gstart = d_gstart; G.gfirst = d_gfirst; G.gkeys = d_gkeys;
+  G.gplaced = d_gplaced; G.cnt = cnt;
+  hipLaunchKernelGGL(heads_kernel, dim3(ntiles), dim3(256), 0, st, G);
+  if (G.scanned) hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, G);
+  hipLaunchKernelGGL(gather_kernel, dim3(ntiles), dim3(256), 0, st, G);
   if (c->timing) STRL_HIP(hipEventRecord(c->ev[5], st));
   // ---- sweep ---------------------------------------------------------------------------------------
   ClusterParams P{};
-  P.n = n; P.pos = d_pos; P.split = d_split; P.sample = d_sample; P.gid = d_gid; P.gstart = d_gstart; P.gplaced = d_gplaced;
-  P.n_groups = n_groups; P.ends = d_ends; P.is_start = d_head; P.max_dist = R.window; P.min_support = R.min_support;
+  P.d_n = d_n; P.n_max = n_max; P.pos = d_pos; P.split = d_split; P.sample = d_sample; P.gid = d_gid; P.gstart = d_gstart; P.gplaced = d_gplaced;
+  P.ends = d_ends; P.is_start = d_isstart; P.cnt = cnt; P.big = B[B_BIG].as<uint32_t>(); P.big_words = big_words;
+  P.cand = B[B_CAND].as<uint4>(); P.cand_cap = cand_cap; P.out = B[B_OUT].as<RawBounds>();
+  P.max_dist = R.window; P.min_support = R.min_support;
   P.min_clip = R.min_clip; P.min_clip_total = R.min_clip_total; P.max_clip_dist = R.max_clip_dist; P.mode = R.mode;
-  STRL_HIP(hipMemsetAsync(d_head, 0, (size_t)n * 4, st));
   hipLaunchKernelGGL(ends_kernel, dim3(nb), dim3(TB), 0, st, P);
-  hipLaunchKernelGGL(walk_kernel, dim3((n_groups + 63) / 64), dim3(64), 0, st, P);
-  t = tmpb;
-  STRL_HIP(hipcub::DeviceScan::ExclusiveSum(B[B_TMP].p, t, d_head, d_scan, (int)n, st));
-  if ((rc = need(B_F, (size_t)n * 4 + 96 + (size_t)n * 16))) return rc;   // cluster starts, two counters, candidate list
-  uint32_t *d_cl_start = B[B_F].as<uint32_t>(), *d_ncl = d_cl_start + n;
-  hipLaunchKernelGGL(scatter_starts_kernel, dim3(nb), dim3(TB), 0, st, n, d_head, d_scan, d_cl_start, d_ncl);
-  if (!replay) {
-    STRL_HIP(hipMemcpyAsync(&R.n_clusters, d_ncl, 4, hipMemcpyDeviceToHost, st));
-    STRL_HIP(hipStreamSynchronize(st));
-  }
-  const uint32_t n_clusters = R.n_clusters;
+  hipLaunchKernelGGL(walk_kernel, dim3((uint32_t)((n1 + 63) / 64)), dim3(64), 0, st, P);
   if (c->timing) STRL_HIP(hipEventRecord(c->ev[6], st));
   // ---- bounds ---------------------------------------------------------------------------------------
-  if (n_clusters) {
-    const size_t scratch_dw = 4ull * (16ull * n_clusters + 3ull * n) + 64;
-    if (!replay) {
-      if ((rc = c->soft_tmp.reserve(scratch_dw * 4))) return rc;
-      if ((rc = need(B_KEYG, std::max((size_t)n * 8, (size_t)2 * n_clusters * sizeof(RawBounds))))) return rc;   // reused as output
-    }
-    P.cl_start = d_cl_start; P.n_clusters = d_ncl; P.scratch = c->soft_tmp.as<uint32_t>(); P.out = B[B_KEYG].as<RawBounds>();
-    P.n_cand = d_ncl + 1;
-    P.cand = reinterpret_cast<uint4 *>(B[B_F].as<uint8_t>() + (((size_t)n * 4 + 64 + 15) & ~(size_t)15));
-    STRL_HIP(hipMemsetAsync(P.n_cand, 0, 4, st));
-    hipLaunchKernelGGL(bounds_filter_kernel, dim3((n_clusters + 1023) / 1024), dim3(1024), 0, st, P);
-    hipLaunchKernelGGL(bounds_rows_kernel, dim3(std::min<uint32_t>(n_clusters, 32768u)), dim3(64), 0, st, P);
-    STRL_HIP(hipGetLastError());
-  }
+  hipLaunchKernelGGL(bounds_filter_kernel, dim3((uint32_t)((n1 + 1023) / 1024)), dim3(1024), 0, st, P);
+  hipLaunchKernelGGL(bounds_rows_kernel, dim3(std::min<uint32_t>(cand_cap, 32768u)), dim3(64), 0, st, P);
+  STRL_HIP(hipGetLastError());
   if (c->timing) STRL_HIP(hipEventRecord(c->ev[7], st));
   return STRL_OK;
 }
 
-// c.reads of every returned bound: the sorted permutation is still resident (B_PERM0)
+// c.reads of every returned bound: the sorted permutation is still resident
 extern "C" int strl_cluster_members(strl_ctx *c, uint64_t *member_off, uint32_t *members, uint64_t cap, uint64_t *n_members) {
   if (!c || !member_off || !n_members) { set_error("null argument"); return STRL_ERR_ARG; }
   const ClusterRun &R = c->cl_run;
@@ -470,7 +623,8 @@ extern "C" int strl_cluster_members(strl_ctx *c, uint64_t *member_off, uint32_t 
   if (!tot) return STRL_OK;
   STRL_HIP(hipSetDevice(c->device));
   std::vector<uint32_t> perm(R.n);
-  STRL_HIP(hipMemcpyAsync(perm.data(), c->c_buf[B_PERM0].p, (size_t)R.n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (!R.perm) { set_error("strl_cluster_members: no clustering pass on this context"); return STRL_ERR_ARG; }
+  STRL_HIP(hipMemcpyAsync(perm.data(), R.perm, (size_t)R.n * 4, hipMemcpyDeviceToHost, c->stream));
   STRL_HIP(hipStreamSynchronize(c->stream));
   uint64_t k = 0;
   for (size_t j = 0; j < R.b_first.size(); ++j)
@@ -481,102 +635,75 @@ extern "C" int strl_cluster_members(strl_ctx *c, uint64_t *member_off, uint32_t 
   return STRL_OK;
 }
 
-// Re-run the device side of the last strl_cluster call on the same resident treads, asynchronously.
-extern "C" int strl_cluster_replay(strl_ctx *c) {
-  if (!c) return STRL_ERR_ARG;
-  if (c->cl_run.n == 0) { set_error("strl_cluster_replay: no previous strl_cluster call on this context"); return STRL_ERR_ARG; }
-  STRL_HIP(hipSetDevice(c->device));
-  return cluster_device_pass(c, true);
-}
 
-extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in, int mode, uint32_t window, int32_t min_support,
-                            uint16_t min_clip, uint16_t min_clip_total, uint16_t max_clip_dist, strl_bounds *out, uint64_t cap,
-                            uint64_t *n_out, strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced,
-                            strl_cluster_stats *stats) {
-  if (!c || (!treads && n_in) || (!out && cap)) { set_error("null argument"); return STRL_ERR_ARG; }
-  if (n_out) *n_out = 0;
-  if (n_unplaced) *n_unplaced = 0;
-  if (stats) memset(stats, 0, sizeof *stats);
-  STRL_HIP(hipSetDevice(c->device));
-  // ---- host: keys -------------------------------------------------------------------------------
-  std::vector<uint32_t> h_pos, h_sample;
-  std::vector<uint8_t> h_split;
-  std::vector<uint64_t> h_key;
-  std::vector<uint32_t> kept;
-  std::vector<std::pair<uint64_t, uint32_t>> ghosts;   // (group key, index) of treads that only hold their group's place
-  bool any_skipped = mode == STRL_MODE_MERGE;
-  h_pos.reserve(n_in); h_sample.reserve(n_in); h_split.reserve(n_in); h_key.reserve(n_in);
-  for (uint64_t i = 0; i < n_in; ++i) {
-    const strl_tread &t = treads[i];
-    if (mode == STRL_MODE_MERGE && t.tid < 0) continue;           // unpack_file(drop_unplaced=true), merge.nim:101
-    if (t.tid < -1) { set_error("tread %llu: tid %d", (unsigned long long)i, t.tid); return STRL_ERR_ARG; }
-    const bool ghost = t.split == STRL_SOFT_TAKEN;   // given to a -l/-b locus: still a key of the table, no longer a read
-    any_skipped |= ghost;
-    bool ok = true;
-    uint32_t len = 0, code = 0;
-    while (len < 6 && t.repeat[len]) { code = (code << 2) | base_code(t.repeat[len], ok); ++len; }
-    for (uint32_t j = len; j < 6; ++j) if (t.repeat[j]) ok = false;
-    if (!ok) { set_error("tread %llu: repeat unit is not a NUL-padded ACGT string", (unsigned long long)i); return STRL_ERR_ARG; }
-    const uint64_t gkey = ((uint64_t)(uint32_t)(t.tid + 1) << 15) | ((uint64_t)len << 12) | code;
-    if (ghost) { ghosts.push_back({gkey, (uint32_t)i}); continue; }
-    h_key.push_back(gkey);
-    h_pos.push_back(t.position);
-    h_split.push_back(t.split);
-    h_sample.push_back((uint32_t)t.qname_id);
-    kept.push_back((uint32_t)i);
-  }
-  if (!any_skipped) kept.clear();                     // identity
-  const uint64_t n64 = h_pos.size();
-  if (n64 > 0x7ffffff0ull) { set_error("too many treads"); return STRL_ERR_ARG; }
-  const uint32_t n = (uint32_t)n64;
-  if (stats) stats->n_treads = n;
-  if (n == 0) return STRL_OK;                        // (only ghosts left: nothing to cluster, nothing to report)
-
-  // ---- upload, then one device pass ------------------------------------------------------------------
-  strl::DevBuf *B = c->c_buf;
-  int rc;
-  auto need = [&](int i, size_t bytes) { return B[i].reserve(std::max<size_t>(bytes, 256)); };
-  if ((rc = need(B_POSIN, (size_t)n * 4)) || (rc = need(B_SPLITIN, n)) || (rc = need(B_SAMPLEIN, (size_t)n * 4)) ||
-      (rc = need(B_KEYIN, (size_t)n * 8)))
-    return rc;
-  hipStream_t st = c->stream;
-  STRL_HIP(hipMemcpyAsync(B[B_POSIN].p, h_pos.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-  STRL_HIP(hipMemcpyAsync(B[B_SPLITIN].p, h_split.data(), n, hipMemcpyHostToDevice, st));
-  STRL_HIP(hipMemcpyAsync(B[B_SAMPLEIN].p, h_sample.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-  uint64_t maxkey = 0;
-  for (uint64_t k : h_key) maxkey = std::max(maxkey, k);
-  int kbits = 1;
-  while (kbits < 64 && (maxkey >> kbits)) ++kbits;
-  const bool composite = kbits <= 32;
-  if (composite) for (uint32_t i = 0; i < n; ++i) h_key[i] = (h_key[i] << 32) | h_pos[i];
-  STRL_HIP(hipMemcpyAsync(B[B_KEYIN].p, h_key.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+// ---- results of the last device pass -> the reference's row order (host) ------------------------------------------------
+// Row order of -bounds.txt = Nim Table slot order of the (tid, repeat) groups inserted in first-appearance order
+// (call.nim:223, merge.nim:172), clusters in position order within a group.
+static int cluster_collect(strl_ctx *c, const std::vector<std::pair<uint64_t, uint32_t>> &ghosts_in, strl_bounds *out, uint64_t cap,
+                           uint64_t *n_out, strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced, strl_cluster_stats *stats) {
   ClusterRun &R = c->cl_run;
-  R = ClusterRun{};
-  R.n = n; R.kbits = kbits; R.composite = composite; R.mode = mode; R.window = window; R.min_support = min_support; R.min_clip = min_clip;
-  R.min_clip_total = min_clip_total; R.max_clip_dist = max_clip_dist;
-  R.kept.swap(kept);
-  if ((rc = cluster_device_pass(c, false))) return rc;
-  const uint32_t n_groups = R.n_groups, n_clusters = R.n_clusters;
-  // ---- results back ------------------------------------------------------------------------------------
-  std::vector<RawBounds> raw((size_t)2 * n_clusters);
+  strl::DevBuf *B = c->c_buf;
+  hipStream_t st = c->stream;
+  uint32_t cnt[CC_WORDS];
+  uint32_t n_dev = 0;
+  STRL_HIP(hipMemcpyAsync(cnt, B[B_CNT].p, CC_WORDS * 4, hipMemcpyDeviceToHost, st));
+  STRL_HIP(hipMemcpyAsync(&n_dev, R.d_n, 4, hipMemcpyDeviceToHost, st));
+  STRL_HIP(hipStreamSynchronize(st));
+  if (n_dev > R.n_max) { set_error("clustering: %u treads, capacity %u", n_dev, R.n_max); return STRL_ERR_CAPACITY; }
+  const uint32_t err = cnt[CC_ERR];
+  if (err & CERR_UNIT) { set_error("a tread's repeat unit is not a NUL-padded ACGT string"); return STRL_ERR_ARG; }
+  if (err & CERR_TID) { set_error("a tread's tid is outside [-1, %d)", R.n_tid); return STRL_ERR_ARG; }
+  if (err & CERR_POS) { set_error("a tread's position needs more than %d bits", R.pos_bits); return STRL_ERR_ARG; }
+  if (err & (CERR_CAND | CERR_BIG)) { set_error("clustering scratch exhausted (internal capacity)"); return STRL_ERR_CAPACITY; }
+  R.n = n_dev;
+  const uint32_t n1 = std::max<uint32_t>(R.n_max, 1);
+  const uint32_t n_groups = n_dev ? cnt[CC_NGROUPS] : 0, n_cand = n_dev ? cnt[CC_NCAND] : 0;
+  R.n_groups = n_groups; R.n_clusters = cnt[CC_NCLUSTERS];
+  R.b_first.clear(); R.b_count.clear();
+  if (stats) {
+    stats->n_treads = n_dev; stats->n_groups = n_groups; stats->n_clusters = cnt[CC_NCLUSTERS];
+    if (c->timing) {
+      (void)hipEventElapsedTime(&stats->ms_sort, c->ev[4], c->ev[5]);
+      (void)hipEventElapsedTime(&stats->ms_sweep, c->ev[5], c->ev[6]);
+      (void)hipEventElapsedTime(&stats->ms_bounds, c->ev[6], c->ev[7]);
+    }
+  }
+  if (n_dev == 0 && ghosts_in.empty()) return STRL_OK;
+  std::vector<RawBounds> raw((size_t)2 * n_cand);
   std::vector<uint64_t> g_keys(n_groups);
-  std::vector<uint32_t> g_start(n_groups + 1), g_first(n_groups), cl_start(n_clusters);
+  std::vector<uint32_t> g_start(n_groups + 1), g_first(n_groups);
   {
-    uint64_t *d_gkeys = B[B_E].as<uint64_t>();
-    uint32_t *d_gstart = reinterpret_cast<uint32_t *>(d_gkeys + n_groups);
-    uint32_t *d_gfirst = d_gstart + (n_groups + 1);
-    if (n_clusters) STRL_HIP(hipMemcpyAsync(raw.data(), B[B_KEYG].p, raw.size() * sizeof(RawBounds), hipMemcpyDeviceToHost, st));
-    STRL_HIP(hipMemcpyAsync(g_keys.data(), d_gkeys, (size_t)n_groups * 8, hipMemcpyDeviceToHost, st));
-    STRL_HIP(hipMemcpyAsync(g_start.data(), d_gstart, (size_t)(n_groups + 1) * 4, hipMemcpyDeviceToHost, st));
-    STRL_HIP(hipMemcpyAsync(g_first.data(), d_gfirst, (size_t)n_groups * 4, hipMemcpyDeviceToHost, st));
-    if (n_clusters) STRL_HIP(hipMemcpyAsync(cl_start.data(), B[B_F].p, (size_t)n_clusters * 4, hipMemcpyDeviceToHost, st));
+    uint64_t *d_gkeys = B[B_GROUPS].as<uint64_t>();
+    uint32_t *d_gstart = reinterpret_cast<uint32_t *>(d_gkeys + n1);
+    uint32_t *d_gfirst = d_gstart + ((size_t)n1 + 1);
+    if (n_cand) STRL_HIP(hipMemcpyAsync(raw.data(), B[B_OUT].p, raw.size() * sizeof(RawBounds), hipMemcpyDeviceToHost, st));
+    if (n_groups) {
+      STRL_HIP(hipMemcpyAsync(g_keys.data(), d_gkeys, (size_t)n_groups * 8, hipMemcpyDeviceToHost, st));
+      STRL_HIP(hipMemcpyAsync(g_start.data(), d_gstart, (size_t)(n_groups + 1) * 4, hipMemcpyDeviceToHost, st));
+      STRL_HIP(hipMemcpyAsync(g_first.data(), d_gfirst, (size_t)n_groups * 4, hipMemcpyDeviceToHost, st));
+    }
     STRL_HIP(hipStreamSynchronize(st));
   }
-
-  // ---- host: reference row order = Nim Table slot order of the groups (insertion = first appearance) ----
+  // candidates arrive in arbitrary order: by (group, first read) they are the clusters of a group in position order
+  std::vector<uint32_t> cidx(n_cand);
+  for (uint32_t k = 0; k < n_cand; ++k) cidx[k] = k;
+  std::sort(cidx.begin(), cidx.end(), [&](uint32_t a, uint32_t b) {
+    const RawBounds &x = raw[(size_t)2 * a], &y = raw[(size_t)2 * b];
+    return x.gid != y.gid ? x.gid < y.gid : x.first < y.first;
+  });
+  std::vector<uint32_t> cl_lo(n_groups + 1, 0);
+  {
+    uint32_t ci = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+      cl_lo[g] = ci;
+      while (ci < n_cand && raw[(size_t)2 * cidx[ci]].gid == g) ++ci;
+    }
+    cl_lo[n_groups] = ci;
+  }
   // Table keys in insertion order = first appearance in the caller's array, counting the place-holding treads too
   struct KeyEnt { uint64_t key; uint32_t first; int32_t g; };
   std::vector<KeyEnt> ents;
+  std::vector<std::pair<uint64_t, uint32_t>> ghosts = ghosts_in;
   ents.reserve(n_groups + ghosts.size());
   for (uint32_t g = 0; g < n_groups; ++g) ents.push_back(KeyEnt{g_keys[g], R.kept.empty() ? g_first[g] : R.kept[g_first[g]], (int32_t)g});
   if (!ghosts.empty()) {
@@ -603,16 +730,6 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
     hcodes[q] = nim::hash_tid_rep((int32_t)(ents[q].key >> 15) - 1, rep);
   }
   const std::vector<int64_t> order = nim::table_slot_order(hcodes, 8192);           // newTable(8192): call.nim:118, merge.nim:92
-  // clusters are in sorted order => grouped; index them per group
-  std::vector<uint32_t> cl_lo(n_groups + 1, 0);
-  {
-    uint32_t ci = 0;
-    for (uint32_t g = 0; g < n_groups; ++g) {
-      cl_lo[g] = ci;
-      while (ci < n_clusters && cl_start[ci] < g_start[g + 1]) ++ci;
-    }
-    cl_lo[n_groups] = ci;
-  }
   uint64_t no = 0, nu = 0;
   for (int64_t q : order) {
     if (ents[(size_t)q].g < 0) continue;                                              // every read of the group went to a locus
@@ -622,7 +739,7 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
     char rep[7];
     key_unit(key, rep);
     if (tid < 0) {                                                                    // call.nim:226-228
-      if (mode == STRL_MODE_CALL) {
+      if (R.mode == STRL_MODE_CALL) {
         if (unplaced && nu < unplaced_cap) { memcpy(unplaced[nu].repeat, rep, 7); unplaced[nu].count = (int64_t)(g_start[g + 1] - g_start[g]); }
         ++nu;
       }
@@ -630,9 +747,9 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
     }
     for (uint32_t ci = cl_lo[g]; ci < cl_lo[g + 1]; ++ci)
       for (int half = 0; half < 2; ++half) {
-        const RawBounds &r = raw[(size_t)2 * ci + half];
+        const RawBounds &r = raw[(size_t)2 * cidx[ci] + half];
         if (!r.valid) continue;
-        if (no < cap) {
+        if (no < cap && out) {
           strl_bounds &b = out[no];
           b.tid = tid; b.left = r.left; b.left_most = r.left_most; b.right = r.right; b.right_most = r.right_most;
           b.center_mass = r.center_mass; b.n_left = r.n_left; b.n_right = r.n_right; b.n_total = r.n_total;
@@ -644,14 +761,106 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
   }
   if (n_out) *n_out = no;
   if (n_unplaced) *n_unplaced = nu;
-  if (stats) {
-    stats->n_groups = n_groups; stats->n_clusters = n_clusters; stats->n_bounds = no;
-    if (c->timing) {
-      (void)hipEventElapsedTime(&stats->ms_sort, c->ev[4], c->ev[5]);
-      (void)hipEventElapsedTime(&stats->ms_sweep, c->ev[5], c->ev[6]);
-      (void)hipEventElapsedTime(&stats->ms_bounds, c->ev[6], c->ev[7]);
-    }
-  }
-  if (no > cap) { set_error("bounds capacity %llu too small, need %llu", (unsigned long long)cap, (unsigned long long)no); return STRL_ERR_CAPACITY; }
+  if (stats) stats->n_bounds = no;
+  if (out && no > cap) { set_error("bounds capacity %llu too small, need %llu", (unsigned long long)cap, (unsigned long long)no); return STRL_ERR_CAPACITY; }
   return STRL_OK;
+}
+
+static inline int bits_for(uint64_t v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; }
+
+// Re-run the device side of the last clustering pass on the same resident treads, asynchronously.
+extern "C" int strl_cluster_replay(strl_ctx *c) {
+  if (!c) return STRL_ERR_ARG;
+  if (!c->cl_run.treads) { set_error("strl_cluster_replay: no previous clustering pass on this context"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  return cluster_device_pass(c, c->cl_run.treads, c->cl_run.d_n);
+}
+
+extern "C" int strl_cluster_resident(strl_ctx *c, int mode, int32_t n_tid, int pos_bits, uint32_t window, int32_t min_support, uint16_t min_clip,
+                                     uint16_t min_clip_total, uint16_t max_clip_dist, strl_bounds *out, uint64_t cap, uint64_t *n_out,
+                                     strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced, strl_cluster_stats *stats) {
+  if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
+  if (!c->n_treads_dev) { set_error("strl_cluster_resident: no strl_extract_device call on this context"); return STRL_ERR_ARG; }
+  if (mode != STRL_MODE_CALL) { set_error("strl_cluster_resident clusters the treads of one sample (STRL_MODE_CALL)"); return STRL_ERR_ARG; }
+  if (n_tid < 0 || pos_bits < 0 || pos_bits > 32) { set_error("bad argument"); return STRL_ERR_ARG; }
+  if (n_out) *n_out = 0;
+  if (n_unplaced) *n_unplaced = 0;
+  if (stats) memset(stats, 0, sizeof *stats);
+  STRL_HIP(hipSetDevice(c->device));
+  ClusterRun &R = c->cl_run;
+  R = ClusterRun{};
+  R.n_max = c->tread_cap; R.n_tid = n_tid; R.mode = mode; R.window = window; R.min_support = min_support; R.min_clip = min_clip;
+  R.min_clip_total = min_clip_total; R.max_clip_dist = max_clip_dist;
+  R.pos_bits = pos_bits ? pos_bits : 32;
+  R.kbits = bits_for((uint64_t)n_tid) + 15;
+  R.composite = R.pos_bits + R.kbits <= 64;
+  R.treads = c->treads.as<strl_tread>(); R.d_n = c->n_treads_dev;
+  int rc;
+  if ((rc = cluster_device_pass(c, R.treads, R.d_n))) return rc;
+  if (!out && !n_out && !stats && !n_unplaced) return STRL_OK;      // asynchronous: results stay on the device
+  return cluster_collect(c, {}, out, cap, n_out, unplaced, unplaced_cap, n_unplaced, stats);
+}
+
+extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in, int mode, uint32_t window, int32_t min_support,
+                            uint16_t min_clip, uint16_t min_clip_total, uint16_t max_clip_dist, strl_bounds *out, uint64_t cap,
+                            uint64_t *n_out, strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced,
+                            strl_cluster_stats *stats) {
+  if (!c || (!treads && n_in) || (!out && cap)) { set_error("null argument"); return STRL_ERR_ARG; }
+  if (n_out) *n_out = 0;
+  if (n_unplaced) *n_unplaced = 0;
+  if (stats) memset(stats, 0, sizeof *stats);
+  STRL_HIP(hipSetDevice(c->device));
+  // ---- host: drop what the reference drops on load, note the place holders -------------------------
+  std::vector<strl_tread> ft;
+  std::vector<uint32_t> kept;
+  std::vector<std::pair<uint64_t, uint32_t>> ghosts;   // (group key, index) of treads that only hold their group's place
+  bool any_skipped = false;
+  int32_t max_tid = -1;
+  uint32_t max_pos = 0;
+  ft.reserve(n_in);
+  for (uint64_t i = 0; i < n_in; ++i) {
+    const strl_tread &t = treads[i];
+    if (mode == STRL_MODE_MERGE && t.tid < 0) { any_skipped = true; continue; }   // unpack_file(drop_unplaced=true), merge.nim:101
+    if (t.tid < -1) { set_error("tread %llu: tid %d", (unsigned long long)i, t.tid); return STRL_ERR_ARG; }
+    if (t.split == STRL_SOFT_TAKEN) {   // given to a -l/-b locus: still a key of the table, no longer a read
+      bool ok = true;
+      uint32_t len = 0, code = 0;
+      while (len < 6 && t.repeat[len]) { code = (code << 2) | base_code(t.repeat[len], ok); ++len; }
+      for (uint32_t j = len; j < 6; ++j) if (t.repeat[j]) ok = false;
+      if (!ok) { set_error("tread %llu: repeat unit is not a NUL-padded ACGT string", (unsigned long long)i); return STRL_ERR_ARG; }
+      ghosts.push_back({((uint64_t)(uint32_t)(t.tid + 1) << 15) | ((uint64_t)len << 12) | code, (uint32_t)i});
+      any_skipped = true;
+      continue;
+    }
+    max_tid = std::max(max_tid, t.tid);
+    max_pos = std::max(max_pos, t.position);
+    ft.push_back(t);
+    kept.push_back((uint32_t)i);
+  }
+  if (!any_skipped) kept.clear();                     // identity
+  const uint64_t n64 = ft.size();
+  if (n64 > 0x7ffffff0ull) { set_error("too many treads"); return STRL_ERR_ARG; }
+  const uint32_t n = (uint32_t)n64;
+  if (stats) stats->n_treads = n;
+  if (n == 0) return STRL_OK;                        // (only ghosts left: nothing to cluster, nothing to report)
+  // ---- upload, one device pass, results ---------------------------------------------------------------
+  strl::DevBuf *B = c->c_buf;
+  int rc;
+  if ((rc = B[B_TREADS].reserve((size_t)n * sizeof(strl_tread))) || (rc = B[B_CNT].reserve(CC_WORDS * 4))) return rc;
+  hipStream_t st = c->stream;
+  STRL_HIP(hipMemcpyAsync(B[B_TREADS].p, ft.data(), (size_t)n * sizeof(strl_tread), hipMemcpyHostToDevice, st));
+  STRL_HIP(hipMemcpyAsync(B[B_CNT].p, &n, 4, hipMemcpyHostToDevice, st));
+  ClusterRun &R = c->cl_run;
+  R = ClusterRun{};
+  R.n_max = n; R.n = n; R.n_tid = max_tid + 1; R.mode = mode; R.window = window; R.min_support = min_support; R.min_clip = min_clip;
+  R.min_clip_total = min_clip_total; R.max_clip_dist = max_clip_dist;
+  R.kbits = bits_for((uint64_t)(uint32_t)(max_tid + 1)) + 15;
+  R.pos_bits = bits_for(max_pos);
+  if (getenv("STRL_CLUSTER_TWO_SORTS")) R.pos_bits = 64;   // tests: force the two-sort path
+  R.composite = R.pos_bits + R.kbits <= 64;
+  if (!R.composite) R.pos_bits = 32;
+  R.kept.swap(kept);
+  R.treads = B[B_TREADS].as<strl_tread>(); R.d_n = B[B_CNT].as<uint32_t>() + CC_N;
+  if ((rc = cluster_device_pass(c, R.treads, R.d_n))) return rc;
+  return cluster_collect(c, ghosts, out, cap, n_out, unplaced, unplaced_cap, n_unplaced, stats);
 }

@@ -44,16 +44,20 @@ __host__ __device__ inline uint64_t fmix64(uint64_t h) {
 
 }  // namespace strl
 
-// what strl_cluster_replay needs to re-run the device side of the last strl_cluster call
+// the last clustering pass of a context: what strl_cluster_replay / strl_cluster_members need
 struct ClusterRun {
-  uint32_t n = 0, n_groups = 0, n_clusters = 0;
-  int kbits = 0, mode = 0;
+  uint32_t n_max = 0;              // launch bound of the pass (treads the buffers are sized for)
+  uint32_t n = 0, n_groups = 0, n_clusters = 0;   // known after the results were collected
+  int32_t n_tid = 0;
+  int kbits = 0, pos_bits = 32, mode = 0;
   bool composite = false;
   uint32_t window = 0;
   int32_t min_support = 0;
   uint32_t min_clip = 0, min_clip_total = 0, max_clip_dist = 0;
-  size_t tmpb = 0;
-  // members of the bounds the last strl_cluster returned: [first, first + count) in sorted order; `kept` maps the
+  const strl_tread *treads = nullptr;   // device
+  const uint32_t *d_n = nullptr;        // device
+  const uint32_t *perm = nullptr;       // device: sorted index -> input index
+  // members of the bounds the last pass returned: [first, first + count) in sorted order; `kept` maps the
   // uploaded (filtered) treads back to the caller's indices when merge mode dropped unplaced ones
   std::vector<uint32_t> b_first, b_count, kept;
 };

@@ -53,7 +53,8 @@ def test_soa_from_records(batch, oracle):
         ops = [(int(c) & 15, int(c) >> 4) for c in rec.cigar[a:b]]
         ref_len = sum(l for o, l in ops if o in (0, 2, 3, 7, 8)) if not (rec.flag[i] & 4) else 0
         assert soa.end[i] == rec.pos[i] + (ref_len or 1)
-        assert soa.clip_l[i] == (ops[0][1] if ops and ops[0][0] == 4 else 0)
+        single_m = len(ops) == 1 and ops[0][0] == 0      # clip_l carries the M length of a single-M cigar (extract.nim:33)
+        assert soa.clip_l[i] == (ops[0][1] if ops and (ops[0][0] == 4 or single_m) else 0)
         assert soa.clip_r[i] == (ops[-1][1] if ops and ops[-1][0] == 4 else 0)
         assert bool(soa.cig[i] & 1) == (len(ops) == 1 and ops[0][0] == 0)
         assert bool(soa.cig[i] & 16) == (len(ops) == 0)

@@ -214,9 +214,13 @@ def test_cluster_large_positions_and_ties(ctx, oracle):
             assert np.array_equal(b[f], exp_b[f]), f
 
 
-def test_cluster_many_contigs_two_pass_sort(ctx, oracle):
-    """tid >= 2^17 makes the (tid, unit) key wider than 32 bits: the composite single sort is replaced by the
-    position sort + stable group sort; rows must not change."""
+@pytest.mark.parametrize("force_two", [False, True])
+def test_cluster_many_contigs_two_pass_sort(ctx, oracle, monkeypatch, force_two):
+    """tid >= 2^17 makes the (tid, unit) key wider than 32 bits.  One 64-bit composite key still holds it; when
+    group key + position bits exceed 64 (forced here) the single sort is replaced by the position sort + stable group
+    sort; rows must not change."""
+    if force_two:
+        monkeypatch.setenv("STRL_CLUSTER_TWO_SORTS", "1")
     t = synth.synth_treads(n_samples=2, n_loci=200, seed=9, contig_len=1_000_000)
     t["tid"] = t["tid"] + 140000
     ot = np.zeros(len(t), oracle.TREAD_DTYPE)
@@ -227,3 +231,91 @@ def test_cluster_many_contigs_two_pass_sort(ctx, oracle):
     assert len(exp_b) > 10
     for f in ("tid", "left", "right", "left_most", "right_most", "center_mass", "n_left", "n_right", "n_total", "repeat"):
         assert np.array_equal(b[f], exp_b[f]), f
+
+
+def _pair_soa(rec, soa):
+    """the pairing arrays of strl_pair_soa for a host batch"""
+    k = soa.rv.keep
+    qh = api.qname_hash(rec)
+    keep = (k["mtid"], k["mpos"], k["flag"], qh)
+    return api.CPairSoa(*[a.ctypes.data for a in keep]), keep
+
+
+@pytest.mark.parametrize("n_pairs,seed,p,q", [(30000, 4321, 0.8, 40), (6000, 17, 0.65, 10)])
+def test_extract_device_and_resident_clustering_match_oracle(ctx, oracle, n_pairs, seed, p, q):
+    """scoring + pair logic + clustering all on the device, nothing but the final rows crossing to the host"""
+    rec, g = synth.synth_wgs(n_pairs, seed=seed, contig_len=3_000_000)
+    frag = synth.frag_hist(rec)
+    med = oracle.median(frag)
+    ctx.set_opts(p, q, med)
+    ctx.set_genome(g)
+    soa = api.Soa(rec)
+    cp, keep = _pair_soa(rec, soa)
+    n_tail = int((rec.tid < 0).sum())
+    ctx.extract_device(soa.c_struct(), cp, n_tail)
+    got, st = ctx.treads_fetch()
+    exp = oracle.extract(rec, g, oracle.make_opts(med, p, q))
+    ok, why = treads_equal(got, exp)
+    assert ok and len(exp) > 100, why
+    assert st.n_reads == rec.n and st.n_scored + st.n_skipped == rec.n
+    window = api.frag_median(frag, 0.99)
+    mcd = int(0.5 * api.frag_median(frag, 0.5))
+    b, u, cs = ctx.cluster_resident(len(rec.targets), window, min_support=3, max_clip_dist=mcd, pos_bits=24)
+    eb, eu = oracle.call_bounds(exp, 1, window, min_support=3, max_clip_dist=mcd)
+    assert [api.bounds_row(x, "c") for x in b] == [oracle.bounds_row(x, "c") for x in eb] and len(eb) > 5
+    assert [(x["repeat"].decode(), int(x["count"])) for x in u] == [(r, int(k)) for r, k in eu]
+    # the same rows from the host-array entry point
+    b2, u2, _ = ctx.cluster(got, api.MODE_CALL, window, min_support=3, max_clip_dist=mcd)
+    assert np.array_equal(b, b2) and np.array_equal(u, u2)
+
+
+def test_pair_logic_corner_cases_on_the_device(ctx, oracle):
+    """qname groups the reference treats specially: a third record with a qname already paired, a one-op soft clip
+    (both loop iterations of add_soft look at cigar[0]), secondary / supplementary records, an unpaired read, equal
+    start positions, the unmapped tail that is visited twice."""
+    A, C_, T = "A" * 150, "CAG" * 50, "ACGT" * 37 + "AC"
+    rows = [
+        # tid pos mtid mpos flag mapq cigar seq qname
+        (0, 100, 0, 400, 99, 60, "150M", C_, "p1"), (0, 400, 0, 100, 147, 60, "150M", T, "p1"),
+        (0, 120, 0, 120, 99, 60, "150M", C_, "same"), (0, 120, 0, 120, 147, 60, "150M", A, "same"),
+        (0, 130, 0, 500, 99, 60, "150S", C_, "oneop"), (0, 500, 0, 130, 147, 60, "150M", T, "oneop"),
+        (0, 140, 0, 600, 99, 60, "100M50S", T[:100] + "AC" * 25, "clip"), (0, 600, 0, 140, 147, 60, "40S110M", "TG" * 20 + T[:110], "clip"),
+        (0, 150, 0, 700, 99 | 0x100, 60, "150M", C_, "p1"), (0, 160, 0, 700, 99 | 0x800, 60, "150M", C_, "p1"),
+        (0, 170, 0, 100, 99, 60, "150M", C_, "p1"),           # third primary record of a qname
+        (0, 180, -1, -1, 0, 60, "150M", C_, "lonely"),
+        (1, 50, 0, 90, 147, 30, "150M", A, "xchrom"), (0, 90, 1, 50, 99, 10, "150M", C_, "xchrom"),
+        (-1, -1, -1, -1, 77, 0, "*", C_, "un1"), (-1, -1, -1, -1, 141, 0, "*", C_, "un1"),
+        (-1, -1, -1, -1, 77, 0, "*", A, "un2"), (-1, -1, -1, -1, 141, 0, "*", T, "un2"),
+    ]
+    rows.sort(key=lambda r: ((1 << 40) if r[0] < 0 else (r[0] << 32) + max(r[1], 0)))
+    rec = RecordBatch.from_fields(*[[r[j] for r in rows] for j in range(9)])
+    for p, q in ((0.8, 40), (0.5, 0)):
+        ctx.set_opts(p, q, 350)
+        ctx.set_genome(None)
+        got, _ = ctx.extract(rec)
+        exp = oracle.extract(rec, None, oracle.make_opts(350, p, q))
+        ok, why = treads_equal(got, exp)
+        assert ok and len(exp) >= 8, why
+        soa = api.Soa(rec)
+        cp, keep = _pair_soa(rec, soa)
+        ctx.extract_device(soa.c_struct(), cp, int((rec.tid < 0).sum()))
+        got2, _ = ctx.treads_fetch()
+        ok, why = treads_equal(got2, exp)
+        assert ok, why
+
+
+def test_too_many_records_under_one_qname_fall_back_to_the_host_pair_logic(ctx, oracle):
+    C_ = "CAG" * 50
+    n = 16
+    rec = RecordBatch.from_fields([0] * n, list(range(100, 100 + n)), [0] * n, [5000] * n, [99] * n, [60] * n, ["150M"] * n, [C_] * n, ["dup"] * n)
+    ctx.set_opts(0.8, 40, 350)
+    ctx.set_genome(None)
+    soa = api.Soa(rec)
+    cp, keep = _pair_soa(rec, soa)
+    ctx.extract_device(soa.c_struct(), cp, 0)
+    with pytest.raises(api.StrlingError):
+        ctx.treads_fetch()
+    got, _ = ctx.extract(rec)                       # strl_extract replays such a batch on the host
+    exp = oracle.extract(rec, None, oracle.make_opts(350, 0.8, 40))
+    ok, why = treads_equal(got, exp)
+    assert ok, why
