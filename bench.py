@@ -1,19 +1,25 @@
 #!/usr/bin/env python
-"""bench.py -- reads/s through the extract hot path on N MI355X (one process per GPU).
+"""bench.py -- reads/s through the extract + cluster hot path on N MI355X (one process per GPU).
 
-A "step" = one pass of the device hot path over one HBM-resident batch of synthetic 150 bp paired-end WGS
-records (input S1): the extract kernels (classify -> score -> soft-clip scan, the whole
-`strl_score_reads` entry point) followed by the clustering pass (stable radix sorts -> sweep -> bounds,
-`strl_cluster_replay`) over the STR reads such a batch yields.  Reads shard by record, so with N > 1 every rank scores
-its own batch and no collective sits on the data path (weak scaling); the only collectives are
-the barrier + MAX of the elapsed time the contract asks for.
+A "step" = one pass of the WHOLE device hot path over one HBM-resident batch of 2^25 DISTINCT synthetic 150 bp
+paired-end WGS records (input S1):
+    classify (skip predicate) -> scorer (whole reads) -> soft-clip scan          strl_extract_device, scoring half
+    -> pair logic on the device (Bloom mark, probe, hash join, Cache.add replay, .bin order)      ... pairing half
+    -> clustering of the treads THAT STEP produced (keys, radix sort, sweep, bounds)               strl_cluster_resident
+Nothing crosses to the host inside a step and no stage is replayed from precomputed data.  Reads shard by record, so with
+N > 1 every rank runs the extract half on its own batch; before clustering the ranks all-gather their treads (RCCL) and
+every rank clusters the (tid, unit) groups it owns (strling_amd/dist.py).
 
-Prints ONE JSON line on rank 0 (see the task contract): value = reads of ALL ranks / max-rank time.
+Prints ONE JSON line on rank 0: value = reads of ALL ranks / max-rank time; `roofline` for the slowest kernel launch
+(HIP events on the kernels' own stream); `cpu_baseline` = the oracle's extract + cluster over the same stages, 1 thread;
+`end_to_end` = `strling extract` + `strling call`-style clustering from a BAM file on this box (host decode included).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -30,18 +36,39 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads-per-gpu", type=int, default=2 ** 25, help="reads resident per GPU (2^24 pairs, SURVEY S1)")
-    ap.add_argument("--base-pairs", type=int, default=2 ** 18, help="unique synthetic pairs generated on the host, tiled in HBM")
+    ap.add_argument("--chunks", type=int, default=64, help="independent synthetic sub-samples the batch is generated from (in parallel)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e-pairs", type=int, default=2 ** 21, help="pairs of the BAM file the end-to-end leg decodes")
+    ap.add_argument("--cache", default="", help="directory to keep the generated batch in (profiling runs reload it instead of forking generators)")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    from strling_amd import api, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # ---- synthetic S1 batch: DISTINCT reads, generated before the GPU runtime starts (worker processes fork) ----
+    from strling_amd import synth
+    t_gen = time.perf_counter()
+    n_chunks = max(1, min(args.chunks, args.reads_per_gpu // 2048))
+    pairs_per_chunk = max(1, args.reads_per_gpu // 2 // n_chunks)
+    procs = max(1, min(n_chunks, (os.cpu_count() or 2) // max(1, min(world, 8)) - 2))
+    cache = os.path.join(args.cache, f"s1_{args.reads_per_gpu}_{n_chunks}_{rank}.pkl") if args.cache else ""
+    if cache and os.path.exists(cache):
+        import pickle
+        rec, g = pickle.load(open(cache, "rb"))
+    else:
+        rec, g = synth.synth_wgs_chunks(n_chunks, pairs_per_chunk, seed=1234 + 1000 * rank, procs=procs)
+        if cache:
+            import pickle
+            pickle.dump((rec, g), open(cache, "wb"), protocol=4)
+    t_gen = time.perf_counter() - t_gen
+
+    import torch
+    import torch.distributed as dist
+    from strling_amd import api
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     local = local % torch.cuda.device_count()       # (a 2-rank dry run on a 1-GPU box maps both ranks to cuda:0)
@@ -54,71 +81,51 @@ def main():
             dist.init_process_group(backend)
     dev = torch.device("cuda", local)
 
-    # ---- synthetic S1 base sample on the host, tiled into HBM -------------------------------------
-    rec, g = synth.synth_wgs(args.base_pairs, seed=1234 + rank)
     soa = api.Soa(rec)
-    n_base = soa.n
-    tiles = max(1, args.reads_per_gpu // n_base)
-    n = n_base * tiles
-    stride16 = int(soa.seq_off[1] - soa.seq_off[0]) if n_base > 1 else 5
-    seq_bytes_base = n_base * stride16 * 16
-
-    def tile(a, dt):
-        return torch.from_numpy(np.ascontiguousarray(a)).to(dev).view(dt).repeat(tiles)
-
-    d = dict(tid=tile(soa.tid, torch.int32), pos=tile(soa.pos, torch.int32), end=tile(soa.end, torch.int32),
-             l_seq=tile(soa.l_seq.view(np.int16), torch.int16), clip_l=tile(soa.clip_l.view(np.int16), torch.int16),
-             clip_r=tile(soa.clip_r.view(np.int16), torch.int16), mapq=tile(soa.mapq, torch.uint8), cig=tile(soa.cig, torch.uint8))
-    so = torch.from_numpy(soa.seq_off.astype(np.int64)).to(dev)
-    d["seq_off"] = (so[None, :] + (torch.arange(tiles, device=dev, dtype=torch.int64) * (seq_bytes_base // 16))[:, None]).reshape(-1).to(torch.int32)
-    seq_base = torch.from_numpy(soa.seq4[:seq_bytes_base]).to(dev)
-    d["seq4"] = torch.cat([seq_base.repeat(tiles), torch.zeros(64, dtype=torch.uint8, device=dev)])
-    whole = torch.zeros(n, dtype=torch.int32, device=dev)
-    soft_cap = max(1024, n // 8)
-    soft = torch.zeros((soft_cap, 4), dtype=torch.int32, device=dev)
-    cs = api.CReadSoa(n, d["tid"].data_ptr(), d["pos"].data_ptr(), d["end"].data_ptr(), d["seq_off"].data_ptr(), d["l_seq"].data_ptr(),
-                      d["clip_l"].data_ptr(), d["clip_r"].data_ptr(), d["mapq"].data_ptr(), d["cig"].data_ptr(), d["seq4"].data_ptr(),
-                      d["seq4"].numel(), soa.max_l_seq, api.MEM_DEVICE)
-    torch.cuda.synchronize()
-
-    ctx = api.Context(local)
-    med = api.frag_median(synth.frag_hist(rec))
-    ctx.set_opts(0.8, 40, med)      # reference defaults: -p 0.8 -q 40 (extract.nim:255-256)
-    ctx.set_genome(g)
-
-    # the STR reads of the batch: extract the unique sample through the full path (GPU scoring + host pair logic) and
-    # give every tile its own contigs, as if the genome were `tiles` times larger (no artificial pile-ups)
-    base_treads, _ = ctx.extract(rec)
-    treads = np.tile(base_treads, tiles)
-    n_contigs = len(rec.targets)
-    placed = treads["tid"] >= 0
-    treads["tid"] = np.where(placed, treads["tid"] + np.repeat(np.arange(tiles, dtype=np.int32) * n_contigs, base_treads.size), -1)
+    n = soa.n
+    L = int(soa.max_l_seq)
+    qh = api.qname_hash(rec)
+    n_tail = int((rec.tid < 0).sum())
+    n_tid = len(rec.targets)
     frag = synth.frag_hist(rec)
+    med = api.frag_median(frag)
     window = api.frag_median(frag, 0.99)                     # call.nim:114
     max_clip_dist = int(0.5 * api.frag_median(frag, 0.5))    # call.nim:232
-    bounds, unplaced, cst = ctx.cluster(treads, api.MODE_CALL, window, min_support=5, max_clip_dist=max_clip_dist)
+    pos_bits = max(int(max(ln for _, ln in rec.targets)) + 8192, 2).bit_length()
 
-    # N > 1: the exchange step of SURVEY section 8(e) -- one RCCL all-gather of the compact tread arrays (32 B per STR read)
-    # before clustering, after which every rank clusters an equal share of the (tid, unit) groups.  The synthetic ranks
-    # hold equally sized tread sets, so the share a rank clusters is as large as its own set: the replayed pass.
+    def up(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    keep = rec.mtid, rec.mpos, rec.flag
+    d = dict(tid=up(soa.tid), pos=up(soa.pos), end=up(soa.end), seq_off=up(soa.seq_off.view(np.int32)), l_seq=up(soa.l_seq.view(np.int16)),
+             clip_l=up(soa.clip_l.view(np.int16)), clip_r=up(soa.clip_r.view(np.int16)), mapq=up(soa.mapq), cig=up(soa.cig),
+             seq4=up(soa.seq4), mtid=up(np.asarray(rec.mtid, np.int32)), mpos=up(np.asarray(rec.mpos, np.int32)),
+             flag=up(np.asarray(rec.flag, np.uint16).view(np.int16)), qhash=up(qh.view(np.int64)))
+    cs = api.CReadSoa(n, d["tid"].data_ptr(), d["pos"].data_ptr(), d["end"].data_ptr(), d["seq_off"].data_ptr(), d["l_seq"].data_ptr(),
+                      d["clip_l"].data_ptr(), d["clip_r"].data_ptr(), d["mapq"].data_ptr(), d["cig"].data_ptr(), d["seq4"].data_ptr(),
+                      d["seq4"].numel(), L, api.MEM_DEVICE)
+    cp = api.CPairSoa(d["mtid"].data_ptr(), d["mpos"].data_ptr(), d["flag"].data_ptr(), d["qhash"].data_ptr())
+    torch.cuda.synchronize()
+    del soa, qh
+    rec.seq4 = None
+
+    ctx = api.Context(local)
+    ctx.set_opts(0.8, 40, med)      # reference defaults: -p 0.8 -q 40 (extract.nim:255-256)
+    ctx.set_genome(g)
+    item_cap, tread_cap = n // 8 + 65536, n // 16 + 65536
+
+    # ---- one synchronous pass: unit counts of every stage, and the result of the step -------------------------------
+    ctx.extract_device(cs, cp, n_tail, item_cap, tread_cap)
+    treads, st = ctx.treads_fetch()
+    bounds, unplaced, cst = ctx.cluster_resident(n_tid, window, min_support=5, max_clip_dist=max_clip_dist, pos_bits=pos_bits)
+    n_treads = int(treads.size)
+
     exchange = None
-    cstream = torch.cuda.ExternalStream(ctx.stream)
     if world > 1:
+        from strling_amd import dist as sdist
         try:
-            t_mine = torch.from_numpy(np.ascontiguousarray(treads).view(np.uint8).copy()).to(dev)
-            n_max = torch.tensor([t_mine.numel()], dtype=torch.int64, device=dev)
-            dist.all_reduce(n_max, op=dist.ReduceOp.MAX)      # ranks hold different samples: pad to the largest tread array
-            t_local = torch.zeros(int(n_max.item()), dtype=torch.uint8, device=dev)
-            t_local[:t_mine.numel()] = t_mine
-            t_all = torch.empty(world * t_local.numel(), dtype=torch.uint8, device=dev)
-            gather_done = torch.cuda.Event()
-
-            def exchange():
-                dist.all_gather_into_tensor(t_all, t_local)
-                gather_done.record()
-                cstream.wait_event(gather_done)      # the clustering kernels of this step start after the gather
-
-            exchange()
+            exchange = sdist.DeviceClusterExchange(ctx, world, rank, n_treads, dev)
+            exchange.step(n_tid * 1, window, 5, max_clip_dist, pos_bits)
             torch.cuda.synchronize()
         except Exception as e:                        # keep the shard-only measurement if the collective is unavailable
             print(f"[bench] rank {rank}: tread all-gather disabled: {e}", file=sys.stderr)
@@ -128,37 +135,25 @@ def main():
         if int(ok.item()) == 0:
             exchange = None
 
-    # one synchronous pass for the unit counts of each kernel
-    n_soft, st = ctx.score_device(cs, whole.data_ptr(), soft.data_ptr(), soft_cap, sync=True)
-    for _ in range(args.warmup):
-        ctx.score_device(cs, whole.data_ptr(), soft.data_ptr(), soft_cap)
-        if exchange:
-            exchange()
-        ctx.cluster_replay()
-    ctx.sync()
-    # clustering pass alone, HIP events on the context stream
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    with torch.cuda.stream(cstream):
-        ev0.record()
-        for _ in range(5):
-            ctx.cluster_replay()
-        ev1.record()
-    ctx.sync()
-    ms_cluster = ev0.elapsed_time(ev1) / 5
-    ctx.enable_timing(True)
+    def step():
+        ctx.extract_device(cs, cp, n_tail, item_cap, tread_cap)
+        if exchange is not None:
+            exchange.step(n_tid, window, 5, max_clip_dist, pos_bits)
+        else:
+            ctx.cluster_resident(n_tid, window, min_support=5, max_clip_dist=max_clip_dist, pos_bits=pos_bits, fetch=False)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ctx.score_device(cs, whole.data_ptr(), soft.data_ptr(), soft_cap)
-        if exchange:
-            exchange()
-        ctx.cluster_replay()
+        step()
     ctx.sync()
     barrier()
     el = time.perf_counter() - t0
@@ -166,22 +161,42 @@ def main():
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+
+    # ---- per-launch times: a few instrumented steps with HIP events on the kernels' own stream ----------------------
+    ctx.enable_timing(True)
+    n_inst = 5
+    pair_ms, cl_ms = {}, {}
+    for _ in range(n_inst):
+        ctx.extract_device(cs, cp, n_tail, item_cap, tread_cap)
+        for k, v in ctx.pair_times().items():
+            pair_ms[k] = pair_ms.get(k, 0.0) + v / n_inst
+        ctx.cluster_resident(n_tid, window, min_support=5, max_clip_dist=max_clip_dist, pos_bits=pos_bits, fetch=False)
+        for k, v in ctx.cluster_times().items():
+            cl_ms[k] = cl_ms.get(k, 0.0) + v / n_inst
     detail, launches = ctx.kernel_times_detail()
     ctx.enable_timing(False)
+    launches = max(1, launches)
+    ms = {k: v / launches for k, v in detail.items()}
+    ms.update(pair_ms)
+    ms.update(cl_ms)
 
-    # ---- roofline of the dominant kernel (HIP-event durations on the kernels' own stream) ----------
-    # One entry per kernel LAUNCH of a scoring pass; algorithmic bytes per launch as in DESIGN.md "Kernels":
+    # ---- roofline of the slowest launch -----------------------------------------------------------------------------
+    # Algorithmic bytes per launch (DESIGN.md "Kernels"):
     #   classify   13 B of coordinates read + 4 B written (result word or queue slot) per read
     #   stage A    16 B queue entry + ceil(L/2) B SEQ read + 4 B result written per item
     #   stage B    32 B item + ceil(L/2) B SEQ + 4 B result per item that reaches k = 5
     #   segments   16 B item + the clipped bases (counted as ceil(L/4) B on average) + 16 B result record
     #   compaction 16 B state read per slot + 32 B item written per survivor; soft items: 1 B flag per slot, 16 B entry
     #              read + 16 B item written per clipped end
-    launches = max(1, launches)
-    L = int(soa.max_l_seq)
+    #   pair mark + probe  16 B per soft-clip record + 8 B qname hash per read (the one full pass the pair logic adds)
+    #                      + 12 B written per join item
+    #   join sort / order sort  (12 B read + 12 B written) per item per 8-bit pass (4 passes each)
+    #   replay     12 B item + ~40 B of metadata gathered per read item + 40 B per emitted tread
+    #   cluster    32 B tread read + 25 B keys/payload written, 6 sort passes x 24 B, 41 B gathered + written per tread, sweep 16 B
     seq_b = (L + 1) // 2
-    ms = {k: v / launches for k, v in detail.items()}
     nbw, nbs = int(st.n_stage_b_whole), int(st.n_stage_b_soft)
+    n_items = int(min(item_cap, 2.3 * n_treads + st.n_soft_items * 0.4))
+    key_passes = (pos_bits + max(n_tid, 1).bit_length() + 15 + 7) // 8
     alg = {
         "classify_kernel": 17.0 * n,
         "score_kernel<whole,A>": (20.0 + seq_b) * st.n_scored,
@@ -191,56 +206,68 @@ def main():
         "score_kernel<segment,A>": (32.0 + (L + 3) // 4) * st.n_soft_items,
         "compact_kernel<segment>": 16.0 * st.n_soft_items + 32.0 * nbs,
         "score_kernel<segment,B>": (48.0 + (L + 3) // 4) * nbs,
+        "pair_mark_probe": 16.0 * st.n_soft_items + 8.0 * n + 12.0 * n_items,
+        "pair_join_sort": 4 * 24.0 * n_items,
+        "pair_replay": 52.0 * n_items + 44.0 * n_treads,
+        "pair_order": 4 * 24.0 * n_treads + 64.0 * n_treads,
+        "cluster_keys_sort_groups": (57.0 + key_passes * 24.0 + 41.0) * n_treads,
+        "cluster_sweep": 16.0 * n_treads,
+        "cluster_bounds": 8.0 * n_treads + 44.0 * len(bounds),
     }
     kernels = {k: (ms[k], alg[k]) for k in ms}
     groups = {"classify_kernel": ms["classify_kernel"],
               "score_kernel<whole>": ms["score_kernel<whole,A>"] + ms["compact_kernel<whole>"] + ms["score_kernel<whole,B>"],
               "score_kernel<soft>": ms["soft_compact_kernel"] + ms["score_kernel<segment,A>"] + ms["compact_kernel<segment>"] + ms["score_kernel<segment,B>"],
-              # clustering: 36 small launches (merge sort of the composite key, scans, sweep, bounds); reported as one pass
-              "cluster_pass": ms_cluster}
-    cluster_alg = (2 * (4 + 4) * 2 + 2 * (8 + 4) * 2 + 24.0) * treads.size + 44.0 * len(bounds)
-    # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    # separate runs of tools/prof_run.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null if absent
-    traffic = {}
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "f_traffic.json")))["kernels"]
-        pick = {"classify_kernel": "classify_kernel", "score_kernel<whole,A>": "<10, 64, 0, 0", "compact_kernel<whole>": "compact_kernel<1, 0>",
-                "score_kernel<whole,B>": "<10, 64, 0, 1", "soft_compact_kernel": "soft_compact_kernel", "score_kernel<segment,A>": "<10, 64, 1, 0",
-                "compact_kernel<segment>": "compact_kernel<1, 1>", "score_kernel<segment,B>": "<10, 64, 1, 1"}
-        for k, pat in pick.items():
-            traffic[k] = sum(v["hbm_bytes_corrected"] for name, v in tj.items() if pat in name)
-    except Exception:
-        traffic = {}
-    dom = max(kernels, key=lambda k: kernels[k][0])
+              "pair_logic": sum(pair_ms.values()), "cluster_pass": sum(cl_ms.values())}
+    single = {k: v for k, v in kernels.items() if not (k.startswith("pair_") or k.startswith("cluster_")) or k == "pair_mark_probe"}
+    dom = max(single, key=lambda k: single[k][0])     # slowest single launch (the pair / cluster entries are launch groups)
     dom_ms, dom_bytes = kernels[dom]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02", "traffic.json")))["kernels"]
+        pick = {"classify_kernel": "classify_kernel", "score_kernel<whole,A>": "<10, 64, 0, 0", "score_kernel<segment,A>": "<10, 64, 1, 0",
+                "pair_mark_probe": "pair_probe_kernel"}
+        if dom in pick and n == 2 ** 25 and L == 150:
+            traffic = sum(v["hbm_bytes_corrected"] for name, v in tj.items() if pick[dom] in name) or None
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": traffic.get(dom) if (n == 2 ** 25 and L == 150) else None,
-                "traffic_note": "HBM bytes per launch of that kernel from profiles/r01/f_traffic.json (PMC, same workload)",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                "traffic_note": "HBM bytes per launch of that kernel from profiles/r02/traffic.json (PMC, same workload)",
                 "kernel_ms": {k: round(v[0], 4) for k, v in kernels.items()},
                 "kernel_alg_bytes": {k: int(v[1]) for k, v in kernels.items()},
                 "kernel_alg_GBps": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0.0 for k, v in kernels.items()},
                 "group_ms": {k: round(v, 4) for k, v in groups.items()},
-                "pipeline_alg_GBps": round((sum(v[1] for v in kernels.values()) + cluster_alg) / (el / args.steps) / 1e9, 2),
+                "pipeline_alg_GBps": round(sum(v[1] for v in kernels.values()) / (el / args.steps) / 1e9, 2),
                 "survey_115B_per_read_GBps": round(115.0 * n / (el / args.steps) / 1e9, 2)}
 
-    # ---- CPU baseline: the oracle ("port" of the reference algorithm), 1 thread, bounded sample ----
+    # ---- CPU baseline: the oracle ("port" of the reference algorithm) over the SAME stages, 1 thread, bounded sample ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        sample_pairs = min(args.base_pairs, 2 ** 17)
-        srec, sg = synth.synth_wgs(sample_pairs, seed=1234)
-        opts = O.make_opts(med, 0.8, 40)
+        srec, sg = synth.synth_wgs(2 ** 17, seed=1234)
+        sfrag = synth.frag_hist(srec)
+        smed = O.median(sfrag)
+        opts = O.make_opts(smed, 0.8, 40)
         reads_done, t_cpu = 0, 0.0
         while t_cpu < args.cpu_seconds:
             t1 = time.perf_counter()
-            O.extract(srec, sg, opts)
+            et = O.extract(srec, sg, opts)
+            O.call_bounds(et, 1, api.frag_median(sfrag, 0.99), min_support=5, max_clip_dist=int(0.5 * smed))
             t_cpu += time.perf_counter() - t1
             reads_done += srec.n
         cpu = {"value": round(reads_done / t_cpu, 1), "unit": "reads/s", "cores": 1, "kind": "port",
-               "sample": f"oracle extract loop (skip predicate + get_repeat + add_soft + pair logic) over the S1 mix, "
+               "sample": f"oracle extract loop (skip predicate + get_repeat + add_soft + pair logic) + cluster/bounds over the S1 mix, "
                          f"{srec.n} reads x {reads_done // srec.n} passes, {t_cpu:.1f} s, single thread like the reference (threads=0)"}
+
+    # ---- end to end: BAM file -> .bin (strling extract) on this box, host decode included ---------------------------
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_e2e:
+        try:
+            e2e = end_to_end(args.e2e_pairs)
+        except Exception as e:
+            e2e = {"error": str(e)[:300]}
 
     if rank == 0:
         total_reads = n * world * args.steps
@@ -249,19 +276,29 @@ def main():
             "value": round(total_reads / el, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32 integer", "data": "synthetic",
-            "config": {"workload": f"{world}xMI355X: 30x 150 bp PE synthetic WGS, k=2-6 repeat-unit scorer + soft-clip scan + on-GPU radix-sort/segmented clustering (BASELINE.json configs[1]+[2])",
-                       "reads_per_gpu": n, "read_len": L, "unique_reads_per_gpu": n_base, "tiles": tiles,
+            "config": {"workload": f"{world}xMI355X: 30x 150 bp PE synthetic WGS, k=2-6 repeat-unit scorer + soft-clip scan + device pair logic + on-GPU radix-sort/segmented clustering (BASELINE.json configs[1]+[2])",
+                       "reads_per_gpu": n, "read_len": L, "unique_reads_per_gpu": n, "tiles": 1, "generate_s": round(t_gen, 1),
                        "skipped_frac": round(st.n_skipped / n, 4), "scored_reads": int(st.n_scored), "soft_items": int(st.n_soft_items),
-                       "str_reads_clustered": int(treads.size), "clusters": int(cst.n_clusters), "bounds": int(len(bounds)),
-                       "timed_region": "classify + score + soft-clip kernels, then radix-sort + sweep + bounds clustering kernels, all on HBM-resident data; BAM decode, PCIe and the host pair logic between the two are excluded",
+                       "str_reads_clustered": n_treads, "clusters": int(cst.n_clusters), "bounds": int(len(bounds)),
+                       "timed_region": "every kernel of the path on HBM-resident records: classify + score + soft-clip scan, the pair logic (Cache.add) on the device, "
+                                       "then keys + radix sort + sweep + bounds over the treads the same step produced; BAM decode, PCIe, the host-side row order "
+                                       "(Nim table order) and file writing are in end_to_end, not here",
                        "parallelism": (f"records sharded over {world} GPU(s), no data-path collective" if exchange is None else
-                                       f"records sharded over {world} GPUs; per step one RCCL all-gather of the compact tread arrays "
-                                       f"({treads.size * 32} B per rank) before clustering, every rank clusters an equal share of the groups")},
-            "roofline": roofline, "cpu_baseline": cpu,
+                                       f"records sharded over {world} GPUs; per step one RCCL all-gather of the tread arrays "
+                                       f"({exchange.pad * 32} B per rank) before clustering, every rank clusters the (tid, unit) groups it owns")},
+            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e,
         }
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def end_to_end(n_pairs):
+    """`strling extract` from a BAM file written to local disk (page cache warm), wall clock, all host threads."""
+    from strling_amd import build
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_bench
+    return e2e_bench.run(n_pairs, build.CLI)
 
 
 if __name__ == "__main__":

@@ -280,6 +280,9 @@ int strl_cluster_resident(strl_ctx *ctx, int mode, int32_t n_tid, int pos_bits, 
                           uint16_t min_clip_total, uint16_t max_clip_dist, strl_bounds *out, uint64_t cap, uint64_t *n_out,
                           strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced, strl_cluster_stats *stats);
 
+/* HIP-event times (ms) of the last clustering pass when timing is enabled: keys + sort + group tables | ends + walk | bounds */
+int strl_ctx_cluster_times(strl_ctx *ctx, double ms[3]);
+
 /* The (tid, unit) groups of `treads` in the order the reference iterates its Table (call.nim:223, merge.nim:172) -- the
  * order strl_cluster emits the groups' rows in.  Host only.  A multi-GPU run that clusters disjoint sets of groups on
  * different ranks puts the gathered rows back into the reference's order with it (strling_amd/dist.py). */

@@ -103,7 +103,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
            "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order",
-           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident"]
+           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times"]
 
 
 def lib_path():
@@ -170,6 +170,7 @@ def load(build_if_missing=True):
     L.strl_cluster_resident.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int, C.c_uint32, C.c_int32, C.c_uint16, C.c_uint16, C.c_uint16,
                                         C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                         C.POINTER(ClusterStats)]
+    L.strl_ctx_cluster_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 3)]
     L.strl_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
     _LIB = L
     return L
@@ -434,6 +435,11 @@ class Context:
                 continue
             _check(rc)
             return out[:no.value].copy(), unpl[:nu.value].copy(), st
+
+    def cluster_times(self):
+        ms = (C.c_double * 3)()
+        _check(self.L.strl_ctx_cluster_times(self.h, C.byref(ms)))
+        return dict(zip(["cluster_keys_sort_groups", "cluster_sweep", "cluster_bounds"], list(ms)))
 
     def cluster_members(self, n_bounds):
         """indices (into the tread array of the last cluster() call) of every returned bound's reads, cluster order"""

@@ -766,6 +766,18 @@ static int cluster_collect(strl_ctx *c, const std::vector<std::pair<uint64_t, ui
   return STRL_OK;
 }
 
+extern "C" int strl_ctx_cluster_times(strl_ctx *c, double ms[3]) {
+  if (!c || !ms) return STRL_ERR_ARG;
+  STRL_HIP(hipSetDevice(c->device));
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 3; ++k) {
+    float f = 0.f;
+    if (c->timing) (void)hipEventElapsedTime(&f, c->ev[4 + k], c->ev[5 + k]);
+    ms[k] = f;
+  }
+  return STRL_OK;
+}
+
 static inline int bits_for(uint64_t v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; }
 
 // Re-run the device side of the last clustering pass on the same resident treads, asynchronously.

@@ -31,7 +31,8 @@ def synth_genome_str(rng, n_contigs, contig_len, overlap_frac=0.03, read_len=150
 
 
 def synth_wgs(n_pairs, seed=1234, read_len=150, n_contigs=25, contig_len=10_000_000, str_frac=0.01, soft_frac=0.03,
-              indel_frac=0.01, unmapped_frac=0.005, interchrom_frac=0.01, genome_overlap=0.03, with_qnames=True, hot_loci=2):
+              indel_frac=0.01, unmapped_frac=0.005, interchrom_frac=0.01, genome_overlap=0.03, with_qnames=True, hot_loci=2,
+              pair_id_base=0):
     """-> (RecordBatch sorted like a coordinate-sorted BAM with the unmapped tail last, GenomeStr)."""
     rng = _rng(seed)
     L = read_len
@@ -211,7 +212,7 @@ def synth_wgs(n_pairs, seed=1234, read_len=150, n_contigs=25, contig_len=10_000_
     cigar = cigar[src]
     seq4, seq_off = pack_codes4(codes[order], l_seq[order])
     if with_qnames:
-        names = np.char.add("q", pair_id.astype(str)).astype("S")
+        names = np.char.add("q", (pair_id + pair_id_base).astype(str)).astype("S")
         qlen = np.char.str_len(names)
         qoff = np.zeros(n + 1, np.uint64)
         qoff[1:] = np.cumsum(qlen)
@@ -222,6 +223,73 @@ def synth_wgs(n_pairs, seed=1234, read_len=150, n_contigs=25, contig_len=10_000_
     rec = RecordBatch(tid[order], pos[order], mtid[order], mpos[order], flag[order], mapq[order], new_off, cigar, seq_off,
                       l_seq[order], seq4, qoff, qnames, isize[order],
                       [(f"chr{i + 1}", contig_len) for i in range(n_contigs)])
+    return rec, g
+
+
+def _chunk_worker(a):
+    pairs, seed, base, kw = a
+    rec, g = synth_wgs(pairs, seed=seed, pair_id_base=base, **kw)
+    m = int((rec.tid >= 0).sum())                    # mapped records come first (coordinate order), the unmapped tail last
+    stride = int(rec.seq_off[1] - rec.seq_off[0]) if rec.n > 1 else 16
+    rows = rec.seq4[: rec.n * stride].reshape(rec.n, stride)
+    ncig = np.diff(rec.cigar_off.astype(np.int64))
+    qlen = np.diff(rec.qname_off.astype(np.int64))
+    c0, q0 = int(rec.cigar_off[m]), int(rec.qname_off[m])
+    qn = bytes(rec.qnames)
+    parts = []
+    for sl, cg, qb in ((slice(0, m), rec.cigar[:c0], qn[:q0]), (slice(m, rec.n), rec.cigar[c0:], qn[q0:])):
+        parts.append(dict(tid=rec.tid[sl], pos=rec.pos[sl], mtid=rec.mtid[sl], mpos=rec.mpos[sl], flag=rec.flag[sl], mapq=rec.mapq[sl],
+                          ncig=ncig[sl], cigar=cg, rows=rows[sl], l_seq=rec.l_seq[sl], qlen=qlen[sl], qnames=qb, isize=rec.isize[sl]))
+    return parts, g, rec.targets
+
+
+def synth_wgs_chunks(n_chunks, pairs_per_chunk, seed=1234, procs=None, **kw):
+    """A large S1 batch of DISTINCT reads: n_chunks independent synth_wgs samples (seed + chunk), each on its own set of
+    contigs, generated by a pool of worker processes and merged into one coordinate-sorted batch with one unmapped tail.
+    Deterministic in (n_chunks, pairs_per_chunk, seed).  Call before anything initialises the GPU runtime (fork)."""
+    import multiprocessing as mp
+    import os
+    jobs = [(pairs_per_chunk, seed + c, c * pairs_per_chunk, kw) for c in range(n_chunks)]
+    procs = procs or min(n_chunks, max(1, (os.cpu_count() or 2) // 2))
+    if n_chunks == 1 or procs == 1:
+        res = [_chunk_worker(j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(procs) as pool:
+            res = pool.map(_chunk_worker, jobs, chunksize=1)
+    n_contigs = res[0][1].n_tid
+    pieces = [r[0][0] for r in res] + [r[0][1] for r in res]          # every chunk's mapped part, then every tail
+    shift = [c * n_contigs for c in range(n_chunks)] * 2
+
+    def cat(key, dtype=None):
+        a = np.concatenate([p[key] for p in pieces])
+        return a.astype(dtype) if dtype is not None else a
+
+    def cat_tid(key):
+        return np.concatenate([np.where(p[key] >= 0, p[key] + sh, p[key]).astype(np.int32) for p, sh in zip(pieces, shift)])
+
+    n = sum(p["tid"].size for p in pieces)
+    cig_off = np.zeros(n + 1, np.uint32)
+    cig_off[1:] = np.cumsum(cat("ncig"))
+    qoff = np.zeros(n + 1, np.uint64)
+    qoff[1:] = np.cumsum(cat("qlen"))
+    rows = np.concatenate([p["rows"] for p in pieces])
+    stride = rows.shape[1]
+    seq4 = np.zeros(n * stride + 32, np.uint8)
+    seq4[: n * stride] = rows.reshape(-1)
+    targets = []
+    for c, r in enumerate(res):
+        targets += [(f"s{c}{name}", ln) for name, ln in r[2]]
+    rec = RecordBatch(cat_tid("tid"), cat("pos"), cat_tid("mtid"), cat("mpos"), cat("flag"), cat("mapq"), cig_off, cat("cigar"),
+                      np.arange(n, dtype=np.uint64) * np.uint64(stride), cat("l_seq"), seq4, qoff, b"".join(p["qnames"] for p in pieces),
+                      cat("isize"), targets)
+    gs = [r[1] for r in res]
+    off = np.zeros(n_chunks * n_contigs + 1, np.int64)
+    base = 0
+    for c, g in enumerate(gs):
+        off[c * n_contigs + 1:(c + 1) * n_contigs + 1] = g.iv_off[1:] + base
+        base += int(g.iv_off[-1])
+    g = GenomeStr(n_chunks * n_contigs, np.concatenate([g.has_chrom for g in gs]), off, np.concatenate([g.iv_start for g in gs]),
+                  np.concatenate([g.iv_stop for g in gs]))
     return rec, g
 
 
