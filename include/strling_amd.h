@@ -107,14 +107,25 @@ typedef struct {
   int32_t mem;             /* STRL_MEM_HOST or STRL_MEM_DEVICE: where ALL pointers above live */
 } strl_read_soa;
 
-/* The per-read fields the pair logic (Cache.add, extract.nim:192-248) needs on top of strl_read_soa; same `mem` as the
- * read batch they belong to. */
+/* What the pair logic (Cache.add, extract.nim:192-248 with to_tread, add_soft, adjust_by) reads of one record, as ONE
+ * 32-byte row: the join touches a few per cent of the records at random, and a row is one memory transaction where the
+ * column arrays of strl_read_soa would be a dozen.  Same `mem` as the read batch the rows belong to. */
 typedef struct {
-  const int32_t *mtid;   /* [n] aln.mate_chrom tid */
-  const int32_t *mpos;   /* [n] aln.mate_pos */
-  const uint16_t *flag;  /* [n] aln.flag */
-  const uint64_t *qhash; /* [n] 64-bit hash of aln.qname (strl_qname_hash); the Cache is keyed by it */
+  int32_t tid, pos;      /* aln.tid, aln.start */
+  int32_t mtid, mpos;    /* aln.mate_tid, aln.mate_pos */
+  int32_t end;           /* aln.stop */
+  uint16_t flag, l_seq;
+  uint16_t clip_l, clip_r; /* as in strl_read_soa */
+  uint8_t mapq, cig;
+  uint16_t pad;
+} strl_pair_rec;
+typedef struct {
+  const strl_pair_rec *rec; /* [n] */
+  const uint64_t *qhash;    /* [n] 64-bit hash of aln.qname (strl_qname_hash); the Cache is keyed by it */
 } strl_pair_soa;
+/* Host: the rows of a batch from its records and the arrays strl_soa_from_records derived (out[n]). */
+int strl_pair_rows(const strl_records *rec, const int32_t *end, const uint16_t *clip_l, const uint16_t *clip_r, const uint8_t *cig,
+                   strl_pair_rec *out);
 
 /* Host: derive the SoA metadata arrays from BAM-native records (replaces the hts-nim accessors
  * used at extract.nim:30-38,83-87,98-119: cigar ops, aln.stop, clip lengths).  Caller provides the
@@ -227,9 +238,9 @@ int strl_extract_device(strl_ctx *ctx, const strl_read_soa *soa, const strl_pair
  * doAssert repeat_count < 256 (extract.nim:72) would have fired; STRL_ERR_FORMAT: more than 12 records share one qname
  * hash (malformed input -- use the host pair logic, strl_pair_reads). */
 int strl_treads_fetch(strl_ctx *ctx, strl_tread *out, uint64_t cap, uint64_t *n_out, strl_score_stats *stats);
-/* HIP-event times (ms) of the last strl_extract_device call when timing is enabled: mark + probe | join sort | replay |
- * order sort + gather. */
-int strl_ctx_pair_times(strl_ctx *ctx, double ms[4]);
+/* HIP-event times (ms) of the last strl_extract_device call when timing is enabled: soft-clip join items | probe |
+ * join sort | replay | order sort + gather. */
+int strl_ctx_pair_times(strl_ctx *ctx, double ms[5]);
 
 /* Stable LSD radix sort of (key, value) pairs by key bits [bit_lo, bit_lo + bits) on the device (the sort of the
  * clustering and pairing paths: call.nim:127-130 / merge.nim:132-135 `sort` by position inside a (tid, repeat) group

@@ -42,7 +42,12 @@ class CReadSoa(C.Structure):
 
 
 class CPairSoa(C.Structure):
-    _fields_ = [("mtid", C.c_void_p), ("mpos", C.c_void_p), ("flag", C.c_void_p), ("qhash", C.c_void_p)]
+    _fields_ = [("rec", C.c_void_p), ("qhash", C.c_void_p)]
+
+
+PAIR_REC_DTYPE = np.dtype([("tid", "<i4"), ("pos", "<i4"), ("mtid", "<i4"), ("mpos", "<i4"), ("end", "<i4"), ("flag", "<u2"), ("l_seq", "<u2"),
+                           ("clip_l", "<u2"), ("clip_r", "<u2"), ("mapq", "u1"), ("cig", "u1"), ("pad", "<u2")])
+assert PAIR_REC_DTYPE.itemsize == 32
 
 
 class ScoreStats(C.Structure):
@@ -103,7 +108,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
            "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order",
-           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times"]
+           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows"]
 
 
 def lib_path():
@@ -166,10 +171,11 @@ def load(build_if_missing=True):
     L.strl_assign_reads_loci.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
     L.strl_extract_device.argtypes = [C.c_void_p, C.POINTER(CReadSoa), C.POINTER(CPairSoa), C.c_int64, C.c_uint64, C.c_uint64]
     L.strl_treads_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(ScoreStats)]
-    L.strl_ctx_pair_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 4)]
+    L.strl_ctx_pair_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 5)]
     L.strl_cluster_resident.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int, C.c_uint32, C.c_int32, C.c_uint16, C.c_uint16, C.c_uint16,
                                         C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                         C.POINTER(ClusterStats)]
+    L.strl_pair_rows.argtypes = [C.POINTER(CRecords)] + [C.c_void_p] * 5
     L.strl_ctx_cluster_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 3)]
     L.strl_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
     _LIB = L
@@ -235,6 +241,14 @@ class Soa:
                                        self.clip_l.ctypes.data, self.clip_r.ctypes.data, self.cig.ctypes.data, C.byref(mx)))
         self.max_l_seq = mx.value
         self.tid, self.pos, self.mapq, self.seq4 = rv.keep["tid"], rv.keep["pos"], rv.keep["mapq"], rv.keep["seq4"]
+
+    def pair_rows(self):
+        """the 32-byte rows + qname hashes the pair logic reads (strl_pair_rows, strl_qname_hash) -> (rows, qhash)"""
+        rows = np.zeros(max(self.n, 1), PAIR_REC_DTYPE)
+        _check(load().strl_pair_rows(C.byref(self.rv.c), _ptr(self.end), _ptr(self.clip_l), _ptr(self.clip_r), _ptr(self.cig), rows.ctypes.data))
+        qh = np.zeros(max(self.n, 1), np.uint64)
+        _check(load().strl_qname_hash(C.byref(self.rv.c), qh.ctypes.data))
+        return rows[:self.n], qh[:self.n]
 
     def c_struct(self):
         return CReadSoa(self.n, _ptr(self.tid), _ptr(self.pos), _ptr(self.end), _ptr(self.seq_off), _ptr(self.l_seq),
@@ -366,9 +380,9 @@ class Context:
         return out[:no.value], st
 
     def pair_times(self):
-        ms = (C.c_double * 4)()
+        ms = (C.c_double * 5)()
         _check(self.L.strl_ctx_pair_times(self.h, C.byref(ms)))
-        return dict(zip(["pair_mark_probe", "pair_join_sort", "pair_replay", "pair_order"], list(ms)))
+        return dict(zip(["pair_soft_items_kernel", "pair_probe_kernel", "pair_join_sort", "pair_groups_kernel", "pair_order"], list(ms)))
 
     # ---- extract (score + pair) -----------------------------------------------------------------
     def extract(self, rec: RecordBatch, n_tail=-1):

@@ -323,6 +323,18 @@ int strl_soa_from_records(const strl_records *rec, int32_t *end, uint32_t *seq_o
   return STRL_OK;
 }
 
+int strl_pair_rows(const strl_records *rec, const int32_t *end, const uint16_t *clip_l, const uint16_t *clip_r, const uint8_t *cig,
+                   strl_pair_rec *out) {
+  if (!rec || (rec->n && (!end || !clip_l || !clip_r || !cig || !out))) { set_error("null argument"); return STRL_ERR_ARG; }
+  for (int64_t i = 0; i < rec->n; ++i) {
+    strl_pair_rec &o = out[i];
+    o.tid = rec->tid[i]; o.pos = rec->pos[i]; o.mtid = rec->mtid[i]; o.mpos = rec->mpos[i]; o.end = end[i];
+    o.flag = rec->flag[i]; o.l_seq = (uint16_t)rec->l_seq[i]; o.clip_l = clip_l[i]; o.clip_r = clip_r[i];
+    o.mapq = rec->mapq[i]; o.cig = cig[i]; o.pad = 0;
+  }
+  return STRL_OK;
+}
+
 int strl_pair_reads(const strl_records *rec, const strl_opts *opts, const uint32_t *whole, const strl_soft_rec *soft,
                     uint64_t n_soft, int64_t n_tail, strl_tread *out, uint64_t cap, uint64_t *n_out) {
   if (!rec || !opts || (!whole && rec->n) || (!out && cap)) { set_error("null argument"); return STRL_ERR_ARG; }
@@ -539,7 +551,9 @@ int strl_extract(strl_ctx *ctx, const strl_records *rec, int64_t n_tail, strl_tr
   soa.n = n; soa.tid = rec->tid; soa.pos = rec->pos; soa.end = end.data(); soa.seq_off = so.data(); soa.l_seq = ls.data();
   soa.clip_l = cl.data(); soa.clip_r = cr.data(); soa.mapq = rec->mapq; soa.cig = cig.data(); soa.seq4 = rec->seq4;
   soa.seq4_bytes = seq_bytes; soa.max_l_seq = mx; soa.mem = STRL_MEM_HOST;
-  strl_pair_soa pp{rec->mtid, rec->mpos, rec->flag, qh.data()};
+  std::vector<strl_pair_rec> rows(n);
+  if ((rc = strl_pair_rows(rec, end.data(), cl.data(), cr.data(), cig.data(), rows.data()))) return rc;
+  strl_pair_soa pp{rows.data(), qh.data()};
   if (n_tail < 0) { n_tail = 0; while ((size_t)n_tail < n && rec->tid[n - 1 - (size_t)n_tail] < 0) ++n_tail; }
   // scoring + pair logic on the device; capacities first from the defaults, then from the hard bounds
   for (int attempt = 0; attempt < 2; ++attempt) {

@@ -29,15 +29,12 @@
 namespace strl {
 
 constexpr uint16_t F_PROPER = 0x2, F_REVERSE = 0x10, F_MREVERSE = 0x20, F_SECONDARY = 0x100, F_SUPPL = 0x800;
-constexpr int PAIR_MAXM = 12;   // items (reads + hot soft-clip records) of one hash run a lane can replay
-constexpr int PAIR_MAXE = 12;   // treads one run may emit
+constexpr int PAIR_MAXM = 15;   // items (reads + hot soft-clip records) of one hash run a lane can replay
 
 struct PairParams {
   uint32_t n;               // reads of the batch
   uint32_t tail_start;      // first record of the unmapped tail visited a second time (n if none)
-  const int32_t *tid, *pos, *end, *mtid, *mpos;
-  const uint16_t *flag, *l_seq, *clip_l, *clip_r;
-  const uint8_t *mapq, *cig;
+  const strl_pair_rec *rec;    // one 32-byte row per read
   const uint64_t *qhash;
   const uint32_t *whole;
   const strl_soft_rec *soft;
@@ -59,11 +56,11 @@ struct PairParams {
 };
 
 // Soft-clip records with a result under either threshold: mark their read's qname group and make them join items.
-// One queue-space atomic per 8192 records (the same-address atomic rate of the L2 is ~88 per microsecond).
+// One queue-space atomic per 2048 records (the same-address atomic rate of the L2 is ~88 per microsecond).
 __global__ __launch_bounds__(1024) void pair_soft_items_kernel(PairParams P) {
   __shared__ uint32_t wcnt[128];
   __shared__ uint32_t base_sh;
-  constexpr int U = 8;
+  constexpr int U = 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long below = (1ull << lane) - 1ull;
   uint32_t n_src = P.score_cnt[CNT_SOFT];
@@ -111,9 +108,10 @@ __global__ __launch_bounds__(1024) void pair_soft_items_kernel(PairParams P) {
 }
 
 // The one full pass of the pair logic: qname hash of every read against the bitmap.  Each wave owns a contiguous range
-// of reads and stages its hits in LDS; a flush reserves item space with one atomic per ~512 hits (classify_kernel's
-// scheme) and gathers the hashes of the staged reads again.
-constexpr int PR_STAGE = 512, PR_ILP = 8;
+// of reads and stages its hits in LDS; a flush reserves item space with ONE atomic (same-address atomics run at ~88 per
+// microsecond on the L2, so a wave flushes once, at the end, unless its stage fills) and gathers the hashes of the
+// staged reads again.
+constexpr int PR_STAGE = 2048, PR_ILP = 8;
 __global__ __launch_bounds__(256) void pair_probe_kernel(PairParams P) {
   __shared__ uint32_t stage[4][PR_STAGE + 64 * PR_ILP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -152,11 +150,26 @@ __global__ __launch_bounds__(256) void pair_probe_kernel(PairParams P) {
   load(r0, cur);
   for (uint64_t base = r0; base < r1; base += 64 * PR_ILP) {
     load(base + 64 * PR_ILP, nxt);
+    // first bit of all PR_ILP reads (independent loads), then the second bit of the few that passed
+    uint64_t m[PR_ILP];
+    uint32_t w0[PR_ILP];
+#pragma unroll
+    for (int j = 0; j < PR_ILP; ++j) {
+      m[j] = fmix64(cur[j]);
+      w0[j] = P.bloom[((uint32_t)m[j] & P.bloom_mask) >> 5];
+    }
     bool hit[PR_ILP];
 #pragma unroll
     for (int j = 0; j < PR_ILP; ++j) {
       const uint64_t r = base + 64ull * j + lane;
-      hit[j] = r < r1 && bloom_test(P.bloom, P.bloom_mask, fmix64(cur[j]));
+      hit[j] = r < r1 && ((w0[j] >> ((uint32_t)m[j] & 31u)) & 1u);
+    }
+#pragma unroll
+    for (int j = 0; j < PR_ILP; ++j) {
+      if (hit[j]) {
+        const uint32_t b1 = (uint32_t)(m[j] >> 32) & P.bloom_mask;
+        hit[j] = (P.bloom[b1 >> 5] >> (b1 & 31u)) & 1u;
+      }
     }
 #pragma unroll
     for (int j = 0; j < PR_ILP; ++j) {
@@ -243,15 +256,33 @@ __device__ inline bool unplaced_pair(const DTread &A, const DTread &B, const Pai
   return false;
 }
 
-struct Emit {   // what one run emits, buffered until the block reserves output space
-  strl_tread t[PAIR_MAXE];
-  uint64_t key[PAIR_MAXE];
-  int n;
-  bool overflow;
+// One sorted join item with everything the replay needs, gathered by the item's own lane (coalesced over the block) and
+// kept in LDS: the head lane of a run then works out of LDS instead of chasing a dozen arrays per record.
+struct PItem {   // 48 bytes
+  uint64_t key;      // mixed qname hash
+  uint32_t val;      // read index, or 0x80000000 | soft record index
+  int32_t tid, pos, mtid, mpos, end;      // soft record: tid = read_side, pos = res_first, mtid = res_after
+  uint32_t whole;
+  uint16_t flag, clip_l, clip_r, l_seq;
+  uint8_t mapq, cig;
+  uint16_t pad;
 };
-__device__ inline void emit(Emit &E, const DTread &d, uint64_t vidx, uint32_t &seq) {
-  if (E.n >= PAIR_MAXE) { E.overflow = true; return; }
-  strl_tread &t = E.t[E.n];
+static_assert(sizeof(PItem) == 48, "PItem layout");
+
+constexpr int PG_BLOCK = 1024;               // items per block
+constexpr int PG_HALO = 16;                  // a run that starts in the block may reach this far into the next one
+constexpr int PG_EMIT = 1024;                // treads one block may emit (LDS staging)
+
+struct EmitStage {   // block-wide staging of the emitted treads in LDS
+  strl_tread *t;
+  uint64_t *key;
+  uint32_t *count;
+};
+__device__ inline void emit(const EmitStage &E, const DTread &d, uint64_t vidx, uint32_t &seq, uint32_t &err) {
+  const uint32_t slot = atomicAdd(E.count, 1u);
+  const uint32_t k = seq++;
+  if (slot >= (uint32_t)PG_EMIT) { err |= PAIR_ERR_LOCAL; return; }
+  strl_tread t;
   t.tid = d.tid;
   t.position = d.position;
 #pragma unroll
@@ -262,64 +293,63 @@ __device__ inline void emit(Emit &E, const DTread &d, uint64_t vidx, uint32_t &s
   t.repeat_count = d.count;
   t.align_length = d.align_length;
   t.qname_id = (int64_t)d.qid;
-  E.key[E.n] = (vidx << 2) | (uint64_t)(seq & 3u);
-  ++seq;
-  ++E.n;
+  E.t[slot] = t;
+  E.key[slot] = (vidx << 2) | (uint64_t)(k & 3u);
 }
 
 struct GroupCtx {
   const PairParams &P;
-  const uint32_t *vals;   // sorted values of the (sub)group's items
-  int i0, i1;             // [i0, i1) reads then soft records
+  const PItem *it;        // the block's items in LDS
+  uint64_t perm;          // 4-bit indices (relative to `base`) of the run's items sorted by (hash, value)
+  int base, i0, i1;       // perm entries [i0, i1) = this qname group: reads first, then its soft records
   uint32_t *err;
+  __device__ const PItem &item(int j) const { return it[base + (int)((perm >> (4 * j)) & 15u)]; }
 };
 
 // to_tread, extract.nim:63-87, from the packed scorer word and the SoA metadata
-__device__ inline DTread to_tread(const PairParams &P, uint32_t r, uint32_t &err) {
-  const uint32_t w = P.whole[r];
+__device__ inline DTread to_tread(const PItem &x, uint32_t &err) {
+  const uint32_t w = x.whole;
   DTread t;
   t.k = STRL_RES_K(w);
   t.code = STRL_RES_CODE(w);
   const uint32_t cnt = STRL_RES_COUNT(w);
   if (cnt >= 256) err |= PAIR_ERR_ASSERT;   // doAssert extract.nim:72
-  const uint32_t cg = P.cig[r];
+  const uint32_t cg = x.cig;
   // extract.nim:33 / :38: the M length of a skipped read (clip_l carries it for single-M cigars), else len(read)
-  const uint32_t al = (w & STRL_RES_SKIPPED) ? (uint32_t)P.clip_l[r] : (uint32_t)P.l_seq[r];
-  t.tid = P.tid[r];
-  const int32_t ps = P.pos[r];
-  t.position = (uint32_t)(ps > 0 ? ps : 0);
-  t.flag = P.flag[r];
+  const uint32_t al = (w & STRL_RES_SKIPPED) ? (uint32_t)x.clip_l : (uint32_t)x.l_seq;
+  t.tid = x.tid;
+  t.position = (uint32_t)(x.pos > 0 ? x.pos : 0);
+  t.flag = x.flag;
   t.count = (uint8_t)cnt;
   t.align_length = (uint8_t)al;
   t.split = STRL_SOFT_NONE;
-  t.mapq = P.mapq[r];
-  t.qid = r;
+  t.mapq = x.mapq;
+  t.qid = x.val;
   const bool multi = !(cg & (STRL_CIG_ONE_OP | STRL_CIG_NONE));
-  if (multi && (cg & STRL_CIG_FIRST_S) && P.clip_l[r] > 16) t.split = STRL_SOFT_NONE_LEFT;
-  if (multi && (cg & STRL_CIG_LAST_S) && P.clip_r[r] > 16) t.split = STRL_SOFT_NONE_RIGHT;
+  if (multi && (cg & STRL_CIG_FIRST_S) && x.clip_l > 16) t.split = STRL_SOFT_NONE_LEFT;
+  if (multi && (cg & STRL_CIG_LAST_S) && x.clip_r > 16) t.split = STRL_SOFT_NONE_RIGHT;
   return t;
 }
 
 // add_soft, extract.nim:93-132, consuming the soft-clip records that joined the group (records without a result
 // under either threshold never joined: they could only `continue` at :117)
-__device__ inline void add_soft(const GroupCtx &G, uint32_t r, bool first_seen, uint32_t read_k, Emit &E, uint64_t vidx, uint32_t &seq) {
+__device__ inline void add_soft(const GroupCtx &G, const PItem &x, bool first_seen, uint32_t read_k, const EmitStage &E, uint64_t vidx, uint32_t &seq) {
   const PairParams &P = G.P;
-  if (P.mapq[r] < P.min_mapq) return;
-  const uint32_t cg = P.cig[r];
+  if (x.mapq < P.min_mapq) return;
+  const uint32_t cg = x.cig;
   if ((cg & STRL_CIG_NONE) || !(cg & (STRL_CIG_FIRST_S | STRL_CIG_LAST_S))) return;
   for (int q = 0; q < 2; ++q) {
     // cig_index in [0, L-1]: with a single op both iterations look at op 0
     const int side = (q == 0 || (cg & STRL_CIG_ONE_OP)) ? 0 : 1;
     if (!(cg & (side == 0 ? STRL_CIG_FIRST_S : STRL_CIG_LAST_S))) continue;
-    const uint32_t clen = side == 0 ? P.clip_l[r] : P.clip_r[r];
+    const uint32_t clen = side == 0 ? x.clip_l : x.clip_r;
     if (read_k == 0 && clen <= 16) continue;
     uint32_t w = 0;
-    const uint32_t want = (r << 1) | (uint32_t)side;
+    const uint32_t want = (x.val << 1) | (uint32_t)side;
     for (int j = G.i0; j < G.i1; ++j) {
-      const uint32_t v = G.vals[j];
-      if (!(v & 0x80000000u)) continue;
-      const strl_soft_rec s = P.soft[v & 0x7fffffffu];
-      if (s.read_side == want) { w = first_seen ? s.res_first : s.res_after; break; }
+      const PItem &s = G.item(j);
+      if (!(s.val & 0x80000000u)) continue;
+      if ((uint32_t)s.tid == want) { w = first_seen ? (uint32_t)s.pos : (uint32_t)s.mtid; break; }
     }
     const uint32_t cnt = STRL_RES_COUNT(w);
     if (cnt == 0) continue;
@@ -327,34 +357,32 @@ __device__ inline void add_soft(const GroupCtx &G, uint32_t r, bool first_seen, 
     DTread t;
     t.k = STRL_RES_K(w);
     t.code = STRL_RES_CODE(w);
-    t.tid = P.tid[r];
-    const int32_t p = side == 0 ? P.pos[r] : P.end[r];
+    t.tid = x.tid;
+    const int32_t p = side == 0 ? x.pos : x.end;
     t.position = (uint32_t)(p > 0 ? p : 0);
-    t.flag = P.flag[r];
+    t.flag = x.flag;
     t.count = (uint8_t)cnt;
     t.align_length = (uint8_t)clen;
     t.split = side == 0 ? STRL_SOFT_LEFT : STRL_SOFT_RIGHT;
-    t.mapq = P.mapq[r];
-    t.qid = r;
+    t.mapq = x.mapq;
+    t.qid = x.val;
     if (p_repeat(t) < 0.9) continue;
-    emit(E, t, vidx, seq);
+    emit(E, t, vidx, seq, *G.err);
   }
 }
 
-// Cache.add, extract.nim:192-248, for record r of the group
-__device__ inline void cache_add(const GroupCtx &G, uint32_t r, uint64_t vidx, bool &stored, DTread &S, Emit &E) {
+// Cache.add, extract.nim:192-248, for one record of the group
+__device__ inline void cache_add(const GroupCtx &G, const PItem &x, uint64_t vidx, bool &stored, DTread &S, const EmitStage &E) {
   const PairParams &P = G.P;
-  const uint16_t fl = P.flag[r];
-  if (fl & (F_SECONDARY | F_SUPPL)) return;   // extract.nim:309,327
-  const int32_t tid = P.tid[r], mtid = P.mtid[r], start = P.pos[r], mpos = P.mpos[r];
-  const bool after_mate = tid > mtid || (tid == mtid && (start > mpos || (start == mpos && stored)));
+  if (x.flag & (F_SECONDARY | F_SUPPL)) return;   // extract.nim:309,327
+  const bool after_mate = x.tid > x.mtid || (x.tid == x.mtid && (x.pos > x.mpos || (x.pos == x.mpos && stored)));
   uint32_t seq = 0;
   if (after_mate) {
     if (!stored) return;
     DTread mate = S;
     stored = false;
-    DTread self = to_tread(P, r, *G.err);
-    add_soft(G, r, false, self.k, E, vidx, seq);
+    DTread self = to_tread(x, *G.err);
+    add_soft(G, x, false, self.k, E, vidx, seq);
     if (mate.count == 0 && self.count == 0) return;
     if (unplaced_pair(self, mate, P)) {
       if (self.k == 0 || mate.k == 0) return;
@@ -364,97 +392,130 @@ __device__ inline void cache_add(const GroupCtx &G, uint32_t r, uint64_t vidx, b
       mate.code = canonical_repeat(mate.code, mate.k);
       mate.position = 0;
       mate.tid = -1;
-      emit(E, self, vidx, seq);
-      emit(E, mate, vidx, seq);
+      emit(E, self, vidx, seq, *G.err);
+      emit(E, mate, vidx, seq, *G.err);
       return;
     }
     const uint32_t mp = mate.position;
-    if (adjust_by(mate, self, P, self.position)) emit(E, mate, vidx, seq);
-    if (adjust_by(self, mate, P, mp)) emit(E, self, vidx, seq);
+    if (adjust_by(mate, self, P, self.position)) emit(E, mate, vidx, seq, *G.err);
+    if (adjust_by(self, mate, P, mp)) emit(E, self, vidx, seq, *G.err);
   } else {
-    const DTread tr = to_tread(P, r, *G.err);
-    add_soft(G, r, true, tr.k, E, vidx, seq);
+    const DTread tr = to_tread(x, *G.err);
+    add_soft(G, x, true, tr.k, E, vidx, seq);
     if (stored) stored = false;   // hasKeyOrPut hit: warn + take, the new tread is not stored (:245-248)
     else { S = tr; stored = true; }
   }
 }
 
-// One lane per run of items with equal low 32 hash bits (the sorted key); lanes that do not start a run idle.
-__global__ __launch_bounds__(1024) void pair_groups_kernel(PairParams P) {
-  __shared__ uint32_t wtot[16];
-  __shared__ uint32_t base_sh;
+// A block takes 1024 consecutive sorted items.  Phase 1: every lane gathers the metadata of ITS item into LDS (all
+// gathers of the block in flight together).  Phase 2: the lane of the first item of a run (equal low 32 hash bits)
+// replays Cache.add for the run out of LDS; emitted treads are staged in LDS.  Phase 3: one atomic reserves the block's
+// output space, all lanes copy the staging area out.
+__global__ __launch_bounds__(PG_BLOCK) void pair_groups_kernel(PairParams P) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t pg_lds[];
+  PItem *items = reinterpret_cast<PItem *>(pg_lds);
+  strl_tread *st_t = reinterpret_cast<strl_tread *>(pg_lds + sizeof(PItem) * (PG_BLOCK + PG_HALO));
+  uint64_t *st_k = reinterpret_cast<uint64_t *>(st_t + PG_EMIT);
+  uint32_t *sh = reinterpret_cast<uint32_t *>(st_k + PG_EMIT);   // [0] emitted count, [1] output base
   uint32_t n_items = P.pc[PC_ITEMS];
   if (n_items > P.item_cap) n_items = P.item_cap;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t b0 = blockIdx.x * 1024u; b0 < n_items; b0 += gridDim.x * 1024u) {
+  const EmitStage E{st_t, st_k, sh};
+  for (uint32_t b0 = blockIdx.x * (uint32_t)PG_BLOCK; b0 < n_items; b0 += gridDim.x * (uint32_t)PG_BLOCK) {
+    if (threadIdx.x == 0) sh[0] = 0;
+    // ---- phase 1: gather ----
+    for (uint32_t l = threadIdx.x; l < (uint32_t)(PG_BLOCK + PG_HALO); l += PG_BLOCK) {
+      const uint32_t i = b0 + l;
+      PItem x{};
+      x.key = ~0ull;
+      if (i < n_items) {
+        x.key = P.item_key[i];
+        x.val = P.item_val[i];
+        if (x.val & 0x80000000u) {
+          const strl_soft_rec s = P.soft[x.val & 0x7fffffffu];
+          x.tid = (int32_t)s.read_side; x.pos = (int32_t)s.res_first; x.mtid = (int32_t)s.res_after;
+        } else {
+          const uint32_t r = x.val;
+          const uint4 *rp = reinterpret_cast<const uint4 *>(P.rec + r);
+          union { uint4 q[2]; strl_pair_rec o; } u;
+          u.q[0] = rp[0];
+          u.q[1] = rp[1];
+          x.tid = u.o.tid; x.pos = u.o.pos; x.mtid = u.o.mtid; x.mpos = u.o.mpos; x.end = u.o.end;
+          x.whole = P.whole[r]; x.flag = u.o.flag; x.clip_l = u.o.clip_l; x.clip_r = u.o.clip_r; x.l_seq = u.o.l_seq;
+          x.mapq = u.o.mapq; x.cig = u.o.cig;
+        }
+      }
+      items[l] = x;
+    }
+    __syncthreads();
+    // ---- phase 2: replay ----
     const uint32_t i = b0 + threadIdx.x;
-    Emit E;
-    E.n = 0;
-    E.overflow = false;
     uint32_t err = 0;
     if (i < n_items) {
-      const uint32_t lo = (uint32_t)P.item_key[i];
-      const bool head = i == 0 || (uint32_t)P.item_key[i - 1] != lo;
+      const int me = (int)threadIdx.x;
+      const uint32_t lo = (uint32_t)items[me].key;
+      const bool head = i == 0 || (me > 0 ? (uint32_t)items[me - 1].key : (uint32_t)P.item_key[i - 1]) != lo;
       if (head) {
-        uint64_t hk[PAIR_MAXM];
-        uint32_t hv[PAIR_MAXM];
+        // the run, as a permutation sorted by (hash, value): reads (ascending record index) before the soft-clip
+        // records of the same hash
+        uint64_t perm = 0;
         int m = 0;
         bool too_long = false;
-        for (uint32_t j = i; j < n_items; ++j) {
-          const uint64_t k = P.item_key[j];
-          if ((uint32_t)k != lo) break;
+        for (int j = me; j < PG_BLOCK + PG_HALO && b0 + (uint32_t)j < n_items; ++j) {
+          if ((uint32_t)items[j].key != lo) break;
           if (m == PAIR_MAXM) { too_long = true; break; }
-          // insertion by (hash, value): reads (ascending record index) before the soft-clip records of the same hash
-          const uint32_t v = P.item_val[j];
+          const uint64_t k = items[j].key;
+          const uint32_t v = items[j].val;
           int q = m;
-          while (q > 0 && (hk[q - 1] > k || (hk[q - 1] == k && hv[q - 1] > v))) { hk[q] = hk[q - 1]; hv[q] = hv[q - 1]; --q; }
-          hk[q] = k; hv[q] = v;
+          while (q > 0) {
+            const PItem &o = items[me + (int)((perm >> (4 * (q - 1))) & 15u)];
+            if (o.key > k || (o.key == k && o.val > v)) --q; else break;
+          }
+          const uint64_t lowmask = (1ull << (4 * q)) - 1ull;
+          perm = (perm & lowmask) | ((uint64_t)(j - me) << (4 * q)) | ((perm & ~lowmask) << 4);
           ++m;
         }
         if (too_long) err |= PAIR_ERR_RUN;
         else {
+          GroupCtx G{P, items, perm, me, 0, 0, &err};
           int a = 0;
           while (a < m) {
             int b = a + 1;
-            while (b < m && hk[b] == hk[a]) ++b;
-            GroupCtx G{P, hv, a, b, &err};
+            while (b < m && G.item(b).key == G.item(a).key) ++b;
+            G.i0 = a; G.i1 = b;
             bool stored = false;
             DTread S{};
             for (int j = a; j < b; ++j) {            // extract.nim:308-322
-              if (hv[j] & 0x80000000u) break;
-              cache_add(G, hv[j], (uint64_t)hv[j], stored, S, E);
+              const PItem &x = G.item(j);
+              if (x.val & 0x80000000u) break;
+              cache_add(G, x, (uint64_t)x.val, stored, S, E);
             }
             for (int j = a; j < b; ++j) {            // extract.nim:326-329: the unmapped tail once more
-              if (hv[j] & 0x80000000u) break;
-              if (hv[j] >= P.tail_start) cache_add(G, hv[j], (uint64_t)P.n + (uint64_t)(hv[j] - P.tail_start), stored, S, E);
+              const PItem &x = G.item(j);
+              if (x.val & 0x80000000u) break;
+              if (x.val >= P.tail_start) cache_add(G, x, (uint64_t)P.n + (uint64_t)(x.val - P.tail_start), stored, S, E);
             }
             a = b;
           }
         }
       }
     }
-    if (E.overflow) err |= PAIR_ERR_LOCAL;
     if (err) atomicOr(&P.pc[PC_ERR], err);
-    // block-wide reservation of output space: one atomic per 1024 items
-    uint32_t inc = (uint32_t)E.n;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(inc, d);
-      if (lane >= d) inc += o;
-    }
-    if (lane == 63) wtot[wave] = inc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t tot = 0;
-      for (int w = 0; w < 16; ++w) { const uint32_t c = wtot[w]; wtot[w] = tot; tot += c; }
-      base_sh = tot ? atomicAdd(&P.pc[PC_EMIT], tot) : 0u;
-    }
+    // ---- phase 3: write the block's treads ----
+    uint32_t ne = sh[0];
+    if (ne > (uint32_t)PG_EMIT) ne = PG_EMIT;
+    if (threadIdx.x == 0) sh[1] = ne ? atomicAdd(&P.pc[PC_EMIT], ne) : 0u;
     __syncthreads();
-    const uint32_t at = base_sh + wtot[wave] + inc - (uint32_t)E.n;
-    for (int e = 0; e < E.n; ++e) {
-      const uint32_t d = at + (uint32_t)e;
-      if (d < P.emit_cap) { P.emit[d] = E.t[e]; P.emit_key[d] = E.key[e]; P.emit_val[d] = d; }
-      else atomicOr(&P.pc[PC_ERR], PAIR_ERR_EMIT);
+    const uint32_t base = sh[1];
+    for (uint32_t e = threadIdx.x; e < ne; e += PG_BLOCK) {
+      const uint32_t d = base + e;
+      if (d < P.emit_cap) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(st_t + e);
+        uint4 *dst = reinterpret_cast<uint4 *>(P.emit + d);
+        dst[0] = src[0]; dst[1] = src[1];
+        P.emit_key[d] = st_k[e];
+        P.emit_val[d] = d;
+      } else atomicOr(&P.pc[PC_ERR], PAIR_ERR_EMIT);
     }
     __syncthreads();
   }
@@ -501,8 +562,7 @@ int strl_pair_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *p
   PairParams P{};
   P.n = (uint32_t)n;
   P.tail_start = (uint32_t)(n - (uint64_t)n_tail);
-  P.tid = s->tid; P.pos = s->pos; P.end = s->end; P.mtid = pp->mtid; P.mpos = pp->mpos; P.flag = pp->flag;
-  P.l_seq = s->l_seq; P.clip_l = s->clip_l; P.clip_r = s->clip_r; P.mapq = s->mapq; P.cig = s->cig; P.qhash = pp->qhash;
+  P.rec = pp->rec; P.qhash = pp->qhash;
   P.whole = whole; P.soft = soft; P.score_cnt = c->counters.as<uint32_t>();
   P.scap = (uint32_t)std::max<uint64_t>(std::min<uint64_t>(soft_cap, 2 * n), 1);
   P.bloom = c->bloom.as<uint32_t>(); P.bloom_mask = c->bloom_mask;
@@ -513,19 +573,21 @@ int strl_pair_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *p
   hipEvent_t *ev = c->timing ? c->pev : nullptr;
   if (ev) STRL_HIP(hipEventRecord(ev[0], st));
   if (n) {
-    hipLaunchKernelGGL(pair_soft_items_kernel, dim3(256), dim3(1024), 0, st, P);
-    const int pblocks = (int)std::min<uint64_t>((n + 2047) / 2048, 2048);
+    hipLaunchKernelGGL(pair_soft_items_kernel, dim3(512), dim3(1024), 0, st, P);
+    if (ev) STRL_HIP(hipEventRecord(ev[1], st));
+    const int pblocks = (int)std::min<uint64_t>((n + 2047) / 2048, 512);
     hipLaunchKernelGGL(pair_probe_kernel, dim3(pblocks), dim3(256), 0, st, P);
     STRL_HIP(hipGetLastError());
   }
-  if (ev) STRL_HIP(hipEventRecord(ev[1], st));
+  else if (ev) STRL_HIP(hipEventRecord(ev[1], st));
+  if (ev) STRL_HIP(hipEventRecord(ev[2], st));
   // join: sort the items by the low 32 bits of the (mixed) hash; runs are disambiguated by the full hash in the replay
   uint64_t *ik = nullptr;
   uint32_t *iv = nullptr;
   int e = radix_sort_pairs(st, P.pc + PC_ITEMS, icap, c->p_key0.as<uint64_t>(), c->p_val0.as<uint32_t>(), c->p_key1.as<uint64_t>(),
                            c->p_val1.as<uint32_t>(), c->sort_scratch.p, c->sort_scratch.cap, 0, 32, &ik, &iv);
   if (e) { set_error("radix_sort_pairs failed: %s", hipGetErrorString((hipError_t)e)); return STRL_ERR_HIP; }
-  if (ev) STRL_HIP(hipEventRecord(ev[2], st));
+  if (ev) STRL_HIP(hipEventRecord(ev[3], st));
   // the sorted items sit in (ik, iv); the emission keys go to the other pair of buffers
   P.item_key = ik; P.item_val = iv;
   const bool in0 = ik == c->p_key0.as<uint64_t>();
@@ -533,10 +595,16 @@ int strl_pair_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *p
   uint32_t *evl = in0 ? c->p_val1.as<uint32_t>() : c->p_val0.as<uint32_t>();
   P.emit_key = ek; P.emit_val = evl;
   if (n) {
-    hipLaunchKernelGGL(pair_groups_kernel, dim3((unsigned)std::min<uint32_t>((icap + 1023) / 1024, 4096)), dim3(1024), 0, st, P);
+    const size_t pg_shmem = sizeof(PItem) * (PG_BLOCK + PG_HALO) + (sizeof(strl_tread) + 8) * PG_EMIT + 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+      STRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_groups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_shmem));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(pair_groups_kernel, dim3((unsigned)std::min<uint32_t>((icap + PG_BLOCK - 1) / PG_BLOCK, 4096)), dim3(PG_BLOCK), pg_shmem, st, P);
     STRL_HIP(hipGetLastError());
   }
-  if (ev) STRL_HIP(hipEventRecord(ev[3], st));
+  if (ev) STRL_HIP(hipEventRecord(ev[4], st));
   // the items are consumed: their buffers are the sort's second pair now
   uint64_t *ok = nullptr;
   uint32_t *ov = nullptr;
@@ -545,7 +613,7 @@ int strl_pair_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *p
   c->n_treads_dev = reinterpret_cast<uint32_t *>(c->treads.as<uint8_t>() + (size_t)ecap * sizeof(strl_tread));
   hipLaunchKernelGGL(pair_order_kernel, dim3((ecap + 255) / 256), dim3(256), 0, st, P.pc, ecap, P.emit, ov, c->treads.as<strl_tread>(), c->n_treads_dev);
   STRL_HIP(hipGetLastError());
-  if (ev) STRL_HIP(hipEventRecord(ev[4], st));
+  if (ev) STRL_HIP(hipEventRecord(ev[5], st));
   c->tread_cap = ecap;
   c->pair_item_cap = icap;
   return STRL_OK;

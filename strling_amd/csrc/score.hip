@@ -921,8 +921,8 @@ static int stage_batch(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa 
   d->mem = STRL_MEM_DEVICE;
   if (pp) {
     struct { strl::DevBuf *b; const void *src; size_t bytes; const void **dst; } cq[] = {
-        {&c->st_mtid, pp->mtid, (size_t)n * 4, (const void **)&dpp->mtid}, {&c->st_mpos, pp->mpos, (size_t)n * 4, (const void **)&dpp->mpos},
-        {&c->st_flag, pp->flag, (size_t)n * 2, (const void **)&dpp->flag}, {&c->st_qhash, pp->qhash, (size_t)n * 8, (const void **)&dpp->qhash}};
+        {&c->st_mtid, pp->rec, (size_t)n * sizeof(strl_pair_rec), (const void **)&dpp->rec},
+        {&c->st_qhash, pp->qhash, (size_t)n * 8, (const void **)&dpp->qhash}};
     for (auto &x : cq) {
       if ((rc = x.b->reserve(std::max<size_t>(x.bytes, 64)))) return rc;
       if (x.bytes) STRL_HIP(hipMemcpyAsync(x.b->p, x.src, x.bytes, hipMemcpyHostToDevice, c->stream));
@@ -1005,7 +1005,7 @@ int strl_score_reads(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, strl_
 int strl_extract_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *pp, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap) {
   if (!c || !s || !pp) { set_error("null argument"); return STRL_ERR_ARG; }
   if (!c->have_opts) { set_error("strl_ctx_set_opts must be called before scoring"); return STRL_ERR_ARG; }
-  if (s->n && (!pp->mtid || !pp->mpos || !pp->flag || !pp->qhash)) { set_error("strl_extract_device: incomplete strl_pair_soa"); return STRL_ERR_ARG; }
+  if (s->n && (!pp->rec || !pp->qhash)) { set_error("strl_extract_device: incomplete strl_pair_soa"); return STRL_ERR_ARG; }
   STRL_HIP(hipSetDevice(c->device));
   const uint64_t n = s->n;
   if (n_tail < 0 || (uint64_t)n_tail > n) { set_error("strl_extract_device: n_tail must be in [0, n]"); return STRL_ERR_ARG; }
@@ -1053,11 +1053,11 @@ int strl_treads_fetch(strl_ctx *c, strl_tread *out, uint64_t cap, uint64_t *n_ou
   return STRL_OK;
 }
 
-int strl_ctx_pair_times(strl_ctx *c, double ms[4]) {
+int strl_ctx_pair_times(strl_ctx *c, double ms[5]) {
   if (!c || !ms) return STRL_ERR_ARG;
   STRL_HIP(hipSetDevice(c->device));
   STRL_HIP(hipStreamSynchronize(c->stream));
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < 5; ++k) {
     float f = 0.f;
     if (c->timing) (void)hipEventElapsedTime(&f, c->pev[k], c->pev[k + 1]);
     ms[k] = f;

@@ -14,8 +14,7 @@ namespace strl {
 constexpr uint32_t SORT_THREADS = 256;                       // 4 waves per tile
 constexpr uint32_t SORT_KPT = 8;                             // keys per thread
 constexpr uint32_t SORT_TILE = SORT_THREADS * SORT_KPT;      // 2048 keys per tile
-constexpr uint32_t SORT_CHUNK = 256;                         // tiles per chunk (one chunk: offsets are summed inside the scatter launch)
-constexpr uint32_t SORT_ATOMIC_HIST_MAX = 1u << 21;          // below: the scatter of pass p builds pass p+1's tile histograms with atomics
+constexpr uint32_t SORT_CHUNK = 32;                          // tiles per chunk of the two-level histogram tables
 
 // bytes of scratch radix_sort_pairs needs for n_max elements and `bits` key bits
 size_t radix_sort_scratch_bytes(uint32_t n_max, int bits);

@@ -10,12 +10,13 @@
 //   * In-tile stable ranking without sorting: per round every lane finds the lanes of its wave that hold the same digit
 //     with 8 ballots ("match"), the lowest such lane bumps the wave's private LDS counter once for the whole peer
 //     group, ranks follow from popcounts.  Waves own disjoint LDS rows, so no cross-wave atomics.
-//   * No scan kernel: the per-tile digit histograms H[tile][256] are tile-major (a 1 KiB row per tile); a tile obtains
-//     "keys with my digit in earlier tiles" by summing the rows before it (each wave reads whole rows with one
-//     16-byte load per lane) and the digit bases from the column totals -- up to 256 tiles (512 Ki keys) inside the
-//     same launch.  Beyond that a two-level variant adds a chunk-sum and a chunk-scan launch per pass.
-//   * No histogram kernel after the first pass (up to 2 Mi keys): while scattering pass p, every key also bumps
-//     H_{p+1}[destination tile][next digit] with a fire-and-forget atomic (distinct addresses, no return value).
+//   * No scan kernel: the digit histograms are kept per tile, H[tile][256], and per chunk of 32 tiles, C[chunk][256]
+//     (1 KiB rows).  A tile obtains "keys with my digit in earlier tiles" by summing the chunk rows before its chunk
+//     and the tile rows of its own chunk before it, and the digit bases from the totals of all chunk rows -- each wave
+//     reads whole rows with one 16-byte load per lane, 8 loads in flight: (tiles / 32 + 31) rows at most.
+//     The histogram kernel of a pass writes its tile row and adds it to its chunk row (256 uncontended atomics per
+//     tile).  Building the next pass' tables with per-key atomics while scattering was tried: skewed digits put
+//     thousands of atomics on one address (~88 per microsecond on the L2): 0.23 ms per pass instead of 0.02.
 //   * The element count is read from device memory, so sorts can be enqueued behind the kernels that produce their
 //     input without a host round trip.
 //
@@ -35,10 +36,9 @@ struct SortPass {
   uint64_t *kout;
   uint32_t *vout;
   uint32_t *H;    // [tiles][256] digit histogram of every tile of the INPUT order of this pass
-  uint32_t *Hn;   // the same for the next pass (built here with atomics), or nullptr
-  uint32_t *C;    // [chunks][256] two-level offsets (only when more than one chunk is active)
-  int shift, shift_n;
-  uint32_t mask, mask_n;
+  uint32_t *C;    // [chunks][256] the same per chunk of SORT_CHUNK tiles
+  int shift;
+  uint32_t mask;
 };
 
 __device__ __forceinline__ uint32_t active_n(const SortPass &a) {
@@ -46,6 +46,7 @@ __device__ __forceinline__ uint32_t active_n(const SortPass &a) {
   return n < a.n_max ? n : a.n_max;
 }
 
+// tile + chunk histograms of the input order of a pass
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(SortPass a) {
   __shared__ uint32_t bins[256];
   const uint32_t n = active_n(a);
@@ -59,7 +60,9 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(SortPass a) {
     if (e < n) atomicAdd(&bins[(uint32_t)(a.kin[e] >> a.shift) & a.mask], 1u);
   }
   __syncthreads();
-  a.H[(uint64_t)t * 256 + threadIdx.x] = bins[threadIdx.x];
+  const uint32_t c = bins[threadIdx.x];
+  a.H[(uint64_t)t * 256 + threadIdx.x] = c;
+  if (c) __hip_atomic_fetch_add(&a.C[(uint64_t)(t / SORT_CHUNK) * 256 + threadIdx.x], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // exclusive scan of one value per thread over the 256 threads of a block (digit bases)
@@ -79,16 +82,14 @@ __device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t *wsu
   return base + inc - v;
 }
 
-// column sums of the histogram rows [lo, hi): wave q takes rows lo + q, lo + q + 4, ...; lane l the digits 4l .. 4l+3.
-// `below` only accumulates rows < t.
-__device__ __forceinline__ void row_sums(const uint32_t *H, uint32_t lo, uint32_t hi, uint32_t t, uint4 &tot, uint4 &below) {
+// column sums of the 1 KiB rows [lo, hi) of a table: wave q takes rows lo + q, lo + q + 4, ...; lane l the digits
+// 4l .. 4l+3.  `below` only accumulates rows < cut.
+__device__ __forceinline__ void row_sums(const uint32_t *T, uint32_t lo, uint32_t hi, uint32_t cut, uint4 &tot, uint4 &below) {
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const uint4 *R = reinterpret_cast<const uint4 *>(H);
-  tot = make_uint4(0, 0, 0, 0);
-  below = make_uint4(0, 0, 0, 0);
+  const uint4 *R = reinterpret_cast<const uint4 *>(T);
   auto acc = [&](const uint4 &h, uint32_t row) {
     tot.x += h.x; tot.y += h.y; tot.z += h.z; tot.w += h.w;
-    if (row < t) { below.x += h.x; below.y += h.y; below.z += h.z; below.w += h.w; }
+    if (row < cut) { below.x += h.x; below.y += h.y; below.z += h.z; below.w += h.w; }
   };
   uint32_t r = lo + (uint32_t)q;
   for (; r + 28 < hi; r += 32) {   // 8 independent 16-byte loads in flight per lane
@@ -99,44 +100,6 @@ __device__ __forceinline__ void row_sums(const uint32_t *H, uint32_t lo, uint32_
     for (int u = 0; u < 8; ++u) acc(h[u], r + 4 * u);
   }
   for (; r < hi; r += 4) acc(R[(uint64_t)r * 64 + lane], r);
-}
-
-// two-level offsets, first level: C[c][d] = sum of the rows of chunk c
-__global__ __launch_bounds__(SORT_THREADS) void sort_chunk_sum_kernel(SortPass a) {
-  __shared__ uint4 part[4][64];
-  const uint32_t n = active_n(a);
-  const uint32_t ntiles = (n + SORT_TILE - 1) / SORT_TILE, nchunks = (ntiles + SORT_CHUNK - 1) / SORT_CHUNK;
-  const uint32_t c = blockIdx.x;
-  if (nchunks <= 1 || c >= nchunks) return;
-  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const uint32_t lo = c * SORT_CHUNK, hi = lo + SORT_CHUNK < ntiles ? lo + SORT_CHUNK : ntiles;
-  uint4 tot, below;
-  row_sums(a.H, lo, hi, 0u, tot, below);
-  part[q][lane] = tot;
-  __syncthreads();
-  if (q == 0) {
-    uint4 s = part[0][lane];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) { const uint4 o = part[w][lane]; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
-    reinterpret_cast<uint4 *>(a.C)[(uint64_t)c * 64 + lane] = s;
-  }
-}
-
-// second level: C[c][d] <- digit base of d + keys with digit d in the chunks before c
-__global__ __launch_bounds__(SORT_THREADS) void sort_chunk_scan_kernel(SortPass a) {
-  __shared__ uint32_t wsum[4];
-  const uint32_t n = active_n(a);
-  const uint32_t ntiles = (n + SORT_TILE - 1) / SORT_TILE, nchunks = (ntiles + SORT_CHUNK - 1) / SORT_CHUNK;
-  if (nchunks <= 1) return;
-  const uint32_t d = threadIdx.x;
-  uint32_t run = 0;
-  for (uint32_t c = 0; c < nchunks; ++c) {
-    const uint32_t v = a.C[(uint64_t)c * 256 + d];
-    a.C[(uint64_t)c * 256 + d] = run;
-    run += v;
-  }
-  const uint32_t base = block_excl_scan256(run, wsum);
-  for (uint32_t c = 0; c < nchunks; ++c) a.C[(uint64_t)c * 256 + d] += base;
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(SortPass a) {
@@ -163,12 +126,14 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(SortPass a) 
 #pragma unroll
   for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
 
-  // ---- where digit d of this tile starts in the output: digit base + same digit in earlier tiles ----
+  // ---- where digit d of this tile starts in the output: digit base + same digit in earlier tiles.
+  // Two levels, both summed here: the chunk table (every chunk: totals; chunks before mine: below) and the tile rows
+  // of my own chunk before me.
   {
     const uint32_t c = t / SORT_CHUNK;
-    const bool one = nchunks <= 1;
-    uint4 tot, below;
-    row_sums(a.H, one ? 0u : c * SORT_CHUNK, one ? ntiles : t, t, tot, below);
+    uint4 tot = make_uint4(0, 0, 0, 0), below = make_uint4(0, 0, 0, 0), dummy = make_uint4(0, 0, 0, 0);
+    row_sums(a.C, 0u, nchunks, c, tot, below);
+    row_sums(a.H, c * SORT_CHUNK, t, t, dummy, below);
     pb[wave][lane] = below;
     pt[wave][lane] = tot;
   }
@@ -180,8 +145,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(SortPass a) 
     uint32_t below = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) { below += b[w * 256 + d]; tot += tt[w * 256 + d]; }
-    if (nchunks <= 1) off = block_excl_scan256(tot, wsum) + below;
-    else off = a.C[(uint64_t)(t / SORT_CHUNK) * 256 + d] + below;
+    off = block_excl_scan256(tot, wsum) + below;
   }
 
   // ---- stable rank inside the wave: match lanes with the same digit, one LDS add per (round, digit) ----
@@ -218,10 +182,6 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(SortPass a) 
       const uint32_t p = cnt[wave][d] + rank[r];
       a.kout[p] = key[r];
       a.vout[p] = val[r];
-      if (a.Hn) {
-        const uint32_t dn = (uint32_t)(key[r] >> a.shift_n) & a.mask_n;
-        __hip_atomic_fetch_add(&a.Hn[(uint64_t)(p / SORT_TILE) * 256 + dn], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
     }
   }
 }
@@ -233,7 +193,7 @@ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 size_t radix_sort_scratch_bytes(uint32_t n_max, int bits) {
   const uint32_t P = (uint32_t)(bits + 7) / 8;
   const uint32_t ntiles = div_up(n_max ? n_max : 1, SORT_TILE), nchunks = div_up(ntiles, SORT_CHUNK);
-  return ((size_t)(P ? P : 1) * ntiles + nchunks) * 1024 + 256;
+  return (size_t)(P ? P : 1) * ((size_t)ntiles + nchunks) * 1024 + 256;
 }
 
 int radix_sort_pairs(hipStream_t st, const uint32_t *d_n, uint32_t n_max, uint64_t *keys, uint32_t *vals, uint64_t *keys_alt,
@@ -245,31 +205,24 @@ int radix_sort_pairs(hipStream_t st, const uint32_t *d_n, uint32_t n_max, uint64
   if (scratch_bytes < radix_sort_scratch_bytes(n_max, bits)) return (int)hipErrorInvalidValue;
   const uint32_t P = (uint32_t)(bits + 7) / 8;
   const uint32_t ntiles = div_up(n_max, SORT_TILE), nchunks = div_up(ntiles, SORT_CHUNK);
-  uint32_t *H = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(scratch) + 255) & ~(uintptr_t)255);
-  const size_t hwords = (size_t)ntiles * 256;
-  uint32_t *C = H + (size_t)P * hwords;
-  const bool atomic_hist = n_max <= SORT_ATOMIC_HIST_MAX;
+  // scratch: chunk tables of all passes, then tile tables of all passes
+  uint32_t *C = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(scratch) + 255) & ~(uintptr_t)255);
+  const size_t cwords = (size_t)nchunks * 256, hwords = (size_t)ntiles * 256;
+  uint32_t *H = C + (size_t)P * cwords;
   hipError_t e;
-  if (atomic_hist && P > 1 && (e = hipMemsetAsync(H + hwords, 0, (size_t)(P - 1) * hwords * 4, st)) != hipSuccess) return (int)e;
+  // the chunk tables are accumulated with (256 per tile, uncontended) atomics by the histogram kernel
+  if ((e = hipMemsetAsync(C, 0, (size_t)P * cwords * 4, st)) != hipSuccess) return (int)e;
   uint64_t *kin = keys, *kout = keys_alt;
   uint32_t *vin = vals, *vout = vals_alt;
   for (uint32_t p = 0; p < P; ++p) {
     SortPass a{};
     a.d_n = d_n; a.n_max = n_max; a.kin = kin; a.vin = vin; a.kout = kout; a.vout = vout;
     a.H = H + (size_t)p * hwords;
-    a.Hn = (atomic_hist && p + 1 < P) ? H + (size_t)(p + 1) * hwords : nullptr;
-    a.C = C;
+    a.C = C + (size_t)p * cwords;
     a.shift = bit_lo + 8 * (int)p;
     const int rem = bits - 8 * (int)p;
     a.mask = rem >= 8 ? 0xffu : ((1u << rem) - 1u);
-    a.shift_n = a.shift + 8;
-    const int rem_n = rem - 8;
-    a.mask_n = rem_n >= 8 ? 0xffu : (rem_n > 0 ? ((1u << rem_n) - 1u) : 0u);
-    if (p == 0 || !atomic_hist) hipLaunchKernelGGL(sort_hist_kernel, dim3(ntiles), dim3(SORT_THREADS), 0, st, a);
-    if (nchunks > 1) {
-      hipLaunchKernelGGL(sort_chunk_sum_kernel, dim3(nchunks), dim3(SORT_THREADS), 0, st, a);
-      hipLaunchKernelGGL(sort_chunk_scan_kernel, dim3(1), dim3(SORT_THREADS), 0, st, a);
-    }
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(ntiles), dim3(SORT_THREADS), 0, st, a);
     hipLaunchKernelGGL(sort_scatter_kernel, dim3(ntiles), dim3(SORT_THREADS), 0, st, a);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     uint64_t *tk = kin; kin = kout; kout = tk;

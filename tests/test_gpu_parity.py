@@ -235,10 +235,8 @@ def test_cluster_many_contigs_two_pass_sort(ctx, oracle, monkeypatch, force_two)
 
 def _pair_soa(rec, soa):
     """the pairing arrays of strl_pair_soa for a host batch"""
-    k = soa.rv.keep
-    qh = api.qname_hash(rec)
-    keep = (k["mtid"], k["mpos"], k["flag"], qh)
-    return api.CPairSoa(*[a.ctypes.data for a in keep]), keep
+    keep = soa.pair_rows()
+    return api.CPairSoa(keep[0].ctypes.data, keep[1].ctypes.data), keep
 
 
 @pytest.mark.parametrize("n_pairs,seed,p,q", [(30000, 4321, 0.8, 40), (6000, 17, 0.65, 10)])

@@ -46,3 +46,9 @@ def test_sort_skewed_digits_and_large_two_level(ctx):
     keys = np.where(rng.random(n) < 0.7, np.uint64(7) << np.uint64(32), rng.integers(0, 2 ** 40, size=n, dtype=np.uint64))
     keys |= rng.integers(0, 2 ** 12, size=n, dtype=np.uint64)
     _check(ctx, keys, 0, 40)
+
+
+def test_sort_above_the_atomic_histogram_limit(ctx):
+    rng = np.random.Generator(np.random.Philox(8))
+    n = 9_000_000                       # > 2^23: one histogram kernel per pass
+    _check(ctx, rng.integers(0, 2 ** 24, size=n, dtype=np.uint64), 0, 24)
