@@ -40,13 +40,21 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--e2e-pairs", type=int, default=2 ** 21, help="pairs of the BAM file the end-to-end leg decodes")
+    ap.add_argument("--e2e-pairs", type=int, default=2 ** 23, help="pairs of the BAM file the end-to-end leg decodes")
     ap.add_argument("--cache", default="", help="directory to keep the generated batch in (profiling runs reload it instead of forking generators)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # ---- end to end first (it forks generators and runs the CLI, which wants the GPU to itself): BAM file -> .bin -----
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_e2e:
+        try:
+            e2e = end_to_end(args.e2e_pairs)
+        except Exception as e:
+            e2e = {"error": str(e)[:300]}
 
     # ---- synthetic S1 batch: DISTINCT reads, generated before the GPU runtime starts (worker processes fork) ----
     from strling_amd import synth
@@ -261,14 +269,6 @@ def main():
                "sample": f"oracle extract loop (skip predicate + get_repeat + add_soft + pair logic) + cluster/bounds over the S1 mix, "
                          f"{srec.n} reads x {reads_done // srec.n} passes, {t_cpu:.1f} s, single thread like the reference (threads=0)"}
 
-    # ---- end to end: BAM file -> .bin (strling extract) on this box, host decode included ---------------------------
-    e2e = None
-    if rank == 0 and world == 1 and not args.no_e2e:
-        try:
-            e2e = end_to_end(args.e2e_pairs)
-        except Exception as e:
-            e2e = {"error": str(e)[:300]}
-
     if rank == 0:
         total_reads = n * world * args.steps
         out = {
@@ -298,7 +298,13 @@ def end_to_end(n_pairs):
     from strling_amd import build
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import e2e_bench
-    return e2e_bench.run(n_pairs, build.CLI)
+    inp = e2e_bench.make_input(n_pairs)
+    try:
+        return e2e_bench.run(inp, build.CLI)
+    finally:
+        for k in ("bam", "bed", "out"):
+            if os.path.exists(inp[k]):
+                os.remove(inp[k])
 
 
 if __name__ == "__main__":

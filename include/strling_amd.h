@@ -233,6 +233,15 @@ int strl_pairer_result(strl_pairer *pairer, const strl_tread **treads, uint64_t 
  * Qname groups are keyed by the 64-bit hash alone (two different qnames with equal hashes would be treated as one group). */
 int strl_extract_device(strl_ctx *ctx, const strl_read_soa *soa, const strl_pair_soa *pair, int64_t n_tail, uint64_t item_cap,
                         uint64_t tread_cap);
+/* The same for an input that arrives in chunks (a BAM file being decoded): the chunks are scored as they come, in file
+ * order; per-read rows, qname hashes and scorer results of ALL chunks stay resident in HBM (44 B per read: a 30x genome is
+ * ~27 GB of the 288 GB) and the pair logic runs once, at strl_extract_finish, over the whole input -- exactly the
+ * reference's single Cache over the whole file (extract.nim:298), with no per-chunk state to carry.  At most 2^31 - 16
+ * records.  n_reads_hint (may be 0) pre-sizes the buffers.  Then strl_treads_fetch as above (qname_id = record index over
+ * all chunks). */
+int strl_extract_begin(strl_ctx *ctx, uint64_t n_reads_hint);
+int strl_extract_add(strl_ctx *ctx, const strl_read_soa *chunk, const strl_pair_soa *pair);
+int strl_extract_finish(strl_ctx *ctx, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap);
 /* Wait for the last strl_extract_device call and copy its treads to the host (out may be NULL to only get the count).
  * STRL_ERR_CAPACITY: a capacity was exceeded (n_out = treads needed when known); STRL_ERR_ASSERT: the reference's
  * doAssert repeat_count < 256 (extract.nim:72) would have fired; STRL_ERR_FORMAT: more than 12 records share one qname

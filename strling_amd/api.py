@@ -108,7 +108,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
            "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order",
-           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows"]
+           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish"]
 
 
 def lib_path():
@@ -175,6 +175,9 @@ def load(build_if_missing=True):
     L.strl_cluster_resident.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int, C.c_uint32, C.c_int32, C.c_uint16, C.c_uint16, C.c_uint16,
                                         C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                         C.POINTER(ClusterStats)]
+    L.strl_extract_begin.argtypes = [C.c_void_p, C.c_uint64]
+    L.strl_extract_add.argtypes = [C.c_void_p, C.POINTER(CReadSoa), C.POINTER(CPairSoa)]
+    L.strl_extract_finish.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64]
     L.strl_pair_rows.argtypes = [C.POINTER(CRecords)] + [C.c_void_p] * 5
     L.strl_ctx_cluster_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 3)]
     L.strl_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
@@ -368,6 +371,13 @@ class Context:
     def extract_device(self, cs: CReadSoa, cp: CPairSoa, n_tail, item_cap=0, tread_cap=0):
         """scoring + pair logic of one batch, asynchronous for device-resident batches (strl_extract_device)"""
         _check(self.L.strl_extract_device(self.h, C.byref(cs), C.byref(cp), n_tail, item_cap, tread_cap))
+
+    def extract_chunks(self, chunks, n_tail, hint=0):
+        """chunked form: chunks = iterable of (CReadSoa, CPairSoa) in file order (strl_extract_begin / _add / _finish)"""
+        _check(self.L.strl_extract_begin(self.h, hint))
+        for cs, cp in chunks:
+            _check(self.L.strl_extract_add(self.h, C.byref(cs), C.byref(cp)))
+        _check(self.L.strl_extract_finish(self.h, n_tail, 0, 0))
 
     def treads_fetch(self, want=True):
         """-> (treads of the last extract_device call in .bin order, ScoreStats)"""

@@ -73,6 +73,64 @@ def write_bam(path, rec, header_text=None, level=1, block=0xFF00, index=True, re
     return text.decode()
 
 
+def _raw_records(rec, a, b):
+    isize = rec.isize if rec.isize is not None else np.zeros(rec.n, np.int32)
+    out = bytearray()
+    qn_all = bytes(rec.qnames)
+    for i in range(a, b):
+        qn = qn_all[int(rec.qname_off[i]):int(rec.qname_off[i + 1])] + b"\0"
+        c0, c1 = int(rec.cigar_off[i]), int(rec.cigar_off[i + 1])
+        l_seq = int(rec.l_seq[i])
+        so = int(rec.seq_off[i])
+        seq = bytes(rec.seq4[so:so + (l_seq + 1) // 2])
+        if l_seq & 1 and seq:
+            seq = seq[:-1] + bytes([seq[-1] & 0xF0])
+        body = struct.pack("<iiBBHHHiiii", int(rec.tid[i]), int(rec.pos[i]), len(qn), int(rec.mapq[i]), 4680, c1 - c0,
+                           int(rec.flag[i]), l_seq, int(rec.mtid[i]), int(rec.mpos[i]), int(isize[i])) + qn + \
+            rec.cigar[c0:c1].astype("<u4").tobytes() + seq + b"\xff" * l_seq
+        out += struct.pack("<i", len(body)) + body
+    return out
+
+
+_PAR = {}
+
+
+def _par_worker(rng):
+    a, b = rng
+    raw = _raw_records(_PAR["rec"], a, b)
+    blk, lvl = _PAR["block"], _PAR["level"]
+    return b"".join(_bgzf_block(bytes(raw[o:o + blk]), lvl) for o in range(0, len(raw), blk))
+
+
+def write_bam_parallel(path, rec, level=1, block=0xFF00, procs=None, records_per_task=1 << 16):
+    """Benchmark inputs: the same BAM bytes as write_bam would produce record for record, but built and compressed by a pool
+    of forked workers (record ranges are compressed independently, so BGZF block boundaries differ) and without an index.
+    Call before the GPU runtime is initialised in this process."""
+    import multiprocessing as mp
+    import os
+    text = sam_header(rec.targets).encode()
+    hdr = bytearray(b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(rec.targets)))
+    for name, length in rec.targets:
+        nb = name.encode() + b"\0"
+        hdr += struct.pack("<i", len(nb)) + nb + struct.pack("<i", length)
+    tasks = [(a, min(rec.n, a + records_per_task)) for a in range(0, rec.n, records_per_task)]
+    _PAR.update(rec=rec, block=block, level=level)
+    procs = procs or max(1, (os.cpu_count() or 2) // 2)
+    with open(path, "wb") as f:
+        for o in range(0, len(hdr), block):
+            f.write(_bgzf_block(bytes(hdr[o:o + block]), level))
+        if procs == 1 or len(tasks) == 1:
+            for t in tasks:
+                f.write(_par_worker(t))
+        else:
+            with mp.get_context("fork").Pool(min(procs, len(tasks))) as pool:
+                for part in pool.imap(_par_worker, tasks, chunksize=1):
+                    f.write(part)
+        f.write(_EOF)
+    _PAR.clear()
+    return text.decode()
+
+
 def _reg2bin(beg, end):
     end -= 1
     if beg >> 14 == end >> 14:

@@ -1,11 +1,12 @@
 // strling -- command-line front end over libstrling_amd.so, keeping the reference's CLI surface and files:
 //   strling extract [-f FASTA] [-g STR.bed] [-p 0.8] [-q 40] [-v] BAM BIN      (src/strpkg/extract.nim:250-350)
 //   strling merge   [-w -1] [-m 5] [-c 0] [-t 0] [-q 40] [-o PREFIX] [-v] BIN...  (src/strpkg/merge.nim:47-191)
-// The BAM is decoded on the host (own BGZF/BAM reader), batches go through the C ABI into the HIP kernels,
-// the pair logic runs in the streaming pairer, and the .bin / -bounds.txt writers are byte-compatible with the
 //   strling index   [-g STR.bed] [-p 0.8] FASTA                                  (src/strpkg/genome_strs.nim:61-135,175-205)
-//   strling call    [-m 5] [-c 0] [-t 0] [-q 40] [-o PREFIX] [-v] BAM BIN              (src/strpkg/call.nim:51-285)
-// reference's.  Not in this build (SURVEY.md section 8f "next"): CRAM input, -l/--loci and -b/--bounds.
+//   strling call    [-m 5] [-c 0] [-t 0] [-q 40] [-l BED] [-b BOUNDS] [-o PREFIX] [-v] BAM BIN   (src/strpkg/call.nim:51-285)
+// The BAM is decoded on the host (own multi-threaded BGZF/BAM reader), batches go through the C ABI into the HIP kernels
+// as they are decoded, the pair logic (Cache.add) runs on the device once the whole file has been scored, and the
+// .bin / -bounds.txt / -genotype.txt / -unplaced.txt writers are byte-compatible with the reference's.
+// Not in this build: CRAM input (needs htslib's codec stack; the reference's error text is kept).
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -110,11 +111,11 @@ static void append_record(RecordBatch &dst, const RecordBatch &src, size_t i) {
 }
 
 // utils.nim:86-111
-// decode threads: STRL_THREADS, else what the machine has, at most 32 (the reference decodes on one: threads=0, extract.nim:275)
+// decode threads: STRL_THREADS, else what the machine has, at most 64 (the reference decodes on one: threads=0, extract.nim:275)
 static int decode_threads() {
   const char *e = getenv("STRL_THREADS");
   if (e && atoi(e) > 0) return atoi(e);
-  return (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  return (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
 }
 
 static void fragment_length_distribution(const std::string &bam, uint32_t frag[4096]) {
@@ -295,14 +296,29 @@ static int extract_main(int argc, char **argv) {
   if (is_tmp) remove(bed_path.c_str());
   strl_genome_str gs{(int32_t)rd.targets().size(), g.has.data(), g.off.data(), g.st.data(), g.en.data()};
   CHECK(strl_ctx_set_genome(ctx, &gs));
+  // Pair logic: on the device over the whole file (default), or the host's streaming Cache (STRL_PAIR=host; also the
+  // way out for inputs the device join refuses: more than 15 records under one qname hash).
+  const char *pair_env = getenv("STRL_PAIR");
+  const bool host_pair = pair_env && strcmp(pair_env, "host") == 0;
   strl_pairer *pairer = nullptr;
-  CHECK(strl_pairer_create(&opts, &pairer));
+  if (host_pair) CHECK(strl_pairer_create(&opts, &pairer));
+  else CHECK(strl_extract_begin(ctx, 0));
 
-  std::vector<int32_t> end;
-  std::vector<uint32_t> so, whole;
-  std::vector<uint16_t> ls, cl, cr;
-  std::vector<uint8_t> cig;
+  ThreadPool prep(decode_threads());
+  rvec<int32_t> end;
+  rvec<uint32_t> so;
+  std::vector<uint32_t> whole;
+  rvec<uint16_t> ls, cl, cr;
+  rvec<uint8_t> cig;
+  rvec<strl_pair_rec> rows;
+  rvec<uint64_t> qh;
   std::vector<strl_soft_rec> soft;
+  // qnames of every record seen so far (device path): a tread names its record by index
+  struct QChunk { uint64_t first; std::string names; rvec<uint64_t> off; };
+  std::vector<QChunk> qchunks;
+  uint64_t n_seen = 0;       // records handed to the device so far (secondary / supplementary included: they keep their index)
+  int64_t n_tail = 0;        // length of the trailing run of unplaced records: the "*" region extract.nim:326 visits again
+  int64_t tail_primary = 0;  // primary records among them
   double t_read = 0, t_soa = 0, t_score = 0, t_pair = 0;   // -v: where the wall time of the loop goes
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
@@ -311,20 +327,56 @@ static int extract_main(int argc, char **argv) {
     if (!n) return;
     const auto ta = now();
     strl_records rec = b.view();
-    end.resize(n); so.resize(n); whole.resize(n); ls.resize(n); cl.resize(n); cr.resize(n); cig.resize(n); soft.resize(2 * n + 2);
+    end.resize(n); so.resize(n); ls.resize(n); cl.resize(n); cr.resize(n); cig.resize(n);
+    if (!host_pair) { rows.resize(n); qh.resize(n); }
+    // SoA derivation (+ pair rows + qname hashes) of disjoint record ranges in parallel
+    const size_t parts = std::min<size_t>(std::max<size_t>(n / 4096, 1), (size_t)prep.size() * 4);
+    std::vector<uint32_t> mxs(parts, 0);
+    std::vector<int> rcs(parts, 0);
+    std::vector<std::string> errs(parts);
+    prep.parallel_for(parts, [&](size_t part) {
+      const size_t i0 = n * part / parts, i1 = n * (part + 1) / parts;
+      strl_records sub = rec;
+      sub.n = (int64_t)(i1 - i0);
+      sub.tid += i0; sub.pos += i0; sub.mtid += i0; sub.mpos += i0; sub.flag += i0; sub.mapq += i0; sub.cigar_off += i0; sub.seq_off += i0;
+      sub.l_seq += i0; sub.qname_off += i0;
+      int rc = strl_soa_from_records(&sub, end.data() + i0, so.data() + i0, ls.data() + i0, cl.data() + i0, cr.data() + i0, cig.data() + i0, &mxs[part]);
+      if (!rc && !host_pair) rc = strl_pair_rows(&sub, end.data() + i0, cl.data() + i0, cr.data() + i0, cig.data() + i0, rows.data() + i0);
+      if (!rc && !host_pair) rc = strl_qname_hash(&sub, qh.data() + i0);
+      rcs[part] = rc;
+      if (rc) errs[part] = strl_last_error();
+    });
     uint32_t mx = 0;
-    CHECK(strl_soa_from_records(&rec, end.data(), so.data(), ls.data(), cl.data(), cr.data(), cig.data(), &mx));
+    for (size_t k = 0; k < parts; ++k) { if (rcs[k]) quit("[strling] %s (status %d)", errs[k].c_str(), rcs[k]); mx = std::max(mx, mxs[k]); }
     strl_read_soa soa{};
     soa.n = n; soa.tid = rec.tid; soa.pos = rec.pos; soa.end = end.data(); soa.seq_off = so.data(); soa.l_seq = ls.data();
     soa.clip_l = cl.data(); soa.clip_r = cr.data(); soa.mapq = rec.mapq; soa.cig = cig.data(); soa.seq4 = rec.seq4;
     soa.seq4_bytes = b.seq4.size(); soa.max_l_seq = mx; soa.mem = STRL_MEM_HOST;
-    uint64_t ns = 0;
     const auto tb = now();
-    CHECK(strl_score_reads(ctx, &soa, whole.data(), soft.data(), 2 * n, &ns, nullptr));
-    const auto tc = now();
-    CHECK(strl_pairer_add(pairer, &rec, whole.data(), soft.data(), ns));
-    const auto td = now();
-    t_soa += secs(ta, tb); t_score += secs(tb, tc); t_pair += secs(tc, td);
+    if (host_pair) {
+      whole.resize(n); soft.resize(2 * n + 2);
+      uint64_t ns = 0;
+      CHECK(strl_score_reads(ctx, &soa, whole.data(), soft.data(), 2 * n, &ns, nullptr));
+      const auto tc = now();
+      CHECK(strl_pairer_add(pairer, &rec, whole.data(), soft.data(), ns));
+      t_score += secs(tb, tc); t_pair += secs(tc, now());
+    } else {
+      const strl_pair_soa pp{rows.data(), qh.data()};
+      CHECK(strl_extract_add(ctx, &soa, &pp));
+      CHECK(strl_ctx_sync(ctx));                       // the batch's buffers are reused by the decoder
+      QChunk q;
+      q.first = n_seen;
+      q.names.swap(b.qnames);
+      q.off.swap(b.qname_off);
+      qchunks.push_back(std::move(q));
+      for (size_t i = 0; i < n; ++i) {
+        if (rec.tid[i] < 0) { ++n_tail; if (!(rec.flag[i] & (0x100 | 0x800))) ++tail_primary; }
+        else { n_tail = 0; tail_primary = 0; }
+      }
+      n_seen += n;
+      t_score += secs(tb, now());
+    }
+    t_soa += secs(ta, tb);
   };
 
   fprintf(stderr, "[strling] collecting str-like reads\n");
@@ -369,7 +421,7 @@ static int extract_main(int argc, char **argv) {
     if (got == 0) break;
     for (size_t i = 0; i < (size_t)got; ++i) {
       const uint16_t f = b.flag[i];
-      if (b.tid[i] >= 0) { if (tail.size()) tail.clear(); } else append_record(tail, b, i);            // the "*" region: unplaced records at the end
+      if (host_pair) { if (b.tid[i] >= 0) { if (tail.size()) tail.clear(); } else append_record(tail, b, i); }   // the "*" region: unplaced records at the end
       if (f & (0x100 | 0x800)) continue;
       if (b.tid[i] != last_tid && b.tid[i] >= 0) {
         if (rd.targets()[(size_t)b.tid[i]].length > 2000000u) fprintf(stderr, "[strling] extracting chromosome:%s\n", rd.targets()[(size_t)b.tid[i]].name.c_str());
@@ -390,14 +442,46 @@ static int extract_main(int argc, char **argv) {
   }
   producer.join();
   fprintf(stderr, "[strling] extracting unmapped reads\n");
-  for (size_t i = 0; i < tail.size(); ++i) if (!(tail.flag[i] & (0x100 | 0x800))) ++nreads;
-  run_batch(tail);                                                                // extract.nim:326-329
 
-  const strl_tread *treads;
-  const uint64_t *qoff;
-  const char *qn;
+  std::vector<strl_tread> dev_treads;
+  std::vector<uint64_t> dev_qoff;
+  std::string dev_qn;
+  const strl_tread *treads = nullptr;
+  const uint64_t *qoff = nullptr;
+  const char *qn = nullptr;
   uint64_t nt = 0, pending = 0;
-  CHECK(strl_pairer_result(pairer, &treads, &nt, &qoff, &qn, &pending));
+  if (host_pair) {
+    for (size_t i = 0; i < tail.size(); ++i) if (!(tail.flag[i] & (0x100 | 0x800))) ++nreads;
+    run_batch(tail);                                                                // extract.nim:326-329
+    CHECK(strl_pairer_result(pairer, &treads, &nt, &qoff, &qn, &pending));
+  } else {
+    nreads += tail_primary;   // the "*" region is counted a second time by the reference's progress counter (extract.nim:326-329)
+    const auto tp0 = now();
+    int rc = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      CHECK(strl_extract_finish(ctx, n_tail, attempt ? 3 * n_seen + 16 : 0, attempt ? 8 * n_seen + 16 : 0));
+      rc = strl_treads_fetch(ctx, nullptr, 0, &nt, nullptr);
+      if (rc != STRL_ERR_CAPACITY) break;
+    }
+    if (rc == STRL_ERR_FORMAT) quit("[strling] %s; rerun with STRL_PAIR=host", strl_last_error());
+    if (rc) quit("[strling] %s (status %d)", strl_last_error(), rc);
+    dev_treads.resize((size_t)nt + 1);
+    CHECK(strl_treads_fetch(ctx, dev_treads.data(), nt, &nt, nullptr));
+    t_pair += secs(tp0, now());
+    dev_qoff.assign(1, 0);
+    for (uint64_t i = 0; i < nt; ++i) {
+      strl_tread &t = dev_treads[(size_t)i];
+      const uint64_t g = (uint64_t)t.qname_id;
+      size_t lo = 0, hi = qchunks.size();
+      while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (qchunks[mid].first <= g) lo = mid; else hi = mid; }
+      const QChunk &q = qchunks[lo];
+      const uint64_t k = g - q.first;
+      dev_qn.append(q.names, (size_t)q.off[(size_t)k], (size_t)(q.off[(size_t)k + 1] - q.off[(size_t)k]));
+      dev_qoff.push_back(dev_qn.size());
+      t.qname_id = (int64_t)i;
+    }
+    treads = dev_treads.data(); qoff = dev_qoff.data(); qn = dev_qn.data();
+  }
   fprintf(stderr, "[strling] writing binary file:%s\n", bin.c_str());
   CHECK(strl_bin_write(bin.c_str(), (float)p, min_mapq, frag, rd.header_text().data(), (int32_t)rd.header_text().size(), treads, nt, qoff, qn));
   fprintf(stderr, "[strling] finished extraction\n");
@@ -406,7 +490,7 @@ static int extract_main(int argc, char **argv) {
     fprintf(stderr, "[strling] seconds: total %.3f  waiting for the decoder %.3f  soa %.3f  device scoring (incl. copies) %.3f  pair logic %.3f\n",
             secs(t0, now()), t_read, t_soa, t_score, t_pair);
   }
-  strl_pairer_destroy(pairer);
+  if (pairer) strl_pairer_destroy(pairer);
   strl_ctx_destroy(ctx);
   return 0;
 }

@@ -25,6 +25,9 @@ struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
   int reserve(size_t bytes);
+  // like reserve, but the first keep_bytes survive a reallocation (copied on `st`, which is synchronised before the old
+  // block is freed); grows geometrically
+  int grow(size_t bytes, size_t keep_bytes, hipStream_t st);
   void release();
   template <typename T> T *as() { return static_cast<T *>(p); }
 };
@@ -34,6 +37,8 @@ constexpr int CNT_STRIDE = 16;
 constexpr int CNT_QUEUE = 0, CNT_SOFT = 16, CNT_SKIP = 32, CNT_SBW = 48, CNT_SBS = 64, CNT_WORDS = 80;
 // counters of the device pair logic (strl_ctx::pair_cnt)
 constexpr int PC_ITEMS = 0, PC_EMIT = 16, PC_ERR = 32, PC_WORDS = 48;
+// counters of a chunked extract (strl_ctx::x_cnt): soft records appended so far, then the sums of the chunks' CNT_* counters
+constexpr int XC_SOFT = 0, XC_SKIP = 1, XC_QUEUE = 2, XC_SBW = 3, XC_SBS = 4, XC_SOFT_ITEMS = 5, XC_WORDS = 16;
 constexpr uint32_t PAIR_ERR_RUN = 1u, PAIR_ERR_ASSERT = 2u, PAIR_ERR_ITEMS = 4u, PAIR_ERR_EMIT = 8u, PAIR_ERR_LOCAL = 16u;
 
 // murmur3 finaliser: a bijection on 64-bit words, so equality of mixed hashes == equality of hashes
@@ -93,11 +98,15 @@ struct strl_ctx {
   uint32_t *n_treads_dev = nullptr;
   uint32_t tread_cap = 0, pair_item_cap = 0;
   uint64_t ex_n = 0, ex_soft_cap = 0;
+  // chunked extract (strl_extract_begin / _add / _finish): per-read state of all chunks so far
+  strl::DevBuf x_rows, x_qhash, x_whole, x_soft, x_cnt;
+  uint64_t x_n = 0, x_soft_cap = 0;
+  bool x_open = false, x_mode = false;
   hipEvent_t pev[6] = {};
   // staging of the pairing arrays for host-memory batches
   strl::DevBuf st_mtid, st_mpos, st_flag, st_qhash;
 };
 
 // pair.hip: enqueue the device pair logic behind a scoring pass of the same batch
-int strl_pair_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *pp, const uint32_t *whole, const strl_soft_rec *soft,
-                     uint64_t soft_cap, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap);
+int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uint32_t *whole, const strl_soft_rec *soft,
+                     const uint32_t *d_n_soft, uint64_t soft_cap, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap);

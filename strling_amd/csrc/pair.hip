@@ -38,7 +38,7 @@ struct PairParams {
   const uint64_t *qhash;
   const uint32_t *whole;
   const strl_soft_rec *soft;
-  const uint32_t *score_cnt;   // CNT_* counters of the scoring pass
+  const uint32_t *d_n_soft;    // number of soft-clip records (device)
   uint32_t scap;
   uint32_t *bloom;
   uint32_t bloom_mask;         // bits - 1
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(1024) void pair_soft_items_kernel(PairParams P) {
   constexpr int U = 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long below = (1ull << lane) - 1ull;
-  uint32_t n_src = P.score_cnt[CNT_SOFT];
+  uint32_t n_src = *P.d_n_soft;
   if (n_src > P.scap) n_src = P.scap;
   for (uint32_t b0 = blockIdx.x * (1024u * U); b0 < n_src; b0 += gridDim.x * (1024u * U)) {
     uint64_t m[U];
@@ -542,9 +542,9 @@ using namespace strl;
 // Enqueue the pair logic behind a scoring pass of the same batch (score_device has run on c->stream with the pairing
 // arrays given, so the whole-read marks are in the bitmap).  Everything is asynchronous; results stay on the device:
 // c->treads[0, *c->n_treads).
-int strl_pair_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *pp, const uint32_t *whole, const strl_soft_rec *soft,
-                     uint64_t soft_cap, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap) {
-  const uint64_t n = s->n;
+int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uint32_t *whole, const strl_soft_rec *soft,
+                     const uint32_t *d_n_soft, uint64_t soft_cap, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap) {
+  if (n > 0x7ffffff0ull) { set_error("pair logic: at most 2^31 - 16 records"); return STRL_ERR_ARG; }
   if (n_tail < 0 || (uint64_t)n_tail > n) { set_error("strl_pair_device: n_tail must be in [0, n]"); return STRL_ERR_ARG; }
   if (item_cap > 0x7ffffff0ull || tread_cap > 0x7ffffff0ull) { set_error("pair capacities too large"); return STRL_ERR_ARG; }
   hipStream_t st = c->stream;
@@ -563,7 +563,7 @@ int strl_pair_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *p
   P.n = (uint32_t)n;
   P.tail_start = (uint32_t)(n - (uint64_t)n_tail);
   P.rec = pp->rec; P.qhash = pp->qhash;
-  P.whole = whole; P.soft = soft; P.score_cnt = c->counters.as<uint32_t>();
+  P.whole = whole; P.soft = soft; P.d_n_soft = d_n_soft;
   P.scap = (uint32_t)std::max<uint64_t>(std::min<uint64_t>(soft_cap, 2 * n), 1);
   P.bloom = c->bloom.as<uint32_t>(); P.bloom_mask = c->bloom_mask;
   P.item_key = c->p_key0.as<uint64_t>(); P.item_val = c->p_val0.as<uint32_t>(); P.item_cap = icap;

@@ -38,6 +38,22 @@ int DevBuf::reserve(size_t bytes) {
   cap = want;
   return STRL_OK;
 }
+int DevBuf::grow(size_t bytes, size_t keep_bytes, hipStream_t st) {
+  if (bytes <= cap && p) return STRL_OK;
+  void *np = nullptr;
+  const size_t want = std::max(bytes + bytes / 8 + 256, cap * 2);
+  STRL_HIP(hipMalloc(&np, want));
+  if (p && keep_bytes) {
+    STRL_HIP(hipMemcpyAsync(np, p, std::min(keep_bytes, cap), hipMemcpyDeviceToDevice, st));
+    STRL_HIP(hipStreamSynchronize(st));
+  } else if (p) {
+    STRL_HIP(hipStreamSynchronize(st));
+  }
+  if (p) (void)hipFree(p);
+  p = np;
+  cap = want;
+  return STRL_OK;
+}
 void DevBuf::release() {
   if (p) (void)hipFree(p);
   p = nullptr;
@@ -674,7 +690,7 @@ void strl_ctx_destroy(strl_ctx *c) {
                           &c->soft_tmp, &c->sb_whole, &c->sb_soft, &c->queue_r, &c->soft_dense, &c->sb_state_w, &c->sb_state_s, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
                           &c->st_mapq, &c->st_cig, &c->st_seq4, &c->st_whole, &c->st_soft, &c->st_text,
                           &c->p_key0, &c->p_key1, &c->p_val0, &c->p_val1, &c->p_emit, &c->sort_scratch, &c->pair_cnt, &c->bloom, &c->treads,
-                          &c->st_mtid, &c->st_mpos, &c->st_flag, &c->st_qhash};
+                          &c->st_mtid, &c->st_mpos, &c->st_flag, &c->st_qhash, &c->x_rows, &c->x_qhash, &c->x_whole, &c->x_soft, &c->x_cnt};
   for (auto *b : bufs) b->release();
   for (auto &b : c->c_buf) b.release();
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -817,8 +833,20 @@ int strl_ctx_set_genome(strl_ctx *c, const strl_genome_str *g) {
   return STRL_OK;
 }
 
+// Bloom bitmap of the hot qname groups: ~n/2 bits (2 MB for 2^25 reads: L2 resident), two bits per key
+static int bloom_reset(strl_ctx *c, uint64_t n) {
+  uint64_t bits = 1ull << 16;
+  while (bits < n / 2 && bits < (1ull << 27)) bits <<= 1;
+  int rc;
+  if ((rc = c->bloom.reserve((size_t)(bits / 8)))) return rc;
+  STRL_HIP(hipMemsetAsync(c->bloom.p, 0, (size_t)(bits / 8), c->stream));
+  c->bloom_mask = (uint32_t)(bits - 1);
+  return STRL_OK;
+}
+
 static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, strl_soft_rec *soft, uint64_t soft_cap,
-                        uint64_t *n_soft, strl_score_stats *stats, bool sync_counts, const strl_pair_soa *pp = nullptr) {
+                        uint64_t *n_soft, strl_score_stats *stats, bool sync_counts, const strl_pair_soa *pp = nullptr,
+                        bool fresh_bloom = true) {
   const uint64_t n = s->n;
   if (n > 0x3fffffffull) { set_error("batch too large (%llu reads; limit 2^30-1)", (unsigned long long)n); return STRL_ERR_ARG; }
   if (s->max_l_seq > STRL_MAX_READ_LEN) { set_error("read of %u bases exceeds STRL_MAX_READ_LEN=%d", s->max_l_seq, STRL_MAX_READ_LEN); return STRL_ERR_ARG; }
@@ -851,12 +879,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   P.min_mapq = c->opts.min_mapq;
   P.seg_row0 = 2; P.seg_row1 = 3;
   if (pp) {
-    // Bloom bitmap of the hot qname groups: ~n/2 bits (2 MB for 2^25 reads: L2 resident), two bits per key
-    uint64_t bits = 1ull << 16;
-    while (bits < n / 2 && bits < (1ull << 27)) bits <<= 1;
-    if ((rc = c->bloom.reserve((size_t)(bits / 8)))) return rc;
-    STRL_HIP(hipMemsetAsync(c->bloom.p, 0, (size_t)(bits / 8), c->stream));
-    c->bloom_mask = (uint32_t)(bits - 1);
+    if (fresh_bloom && (rc = bloom_reset(c, n))) return rc;
     P.qhash = pp->qhash; P.bloom = c->bloom.as<uint32_t>(); P.bloom_mask = c->bloom_mask;
   }
   hipEvent_t *tev = c->timing ? &c->ring[(c->ring_pos % RING) * EV_PER] : nullptr;
@@ -1020,19 +1043,113 @@ int strl_extract_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa
   const uint64_t soft_cap = std::min<uint64_t>(item_cap, 2 * n + 2);
   if ((rc = c->st_whole.reserve((size_t)std::max<uint64_t>(n, 1) * 4))) return rc;
   if ((rc = c->st_soft.reserve((size_t)std::max<uint64_t>(soft_cap, 1) * sizeof(strl_soft_rec)))) return rc;
-  c->ex_n = n; c->ex_soft_cap = soft_cap;
+  c->ex_n = n; c->ex_soft_cap = soft_cap; c->x_mode = false;
   if ((rc = score_device(c, &d, c->st_whole.as<uint32_t>(), c->st_soft.as<strl_soft_rec>(), soft_cap, nullptr, nullptr, false, &dp))) return rc;
-  return strl_pair_device(c, &d, &dp, c->st_whole.as<uint32_t>(), c->st_soft.as<strl_soft_rec>(), soft_cap, n_tail, item_cap, tread_cap);
+  return strl_pair_device(c, n, &dp, c->st_whole.as<uint32_t>(), c->st_soft.as<strl_soft_rec>(), c->counters.as<uint32_t>() + CNT_SOFT, soft_cap,
+                          n_tail, item_cap, tread_cap);
+}
+
+// ---- the same in chunks: a BAM being decoded hands over batches in file order, the pair logic runs once at the end ----
+namespace strl {
+__global__ void soft_append_kernel(const strl_soft_rec *src, const uint32_t *cnt, uint32_t src_cap, uint32_t read_base, strl_soft_rec *dst,
+                                   uint32_t dst_cap, uint32_t *xc) {
+  __shared__ uint32_t base_sh;
+  uint32_t n = cnt[CNT_SOFT];
+  if (n > src_cap) n = src_cap;
+  if (threadIdx.x == 0) {
+    base_sh = atomicAdd(&xc[XC_SOFT], n);   // one block: this is the only writer of the counter
+    xc[XC_SKIP] += cnt[CNT_SKIP]; xc[XC_QUEUE] += cnt[CNT_QUEUE]; xc[XC_SBW] += cnt[CNT_SBW]; xc[XC_SBS] += cnt[CNT_SBS];
+    xc[XC_SOFT_ITEMS] += cnt[CNT_SOFT];
+  }
+  __syncthreads();
+  const uint32_t base = base_sh;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    strl_soft_rec s = src[i];
+    s.read_side += read_base << 1;
+    if (base + i < dst_cap) dst[base + i] = s;
+  }
+}
+}  // namespace strl
+
+int strl_extract_begin(strl_ctx *c, uint64_t n_reads_hint) {
+  if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
+  if (!c->have_opts) { set_error("strl_ctx_set_opts must be called before scoring"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  int rc;
+  const uint64_t hint = std::max<uint64_t>(n_reads_hint, 1 << 20);
+  if ((rc = c->x_rows.grow((size_t)hint * sizeof(strl_pair_rec), 0, c->stream)) || (rc = c->x_qhash.grow((size_t)hint * 8, 0, c->stream)) ||
+      (rc = c->x_whole.grow((size_t)hint * 4, 0, c->stream)) || (rc = c->x_soft.grow((size_t)(hint / 8 + 65536) * sizeof(strl_soft_rec), 0, c->stream)) ||
+      (rc = c->x_cnt.reserve(XC_WORDS * 4)))
+    return rc;
+  STRL_HIP(hipMemsetAsync(c->x_cnt.p, 0, XC_WORDS * 4, c->stream));
+  if ((rc = bloom_reset(c, std::max<uint64_t>(hint, 1ull << 28)))) return rc;   // 16 MB: sized for a whole genome of reads
+  c->x_n = 0; c->x_soft_cap = 0; c->x_open = true;
+  return STRL_OK;
+}
+
+int strl_extract_add(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *pp) {
+  if (!c || !s || !pp) { set_error("null argument"); return STRL_ERR_ARG; }
+  if (!c->x_open) { set_error("strl_extract_add without strl_extract_begin"); return STRL_ERR_ARG; }
+  if (s->n && (!pp->rec || !pp->qhash)) { set_error("strl_extract_add: incomplete strl_pair_soa"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  const uint64_t n = s->n, at = c->x_n;
+  if (!n) return STRL_OK;
+  if (at + n > 0x7ffffff0ull) { set_error("chunked extract: more than 2^31 - 16 records"); return STRL_ERR_ARG; }
+  int rc;
+  if ((rc = c->x_rows.grow((size_t)(at + n) * sizeof(strl_pair_rec), (size_t)at * sizeof(strl_pair_rec), c->stream)) ||
+      (rc = c->x_qhash.grow((size_t)(at + n) * 8, (size_t)at * 8, c->stream)) || (rc = c->x_whole.grow((size_t)(at + n) * 4, (size_t)at * 4, c->stream)))
+    return rc;
+  // soft-clip records: a chunk can add two per read, the typical rate is a few per cent: keep n / 4 + 64 Ki free behind the
+  // records counted so far (the count lives on the device; it is bounded by what earlier chunks could have added)
+  c->x_soft_cap = std::max<uint64_t>(c->x_soft_cap, (at + n) / 4 + 65536);
+  if ((rc = c->x_soft.grow((size_t)c->x_soft_cap * sizeof(strl_soft_rec), c->x_soft.cap, c->stream))) return rc;
+  strl_read_soa d = *s;
+  const hipMemcpyKind kind = s->mem == STRL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (s->mem != STRL_MEM_DEVICE && (rc = stage_batch(c, s, nullptr, &d, nullptr))) return rc;
+  strl_pair_rec *rows = c->x_rows.as<strl_pair_rec>() + at;
+  uint64_t *qh = c->x_qhash.as<uint64_t>() + at;
+  STRL_HIP(hipMemcpyAsync(rows, pp->rec, (size_t)n * sizeof(strl_pair_rec), kind, c->stream));
+  STRL_HIP(hipMemcpyAsync(qh, pp->qhash, (size_t)n * 8, kind, c->stream));
+  const strl_pair_soa dp{rows, qh};
+  const uint64_t chunk_soft = std::min<uint64_t>(2 * n + 2, n / 4 + 65536);
+  if ((rc = c->st_soft.reserve((size_t)chunk_soft * sizeof(strl_soft_rec)))) return rc;
+  if ((rc = score_device(c, &d, c->x_whole.as<uint32_t>() + at, c->st_soft.as<strl_soft_rec>(), chunk_soft, nullptr, nullptr, false, &dp, false))) return rc;
+  hipLaunchKernelGGL(strl::soft_append_kernel, dim3(1), dim3(1024), 0, c->stream, c->st_soft.as<strl_soft_rec>(), c->counters.as<uint32_t>(), (uint32_t)chunk_soft,
+                     (uint32_t)at, c->x_soft.as<strl_soft_rec>(), (uint32_t)std::min<uint64_t>(c->x_soft_cap, 0xffffffffull), c->x_cnt.as<uint32_t>());
+  STRL_HIP(hipGetLastError());
+  c->x_n = at + n;
+  return STRL_OK;
+}
+
+int strl_extract_finish(strl_ctx *c, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap) {
+  if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
+  if (!c->x_open && !c->x_mode) { set_error("strl_extract_finish without strl_extract_begin"); return STRL_ERR_ARG; }   // (again after a capacity error: fine)
+  STRL_HIP(hipSetDevice(c->device));
+  const uint64_t n = c->x_n;
+  if (n_tail < 0 || (uint64_t)n_tail > n) { set_error("strl_extract_finish: n_tail must be in [0, n]"); return STRL_ERR_ARG; }
+  if (!item_cap) item_cap = n / 8 + 65536;
+  if (!tread_cap) tread_cap = n / 16 + 65536;
+  item_cap = std::min<uint64_t>(item_cap, 3 * n + 16);
+  tread_cap = std::min<uint64_t>(tread_cap, 8 * n + 16);
+  c->x_open = false; c->x_mode = true;
+  c->ex_n = n; c->ex_soft_cap = c->x_soft_cap;
+  const strl_pair_soa dp{c->x_rows.as<strl_pair_rec>(), c->x_qhash.as<uint64_t>()};
+  return strl_pair_device(c, n, &dp, c->x_whole.as<uint32_t>(), c->x_soft.as<strl_soft_rec>(), c->x_cnt.as<uint32_t>() + XC_SOFT,
+                          std::max<uint64_t>(c->x_soft_cap, 1), n_tail, item_cap, tread_cap);
 }
 
 int strl_treads_fetch(strl_ctx *c, strl_tread *out, uint64_t cap, uint64_t *n_out, strl_score_stats *stats) {
   if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
   if (!c->n_treads_dev) { set_error("strl_treads_fetch: no strl_extract_device call on this context"); return STRL_ERR_ARG; }
   STRL_HIP(hipSetDevice(c->device));
-  uint32_t raw[CNT_WORDS], pc[PC_WORDS];
+  uint32_t raw[CNT_WORDS], pc[PC_WORDS], xc[XC_WORDS];
   STRL_HIP(hipMemcpyAsync(raw, c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
   STRL_HIP(hipMemcpyAsync(pc, c->pair_cnt.p, PC_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
+  if (c->x_mode) STRL_HIP(hipMemcpyAsync(xc, c->x_cnt.p, XC_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
   STRL_HIP(hipStreamSynchronize(c->stream));
+  if (c->x_mode) {   // chunked extract: the sums over the chunks
+    raw[CNT_SKIP] = xc[XC_SKIP]; raw[CNT_QUEUE] = xc[XC_QUEUE]; raw[CNT_SBW] = xc[XC_SBW]; raw[CNT_SBS] = xc[XC_SBS]; raw[CNT_SOFT] = xc[XC_SOFT];
+  }
   if (stats) {
     memset(stats, 0, sizeof *stats);
     stats->n_reads = c->ex_n; stats->n_skipped = raw[CNT_SKIP]; stats->n_scored = raw[CNT_QUEUE]; stats->n_soft_items = raw[CNT_SOFT];

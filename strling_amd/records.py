@@ -109,6 +109,20 @@ class RecordBatch:
     def n(self):
         return int(self.tid.size)
 
+    def slice(self, a, b):
+        """records [a, b) as a batch of their own (offsets rebased; SEQ keeps its 16-byte alignment)"""
+        c0, c1 = int(self.cigar_off[a]), int(self.cigar_off[b])
+        q0, q1 = int(self.qname_off[a]), int(self.qname_off[b])
+        s0 = int(self.seq_off[a]) if b > a else 0
+        s1 = (int(self.seq_off[b - 1]) + (int(self.l_seq[b - 1]) + 1) // 2 + 15) // 16 * 16 if b > a else 0
+        seq4 = np.zeros(s1 - s0 + 32, np.uint8)
+        seq4[: s1 - s0] = self.seq4[s0:s1]
+        return RecordBatch(self.tid[a:b], self.pos[a:b], self.mtid[a:b], self.mpos[a:b], self.flag[a:b], self.mapq[a:b],
+                           (self.cigar_off[a:b + 1] - np.uint32(c0)).astype(np.uint32), self.cigar[c0:c1],
+                           (self.seq_off[a:b] - np.uint64(s0)).astype(np.uint64), self.l_seq[a:b], seq4,
+                           (self.qname_off[a:b + 1] - np.uint64(q0)).astype(np.uint64), bytes(self.qnames[q0:q1]),
+                           None if self.isize is None else self.isize[a:b], self.targets)
+
     def qname(self, i):
         return self.qnames[int(self.qname_off[i]):int(self.qname_off[i + 1])]
 

@@ -317,3 +317,27 @@ def test_too_many_records_under_one_qname_fall_back_to_the_host_pair_logic(ctx, 
     exp = oracle.extract(rec, None, oracle.make_opts(350, 0.8, 40))
     ok, why = treads_equal(got, exp)
     assert ok, why
+
+
+@pytest.mark.parametrize("cuts", [[], [1], [5000, 5001, 20000, 43000], [59999]])
+def test_chunked_extract_matches_oracle(ctx, oracle, cuts):
+    """strl_extract_begin / _add / _finish: chunks scored as they arrive, the pair logic once over the whole input --
+    pairs that straddle chunk boundaries, empty chunks and the twice-visited tail included"""
+    rec, g = synth.synth_wgs(30000, seed=77, contig_len=2_000_000)
+    med = oracle.median(synth.frag_hist(rec))
+    ctx.set_opts(0.8, 40, med)
+    ctx.set_genome(g)
+    edges = [0] + cuts + [rec.n]
+    keep, chunks = [], []
+    for a, b in zip(edges[:-1], edges[1:]):
+        part = rec.slice(a, b)
+        soa = api.Soa(part)
+        rows, qh = soa.pair_rows()
+        keep.append((part, soa, rows, qh))
+        chunks.append((soa.c_struct(), api.CPairSoa(rows.ctypes.data, qh.ctypes.data)))
+    ctx.extract_chunks(chunks, int((rec.tid < 0).sum()))
+    got, st = ctx.treads_fetch()
+    exp = oracle.extract(rec, g, oracle.make_opts(med, 0.8, 40))
+    ok, why = treads_equal(got, exp)
+    assert ok and len(exp) > 300, why
+    assert st.n_reads == rec.n and st.n_scored + st.n_skipped == rec.n

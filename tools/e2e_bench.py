@@ -1,5 +1,6 @@
 """End-to-end `strling extract` rate (BAM bytes -> .bin) on a synthetic BAM, with the CLI's own phase breakdown.
-usage: python tools/e2e_bench.py [n_pairs] [threads...]     (GPU box)"""
+usage: python tools/e2e_bench.py [n_pairs] [threads...]     (GPU box)
+As a module: make_input(n_pairs) before the GPU runtime starts in this process (it forks), run(paths, cli, threads)."""
 import json
 import os
 import subprocess
@@ -7,25 +8,48 @@ import sys
 import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import numpy as np
-from strling_amd import bamio, build, synth
 
-n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 400_000
-repeat = int(os.environ.get("REPEAT", "1"))
-threads = [int(x) for x in sys.argv[2:]] or [1]
-d = os.environ.get("TMPDIR", "/tmp")
-bam, bed, out = f"{d}/e2e.bam", f"{d}/e2e.str", f"{d}/e2e.bin"
-t0 = time.time()
-rec, g = synth.synth_wgs(n_pairs, seed=99)
-bamio.write_bam(bam, rec, level=6, repeat=repeat)
-bamio.write_genome_bed(bed, g, rec.targets)
-res = {"reads": rec.n * repeat, "bam_MB": round(os.path.getsize(bam) / 1e6, 1), "make_s": round(time.time() - t0, 1), "nproc": os.cpu_count(), "runs": []}
-for t in threads:
-    env = dict(os.environ, STRL_THREADS=str(t), STRL_DECODE_TIMING="1")
-    t1 = time.time()
-    r = subprocess.run([build.CLI, "extract", "-v", "-g", bed, bam, out], capture_output=True, text=True, env=env)
-    wall = time.time() - t1
-    line = [l for l in r.stderr.splitlines() if "seconds: total" in l]
-    dec = [l.split("decode seconds:")[1].strip() for l in r.stderr.splitlines() if "decode seconds:" in l]
-    res["runs"].append({"threads": t, "decode": dec, "rc": r.returncode, "wall_s": round(wall, 3), "reads_per_s": round(rec.n * repeat / wall), "phases": line[-1].split("seconds:")[1].strip() if line else r.stderr[-300:]})
-print(json.dumps(res))
+
+def make_input(n_pairs, d=None, level=1):
+    """-> dict(bam, bed, out, reads, bam_MB, make_s).  S1 mix, distinct reads, coordinate sorted, no index."""
+    from strling_amd import bamio, synth
+    d = d or os.environ.get("TMPDIR", "/tmp")
+    bam, bed, out = f"{d}/e2e_{n_pairs}.bam", f"{d}/e2e_{n_pairs}.str", f"{d}/e2e_{n_pairs}.bin"
+    t0 = time.time()
+    chunks = max(1, min(64, n_pairs // 65536))
+    rec, g = synth.synth_wgs_chunks(chunks, n_pairs // chunks, seed=99)
+    bamio.write_bam_parallel(bam, rec, level=level)
+    bamio.write_genome_bed(bed, g, rec.targets)
+    return {"bam": bam, "bed": bed, "out": out, "reads": rec.n, "bam_MB": round(os.path.getsize(bam) / 1e6, 1), "make_s": round(time.time() - t0, 1)}
+
+
+def run(inp, cli, threads=(0,)):
+    """runs `strling extract -v` on the prepared input once per thread count (0 = the CLI's default) -> end_to_end block"""
+    res = {"unit": "reads/s", "reads": inp["reads"], "bam_MB": inp["bam_MB"], "host_threads_available": os.cpu_count(), "runs": []}
+    for t in threads:
+        env = dict(os.environ, STRL_DECODE_TIMING="1")
+        if t:
+            env["STRL_THREADS"] = str(t)
+        t1 = time.time()
+        r = subprocess.run([cli, "extract", "-v", "-g", inp["bed"], inp["bam"], inp["out"]], capture_output=True, text=True, env=env)
+        wall = time.time() - t1
+        line = [l for l in r.stderr.splitlines() if "seconds: total" in l]
+        dec = [l.split("decode seconds:")[1].strip() for l in r.stderr.splitlines() if "decode seconds:" in l]
+        loop_s = float(line[-1].split("total")[1].split()[0]) if line else None
+        res["runs"].append({"decode_threads": t or "default(min(64, nproc))", "rc": r.returncode, "wall_s": round(wall, 3),
+                            "reads_per_s_wall": round(inp["reads"] / wall), "loop_s": loop_s,
+                            "reads_per_s_loop": round(inp["reads"] / loop_s) if loop_s else None, "decode": dec,
+                            "phases": line[-1].split("seconds:")[1].strip() if line else r.stderr[-300:]})
+    best = max(res["runs"], key=lambda x: x["reads_per_s_wall"])
+    res["value"] = best["reads_per_s_wall"]
+    res["note"] = ("`strling extract` BAM file (page cache) -> .bin, whole process wall clock incl. start-up, fragment-length pass, BGZF inflate + "
+                   "parse on the host threads, H2D, all kernels, pair logic on the device, .bin writing; reads_per_s_loop excludes process start-up")
+    return res
+
+
+if __name__ == "__main__":
+    from strling_amd import build
+    n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 400_000
+    threads = [int(x) for x in sys.argv[2:]] or [0]
+    inp = make_input(n_pairs)
+    print(json.dumps(run(inp, build.CLI, threads)))
