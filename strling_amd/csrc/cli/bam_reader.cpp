@@ -55,10 +55,11 @@ bool BamReader::fill(std::string &err) {
     if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f_) != xlen - 6) { err = "truncated BGZF header"; return false; }
     for (uint32_t o = 0; o + 4 <= xlen;) {
       const uint32_t sl = extra[o + 2] | (extra[o + 3] << 8);
+      if (o + 4 + sl > xlen) { err = "malformed BGZF extra field"; return false; }
       if (extra[o] == 'B' && extra[o + 1] == 'C' && sl == 2) bsize = (extra[o + 4] | (extra[o + 5] << 8)) + 1u;
       o += 4 + sl;
     }
-    if (!bsize) { err = "BGZF block without BC field"; return false; }
+    if (!bsize || bsize < 12 + xlen + 8) { err = "BGZF block without BC field"; return false; }   // (same guard as BamStream::load_chunk)
     const uint32_t clen = bsize - 12 - xlen - 8;
     cbuf_.resize(clen + 8);
     if (fread(cbuf_.data(), 1, clen + 8, f_) != clen + 8) { err = "truncated BGZF block"; return false; }
@@ -348,6 +349,7 @@ bool BamStream::load_chunk(std::string &err) {
     for (uint32_t o = 0; o + 4 <= xlen;) {
       const uint8_t *x = h + 12 + o;
       const uint32_t sl = x[2] | (x[3] << 8);
+      if (o + 4 + sl > xlen) { err = "malformed BGZF extra field"; return false; }
       if (x[0] == 'B' && x[1] == 'C' && sl == 2) bsize = (x[4] | (x[5] << 8)) + 1u;
       o += 4 + sl;
     }

@@ -575,6 +575,21 @@ static int locus_row(char *buf, int cap, const strl_locus &L, const char *chrom)
                   b.center_mass, (unsigned)b.n_left, (unsigned)b.n_right, (unsigned)b.n_total);
 }
 
+// targets.fill(fasta), merge.nim:27-34: names and lengths of the FASTA's .fai in file order
+static std::vector<BamTarget> targets_from_fai(const std::string &fasta) {
+  FILE *f = fopen((fasta + ".fai").c_str(), "r");
+  if (!f || !file_exists(fasta)) { if (f) fclose(f); quit("could not open fasta:%s", fasta.c_str()); }
+  std::vector<BamTarget> t;
+  char line[1 << 16];
+  while (fgets(line, sizeof line, f)) {
+    char name[4096];
+    unsigned long long len = 0;
+    if (sscanf(line, "%4095[^\t]\t%llu", name, &len) == 2) t.push_back(BamTarget{name, (uint32_t)len});
+  }
+  fclose(f);
+  return t;
+}
+
 static int merge_main(int argc, char **argv) {
   const char *usage =
       "strling merge\n\nUsage:\n  strling merge [options] [bin ...]\n\nOptions:\n  -w, --window=WINDOW        Number of bp within which to search for reads supporting the other side of a bound. "
@@ -583,13 +598,33 @@ static int merge_main(int argc, char **argv) {
       "  -c, --min-clip=MIN_CLIP    minimum number of supporting clipped reads for each side of a locus (default: 0)\n"
       "  -t, --min-clip-total=MIN_CLIP_TOTAL\n                             minimum total number of supporting clipped reads for a locus (default: 0)\n"
       "  -q, --min-mapq=MIN_MAPQ    minimum mapping quality (does not apply to STR reads) (default: 40)\n"
-      "  -o, --output-prefix=OUTPUT_PREFIX\n                             prefix for output files. Suffix will be -bounds.txt (default: strling)\n  -v, --verbose\n  -h, --help                 Show this help\n";
+      "  -o, --output-prefix=OUTPUT_PREFIX\n                             prefix for output files. Suffix will be -bounds.txt (default: strling)\n"
+      "  -f, --fasta=FASTA          path to fasta file (required if using CRAM input)\n"
+      "  --chromosome=CHROMOSOME    chromosome to restrict parsing. helps with memory/parallelization for large cohorts (default: -2)\n"
+      "  -l, --bed=BED              Annoated bed file specifying additional STR loci to genotype. Format is: chr start stop repeatunit [name]\n"
+      "  -d, --diff-refs            allow bin files generated on a mixture of reference genomes (by default differing references will produce an error). "
+      "Reports chromosomes in the first bin or -f if provided\n  -v, --verbose\n  -h, --help                 Show this help\n";
   if (argc <= 2) { fputs(usage, stdout); return 0; }
   const Args a = parse(argc, argv, 2, {{"fasta", 'f', true}, {"window", 'w', true}, {"min-support", 'm', true}, {"chromosome", 'C', true},
                                        {"min-clip", 'c', true}, {"min-clip-total", 't', true}, {"min-mapq", 'q', true}, {"bed", 'l', true},
                                        {"output-prefix", 'o', true}, {"diff-refs", 'd', false}, {"verbose", 'v', false}}, usage);
   if (a.flag("bed") && !file_exists(a.get("bed", ""))) quit("couldn't open bed file");     // merge.nim:80-82
-  if (a.flag("chromosome")) quit("[strling] --chromosome is not supported by this build");
+  const bool allow_diff = a.flag("diff-refs");
+  std::vector<BamTarget> targets;
+  if (a.flag("fasta") && allow_diff) targets = targets_from_fai(a.get("fasta", ""));          // merge.nim:84-86
+  // --chromosome: the tid of that name IN THE FASTA (merge.nim:36-45,89); reads of other tids are dropped while a bin is read
+  bool have_req = false;
+  int32_t requested_tid = 0;
+  if (a.flag("chromosome") && a.get("chromosome", "-2") != "-2") {
+    const std::string chrom = a.get("chromosome", "");
+    const std::vector<BamTarget> ft = targets_from_fai(a.get("fasta", ""));
+    if (ft.empty()) quit("Error: unhandled exception: [strling merge] chromosome: %s specified, but no targets found in fasta. Specify a valid fasta file. [ValueError]", chrom.c_str());
+    int found = -1;
+    for (size_t k = 0; k < ft.size() && found < 0; ++k) if (ft[k].name == chrom) found = (int)k;
+    if (found < 0) quit("Error: unhandled exception: [strling merge] chromosome: %s not found in fasta, check name and 'chr' prefix [ValueError]", chrom.c_str());
+    have_req = true;
+    requested_tid = found;
+  }
   int window = atoi(a.get("window", "-1").c_str());
   const int min_support = atoi(a.get("min-support", "5").c_str());
   const uint16_t min_clip = (uint16_t)atoi(a.get("min-clip", "0").c_str());
@@ -599,8 +634,6 @@ static int merge_main(int argc, char **argv) {
 
   uint32_t frag[4096] = {0};
   std::vector<strl_tread> all;
-  std::string header0;
-  std::vector<BamTarget> targets;
   for (size_t si = 0; si < a.pos.size(); ++si) {
     const std::string &path = a.pos[si];
     if (verbose) fprintf(stderr, "[strling] reading bin file: %s\n", path.c_str());
@@ -612,11 +645,11 @@ static int merge_main(int argc, char **argv) {
     std::vector<char> qn((size_t)info.qnames_bytes + 1);
     CHECK(strl_bin_read(path.c_str(), &info, &hdr[0], t.data(), qo.data(), qn.data()));
     const std::vector<BamTarget> tg = targets_from_header(hdr);
-    if (si == 0) { header0 = hdr; targets = tg; }
+    if (targets.empty()) targets = tg;                                            // merge.nim:104-105
     else {
       bool same = tg.size() == targets.size();
       for (size_t k = 0; same && k < tg.size(); ++k) same = tg[k].name == targets[k].name && tg[k].length == targets[k].length;
-      if (!same && !a.flag("diff-refs")) quit("[strling] Error: inconsistent bam header for %s. Were all samples run on the same reference genome?", path.c_str());
+      if (!same && !allow_diff) quit("[strling] Error: inconsistent bam header for %s. Were all samples run on the same reference genome?", path.c_str());
     }
     for (int k = 0; k < 4096; ++k) {                                               // merge.nim:112-115
       const uint32_t before = frag[k];
@@ -625,6 +658,7 @@ static int merge_main(int argc, char **argv) {
     }
     uint64_t kept = 0;
     for (int32_t k = 0; k < info.n_reads; ++k) {
+      if (have_req && t[(size_t)k].tid != requested_tid) continue;                 // unpack.nim:126 requested_tid
       if (t[(size_t)k].tid < 0) continue;                                          // unpack_file(drop_unplaced=true)
       t[(size_t)k].qname_id = (int64_t)si;                                         // merge.nim:118-125: qname := sample index
       all.push_back(t[(size_t)k]);
@@ -644,6 +678,7 @@ static int merge_main(int argc, char **argv) {
   std::vector<strl_locus> loci;
   if (a.flag("bed")) {
     loci = parse_bed(a.get("bed", ""), targets, (uint32_t)window);
+    if (have_req) loci.erase(std::remove_if(loci.begin(), loci.end(), [&](const strl_locus &L) { return L.b.tid != requested_tid; }), loci.end());   // cluster.nim:139
     std::vector<uint64_t> aoff(loci.size() + 1);
     CHECK(strl_assign_reads_loci(all.data(), all.size(), STRL_MODE_MERGE, loci.data(), loci.size(), aoff.data(), nullptr, 0));
   }

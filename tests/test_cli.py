@@ -215,3 +215,118 @@ def test_extract_builds_missing_genome_index(oracle, tmp_path):
     assert open(out2, "rb").read() == exp
     r = _run(["extract", bam, out2])
     assert r.returncode == 1 and "couldn't open fasta" in r.stderr
+
+
+def _three_bins(oracle, tmp_path, targets_of=None):
+    bins, per_sample, frag_sum, rec = [], [], np.zeros(4096, np.uint64), None
+    for s in range(3):
+        rec, g = synth.synth_wgs(5000, seed=200 + s, contig_len=300_000, str_frac=0.05)
+        frag = synth.frag_hist(rec)
+        t = oracle.extract(rec, g, oracle.make_opts(oracle.median(frag), 0.8, 40))
+        p = str(tmp_path / f"m{s}.bin")
+        tt = np.zeros(len(t), api.TREAD_DTYPE)
+        for f in tt.dtype.names:
+            tt[f] = t[f]
+        targets = targets_of(s, rec.targets) if targets_of else rec.targets
+        api.bin_write(p, 0.8, 40, frag, bamio.sam_header(targets), tt, rec.qname_off, rec.qnames)
+        bins.append(p)
+        keep = t[t["tid"] >= 0].copy()
+        keep["qname_id"] = s
+        per_sample.append(keep)
+        frag_sum += frag
+    return bins, per_sample, frag_sum.astype(np.uint32), rec.targets
+
+
+def _write_fai(path, targets):
+    open(path, "w").write(">x\nA\n")
+    with open(path + ".fai", "w") as f:
+        off = 0
+        for name, ln in targets:
+            f.write(f"{name}\t{ln}\t{off}\t70\t71\n")
+            off += ln + ln // 70 + 10
+
+
+@pytest.mark.gpu
+def test_merge_chromosome_restricts_reads_and_loci(oracle, tmp_path):
+    """merge --chromosome (merge.nim:52,89,101; unpack.nim:126; cluster.nim:139): the by-chromosome joint pipeline"""
+    bins, per_sample, frag, targets = _three_bins(oracle, tmp_path)
+    fa = str(tmp_path / "ref.fa")
+    _write_fai(fa, targets)
+    window, mcd = oracle.median(frag, 0.98), int(0.5 * oracle.median(frag, 0.5))
+    header = "#chrom\tleft\tright\trepeat\tname\tleft_most\tright_most\tcenter_mass\tn_left\tn_right\tn_total"
+    allt = np.concatenate(per_sample)
+    seen_rows = 0
+    for tid in (0, 7, len(targets) - 1):
+        prefix = str(tmp_path / f"chrom{tid}")
+        r = _run(["merge", "-m", "2", "-f", fa, "--chromosome", targets[tid][0], "-o", prefix] + bins)
+        assert r.returncode == 0, r.stderr
+        exp_b, _ = oracle.call_bounds(allt[allt["tid"] == tid], 0, window, min_support=2, max_clip_dist=mcd)
+        exp = [header] + [oracle.bounds_row(b, targets[int(b["tid"])][0]) for b in exp_b]
+        assert open(prefix + "-bounds.txt").read().rstrip("\n").split("\n") == exp
+        seen_rows += len(exp_b)
+    assert seen_rows > 0
+    # a -l BED keeps only the loci of that chromosome
+    bed = str(tmp_path / "loci.bed")
+    open(bed, "w").write(f"{targets[0][0]}\t1000\t1020\tCAG\tl0\n{targets[7][0]}\t2000\t2030\tAT\n")
+    prefix = str(tmp_path / "chrom_bed")
+    r = _run(["merge", "-m", "2", "-f", fa, "--chromosome", targets[7][0], "-l", bed, "-o", prefix] + bins)
+    assert r.returncode == 0, r.stderr
+    rows = open(prefix + "-bounds.txt").read().rstrip("\n").split("\n")
+    assert rows[1].split("\t")[:4] == [targets[7][0], "2000", "2030", "AT"] and all(x.split("\t")[0] == targets[7][0] for x in rows[1:])
+    # errors of get_tid(fasta, chromosome), merge.nim:36-45
+    r = _run(["merge", "-f", fa, "--chromosome", "nope", "-o", prefix] + bins)
+    assert r.returncode == 1 and "chromosome: nope not found in fasta" in r.stderr
+    r = _run(["merge", "-f", str(tmp_path / "missing.fa"), "--chromosome", "chr1", "-o", prefix] + bins)
+    assert r.returncode == 1 and "could not open fasta" in r.stderr
+
+
+@pytest.mark.gpu
+def test_merge_diff_refs(oracle, tmp_path):
+    """-d lets bins with differing headers through (merge.nim:60,107-108); chromosome names then come from the first bin, or
+    from the .fai of -f when both are given (merge.nim:84-86)"""
+    def targets_of(s, targets):
+        return targets if s != 1 else [(n + "_alt", ln) for n, ln in targets]
+    bins, per_sample, frag, targets = _three_bins(oracle, tmp_path, targets_of)
+    prefix = str(tmp_path / "d")
+    r = _run(["merge", "-m", "2", "-o", prefix] + bins)
+    assert r.returncode == 1 and "inconsistent bam header" in r.stderr
+    r = _run(["merge", "-m", "2", "-d", "-o", prefix] + bins)
+    assert r.returncode == 0, r.stderr
+    window, mcd = oracle.median(frag, 0.98), int(0.5 * oracle.median(frag, 0.5))
+    exp_b, _ = oracle.call_bounds(np.concatenate(per_sample), 0, window, min_support=2, max_clip_dist=mcd)
+    got = open(prefix + "-bounds.txt").read().rstrip("\n").split("\n")[1:]
+    assert got == [oracle.bounds_row(b, targets[int(b["tid"])][0]) for b in exp_b] and len(got) > 3
+    fa = str(tmp_path / "other.fa")
+    renamed = [("fa_" + n, ln) for n, ln in targets]
+    _write_fai(fa, renamed)
+    r = _run(["merge", "-m", "2", "-d", "-f", fa, "-o", prefix] + bins)
+    assert r.returncode == 0, r.stderr
+    got = open(prefix + "-bounds.txt").read().rstrip("\n").split("\n")[1:]
+    assert got == [oracle.bounds_row(b, renamed[int(b["tid"])][0]) for b in exp_b]
+
+
+@pytest.mark.gpu
+def test_cram_input_gets_the_reference_error(tmp_path):
+    """CRAM needs htslib's codec stack, which this build does not have: `couldn't open bam` like extract.nim:276"""
+    p = str(tmp_path / "x.cram")
+    open(p, "wb").write(b"CRAM\x03\x00" + b"\0" * 64)
+    r = _run(["extract", p, str(tmp_path / "x.bin")])
+    assert r.returncode == 1 and "couldn't open bam" in r.stderr
+
+
+def test_malformed_bgzf_blocks_are_rejected(tmp_path):
+    """a BC size smaller than the block's own header and an extra subfield running past XLEN: an error, not an allocation
+    of gigabytes / a read past the buffer (both readers)"""
+    import struct
+    rec, _ = synth.synth_wgs(50, seed=3, contig_len=100_000)
+    good = str(tmp_path / "g.bam")
+    bamio.write_bam(good, rec)
+    data = bytearray(open(good, "rb").read())
+    bad1 = bytes(data[:16]) + struct.pack("<H", 5) + bytes(data[18:])            # BSIZE - 1 = 5 < header size
+    bad2 = bytes(data[:14]) + struct.pack("<H", 200) + bytes(data[16:])          # subfield length 200 > XLEN
+    for i, b in enumerate((bad1, bad2)):
+        p = str(tmp_path / f"bad{i}.bam")
+        open(p, "wb").write(b)
+        for mode in ([], ["stream"]):
+            r = _run(["_dump", p] + mode)
+            assert r.returncode != 0 and ("BGZF" in r.stderr or "couldn't open" in r.stderr), r.stderr[-300:]
