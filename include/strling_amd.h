@@ -257,6 +257,16 @@ int strl_ctx_pair_times(strl_ctx *ctx, double ms[5]);
  * only knows an upper bound of the count would. */
 int strl_sort_pairs(strl_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t n, uint64_t n_max, int bit_lo, int bits);
 
+/* The pair rules on single treads, so that known-answer vectors (the reference's tests/test_extract.nim:7-19,
+ * tests/test_strling.nim:91-107, tests/test_utils.nim:66-74) can be run through the product's own code: with a context the
+ * DEVICE functions the replay kernel calls, with ctx == NULL the host twins the streaming pairer (strl_pairer_*) calls.
+ * ADJUST_BY: A.adjust_by(B, opts, B_position), extract.nim:141-179 -> *result = its return value, A updated.
+ * UNPLACED_PAIR: extract.nim:182-190 -> *result.  CANONICAL: A.repeat := canonical_repeat(A.repeat), utils.nim:304-316. */
+#define STRL_RULE_ADJUST_BY 0
+#define STRL_RULE_UNPLACED_PAIR 1
+#define STRL_RULE_CANONICAL 2
+int strl_pair_rule(strl_ctx *ctx, int op, strl_tread *A, const strl_tread *B, const strl_opts *opts, uint32_t B_position, int *result);
+
 /* 64-bit hash of every record's qname (out[n]).  Qname groups never interact in the pair logic, so a multi-GPU
  * run only has to bring together the records whose hash belongs to a group that can emit (strling_amd/dist.py). */
 int strl_qname_hash(const strl_records *rec, uint64_t *out);
@@ -299,6 +309,11 @@ int strl_cluster(strl_ctx *ctx, const strl_tread *treads, uint64_t n, int mode, 
 int strl_cluster_resident(strl_ctx *ctx, int mode, int32_t n_tid, int pos_bits, uint32_t window, int32_t min_support, uint16_t min_clip,
                           uint16_t min_clip_total, uint16_t max_clip_dist, strl_bounds *out, uint64_t cap, uint64_t *n_out,
                           strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced, strl_cluster_stats *stats);
+
+/* bounds() (cluster.nim:175-250) + the gate of callclusters.nim:52-66 on one bare cluster -- reads sorted by position,
+ * Cluster.left_most = right_most = 0 -- run by the device function the clustering kernels call.  *good = the gate's verdict. */
+int strl_bounds_bare(strl_ctx *ctx, const uint32_t *positions, const uint8_t *splits, uint32_t n, uint16_t min_clip, uint16_t min_clip_total,
+                     uint16_t max_clip_dist, strl_bounds *out, int *good);
 
 /* HIP-event times (ms) of the last clustering pass when timing is enabled: keys + sort + group tables | ends + walk | bounds */
 int strl_ctx_cluster_times(strl_ctx *ctx, double ms[3]);

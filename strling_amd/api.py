@@ -108,7 +108,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
            "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order",
-           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish"]
+           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare"]
 
 
 def lib_path():
@@ -178,6 +178,8 @@ def load(build_if_missing=True):
     L.strl_extract_begin.argtypes = [C.c_void_p, C.c_uint64]
     L.strl_extract_add.argtypes = [C.c_void_p, C.POINTER(CReadSoa), C.POINTER(CPairSoa)]
     L.strl_extract_finish.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64]
+    L.strl_pair_rule.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Opts), C.c_uint32, C.POINTER(C.c_int)]
+    L.strl_bounds_bare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint16, C.c_uint16, C.c_uint16, C.c_void_p, C.POINTER(C.c_int)]
     L.strl_pair_rows.argtypes = [C.POINTER(CRecords)] + [C.c_void_p] * 5
     L.strl_ctx_cluster_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 3)]
     L.strl_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
@@ -460,6 +462,15 @@ class Context:
             _check(rc)
             return out[:no.value].copy(), unpl[:nu.value].copy(), st
 
+    def bounds_bare(self, positions, splits, max_clip_dist, min_clip=0, min_clip_total=0):
+        """bounds() + gate of one bare cluster (strl_bounds_bare) -> (bounds record, good)"""
+        p = np.ascontiguousarray(positions, np.uint32)
+        sp = np.ascontiguousarray(splits, np.uint8)
+        out = np.zeros(1, BOUNDS_DTYPE)
+        good = C.c_int(0)
+        _check(self.L.strl_bounds_bare(self.h, p.ctypes.data, sp.ctypes.data, p.size, min_clip, min_clip_total, max_clip_dist, out.ctypes.data, C.byref(good)))
+        return out[0], bool(good.value)
+
     def cluster_times(self):
         ms = (C.c_double * 3)()
         _check(self.L.strl_ctx_cluster_times(self.h, C.byref(ms)))
@@ -504,6 +515,17 @@ def pair_reads(rec, opts, whole, soft, n_tail=-1):
             continue
         _check(rc)
         return out[:no.value].copy()
+
+
+def pair_rule(ctx, op, A, B, opts, B_position=0):
+    """one pair rule on single treads (strl_pair_rule): ctx = a Context (device code) or None (host twin).
+    op 0 adjust_by, 1 unplaced_pair, 2 canonical_repeat; opts = (p, min_mapq, median_fragment_length) -> (result, A after)"""
+    a = np.ascontiguousarray(A, TREAD_DTYPE).reshape(1).copy()
+    b = np.ascontiguousarray(B, TREAD_DTYPE).reshape(1).copy()
+    o = Opts(int(opts[2]), float(opts[0]), int(opts[1]))
+    res = C.c_int(0)
+    _check(load().strl_pair_rule(ctx.h if ctx is not None else None, op, a.ctypes.data, b.ctypes.data, C.byref(o), int(B_position), C.byref(res)))
+    return res.value, a[0]
 
 
 def _noop():

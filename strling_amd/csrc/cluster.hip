@@ -513,6 +513,12 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherParams G) {
   }
 }
 
+// bounds() + the callclusters gate on ONE bare cluster (Cluster.left_most = right_most = 0), reads [0, n) sorted by
+// position: what the reference's tests/test_cluster.nim bounds() vectors exercise
+__global__ void bounds_bare_kernel(ClusterParams P, uint32_t n, uint32_t *scratch, uint32_t cap) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) emit_bounds(P, GlobalView{P.pos, P.split, P.sample}, 0u, n, 0u, 0u, scratch, cap, P.out[0]);
+}
+
 static inline uint32_t base_code(char b, bool &ok) {
   switch (b) { case 'C': return 0; case 'A': return 1; case 'T': return 2; case 'G': return 3; default: ok = false; return 0; }
 }
@@ -763,6 +769,37 @@ static int cluster_collect(strl_ctx *c, const std::vector<std::pair<uint64_t, ui
   if (n_unplaced) *n_unplaced = nu;
   if (stats) stats->n_bounds = no;
   if (out && no > cap) { set_error("bounds capacity %llu too small, need %llu", (unsigned long long)cap, (unsigned long long)no); return STRL_ERR_CAPACITY; }
+  return STRL_OK;
+}
+
+extern "C" int strl_bounds_bare(strl_ctx *c, const uint32_t *positions, const uint8_t *splits, uint32_t n, uint16_t min_clip, uint16_t min_clip_total,
+                                uint16_t max_clip_dist, strl_bounds *out, int *good) {
+  if (!c || !positions || !splits || !out || !good || n == 0 || n > (1u << 20)) { set_error("bad argument"); return STRL_ERR_ARG; }
+  for (uint32_t i = 1; i < n; ++i) if (positions[i] < positions[i - 1]) { set_error("strl_bounds_bare: reads must be sorted by position"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  DevBuf buf;
+  const size_t sw = 4ull * (16ull + 3ull * n);
+  int rc;
+  if ((rc = buf.reserve((size_t)n * 9 + sw * 4 + sizeof(RawBounds) + 64))) return rc;
+  uint32_t *d_pos = buf.as<uint32_t>(), *d_sample = d_pos + n, *d_scratch = d_sample + n;
+  RawBounds *d_out = reinterpret_cast<RawBounds *>(d_scratch + sw);
+  uint8_t *d_split = reinterpret_cast<uint8_t *>(d_out + 1);
+  STRL_HIP(hipMemcpyAsync(d_pos, positions, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  STRL_HIP(hipMemsetAsync(d_sample, 0, (size_t)n * 4, c->stream));
+  STRL_HIP(hipMemcpyAsync(d_split, splits, n, hipMemcpyHostToDevice, c->stream));
+  ClusterParams P{};
+  P.pos = d_pos; P.split = d_split; P.sample = d_sample; P.out = d_out; P.mode = STRL_MODE_CALL; P.min_support = 0;
+  P.min_clip = min_clip; P.min_clip_total = min_clip_total; P.max_clip_dist = max_clip_dist;
+  hipLaunchKernelGGL(bounds_bare_kernel, dim3(1), dim3(64), 0, c->stream, P, n, d_scratch, 16u + 3u * n);
+  STRL_HIP(hipGetLastError());
+  RawBounds r{};
+  STRL_HIP(hipMemcpyAsync(&r, d_out, sizeof r, hipMemcpyDeviceToHost, c->stream));
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  buf.release();
+  memset(out, 0, sizeof *out);
+  *good = (int)r.valid;
+  out->left = r.left; out->left_most = r.left_most; out->right = r.right; out->right_most = r.right_most; out->center_mass = r.center_mass;
+  out->n_left = r.n_left; out->n_right = r.n_right; out->n_total = r.n_total;
   return STRL_OK;
 }
 

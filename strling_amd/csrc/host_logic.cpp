@@ -756,6 +756,16 @@ int strl_bin_read(const char *path, strl_bin_info *info, char *sam_header, strl_
   return STRL_OK;
 }
 
+extern "C" int strl_pair_rule_device(strl_ctx *c, int op, strl_tread *A, const strl_tread *B, const strl_opts *o, uint32_t B_position, int *result);
+int strl_pair_rule(strl_ctx *c, int op, strl_tread *A, const strl_tread *B, const strl_opts *o, uint32_t B_position, int *result) {
+  if (c) return strl_pair_rule_device(c, op, A, B, o, B_position, result);
+  if (!A || !B || !o || !result || op < 0 || op > 2) { set_error("bad argument"); return STRL_ERR_ARG; }
+  if (op == STRL_RULE_ADJUST_BY) *result = adjust_by(*A, *B, *o, B_position) ? 1 : 0;
+  else if (op == STRL_RULE_UNPLACED_PAIR) *result = unplaced_pair(*A, *B, *o) ? 1 : 0;
+  else { canonical_repeat(A->repeat); *result = 0; }
+  return STRL_OK;
+}
+
 void strl_canonical_repeat(const char in[6], char out[6]) {   // utils.nim:304-316
   memcpy(out, in, 6);
   canonical_repeat(out);

@@ -535,9 +535,57 @@ __global__ __launch_bounds__(256) void pair_order_kernel(const uint32_t *pc, uin
   dst[1] = src[1];
 }
 
+// The pair rules on single treads, for known-answer tests of exactly the device functions the replay calls
+__device__ inline DTread dtread_from(const strl_tread &t) {
+  DTread d{};
+  d.tid = t.tid; d.position = t.position; d.flag = t.flag; d.split = t.split; d.mapq = t.mapping_quality; d.count = t.repeat_count;
+  d.align_length = t.align_length; d.qid = (uint32_t)t.qname_id;
+  for (int j = 0; j < 6 && t.repeat[j]; ++j) {
+    uint32_t c = 1;
+    switch (t.repeat[j]) { case 'C': c = 0; break; case 'A': c = 1; break; case 'T': c = 2; break; case 'G': c = 3; break; }
+    d.code = (d.code << 2) | c;
+    ++d.k;
+  }
+  return d;
+}
+__device__ inline void dtread_to(const DTread &d, strl_tread &t) {
+  t.tid = d.tid; t.position = d.position; t.flag = d.flag; t.split = d.split; t.mapping_quality = d.mapq; t.repeat_count = d.count;
+  t.align_length = d.align_length;
+  for (int j = 0; j < 6; ++j) t.repeat[j] = (uint32_t)j < d.k ? "CATG"[(d.code >> (2 * (d.k - 1 - j))) & 3u] : (char)0;
+}
+__global__ void pair_rules_kernel(int op, strl_tread *A, const strl_tread *B, PairParams P, uint32_t B_position, int *res) {
+  DTread a = dtread_from(*A);
+  const DTread b = dtread_from(*B);
+  if (op == 0) *res = adjust_by(a, b, P, B_position) ? 1 : 0;
+  else if (op == 1) *res = unplaced_pair(a, b, P) ? 1 : 0;
+  else { a.code = canonical_repeat(a.code, a.k); *res = 0; }
+  dtread_to(a, *A);
+}
+
 }  // namespace strl
 
 using namespace strl;
+
+extern "C" int strl_pair_rule_device(strl_ctx *c, int op, strl_tread *A, const strl_tread *B, const strl_opts *o, uint32_t B_position, int *result) {
+  if (!c || !A || !B || !o || !result || op < 0 || op > 2) { set_error("bad argument"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  DevBuf buf;
+  int rc;
+  if ((rc = buf.reserve(2 * sizeof(strl_tread) + 16))) return rc;
+  strl_tread *dA = buf.as<strl_tread>(), *dB = dA + 1;
+  int *dres = reinterpret_cast<int *>(dB + 1);
+  STRL_HIP(hipMemcpyAsync(dA, A, sizeof *A, hipMemcpyHostToDevice, c->stream));
+  STRL_HIP(hipMemcpyAsync(dB, B, sizeof *B, hipMemcpyHostToDevice, c->stream));
+  PairParams P{};
+  P.p = o->proportion_repeat; P.min_mapq = o->min_mapq; P.frag_median = o->median_fragment_length;
+  hipLaunchKernelGGL(pair_rules_kernel, dim3(1), dim3(1), 0, c->stream, op, dA, dB, P, B_position, dres);
+  STRL_HIP(hipGetLastError());
+  STRL_HIP(hipMemcpyAsync(A, dA, sizeof *A, hipMemcpyDeviceToHost, c->stream));
+  STRL_HIP(hipMemcpyAsync(result, dres, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  buf.release();
+  return STRL_OK;
+}
 
 // Enqueue the pair logic behind a scoring pass of the same batch (score_device has run on c->stream with the pairing
 // arrays given, so the whole-read marks are in the bitmap).  Everything is asynchronous; results stay on the device:

@@ -246,7 +246,8 @@ def _chunk_worker(a):
 def synth_wgs_chunks(n_chunks, pairs_per_chunk, seed=1234, procs=None, **kw):
     """A large S1 batch of DISTINCT reads: n_chunks independent synth_wgs samples (seed + chunk), each on its own set of
     contigs, generated by a pool of worker processes and merged into one coordinate-sorted batch with one unmapped tail.
-    Deterministic in (n_chunks, pairs_per_chunk, seed).  Call before anything initialises the GPU runtime (fork)."""
+    Deterministic in (n_chunks, pairs_per_chunk, seed).  The workers are forked and only run numpy (they never touch the GPU
+    runtime the parent may have initialised)."""
     import multiprocessing as mp
     import os
     jobs = [(pairs_per_chunk, seed + c, c * pairs_per_chunk, kw) for c in range(n_chunks)]

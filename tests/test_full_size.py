@@ -121,3 +121,47 @@ def test_joint_merge_at_s2_scale(ctx, oracle):
         got = np.sort(np.array([tuple([int(x["tid"]) - k * n_contigs] + [x[f] for f in fields]) for x in bk], dtype=exp_sorted.dtype))
         assert np.array_equal(got, exp_sorted), k
     print(f"S2 scale: {len(t)} treads, {st.n_groups} groups, {st.n_clusters} clusters, {len(b)} bounds in {dt:.2f} s (host keys + device pass + row order)")
+
+
+def test_full_size_distinct_reads_whole_path_matches_the_oracle(oracle):
+    """BASELINE.json configs[1]+[2] at full size without tiling: 2^25 DISTINCT reads (64 independent sub-samples merged into
+    one coordinate-sorted batch) through the whole device path -- scorer, soft-clip scan, pair logic, clustering -- and the
+    oracle over the same 2^25 records: identical treads (same order) and identical -bounds rows.  Plus the scorer words of
+    16 random 2^16-read slices, read by read."""
+    rng = np.random.default_rng(99)
+    rec, g = synth.synth_wgs_chunks(64, 2 ** 18, seed=4321)
+    assert rec.n == 2 ** 25
+    frag = synth.frag_hist(rec)
+    med = api.frag_median(frag)
+    window, mcd = api.frag_median(frag, 0.99), int(0.5 * api.frag_median(frag, 0.5))
+    ctx = api.Context(0)
+    ctx.set_opts(0.8, 40, med)
+    ctx.set_genome(g)
+    soa = api.Soa(rec)
+    rows, qh = soa.pair_rows()
+    n_tail = int((rec.tid < 0).sum())
+    ctx.extract_device(soa.c_struct(), api.CPairSoa(rows.ctypes.data, qh.ctypes.data), n_tail)
+    got, st = ctx.treads_fetch()
+    b, u, cst = ctx.cluster_resident(len(rec.targets), window, min_support=5, max_clip_dist=mcd, pos_bits=24)
+    opts = oracle.make_opts(med, 0.8, 40)
+    exp = oracle.extract(rec, g, opts)
+    assert len(exp) > 400_000
+    for f in ("tid", "position", "repeat", "flag", "split", "mapping_quality", "repeat_count", "align_length", "qname_id"):
+        assert np.array_equal(np.asarray(got[f]), np.asarray(exp[f])), f
+    eb, eu = oracle.call_bounds(exp, 1, window, min_support=5, max_clip_dist=mcd)
+    assert len(eb) > 3000 and len(b) == len(eb)
+    for f in ("tid", "left", "right", "left_most", "right_most", "center_mass", "n_left", "n_right", "n_total", "repeat"):
+        assert np.array_equal(b[f], eb[f]), f                       # same rows in the reference's row order
+    assert [(x["repeat"].decode(), int(x["count"])) for x in u] == [(r, int(k)) for r, k in eu]
+    assert st.n_reads == rec.n and st.n_scored + st.n_skipped == rec.n
+    # scorer words of random slices, every read
+    for a in rng.integers(0, rec.n - 2 ** 16, size=16):
+        part = rec.slice(int(a), int(a) + 2 ** 16)
+        whole, soft, _ = ctx.score_reads(part)
+        exp_whole, exp_soft = oracle_words(oracle, part, g, opts)
+        assert np.array_equal(whole, exp_whole), int(a)
+        items = soft_items_expected(part, exp_whole, 40)
+        assert soft["read_side"].tolist() == [(i << 1) | s for i, s in items]
+        assert soft["res_first"].tolist() == [exp_soft[it][0] for it in items]
+        assert soft["res_after"].tolist() == [exp_soft[it][1] for it in items]
+    ctx.close()
