@@ -310,6 +310,20 @@ int strl_cluster_resident(strl_ctx *ctx, int mode, int32_t n_tid, int pos_bits, 
                           uint16_t min_clip_total, uint16_t max_clip_dist, strl_bounds *out, uint64_t cap, uint64_t *n_out,
                           strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced, strl_cluster_stats *stats);
 
+/* ---- multi-GPU clustering (one process per GPU) ----
+ * The device buffer strl_extract_device left its treads in: *treads (strl_tread[*cap]) and *count (uint32 on the device).
+ * A host framework (torch.distributed over RCCL) all-gathers these buffers; nothing is copied to the host. */
+int strl_ctx_treads_device(strl_ctx *ctx, void **treads, uint64_t *cap, void **count);
+/* `gathered` (device) = world x pad treads, rank-major: rank r's treads are gathered[r * pad .. r * pad + counts[r]) with
+ * counts (device, uint32[world]) -- what all_gather_into_tensor over the ranks' padded tread buffers produces.  This rank
+ * keeps the treads of the (tid, unit) groups it owns (a hash of the key modulo world, computed on the device), in global
+ * (rank, .bin) order, and clusters them like strl_cluster_resident.  Rows of different ranks are disjoint sets of groups;
+ * strl_group_order over all treads gives the reference's order of the groups. */
+int strl_cluster_gathered(strl_ctx *ctx, const strl_tread *gathered, const uint32_t *counts, int world, uint32_t pad, int rank, int mode,
+                          int32_t n_tid, int pos_bits, uint32_t window, int32_t min_support, uint16_t min_clip, uint16_t min_clip_total,
+                          uint16_t max_clip_dist, strl_bounds *out, uint64_t cap, uint64_t *n_out, strl_unplaced *unplaced,
+                          uint64_t unplaced_cap, uint64_t *n_unplaced, strl_cluster_stats *stats);
+
 /* bounds() (cluster.nim:175-250) + the gate of callclusters.nim:52-66 on one bare cluster -- reads sorted by position,
  * Cluster.left_most = right_most = 0 -- run by the device function the clustering kernels call.  *good = the gate's verdict. */
 int strl_bounds_bare(strl_ctx *ctx, const uint32_t *positions, const uint8_t *splits, uint32_t n, uint16_t min_clip, uint16_t min_clip_total,

@@ -108,7 +108,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
            "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order",
-           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare"]
+           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered"]
 
 
 def lib_path():
@@ -180,6 +180,10 @@ def load(build_if_missing=True):
     L.strl_extract_finish.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64]
     L.strl_pair_rule.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Opts), C.c_uint32, C.POINTER(C.c_int)]
     L.strl_bounds_bare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint16, C.c_uint16, C.c_uint16, C.c_void_p, C.POINTER(C.c_int)]
+    L.strl_ctx_treads_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)]
+    L.strl_cluster_gathered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int32, C.c_int, C.c_uint32,
+                                        C.c_int32, C.c_uint16, C.c_uint16, C.c_uint16, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
+                                        C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(ClusterStats)]
     L.strl_pair_rows.argtypes = [C.POINTER(CRecords)] + [C.c_void_p] * 5
     L.strl_ctx_cluster_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 3)]
     L.strl_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
@@ -475,6 +479,34 @@ class Context:
         ms = (C.c_double * 3)()
         _check(self.L.strl_ctx_cluster_times(self.h, C.byref(ms)))
         return dict(zip(["cluster_keys_sort_groups", "cluster_sweep", "cluster_bounds"], list(ms)))
+
+    def treads_device(self):
+        """(device pointer of the resident treads, capacity in treads, device pointer of their uint32 count)"""
+        p, cap, cnt = C.c_void_p(), C.c_uint64(0), C.c_void_p()
+        _check(self.L.strl_ctx_treads_device(self.h, C.byref(p), C.byref(cap), C.byref(cnt)))
+        return p.value, cap.value, cnt.value
+
+    def cluster_gathered(self, gathered_ptr, counts_ptr, world, pad, rank, n_tid, window, min_support=5, min_clip=0, min_clip_total=0,
+                         max_clip_dist=200, pos_bits=0, mode=MODE_CALL, fetch=True):
+        """this rank's share of an all-gathered tread set (strl_cluster_gathered); fetch=False only enqueues the kernels"""
+        if not fetch:
+            _check(self.L.strl_cluster_gathered(self.h, gathered_ptr, counts_ptr, world, pad, rank, mode, n_tid, pos_bits, window, min_support,
+                                                min_clip, min_clip_total, max_clip_dist, None, 0, None, None, 0, None, None))
+            return None
+        cap = 1 << 16
+        while True:
+            out = np.zeros(cap, BOUNDS_DTYPE)
+            unpl = np.zeros(8192, UNPLACED_DTYPE)
+            no, nu = C.c_uint64(0), C.c_uint64(0)
+            st = ClusterStats()
+            rc = self.L.strl_cluster_gathered(self.h, gathered_ptr, counts_ptr, world, pad, rank, mode, n_tid, pos_bits, window, min_support,
+                                              min_clip, min_clip_total, max_clip_dist, out.ctypes.data, cap, C.byref(no), unpl.ctypes.data,
+                                              unpl.size, C.byref(nu), C.byref(st))
+            if rc == -4 and no.value > cap:
+                cap = int(no.value)
+                continue
+            _check(rc)
+            return out[:no.value].copy(), unpl[:nu.value].copy(), st
 
     def cluster_members(self, n_bounds):
         """indices (into the tread array of the last cluster() call) of every returned bound's reads, cluster order"""

@@ -519,6 +519,51 @@ __global__ void bounds_bare_kernel(ClusterParams P, uint32_t n, uint32_t *scratc
   if (threadIdx.x == 0 && blockIdx.x == 0) emit_bounds(P, GlobalView{P.pos, P.split, P.sample}, 0u, n, 0u, 0u, scratch, cap, P.out[0]);
 }
 
+// ---- multi-GPU: the share of an all-gathered tread set this rank clusters ------------------------------------------
+// owner of a (tid, unit) group: any function of the key works, groups never interact (strling_amd/dist.py group_owner)
+__device__ __forceinline__ uint32_t group_owner(const strl_tread &t, uint32_t world) {
+  uint64_t h = (uint64_t)(int64_t)t.tid * 0x9E3779B97F4A7C15ull;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) h = (h ^ (uint64_t)(uint8_t)t.repeat[j]) * 0x100000001B3ull;
+  return (uint32_t)((h >> 17) % (uint64_t)world);
+}
+// gathered = world x pad treads, rank-major, rank r's treads in [r * pad, r * pad + counts[r]).  key 0 = mine, 1 = not
+// mine / padding; a stable one-bit sort then brings my treads to the front in global (rank, .bin) order.
+__global__ __launch_bounds__(1024) void owned_keys_kernel(const strl_tread *gathered, const uint32_t *counts, uint32_t world, uint32_t pad, uint32_t rank,
+                                                          uint64_t *key, uint32_t *val, uint32_t *n_total, uint32_t *n_owned, uint32_t *err) {
+  __shared__ uint32_t wcnt[16];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t tot = world * pad;
+  bool mine = false;
+  if (i < tot) {
+    const uint32_t r = i / pad, j = i - r * pad;
+    const uint32_t c = counts[r];
+    if (j == 0 && c > pad) atomicOr(err, CERR_CAND);
+    if (j < (c < pad ? c : pad)) mine = group_owner(gathered[i], world) == rank;
+    key[i] = mine ? 0ull : 1ull;
+    val[i] = i;
+  }
+  if (i == 0) *n_total = tot;
+  const unsigned long long m = __ballot(mine);
+  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < 16; ++w) t += wcnt[w];
+    if (t) atomicAdd(n_owned, t);
+  }
+}
+__global__ void owned_gather_kernel(const strl_tread *gathered, const uint32_t *perm, const uint32_t *n_owned, uint32_t n_max, strl_tread *out) {
+  uint32_t n = *n_owned;
+  if (n > n_max) n = n_max;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4 *src = reinterpret_cast<const uint4 *>(gathered + perm[i]);
+  uint4 *dst = reinterpret_cast<uint4 *>(out + i);
+  dst[0] = src[0];
+  dst[1] = src[1];
+}
+
 static inline uint32_t base_code(char b, bool &ok) {
   switch (b) { case 'C': return 0; case 'A': return 1; case 'T': return 2; case 'G': return 3; default: ok = false; return 0; }
 }
@@ -847,6 +892,63 @@ extern "C" int strl_cluster_resident(strl_ctx *c, int mode, int32_t n_tid, int p
   int rc;
   if ((rc = cluster_device_pass(c, R.treads, R.d_n))) return rc;
   if (!out && !n_out && !stats && !n_unplaced) return STRL_OK;      // asynchronous: results stay on the device
+  return cluster_collect(c, {}, out, cap, n_out, unplaced, unplaced_cap, n_unplaced, stats);
+}
+
+extern "C" int strl_ctx_treads_device(strl_ctx *c, void **treads, uint64_t *cap, void **count) {
+  if (!c || !c->n_treads_dev) { set_error("strl_ctx_treads_device: no strl_extract_device call on this context"); return STRL_ERR_ARG; }
+  if (treads) *treads = c->treads.p;
+  if (cap) *cap = c->tread_cap;
+  if (count) *count = c->n_treads_dev;
+  return STRL_OK;
+}
+
+extern "C" int strl_cluster_gathered(strl_ctx *c, const strl_tread *gathered, const uint32_t *counts, int world, uint32_t pad, int rank, int mode,
+                                     int32_t n_tid, int pos_bits, uint32_t window, int32_t min_support, uint16_t min_clip, uint16_t min_clip_total,
+                                     uint16_t max_clip_dist, strl_bounds *out, uint64_t cap, uint64_t *n_out, strl_unplaced *unplaced,
+                                     uint64_t unplaced_cap, uint64_t *n_unplaced, strl_cluster_stats *stats) {
+  if (!c || !gathered || !counts || world < 1 || rank < 0 || rank >= world || pad == 0) { set_error("bad argument"); return STRL_ERR_ARG; }
+  if ((uint64_t)world * pad > 0x7ffffff0ull || n_tid < 0 || pos_bits < 0 || pos_bits > 32) { set_error("bad argument"); return STRL_ERR_ARG; }
+  if (n_out) *n_out = 0;
+  if (n_unplaced) *n_unplaced = 0;
+  if (stats) memset(stats, 0, sizeof *stats);
+  STRL_HIP(hipSetDevice(c->device));
+  const uint32_t tot = (uint32_t)world * pad;
+  strl::DevBuf *B = c->c_buf;
+  hipStream_t st = c->stream;
+  int rc;
+  if ((rc = B[B_TREADS].reserve((size_t)tot * sizeof(strl_tread))) || (rc = B[B_CNT].reserve(CC_WORDS * 4)) || (rc = B[B_KEY0].reserve((size_t)tot * 8)) ||
+      (rc = B[B_KEY1].reserve((size_t)tot * 8)) || (rc = B[B_VAL0].reserve((size_t)tot * 4)) || (rc = B[B_VAL1].reserve((size_t)tot * 4)) ||
+      (rc = B[B_SORT].reserve(radix_sort_scratch_bytes(tot, 64))) || (rc = c->g_aux.reserve(256)))
+    return rc;
+  // counters of the partition live next to the clustering counters: [CC_N] = owned count, scratch words for total / error
+  uint32_t *cnt = B[B_CNT].as<uint32_t>();
+  uint32_t *aux = c->g_aux.as<uint32_t>();          // [0] total, [1] error flag of the partition
+  STRL_HIP(hipMemsetAsync(cnt, 0, 4, st));
+  STRL_HIP(hipMemsetAsync(aux, 0, 8, st));
+  hipLaunchKernelGGL(owned_keys_kernel, dim3((tot + 1023) / 1024), dim3(1024), 0, st, gathered, counts, (uint32_t)world, pad, (uint32_t)rank,
+                     B[B_KEY0].as<uint64_t>(), B[B_VAL0].as<uint32_t>(), aux, cnt + CC_N, aux + 1);
+  uint64_t *sk = nullptr;
+  uint32_t *sv = nullptr;
+  const int e = radix_sort_pairs(st, aux, tot, B[B_KEY0].as<uint64_t>(), B[B_VAL0].as<uint32_t>(), B[B_KEY1].as<uint64_t>(), B[B_VAL1].as<uint32_t>(),
+                                 B[B_SORT].p, B[B_SORT].cap, 0, 1, &sk, &sv);
+  if (e) { set_error("radix_sort_pairs failed: %s", hipGetErrorString((hipError_t)e)); return STRL_ERR_HIP; }
+  hipLaunchKernelGGL(owned_gather_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, gathered, sv, cnt + CC_N, tot, B[B_TREADS].as<strl_tread>());
+  STRL_HIP(hipGetLastError());
+  ClusterRun &R = c->cl_run;
+  R = ClusterRun{};
+  R.n_max = tot; R.n_tid = n_tid; R.mode = mode; R.window = window; R.min_support = min_support; R.min_clip = min_clip;
+  R.min_clip_total = min_clip_total; R.max_clip_dist = max_clip_dist;
+  R.pos_bits = pos_bits ? pos_bits : 32;
+  R.kbits = bits_for((uint64_t)n_tid) + 15;
+  R.composite = R.pos_bits + R.kbits <= 64;
+  R.treads = B[B_TREADS].as<strl_tread>(); R.d_n = cnt + CC_N;
+  if ((rc = cluster_device_pass(c, R.treads, R.d_n))) return rc;
+  if (!out && !n_out && !stats && !n_unplaced) return STRL_OK;
+  uint32_t perr = 0;
+  STRL_HIP(hipMemcpyAsync(&perr, aux + 1, 4, hipMemcpyDeviceToHost, st));
+  STRL_HIP(hipStreamSynchronize(st));
+  if (perr) { set_error("strl_cluster_gathered: a rank sent more treads than `pad`"); return STRL_ERR_CAPACITY; }
   return cluster_collect(c, {}, out, cap, n_out, unplaced, unplaced_cap, n_unplaced, stats);
 }
 

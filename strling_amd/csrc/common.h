@@ -99,7 +99,7 @@ struct strl_ctx {
   uint32_t tread_cap = 0, pair_item_cap = 0;
   uint64_t ex_n = 0, ex_soft_cap = 0;
   // chunked extract (strl_extract_begin / _add / _finish): per-read state of all chunks so far
-  strl::DevBuf x_rows, x_qhash, x_whole, x_soft, x_cnt;
+  strl::DevBuf x_rows, x_qhash, x_whole, x_soft, x_cnt, g_aux;
   uint64_t x_n = 0, x_soft_cap = 0;
   bool x_open = false, x_mode = false;
   hipEvent_t pev[6] = {};

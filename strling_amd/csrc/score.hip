@@ -690,7 +690,7 @@ void strl_ctx_destroy(strl_ctx *c) {
                           &c->soft_tmp, &c->sb_whole, &c->sb_soft, &c->queue_r, &c->soft_dense, &c->sb_state_w, &c->sb_state_s, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
                           &c->st_mapq, &c->st_cig, &c->st_seq4, &c->st_whole, &c->st_soft, &c->st_text,
                           &c->p_key0, &c->p_key1, &c->p_val0, &c->p_val1, &c->p_emit, &c->sort_scratch, &c->pair_cnt, &c->bloom, &c->treads,
-                          &c->st_mtid, &c->st_mpos, &c->st_flag, &c->st_qhash, &c->x_rows, &c->x_qhash, &c->x_whole, &c->x_soft, &c->x_cnt};
+                          &c->st_mtid, &c->st_mpos, &c->st_flag, &c->st_qhash, &c->x_rows, &c->x_qhash, &c->x_whole, &c->x_soft, &c->x_cnt, &c->g_aux};
   for (auto *b : bufs) b->release();
   for (auto &b : c->c_buf) b.release();
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);

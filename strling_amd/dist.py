@@ -138,3 +138,78 @@ def cluster_sharded(cluster_fn, treads_local, mode, group=None):
     key_b = np.array([order[(int(x["tid"]), bytes(x["repeat"]))] for x in bs], np.int64) if len(bs) else np.zeros(0, np.int64)
     key_u = np.array([order[(-1, bytes(x["repeat"]))] for x in us], np.int64) if len(us) else np.zeros(0, np.int64)
     return bs[np.argsort(key_b, kind="stable")], us[np.argsort(key_u, kind="stable")]
+
+
+class _DevArray:
+    """a device buffer of the C ABI as something torch.as_tensor can wrap (zero copy)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class DeviceClusterExchange:
+    """The multi-GPU clustering step on DEVICE buffers: every rank's resident treads (what
+    strl_extract_device left in its context) are all-gathered as padded device tensors -- RCCL over xGMI with the "nccl"
+    backend; with "gloo" (tests, dry runs) the same tensors are staged through the host, since gloo has no device all-gather --
+    and every rank clusters the (tid, unit) groups it owns: the owner filter, the order-preserving compaction and the
+    clustering all run on the device (strl_cluster_gathered).  The same object serves bench.py and tests/test_dist.py."""
+
+    def __init__(self, ctx, world, rank, n_treads_hint, dev, group=None):
+        import torch
+        self.ctx, self.world, self.rank, self.group, self.dev = ctx, world, rank, group, dev
+        pad = torch.tensor([int(n_treads_hint * 1.25) + 4096], dtype=torch.int64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(pad, op=dist.ReduceOp.MAX, group=group)          # ranks hold different samples: pad to the largest
+        self.pad = int(pad.item())
+        self.t_local = torch.zeros(self.pad * 32, dtype=torch.uint8, device=dev)
+        self.t_all = torch.zeros(world * self.pad * 32, dtype=torch.uint8, device=dev)
+        self.c_all = torch.zeros(world, dtype=torch.int32, device=dev)
+        self.stream = torch.cuda.ExternalStream(ctx.stream)                # the context's own stream: kernels and collectives in order
+
+    def gather(self):
+        import torch
+        ptr, cap, cnt = self.ctx.treads_device()
+        src = torch.as_tensor(_DevArray(ptr, cap * 32), device=self.dev)
+        c_local = torch.as_tensor(_DevArray(cnt, 4), device=self.dev).view(torch.int32)
+        with torch.cuda.stream(self.stream):
+            m = min(self.pad, cap) * 32
+            self.t_local[:m].copy_(src[:m])
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_gather_into_tensor(self.t_all, self.t_local, group=self.group)
+                dist.all_gather_into_tensor(self.c_all, c_local, group=self.group)
+            else:                                                            # gloo: no device all-gather -- stage through the host
+                th, ch = self.t_local.cpu(), c_local.cpu()
+                ta, ca = torch.empty(self.world * th.numel(), dtype=torch.uint8), torch.empty(self.world, dtype=torch.int32)
+                dist.all_gather_into_tensor(ta, th, group=self.group)
+                dist.all_gather_into_tensor(ca, ch, group=self.group)
+                self.t_all.copy_(ta)
+                self.c_all.copy_(ca)
+
+    def step(self, n_tid, window, min_support, max_clip_dist, pos_bits=0, fetch=False):
+        """gather + cluster my share; fetch=False: everything stays enqueued on the context stream"""
+        self.gather()
+        return self.ctx.cluster_gathered(self.t_all.data_ptr(), self.c_all.data_ptr(), self.world, self.pad, self.rank, n_tid, window,
+                                         min_support=min_support, max_clip_dist=max_clip_dist, pos_bits=pos_bits, fetch=fetch)
+
+    def gathered_treads(self):
+        """all ranks' treads in global (rank, .bin) order as a host array (for the final row order, strl_group_order)"""
+        import torch
+        torch.cuda.synchronize()
+        c = self.c_all.cpu().numpy()
+        raw = self.t_all.cpu().numpy().view(api.TREAD_DTYPE)
+        return np.concatenate([raw[r * self.pad: r * self.pad + int(c[r])] for r in range(self.world)])
+
+
+def cluster_sharded_device(ex, mode_call_args, n_tid):
+    """Whole multi-GPU clustering through a DeviceClusterExchange: my share on the device, then the rows of all ranks in the
+    reference's row order (identical on every rank).  mode_call_args = dict(window=, min_support=, max_clip_dist=, pos_bits=)."""
+    b, u, _ = ex.step(n_tid, mode_call_args["window"], mode_call_args["min_support"], mode_call_args["max_clip_dist"],
+                      mode_call_args.get("pos_bits", 0), fetch=True)
+    rows = [None] * ex.world
+    dist.all_gather_object(rows, (b, u), group=ex.group)
+    all_t = ex.gathered_treads()
+    order = {k: i for i, k in enumerate(api.group_order(all_t, api.MODE_CALL))}
+    bs = np.concatenate([r[0] for r in rows])
+    us = np.concatenate([r[1] for r in rows])
+    key_b = np.array([order[(int(x["tid"]), bytes(x["repeat"]))] for x in bs], np.int64) if len(bs) else np.zeros(0, np.int64)
+    key_u = np.array([order[(-1, bytes(x["repeat"]))] for x in us], np.int64) if len(us) else np.zeros(0, np.int64)
+    return bs[np.argsort(key_b, kind="stable")], us[np.argsort(key_u, kind="stable")]

@@ -130,3 +130,62 @@ def test_sharded_clustering_row_order_matches_single_process():
 @pytest.mark.gpu
 def test_sharded_clustering_on_the_device():
     _run_cluster(True)
+
+
+def _device_exchange_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from strling_amd import api, dist as sdist, synth
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        recs = [synth.synth_wgs(12000, seed=500 + r, contig_len=1_500_000) for r in range(world)]     # every rank could make all of them
+        frag = synth.frag_hist(recs[0][0])
+        med, window, mcd = O.median(frag), O.median(frag, 0.99), int(0.5 * O.median(frag, 0.5))
+        rec, g = recs[rank]
+        ctx = api.Context(0)
+        ctx.set_opts(0.8, 40, med)
+        ctx.set_genome(g)
+        soa = api.Soa(rec)
+        rows, qh = soa.pair_rows()
+        ctx.extract_device(soa.c_struct(), api.CPairSoa(rows.ctypes.data, qh.ctypes.data), int((rec.tid < 0).sum()))
+        mine, _ = ctx.treads_fetch()
+        ex = sdist.DeviceClusterExchange(ctx, world, rank, len(mine), dev)
+        b, u = sdist.cluster_sharded_device(ex, dict(window=window, min_support=3, max_clip_dist=mcd, pos_bits=22), len(rec.targets))
+        # single-process answer: the treads of all ranks in rank order through the oracle
+        opts = O.make_opts(med, 0.8, 40)
+        all_t = np.concatenate([O.extract(r, gg, opts) for r, gg in recs])
+        eb, eu = O.call_bounds(all_t, 1, window, min_support=3, max_clip_dist=mcd)
+        rows_got = [api.bounds_row(x, f"chr{int(x['tid']) + 1}") for x in b]
+        rows_exp = [O.bounds_row(x, f"chr{int(x['tid']) + 1}") for x in eb]
+        ok = rows_got == rows_exp and len(rows_exp) > 10 and [(x["repeat"].decode(), int(x["count"])) for x in u] == [(r, int(k)) for r, k in eu]
+        # the asynchronous form (what bench.py times) leaves the same share on the device
+        ex.step(len(rec.targets), window, 3, mcd, 22, fetch=False)
+        ctx.sync()
+        q.put((rank, bool(ok), len(rows_got), len(rows_exp)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_device_tread_exchange_and_owned_clustering():
+    """world size 2 on one GPU: both ranks extract their own sample on the device, all-gather the resident tread buffers
+    (gloo here, RCCL in bench.py -- same DeviceClusterExchange object), cluster the groups they own on the device; the merged
+    rows equal the oracle's rows for the union, in the reference's order"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_device_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, ok, n, ne in res:
+        assert ok and n == ne, (rank, ok, n, ne)
