@@ -8,6 +8,44 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+
+# ---- calibration run (tools/calib_traffic.hip): counter bytes / known bytes per access shape --------------------
+calib = {}
+try:
+    known = json.load(open(os.path.join(root, "calib_bytes.json")))["bytes"]
+    raw = defaultdict(lambda: defaultdict(list))
+    for d, ctr in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
+        for path in glob.glob(os.path.join(root, d, "**", "run_counter_collection.csv"), recursive=True):
+            disp = defaultdict(float)
+            for row in csv.DictReader(open(path)):
+                if row["Counter_Name"] == ctr:
+                    disp[(row["Kernel_Name"], row["Dispatch_Id"])] += float(row["Counter_Value"])
+            for (name, _), v in disp.items():
+                raw[name][ctr].append(v)
+    for name, cs in raw.items():
+        key = next((k for k in known if name.startswith(k) or k in name), None)
+        if key is None:
+            continue
+        kb = known[key]
+        ent = {"known_bytes": kb}
+        for ctr, vs in cs.items():
+            ent[ctr + "_KiB"] = round(sum(vs) / len(vs), 1)
+        f = ent.get("FETCH_SIZE_KiB", 0.0) * 1024
+        w = ent.get("WRITE_SIZE_KiB", 0.0) * 1024
+        if isinstance(kb, dict):
+            ent["fetch_over_element_bytes"] = round(f / (kb["elements"] + kb["index"]), 3)
+            ent["fetch_over_line_bytes"] = round(f / (kb["lines64"] + kb["index"]), 3)
+        elif "store" in key:
+            ent["write_over_known"] = round(w / kb, 3)
+        else:
+            ent["fetch_over_known"] = round(f / kb, 3)
+        calib[key] = ent
+    json.dump({"note": "rocprofv3 FETCH_SIZE / WRITE_SIZE (KiB, raw) of tools/calib_traffic.hip against the bytes each kernel must move; "
+                       "fetch_over_known ~0.5 confirms the guide's x2 correction for wide streaming reads on gfx950",
+               "kernels": calib}, open(os.path.join(root, "calibration.json"), "w"), indent=1)
+except Exception as e:
+    print("no calibration:", e)
+
 per = defaultdict(lambda: defaultdict(list))
 for d in ("fetch", "write", "pmc1", "pmc2"):
     for path in glob.glob(os.path.join(root, d, "**", "run_counter_collection.csv"), recursive=True):
