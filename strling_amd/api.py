@@ -108,7 +108,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
            "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order",
-           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered"]
+           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered", "strl_inflate_blocks"]
 
 
 def lib_path():
@@ -184,6 +184,7 @@ def load(build_if_missing=True):
     L.strl_cluster_gathered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int32, C.c_int, C.c_uint32,
                                         C.c_int32, C.c_uint16, C.c_uint16, C.c_uint16, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
                                         C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(ClusterStats)]
+    L.strl_inflate_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
     L.strl_pair_rows.argtypes = [C.POINTER(CRecords)] + [C.c_void_p] * 5
     L.strl_ctx_cluster_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 3)]
     L.strl_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
@@ -474,6 +475,21 @@ class Context:
         good = C.c_int(0)
         _check(self.L.strl_bounds_bare(self.h, p.ctypes.data, sp.ctypes.data, p.size, min_clip, min_clip_total, max_clip_dist, out.ctypes.data, C.byref(good)))
         return out[0], bool(good.value)
+
+    def inflate_blocks(self, streams, sizes):
+        """raw DEFLATE streams (list of bytes) with their inflated sizes -> list of inflated bytes (strl_inflate_blocks)"""
+        comp = np.frombuffer(b"".join(streams) + b"\0" * 8, np.uint8)
+        clen = np.array([len(s) for s in streams], np.uint32)
+        coff = np.zeros(len(streams), np.uint64)
+        coff[1:] = np.cumsum(clen[:-1], dtype=np.uint64)
+        isz = np.asarray(sizes, np.uint32)
+        out = np.zeros(int(isz.sum()) + 16, np.uint8)
+        _check(self.L.strl_inflate_blocks(self.h, comp.ctypes.data, int(clen.sum()), _ptr(coff), _ptr(clen), _ptr(isz), len(streams), out.ctypes.data, out.size))
+        res, o = [], 0
+        for n in isz:
+            res.append(out[o:o + int(n)].tobytes())
+            o += int(n)
+        return res
 
     def cluster_times(self):
         ms = (C.c_double * 3)()
