@@ -1,0 +1,94 @@
+"""The device DEFLATE decoder's per-lane core (strling_amd/csrc/inflate_core.h) compiled for the host against zlib: every
+block type, odd output alignments, multi-block streams.  CPU only -- the GPU run of the same vectors is test_bgzf_device.py."""
+import ctypes as C
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    so = os.path.join(HERE, "emu", "libinflate_emu.so")
+    src = os.path.join(HERE, "emu", "inflate_emu.cpp")
+    core = os.path.join(HERE, "..", "strling_amd", "csrc", "inflate_core.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(core)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
+    L = C.CDLL(so)
+    L.emu_inflate.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]
+    return L
+
+
+def deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, flush_every=0):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    if not flush_every:
+        return c.compress(data) + c.flush()
+    out = b""
+    for o in range(0, len(data), flush_every):
+        out += c.compress(data[o:o + flush_every]) + c.flush(zlib.Z_FULL_FLUSH if (o // flush_every) % 2 else zlib.Z_SYNC_FLUSH)
+    return out + c.flush()
+
+
+def corpus(rng):
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    yield b""
+    yield b"A"
+    yield bytes(rng.choice(acgt, 65280))                                   # a full BGZF block of sequence-like text
+    yield bytes(rng.integers(0, 256, 65280, dtype=np.uint8))               # incompressible
+    yield b"\xff" * 65280                                                  # one long run (distance-1 matches of length 258)
+    yield (b"CAG" * 30000)[:65000]
+    yield (b"ACGTTGCAAT" * 7000)[:65000]                                   # period 10: the 4-bytes-at-a-time ring path
+    yield bytes(rng.integers(0, 4, 30000, dtype=np.uint8)) + b"\0" * 20000 + bytes(rng.choice(acgt, 15000))
+    rec = bytearray()
+    for i in range(230):                                                   # BAM-record-like: binary header + name + packed seq + 0xff quals
+        rec += bytes(rng.integers(0, 256, 36, dtype=np.uint8)) + b"q%d\0" % (i * 7919) + bytes(rng.integers(0, 256, 75, dtype=np.uint8)) + b"\xff" * 150
+    yield bytes(rec)
+    far = bytes(rng.integers(0, 256, 3000, dtype=np.uint8))                # matches further back than the 1 KiB ring
+    yield far + bytes(rng.integers(0, 256, 2000, dtype=np.uint8)) + far + far[:1500] + bytes(rng.integers(0, 256, 700, dtype=np.uint8)) + far
+
+
+VARIANTS = (dict(level=1), dict(level=6), dict(level=9), dict(level=0), dict(level=6, strategy=zlib.Z_FIXED),
+            dict(level=6, strategy=zlib.Z_HUFFMAN_ONLY), dict(level=6, strategy=zlib.Z_RLE), dict(level=4, flush_every=5000))
+
+
+def test_inflate_core_matches_zlib(emu):
+    rng = np.random.default_rng(3)
+    n = 0
+    for data in corpus(rng):
+        for kw in VARIANTS:
+            s = deflate(data, **kw)
+            out = C.create_string_buffer(len(data) + 1)
+            rc = emu.emu_inflate(s, len(s), out, len(data))
+            assert rc == 0 and out.raw[:len(data)] == data, (n, kw, rc)
+            n += 1
+    assert n >= 80
+
+
+def test_inflate_core_tail_with_a_full_ring(emu):
+    """streams of every length mod 16 around multiples of the ring size: the partial last dword must not clobber the bytes
+    1 KiB older that are still waiting in the ring"""
+    rng = np.random.default_rng(8)
+    for n in list(range(1000, 1100)) + list(range(37850, 37950)):
+        data = bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), n))
+        s = deflate(data, level=int(rng.integers(1, 10)))
+        out = C.create_string_buffer(n + 1)
+        assert emu.emu_inflate(s, len(s), out, n) == 0 and out.raw[:n] == data, n
+
+
+def test_inflate_core_rejects_bad_streams(emu):
+    rng = np.random.default_rng(5)
+    data = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 20000))
+    s = deflate(data)
+    out = C.create_string_buffer(len(data) + 64)
+    assert emu.emu_inflate(s, len(s), out, len(data) + 1) != 0                # ISIZE too large
+    assert emu.emu_inflate(s, len(s), out, len(data) - 1) != 0                # ISIZE too small
+    assert emu.emu_inflate(s[:len(s) // 2], len(s) // 2, out, len(data)) != 0  # truncated stream
+    bad = 0
+    for k in range(40):
+        g = bytes(rng.integers(0, 256, 3000, dtype=np.uint8))
+        bad += emu.emu_inflate(g, len(g), out, 20000) != 0
+    assert bad == 40                                                          # garbage never decodes to exactly 20000 bytes
