@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(InflateParams P) {
   const uint32_t b = blockIdx.x * 64u + (uint32_t)lane;
   if (b >= P.n_blocks) return;
   const int err = inflate_lane(P.comp + P.coff[b], P.clen[b], P.out + P.uoff[b], P.isize[b], sym_ll, sym_d, cnt, offs,
-                               reinterpret_cast<uint32_t *>(win) + lane);
+                               reinterpret_cast<uint32_t *>(win), reinterpret_cast<uint32_t *>(win + INF_WIN_BYTES), lane);
   if (err) atomicOr(P.err, (uint32_t)err);
 }
 

@@ -21,27 +21,40 @@ namespace strl {
 
 constexpr int INF_ERR_DATA = 1, INF_ERR_SIZE = 2;
 
-INF_TABLE uint16_t d_lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-INF_TABLE uint8_t d_lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-INF_TABLE uint16_t d_dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-INF_TABLE uint8_t d_dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-INF_TABLE uint8_t d_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+// RFC 1951 3.2.5 in closed form (a table in global memory would be a dependent ~600-cycle load per match):
+//   length code s (0..28): s < 8: 3 + s, no extra bits; s == 28: 258; else e = (s - 4) / 4 extra bits, base ((4 + s % 4) << e) + 3
+//   distance code d (0..29): d < 4: 1 + d; else e = (d - 2) / 2 extra bits, base ((2 + d % 2) << e) + 1
+INF_DEV void len_code(int s, uint32_t &base, int &ext) {
+  if (s < 8) { base = 3u + (uint32_t)s; ext = 0; }
+  else if (s == 28) { base = 258; ext = 0; }
+  else { ext = (s - 4) >> 2; base = ((4u + ((uint32_t)s & 3u)) << ext) + 3u; }
+}
+INF_DEV void dist_code(int d, uint32_t &base, int &ext) {
+  if (d < 4) { base = 1u + (uint32_t)d; ext = 0; }
+  else { ext = (d - 2) >> 1; base = ((2u + ((uint32_t)d & 1u)) << ext) + 1u; }
+}
+// order of the code-length code lengths (RFC 1951 3.2.7), 5 bits each: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+INF_DEV int cl_order(int i) {
+  const uint64_t lo = 16ull | (17ull << 5) | (18ull << 10) | (0ull << 15) | (8ull << 20) | (7ull << 25) | (9ull << 30) | (6ull << 35) |
+                      (10ull << 40) | (5ull << 45) | (11ull << 50) | (4ull << 55);
+  const uint64_t hi = 12ull | (3ull << 5) | (13ull << 10) | (2ull << 15) | (14ull << 20) | (1ull << 25) | (15ull << 30);
+  return (int)((i < 12 ? lo >> (5 * i) : hi >> (5 * (i - 12))) & 31u);
+}
 
-// LDS of one wave: symbol tables + count scratch (u16 rows), then the output ring (dword rows); the code-length array used
-// while a block's tables are built shares the ring's space (the ring is flushed first).
+// LDS of one wave: symbol tables + count scratch (u16 rows), the output ring (dword rows), the code-length column.
 constexpr int L_SYMLL = 288, L_SYMD = 32, L_LENS = 320, L_CNT = 16;
-constexpr int INF_R = 1024;                                       // bytes of output a lane keeps in LDS (ring; flushed by halves)
+constexpr int INF_R = 1024;                                       // bytes of output a lane keeps in LDS (ring, flushed 256 bytes at a time)
 constexpr int INF_TAB_BYTES = (L_SYMLL + L_SYMD + 2 * L_CNT) * INF_LANES * 2;
 constexpr int INF_WIN_BYTES = INF_R * INF_LANES;
-static_assert(INF_R >= L_LENS, "the code-length column must fit the lane's ring");
-constexpr int INF_LDS_BYTES = INF_TAB_BYTES + INF_WIN_BYTES;
+constexpr int INF_LENS_BYTES = L_LENS * INF_LANES;
+constexpr int INF_LDS_BYTES = INF_TAB_BYTES + INF_WIN_BYTES + INF_LENS_BYTES;
 
-// The code-length column used while tables are built lives in the lane's OWN ring dwords (byte s in dword s / 4), so a
-// lane that rebuilds its tables never touches the ring of a lane that is in the middle of a block.
+// The code-length column used while a block's tables are built: its own LDS rows (dword-interleaved like the ring: byte s
+// of a lane in dword s / 4 of the lane's column), so that a table build leaves the ring -- the LZ77 history -- intact.
 struct LensCol {
-  uint32_t *ring;
-  INF_DEV uint8_t get(int s) const { return reinterpret_cast<const uint8_t *>(ring + (s >> 2) * INF_LANES)[s & 3]; }
-  INF_DEV void set(int s, uint8_t v) const { reinterpret_cast<uint8_t *>(ring + (s >> 2) * INF_LANES)[s & 3] = v; }
+  uint32_t *col;
+  INF_DEV uint8_t get(int s) const { return reinterpret_cast<const uint8_t *>(col + (s >> 2) * INF_LANES)[s & 3]; }
+  INF_DEV void set(int s, uint8_t v) const { reinterpret_cast<uint8_t *>(col + (s >> 2) * INF_LANES)[s & 3] = v; }
 };
 
 struct BitReader {
@@ -80,11 +93,17 @@ struct Counts { uint32_t c[5]; };
 // then ONE table access.  Returns -1 for an invalid code.
 INF_DEV int huff_decode(BitReader &br, const Counts &C, const uint16_t *sym) {
   int code = 0, first = 0, index = 0;
+  uint32_t w = (uint32_t)br.buf;            // the next >= 15 bits (the caller refilled): 32-bit work, one 64-bit shift at the end
 #pragma unroll
   for (int len = 1; len <= 15; ++len) {
-    code |= (int)br.bit();
+    code |= (int)(w & 1u);
+    w >>= 1;
     const int count = (int)INF_CNT_OF(C, len);
-    if (code - count < first) return (int)sym[(index + (code - first)) * INF_LANES];
+    if (code - count < first) {
+      br.buf >>= len;
+      br.cnt -= len;
+      return (int)sym[(index + (code - first)) * INF_LANES];
+    }
     index += count;
     first += count;
     first <<= 1;
@@ -126,14 +145,17 @@ INF_DEV bool huff_build(const LensCol &lens, int base, int n, uint16_t *cnt, uin
 // ring come from global memory (flushed long before: no load-after-store round trips).
 struct OutRing {
   uint32_t *ring;      // this lane's dword 0 (dword j at ring[j * INF_LANES])
+  uint32_t *ring0;     // lane 0's dword 0: the cooperative flush reads other lanes' columns
+  int lane;
   uint8_t *gbase;      // 16-byte aligned global address of virtual position 0
   uint32_t a0;         // virtual position of the stream's first byte
   uint32_t v;          // virtual position of the next byte
   uint32_t cur;        // pending dword: bytes [v & ~3, v)
   uint32_t lo;         // bytes at virtual positions >= lo (and below v & ~3) are valid in the ring
   uint32_t flushed;    // bytes below `flushed` are in global memory
-  INF_DEV void init(uint32_t *ring_lane, uint8_t *out) {
-    ring = ring_lane;
+  INF_DEV void init(uint32_t *ring_lane0, int lane_, uint8_t *out) {
+    ring0 = ring_lane0; lane = lane_;
+    ring = ring_lane0 + lane_;
     const uintptr_t a = reinterpret_cast<uintptr_t>(out);
     a0 = (uint32_t)(a & 15u);
     gbase = out - a0;
@@ -160,12 +182,44 @@ struct OutRing {
     }
     flushed = to;
   }
-  INF_DEV void commit() {   // v is dword aligned: cur holds bytes [v - 4, v)
-    if (v - flushed > (uint32_t)INF_R) {        // the slot of [v - 4, v) still holds unflushed bytes: the older half leaves first
-      const uint32_t to = (flushed + (uint32_t)(INF_R / 2)) & ~15u;
+  // Room for the longest symbol (258 bytes) before a symbol is decoded, so that put() never has to flush.  The lanes of a
+  // wave that are here together flush for one another: a lane that is short of room has its oldest <= 256 bytes written
+  // by ALL of them, one dword each -- one coalesced 256-byte store instead of a 16-iteration loop that the other 63 lanes
+  // would sit through (a lane fills its ring every few hundred symbols, so with 64 lanes somebody nearly always would).
+  INF_DEV void make_room() {
+#ifdef STRL_EMU
+    while (v - flushed > (uint32_t)(INF_R - 264)) {
+      const uint32_t to = (flushed + 256u) & ~255u;
       flush_to(to);
       if (lo < to) lo = to;
     }
+#else
+    for (;;) {
+      const bool need = v - flushed > (uint32_t)(INF_R - 264);
+      unsigned long long m = __ballot(need);
+      if (!m) break;
+      const unsigned long long act = __ballot(true);
+      const uint32_t n_act = (uint32_t)__popcll(act), rank = (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
+      while (m) {
+        const int L = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        uint32_t p = (uint32_t)__shfl((int)flushed, L);
+        const uint32_t q = (p + 256u) & ~255u;
+        const uint64_t gb = ((uint64_t)(uint32_t)__shfl((int)(reinterpret_cast<uintptr_t>(gbase) >> 32), L) << 32) |
+                            (uint32_t)__shfl((int)(reinterpret_cast<uintptr_t>(gbase) & 0xffffffffu), L);
+        uint8_t *g = reinterpret_cast<uint8_t *>(gb);
+        if (lane == L) while ((p & 3u) && p < q) { g[p] = (uint8_t)(ring_dword(p) >> (8 * (p & 3u))); ++p; }   // unaligned start of the stream
+        p = (p + 3u) & ~3u;
+        for (uint32_t d = rank; p + 4 * d < q; d += n_act) {
+          const uint32_t pos = p + 4 * d;
+          *reinterpret_cast<uint32_t *>(g + pos) = ring0[((pos & (uint32_t)(INF_R - 1)) >> 2) * INF_LANES + L];
+        }
+        if (lane == L) { flushed = q; if (lo < q) lo = q; }
+      }
+    }
+#endif
+  }
+  INF_DEV void commit() {   // v is dword aligned: cur holds bytes [v - 4, v); make_room() guaranteed the slot is free
     ring[(((v - 4) & (uint32_t)(INF_R - 1)) >> 2) * INF_LANES] = cur;
     cur = 0;
   }
@@ -239,12 +293,12 @@ INF_DEV void lz_copy(OutRing &W, uint32_t dist, uint32_t len) {
 // lane's ring (dword column) whose bytes double as the code-length column `lens` while tables are built.  Returns 0 or
 // INF_ERR_*.
 INF_DEV int inflate_lane(const uint8_t *comp, uint32_t clen, uint8_t *out_ptr, uint32_t isize, uint16_t *sym_ll, uint16_t *sym_d, uint16_t *cnt,
-                         uint16_t *offs, uint32_t *win) {
-  const LensCol lens{win};
+                         uint16_t *offs, uint32_t *win0, uint32_t *lens0, int lane) {
+  const LensCol lens{lens0 + lane};
   BitReader br;
   br.init(comp, clen);
   OutRing W;
-  W.init(win, out_ptr);
+  W.init(win0, lane, out_ptr);
   const uint32_t vend = W.a0 + isize;              // virtual position one past the last byte
   int err = 0;
   bool last = false;
@@ -259,14 +313,15 @@ INF_DEV int inflate_lane(const uint8_t *comp, uint32_t clen, uint8_t *out_ptr, u
       br.refill();
       const uint32_t nlen = br.bits(16);
       if ((len ^ 0xffffu) != nlen || W.v + len > vend) { err = INF_ERR_DATA; break; }
-      for (uint32_t i = 0; i < len; ++i) { br.refill(); W.put(br.bits(8)); }
+      for (uint32_t i = 0; i < len; ++i) {
+        if (!(i & 127u)) W.make_room();
+        br.refill();
+        W.put(br.bits(8));
+      }
       if (br.overrun()) { err = INF_ERR_DATA; break; }
       continue;
     }
     if (type == 3) { err = INF_ERR_DATA; break; }
-    // the code lengths use the ring's LDS: flush what it holds; older bytes are then only in global memory
-    W.flush_all();
-    W.lo = W.v & ~3u;                      // (the pending dword stays in its register)
     Counts CL{}, CD{};
     if (type == 1) {                       // fixed codes
       for (int s = 0; s < 144; ++s) lens.set(s, 8);
@@ -282,7 +337,7 @@ INF_DEV int inflate_lane(const uint8_t *comp, uint32_t clen, uint8_t *out_ptr, u
       const int ncode = (int)br.bits(4) + 4;
       if (nlen > 286 || ndist > 30) { err = INF_ERR_DATA; break; }
       for (int i = 0; i < 19; ++i) lens.set(i, 0);
-      for (int i = 0; i < ncode; ++i) { br.refill(); lens.set(d_clorder[i], (uint8_t)br.bits(3)); }
+      for (int i = 0; i < ncode; ++i) { br.refill(); lens.set(cl_order(i), (uint8_t)br.bits(3)); }
       Counts CC{};
       if (!huff_build(lens, 0, 19, cnt, offs, sym_d, CC)) { err = INF_ERR_DATA; break; }   // the code-length code lives in sym_d for now
       // the decoded lengths must not overwrite the code-length code's own lengths while they are read: they are not read
@@ -312,6 +367,7 @@ INF_DEV int inflate_lane(const uint8_t *comp, uint32_t clen, uint8_t *out_ptr, u
     }
     // ---- the symbols of this block ----
     for (;;) {
+      W.make_room();
       br.refill();
       int s = huff_decode(br, CL, sym_ll);
       if (s < 0) { err = INF_ERR_DATA; break; }
@@ -322,11 +378,15 @@ INF_DEV int inflate_lane(const uint8_t *comp, uint32_t clen, uint8_t *out_ptr, u
       else {
         s -= 257;
         if (s >= 29) { err = INF_ERR_DATA; break; }
-        const uint32_t len = d_lbase[s] + br.bits(d_lext[s]);
+        uint32_t lb, db;
+        int le, de;
+        len_code(s, lb, le);
+        const uint32_t len = lb + br.bits(le);
         br.refill();
         const int ds = huff_decode(br, CD, sym_d);
         if (ds < 0 || ds >= 30) { err = INF_ERR_DATA; break; }
-        const uint32_t dist = d_dbase[ds] + br.bits(d_dext[ds]);
+        dist_code(ds, db, de);
+        const uint32_t dist = db + br.bits(de);
         if (dist > W.v - W.a0 || W.v + len > vend) { err = INF_ERR_DATA; break; }
         lz_copy(W, dist, len);
       }
