@@ -327,7 +327,7 @@ bool BamStream::open(const std::string &path, int threads, std::string &err) {
 bool BamStream::load_chunk(std::string &err) {
   struct Blk { const uint8_t *c; uint32_t clen, isize; size_t out; };
   static const char *env_blocks = getenv("STRL_CHUNK_BLOCKS");   // tests: tiny superchunks to exercise the carry path
-  const size_t max_blocks = env_blocks && atoi(env_blocks) > 0 ? (size_t)atoi(env_blocks) : 64 * (size_t)pool_->size() + 64, max_bytes = (size_t)96 << 20;
+  const size_t max_blocks = env_blocks && atoi(env_blocks) > 0 ? (size_t)atoi(env_blocks) : 64 * (size_t)pool_->size() + 64, max_bytes = (size_t)256 << 20;
   std::vector<Blk> blks;
   const double t0 = DecodeClock::now();
   // bytes behind the last complete record of the previous superchunk
@@ -339,6 +339,7 @@ bool BamStream::load_chunk(std::string &err) {
     skip_ = 0;
   }
   size_t total = carry;
+  const size_t chunk_c0 = cpos_;
   while (cpos_ < map_len_ && blks.size() < max_blocks && total < max_bytes) {
     if (cpos_ + 18 > map_len_) { err = "truncated BGZF header"; return false; }
     const uint8_t *h = map_ + cpos_;
@@ -361,62 +362,163 @@ bool BamStream::load_chunk(std::string &err) {
     cpos_ += bsize;
   }
   if (cpos_ >= map_len_) eof_ = true;
+  {
+    // Fault the superchunk's part of the file mapping in with ONE call: otherwise every inflate thread takes page faults on
+    // the shared address space (a quarter of a million for a 1 GB file) and the threads serialise in the kernel.
+    const size_t pg = 4096, a0 = (chunk_c0 / pg) * pg;
+#ifndef MADV_POPULATE_READ
+#define MADV_POPULATE_READ 22
+#endif
+    if (madvise(const_cast<uint8_t *>(map_) + a0, cpos_ - a0, MADV_POPULATE_READ) != 0)
+      (void)madvise(const_cast<uint8_t *>(map_) + a0, cpos_ - a0, MADV_WILLNEED);
+  }
+  const size_t u_cap_before = u_.capacity();
   u_.resize(total);
+  if (u_.capacity() != u_cap_before) (void)madvise(u_.data(), u_.capacity(), MADV_HUGEPAGE);   // fewer, larger first-touch faults
   if (carry) memcpy(u_.data(), prev_.data(), carry);
   std::atomic<bool> bad{false};
   const double t1 = DecodeClock::now();
-  // Each task inflates one block and then walks the block_size chain through it -- while the data is still in that
-  // core's cache -- starting where the previous block's walk stopped (start[k], published by task k - 1; tasks are
-  // claimed in increasing order, so the task a walk waits for is always already running).  A record whose fixed
-  // 36-byte part is not complete inside the blocks done so far is handed on to the next block.
+  // The blocks are split into contiguous groups, one task each.  A task inflates its blocks one after the other and walks
+  // the block_size chain of the records that start in them while the data is still in its core's cache.  Nothing waits for
+  // anything: a group other than the first does not know where its first record starts, so it GUESSES -- the first offset
+  // from which a chain of plausible BAM records runs (sizes, refIDs, name length and terminator, cigar / sequence lengths
+  // that fit block_size) -- and the guesses are verified afterwards: the exact chain of the groups before it must arrive
+  // exactly at a group's guessed start, or that group is walked again from where the chain really arrives.  (A chain of
+  // per-block walks that wait for one another, the previous design, collapsed beyond ~32 threads: one descheduled
+  // thread stalled all the spinning ones.)
   const size_t nb = blks.size(), total_n = u_.size();
-  struct alignas(64) Link { std::atomic<int64_t> v{-1}; int64_t load(std::memory_order o = std::memory_order_seq_cst) const { return v.load(o); }
-                            void store(int64_t x, std::memory_order o = std::memory_order_seq_cst) { v.store(x, o); } };
-  std::vector<Link> start(nb + 1);                       // one cache line each: every link has one writer and one spinning reader
-  start[0].store((int64_t)skip_, std::memory_order_release);
-  std::vector<std::vector<RecMeta>> found(nb);
-  pool_->parallel_for(nb, [&](size_t k) {
+  const int32_t n_ref = (int32_t)targets_.size();
+  const size_t G = std::max<size_t>(1, std::min<size_t>(nb, (size_t)pool_->size() * 2));
+  struct Group { size_t b0, b1; int64_t start = -1, end = -1; bool ok = true; std::vector<RecMeta> recs, junction; };
+  std::vector<Group> groups(G);
+  for (size_t g = 0; g < G; ++g) { groups[g].b0 = nb * g / G; groups[g].b1 = nb * (g + 1) / G; }
+  const uint8_t *U = u_.data();
+  // one record header at q (all 36 bytes readable): fields + plausibility
+  auto header = [&](size_t q, RecMeta &m, uint32_t &bs) -> bool {
+    memcpy(&bs, U + q, 4);
+    const uint8_t *r = U + q + 4;
+    m.off = q;
+    m.l_qname = r[8];
+    memcpy(&m.n_cigar, r + 12, 2);
+    memcpy(&m.l_seq, r + 16, 4);
+    return !(bs < 32 || m.l_seq < 0 || 32 + (size_t)m.l_qname + 4u * m.n_cigar + (size_t)(m.l_seq + 1) / 2 > bs);
+  };
+  auto plausible = [&](size_t q, size_t avail, size_t &next) -> int {   // 1 plausible record, 0 not a record, -1 cannot tell (too few bytes)
+    if (q + 36 > avail) return -1;
+    RecMeta m;
+    uint32_t bs;
+    if (!header(q, m, bs) || bs > (1u << 26)) return 0;
+    int32_t ref, pos, nref, npos;
+    memcpy(&ref, U + q + 4, 4); memcpy(&pos, U + q + 8, 4); memcpy(&nref, U + q + 24, 4); memcpy(&npos, U + q + 28, 4);
+    if (ref < -1 || ref >= n_ref || nref < -1 || nref >= n_ref || pos < -1 || npos < -1 || m.l_qname < 1) return 0;
+    if ((size_t)m.l_seq + (size_t)(m.l_seq + 1) / 2 + 32 + m.l_qname + 4u * m.n_cigar > bs) return 0;   // the quality string has to fit as well
+    const size_t name_end = q + 36 + m.l_qname - 1;
+    if (name_end < avail && U[name_end] != 0) return 0;
+    for (size_t c = q + 36; c < name_end && c < avail; ++c) if (U[c] < 33 || U[c] > 126) return 0;
+    next = q + 4 + (size_t)bs;
+    return 1;
+  };
+  auto guess_start = [&](size_t from, size_t avail) -> int64_t {
+    for (size_t o = from; o + 36 <= avail && o < from + (1u << 20); ++o) {
+      size_t c = o, nx = 0;
+      int n_ok = 0, verdict = 1;
+      while (n_ok < 8) {
+        const int r = plausible(c, avail, nx);
+        if (r == 0) { verdict = 0; break; }
+        if (r < 0) { verdict = n_ok >= 3 ? 1 : -1; break; }
+        ++n_ok;
+        c = nx;
+      }
+      if (verdict == 1) return (int64_t)o;
+      if (verdict < 0) return -1;          // ran out of inflated bytes before the chain was long enough: cannot tell yet
+    }
+    return -1;
+  };
+  auto walk = [&](Group &gr, size_t &q, size_t limit) {   // records whose 36-byte header lies inside [.., limit)
+    while (q + 36 <= limit) {
+      RecMeta m;
+      uint32_t bs;
+      if (!header(q, m, bs)) { gr.ok = false; return; }
+      gr.recs.push_back(m);
+      q += 4 + (size_t)bs;
+    }
+  };
+  pool_->parallel_for(G, [&](size_t g) {
+    Group &gr = groups[g];
+    if (gr.b0 == gr.b1) return;
+    const size_t g_begin = blks[gr.b0].out, g_end = blks[gr.b1 - 1].out + blks[gr.b1 - 1].isize;
+    gr.recs.reserve((g_end - g_begin) / 160 + 8);
+    size_t q = 0;
+    bool have = false;
+    if (g == 0) { q = skip_; have = true; gr.start = (int64_t)skip_; }
     z_stream zs;
     memset(&zs, 0, sizeof zs);
-    bool ok = inflateInit2(&zs, -15) == Z_OK;
-    if (ok) {
+    if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return; }
+    for (size_t k = gr.b0; k < gr.b1 && !bad; ++k) {
+      if (k != gr.b0 && inflateReset(&zs) != Z_OK) { bad = true; break; }
       zs.next_in = const_cast<uint8_t *>(blks[k].c); zs.avail_in = blks[k].clen;
       zs.next_out = u_.data() + blks[k].out; zs.avail_out = blks[k].isize;
       const int rc = inflate(&zs, Z_FINISH);
-      ok = rc == Z_STREAM_END && zs.total_out == blks[k].isize;
-      inflateEnd(&zs);
+      if (rc != Z_STREAM_END || zs.total_out != blks[k].isize) { bad = true; break; }
+      const size_t avail = blks[k].out + blks[k].isize;
+      if (!have && gr.ok && (avail - g_begin >= 8192 || k + 1 == gr.b1)) {
+        const int64_t s0 = guess_start(g_begin, avail);
+        if (s0 >= 0) { q = (size_t)s0; gr.start = s0; have = true; }
+      }
+      if (have && gr.ok) walk(gr, q, avail);
     }
-    if (!ok) bad = true;
-    int64_t p;
-    for (unsigned spins = 0; (p = start[k].load(std::memory_order_acquire)) < 0; ++spins) {
-      if (bad) { start[k + 1].store(0, std::memory_order_release); return; }
-      if (spins < 4096) __builtin_ia32_pause(); else std::this_thread::yield();
-    }
-    const size_t end_k = blks[k].out + blks[k].isize;
-    std::vector<RecMeta> &out = found[k];
-    out.reserve(blks[k].isize / 128 + 4);
-    size_t q = (size_t)p;
-    while (ok && q + 36 <= end_k) {
-      uint32_t bs;
-      memcpy(&bs, u_.data() + q, 4);
-      const uint8_t *r = u_.data() + q + 4;
-      RecMeta m;
-      m.off = q;
-      m.l_qname = r[8];
-      memcpy(&m.n_cigar, r + 12, 2);
-      memcpy(&m.l_seq, r + 16, 4);
-      if (bs < 32 || m.l_seq < 0 || 32 + (size_t)m.l_qname + 4u * m.n_cigar + (size_t)(m.l_seq + 1) / 2 > bs) { bad = true; ok = false; break; }
-      out.push_back(m);
-      q += 4 + (size_t)bs;
-    }
-    start[k + 1].store((int64_t)q, std::memory_order_release);
+    inflateEnd(&zs);
+    gr.end = have && gr.ok ? (int64_t)q : -1;
   });
-  if (bad) { err = "BGZF inflate failed or corrupt BAM record"; return false; }
+  if (bad) { err = "BGZF inflate failed"; return false; }
   const double t2 = DecodeClock::now();
-  // record table of the superchunk: the per-block lists in order, minus the records that are not complete yet
+  // ---- stitch: follow the exact chain through the junctions, verify every guess, walk again what was guessed wrong ----
+  size_t cur = 0;
+  for (size_t g = 0; g < G; ++g) {
+    Group &gr = groups[g];
+    if (gr.b0 == gr.b1) continue;
+    const size_t g_end = blks[gr.b1 - 1].out + blks[gr.b1 - 1].isize;
+    if (g == 0) {
+      if (!gr.ok) { err = "corrupt BAM record"; return false; }
+      cur = (size_t)gr.end;
+      continue;
+    }
+    const size_t g_begin = blks[gr.b0].out;
+    Group &prev = groups[g - 1];
+    // records that start before this group's data but whose header reaches into it (the previous walk could not read them)
+    while (cur < g_begin && cur + 36 <= total_n) {
+      RecMeta m;
+      uint32_t bs;
+      if (!header(cur, m, bs)) { err = "corrupt BAM record"; return false; }
+      prev.junction.push_back(m);
+      cur += 4 + (size_t)bs;
+    }
+    if (cur < g_begin) {                                    // the last record of the superchunk is not complete yet:
+      for (size_t h = g; h < G; ++h) groups[h].recs.clear();  // nothing that was guessed behind it counts
+      break;
+    }
+    if (gr.ok && gr.start == (int64_t)cur) { cur = (size_t)gr.end; continue; }
+    gr.recs.clear();                                        // guessed wrong (or not at all): the chain arrives at `cur`
+    gr.ok = true;
+    gr.start = (int64_t)cur;
+    size_t q = cur;
+    walk(gr, q, g_end);
+    if (!gr.ok) { err = "corrupt BAM record"; return false; }
+    gr.end = (int64_t)q;
+    cur = q;
+  }
+  // record table of the superchunk: the groups' lists in order, minus a last record that is not complete yet
   recs_.clear();
   rec_next_ = 0;
-  for (size_t k = 0; k < nb; ++k) recs_.insert(recs_.end(), found[k].begin(), found[k].end());
+  {
+    std::vector<size_t> at(2 * G + 1, 0);
+    for (size_t g = 0; g < G; ++g) { at[2 * g + 1] = at[2 * g] + groups[g].recs.size(); at[2 * g + 2] = at[2 * g + 1] + groups[g].junction.size(); }
+    recs_.resize(at[2 * G]);
+    pool_->parallel_for(G, [&](size_t g) {
+      if (!groups[g].recs.empty()) memcpy(recs_.data() + at[2 * g], groups[g].recs.data(), groups[g].recs.size() * sizeof(RecMeta));
+      if (!groups[g].junction.empty()) memcpy(recs_.data() + at[2 * g + 1], groups[g].junction.data(), groups[g].junction.size() * sizeof(RecMeta));
+    });
+  }
   const size_t n = total_n;
   auto rec_end = [&](const RecMeta &m) { uint32_t bs; memcpy(&bs, u_.data() + m.off, 4); return (size_t)m.off + 4 + (size_t)bs; };
   if (!recs_.empty() && rec_end(recs_.back()) > n) recs_.pop_back();   // only the last one can reach past the superchunk
@@ -440,19 +542,41 @@ int64_t BamStream::read(RecordBatch &b, int64_t max_records, std::string &err) {
     const RecMeta *rm = recs_.data() + rec_next_;
     // output offsets of this part
     const size_t base = b.tid.size();
-    std::vector<uint32_t> cig_at(m + 1);
-    std::vector<uint64_t> qn_at(m + 1), seq_at(m + 1);
-    cig_at[0] = b.cigar_off.back();
-    qn_at[0] = b.qname_off.back();
-    size_t so = b.seq4.size();
-    for (size_t i = 0; i < m; ++i) {
-      cig_at[i + 1] = cig_at[i] + rm[i].n_cigar;
-      qn_at[i + 1] = qn_at[i] + (rm[i].l_qname ? rm[i].l_qname - 1u : 0u);
-      so = (so + 15) & ~(size_t)15;
-      seq_at[i] = so;
-      so += (size_t)(rm[i].l_seq + 1) / 2;
+    rvec<uint32_t> cig_at(m + 1);
+    rvec<uint64_t> qn_at(m + 1), seq_at(m + 1);
+    size_t so;
+    {
+      // output offsets of every record: sums per part in parallel, a scan over the parts, offsets per part in parallel.
+      // (SEQ is padded to 16 bytes per record, so a part's SEQ size does not depend on where it starts once the start is
+      // 16-byte aligned, which the first record's padding guarantees.)
+      const size_t P = std::min<size_t>(std::max<size_t>(m / 8192, 1), (size_t)pool_->size() * 4);
+      std::vector<uint64_t> pc(P + 1, 0), pq(P + 1, 0), ps(P + 1, 0);
+      pool_->parallel_for(P, [&](size_t part) {
+        const size_t i0 = m * part / P, i1 = m * (part + 1) / P;
+        uint64_t c = 0, q = 0, sq = 0;
+        for (size_t i = i0; i < i1; ++i) {
+          c += rm[i].n_cigar;
+          q += rm[i].l_qname ? rm[i].l_qname - 1u : 0u;
+          sq += ((uint64_t)(rm[i].l_seq + 1) / 2 + 15) & ~(uint64_t)15;
+        }
+        pc[part + 1] = c; pq[part + 1] = q; ps[part + 1] = sq;
+      });
+      pc[0] = b.cigar_off.back(); pq[0] = b.qname_off.back(); ps[0] = (b.seq4.size() + 15) & ~(size_t)15;
+      for (size_t k = 0; k < P; ++k) { pc[k + 1] += pc[k]; pq[k + 1] += pq[k]; ps[k + 1] += ps[k]; }
+      pool_->parallel_for(P, [&](size_t part) {
+        const size_t i0 = m * part / P, i1 = m * (part + 1) / P;
+        uint64_t c = pc[part], q = pq[part], sq = ps[part];
+        for (size_t i = i0; i < i1; ++i) {
+          cig_at[i] = (uint32_t)c; qn_at[i] = q; seq_at[i] = sq;
+          c += rm[i].n_cigar;
+          q += rm[i].l_qname ? rm[i].l_qname - 1u : 0u;
+          sq += ((uint64_t)(rm[i].l_seq + 1) / 2 + 15) & ~(uint64_t)15;
+        }
+      });
+      cig_at[m] = (uint32_t)pc[P]; qn_at[m] = pq[P]; seq_at[m] = ps[P];
+      // the last record keeps its true length (no padding behind it), like the sequential layout
+      so = m ? seq_at[m - 1] + (size_t)(rm[m - 1].l_seq + 1) / 2 : b.seq4.size();
     }
-    seq_at[m] = so;
     b.tid.resize(base + m); b.pos.resize(base + m); b.mtid.resize(base + m); b.mpos.resize(base + m); b.isize.resize(base + m);
     b.l_seq.resize(base + m); b.flag.resize(base + m); b.mapq.resize(base + m); b.seq_off.resize(base + m);
     b.cigar_off.resize(base + m + 1); b.qname_off.resize(base + m + 1);

@@ -111,11 +111,28 @@ static void append_record(RecordBatch &dst, const RecordBatch &src, size_t i) {
 }
 
 // utils.nim:86-111
-// decode threads: STRL_THREADS, else what the machine has, at most 64 (the reference decodes on one: threads=0, extract.nim:275)
+// decode threads: STRL_THREADS, else what the machine (or the container's CPU quota) has, at most 64 (the reference decodes on one: threads=0, extract.nim:275)
+static int cpu_quota() {   // CPUs this process may actually use: the cgroup CPU quota when there is one (containers), else the hardware
+  unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  long long quota = -1, period = 100000;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
+    char q[64];
+    if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+    fclose(f);
+  } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+    if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+    fclose(g);
+    if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
+  }
+  if (quota > 0 && period > 0) hw = (unsigned)std::min<long long>(hw, std::max<long long>(1, (quota + period - 1) / period));
+  return (int)hw;
+}
 static int decode_threads() {
   const char *e = getenv("STRL_THREADS");
   if (e && atoi(e) > 0) return atoi(e);
-  return (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  // More threads than the CPU quota do not decode faster, they get throttled (measured: a 16-CPU quota on a 256-thread box)
+  static const int n = std::max(1, std::min(64, cpu_quota()));
+  return n;
 }
 
 static void fragment_length_distribution(const std::string &bam, uint32_t frag[4096]) {
@@ -304,7 +321,7 @@ static int extract_main(int argc, char **argv) {
   if (host_pair) CHECK(strl_pairer_create(&opts, &pairer));
   else CHECK(strl_extract_begin(ctx, 0));
 
-  ThreadPool prep(decode_threads());
+  ThreadPool prep(std::min(decode_threads(), 16));   // SoA preparation is light; the decoder keeps the other cores
   rvec<int32_t> end;
   rvec<uint32_t> so;
   std::vector<uint32_t> whole;
@@ -897,6 +914,31 @@ static int dump_main(int argc, char **argv) {
 
 // `strling _region BAM TID BEG END`: qname and start of every record the indexed region read returns that passes htslib's
 // iterator filter (reader self-check; needs no GPU)
+// strling _decode BAM [BATCH]: the multi-threaded reader alone (inflate + record scan + parse into batches), for timing
+static int decode_main(int argc, char **argv) {
+  if (argc < 3) quit("usage: strling _decode BAM [BATCH]");
+  const int64_t batch = argc > 3 ? atoll(argv[3]) : 1048576;
+  BamStream rs;
+  std::string err;
+  if (!rs.open(argv[2], decode_threads(), err)) quit("couldn't open bam");
+  RecordBatch b;
+  int64_t n = 0;
+  uint64_t sum = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    b.clear();
+    const int64_t got = rs.read(b, batch, err);
+    if (got < 0) quit("[strling] error reading %s: %s", argv[2], err.c_str());
+    if (got == 0) break;
+    n += got;
+    sum += (uint64_t)b.pos[(size_t)got - 1] + b.seq4[b.seq4.size() / 2];
+  }
+  const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  fprintf(stderr, "[strling] decoded %lld records in %.3f s with %d threads: %.1f reads/s (checksum %llu)\n", (long long)n, s, decode_threads(),
+          (double)n / std::max(s, 1e-9), (unsigned long long)sum);
+  return 0;
+}
+
 static int region_main(int argc, char **argv) {
   if (argc < 6) quit("usage: strling _region BAM TID BEG END");
   BamReader rd;
@@ -961,6 +1003,7 @@ int main(int argc, char **argv) {
   if (cmd == "index") return index_main(argc, argv);
   if (cmd == "call") return call_main(argc, argv);
   if (cmd == "_dump") return dump_main(argc, argv);
+  if (cmd == "_decode") return decode_main(argc, argv);
   if (cmd == "_region") return region_main(argc, argv);
   if (cmd == "pull_region")
     quit("[strling] `%s` is not part of this build (the MI355X path covers index, extract, merge and call; see DESIGN.md section 9)", cmd.c_str());

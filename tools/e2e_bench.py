@@ -25,7 +25,14 @@ def make_input(n_pairs, d=None, level=1):
 
 def run(inp, cli, threads=(0,)):
     """runs `strling extract -v` on the prepared input once per thread count (0 = the CLI's default) -> end_to_end block"""
-    res = {"unit": "reads/s", "reads": inp["reads"], "bam_MB": inp["bam_MB"], "host_threads_available": os.cpu_count(), "runs": []}
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else round(int(q) / int(per), 1)
+    except Exception:
+        pass
+    res = {"unit": "reads/s", "reads": inp["reads"], "bam_MB": inp["bam_MB"], "host_threads_available": os.cpu_count(), "cgroup_cpu_quota": quota,
+           "runs": []}
     for t in threads:
         env = dict(os.environ, STRL_DECODE_TIMING="1")
         if t:
@@ -36,7 +43,7 @@ def run(inp, cli, threads=(0,)):
         line = [l for l in r.stderr.splitlines() if "seconds: total" in l]
         dec = [l.split("decode seconds:")[1].strip() for l in r.stderr.splitlines() if "decode seconds:" in l]
         loop_s = float(line[-1].split("total")[1].split()[0]) if line else None
-        res["runs"].append({"decode_threads": t or "default(min(64, nproc))", "rc": r.returncode, "wall_s": round(wall, 3),
+        res["runs"].append({"decode_threads": t or "default: min(64, CPU quota)", "rc": r.returncode, "wall_s": round(wall, 3),
                             "reads_per_s_wall": round(inp["reads"] / wall), "loop_s": loop_s,
                             "reads_per_s_loop": round(inp["reads"] / loop_s) if loop_s else None, "decode": dec,
                             "phases": line[-1].split("seconds:")[1].strip() if line else r.stderr[-300:]})
