@@ -327,6 +327,8 @@ struct KeyParams {
   uint32_t *pos_in, *sample_in;
   uint8_t *split_in;
   uint64_t *gkey_in;
+  uint64_t *first_in;           // what orders the groups' first appearances: the input index, or ...
+  const uint64_t *first_key;    // ... the emission key of an unordered tread (treads straight from the pair logic), or nullptr
   uint32_t *cnt;
   int composite, pos_bits;
   int32_t n_tid;    // tids must be < n_tid
@@ -358,6 +360,7 @@ __global__ __launch_bounds__(256) void tread_keys_kernel(KeyParams K) {
   K.pos_in[i] = t.position;
   K.split_in[i] = t.split;
   K.sample_in[i] = (uint32_t)t.qname_id;
+  K.first_in[i] = K.first_key ? K.first_key[i] : (uint64_t)i;
   K.val[i] = i;
   if (K.composite) {
     if (K.pos_bits < 32 && (t.position >> K.pos_bits)) err |= CERR_POS;
@@ -385,11 +388,13 @@ struct GatherParams {
   int shift;                // group key = key >> shift
   const uint32_t *pos_in, *sample_in;
   const uint8_t *split_in;
+  const uint64_t *first_in;
   uint32_t *tile_heads;     // [tiles] heads per tile (exclusive prefix when `scanned`)
   int scanned;
   uint32_t *pos, *sample, *gid;
   uint8_t *split;
-  uint32_t *gstart, *gfirst;
+  uint32_t *gstart;
+  uint64_t *gfirst;
   uint64_t *gkeys;
   uint8_t *gplaced;
   uint32_t *cnt;
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(256) void heads_kernel(GatherParams G) {
   for (uint32_t r = 0; r < 8; ++r) {
     const uint32_t j = t * GT_TILE + r * 256u + threadIdx.x;
     if (j < n) {
-      G.gfirst[j] = 0xffffffffu;          // (n_groups <= n) first appearance, filled by atomicMin in gather_kernel
+      G.gfirst[j] = ~0ull;                // (n_groups <= n) first appearance, filled by atomicMin in gather_kernel
       c += is_head(G, j, G.key[j]) ? 1u : 0u;
     }
   }
@@ -485,9 +490,11 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherParams G) {
     const uint32_t j = j0 + 64u * r;
     const bool in = j < n;
     uint32_t src = 0xffffffffu, g = 0xffffffffu;
+    uint64_t fk = ~0ull;
     if (in) {
       g = run + (uint32_t)__popcll(hm[r] & le) - 1u;
       src = G.perm[j];
+      fk = G.first_in[src];
       G.pos[j] = G.pos_in[src];
       G.split[j] = G.split_in[src];
       G.sample[j] = G.sample_in[src];
@@ -499,17 +506,18 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherParams G) {
       if (j == n - 1) { G.gstart[g + 1] = n; G.cnt[CC_NGROUPS] = g + 1; }
     }
     run += (uint32_t)__popcll(hm[r]);
-    // First appearance in input order (=> Nim Table insertion order) = min of `src` per group.  Group ids are
-    // non-decreasing along the wave, so a segmented suffix-min leaves each run's minimum in its first lane and only
+    // First appearance in input order (=> Nim Table insertion order) = min of the first-appearance key per group.  Group ids
+    // are non-decreasing along the wave, so a segmented suffix-min leaves each run's minimum in its first lane and only
     // that lane touches memory (one atomic per (wave-round, group) instead of one per tread on a handful of hot addresses).
-    uint32_t v = src;
+    uint64_t v = fk;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t ov = __shfl_down(v, d), og = __shfl_down(g, d);
+      const uint64_t ov = ((uint64_t)(uint32_t)__shfl_down((int)(v >> 32), d) << 32) | (uint32_t)__shfl_down((int)(v & 0xffffffffu), d);
+      const uint32_t og = __shfl_down(g, d);
       if (lane + d < 64 && og == g) v = v < ov ? v : ov;
     }
     const uint32_t pg = __shfl_up(g, 1);
-    if (in && (lane == 0 || pg != g)) atomicMin(&G.gfirst[g], v);
+    if (in && (lane == 0 || pg != g)) atomicMin(reinterpret_cast<unsigned long long *>(&G.gfirst[g]), (unsigned long long)v);
   }
 }
 
@@ -572,7 +580,7 @@ static inline uint32_t base_code(char b, bool &ok) {
 
 using namespace strl;
 
-enum { B_TREADS, B_KEY0, B_KEY1, B_VAL0, B_VAL1, B_SORT, B_IN, B_SORTED, B_TILES, B_GROUPS, B_CAND, B_OUT, B_BIG, B_CNT, B_GKEY };
+enum { B_TREADS, B_KEY0, B_KEY1, B_VAL0, B_VAL1, B_SORT, B_IN, B_SORTED, B_TILES, B_GROUPS, B_CAND, B_OUT, B_BIG, B_CNT, B_GKEY, B_FIRST };
 
 // The whole device side of a clustering pass over `treads` (device memory; count at d_n, at most n_max): keys, sort,
 // group tables, ends/walk sweep, bounds.  Asynchronous: no host synchronisation, every launch is sized by n_max.
@@ -591,7 +599,7 @@ static int cluster_device_pass(strl_ctx *c, const strl_tread *treads, const uint
   auto need = [&](int i, size_t bytes) { return B[i].reserve(std::max<size_t>(bytes, 256)); };
   if ((rc = need(B_KEY0, n1 * 8)) || (rc = need(B_KEY1, n1 * 8)) || (rc = need(B_VAL0, n1 * 4)) || (rc = need(B_VAL1, n1 * 4)) ||
       (rc = need(B_SORT, sb)) || (rc = need(B_IN, n1 * 9 + 64)) || (rc = need(B_SORTED, n1 * 21 + 64)) || (rc = need(B_TILES, (size_t)ntiles * 4)) ||
-      (rc = need(B_GROUPS, n1 * 17 + 64)) || (rc = need(B_CAND, (size_t)cand_cap * 16)) || (rc = need(B_OUT, (size_t)cand_cap * 2 * sizeof(RawBounds))) ||
+      (rc = need(B_GROUPS, n1 * 21 + 64)) || (rc = need(B_FIRST, n1 * 8)) || (rc = need(B_CAND, (size_t)cand_cap * 16)) || (rc = need(B_OUT, (size_t)cand_cap * 2 * sizeof(RawBounds))) ||
       (rc = need(B_BIG, (size_t)big_words * 4)) || (rc = need(B_CNT, CC_WORDS * 4)) || (!R.composite && (rc = need(B_GKEY, n1 * 8))))
     return rc;
   uint32_t *cnt = B[B_CNT].as<uint32_t>();
@@ -605,6 +613,7 @@ static int cluster_device_pass(strl_ctx *c, const strl_tread *treads, const uint
   KeyParams K{};
   K.d_n = d_n; K.n_max = n_max; K.treads = treads; K.key = B[B_KEY0].as<uint64_t>(); K.val = B[B_VAL0].as<uint32_t>();
   K.pos_in = d_posin; K.sample_in = d_samplein; K.split_in = d_splitin; K.gkey_in = R.composite ? nullptr : B[B_GKEY].as<uint64_t>();
+  K.first_in = B[B_FIRST].as<uint64_t>(); K.first_key = R.first_key;
   K.cnt = cnt; K.composite = R.composite ? 1 : 0; K.pos_bits = R.pos_bits; K.n_tid = R.n_tid;
   hipLaunchKernelGGL(tread_keys_kernel, dim3(nb), dim3(TB), 0, st, K);
   uint64_t *sk = nullptr;
@@ -630,12 +639,12 @@ static int cluster_device_pass(strl_ctx *c, const strl_tread *treads, const uint
   uint32_t *d_pos = B[B_SORTED].as<uint32_t>(), *d_sample = d_pos + n1, *d_gid = d_sample + n1, *d_ends = d_gid + n1, *d_isstart = d_ends + n1;
   uint8_t *d_split = reinterpret_cast<uint8_t *>(d_isstart + n1);
   uint64_t *d_gkeys = B[B_GROUPS].as<uint64_t>();
-  uint32_t *d_gstart = reinterpret_cast<uint32_t *>(d_gkeys + n1);
-  uint32_t *d_gfirst = d_gstart + (n1 + 1);
-  uint8_t *d_gplaced = reinterpret_cast<uint8_t *>(d_gfirst + n1);
+  uint64_t *d_gfirst = d_gkeys + n1;
+  uint32_t *d_gstart = reinterpret_cast<uint32_t *>(d_gfirst + n1);
+  uint8_t *d_gplaced = reinterpret_cast<uint8_t *>(d_gstart + (n1 + 1));
   GatherParams G{};
   G.d_n = d_n; G.n_max = n_max; G.key = sk; G.perm = sv; G.shift = R.composite ? R.pos_bits : 0;
-  G.pos_in = d_posin; G.sample_in = d_samplein; G.split_in = d_splitin; G.tile_heads = B[B_TILES].as<uint32_t>();
+  G.pos_in = d_posin; G.sample_in = d_samplein; G.split_in = d_splitin; G.first_in = B[B_FIRST].as<uint64_t>(); G.tile_heads = B[B_TILES].as<uint32_t>();
   G.scanned = ntiles > 1024 ? 1 : 0;
   G.pos = d_pos; G.sample = d_sample; G.gid = d_gid; G.split = d_split; G.gstart = d_gstart; G.gfirst = d_gfirst; G.gkeys = d_gkeys;
   G.gplaced = d_gplaced; G.cnt = cnt;
@@ -722,16 +731,17 @@ static int cluster_collect(strl_ctx *c, const std::vector<std::pair<uint64_t, ui
   if (n_dev == 0 && ghosts_in.empty()) return STRL_OK;
   std::vector<RawBounds> raw((size_t)2 * n_cand);
   std::vector<uint64_t> g_keys(n_groups);
-  std::vector<uint32_t> g_start(n_groups + 1), g_first(n_groups);
+  std::vector<uint32_t> g_start(n_groups + 1);
+  std::vector<uint64_t> g_first(n_groups);
   {
     uint64_t *d_gkeys = B[B_GROUPS].as<uint64_t>();
-    uint32_t *d_gstart = reinterpret_cast<uint32_t *>(d_gkeys + n1);
-    uint32_t *d_gfirst = d_gstart + ((size_t)n1 + 1);
+    uint64_t *d_gfirst = d_gkeys + n1;
+    uint32_t *d_gstart = reinterpret_cast<uint32_t *>(d_gfirst + n1);
     if (n_cand) STRL_HIP(hipMemcpyAsync(raw.data(), B[B_OUT].p, raw.size() * sizeof(RawBounds), hipMemcpyDeviceToHost, st));
     if (n_groups) {
       STRL_HIP(hipMemcpyAsync(g_keys.data(), d_gkeys, (size_t)n_groups * 8, hipMemcpyDeviceToHost, st));
       STRL_HIP(hipMemcpyAsync(g_start.data(), d_gstart, (size_t)(n_groups + 1) * 4, hipMemcpyDeviceToHost, st));
-      STRL_HIP(hipMemcpyAsync(g_first.data(), d_gfirst, (size_t)n_groups * 4, hipMemcpyDeviceToHost, st));
+      STRL_HIP(hipMemcpyAsync(g_first.data(), d_gfirst, (size_t)n_groups * 8, hipMemcpyDeviceToHost, st));
     }
     STRL_HIP(hipStreamSynchronize(st));
   }
@@ -752,11 +762,11 @@ static int cluster_collect(strl_ctx *c, const std::vector<std::pair<uint64_t, ui
     cl_lo[n_groups] = ci;
   }
   // Table keys in insertion order = first appearance in the caller's array, counting the place-holding treads too
-  struct KeyEnt { uint64_t key; uint32_t first; int32_t g; };
+  struct KeyEnt { uint64_t key; uint64_t first; int32_t g; };
   std::vector<KeyEnt> ents;
   std::vector<std::pair<uint64_t, uint32_t>> ghosts = ghosts_in;
   ents.reserve(n_groups + ghosts.size());
-  for (uint32_t g = 0; g < n_groups; ++g) ents.push_back(KeyEnt{g_keys[g], R.kept.empty() ? g_first[g] : R.kept[g_first[g]], (int32_t)g});
+  for (uint32_t g = 0; g < n_groups; ++g) ents.push_back(KeyEnt{g_keys[g], R.kept.empty() ? g_first[g] : (uint64_t)R.kept[(size_t)g_first[g]], (int32_t)g});
   if (!ghosts.empty()) {
     std::sort(ghosts.begin(), ghosts.end());
     std::vector<KeyEnt> real = ents;
@@ -764,8 +774,8 @@ static int cluster_collect(strl_ctx *c, const std::vector<std::pair<uint64_t, ui
     for (size_t q = 0; q < ghosts.size(); ++q) {
       if (q && ghosts[q].first == ghosts[q - 1].first) continue;       // first (smallest index) ghost of each key
       auto it = std::lower_bound(real.begin(), real.end(), ghosts[q].first, [](const KeyEnt &a, uint64_t k) { return a.key < k; });
-      if (it != real.end() && it->key == ghosts[q].first) { KeyEnt &e = ents[(size_t)it->g]; e.first = std::min(e.first, ghosts[q].second); }
-      else ents.push_back(KeyEnt{ghosts[q].first, ghosts[q].second, -1});
+      if (it != real.end() && it->key == ghosts[q].first) { KeyEnt &e = ents[(size_t)it->g]; e.first = std::min<uint64_t>(e.first, ghosts[q].second); }
+      else ents.push_back(KeyEnt{ghosts[q].first, (uint64_t)ghosts[q].second, -1});
     }
   }
   std::sort(ents.begin(), ents.end(), [](const KeyEnt &a, const KeyEnt &b) { return a.first < b.first; });
@@ -888,7 +898,10 @@ extern "C" int strl_cluster_resident(strl_ctx *c, int mode, int32_t n_tid, int p
   R.pos_bits = pos_bits ? pos_bits : 32;
   R.kbits = bits_for((uint64_t)n_tid) + 15;
   R.composite = R.pos_bits + R.kbits <= 64;
-  R.treads = c->treads.as<strl_tread>(); R.d_n = c->n_treads_dev;
+  // The treads as the pair logic emitted them (unordered) with their emission keys: clustering does not need the .bin order,
+  // only which group appears first in it (ties between equal positions never change a row: bounds() works on counts)
+  if (c->pair_ordered) { R.treads = c->treads.as<strl_tread>(); R.d_n = c->n_treads_dev; R.first_key = nullptr; }   // (already ordered for a fetch)
+  else { R.treads = c->p_emit.as<strl_tread>(); R.d_n = c->pair_cnt.as<uint32_t>() + PC_EMIT; R.first_key = c->po_key; }
   int rc;
   if ((rc = cluster_device_pass(c, R.treads, R.d_n))) return rc;
   if (!out && !n_out && !stats && !n_unplaced) return STRL_OK;      // asynchronous: results stay on the device
@@ -897,6 +910,8 @@ extern "C" int strl_cluster_resident(strl_ctx *c, int mode, int32_t n_tid, int p
 
 extern "C" int strl_ctx_treads_device(strl_ctx *c, void **treads, uint64_t *cap, void **count) {
   if (!c || !c->n_treads_dev) { set_error("strl_ctx_treads_device: no strl_extract_device call on this context"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  { const int rc0 = strl_pair_order(c); if (rc0) return rc0; }           // the gather wants the .bin order
   if (treads) *treads = c->treads.p;
   if (cap) *cap = c->tread_cap;
   if (count) *count = c->n_treads_dev;

@@ -62,6 +62,7 @@ struct ClusterRun {
   const strl_tread *treads = nullptr;   // device
   const uint32_t *d_n = nullptr;        // device
   const uint32_t *perm = nullptr;       // device: sorted index -> input index
+  const uint64_t *first_key = nullptr;  // device: per-tread key that orders first appearances (nullptr: the input index)
   // members of the bounds the last pass returned: [first, first + count) in sorted order; `kept` maps the
   // uploaded (filtered) treads back to the caller's indices when merge mode dropped unplaced ones
   std::vector<uint32_t> b_first, b_count, kept;
@@ -97,6 +98,11 @@ struct strl_ctx {
   strl::DevBuf treads;
   uint32_t *n_treads_dev = nullptr;
   uint32_t tread_cap = 0, pair_item_cap = 0;
+  // the last pair pass' treads before ordering: p_emit[i] with emission key po_key[i] (and the sort's other buffers)
+  uint64_t *po_key = nullptr, *po_key_alt = nullptr;
+  uint32_t *po_val = nullptr, *po_val_alt = nullptr;
+  int po_bits = 0;
+  bool pair_ordered = false;
   uint64_t ex_n = 0, ex_soft_cap = 0;
   // chunked extract (strl_extract_begin / _add / _finish): per-read state of all chunks so far
   strl::DevBuf x_rows, x_qhash, x_whole, x_soft, x_cnt, g_aux;
@@ -108,5 +114,6 @@ struct strl_ctx {
 };
 
 // pair.hip: enqueue the device pair logic behind a scoring pass of the same batch
+int strl_pair_order(strl_ctx *c);
 int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uint32_t *whole, const strl_soft_rec *soft,
                      const uint32_t *d_n_soft, uint64_t soft_cap, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap);

@@ -271,17 +271,17 @@ static_assert(sizeof(PItem) == 48, "PItem layout");
 
 constexpr int PG_BLOCK = 1024;               // items per block
 constexpr int PG_HALO = 16;                  // a run that starts in the block may reach this far into the next one
-constexpr int PG_EMIT = 1024;                // treads one block may emit (LDS staging)
+constexpr int PG_EMIT = 512;                 // treads one block may emit (LDS staging; 70 KB per block in all: two blocks per CU)
 
 struct EmitStage {   // block-wide staging of the emitted treads in LDS
   strl_tread *t;
   uint64_t *key;
   uint32_t *count;
+  const PairParams *P;
 };
 __device__ inline void emit(const EmitStage &E, const DTread &d, uint64_t vidx, uint32_t &seq, uint32_t &err) {
   const uint32_t slot = atomicAdd(E.count, 1u);
   const uint32_t k = seq++;
-  if (slot >= (uint32_t)PG_EMIT) { err |= PAIR_ERR_LOCAL; return; }
   strl_tread t;
   t.tid = d.tid;
   t.position = d.position;
@@ -293,8 +293,12 @@ __device__ inline void emit(const EmitStage &E, const DTread &d, uint64_t vidx, 
   t.repeat_count = d.count;
   t.align_length = d.align_length;
   t.qname_id = (int64_t)d.qid;
-  E.t[slot] = t;
-  E.key[slot] = (vidx << 2) | (uint64_t)(k & 3u);
+  const uint64_t key = (vidx << 2) | (uint64_t)(k & 3u);
+  if (slot < (uint32_t)PG_EMIT) { E.t[slot] = t; E.key[slot] = key; return; }
+  // the block's staging area is full (nearly every group of this block emits): straight to the output, one atomic each
+  const uint32_t g = atomicAdd(&E.P->pc[PC_EMIT], 1u);
+  if (g < E.P->emit_cap) { E.P->emit[g] = t; E.P->emit_key[g] = key; E.P->emit_val[g] = g; }
+  else err |= PAIR_ERR_EMIT;
 }
 
 struct GroupCtx {
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(PG_BLOCK) void pair_groups_kernel(PairParams P) {
   uint32_t *sh = reinterpret_cast<uint32_t *>(st_k + PG_EMIT);   // [0] emitted count, [1] output base
   uint32_t n_items = P.pc[PC_ITEMS];
   if (n_items > P.item_cap) n_items = P.item_cap;
-  const EmitStage E{st_t, st_k, sh};
+  const EmitStage E{st_t, st_k, sh, &P};
   for (uint32_t b0 = blockIdx.x * (uint32_t)PG_BLOCK; b0 < n_items; b0 += gridDim.x * (uint32_t)PG_BLOCK) {
     if (threadIdx.x == 0) sh[0] = 0;
     // ---- phase 1: gather ----
@@ -587,6 +591,26 @@ extern "C" int strl_pair_rule_device(strl_ctx *c, int op, strl_tread *A, const s
   return STRL_OK;
 }
 
+// Treads of the last strl_pair_device call into the order of the reference's .bin file (c->treads); idempotent.
+int strl_pair_order(strl_ctx *c) {
+  if (!c->n_treads_dev) { set_error("no strl_extract_device call on this context"); return STRL_ERR_ARG; }
+  if (c->pair_ordered) return STRL_OK;
+  hipStream_t st = c->stream;
+  const uint32_t ecap = c->tread_cap;
+  uint64_t *ok = nullptr;
+  uint32_t *ov = nullptr;
+  const int e = radix_sort_pairs(st, c->pair_cnt.as<uint32_t>() + PC_EMIT, ecap, c->po_key, c->po_val, c->po_key_alt, c->po_val_alt, c->sort_scratch.p,
+                                 c->sort_scratch.cap, 0, c->po_bits, &ok, &ov);
+  if (e) { set_error("radix_sort_pairs failed: %s", hipGetErrorString((hipError_t)e)); return STRL_ERR_HIP; }
+  uint32_t *n_out = reinterpret_cast<uint32_t *>(c->treads.as<uint8_t>() + (size_t)ecap * sizeof(strl_tread));
+  hipLaunchKernelGGL(pair_order_kernel, dim3((ecap + 255) / 256), dim3(256), 0, st, c->pair_cnt.as<uint32_t>(), ecap, c->p_emit.as<strl_tread>(), ov,
+                     c->treads.as<strl_tread>(), n_out);
+  STRL_HIP(hipGetLastError());
+  c->n_treads_dev = n_out;
+  c->pair_ordered = true;
+  return STRL_OK;
+}
+
 // Enqueue the pair logic behind a scoring pass of the same batch (score_device has run on c->stream with the pairing
 // arrays given, so the whole-read marks are in the bitmap).  Everything is asynchronous; results stay on the device:
 // c->treads[0, *c->n_treads).
@@ -653,14 +677,12 @@ int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uin
     STRL_HIP(hipGetLastError());
   }
   if (ev) STRL_HIP(hipEventRecord(ev[4], st));
-  // the items are consumed: their buffers are the sort's second pair now
-  uint64_t *ok = nullptr;
-  uint32_t *ov = nullptr;
-  e = radix_sort_pairs(st, P.pc + PC_EMIT, ecap, ek, evl, ik, iv, c->sort_scratch.p, c->sort_scratch.cap, 0, ebits, &ok, &ov);
-  if (e) { set_error("radix_sort_pairs failed: %s", hipGetErrorString((hipError_t)e)); return STRL_ERR_HIP; }
-  c->n_treads_dev = reinterpret_cast<uint32_t *>(c->treads.as<uint8_t>() + (size_t)ecap * sizeof(strl_tread));
-  hipLaunchKernelGGL(pair_order_kernel, dim3((ecap + 255) / 256), dim3(256), 0, st, P.pc, ecap, P.emit, ov, c->treads.as<strl_tread>(), c->n_treads_dev);
-  STRL_HIP(hipGetLastError());
+  // The treads now sit in p_emit in arbitrary order, each with its emission key.  Putting them into the order of the .bin
+  // file costs another sort; it is done when somebody asks for the ordered array (strl_treads_fetch, the multi-GPU
+  // gather), not here: clustering only needs the keys (first appearance of a group), see strl_cluster_resident.
+  c->po_key = ek; c->po_val = evl; c->po_key_alt = ik; c->po_val_alt = iv; c->po_bits = ebits;
+  c->pair_ordered = false;
+  c->n_treads_dev = c->pair_cnt.as<uint32_t>() + PC_EMIT;          // (clamped to tread_cap by every reader)
   if (ev) STRL_HIP(hipEventRecord(ev[5], st));
   c->tread_cap = ecap;
   c->pair_item_cap = icap;

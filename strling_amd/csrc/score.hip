@@ -146,7 +146,58 @@ __device__ __forceinline__ void skip_predicate_n(const ScoreParams &P, const uin
     for (int j = 0; j < N; ++j) ti[j] = P.g_tid[cand[j] ? t[j] : 0];
   }
   // lapper.find(start, stop) <=> any interval with iv.start < stop and iv.stop > start.
-  // idx = number of intervals with iv.start < stop: bin directory, then a short scan inside the bin.
+  // With idx = number of intervals with iv.start < stop, that is: (max stop of intervals 0 .. idx-1) > start = g_iv[idx].y.
+  //
+  // Merge-join fast path.  The reads of a wave iteration are consecutive records of a coordinate-sorted file: they sit on
+  // one contig within a few kilobases, and only a handful of intervals START inside that span.  So the wave looks the span
+  // up ONCE -- bin directory, then a window of WIN consecutive {start, running max stop} entries, all at wave-uniform
+  // addresses -- and every read finds its idx by comparing its stop with the window's starts in registers: no per-lane
+  // dependent global loads at all (they were what bounded this kernel: three round trips per batch of reads at three
+  // waves per SIMD).  A window that does not cover the span (unsorted input, a very dense stretch) falls through to the
+  // per-read path below.
+  constexpr int WIN = 8;
+  if (uniform) {
+    int32_t smin = INT32_MAX, smax = INT32_MIN;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      cand[j] = cand[j] && ti[0].has;
+      if (cand[j]) { smin = stop[j] < smin ? stop[j] : smin; smax = stop[j] > smax ? stop[j] : smax; }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int32_t a = __shfl_xor(smin, d), b = __shfl_xor(smax, d);
+      smin = a < smin ? a : smin;
+      smax = b > smax ? b : smax;
+    }
+    smin = __builtin_amdgcn_readfirstlane(smin);
+    smax = __builtin_amdgcn_readfirstlane(smax);
+    if (smin > smax) {          // no candidate in the wave
+#pragma unroll
+      for (int j = 0; j < N; ++j) skip[j] = false;
+      return;
+    }
+    const TidInfo tu = ti[0];
+    const int32_t b0 = smin > 0 ? (smin >> BIN_SHIFT) : 0;
+    int32_t i0 = tu.n_iv;
+    if (b0 < tu.n_bins) i0 = (int32_t)P.g_bins[tu.bin_off + b0].x;      // # starts below the bin: <= idx(smin)
+    i0 = __builtin_amdgcn_readfirstlane(i0);
+    const int2 *w = P.g_iv + tu.iv_off + i0;
+    const int32_t rem = tu.n_iv - i0;                                    // entries i0 .. n_iv exist (n_iv = the sentinel)
+    int2 e[WIN];
+#pragma unroll
+    for (int q = 0; q < WIN; ++q) e[q] = w[q < rem ? q : rem];
+    if (e[WIN - 1].x >= smax) {                                          // the window holds every start below the largest stop
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        int32_t pm = e[0].y;
+#pragma unroll
+        for (int q = 0; q + 1 < WIN; ++q) pm = e[q].x < stop[j] ? e[q + 1].y : pm;   // starts ascend: the last true one decides
+        skip[j] = cand[j] && !(pm > start[j]);
+      }
+      return;
+    }
+  }
+  // per-read path: idx = number of intervals with iv.start < stop: bin directory, then a short scan inside the bin.
   int32_t idx[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -1142,6 +1193,7 @@ int strl_treads_fetch(strl_ctx *c, strl_tread *out, uint64_t cap, uint64_t *n_ou
   if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
   if (!c->n_treads_dev) { set_error("strl_treads_fetch: no strl_extract_device call on this context"); return STRL_ERR_ARG; }
   STRL_HIP(hipSetDevice(c->device));
+  { const int rc0 = strl_pair_order(c); if (rc0) return rc0; }
   uint32_t raw[CNT_WORDS], pc[PC_WORDS], xc[XC_WORDS];
   STRL_HIP(hipMemcpyAsync(raw, c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
   STRL_HIP(hipMemcpyAsync(pc, c->pair_cnt.p, PC_WORDS * 4, hipMemcpyDeviceToHost, c->stream));

@@ -267,6 +267,32 @@ def test_extract_device_and_resident_clustering_match_oracle(ctx, oracle, n_pair
     assert np.array_equal(b, b2) and np.array_equal(u, u2)
 
 
+def test_resident_clustering_before_and_after_the_bin_order_sort(ctx, oracle):
+    """strl_cluster_resident straight behind strl_extract_device clusters the treads as the pair logic emitted them
+    (unordered, first appearance from the emission keys); after a fetch it clusters the ordered array: same rows either way.
+    The batch is nearly all STR reads: most qname groups emit."""
+    rec, g = synth.synth_wgs(6000, seed=91, contig_len=400_000, str_frac=0.9, n_contigs=4)
+    frag = synth.frag_hist(rec)
+    med = oracle.median(frag)
+    ctx.set_opts(0.8, 40, med)
+    ctx.set_genome(g)
+    soa = api.Soa(rec)
+    cp, keep = _pair_soa(rec, soa)
+    window, mcd = api.frag_median(frag, 0.99), int(0.5 * api.frag_median(frag, 0.5))
+    ctx.extract_device(soa.c_struct(), cp, int((rec.tid < 0).sum()))
+    b1, u1, _ = ctx.cluster_resident(len(rec.targets), window, min_support=3, max_clip_dist=mcd)          # unordered treads
+    got, _ = ctx.treads_fetch()                                                                             # orders them
+    b2, u2, _ = ctx.cluster_resident(len(rec.targets), window, min_support=3, max_clip_dist=mcd)          # ordered treads
+    exp = oracle.extract(rec, g, oracle.make_opts(med, 0.8, 40))
+    ok, why = treads_equal(got, exp)
+    assert ok and len(exp) > 3000, why
+    eb, eu = oracle.call_bounds(exp, 1, window, min_support=3, max_clip_dist=mcd)
+    rows = [oracle.bounds_row(x, "c") for x in eb]
+    assert [api.bounds_row(x, "c") for x in b1] == rows and [api.bounds_row(x, "c") for x in b2] == rows and len(rows) > 5
+    assert [(x["repeat"].decode(), int(x["count"])) for x in u1] == [(r, int(k)) for r, k in eu]
+    assert np.array_equal(u1, u2)
+
+
 def test_pair_logic_corner_cases_on_the_device(ctx, oracle):
     """qname groups the reference treats specially: a third record with a qname already paired, a one-op soft clip
     (both loop iterations of add_soft look at cigar[0]), secondary / supplementary records, an unpaired read, equal
