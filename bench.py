@@ -62,12 +62,12 @@ def main():
     n_chunks = max(1, min(args.chunks, args.reads_per_gpu // 2048))
     pairs_per_chunk = max(1, args.reads_per_gpu // 2 // n_chunks)
     procs = max(1, min(n_chunks, (os.cpu_count() or 2) // max(1, min(world, 8)) - 2))
-    cache = os.path.join(args.cache, f"s1_{args.reads_per_gpu}_{n_chunks}_{rank}.pkl") if args.cache else ""
+    cache = os.path.join(args.cache, f"s1x30_{args.reads_per_gpu}_{n_chunks}_{rank}.pkl") if args.cache else ""
     if cache and os.path.exists(cache):
         import pickle
         rec, g = pickle.load(open(cache, "rb"))
     else:
-        rec, g = synth.synth_wgs_chunks(n_chunks, pairs_per_chunk, seed=1234 + 1000 * rank, procs=procs)
+        rec, g = synth.synth_wgs_30x(n_chunks, pairs_per_chunk, seed=1234 + 1000 * rank, procs=procs)
         if cache:
             import pickle
             pickle.dump((rec, g), open(cache, "wb"), protocol=4)
@@ -99,7 +99,7 @@ def main():
     med = api.frag_median(frag)
     window = api.frag_median(frag, 0.99)                     # call.nim:114
     max_clip_dist = int(0.5 * api.frag_median(frag, 0.5))    # call.nim:232
-    pos_bits = max(int(max(ln for _, ln in rec.targets)) + 8192, 2).bit_length()
+    pos_bits = max(int(max(ln for _, ln in rec.targets)) + 8192, 2).bit_length() + 1   # + the half that holds adjust_by's wrapped positions
 
     def up(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)

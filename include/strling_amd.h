@@ -303,9 +303,10 @@ int strl_cluster(strl_ctx *ctx, const strl_tread *treads, uint64_t n, int mode, 
                  strl_cluster_stats *stats);
 
 /* The same over the treads the last strl_extract_device call left resident in the context (extract -> call without a
- * host round trip; STRL_MODE_CALL only).  n_tid = number of contigs of the BAM header (every tid < n_tid); pos_bits: bits
- * that hold every tread position (0 = 32), e.g. 28 for a genome whose longest contig is < 2^28 bases -- fewer key bits,
- * fewer sort passes.  With out, n_out, n_unplaced and stats all NULL the call only enqueues the kernels (asynchronous). */
+ * host round trip; STRL_MODE_CALL only).  n_tid = number of contigs of the BAM header (every tid < n_tid); pos_bits: width
+ * of the position field of the sort key (0 = 32; else >= 2): 1 + the bits that hold every position on a contig, e.g. 29 for
+ * a genome whose longest contig is < 2^28 bases -- fewer key bits, fewer sort passes.  The upper half of the field takes
+ * the positions adjust_by wrapped below zero (uint32 arithmetic, utils.nim:304-310), in the reference's uint32 order.  With out, n_out, n_unplaced and stats all NULL the call only enqueues the kernels (asynchronous). */
 int strl_cluster_resident(strl_ctx *ctx, int mode, int32_t n_tid, int pos_bits, uint32_t window, int32_t min_support, uint16_t min_clip,
                           uint16_t min_clip_total, uint16_t max_clip_dist, strl_bounds *out, uint64_t cap, uint64_t *n_out,
                           strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced, strl_cluster_stats *stats);

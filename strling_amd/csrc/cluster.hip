@@ -330,7 +330,7 @@ struct KeyParams {
   uint64_t *first_in;           // what orders the groups' first appearances: the input index, or ...
   const uint64_t *first_key;    // ... the emission key of an unordered tread (treads straight from the pair logic), or nullptr
   uint32_t *cnt;
-  int composite, pos_bits;
+  int composite, pos_bits, fold;
   int32_t n_tid;    // tids must be < n_tid
 };
 __global__ __launch_bounds__(256) void tread_keys_kernel(KeyParams K) {
@@ -363,8 +363,20 @@ __global__ __launch_bounds__(256) void tread_keys_kernel(KeyParams K) {
   K.first_in[i] = K.first_key ? K.first_key[i] : (uint64_t)i;
   K.val[i] = i;
   if (K.composite) {
-    if (K.pos_bits < 32 && (t.position >> K.pos_bits)) err |= CERR_POS;
-    K.key[i] = (gkey << K.pos_bits) | t.position;
+    // A caller-given pos_bits < 32 covers [0, 2^(pos_bits-1)) and, folded into the upper half of the field in the same
+    // uint32 order, the positions adjust_by wrapped below zero (utils.nim:304-310: uint32 arithmetic near a contig start).
+    uint32_t pe = t.position;
+    if (!K.fold) {
+      if (K.pos_bits < 32 && (pe >> K.pos_bits)) err |= CERR_POS;
+    } else if (K.pos_bits < 32) {
+      const uint32_t half = 1u << (K.pos_bits - 1);
+      if (pe >= half) {
+        if (pe < 0u - half) err |= CERR_POS;
+        pe += 1u << K.pos_bits;            // mod 2^32: [2^32 - half, 2^32) -> [half, 2^pos_bits)
+        pe &= (1u << K.pos_bits) - 1u;
+      }
+    }
+    K.key[i] = (gkey << K.pos_bits) | pe;
   } else {
     K.key[i] = t.position;
     K.gkey_in[i] = gkey;
@@ -614,7 +626,7 @@ static int cluster_device_pass(strl_ctx *c, const strl_tread *treads, const uint
   K.d_n = d_n; K.n_max = n_max; K.treads = treads; K.key = B[B_KEY0].as<uint64_t>(); K.val = B[B_VAL0].as<uint32_t>();
   K.pos_in = d_posin; K.sample_in = d_samplein; K.split_in = d_splitin; K.gkey_in = R.composite ? nullptr : B[B_GKEY].as<uint64_t>();
   K.first_in = B[B_FIRST].as<uint64_t>(); K.first_key = R.first_key;
-  K.cnt = cnt; K.composite = R.composite ? 1 : 0; K.pos_bits = R.pos_bits; K.n_tid = R.n_tid;
+  K.cnt = cnt; K.composite = R.composite ? 1 : 0; K.pos_bits = R.pos_bits; K.fold = R.fold ? 1 : 0; K.n_tid = R.n_tid;
   hipLaunchKernelGGL(tread_keys_kernel, dim3(nb), dim3(TB), 0, st, K);
   uint64_t *sk = nullptr;
   uint32_t *sv = nullptr;
@@ -886,7 +898,7 @@ extern "C" int strl_cluster_resident(strl_ctx *c, int mode, int32_t n_tid, int p
   if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
   if (!c->n_treads_dev) { set_error("strl_cluster_resident: no strl_extract_device call on this context"); return STRL_ERR_ARG; }
   if (mode != STRL_MODE_CALL) { set_error("strl_cluster_resident clusters the treads of one sample (STRL_MODE_CALL)"); return STRL_ERR_ARG; }
-  if (n_tid < 0 || pos_bits < 0 || pos_bits > 32) { set_error("bad argument"); return STRL_ERR_ARG; }
+  if (n_tid < 0 || pos_bits < 0 || pos_bits > 32 || pos_bits == 1) { set_error("bad argument"); return STRL_ERR_ARG; }
   if (n_out) *n_out = 0;
   if (n_unplaced) *n_unplaced = 0;
   if (stats) memset(stats, 0, sizeof *stats);
@@ -896,6 +908,7 @@ extern "C" int strl_cluster_resident(strl_ctx *c, int mode, int32_t n_tid, int p
   R.n_max = c->tread_cap; R.n_tid = n_tid; R.mode = mode; R.window = window; R.min_support = min_support; R.min_clip = min_clip;
   R.min_clip_total = min_clip_total; R.max_clip_dist = max_clip_dist;
   R.pos_bits = pos_bits ? pos_bits : 32;
+  R.fold = true;
   R.kbits = bits_for((uint64_t)n_tid) + 15;
   R.composite = R.pos_bits + R.kbits <= 64;
   // The treads as the pair logic emitted them (unordered) with their emission keys: clustering does not need the .bin order,
@@ -955,6 +968,7 @@ extern "C" int strl_cluster_gathered(strl_ctx *c, const strl_tread *gathered, co
   R.n_max = tot; R.n_tid = n_tid; R.mode = mode; R.window = window; R.min_support = min_support; R.min_clip = min_clip;
   R.min_clip_total = min_clip_total; R.max_clip_dist = max_clip_dist;
   R.pos_bits = pos_bits ? pos_bits : 32;
+  R.fold = true;
   R.kbits = bits_for((uint64_t)n_tid) + 15;
   R.composite = R.pos_bits + R.kbits <= 64;
   R.treads = B[B_TREADS].as<strl_tread>(); R.d_n = cnt + CC_N;
@@ -1022,6 +1036,7 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
   R.min_clip_total = min_clip_total; R.max_clip_dist = max_clip_dist;
   R.kbits = bits_for((uint64_t)(uint32_t)(max_tid + 1)) + 15;
   R.pos_bits = bits_for(max_pos);
+  R.fold = false;
   if (getenv("STRL_CLUSTER_TWO_SORTS")) R.pos_bits = 64;   // tests: force the two-sort path
   R.composite = R.pos_bits + R.kbits <= 64;
   if (!R.composite) R.pos_bits = 32;

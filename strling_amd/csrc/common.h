@@ -55,6 +55,7 @@ struct ClusterRun {
   uint32_t n = 0, n_groups = 0, n_clusters = 0;   // known after the results were collected
   int32_t n_tid = 0;
   int kbits = 0, pos_bits = 32, mode = 0;
+  bool fold = false;   // pos_bits is a caller's bound (resident / gathered treads): the field's upper half takes wrapped positions
   bool composite = false;
   uint32_t window = 0;
   int32_t min_support = 0;

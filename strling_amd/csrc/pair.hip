@@ -647,7 +647,8 @@ int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uin
   if (n) {
     hipLaunchKernelGGL(pair_soft_items_kernel, dim3(512), dim3(1024), 0, st, P);
     if (ev) STRL_HIP(hipEventRecord(ev[1], st));
-    const int pblocks = (int)std::min<uint64_t>((n + 2047) / 2048, 512);
+    static const int env_p = getenv("STRL_GRID_P") ? atoi(getenv("STRL_GRID_P")) : 0;
+    const int pblocks = (int)std::min<uint64_t>((n + 2047) / 2048, env_p > 0 ? (uint64_t)env_p : 1024);   // 4 resident blocks (40 KB of LDS each) per CU; measured 256..4096
     hipLaunchKernelGGL(pair_probe_kernel, dim3(pblocks), dim3(256), 0, st, P);
     STRL_HIP(hipGetLastError());
   }

@@ -117,9 +117,38 @@ constexpr int CL_ILP = 8;        // reads per lane per iteration (independent lo
 // The predicate for N independent reads of one lane, written as straight-line PHASES (all directory loads, then all
 // bin loads, then all interval loads) so that the N lookup chains are in flight together: N separately inlined
 // while-loops serialise their chains, and the kernel is bound by exactly that latency.
+// One read against the table, the general way: bin directory, then a short scan inside the bin.  Out of line on purpose:
+// it serves the rare wave iteration the merge join below cannot (a contig boundary, unsorted input, a very dense
+// stretch), and inlining N copies of its three dependent loads costs the common path ~90 VGPRs (a wave less per SIMD).
+__device__ __noinline__ bool skip_one(const TidInfo *g_tid, const uint2 *g_bins, const int2 *g_iv, int32_t t, int32_t start, int32_t stop) {
+  const TidInfo ti = g_tid[t];
+  if (!ti.has) return false;
+  const int32_t b = stop > 0 ? (stop >> BIN_SHIFT) : 0;
+  int32_t idx = ti.n_iv;                 // idx = number of intervals with iv.start < stop
+  if (b < ti.n_bins) idx = (int32_t)g_bins[ti.bin_off + b].x;
+  int2 c = g_iv[ti.iv_off + idx];
+  while (c.x < stop) {                   // a start inside the bin below `stop`: rare, and the sentinel ends it
+    ++idx;
+    c = g_iv[ti.iv_off + idx];
+  }
+  return !(c.y > start);                 // c.y = longest reach of the intervals starting before `stop`
+}
+
+// The merge join's wave-uniform state, carried ACROSS the iterations of a wave: the contig entry and a window of WIN
+// consecutive {start, running max stop} entries.  Consecutive iterations of a coordinate-sorted wave advance a few
+// kilobases, a window spans tens of kilobases: most iterations reuse it and issue no table load at all.
+constexpr int JOIN_WIN = 8;
+struct JoinState {
+  int32_t t;              // contig the entry / window belong to (-2: none yet)
+  int32_t lo;             // every table entry before the window starts below `lo`
+  int32_t valid;
+  TidInfo tu;
+  int2 e[JOIN_WIN];
+};
+
 template <int N>
-__device__ __forceinline__ void skip_predicate_n(const ScoreParams &P, const uint32_t (&cg)[N], const int32_t (&t)[N], const int32_t (&start)[N],
-                                                 const int32_t (&stop)[N], const bool (&in)[N], bool (&skip)[N]) {
+__device__ __forceinline__ void skip_predicate_n(const ScoreParams &P, JoinState &J, const uint32_t (&cg)[N], const int32_t (&t)[N],
+                                                 const int32_t (&start)[N], const int32_t (&stop)[N], const bool (&in)[N], bool (&skip)[N]) {
   bool cand[N];
   bool any = false;
 #pragma unroll
@@ -127,7 +156,14 @@ __device__ __forceinline__ void skip_predicate_n(const ScoreParams &P, const uin
     cand[j] = in[j] && (cg[j] & STRL_CIG_SINGLE_M) && t[j] >= 0 && t[j] < P.n_tid;
     any |= cand[j];
   }
-  // A coordinate-sorted wave almost always sits on ONE contig: fetch its directory entry once (uniform address).
+  // lapper.find(start, stop) <=> any interval with iv.start < stop and iv.stop > start.
+  // With idx = number of intervals with iv.start < stop, that is: (max stop of intervals 0 .. idx-1) > start = g_iv[idx].y.
+  //
+  // Merge join.  The reads of a wave iteration are consecutive records of a coordinate-sorted file: they sit on ONE
+  // contig within a few kilobases, and only a handful of intervals START inside that span.  So the wave looks the span
+  // up ONCE -- contig entry, bin directory, then a window of JOIN_WIN consecutive {start, running max stop} entries, all
+  // at wave-uniform addresses -- and every read finds its idx by comparing its stop with the window's starts in
+  // registers: no per-lane dependent global loads at all.
   int32_t t0 = 0;
 #pragma unroll
   for (int j = N - 1; j >= 0; --j) if (cand[j]) t0 = t[j];
@@ -135,32 +171,23 @@ __device__ __forceinline__ void skip_predicate_n(const ScoreParams &P, const uin
   bool same = true;
 #pragma unroll
   for (int j = 0; j < N; ++j) same = same && (!cand[j] || t[j] == t0);
-  const bool uniform = __all(same) && __any(any);
-  TidInfo ti[N];
-  if (uniform) {
-    const TidInfo tu = P.g_tid[__builtin_amdgcn_readfirstlane(t0 < 0 ? 0 : (t0 < P.n_tid ? t0 : 0))];
+  if (!__any(any)) {
 #pragma unroll
-    for (int j = 0; j < N; ++j) ti[j] = tu;
-  } else {
-#pragma unroll
-    for (int j = 0; j < N; ++j) ti[j] = P.g_tid[cand[j] ? t[j] : 0];
+    for (int j = 0; j < N; ++j) skip[j] = false;
+    return;
   }
-  // lapper.find(start, stop) <=> any interval with iv.start < stop and iv.stop > start.
-  // With idx = number of intervals with iv.start < stop, that is: (max stop of intervals 0 .. idx-1) > start = g_iv[idx].y.
-  //
-  // Merge-join fast path.  The reads of a wave iteration are consecutive records of a coordinate-sorted file: they sit on
-  // one contig within a few kilobases, and only a handful of intervals START inside that span.  So the wave looks the span
-  // up ONCE -- bin directory, then a window of WIN consecutive {start, running max stop} entries, all at wave-uniform
-  // addresses -- and every read finds its idx by comparing its stop with the window's starts in registers: no per-lane
-  // dependent global loads at all (they were what bounded this kernel: three round trips per batch of reads at three
-  // waves per SIMD).  A window that does not cover the span (unsorted input, a very dense stretch) falls through to the
-  // per-read path below.
-  constexpr int WIN = 8;
-  if (uniform) {
+  constexpr int WIN = JOIN_WIN;
+  if (__all(same)) {
+    if (t0 != J.t) {
+      J.tu = P.g_tid[__builtin_amdgcn_readfirstlane(t0 < 0 ? 0 : (t0 < P.n_tid ? t0 : 0))];
+      J.t = t0;
+      J.valid = 0;
+    }
+    const TidInfo &tu = J.tu;
     int32_t smin = INT32_MAX, smax = INT32_MIN;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      cand[j] = cand[j] && ti[0].has;
+      cand[j] = cand[j] && tu.has;
       if (cand[j]) { smin = stop[j] < smin ? stop[j] : smin; smax = stop[j] > smax ? stop[j] : smax; }
     }
 #pragma unroll
@@ -176,53 +203,41 @@ __device__ __forceinline__ void skip_predicate_n(const ScoreParams &P, const uin
       for (int j = 0; j < N; ++j) skip[j] = false;
       return;
     }
-    const TidInfo tu = ti[0];
-    const int32_t b0 = smin > 0 ? (smin >> BIN_SHIFT) : 0;
-    int32_t i0 = tu.n_iv;
-    if (b0 < tu.n_bins) i0 = (int32_t)P.g_bins[tu.bin_off + b0].x;      // # starts below the bin: <= idx(smin)
-    i0 = __builtin_amdgcn_readfirstlane(i0);
-    const int2 *w = P.g_iv + tu.iv_off + i0;
-    const int32_t rem = tu.n_iv - i0;                                    // entries i0 .. n_iv exist (n_iv = the sentinel)
-    int2 e[WIN];
+    if (!(J.valid && smin >= J.lo && J.e[WIN - 1].x >= smax)) {          // (re)load the window at the bin of the smallest stop
+      const int32_t b0 = smin > 0 ? (smin >> BIN_SHIFT) : 0;
+      int32_t i0 = tu.n_iv;
+      if (b0 < tu.n_bins) i0 = (int32_t)P.g_bins[tu.bin_off + b0].x;    // # starts below the bin: <= idx(smin)
+      i0 = __builtin_amdgcn_readfirstlane(i0);
+      const int2 *w = P.g_iv + tu.iv_off + i0;
+      const int32_t rem = tu.n_iv - i0;                                  // entries i0 .. n_iv exist (n_iv = the sentinel)
 #pragma unroll
-    for (int q = 0; q < WIN; ++q) e[q] = w[q < rem ? q : rem];
-    if (e[WIN - 1].x >= smax) {                                          // the window holds every start below the largest stop
+      for (int q = 0; q < WIN; ++q) {
+        const int2 v = w[q < rem ? q : rem];
+        J.e[q].x = __builtin_amdgcn_readfirstlane(v.x);
+        J.e[q].y = __builtin_amdgcn_readfirstlane(v.y);
+      }
+      J.lo = b0 << BIN_SHIFT;                                            // (past the last bin every start lies below it, too)
+      J.valid = 1;
+    }
+    if (J.e[WIN - 1].x >= smax) {                                        // the window holds every start below the largest stop
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        int32_t pm = e[0].y;
+        int32_t pm = J.e[0].y;
 #pragma unroll
-        for (int q = 0; q + 1 < WIN; ++q) pm = e[q].x < stop[j] ? e[q + 1].y : pm;   // starts ascend: the last true one decides
+        for (int q = 0; q + 1 < WIN; ++q) pm = J.e[q].x < stop[j] ? J.e[q + 1].y : pm;   // starts ascend: the last true one decides
         skip[j] = cand[j] && !(pm > start[j]);
       }
       return;
     }
   }
-  // per-read path: idx = number of intervals with iv.start < stop: bin directory, then a short scan inside the bin.
-  int32_t idx[N];
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    cand[j] = cand[j] && ti[j].has;
-    const int32_t b = stop[j] > 0 ? (stop[j] >> BIN_SHIFT) : 0;
-    idx[j] = ti[j].n_iv;
-    if (cand[j] && b < ti[j].n_bins) idx[j] = (int32_t)P.g_bins[ti[j].bin_off + b].x;
-  }
-  int2 c[N];
-#pragma unroll
-  for (int j = 0; j < N; ++j) c[j] = cand[j] ? P.g_iv[ti[j].iv_off + idx[j]] : make_int2(INT32_MAX, INT32_MIN);
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    while (c[j].x < stop[j]) {   // a start inside the bin below `stop`: rare, and the sentinel ends it
-      ++idx[j];
-      c[j] = P.g_iv[ti[j].iv_off + idx[j]];
-    }
-    skip[j] = cand[j] && !(c[j].y > start[j]);   // c.y = longest reach of the intervals starting before `stop`
-  }
+  for (int j = 0; j < N; ++j) skip[j] = cand[j] && skip_one(P.g_tid, P.g_bins, P.g_iv, t[j], start[j], stop[j]);
 }
 
 // VEC: a lane owns 4 consecutive reads per group and fetches their coordinates with 16-byte loads (needs 16-byte aligned
 // arrays; the host picks the scalar variant otherwise).
 template <bool VEC>
-__global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
+__global__ __launch_bounds__(256, 4) void classify_kernel(ScoreParams P) {
   // Each wave owns one contiguous range of reads.  Kept read indices are staged in LDS; a flush reserves queue
   // space with ONE global atomic (one same-address atomic per wave-iteration ran into the ~88 ops/us limit of
   // the L2 atomic unit: 12 ms per 2^25 reads) and gathers the reads' metadata into self-contained 16-byte items.
@@ -303,6 +318,8 @@ __global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
     }
   };
   In cur[CL_ILP], nxt[CL_ILP];
+  JoinState join;
+  join.t = -2; join.valid = 0; join.lo = 0;
   load(r0, cur);
   for (uint64_t base = r0; base < r1; base += 64 * CL_ILP) {
     load(base + 64 * CL_ILP, nxt);   // next iteration's streaming loads fly while this one chases the interval table
@@ -314,7 +331,7 @@ __global__ __launch_bounds__(256) void classify_kernel(ScoreParams P) {
       inr[j] = ridx(base, j) < r1;
       cgs[j] = cur[j].cg; ts[j] = cur[j].t; sts[j] = cur[j].st; ens[j] = cur[j].en;
     }
-    skip_predicate_n<CL_ILP>(P, cgs, ts, sts, ens, inr, skipped);
+    skip_predicate_n<CL_ILP>(P, join, cgs, ts, sts, ens, inr, skipped);
 #pragma unroll
     for (int j = 0; j < CL_ILP; ++j) {
       need[j] = inr[j] && !skipped[j];
@@ -938,7 +955,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   if (tev) STRL_HIP(hipEventRecord(tev[0], c->stream));
   if (n) {
     static const int env_c = getenv("STRL_GRID_C") ? atoi(getenv("STRL_GRID_C")) : 0;
-    const int cblocks = (int)std::min<uint64_t>((n + 255) / 256, env_c > 0 ? (uint64_t)env_c : 1536);   // 2 x (256 CUs x 3 resident blocks at 164 VGPRs); measured 768..16384
+    const int cblocks = (int)std::min<uint64_t>((n + 255) / 256, env_c > 0 ? (uint64_t)env_c : 1024);   // one round: 256 CUs x 4 resident blocks (124 VGPRs, 16 KB of LDS); measured 768..10240
     const bool vec = (((uintptr_t)P.tid | (uintptr_t)P.pos | (uintptr_t)P.end | (uintptr_t)P.whole) & 15u) == 0 && ((uintptr_t)P.cig & 3u) == 0;
     if (vec) hipLaunchKernelGGL(classify_kernel<true>, dim3(cblocks), dim3(256), 0, c->stream, P);
     else hipLaunchKernelGGL(classify_kernel<false>, dim3(cblocks), dim3(256), 0, c->stream, P);

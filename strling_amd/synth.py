@@ -294,6 +294,17 @@ def synth_wgs_chunks(n_chunks, pairs_per_chunk, seed=1234, procs=None, **kw):
     return rec, g
 
 
+def synth_wgs_30x(n_chunks, pairs_per_chunk, seed=1234, procs=None, coverage=30.0, read_len=150, loci=3200, **kw):
+    """A slab of a 30x WGS (BASELINE.json: "30x 150 bp PE synthetic WGS"): synth_wgs_chunks with the genome sized so that the
+    batch covers it `coverage` times -- consecutive records of the coordinate-sorted batch start ~5 bp apart, as in a real
+    30x BAM, instead of hundreds of bases apart.  Every chunk owns two contigs of reads * read_len / coverage / 2 bases;
+    the expanded loci the STR-rich reads pile up on stay `loci` in all (so clusters keep the size real expansions have)."""
+    contig_len = max(20_000, int(2 * pairs_per_chunk * read_len / coverage / 2))
+    hot = max(1, loci // (2 * n_chunks))
+    return synth_wgs_chunks(n_chunks, pairs_per_chunk, seed=seed, procs=procs, read_len=read_len, n_contigs=2, contig_len=contig_len,
+                            hot_loci=hot, **kw)
+
+
 def frag_hist(rec):
     """utils.fragment_length_distribution (utils.nim:86-111) on an in-memory batch, without the 100k-record
     skip (the batch IS the sample): histogram of isize in [0, 4095] over proper-pair primary records."""

@@ -129,7 +129,7 @@ def test_full_size_distinct_reads_whole_path_matches_the_oracle(oracle):
     oracle over the same 2^25 records: identical treads (same order) and identical -bounds rows.  Plus the scorer words of
     16 random 2^16-read slices, read by read."""
     rng = np.random.default_rng(99)
-    rec, g = synth.synth_wgs_chunks(64, 2 ** 18, seed=4321)
+    rec, g = synth.synth_wgs_30x(64, 2 ** 18, seed=4321)
     assert rec.n == 2 ** 25
     frag = synth.frag_hist(rec)
     med = api.frag_median(frag)
@@ -142,7 +142,7 @@ def test_full_size_distinct_reads_whole_path_matches_the_oracle(oracle):
     n_tail = int((rec.tid < 0).sum())
     ctx.extract_device(soa.c_struct(), api.CPairSoa(rows.ctypes.data, qh.ctypes.data), n_tail)
     got, st = ctx.treads_fetch()
-    b, u, cst = ctx.cluster_resident(len(rec.targets), window, min_support=5, max_clip_dist=mcd, pos_bits=24)
+    b, u, cst = ctx.cluster_resident(len(rec.targets), window, min_support=5, max_clip_dist=mcd, pos_bits=22)
     opts = oracle.make_opts(med, 0.8, 40)
     exp = oracle.extract(rec, g, opts)
     assert len(exp) > 400_000

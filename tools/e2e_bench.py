@@ -17,7 +17,7 @@ def make_input(n_pairs, d=None, level=1):
     bam, bed, out = f"{d}/e2e_{n_pairs}.bam", f"{d}/e2e_{n_pairs}.str", f"{d}/e2e_{n_pairs}.bin"
     t0 = time.time()
     chunks = max(1, min(64, n_pairs // 65536))
-    rec, g = synth.synth_wgs_chunks(chunks, n_pairs // chunks, seed=99)
+    rec, g = synth.synth_wgs_30x(chunks, n_pairs // chunks, seed=99)
     bamio.write_bam_parallel(bam, rec, level=level)
     bamio.write_genome_bed(bed, g, rec.targets)
     return {"bam": bam, "bed": bed, "out": out, "reads": rec.n, "bam_MB": round(os.path.getsize(bam) / 1e6, 1), "make_s": round(time.time() - t0, 1)}
