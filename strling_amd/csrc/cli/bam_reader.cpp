@@ -1,6 +1,7 @@
 // bam_reader.cpp -- see bam_reader.h.  BGZF = concatenated gzip members with a BC extra field carrying the
-// compressed block size (SAM spec 4.1); each is inflated with raw zlib into a <= 64 KiB buffer.
+// compressed block size (SAM spec 4.1); each is inflated into a <= 64 KiB buffer (fast_inflate.cpp, zlib behind it).
 #include "bam_reader.h"
+#include "fast_inflate.h"
 #include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
@@ -16,6 +17,22 @@
 #include <thread>
 
 namespace strl {
+
+// One BGZF block: cli/fast_inflate.cpp first, zlib when it declines (zlib's verdict on a bad stream is the one reported).
+// c[clen .. clen + 8) must be readable: it is the block's CRC32 + ISIZE trailer.  STRL_INFLATE=zlib forces zlib.
+static bool inflate_block(const uint8_t *c, uint32_t clen, uint8_t *out, uint32_t isize) {
+  static const bool zlib_only = getenv("STRL_INFLATE") && !strcmp(getenv("STRL_INFLATE"), "zlib");
+  if (!zlib_only && fast_inflate(c, clen, out, isize) == 0) return true;
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  if (inflateInit2(&zs, -15) != Z_OK) return false;
+  zs.next_in = const_cast<uint8_t *>(c); zs.avail_in = clen;
+  zs.next_out = out; zs.avail_out = isize;
+  const int rc = inflate(&zs, Z_FINISH);
+  const bool ok = rc == Z_STREAM_END && zs.total_out == isize;
+  inflateEnd(&zs);
+  return ok;
+}
 
 void RecordBatch::clear() {
   tid.clear(); pos.clear(); mtid.clear(); mpos.clear(); isize.clear(); l_seq.clear(); flag.clear(); mapq.clear();
@@ -67,13 +84,7 @@ bool BamReader::fill(std::string &err) {
     const uint32_t isz = cbuf_[clen + 4] | (cbuf_[clen + 5] << 8) | (cbuf_[clen + 6] << 16) | ((uint32_t)cbuf_[clen + 7] << 24);
     if (isz == 0) continue;
     ubuf_.resize(isz);
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) { err = "inflateInit2 failed"; return false; }
-    zs.next_in = cbuf_.data(); zs.avail_in = clen; zs.next_out = ubuf_.data(); zs.avail_out = isz;
-    const int rc = inflate(&zs, Z_FINISH);
-    inflateEnd(&zs);
-    if (rc != Z_STREAM_END || zs.total_out != isz) { err = "BGZF inflate failed"; return false; }
+    if (!inflate_block(cbuf_.data(), clen, ubuf_.data(), isz)) { err = "BGZF inflate failed"; return false; }
     return true;
   }
 }
@@ -451,15 +462,8 @@ bool BamStream::load_chunk(std::string &err) {
     size_t q = 0;
     bool have = false;
     if (g == 0) { q = skip_; have = true; gr.start = (int64_t)skip_; }
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return; }
     for (size_t k = gr.b0; k < gr.b1 && !bad; ++k) {
-      if (k != gr.b0 && inflateReset(&zs) != Z_OK) { bad = true; break; }
-      zs.next_in = const_cast<uint8_t *>(blks[k].c); zs.avail_in = blks[k].clen;
-      zs.next_out = u_.data() + blks[k].out; zs.avail_out = blks[k].isize;
-      const int rc = inflate(&zs, Z_FINISH);
-      if (rc != Z_STREAM_END || zs.total_out != blks[k].isize) { bad = true; break; }
+      if (!inflate_block(blks[k].c, blks[k].clen, u_.data() + blks[k].out, blks[k].isize)) { bad = true; break; }
       const size_t avail = blks[k].out + blks[k].isize;
       if (!have && gr.ok && (avail - g_begin >= 8192 || k + 1 == gr.b1)) {
         const int64_t s0 = guess_start(g_begin, avail);
@@ -467,7 +471,6 @@ bool BamStream::load_chunk(std::string &err) {
       }
       if (have && gr.ok) walk(gr, q, avail);
     }
-    inflateEnd(&zs);
     gr.end = have && gr.ok ? (int64_t)q : -1;
   });
   if (bad) { err = "BGZF inflate failed"; return false; }

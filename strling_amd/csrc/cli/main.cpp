@@ -26,12 +26,15 @@
 
 using namespace strl;
 
+static std::thread *g_bg_init = nullptr;   // device bring-up running beside the first host pass; exit() waits for it
+
 [[noreturn]] static void quit(const char *fmt, ...) {   // Nim `quit msg`: message on stderr, exit code 1
   va_list ap;
   va_start(ap, fmt);
   vfprintf(stderr, fmt, ap);
   va_end(ap);
   fputc('\n', stderr);
+  if (g_bg_init && g_bg_init->joinable() && g_bg_init->get_id() != std::this_thread::get_id()) g_bg_init->join();
   exit(1);
 }
 #define CHECK(call)                                                        \
@@ -130,8 +133,11 @@ static int cpu_quota() {   // CPUs this process may actually use: the cgroup CPU
 static int decode_threads() {
   const char *e = getenv("STRL_THREADS");
   if (e && atoi(e) > 0) return atoi(e);
-  // More threads than the CPU quota do not decode faster, they get throttled (measured: a 16-CPU quota on a 256-thread box)
-  static const int n = std::max(1, std::min(64, cpu_quota()));
+  // 1.5 threads per granted CPU: decode threads stall on page faults of the file mapping and on memory, so a modest
+  // oversubscription pays (measured under a 16-CPU quota on a 256-thread box: 16 threads 2.4e7 reads/s, 20-48 threads
+  // 2.8-3.0e7); far more threads than the quota only get throttled.
+  static const int n = std::max(1, std::min({64, (int)std::thread::hardware_concurrency() > 0 ? (int)std::thread::hardware_concurrency() : 64,
+                                              (3 * cpu_quota() + 1) / 2}));
   return n;
 }
 
@@ -280,6 +286,16 @@ static int extract_main(int argc, char **argv) {
   const bool verbose = a.flag("verbose");
   const int64_t batch = atoll(a.get("batch", "1048576").c_str());
 
+  // The HIP runtime + device context come up (a few hundred ms of driver work on one thread) while the host threads
+  // run the fragment-length pass.
+  strl_ctx *ctx = nullptr;
+  int ctx_rc = 0;
+  std::string ctx_err;
+  std::thread ctx_thread([&] {
+    ctx_rc = strl_ctx_create(0, &ctx);
+    if (ctx_rc) ctx_err = strl_last_error();     // (the error text is thread-local in the library)
+  });
+  g_bg_init = &ctx_thread;
   uint32_t frag[4096];
   fragment_length_distribution(bam, frag);                                        // extract.nim:281
   const int frag_median = strl_frag_median(frag, 0.5);
@@ -290,8 +306,9 @@ static int extract_main(int argc, char **argv) {
   BamStream rd;
   std::string err;
   if (!rd.open(bam, decode_threads(), err)) quit("couldn't open bam");
-  strl_ctx *ctx = nullptr;
-  CHECK(strl_ctx_create(0, &ctx));
+  ctx_thread.join();
+  g_bg_init = nullptr;
+  if (ctx_rc) quit("[strling] %s (status %d)", ctx_err.c_str(), ctx_rc);
   strl_opts opts{frag_median, p, min_mapq};
   CHECK(strl_ctx_set_opts(ctx, &opts));
   // genome_repeats, genome_strs.nim:107-146: existing file, or build it from the FASTA (into a temporary file when

@@ -43,7 +43,7 @@ def run(inp, cli, threads=(0,)):
         line = [l for l in r.stderr.splitlines() if "seconds: total" in l]
         dec = [l.split("decode seconds:")[1].strip() for l in r.stderr.splitlines() if "decode seconds:" in l]
         loop_s = float(line[-1].split("total")[1].split()[0]) if line else None
-        res["runs"].append({"decode_threads": t or "default: min(64, CPU quota)", "rc": r.returncode, "wall_s": round(wall, 3),
+        res["runs"].append({"decode_threads": t or "default: min(64, 1.5 x CPU quota)", "rc": r.returncode, "wall_s": round(wall, 3),
                             "reads_per_s_wall": round(inp["reads"] / wall), "loop_s": loop_s,
                             "reads_per_s_loop": round(inp["reads"] / loop_s) if loop_s else None, "decode": dec,
                             "phases": line[-1].split("seconds:")[1].strip() if line else r.stderr[-300:]})
