@@ -306,10 +306,18 @@ int strl_cluster(strl_ctx *ctx, const strl_tread *treads, uint64_t n, int mode, 
  * host round trip; STRL_MODE_CALL only).  n_tid = number of contigs of the BAM header (every tid < n_tid); pos_bits: width
  * of the position field of the sort key (0 = 32; else >= 2): 1 + the bits that hold every position on a contig, e.g. 29 for
  * a genome whose longest contig is < 2^28 bases -- fewer key bits, fewer sort passes.  The upper half of the field takes
- * the positions adjust_by wrapped below zero (uint32 arithmetic, utils.nim:304-310), in the reference's uint32 order.  With out, n_out, n_unplaced and stats all NULL the call only enqueues the kernels (asynchronous). */
+ * the positions adjust_by wrapped below zero (uint32 arithmetic, utils.nim:304-310), in the reference's uint32 order.  With out, n_out, n_unplaced and stats all NULL the call only enqueues the kernels (asynchronous, on the context's side
+ * stream; see strl_cluster_collect). */
 int strl_cluster_resident(strl_ctx *ctx, int mode, int32_t n_tid, int pos_bits, uint32_t window, int32_t min_support, uint16_t min_clip,
                           uint16_t min_clip_total, uint16_t max_clip_dist, strl_bounds *out, uint64_t cap, uint64_t *n_out,
                           strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced, strl_cluster_stats *stats);
+
+/* Results of the last asynchronous strl_cluster_resident (all outputs NULL there).  Such a pass runs on a side stream of the
+ * context: it overlaps whatever the caller enqueues next -- typically strl_extract_device of the NEXT batch, whose VALU-bound
+ * scorer hides the clustering's many small launches -- and may be collected after that call has been issued; the pair logic
+ * of the next batch waits for it on the device.  Same outputs and order as strl_cluster. */
+int strl_cluster_collect(strl_ctx *ctx, strl_bounds *out, uint64_t cap, uint64_t *n_out, strl_unplaced *unplaced, uint64_t unplaced_cap,
+                         uint64_t *n_unplaced, strl_cluster_stats *stats);
 
 /* ---- multi-GPU clustering (one process per GPU) ----
  * The device buffer strl_extract_device left its treads in: *treads (strl_tread[*cap]) and *count (uint32 on the device).

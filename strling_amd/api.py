@@ -108,7 +108,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
            "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order",
-           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered", "strl_inflate_blocks"]
+           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered", "strl_inflate_blocks", "strl_cluster_collect"]
 
 
 def lib_path():
@@ -175,6 +175,8 @@ def load(build_if_missing=True):
     L.strl_cluster_resident.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int, C.c_uint32, C.c_int32, C.c_uint16, C.c_uint16, C.c_uint16,
                                         C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                         C.POINTER(ClusterStats)]
+    L.strl_cluster_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                       C.POINTER(ClusterStats)]
     L.strl_extract_begin.argtypes = [C.c_void_p, C.c_uint64]
     L.strl_extract_add.argtypes = [C.c_void_p, C.POINTER(CReadSoa), C.POINTER(CPairSoa)]
     L.strl_extract_finish.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64]
@@ -461,6 +463,22 @@ class Context:
             rc = self.L.strl_cluster_resident(self.h, MODE_CALL, n_tid, pos_bits, window, min_support, min_clip, min_clip_total,
                                               max_clip_dist, out.ctypes.data, cap, C.byref(no), unpl.ctypes.data, unpl.size,
                                               C.byref(nu), C.byref(st))
+            if rc == -4 and no.value > cap:
+                cap = int(no.value)
+                continue
+            _check(rc)
+            return out[:no.value].copy(), unpl[:nu.value].copy(), st
+
+    def cluster_collect(self, cap=None):
+        """results of the last cluster_resident(fetch=False) -- which ran on the context's side stream, overlapping whatever
+        was enqueued after it (strl_cluster_collect) -> (bounds, unplaced, stats)"""
+        cap = cap or 1 << 16
+        while True:
+            out = np.zeros(cap, BOUNDS_DTYPE)
+            unpl = np.zeros(8192, UNPLACED_DTYPE)
+            no, nu = C.c_uint64(0), C.c_uint64(0)
+            st = ClusterStats()
+            rc = self.L.strl_cluster_collect(self.h, out.ctypes.data, cap, C.byref(no), unpl.ctypes.data, unpl.size, C.byref(nu), C.byref(st))
             if rc == -4 and no.value > cap:
                 cap = int(no.value)
                 continue

@@ -40,7 +40,7 @@ struct RawBounds {  // one candidate row per (candidate cluster, half)
 };
 
 // device-side counters of one clustering pass
-constexpr int CC_N = 0, CC_NGROUPS = 1, CC_NCAND = 2, CC_NCLUSTERS = 3, CC_BIG = 4, CC_ERR = 5, CC_WORDS = 16;
+constexpr int CC_N = 0, CC_NGROUPS = 1, CC_NCAND = 2, CC_NCLUSTERS = 3, CC_BIG = 4, CC_ERR = 5, CC_NSEEN = 6, CC_WORDS = 16;   // CC_NSEEN: *d_n as the pass saw it
 constexpr uint32_t CERR_UNIT = 1u, CERR_TID = 2u, CERR_POS = 4u, CERR_CAND = 8u, CERR_BIG = 16u;
 
 struct ClusterParams {
@@ -335,6 +335,7 @@ struct KeyParams {
 };
 __global__ __launch_bounds__(256) void tread_keys_kernel(KeyParams K) {
   uint32_t n = *K.d_n;
+  if (blockIdx.x == 0 && threadIdx.x == 0) K.cnt[CC_NSEEN] = n;     // (the counter itself may belong to the next batch by the time the host collects)
   if (n > K.n_max) n = K.n_max;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
@@ -596,11 +597,11 @@ enum { B_TREADS, B_KEY0, B_KEY1, B_VAL0, B_VAL1, B_SORT, B_IN, B_SORTED, B_TILES
 
 // The whole device side of a clustering pass over `treads` (device memory; count at d_n, at most n_max): keys, sort,
 // group tables, ends/walk sweep, bounds.  Asynchronous: no host synchronisation, every launch is sized by n_max.
-static int cluster_device_pass(strl_ctx *c, const strl_tread *treads, const uint32_t *d_n) {
+static int cluster_device_pass(strl_ctx *c, const strl_tread *treads, const uint32_t *d_n, hipStream_t st = nullptr) {
   ClusterRun &R = c->cl_run;
   const uint32_t n_max = R.n_max;
   strl::DevBuf *B = c->c_buf;
-  hipStream_t st = c->stream;
+  if (!st) st = c->stream;
   int rc;
   const size_t n1 = std::max<size_t>(n_max, 1);
   const uint32_t cand_cap = (uint32_t)(n1 / (size_t)std::max(1, R.min_support) + 1);
@@ -684,6 +685,7 @@ static int cluster_device_pass(strl_ctx *c, const strl_tread *treads, const uint
 
 // c.reads of every returned bound: the sorted permutation is still resident
 extern "C" int strl_cluster_members(strl_ctx *c, uint64_t *member_off, uint32_t *members, uint64_t cap, uint64_t *n_members) {
+  if (c) { const int rcj = side_join(c); if (rcj) return rcj; }
   if (!c || !member_off || !n_members) { set_error("null argument"); return STRL_ERR_ARG; }
   const ClusterRun &R = c->cl_run;
   uint64_t tot = 0;
@@ -719,8 +721,8 @@ static int cluster_collect(strl_ctx *c, const std::vector<std::pair<uint64_t, ui
   uint32_t cnt[CC_WORDS];
   uint32_t n_dev = 0;
   STRL_HIP(hipMemcpyAsync(cnt, B[B_CNT].p, CC_WORDS * 4, hipMemcpyDeviceToHost, st));
-  STRL_HIP(hipMemcpyAsync(&n_dev, R.d_n, 4, hipMemcpyDeviceToHost, st));
   STRL_HIP(hipStreamSynchronize(st));
+  n_dev = cnt[CC_NSEEN];
   if (n_dev > R.n_max) { set_error("clustering: %u treads, capacity %u", n_dev, R.n_max); return STRL_ERR_CAPACITY; }
   const uint32_t err = cnt[CC_ERR];
   if (err & CERR_UNIT) { set_error("a tread's repeat unit is not a NUL-padded ACGT string"); return STRL_ERR_ARG; }
@@ -841,6 +843,7 @@ static int cluster_collect(strl_ctx *c, const std::vector<std::pair<uint64_t, ui
 
 extern "C" int strl_bounds_bare(strl_ctx *c, const uint32_t *positions, const uint8_t *splits, uint32_t n, uint16_t min_clip, uint16_t min_clip_total,
                                 uint16_t max_clip_dist, strl_bounds *out, int *good) {
+  if (c) { const int rcj = side_join(c); if (rcj) return rcj; }
   if (!c || !positions || !splits || !out || !good || n == 0 || n > (1u << 20)) { set_error("bad argument"); return STRL_ERR_ARG; }
   for (uint32_t i = 1; i < n; ++i) if (positions[i] < positions[i - 1]) { set_error("strl_bounds_bare: reads must be sorted by position"); return STRL_ERR_ARG; }
   STRL_HIP(hipSetDevice(c->device));
@@ -871,6 +874,7 @@ extern "C" int strl_bounds_bare(strl_ctx *c, const uint32_t *positions, const ui
 }
 
 extern "C" int strl_ctx_cluster_times(strl_ctx *c, double ms[3]) {
+  if (c) { const int rcj = side_join(c); if (rcj) return rcj; }
   if (!c || !ms) return STRL_ERR_ARG;
   STRL_HIP(hipSetDevice(c->device));
   STRL_HIP(hipStreamSynchronize(c->stream));
@@ -886,6 +890,7 @@ static inline int bits_for(uint64_t v) { int b = 1; while (b < 64 && (v >> b)) +
 
 // Re-run the device side of the last clustering pass on the same resident treads, asynchronously.
 extern "C" int strl_cluster_replay(strl_ctx *c) {
+  if (c) { const int rcj = side_join(c); if (rcj) return rcj; }
   if (!c) return STRL_ERR_ARG;
   if (!c->cl_run.treads) { set_error("strl_cluster_replay: no previous clustering pass on this context"); return STRL_ERR_ARG; }
   STRL_HIP(hipSetDevice(c->device));
@@ -895,6 +900,7 @@ extern "C" int strl_cluster_replay(strl_ctx *c) {
 extern "C" int strl_cluster_resident(strl_ctx *c, int mode, int32_t n_tid, int pos_bits, uint32_t window, int32_t min_support, uint16_t min_clip,
                                      uint16_t min_clip_total, uint16_t max_clip_dist, strl_bounds *out, uint64_t cap, uint64_t *n_out,
                                      strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced, strl_cluster_stats *stats) {
+  if (c) { const int rcj = side_join(c); if (rcj) return rcj; }
   if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
   if (!c->n_treads_dev) { set_error("strl_cluster_resident: no strl_extract_device call on this context"); return STRL_ERR_ARG; }
   if (mode != STRL_MODE_CALL) { set_error("strl_cluster_resident clusters the treads of one sample (STRL_MODE_CALL)"); return STRL_ERR_ARG; }
@@ -916,12 +922,36 @@ extern "C" int strl_cluster_resident(strl_ctx *c, int mode, int32_t n_tid, int p
   if (c->pair_ordered) { R.treads = c->treads.as<strl_tread>(); R.d_n = c->n_treads_dev; R.first_key = nullptr; }   // (already ordered for a fetch)
   else { R.treads = c->p_emit.as<strl_tread>(); R.d_n = c->pair_cnt.as<uint32_t>() + PC_EMIT; R.first_key = c->po_key; }
   int rc;
+  const bool async = !out && !n_out && !stats && !n_unplaced;     // results stay on the device
+  static const bool no_overlap = getenv("STRL_NO_OVERLAP") != nullptr;
+  if (async && !c->timing && !no_overlap) {
+    // overlapped with whatever the main stream is given next (the scorer of the next batch): side stream, fenced by events
+    STRL_HIP(hipEventRecord(c->ev_main_done, c->stream));
+    STRL_HIP(hipStreamWaitEvent(c->stream2, c->ev_main_done, 0));
+    if ((rc = cluster_device_pass(c, R.treads, R.d_n, c->stream2))) return rc;
+    STRL_HIP(hipEventRecord(c->ev_side_done, c->stream2));
+    c->side_pending = true;
+    return STRL_OK;
+  }
   if ((rc = cluster_device_pass(c, R.treads, R.d_n))) return rc;
-  if (!out && !n_out && !stats && !n_unplaced) return STRL_OK;      // asynchronous: results stay on the device
+  if (async) return STRL_OK;
+  return cluster_collect(c, {}, out, cap, n_out, unplaced, unplaced_cap, n_unplaced, stats);
+}
+
+extern "C" int strl_cluster_collect(strl_ctx *c, strl_bounds *out, uint64_t cap, uint64_t *n_out, strl_unplaced *unplaced, uint64_t unplaced_cap,
+                                    uint64_t *n_unplaced, strl_cluster_stats *stats) {
+  if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
+  if (!c->cl_run.n_max && !c->cl_run.d_n) { set_error("strl_cluster_collect: no clustering pass on this context"); return STRL_ERR_ARG; }
+  if (n_out) *n_out = 0;
+  if (n_unplaced) *n_unplaced = 0;
+  if (stats) memset(stats, 0, sizeof *stats);
+  STRL_HIP(hipSetDevice(c->device));
+  { const int rcj = side_join(c); if (rcj) return rcj; }
   return cluster_collect(c, {}, out, cap, n_out, unplaced, unplaced_cap, n_unplaced, stats);
 }
 
 extern "C" int strl_ctx_treads_device(strl_ctx *c, void **treads, uint64_t *cap, void **count) {
+  if (c) { const int rcj = side_join(c); if (rcj) return rcj; }
   if (!c || !c->n_treads_dev) { set_error("strl_ctx_treads_device: no strl_extract_device call on this context"); return STRL_ERR_ARG; }
   STRL_HIP(hipSetDevice(c->device));
   { const int rc0 = strl_pair_order(c); if (rc0) return rc0; }           // the gather wants the .bin order
@@ -935,6 +965,7 @@ extern "C" int strl_cluster_gathered(strl_ctx *c, const strl_tread *gathered, co
                                      int32_t n_tid, int pos_bits, uint32_t window, int32_t min_support, uint16_t min_clip, uint16_t min_clip_total,
                                      uint16_t max_clip_dist, strl_bounds *out, uint64_t cap, uint64_t *n_out, strl_unplaced *unplaced,
                                      uint64_t unplaced_cap, uint64_t *n_unplaced, strl_cluster_stats *stats) {
+  if (c) { const int rcj = side_join(c); if (rcj) return rcj; }
   if (!c || !gathered || !counts || world < 1 || rank < 0 || rank >= world || pad == 0) { set_error("bad argument"); return STRL_ERR_ARG; }
   if ((uint64_t)world * pad > 0x7ffffff0ull || n_tid < 0 || pos_bits < 0 || pos_bits > 32) { set_error("bad argument"); return STRL_ERR_ARG; }
   if (n_out) *n_out = 0;
@@ -985,6 +1016,7 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
                             uint16_t min_clip, uint16_t min_clip_total, uint16_t max_clip_dist, strl_bounds *out, uint64_t cap,
                             uint64_t *n_out, strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced,
                             strl_cluster_stats *stats) {
+  if (c) { const int rcj = side_join(c); if (rcj) return rcj; }
   if (!c || (!treads && n_in) || (!out && cap)) { set_error("null argument"); return STRL_ERR_ARG; }
   if (n_out) *n_out = 0;
   if (n_unplaced) *n_unplaced = 0;

@@ -69,9 +69,18 @@ struct ClusterRun {
   std::vector<uint32_t> b_first, b_count, kept;
 };
 
+struct strl_ctx;
+int side_join(strl_ctx *c);   // main stream waits for the side stream's pending work (score.hip)
+
 struct strl_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // Side stream: an asynchronous strl_cluster_resident (results stay on the device) runs here, so that the clustering of
+  // one batch -- 22 small, latency-bound launches -- overlaps the VALU-bound scorer of the next batch.  Whatever touches
+  // the treads or the cluster state afterwards calls side_join() first.
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_main_done = nullptr, ev_side_done = nullptr;
+  bool side_pending = false;
   bool timing = false;
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> ring;   // 4 events per recorded strl_score_reads launch

@@ -593,6 +593,7 @@ extern "C" int strl_pair_rule_device(strl_ctx *c, int op, strl_tread *A, const s
 
 // Treads of the last strl_pair_device call into the order of the reference's .bin file (c->treads); idempotent.
 int strl_pair_order(strl_ctx *c) {
+  { const int rcj = side_join(c); if (rcj) return rcj; }      // an overlapped clustering may still read the unordered treads
   if (!c->n_treads_dev) { set_error("no strl_extract_device call on this context"); return STRL_ERR_ARG; }
   if (c->pair_ordered) return STRL_OK;
   hipStream_t st = c->stream;
@@ -621,6 +622,7 @@ int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uin
   if (item_cap > 0x7ffffff0ull || tread_cap > 0x7ffffff0ull) { set_error("pair capacities too large"); return STRL_ERR_ARG; }
   hipStream_t st = c->stream;
   int rc;
+  if ((rc = side_join(c))) return rc;      // the previous batch's clustering (side stream) reads the buffers written here
   const uint32_t icap = (uint32_t)std::max<uint64_t>(item_cap, 1024), ecap = (uint32_t)std::max<uint64_t>(tread_cap, 1024);
   int ebits = 3;   // emission key: (virtual record index < 2n) << 2 | sequence number
   while (ebits < 40 && ((2 * n) >> (ebits - 2))) ++ebits;

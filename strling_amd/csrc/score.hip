@@ -702,6 +702,14 @@ static constexpr uint64_t RING = 256;
 // compaction | stage A, compaction, stage B (segments)
 static constexpr int EV_PER = 9;
 
+int side_join(strl_ctx *c) {
+  if (c->side_pending) {
+    STRL_HIP(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
+    c->side_pending = false;
+  }
+  return STRL_OK;
+}
+
 extern "C" {
 
 #ifdef STRL_PHASE_TIMING
@@ -734,6 +742,9 @@ int strl_ctx_create(int device_ordinal, strl_ctx **out) {
   strl_ctx *c = new strl_ctx();
   c->device = device_ordinal;
   STRL_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  STRL_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  STRL_HIP(hipEventCreateWithFlags(&c->ev_main_done, hipEventDisableTiming));
+  STRL_HIP(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
   for (auto &e : c->ev) STRL_HIP(hipEventCreate(&e));
   for (auto &e : c->pev) STRL_HIP(hipEventCreate(&e));
   std::vector<uint16_t> lut;
@@ -753,6 +764,7 @@ int strl_ctx_create(int device_ordinal, strl_ctx **out) {
 void strl_ctx_destroy(strl_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   (void)hipStreamSynchronize(c->stream);
   strl::DevBuf *bufs[] = {&c->lut, &c->thr, &c->g_tid, &c->g_bins, &c->g_start, &c->g_pmax, &c->queue, &c->soft_queue, &c->counters,
                           &c->soft_tmp, &c->sb_whole, &c->sb_soft, &c->queue_r, &c->soft_dense, &c->sb_state_w, &c->sb_state_s, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
@@ -764,6 +776,9 @@ void strl_ctx_destroy(strl_ctx *c) {
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->pev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->ring) if (e) (void)hipEventDestroy(e);
+  if (c->ev_main_done) (void)hipEventDestroy(c->ev_main_done);
+  if (c->ev_side_done) (void)hipEventDestroy(c->ev_side_done);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -771,6 +786,8 @@ void strl_ctx_destroy(strl_ctx *c) {
 void *strl_ctx_stream(strl_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int strl_ctx_sync(strl_ctx *c) {
   if (!c) return STRL_ERR_ARG;
+  STRL_HIP(hipSetDevice(c->device));
+  { const int rc = side_join(c); if (rc) return rc; }
   STRL_HIP(hipStreamSynchronize(c->stream));
   return STRL_OK;
 }

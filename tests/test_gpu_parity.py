@@ -267,6 +267,48 @@ def test_extract_device_and_resident_clustering_match_oracle(ctx, oracle, n_pair
     assert np.array_equal(b, b2) and np.array_equal(u, u2)
 
 
+def test_overlapped_clustering_of_one_batch_and_extract_of_the_next(ctx, oracle):
+    """The pipeline the bench times: batch A's clustering runs asynchronously on the context's side stream while batch B's
+    extract is enqueued; collecting A's rows after B's extract was issued gives A's rows, B's treads are B's, and B's own
+    clustering afterwards is B's -- three rounds, alternating batches, against the oracle."""
+    batches = []
+    for seed, n_pairs in ((7001, 20000), (7002, 26000)):
+        rec, g = synth.synth_wgs(n_pairs, seed=seed, contig_len=2_000_000)
+        frag = synth.frag_hist(rec)
+        med = oracle.median(frag)
+        soa = api.Soa(rec)
+        cp, keep = _pair_soa(rec, soa)
+        window, mcd = api.frag_median(frag, 0.99), int(0.5 * api.frag_median(frag, 0.5))
+        exp = oracle.extract(rec, g, oracle.make_opts(med, 0.8, 40))
+        eb, eu = oracle.call_bounds(exp, 1, window, min_support=3, max_clip_dist=mcd)
+        batches.append(dict(rec=rec, g=g, med=med, soa=soa, cp=cp, keep=keep, window=window, mcd=mcd, exp=exp,
+                            rows=[oracle.bounds_row(x, "c") for x in eb], unpl=[(r, int(k)) for r, k in eu]))
+    assert all(len(b["rows"]) > 5 for b in batches) and batches[0]["rows"] != batches[1]["rows"]
+
+    def extract(b):
+        ctx.set_opts(0.8, 40, b["med"])
+        ctx.set_genome(b["g"])
+        ctx.extract_device(b["soa"].c_struct(), b["cp"], int((b["rec"].tid < 0).sum()))
+
+    def cluster_async(b):
+        ctx.cluster_resident(len(b["rec"].targets), b["window"], min_support=3, max_clip_dist=b["mcd"], pos_bits=24, fetch=False)
+
+    def check_rows(b, got):
+        rows, unpl, _ = got
+        assert [api.bounds_row(x, "c") for x in rows] == b["rows"]
+        assert [(x["repeat"].decode(), int(x["count"])) for x in unpl] == b["unpl"]
+
+    extract(batches[0])
+    for r in range(3):
+        cur, nxt = batches[r % 2], batches[(r + 1) % 2]
+        cluster_async(cur)              # side stream
+        extract(nxt)                    # main stream: scorer of the next batch overlaps; its pair logic waits on the device
+        check_rows(cur, ctx.cluster_collect())
+        got, _ = ctx.treads_fetch()
+        ok, why = treads_equal(got, nxt["exp"])
+        assert ok, why
+
+
 def test_resident_clustering_before_and_after_the_bin_order_sort(ctx, oracle):
     """strl_cluster_resident straight behind strl_extract_device clusters the treads as the pair logic emitted them
     (unordered, first appearance from the emission keys); after a fetch it clusters the ordered array: same rows either way.
