@@ -26,6 +26,7 @@
 #include "common.h"
 #include "nim_tables.h"
 #include "sort.h"
+#include "device_util.h"
 
 namespace nim { std::vector<int64_t> table_slot_order(const std::vector<uint64_t> &hcodes, uint64_t initial_size); }
 
@@ -616,7 +617,8 @@ static int cluster_device_pass(strl_ctx *c, const strl_tread *treads, const uint
       (rc = need(B_BIG, (size_t)big_words * 4)) || (rc = need(B_CNT, CC_WORDS * 4)) || (!R.composite && (rc = need(B_GKEY, n1 * 8))))
     return rc;
   uint32_t *cnt = B[B_CNT].as<uint32_t>();
-  STRL_HIP(hipMemsetAsync(cnt + 1, 0, (CC_WORDS - 1) * 4, st));   // CC_N stays (host path stores n there)
+  STRL_HIP(zero_words(cnt + 4, (CC_WORDS - 4) * 4, st));   // (16-byte aligned part)
+  STRL_HIP(hipMemsetAsync(cnt + 1, 0, 3 * 4, st));   // CC_N stays (host path stores n there)
   const int TB = 256;
   const uint32_t nb = (uint32_t)((n1 + TB - 1) / TB);
   if (c->timing) STRL_HIP(hipEventRecord(c->ev[4], st));
@@ -900,7 +902,10 @@ extern "C" int strl_cluster_replay(strl_ctx *c) {
 extern "C" int strl_cluster_resident(strl_ctx *c, int mode, int32_t n_tid, int pos_bits, uint32_t window, int32_t min_support, uint16_t min_clip,
                                      uint16_t min_clip_total, uint16_t max_clip_dist, strl_bounds *out, uint64_t cap, uint64_t *n_out,
                                      strl_unplaced *unplaced, uint64_t unplaced_cap, uint64_t *n_unplaced, strl_cluster_stats *stats) {
-  if (c) { const int rcj = side_join(c); if (rcj) return rcj; }
+  static const bool no_overlap = getenv("STRL_NO_OVERLAP") != nullptr;
+  const bool async = !out && !n_out && !stats && !n_unplaced;     // results stay on the device
+  const bool on_side = c && async && !c->timing && !no_overlap;   // the side stream runs its work in order: no join needed
+  if (c && !on_side) { const int rcj = side_join(c); if (rcj) return rcj; }
   if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
   if (!c->n_treads_dev) { set_error("strl_cluster_resident: no strl_extract_device call on this context"); return STRL_ERR_ARG; }
   if (mode != STRL_MODE_CALL) { set_error("strl_cluster_resident clusters the treads of one sample (STRL_MODE_CALL)"); return STRL_ERR_ARG; }
@@ -922,12 +927,12 @@ extern "C" int strl_cluster_resident(strl_ctx *c, int mode, int32_t n_tid, int p
   if (c->pair_ordered) { R.treads = c->treads.as<strl_tread>(); R.d_n = c->n_treads_dev; R.first_key = nullptr; }   // (already ordered for a fetch)
   else { R.treads = c->p_emit.as<strl_tread>(); R.d_n = c->pair_cnt.as<uint32_t>() + PC_EMIT; R.first_key = c->po_key; }
   int rc;
-  const bool async = !out && !n_out && !stats && !n_unplaced;     // results stay on the device
-  static const bool no_overlap = getenv("STRL_NO_OVERLAP") != nullptr;
-  if (async && !c->timing && !no_overlap) {
+  if (on_side) {
     // overlapped with whatever the main stream is given next (the scorer of the next batch): side stream, fenced by events
-    STRL_HIP(hipEventRecord(c->ev_main_done, c->stream));
-    STRL_HIP(hipStreamWaitEvent(c->stream2, c->ev_main_done, 0));
+    if (!c->pair_on_side) {       // treads made on the main stream: fence; made on the side stream: already in order there
+      STRL_HIP(hipEventRecord(c->ev_main_done, c->stream));
+      STRL_HIP(hipStreamWaitEvent(c->stream2, c->ev_main_done, 0));
+    }
     if ((rc = cluster_device_pass(c, R.treads, R.d_n, c->stream2))) return rc;
     STRL_HIP(hipEventRecord(c->ev_side_done, c->stream2));
     c->side_pending = true;

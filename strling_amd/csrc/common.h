@@ -81,6 +81,16 @@ struct strl_ctx {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_main_done = nullptr, ev_side_done = nullptr;
   bool side_pending = false;
+  // strl_extract_device on device-resident input goes further: the pair logic of batch i (latency-bound: Bloom probes,
+  // sorts, gathers) runs on the side stream too, beside classify + scorer of batch i + 1 on the main stream.  What the
+  // pair logic reads of the scorer's output exists twice (whole[], soft-clip records, counters, Bloom bitmap); a call
+  // swaps the sets and waits (on the device) until the side stream is done with the set it is about to overwrite.
+  strl::DevBuf st_whole2, st_soft2, counters2, bloom2;
+  uint32_t bloom_mask2 = 0;
+  hipEvent_t ev_head_done = nullptr, ev_set_free[2] = {nullptr, nullptr};
+  bool set_used[2] = {false, false};
+  int set = 0;
+  bool pair_on_side = false;       // the last pair logic ran on the side stream (its treads are ordered there already)
   bool timing = false;
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> ring;   // 4 events per recorded strl_score_reads launch
@@ -126,4 +136,5 @@ struct strl_ctx {
 // pair.hip: enqueue the device pair logic behind a scoring pass of the same batch
 int strl_pair_order(strl_ctx *c);
 int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uint32_t *whole, const strl_soft_rec *soft,
-                     const uint32_t *d_n_soft, uint64_t soft_cap, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap);
+                     const uint32_t *d_n_soft, uint64_t soft_cap, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap,
+                     hipStream_t on_stream = nullptr);   // nullptr = the main stream

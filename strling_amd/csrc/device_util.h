@@ -1,5 +1,6 @@
 // device_util.h -- small device-side helpers shared by the .hip translation units
 #pragma once
+#include <algorithm>
 #include "common.h"
 
 namespace strl {
@@ -17,4 +18,20 @@ __device__ __forceinline__ bool bloom_test(const uint32_t *bloom, uint32_t mask,
   return (bloom[b1 >> 5] >> (b1 & 31u)) & 1u;
 }
 
+
+// Zero-fill as a kernel of our own instead of hipMemsetAsync: the runtime's fill goes through its blit path (a kernel
+// launch plus bookkeeping on the runtime's side per call); here it is one plain launch on the caller's stream.
+static __global__ void zero_words_kernel(uint32_t *p, size_t n_words) {
+  const size_t n4 = n_words / 4, stride = (size_t)gridDim.x * blockDim.x;
+  uint4 *q = reinterpret_cast<uint4 *>(p);                 // (hipMalloc'd buffers: 16-byte aligned)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) q[i] = make_uint4(0, 0, 0, 0);
+  if (blockIdx.x == 0 && threadIdx.x < (n_words & 3)) p[n4 * 4 + threadIdx.x] = 0;
+}
+static inline hipError_t zero_words(void *p, size_t bytes, hipStream_t st) {   // p 16-byte aligned, bytes a multiple of 4
+  const size_t words = bytes / 4;
+  if (!words) return hipSuccess;
+  const unsigned blocks = (unsigned)std::min<size_t>((words / 4 + 255) / 256 + 1, 1024);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(256), 0, st, static_cast<uint32_t *>(p), words);
+  return hipGetLastError();
+}
 }  // namespace strl

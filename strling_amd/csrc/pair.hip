@@ -616,13 +616,15 @@ int strl_pair_order(strl_ctx *c) {
 // arrays given, so the whole-read marks are in the bitmap).  Everything is asynchronous; results stay on the device:
 // c->treads[0, *c->n_treads).
 int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uint32_t *whole, const strl_soft_rec *soft,
-                     const uint32_t *d_n_soft, uint64_t soft_cap, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap) {
+                     const uint32_t *d_n_soft, uint64_t soft_cap, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap, hipStream_t on_stream) {
   if (n > 0x7ffffff0ull) { set_error("pair logic: at most 2^31 - 16 records"); return STRL_ERR_ARG; }
   if (n_tail < 0 || (uint64_t)n_tail > n) { set_error("strl_pair_device: n_tail must be in [0, n]"); return STRL_ERR_ARG; }
   if (item_cap > 0x7ffffff0ull || tread_cap > 0x7ffffff0ull) { set_error("pair capacities too large"); return STRL_ERR_ARG; }
-  hipStream_t st = c->stream;
+  hipStream_t st = on_stream ? on_stream : c->stream;
   int rc;
-  if ((rc = side_join(c))) return rc;      // the previous batch's clustering (side stream) reads the buffers written here
+  // the previous batch's clustering (side stream) reads the buffers written here; on the side stream itself the order is given
+  if (st == c->stream && (rc = side_join(c))) return rc;
+  c->pair_on_side = false;
   const uint32_t icap = (uint32_t)std::max<uint64_t>(item_cap, 1024), ecap = (uint32_t)std::max<uint64_t>(tread_cap, 1024);
   int ebits = 3;   // emission key: (virtual record index < 2n) << 2 | sequence number
   while (ebits < 40 && ((2 * n) >> (ebits - 2))) ++ebits;
@@ -632,7 +634,7 @@ int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uin
       (rc = c->p_emit.reserve((size_t)ecap * sizeof(strl_tread))) || (rc = c->treads.reserve((size_t)ecap * sizeof(strl_tread) + 64)) ||
       (rc = c->sort_scratch.reserve(sb)) || (rc = c->pair_cnt.reserve(PC_WORDS * 4 + 64)))
     return rc;
-  STRL_HIP(hipMemsetAsync(c->pair_cnt.p, 0, PC_WORDS * 4 + 64, st));
+  STRL_HIP(zero_words(c->pair_cnt.p, PC_WORDS * 4 + 64, st));
   PairParams P{};
   P.n = (uint32_t)n;
   P.tail_start = (uint32_t)(n - (uint64_t)n_tail);

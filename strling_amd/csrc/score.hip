@@ -745,6 +745,8 @@ int strl_ctx_create(int device_ordinal, strl_ctx **out) {
   STRL_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   STRL_HIP(hipEventCreateWithFlags(&c->ev_main_done, hipEventDisableTiming));
   STRL_HIP(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
+  STRL_HIP(hipEventCreateWithFlags(&c->ev_head_done, hipEventDisableTiming));
+  for (auto &e : c->ev_set_free) STRL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : c->ev) STRL_HIP(hipEventCreate(&e));
   for (auto &e : c->pev) STRL_HIP(hipEventCreate(&e));
   std::vector<uint16_t> lut;
@@ -778,6 +780,9 @@ void strl_ctx_destroy(strl_ctx *c) {
   for (auto &e : c->ring) if (e) (void)hipEventDestroy(e);
   if (c->ev_main_done) (void)hipEventDestroy(c->ev_main_done);
   if (c->ev_side_done) (void)hipEventDestroy(c->ev_side_done);
+  if (c->ev_head_done) (void)hipEventDestroy(c->ev_head_done);
+  for (auto &e : c->ev_set_free) if (e) (void)hipEventDestroy(e);
+  c->st_whole2.release(); c->st_soft2.release(); c->counters2.release(); c->bloom2.release();
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -924,15 +929,18 @@ static int bloom_reset(strl_ctx *c, uint64_t n) {
   while (bits < n / 2 && bits < (1ull << 27)) bits <<= 1;
   int rc;
   if ((rc = c->bloom.reserve((size_t)(bits / 8)))) return rc;
-  STRL_HIP(hipMemsetAsync(c->bloom.p, 0, (size_t)(bits / 8), c->stream));
+  STRL_HIP(zero_words(c->bloom.p, (size_t)(bits / 8), c->stream));
   c->bloom_mask = (uint32_t)(bits - 1);
   return STRL_OK;
 }
 
 static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, strl_soft_rec *soft, uint64_t soft_cap,
                         uint64_t *n_soft, strl_score_stats *stats, bool sync_counts, const strl_pair_soa *pp = nullptr,
-                        bool fresh_bloom = true) {
+                        bool fresh_bloom = true, bool side_busy_ok = false) {
   const uint64_t n = s->n;
+  // the side stream may still read this context's counters / Bloom bitmap / results (pair logic of the previous batch):
+  // every scoring pass waits for it, except the overlapped strl_extract_device, which works on the other set of buffers
+  if (!side_busy_ok) { const int rcj = side_join(c); if (rcj) return rcj; }
   if (n > 0x3fffffffull) { set_error("batch too large (%llu reads; limit 2^30-1)", (unsigned long long)n); return STRL_ERR_ARG; }
   if (s->max_l_seq > STRL_MAX_READ_LEN) { set_error("read of %u bases exceeds STRL_MAX_READ_LEN=%d", s->max_l_seq, STRL_MAX_READ_LEN); return STRL_ERR_ARG; }
   int rc;
@@ -945,7 +953,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   if ((rc = c->sb_state_s.reserve((size_t)scap * 16))) return rc;
   if ((rc = c->sb_whole.reserve((size_t)n1 * 32))) return rc;
   if ((rc = c->sb_soft.reserve((size_t)scap * 32))) return rc;
-  STRL_HIP(hipMemsetAsync(c->counters.p, 0, CNT_WORDS * 4, c->stream));
+  STRL_HIP(zero_words(c->counters.p, CNT_WORDS * 4, c->stream));
   ScoreParams P{};
   P.n = n;
   P.tid = s->tid; P.pos = s->pos; P.end = s->end; P.seq_off = s->seq_off; P.l_seq = s->l_seq;
@@ -1126,12 +1134,35 @@ int strl_extract_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa
   int rc;
   if (s->mem != STRL_MEM_DEVICE && (rc = stage_batch(c, s, pp, &d, &dp))) return rc;
   const uint64_t soft_cap = std::min<uint64_t>(item_cap, 2 * n + 2);
+  // Device-resident input: classify + scorer of this batch on the main stream, its pair logic on the side stream -- where
+  // the previous batch's pair logic and clustering may still be running while this call's scorer already executes.
+  static const bool no_overlap = getenv("STRL_NO_OVERLAP") != nullptr;
+  const bool overlap = s->mem == STRL_MEM_DEVICE && !c->timing && !no_overlap;
+  if (overlap) {
+    std::swap(c->st_whole, c->st_whole2); std::swap(c->st_soft, c->st_soft2); std::swap(c->counters, c->counters2);
+    std::swap(c->bloom, c->bloom2); std::swap(c->bloom_mask, c->bloom_mask2);
+    c->set ^= 1;
+    if ((rc = c->counters.reserve(CNT_WORDS * 4))) return rc;
+    if (c->set_used[c->set]) STRL_HIP(hipStreamWaitEvent(c->stream, c->ev_set_free[c->set], 0));   // the side stream is done with this set
+  }
   if ((rc = c->st_whole.reserve((size_t)std::max<uint64_t>(n, 1) * 4))) return rc;
   if ((rc = c->st_soft.reserve((size_t)std::max<uint64_t>(soft_cap, 1) * sizeof(strl_soft_rec)))) return rc;
   c->ex_n = n; c->ex_soft_cap = soft_cap; c->x_mode = false;
-  if ((rc = score_device(c, &d, c->st_whole.as<uint32_t>(), c->st_soft.as<strl_soft_rec>(), soft_cap, nullptr, nullptr, false, &dp))) return rc;
-  return strl_pair_device(c, n, &dp, c->st_whole.as<uint32_t>(), c->st_soft.as<strl_soft_rec>(), c->counters.as<uint32_t>() + CNT_SOFT, soft_cap,
-                          n_tail, item_cap, tread_cap);
+  if ((rc = score_device(c, &d, c->st_whole.as<uint32_t>(), c->st_soft.as<strl_soft_rec>(), soft_cap, nullptr, nullptr, false, &dp, true, overlap))) return rc;
+  if (!overlap)
+    return strl_pair_device(c, n, &dp, c->st_whole.as<uint32_t>(), c->st_soft.as<strl_soft_rec>(), c->counters.as<uint32_t>() + CNT_SOFT, soft_cap,
+                            n_tail, item_cap, tread_cap);
+  STRL_HIP(hipEventRecord(c->ev_head_done, c->stream));
+  STRL_HIP(hipStreamWaitEvent(c->stream2, c->ev_head_done, 0));
+  if ((rc = strl_pair_device(c, n, &dp, c->st_whole.as<uint32_t>(), c->st_soft.as<strl_soft_rec>(), c->counters.as<uint32_t>() + CNT_SOFT, soft_cap,
+                             n_tail, item_cap, tread_cap, c->stream2)))
+    return rc;
+  STRL_HIP(hipEventRecord(c->ev_set_free[c->set], c->stream2));
+  c->set_used[c->set] = true;
+  STRL_HIP(hipEventRecord(c->ev_side_done, c->stream2));
+  c->side_pending = true;
+  c->pair_on_side = true;
+  return STRL_OK;
 }
 
 // ---- the same in chunks: a BAM being decoded hands over batches in file order, the pair logic runs once at the end ----

@@ -23,6 +23,7 @@
 // HBM traffic per pass: 12 B read + 12 B written per pair (+ the 1 KiB histogram rows); at 5x10^5 pairs that is 12 MB
 // per pass -- microseconds at HBM speed; what is left is the launch boundary and the L2 latency of the row sums.
 #include "sort.h"
+#include "device_util.h"
 
 namespace strl {
 
@@ -211,7 +212,7 @@ int radix_sort_pairs(hipStream_t st, const uint32_t *d_n, uint32_t n_max, uint64
   uint32_t *H = C + (size_t)P * cwords;
   hipError_t e;
   // the chunk tables are accumulated with (256 per tile, uncontended) atomics by the histogram kernel
-  if ((e = hipMemsetAsync(C, 0, (size_t)P * cwords * 4, st)) != hipSuccess) return (int)e;
+  if ((e = zero_words(C, (size_t)P * cwords * 4, st)) != hipSuccess) return (int)e;
   uint64_t *kin = keys, *kout = keys_alt;
   uint32_t *vin = vals, *vout = vals_alt;
   for (uint32_t p = 0; p < P; ++p) {
