@@ -282,42 +282,48 @@ __global__ __launch_bounds__(256, 4) void classify_kernel(ScoreParams P) {
       cnt = 0;
     }
   };
-  struct In { uint32_t cg; int32_t t, st, en; };
-  auto load = [&](uint64_t base, In (&x)[CL_ILP]) {
+  // What a load leaves in registers is the RAW vector (for VEC: a group of 4 consecutive reads), unpacked only when the
+  // iteration that consumes it starts: unpacking at load time (byte extraction of the cigar classes) put an s_waitcnt
+  // right behind the loads and serialised every prefetch with its own latency.
+  struct In { int4 t, s, e; uint32_t c; };                    // VEC: 4 reads; scalar variant: .x / low byte only
+  constexpr int NIN = VEC ? CL_ILP / 4 : CL_ILP;
+  auto load = [&](uint64_t base, In (&x)[NIN]) {
     if (VEC) {
 #pragma unroll
-      for (int gq = 0; gq < CL_ILP / 4; ++gq) {
+      for (int gq = 0; gq < NIN; ++gq) {
         const uint64_t r = base + 256ull * gq + 4ull * lane;
         if (r + 3 < r1) {
-          const int4 t4 = reinterpret_cast<const int4 *>(P.tid)[r >> 2];
-          const int4 s4 = reinterpret_cast<const int4 *>(P.pos)[r >> 2];
-          const int4 e4 = reinterpret_cast<const int4 *>(P.end)[r >> 2];
-          const uint32_t c4 = reinterpret_cast<const uint32_t *>(P.cig)[r >> 2];
-          x[4 * gq + 0] = In{c4 & 0xffu, t4.x, s4.x, e4.x};
-          x[4 * gq + 1] = In{(c4 >> 8) & 0xffu, t4.y, s4.y, e4.y};
-          x[4 * gq + 2] = In{(c4 >> 16) & 0xffu, t4.z, s4.z, e4.z};
-          x[4 * gq + 3] = In{c4 >> 24, t4.w, s4.w, e4.w};
-        } else {
+          x[gq].t = reinterpret_cast<const int4 *>(P.tid)[r >> 2];
+          x[gq].s = reinterpret_cast<const int4 *>(P.pos)[r >> 2];
+          x[gq].e = reinterpret_cast<const int4 *>(P.end)[r >> 2];
+          x[gq].c = reinterpret_cast<const uint32_t *>(P.cig)[r >> 2];
+        } else {                                               // the ragged end of the wave's range
+          int32_t t[4], st[4], en[4];
+          uint32_t cg = 0;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const bool in = r + q < r1;
-            x[4 * gq + q] = In{in ? (uint32_t)P.cig[r + q] : 0u, in ? P.tid[r + q] : -1, in ? P.pos[r + q] : 0, in ? P.end[r + q] : 0};
+            cg |= (in ? (uint32_t)P.cig[r + q] : 0u) << (8 * q);
+            t[q] = in ? P.tid[r + q] : -1; st[q] = in ? P.pos[r + q] : 0; en[q] = in ? P.end[r + q] : 0;
           }
+          x[gq].t = make_int4(t[0], t[1], t[2], t[3]); x[gq].s = make_int4(st[0], st[1], st[2], st[3]);
+          x[gq].e = make_int4(en[0], en[1], en[2], en[3]); x[gq].c = cg;
         }
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < CL_ILP; ++j) {
+      for (int j = 0; j < NIN; ++j) {
         const uint64_t r = base + 64 * j + lane;
         const bool in = r < r1;
-        x[j].cg = in ? P.cig[r] : 0u;
-        x[j].t = in ? P.tid[r] : -1;
-        x[j].st = in ? P.pos[r] : 0;
-        x[j].en = in ? P.end[r] : 0;
+        x[j].c = in ? P.cig[r] : 0u;
+        x[j].t.x = in ? P.tid[r] : -1;
+        x[j].s.x = in ? P.pos[r] : 0;
+        x[j].e.x = in ? P.end[r] : 0;
       }
     }
   };
-  In cur[CL_ILP], nxt[CL_ILP];
+  auto comp = [](const int4 &v, int q) -> int32_t { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; };
+  In cur[NIN], nxt[NIN];
   JoinState join;
   join.t = -2; join.valid = 0; join.lo = 0;
   load(r0, cur);
@@ -329,7 +335,12 @@ __global__ __launch_bounds__(256, 4) void classify_kernel(ScoreParams P) {
 #pragma unroll
     for (int j = 0; j < CL_ILP; ++j) {
       inr[j] = ridx(base, j) < r1;
-      cgs[j] = cur[j].cg; ts[j] = cur[j].t; sts[j] = cur[j].st; ens[j] = cur[j].en;
+      if (VEC) {
+        const In &g4 = cur[j >> 2];
+        cgs[j] = (g4.c >> (8 * (j & 3))) & 0xffu; ts[j] = comp(g4.t, j & 3); sts[j] = comp(g4.s, j & 3); ens[j] = comp(g4.e, j & 3);
+      } else {
+        cgs[j] = cur[j].c; ts[j] = cur[j].t.x; sts[j] = cur[j].s.x; ens[j] = cur[j].e.x;
+      }
     }
     skip_predicate_n<CL_ILP>(P, join, cgs, ts, sts, ens, inr, skipped);
 #pragma unroll
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(256, 4) void classify_kernel(ScoreParams P) {
     }
     if (cnt >= CL_STAGE) flush();
 #pragma unroll
-    for (int j = 0; j < CL_ILP; ++j) cur[j] = nxt[j];
+    for (int j = 0; j < NIN; ++j) cur[j] = nxt[j];
   }
   flush();
   if (lane == 0 && nskip) atomicAdd(&P.counters[CNT_SKIP], nskip);
