@@ -232,6 +232,7 @@ def main():
     dom_ms, dom_bytes = kernels[dom]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     traffic = None
+    tj, pick = {}, {}
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r02", "traffic.json")))["kernels"]
         pick = {"classify_kernel": "classify_kernel", "score_kernel<whole,A>": "<10, 64, 0, 0", "score_kernel<segment,A>": "<10, 64, 1, 0",
@@ -240,9 +241,35 @@ def main():
             traffic = sum(v["hbm_bytes_corrected"] for name, v in tj.items() if pick[dom] in name) or None
     except Exception:
         traffic = None
+    # The slowest launch may be one that HBM does not bound at all (the scorer stages issue integer VALU instructions ~88 % of
+    # the time): report its VALU issue utilisation from the committed PMC pass next to the HBM figure, and the slowest launch
+    # that IS bound by HBM traffic (the skip-predicate pass) separately.
+    valu_frac = None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_counters.json")))
+        if dom in pick and n == 2 ** 25 and L == 150:
+            insts = [v["SQ_INSTS_VALU"] for name, v in pj.items() if pick[dom] in name and "SQ_INSTS_VALU" in v]
+            if insts and dom_ms > 0:      # a wave64 VALU instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
+                valu_frac = round(insts[0] * 4.0 / (dom_ms * 1e-3 * 2.4e9 * 1024), 3)
+    except Exception:
+        valu_frac = None
+    c_ms, c_bytes = kernels["classify_kernel"]
+    c_traffic = None
+    try:
+        if n == 2 ** 25 and L == 150:
+            c_traffic = sum(v["hbm_bytes_corrected"] for name, v in tj.items() if "classify_kernel" in name) or None
+    except Exception:
+        c_traffic = None
+    c_ach = c_bytes / (c_ms * 1e-3) / 1e9 if c_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                 "traffic_note": "HBM bytes per launch of that kernel from profiles/r02/traffic.json (PMC, same workload)",
+                "valu_issue_frac": valu_frac,
+                "valu_note": "SQ_INSTS_VALU (profiles/r02/pmc_counters.json) x 4 cycles / (launch time x 1024 SIMDs x 2.4 GHz): the scorer launches are bound by integer VALU issue, not by HBM",
+                "hbm_bound_launch": {"kernel": "classify_kernel", "achieved": round(c_ach, 2), "frac": round(c_ach / HBM_PEAK_GBPS, 5), "traffic": c_traffic,
+                                     "note": "slowest launch that HBM traffic bounds (13 B read + 4 B written per read, algorithmic)"},
+                "times_note": "kernel_ms / group_ms: un-overlapped launch times from instrumented steps (HIP events, one stream); ms_per_step is the "
+                              "pipelined period: pair logic + clustering of step i run on a side stream beside classify + scorer of step i + 1",
                 "kernel_ms": {k: round(v[0], 4) for k, v in kernels.items()},
                 "kernel_alg_bytes": {k: int(v[1]) for k, v in kernels.items()},
                 "kernel_alg_GBps": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0.0 for k, v in kernels.items()},
@@ -281,7 +308,8 @@ def main():
                        "skipped_frac": round(st.n_skipped / n, 4), "scored_reads": int(st.n_scored), "soft_items": int(st.n_soft_items),
                        "str_reads_clustered": n_treads, "clusters": int(cst.n_clusters), "bounds": int(len(bounds)),
                        "timed_region": "every kernel of the path on HBM-resident records: classify + score + soft-clip scan, the pair logic (Cache.add) on the device, "
-                                       "then keys + radix sort + sweep + bounds over the treads the same step produced; BAM decode, PCIe, the host-side row order "
+                                       "then keys + radix sort + sweep + bounds over the treads the same step produced; consecutive steps are pipelined on two streams of "
+                                       "the context (the side stream runs pair logic + clustering of a step while the next step's scorer runs); BAM decode, PCIe, the host-side row order "
                                        "(Nim table order) and file writing are in end_to_end, not here",
                        "parallelism": (f"records sharded over {world} GPU(s), no data-path collective" if exchange is None else
                                        f"records sharded over {world} GPUs; per step one RCCL all-gather of the tread arrays "
