@@ -617,8 +617,11 @@ static int cluster_device_pass(strl_ctx *c, const strl_tread *treads, const uint
       (rc = need(B_BIG, (size_t)big_words * 4)) || (rc = need(B_CNT, CC_WORDS * 4)) || (!R.composite && (rc = need(B_GKEY, n1 * 8))))
     return rc;
   uint32_t *cnt = B[B_CNT].as<uint32_t>();
-  STRL_HIP(zero_words(cnt + 4, (CC_WORDS - 4) * 4, st));   // (16-byte aligned part)
-  STRL_HIP(hipMemsetAsync(cnt + 1, 0, 3 * 4, st));   // CC_N stays (host path stores n there)
+  const int sort_bits0 = R.composite ? R.pos_bits + R.kbits : 32;
+  void *st_tab = nullptr;
+  size_t st_bytes = 0;
+  radix_sort_tables(B[B_SORT].p, n_max, sort_bits0, &st_tab, &st_bytes);   // the (first) sort's chunk tables: zeroed with the counters
+  STRL_HIP(zero_words2(cnt + 1, (CC_WORDS - 1) * 4, st_tab, st_bytes, st));   // CC_N stays (host path stores n there)
   const int TB = 256;
   const uint32_t nb = (uint32_t)((n1 + TB - 1) / TB);
   if (c->timing) STRL_HIP(hipEventRecord(c->ev[4], st));
@@ -636,11 +639,11 @@ static int cluster_device_pass(strl_ctx *c, const strl_tread *treads, const uint
   int e;
   if (R.composite) {
     e = radix_sort_pairs(st, d_n, n_max, B[B_KEY0].as<uint64_t>(), B[B_VAL0].as<uint32_t>(), B[B_KEY1].as<uint64_t>(), B[B_VAL1].as<uint32_t>(),
-                         B[B_SORT].p, B[B_SORT].cap, 0, R.pos_bits + R.kbits, &sk, &sv);
+                         B[B_SORT].p, B[B_SORT].cap, 0, R.pos_bits + R.kbits, &sk, &sv, true);
   } else {
     // stable sort by position, then stable sort by (tid, unit)  ==  group + algorithm.sort by position
     e = radix_sort_pairs(st, d_n, n_max, B[B_KEY0].as<uint64_t>(), B[B_VAL0].as<uint32_t>(), B[B_KEY1].as<uint64_t>(), B[B_VAL1].as<uint32_t>(),
-                         B[B_SORT].p, B[B_SORT].cap, 0, 32, &sk, &sv);
+                         B[B_SORT].p, B[B_SORT].cap, 0, 32, &sk, &sv, true);
     if (!e) {
       uint64_t *ok = sk == B[B_KEY0].as<uint64_t>() ? B[B_KEY1].as<uint64_t>() : B[B_KEY0].as<uint64_t>();
       uint32_t *ov = sv == B[B_VAL0].as<uint32_t>() ? B[B_VAL1].as<uint32_t>() : B[B_VAL0].as<uint32_t>();
@@ -660,7 +663,7 @@ static int cluster_device_pass(strl_ctx *c, const strl_tread *treads, const uint
   GatherParams G{};
   G.d_n = d_n; G.n_max = n_max; G.key = sk; G.perm = sv; G.shift = R.composite ? R.pos_bits : 0;
   G.pos_in = d_posin; G.sample_in = d_samplein; G.split_in = d_splitin; G.first_in = B[B_FIRST].as<uint64_t>(); G.tile_heads = B[B_TILES].as<uint32_t>();
-  G.scanned = ntiles > 1024 ? 1 : 0;
+  G.scanned = ntiles > 4096 ? 1 : 0;   // below that a tile sums the head counts before it itself (<= 16 KB, one launch less)
   G.pos = d_pos; G.sample = d_sample; G.gid = d_gid; G.split = d_split; G.gstart = d_gstart; G.gfirst = d_gfirst; G.gkeys = d_gkeys;
   G.gplaced = d_gplaced; G.cnt = cnt;
   hipLaunchKernelGGL(heads_kernel, dim3(ntiles), dim3(256), 0, st, G);

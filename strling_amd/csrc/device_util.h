@@ -27,6 +27,20 @@ static __global__ void zero_words_kernel(uint32_t *p, size_t n_words) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) q[i] = make_uint4(0, 0, 0, 0);
   if (blockIdx.x == 0 && threadIdx.x < (n_words & 3)) p[n4 * 4 + threadIdx.x] = 0;
 }
+// two regions in one launch (counters + a sort's chunk tables): under a second stream that saturates the chip every small
+// launch of a dependent chain costs tens of microseconds, so launches are worth saving
+static __global__ void zero_words2_kernel(uint32_t *p, size_t n_words, uint32_t *q, size_t m_words) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = i0; i < n_words; i += stride) p[i] = 0;
+  for (size_t i = i0; i < m_words; i += stride) q[i] = 0;
+}
+static inline hipError_t zero_words2(void *p, size_t bytes, void *q, size_t qbytes, hipStream_t st) {
+  const size_t w = std::max(bytes, qbytes) / 4;
+  if (!w) return hipSuccess;
+  const unsigned blocks = (unsigned)std::min<size_t>((w + 255) / 256, 1024);
+  hipLaunchKernelGGL(zero_words2_kernel, dim3(blocks), dim3(256), 0, st, static_cast<uint32_t *>(p), bytes / 4, static_cast<uint32_t *>(q), qbytes / 4);
+  return hipGetLastError();
+}
 static inline hipError_t zero_words(void *p, size_t bytes, hipStream_t st) {   // p 16-byte aligned, bytes a multiple of 4
   const size_t words = bytes / 4;
   if (!words) return hipSuccess;

@@ -634,7 +634,10 @@ int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uin
       (rc = c->p_emit.reserve((size_t)ecap * sizeof(strl_tread))) || (rc = c->treads.reserve((size_t)ecap * sizeof(strl_tread) + 64)) ||
       (rc = c->sort_scratch.reserve(sb)) || (rc = c->pair_cnt.reserve(PC_WORDS * 4 + 64)))
     return rc;
-  STRL_HIP(zero_words(c->pair_cnt.p, PC_WORDS * 4 + 64, st));
+  void *jt = nullptr;
+  size_t jt_bytes = 0;
+  radix_sort_tables(c->sort_scratch.p, icap, 32, &jt, &jt_bytes);           // the join sort's chunk tables: zeroed with the counters
+  STRL_HIP(zero_words2(c->pair_cnt.p, PC_WORDS * 4 + 64, jt, jt_bytes, st));
   PairParams P{};
   P.n = (uint32_t)n;
   P.tail_start = (uint32_t)(n - (uint64_t)n_tail);
@@ -662,7 +665,7 @@ int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uin
   uint64_t *ik = nullptr;
   uint32_t *iv = nullptr;
   int e = radix_sort_pairs(st, P.pc + PC_ITEMS, icap, c->p_key0.as<uint64_t>(), c->p_val0.as<uint32_t>(), c->p_key1.as<uint64_t>(),
-                           c->p_val1.as<uint32_t>(), c->sort_scratch.p, c->sort_scratch.cap, 0, 32, &ik, &iv);
+                           c->p_val1.as<uint32_t>(), c->sort_scratch.p, c->sort_scratch.cap, 0, 32, &ik, &iv, true);
   if (e) { set_error("radix_sort_pairs failed: %s", hipGetErrorString((hipError_t)e)); return STRL_ERR_HIP; }
   if (ev) STRL_HIP(hipEventRecord(ev[3], st));
   // the sorted items sit in (ik, iv); the emission keys go to the other pair of buffers

@@ -24,6 +24,11 @@ size_t radix_sort_scratch_bytes(uint32_t n_max, int bits);
 // `st`; nothing synchronises.  bits == 0: nothing to do (result = input).  Returns a hipError_t as int (0 = ok).
 int radix_sort_pairs(hipStream_t st, const uint32_t *d_n, uint32_t n_max, uint64_t *keys, uint32_t *vals, uint64_t *keys_alt,
                      uint32_t *vals_alt, void *scratch, size_t scratch_bytes, int bit_lo, int bits, uint64_t **out_keys,
-                     uint32_t **out_vals);
+                     uint32_t **out_vals, bool tables_zeroed = false);
+
+// The part of `scratch` a sort accumulates into with atomics and therefore needs zeroed first (its chunk tables).  A caller
+// that zeroes other things on the same stream anyway can include this region in its own fill (one launch instead of two)
+// and pass tables_zeroed = true.
+void radix_sort_tables(void *scratch, uint32_t n_max, int bits, void **p, size_t *bytes);
 
 }  // namespace strl

@@ -197,9 +197,18 @@ size_t radix_sort_scratch_bytes(uint32_t n_max, int bits) {
   return (size_t)(P ? P : 1) * ((size_t)ntiles + nchunks) * 1024 + 256;
 }
 
+void radix_sort_tables(void *scratch, uint32_t n_max, int bits, void **p, size_t *bytes) {
+  *p = nullptr; *bytes = 0;
+  if (bits <= 0 || n_max == 0 || !scratch) return;
+  const uint32_t P = (uint32_t)(bits + 7) / 8;
+  const uint32_t ntiles = div_up(n_max, SORT_TILE), nchunks = div_up(ntiles, SORT_CHUNK);
+  *p = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(scratch) + 255) & ~(uintptr_t)255);
+  *bytes = (size_t)P * nchunks * 256 * 4;
+}
+
 int radix_sort_pairs(hipStream_t st, const uint32_t *d_n, uint32_t n_max, uint64_t *keys, uint32_t *vals, uint64_t *keys_alt,
                      uint32_t *vals_alt, void *scratch, size_t scratch_bytes, int bit_lo, int bits, uint64_t **out_keys,
-                     uint32_t **out_vals) {
+                     uint32_t **out_vals, bool tables_zeroed) {
   if (out_keys) *out_keys = keys;
   if (out_vals) *out_vals = vals;
   if (bits <= 0 || n_max == 0) return 0;
@@ -212,7 +221,7 @@ int radix_sort_pairs(hipStream_t st, const uint32_t *d_n, uint32_t n_max, uint64
   uint32_t *H = C + (size_t)P * cwords;
   hipError_t e;
   // the chunk tables are accumulated with (256 per tile, uncontended) atomics by the histogram kernel
-  if ((e = zero_words(C, (size_t)P * cwords * 4, st)) != hipSuccess) return (int)e;
+  if (!tables_zeroed && (e = zero_words(C, (size_t)P * cwords * 4, st)) != hipSuccess) return (int)e;
   uint64_t *kin = keys, *kout = keys_alt;
   uint32_t *vin = vals, *vout = vals_alt;
   for (uint32_t p = 0; p < P; ++p) {
