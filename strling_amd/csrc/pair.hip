@@ -111,7 +111,7 @@ __global__ __launch_bounds__(1024) void pair_soft_items_kernel(PairParams P) {
 // of reads and stages its hits in LDS; a flush reserves item space with ONE atomic (same-address atomics run at ~88 per
 // microsecond on the L2, so a wave flushes once, at the end, unless its stage fills) and gathers the hashes of the
 // staged reads again.
-constexpr int PR_STAGE = 2048, PR_ILP = 8;
+constexpr int PR_STAGE = 1024, PR_ILP = 8;
 __global__ __launch_bounds__(256) void pair_probe_kernel(PairParams P) {
   __shared__ uint32_t stage[4][PR_STAGE + 64 * PR_ILP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -269,9 +269,9 @@ struct PItem {   // 48 bytes
 };
 static_assert(sizeof(PItem) == 48, "PItem layout");
 
-constexpr int PG_BLOCK = 1024;               // items per block
+constexpr int PG_BLOCK = 512;                // items per block
 constexpr int PG_HALO = 16;                  // a run that starts in the block may reach this far into the next one
-constexpr int PG_EMIT = 512;                 // treads one block may emit (LDS staging; 70 KB per block in all: two blocks per CU)
+constexpr int PG_EMIT = 256;                 // treads one block may emit (LDS staging; 35 KB per block in all: four blocks per CU)
 
 struct EmitStage {   // block-wide staging of the emitted treads in LDS
   strl_tread *t;
@@ -681,7 +681,7 @@ int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uin
       STRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_groups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_shmem));
       attr_done = true;
     }
-    hipLaunchKernelGGL(pair_groups_kernel, dim3((unsigned)std::min<uint32_t>((icap + PG_BLOCK - 1) / PG_BLOCK, 4096)), dim3(PG_BLOCK), pg_shmem, st, P);
+    hipLaunchKernelGGL(pair_groups_kernel, dim3((unsigned)std::min<uint32_t>((icap + PG_BLOCK - 1) / PG_BLOCK, 8192)), dim3(PG_BLOCK), pg_shmem, st, P);
     STRL_HIP(hipGetLastError());
   }
   if (ev) STRL_HIP(hipEventRecord(ev[4], st));
