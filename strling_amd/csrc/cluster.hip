@@ -689,8 +689,20 @@ static int cluster_device_pass(strl_ctx *c, const strl_tread *treads, const uint
 }
 
 // c.reads of every returned bound: the sorted permutation is still resident
+// The last clustering pass may live in the context's other tail set (an overlapped strl_extract_device has swapped the sets
+// since): bring it in for the duration of a call that reads it.
+namespace {
+struct LastClusterScope {
+  strl_ctx *c;
+  bool swapped;
+  explicit LastClusterScope(strl_ctx *ctx) : c(ctx), swapped(ctx && ctx->cl_where == 1) { if (swapped) swap_tail(c); }
+  ~LastClusterScope() { if (swapped) swap_tail(c); }
+};
+}  // namespace
+
 extern "C" int strl_cluster_members(strl_ctx *c, uint64_t *member_off, uint32_t *members, uint64_t cap, uint64_t *n_members) {
   if (c) { const int rcj = side_join(c); if (rcj) return rcj; }
+  LastClusterScope last_cluster(c);
   if (!c || !member_off || !n_members) { set_error("null argument"); return STRL_ERR_ARG; }
   const ClusterRun &R = c->cl_run;
   uint64_t tot = 0;
@@ -880,6 +892,7 @@ extern "C" int strl_bounds_bare(strl_ctx *c, const uint32_t *positions, const ui
 
 extern "C" int strl_ctx_cluster_times(strl_ctx *c, double ms[3]) {
   if (c) { const int rcj = side_join(c); if (rcj) return rcj; }
+  LastClusterScope last_cluster(c);
   if (!c || !ms) return STRL_ERR_ARG;
   STRL_HIP(hipSetDevice(c->device));
   STRL_HIP(hipStreamSynchronize(c->stream));
@@ -896,6 +909,7 @@ static inline int bits_for(uint64_t v) { int b = 1; while (b < 64 && (v >> b)) +
 // Re-run the device side of the last clustering pass on the same resident treads, asynchronously.
 extern "C" int strl_cluster_replay(strl_ctx *c) {
   if (c) { const int rcj = side_join(c); if (rcj) return rcj; }
+  LastClusterScope last_cluster(c);
   if (!c) return STRL_ERR_ARG;
   if (!c->cl_run.treads) { set_error("strl_cluster_replay: no previous clustering pass on this context"); return STRL_ERR_ARG; }
   STRL_HIP(hipSetDevice(c->device));
@@ -917,6 +931,7 @@ extern "C" int strl_cluster_resident(strl_ctx *c, int mode, int32_t n_tid, int p
   if (n_unplaced) *n_unplaced = 0;
   if (stats) memset(stats, 0, sizeof *stats);
   STRL_HIP(hipSetDevice(c->device));
+  c->cl_where = 0;
   ClusterRun &R = c->cl_run;
   R = ClusterRun{};
   R.n_max = c->tread_cap; R.n_tid = n_tid; R.mode = mode; R.window = window; R.min_support = min_support; R.min_clip = min_clip;
@@ -949,12 +964,14 @@ extern "C" int strl_cluster_resident(strl_ctx *c, int mode, int32_t n_tid, int p
 extern "C" int strl_cluster_collect(strl_ctx *c, strl_bounds *out, uint64_t cap, uint64_t *n_out, strl_unplaced *unplaced, uint64_t unplaced_cap,
                                     uint64_t *n_unplaced, strl_cluster_stats *stats) {
   if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
-  if (!c->cl_run.n_max && !c->cl_run.d_n) { set_error("strl_cluster_collect: no clustering pass on this context"); return STRL_ERR_ARG; }
+  { const ClusterRun &lr = c->cl_where ? c->alt.cl_run : c->cl_run;
+    if (!lr.n_max && !lr.d_n) { set_error("strl_cluster_collect: no clustering pass on this context"); return STRL_ERR_ARG; } }
   if (n_out) *n_out = 0;
   if (n_unplaced) *n_unplaced = 0;
   if (stats) memset(stats, 0, sizeof *stats);
   STRL_HIP(hipSetDevice(c->device));
   { const int rcj = side_join(c); if (rcj) return rcj; }
+  LastClusterScope last_cluster(c);
   return cluster_collect(c, {}, out, cap, n_out, unplaced, unplaced_cap, n_unplaced, stats);
 }
 
@@ -1002,6 +1019,7 @@ extern "C" int strl_cluster_gathered(strl_ctx *c, const strl_tread *gathered, co
   if (e) { set_error("radix_sort_pairs failed: %s", hipGetErrorString((hipError_t)e)); return STRL_ERR_HIP; }
   hipLaunchKernelGGL(owned_gather_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, gathered, sv, cnt + CC_N, tot, B[B_TREADS].as<strl_tread>());
   STRL_HIP(hipGetLastError());
+  c->cl_where = 0;
   ClusterRun &R = c->cl_run;
   R = ClusterRun{};
   R.n_max = tot; R.n_tid = n_tid; R.mode = mode; R.window = window; R.min_support = min_support; R.min_clip = min_clip;
@@ -1070,6 +1088,7 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
   hipStream_t st = c->stream;
   STRL_HIP(hipMemcpyAsync(B[B_TREADS].p, ft.data(), (size_t)n * sizeof(strl_tread), hipMemcpyHostToDevice, st));
   STRL_HIP(hipMemcpyAsync(B[B_CNT].p, &n, 4, hipMemcpyHostToDevice, st));
+  c->cl_where = 0;
   ClusterRun &R = c->cl_run;
   R = ClusterRun{};
   R.n_max = n; R.n = n; R.n_tid = max_tid + 1; R.mode = mode; R.window = window; R.min_support = min_support; R.min_clip = min_clip;

@@ -70,7 +70,27 @@ struct ClusterRun {
 };
 
 struct strl_ctx;
-int side_join(strl_ctx *c);   // main stream waits for the side stream's pending work (score.hip)
+int side_join(strl_ctx *c);   // main stream waits for the side streams' pending work (score.hip)
+void swap_tail(strl_ctx *c);  // exchange the current set of pair-logic / clustering state with the other one (score.hip)
+
+// Everything the pair logic and the clustering of ONE batch own (the "tail" of a step).  A context has two: the members of
+// strl_ctx with these names are the current set, `alt` the other.  The overlapped strl_extract_device alternates between
+// them, each with its own side stream, so the tails of two consecutive batches -- chains of small dependent launches that
+// crawl while the main stream saturates the chip -- make progress side by side.
+struct TailSet {
+  strl::DevBuf c_buf[16];
+  ClusterRun cl_run;
+  strl::DevBuf p_key0, p_key1, p_val0, p_val1, p_emit, sort_scratch, pair_cnt, treads;
+  uint32_t *n_treads_dev = nullptr;
+  uint32_t tread_cap = 0, pair_item_cap = 0;
+  uint64_t *po_key = nullptr, *po_key_alt = nullptr;
+  uint32_t *po_val = nullptr, *po_val_alt = nullptr;
+  int po_bits = 0;
+  bool pair_ordered = false;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_side_done = nullptr;
+  bool side_pending = false, pair_on_side = false;
+};
 
 struct strl_ctx {
   int device = 0;
@@ -91,6 +111,8 @@ struct strl_ctx {
   bool set_used[2] = {false, false};
   int set = 0;
   bool pair_on_side = false;       // the last pair logic ran on the side stream (its treads are ordered there already)
+  TailSet alt;                     // the other tail set (see TailSet)
+  int cl_where = 0;                // the last clustering pass lives in: 0 = the current tail set, 1 = alt
   bool timing = false;
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> ring;   // 4 events per recorded strl_score_reads launch

@@ -718,7 +718,25 @@ int side_join(strl_ctx *c) {
     STRL_HIP(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
     c->side_pending = false;
   }
+  if (c->alt.side_pending) {
+    STRL_HIP(hipStreamWaitEvent(c->stream, c->alt.ev_side_done, 0));
+    c->alt.side_pending = false;
+  }
   return STRL_OK;
+}
+
+void swap_tail(strl_ctx *c) {
+  TailSet &a = c->alt;
+  for (int i = 0; i < 16; ++i) std::swap(c->c_buf[i], a.c_buf[i]);
+  std::swap(c->cl_run, a.cl_run);
+  std::swap(c->p_key0, a.p_key0); std::swap(c->p_key1, a.p_key1); std::swap(c->p_val0, a.p_val0); std::swap(c->p_val1, a.p_val1);
+  std::swap(c->p_emit, a.p_emit); std::swap(c->sort_scratch, a.sort_scratch); std::swap(c->pair_cnt, a.pair_cnt); std::swap(c->treads, a.treads);
+  std::swap(c->n_treads_dev, a.n_treads_dev); std::swap(c->tread_cap, a.tread_cap); std::swap(c->pair_item_cap, a.pair_item_cap);
+  std::swap(c->po_key, a.po_key); std::swap(c->po_key_alt, a.po_key_alt); std::swap(c->po_val, a.po_val); std::swap(c->po_val_alt, a.po_val_alt);
+  std::swap(c->po_bits, a.po_bits); std::swap(c->pair_ordered, a.pair_ordered);
+  std::swap(c->stream2, a.stream2); std::swap(c->ev_side_done, a.ev_side_done);
+  std::swap(c->side_pending, a.side_pending); std::swap(c->pair_on_side, a.pair_on_side);
+  c->cl_where ^= 1;
 }
 
 extern "C" {
@@ -754,6 +772,8 @@ int strl_ctx_create(int device_ordinal, strl_ctx **out) {
   c->device = device_ordinal;
   STRL_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   STRL_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  STRL_HIP(hipStreamCreateWithFlags(&c->alt.stream2, hipStreamNonBlocking));
+  STRL_HIP(hipEventCreateWithFlags(&c->alt.ev_side_done, hipEventDisableTiming));
   STRL_HIP(hipEventCreateWithFlags(&c->ev_main_done, hipEventDisableTiming));
   STRL_HIP(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
   STRL_HIP(hipEventCreateWithFlags(&c->ev_head_done, hipEventDisableTiming));
@@ -778,6 +798,7 @@ void strl_ctx_destroy(strl_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  if (c->alt.stream2) (void)hipStreamSynchronize(c->alt.stream2);
   (void)hipStreamSynchronize(c->stream);
   strl::DevBuf *bufs[] = {&c->lut, &c->thr, &c->g_tid, &c->g_bins, &c->g_start, &c->g_pmax, &c->queue, &c->soft_queue, &c->counters,
                           &c->soft_tmp, &c->sb_whole, &c->sb_soft, &c->queue_r, &c->soft_dense, &c->sb_state_w, &c->sb_state_s, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
@@ -795,6 +816,14 @@ void strl_ctx_destroy(strl_ctx *c) {
   for (auto &e : c->ev_set_free) if (e) (void)hipEventDestroy(e);
   c->st_whole2.release(); c->st_soft2.release(); c->counters2.release(); c->bloom2.release();
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->alt.stream2) (void)hipStreamDestroy(c->alt.stream2);
+  if (c->alt.ev_side_done) (void)hipEventDestroy(c->alt.ev_side_done);
+  {
+    TailSet &a = c->alt;
+    strl::DevBuf *ab[] = {&a.p_key0, &a.p_key1, &a.p_val0, &a.p_val1, &a.p_emit, &a.sort_scratch, &a.pair_cnt, &a.treads};
+    for (auto *b : ab) b->release();
+    for (auto &b : a.c_buf) b.release();
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1153,6 +1182,7 @@ int strl_extract_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa
     std::swap(c->st_whole, c->st_whole2); std::swap(c->st_soft, c->st_soft2); std::swap(c->counters, c->counters2);
     std::swap(c->bloom, c->bloom2); std::swap(c->bloom_mask, c->bloom_mask2);
     c->set ^= 1;
+    swap_tail(c);                   // this batch's pair logic and clustering: the other tail set, on its own side stream
     if ((rc = c->counters.reserve(CNT_WORDS * 4))) return rc;
     if (c->set_used[c->set]) STRL_HIP(hipStreamWaitEvent(c->stream, c->ev_set_free[c->set], 0));   // the side stream is done with this set
   }

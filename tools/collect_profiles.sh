@@ -10,6 +10,7 @@ cd $R && python bench.py --cache /tmp --steps 20 --warmup 3 > $O/bench.json 2> $
 cd /tmp && export TMPDIR=/tmp
 run() { d=$1; shift; STEPS=${STEPS:-30} timeout 900 rocprofv3 "$@" --output-format csv -d $O/$d -o run -- python $R/tools/prof_run.py > $O/$d.log 2>&1; }
 run kt --kernel-trace --stats
+STRL_NO_OVERLAP=1 run kt_serial --kernel-trace --stats     # every launch alone on the device: comparable with bench.py's kernel_ms
 run fetch --pmc FETCH_SIZE
 run write --pmc WRITE_SIZE
 run pmc1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU
