@@ -689,14 +689,14 @@ static int cluster_device_pass(strl_ctx *c, const strl_tread *treads, const uint
 }
 
 // c.reads of every returned bound: the sorted permutation is still resident
-// The last clustering pass may live in the context's other tail set (an overlapped strl_extract_device has swapped the sets
-// since): bring it in for the duration of a call that reads it.
+// The last clustering pass may live in one of the context's other tail sets (overlapped strl_extract_device calls have rotated the
+// sets since): bring it in for the duration of a call that reads it.
 namespace {
 struct LastClusterScope {
   strl_ctx *c;
-  bool swapped;
-  explicit LastClusterScope(strl_ctx *ctx) : c(ctx), swapped(ctx && ctx->cl_where == 1) { if (swapped) swap_tail(c); }
-  ~LastClusterScope() { if (swapped) swap_tail(c); }
+  int k;       // position of the last clustering pass' set; N_SETS - k rotations bring it to the front, k more restore the order
+  explicit LastClusterScope(strl_ctx *ctx) : c(ctx), k(ctx ? ctx->cl_where : 0) { if (k) for (int i = 0; i < N_SETS - k; ++i) rotate_tail(c); }
+  ~LastClusterScope() { for (int i = 0; i < k; ++i) rotate_tail(c); }
 };
 }  // namespace
 
@@ -964,7 +964,7 @@ extern "C" int strl_cluster_resident(strl_ctx *c, int mode, int32_t n_tid, int p
 extern "C" int strl_cluster_collect(strl_ctx *c, strl_bounds *out, uint64_t cap, uint64_t *n_out, strl_unplaced *unplaced, uint64_t unplaced_cap,
                                     uint64_t *n_unplaced, strl_cluster_stats *stats) {
   if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
-  { const ClusterRun &lr = c->cl_where ? c->alt.cl_run : c->cl_run;
+  { const ClusterRun &lr = c->cl_where ? c->alt[c->cl_where - 1].cl_run : c->cl_run;
     if (!lr.n_max && !lr.d_n) { set_error("strl_cluster_collect: no clustering pass on this context"); return STRL_ERR_ARG; } }
   if (n_out) *n_out = 0;
   if (n_unplaced) *n_unplaced = 0;

@@ -71,11 +71,12 @@ struct ClusterRun {
 
 struct strl_ctx;
 int side_join(strl_ctx *c);   // main stream waits for the side streams' pending work (score.hip)
-void swap_tail(strl_ctx *c);  // exchange the current set of pair-logic / clustering state with the other one (score.hip)
+void rotate_tail(strl_ctx *c);  // make the least recently used set of pair-logic / clustering state the current one (score.hip)
+constexpr int N_SETS = 2;        // batches in flight on a context: buffer sets of the scorer's output and of the tail (3 measured no faster than 2)
 
-// Everything the pair logic and the clustering of ONE batch own (the "tail" of a step).  A context has two: the members of
-// strl_ctx with these names are the current set, `alt` the other.  The overlapped strl_extract_device alternates between
-// them, each with its own side stream, so the tails of two consecutive batches -- chains of small dependent launches that
+// Everything the pair logic and the clustering of ONE batch own (the "tail" of a step).  A context has N_SETS: the members of
+// strl_ctx with these names are the current set, `alt[]` the others (most recently used first).  The overlapped
+// strl_extract_device rotates through them, each with its own side stream, so the tails of consecutive batches -- chains of small dependent launches that
 // crawl while the main stream saturates the chip -- make progress side by side.
 struct TailSet {
   strl::DevBuf c_buf[16];
@@ -103,16 +104,15 @@ struct strl_ctx {
   bool side_pending = false;
   // strl_extract_device on device-resident input goes further: the pair logic of batch i (latency-bound: Bloom probes,
   // sorts, gathers) runs on the side stream too, beside classify + scorer of batch i + 1 on the main stream.  What the
-  // pair logic reads of the scorer's output exists twice (whole[], soft-clip records, counters, Bloom bitmap); a call
-  // swaps the sets and waits (on the device) until the side stream is done with the set it is about to overwrite.
-  strl::DevBuf st_whole2, st_soft2, counters2, bloom2;
-  uint32_t bloom_mask2 = 0;
-  hipEvent_t ev_head_done = nullptr, ev_set_free[2] = {nullptr, nullptr};
-  bool set_used[2] = {false, false};
+  // pair logic reads of the scorer's output exists N_SETS times (whole[], soft-clip records, counters, Bloom bitmap); a call
+  // rotates the sets and waits (on the device) until the side stream is done with the set it is about to overwrite.
+  struct HeadSet { strl::DevBuf st_whole, st_soft, counters, bloom; uint32_t bloom_mask = 0; } head_alt[N_SETS - 1];   // most recently used first
+  hipEvent_t ev_head_done = nullptr, ev_set_free[N_SETS] = {};
+  bool set_used[N_SETS] = {};
   int set = 0;
   bool pair_on_side = false;       // the last pair logic ran on the side stream (its treads are ordered there already)
-  TailSet alt;                     // the other tail set (see TailSet)
-  int cl_where = 0;                // the last clustering pass lives in: 0 = the current tail set, 1 = alt
+  TailSet alt[N_SETS - 1];         // the other tail sets (see TailSet), most recently used first
+  int cl_where = 0;                // the last clustering pass lives in: 0 = the current tail set, k = alt[k - 1]
   bool timing = false;
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> ring;   // 4 events per recorded strl_score_reads launch

@@ -718,15 +718,15 @@ int side_join(strl_ctx *c) {
     STRL_HIP(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
     c->side_pending = false;
   }
-  if (c->alt.side_pending) {
-    STRL_HIP(hipStreamWaitEvent(c->stream, c->alt.ev_side_done, 0));
-    c->alt.side_pending = false;
-  }
+  for (auto &a : c->alt)
+    if (a.side_pending) {
+      STRL_HIP(hipStreamWaitEvent(c->stream, a.ev_side_done, 0));
+      a.side_pending = false;
+    }
   return STRL_OK;
 }
 
-void swap_tail(strl_ctx *c) {
-  TailSet &a = c->alt;
+static void swap_tail_with(strl_ctx *c, TailSet &a) {
   for (int i = 0; i < 16; ++i) std::swap(c->c_buf[i], a.c_buf[i]);
   std::swap(c->cl_run, a.cl_run);
   std::swap(c->p_key0, a.p_key0); std::swap(c->p_key1, a.p_key1); std::swap(c->p_val0, a.p_val0); std::swap(c->p_val1, a.p_val1);
@@ -736,7 +736,20 @@ void swap_tail(strl_ctx *c) {
   std::swap(c->po_bits, a.po_bits); std::swap(c->pair_ordered, a.pair_ordered);
   std::swap(c->stream2, a.stream2); std::swap(c->ev_side_done, a.ev_side_done);
   std::swap(c->side_pending, a.side_pending); std::swap(c->pair_on_side, a.pair_on_side);
-  c->cl_where ^= 1;
+}
+// current -> alt[0] -> alt[1] -> ... -> current: the least recently used set (the last alternative) becomes current, the set
+// that was current becomes alt[0].  N_SETS rotations restore the arrangement.
+void rotate_tail(strl_ctx *c) {
+  for (int k = 0; k < N_SETS - 1; ++k) swap_tail_with(c, c->alt[k]);
+  c->cl_where = (c->cl_where + 1) % N_SETS;
+}
+static void rotate_head(strl_ctx *c) {
+  for (int k = 0; k < N_SETS - 1; ++k) {
+    strl_ctx::HeadSet &h = c->head_alt[k];
+    std::swap(c->st_whole, h.st_whole); std::swap(c->st_soft, h.st_soft); std::swap(c->counters, h.counters);
+    std::swap(c->bloom, h.bloom); std::swap(c->bloom_mask, h.bloom_mask);
+  }
+  c->set = (c->set + 1) % N_SETS;
 }
 
 extern "C" {
@@ -772,8 +785,10 @@ int strl_ctx_create(int device_ordinal, strl_ctx **out) {
   c->device = device_ordinal;
   STRL_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   STRL_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-  STRL_HIP(hipStreamCreateWithFlags(&c->alt.stream2, hipStreamNonBlocking));
-  STRL_HIP(hipEventCreateWithFlags(&c->alt.ev_side_done, hipEventDisableTiming));
+  for (auto &a : c->alt) {
+    STRL_HIP(hipStreamCreateWithFlags(&a.stream2, hipStreamNonBlocking));
+    STRL_HIP(hipEventCreateWithFlags(&a.ev_side_done, hipEventDisableTiming));
+  }
   STRL_HIP(hipEventCreateWithFlags(&c->ev_main_done, hipEventDisableTiming));
   STRL_HIP(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
   STRL_HIP(hipEventCreateWithFlags(&c->ev_head_done, hipEventDisableTiming));
@@ -798,7 +813,7 @@ void strl_ctx_destroy(strl_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-  if (c->alt.stream2) (void)hipStreamSynchronize(c->alt.stream2);
+  for (auto &a : c->alt) if (a.stream2) (void)hipStreamSynchronize(a.stream2);
   (void)hipStreamSynchronize(c->stream);
   strl::DevBuf *bufs[] = {&c->lut, &c->thr, &c->g_tid, &c->g_bins, &c->g_start, &c->g_pmax, &c->queue, &c->soft_queue, &c->counters,
                           &c->soft_tmp, &c->sb_whole, &c->sb_soft, &c->queue_r, &c->soft_dense, &c->sb_state_w, &c->sb_state_s, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
@@ -814,16 +829,15 @@ void strl_ctx_destroy(strl_ctx *c) {
   if (c->ev_side_done) (void)hipEventDestroy(c->ev_side_done);
   if (c->ev_head_done) (void)hipEventDestroy(c->ev_head_done);
   for (auto &e : c->ev_set_free) if (e) (void)hipEventDestroy(e);
-  c->st_whole2.release(); c->st_soft2.release(); c->counters2.release(); c->bloom2.release();
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
-  if (c->alt.stream2) (void)hipStreamDestroy(c->alt.stream2);
-  if (c->alt.ev_side_done) (void)hipEventDestroy(c->alt.ev_side_done);
-  {
-    TailSet &a = c->alt;
+  for (auto &a : c->alt) {
+    if (a.stream2) (void)hipStreamDestroy(a.stream2);
+    if (a.ev_side_done) (void)hipEventDestroy(a.ev_side_done);
     strl::DevBuf *ab[] = {&a.p_key0, &a.p_key1, &a.p_val0, &a.p_val1, &a.p_emit, &a.sort_scratch, &a.pair_cnt, &a.treads};
     for (auto *b : ab) b->release();
     for (auto &b : a.c_buf) b.release();
   }
+  for (auto &h : c->head_alt) { h.st_whole.release(); h.st_soft.release(); h.counters.release(); h.bloom.release(); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1179,10 +1193,8 @@ int strl_extract_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa
   static const bool no_overlap = getenv("STRL_NO_OVERLAP") != nullptr;
   const bool overlap = s->mem == STRL_MEM_DEVICE && !c->timing && !no_overlap;
   if (overlap) {
-    std::swap(c->st_whole, c->st_whole2); std::swap(c->st_soft, c->st_soft2); std::swap(c->counters, c->counters2);
-    std::swap(c->bloom, c->bloom2); std::swap(c->bloom_mask, c->bloom_mask2);
-    c->set ^= 1;
-    swap_tail(c);                   // this batch's pair logic and clustering: the other tail set, on its own side stream
+    rotate_head(c);                 // the scorer's output of this batch: the least recently used set
+    rotate_tail(c);                 // this batch's pair logic and clustering: likewise, on that set's own side stream
     if ((rc = c->counters.reserve(CNT_WORDS * 4))) return rc;
     if (c->set_used[c->set]) STRL_HIP(hipStreamWaitEvent(c->stream, c->ev_set_free[c->set], 0));   // the side stream is done with this set
   }
