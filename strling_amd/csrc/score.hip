@@ -547,9 +547,16 @@ template <int MODE, int STAGE> struct Item {
 //          the ladder, the SEQ chunks and thresholds of item i+1 and the queue entry of item i+2 are in flight.
 template <int NW, int SLOTS, int MODE, int STAGE, int BLOCK>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? 4 : 1) void score_kernel(ScoreParams P) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr int LUTK = STAGE == 0 ? LUT_A_DWORDS : LUT_DWORDS;   // k-mer tables this stage looks up
   constexpr int LUTW = LUTK + 256;                                  // + the byte -> 2-bit conversion table
+  // Statically sized LDS where it fits the 64 KB a static allocation may have: the tables then sit at compile-time
+  // addresses that fold into the ds_* offset fields (with a dynamic allocation every table access paid a `v_add 0` for
+  // the unknown base: ~100 VALU instructions per read in a kernel that is bound by exactly those).
+  constexpr int LDS_WORDS = LUTW + (BLOCK / 64) * table_rows<NW, SLOTS, STAGE>() * 64;
+  constexpr bool STATIC_LDS = (size_t)LDS_WORDS * 4 <= 65536;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_st[STATIC_LDS ? LDS_WORDS : 4];
+  uint32_t *const lds = STATIC_LDS ? lds_st : lds_dyn;
   for (int i = threadIdx.x; i < LUTK; i += BLOCK) lds[i] = reinterpret_cast<const uint32_t *>(P.lut)[i];
   for (int i = threadIdx.x; i < 256; i += BLOCK) lds[LUTK + i] = reinterpret_cast<const uint32_t *>(P.lut)[LUT_DWORDS + i];
   __syncthreads();
@@ -668,9 +675,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? 4 : 1) void sco
 // ---- host side of this translation unit -------------------------------------------------------
 template <int NW, int SLOTS, int MODE, int STAGE, int BLOCK> static int launch_score(strl_ctx *ctx, const ScoreParams &P, int blocks) {
   auto kfn = score_kernel<NW, SLOTS, MODE, STAGE, BLOCK>;
-  const size_t shmem = (size_t)((STAGE == 0 ? LUT_A_DWORDS : LUT_DWORDS) + 256) * 4 + (size_t)(BLOCK / 64) * table_rows<NW, SLOTS, STAGE>() * 64 * 4;
+  size_t shmem = (size_t)((STAGE == 0 ? LUT_A_DWORDS : LUT_DWORDS) + 256) * 4 + (size_t)(BLOCK / 64) * table_rows<NW, SLOTS, STAGE>() * 64 * 4;
+  if (shmem <= 65536) shmem = 0;      // the kernel allocates it statically (see STATIC_LDS there)
   static bool attr_done = false;
-  if (!attr_done) {
+  if (!attr_done && shmem) {
     STRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     attr_done = true;
   }

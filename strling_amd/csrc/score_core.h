@@ -240,20 +240,22 @@ STRL_DEV void hist_pass(const Seg<NW> &sg, bool active, uint32_t *tab, const uin
       if (K <= 3) {  // 10 / 24 x 32-bit bins (one per class); windows past a lane's end hit a dummy row and get key 0
         constexpr uint32_t DUMMY = (uint32_t)LutCls<K>::n;
         uint32_t old[B];
+        // The bins count in units of 1 << 15, so the value the LDS atomic returns already sits in the key's count field
+        // and the key is ONE three-operand add (count field + tie-break constant + class: no overlapping bits).
         if (full) {
 #pragma unroll
-          for (int j = 0; j < B; ++j) old[j] = strl_lds_add(tab + code[j] * STRL_LANES, 1u);
+          for (int j = 0; j < B; ++j) old[j] = strl_lds_add(tab + code[j] * STRL_LANES, 1u << 15);
 #pragma unroll
-          for (int j = 0; j < B; ++j) key[j] = ((old[j] << 15) + kc[j]) | code[j];
+          for (int j = 0; j < B; ++j) key[j] = old[j] + kc[j] + code[j];
         } else {
 #pragma unroll
           for (int j = 0; j < B; ++j) {
             old[j] = 0;
-            if (b0 + j < NWIN) old[j] = strl_lds_add(tab + ((b0 + j < nwin) ? code[j] : DUMMY) * STRL_LANES, 1u);
+            if (b0 + j < NWIN) old[j] = strl_lds_add(tab + ((b0 + j < nwin) ? code[j] : DUMMY) * STRL_LANES, 1u << 15);
           }
 #pragma unroll
           for (int j = 0; j < B; ++j) {
-            const uint32_t k = ((old[j] << 15) + kc[j]) | code[j];
+            const uint32_t k = old[j] + kc[j] + code[j];
             key[j] = (b0 + j < NWIN && b0 + j < nwin) ? k : 0u;
           }
         }
