@@ -33,8 +33,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--reads-per-gpu", type=int, default=2 ** 25, help="reads resident per GPU (2^24 pairs, SURVEY S1)")
     ap.add_argument("--chunks", type=int, default=64, help="independent synthetic sub-samples the batch is generated from (in parallel)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline budget (rank 0, N=1 only)")
@@ -153,6 +153,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import gc
+    gc.collect()
+    gc.disable()                 # no collector pause inside the timed region (the loop allocates next to nothing)
     for _ in range(args.warmup):
         step()
     ctx.sync()
@@ -163,6 +166,7 @@ def main():
     ctx.sync()
     barrier()
     el = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -269,7 +273,7 @@ def main():
                 "hbm_bound_launch": {"kernel": "classify_kernel", "achieved": round(c_ach, 2), "frac": round(c_ach / HBM_PEAK_GBPS, 5), "traffic": c_traffic,
                                      "note": "slowest launch that HBM traffic bounds (13 B read + 4 B written per read, algorithmic)"},
                 "times_note": "kernel_ms / group_ms: un-overlapped launch times from instrumented steps (HIP events, one stream); ms_per_step is the "
-                              "pipelined period: pair logic + clustering of step i run on a side stream beside classify + scorer of step i + 1",
+                              "pipelined period: pair logic + clustering of step i run on side streams beside classify + scorer of step i + 1 and the tail of step i - 1",
                 "kernel_ms": {k: round(v[0], 4) for k, v in kernels.items()},
                 "kernel_alg_bytes": {k: int(v[1]) for k, v in kernels.items()},
                 "kernel_alg_GBps": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0.0 for k, v in kernels.items()},
@@ -308,8 +312,8 @@ def main():
                        "skipped_frac": round(st.n_skipped / n, 4), "scored_reads": int(st.n_scored), "soft_items": int(st.n_soft_items),
                        "str_reads_clustered": n_treads, "clusters": int(cst.n_clusters), "bounds": int(len(bounds)),
                        "timed_region": "every kernel of the path on HBM-resident records: classify + score + soft-clip scan, the pair logic (Cache.add) on the device, "
-                                       "then keys + radix sort + sweep + bounds over the treads the same step produced; consecutive steps are pipelined on two streams of "
-                                       "the context (the side stream runs pair logic + clustering of a step while the next step's scorer runs); BAM decode, PCIe, the host-side row order "
+                                       "then keys + radix sort + sweep + bounds over the treads the same step produced; consecutive steps are pipelined on the "
+                                       "context's streams (side streams run pair logic + clustering of a step while the next step's scorer runs); BAM decode, PCIe, the host-side row order "
                                        "(Nim table order) and file writing are in end_to_end, not here",
                        "parallelism": (f"records sharded over {world} GPU(s), no data-path collective" if exchange is None else
                                        f"records sharded over {world} GPUs; per step one RCCL all-gather of the tread arrays "

@@ -126,6 +126,8 @@ def write_bam_parallel(path, rec, level=1, block=0xFF00, procs=None, records_per
             with mp.get_context("fork").Pool(min(procs, len(tasks))) as pool:
                 for part in pool.imap(_par_worker, tasks, chunksize=1):
                     f.write(part)
+                pool.close()
+                pool.join()
         f.write(_EOF)
     _PAR.clear()
     return text.decode()

@@ -257,6 +257,8 @@ def synth_wgs_chunks(n_chunks, pairs_per_chunk, seed=1234, procs=None, **kw):
     else:
         with mp.get_context("fork").Pool(procs) as pool:
             res = pool.map(_chunk_worker, jobs, chunksize=1)
+            pool.close()
+            pool.join()        # the workers are gone before the caller goes on (nothing of theirs runs beside a timed region)
     n_contigs = res[0][1].n_tid
     pieces = [r[0][0] for r in res] + [r[0][1] for r in res]          # every chunk's mapped part, then every tail
     shift = [c * n_contigs for c in range(n_chunks)] * 2
