@@ -323,6 +323,11 @@ int strl_cluster_collect(strl_ctx *ctx, strl_bounds *out, uint64_t cap, uint64_t
  * The device buffer strl_extract_device left its treads in: *treads (strl_tread[*cap]) and *count (uint32 on the device).
  * A host framework (torch.distributed over RCCL) all-gathers these buffers; nothing is copied to the host. */
 int strl_ctx_treads_device(strl_ctx *ctx, void **treads, uint64_t *cap, void **count);
+/* The HIP stream (hipStream_t) the tail of the last strl_extract_device call runs on -- the context's main stream, or a side
+ * stream when that call overlapped its pair logic with the next batch's scorer.  Enqueue the all-gather there: it is then
+ * ordered behind the batch's pair logic (and the .bin-order sort strl_ctx_treads_device adds) and before an asynchronous
+ * strl_cluster_gathered, and the whole exchange step overlaps the next strl_extract_device. */
+void *strl_ctx_tail_stream(strl_ctx *ctx);
 /* `gathered` (device) = world x pad treads, rank-major: rank r's treads are gathered[r * pad .. r * pad + counts[r]) with
  * counts (device, uint32[world]) -- what all_gather_into_tensor over the ranks' padded tread buffers produces.  This rank
  * keeps the treads of the (tid, unit) groups it owns (a hash of the key modulo world, computed on the device), in global

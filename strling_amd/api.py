@@ -108,7 +108,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
            "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order",
-           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered", "strl_inflate_blocks", "strl_cluster_collect"]
+           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered", "strl_inflate_blocks", "strl_cluster_collect", "strl_ctx_tail_stream"]
 
 
 def lib_path():
@@ -175,6 +175,8 @@ def load(build_if_missing=True):
     L.strl_cluster_resident.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int, C.c_uint32, C.c_int32, C.c_uint16, C.c_uint16, C.c_uint16,
                                         C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                         C.POINTER(ClusterStats)]
+    L.strl_ctx_tail_stream.argtypes = [C.c_void_p]
+    L.strl_ctx_tail_stream.restype = C.c_void_p
     L.strl_cluster_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                        C.POINTER(ClusterStats)]
     L.strl_extract_begin.argtypes = [C.c_void_p, C.c_uint64]
@@ -513,6 +515,10 @@ class Context:
         ms = (C.c_double * 3)()
         _check(self.L.strl_ctx_cluster_times(self.h, C.byref(ms)))
         return dict(zip(["cluster_keys_sort_groups", "cluster_sweep", "cluster_bounds"], list(ms)))
+
+    def tail_stream(self):
+        """hipStream_t (as an int) the tail of the last extract_device call runs on (strl_ctx_tail_stream)"""
+        return int(self.L.strl_ctx_tail_stream(self.h) or 0)
 
     def treads_device(self):
         """(device pointer of the resident treads, capacity in treads, device pointer of their uint32 count)"""

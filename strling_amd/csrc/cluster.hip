@@ -975,11 +975,25 @@ extern "C" int strl_cluster_collect(strl_ctx *c, strl_bounds *out, uint64_t cap,
   return cluster_collect(c, {}, out, cap, n_out, unplaced, unplaced_cap, n_unplaced, stats);
 }
 
+// The stream the tail of the last strl_extract_device call runs on: work enqueued there (a collective over the buffers
+// strl_ctx_treads_device returns, strl_cluster_gathered) is ordered behind that batch's pair logic and overlaps the next
+// batch's scorer on the main stream.
+static bool tail_on_side(strl_ctx *c) {
+  static const bool no_overlap = getenv("STRL_NO_OVERLAP") != nullptr;
+  return c->pair_on_side && !c->timing && !no_overlap;
+}
+extern "C" void *strl_ctx_tail_stream(strl_ctx *c) {
+  if (!c) return nullptr;
+  return (void *)(tail_on_side(c) ? c->stream2 : c->stream);
+}
+
 extern "C" int strl_ctx_treads_device(strl_ctx *c, void **treads, uint64_t *cap, void **count) {
-  if (c) { const int rcj = side_join(c); if (rcj) return rcj; }
+  const bool side = c && c->n_treads_dev && tail_on_side(c);
+  if (c && !side) { const int rcj = side_join(c); if (rcj) return rcj; }
   if (!c || !c->n_treads_dev) { set_error("strl_ctx_treads_device: no strl_extract_device call on this context"); return STRL_ERR_ARG; }
   STRL_HIP(hipSetDevice(c->device));
-  { const int rc0 = strl_pair_order(c); if (rc0) return rc0; }           // the gather wants the .bin order
+  { const int rc0 = strl_pair_order(c, side ? c->stream2 : nullptr); if (rc0) return rc0; }           // the gather wants the .bin order
+  if (side) { STRL_HIP(hipEventRecord(c->ev_side_done, c->stream2)); c->side_pending = true; }
   if (treads) *treads = c->treads.p;
   if (cap) *cap = c->tread_cap;
   if (count) *count = c->n_treads_dev;
@@ -990,7 +1004,11 @@ extern "C" int strl_cluster_gathered(strl_ctx *c, const strl_tread *gathered, co
                                      int32_t n_tid, int pos_bits, uint32_t window, int32_t min_support, uint16_t min_clip, uint16_t min_clip_total,
                                      uint16_t max_clip_dist, strl_bounds *out, uint64_t cap, uint64_t *n_out, strl_unplaced *unplaced,
                                      uint64_t unplaced_cap, uint64_t *n_unplaced, strl_cluster_stats *stats) {
-  if (c) { const int rcj = side_join(c); if (rcj) return rcj; }
+  // Asynchronous call behind an extract whose pair logic ran on a side stream: the whole exchange step (the caller's
+  // collectives on strl_ctx_tail_stream, then this) stays on that stream and overlaps the next batch's scorer.
+  static const bool no_overlap = getenv("STRL_NO_OVERLAP") != nullptr;
+  const bool on_side = c && !out && !n_out && !stats && !n_unplaced && c->pair_on_side && !c->timing && !no_overlap;
+  if (c && !on_side) { const int rcj = side_join(c); if (rcj) return rcj; }
   if (!c || !gathered || !counts || world < 1 || rank < 0 || rank >= world || pad == 0) { set_error("bad argument"); return STRL_ERR_ARG; }
   if ((uint64_t)world * pad > 0x7ffffff0ull || n_tid < 0 || pos_bits < 0 || pos_bits > 32) { set_error("bad argument"); return STRL_ERR_ARG; }
   if (n_out) *n_out = 0;
@@ -999,7 +1017,7 @@ extern "C" int strl_cluster_gathered(strl_ctx *c, const strl_tread *gathered, co
   STRL_HIP(hipSetDevice(c->device));
   const uint32_t tot = (uint32_t)world * pad;
   strl::DevBuf *B = c->c_buf;
-  hipStream_t st = c->stream;
+  hipStream_t st = on_side ? c->stream2 : c->stream;
   int rc;
   if ((rc = B[B_TREADS].reserve((size_t)tot * sizeof(strl_tread))) || (rc = B[B_CNT].reserve(CC_WORDS * 4)) || (rc = B[B_KEY0].reserve((size_t)tot * 8)) ||
       (rc = B[B_KEY1].reserve((size_t)tot * 8)) || (rc = B[B_VAL0].reserve((size_t)tot * 4)) || (rc = B[B_VAL1].reserve((size_t)tot * 4)) ||
@@ -1029,7 +1047,12 @@ extern "C" int strl_cluster_gathered(strl_ctx *c, const strl_tread *gathered, co
   R.kbits = bits_for((uint64_t)n_tid) + 15;
   R.composite = R.pos_bits + R.kbits <= 64;
   R.treads = B[B_TREADS].as<strl_tread>(); R.d_n = cnt + CC_N;
-  if ((rc = cluster_device_pass(c, R.treads, R.d_n))) return rc;
+  if ((rc = cluster_device_pass(c, R.treads, R.d_n, st))) return rc;
+  if (on_side) {
+    STRL_HIP(hipEventRecord(c->ev_side_done, c->stream2));
+    c->side_pending = true;
+    return STRL_OK;
+  }
   if (!out && !n_out && !stats && !n_unplaced) return STRL_OK;
   uint32_t perr = 0;
   STRL_HIP(hipMemcpyAsync(&perr, aux + 1, 4, hipMemcpyDeviceToHost, st));

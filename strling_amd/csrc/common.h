@@ -156,7 +156,7 @@ struct strl_ctx {
 };
 
 // pair.hip: enqueue the device pair logic behind a scoring pass of the same batch
-int strl_pair_order(strl_ctx *c);
+int strl_pair_order(strl_ctx *c, hipStream_t on_stream = nullptr);   // nullptr = the main stream (after a side_join)
 int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uint32_t *whole, const strl_soft_rec *soft,
                      const uint32_t *d_n_soft, uint64_t soft_cap, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap,
                      hipStream_t on_stream = nullptr);   // nullptr = the main stream

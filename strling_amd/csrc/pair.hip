@@ -592,11 +592,14 @@ extern "C" int strl_pair_rule_device(strl_ctx *c, int op, strl_tread *A, const s
 }
 
 // Treads of the last strl_pair_device call into the order of the reference's .bin file (c->treads); idempotent.
-int strl_pair_order(strl_ctx *c) {
-  { const int rcj = side_join(c); if (rcj) return rcj; }      // an overlapped clustering may still read the unordered treads
+int strl_pair_order(strl_ctx *c, hipStream_t on_stream) {
+  const bool on_main = !on_stream || on_stream == c->stream;
+  // on the main stream: an overlapped clustering may still read the unordered treads; on the tail's own side stream the
+  // order of the launches is the order of the work
+  if (on_main) { const int rcj = side_join(c); if (rcj) return rcj; }
   if (!c->n_treads_dev) { set_error("no strl_extract_device call on this context"); return STRL_ERR_ARG; }
   if (c->pair_ordered) return STRL_OK;
-  hipStream_t st = c->stream;
+  hipStream_t st = on_main ? c->stream : on_stream;
   const uint32_t ecap = c->tread_cap;
   uint64_t *ok = nullptr;
   uint32_t *ov = nullptr;

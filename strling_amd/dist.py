@@ -160,14 +160,28 @@ class DeviceClusterExchange:
         pad = torch.tensor([int(n_treads_hint * 1.25) + 4096], dtype=torch.int64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
         dist.all_reduce(pad, op=dist.ReduceOp.MAX, group=group)          # ranks hold different samples: pad to the largest
         self.pad = int(pad.item())
-        self.t_local = torch.zeros(self.pad * 32, dtype=torch.uint8, device=dev)
-        self.t_all = torch.zeros(world * self.pad * 32, dtype=torch.uint8, device=dev)
-        self.c_all = torch.zeros(world, dtype=torch.int32, device=dev)
-        self.stream = torch.cuda.ExternalStream(ctx.stream)                # the context's own stream: kernels and collectives in order
+        # One set of exchange buffers per stream the context runs a batch's tail on (an overlapped extract alternates between
+        # side streams; the buffers of a step must outlive the asynchronous clustering that reads them).
+        self._sets = {}
+        self._use(ctx.stream)
+
+    def _new_set(self, handle):
+        import torch
+        st = dict(t_local=torch.zeros(self.pad * 32, dtype=torch.uint8, device=self.dev),
+                  t_all=torch.zeros(self.world * self.pad * 32, dtype=torch.uint8, device=self.dev),
+                  c_all=torch.zeros(self.world, dtype=torch.int32, device=self.dev),
+                  stream=torch.cuda.ExternalStream(handle))                 # the context's own stream: kernels and collectives in order
+        self._sets[handle] = st
+        return st
+
+    def _use(self, handle):
+        st = self._sets.get(handle) or self._new_set(handle)
+        self.t_local, self.t_all, self.c_all, self.stream = st["t_local"], st["t_all"], st["c_all"], st["stream"]
 
     def gather(self):
         import torch
-        ptr, cap, cnt = self.ctx.treads_device()
+        ptr, cap, cnt = self.ctx.treads_device()                             # (orders the treads on the tail's stream)
+        self._use(self.ctx.tail_stream() or self.ctx.stream)
         src = torch.as_tensor(_DevArray(ptr, cap * 32), device=self.dev)
         c_local = torch.as_tensor(_DevArray(cnt, 4), device=self.dev).view(torch.int32)
         with torch.cuda.stream(self.stream):

@@ -168,7 +168,31 @@ def _device_exchange_worker(rank, world, port, q):
         # the asynchronous form (what bench.py times) leaves the same share on the device
         ex.step(len(rec.targets), window, 3, mcd, 22, fetch=False)
         ctx.sync()
-        q.put((rank, bool(ok), len(rows_got), len(rows_exp)))
+        # ... and on DEVICE-RESIDENT input, where the pair logic, the .bin-order sort, the gather and the clustering of a batch
+        # all run on a side stream of the context while the next batch's scorer runs on the main stream: two batches back
+        # to back, my share of each collected afterwards, against the synchronous share
+        share_b, share_u, _ = ex.step(len(rec.targets), window, 3, mcd, 22, fetch=True)
+
+        def up(a):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        d = {k: up(getattr(soa, k)) for k in ("tid", "pos", "end", "seq_off", "l_seq", "clip_l", "clip_r", "mapq", "cig", "seq4")}
+        drows, dqh = up(rows.view(np.uint8)), up(qh)
+        cs = api.CReadSoa(soa.n, d["tid"].data_ptr(), d["pos"].data_ptr(), d["end"].data_ptr(), d["seq_off"].data_ptr(), d["l_seq"].data_ptr(),
+                          d["clip_l"].data_ptr(), d["clip_r"].data_ptr(), d["mapq"].data_ptr(), d["cig"].data_ptr(), d["seq4"].data_ptr(),
+                          d["seq4"].numel(), soa.max_l_seq, api.MEM_DEVICE)
+        cp = api.CPairSoa(drows.data_ptr(), dqh.data_ptr())
+        torch.cuda.synchronize()
+        n_tail = int((rec.tid < 0).sum())
+        side_ok = True
+        for _ in range(3):
+            ctx.extract_device(cs, cp, n_tail)
+            side_ok = side_ok and ctx.tail_stream() != ctx.stream          # the tail of this batch runs on a side stream
+            ex.step(len(rec.targets), window, 3, mcd, 22, fetch=False)
+            ctx.extract_device(cs, cp, n_tail)                            # the next batch's scorer overlaps the exchange
+            b2, u2, _ = ctx.cluster_collect()
+            side_ok = side_ok and np.array_equal(b2, share_b) and np.array_equal(u2, share_u)
+        ctx.sync()
+        q.put((rank, bool(ok and side_ok), len(rows_got), len(rows_exp)))
     finally:
         dist.destroy_process_group()
 
