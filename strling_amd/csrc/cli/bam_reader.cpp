@@ -302,6 +302,10 @@ struct DecodeClock {   // STRL_DECODE_TIMING=1: where the reader's time goes, pr
 BamStream::~BamStream() { close(); }
 void BamStream::close() {
   if (g_clk.on && map_) fprintf(stderr, "[strling] decode seconds: walk+carry %.3f inflate %.3f record scan %.3f parse %.3f\n", g_clk.walk, g_clk.inflate, g_clk.scan, g_clk.parse);
+  { std::lock_guard<std::mutex> lk(w_mu_); w_stop_ = true; }
+  w_cv_.notify_all();
+  if (walker_.joinable()) walker_.join();
+  w_stop_ = false; w_state_ = 0; wblks_.clear(); w_taken_ = 0; w_err_.clear();
   if (map_) munmap(const_cast<uint8_t *>(map_), map_len_);
   map_ = nullptr; map_len_ = 0;
   delete pool_;
@@ -330,6 +334,60 @@ bool BamStream::open(const std::string &path, int threads, std::string &err) {
   map_ = static_cast<const uint8_t *>(m);
   if (map_len_) madvise(const_cast<uint8_t *>(map_), map_len_, MADV_SEQUENTIAL);
   pool_ = new ThreadPool(threads);
+  w_end_ = cpos_;
+  walker_ = std::thread([this] {
+    size_t pos = w_end_;
+    std::vector<WBlk> local;
+    int state = 0;
+    std::string werr;
+    auto publish = [&]() -> bool {      // hand over what was found; false = asked to stop
+      std::unique_lock<std::mutex> lk(w_mu_);
+      wblks_.insert(wblks_.end(), local.begin(), local.end());
+      local.clear();
+      w_end_ = pos; w_state_ = state; w_err_ = werr;
+      w_cv_.notify_all();
+      // stay at most ~64 Ki blocks (about a gigabyte of BAM) ahead of the decoder
+      w_cv_.wait(lk, [&] { return w_stop_ || state != 0 || wblks_.size() - w_taken_ < 65536; });
+      return !w_stop_;
+    };
+#ifndef MADV_POPULATE_READ
+#define MADV_POPULATE_READ 22
+#endif
+    size_t mapped = (pos / 4096) * 4096;
+    while (state == 0) {
+      if (pos >= map_len_) { state = 1; break; }
+      if (pos + ((size_t)16 << 20) > mapped && mapped < map_len_) {
+        // Map the file ahead of the walk in 64 MB pieces with ONE call each: otherwise every inflate thread takes page
+        // faults on the shared address space (a quarter of a million for a 1 GB file) and the threads serialise in the kernel.
+        const size_t len = std::min<size_t>((size_t)64 << 20, map_len_ - mapped);
+        if (madvise(const_cast<uint8_t *>(map_) + mapped, len, MADV_POPULATE_READ) != 0) (void)madvise(const_cast<uint8_t *>(map_) + mapped, len, MADV_WILLNEED);
+        mapped += len;
+      }
+      if (pos + 18 > map_len_) { state = 2; werr = "truncated BGZF header"; break; }
+      const uint8_t *h = map_ + pos;
+      if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { state = 2; werr = "not a BGZF block"; break; }
+      const uint32_t xlen = h[10] | (h[11] << 8);
+      if (pos + 12 + xlen > map_len_) { state = 2; werr = "truncated BGZF header"; break; }
+      uint32_t bsize = 0;
+      bool bad_extra = false;
+      for (uint32_t o = 0; o + 4 <= xlen;) {
+        const uint8_t *x = h + 12 + o;
+        const uint32_t sl = x[2] | (x[3] << 8);
+        if (o + 4 + sl > xlen) { bad_extra = true; break; }
+        if (x[0] == 'B' && x[1] == 'C' && sl == 2) bsize = (x[4] | (x[5] << 8)) + 1u;
+        o += 4 + sl;
+      }
+      if (bad_extra) { state = 2; werr = "malformed BGZF extra field"; break; }
+      if (!bsize || bsize < 12 + xlen + 8) { state = 2; werr = "BGZF block without BC field"; break; }
+      if (pos + bsize > map_len_) { state = 2; werr = "truncated BGZF block"; break; }
+      const uint8_t *f = h + bsize - 4;
+      const uint32_t isz = f[0] | (f[1] << 8) | (f[2] << 16) | ((uint32_t)f[3] << 24);
+      pos += bsize;
+      if (isz) local.push_back(WBlk{(size_t)(h + 12 + xlen - map_), bsize - 12 - xlen - 8, isz, pos});
+      if (local.size() >= 512 && !publish()) return;
+    }
+    (void)publish();
+  });
   eof_ = false; rec_next_ = 0; recs_.clear(); u_.clear(); prev_.clear();
   return true;
 }
@@ -350,39 +408,30 @@ bool BamStream::load_chunk(std::string &err) {
     skip_ = 0;
   }
   size_t total = carry;
-  const size_t chunk_c0 = cpos_;
-  while (cpos_ < map_len_ && blks.size() < max_blocks && total < max_bytes) {
-    if (cpos_ + 18 > map_len_) { err = "truncated BGZF header"; return false; }
-    const uint8_t *h = map_ + cpos_;
-    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF block"; return false; }
-    const uint32_t xlen = h[10] | (h[11] << 8);
-    if (cpos_ + 12 + xlen > map_len_) { err = "truncated BGZF header"; return false; }
-    uint32_t bsize = 0;
-    for (uint32_t o = 0; o + 4 <= xlen;) {
-      const uint8_t *x = h + 12 + o;
-      const uint32_t sl = x[2] | (x[3] << 8);
-      if (o + 4 + sl > xlen) { err = "malformed BGZF extra field"; return false; }
-      if (x[0] == 'B' && x[1] == 'C' && sl == 2) bsize = (x[4] | (x[5] << 8)) + 1u;
-      o += 4 + sl;
-    }
-    if (!bsize || bsize < 12 + xlen + 8) { err = "BGZF block without BC field"; return false; }
-    if (cpos_ + bsize > map_len_) { err = "truncated BGZF block"; return false; }
-    const uint8_t *f = h + bsize - 4;
-    const uint32_t isz = f[0] | (f[1] << 8) | (f[2] << 16) | ((uint32_t)f[3] << 24);
-    if (isz) { blks.push_back(Blk{h + 12 + xlen, bsize - 12 - xlen - 8, isz, total}); total += isz; }
-    cpos_ += bsize;
-  }
-  if (cpos_ >= map_len_) eof_ = true;
   {
-    // Fault the superchunk's part of the file mapping in with ONE call: otherwise every inflate thread takes page faults on
-    // the shared address space (a quarter of a million for a 1 GB file) and the threads serialise in the kernel.
-    const size_t pg = 4096, a0 = (chunk_c0 / pg) * pg;
-#ifndef MADV_POPULATE_READ
-#define MADV_POPULATE_READ 22
-#endif
-    if (madvise(const_cast<uint8_t *>(map_) + a0, cpos_ - a0, MADV_POPULATE_READ) != 0)
-      (void)madvise(const_cast<uint8_t *>(map_) + a0, cpos_ - a0, MADV_WILLNEED);
+    // block descriptors from the walker thread: as many as this superchunk takes, waiting only if the walker is behind
+    std::unique_lock<std::mutex> lk(w_mu_);
+    for (;;) {
+      while (w_taken_ < wblks_.size() && blks.size() < max_blocks && total < max_bytes) {
+        const WBlk &w = wblks_[w_taken_++];
+        blks.push_back(Blk{map_ + w.c_off, w.clen, w.isize, total});
+        total += w.isize;
+        cpos_ = w.next;
+      }
+      if (blks.size() >= max_blocks || total >= max_bytes) break;
+      if (w_state_ == 2) {
+        // blocks before the damaged one are decoded first, like the sequential reader would; the error comes with the next call
+        if (blks.empty()) { err = w_err_; return false; }
+        break;
+      }
+      if (w_state_ == 1) { cpos_ = map_len_; break; }
+      w_cv_.wait(lk);
+    }
+    if (w_taken_ > 32768) { wblks_.erase(wblks_.begin(), wblks_.begin() + (long)w_taken_); w_taken_ = 0; }
+    if (w_state_ == 1 && w_taken_ == wblks_.size()) cpos_ = map_len_;
   }
+  w_cv_.notify_all();
+  if (cpos_ >= map_len_) eof_ = true;
   const size_t u_cap_before = u_.capacity();
   u_.resize(total);
   if (u_.capacity() != u_cap_before) (void)madvise(u_.data(), u_.capacity(), MADV_HUGEPAGE);   // fewer, larger first-touch faults

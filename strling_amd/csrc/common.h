@@ -97,7 +97,7 @@ struct strl_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   // Side stream: an asynchronous strl_cluster_resident (results stay on the device) runs here, so that the clustering of
-  // one batch -- 22 small, latency-bound launches -- overlaps the VALU-bound scorer of the next batch.  Whatever touches
+  // one batch -- 20 small, latency-bound launches -- overlaps the VALU-bound scorer of the next batch.  Whatever touches
   // the treads or the cluster state afterwards calls side_join() first.
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_main_done = nullptr, ev_side_done = nullptr;

@@ -1,13 +1,15 @@
 // score.hip -- HIP kernels + C-ABI entry points for the extract-side hot path (gfx950).
 //
-//  classify_kernel : one read per lane, streams the 13 B/read of coordinates + cigar class,
-//                    evaluates the skip predicate of extract.nim:30-34 against the genome STR
-//                    intervals (binary search + prefix-max of stops), writes the "skipped"
-//                    result word or appends the read to the scoring queue (one atomic per wave).
-//                    HBM-bound.
+//  classify_kernel : eight reads per lane and iteration, a wave owns a contiguous range of reads; streams the
+//                    13 B/read of coordinates + cigar class, evaluates the skip predicate of
+//                    extract.nim:30-34 against the genome STR intervals (a wave-level merge join against a
+//                    window of {start, running max stop} entries; bin directory + short scan for reads
+//                    outside it), writes the "skipped" result word or stages the read for the scoring
+//                    queue (one queue atomic per 512 staged reads).  HBM-bound.
 //  score_kernel<0> : one queued read per lane -> utils.get_repeat on the whole read
 //                    (score_core.h), writes the packed result, queues the soft-clipped ends
-//                    add_soft (extract.nim:93-106) would look at.  Integer-ALU/LDS bound.
+//                    add_soft (extract.nim:93-106) would look at.  Bound by integer VALU issue (0.75-0.87 of
+//                    all issue slots, profiles/r02).
 //  score_kernel<1> : one queued soft-clipped end per lane, scored once, evaluated against both
 //                    lowered thresholds (extract.nim:207-211 and :241-244).
 #include <stdarg.h>
