@@ -225,9 +225,13 @@ int strl_pairer_result(strl_pairer *pairer, const strl_tread **treads, uint64_t 
 
 /* ---- the extract hot loop on the device, end to end (replaces extract.nim:308-329 for one batch that is the whole input):
  * skip predicate + scorer + soft-clip scan (strl_score_reads) and the pair logic (Cache.add with to_tread, add_soft,
- * adjust_by, unplaced_pair; the second visit of the last n_tail records, extract.nim:326-329), all as kernels on the context
- * stream.  Asynchronous when soa->mem == STRL_MEM_DEVICE: nothing is copied to the host, the treads stay resident in the
+ * adjust_by, unplaced_pair; the second visit of the last n_tail records, extract.nim:326-329), all as kernels on the context's
+ * streams.  Asynchronous when soa->mem == STRL_MEM_DEVICE: nothing is copied to the host, the treads stay resident in the
  * context in the order of the reference's .bin file (qname_id = record index) for strl_treads_fetch / strl_cluster_resident.
+ * Consecutive calls on device-resident input overlap: the pair logic of a batch runs on a side stream of the context while
+ * the scorer of the next call's batch runs on the main stream (the context keeps two sets of the buffers involved); every
+ * entry point that reads the results waits for the side streams first, so the caller sees the order of its calls.  The
+ * input arrays of a call must stay valid and unchanged until a later synchronising call (strl_treads_fetch, strl_ctx_sync).
  * item_cap bounds the records that take part in the join (reads of qname groups with a repeat + their soft-clip records),
  * tread_cap the treads; 0 = defaults from n.  Exceeding either is reported by strl_treads_fetch (STRL_ERR_CAPACITY).
  * Qname groups are keyed by the 64-bit hash alone (two different qnames with equal hashes would be treated as one group). */
