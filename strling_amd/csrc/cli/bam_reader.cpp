@@ -304,12 +304,16 @@ void BamStream::close() {
   if (g_clk.on && map_) fprintf(stderr, "[strling] decode seconds: walk+carry %.3f inflate %.3f record scan %.3f parse %.3f\n", g_clk.walk, g_clk.inflate, g_clk.scan, g_clk.parse);
   { std::lock_guard<std::mutex> lk(w_mu_); w_stop_ = true; }
   w_cv_.notify_all();
+  if (loading_ && load_.valid()) (void)load_.get();      // a load in flight sees w_stop_ and returns
+  loading_ = false;
   if (walker_.joinable()) walker_.join();
   w_stop_ = false; w_state_ = 0; wblks_.clear(); w_taken_ = 0; w_err_.clear();
   if (map_) munmap(const_cast<uint8_t *>(map_), map_len_);
   map_ = nullptr; map_len_ = 0;
   delete pool_;
   pool_ = nullptr;
+  delete pool2_;
+  pool2_ = nullptr;
 }
 
 bool BamStream::open(const std::string &path, int threads, std::string &err) {
@@ -334,6 +338,7 @@ bool BamStream::open(const std::string &path, int threads, std::string &err) {
   map_ = static_cast<const uint8_t *>(m);
   if (map_len_) madvise(const_cast<uint8_t *>(map_), map_len_, MADV_SEQUENTIAL);
   pool_ = new ThreadPool(threads);
+  pool2_ = new ThreadPool(std::max(1, threads / 2));
   w_end_ = cpos_;
   walker_ = std::thread([this] {
     size_t pos = w_end_;
@@ -388,7 +393,8 @@ bool BamStream::open(const std::string &path, int threads, std::string &err) {
     }
     (void)publish();
   });
-  eof_ = false; rec_next_ = 0; recs_.clear(); u_.clear(); prev_.clear();
+  eof_ = false; rec_next_ = 0; recs_.clear(); u_.clear(); prev_.clear(); have_prev_ = false;
+  cu_.clear(); crecs_.clear(); ceof_ = false; loading_ = false;
   return true;
 }
 
@@ -401,10 +407,8 @@ bool BamStream::load_chunk(std::string &err) {
   const double t0 = DecodeClock::now();
   // bytes behind the last complete record of the previous superchunk
   size_t carry = 0;
-  if (!u_.empty()) {
-    const size_t done = recs_.empty() ? skip_ : (size_t)(recs_.back().off + 4 + [&] { uint32_t bs; memcpy(&bs, u_.data() + recs_.back().off, 4); return bs; }());
-    carry = u_.size() - done;
-    prev_.assign(u_.begin() + (long)done, u_.end());
+  if (have_prev_) {                  // stashed at the end of the previous load (u_ itself has gone to the parser since)
+    carry = prev_.size();
     skip_ = 0;
   }
   size_t total = carry;
@@ -425,6 +429,7 @@ bool BamStream::load_chunk(std::string &err) {
         break;
       }
       if (w_state_ == 1) { cpos_ = map_len_; break; }
+      if (w_stop_) { err = "reader closed"; return false; }
       w_cv_.wait(lk);
     }
     if (w_taken_ > 32768) { wblks_.erase(wblks_.begin(), wblks_.begin() + (long)w_taken_); w_taken_ = 0; }
@@ -561,7 +566,6 @@ bool BamStream::load_chunk(std::string &err) {
   }
   // record table of the superchunk: the groups' lists in order, minus a last record that is not complete yet
   recs_.clear();
-  rec_next_ = 0;
   {
     std::vector<size_t> at(2 * G + 1, 0);
     for (size_t g = 0; g < G; ++g) { at[2 * g + 1] = at[2 * g] + groups[g].recs.size(); at[2 * g + 2] = at[2 * g + 1] + groups[g].junction.size(); }
@@ -576,6 +580,8 @@ bool BamStream::load_chunk(std::string &err) {
   if (!recs_.empty() && rec_end(recs_.back()) > n) recs_.pop_back();   // only the last one can reach past the superchunk
   const size_t p = recs_.empty() ? skip_ : rec_end(recs_.back());      // what lies behind it is carried into the next superchunk
   if (eof_ && p != n) { err = "truncated BAM record at end of file"; return false; }
+  prev_.assign(u_.begin() + (long)p, u_.end());     // what the next superchunk starts with
+  have_prev_ = true;
   const double t3 = DecodeClock::now();
   g_clk.walk += t1 - t0; g_clk.inflate += t2 - t1; g_clk.scan += t3 - t2;
   return true;
@@ -584,14 +590,23 @@ bool BamStream::load_chunk(std::string &err) {
 int64_t BamStream::read(RecordBatch &b, int64_t max_records, std::string &err) {
   int64_t n = 0;
   while (n < max_records) {
-    if (rec_next_ == recs_.size()) {
-      if (eof_) break;
-      if (!load_chunk(err)) return -1;
-      if (recs_.empty()) { if (eof_) break; continue; }
+    if (rec_next_ == crecs_.size()) {
+      if (ceof_) break;
+      // the next superchunk: loaded in the background while the previous one was parsed
+      if (!loading_) { loading_ = true; load_ = std::async(std::launch::async, [this] { load_err_.clear(); return load_chunk(load_err_); }); }
+      const bool ok = load_.get();
+      loading_ = false;
+      if (!ok) { err = load_err_; return -1; }
+      cu_.swap(u_);
+      crecs_.swap(recs_);
+      ceof_ = eof_;
+      rec_next_ = 0;
+      if (!ceof_) { loading_ = true; load_ = std::async(std::launch::async, [this] { load_err_.clear(); return load_chunk(load_err_); }); }
+      if (crecs_.empty()) { if (ceof_) break; continue; }
     }
-    const size_t m = (size_t)std::min<int64_t>(max_records - n, (int64_t)(recs_.size() - rec_next_));
+    const size_t m = (size_t)std::min<int64_t>(max_records - n, (int64_t)(crecs_.size() - rec_next_));
     const double tp0 = DecodeClock::now();
-    const RecMeta *rm = recs_.data() + rec_next_;
+    const RecMeta *rm = crecs_.data() + rec_next_;
     // output offsets of this part
     const size_t base = b.tid.size();
     rvec<uint32_t> cig_at(m + 1);
@@ -601,9 +616,9 @@ int64_t BamStream::read(RecordBatch &b, int64_t max_records, std::string &err) {
       // output offsets of every record: sums per part in parallel, a scan over the parts, offsets per part in parallel.
       // (SEQ is padded to 16 bytes per record, so a part's SEQ size does not depend on where it starts once the start is
       // 16-byte aligned, which the first record's padding guarantees.)
-      const size_t P = std::min<size_t>(std::max<size_t>(m / 8192, 1), (size_t)pool_->size() * 4);
+      const size_t P = std::min<size_t>(std::max<size_t>(m / 8192, 1), (size_t)pool2_->size() * 4);
       std::vector<uint64_t> pc(P + 1, 0), pq(P + 1, 0), ps(P + 1, 0);
-      pool_->parallel_for(P, [&](size_t part) {
+      pool2_->parallel_for(P, [&](size_t part) {
         const size_t i0 = m * part / P, i1 = m * (part + 1) / P;
         uint64_t c = 0, q = 0, sq = 0;
         for (size_t i = i0; i < i1; ++i) {
@@ -615,7 +630,7 @@ int64_t BamStream::read(RecordBatch &b, int64_t max_records, std::string &err) {
       });
       pc[0] = b.cigar_off.back(); pq[0] = b.qname_off.back(); ps[0] = (b.seq4.size() + 15) & ~(size_t)15;
       for (size_t k = 0; k < P; ++k) { pc[k + 1] += pc[k]; pq[k + 1] += pq[k]; ps[k + 1] += ps[k]; }
-      pool_->parallel_for(P, [&](size_t part) {
+      pool2_->parallel_for(P, [&](size_t part) {
         const size_t i0 = m * part / P, i1 = m * (part + 1) / P;
         uint64_t c = pc[part], q = pq[part], sq = ps[part];
         for (size_t i = i0; i < i1; ++i) {
@@ -633,11 +648,11 @@ int64_t BamStream::read(RecordBatch &b, int64_t max_records, std::string &err) {
     b.l_seq.resize(base + m); b.flag.resize(base + m); b.mapq.resize(base + m); b.seq_off.resize(base + m);
     b.cigar_off.resize(base + m + 1); b.qname_off.resize(base + m + 1);
     b.cigar.resize(cig_at[m]); b.qnames.resize(qn_at[m]); b.seq4.resize(so);
-    const size_t parts = std::min<size_t>(m, (size_t)pool_->size() * 4);
-    pool_->parallel_for(parts, [&](size_t part) {
+    const size_t parts = std::min<size_t>(m, (size_t)pool2_->size() * 4);
+    pool2_->parallel_for(parts, [&](size_t part) {
       const size_t i0 = m * part / parts, i1 = m * (part + 1) / parts;
       for (size_t i = i0; i < i1; ++i) {
-        const uint8_t *p = u_.data() + rm[i].off + 4;
+        const uint8_t *p = cu_.data() + rm[i].off + 4;
         const size_t o = base + i;
         memcpy(&b.tid[o], p, 4); memcpy(&b.pos[o], p + 4, 4);
         b.mapq[o] = p[9];

@@ -12,6 +12,7 @@
 #include <utility>
 #include <condition_variable>
 #include <mutex>
+#include <future>
 #include <atomic>
 #include <string>
 #include <thread>
@@ -118,11 +119,21 @@ class BamStream {
   bool load_chunk(std::string &err);
   const uint8_t *map_ = nullptr;
   size_t map_len_ = 0, cpos_ = 0;
-  rvec<uint8_t> u_, prev_;            // decompressed superchunk (leftover of the previous one in front)
-  std::vector<RecMeta> recs_;         // complete records of the current superchunk
-  size_t rec_next_ = 0, skip_ = 0;
-  bool eof_ = false;
+  // The superchunk being LOADED (inflate + record scan, load_chunk, on a thread of its own) ...
+  rvec<uint8_t> u_, prev_;            // decompressed superchunk (leftover of the previous one in front); prev_ = that leftover
+  std::vector<RecMeta> recs_;         // complete records of that superchunk
+  size_t skip_ = 0;
+  bool eof_ = false, have_prev_ = false;
   ThreadPool *pool_ = nullptr;
+  // ... and the one being PARSED into batches by read(): the two run side by side (inflate is compute-bound, the parse is
+  // bound by memory traffic), swapping buffers when read() runs out of records.
+  rvec<uint8_t> cu_;
+  std::vector<RecMeta> crecs_;
+  size_t rec_next_ = 0;
+  bool ceof_ = false, loading_ = false;
+  ThreadPool *pool2_ = nullptr;       // the parse's own pool
+  std::future<bool> load_;
+  std::string load_err_;
   std::string text_;
   std::vector<BamTarget> targets_;
   // The BGZF header walk (18 bytes of every ~16 KB block: two or three dependent cache misses per block, 0.1 s per GB of

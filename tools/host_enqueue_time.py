@@ -26,7 +26,16 @@ def step():
     ctx.cluster_resident(n_tid, window, min_support=5, max_clip_dist=mcd, pos_bits=pos_bits, fetch=False)
 for _ in range(3): step()
 ctx.sync()
-for K in (1, 2, 5, 20):
+MODE = os.environ.get("STEP_MODE", "full")     # full | extract (no clustering) : what each part costs in the overlapped pipeline
+if MODE == "extract":
+    for K in (50, 200):
+        t0 = time.perf_counter()
+        for _ in range(K):
+            ctx.extract_device(cs, cp, n_tail, ic, tc)
+        ctx.sync()
+        print("extract only: ms/step %.3f" % ((time.perf_counter() - t0) / K * 1e3))
+    sys.exit(0)
+for K in (1, 2, 5, 20, 200):
     t0 = time.perf_counter()
     ts = []
     for _ in range(K):
