@@ -940,7 +940,7 @@ static int decode_main(int argc, char **argv) {
   if (!rs.open(argv[2], decode_threads(), err)) quit("couldn't open bam");
   RecordBatch b;
   int64_t n = 0;
-  uint64_t sum = 0;
+  uint64_t sum = 0xcbf29ce484222325ull;
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
     b.clear();
@@ -948,7 +948,17 @@ static int decode_main(int argc, char **argv) {
     if (got < 0) quit("[strling] error reading %s: %s", argv[2], err.c_str());
     if (got == 0) break;
     n += got;
-    sum += (uint64_t)b.pos[(size_t)got - 1] + b.seq4[b.seq4.size() / 2];
+    // order-sensitive checksum over every field of every record (FNV-1a over the values, not over the batch layout: the
+    // same file must give the same sum whatever the batch size, thread count, superchunk size or inflate engine)
+    auto mix = [&](uint64_t v) { sum = (sum ^ v) * 0x100000001b3ull; };
+    for (size_t i = 0; i < (size_t)got; ++i) {
+      mix((uint64_t)(uint32_t)b.tid[i]); mix((uint64_t)(uint32_t)b.pos[i]); mix((uint64_t)(uint32_t)b.mtid[i]); mix((uint64_t)(uint32_t)b.mpos[i]);
+      mix((uint64_t)(uint32_t)b.isize[i]); mix(b.flag[i]); mix(b.mapq[i]); mix((uint64_t)(uint32_t)b.l_seq[i]);
+      for (uint32_t c = b.cigar_off[i]; c < b.cigar_off[i + 1]; ++c) mix(b.cigar[c]);
+      const uint8_t *sq = b.seq4.data() + b.seq_off[i];
+      for (size_t k = 0; k < (size_t)(b.l_seq[i] + 1) / 2; ++k) mix(sq[k]);
+      for (uint64_t k = b.qname_off[i]; k < b.qname_off[i + 1]; ++k) mix((uint8_t)b.qnames[(size_t)k]);
+    }
   }
   const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   fprintf(stderr, "[strling] decoded %lld records in %.3f s with %d threads: %.1f reads/s (checksum %llu)\n", (long long)n, s, decode_threads(),

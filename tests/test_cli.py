@@ -330,3 +330,40 @@ def test_malformed_bgzf_blocks_are_rejected(tmp_path):
         for mode in ([], ["stream"]):
             r = _run(["_dump", p] + mode)
             assert r.returncode != 0 and ("BGZF" in r.stderr or "couldn't open" in r.stderr), r.stderr[-300:]
+
+
+def _fnv_records(rec):
+    """the checksum `strling _decode` prints, computed from the batch the BAM was written from: FNV-1a over every field of
+    every record in file order (tid, pos, mtid, mpos, isize, flag, mapq, l_seq, cigar words, SEQ bytes, qname bytes)"""
+    M = (1 << 64) - 1
+    s = 0xcbf29ce484222325
+    P = 0x100000001b3
+    u32 = lambda v: int(v) & 0xffffffff
+    seq4 = rec.seq4
+    qn = bytes(rec.qnames)
+    for i in range(rec.n):
+        vals = [u32(rec.tid[i]), u32(rec.pos[i]), u32(rec.mtid[i]), u32(rec.mpos[i]), u32(rec.isize[i]), int(rec.flag[i]), int(rec.mapq[i]), u32(rec.l_seq[i])]
+        vals += [int(c) for c in rec.cigar[int(rec.cigar_off[i]):int(rec.cigar_off[i + 1])]]
+        o = int(rec.seq_off[i])
+        vals += seq4[o:o + (int(rec.l_seq[i]) + 1) // 2].tolist()
+        vals += list(qn[int(rec.qname_off[i]):int(rec.qname_off[i + 1])])
+        for v in vals:
+            s = ((s ^ v) * P) & M
+    return s
+
+
+def test_stream_reader_is_the_same_for_every_engine_and_shape(tmp_path):
+    """CPU only (`strling _decode` needs no GPU): the multi-threaded reader -- header-walk thread, background superchunk
+    loads, speculative record starts, own DEFLATE decoder or zlib -- delivers exactly the records that were written, in
+    order, whatever the thread count, superchunk size, batch size or inflate engine."""
+    rec, _ = synth.synth_wgs(3000, seed=77, contig_len=300_000, n_contigs=3)
+    bam = str(tmp_path / "d.bam")
+    bamio.write_bam(bam, rec, level=6)
+    want = _fnv_records(rec)
+    for env, batch in (({"STRL_THREADS": "1"}, "1048576"), ({"STRL_THREADS": "4"}, "1000"), ({"STRL_THREADS": "3", "STRL_CHUNK_BLOCKS": "1"}, "777"),
+                       ({"STRL_THREADS": "4", "STRL_CHUNK_BLOCKS": "2", "STRL_INFLATE": "zlib"}, "65536"), ({"STRL_THREADS": "7", "STRL_CHUNK_BLOCKS": "3"}, "5")):
+        r = _run(["_decode", bam, batch], env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        line = [l for l in r.stderr.splitlines() if "decoded" in l][-1]
+        assert f"decoded {rec.n} records" in line, line
+        assert f"(checksum {want})" in line, (env, line)
