@@ -917,6 +917,7 @@ int strl_ctx_set_opts(strl_ctx *c, const strl_opts *o) {
 int strl_ctx_set_genome(strl_ctx *c, const strl_genome_str *g) {
   if (!c) return STRL_ERR_ARG;
   STRL_HIP(hipSetDevice(c->device));
+  STRL_HIP(hipStreamSynchronize(c->stream));     // a skip-predicate pass still in flight reads the tables replaced below
   if (!g || g->n_tid <= 0) {
     // empty table: no chromosome is a key, nothing is skipped.  The kernels still dereference entry 0 of each array for
     // lanes without a candidate read, so the arrays must exist.

@@ -267,8 +267,10 @@ def test_extract_device_and_resident_clustering_match_oracle(ctx, oracle, n_pair
     assert np.array_equal(b, b2) and np.array_equal(u, u2)
 
 
-def test_overlapped_clustering_of_one_batch_and_extract_of_the_next(ctx, oracle):
-    """The pipeline the bench times: batch A's clustering runs asynchronously on the context's side stream while batch B's
+@pytest.mark.parametrize("resident", [False, True])
+def test_overlapped_clustering_of_one_batch_and_extract_of_the_next(ctx, oracle, resident):
+    """(resident: the batches' arrays live on the device, so the pair logic of a batch runs on a side stream as well and the
+    context rotates through its buffer sets.)  The pipeline the bench times: batch A's clustering runs asynchronously on the context's side stream while batch B's
     extract is enqueued; collecting A's rows after B's extract was issued gives A's rows, B's treads are B's, and B's own
     clustering afterwards is B's -- three rounds, alternating batches, against the oracle."""
     batches = []
@@ -281,14 +283,22 @@ def test_overlapped_clustering_of_one_batch_and_extract_of_the_next(ctx, oracle)
         window, mcd = api.frag_median(frag, 0.99), int(0.5 * api.frag_median(frag, 0.5))
         exp = oracle.extract(rec, g, oracle.make_opts(med, 0.8, 40))
         eb, eu = oracle.call_bounds(exp, 1, window, min_support=3, max_clip_dist=mcd)
-        batches.append(dict(rec=rec, g=g, med=med, soa=soa, cp=cp, keep=keep, window=window, mcd=mcd, exp=exp,
+        cs = soa.c_struct()
+        if resident:
+            import torch
+            from helpers import device_batch
+            cs, cp, keep_dev = device_batch(torch, torch.device("cuda", 0), soa, keep[0], keep[1])
+            keep = (keep, keep_dev)
+        batches.append(dict(rec=rec, g=g, med=med, soa=soa, cs=cs, cp=cp, keep=keep, window=window, mcd=mcd, exp=exp,
                             rows=[oracle.bounds_row(x, "c") for x in eb], unpl=[(r, int(k)) for r, k in eu]))
     assert all(len(b["rows"]) > 5 for b in batches) and batches[0]["rows"] != batches[1]["rows"]
 
     def extract(b):
         ctx.set_opts(0.8, 40, b["med"])
         ctx.set_genome(b["g"])
-        ctx.extract_device(b["soa"].c_struct(), b["cp"], int((b["rec"].tid < 0).sum()))
+        ctx.extract_device(b["cs"], b["cp"], int((b["rec"].tid < 0).sum()))
+        if resident:
+            assert ctx.tail_stream() != ctx.stream      # this batch's pair logic runs on a side stream
 
     def cluster_async(b):
         ctx.cluster_resident(len(b["rec"].targets), b["window"], min_support=3, max_clip_dist=b["mcd"], pos_bits=24, fetch=False)
@@ -299,13 +309,25 @@ def test_overlapped_clustering_of_one_batch_and_extract_of_the_next(ctx, oracle)
         assert [(x["repeat"].decode(), int(x["count"])) for x in unpl] == b["unpl"]
 
     extract(batches[0])
-    for r in range(3):
+    for r in range(5):
         cur, nxt = batches[r % 2], batches[(r + 1) % 2]
         cluster_async(cur)              # side stream
         extract(nxt)                    # main stream: scorer of the next batch overlaps; its pair logic waits on the device
         check_rows(cur, ctx.cluster_collect())
         got, _ = ctx.treads_fetch()
         ok, why = treads_equal(got, nxt["exp"])
+        assert ok, why
+    # ... and the way the bench drives it: many steps enqueued back to back without a single synchronisation in between
+    # (buffer sets are reused while earlier steps are still in flight), only the last step's results looked at
+    for rounds in (7, 8):
+        last = None
+        for r in range(rounds):
+            last = batches[r % 2]
+            extract(last)
+            cluster_async(last)
+        check_rows(last, ctx.cluster_collect())
+        got, _ = ctx.treads_fetch()
+        ok, why = treads_equal(got, last["exp"])
         assert ok, why
 
 
