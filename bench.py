@@ -167,6 +167,15 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     gc.enable()
+    # the last timed step's results, collected after the fact, are the synchronous pass' results (same batch every step):
+    # the pipelined steps computed what the un-pipelined one did
+    verified = None
+    if exchange is None and args.steps > 0:
+        b_last, u_last, _ = ctx.cluster_collect()
+        t_last, _ = ctx.treads_fetch()
+        verified = bool(np.array_equal(b_last, bounds) and np.array_equal(u_last, unplaced) and np.array_equal(t_last, treads))
+        if not verified:
+            raise SystemExit("bench.py: the pipelined steps did not reproduce the synchronous pass' treads / bounds")
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -311,6 +320,7 @@ def main():
                        "reads_per_gpu": n, "read_len": L, "unique_reads_per_gpu": n, "tiles": 1, "generate_s": round(t_gen, 1),
                        "skipped_frac": round(st.n_skipped / n, 4), "scored_reads": int(st.n_scored), "soft_items": int(st.n_soft_items),
                        "str_reads_clustered": n_treads, "clusters": int(cst.n_clusters), "bounds": int(len(bounds)),
+                       "last_step_equals_synchronous_pass": verified,
                        "timed_region": "every kernel of the path on HBM-resident records: classify + score + soft-clip scan, the pair logic (Cache.add) on the device, "
                                        "then keys + radix sort + sweep + bounds over the treads the same step produced; consecutive steps are pipelined on the "
                                        "context's streams (side streams run pair logic + clustering of a step while the next step's scorer runs); BAM decode, PCIe, the host-side row order "
