@@ -434,11 +434,13 @@ int strl_call_row(char *buf, int cap, const strl_call *call, const char *chrom);
 void strl_canonical_repeat(const char in[6], char out[6]);
 
 /* ---- BGZF / BAM front end on the device (the reference reads the BAM through htslib on one thread, extract.nim:275,289) ----
- * Inflate n raw DEFLATE streams (the payloads of BGZF blocks: RFC 1951, <= 64 KiB inflated each) on the GPU, one lane per
- * stream.  comp = all compressed bytes, coff/clen = where each stream sits in it, isize = its inflated size (the BGZF
+ * Inflate n raw DEFLATE streams (the payloads of BGZF blocks: RFC 1951, <= 64 KiB inflated each) on the GPU, one wavefront
+ * per stream.  comp = all compressed bytes, coff/clen = where each stream sits in it, isize = its inflated size (the BGZF
  * footer's ISIZE); out receives the streams back to back.  STRL_ERR_FORMAT for invalid data or a size mismatch. */
 int strl_inflate_blocks(strl_ctx *ctx, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen,
                         const uint32_t *isize, uint32_t n_blocks, uint8_t *out, uint64_t out_bytes);
+/* HIP-event time (ms) of the inflate kernel of the last strl_inflate_blocks call (copies excluded). */
+int strl_ctx_inflate_ms(strl_ctx *ctx, double *ms);
 
 /* ---- fragment-length statistics (utils.nim:139-146) ---- */
 int strl_frag_median(const uint32_t frag[4096], double pct);

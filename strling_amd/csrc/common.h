@@ -151,6 +151,7 @@ struct strl_ctx {
   uint64_t x_n = 0, x_soft_cap = 0;
   bool x_open = false, x_mode = false;
   hipEvent_t pev[6] = {};
+  double inflate_ms = 0;           // kernel time of the last strl_inflate_blocks call
   // staging of the pairing arrays for host-memory batches
   strl::DevBuf st_mtid, st_mpos, st_flag, st_qhash;
 };

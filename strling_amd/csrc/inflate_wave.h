@@ -1,0 +1,508 @@
+// inflate_wave.h -- DEFLATE (RFC 1951) decoder of bgzf.hip: ONE WAVEFRONT per BGZF block (extract.nim:275,289 read the BAM
+// through htslib's single-threaded inflate).
+//
+// DEFLATE is serial inside a stream, a BAM is tens of thousands to millions of independent <= 64 KiB streams.  Round 2 gave
+// every LANE a stream: 64 divergent decoders per wave, tables too big for more than one wave per CU -> 6.6 GB/s.  Here a
+// whole wave owns one stream and nothing diverges:
+//   * the symbol loop is WAVE-UNIFORM: bit buffer, positions and table entries live in scalar registers (the compiler keeps
+//     uniform values in SGPRs and runs the shifts/masks on the scalar ALU); the only vector work per symbol is the LDS table
+//     lookup (one broadcast ds_read + v_readfirstlane);
+//   * input: each lane holds one dword of a 256-byte window of the compressed stream (one coalesced load per 256 bytes, the
+//     next window prefetched); the bit buffer is refilled with v_readlane -- no LDS, no scalar-cache traffic;
+//   * literals are collected with v_writelane into one VGPR (lane = output position mod 64) and leave as one coalesced
+//     64-byte store; LZ77 matches are copied by all 64 lanes at once, periodic (distance < length) matches included:
+//     byte k of a match is out[pos - D + k mod D], which only reads bytes written BEFORE the match;
+//   * Huffman tables are built by the 64 lanes together: per-length ranks by ballots, then every lane fills its share of the
+//     direct-lookup tables entry by entry through a canonical decode of the entry's own index (no scattered replication);
+//     10-bit first level for literal/length codes, 8-bit for distances, longer codes fall back to a canonical search.
+//   * there is NOT ONE lane-dependent branch in the kernel: lanes that have nothing to load or store in a step get an
+//     out-of-range offset into a bounds-checked buffer descriptor (the hardware drops the access) or a dummy LDS slot.
+//     This is what keeps the symbol loop scalar: with a divergent `if` anywhere near it LLVM sinks uniform code into the
+//     branch's arms and the uniformity analysis then marks everything behind the join as divergent (VGPRs, exec masks).
+//     The descriptors also bound every global access to the stream's input and the block's output: corrupt data cannot make
+//     the decoder read or write anywhere else.
+// About 7 KB of LDS per wave (5-6 waves per SIMD), no divergence, every global access coalesced.
+//
+// The same source compiles for the host (STRL_EMU: the 64 lanes become loops) purely so that the CPU-only test-suite can
+// run the decoder logic against zlib; the product never runs that build.
+#pragma once
+#include <stdint.h>
+
+#ifdef STRL_EMU
+#include <string.h>
+#define IW_DEV inline
+#define IW_FOR_LANES for (int lane = 0; lane < 64; ++lane)
+#define IW_U(x) (x)
+#define IW_RCP(x) (1.0f / (x))
+#define IW_SYNC() ((void)0)
+#define IW_BALLOT(out, expr)                                          \
+  do {                                                                \
+    uint64_t iw_m_ = 0;                                               \
+    for (int lane = 0; lane < 64; ++lane)                             \
+      if (expr) iw_m_ |= 1ull << lane;                                \
+    (out) = iw_m_;                                                    \
+  } while (0)
+namespace strl {
+template <class T> struct IwLane {
+  T v[64];
+  IW_DEV T &operator[](int l) { return v[l]; }
+  IW_DEV const T &operator[](int l) const { return v[l]; }
+};
+IW_DEV uint32_t iw_readlane(const IwLane<uint32_t> &r, uint32_t k) { return r.v[k]; }
+IW_DEV void iw_writelane(IwLane<uint32_t> &r, uint32_t k, uint32_t val) { r.v[k] = val; }
+IW_DEV uint32_t iw_brev(uint32_t x) {
+  x = (x >> 16) | (x << 16);
+  x = ((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8);
+  x = ((x & 0xf0f0f0f0u) >> 4) | ((x & 0x0f0f0f0fu) << 4);
+  x = ((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2);
+  x = ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1);
+  return x;
+}
+IW_DEV uint32_t iw_popc_below(uint64_t m, int lane) { return (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull)); }
+IW_DEV uint32_t iw_popc(uint64_t m) { return (uint32_t)__builtin_popcountll(m); }
+// bounds-checked view of global memory: loads outside [0, n) give 0, stores outside are dropped
+struct IwBuf { uint8_t *p; uint32_t n; };
+IW_DEV IwBuf iw_make_buf(const void *p, uint64_t n) { return IwBuf{(uint8_t *)p, n > 0x7ffffffcull ? 0x7ffffffcu : (uint32_t)n}; }
+IW_DEV uint32_t iw_ld32(const IwBuf &b, uint32_t off) { uint32_t v = 0; if ((uint64_t)off + 4 <= b.n) memcpy(&v, b.p + off, 4); return v; }
+IW_DEV uint32_t iw_ld8(const IwBuf &b, uint32_t off) { return off < b.n ? b.p[off] : 0u; }
+IW_DEV void iw_st8(const IwBuf &b, uint32_t off, uint32_t v) { if (off < b.n) b.p[off] = (uint8_t)v; }
+}  // namespace strl
+#else
+#include <hip/hip_runtime.h>
+#define IW_DEV __device__ __forceinline__
+#define IW_FOR_LANES for (int lane = (int)threadIdx.x, iw_once_ = 1; iw_once_; iw_once_ = 0)
+#define IW_U(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#define IW_RCP(x) __builtin_amdgcn_rcpf(x)
+#define IW_SYNC()                                              \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     \
+    __builtin_amdgcn_wave_barrier();                           \
+  } while (0)
+#define IW_BALLOT(out, expr)                 \
+  do {                                       \
+    const int lane = (int)threadIdx.x;       \
+    (out) = __ballot(expr);                  \
+  } while (0)
+namespace strl {
+template <class T> struct IwLane {
+  T x;
+  IW_DEV T &operator[](int) { return x; }
+  IW_DEV const T &operator[](int) const { return x; }
+};
+IW_DEV uint32_t iw_readlane(const IwLane<uint32_t> &r, uint32_t k) { return (uint32_t)__builtin_amdgcn_readlane((int)r.x, (int)k); }
+__device__ int iw_llvm_writelane(int, int, int) __asm("llvm.amdgcn.writelane");
+IW_DEV void iw_writelane(IwLane<uint32_t> &r, uint32_t k, uint32_t val) { r.x = (uint32_t)iw_llvm_writelane((int)val, (int)k, (int)r.x); }   // k, val wave-uniform
+IW_DEV uint32_t iw_brev(uint32_t x) { return __builtin_bitreverse32(x); }
+IW_DEV uint32_t iw_popc_below(uint64_t m, int) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+IW_DEV uint32_t iw_popc(uint64_t m) { return (uint32_t)__popcll(m); }
+// bounds-checked view of global memory (raw buffer descriptor, stride 0): the hardware returns 0 for loads outside
+// [0, num_records) and drops stores there
+struct IwBuf { __amdgpu_buffer_rsrc_t r; };
+IW_DEV IwBuf iw_make_buf(const void *p, uint64_t n) {
+  return IwBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, n > 0x7ffffffcull ? 0x7ffffffc : (int)n, 0x00020000)};
+}
+IW_DEV uint32_t iw_ld32(const IwBuf &b, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)off, 0, 0); }
+IW_DEV uint32_t iw_ld8(const IwBuf &b, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b8(b.r, (int)off, 0, 0); }
+IW_DEV void iw_st8(const IwBuf &b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, b.r, (int)off, 0, 0); }
+}  // namespace strl
+#endif
+
+namespace strl {
+
+constexpr int IW_ERR_DATA = 1, IW_ERR_SIZE = 2;
+constexpr uint32_t IW_OOB = 0x80000000u;   // an offset no descriptor of this file covers (num_records < 2^31)
+constexpr int IW_LIT_ROOT = 10, IW_DIST_ROOT = 8, IW_CL_ROOT = 7;
+
+// Table entry (u32): [3:0] code length (0 = "not in the first-level table": canonical search / invalid), [7:4] extra bits,
+// [9:8] kind (0 literal / plain value, 1 base value of a length or distance code, 2 end of block), [31:16] value.
+constexpr uint32_t IW_KIND_BASE = 1u << 8, IW_KIND_EOB = 2u << 8;
+
+// LDS of one wave.  The code-length code's tables are only alive while the literal/length and distance code lengths are
+// being read, before the distance table is built: they share its storage.
+struct IwLds {
+  uint32_t lit_tab[1 << IW_LIT_ROOT];
+  union {
+    uint32_t dist_tab[1 << IW_DIST_ROOT];
+    struct {
+      uint32_t cl_tab[1 << IW_CL_ROOT];
+      uint32_t cl_sorted[32];                          // 19 symbols; [31] = the dummy slot of idle lanes
+      uint32_t cl_limit[16], cl_delta[16], cl_offs[16];
+    } cl;
+  };
+  uint32_t ll_sorted[288 + 1];                         // [288] / [32]: dummy slots of idle lanes
+  uint32_t d_sorted[32 + 1];
+  uint32_t ll_limit[16], ll_delta[16], ll_offs[16];   // per code length 1..15: see iw_build
+  uint32_t d_limit[16], d_delta[16], d_offs[16];
+  uint8_t lens[320 + 4];                               // code lengths: literal/length symbols, then distance symbols; [320] dummy
+};
+
+// RFC 1951 3.2.5 in closed form.
+//   length symbol 257 + c: c < 8: 3 + c; c == 28: 258; else e = (c - 4) / 4 extra bits, base ((4 + c % 4) << e) + 3
+//   distance symbol d: d < 4: 1 + d; else e = (d - 2) / 2 extra bits, base ((2 + d % 2) << e) + 1
+enum { IW_CODES = 0, IW_LENS = 1, IW_DISTS = 2 };
+template <int KIND> IW_DEV uint32_t iw_entry_of(uint32_t s) {
+  if (KIND == IW_CODES) return s << 16;
+  if (KIND == IW_LENS) {
+    if (s < 256u) return s << 16;
+    if (s == 256u) return IW_KIND_EOB;
+    const uint32_t c = s - 257u;
+    if (c > 28u) return IW_KIND_BASE;                                  // 286, 287: take part in the code, never valid (length 0)
+    if (c < 8u) return ((3u + c) << 16) | IW_KIND_BASE;
+    if (c == 28u) return (258u << 16) | IW_KIND_BASE;
+    const uint32_t e = (c - 4u) >> 2;
+    return ((((4u + (c & 3u)) << e) + 3u) << 16) | IW_KIND_BASE | (e << 4);
+  }
+  if (s > 29u) return IW_KIND_BASE;                                    // 30, 31: never valid (distance 0)
+  if (s < 4u) return ((1u + s) << 16) | IW_KIND_BASE;
+  const uint32_t e = (s - 2u) >> 1;
+  return ((((2u + (s & 1u)) << e) + 1u) << 16) | IW_KIND_BASE | (e << 4);
+}
+
+// order of the code-length code lengths (RFC 1951 3.2.7), 5 bits each: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+IW_DEV uint32_t iw_cl_order(uint32_t i) {
+  const uint64_t lo = 16ull | (17ull << 5) | (18ull << 10) | (0ull << 15) | (8ull << 20) | (7ull << 25) | (9ull << 30) | (6ull << 35) |
+                      (10ull << 40) | (5ull << 45) | (11ull << 50) | (4ull << 55);
+  const uint64_t hi = 12ull | (3ull << 5) | (13ull << 10) | (2ull << 15) | (14ull << 20) | (1ull << 25) | (15ull << 30);
+  return (uint32_t)((i < 12u ? lo >> (5u * i) : hi >> (5u * (i - 12u))) & 31u);
+}
+
+// Build the decoding tables of one Huffman code from its code lengths (lane s + 64 j holds the length of symbol s + 64 j in
+// len[j]; 0 = unused).  Canonical codes (RFC 1951 3.2.2): codes of one length are consecutive, in symbol order, shorter
+// codes first.  With v16 = the next 16 stream bits read most-significant-bit first,
+//   limit[l] = (first code of length l + number of codes of length l) << (16 - l): v16 < limit[l] <=> the code has <= l bits
+//   delta[l] = (index of the first length-l symbol in `sorted`) - (first code of length l)
+//   sorted[] = the symbols ordered by (length, symbol), already as table entries without their length
+// so a code of length l decodes to sorted[(v16 >> (16 - l)) + delta[l]].  tab[] is the direct table for the first ROOT bits
+// (stream order = least significant bit first): every lane fills entries lane, lane + 64, ... by decoding the entry's own
+// index; longer codes leave 0 there and go through iw_slow.  `dummy` = a slot of sorted[] behind the symbols.
+// Returns 0 for an over-subscribed code, or an incomplete one where zlib refuses it (inftrees.c: incomplete codes are
+// only allowed for a literal/length or distance code consisting of ONE code of length 1; no codes at all is allowed too).
+template <int ROUNDS, int ROOT, int KIND>
+IW_DEV uint32_t iw_build(const IwLane<uint32_t> (&len)[ROUNDS], uint32_t *tab, uint32_t *sorted, uint32_t dummy, uint32_t *limit, uint32_t *delta,
+                         uint32_t *offs) {
+  IwLane<uint32_t> rank[ROUNDS];
+  IW_FOR_LANES {
+#pragma unroll
+    for (int j = 0; j < ROUNDS; ++j) rank[j][lane] = 0;
+  }
+  uint32_t cnt[16];
+#pragma unroll
+  for (int l = 1; l <= 15; ++l) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < ROUNDS; ++j) {
+      uint64_t m;
+      IW_BALLOT(m, len[j][lane] == (uint32_t)l);
+      IW_FOR_LANES {
+        const uint32_t r = c + iw_popc_below(m, lane);
+        rank[j][lane] = len[j][lane] == (uint32_t)l ? r : rank[j][lane];
+      }
+      c += iw_popc(m);
+    }
+    cnt[l] = c;
+  }
+  uint32_t code = 0, off = 0, max_len = 0, over = 0;
+#pragma unroll
+  for (int l = 1; l <= 15; ++l) {
+    const uint32_t first = code, end = first + cnt[l];
+    over |= (uint32_t)(end > (1u << l));
+    max_len = cnt[l] ? (uint32_t)l : max_len;
+    const uint32_t lim = end << (16 - l), del = off - first, o = off;
+    limit[l] = lim; delta[l] = del; offs[l] = o;                     // every lane stores the same value: no branch
+    code = end << 1;
+    off += cnt[l];
+  }
+  const uint32_t complete = (uint32_t)(code == (1u << 16));           // after l = 15: code = (first + cnt) << 1
+  const uint32_t bad = over | (uint32_t)(!complete && off != 0u && (KIND == IW_CODES || max_len != 1u));
+  IW_SYNC();
+  IW_FOR_LANES {
+#pragma unroll
+    for (int j = 0; j < ROUNDS; ++j) {
+      const uint32_t l = len[j][lane];
+      const uint32_t at = l ? offs[l] + rank[j][lane] : dummy;        // (offs[0] is never written: the select keeps it out)
+      sorted[at < dummy ? at : dummy] = iw_entry_of<KIND>((uint32_t)(j * 64 + lane));
+    }
+  }
+  IW_SYNC();
+  uint32_t lim[ROOT + 1];
+#pragma unroll
+  for (int l = 1; l <= ROOT; ++l) lim[l] = IW_U(limit[l]);
+  for (uint32_t i0 = 0; i0 < (1u << ROOT); i0 += 64u) {
+    IW_FOR_LANES {
+      const uint32_t i = i0 + (uint32_t)lane;
+      const uint32_t v16 = iw_brev(i) >> 16;
+      uint32_t l = 0;
+#pragma unroll
+      for (int k = ROOT; k >= 1; --k) l = v16 < lim[k] ? (uint32_t)k : l;
+      const uint32_t at = l ? (v16 >> (16u - l)) + delta[l] : dummy;
+      const uint32_t e = sorted[at < dummy ? at : dummy] | l;
+      tab[i] = l ? e : 0u;
+    }
+  }
+  IW_SYNC();
+  return IW_U(bad) ^ 1u;
+}
+
+// A code longer than the first-level table (or an unused prefix): canonical search over the remaining lengths.  0 = invalid.
+IW_DEV uint32_t iw_slow(uint64_t bb, const uint32_t *limit, const uint32_t *delta, const uint32_t *sorted, uint32_t dummy, int root) {
+  const uint32_t v16 = iw_brev((uint32_t)bb) >> 16;
+  for (int l = root + 1; l <= 15; ++l) {
+    const uint32_t lim = IW_U(limit[l]);
+    if (v16 < lim) {
+      const uint32_t at = (v16 >> (16 - l)) + IW_U(delta[l]);
+      return IW_U(sorted[at < dummy ? at : dummy]) | (uint32_t)l;
+    }
+  }
+  return 0u;
+}
+
+// The compressed stream as the wave sees it: 64 dwords per lane-register, the next 64 prefetched.
+struct IwBits {
+  IwBuf in;                    // the stream piece from its dword-aligned origin on, bounds-checked
+  uint32_t w0, widx;           // dword index of cur[lane 0]; next dword of cur to enter the bit buffer
+  uint32_t skip;               // bytes between the origin and the first byte of the stream piece this reader was started on
+  IwLane<uint32_t> cur, nxt;
+  uint64_t bb;
+  uint32_t nbits;
+
+  IW_DEV void load(IwLane<uint32_t> &r, uint32_t first) {
+    IW_FOR_LANES { r[lane] = iw_ld32(in, 4u * (first + (uint32_t)lane)); }
+  }
+  // start reading at byte `off` of `comp`; `readable` = bytes of comp that may be loaded (a multiple of 4 behind every stream)
+  IW_DEV void init(const uint8_t *comp, uint64_t off, uint64_t readable) {
+    const uint64_t a = off & ~(uint64_t)3;
+    skip = (uint32_t)(off & 3u);
+    in = iw_make_buf(comp + a, readable > a ? readable - a : 0);
+    w0 = 0; widx = 0; bb = 0; nbits = 0;
+    load(cur, 0);
+    load(nxt, 64);
+    refill();
+    bb >>= 8u * skip;
+    nbits -= 8u * skip;
+  }
+  IW_DEV void refill() {            // afterwards nbits >= 33
+    if (nbits <= 32u) {
+      const uint32_t w = iw_readlane(cur, widx);
+      bb |= (uint64_t)w << nbits;
+      nbits += 32u;
+      if (++widx == 64u) {
+        cur = nxt;
+        w0 += 64u;
+        widx = 0;
+        load(nxt, w0 + 64u);
+      }
+    }
+  }
+  IW_DEV uint32_t bits(uint32_t n) {   // n <= 16 (0 allowed); the caller keeps nbits >= n
+    const uint32_t v = (uint32_t)bb & ((1u << n) - 1u);
+    bb >>= n;
+    nbits -= n;
+    return v;
+  }
+  // bytes from the origin to the next unread bit (exact once nbits is a multiple of 8)
+  IW_DEV uint32_t byte_pos() const { return 4u * (w0 + widx) - (nbits >> 3); }
+  // bits consumed since init
+  IW_DEV uint64_t consumed() const { return 32ull * (w0 + widx) - nbits - 8ull * skip; }
+};
+
+// Output of one stream: literals wait in a lane register (lane = position mod 64) for one coalesced store.
+struct IwOut {
+  IwBuf out;                      // the block's output [0, isize), bounds-checked
+  uint32_t isize, pos, fpos;      // next output position; first position still waiting in `pend`
+  IwLane<uint32_t> pend;
+  IW_DEV void flush() {
+    if (fpos < pos) {
+      const uint32_t lo = fpos & 63u, n = pos - fpos, w = fpos & ~63u;
+      IW_FOR_LANES { iw_st8(out, (uint32_t)lane - lo < n ? w + (uint32_t)lane : IW_OOB, pend[lane]); }
+      fpos = pos;
+    }
+  }
+  IW_DEV void literal(uint32_t b) {   // caller checked pos < isize
+    iw_writelane(pend, pos & 63u, b);
+    ++pos;
+    if ((pos & 63u) == 0u) flush();
+  }
+  // LZ77 match: length L (3..258), distance D (1..pos).  Byte k is out[pos - D + k mod D]: every source byte was written
+  // before the match started, so all lanes copy at once, also when the match overlaps itself (D < L).
+  IW_DEV void match(uint32_t L, uint32_t D) {
+    flush();
+    const uint32_t src = pos - D;
+    if (D >= L) {
+      for (uint32_t k0 = 0; k0 < L; k0 += 64u) {
+        IW_FOR_LANES {
+          const uint32_t k = k0 + (uint32_t)lane;
+          const uint32_t v = iw_ld8(out, k < L ? src + k : IW_OOB);
+          iw_st8(out, k < L ? pos + k : IW_OOB, v);
+        }
+      }
+    } else {
+      const float rcp = IW_RCP((float)D);
+      for (uint32_t k0 = 0; k0 < L; k0 += 64u) {
+        IW_FOR_LANES {
+          const uint32_t k = k0 + (uint32_t)lane;
+          const uint32_t q = (uint32_t)((float)k * rcp);
+          int32_t r = (int32_t)k - (int32_t)(q * D);         // q is within one of k / D: one correction either way
+          r = r < 0 ? r + (int32_t)D : r;
+          r = r >= (int32_t)D ? r - (int32_t)D : r;
+          const uint32_t v = iw_ld8(out, k < L ? src + (uint32_t)r : IW_OOB);
+          iw_st8(out, k < L ? pos + k : IW_OOB, v);
+        }
+      }
+    }
+    pos += L;
+    fpos = pos;
+  }
+  // `n` bytes from the compressed stream itself (a stored block), starting `p` bytes behind the reader's origin
+  IW_DEV void raw(const IwBuf &in, uint32_t p, uint32_t n) {
+    flush();
+    for (uint32_t k0 = 0; k0 < n; k0 += 64u) {
+      IW_FOR_LANES {
+        const uint32_t k = k0 + (uint32_t)lane;
+        const uint32_t v = iw_ld8(in, k < n ? p + k : IW_OOB);
+        iw_st8(out, k < n ? pos + k : IW_OOB, v);
+      }
+    }
+    pos += n;
+    fpos = pos;
+  }
+};
+
+// Inflate the raw DEFLATE stream comp[off, off + clen) into out[0, isize).  comp[0, readable) may be loaded (readable is a
+// multiple of 4 and >= off + clen).  Returns 0 or IW_ERR_* flags; never touches memory outside comp[0, readable) and
+// out[0, isize).
+IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t readable, uint8_t *out, uint32_t isize, IwLds &S) {
+  IwBits br;
+  br.init(comp, off, readable);
+  uint64_t stream_bits = 8ull * clen;     // bits of the stream still ahead of this reader's origin (stored blocks restart the reader)
+  uint64_t origin = off & ~(uint64_t)3;   // where the reader's origin sits in comp
+  IwOut o;
+  o.out = iw_make_buf(out, isize);
+  o.isize = isize; o.pos = 0; o.fpos = 0;
+  IW_FOR_LANES { o.pend[lane] = 0; }
+  for (;;) {
+    br.refill();
+    const uint32_t bfinal = br.bits(1), btype = br.bits(2);
+    if (btype == 3u) return IW_ERR_DATA;
+    if (btype == 0u) {
+      br.bits(br.nbits & 7u);                                   // to the next byte boundary
+      br.refill();
+      const uint32_t len = br.bits(16);
+      br.refill();
+      const uint32_t nlen = br.bits(16);
+      if ((len ^ 0xffffu) != nlen) return IW_ERR_DATA;
+      const uint64_t used = br.consumed();
+      if (used + 8ull * len > stream_bits) return IW_ERR_DATA;  // the stored bytes reach past the stream
+      if (o.pos + len > isize) return IW_ERR_SIZE;
+      const uint32_t p = br.byte_pos();
+      o.raw(br.in, p, len);
+      stream_bits -= used + 8ull * len;
+      const uint64_t noff = origin + p + len;
+      origin = noff & ~(uint64_t)3;
+      br.init(comp, noff, readable);
+    } else {
+      uint32_t hlit, hdist;
+      if (btype == 1u) {
+        hlit = 288; hdist = 32;
+        for (uint32_t s0 = 0; s0 < 320u; s0 += 64u) {
+          IW_FOR_LANES {
+            const uint32_t s = s0 + (uint32_t)lane;
+            S.lens[s] = (uint8_t)(s < 144u ? 8 : s < 256u ? 9 : s < 280u ? 7 : s < 288u ? 8 : 5);
+          }
+        }
+      } else {
+        hlit = br.bits(5) + 257u;
+        hdist = br.bits(5) + 1u;
+        const uint32_t hclen = br.bits(4) + 4u;
+        if (hlit > 286u || hdist > 30u) return IW_ERR_DATA;
+        uint64_t clv = 0;                                       // 3 bits per code-length symbol
+        for (uint32_t i = 0; i < hclen; ++i) {
+          br.refill();
+          clv |= (uint64_t)br.bits(3) << (3u * iw_cl_order(i));
+        }
+        IwLane<uint32_t> cll[1];
+        IW_FOR_LANES { cll[0][lane] = lane < 19 ? (uint32_t)(clv >> (3 * (lane < 19 ? lane : 0))) & 7u : 0u; }
+        if (!iw_build<1, IW_CL_ROOT, IW_CODES>(cll, S.cl.cl_tab, S.cl.cl_sorted, 31u, S.cl.cl_limit, S.cl.cl_delta, S.cl.cl_offs)) return IW_ERR_DATA;
+        const uint32_t n = hlit + hdist;
+        uint32_t i = 0, prev = 0;
+        while (i < n) {
+          br.refill();
+          const uint32_t e = IW_U(S.cl.cl_tab[(uint32_t)br.bb & ((1u << IW_CL_ROOT) - 1u)]);
+          if (!(e & 15u)) return IW_ERR_DATA;
+          br.bits(e & 15u);
+          const uint32_t s = e >> 16;
+          uint32_t rep, val;
+          if (s < 16u) { rep = 1; val = s; }
+          else if (s == 16u) { if (!i) return IW_ERR_DATA; rep = 3u + br.bits(2); val = prev; }
+          else if (s == 17u) { rep = 3u + br.bits(3); val = 0; }
+          else { rep = 11u + br.bits(7); val = 0; }
+          if (i + rep > n) return IW_ERR_DATA;
+          for (uint32_t r0 = 0; r0 < rep; r0 += 64u) {
+            IW_FOR_LANES {
+              const uint32_t r = r0 + (uint32_t)lane;
+              S.lens[r < rep ? i + r : 320u] = (uint8_t)val;
+            }
+          }
+          i += rep;
+          prev = val;
+        }
+        IW_SYNC();
+        if (IW_U(S.lens[256]) == 0u) return IW_ERR_DATA;        // no end-of-block code (inflate.c: "missing end-of-block")
+      }
+      IW_SYNC();
+      {
+        IwLane<uint32_t> ll[5];
+        IW_FOR_LANES {
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const uint32_t s = (uint32_t)(j * 64 + lane);
+            const uint32_t v = S.lens[s < 320u ? s : 320u];
+            ll[j][lane] = s < hlit ? v : 0u;
+          }
+        }
+        IwLane<uint32_t> dl[1];
+        IW_FOR_LANES {
+          const uint32_t v = S.lens[(uint32_t)lane < 32u ? hlit + (uint32_t)lane : 320u];
+          dl[0][lane] = (uint32_t)lane < hdist ? v : 0u;
+        }
+        IW_SYNC();                                              // (the code-length tables alias the distance table)
+        if (!iw_build<5, IW_LIT_ROOT, IW_LENS>(ll, S.lit_tab, S.ll_sorted, 288u, S.ll_limit, S.ll_delta, S.ll_offs)) return IW_ERR_DATA;
+        if (!iw_build<1, IW_DIST_ROOT, IW_DISTS>(dl, S.dist_tab, S.d_sorted, 32u, S.d_limit, S.d_delta, S.d_offs)) return IW_ERR_DATA;
+      }
+      for (;;) {
+        br.refill();
+        uint32_t e = IW_U(S.lit_tab[(uint32_t)br.bb & ((1u << IW_LIT_ROOT) - 1u)]);
+        if (!(e & 15u)) {
+          e = iw_slow(br.bb, S.ll_limit, S.ll_delta, S.ll_sorted, 288u, IW_LIT_ROOT);
+          if (!e) return IW_ERR_DATA;
+        }
+        br.bits(e & 15u);
+        const uint32_t kind = e & (3u << 8);
+        if (kind == 0u) {
+          if (o.pos >= isize) return IW_ERR_SIZE;
+          o.literal(e >> 16);
+          continue;
+        }
+        if (kind == IW_KIND_EOB) break;
+        const uint32_t L = (e >> 16) + br.bits((e >> 4) & 15u);
+        br.refill();
+        uint32_t d = IW_U(S.dist_tab[(uint32_t)br.bb & ((1u << IW_DIST_ROOT) - 1u)]);
+        if (!(d & 15u)) {
+          d = iw_slow(br.bb, S.d_limit, S.d_delta, S.d_sorted, 32u, IW_DIST_ROOT);
+          if (!d) return IW_ERR_DATA;
+        }
+        br.bits(d & 15u);
+        const uint32_t D = (d >> 16) + br.bits((d >> 4) & 15u);
+        if (L < 3u || D == 0u || D > o.pos) return IW_ERR_DATA;
+        if (o.pos + L > isize) return IW_ERR_SIZE;
+        o.match(L, D);
+      }
+    }
+    if (bfinal) break;
+  }
+  o.flush();
+  if (br.consumed() > stream_bits) return IW_ERR_DATA;          // the decoder read past the end of the stream
+  if (o.pos != isize) return IW_ERR_SIZE;
+  return 0;
+}
+
+}  // namespace strl

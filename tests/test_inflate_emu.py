@@ -1,5 +1,7 @@
-"""The device DEFLATE decoder's per-lane core (strling_amd/csrc/inflate_core.h) compiled for the host against zlib: every
-block type, odd output alignments, multi-block streams.  CPU only -- the GPU run of the same vectors is test_bgzf_device.py."""
+"""The device DEFLATE decoder's core (strling_amd/csrc/inflate_wave.h: one wave per stream) compiled for the host, its 64
+lanes as loops, against zlib: every block type, every input alignment, multi-block streams, corrupt and truncated streams
+(the bytes behind the readable range and around the output are poisoned and checked).  CPU only -- the GPU run of the same
+vectors is test_bgzf_device.py."""
 import ctypes as C
 import os
 import subprocess
@@ -15,11 +17,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def emu():
     so = os.path.join(HERE, "emu", "libinflate_emu.so")
     src = os.path.join(HERE, "emu", "inflate_emu.cpp")
-    core = os.path.join(HERE, "..", "strling_amd", "csrc", "inflate_core.h")
+    core = os.path.join(HERE, "..", "strling_amd", "csrc", "inflate_wave.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(core)):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
     L = C.CDLL(so)
     L.emu_inflate.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]
+    L.emu_inflate_at.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32]
     return L
 
 
@@ -68,15 +71,48 @@ def test_inflate_core_matches_zlib(emu):
     assert n >= 80
 
 
-def test_inflate_core_tail_with_a_full_ring(emu):
-    """streams of every length mod 16 around multiples of the ring size: the partial last dword must not clobber the bytes
-    1 KiB older that are still waiting in the ring"""
+def test_inflate_core_every_alignment_and_length(emu):
+    """streams of every length mod 64 at every input alignment: the 256-byte input window, the partial first dword and the
+    64-byte literal flush all have their edges here"""
     rng = np.random.default_rng(8)
-    for n in list(range(1000, 1100)) + list(range(37850, 37950)):
+    for n in list(range(1, 140)) + list(range(1000, 1070)) + list(range(37850, 37900)):
         data = bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), n))
         s = deflate(data, level=int(rng.integers(1, 10)))
         out = C.create_string_buffer(n + 1)
-        assert emu.emu_inflate(s, len(s), out, n) == 0 and out.raw[:n] == data, n
+        assert emu.emu_inflate_at(s, len(s), n % 7, out, n) == 0 and out.raw[:n] == data, n
+    data = bytes(rng.integers(0, 6, 3000, dtype=np.uint8)) * 3
+    for lvl in (0, 1, 6):
+        s = deflate(data, level=lvl, flush_every=700 if lvl else 0)
+        for lead in range(0, 9):
+            out = C.create_string_buffer(len(data) + 1)
+            assert emu.emu_inflate_at(s, len(s), lead, out, len(data)) == 0 and out.raw[:len(data)] == data, (lvl, lead)
+
+
+def test_inflate_core_long_codes_and_far_matches(emu):
+    """skewed symbol statistics give 11..15-bit literal/length codes and 9..15-bit distance codes (the canonical search behind
+    the first-level tables); 32 KiB distances; length-258 matches at every distance below 70 (the periodic copy)"""
+    rng = np.random.default_rng(11)
+    p = 0.5 ** np.arange(1, 257)
+    skew = bytes(rng.choice(256, 60000, p=p / p.sum()).astype(np.uint8))
+    far = bytes(rng.integers(0, 256, 400, dtype=np.uint8))
+    blocks = [skew, far + bytes(32768 - 400) + far + skew[:3000] + far]
+    for d in range(1, 70):
+        unit = bytes(rng.integers(0, 256, d, dtype=np.uint8))
+        blocks.append((unit * (900 // d + 2))[:900] + bytes(rng.integers(0, 256, 30, dtype=np.uint8)))
+    for data in blocks:
+        for lvl in (1, 6, 9):
+            s = deflate(data, level=lvl)
+            out = C.create_string_buffer(len(data) + 1)
+            assert emu.emu_inflate(s, len(s), out, len(data)) == 0 and out.raw[:len(data)] == data, (len(data), lvl)
+
+
+def _zlib_ok(stream, n):
+    try:
+        d = zlib.decompressobj(-15)
+        o = d.decompress(stream)
+        return d.eof and len(o) == n and not d.unused_data
+    except zlib.error:
+        return False
 
 
 def test_inflate_core_rejects_bad_streams(emu):
@@ -92,3 +128,30 @@ def test_inflate_core_rejects_bad_streams(emu):
         g = bytes(rng.integers(0, 256, 3000, dtype=np.uint8))
         bad += emu.emu_inflate(g, len(g), out, 20000) != 0
     assert bad == 40                                                          # garbage never decodes to exactly 20000 bytes
+
+
+def test_inflate_core_corrupt_streams_get_zlibs_verdict(emu):
+    """bit flips and truncations of valid streams (dynamic, fixed and stored blocks): the decoder stays inside its buffers
+    (the shim checks the poison on both sides) and accepts a stream only if zlib inflates it to exactly ISIZE bytes with the
+    same content"""
+    rng = np.random.default_rng(21)
+    base = bytes(rng.choice(np.frombuffer(b"ACGTN\xff", np.uint8), 9000))
+    n_acc = 0
+    for kw in (dict(level=6), dict(level=1), dict(level=0), dict(level=6, strategy=zlib.Z_FIXED), dict(level=4, flush_every=1500)):
+        s = deflate(base, **kw)
+        for t in range(160):
+            b = bytearray(s)
+            if t % 4 == 3:
+                b = b[:int(rng.integers(1, len(b)))]
+            else:
+                for _ in range(int(rng.integers(1, 4))):
+                    i = int(rng.integers(0, min(len(b), 200) if t % 2 else len(b)))
+                    b[i] ^= 1 << int(rng.integers(0, 8))
+            b = bytes(b)
+            out = C.create_string_buffer(len(base) + 1)
+            rc = emu.emu_inflate_at(b, len(b), t % 5, out, len(base))
+            assert rc in (0, 1, 2, 3), rc
+            if rc == 0:
+                n_acc += 1
+                assert _zlib_ok(b, len(base)) and out.raw[:len(base)] == zlib.decompress(b, -15), (kw, t)
+    assert n_acc < 400
