@@ -442,6 +442,44 @@ int strl_inflate_blocks(strl_ctx *ctx, const uint8_t *comp, uint64_t comp_bytes,
 /* HIP-event time (ms) of the inflate kernel of the last strl_inflate_blocks call (copies excluded). */
 int strl_ctx_inflate_ms(strl_ctx *ctx, double *ms);
 
+/* ---- `strling extract` with the whole BAM front end on the device (replaces extract.nim:275-329: bam open / `for aln in ibam`
+ * / `query("*")`, i.e. htslib's inflate + bam_read1 + the hts-nim accessors, for the whole file).  The host walks the BGZF
+ * block headers and hands over compressed bytes; inflate, record boundaries, record parsing, the fragment-length words and
+ * the qnames stay on the device.  Chunks are pipelined: strl_front_push(i) enqueues copy + inflate + record scan of chunk i
+ * on a stream of its own, then parses and scores chunk i - 1 on the context's stream (strl_extract_add semantics: rows,
+ * hashes and scorer words of ALL chunks stay resident; finish with strl_extract_finish + strl_treads_fetch).
+ * A BGZF block may be handed over only once and blocks must come in file order; records may straddle blocks and chunks.
+ *   n_ref                 targets in the BAM header (bounds refID / next_refID of a plausible record)
+ *   first_record_offset   bytes between the start of the first pushed block's inflated data and the first record
+ *   comp                  the chunk's compressed bytes; PINNED host memory (strl_pinned_alloc) makes the copy asynchronous; it
+ *                         may be overwritten once the call after the next one has returned
+ *   coff / clen / isize   per block: offset of its DEFLATE payload in comp, payload length, inflated size (BGZF ISIZE)
+ *   done / n_done         summaries of chunks whose scoring has COMPLETED, in file order (push: 0 or 1, finish: up to 2)
+ * Errors: STRL_ERR_FORMAT invalid DEFLATE data / ISIZE / malformed record; STRL_ERR_ARG a record's l_seq > STRL_MAX_READ_LEN. */
+typedef struct {
+  uint64_t n_records;       /* records of the chunk (secondary / supplementary included) */
+  uint64_t n_primary;       /* those that are neither (the reference's progress counter, extract.nim:309,315) */
+  int64_t last_placed;      /* index within the chunk of the last record with tid >= 0; -1: none */
+  uint64_t tail_primary;    /* primary records behind it (the "*" region extract.nim:326 visits again) */
+  uint32_t max_l_seq;
+  uint32_t scan_slow_segments; /* 16 KiB segments whose guessed record start was wrong (walked again sequentially) */
+} strl_front_chunk;
+int strl_front_begin(strl_ctx *ctx, int32_t n_ref, uint64_t first_record_offset, uint64_t n_reads_hint);
+int strl_front_push(strl_ctx *ctx, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize,
+                    uint32_t n_blocks, strl_front_chunk *done, int *n_done);
+int strl_front_finish(strl_ctx *ctx, strl_front_chunk done[2], int *n_done);
+/* flag | (isize in [0, 4095] ? isize : 0xffff) << 16 of records [first, first + n) of the file: what
+ * fragment_length_distribution (utils.nim:86-111) reads of a record.  Synchronises the context's stream. */
+int strl_front_fragwords(strl_ctx *ctx, uint64_t first, uint64_t n, uint32_t *out);
+/* seen[tid] != 0: the contig has had a primary record so far (extract.nim:310-313 prints a line per large one) */
+int strl_front_tids(strl_ctx *ctx, uint8_t *seen, int32_t n_ref);
+/* qnames of the given records (a tread's qname_id) from the device's name arena: names[qname_off[i], qname_off[i + 1]).
+ * STRL_ERR_CAPACITY with *need set when `cap` is too small. */
+int strl_front_qnames(strl_ctx *ctx, const int64_t *record_ids, uint64_t n, uint64_t *qname_off, char *names, uint64_t cap, uint64_t *need);
+/* page-locked host memory for strl_front_push's compressed bytes */
+void *strl_pinned_alloc(uint64_t bytes);
+void strl_pinned_free(void *p);
+
 /* ---- fragment-length statistics (utils.nim:139-146) ---- */
 int strl_frag_median(const uint32_t frag[4096], double pct);
 

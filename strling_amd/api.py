@@ -50,6 +50,15 @@ PAIR_REC_DTYPE = np.dtype([("tid", "<i4"), ("pos", "<i4"), ("mtid", "<i4"), ("mp
 assert PAIR_REC_DTYPE.itemsize == 32
 
 
+class FrontChunk(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_primary", C.c_uint64), ("last_placed", C.c_int64), ("tail_primary", C.c_uint64),
+                ("max_l_seq", C.c_uint32), ("scan_slow_segments", C.c_uint32)]
+
+
+def _front_chunk(c):
+    return {k: int(getattr(c, k)) for k, _ in FrontChunk._fields_}
+
+
 class ScoreStats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_skipped", C.c_uint64), ("n_scored", C.c_uint64), ("n_soft_items", C.c_uint64),
                 ("ms_classify", C.c_float), ("ms_score", C.c_float), ("ms_soft", C.c_float), ("n_stage_b_whole", C.c_uint32),
@@ -108,7 +117,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
            "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order",
-           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered", "strl_inflate_blocks", "strl_ctx_inflate_ms", "strl_cluster_collect", "strl_ctx_tail_stream"]
+           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered", "strl_inflate_blocks", "strl_ctx_inflate_ms", "strl_front_begin", "strl_front_push", "strl_front_finish", "strl_front_fragwords", "strl_front_tids", "strl_front_qnames", "strl_pinned_alloc", "strl_pinned_free", "strl_cluster_collect", "strl_ctx_tail_stream"]
 
 
 def lib_path():
@@ -189,6 +198,16 @@ def load(build_if_missing=True):
                                         C.c_int32, C.c_uint16, C.c_uint16, C.c_uint16, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
                                         C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(ClusterStats)]
     L.strl_inflate_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
+    L.strl_ctx_inflate_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.strl_front_begin.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64]
+    L.strl_front_push.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_int)]
+    L.strl_front_finish.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    L.strl_front_fragwords.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.strl_front_tids.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.strl_front_qnames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.strl_pinned_alloc.argtypes = [C.c_uint64]
+    L.strl_pinned_alloc.restype = C.c_void_p
+    L.strl_pinned_free.argtypes = [C.c_void_p]
     L.strl_pair_rows.argtypes = [C.POINTER(CRecords)] + [C.c_void_p] * 5
     L.strl_ctx_cluster_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 3)]
     L.strl_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
@@ -510,6 +529,91 @@ class Context:
             res.append(out[o:o + int(n)].tobytes())
             o += int(n)
         return res
+
+    # ---- extract with the BAM front end on the device ---------------------------------------------
+    def extract_bam_device(self, path, chunk_blocks=16384, n_reads_hint=0):
+        """`strling extract`'s read loop over a BAM FILE with inflate, record scan and parse on the device
+        (strl_front_begin / _push / _finish + strl_extract_finish).  The host side here only walks BGZF block headers.
+        -> dict(treads, qnames, fragwords, chunks, n_records, n_tail, targets, header)"""
+        import struct, zlib
+        data = np.fromfile(path, np.uint8)
+        raw = data.tobytes()
+        blocks, o = [], 0                                     # (payload offset, payload length, isize)
+        while o < len(raw):
+            xlen = struct.unpack_from("<H", raw, o + 10)[0]
+            bsize = struct.unpack_from("<H", raw, o + 16)[0] + 1
+            isz = struct.unpack_from("<I", raw, o + bsize - 4)[0]
+            if isz:
+                blocks.append((o + 12 + xlen, bsize - 12 - xlen - 8, isz))
+            o += bsize
+        # BAM header: inflate leading blocks on the host until it is complete
+        hdr, k = b"", 0
+
+        def need(nbytes):
+            nonlocal hdr, k
+            while len(hdr) < nbytes and k < len(blocks):
+                po, pl, _ = blocks[k]
+                hdr += zlib.decompress(raw[po:po + pl], -15)
+                k += 1
+            if len(hdr) < nbytes:
+                raise StrlingError("truncated BAM header")
+        need(12)
+        assert hdr[:4] == b"BAM\1"
+        l_text = struct.unpack_from("<i", hdr, 4)[0]
+        need(12 + l_text)
+        text = hdr[8:8 + l_text].decode()
+        n_ref = struct.unpack_from("<i", hdr, 8 + l_text)[0]
+        at, targets = 12 + l_text, []
+        for _ in range(n_ref):
+            need(at + 4)
+            ln = struct.unpack_from("<i", hdr, at)[0]
+            need(at + 8 + ln)
+            targets.append((hdr[at + 4:at + 4 + ln - 1].decode(), struct.unpack_from("<i", hdr, at + 4 + ln)[0]))
+            at += 8 + ln
+        cum, b0 = 0, 0                                        # the block the first record starts in
+        while b0 < len(blocks) and cum + blocks[b0][2] <= at:
+            cum += blocks[b0][2]
+            b0 += 1
+        first_off = at - cum
+        _check(self.L.strl_front_begin(self.h, n_ref, first_off, n_reads_hint))
+        done = (FrontChunk * 2)()
+        nd = C.c_int(0)
+        chunks, keep = [], []
+        for c0 in range(b0, len(blocks), chunk_blocks):
+            cb = blocks[c0:c0 + chunk_blocks]
+            lo, hi = cb[0][0], cb[-1][0] + cb[-1][1]
+            comp = np.ascontiguousarray(data[lo:hi])
+            coff = np.array([b[0] - lo for b in cb], np.uint64)
+            clen = np.array([b[1] for b in cb], np.uint32)
+            isz = np.array([b[2] for b in cb], np.uint32)
+            keep.append((comp, coff, clen, isz))                # pageable memory: the copy is staged by the runtime
+            _check(self.L.strl_front_push(self.h, comp.ctypes.data, comp.size, _ptr(coff), _ptr(clen), _ptr(isz), len(cb), done, C.byref(nd)))
+            chunks += [_front_chunk(done[i]) for i in range(nd.value)]
+            keep = keep[-3:]
+        _check(self.L.strl_front_finish(self.h, done, C.byref(nd)))
+        chunks += [_front_chunk(done[i]) for i in range(nd.value)]
+        n_rec = sum(c["n_records"] for c in chunks)
+        n_tail = 0
+        for c in chunks:                                      # trailing run of unplaced records over the whole file
+            n_tail = c["n_records"] - 1 - c["last_placed"] if c["last_placed"] >= 0 else n_tail + c["n_records"]
+        _check(self.L.strl_extract_finish(self.h, n_tail, 3 * n_rec + 16, 8 * n_rec + 16))
+        no = C.c_uint64(0)
+        _check(self.L.strl_treads_fetch(self.h, None, 0, C.byref(no), None))
+        out = np.zeros(max(1, no.value), TREAD_DTYPE)
+        _check(self.L.strl_treads_fetch(self.h, out.ctypes.data, out.size, C.byref(no), None))
+        out = out[:no.value]
+        ids = np.ascontiguousarray(out["qname_id"], np.int64)
+        qoff = np.zeros(ids.size + 1, np.uint64)
+        needb = C.c_uint64(0)
+        buf = np.zeros(max(16, 256 * ids.size), np.uint8)
+        _check(self.L.strl_front_qnames(self.h, _ptr(ids), ids.size, _ptr(qoff), buf.ctypes.data, buf.size, C.byref(needb)))
+        names = [buf[int(qoff[i]):int(qoff[i + 1])].tobytes() for i in range(ids.size)]
+        fw = np.zeros(max(1, n_rec), np.uint32)
+        _check(self.L.strl_front_fragwords(self.h, 0, n_rec, fw.ctypes.data))
+        seen = np.zeros(max(1, n_ref), np.uint8)
+        _check(self.L.strl_front_tids(self.h, seen.ctypes.data, n_ref))
+        return dict(treads=out, qnames=names, fragwords=fw[:n_rec], chunks=chunks, n_records=n_rec, n_tail=n_tail, targets=targets, header=text,
+                    tids_seen=seen[:n_ref])
 
     def inflate_ms(self):
         """kernel time (ms) of the last inflate_blocks call"""

@@ -1,0 +1,48 @@
+// bgzf_feed.h -- the host side of the device BAM front end (strl_front_*): the file is mapped, a thread walks the BGZF block
+// headers (18 bytes per ~16 KB block) ahead of the consumer, and the consumer copies whole runs of blocks -- compressed --
+// into page-locked buffers for the GPU.  No inflate, no record ever touched on the host (extract.nim:275-329 does both
+// through htslib on one thread).
+#pragma once
+#include <stdint.h>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include "bam_reader.h"
+
+namespace strl {
+
+class BgzfFeed {
+ public:
+  ~BgzfFeed();
+  // header text + targets (read with the plain reader), maps the file, starts the walker at the block the first record is in
+  bool open(const std::string &path, std::string &err);
+  void close();
+  const std::string &header_text() const { return text_; }
+  const std::vector<BamTarget> &targets() const { return targets_; }
+  uint64_t first_record_offset() const { return first_off_; }   // bytes into the first block's inflated data
+  size_t file_bytes() const { return map_len_; }
+  struct Block { size_t c_off; uint32_t clen, isize; };          // DEFLATE payload at map + c_off
+  // Next run of consecutive non-empty blocks: at most max_blocks and max_bytes of file (first block's payload to the last
+  // block's end).  Returns the number of blocks (0 at the end of the file), -1 on a malformed file.
+  int64_t next(std::vector<Block> &out, size_t max_blocks, size_t max_bytes, std::string &err);
+  const uint8_t *map() const { return map_; }
+
+ private:
+  const uint8_t *map_ = nullptr;
+  size_t map_len_ = 0;
+  uint64_t first_off_ = 0;
+  std::string text_;
+  std::vector<BamTarget> targets_;
+  std::thread walker_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<Block> blks_;
+  size_t taken_ = 0;
+  int state_ = 0;        // 0 walking, 1 end of file, 2 error
+  std::string werr_;
+  bool stop_ = false;
+};
+
+}  // namespace strl

@@ -23,6 +23,7 @@
 #include <vector>
 #include "../../../include/strling_amd.h"
 #include "bam_reader.h"
+#include "bgzf_feed.h"
 
 using namespace strl;
 
@@ -269,6 +270,30 @@ static Genome read_genome_bed(const std::string &path, const std::vector<BamTarg
   return g;
 }
 
+// genome_repeats, genome_strs.nim:107-146: existing file, or build it from the FASTA (into a temporary file when
+// no -g was given).  An existing -g is accepted without -f here; the reference insists on opening the FASTA first.
+static void setup_genome(strl_ctx *ctx, const Args &a, const std::vector<BamTarget> &targets) {
+  std::string bed_path = a.get("genome-repeats", "");
+  const bool is_tmp = bed_path.empty();
+  if (is_tmp) {
+    const char *td = getenv("TMPDIR");
+    bed_path = std::string(td ? td : "/tmp") + "/strling." + std::to_string((long)getpid()) + ".bed";
+  }
+  if (is_tmp || !file_exists(bed_path)) {
+    if (!a.flag("fasta")) quit("[strling] couldn't open fasta %s make sure file is present and has a .fai index", a.get("fasta", "").c_str());
+    build_genome_index(ctx, a.get("fasta", ""), bed_path);
+  } else {
+    fprintf(stderr, "[strling] using existing file %s for genome repeats\n", bed_path.c_str());
+  }
+  const Genome g = read_genome_bed(bed_path, targets);
+  fprintf(stderr, "[strling] got STR repeats from genome into an interval tree\n");
+  if (is_tmp) remove(bed_path.c_str());
+  strl_genome_str gs{(int32_t)targets.size(), g.has.data(), g.off.data(), g.st.data(), g.en.data()};
+  CHECK(strl_ctx_set_genome(ctx, &gs));
+}
+
+static int extract_front(const Args &a, const std::string &bam, const std::string &bin, double p, uint8_t min_mapq, bool verbose);
+
 static int extract_main(int argc, char **argv) {
   const char *usage =
       "strling extract\n\nUsage:\n  strling extract [options] bam bin\n\nArguments:\n  bam              path to bam file\n"
@@ -285,6 +310,12 @@ static int extract_main(int argc, char **argv) {
   const uint8_t min_mapq = (uint8_t)atoi(a.get("min-mapq", "40").c_str());
   const bool verbose = a.flag("verbose");
   const int64_t batch = atoll(a.get("batch", "1048576").c_str());
+  {
+    // Default: the whole BAM front end on the device (inflate, record scan, parse: strl_front_*).  STRL_FRONT=host keeps the
+    // host reader (threads inflate and parse, the device scores); STRL_PAIR=host (the host's streaming Cache) implies it.
+    const char *fe = getenv("STRL_FRONT"), *pe = getenv("STRL_PAIR");
+    if (!(fe && strcmp(fe, "host") == 0) && !(pe && strcmp(pe, "host") == 0)) return extract_front(a, bam, bin, p, min_mapq, verbose);
+  }
 
   // The HIP runtime + device context come up (a few hundred ms of driver work on one thread) while the host threads
   // run the fragment-length pass.
@@ -311,25 +342,7 @@ static int extract_main(int argc, char **argv) {
   if (ctx_rc) quit("[strling] %s (status %d)", ctx_err.c_str(), ctx_rc);
   strl_opts opts{frag_median, p, min_mapq};
   CHECK(strl_ctx_set_opts(ctx, &opts));
-  // genome_repeats, genome_strs.nim:107-146: existing file, or build it from the FASTA (into a temporary file when
-  // no -g was given).  An existing -g is accepted without -f here; the reference insists on opening the FASTA first.
-  std::string bed_path = a.get("genome-repeats", "");
-  const bool is_tmp = bed_path.empty();
-  if (is_tmp) {
-    const char *td = getenv("TMPDIR");
-    bed_path = std::string(td ? td : "/tmp") + "/strling." + std::to_string((long)getpid()) + ".bed";
-  }
-  if (is_tmp || !file_exists(bed_path)) {
-    if (!a.flag("fasta")) quit("[strling] couldn't open fasta %s make sure file is present and has a .fai index", a.get("fasta", "").c_str());
-    build_genome_index(ctx, a.get("fasta", ""), bed_path);
-  } else {
-    fprintf(stderr, "[strling] using existing file %s for genome repeats\n", bed_path.c_str());
-  }
-  const Genome g = read_genome_bed(bed_path, rd.targets());
-  fprintf(stderr, "[strling] got STR repeats from genome into an interval tree\n");
-  if (is_tmp) remove(bed_path.c_str());
-  strl_genome_str gs{(int32_t)rd.targets().size(), g.has.data(), g.off.data(), g.st.data(), g.en.data()};
-  CHECK(strl_ctx_set_genome(ctx, &gs));
+  setup_genome(ctx, a, rd.targets());
   // Pair logic: on the device over the whole file (default), or the host's streaming Cache (STRL_PAIR=host; also the
   // way out for inputs the device join refuses: more than 15 records under one qname hash).
   const char *pair_env = getenv("STRL_PAIR");
@@ -525,6 +538,168 @@ static int extract_main(int argc, char **argv) {
             secs(t0, now()), t_read, t_soa, t_score, t_pair);
   }
   if (pairer) strl_pairer_destroy(pairer);
+  strl_ctx_destroy(ctx);
+  return 0;
+}
+
+// `strling extract` with the BAM front end on the device: this thread walks BGZF headers and copies compressed bytes into
+// page-locked buffers; inflate, record scan, parse, scorer, pair logic all run on the GPU (extract.nim:275-348).
+static int extract_front(const Args &a, const std::string &bam, const std::string &bin, double p, uint8_t min_mapq, bool verbose) {
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double>(y - x).count(); };
+  static const char *env_blocks = getenv("STRL_CHUNK_BLOCKS");     // tests: tiny chunks put records across chunk borders
+  const size_t chunk_blocks = env_blocks && atoi(env_blocks) > 0 ? (size_t)atoi(env_blocks) : 8192;
+  const size_t chunk_bytes = std::max<size_t>((size_t)1 << 20, chunk_blocks * 20000);       // compressed bytes one chunk may span
+  strl_ctx *ctx = nullptr;
+  int ctx_rc = 0;
+  std::string ctx_err;
+  uint8_t *pin[2] = {nullptr, nullptr};
+  std::thread ctx_thread([&] {                // the HIP runtime, the context and the page-locked buffers come up beside the header walk
+    ctx_rc = strl_ctx_create(0, &ctx);
+    if (ctx_rc) { ctx_err = strl_last_error(); return; }
+    for (auto &q : pin) q = static_cast<uint8_t *>(strl_pinned_alloc(chunk_bytes + 64));
+  });
+  g_bg_init = &ctx_thread;
+  BgzfFeed feed;
+  std::string err;
+  if (!feed.open(bam, err)) quit("couldn't open bam");
+  ctx_thread.join();
+  g_bg_init = nullptr;
+  if (ctx_rc) quit("[strling] %s (status %d)", ctx_err.c_str(), ctx_rc);
+  if (!pin[0] || !pin[1]) quit("[strling] could not allocate page-locked memory");
+  strl_opts opts{0, p, min_mapq};              // the fragment-length median is only needed by the pair logic: set before strl_extract_finish
+  CHECK(strl_ctx_set_opts(ctx, &opts));
+  setup_genome(ctx, a, feed.targets());
+  const int32_t n_ref = (int32_t)feed.targets().size();
+  CHECK(strl_front_begin(ctx, n_ref, feed.first_record_offset(), feed.file_bytes() / 48));
+
+  fprintf(stderr, "[strling] collecting str-like reads\n");
+  const auto t0 = now();
+  ThreadPool copy_pool(std::min(decode_threads(), 12));
+  std::vector<BgzfFeed::Block> blks;
+  std::vector<uint64_t> coff;
+  std::vector<uint32_t> clen, isz;
+  int64_t nreads = 0, n_tail = 0, tail_primary = 0;
+  uint64_t n_seen = 0, slow_segments = 0;
+  double t_walk = 0, t_copy = 0, t_push = 0;
+  auto account = [&](const strl_front_chunk *done, int n_done) {
+    for (int k = 0; k < n_done; ++k) {
+      const strl_front_chunk &d = done[k];
+      nreads += (int64_t)d.n_primary;
+      n_seen += d.n_records;
+      slow_segments += d.scan_slow_segments;
+      if (d.last_placed >= 0) { n_tail = (int64_t)d.n_records - 1 - d.last_placed; tail_primary = (int64_t)d.tail_primary; }
+      else { n_tail += (int64_t)d.n_records; tail_primary += (int64_t)d.n_primary; }
+      if (verbose) fprintf(stderr, "%lld %.1f reads/sec\n", (long long)nreads, (double)nreads / std::max(secs(t0, now()), 1e-9));
+    }
+  };
+  for (uint64_t ci = 0;; ++ci) {
+    const auto ta = now();
+    // a short first chunk gets the device going while the second is being copied
+    const int64_t nb = feed.next(blks, ci == 0 ? std::min<size_t>(chunk_blocks, 2048) : chunk_blocks, chunk_bytes, err);
+    if (nb < 0) quit("[strling] error reading %s: %s", bam.c_str(), err.c_str());
+    if (nb == 0) break;
+    const auto tb = now();
+    const size_t lo = blks.front().c_off, hi = blks.back().c_off + blks.back().clen;
+    uint8_t *dst = pin[ci & 1];
+    const size_t piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
+    copy_pool.parallel_for(pieces, [&](size_t k) { memcpy(dst + k * piece, feed.map() + lo + k * piece, std::min(piece, hi - lo - k * piece)); });
+    coff.resize((size_t)nb); clen.resize((size_t)nb); isz.resize((size_t)nb);
+    for (size_t k = 0; k < (size_t)nb; ++k) { coff[k] = blks[k].c_off - lo; clen[k] = blks[k].clen; isz[k] = blks[k].isize; }
+    const auto tc = now();
+    strl_front_chunk done[2];
+    int n_done = 0;
+    CHECK(strl_front_push(ctx, dst, hi - lo, coff.data(), clen.data(), isz.data(), (uint32_t)nb, done, &n_done));
+    account(done, n_done);
+    t_walk += secs(ta, tb); t_copy += secs(tb, tc); t_push += secs(tc, now());
+  }
+  const auto tf = now();
+  {
+    strl_front_chunk done[2];
+    int n_done = 0;
+    CHECK(strl_front_finish(ctx, done, &n_done));
+    account(done, n_done);
+  }
+  const double t_drain = secs(tf, now());
+  {   // extract.nim:310-313: one line per large contig that has reads (here: once the whole file has been through)
+    std::vector<uint8_t> seen((size_t)n_ref + 1, 0);
+    CHECK(strl_front_tids(ctx, seen.data(), n_ref));
+    for (int32_t t = 0; t < n_ref; ++t)
+      if (seen[(size_t)t] && feed.targets()[(size_t)t].length > 2000000u) fprintf(stderr, "[strling] extracting chromosome:%s\n", feed.targets()[(size_t)t].name.c_str());
+  }
+  fprintf(stderr, "[strling] extracting unmapped reads\n");
+  nreads += tail_primary;   // the "*" region is counted a second time by the reference's progress counter (extract.nim:326-329)
+  // fragment_length_distribution (utils.nim:86-111, extract.nim:281) from the flag / isize words the parse kept of every record
+  const auto tq = now();
+  uint32_t frag[4096];
+  memset(frag, 0, sizeof frag);
+  {
+    const int64_t n_reads = 2000000, skip_reads = 100000;
+    std::vector<int32_t> skipped;
+    std::vector<uint32_t> fw;
+    int64_t counted = 0;
+    bool done_f = false;
+    for (uint64_t first = 0; first < n_seen && !done_f; first += fw.size()) {
+      fw.resize((size_t)std::min<uint64_t>(n_seen - first, first == 0 ? 2400000 : 8000000));
+      CHECK(strl_front_fragwords(ctx, first, fw.size(), fw.data()));
+      for (size_t k = 0; k < fw.size(); ++k) {
+        const int64_t i = (int64_t)(first + k);
+        const uint32_t f = fw[k] & 0xffffu, is = fw[k] >> 16;
+        if (!(f & 0x2)) continue;
+        if (f & (0x800 | 0x100)) continue;
+        if (is > 4095u) continue;
+        if (i < skip_reads) { skipped.push_back((int32_t)is); continue; }
+        skipped.clear();
+        frag[is]++;
+        if (++counted > n_reads) { done_f = true; break; }
+      }
+    }
+    uint64_t sum = 0;
+    for (int k = 0; k < 4096; ++k) sum += frag[k];
+    if ((uint32_t)sum == 0) {
+      fprintf(stderr, "using first reads in fragment_length_distribution calculation as there were not enough\n");
+      for (int32_t is : skipped) frag[is]++;
+    }
+  }
+  const int frag_median = strl_frag_median(frag, 0.5);
+  if (verbose) {
+    fprintf(stderr, "Calculated median fragment length:%d\n", frag_median);
+    fprintf(stderr, "10th, 90th percentile of fragment length:%d %d\n", strl_frag_median(frag, 0.1), strl_frag_median(frag, 0.9));
+  }
+  opts.median_fragment_length = frag_median;
+  CHECK(strl_ctx_set_opts(ctx, &opts));
+  const double t_frag = secs(tq, now());
+  const auto tp0 = now();
+  uint64_t nt = 0;
+  int rc = 0;
+  auto cap_of = [](uint64_t v) { return std::min<uint64_t>(v, 0x7ffffff0ull); };
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    CHECK(strl_extract_finish(ctx, n_tail, attempt ? cap_of(3 * n_seen + 16) : 0, attempt ? cap_of(8 * n_seen + 16) : 0));
+    rc = strl_treads_fetch(ctx, nullptr, 0, &nt, nullptr);
+    if (rc != STRL_ERR_CAPACITY) break;
+  }
+  if (rc == STRL_ERR_FORMAT) quit("[strling] %s; rerun with STRL_PAIR=host", strl_last_error());
+  if (rc) quit("[strling] %s (status %d)", strl_last_error(), rc);
+  std::vector<strl_tread> treads((size_t)nt + 1);
+  CHECK(strl_treads_fetch(ctx, treads.data(), nt, &nt, nullptr));
+  std::vector<int64_t> ids((size_t)nt);
+  for (uint64_t i = 0; i < nt; ++i) { ids[(size_t)i] = treads[(size_t)i].qname_id; treads[(size_t)i].qname_id = (int64_t)i; }
+  std::vector<uint64_t> qoff((size_t)nt + 1, 0);
+  std::string qn((size_t)nt * 255 + 16, '\0');
+  uint64_t need = 0;
+  CHECK(strl_front_qnames(ctx, ids.data(), nt, qoff.data(), &qn[0], qn.size(), &need));
+  const double t_pair = secs(tp0, now());
+  fprintf(stderr, "[strling] writing binary file:%s\n", bin.c_str());
+  CHECK(strl_bin_write(bin.c_str(), (float)p, min_mapq, frag, feed.header_text().data(), (int32_t)feed.header_text().size(), treads.data(), nt, qoff.data(), qn.data()));
+  fprintf(stderr, "[strling] finished extraction\n");
+  if (verbose) {
+    fprintf(stderr, "[strling] %lld reads, %llu STR reads, 0 reads still waiting for a mate\n", (long long)nreads, (unsigned long long)nt);
+    fprintf(stderr, "[strling] seconds: total %.3f  waiting for block headers %.3f  copying compressed bytes %.3f  enqueueing + waiting for the device %.3f  "
+                    "draining the device %.3f  fragment lengths %.3f  pair logic + names %.3f  (device front end; %llu scan segments walked twice)\n",
+            secs(t0, now()), t_walk, t_copy, t_push, t_drain, t_frag, t_pair, (unsigned long long)slow_segments);
+  }
+  strl_pinned_free(pin[0]);
+  strl_pinned_free(pin[1]);
   strl_ctx_destroy(ctx);
   return 0;
 }

@@ -38,7 +38,7 @@ constexpr int CNT_QUEUE = 0, CNT_SOFT = 16, CNT_SKIP = 32, CNT_SBW = 48, CNT_SBS
 // counters of the device pair logic (strl_ctx::pair_cnt)
 constexpr int PC_ITEMS = 0, PC_EMIT = 16, PC_ERR = 32, PC_WORDS = 48;
 // counters of a chunked extract (strl_ctx::x_cnt): soft records appended so far, then the sums of the chunks' CNT_* counters
-constexpr int XC_SOFT = 0, XC_SKIP = 1, XC_QUEUE = 2, XC_SBW = 3, XC_SBS = 4, XC_SOFT_ITEMS = 5, XC_WORDS = 16;
+constexpr int XC_SOFT = 0, XC_SKIP = 1, XC_QUEUE = 2, XC_SBW = 3, XC_SBS = 4, XC_SOFT_ITEMS = 5, XC_OVERFLOW = 6, XC_WORDS = 16;
 constexpr uint32_t PAIR_ERR_RUN = 1u, PAIR_ERR_ASSERT = 2u, PAIR_ERR_ITEMS = 4u, PAIR_ERR_EMIT = 8u, PAIR_ERR_LOCAL = 16u;
 
 // murmur3 finaliser: a bijection on 64-bit words, so equality of mixed hashes == equality of hashes
@@ -69,6 +69,7 @@ struct ClusterRun {
   std::vector<uint32_t> b_first, b_count, kept;
 };
 
+namespace strl { struct strl_front; }
 struct strl_ctx;
 int side_join(strl_ctx *c);   // main stream waits for the side streams' pending work (score.hip)
 void rotate_tail(strl_ctx *c);  // make the least recently used set of pair-logic / clustering state the current one (score.hip)
@@ -149,9 +150,15 @@ struct strl_ctx {
   // chunked extract (strl_extract_begin / _add / _finish): per-read state of all chunks so far
   strl::DevBuf x_rows, x_qhash, x_whole, x_soft, x_cnt, g_aux;
   uint64_t x_n = 0, x_soft_cap = 0;
+  // host's knowledge of the device-side soft-clip record count: `x_soft_known` records after `x_soft_known_at` reads
+  uint64_t x_soft_known = 0, x_soft_known_at = 0, x_soft_seen_at = 0;
+  uint32_t *x_soft_seen = nullptr;        // pinned
+  hipEvent_t x_soft_seen_ev = nullptr;
+  bool x_soft_pending = false;
   bool x_open = false, x_mode = false;
   hipEvent_t pev[6] = {};
   double inflate_ms = 0;           // kernel time of the last strl_inflate_blocks call
+  strl::strl_front *front = nullptr;   // device BAM front end (front.h), created by strl_front_begin
   // staging of the pairing arrays for host-memory batches
   strl::DevBuf st_mtid, st_mpos, st_flag, st_qhash;
 };

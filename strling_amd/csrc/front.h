@@ -1,0 +1,97 @@
+// front.h -- internal interface of the device BAM front end (front.hip): BGZF blocks -> inflated bytes -> record table ->
+// the structure-of-arrays batch + pair rows + qname hashes the scorer and the pair logic consume, with no host parsing.
+#pragma once
+#include "common.h"
+
+namespace strl {
+
+constexpr uint32_t FRONT_SEG = 16384;            // bytes of inflated data whose records one lane chains through
+constexpr uint32_t FRONT_CARRY_MAX = 1u << 20;   // room in front of a chunk's inflated bytes for the partial record the previous chunk ended in
+constexpr uint32_t FRONT_NONE = 0xffffffffu;
+constexpr uint32_t FRONT_ERR_INFLATE = 1, FRONT_ERR_RECORD = 2, FRONT_ERR_LSEQ = 4, FRONT_ERR_CARRY = 8;
+
+// device-resident summary of one chunk; the host reads it back after the record scan and again after the parse
+struct FrontInfo {
+  uint32_t start0;        // offset of the first record in the chunk's inflated buffer (set by the carry copy / the host)
+  uint32_t end;           // end of the inflated bytes
+  uint32_t n_records;     // complete records (secondary / supplementary included: they keep their index)
+  uint32_t carry_off, carry_len;   // the trailing partial record, carried into the next chunk
+  uint32_t max_l_seq;
+  uint32_t err;           // FRONT_ERR_*
+  uint32_t inflate_err;   // IW_ERR_* of all blocks
+  uint64_t seq_bytes;     // sum of the records' SEQ sizes, each padded to 16 bytes
+  uint64_t qname_bytes;   // sum of the qname lengths (without the NUL)
+  uint32_t all_ok;        // record scan: every segment's chain arrived exactly at the next segment's guessed start
+  uint32_t slow_segments; // segments the sequential fix walked again
+  uint32_t n_primary;     // parse: records that are neither secondary nor supplementary
+  int32_t last_placed;    // parse: index of the last record with tid >= 0, -1 if none
+  uint32_t tail_primary;  // parse: primary records behind it
+  uint32_t pad;
+};
+
+struct FrontSeg {         // one FRONT_SEG-byte segment of the inflated bytes
+  uint32_t guess;         // guessed first record start inside the segment (FRONT_NONE: none found)
+  uint32_t entry;         // where the walk of this segment started
+  uint32_t exit;          // where it ended (first record start at or behind the segment's end, or the record that does not fit)
+  uint32_t cnt;           // complete records starting in the segment
+  uint32_t seq16;         // their SEQ sizes in 16-byte units
+  uint32_t qn;            // their qname bytes
+  uint32_t max_l_seq;
+  uint32_t flags;         // 1 = the walk stopped inside the data (partial record / end of data), 2 = malformed record
+};
+
+// buffers of one chunk in flight (the context keeps two)
+struct FrontSlot {
+  DevBuf comp, infl, coff, clen, uoff, isize, status, seg, recoff, seqoff, qoff, info, base3;
+  uint32_t n_blocks = 0, n_seg = 0;
+  uint64_t infl_bytes = 0, comp_bytes = 0;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_h2d = nullptr;   // record scan done | parse + scoring done (slot reusable) | compressed bytes on the device
+  bool b_pending = false;
+  FrontInfo *h_info = nullptr;   // pinned: [0] as of the record scan, [1] as of the parse
+};
+
+struct strl_front {
+  hipStream_t st_a = nullptr;        // H2D + inflate + record scan
+  FrontSlot slot[2];
+  int n_ref = 0;
+  uint64_t first_off = 0;            // offset of the first record in the first chunk's inflated bytes
+  uint64_t chunks = 0;               // chunks pushed so far
+  int pending = -1;                  // slot whose stage B has not been enqueued yet
+  // per-read state of all chunks (beside x_rows / x_qhash / x_whole of the chunked extract)
+  DevBuf qref, qarena, fragw, tidflag, tid_seen;   // tid_seen[n_ref]: contigs with a primary record so far
+  uint64_t qarena_used = 0;
+  // SoA of the chunk being scored (chunk-temporary)
+  DevBuf s_tid, s_pos, s_end, s_seqoff, s_lseq, s_clipl, s_clipr, s_mapq, s_cig, s_seq4;
+  double ms_inflate = 0, ms_scan = 0, ms_parse = 0;
+  std::vector<hipEvent_t> tev;       // timing events (STRL_FRONT_TIMING)
+};
+
+struct FrontChunkDesc {   // host view of a chunk handed to front_stage_a
+  const uint8_t *comp;    // compressed bytes (pinned host memory for an asynchronous copy)
+  uint64_t comp_bytes;
+  const uint64_t *coff;   // [n] offset of each block's DEFLATE payload in comp
+  const uint32_t *clen, *isize;
+  uint32_t n_blocks;
+};
+
+// front.hip
+int front_stage_a(strl_ctx *c, strl_front *F, int slot, const FrontChunkDesc &d, bool first);
+struct FrontParseOut {
+  int32_t *tid, *pos, *end;
+  uint32_t *seq_off;
+  uint16_t *l_seq, *clip_l, *clip_r;
+  uint8_t *mapq, *cig, *seq4;
+  strl_pair_rec *rows;     // [n] persistent rows of this chunk's records
+  uint64_t *qhash;
+  uint64_t *qref;          // [n] (qname arena offset << 8) | length
+  uint8_t *qarena;         // arena base
+  uint64_t qarena_at;      // where this chunk's names start
+  uint32_t *fragw;         // [n] flag | (isize in [0, 4095] ? isize : 0xffff) << 16
+  uint8_t *tidflag;        // [n] bit 0 primary, bit 1 placed (tid >= 0)
+};
+int front_parse(strl_ctx *c, strl_front *F, int slot, uint32_t n, const FrontParseOut &o, hipStream_t st);
+int front_gather_names(strl_ctx *c, strl_front *F, const uint32_t *d_ids, uint32_t n, uint64_t *d_ref_out, hipStream_t st);
+int front_copy_names(strl_ctx *c, strl_front *F, const uint64_t *d_ref, const uint64_t *d_dst_off, uint32_t n, uint8_t *d_out, hipStream_t st);
+void front_destroy(strl_front *F);
+
+}  // namespace strl

@@ -1,0 +1,477 @@
+// front.hip -- the BAM front end of `strling extract` on the GPU (gfx950), behind the inflate kernel of bgzf.hip:
+// extract.nim:275-329 iterates the BAM through htslib (one thread: inflate, record by record); here a chunk of BGZF blocks
+// (~16 Ki blocks, ~1 GB inflated) goes through
+//   inflate_kernel   (bgzf.hip)      one wave per BGZF block
+//   carry_kernel                     the partial record the previous chunk ended in is copied in front of this chunk's bytes
+//   rec_guess_kernel                 one lane per 16 KiB segment: first offset from which a chain of plausible BAM records runs
+//   rec_walk_kernel                  one lane per segment: follow block_size from the segment's (guessed) start to its end:
+//                                    record count, SEQ / qname byte sums, where the chain leaves the segment
+//   rec_link_kernel                  one block: every walk must arrive EXACTLY at the next segment's guessed start (checked in
+//                                    parallel); if one does not, a single lane follows the true chain and re-walks the
+//                                    segments that were guessed wrong -- a wrong guess costs time, never a result;
+//                                    then exclusive scans give every segment its first record index / SEQ / qname offset
+//   rec_emit_kernel                  one lane per segment: the walk again, writing each record's offset, SEQ slot, qname slot
+//   rec_parse_kernel                 one lane per record -> strl_read_soa columns, strl_pair_rec row, qname hash, SEQ copy
+//                                    (16-byte aligned), qname bytes into the arena, flag/isize word (fragment lengths)
+//   rec_tail_kernel                  primary records behind the last placed one (extract.nim:326 visits "*" again)
+// The host only walks BGZF headers and copies compressed bytes; it never sees a record.
+#include <string.h>
+#include <algorithm>
+#include "front.h"
+#include "device_util.h"
+
+int strl_inflate_device(strl_ctx *c, const uint8_t *d_comp, uint64_t readable, const uint64_t *d_coff, const uint32_t *d_clen, const uint64_t *d_uoff,
+                        const uint32_t *d_isize, uint32_t n_blocks, uint8_t *d_out, uint32_t *d_err, uint8_t *d_status, hipStream_t st);
+
+namespace strl {
+
+__device__ __forceinline__ uint32_t ld32u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint32_t ld16u(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+// BAM record at q: block_size u32 | refID i32 | pos i32 | l_read_name u8 | mapq u8 | bin u16 | n_cigar_op u16 | flag u16 |
+// l_seq u32 | next_refID i32 | next_pos i32 | tlen i32 | read_name | cigar | seq | qual | tags   (SAM spec 4.2)
+struct RecHdr { uint32_t bs; int32_t l_seq; uint32_t l_qname, n_cigar; };
+// the same validity rule as the host reader's (cli/bam_reader.cpp `header`): what htslib's bam_read1 insists on
+__device__ __forceinline__ bool rec_header(const uint8_t *U, uint32_t q, RecHdr &h) {
+  h.bs = ld32u(U + q);
+  h.l_qname = U[q + 12];
+  h.n_cigar = ld16u(U + q + 16);
+  h.l_seq = (int32_t)ld32u(U + q + 20);
+  return !(h.bs < 32u || h.l_seq < 0 || 32ull + h.l_qname + 4ull * h.n_cigar + ((uint64_t)(uint32_t)h.l_seq + 1) / 2 > h.bs);
+}
+
+// 1 plausible record at q, 0 not a record, -1 too few bytes left to tell
+__device__ int rec_plausible(const uint8_t *U, uint64_t q, uint32_t end, int32_t n_ref, uint64_t &next) {
+  if (q + 36 > end) return -1;
+  RecHdr h;
+  if (!rec_header(U, (uint32_t)q, h) || h.bs > (1u << 26)) return 0;
+  const int32_t ref = (int32_t)ld32u(U + q + 4), pos = (int32_t)ld32u(U + q + 8), nref = (int32_t)ld32u(U + q + 24), npos = (int32_t)ld32u(U + q + 28);
+  if (ref < -1 || ref >= n_ref || nref < -1 || nref >= n_ref || pos < -1 || npos < -1 || h.l_qname < 1u) return 0;
+  if ((uint64_t)(uint32_t)h.l_seq + ((uint64_t)(uint32_t)h.l_seq + 1) / 2 + 32 + h.l_qname + 4ull * h.n_cigar > h.bs) return 0;   // the qualities fit too
+  const uint64_t name_end = q + 36 + h.l_qname - 1;
+  if (name_end < end && U[name_end] != 0) return 0;
+  for (uint64_t c = q + 36; c < name_end && c < end; ++c) if (U[c] < 33 || U[c] > 126) return 0;
+  next = q + 4 + (uint64_t)h.bs;
+  return 1;
+}
+
+// follow the block_size chain from e through the records that START before seg_end
+__device__ void walk_segment(const uint8_t *U, uint32_t e, uint64_t seg_end, uint32_t end, FrontSeg &r) {
+  uint64_t q = e;
+  uint32_t cnt = 0, seq16 = 0, qn = 0, maxl = 0, flags = 0;
+  while (q < seg_end) {
+    if (q + 36 > end) { flags |= 1u; break; }
+    RecHdr h;
+    if (!rec_header(U, (uint32_t)q, h)) { flags |= 3u; break; }
+    if (q + 4 + h.bs > end) { flags |= 1u; break; }
+    ++cnt;
+    seq16 += (((uint32_t)h.l_seq + 1u) / 2u + 15u) / 16u;
+    qn += h.l_qname ? h.l_qname - 1u : 0u;
+    maxl = max(maxl, (uint32_t)h.l_seq);
+    q += 4ull + h.bs;
+  }
+  r.entry = e; r.exit = (uint32_t)q; r.cnt = cnt; r.seq16 = seq16; r.qn = qn; r.max_l_seq = maxl; r.flags = flags;
+}
+
+// the partial record behind the last complete one of the previous chunk goes in front of this chunk's bytes
+__global__ void carry_kernel(const uint8_t *prev_infl, const FrontInfo *prev, uint8_t *infl, FrontInfo *info) {
+  const uint32_t len = prev->carry_len <= FRONT_CARRY_MAX ? prev->carry_len : 0u, off = prev->carry_off;
+  for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) infl[FRONT_CARRY_MAX - len + i] = prev_infl[off + i];
+  if (threadIdx.x == 0) info->start0 = FRONT_CARRY_MAX - len;
+}
+
+__global__ __launch_bounds__(64) void rec_guess_kernel(const uint8_t *U, const FrontInfo *info, FrontSeg *seg, uint32_t n_seg, int32_t n_ref) {
+  const uint32_t s = blockIdx.x * 64u + threadIdx.x;
+  if (s >= n_seg) return;
+  const uint32_t start0 = info->start0, end = info->end, s0 = start0 / FRONT_SEG;
+  uint32_t g = FRONT_NONE;
+  if (s > s0) {
+    const uint64_t from = (uint64_t)s * FRONT_SEG, lim = min((uint64_t)end, from + FRONT_SEG);
+    for (uint64_t o = from; o < lim && g == FRONT_NONE; ++o) {
+      // cheap first test on the candidate's block_size before the full chain
+      if (o + 36 > end) break;
+      const uint32_t bs = ld32u(U + o);
+      if (bs < 32u || bs > (1u << 26)) continue;
+      uint64_t c = o, nx = 0;
+      int n_ok = 0;
+      bool good = true;
+      while (n_ok < 4) {
+        const int r = rec_plausible(U, c, end, n_ref, nx);
+        if (r == 0) { good = false; break; }
+        if (r < 0) { good = n_ok >= 1; break; }     // ran into the end of the data: one whole plausible record is all there is
+        ++n_ok;
+        c = nx;
+      }
+      if (good) g = (uint32_t)o;
+    }
+  }
+  seg[s].guess = g;
+}
+
+__global__ __launch_bounds__(64) void rec_walk_kernel(const uint8_t *U, const FrontInfo *info, FrontSeg *seg, uint32_t n_seg) {
+  const uint32_t s = blockIdx.x * 64u + threadIdx.x;
+  if (s >= n_seg) return;
+  const uint32_t start0 = info->start0, end = info->end, s0 = start0 / FRONT_SEG;
+  FrontSeg r = seg[s];
+  const uint32_t e = s == s0 ? start0 : (s > s0 ? r.guess : FRONT_NONE);
+  if (e == FRONT_NONE) { r.entry = FRONT_NONE; r.exit = FRONT_NONE; r.cnt = 0; r.seq16 = 0; r.qn = 0; r.max_l_seq = 0; r.flags = 0; }
+  else walk_segment(U, e, ((uint64_t)s + 1) * FRONT_SEG, end, r);
+  seg[s] = r;
+}
+
+// One block.  reached[] = scratch of n_seg words; base3 = [3][n_seg] exclusive sums of cnt / seq16 / qn.
+__global__ __launch_bounds__(1024) void rec_link_kernel(const uint8_t *U, FrontSeg *seg, uint32_t n_seg, FrontInfo *info, uint32_t *reached, uint32_t *base3) {
+  __shared__ uint32_t sh_bad, sh_stop, sh_err, sh_maxl, sh_carry, sh_slow;
+  __shared__ uint64_t sh_part[3][1024];
+  const uint32_t t = threadIdx.x, nt = blockDim.x;
+  const uint32_t start0 = info->start0, end = info->end, s0 = start0 / FRONT_SEG;
+  if (t == 0) { sh_bad = 0; sh_stop = 0; sh_err = 0; sh_maxl = 0; sh_carry = end; sh_slow = 0; }
+  for (uint32_t s = t; s < n_seg; s += nt) reached[s] = FRONT_NONE;
+  __syncthreads();
+  // every walked segment says where its chain arrives
+  for (uint32_t s = t; s < n_seg; s += nt) {
+    const FrontSeg r = seg[s];
+    if (r.entry == FRONT_NONE) continue;
+    if ((r.flags & 1u) || r.exit >= end) { atomicAdd(&sh_stop, 1u); continue; }
+    if (atomicExch(&reached[r.exit / FRONT_SEG], r.exit) != FRONT_NONE) atomicOr(&sh_bad, 1u);
+  }
+  __syncthreads();
+  // ... and every segment checks that it is reached exactly where it started (the first one: by nobody)
+  for (uint32_t s = t; s < n_seg; s += nt) {
+    const uint32_t e = seg[s].entry, r = reached[s];
+    const uint32_t want = (s == s0 || e == FRONT_NONE) ? FRONT_NONE : e;
+    if (r != want) atomicOr(&sh_bad, 1u);
+  }
+  __syncthreads();
+  const bool ok = !sh_bad && sh_stop == 1u;
+  if (!ok) {
+    // the exact chain, one lane: segments it visits keep (or get) their walk, everything else holds no records
+    for (uint32_t s = t; s < n_seg; s += nt) reached[s] = 0;      // now: visited flags
+    __syncthreads();
+    if (t == 0) {
+      uint32_t e = start0, slow = 0;
+      for (;;) {
+        const uint32_t s = e / FRONT_SEG;
+        if (s >= n_seg) break;
+        if (seg[s].entry != e) {
+          FrontSeg r = seg[s];
+          walk_segment(U, e, ((uint64_t)s + 1) * FRONT_SEG, end, r);
+          seg[s] = r;
+          ++slow;
+        }
+        reached[s] = 1;
+        if ((seg[s].flags & 1u) || seg[s].exit >= end) break;
+        e = seg[s].exit;
+      }
+      sh_slow = slow;
+    }
+    __syncthreads();
+    for (uint32_t s = t; s < n_seg; s += nt)
+      if (!reached[s]) { seg[s].entry = FRONT_NONE; seg[s].cnt = 0; seg[s].seq16 = 0; seg[s].qn = 0; seg[s].flags = 0; seg[s].max_l_seq = 0; }
+    __syncthreads();
+  }
+  // exclusive scans over the segments (each thread a contiguous run), totals, the carry
+  const uint32_t per = (n_seg + nt - 1) / nt, a = min(n_seg, t * per), b = min(n_seg, a + per);
+  uint64_t s_cnt = 0, s_seq = 0, s_qn = 0;
+  uint32_t maxl = 0, err = 0, carry = FRONT_NONE;
+  for (uint32_t s = a; s < b; ++s) {
+    const FrontSeg r = seg[s];
+    s_cnt += r.cnt; s_seq += r.seq16; s_qn += r.qn;
+    maxl = max(maxl, r.max_l_seq);
+    if (r.entry != FRONT_NONE) {
+      if (r.flags & 2u) err |= FRONT_ERR_RECORD;
+      if (r.flags & 1u) carry = r.exit;
+    }
+  }
+  sh_part[0][t] = s_cnt; sh_part[1][t] = s_seq; sh_part[2][t] = s_qn;
+  if (maxl) atomicMax(&sh_maxl, maxl);
+  if (err) atomicOr(&sh_err, err);
+  if (carry != FRONT_NONE) atomicMin(&sh_carry, carry);
+  __syncthreads();
+  if (t < 3) {      // three lanes, one quantity each: 1024 partial sums
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < nt; ++i) { const uint64_t v = sh_part[t][i]; sh_part[t][i] = run; run += v; }
+    if (t == 0) info->n_records = (uint32_t)run;
+    if (t == 1) info->seq_bytes = run * 16ull;
+    if (t == 2) info->qname_bytes = run;
+  }
+  __syncthreads();
+  uint64_t r0 = sh_part[0][t], r1 = sh_part[1][t], r2 = sh_part[2][t];
+  for (uint32_t s = a; s < b; ++s) {
+    const FrontSeg r = seg[s];
+    base3[s] = (uint32_t)r0; base3[n_seg + s] = (uint32_t)r1; base3[2 * n_seg + s] = (uint32_t)r2;
+    r0 += r.cnt; r1 += r.seq16; r2 += r.qn;
+  }
+  if (t == 0) {
+    const uint32_t co = sh_carry;
+    uint32_t e = sh_err;
+    info->carry_off = co;
+    info->carry_len = end - co;
+    if (end - co > FRONT_CARRY_MAX) e |= FRONT_ERR_CARRY;
+    info->max_l_seq = sh_maxl;
+    info->all_ok = ok ? 1u : 0u;
+    info->slow_segments = sh_slow;
+    info->err |= e | (info->inflate_err ? FRONT_ERR_INFLATE : 0u);
+    info->n_primary = 0; info->last_placed = -1; info->tail_primary = 0;
+  }
+}
+
+__global__ __launch_bounds__(64) void rec_emit_kernel(const uint8_t *U, const FrontInfo *info, const FrontSeg *seg, uint32_t n_seg, const uint32_t *base3,
+                                                      uint32_t *recoff, uint32_t *seqoff, uint32_t *qoff) {
+  const uint32_t s = blockIdx.x * 64u + threadIdx.x;
+  if (s >= n_seg) return;
+  const FrontSeg r = seg[s];
+  if (r.entry == FRONT_NONE || !r.cnt) return;
+  uint32_t i = base3[s], so = base3[n_seg + s], qo = base3[2 * n_seg + s];
+  uint64_t q = r.entry;
+  for (uint32_t k = 0; k < r.cnt; ++k) {
+    RecHdr h;
+    (void)rec_header(U, (uint32_t)q, h);
+    recoff[i] = (uint32_t)q; seqoff[i] = so; qoff[i] = qo;
+    ++i;
+    so += (((uint32_t)h.l_seq + 1u) / 2u + 15u) / 16u;
+    qo += h.l_qname ? h.l_qname - 1u : 0u;
+    q += 4ull + h.bs;
+  }
+}
+
+struct ParseParams {
+  const uint8_t *U;
+  const uint32_t *recoff, *seqoff, *qoff;
+  uint32_t n;
+  FrontInfo *info;
+  FrontParseOut o;
+  uint8_t *tid_seen;      // [n_ref] contigs that have a primary record (the CLI's "extracting chromosome" lines)
+  int32_t n_ref;
+};
+
+__global__ __launch_bounds__(256) void rec_parse_kernel(ParseParams P) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const bool act = i < P.n;
+  bool primary = false;
+  int32_t placed_idx = -1;
+  if (act) {
+    const uint32_t q = P.recoff[i];
+    const uint8_t *R = P.U + q;
+    const int32_t tid = (int32_t)ld32u(R + 4), pos = (int32_t)ld32u(R + 8);
+    const uint32_t l_qname = R[12], mapq = R[13], n_cigar = ld16u(R + 16), flag = ld16u(R + 18);
+    const uint32_t l_seq = ld32u(R + 20);
+    const int32_t mtid = (int32_t)ld32u(R + 24), mpos = (int32_t)ld32u(R + 28), isize = (int32_t)ld32u(R + 32);
+    const uint8_t *name = R + 36, *cg = name + l_qname, *sq = cg + 4u * n_cigar;
+    // cigar: what extract.nim:30-38,83-87,98-119 asks of it (strl_soa_from_records is the host's version), and bam_endpos
+    uint32_t cbits = 0, cl = 0, cr = 0;
+    int64_t rl = 0;
+    if (n_cigar == 0) cbits = STRL_CIG_NONE;
+    else {
+      const uint32_t c0 = ld32u(cg), cL = ld32u(cg + 4u * (n_cigar - 1u));
+      if (n_cigar == 1) cbits |= STRL_CIG_ONE_OP;
+      if (n_cigar == 1 && (c0 & 15u) == 0u) { cbits |= STRL_CIG_SINGLE_M; cl = c0 >> 4; }
+      if ((c0 & 15u) == 4u) { cbits |= STRL_CIG_FIRST_S; cl = c0 >> 4; }
+      if ((cL & 15u) == 4u) { cbits |= STRL_CIG_LAST_S; cr = cL >> 4; }
+      if (!(flag & 4u))
+        for (uint32_t j = 0; j < n_cigar; ++j) {
+          const uint32_t c = ld32u(cg + 4u * j), op = c & 15u;
+          if (op == 0u || op == 2u || op == 3u || op == 7u || op == 8u) rl += c >> 4;
+        }
+    }
+    const int32_t end = (int32_t)((int64_t)pos + (rl ? rl : 1));
+    if (l_seq > (uint32_t)STRL_MAX_READ_LEN) atomicOr(&P.info->err, FRONT_ERR_LSEQ);
+    const uint16_t ls16 = (uint16_t)min(l_seq, 65535u), cl16 = (uint16_t)min(cl, 65535u), cr16 = (uint16_t)min(cr, 65535u);
+    P.o.tid[i] = tid; P.o.pos[i] = pos; P.o.end[i] = end;
+    const uint32_t so = P.seqoff[i];
+    P.o.seq_off[i] = so; P.o.l_seq[i] = ls16; P.o.clip_l[i] = cl16; P.o.clip_r[i] = cr16;
+    P.o.mapq[i] = (uint8_t)mapq; P.o.cig[i] = (uint8_t)cbits;
+    strl_pair_rec row;
+    row.tid = tid; row.pos = pos; row.mtid = mtid; row.mpos = mpos; row.end = end;
+    row.flag = (uint16_t)flag; row.l_seq = ls16; row.clip_l = cl16; row.clip_r = cr16; row.mapq = (uint8_t)mapq; row.cig = (uint8_t)cbits; row.pad = 0;
+    P.o.rows[i] = row;
+    // SEQ as it sits in the record (4-bit codes), to a 16-byte aligned slot; the bytes behind it in the last dword zeroed
+    const uint32_t nb = (l_seq + 1u) / 2u;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(P.o.seq4 + (uint64_t)so * 16u);
+    for (uint32_t j = 0; j * 4u < nb; ++j) {
+      uint32_t w = ld32u(sq + 4u * j);
+      const uint32_t left = nb - 4u * j;
+      if (left < 4u) w &= (1u << (8u * left)) - 1u;
+      dst[j] = w;
+    }
+    // qname: bytes into the arena, FNV-1a hash like strl_qname_hash (the Cache of extract.nim:198,245 is keyed by it)
+    const uint32_t ql = l_qname ? l_qname - 1u : 0u;
+    const uint64_t qat = P.o.qarena_at + P.qoff[i];
+    uint8_t *qd = P.o.qarena + qat;
+    uint64_t hsh = 0xcbf29ce484222325ull;
+    for (uint32_t j = 0; j < ql; ++j) {
+      const uint8_t ch = name[j];
+      qd[j] = ch;
+      hsh ^= ch;
+      hsh *= 0x100000001b3ull;
+    }
+    P.o.qhash[i] = hsh ^ (hsh >> 29);
+    P.o.qref[i] = (qat << 8) | ql;
+    P.o.fragw[i] = flag | ((isize >= 0 && isize <= 4095 ? (uint32_t)isize : 0xffffu) << 16);
+    primary = !(flag & 0x900u);
+    P.o.tidflag[i] = (uint8_t)((primary ? 1u : 0u) | (tid >= 0 ? 2u : 0u));
+    if (tid >= 0) placed_idx = (int32_t)i;
+    if (primary && tid >= 0 && tid < P.n_ref) P.tid_seen[tid] = 1;
+  }
+  // chunk summary: one atomic per wave
+  const uint64_t pm = __ballot(primary);
+  int32_t mx = placed_idx;
+  for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
+  if ((threadIdx.x & 63u) == 0u) {
+    if (pm) atomicAdd(&P.info->n_primary, (uint32_t)__popcll(pm));
+    if (mx >= 0) atomicMax(&P.info->last_placed, mx);
+  }
+}
+
+__global__ void rec_tail_kernel(const uint8_t *tidflag, uint32_t n, FrontInfo *info) {
+  const int32_t lp = info->last_placed;
+  uint32_t c = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    if ((int32_t)i > lp && (tidflag[i] & 1u)) ++c;
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+  if ((threadIdx.x & 63u) == 0u && c) atomicAdd(&info->tail_primary, c);
+}
+
+__global__ void name_refs_kernel(const uint64_t *qref, const uint32_t *ids, uint32_t n, uint64_t *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = qref[ids[i]];
+}
+__global__ void name_copy_kernel(const uint8_t *arena, const uint64_t *ref, const uint64_t *dst_off, uint32_t n, uint8_t *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t r = ref[i];
+  const uint8_t *s = arena + (r >> 8);
+  uint8_t *d = out + dst_off[i];
+  for (uint32_t j = 0; j < (uint32_t)(r & 255u); ++j) d[j] = s[j];
+}
+
+static int tick(strl_front *F, hipStream_t st) {   // STRL_FRONT_TIMING: an event behind every stage
+  static const bool on = getenv("STRL_FRONT_TIMING") != nullptr;
+  if (!on) return STRL_OK;
+  hipEvent_t e;
+  STRL_HIP(hipEventCreate(&e));
+  STRL_HIP(hipEventRecord(e, st));
+  F->tev.push_back(e);
+  return STRL_OK;
+}
+
+// H2D of the chunk's compressed bytes + block table, inflate, record scan; asynchronous on F->st_a.  The slot's previous
+// occupant must have been parsed (ev_b) before its buffers are overwritten: waited for on the device.
+int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, bool first) {
+  FrontSlot &S = F->slot[si];
+  FrontSlot &Pv = F->slot[si ^ 1];
+  hipStream_t st = F->st_a;
+  int rc;
+  const uint32_t nb = d.n_blocks;
+  std::vector<uint64_t> uoff(nb);
+  uint64_t tot = 0;
+  for (uint32_t i = 0; i < nb; ++i) {
+    if (d.coff[i] + d.clen[i] > d.comp_bytes) { set_error("block %u reaches past the chunk's compressed bytes", i); return STRL_ERR_ARG; }
+    uoff[i] = FRONT_CARRY_MAX + tot;
+    tot += d.isize[i];
+  }
+  if (tot + FRONT_CARRY_MAX > 0xf0000000ull) { set_error("chunk inflates to %llu bytes (limit 3.7 GB)", (unsigned long long)tot); return STRL_ERR_ARG; }
+  const uint32_t end = (uint32_t)(FRONT_CARRY_MAX + tot), n_seg = (end + FRONT_SEG - 1) / FRONT_SEG;
+  const uint64_t readable = (d.comp_bytes + 3) & ~(uint64_t)3;
+  const uint64_t rec_cap = tot / 36 + 16;          // no record is shorter than 36 bytes
+  if (S.b_pending) STRL_HIP(hipStreamWaitEvent(st, S.ev_b, 0));
+  auto want = [](uint64_t need) { return (size_t)(need + need / 4 + 4096); };   // head-room: later chunks rarely reallocate
+  if (S.comp.cap < readable + 16 && (rc = S.comp.reserve(want(readable + 16)))) return rc;
+  if (S.infl.cap < (uint64_t)end + 256 && (rc = S.infl.reserve(want((uint64_t)end + 256)))) return rc;
+  if (S.coff.cap < (size_t)nb * 8 && ((rc = S.coff.reserve(want((size_t)nb * 8))) || (rc = S.uoff.reserve(want((size_t)nb * 8))) ||
+                                       (rc = S.clen.reserve(want((size_t)nb * 4))) || (rc = S.isize.reserve(want((size_t)nb * 4))) ||
+                                       (rc = S.status.reserve(want(nb)))))
+    return rc;
+  if (S.seg.cap < (size_t)n_seg * sizeof(FrontSeg) && ((rc = S.seg.reserve(want((size_t)n_seg * sizeof(FrontSeg)))) || (rc = S.base3.reserve(want((size_t)n_seg * 16)))))
+    return rc;
+  if (S.recoff.cap < rec_cap * 4 && ((rc = S.recoff.reserve(want(rec_cap * 4))) || (rc = S.seqoff.reserve(want(rec_cap * 4))) || (rc = S.qoff.reserve(want(rec_cap * 4)))))
+    return rc;
+  if ((rc = S.info.reserve(sizeof(FrontInfo)))) return rc;
+  S.n_blocks = nb; S.n_seg = n_seg; S.infl_bytes = tot; S.comp_bytes = d.comp_bytes;
+  if ((rc = tick(F, st))) return rc;
+  STRL_HIP(hipMemcpyAsync(S.comp.p, d.comp, d.comp_bytes, hipMemcpyHostToDevice, st));
+  STRL_HIP(hipEventRecord(S.ev_h2d, st));
+  STRL_HIP(hipMemsetAsync(static_cast<uint8_t *>(S.comp.p) + d.comp_bytes, 0, 16, st));
+  STRL_HIP(hipMemcpyAsync(S.coff.p, d.coff, (size_t)nb * 8, hipMemcpyHostToDevice, st));
+  STRL_HIP(hipMemcpyAsync(S.uoff.p, uoff.data(), (size_t)nb * 8, hipMemcpyHostToDevice, st));
+  STRL_HIP(hipMemcpyAsync(S.clen.p, d.clen, (size_t)nb * 4, hipMemcpyHostToDevice, st));
+  STRL_HIP(hipMemcpyAsync(S.isize.p, d.isize, (size_t)nb * 4, hipMemcpyHostToDevice, st));
+  FrontInfo hi;
+  memset(&hi, 0, sizeof hi);
+  hi.start0 = (uint32_t)(FRONT_CARRY_MAX + (first ? F->first_off : 0));
+  hi.end = end;
+  hi.last_placed = -1;
+  STRL_HIP(hipMemcpyAsync(S.info.p, &hi, sizeof hi, hipMemcpyHostToDevice, st));
+  STRL_HIP(hipMemsetAsync(static_cast<uint8_t *>(S.infl.p) + end, 0, 256, st));      // the parse may load a dword across the end
+  if ((rc = tick(F, st))) return rc;
+  FrontInfo *info = S.info.as<FrontInfo>();
+  if ((rc = strl_inflate_device(c, S.comp.as<uint8_t>(), readable, S.coff.as<uint64_t>(), S.clen.as<uint32_t>(), S.uoff.as<uint64_t>(), S.isize.as<uint32_t>(), nb,
+                                S.infl.as<uint8_t>(), &info->inflate_err, S.status.as<uint8_t>(), st)))
+    return rc;
+  if ((rc = tick(F, st))) return rc;
+  if (!first) {
+    hipLaunchKernelGGL(carry_kernel, dim3(1), dim3(1024), 0, st, Pv.infl.as<uint8_t>(), Pv.info.as<FrontInfo>(), S.infl.as<uint8_t>(), info);
+    STRL_HIP(hipGetLastError());
+  }
+  const unsigned gb = (n_seg + 63) / 64;
+  hipLaunchKernelGGL(rec_guess_kernel, dim3(gb), dim3(64), 0, st, S.infl.as<uint8_t>(), info, S.seg.as<FrontSeg>(), n_seg, (int32_t)F->n_ref);
+  STRL_HIP(hipGetLastError());
+  hipLaunchKernelGGL(rec_walk_kernel, dim3(gb), dim3(64), 0, st, S.infl.as<uint8_t>(), info, S.seg.as<FrontSeg>(), n_seg);
+  STRL_HIP(hipGetLastError());
+  uint32_t *base3 = S.base3.as<uint32_t>();
+  hipLaunchKernelGGL(rec_link_kernel, dim3(1), dim3(1024), 0, st, S.infl.as<uint8_t>(), S.seg.as<FrontSeg>(), n_seg, info, base3 + 3 * (size_t)n_seg, base3);
+  STRL_HIP(hipGetLastError());
+  hipLaunchKernelGGL(rec_emit_kernel, dim3(gb), dim3(64), 0, st, S.infl.as<uint8_t>(), info, S.seg.as<FrontSeg>(), n_seg, base3, S.recoff.as<uint32_t>(),
+                     S.seqoff.as<uint32_t>(), S.qoff.as<uint32_t>());
+  STRL_HIP(hipGetLastError());
+  if ((rc = tick(F, st))) return rc;
+  STRL_HIP(hipMemcpyAsync(S.h_info, S.info.p, sizeof(FrontInfo), hipMemcpyDeviceToHost, st));
+  STRL_HIP(hipEventRecord(S.ev_a, st));
+  return STRL_OK;
+}
+
+int front_parse(strl_ctx *c, strl_front *F, int si, uint32_t n, const FrontParseOut &o, hipStream_t st) {
+  FrontSlot &S = F->slot[si];
+  if (n) {
+    ParseParams P{S.infl.as<uint8_t>(), S.recoff.as<uint32_t>(), S.seqoff.as<uint32_t>(), S.qoff.as<uint32_t>(), n, S.info.as<FrontInfo>(), o,
+                  F->tid_seen.as<uint8_t>(), (int32_t)F->n_ref};
+    hipLaunchKernelGGL(rec_parse_kernel, dim3((n + 255) / 256), dim3(256), 0, st, P);
+    STRL_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rec_tail_kernel, dim3(std::min<unsigned>((n + 255) / 256, 1024)), dim3(256), 0, st, o.tidflag, n, S.info.as<FrontInfo>());
+    STRL_HIP(hipGetLastError());
+  }
+  STRL_HIP(hipMemcpyAsync(S.h_info + 1, S.info.p, sizeof(FrontInfo), hipMemcpyDeviceToHost, st));
+  return STRL_OK;
+}
+
+int front_gather_names(strl_ctx *c, strl_front *F, const uint32_t *d_ids, uint32_t n, uint64_t *d_ref_out, hipStream_t st) {
+  if (!n) return STRL_OK;
+  hipLaunchKernelGGL(name_refs_kernel, dim3((n + 255) / 256), dim3(256), 0, st, F->qref.as<uint64_t>(), d_ids, n, d_ref_out);
+  STRL_HIP(hipGetLastError());
+  return STRL_OK;
+}
+int front_copy_names(strl_ctx *c, strl_front *F, const uint64_t *d_ref, const uint64_t *d_dst_off, uint32_t n, uint8_t *d_out, hipStream_t st) {
+  if (!n) return STRL_OK;
+  hipLaunchKernelGGL(name_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, F->qarena.as<uint8_t>(), d_ref, d_dst_off, n, d_out);
+  STRL_HIP(hipGetLastError());
+  return STRL_OK;
+}
+
+void front_destroy(strl_front *F) {
+  if (!F) return;
+  for (FrontSlot &S : F->slot) {
+    for (DevBuf *b : {&S.comp, &S.infl, &S.coff, &S.clen, &S.uoff, &S.isize, &S.status, &S.seg, &S.recoff, &S.seqoff, &S.qoff, &S.info, &S.base3}) b->release();
+    if (S.ev_a) (void)hipEventDestroy(S.ev_a);
+    if (S.ev_b) (void)hipEventDestroy(S.ev_b);
+    if (S.ev_h2d) (void)hipEventDestroy(S.ev_h2d);
+    if (S.h_info) (void)hipHostFree(S.h_info);
+  }
+  for (DevBuf *b : {&F->qref, &F->qarena, &F->fragw, &F->tidflag, &F->tid_seen, &F->s_tid, &F->s_pos, &F->s_end, &F->s_seqoff, &F->s_lseq, &F->s_clipl, &F->s_clipr, &F->s_mapq,
+                    &F->s_cig, &F->s_seq4})
+    b->release();
+  for (hipEvent_t e : F->tev) (void)hipEventDestroy(e);
+  if (F->st_a) (void)hipStreamDestroy(F->st_a);
+  delete F;
+}
+
+}  // namespace strl

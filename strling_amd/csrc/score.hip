@@ -16,6 +16,7 @@
 #include <string.h>
 #include <algorithm>
 #include "common.h"
+#include "front.h"
 #include "device_util.h"
 #include "score_core.h"
 #include "score_tables.h"
@@ -825,6 +826,9 @@ void strl_ctx_destroy(strl_ctx *c) {
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   for (auto &a : c->alt) if (a.stream2) (void)hipStreamSynchronize(a.stream2);
   (void)hipStreamSynchronize(c->stream);
+  if (c->x_soft_seen_ev) (void)hipEventDestroy(c->x_soft_seen_ev);
+  if (c->x_soft_seen) (void)hipHostFree(c->x_soft_seen);
+  if (c->front) { if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a); strl::front_destroy(c->front); c->front = nullptr; }
   strl::DevBuf *bufs[] = {&c->lut, &c->thr, &c->g_tid, &c->g_bins, &c->g_start, &c->g_pmax, &c->queue, &c->soft_queue, &c->counters,
                           &c->soft_tmp, &c->sb_whole, &c->sb_soft, &c->queue_r, &c->soft_dense, &c->sb_state_w, &c->sb_state_s, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
                           &c->st_mapq, &c->st_cig, &c->st_seq4, &c->st_whole, &c->st_soft, &c->st_text,
@@ -1235,7 +1239,7 @@ __global__ void soft_append_kernel(const strl_soft_rec *src, const uint32_t *cnt
                                    uint32_t dst_cap, uint32_t *xc) {
   __shared__ uint32_t base_sh;
   uint32_t n = cnt[CNT_SOFT];
-  if (n > src_cap) n = src_cap;
+  if (n > src_cap) n = src_cap;                 // (cannot happen: the per-chunk queue holds two records per read)
   if (threadIdx.x == 0) {
     base_sh = atomicAdd(&xc[XC_SOFT], n);   // one block: this is the only writer of the counter
     xc[XC_SKIP] += cnt[CNT_SKIP]; xc[XC_QUEUE] += cnt[CNT_QUEUE]; xc[XC_SBW] += cnt[CNT_SBW]; xc[XC_SBS] += cnt[CNT_SBS];
@@ -1248,6 +1252,7 @@ __global__ void soft_append_kernel(const strl_soft_rec *src, const uint32_t *cnt
     s.read_side += read_base << 1;
     if (base + i < dst_cap) dst[base + i] = s;
   }
+  if (threadIdx.x == 0 && (cnt[CNT_SOFT] > src_cap || (uint64_t)base + n > dst_cap)) xc[XC_OVERFLOW] = 1;   // reported by strl_treads_fetch
 }
 }  // namespace strl
 
@@ -1263,7 +1268,50 @@ int strl_extract_begin(strl_ctx *c, uint64_t n_reads_hint) {
     return rc;
   STRL_HIP(hipMemsetAsync(c->x_cnt.p, 0, XC_WORDS * 4, c->stream));
   if ((rc = bloom_reset(c, std::max<uint64_t>(hint, 1ull << 28)))) return rc;   // 16 MB: sized for a whole genome of reads
-  c->x_n = 0; c->x_soft_cap = 0; c->x_open = true;
+  c->x_n = 0; c->x_soft_cap = c->x_soft.cap / sizeof(strl_soft_rec); c->x_open = true;
+  c->x_soft_known = 0; c->x_soft_known_at = 0;
+  if (c->x_soft_pending) { STRL_HIP(hipEventSynchronize(c->x_soft_seen_ev)); c->x_soft_pending = false; }
+  return STRL_OK;
+}
+
+// the per-chunk part shared by strl_extract_add and the device front end: score the device-resident chunk `d` whose rows and
+// qname hashes already sit at x_rows / x_qhash [at, at + n), append its soft-clip records
+static int extract_add_scored(strl_ctx *c, const strl_read_soa *d, uint64_t at) {
+  const uint64_t n = d->n;
+  int rc;
+  // Soft-clip records: a chunk can add two per read (its hard bound, which the per-chunk queue is sized for), the typical
+  // rate is a few per cent.  The running total lives on the device; the host keeps an upper bound of it -- the last total it
+  // has seen (read back asynchronously behind every chunk) plus two per read added since -- and grows x_soft ahead of that.
+  if (c->x_soft_seen_ev) {
+    while (c->x_soft_pending && hipEventQuery(c->x_soft_seen_ev) == hipSuccess) {
+      c->x_soft_known = *c->x_soft_seen;
+      c->x_soft_known_at = c->x_soft_seen_at;
+      c->x_soft_pending = false;
+    }
+  }
+  const uint64_t bound = c->x_soft_known + 2 * ((at + n) - c->x_soft_known_at) + 2;
+  if (bound > c->x_soft_cap) {
+    c->x_soft_cap = std::max<uint64_t>(bound, (at + n) / 4 + 65536);
+    if ((rc = c->x_soft.grow((size_t)c->x_soft_cap * sizeof(strl_soft_rec), c->x_soft.cap, c->stream))) return rc;
+  }
+  const strl_pair_soa dp{c->x_rows.as<strl_pair_rec>() + at, c->x_qhash.as<uint64_t>() + at};
+  const uint64_t chunk_soft = 2 * n + 2;
+  if ((rc = c->st_soft.reserve((size_t)chunk_soft * sizeof(strl_soft_rec)))) return rc;
+  if ((rc = score_device(c, d, c->x_whole.as<uint32_t>() + at, c->st_soft.as<strl_soft_rec>(), chunk_soft, nullptr, nullptr, false, &dp, false))) return rc;
+  hipLaunchKernelGGL(strl::soft_append_kernel, dim3(1), dim3(1024), 0, c->stream, c->st_soft.as<strl_soft_rec>(), c->counters.as<uint32_t>(), (uint32_t)chunk_soft,
+                     (uint32_t)at, c->x_soft.as<strl_soft_rec>(), (uint32_t)std::min<uint64_t>(c->x_soft_cap, 0xffffffffull), c->x_cnt.as<uint32_t>());
+  STRL_HIP(hipGetLastError());
+  if (!c->x_soft_seen_ev) {
+    STRL_HIP(hipEventCreateWithFlags(&c->x_soft_seen_ev, hipEventDisableTiming));
+    STRL_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->x_soft_seen), 64, hipHostMallocDefault));
+  }
+  if (!c->x_soft_pending) {
+    STRL_HIP(hipMemcpyAsync(c->x_soft_seen, c->x_cnt.as<uint32_t>() + XC_SOFT, 4, hipMemcpyDeviceToHost, c->stream));
+    STRL_HIP(hipEventRecord(c->x_soft_seen_ev, c->stream));
+    c->x_soft_seen_at = at + n;
+    c->x_soft_pending = true;
+  }
+  c->x_n = at + n;
   return STRL_OK;
 }
 
@@ -1279,26 +1327,12 @@ int strl_extract_add(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *p
   if ((rc = c->x_rows.grow((size_t)(at + n) * sizeof(strl_pair_rec), (size_t)at * sizeof(strl_pair_rec), c->stream)) ||
       (rc = c->x_qhash.grow((size_t)(at + n) * 8, (size_t)at * 8, c->stream)) || (rc = c->x_whole.grow((size_t)(at + n) * 4, (size_t)at * 4, c->stream)))
     return rc;
-  // soft-clip records: a chunk can add two per read, the typical rate is a few per cent: keep n / 4 + 64 Ki free behind the
-  // records counted so far (the count lives on the device; it is bounded by what earlier chunks could have added)
-  c->x_soft_cap = std::max<uint64_t>(c->x_soft_cap, (at + n) / 4 + 65536);
-  if ((rc = c->x_soft.grow((size_t)c->x_soft_cap * sizeof(strl_soft_rec), c->x_soft.cap, c->stream))) return rc;
   strl_read_soa d = *s;
   const hipMemcpyKind kind = s->mem == STRL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   if (s->mem != STRL_MEM_DEVICE && (rc = stage_batch(c, s, nullptr, &d, nullptr))) return rc;
-  strl_pair_rec *rows = c->x_rows.as<strl_pair_rec>() + at;
-  uint64_t *qh = c->x_qhash.as<uint64_t>() + at;
-  STRL_HIP(hipMemcpyAsync(rows, pp->rec, (size_t)n * sizeof(strl_pair_rec), kind, c->stream));
-  STRL_HIP(hipMemcpyAsync(qh, pp->qhash, (size_t)n * 8, kind, c->stream));
-  const strl_pair_soa dp{rows, qh};
-  const uint64_t chunk_soft = std::min<uint64_t>(2 * n + 2, n / 4 + 65536);
-  if ((rc = c->st_soft.reserve((size_t)chunk_soft * sizeof(strl_soft_rec)))) return rc;
-  if ((rc = score_device(c, &d, c->x_whole.as<uint32_t>() + at, c->st_soft.as<strl_soft_rec>(), chunk_soft, nullptr, nullptr, false, &dp, false))) return rc;
-  hipLaunchKernelGGL(strl::soft_append_kernel, dim3(1), dim3(1024), 0, c->stream, c->st_soft.as<strl_soft_rec>(), c->counters.as<uint32_t>(), (uint32_t)chunk_soft,
-                     (uint32_t)at, c->x_soft.as<strl_soft_rec>(), (uint32_t)std::min<uint64_t>(c->x_soft_cap, 0xffffffffull), c->x_cnt.as<uint32_t>());
-  STRL_HIP(hipGetLastError());
-  c->x_n = at + n;
-  return STRL_OK;
+  STRL_HIP(hipMemcpyAsync(c->x_rows.as<strl_pair_rec>() + at, pp->rec, (size_t)n * sizeof(strl_pair_rec), kind, c->stream));
+  STRL_HIP(hipMemcpyAsync(c->x_qhash.as<uint64_t>() + at, pp->qhash, (size_t)n * 8, kind, c->stream));
+  return extract_add_scored(c, &d, at);
 }
 
 int strl_extract_finish(strl_ctx *c, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap) {
@@ -1337,6 +1371,7 @@ int strl_treads_fetch(strl_ctx *c, strl_tread *out, uint64_t cap, uint64_t *n_ou
     stats->n_stage_b_whole = raw[CNT_SBW]; stats->n_stage_b_soft = raw[CNT_SBS];
   }
   if (n_out) *n_out = pc[PC_EMIT];
+  if (c->x_mode && xc[XC_OVERFLOW]) { set_error("chunked extract: soft-clip records of a chunk were dropped (%u kept of %u)", xc[XC_SOFT], xc[XC_SOFT_ITEMS]); return STRL_ERR_CAPACITY; }
   if (raw[CNT_SOFT] > c->ex_soft_cap) { set_error("soft-clip queue overflow: %u items, capacity %llu (raise item_cap)", raw[CNT_SOFT], (unsigned long long)c->ex_soft_cap); return STRL_ERR_CAPACITY; }
   const uint32_t err = pc[PC_ERR];
   if (err & PAIR_ERR_ITEMS) { set_error("pair logic: %u join items, capacity %u (raise item_cap)", pc[PC_ITEMS], c->pair_item_cap); return STRL_ERR_CAPACITY; }
@@ -1362,5 +1397,203 @@ int strl_ctx_pair_times(strl_ctx *c, double ms[5]) {
   }
   return STRL_OK;
 }
+
+
+// ---- `strling extract` with the BAM front end on the device (front.hip): the host hands over BGZF blocks, never a record ----
+static int front_fill_done(strl_ctx *c, strl::FrontSlot &S, strl_front_chunk *done) {
+  STRL_HIP(hipEventSynchronize(S.ev_b));
+  S.b_pending = false;
+  const strl::FrontInfo &I = S.h_info[1];
+  if (I.err & strl::FRONT_ERR_LSEQ) { set_error("a record's l_seq is outside [0, %d]", STRL_MAX_READ_LEN); return STRL_ERR_ARG; }
+  if (done) {
+    done->n_records = I.n_records; done->n_primary = I.n_primary; done->last_placed = I.last_placed; done->tail_primary = I.tail_primary;
+    done->max_l_seq = I.max_l_seq; done->scan_slow_segments = I.slow_segments;
+  }
+  return STRL_OK;
+}
+
+// parse + score the chunk in slot si (its record scan was enqueued earlier): waits on the HOST for the scan's counts -- the
+// next chunk's inflate is already queued behind it, so the device does not idle
+static int front_stage_b(strl_ctx *c, strl::strl_front *F, int si) {
+  using namespace strl;
+  FrontSlot &S = F->slot[si];
+  STRL_HIP(hipEventSynchronize(S.ev_a));
+  const FrontInfo I = S.h_info[0];
+  if (I.err & FRONT_ERR_INFLATE) { set_error("invalid BGZF block (DEFLATE data or ISIZE)"); return STRL_ERR_FORMAT; }
+  if (I.err & FRONT_ERR_RECORD) { set_error("malformed BAM record"); return STRL_ERR_FORMAT; }
+  if (I.err & FRONT_ERR_CARRY) { set_error("BAM record of more than %u bytes", FRONT_CARRY_MAX); return STRL_ERR_FORMAT; }
+  const uint64_t n = I.n_records, at = c->x_n;
+  if (at + n > 0x7ffffff0ull) { set_error("chunked extract: more than 2^31 - 16 records"); return STRL_ERR_ARG; }
+  if (I.max_l_seq > (uint32_t)STRL_MAX_READ_LEN) { set_error("a record's l_seq %u is outside [0, %d]", I.max_l_seq, STRL_MAX_READ_LEN); return STRL_ERR_ARG; }
+  int rc;
+  const uint64_t n1 = std::max<uint64_t>(n, 1);
+  if ((rc = c->x_rows.grow((size_t)(at + n1) * sizeof(strl_pair_rec), (size_t)at * sizeof(strl_pair_rec), c->stream)) ||
+      (rc = c->x_qhash.grow((size_t)(at + n1) * 8, (size_t)at * 8, c->stream)) || (rc = c->x_whole.grow((size_t)(at + n1) * 4, (size_t)at * 4, c->stream)) ||
+      (rc = F->qref.grow((size_t)(at + n1) * 8, (size_t)at * 8, c->stream)) || (rc = F->fragw.grow((size_t)(at + n1) * 4, (size_t)at * 4, c->stream)) ||
+      (rc = F->qarena.grow((size_t)(F->qarena_used + I.qname_bytes + 16), (size_t)F->qarena_used, c->stream)))
+    return rc;
+  const uint64_t seq_bytes = I.seq_bytes + 64;
+  auto room = [](uint64_t need) { return (size_t)(need + need / 4 + 4096); };
+  if (F->s_tid.cap < n1 * 4 && ((rc = F->s_tid.reserve(room(n1 * 4))) || (rc = F->s_pos.reserve(room(n1 * 4))) || (rc = F->s_end.reserve(room(n1 * 4))) ||
+                                (rc = F->s_seqoff.reserve(room(n1 * 4))) || (rc = F->s_lseq.reserve(room(n1 * 2))) || (rc = F->s_clipl.reserve(room(n1 * 2))) ||
+                                (rc = F->s_clipr.reserve(room(n1 * 2))) || (rc = F->s_mapq.reserve(room(n1))) || (rc = F->s_cig.reserve(room(n1))) ||
+                                (rc = F->tidflag.reserve(room(n1)))))
+    return rc;
+  if (F->s_seq4.cap < seq_bytes && (rc = F->s_seq4.reserve(room(seq_bytes)))) return rc;
+  FrontParseOut o;
+  o.tid = F->s_tid.as<int32_t>(); o.pos = F->s_pos.as<int32_t>(); o.end = F->s_end.as<int32_t>(); o.seq_off = F->s_seqoff.as<uint32_t>();
+  o.l_seq = F->s_lseq.as<uint16_t>(); o.clip_l = F->s_clipl.as<uint16_t>(); o.clip_r = F->s_clipr.as<uint16_t>();
+  o.mapq = F->s_mapq.as<uint8_t>(); o.cig = F->s_cig.as<uint8_t>(); o.seq4 = F->s_seq4.as<uint8_t>();
+  o.rows = c->x_rows.as<strl_pair_rec>() + at; o.qhash = c->x_qhash.as<uint64_t>() + at; o.qref = F->qref.as<uint64_t>() + at;
+  o.qarena = F->qarena.as<uint8_t>(); o.qarena_at = F->qarena_used; o.fragw = F->fragw.as<uint32_t>() + at; o.tidflag = F->tidflag.as<uint8_t>();
+  // (the scan finished: the host waited for it.  The previous chunk's scorer may still read the chunk-temporary columns:
+  // same stream, so the parse queues behind it.)
+  if ((rc = front_parse(c, F, si, (uint32_t)n, o, c->stream))) return rc;
+  F->qarena_used += I.qname_bytes;
+  if (n) {
+    strl_read_soa d{};
+    d.n = n; d.tid = o.tid; d.pos = o.pos; d.end = o.end; d.seq_off = o.seq_off; d.l_seq = o.l_seq; d.clip_l = o.clip_l; d.clip_r = o.clip_r;
+    d.mapq = o.mapq; d.cig = o.cig; d.seq4 = o.seq4; d.seq4_bytes = seq_bytes; d.max_l_seq = I.max_l_seq; d.mem = STRL_MEM_DEVICE;
+    if ((rc = extract_add_scored(c, &d, at))) return rc;
+  }
+  STRL_HIP(hipEventRecord(S.ev_b, c->stream));
+  S.b_pending = true;
+  return STRL_OK;
+}
+
+int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, uint64_t n_reads_hint) {
+  if (!c || n_ref < 0) { set_error("bad argument"); return STRL_ERR_ARG; }
+  int rc = strl_extract_begin(c, n_reads_hint);
+  if (rc) return rc;
+  if (c->front) { if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a); strl::front_destroy(c->front); c->front = nullptr; }
+  strl::strl_front *F = new strl::strl_front();
+  c->front = F;
+  F->n_ref = n_ref; F->first_off = first_record_offset;
+  STRL_HIP(hipStreamCreateWithFlags(&F->st_a, hipStreamNonBlocking));
+  for (strl::FrontSlot &S : F->slot) {
+    STRL_HIP(hipEventCreateWithFlags(&S.ev_a, hipEventDisableTiming));
+    STRL_HIP(hipEventCreateWithFlags(&S.ev_b, hipEventDisableTiming));
+    STRL_HIP(hipEventCreateWithFlags(&S.ev_h2d, hipEventDisableTiming));
+    STRL_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_info), 2 * sizeof(strl::FrontInfo), hipHostMallocDefault));
+  }
+  if ((rc = F->tid_seen.reserve((size_t)n_ref + 16))) return rc;
+  STRL_HIP(hipMemsetAsync(F->tid_seen.p, 0, (size_t)n_ref + 16, c->stream));
+  const uint64_t hint = std::max<uint64_t>(n_reads_hint, 1 << 20);
+  if ((rc = F->qref.grow((size_t)hint * 8, 0, c->stream)) || (rc = F->fragw.grow((size_t)hint * 4, 0, c->stream)) || (rc = F->qarena.grow((size_t)hint * 24, 0, c->stream)))
+    return rc;
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  return STRL_OK;
+}
+
+int strl_front_push(strl_ctx *c, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize, uint32_t n_blocks,
+                    strl_front_chunk *done, int *n_done) {
+  if (!c || !c->front || !c->x_open || (n_blocks && (!comp || !coff || !clen || !isize))) { set_error("strl_front_push: bad argument / no strl_front_begin"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  strl::strl_front *F = c->front;
+  if (n_done) *n_done = 0;
+  if (!n_blocks) return STRL_OK;
+  const int si = (int)(F->chunks & 1);
+  int rc;
+  if (F->slot[si].b_pending) {           // the chunk before the previous one: its slot is reused now
+    if ((rc = front_fill_done(c, F->slot[si], done))) return rc;
+    if (n_done) *n_done = 1;
+  }
+  const strl::FrontChunkDesc d{comp, comp_bytes, coff, clen, isize, n_blocks};
+  if ((rc = strl::front_stage_a(c, F, si, d, F->chunks == 0))) return rc;
+  ++F->chunks;
+  if (F->chunks >= 2 && (rc = front_stage_b(c, F, si ^ 1))) return rc;
+  return STRL_OK;
+}
+
+int strl_front_finish(strl_ctx *c, strl_front_chunk done[2], int *n_done) {
+  if (!c || !c->front) { set_error("strl_front_finish without strl_front_begin"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  strl::strl_front *F = c->front;
+  if (n_done) *n_done = 0;
+  int rc, k = 0;
+  if (!F->chunks) return STRL_OK;
+  const int last = (int)((F->chunks - 1) & 1);
+  if ((rc = front_stage_b(c, F, last))) return rc;
+  for (int si : {last ^ 1, last}) {
+    if (!F->slot[si].b_pending) continue;
+    if ((rc = front_fill_done(c, F->slot[si], done ? &done[k] : nullptr))) return rc;
+    ++k;
+  }
+  if (n_done) *n_done = k;
+  static const bool timing = getenv("STRL_FRONT_TIMING") != nullptr;
+  if (timing && F->tev.size() >= 5) {       // per chunk: [0] start [1] copies queued [2] inflate done [3] ... scan done
+    STRL_HIP(hipStreamSynchronize(F->st_a));
+    double h2d = 0, inf = 0, scan = 0;
+    for (size_t i = 0; i + 4 < F->tev.size() + 1 && i + 3 < F->tev.size(); i += 4) {
+      float a = 0, b = 0, d = 0;
+      (void)hipEventElapsedTime(&a, F->tev[i], F->tev[i + 1]);
+      (void)hipEventElapsedTime(&b, F->tev[i + 1], F->tev[i + 2]);
+      (void)hipEventElapsedTime(&d, F->tev[i + 2], F->tev[i + 3]);
+      h2d += a; inf += b; scan += d;
+    }
+    fprintf(stderr, "[strling] device front end, ms over %llu chunks: copies to the device %.1f  inflate %.1f  record scan %.1f\n", (unsigned long long)F->chunks, h2d, inf, scan);
+  }
+  return STRL_OK;
+}
+
+int strl_front_fragwords(strl_ctx *c, uint64_t first, uint64_t n, uint32_t *out) {
+  if (!c || !c->front || (n && !out) || first + n > c->x_n) { set_error("strl_front_fragwords: bad range"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  if (n) STRL_HIP(hipMemcpyAsync(out, c->front->fragw.as<uint32_t>() + first, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  return STRL_OK;
+}
+
+int strl_front_tids(strl_ctx *c, uint8_t *seen, int32_t n_ref) {
+  if (!c || !c->front || n_ref > c->front->n_ref || (n_ref && !seen)) { set_error("strl_front_tids: bad argument"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  if (n_ref) STRL_HIP(hipMemcpyAsync(seen, c->front->tid_seen.p, (size_t)n_ref, hipMemcpyDeviceToHost, c->stream));
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  return STRL_OK;
+}
+
+int strl_front_qnames(strl_ctx *c, const int64_t *record_ids, uint64_t n, uint64_t *qname_off, char *names, uint64_t cap, uint64_t *need) {
+  if (!c || !c->front || (n && (!record_ids || !qname_off))) { set_error("strl_front_qnames: bad argument"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  strl::strl_front *F = c->front;
+  if (qname_off) qname_off[0] = 0;
+  if (need) *need = 0;
+  if (!n) return STRL_OK;
+  if (n > 0x7fffffffull) { set_error("strl_front_qnames: too many names"); return STRL_ERR_ARG; }
+  std::vector<uint32_t> ids((size_t)n);
+  for (uint64_t i = 0; i < n; ++i) {
+    if (record_ids[i] < 0 || (uint64_t)record_ids[i] >= c->x_n) { set_error("strl_front_qnames: record %lld out of range", (long long)record_ids[i]); return STRL_ERR_ARG; }
+    ids[(size_t)i] = (uint32_t)record_ids[i];
+  }
+  strl::DevBuf d_ids, d_ref, d_off, d_out;
+  int rc;
+  if ((rc = d_ids.reserve((size_t)n * 4)) || (rc = d_ref.reserve((size_t)n * 8)) || (rc = d_off.reserve((size_t)n * 8))) return rc;
+  STRL_HIP(hipMemcpyAsync(d_ids.p, ids.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  if ((rc = strl::front_gather_names(c, F, d_ids.as<uint32_t>(), (uint32_t)n, d_ref.as<uint64_t>(), c->stream))) return rc;
+  std::vector<uint64_t> ref((size_t)n);
+  STRL_HIP(hipMemcpyAsync(ref.data(), d_ref.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  uint64_t tot = 0;
+  for (uint64_t i = 0; i < n; ++i) { qname_off[i] = tot; tot += ref[(size_t)i] & 255u; }
+  qname_off[n] = tot;
+  if (need) *need = tot;
+  if (tot > cap || (tot && !names)) { d_ids.release(); d_ref.release(); d_off.release(); set_error("strl_front_qnames: %llu bytes of names, capacity %llu", (unsigned long long)tot, (unsigned long long)cap); return STRL_ERR_CAPACITY; }
+  if (tot) {
+    if ((rc = d_out.reserve((size_t)tot))) return rc;
+    STRL_HIP(hipMemcpyAsync(d_off.p, qname_off, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    if ((rc = strl::front_copy_names(c, F, d_ref.as<uint64_t>(), d_off.as<uint64_t>(), (uint32_t)n, d_out.as<uint8_t>(), c->stream))) return rc;
+    STRL_HIP(hipMemcpyAsync(names, d_out.p, (size_t)tot, hipMemcpyDeviceToHost, c->stream));
+    STRL_HIP(hipStreamSynchronize(c->stream));
+  }
+  d_ids.release(); d_ref.release(); d_off.release(); d_out.release();
+  return STRL_OK;
+}
+
+void *strl_pinned_alloc(uint64_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void strl_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
 
 }  // extern "C"

@@ -1,0 +1,94 @@
+"""The BAM front end on the device (front.hip: inflate -> record scan -> parse -> scorer -> pair logic) against the path that
+parses the same records on the host: treads field by field in .bin order, their qnames, the fragment-length words of every
+record, chunk summaries.  Small chunks and odd block sizes put records across BGZF blocks, 16 KiB scan segments and chunks."""
+import os
+
+import numpy as np
+import pytest
+
+from strling_amd import api, bamio, synth
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("tid", "position", "repeat", "flag", "split", "mapping_quality", "repeat_count", "align_length", "qname_id")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _host_reference(ctx, rec, g, med):
+    ctx.set_opts(0.8, 40, med)
+    ctx.set_genome(g)
+    exp, _ = ctx.extract(rec)
+    return exp
+
+
+def _check(ctx, rec, g, path, chunk_blocks, exp):
+    from oracle import oracle as O
+    med = O.median(synth.frag_hist(rec))
+    ctx.set_opts(0.8, 40, med)
+    ctx.set_genome(g)
+    got = ctx.extract_bam_device(path, chunk_blocks=chunk_blocks)
+    assert got["n_records"] == rec.n
+    assert [t[0] for t in got["targets"]] == [t[0] for t in rec.targets]
+    for f in FIELDS:
+        assert np.array_equal(got["treads"][f], exp[f]), (f, chunk_blocks)
+    assert got["qnames"] == [rec.qname(int(i)) for i in exp["qname_id"]]
+    isz = rec.isize if rec.isize is not None else np.zeros(rec.n, np.int32)
+    fw = rec.flag.astype(np.uint32) | (np.where((isz >= 0) & (isz <= 4095), isz, 0xffff).astype(np.uint32) << 16)
+    assert np.array_equal(got["fragwords"], fw)
+    prim = (rec.flag & 0x900) == 0
+    assert sum(c["n_primary"] for c in got["chunks"]) == int(prim.sum())
+    n_tail = 0
+    while n_tail < rec.n and rec.tid[rec.n - 1 - n_tail] < 0:
+        n_tail += 1
+    assert got["n_tail"] == n_tail
+    if n_tail < rec.n:      # the last chunk with a placed record counts the primary records behind it
+        last = [c for c in got["chunks"] if c["last_placed"] >= 0][-1]
+        assert last["tail_primary"] <= int(prim[rec.n - n_tail:].sum())
+    seen = np.zeros(len(rec.targets), np.uint8)
+    seen[np.unique(rec.tid[prim & (rec.tid >= 0)])] = 1
+    assert np.array_equal(got["tids_seen"], seen)
+    return got
+
+
+@pytest.mark.parametrize("n_pairs,block,chunk_blocks", [(3000, 0xFF00, 16384), (6000, 4099, 7), (6000, 0xFF00, 3), (20000, 30011, 5)])
+def test_front_end_matches_the_host_parsed_path(ctx, tmp_path, n_pairs, block, chunk_blocks):
+    from oracle import oracle as O
+    rec, g = synth.synth_wgs(n_pairs, seed=11 + n_pairs, contig_len=600_000)
+    med = O.median(synth.frag_hist(rec))
+    exp = _host_reference(ctx, rec, g, med)
+    assert len(exp) > 50
+    path = str(tmp_path / "a.bam")
+    bamio.write_bam(path, rec, level=6 if block < 0xFF00 else 1, block=block, index=False)
+    got = _check(ctx, rec, g, path, chunk_blocks, exp)
+    assert len(got["chunks"]) >= 1
+    if chunk_blocks < 100:
+        assert len(got["chunks"]) > 3
+
+
+def test_front_end_against_the_oracle(ctx, tmp_path):
+    """... and the whole thing against the CPU restatement of the reference (not only the product's other path)"""
+    from oracle import oracle as O
+    rec, g = synth.synth_wgs(8000, seed=5, contig_len=800_000)
+    med = O.median(synth.frag_hist(rec))
+    exp = O.extract(rec, g, O.make_opts(med, 0.8, 40))
+    path = str(tmp_path / "o.bam")
+    bamio.write_bam(path, rec, level=1, block=20011, index=False)
+    _check(ctx, rec, g, path, 9, exp)
+
+
+def test_front_end_many_soft_clips_per_chunk(ctx, tmp_path):
+    """more than a quarter of the reads of a chunk carry a scored soft clip (adapter-like libraries): every soft-clip record
+    must survive the chunked extract (the per-chunk queue holds two per read)"""
+    from oracle import oracle as O
+    rec, g = synth.synth_wgs(5000, seed=23, contig_len=500_000, soft_frac=0.6)
+    med = O.median(synth.frag_hist(rec))
+    exp = O.extract(rec, g, O.make_opts(med, 0.8, 40))
+    path = str(tmp_path / "s.bam")
+    bamio.write_bam(path, rec, level=1, index=False)
+    _check(ctx, rec, g, path, 16384, exp)
