@@ -32,7 +32,7 @@
 #include <string.h>
 #define IW_DEV inline
 #define IW_FOR_LANES for (int lane = 0; lane < 64; ++lane)
-#define IW_U(x) (x)
+#define IW_U(...) (__VA_ARGS__)
 #define IW_RCP(x) (1.0f / (x))
 #define IW_SYNC() ((void)0)
 #define IW_BALLOT(out, expr)                                          \
@@ -71,7 +71,7 @@ IW_DEV void iw_st8(const IwBuf &b, uint32_t off, uint32_t v) { if (off < b.n) b.
 #include <hip/hip_runtime.h>
 #define IW_DEV __device__ __forceinline__
 #define IW_FOR_LANES for (int lane = (int)threadIdx.x, iw_once_ = 1; iw_once_; iw_once_ = 0)
-#define IW_U(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#define IW_U(...) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(__VA_ARGS__)))
 #define IW_RCP(x) __builtin_amdgcn_rcpf(x)
 #define IW_SYNC()                                              \
   do {                                                         \
@@ -114,8 +114,9 @@ constexpr uint32_t IW_OOB = 0x80000000u;   // an offset no descriptor of this fi
 constexpr int IW_LIT_ROOT = 10, IW_DIST_ROOT = 8, IW_CL_ROOT = 7;
 
 // Table entry (u32): [3:0] code length (0 = "not in the first-level table": canonical search / invalid), [7:4] extra bits,
-// [9:8] kind (0 literal / plain value, 1 base value of a length or distance code, 2 end of block), [31:16] value.
+// [9:8] kind (0 literal / plain value, 1 base value of a length or distance code, 2 end of block), [12] literal, [31:16] value.
 constexpr uint32_t IW_KIND_BASE = 1u << 8, IW_KIND_EOB = 2u << 8;
+constexpr uint32_t IW_FAST_LIT = 1u << 12;   // set in literal entries of the first-level table: what the literal run tests
 
 // LDS of one wave.  The code-length code's tables are only alive while the literal/length and distance code lengths are
 // being read, before the distance table is built: they share its storage.
@@ -143,7 +144,7 @@ enum { IW_CODES = 0, IW_LENS = 1, IW_DISTS = 2 };
 template <int KIND> IW_DEV uint32_t iw_entry_of(uint32_t s) {
   if (KIND == IW_CODES) return s << 16;
   if (KIND == IW_LENS) {
-    if (s < 256u) return s << 16;
+    if (s < 256u) return (s << 16) | IW_FAST_LIT;
     if (s == 256u) return IW_KIND_EOB;
     const uint32_t c = s - 257u;
     if (c > 28u) return IW_KIND_BASE;                                  // 286, 287: take part in the code, never valid (length 0)
@@ -285,13 +286,14 @@ struct IwBits {
       const uint32_t w = iw_readlane(cur, widx);
       bb |= (uint64_t)w << nbits;
       nbits += 32u;
-      if (++widx == 64u) {
-        cur = nxt;
-        w0 += 64u;
-        widx = 0;
-        load(nxt, w0 + 64u);
-      }
+      if (++widx == 64u) rotate();
     }
+  }
+  IW_DEV void rotate() {            // the window is used up: the prefetched one takes over, the one behind it is requested
+    cur = nxt;
+    w0 += 64u;
+    widx = 0;
+    load(nxt, w0 + 64u);
   }
   IW_DEV uint32_t bits(uint32_t n) {   // n <= 16 (0 allowed); the caller keeps nbits >= n
     const uint32_t v = (uint32_t)bb & ((1u << n) - 1u);
@@ -310,6 +312,7 @@ struct IwOut {
   IwBuf out;                      // the block's output [0, isize), bounds-checked
   uint32_t isize, pos, fpos;      // next output position; first position still waiting in `pend`
   IwLane<uint32_t> pend;
+  IwLane<uint32_t> pdata, paddr;  // (device, iw_run) bytes a match has loaded and where they go; IW_OOB: nothing pending
   IW_DEV void flush() {
     if (fpos < pos) {
       const uint32_t lo = fpos & 63u, n = pos - fpos, w = fpos & ~63u;
@@ -367,6 +370,224 @@ struct IwOut {
   }
 };
 
+// The symbol loop proper: literals and plain matches (first-level codes, distance >= length), everything rarer handed back.
+//   code 0: `e` is the entry of a symbol that is neither (nothing consumed; >= 33 bits in the buffer): end of block, a code
+//           longer than the first-level table, an invalid length symbol
+//   code 1: the 256-byte input window is used up (rotate it and come back)
+//   code 4: a match of length L whose distance code is not in the first-level table (L consumed; >= 33 bits in the buffer)
+//   code 5: a match (L, D) the fast copy does not take: it overlaps itself (D < L) or fails a check (caller decides)
+//   code 6: as 4, and the input window is used up
+//   code 7: the output position passed ISIZE
+// On the device this is hand-written ISA.  hipcc turns the same loop into a state machine of 64-bit flag registers, 55
+// scalar instructions per literal and ~150 per match, and the scalar unit (one instruction per cycle per CU, shared by all its
+// waves) is what bounds this kernel: measured 3.5e10 scalar instructions per 2.3 GB launch = the whole kernel time.  Here a
+// literal costs 16 scalar + 3 vector instructions, a match ~45 + 9.  The copy of a match is software-pipelined: its bytes
+// are LOADED when the match is decoded and STORED when the next match (or an exit) comes around -- the ~1 us of load latency
+// passes while the next symbols are decoded; every store is issued before any later load, so a later match that reads
+// these bytes sees them.  bb lives in s[90:91]; s92..s95, m0, vcc are scratch.
+#ifdef STRL_EMU
+IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t *dist_tab, uint32_t &e, uint32_t &code, uint32_t &L, uint32_t &D) {
+  for (;;) {
+    if (br.nbits <= 32u) {
+      const uint32_t w = iw_readlane(br.cur, br.widx);
+      br.bb |= (uint64_t)w << br.nbits;
+      br.nbits += 32u;
+      if (++br.widx == 64u) { code = 1; return; }
+    }
+    e = lit_tab[(uint32_t)br.bb & ((1u << IW_LIT_ROOT) - 1u)];
+    if (e & IW_FAST_LIT) {
+      br.bb >>= e & 15u;
+      br.nbits -= e & 15u;
+      iw_writelane(o.pend, o.pos & 63u, e >> 16);
+      ++o.pos;
+      if (!(o.pos & 63u)) {
+        o.flush();
+        if (o.pos > o.isize) { code = 7; return; }
+      }
+      continue;
+    }
+    if ((e & (3u << 8)) != IW_KIND_BASE || !(e & 15u)) { code = 0; return; }
+    br.bits(e & 15u);
+    L = (e >> 16) + br.bits((e >> 4) & 15u);
+    if (br.nbits <= 32u) {
+      const uint32_t w = iw_readlane(br.cur, br.widx);
+      br.bb |= (uint64_t)w << br.nbits;
+      br.nbits += 32u;
+      if (++br.widx == 64u) { code = 6; return; }
+    }
+    const uint32_t d = dist_tab[(uint32_t)br.bb & ((1u << IW_DIST_ROOT) - 1u)];
+    if (!(d & 15u)) { code = 4; return; }
+    br.bits(d & 15u);
+    D = (d >> 16) + br.bits((d >> 4) & 15u);
+    if (L < 3u || D < L || D > o.pos || o.pos + L > o.isize) { code = 5; return; }
+    o.match(L, D);
+  }
+}
+#else
+IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t *dist_tab, uint32_t &e, uint32_t &code, uint32_t &L, uint32_t &D) {
+  uint32_t vt0, vt1, d;
+  const uint32_t vlit = (uint32_t)reinterpret_cast<uintptr_t>(lit_tab);     // LDS byte addresses (low half of the flat address)
+  const uint32_t vdist = (uint32_t)reinterpret_cast<uintptr_t>(dist_tab);
+  const uint32_t vlane = threadIdx.x;
+  asm volatile(
+      // ---- next symbol: refill, first-level literal/length lookup
+      "L_iw_loop_%=:\n\t"
+      "s_cmp_gt_u32 %[nb], 32\n\t"
+      "s_cbranch_scc1 L_iw_have_%=\n\t"
+      "v_readlane_b32 s92, %[cur], %[wi]\n\t"
+      "s_mov_b32 s93, 0\n\t"
+      "s_add_u32 %[wi], %[wi], 1\n\t"
+      "s_lshl_b64 s[92:93], s[92:93], %[nb]\n\t"
+      "s_add_u32 %[nb], %[nb], 32\n\t"
+      "s_or_b64 s[90:91], s[90:91], s[92:93]\n\t"
+      "s_cmp_eq_u32 %[wi], 64\n\t"
+      "s_cbranch_scc1 L_iw_window_%=\n"
+      "L_iw_have_%=:\n\t"
+      "s_and_b32 s92, s90, 0x3ff\n\t"
+      "v_lshl_add_u32 %[vt0], s92, 2, %[vlit]\n\t"
+      "ds_read_b32 %[vt0], %[vt0]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_readfirstlane_b32 %[e], %[vt0]\n\t"
+      "s_bitcmp1_b32 %[e], 12\n\t"
+      "s_cbranch_scc0 L_iw_notlit_%=\n\t"
+      // ---- literal: into the staging register, lane = position mod 64
+      "s_and_b32 s92, %[e], 15\n\t"
+      "s_and_b32 m0, %[pos], 63\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], s92\n\t"
+      "s_sub_u32 %[nb], %[nb], s92\n\t"
+      "s_lshr_b32 s93, %[e], 16\n\t"
+      "s_add_u32 %[pos], %[pos], 1\n\t"
+      "v_writelane_b32 %[pend], s93, m0\n\t"
+      "s_and_b32 s92, %[pos], 63\n\t"
+      "s_cbranch_scc1 L_iw_loop_%=\n\t"
+      // 64 positions full: one coalesced store of the staged bytes [fpos, pos)
+      "s_and_b32 s92, %[fpos], 63\n\t"
+      "s_sub_u32 s95, %[pos], %[fpos]\n\t"
+      "s_andn2_b32 s94, %[fpos], 63\n\t"
+      "v_subrev_u32_e32 %[vt0], s92, %[vlane]\n\t"
+      "v_cmp_gt_u32_e32 vcc, s95, %[vt0]\n\t"
+      "v_or_b32_e32 %[vt1], s94, %[vlane]\n\t"
+      "v_cndmask_b32_e32 %[vt1], %[voob], %[vt1], vcc\n\t"
+      "buffer_store_byte %[pend], %[vt1], %[rsrc], 0 offen\n\t"
+      "s_mov_b32 %[fpos], %[pos]\n\t"
+      "s_cmp_gt_u32 %[pos], %[isize]\n\t"
+      "s_cbranch_scc0 L_iw_loop_%=\n\t"
+      "s_mov_b32 %[code], 7\n\t"
+      "s_branch L_iw_end_%=\n"
+      // ---- not a first-level literal: a length code of the first-level table, or something for the caller
+      "L_iw_notlit_%=:\n\t"
+      "s_and_b32 s93, %[e], 0x300\n\t"
+      "s_cmp_eq_u32 s93, 0x100\n\t"
+      "s_cbranch_scc0 L_iw_other_%=\n\t"
+      "s_and_b32 s92, %[e], 15\n\t"
+      "s_cbranch_scc0 L_iw_other_%=\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], s92\n\t"
+      "s_sub_u32 %[nb], %[nb], s92\n\t"
+      "s_bfe_u32 s93, %[e], 0x40004\n\t"
+      "s_bfm_b32 s94, s93, 0\n\t"
+      "s_and_b32 s94, s90, s94\n\t"
+      "s_lshr_b32 %[L], %[e], 16\n\t"
+      "s_add_u32 %[L], %[L], s94\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], s93\n\t"
+      "s_sub_u32 %[nb], %[nb], s93\n\t"
+      // refill, first-level distance lookup
+      "s_cmp_gt_u32 %[nb], 32\n\t"
+      "s_cbranch_scc1 L_iw_have2_%=\n\t"
+      "v_readlane_b32 s92, %[cur], %[wi]\n\t"
+      "s_mov_b32 s93, 0\n\t"
+      "s_add_u32 %[wi], %[wi], 1\n\t"
+      "s_lshl_b64 s[92:93], s[92:93], %[nb]\n\t"
+      "s_add_u32 %[nb], %[nb], 32\n\t"
+      "s_or_b64 s[90:91], s[90:91], s[92:93]\n\t"
+      "s_cmp_eq_u32 %[wi], 64\n\t"
+      "s_cbranch_scc1 L_iw_windowL_%=\n"
+      "L_iw_have2_%=:\n\t"
+      "s_and_b32 s92, s90, 0xff\n\t"
+      "v_lshl_add_u32 %[vt0], s92, 2, %[vdist]\n\t"
+      "ds_read_b32 %[vt0], %[vt0]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_readfirstlane_b32 %[d], %[vt0]\n\t"
+      "s_and_b32 s92, %[d], 15\n\t"
+      "s_cbranch_scc0 L_iw_distslow_%=\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], s92\n\t"
+      "s_sub_u32 %[nb], %[nb], s92\n\t"
+      "s_bfe_u32 s93, %[d], 0x40004\n\t"
+      "s_bfm_b32 s94, s93, 0\n\t"
+      "s_and_b32 s94, s90, s94\n\t"
+      "s_lshr_b32 %[D], %[d], 16\n\t"
+      "s_add_u32 %[D], %[D], s94\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], s93\n\t"
+      "s_sub_u32 %[nb], %[nb], s93\n\t"
+      // the fast copy takes L >= 3, D >= L, D <= pos, pos + L <= isize
+      "s_cmp_lt_u32 %[L], 3\n\t"
+      "s_cbranch_scc1 L_iw_match5_%=\n\t"
+      "s_cmp_lt_u32 %[D], %[L]\n\t"
+      "s_cbranch_scc1 L_iw_match5_%=\n\t"
+      "s_cmp_gt_u32 %[D], %[pos]\n\t"
+      "s_cbranch_scc1 L_iw_match5_%=\n\t"
+      "s_add_u32 s92, %[pos], %[L]\n\t"
+      "s_cmp_gt_u32 s92, %[isize]\n\t"
+      "s_cbranch_scc1 L_iw_match5_%=\n\t"
+      // staged literals first (the match may read them)
+      "s_cmp_lt_u32 %[fpos], %[pos]\n\t"
+      "s_cbranch_scc0 L_iw_copy_%=\n\t"
+      "s_and_b32 s92, %[fpos], 63\n\t"
+      "s_sub_u32 s95, %[pos], %[fpos]\n\t"
+      "s_andn2_b32 s94, %[fpos], 63\n\t"
+      "v_subrev_u32_e32 %[vt0], s92, %[vlane]\n\t"
+      "v_cmp_gt_u32_e32 vcc, s95, %[vt0]\n\t"
+      "v_or_b32_e32 %[vt1], s94, %[vlane]\n\t"
+      "v_cndmask_b32_e32 %[vt1], %[voob], %[vt1], vcc\n\t"
+      "buffer_store_byte %[pend], %[vt1], %[rsrc], 0 offen\n"
+      // rounds of 64 bytes: store what the previous round / match loaded, load this round's bytes
+      "L_iw_copy_%=:\n\t"
+      "s_sub_u32 s93, %[pos], %[D]\n\t"
+      "s_mov_b32 s94, 0\n"
+      "L_iw_round_%=:\n\t"
+      "v_add_u32_e32 %[vt0], s94, %[vlane]\n\t"
+      "v_cmp_gt_u32_e32 vcc, %[L], %[vt0]\n\t"
+      "v_add_u32_e32 %[vt1], s93, %[vt0]\n\t"
+      "v_add_u32_e32 %[vt0], %[pos], %[vt0]\n\t"
+      "v_cndmask_b32_e32 %[vt1], %[voob], %[vt1], vcc\n\t"
+      "v_cndmask_b32_e32 %[vt0], %[voob], %[vt0], vcc\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "buffer_store_byte %[pdata], %[paddr], %[rsrc], 0 offen\n\t"
+      "buffer_load_ubyte %[pdata], %[vt1], %[rsrc], 0 offen\n\t"
+      "v_mov_b32_e32 %[paddr], %[vt0]\n\t"
+      "s_add_u32 s94, s94, 64\n\t"
+      "s_cmp_lt_u32 s94, %[L]\n\t"
+      "s_cbranch_scc1 L_iw_round_%=\n\t"
+      "s_add_u32 %[pos], %[pos], %[L]\n\t"
+      "s_mov_b32 %[fpos], %[pos]\n\t"
+      "s_branch L_iw_loop_%=\n"
+      // ---- exits
+      "L_iw_window_%=:\n\t"
+      "s_mov_b32 %[code], 1\n\t"
+      "s_branch L_iw_end_%=\n"
+      "L_iw_windowL_%=:\n\t"
+      "s_mov_b32 %[code], 6\n\t"
+      "s_branch L_iw_end_%=\n"
+      "L_iw_distslow_%=:\n\t"
+      "s_mov_b32 %[code], 4\n\t"
+      "s_branch L_iw_end_%=\n"
+      "L_iw_match5_%=:\n\t"
+      "s_mov_b32 %[code], 5\n\t"
+      "s_branch L_iw_end_%=\n"
+      "L_iw_other_%=:\n\t"
+      "s_mov_b32 %[code], 0\n"
+      // the caller may read or write the output itself: nothing stays pending
+      "L_iw_end_%=:\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "buffer_store_byte %[pdata], %[paddr], %[rsrc], 0 offen\n\t"
+      "v_mov_b32_e32 %[paddr], %[voob]\n\t"
+      : "+{s[90:91]}"(br.bb), [nb] "+s"(br.nbits), [wi] "+s"(br.widx), [pos] "+s"(o.pos), [fpos] "+s"(o.fpos), [pend] "+v"(o.pend.x),
+        [pdata] "+v"(o.pdata.x), [paddr] "+v"(o.paddr.x), [e] "=&s"(e), [code] "=&s"(code), [L] "+s"(L), [D] "+s"(D), [d] "=&s"(d),
+        [vt0] "=&v"(vt0), [vt1] "=&v"(vt1)
+      : [cur] "v"(br.cur.x), [vlit] "v"(vlit), [vdist] "v"(vdist), [vlane] "v"(vlane), [voob] "v"(IW_OOB), [isize] "s"(o.isize), [rsrc] "s"(o.out.r)
+      : "s92", "s93", "s94", "s95", "m0", "vcc", "scc", "memory");
+}
+#endif
+
 // Inflate the raw DEFLATE stream comp[off, off + clen) into out[0, isize).  comp[0, readable) may be loaded (readable is a
 // multiple of 4 and >= off + clen).  Returns 0 or IW_ERR_* flags; never touches memory outside comp[0, readable) and
 // out[0, isize).
@@ -378,7 +599,7 @@ IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t
   IwOut o;
   o.out = iw_make_buf(out, isize);
   o.isize = isize; o.pos = 0; o.fpos = 0;
-  IW_FOR_LANES { o.pend[lane] = 0; }
+  IW_FOR_LANES { o.pend[lane] = 0; o.pdata[lane] = 0; o.paddr[lane] = IW_OOB; }
   for (;;) {
     br.refill();
     const uint32_t bfinal = br.bits(1), btype = br.bits(2);
@@ -468,34 +689,48 @@ IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t
         if (!iw_build<5, IW_LIT_ROOT, IW_LENS>(ll, S.lit_tab, S.ll_sorted, 288u, S.ll_limit, S.ll_delta, S.ll_offs)) return IW_ERR_DATA;
         if (!iw_build<1, IW_DIST_ROOT, IW_DISTS>(dl, S.dist_tab, S.d_sorted, 32u, S.d_limit, S.d_delta, S.d_offs)) return IW_ERR_DATA;
       }
+      // The symbol loop: literals and plain matches in iw_run, what it hands back here.
+      uint32_t why = 0;      // IW_ERR_* when the loop ends for another reason than the end-of-block code
+      uint32_t L = 0, D = 0;
       for (;;) {
-        br.refill();
-        uint32_t e = IW_U(S.lit_tab[(uint32_t)br.bb & ((1u << IW_LIT_ROOT) - 1u)]);
-        if (!(e & 15u)) {
-          e = iw_slow(br.bb, S.ll_limit, S.ll_delta, S.ll_sorted, 288u, IW_LIT_ROOT);
-          if (!e) return IW_ERR_DATA;
+        uint32_t e, code;
+        iw_run(br, o, S.lit_tab, S.dist_tab, e, code, L, D);
+        if (code == 1u) { br.rotate(); continue; }
+        if (code == 7u) { why = IW_ERR_SIZE; break; }
+        if (code == 0u) {
+          if (!(e & 15u)) {
+            e = iw_slow(br.bb, S.ll_limit, S.ll_delta, S.ll_sorted, 288u, IW_LIT_ROOT);
+            if (!e) { why = IW_ERR_DATA; break; }
+          }
+          br.bits(e & 15u);
+          const uint32_t kind = e & (3u << 8);
+          if (kind == 0u) {                                     // a literal with a code longer than the first-level table
+            iw_writelane(o.pend, o.pos & 63u, e >> 16);
+            ++o.pos;
+            if ((o.pos & 63u) == 0u) o.flush();
+            continue;
+          }
+          if (kind == IW_KIND_EOB) break;
+          L = (e >> 16) + br.bits((e >> 4) & 15u);
+          br.refill();
+          code = 4u;
         }
-        br.bits(e & 15u);
-        const uint32_t kind = e & (3u << 8);
-        if (kind == 0u) {
-          if (o.pos >= isize) return IW_ERR_SIZE;
-          o.literal(e >> 16);
-          continue;
+        if (code == 6u) { br.rotate(); code = 4u; }
+        if (code == 4u) {                                       // distance code: first-level table or the canonical search
+          uint32_t d = IW_U(S.dist_tab[(uint32_t)br.bb & ((1u << IW_DIST_ROOT) - 1u)]);
+          if (!(d & 15u)) {
+            d = iw_slow(br.bb, S.d_limit, S.d_delta, S.d_sorted, 32u, IW_DIST_ROOT);
+            if (!d) { why = IW_ERR_DATA; break; }
+          }
+          br.bits(d & 15u);
+          D = (d >> 16) + br.bits((d >> 4) & 15u);
         }
-        if (kind == IW_KIND_EOB) break;
-        const uint32_t L = (e >> 16) + br.bits((e >> 4) & 15u);
-        br.refill();
-        uint32_t d = IW_U(S.dist_tab[(uint32_t)br.bb & ((1u << IW_DIST_ROOT) - 1u)]);
-        if (!(d & 15u)) {
-          d = iw_slow(br.bb, S.d_limit, S.d_delta, S.d_sorted, 32u, IW_DIST_ROOT);
-          if (!d) return IW_ERR_DATA;
-        }
-        br.bits(d & 15u);
-        const uint32_t D = (d >> 16) + br.bits((d >> 4) & 15u);
-        if (L < 3u || D == 0u || D > o.pos) return IW_ERR_DATA;
-        if (o.pos + L > isize) return IW_ERR_SIZE;
+        if (L < 3u || D == 0u || D > o.pos) { why = IW_ERR_DATA; break; }
+        if (o.pos + L > isize) { why = IW_ERR_SIZE; break; }
         o.match(L, D);
       }
+      if (why) return (int)why;
+      if (o.pos > isize) return IW_ERR_SIZE;
     }
     if (bfinal) break;
   }
