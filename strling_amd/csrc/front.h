@@ -46,12 +46,15 @@ struct FrontSlot {
   uint32_t n_blocks = 0, n_seg = 0;
   uint64_t infl_bytes = 0, comp_bytes = 0;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_h2d = nullptr;   // record scan done | parse + scoring done (slot reusable) | compressed bytes on the device
-  bool b_pending = false;
-  FrontInfo *h_info = nullptr;   // pinned: [0] as of the record scan, [1] as of the parse
+  bool b_pending = false, a_pending = false;
+  FrontInfo *h_info = nullptr;   // pinned: [0] as of the record scan, [1] as of the parse, [2] the initial values
+  uint64_t *h_uoff = nullptr;    // pinned: output offsets of the blocks
+  uint32_t h_uoff_cap = 0;
 };
 
 struct strl_front {
-  hipStream_t st_a = nullptr;        // H2D + inflate + record scan
+  hipStream_t st_a = nullptr;        // inflate + record scan
+  hipStream_t st_c = nullptr;        // copies of the compressed bytes to the device: the next chunk's copy runs beside this chunk's inflate
   FrontSlot slot[2];
   int n_ref = 0;
   uint64_t first_off = 0;            // offset of the first record in the first chunk's inflated bytes

@@ -363,7 +363,12 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   hipStream_t st = F->st_a;
   int rc;
   const uint32_t nb = d.n_blocks;
-  std::vector<uint64_t> uoff(nb);
+  if (S.h_uoff_cap < nb) {     // (page-locked: the copy below must not block this thread)
+    if (S.h_uoff) { STRL_HIP(hipStreamSynchronize(F->st_c)); (void)hipHostFree(S.h_uoff); S.h_uoff = nullptr; }
+    S.h_uoff_cap = nb + nb / 4 + 1024;
+    STRL_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_uoff), (size_t)S.h_uoff_cap * 8, hipHostMallocDefault));
+  }
+  uint64_t *uoff = S.h_uoff;
   uint64_t tot = 0;
   for (uint32_t i = 0; i < nb; ++i) {
     if (d.coff[i] + d.clen[i] > d.comp_bytes) { set_error("block %u reaches past the chunk's compressed bytes", i); return STRL_ERR_ARG; }
@@ -389,14 +394,19 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   if ((rc = S.info.reserve(sizeof(FrontInfo)))) return rc;
   S.n_blocks = nb; S.n_seg = n_seg; S.infl_bytes = tot; S.comp_bytes = d.comp_bytes;
   if ((rc = tick(F, st))) return rc;
-  STRL_HIP(hipMemcpyAsync(S.comp.p, d.comp, d.comp_bytes, hipMemcpyHostToDevice, st));
-  STRL_HIP(hipEventRecord(S.ev_h2d, st));
-  STRL_HIP(hipMemsetAsync(static_cast<uint8_t *>(S.comp.p) + d.comp_bytes, 0, 16, st));
-  STRL_HIP(hipMemcpyAsync(S.coff.p, d.coff, (size_t)nb * 8, hipMemcpyHostToDevice, st));
-  STRL_HIP(hipMemcpyAsync(S.uoff.p, uoff.data(), (size_t)nb * 8, hipMemcpyHostToDevice, st));
-  STRL_HIP(hipMemcpyAsync(S.clen.p, d.clen, (size_t)nb * 4, hipMemcpyHostToDevice, st));
-  STRL_HIP(hipMemcpyAsync(S.isize.p, d.isize, (size_t)nb * 4, hipMemcpyHostToDevice, st));
-  FrontInfo hi;
+  // the copies go on a stream of their own: they only have to wait until the slot's previous inflate + scan (which read
+  // these buffers) are done, and this chunk's inflate waits for them
+  hipStream_t sc = F->st_c;
+  if (S.a_pending) STRL_HIP(hipStreamWaitEvent(sc, S.ev_a, 0));
+  STRL_HIP(hipMemcpyAsync(S.comp.p, d.comp, d.comp_bytes, hipMemcpyHostToDevice, sc));
+  STRL_HIP(hipMemsetAsync(static_cast<uint8_t *>(S.comp.p) + d.comp_bytes, 0, 16, sc));
+  STRL_HIP(hipMemcpyAsync(S.coff.p, d.coff, (size_t)nb * 8, hipMemcpyHostToDevice, sc));
+  STRL_HIP(hipMemcpyAsync(S.uoff.p, uoff, (size_t)nb * 8, hipMemcpyHostToDevice, sc));
+  STRL_HIP(hipMemcpyAsync(S.clen.p, d.clen, (size_t)nb * 4, hipMemcpyHostToDevice, sc));
+  STRL_HIP(hipMemcpyAsync(S.isize.p, d.isize, (size_t)nb * 4, hipMemcpyHostToDevice, sc));
+  STRL_HIP(hipEventRecord(S.ev_h2d, sc));
+  STRL_HIP(hipStreamWaitEvent(st, S.ev_h2d, 0));
+  FrontInfo &hi = S.h_info[2];
   memset(&hi, 0, sizeof hi);
   hi.start0 = (uint32_t)(FRONT_CARRY_MAX + (first ? F->first_off : 0));
   hi.end = end;
@@ -427,6 +437,7 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   if ((rc = tick(F, st))) return rc;
   STRL_HIP(hipMemcpyAsync(S.h_info, S.info.p, sizeof(FrontInfo), hipMemcpyDeviceToHost, st));
   STRL_HIP(hipEventRecord(S.ev_a, st));
+  S.a_pending = true;
   return STRL_OK;
 }
 
@@ -465,12 +476,14 @@ void front_destroy(strl_front *F) {
     if (S.ev_b) (void)hipEventDestroy(S.ev_b);
     if (S.ev_h2d) (void)hipEventDestroy(S.ev_h2d);
     if (S.h_info) (void)hipHostFree(S.h_info);
+    if (S.h_uoff) (void)hipHostFree(S.h_uoff);
   }
   for (DevBuf *b : {&F->qref, &F->qarena, &F->fragw, &F->tidflag, &F->tid_seen, &F->s_tid, &F->s_pos, &F->s_end, &F->s_seqoff, &F->s_lseq, &F->s_clipl, &F->s_clipr, &F->s_mapq,
                     &F->s_cig, &F->s_seq4})
     b->release();
   for (hipEvent_t e : F->tev) (void)hipEventDestroy(e);
   if (F->st_a) (void)hipStreamDestroy(F->st_a);
+  if (F->st_c) (void)hipStreamDestroy(F->st_c);
   delete F;
 }
 

@@ -828,7 +828,7 @@ void strl_ctx_destroy(strl_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->x_soft_seen_ev) (void)hipEventDestroy(c->x_soft_seen_ev);
   if (c->x_soft_seen) (void)hipHostFree(c->x_soft_seen);
-  if (c->front) { if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a); strl::front_destroy(c->front); c->front = nullptr; }
+  if (c->front) { if (c->front->st_c) (void)hipStreamSynchronize(c->front->st_c); if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a); strl::front_destroy(c->front); c->front = nullptr; }
   strl::DevBuf *bufs[] = {&c->lut, &c->thr, &c->g_tid, &c->g_bins, &c->g_start, &c->g_pmax, &c->queue, &c->soft_queue, &c->counters,
                           &c->soft_tmp, &c->sb_whole, &c->sb_soft, &c->queue_r, &c->soft_dense, &c->sb_state_w, &c->sb_state_s, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
                           &c->st_mapq, &c->st_cig, &c->st_seq4, &c->st_whole, &c->st_soft, &c->st_text,
@@ -1297,7 +1297,16 @@ static int extract_add_scored(strl_ctx *c, const strl_read_soa *d, uint64_t at) 
   const strl_pair_soa dp{c->x_rows.as<strl_pair_rec>() + at, c->x_qhash.as<uint64_t>() + at};
   const uint64_t chunk_soft = 2 * n + 2;
   if ((rc = c->st_soft.reserve((size_t)chunk_soft * sizeof(strl_soft_rec)))) return rc;
-  if ((rc = score_device(c, d, c->x_whole.as<uint32_t>() + at, c->st_soft.as<strl_soft_rec>(), chunk_soft, nullptr, nullptr, false, &dp, false))) return rc;
+  // the skip-predicate pass stores its words 16 bytes at a time when the destination is aligned (its other variant is ~80x
+  // slower): a chunk that starts at an index that is not a multiple of 4 is scored into a scratch array and copied over
+  uint32_t *whole = c->x_whole.as<uint32_t>() + at;
+  const bool bounce = (at & 3u) != 0;
+  if (bounce) {
+    if ((rc = c->st_whole.reserve((size_t)std::max<uint64_t>(n, 1) * 4))) return rc;
+    whole = c->st_whole.as<uint32_t>();
+  }
+  if ((rc = score_device(c, d, whole, c->st_soft.as<strl_soft_rec>(), chunk_soft, nullptr, nullptr, false, &dp, false))) return rc;
+  if (bounce && n) STRL_HIP(hipMemcpyAsync(c->x_whole.as<uint32_t>() + at, whole, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));
   hipLaunchKernelGGL(strl::soft_append_kernel, dim3(1), dim3(1024), 0, c->stream, c->st_soft.as<strl_soft_rec>(), c->counters.as<uint32_t>(), (uint32_t)chunk_soft,
                      (uint32_t)at, c->x_soft.as<strl_soft_rec>(), (uint32_t)std::min<uint64_t>(c->x_soft_cap, 0xffffffffull), c->x_cnt.as<uint32_t>());
   STRL_HIP(hipGetLastError());
@@ -1470,11 +1479,12 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
   c->front = F;
   F->n_ref = n_ref; F->first_off = first_record_offset;
   STRL_HIP(hipStreamCreateWithFlags(&F->st_a, hipStreamNonBlocking));
+  STRL_HIP(hipStreamCreateWithFlags(&F->st_c, hipStreamNonBlocking));
   for (strl::FrontSlot &S : F->slot) {
     STRL_HIP(hipEventCreateWithFlags(&S.ev_a, hipEventDisableTiming));
     STRL_HIP(hipEventCreateWithFlags(&S.ev_b, hipEventDisableTiming));
     STRL_HIP(hipEventCreateWithFlags(&S.ev_h2d, hipEventDisableTiming));
-    STRL_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_info), 2 * sizeof(strl::FrontInfo), hipHostMallocDefault));
+    STRL_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_info), 3 * sizeof(strl::FrontInfo), hipHostMallocDefault));
   }
   if ((rc = F->tid_seen.reserve((size_t)n_ref + 16))) return rc;
   STRL_HIP(hipMemsetAsync(F->tid_seen.p, 0, (size_t)n_ref + 16, c->stream));
