@@ -309,6 +309,21 @@ def main():
                "sample": f"oracle extract loop (skip predicate + get_repeat + add_soft + pair logic) + cluster/bounds over the S1 mix, "
                          f"{srec.n} reads x {reads_done // srec.n} passes, {t_cpu:.1f} s, single thread like the reference (threads=0)"}
 
+    # ---- ... the same on every core the box grants (process-sharded: the reference is single-threaded per sample, a pipeline
+    #      runs one process per sample), and a decode-inclusive single-thread leg to put beside end_to_end ----
+    cpu_nproc, cpu_e2e = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu_nproc = cpu_baseline_nproc(max(4.0, args.cpu_seconds / 2))
+            cpu_e2e = cpu_baseline_e2e(cpu["value"])
+            if e2e and "runs" in e2e and cpu_e2e:
+                e2e["vs_cpu_baseline_e2e_wall"] = round(e2e["value"] / cpu_e2e["value"], 1)
+                best = max(e2e["runs"], key=lambda x: x["reads_per_s_wall"])
+                if best.get("reads_per_s_loop"):
+                    e2e["vs_cpu_baseline_e2e_loop"] = round(best["reads_per_s_loop"] / cpu_e2e["value"], 1)
+        except Exception as e:
+            cpu_nproc = cpu_nproc or {"error": str(e)[:200]}
+
     if rank == 0:
         total_reads = n * world * args.steps
         out = {
@@ -328,11 +343,81 @@ def main():
                        "parallelism": (f"records sharded over {world} GPU(s), no data-path collective" if exchange is None else
                                        f"records sharded over {world} GPUs; per step one RCCL all-gather of the tread arrays "
                                        f"({exchange.pad * 32} B per rank) before clustering, every rank clusters the (tid, unit) groups it owns")},
-            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_nproc": cpu_nproc, "cpu_baseline_e2e": cpu_e2e, "end_to_end": e2e,
         }
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _cpu_quota():
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else int(q) / int(per)
+    except Exception:
+        return None
+
+
+def _nproc_worker(args):
+    seed, seconds = args
+    from oracle import oracle as O
+    from strling_amd import api, synth
+    srec, sg = synth.synth_wgs(2 ** 16, seed=seed)
+    sfrag = synth.frag_hist(srec)
+    smed = O.median(sfrag)
+    opts = O.make_opts(smed, 0.8, 40)
+    done, t = 0, 0.0
+    t0 = time.perf_counter()
+    while t < seconds:
+        et = O.extract(srec, sg, opts)
+        O.call_bounds(et, 1, api.frag_median(sfrag, 0.99), min_support=5, max_clip_dist=int(0.5 * smed))
+        done += srec.n
+        t = time.perf_counter() - t0
+    return done, t
+
+
+def cpu_baseline_nproc(seconds):
+    """the oracle's extract + cluster loop in P processes at once (one sample each, like a pipeline runs the single-threaded
+    reference), P = the CPUs this container may use"""
+    import multiprocessing as mp
+    quota = _cpu_quota()
+    hw = os.cpu_count() or 1
+    procs = max(1, min(hw, int(quota) if quota else hw, 64))
+    with mp.get_context("spawn").Pool(procs) as pool:
+        res = pool.map(_nproc_worker, [(4321 + k, seconds) for k in range(procs)])
+    reads = sum(r[0] for r in res)
+    wall = max(r[1] for r in res)
+    return {"value": round(reads / wall, 1), "unit": "reads/s", "cores": procs, "kind": "port", "host_threads_visible": hw, "cgroup_cpu_quota": quota,
+            "sample": f"{procs} processes, each the oracle's extract + cluster loop over its own 2^17-read S1 sample for {seconds:.0f} s (decode excluded, "
+                      f"like cpu_baseline); aggregate reads / slowest process' time"}
+
+
+def cpu_baseline_e2e(oracle_reads_per_s):
+    """what the reference's threads=0 run does per read, on one core: inflate the BGZF blocks with zlib, then the extract loop.
+    Inflate is timed on the blocks of a synthetic BAM (same writer as end_to_end), the loop rate is cpu_baseline's; record
+    parsing (htslib bam_read1) is not charged."""
+    import zlib
+    from strling_amd import bamio, synth
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import inflate_bench
+    rec, _ = synth.synth_wgs_30x(1, 2 ** 16, seed=77)
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "cpu_e2e_sample.bam")
+    bamio.write_bam(path, rec, level=1, index=False)
+    streams, sizes = inflate_bench.bam_blocks(path)
+    os.remove(path)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 3.0:
+        for s_ in streams:
+            zlib.decompress(s_, -15)
+        n += 1
+    t_inf = (time.perf_counter() - t0) / n
+    inflate_rps = rec.n / t_inf
+    value = 1.0 / (1.0 / inflate_rps + 1.0 / oracle_reads_per_s)
+    return {"value": round(value, 1), "unit": "reads/s", "cores": 1, "kind": "port",
+            "parts": {"zlib_inflate_reads_per_s": round(inflate_rps, 1), "zlib_inflate_GBps": round(sum(sizes) / t_inf / 1e9, 3), "extract_loop_reads_per_s": oracle_reads_per_s},
+            "sample": f"single thread: zlib inflate of the {len(streams)} BGZF blocks of a {rec.n}-read synthetic BAM (level 1, the end_to_end writer) + cpu_baseline's "
+                      f"extract/cluster rate, combined per read (1 / (1/inflate + 1/loop)); the like-for-like denominator of end_to_end"}
 
 
 def end_to_end(n_pairs):

@@ -59,6 +59,7 @@ struct strl_front {
   int n_ref = 0;
   uint64_t first_off = 0;            // offset of the first record in the first chunk's inflated bytes
   uint64_t chunks = 0;               // chunks pushed so far
+  uint64_t comp_total = 0, infl_total = 0;   // bytes handed over / inflated so far
   int pending = -1;                  // slot whose stage B has not been enqueued yet
   // per-read state of all chunks (beside x_rows / x_qhash / x_whole of the chunked extract)
   DevBuf qref, qarena, fragw, tidflag, tid_seen;   // tid_seen[n_ref]: contigs with a primary record so far

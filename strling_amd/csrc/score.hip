@@ -1511,6 +1511,8 @@ int strl_front_push(strl_ctx *c, const uint8_t *comp, uint64_t comp_bytes, const
   const strl::FrontChunkDesc d{comp, comp_bytes, coff, clen, isize, n_blocks};
   if ((rc = strl::front_stage_a(c, F, si, d, F->chunks == 0))) return rc;
   ++F->chunks;
+  F->comp_total += comp_bytes;
+  F->infl_total += F->slot[si].infl_bytes;
   if (F->chunks >= 2 && (rc = front_stage_b(c, F, si ^ 1))) return rc;
   return STRL_OK;
 }
@@ -1541,7 +1543,8 @@ int strl_front_finish(strl_ctx *c, strl_front_chunk done[2], int *n_done) {
       (void)hipEventElapsedTime(&d, F->tev[i + 2], F->tev[i + 3]);
       h2d += a; inf += b; scan += d;
     }
-    fprintf(stderr, "[strling] device front end, ms over %llu chunks: copies to the device %.1f  inflate %.1f  record scan %.1f\n", (unsigned long long)F->chunks, h2d, inf, scan);
+    fprintf(stderr, "[strling] device front end, ms over %llu chunks: copies to the device %.1f  inflate %.1f  record scan %.1f  (%.1f MB compressed -> %.1f MB inflated)\n",
+            (unsigned long long)F->chunks, h2d, inf, scan, (double)F->comp_total / 1e6, (double)F->infl_total / 1e6);
   }
   return STRL_OK;
 }
