@@ -248,8 +248,10 @@ int strl_extract_add(strl_ctx *ctx, const strl_read_soa *chunk, const strl_pair_
 int strl_extract_finish(strl_ctx *ctx, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap);
 /* Wait for the last strl_extract_device call and copy its treads to the host (out may be NULL to only get the count).
  * STRL_ERR_CAPACITY: a capacity was exceeded (n_out = treads needed when known); STRL_ERR_ASSERT: the reference's
- * doAssert repeat_count < 256 (extract.nim:72) would have fired; STRL_ERR_FORMAT: more than 15 records share one qname
- * hash prefix (malformed input -- use the host pair logic, strl_pair_reads). */
+ * doAssert repeat_count < 256 (extract.nim:72) would have fired; STRL_ERR_FORMAT: more than 512 join items share the low 32
+ * bits of their qname hash (one qname on hundreds of primary records), or -- checked where the device holds the qnames
+ * (strl_front_*) -- two different qnames share one 64-bit hash: repeat with the host pair logic (strl_pair_reads), which
+ * keys on the qname string.  Secondary / supplementary records do not take part in the join. */
 int strl_treads_fetch(strl_ctx *ctx, strl_tread *out, uint64_t cap, uint64_t *n_out, strl_score_stats *stats);
 /* HIP-event times (ms) of the last strl_extract_device call when timing is enabled: soft-clip join items | probe |
  * join sort | replay | order sort + gather. */

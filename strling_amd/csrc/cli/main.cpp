@@ -293,6 +293,7 @@ static void setup_genome(strl_ctx *ctx, const Args &a, const std::vector<BamTarg
 }
 
 static int extract_front(const Args &a, const std::string &bam, const std::string &bin, double p, uint8_t min_mapq, bool verbose);
+constexpr int EXTRACT_AGAIN_ON_HOST = -77;
 
 static int extract_main(int argc, char **argv) {
   const char *usage =
@@ -314,7 +315,11 @@ static int extract_main(int argc, char **argv) {
     // Default: the whole BAM front end on the device (inflate, record scan, parse: strl_front_*).  STRL_FRONT=host keeps the
     // host reader (threads inflate and parse, the device scores); STRL_PAIR=host (the host's streaming Cache) implies it.
     const char *fe = getenv("STRL_FRONT"), *pe = getenv("STRL_PAIR");
-    if (!(fe && strcmp(fe, "host") == 0) && !(pe && strcmp(pe, "host") == 0)) return extract_front(a, bam, bin, p, min_mapq, verbose);
+    if (!(fe && strcmp(fe, "host") == 0) && !(pe && strcmp(pe, "host") == 0)) {
+      const int r = extract_front(a, bam, bin, p, min_mapq, verbose);
+      if (r != EXTRACT_AGAIN_ON_HOST) return r;
+      setenv("STRL_PAIR", "host", 1);       // the device join passed (hash collision / one qname on hundreds of records): the string-keyed Cache
+    }
   }
 
   // The HIP runtime + device context come up (a few hundred ms of driver work on one thread) while the host threads
@@ -344,7 +349,7 @@ static int extract_main(int argc, char **argv) {
   CHECK(strl_ctx_set_opts(ctx, &opts));
   setup_genome(ctx, a, rd.targets());
   // Pair logic: on the device over the whole file (default), or the host's streaming Cache (STRL_PAIR=host; also the
-  // way out for inputs the device join refuses: more than 15 records under one qname hash).
+  // way out -- taken automatically -- for inputs the device join passes on: one qname on hundreds of primary records).
   const char *pair_env = getenv("STRL_PAIR");
   const bool host_pair = pair_env && strcmp(pair_env, "host") == 0;
   strl_pairer *pairer = nullptr;
@@ -506,11 +511,16 @@ static int extract_main(int argc, char **argv) {
     const auto tp0 = now();
     int rc = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
-      CHECK(strl_extract_finish(ctx, n_tail, attempt ? 3 * n_seen + 16 : 0, attempt ? 8 * n_seen + 16 : 0));
+      CHECK(strl_extract_finish(ctx, n_tail, attempt ? std::min<uint64_t>(3 * n_seen + 16, 0x7ffffff0ull) : 0, attempt ? std::min<uint64_t>(8 * n_seen + 16, 0x7ffffff0ull) : 0));
       rc = strl_treads_fetch(ctx, nullptr, 0, &nt, nullptr);
       if (rc != STRL_ERR_CAPACITY) break;
     }
-    if (rc == STRL_ERR_FORMAT) quit("[strling] %s; rerun with STRL_PAIR=host", strl_last_error());
+    if (rc == STRL_ERR_FORMAT) {
+      fprintf(stderr, "[strling] %s: repeating the extraction with the host pair logic\n", strl_last_error());
+      strl_ctx_destroy(ctx);
+      setenv("STRL_PAIR", "host", 1);
+      return extract_main(argc, argv);
+    }
     if (rc) quit("[strling] %s (status %d)", strl_last_error(), rc);
     dev_treads.resize((size_t)nt + 1);
     CHECK(strl_treads_fetch(ctx, dev_treads.data(), nt, &nt, nullptr));
@@ -698,7 +708,12 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     rc = strl_treads_fetch(ctx, nullptr, 0, &nt, nullptr);
     if (rc != STRL_ERR_CAPACITY) break;
   }
-  if (rc == STRL_ERR_FORMAT) quit("[strling] %s; rerun with STRL_PAIR=host", strl_last_error());
+  if (rc == STRL_ERR_FORMAT) {
+    fprintf(stderr, "[strling] %s: repeating the extraction with the host pair logic\n", strl_last_error());
+    for (int k = 0; k < 2; ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
+    strl_ctx_destroy(ctx);
+    return EXTRACT_AGAIN_ON_HOST;
+  }
   if (rc) quit("[strling] %s (status %d)", strl_last_error(), rc);
   std::vector<strl_tread> treads((size_t)nt + 1);
   CHECK(strl_treads_fetch(ctx, treads.data(), nt, &nt, nullptr));

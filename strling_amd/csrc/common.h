@@ -36,10 +36,11 @@ struct DevBuf {
 constexpr int CNT_STRIDE = 16;
 constexpr int CNT_QUEUE = 0, CNT_SOFT = 16, CNT_SKIP = 32, CNT_SBW = 48, CNT_SBS = 64, CNT_WORDS = 80;
 // counters of the device pair logic (strl_ctx::pair_cnt)
-constexpr int PC_ITEMS = 0, PC_EMIT = 16, PC_ERR = 32, PC_WORDS = 48;
+constexpr int PC_ITEMS = 0, PC_EMIT = 16, PC_ERR = 32, PC_SPILL = 40, PC_WORDS = 48;
 // counters of a chunked extract (strl_ctx::x_cnt): soft records appended so far, then the sums of the chunks' CNT_* counters
 constexpr int XC_SOFT = 0, XC_SKIP = 1, XC_QUEUE = 2, XC_SBW = 3, XC_SBS = 4, XC_SOFT_ITEMS = 5, XC_OVERFLOW = 6, XC_WORDS = 16;
-constexpr uint32_t PAIR_ERR_RUN = 1u, PAIR_ERR_ASSERT = 2u, PAIR_ERR_ITEMS = 4u, PAIR_ERR_EMIT = 8u, PAIR_ERR_LOCAL = 16u;
+constexpr int PAIR_LONG_MAX_ITEMS = 512;   // longest hash run the device pair logic replays (pair.hip PAIR_LONG_MAX)
+constexpr uint32_t PAIR_ERR_RUN = 1u, PAIR_ERR_ASSERT = 2u, PAIR_ERR_ITEMS = 4u, PAIR_ERR_EMIT = 8u, PAIR_ERR_LOCAL = 16u, PAIR_ERR_COLLISION = 32u;
 
 // murmur3 finaliser: a bijection on 64-bit words, so equality of mixed hashes == equality of hashes
 __host__ __device__ inline uint64_t fmix64(uint64_t h) {
@@ -156,6 +157,9 @@ struct strl_ctx {
   hipEvent_t x_soft_seen_ev = nullptr;
   bool x_soft_pending = false;
   bool x_open = false, x_mode = false;
+  bool x_front = false;            // the chunks came through the device front end: qnames of all records sit in its arena
+  strl::DevBuf p_spill;            // pair logic: first items of the hash runs too long for the in-block replay
+  bool pg_attr_done = false;
   hipEvent_t pev[6] = {};
   double inflate_ms = 0;           // kernel time of the last strl_inflate_blocks call
   strl::strl_front *front = nullptr;   // device BAM front end (front.h), created by strl_front_begin

@@ -25,11 +25,14 @@
 #include "common.h"
 #include "device_util.h"
 #include "sort.h"
+#include "front.h"
 
 namespace strl {
 
 constexpr uint16_t F_PROPER = 0x2, F_REVERSE = 0x10, F_MREVERSE = 0x20, F_SECONDARY = 0x100, F_SUPPL = 0x800;
-constexpr int PAIR_MAXM = 15;   // items (reads + hot soft-clip records) of one hash run a lane can replay
+constexpr int PAIR_MAXM = 15;   // items (reads + hot soft-clip records) of one hash run a lane replays out of its block's LDS
+constexpr int PAIR_LONG_MAX = PAIR_LONG_MAX_ITEMS;     // ... longer runs go to pair_long_kernel (a block per run), up to this many items
+constexpr uint32_t PAIR_SPILL_CAP = 1u << 16;
 
 struct PairParams {
   uint32_t n;               // reads of the batch
@@ -53,7 +56,22 @@ struct PairParams {
   double p;
   uint32_t min_mapq;
   int32_t frag_median;
+  uint32_t *spill;             // [PAIR_SPILL_CAP] sorted-item index of the first item of every run the block replay passed on
+  const uint64_t *qref;        // device front end only: (qname arena offset << 8) | length per record, else null
+  const uint8_t *qarena;
 };
+
+// The Cache of extract.nim:198,245 is keyed by the qname STRING; the join keys on its 64-bit hash.  Where the names are on
+// the device (front end), the records of one hash group are checked to carry one name: a collision is reported
+// (PAIR_ERR_COLLISION -> the caller repeats the extraction with the string-keyed host Cache), never silently merged.
+__device__ inline bool qname_differs(const PairParams &P, uint32_t r0, uint32_t r1) {
+  if (!P.qref) return false;
+  const uint64_t a = P.qref[r0], b = P.qref[r1];
+  if ((a & 255u) != (b & 255u)) return true;
+  const uint8_t *x = P.qarena + (a >> 8), *y = P.qarena + (b >> 8);
+  for (uint32_t j = 0; j < (uint32_t)(a & 255u); ++j) if (x[j] != y[j]) return true;
+  return false;
+}
 
 // Soft-clip records with a result under either threshold: mark their read's qname group and make them join items.
 // One queue-space atomic per 2048 records (the same-address atomic rate of the L2 is ~88 per microsecond).
@@ -77,6 +95,8 @@ __global__ __launch_bounds__(1024) void pair_soft_items_kernel(PairParams P) {
       if (j < n_src) {
         const strl_soft_rec s = P.soft[j];
         hot[u] = (STRL_RES_COUNT(s.res_first) | STRL_RES_COUNT(s.res_after)) != 0;
+        // secondary / supplementary records never reach Cache.add (extract.nim:309,327): neither they nor their clips join
+        if (hot[u]) hot[u] = !(P.rec[s.read_side >> 1].flag & (F_SECONDARY | F_SUPPL));
         if (hot[u]) {
           m[u] = fmix64(P.qhash[s.read_side >> 1]);
           bloom_set(P.bloom, P.bloom_mask, m[u]);
@@ -168,7 +188,8 @@ __global__ __launch_bounds__(256) void pair_probe_kernel(PairParams P) {
     for (int j = 0; j < PR_ILP; ++j) {
       if (hit[j]) {
         const uint32_t b1 = (uint32_t)(m[j] >> 32) & P.bloom_mask;
-        hit[j] = (P.bloom[b1 >> 5] >> (b1 & 31u)) & 1u;
+        const uint16_t fl = P.rec[base + 64ull * j + lane].flag;      // (secondary / supplementary: see pair_soft_items_kernel)
+        hit[j] = ((P.bloom[b1 >> 5] >> (b1 & 31u)) & 1u) && !(fl & (F_SECONDARY | F_SUPPL));
       }
     }
 #pragma unroll
@@ -307,7 +328,8 @@ struct GroupCtx {
   uint64_t perm;          // 4-bit indices (relative to `base`) of the run's items sorted by (hash, value)
   int base, i0, i1;       // perm entries [i0, i1) = this qname group: reads first, then its soft records
   uint32_t *err;
-  __device__ const PItem &item(int j) const { return it[base + (int)((perm >> (4 * j)) & 15u)]; }
+  bool ident;             // pair_long_kernel: `it` holds the run sorted by (hash, value), no permutation
+  __device__ const PItem &item(int j) const { return ident ? it[base + j] : it[base + (int)((perm >> (4 * j)) & 15u)]; }
 };
 
 // to_tread, extract.nim:63-87, from the packed scorer word and the SoA metadata
@@ -411,6 +433,38 @@ __device__ inline void cache_add(const GroupCtx &G, const PItem &x, uint64_t vid
   }
 }
 
+// Replay of one hash run of m items (G.item(0..m)): per qname group -- equal 64-bit keys, reads in file order before their
+// soft-clip records -- the first pass over all records (extract.nim:308-322), then the unmapped tail once more (:326-329)
+template <class Ctx> __device__ inline void replay_run(Ctx &G, int m, const EmitStage &E) {
+  const PairParams &P = G.P;
+  int a = 0;
+  while (a < m) {
+    int b = a + 1;
+    while (b < m && G.item(b).key == G.item(a).key) ++b;
+    G.i0 = a; G.i1 = b;
+    if (P.qref)
+      for (int j = a + 1; j < b; ++j) {
+        const PItem &x = G.item(j);
+        if (x.val & 0x80000000u) break;
+        if (qname_differs(P, G.item(a).val, x.val)) *G.err |= PAIR_ERR_COLLISION;
+      }
+    bool stored = false;
+    DTread S{};
+    for (int j = a; j < b; ++j) {
+      const PItem &x = G.item(j);
+      if (x.val & 0x80000000u) break;
+      cache_add(G, x, (uint64_t)x.val, stored, S, E);
+    }
+    for (int j = a; j < b; ++j) {
+      const PItem &x = G.item(j);
+      if (x.val & 0x80000000u) break;
+      if (x.val >= P.tail_start) cache_add(G, x, (uint64_t)P.n + (uint64_t)(x.val - P.tail_start), stored, S, E);
+    }
+    a = b;
+  }
+}
+
+
 // A block takes 1024 consecutive sorted items.  Phase 1: every lane gathers the metadata of ITS item into LDS (all
 // gathers of the block in flight together).  Phase 2: the lane of the first item of a run (equal low 32 hash bits)
 // replays Cache.add for the run out of LDS; emitted treads are staged in LDS.  Phase 3: one atomic reserves the block's
@@ -478,28 +532,13 @@ __global__ __launch_bounds__(PG_BLOCK) void pair_groups_kernel(PairParams P) {
           perm = (perm & lowmask) | ((uint64_t)(j - me) << (4 * q)) | ((perm & ~lowmask) << 4);
           ++m;
         }
-        if (too_long) err |= PAIR_ERR_RUN;
-        else {
-          GroupCtx G{P, items, perm, me, 0, 0, &err};
-          int a = 0;
-          while (a < m) {
-            int b = a + 1;
-            while (b < m && G.item(b).key == G.item(a).key) ++b;
-            G.i0 = a; G.i1 = b;
-            bool stored = false;
-            DTread S{};
-            for (int j = a; j < b; ++j) {            // extract.nim:308-322
-              const PItem &x = G.item(j);
-              if (x.val & 0x80000000u) break;
-              cache_add(G, x, (uint64_t)x.val, stored, S, E);
-            }
-            for (int j = a; j < b; ++j) {            // extract.nim:326-329: the unmapped tail once more
-              const PItem &x = G.item(j);
-              if (x.val & 0x80000000u) break;
-              if (x.val >= P.tail_start) cache_add(G, x, (uint64_t)P.n + (uint64_t)(x.val - P.tail_start), stored, S, E);
-            }
-            a = b;
-          }
+        if (too_long) {            // a block of its own replays this run (pair_long_kernel)
+          const uint32_t sl = atomicAdd(&P.pc[PC_SPILL], 1u);
+          if (sl < PAIR_SPILL_CAP) P.spill[sl] = i;
+          else err |= PAIR_ERR_RUN;
+        } else {
+          GroupCtx G{P, items, perm, me, 0, 0, &err, false};
+          replay_run(G, m, E);
         }
       }
     }
@@ -520,6 +559,80 @@ __global__ __launch_bounds__(PG_BLOCK) void pair_groups_kernel(PairParams P) {
         P.emit_key[d] = st_k[e];
         P.emit_val[d] = d;
       } else atomicOr(&P.pc[PC_ERR], PAIR_ERR_EMIT);
+    }
+    __syncthreads();
+  }
+}
+
+// Hash runs of more than PAIR_MAXM items -- several qname groups whose mixed hashes share their low 32 bits (a whole
+// genome's ~10^7 hot groups hold a few triples), or one qname carried by many records -- one block per run: the items are
+// gathered into LDS, ordered by (hash, value) with a rank sort, and one lane replays them like the block replay does.
+// Runs beyond PAIR_LONG_MAX items set PAIR_ERR_RUN (the caller falls back to the host's string-keyed Cache).
+__global__ __launch_bounds__(PAIR_LONG_MAX) void pair_long_kernel(PairParams P) {
+  __shared__ PItem raw[PAIR_LONG_MAX], srt[PAIR_LONG_MAX];
+  __shared__ strl_tread st_t[PG_EMIT];
+  __shared__ uint64_t st_k[PG_EMIT];
+  __shared__ uint32_t sh[4];
+  uint32_t n_items = P.pc[PC_ITEMS];
+  if (n_items > P.item_cap) n_items = P.item_cap;
+  uint32_t n_spill = P.pc[PC_SPILL];
+  if (n_spill > PAIR_SPILL_CAP) n_spill = PAIR_SPILL_CAP;
+  const EmitStage E{st_t, st_k, sh, &P};
+  for (uint32_t e = blockIdx.x; e < n_spill; e += gridDim.x) {
+    const uint32_t i0 = P.spill[e];
+    const uint32_t lo = (uint32_t)P.item_key[i0];
+    if (threadIdx.x == 0) { sh[0] = 0; sh[3] = PAIR_LONG_MAX; }
+    __syncthreads();
+    // the run is contiguous from i0: its length = the first index that is not part of it
+    const uint32_t i = i0 + threadIdx.x;
+    const bool mine = i < n_items && (uint32_t)P.item_key[i] == lo;
+    if (!mine) atomicMin(&sh[3], threadIdx.x);
+    __syncthreads();
+    const uint32_t m = sh[3];
+    const bool beyond = m == (uint32_t)PAIR_LONG_MAX && i0 + PAIR_LONG_MAX < n_items && (uint32_t)P.item_key[i0 + PAIR_LONG_MAX] == lo;
+    uint32_t err = 0;
+    if (beyond) { if (threadIdx.x == 0) atomicOr(&P.pc[PC_ERR], PAIR_ERR_RUN); __syncthreads(); continue; }
+    if (threadIdx.x < m) {
+      PItem x{};
+      x.key = P.item_key[i];
+      x.val = P.item_val[i];
+      if (x.val & 0x80000000u) {
+        const strl_soft_rec s = P.soft[x.val & 0x7fffffffu];
+        x.tid = (int32_t)s.read_side; x.pos = (int32_t)s.res_first; x.mtid = (int32_t)s.res_after;
+      } else {
+        const strl_pair_rec o = P.rec[x.val];
+        x.tid = o.tid; x.pos = o.pos; x.mtid = o.mtid; x.mpos = o.mpos; x.end = o.end;
+        x.whole = P.whole[x.val]; x.flag = o.flag; x.clip_l = o.clip_l; x.clip_r = o.clip_r; x.l_seq = o.l_seq;
+        x.mapq = o.mapq; x.cig = o.cig;
+      }
+      raw[threadIdx.x] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < m) {      // rank sort by (hash, value): (key, val) pairs are distinct
+      const PItem x = raw[threadIdx.x];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < m; ++j) {
+        const PItem &o = raw[j];
+        if (o.key < x.key || (o.key == x.key && o.val < x.val)) ++rank;
+      }
+      srt[rank] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      GroupCtx G{P, srt, 0, 0, 0, 0, &err, true};
+      replay_run(G, (int)m, E);
+      if (err) atomicOr(&P.pc[PC_ERR], err);
+    }
+    __syncthreads();
+    uint32_t ne = sh[0];
+    if (ne > (uint32_t)PG_EMIT) ne = PG_EMIT;
+    if (threadIdx.x == 0) sh[1] = ne ? atomicAdd(&P.pc[PC_EMIT], ne) : 0u;
+    __syncthreads();
+    const uint32_t base = sh[1];
+    for (uint32_t k = threadIdx.x; k < ne; k += blockDim.x) {
+      const uint32_t d = base + k;
+      if (d < P.emit_cap) { P.emit[d] = st_t[k]; P.emit_key[d] = st_k[k]; P.emit_val[d] = d; }
+      else atomicOr(&P.pc[PC_ERR], PAIR_ERR_EMIT);
     }
     __syncthreads();
   }
@@ -635,7 +748,7 @@ int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uin
   if ((rc = c->p_key0.reserve((size_t)std::max(icap, ecap) * 8)) || (rc = c->p_key1.reserve((size_t)std::max(icap, ecap) * 8)) ||
       (rc = c->p_val0.reserve((size_t)std::max(icap, ecap) * 4)) || (rc = c->p_val1.reserve((size_t)std::max(icap, ecap) * 4)) ||
       (rc = c->p_emit.reserve((size_t)ecap * sizeof(strl_tread))) || (rc = c->treads.reserve((size_t)ecap * sizeof(strl_tread) + 64)) ||
-      (rc = c->sort_scratch.reserve(sb)) || (rc = c->pair_cnt.reserve(PC_WORDS * 4 + 64)))
+      (rc = c->sort_scratch.reserve(sb)) || (rc = c->pair_cnt.reserve(PC_WORDS * 4 + 64)) || (rc = c->p_spill.reserve((size_t)PAIR_SPILL_CAP * 4)))
     return rc;
   void *jt = nullptr;
   size_t jt_bytes = 0;
@@ -652,6 +765,11 @@ int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uin
   P.pc = c->pair_cnt.as<uint32_t>();
   P.emit = c->p_emit.as<strl_tread>(); P.emit_key = c->p_key0.as<uint64_t>(); P.emit_val = c->p_val0.as<uint32_t>(); P.emit_cap = ecap;
   P.p = c->opts.proportion_repeat; P.min_mapq = c->opts.min_mapq; P.frag_median = c->opts.median_fragment_length;
+  P.spill = c->p_spill.as<uint32_t>();
+  // the qnames of every record, when the device front end parsed them and this is its chunked extract (x_rows are the rows)
+  const bool names = c->x_front && c->front && pp->rec == c->x_rows.as<strl_pair_rec>();
+  P.qref = names ? c->front->qref.as<uint64_t>() : nullptr;
+  P.qarena = names ? c->front->qarena.as<uint8_t>() : nullptr;
   hipEvent_t *ev = c->timing ? c->pev : nullptr;
   if (ev) STRL_HIP(hipEventRecord(ev[0], st));
   if (n) {
@@ -679,12 +797,13 @@ int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uin
   P.emit_key = ek; P.emit_val = evl;
   if (n) {
     const size_t pg_shmem = sizeof(PItem) * (PG_BLOCK + PG_HALO) + (sizeof(strl_tread) + 8) * PG_EMIT + 16;
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (!c->pg_attr_done) {      // (per context: contexts may sit on different devices)
       STRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_groups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_shmem));
-      attr_done = true;
+      c->pg_attr_done = true;
     }
     hipLaunchKernelGGL(pair_groups_kernel, dim3((unsigned)std::min<uint32_t>((icap + PG_BLOCK - 1) / PG_BLOCK, 8192)), dim3(PG_BLOCK), pg_shmem, st, P);
+    STRL_HIP(hipGetLastError());
+    hipLaunchKernelGGL(pair_long_kernel, dim3(64), dim3(PAIR_LONG_MAX), 0, st, P);      // (no spilled runs: 64 blocks read one counter)
     STRL_HIP(hipGetLastError());
   }
   if (ev) STRL_HIP(hipEventRecord(ev[4], st));

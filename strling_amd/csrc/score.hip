@@ -1268,7 +1268,7 @@ int strl_extract_begin(strl_ctx *c, uint64_t n_reads_hint) {
     return rc;
   STRL_HIP(hipMemsetAsync(c->x_cnt.p, 0, XC_WORDS * 4, c->stream));
   if ((rc = bloom_reset(c, std::max<uint64_t>(hint, 1ull << 28)))) return rc;   // 16 MB: sized for a whole genome of reads
-  c->x_n = 0; c->x_soft_cap = c->x_soft.cap / sizeof(strl_soft_rec); c->x_open = true;
+  c->x_n = 0; c->x_soft_cap = c->x_soft.cap / sizeof(strl_soft_rec); c->x_open = true; c->x_front = false;
   c->x_soft_known = 0; c->x_soft_known_at = 0;
   if (c->x_soft_pending) { STRL_HIP(hipEventSynchronize(c->x_soft_seen_ev)); c->x_soft_pending = false; }
   return STRL_OK;
@@ -1385,7 +1385,8 @@ int strl_treads_fetch(strl_ctx *c, strl_tread *out, uint64_t cap, uint64_t *n_ou
   const uint32_t err = pc[PC_ERR];
   if (err & PAIR_ERR_ITEMS) { set_error("pair logic: %u join items, capacity %u (raise item_cap)", pc[PC_ITEMS], c->pair_item_cap); return STRL_ERR_CAPACITY; }
   if (err & PAIR_ERR_EMIT) { set_error("pair logic: %u treads, capacity %u (raise tread_cap)", pc[PC_EMIT], c->tread_cap); return STRL_ERR_CAPACITY; }
-  if (err & (PAIR_ERR_RUN | PAIR_ERR_LOCAL)) { set_error("pair logic: more than 12 records / emissions under one qname hash"); return STRL_ERR_FORMAT; }
+  if (err & PAIR_ERR_COLLISION) { set_error("pair logic: two different qnames share one 64-bit hash (use the host pair logic, strl_pair_reads: it keys on the string)"); return STRL_ERR_FORMAT; }
+  if (err & (PAIR_ERR_RUN | PAIR_ERR_LOCAL)) { set_error("pair logic: more than %d join items share the low 32 bits of their qname hash (use the host pair logic, strl_pair_reads)", strl::PAIR_LONG_MAX_ITEMS); return STRL_ERR_FORMAT; }
   if (err & PAIR_ERR_ASSERT) { set_error("repeat_count >= 256 (doAssert extract.nim:72)"); return STRL_ERR_ASSERT; }
   const uint64_t n = pc[PC_EMIT];
   if (out) {
@@ -1477,6 +1478,7 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
   if (c->front) { if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a); strl::front_destroy(c->front); c->front = nullptr; }
   strl::strl_front *F = new strl::strl_front();
   c->front = F;
+  c->x_front = true;
   F->n_ref = n_ref; F->first_off = first_record_offset;
   STRL_HIP(hipStreamCreateWithFlags(&F->st_a, hipStreamNonBlocking));
   STRL_HIP(hipStreamCreateWithFlags(&F->st_c, hipStreamNonBlocking));

@@ -392,19 +392,26 @@ def test_pair_logic_corner_cases_on_the_device(ctx, oracle):
         assert ok, why
 
 
-def test_too_many_records_under_one_qname_fall_back_to_the_host_pair_logic(ctx, oracle):
+@pytest.mark.parametrize("n", [16, 200, 700])
+def test_many_records_under_one_qname(ctx, oracle, n):
+    """one qname on n primary records: up to 512 join items the device replays the run (a block of its own, pair_long_kernel);
+    beyond, it reports the run and strl_extract repeats the batch on the host's string-keyed Cache"""
     C_ = "CAG" * 50
-    n = 16
     rec = RecordBatch.from_fields([0] * n, list(range(100, 100 + n)), [0] * n, [5000] * n, [99] * n, [60] * n, ["150M"] * n, [C_] * n, ["dup"] * n)
     ctx.set_opts(0.8, 40, 350)
     ctx.set_genome(None)
+    exp = oracle.extract(rec, None, oracle.make_opts(350, 0.8, 40))
     soa = api.Soa(rec)
     cp, keep = _pair_soa(rec, soa)
     ctx.extract_device(soa.c_struct(), cp, 0)
-    with pytest.raises(api.StrlingError):
-        ctx.treads_fetch()
-    got, _ = ctx.extract(rec)                       # strl_extract replays such a batch on the host
-    exp = oracle.extract(rec, None, oracle.make_opts(350, 0.8, 40))
+    if n <= 512:
+        got, _ = ctx.treads_fetch()
+        ok, why = treads_equal(got, exp)
+        assert ok, why
+    else:
+        with pytest.raises(api.StrlingError):
+            ctx.treads_fetch()
+    got, _ = ctx.extract(rec)
     ok, why = treads_equal(got, exp)
     assert ok, why
 
