@@ -119,6 +119,31 @@ def test_extract_bin_is_byte_identical_to_oracle(sample, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("front", ["device", "host"])
+def test_extract_never_quits_on_a_qname_carried_by_hundreds_of_records(oracle, tmp_path, front):
+    """700 primary records under one qname: more than the device join replays (512 items).  The CLI repeats the extraction
+    with the host's string-keyed Cache by itself -- same .bin as the oracle -- instead of quitting (extract.nim never fails there)."""
+    from strling_amd.records import RecordBatch
+    n = 700
+    rec = RecordBatch.from_fields([0] * n, list(range(100, 100 + n)), [0] * n, [5000] * n, [99] * n, [60] * n, ["150M"] * n, ["CAG" * 50] * n, ["dup"] * n,
+                                  isize=[300] * n, targets=[("chr1", 100000)])
+    bam, bed, out = str(tmp_path / "d.bam"), str(tmp_path / "d.bed"), str(tmp_path / "d.bin")
+    hdr = bamio.write_bam(bam, rec, index=False)
+    open(bed, "w").close()
+    env = dict(os.environ)
+    if front == "host":
+        env["STRL_FRONT"] = "host"
+    r = _run(["extract", "-g", bed, bam, out], env=env)
+    assert r.returncode == 0, r.stderr
+    assert "repeating the extraction with the host pair logic" in r.stderr
+    frag = synth.frag_hist(rec)
+    med = oracle.median(frag)
+    exp_t = oracle.extract(rec, None, oracle.make_opts(med, 0.8, 40))
+    exp = oracle.bin_write(0.8, 40, frag, hdr.rstrip("\0"), exp_t, rec.qname_off, rec.qnames)
+    assert open(out, "rb").read() == exp
+
+
+@pytest.mark.gpu
 def test_merge_bounds_match_oracle(sample, oracle, tmp_path):
     """strling merge BIN... -> -bounds.txt identical (rows and row order) to the oracle's merge clustering."""
     bins, all_t, frag_sum = [], [], np.zeros(4096, np.uint64)
