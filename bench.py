@@ -129,12 +129,21 @@ def main():
     exchange = None
     if world > 1:
         from strling_amd import dist as sdist
-        try:
-            exchange = sdist.DeviceClusterExchange(ctx, world, rank, n_treads, dev)
-            exchange.step(n_tid * 1, window, 5, max_clip_dist, pos_bits)
-            torch.cuda.synchronize()
-        except Exception as e:                        # keep the shard-only measurement if the collective is unavailable
-            print(f"[bench] rank {rank}: tread all-gather disabled: {e}", file=sys.stderr)
+        # the collective inside the library (comm.hip: ncclAllGather on the tail's stream, the entry point the CLI's --gpus N
+        # uses too); STRL_TORCH_COMM=1, or a failure here, keeps torch.distributed's all_gather_into_tensor
+        for cls in ([] if os.environ.get("STRL_TORCH_COMM") else [sdist.NativeClusterExchange]) + [sdist.DeviceClusterExchange]:
+            try:
+                exchange = cls(ctx, world, rank, n_treads, dev)
+                exchange.step(n_tid * 1, window, 5, max_clip_dist, pos_bits)
+                torch.cuda.synchronize()
+                ok1 = 1
+            except Exception as e:                    # keep the shard-only measurement if the collective is unavailable
+                print(f"[bench] rank {rank}: {cls.__name__} unavailable: {e}", file=sys.stderr)
+                exchange, ok1 = None, 0
+            ok_all = torch.tensor([ok1], device=dev)
+            dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)      # all ranks must take the same path
+            if int(ok_all.item()) == 1:
+                break
             exchange = None
         ok = torch.tensor([1 if exchange is not None else 0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)     # all ranks must agree, or the collective would hang
@@ -341,7 +350,7 @@ def main():
                                        "context's streams (side streams run pair logic + clustering of a step while the next step's scorer runs); BAM decode, PCIe, the host-side row order "
                                        "(Nim table order) and file writing are in end_to_end, not here",
                        "parallelism": (f"records sharded over {world} GPU(s), no data-path collective" if exchange is None else
-                                       f"records sharded over {world} GPUs; per step one RCCL all-gather of the tread arrays "
+                                       f"records sharded over {world} GPUs; per step one RCCL all-gather of the tread arrays [{type(exchange).__name__}] "
                                        f"({exchange.pad * 32} B per rank) before clustering, every rank clusters the (tid, unit) groups it owns")},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_nproc": cpu_nproc, "cpu_baseline_e2e": cpu_e2e, "end_to_end": e2e,
         }

@@ -344,6 +344,28 @@ int strl_cluster_gathered(strl_ctx *ctx, const strl_tread *gathered, const uint3
                           uint16_t max_clip_dist, strl_bounds *out, uint64_t cap, uint64_t *n_out, strl_unplaced *unplaced,
                           uint64_t unplaced_cap, uint64_t *n_unplaced, strl_cluster_stats *stats);
 
+/* ---- the same exchange inside the library: RCCL over xGMI (comm.hip).  The reference is single-threaded per sample
+ * (merge.nim:52,89 is its only sharding knob); this is north_star's "RCCL all-gather ... before clustering".
+ * Ranks = one process per GPU: rank 0 calls strl_comm_unique_id, the bytes travel by the host framework's own means
+ * (torch.distributed broadcast, MPI_Bcast), every rank calls strl_ctx_comm_init; then strl_cluster_exchange per step:
+ * .bin-order sort of the resident treads, ncclAllGather of the padded tread buffers and their counts on the stream the
+ * batch's tail runs on, strl_cluster_gathered.  `pad` = the most treads a rank contributes, equal on all ranks.
+ * Ranks = one process, n contexts (the CLI's --gpus N): strl_ctxs_comm_init (ncclCommInitAll on n different devices; where
+ * contexts share a device -- RCCL refuses two ranks per device -- the exchange is made with ordered device copies), then
+ * strl_ctxs_cluster_exchange for all of them and strl_cluster_collect per context.
+ * strl_exchange_treads: all ranks' treads of the last exchange in (rank, .bin) order, for strl_group_order. */
+#define STRL_COMM_ID_BYTES 128
+int strl_comm_unique_id(uint8_t id[STRL_COMM_ID_BYTES]);
+int strl_ctx_comm_init(strl_ctx *ctx, int world, int rank, const uint8_t id[STRL_COMM_ID_BYTES]);
+int strl_ctxs_comm_init(strl_ctx **ctxs, int n);
+int strl_ctx_comm_info(strl_ctx *ctx, int *world, int *rank, int *uses_rccl);
+int strl_cluster_exchange(strl_ctx *ctx, uint32_t pad, int mode, int32_t n_tid, int pos_bits, uint32_t window, int32_t min_support, uint16_t min_clip,
+                          uint16_t min_clip_total, uint16_t max_clip_dist, strl_bounds *out, uint64_t cap, uint64_t *n_out, strl_unplaced *unplaced,
+                          uint64_t unplaced_cap, uint64_t *n_unplaced, strl_cluster_stats *stats);
+int strl_ctxs_cluster_exchange(strl_ctx **ctxs, int n, uint32_t pad, int mode, int32_t n_tid, int pos_bits, uint32_t window, int32_t min_support,
+                               uint16_t min_clip, uint16_t min_clip_total, uint16_t max_clip_dist);
+int strl_exchange_treads(strl_ctx *ctx, strl_tread *out, uint64_t cap, uint64_t *n_out);
+
 /* bounds() (cluster.nim:175-250) + the gate of callclusters.nim:52-66 on one bare cluster -- reads sorted by position,
  * Cluster.left_most = right_most = 0 -- run by the device function the clustering kernels call.  *good = the gate's verdict. */
 int strl_bounds_bare(strl_ctx *ctx, const uint32_t *positions, const uint8_t *splits, uint32_t n, uint16_t min_clip, uint16_t min_clip_total,

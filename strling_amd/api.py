@@ -117,7 +117,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
            "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order",
-           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered", "strl_inflate_blocks", "strl_ctx_inflate_ms", "strl_front_begin", "strl_front_push", "strl_front_finish", "strl_front_fragwords", "strl_front_tids", "strl_front_qnames", "strl_pinned_alloc", "strl_pinned_free", "strl_cluster_collect", "strl_ctx_tail_stream"]
+           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered", "strl_inflate_blocks", "strl_ctx_inflate_ms", "strl_front_begin", "strl_front_push", "strl_front_finish", "strl_front_fragwords", "strl_front_tids", "strl_front_qnames", "strl_pinned_alloc", "strl_pinned_free", "strl_comm_unique_id", "strl_ctx_comm_init", "strl_ctxs_comm_init", "strl_ctx_comm_info", "strl_cluster_exchange", "strl_ctxs_cluster_exchange", "strl_exchange_treads", "strl_cluster_collect", "strl_ctx_tail_stream"]
 
 
 def lib_path():
@@ -208,6 +208,14 @@ def load(build_if_missing=True):
     L.strl_pinned_alloc.argtypes = [C.c_uint64]
     L.strl_pinned_alloc.restype = C.c_void_p
     L.strl_pinned_free.argtypes = [C.c_void_p]
+    L.strl_comm_unique_id.argtypes = [C.c_void_p]
+    L.strl_ctx_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.strl_ctxs_comm_init.argtypes = [C.c_void_p, C.c_int]
+    L.strl_ctx_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.strl_cluster_exchange.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int32, C.c_int, C.c_uint32, C.c_int32, C.c_uint16, C.c_uint16, C.c_uint16,
+                                        C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(ClusterStats)]
+    L.strl_ctxs_cluster_exchange.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int32, C.c_int, C.c_uint32, C.c_int32, C.c_uint16, C.c_uint16, C.c_uint16]
+    L.strl_exchange_treads.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.strl_pair_rows.argtypes = [C.POINTER(CRecords)] + [C.c_void_p] * 5
     L.strl_ctx_cluster_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 3)]
     L.strl_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
@@ -658,6 +666,60 @@ class Context:
             _check(rc)
             return out[:no.value].copy(), unpl[:nu.value].copy(), st
 
+    # ---- the exchange step inside the library (comm.hip: RCCL over xGMI / device copies) ---------
+    def comm_init(self, world, rank, unique_id=None):
+        """one process per GPU: join the RCCL communicator `unique_id` (bytes from comm_unique_id() on rank 0) names"""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        _check(self.L.strl_ctx_comm_init(self.h, world, rank, buf))
+
+    def comm_info(self):
+        w, r, u = C.c_int(0), C.c_int(0), C.c_int(0)
+        _check(self.L.strl_ctx_comm_info(self.h, C.byref(w), C.byref(r), C.byref(u)))
+        return w.value, r.value, bool(u.value)
+
+    def cluster_exchange(self, pad, n_tid, window, min_support=5, min_clip=0, min_clip_total=0, max_clip_dist=200, pos_bits=0, mode=MODE_CALL, fetch=True):
+        """all-gather of the resident treads over the context's communicator + clustering of my (tid, unit) groups
+        (strl_cluster_exchange); fetch=False only enqueues"""
+        if not fetch:
+            _check(self.L.strl_cluster_exchange(self.h, pad, mode, n_tid, pos_bits, window, min_support, min_clip, min_clip_total, max_clip_dist,
+                                                None, 0, None, None, 0, None, None))
+            return None
+        cap = 1 << 16
+        while True:
+            out = np.zeros(cap, BOUNDS_DTYPE)
+            unpl = np.zeros(8192, UNPLACED_DTYPE)
+            no, nu = C.c_uint64(0), C.c_uint64(0)
+            st = ClusterStats()
+            rc = self.L.strl_cluster_exchange(self.h, pad, mode, n_tid, pos_bits, window, min_support, min_clip, min_clip_total, max_clip_dist,
+                                              out.ctypes.data, cap, C.byref(no), unpl.ctypes.data, unpl.size, C.byref(nu), C.byref(st))
+            if rc == -4 and no.value > cap:
+                cap = int(no.value)
+                continue
+            _check(rc)
+            return out[:no.value].copy(), unpl[:nu.value].copy(), st
+
+    def exchange_treads(self):
+        """all ranks' treads of the last exchange, (rank, .bin) order"""
+        n = C.c_uint64(0)
+        _check(self.L.strl_exchange_treads(self.h, None, 0, C.byref(n)))
+        out = np.zeros(max(1, n.value), TREAD_DTYPE)
+        _check(self.L.strl_exchange_treads(self.h, out.ctypes.data, out.size, C.byref(n)))
+        return out[:n.value]
+
+    def cluster_collect(self, cap=1 << 16):
+        """rows of the last (asynchronous) clustering pass of this context (strl_cluster_collect)"""
+        while True:
+            out = np.zeros(cap, BOUNDS_DTYPE)
+            unpl = np.zeros(8192, UNPLACED_DTYPE)
+            no, nu = C.c_uint64(0), C.c_uint64(0)
+            st = ClusterStats()
+            rc = self.L.strl_cluster_collect(self.h, out.ctypes.data, cap, C.byref(no), unpl.ctypes.data, unpl.size, C.byref(nu), C.byref(st))
+            if rc == -4 and no.value > cap:
+                cap = int(no.value)
+                continue
+            _check(rc)
+            return out[:no.value].copy(), unpl[:nu.value].copy(), st
+
     def cluster_members(self, n_bounds):
         """indices (into the tread array of the last cluster() call) of every returned bound's reads, cluster order"""
         off = np.zeros(n_bounds + 1, np.uint64)
@@ -670,6 +732,28 @@ class Context:
     def cluster_replay(self):
         """device side of the last cluster() call again, asynchronously (bench)"""
         _check(self.L.strl_cluster_replay(self.h))
+
+
+def comm_unique_id():
+    """128 bytes that name a new RCCL communicator (rank 0 makes them, every rank passes them to Context.comm_init)"""
+    L = load()
+    buf = (C.c_uint8 * 128)()
+    _check(L.strl_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def group_comm_init(ctxs):
+    """one process, several contexts: RCCL when they sit on different devices, ordered device copies when they share one"""
+    L = load()
+    arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    _check(L.strl_ctxs_comm_init(arr, len(ctxs)))
+
+
+def group_cluster_exchange(ctxs, n_tid, window, min_support=5, min_clip=0, min_clip_total=0, max_clip_dist=200, pos_bits=0, mode=MODE_CALL, pad=0):
+    """the exchange step for all contexts of a one-process group (strl_ctxs_cluster_exchange); rows: Context.cluster_collect"""
+    L = load()
+    arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    _check(L.strl_ctxs_cluster_exchange(arr, len(ctxs), pad, mode, n_tid, pos_bits, window, min_support, min_clip, min_clip_total, max_clip_dist))
 
 
 def qname_hash(rec):

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libstrling_amd.so")
 CLI = os.path.join(LIBDIR, "strling")
-SOURCES = ["score.hip", "pair.hip", "sort.hip", "cluster.hip", "bgzf.hip", "front.hip", "host_logic.cpp", "call_logic.cpp", "nim_tables.cpp"]
+SOURCES = ["score.hip", "pair.hip", "sort.hip", "cluster.hip", "bgzf.hip", "front.hip", "comm.hip", "host_logic.cpp", "call_logic.cpp", "nim_tables.cpp"]
 CLI_SOURCES = ["cli/main.cpp", "cli/bam_reader.cpp", "cli/fast_inflate.cpp", "cli/bgzf_feed.cpp"]
 HEADERS = ["common.h", "device_util.h", "sort.h", "inflate_wave.h", "front.h", "score_core.h", "score_tables.h", "nim_tables.h", "cli/bam_reader.h", "cli/fast_inflate.h", "cli/bgzf_feed.h", "../../include/strling_amd.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
@@ -37,7 +37,7 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
     if force or _stale(LIB, deps):
-        cmd = [_hipcc()] + FLAGS + ["-shared", "-o", LIB] + srcs
+        cmd = [_hipcc()] + FLAGS + ["-shared", "-o", LIB] + srcs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)

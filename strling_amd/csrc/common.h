@@ -70,7 +70,7 @@ struct ClusterRun {
   std::vector<uint32_t> b_first, b_count, kept;
 };
 
-namespace strl { struct strl_front; }
+namespace strl { struct strl_front; struct strl_comm; void comm_destroy(strl_comm *m); }
 struct strl_ctx;
 int side_join(strl_ctx *c);   // main stream waits for the side streams' pending work (score.hip)
 void rotate_tail(strl_ctx *c);  // make the least recently used set of pair-logic / clustering state the current one (score.hip)
@@ -163,6 +163,7 @@ struct strl_ctx {
   hipEvent_t pev[6] = {};
   double inflate_ms = 0;           // kernel time of the last strl_inflate_blocks call
   strl::strl_front *front = nullptr;   // device BAM front end (front.h), created by strl_front_begin
+  strl::strl_comm *comm = nullptr;     // multi-GPU exchange (comm.hip): RCCL communicator / local group of this context
   // staging of the pairing arrays for host-memory batches
   strl::DevBuf st_mtid, st_mpos, st_flag, st_qhash;
 };

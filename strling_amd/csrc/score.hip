@@ -826,6 +826,7 @@ void strl_ctx_destroy(strl_ctx *c) {
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   for (auto &a : c->alt) if (a.stream2) (void)hipStreamSynchronize(a.stream2);
   (void)hipStreamSynchronize(c->stream);
+  if (c->comm) { strl::comm_destroy(c->comm); c->comm = nullptr; }
   if (c->x_soft_seen_ev) (void)hipEventDestroy(c->x_soft_seen_ev);
   if (c->x_soft_seen) (void)hipHostFree(c->x_soft_seen);
   if (c->front) { if (c->front->st_c) (void)hipStreamSynchronize(c->front->st_c); if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a); strl::front_destroy(c->front); c->front = nullptr; }

@@ -213,6 +213,29 @@ class DeviceClusterExchange:
         return np.concatenate([raw[r * self.pad: r * self.pad + int(c[r])] for r in range(self.world)])
 
 
+class NativeClusterExchange:
+    """The same step with the collective INSIDE the library (comm.hip): strl_cluster_exchange = .bin-order sort, ncclAllGather of
+    the padded tread buffers on the tail's stream, strl_cluster_gathered.  torch.distributed only carries the 128-byte
+    communicator id to the ranks and agrees on the padding.  Interface of DeviceClusterExchange."""
+
+    def __init__(self, ctx, world, rank, n_treads_hint, dev, group=None):
+        import torch
+        self.ctx, self.world, self.rank, self.group, self.dev = ctx, world, rank, group, dev
+        on_dev = dist.get_backend(group) == "nccl"
+        pad = torch.tensor([int(n_treads_hint * 1.25) + 4096], dtype=torch.int64, device=dev if on_dev else "cpu")
+        dist.all_reduce(pad, op=dist.ReduceOp.MAX, group=group)
+        self.pad = int(pad.item())
+        box = [api.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        ctx.comm_init(world, rank, box[0])
+
+    def step(self, n_tid, window, min_support, max_clip_dist, pos_bits=0, fetch=False):
+        return self.ctx.cluster_exchange(self.pad, n_tid, window, min_support=min_support, max_clip_dist=max_clip_dist, pos_bits=pos_bits, fetch=fetch)
+
+    def gathered_treads(self):
+        return self.ctx.exchange_treads()
+
+
 def cluster_sharded_device(ex, mode_call_args, n_tid):
     """Whole multi-GPU clustering through a DeviceClusterExchange: my share on the device, then the rows of all ranks in the
     reference's row order (identical on every rank).  mode_call_args = dict(window=, min_support=, max_clip_dist=, pos_bits=)."""
