@@ -354,6 +354,9 @@ int strl_cluster_gathered(strl_ctx *ctx, const strl_tread *gathered, const uint3
  * contexts share a device -- RCCL refuses two ranks per device -- the exchange is made with ordered device copies), then
  * strl_ctxs_cluster_exchange for all of them and strl_cluster_collect per context.
  * strl_exchange_treads: all ranks' treads of the last exchange in (rank, .bin) order, for strl_group_order. */
+/* host treads -> the context's resident treads (as if strl_extract_device had left them): how `strling merge --gpus N`
+ * hands every context its share of the .bin files' treads before strl_ctxs_cluster_exchange */
+int strl_ctx_set_treads(strl_ctx *ctx, const strl_tread *treads, uint64_t n);
 #define STRL_COMM_ID_BYTES 128
 int strl_comm_unique_id(uint8_t id[STRL_COMM_ID_BYTES]);
 int strl_ctx_comm_init(strl_ctx *ctx, int world, int rank, const uint8_t id[STRL_COMM_ID_BYTES]);

@@ -860,11 +860,13 @@ static int merge_main(int argc, char **argv) {
       "  --chromosome=CHROMOSOME    chromosome to restrict parsing. helps with memory/parallelization for large cohorts (default: -2)\n"
       "  -l, --bed=BED              Annoated bed file specifying additional STR loci to genotype. Format is: chr start stop repeatunit [name]\n"
       "  -d, --diff-refs            allow bin files generated on a mixture of reference genomes (by default differing references will produce an error). "
-      "Reports chromosomes in the first bin or -f if provided\n  -v, --verbose\n  -h, --help                 Show this help\n";
+      "Reports chromosomes in the first bin or -f if provided\n"
+      "  --gpus=N                   cluster on N GPUs: the samples' reads shard over them, RCCL all-gather, every GPU clusters the (chromosome, repeat unit) "
+      "groups it owns (default: 1)\n  -v, --verbose\n  -h, --help                 Show this help\n";
   if (argc <= 2) { fputs(usage, stdout); return 0; }
   const Args a = parse(argc, argv, 2, {{"fasta", 'f', true}, {"window", 'w', true}, {"min-support", 'm', true}, {"chromosome", 'C', true},
                                        {"min-clip", 'c', true}, {"min-clip-total", 't', true}, {"min-mapq", 'q', true}, {"bed", 'l', true},
-                                       {"output-prefix", 'o', true}, {"diff-refs", 'd', false}, {"verbose", 'v', false}}, usage);
+                                       {"output-prefix", 'o', true}, {"diff-refs", 'd', false}, {"verbose", 'v', false}, {"gpus", 'G', true}}, usage);
   if (a.flag("bed") && !file_exists(a.get("bed", ""))) quit("couldn't open bed file");     // merge.nim:80-82
   const bool allow_diff = a.flag("diff-refs");
   std::vector<BamTarget> targets;
@@ -940,11 +942,54 @@ static int merge_main(int argc, char **argv) {
     CHECK(strl_assign_reads_loci(all.data(), all.size(), STRL_MODE_MERGE, loci.data(), loci.size(), aoff.data(), nullptr, 0));
   }
   strl_ctx *ctx = nullptr;
-  CHECK(strl_ctx_create(0, &ctx));
   std::vector<strl_bounds> bounds(std::max<size_t>(all.size(), 16));
   uint64_t nb = 0, nu = 0;
-  CHECK(strl_cluster(ctx, all.data(), all.size(), STRL_MODE_MERGE, (uint32_t)window, min_support, min_clip, min_clip_total, max_clip_dist,
-                     bounds.data(), bounds.size(), &nb, nullptr, 0, &nu, nullptr));
+  const int gpus = std::max(1, atoi(a.get("gpus", "1").c_str()));
+  if (gpus == 1) {
+    CHECK(strl_ctx_create(0, &ctx));
+    CHECK(strl_cluster(ctx, all.data(), all.size(), STRL_MODE_MERGE, (uint32_t)window, min_support, min_clip, min_clip_total, max_clip_dist,
+                       bounds.data(), bounds.size(), &nb, nullptr, 0, &nu, nullptr));
+  } else {
+    // contiguous shares of the reads (sample order is kept: rank-major = input order) go to the contexts,
+    // one per device -- round-robin over the devices there are, so `--gpus 2` also runs on a one-GPU box --, the tread buffers
+    // are all-gathered (RCCL over xGMI between different devices) and every context clusters the groups it owns; the rows come
+    // back in the reference's order of the groups (first appearance, Nim table order: strl_group_order).
+    const int n_dev = std::max(1, strl_device_count());
+    std::vector<strl_ctx *> ctxs((size_t)gpus, nullptr);
+    for (int r = 0; r < gpus; ++r) CHECK(strl_ctx_create(r % n_dev, &ctxs[(size_t)r]));
+    CHECK(strl_ctxs_comm_init(ctxs.data(), gpus));
+    const size_t per = (all.size() + (size_t)gpus - 1) / (size_t)gpus;
+    for (int r = 0; r < gpus; ++r) {
+      const size_t lo = std::min(all.size(), per * (size_t)r), hi = std::min(all.size(), lo + per);
+      CHECK(strl_ctx_set_treads(ctxs[(size_t)r], all.data() + lo, hi - lo));
+    }
+    CHECK(strl_ctxs_cluster_exchange(ctxs.data(), gpus, (uint32_t)std::max<size_t>(per, 1), STRL_MODE_MERGE, (int32_t)targets.size(), 0, (uint32_t)window, min_support,
+                                     min_clip, min_clip_total, max_clip_dist));
+    std::vector<strl_bounds> part(bounds.size());
+    std::vector<strl_bounds> got;
+    for (int r = 0; r < gpus; ++r) {
+      uint64_t k = 0, ku = 0;
+      CHECK(strl_cluster_collect(ctxs[(size_t)r], part.data(), part.size(), &k, nullptr, 0, &ku, nullptr));
+      got.insert(got.end(), part.begin(), part.begin() + (long)k);
+    }
+    std::vector<strl_group_key> keys(all.size() + 1);
+    uint64_t ng = 0;
+    CHECK(strl_group_order(all.data(), all.size(), STRL_MODE_MERGE, keys.data(), keys.size(), &ng));
+    std::map<std::pair<int32_t, std::string>, uint64_t> rank_of;
+    for (uint64_t k = 0; k < ng; ++k) rank_of[{keys[(size_t)k].tid, std::string(keys[(size_t)k].repeat, strnlen(keys[(size_t)k].repeat, 6))}] = k;
+    std::stable_sort(got.begin(), got.end(), [&](const strl_bounds &x, const strl_bounds &y) {
+      return rank_of[{x.tid, std::string(x.repeat, strnlen(x.repeat, 6))}] < rank_of[{y.tid, std::string(y.repeat, strnlen(y.repeat, 6))}];
+    });
+    nb = got.size();
+    std::copy(got.begin(), got.end(), bounds.begin());
+    if (verbose) {
+      int w = 0, rk = 0, rccl = 0;
+      (void)strl_ctx_comm_info(ctxs[0], &w, &rk, &rccl);
+      fprintf(stderr, "[strling] clustered on %d contexts over %d device(s), exchange by %s\n", gpus, std::min(gpus, n_dev), rccl ? "RCCL all-gather" : "device copies (contexts share a device)");
+    }
+    for (int r = 1; r < gpus; ++r) strl_ctx_destroy(ctxs[(size_t)r]);
+    ctx = ctxs[0];
+  }
   const std::string outp = prefix + "-bounds.txt";
   FILE *fo = fopen(outp.c_str(), "w");
   if (!fo) quit("couldn't open output file");

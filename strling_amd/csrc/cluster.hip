@@ -987,6 +987,27 @@ extern "C" void *strl_ctx_tail_stream(strl_ctx *c) {
   return (void *)(tail_on_side(c) ? c->stream2 : c->stream);
 }
 
+// Make a host array of treads the context's resident treads (what strl_extract_device would have left): the multi-GPU
+// `strling merge` shards the treads of its .bin files over the contexts this way before the exchange step.
+extern "C" int strl_ctx_set_treads(strl_ctx *c, const strl_tread *treads, uint64_t n) {
+  if (!c || (n && !treads) || n > 0x7ffffff0ull) { set_error("strl_ctx_set_treads: bad argument"); return STRL_ERR_ARG; }
+  { const int rcj = side_join(c); if (rcj) return rcj; }
+  STRL_HIP(hipSetDevice(c->device));
+  const uint32_t cap = (uint32_t)std::max<uint64_t>(n, 1);
+  int rc;
+  if ((rc = c->treads.reserve((size_t)cap * sizeof(strl_tread) + 64))) return rc;
+  if (n) STRL_HIP(hipMemcpyAsync(c->treads.p, treads, (size_t)n * sizeof(strl_tread), hipMemcpyHostToDevice, c->stream));
+  uint32_t *cnt = reinterpret_cast<uint32_t *>(c->treads.as<uint8_t>() + (size_t)cap * sizeof(strl_tread));
+  const uint32_t n32 = (uint32_t)n;
+  STRL_HIP(hipMemcpyAsync(cnt, &n32, 4, hipMemcpyHostToDevice, c->stream));
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  c->n_treads_dev = cnt;
+  c->tread_cap = cap;
+  c->pair_ordered = true;
+  c->pair_on_side = false;
+  return STRL_OK;
+}
+
 extern "C" int strl_ctx_treads_device(strl_ctx *c, void **treads, uint64_t *cap, void **count) {
   const bool side = c && c->n_treads_dev && tail_on_side(c);
   if (c && !side) { const int rcj = side_join(c); if (rcj) return rcj; }

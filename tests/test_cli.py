@@ -174,6 +174,13 @@ def test_merge_bounds_match_oracle(sample, oracle, tmp_path):
     got = open(prefix + "-bounds.txt").read().rstrip("\n").split("\n")
     assert len(exp) > 3
     assert got == exp
+    # ... and clustered on several contexts (shares of the reads, exchange, owned groups, the reference's row order): the same file
+    for gpus in ("2", "3"):
+        pg = str(tmp_path / f"joint{gpus}")
+        r = _run(["merge", "-m", "2", "-v", "--gpus", gpus, "-o", pg] + bins)
+        assert r.returncode == 0, r.stderr
+        assert f"clustered on {gpus} contexts" in r.stderr
+        assert open(pg + "-bounds.txt").read() == open(prefix + "-bounds.txt").read(), gpus
 
 
 def _write_fasta(path, contigs, width=70, gz=False):
