@@ -495,6 +495,17 @@ int strl_front_begin(strl_ctx *ctx, int32_t n_ref, uint64_t first_record_offset,
 int strl_front_push(strl_ctx *ctx, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize,
                     uint32_t n_blocks, strl_front_chunk *done, int *n_done);
 int strl_front_finish(strl_ctx *ctx, strl_front_chunk done[2], int *n_done);
+/* One file on several GPUs (`strling extract --gpus N`; the reference has no counterpart, extract.nim:275 is one thread): the
+ * chunks go round-robin over n contexts, each with its own strl_front_begin (only the context that gets the file's first
+ * chunk uses first_record_offset).  strl_front_push_after: like strl_front_push, `prev` = the context the file's previous
+ * chunk went to (the partial record in front of this chunk comes from there, over xGMI when that is another device).
+ * After every context's strl_front_finish, strl_ctxs_extract_gather moves what the pair logic needs of every record
+ * (52 B: row, qname hash, scorer word, name reference; + soft-clip records, names, Bloom bits) to ctxs[0] in file order;
+ * ctxs[0] then continues like a one-GPU run: strl_front_fragwords, strl_extract_finish, strl_treads_fetch, strl_front_qnames.
+ * chunk_owner[k] / chunk_records[k]: context index and strl_front_chunk.n_records of the file's k-th chunk. */
+int strl_front_push_after(strl_ctx *ctx, strl_ctx *prev, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen,
+                          const uint32_t *isize, uint32_t n_blocks, strl_front_chunk *done, int *n_done);
+int strl_ctxs_extract_gather(strl_ctx **ctxs, int n, const uint32_t *chunk_owner, const uint64_t *chunk_records, uint64_t n_chunks);
 /* flag | (isize in [0, 4095] ? isize : 0xffff) << 16 of records [first, first + n) of the file: what
  * fragment_length_distribution (utils.nim:86-111) reads of a record.  Synchronises the context's stream. */
 int strl_front_fragwords(strl_ctx *ctx, uint64_t first, uint64_t n, uint32_t *out);

@@ -272,7 +272,7 @@ static Genome read_genome_bed(const std::string &path, const std::vector<BamTarg
 
 // genome_repeats, genome_strs.nim:107-146: existing file, or build it from the FASTA (into a temporary file when
 // no -g was given).  An existing -g is accepted without -f here; the reference insists on opening the FASTA first.
-static void setup_genome(strl_ctx *ctx, const Args &a, const std::vector<BamTarget> &targets) {
+static void setup_genome(strl_ctx *ctx, const Args &a, const std::vector<BamTarget> &targets, const std::vector<strl_ctx *> &more = {}) {
   std::string bed_path = a.get("genome-repeats", "");
   const bool is_tmp = bed_path.empty();
   if (is_tmp) {
@@ -290,6 +290,7 @@ static void setup_genome(strl_ctx *ctx, const Args &a, const std::vector<BamTarg
   if (is_tmp) remove(bed_path.c_str());
   strl_genome_str gs{(int32_t)targets.size(), g.has.data(), g.off.data(), g.st.data(), g.en.data()};
   CHECK(strl_ctx_set_genome(ctx, &gs));
+  for (strl_ctx *m : more) CHECK(strl_ctx_set_genome(m, &gs));
 }
 
 static int extract_front(const Args &a, const std::string &bam, const std::string &bin, double p, uint8_t min_mapq, bool verbose);
@@ -301,10 +302,12 @@ static int extract_main(int argc, char **argv) {
       "  bin              path bin to output bin file to be created\n\nOptions:\n  -f, --fasta=FASTA          path to fasta file (required for CRAM)\n"
       "  -g, --genome-repeats=GENOME_REPEATS\n                             optional path to genome repeats file. if it does not exist, it will be created\n"
       "  -p, --proportion-repeat=PROPORTION_REPEAT\n                             proportion of read that is repetitive to be considered as STR (default: 0.8)\n"
-      "  -q, --min-mapq=MIN_MAPQ    minimum mapping quality (does not apply to STR reads) (default: 40)\n  -v, --verbose\n  -h, --help                 Show this help\n";
+      "  -q, --min-mapq=MIN_MAPQ    minimum mapping quality (does not apply to STR reads) (default: 40)\n"
+      "  --gpus=N                   spread the file's chunks over N GPUs (inflate, parse and scoring there; the pair logic on the first) (default: 1)\n"
+      "  -v, --verbose\n  -h, --help                 Show this help\n";
   if (argc <= 2) { fputs(usage, stdout); return 0; }
   const Args a = parse(argc, argv, 2, {{"fasta", 'f', true}, {"genome-repeats", 'g', true}, {"proportion-repeat", 'p', true},
-                                       {"min-mapq", 'q', true}, {"verbose", 'v', false}, {"batch", 'B', true}}, usage);
+                                       {"min-mapq", 'q', true}, {"verbose", 'v', false}, {"batch", 'B', true}, {"gpus", 'G', true}}, usage);
   if (a.pos.size() != 2) quit("expected 2 arguments (bam, bin)\n%s", usage);
   const std::string bam = a.pos[0], bin = a.pos[1];
   const double p = atof(a.get("proportion-repeat", "0.8").c_str());
@@ -554,20 +557,22 @@ static int extract_main(int argc, char **argv) {
 
 // `strling extract` with the BAM front end on the device: this thread walks BGZF headers and copies compressed bytes into
 // page-locked buffers; inflate, record scan, parse, scorer, pair logic all run on the GPU (extract.nim:275-348).
+// --gpus N: the file's chunks go round-robin over N contexts (one per device, round-robin over the devices there are);
+// what the pair logic needs of every record is gathered on the first one at the end (strl_ctxs_extract_gather).
 static int extract_front(const Args &a, const std::string &bam, const std::string &bin, double p, uint8_t min_mapq, bool verbose) {
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double>(y - x).count(); };
   static const char *env_blocks = getenv("STRL_CHUNK_BLOCKS");     // tests: tiny chunks put records across chunk borders
   const size_t chunk_blocks = env_blocks && atoi(env_blocks) > 0 ? (size_t)atoi(env_blocks) : 8192;
   const size_t chunk_bytes = std::max<size_t>((size_t)1 << 20, chunk_blocks * 20000);       // compressed bytes one chunk may span
-  strl_ctx *ctx = nullptr;
-  int ctx_rc = 0;
-  std::string ctx_err;
-  uint8_t *pin[2] = {nullptr, nullptr};
-  uint8_t *pin_meta[2] = {nullptr, nullptr};  // block tables of the chunk: coff u64 | clen u32 | isize u32
+  const int G = std::max(1, atoi(a.get("gpus", "1").c_str()));
+  std::vector<strl_ctx *> ctxs((size_t)G, nullptr);
+  std::vector<int> ctx_rc((size_t)G, 0);
+  std::vector<std::string> ctx_err((size_t)G);
+  std::vector<uint8_t *> pin((size_t)2 * G, nullptr), pin_meta((size_t)2 * G, nullptr);   // two per context: [2 g + (its chunk count & 1)]
   const auto t_start = now();
   double t_ctx = 0, t_pin = 0;
-  // the HIP runtime, the context and the page-locked buffers come up on two threads beside the header walk
+  // the HIP runtime, the contexts and the page-locked buffers come up on threads beside the header walk
   std::thread pin_thread([&] {
     const auto c0 = now();
     for (auto &q : pin) q = static_cast<uint8_t *>(strl_pinned_alloc(chunk_bytes + 64));
@@ -576,8 +581,11 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   });
   std::thread ctx_thread([&] {
     const auto c0 = now();
-    ctx_rc = strl_ctx_create(0, &ctx);
-    if (ctx_rc) ctx_err = strl_last_error();
+    const int n_dev = std::max(1, strl_device_count());
+    for (int g = 0; g < G; ++g) {
+      ctx_rc[(size_t)g] = strl_ctx_create(g % n_dev, &ctxs[(size_t)g]);
+      if (ctx_rc[(size_t)g]) { ctx_err[(size_t)g] = strl_last_error(); break; }
+    }
     t_ctx = secs(c0, now());
   });
   g_bg_init = &ctx_thread;
@@ -588,14 +596,15 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   pin_thread.join();
   g_bg_init = nullptr;
   if (!opened) quit("couldn't open bam");
-  if (ctx_rc) quit("[strling] %s (status %d)", ctx_err.c_str(), ctx_rc);
-  if (!pin[0] || !pin[1] || !pin_meta[0] || !pin_meta[1]) quit("[strling] could not allocate page-locked memory");
+  for (int g = 0; g < G; ++g) if (ctx_rc[(size_t)g]) quit("[strling] %s (status %d)", ctx_err[(size_t)g].c_str(), ctx_rc[(size_t)g]);
+  for (size_t k = 0; k < pin.size(); ++k) if (!pin[k] || !pin_meta[k]) quit("[strling] could not allocate page-locked memory");
+  strl_ctx *ctx = ctxs[0];
   const double t_open = secs(t_start, now());
   strl_opts opts{0, p, min_mapq};              // the fragment-length median is only needed by the pair logic: set before strl_extract_finish
-  CHECK(strl_ctx_set_opts(ctx, &opts));
-  setup_genome(ctx, a, feed.targets());
+  for (strl_ctx *c : ctxs) CHECK(strl_ctx_set_opts(c, &opts));
+  setup_genome(ctx, a, feed.targets(), std::vector<strl_ctx *>(ctxs.begin() + 1, ctxs.end()));
   const int32_t n_ref = (int32_t)feed.targets().size();
-  CHECK(strl_front_begin(ctx, n_ref, feed.first_record_offset(), feed.file_bytes() / 48));
+  for (strl_ctx *c : ctxs) CHECK(strl_front_begin(c, n_ref, feed.first_record_offset(), feed.file_bytes() / 48 / (size_t)G));
 
   fprintf(stderr, "[strling] collecting str-like reads\n");
   const auto t0 = now();
@@ -604,9 +613,19 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   int64_t nreads = 0, n_tail = 0, tail_primary = 0;
   uint64_t n_seen = 0, slow_segments = 0;
   double t_walk = 0, t_copy = 0, t_push = 0;
-  auto account = [&](const strl_front_chunk *done, int n_done) {
-    for (int k = 0; k < n_done; ++k) {
-      const strl_front_chunk &d = done[k];
+  // summaries arrive per context in the order of ITS chunks; the file order is what counts
+  std::vector<strl_front_chunk> summary;                 // by chunk of the file
+  std::vector<uint32_t> chunk_owner;
+  std::vector<std::vector<uint64_t>> waiting((size_t)G);  // per context: its chunks without a summary yet
+  std::vector<size_t> waiting_at((size_t)G, 0);
+  uint64_t accounted = 0;
+  auto got = [&](int g, const strl_front_chunk *done, int n_done) {
+    for (int k = 0; k < n_done; ++k) summary[(size_t)waiting[(size_t)g][waiting_at[(size_t)g]++]] = done[k];
+  };
+  std::vector<uint8_t> have;
+  auto account = [&] {           // the leading run of chunks whose summaries are in, in file order
+    while (accounted < summary.size() && have[(size_t)accounted]) {
+      const strl_front_chunk &d = summary[(size_t)accounted++];
       nreads += (int64_t)d.n_primary;
       n_seen += d.n_records;
       slow_segments += d.scan_slow_segments;
@@ -615,6 +634,8 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
       if (verbose) fprintf(stderr, "%lld %.1f reads/sec\n", (long long)nreads, (double)nreads / std::max(secs(t0, now()), 1e-9));
     }
   };
+  auto mark = [&](int g, size_t before) { for (size_t k = before; k < waiting_at[(size_t)g]; ++k) have[(size_t)waiting[(size_t)g][k]] = 1; };
+  std::vector<uint64_t> pushes((size_t)G, 0);
   for (uint64_t ci = 0;; ++ci) {
     const auto ta = now();
     // a short first chunk gets the device going while the second is being copied
@@ -622,26 +643,45 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     if (nb < 0) quit("[strling] error reading %s: %s", bam.c_str(), err.c_str());
     if (nb == 0) break;
     const auto tb = now();
+    const int g = (int)(ci % (uint64_t)G);
     const size_t lo = blks.front().c_off, hi = blks.back().c_off + blks.back().clen;
-    uint8_t *dst = pin[ci & 1];
+    const size_t slot = (size_t)2 * g + (size_t)(pushes[(size_t)g] & 1);
+    uint8_t *dst = pin[slot];
     const size_t piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
     copy_pool.parallel_for(pieces, [&](size_t k) { memcpy(dst + k * piece, feed.map() + lo + k * piece, std::min(piece, hi - lo - k * piece)); });
-    uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[ci & 1]);
+    uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[slot]);
     uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks;
     for (size_t k = 0; k < (size_t)nb; ++k) { coff[k] = blks[k].c_off - lo; clen[k] = blks[k].clen; isz[k] = blks[k].isize; }
     const auto tc = now();
     strl_front_chunk done[2];
     int n_done = 0;
-    CHECK(strl_front_push(ctx, dst, hi - lo, coff, clen, isz, (uint32_t)nb, done, &n_done));
-    account(done, n_done);
+    summary.push_back(strl_front_chunk{});
+    have.push_back(0);
+    chunk_owner.push_back((uint32_t)g);
+    waiting[(size_t)g].push_back(ci);
+    const size_t before = waiting_at[(size_t)g];
+    CHECK(strl_front_push_after(ctxs[(size_t)g], ci ? ctxs[(size_t)((ci - 1) % (uint64_t)G)] : nullptr, dst, hi - lo, coff, clen, isz, (uint32_t)nb, done, &n_done));
+    ++pushes[(size_t)g];
+    got(g, done, n_done);
+    mark(g, before);
+    account();
     t_walk += secs(ta, tb); t_copy += secs(tb, tc); t_push += secs(tc, now());
   }
   const auto tf = now();
-  {
+  for (int g = 0; g < G; ++g) {
     strl_front_chunk done[2];
     int n_done = 0;
-    CHECK(strl_front_finish(ctx, done, &n_done));
-    account(done, n_done);
+    const size_t before = waiting_at[(size_t)g];
+    CHECK(strl_front_finish(ctxs[(size_t)g], done, &n_done));
+    got(g, done, n_done);
+    mark(g, before);
+  }
+  account();
+  if (G > 1) {
+    std::vector<uint64_t> recs(summary.size());
+    for (size_t k = 0; k < summary.size(); ++k) recs[k] = summary[k].n_records;
+    CHECK(strl_ctxs_extract_gather(ctxs.data(), G, chunk_owner.data(), recs.data(), recs.size()));
+    if (verbose) fprintf(stderr, "[strling] %zu chunks over %d contexts on %d device(s); per-read state gathered on the first\n", summary.size(), G, std::min(G, std::max(1, strl_device_count())));
   }
   const double t_drain = secs(tf, now());
   {   // extract.nim:310-313: one line per large contig that has reads (here: once the whole file has been through)
@@ -710,8 +750,8 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   }
   if (rc == STRL_ERR_FORMAT) {
     fprintf(stderr, "[strling] %s: repeating the extraction with the host pair logic\n", strl_last_error());
-    for (int k = 0; k < 2; ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
-    strl_ctx_destroy(ctx);
+    for (size_t k = 0; k < pin.size(); ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
+    for (strl_ctx *c : ctxs) strl_ctx_destroy(c);
     return EXTRACT_AGAIN_ON_HOST;
   }
   if (rc) quit("[strling] %s (status %d)", strl_last_error(), rc);
@@ -739,8 +779,8 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   // the process ends here: the driver reclaims device and page-locked memory faster than freeing them piece by piece would
   // (STRL_TEARDOWN=1 frees them explicitly)
   if (getenv("STRL_TEARDOWN")) {
-    for (int k = 0; k < 2; ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
-    strl_ctx_destroy(ctx);
+    for (size_t k = 0; k < pin.size(); ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
+    for (strl_ctx *c : ctxs) strl_ctx_destroy(c);
     return 0;
   }
   // ... and so does the runtime's own shutdown (~0.15 s with gigabytes of device memory mapped).  Under a profiler the normal

@@ -42,9 +42,11 @@ struct FrontSeg {         // one FRONT_SEG-byte segment of the inflated bytes
 
 // buffers of one chunk in flight (the context keeps two)
 struct FrontSlot {
-  DevBuf comp, infl, coff, clen, uoff, isize, status, seg, recoff, seqoff, qoff, info, base3;
+  DevBuf comp, infl, coff, clen, uoff, isize, status, seg, recoff, seqoff, qoff, info, base3, carry_stage;
   uint32_t n_blocks = 0, n_seg = 0;
   uint64_t infl_bytes = 0, comp_bytes = 0;
+  hipEvent_t ev_read = nullptr;   // another context copied this slot's tail (multi-GPU carry)
+  bool read_pending = false;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_h2d = nullptr;   // record scan done | parse + scoring done (slot reusable) | compressed bytes on the device
   bool b_pending = false, a_pending = false;
   FrontInfo *h_info = nullptr;   // pinned: [0] as of the record scan, [1] as of the parse, [2] the initial values
@@ -59,6 +61,9 @@ struct strl_front {
   int n_ref = 0;
   uint64_t first_off = 0;            // offset of the first record in the first chunk's inflated bytes
   uint64_t chunks = 0;               // chunks pushed so far
+  bool not_first = false;            // (multi-GPU) this context's first chunk is not the file's first
+  int last_slot = -1;                // slot of the chunk pushed last
+  uint32_t last_end = 0;             // end of its inflated bytes
   uint64_t comp_total = 0, infl_total = 0;   // bytes handed over / inflated so far
   int pending = -1;                  // slot whose stage B has not been enqueued yet
   // per-read state of all chunks (beside x_rows / x_qhash / x_whole of the chunked extract)
@@ -78,8 +83,20 @@ struct FrontChunkDesc {   // host view of a chunk handed to front_stage_a
   uint32_t n_blocks;
 };
 
+// where the partial record in front of a chunk comes from when the previous chunk went to ANOTHER context (multi-GPU
+// extract: chunks go round-robin over the contexts): that context's slot, its device, the event behind its record scan
+struct FrontCarrySrc {
+  const uint8_t *infl;
+  const FrontInfo *info;
+  uint32_t end;          // end of the inflated bytes in that slot
+  int device;
+  hipEvent_t ev_a;
+  hipEvent_t ev_read;    // recorded by the reader behind its copy: the owner waits for it before it overwrites the slot
+  bool *read_pending;
+};
+
 // front.hip
-int front_stage_a(strl_ctx *c, strl_front *F, int slot, const FrontChunkDesc &d, bool first);
+int front_stage_a(strl_ctx *c, strl_front *F, int slot, const FrontChunkDesc &d, bool first, const FrontCarrySrc *carry = nullptr);
 struct FrontParseOut {
   int32_t *tid, *pos, *end;
   uint32_t *seq_off;

@@ -80,6 +80,19 @@ __global__ void carry_kernel(const uint8_t *prev_infl, const FrontInfo *prev, ui
   if (threadIdx.x == 0) info->start0 = FRONT_CARRY_MAX - len;
 }
 
+// ... the same when the previous chunk sits in another context: `stage` holds the last stage_len bytes of its inflated data
+// (copied over by the copy engine), then that slot's FrontInfo
+__global__ void carry_stage_kernel(const uint8_t *stage, uint32_t stage_len, uint32_t prev_end, uint8_t *infl, FrontInfo *info) {
+  const FrontInfo *prev = reinterpret_cast<const FrontInfo *>(stage + FRONT_CARRY_MAX + 64);
+  const uint32_t len = prev->carry_len <= stage_len ? prev->carry_len : 0u;
+  const uint32_t off = prev->carry_off - (prev_end - stage_len);      // carry_off >= prev_end - len >= prev_end - stage_len
+  for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) infl[FRONT_CARRY_MAX - len + i] = stage[off + i];
+  if (threadIdx.x == 0) {
+    info->start0 = FRONT_CARRY_MAX - len;
+    if (prev->carry_len > stage_len) atomicOr(&info->err, FRONT_ERR_CARRY);
+  }
+}
+
 __global__ __launch_bounds__(64) void rec_guess_kernel(const uint8_t *U, const FrontInfo *info, FrontSeg *seg, uint32_t n_seg, int32_t n_ref) {
   const uint32_t s = blockIdx.x * 64u + threadIdx.x;
   if (s >= n_seg) return;
@@ -357,7 +370,7 @@ static int tick(strl_front *F, hipStream_t st) {   // STRL_FRONT_TIMING: an even
 
 // H2D of the chunk's compressed bytes + block table, inflate, record scan; asynchronous on F->st_a.  The slot's previous
 // occupant must have been parsed (ev_b) before its buffers are overwritten: waited for on the device.
-int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, bool first) {
+int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, bool first, const FrontCarrySrc *carry) {
   FrontSlot &S = F->slot[si];
   FrontSlot &Pv = F->slot[si ^ 1];
   hipStream_t st = F->st_a;
@@ -380,6 +393,7 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   const uint64_t readable = (d.comp_bytes + 3) & ~(uint64_t)3;
   const uint64_t rec_cap = tot / 36 + 16;          // no record is shorter than 36 bytes
   if (S.b_pending) STRL_HIP(hipStreamWaitEvent(st, S.ev_b, 0));
+  if (S.read_pending) { STRL_HIP(hipStreamWaitEvent(st, S.ev_read, 0)); S.read_pending = false; }   // another context took its carry from this slot
   auto want = [](uint64_t need) { return (size_t)(need + need / 4 + 4096); };   // head-room: later chunks rarely reallocate
   if (S.comp.cap < readable + 16 && (rc = S.comp.reserve(want(readable + 16)))) return rc;
   if (S.infl.cap < (uint64_t)end + 256 && (rc = S.infl.reserve(want((uint64_t)end + 256)))) return rc;
@@ -419,8 +433,26 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
                                 S.infl.as<uint8_t>(), &info->inflate_err, S.status.as<uint8_t>(), st)))
     return rc;
   if ((rc = tick(F, st))) return rc;
-  if (!first) {
+  if (!first && !carry) {
     hipLaunchKernelGGL(carry_kernel, dim3(1), dim3(1024), 0, st, Pv.infl.as<uint8_t>(), Pv.info.as<FrontInfo>(), S.infl.as<uint8_t>(), info);
+    STRL_HIP(hipGetLastError());
+  } else if (!first) {
+    // the previous chunk lives in another context (possibly on another device): its tail and its summary come over by a copy
+    // behind its record scan, then the carry is cut out locally
+    const uint32_t stage_len = std::min<uint32_t>(carry->end, FRONT_CARRY_MAX);
+    if ((rc = S.carry_stage.reserve((size_t)FRONT_CARRY_MAX + 64 + sizeof(FrontInfo) + 64))) return rc;
+    STRL_HIP(hipStreamWaitEvent(st, carry->ev_a, 0));
+    uint8_t *stg = S.carry_stage.as<uint8_t>();
+    if (carry->device == c->device) {
+      STRL_HIP(hipMemcpyAsync(stg, carry->infl + (carry->end - stage_len), stage_len, hipMemcpyDeviceToDevice, st));
+      STRL_HIP(hipMemcpyAsync(stg + FRONT_CARRY_MAX + 64, carry->info, sizeof(FrontInfo), hipMemcpyDeviceToDevice, st));
+    } else {
+      STRL_HIP(hipMemcpyPeerAsync(stg, c->device, carry->infl + (carry->end - stage_len), carry->device, stage_len, st));
+      STRL_HIP(hipMemcpyPeerAsync(stg + FRONT_CARRY_MAX + 64, c->device, carry->info, carry->device, sizeof(FrontInfo), st));
+    }
+    STRL_HIP(hipEventRecord(carry->ev_read, st));
+    *carry->read_pending = true;
+    hipLaunchKernelGGL(carry_stage_kernel, dim3(1), dim3(1024), 0, st, stg, stage_len, carry->end, S.infl.as<uint8_t>(), info);
     STRL_HIP(hipGetLastError());
   }
   const unsigned gb = (n_seg + 63) / 64;
@@ -438,6 +470,8 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   STRL_HIP(hipMemcpyAsync(S.h_info, S.info.p, sizeof(FrontInfo), hipMemcpyDeviceToHost, st));
   STRL_HIP(hipEventRecord(S.ev_a, st));
   S.a_pending = true;
+  F->last_slot = si;
+  F->last_end = end;
   return STRL_OK;
 }
 
@@ -471,10 +505,11 @@ int front_copy_names(strl_ctx *c, strl_front *F, const uint64_t *d_ref, const ui
 void front_destroy(strl_front *F) {
   if (!F) return;
   for (FrontSlot &S : F->slot) {
-    for (DevBuf *b : {&S.comp, &S.infl, &S.coff, &S.clen, &S.uoff, &S.isize, &S.status, &S.seg, &S.recoff, &S.seqoff, &S.qoff, &S.info, &S.base3}) b->release();
+    for (DevBuf *b : {&S.comp, &S.infl, &S.coff, &S.clen, &S.uoff, &S.isize, &S.status, &S.seg, &S.recoff, &S.seqoff, &S.qoff, &S.info, &S.base3, &S.carry_stage}) b->release();
     if (S.ev_a) (void)hipEventDestroy(S.ev_a);
     if (S.ev_b) (void)hipEventDestroy(S.ev_b);
     if (S.ev_h2d) (void)hipEventDestroy(S.ev_h2d);
+    if (S.ev_read) (void)hipEventDestroy(S.ev_read);
     if (S.h_info) (void)hipHostFree(S.h_info);
     if (S.h_uoff) (void)hipHostFree(S.h_uoff);
   }

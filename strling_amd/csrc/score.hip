@@ -1257,6 +1257,147 @@ __global__ void soft_append_kernel(const strl_soft_rec *src, const uint32_t *cnt
 }
 }  // namespace strl
 
+namespace strl {
+// multi-GPU extract, gather of the contexts' per-read state on one of them: soft-clip records carry the index of their read
+// in the context that scored them -> its index in the file.  lbase / gbase: first local / global record of that context's chunks.
+__global__ void soft_rebase_kernel(strl_soft_rec *soft, uint32_t n, const uint32_t *lbase, const uint32_t *gbase, uint32_t n_chunks) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t rs = soft[i].read_side, r = rs >> 1;
+  uint32_t lo = 0, hi = n_chunks;              // last chunk with lbase <= r
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (lbase[mid] <= r) lo = mid; else hi = mid; }
+  soft[i].read_side = ((gbase[lo] + (r - lbase[lo])) << 1) | (rs & 1u);
+}
+__global__ void qref_rebase_kernel(uint64_t *qref, uint32_t n, uint64_t arena_base) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) qref[i] += arena_base << 8;
+}
+__global__ void words_or_kernel(uint32_t *dst, const uint32_t *src, size_t n_words) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) dst[i] |= src[i];
+}
+}  // namespace strl
+
+static int copy_between(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t st) {
+  if (!bytes) return STRL_OK;
+  if (dst_dev == src_dev) STRL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+  else STRL_HIP(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st));
+  return STRL_OK;
+}
+
+// `strling extract --gpus N`: the chunks of one file went round-robin over n contexts (strl_front_push_after), each scored
+// its chunks.  The pair logic needs every record of a qname group in one place, and what it needs of a record is small
+// (32-byte row, hash, scorer word, name reference: 52 B against the ~290 B of the record and the work of inflating and
+// scoring it): everything is gathered on ctxs[0] in FILE order -- per chunk copies over xGMI (peer DMA) --, soft-clip
+// records and name references are re-based, the Bloom bitmaps OR-ed; ctxs[0] then is in the state of a one-GPU chunked
+// extract of the whole file (strl_extract_finish, strl_front_fragwords, strl_front_qnames work as usual).
+// chunk_owner[k] / chunk_records[k]: context and record count (strl_front_chunk.n_records) of the file's k-th chunk.
+int strl_ctxs_extract_gather(strl_ctx **ctxs, int n, const uint32_t *chunk_owner, const uint64_t *chunk_records, uint64_t n_chunks) {
+  using namespace strl;
+  if (!ctxs || n < 1 || (n_chunks && (!chunk_owner || !chunk_records))) { set_error("strl_ctxs_extract_gather: bad argument"); return STRL_ERR_ARG; }
+  for (int g = 0; g < n; ++g) {
+    if (!ctxs[g] || !ctxs[g]->front || !ctxs[g]->x_open) { set_error("strl_ctxs_extract_gather: context %d has no open front end", g); return STRL_ERR_ARG; }
+    if (ctxs[g]->bloom_mask != ctxs[0]->bloom_mask) { set_error("strl_ctxs_extract_gather: Bloom bitmaps differ in size"); return STRL_ERR_ARG; }
+    STRL_HIP(hipSetDevice(ctxs[g]->device));
+    STRL_HIP(hipStreamSynchronize(ctxs[g]->stream));
+  }
+  if (n == 1) return STRL_OK;
+  strl_ctx *c0 = ctxs[0];
+  strl_front *F0 = c0->front;
+  std::vector<uint64_t> local_n((size_t)n, 0), gbase((size_t)n_chunks, 0), lbase((size_t)n_chunks, 0);
+  uint64_t tot = 0;
+  for (uint64_t k = 0; k < n_chunks; ++k) {
+    if (chunk_owner[k] >= (uint32_t)n) { set_error("strl_ctxs_extract_gather: chunk owner out of range"); return STRL_ERR_ARG; }
+    gbase[(size_t)k] = tot; lbase[(size_t)k] = local_n[chunk_owner[k]];
+    tot += chunk_records[k]; local_n[chunk_owner[k]] += chunk_records[k];
+  }
+  for (int g = 0; g < n; ++g)
+    if (local_n[(size_t)g] != ctxs[g]->x_n) { set_error("strl_ctxs_extract_gather: context %d holds %llu records, its chunks say %llu", g, (unsigned long long)ctxs[g]->x_n, (unsigned long long)local_n[(size_t)g]); return STRL_ERR_ARG; }
+  if (tot > 0x7ffffff0ull) { set_error("chunked extract: more than 2^31 - 16 records"); return STRL_ERR_ARG; }
+  // totals of the soft-clip records, the name arenas, the counters
+  std::vector<uint32_t> xc((size_t)n * XC_WORDS);
+  std::vector<uint64_t> soft_at((size_t)n + 1, 0), arena_at((size_t)n + 1, 0);
+  for (int g = 0; g < n; ++g) {
+    STRL_HIP(hipSetDevice(ctxs[g]->device));
+    STRL_HIP(hipMemcpy(&xc[(size_t)g * XC_WORDS], ctxs[g]->x_cnt.p, XC_WORDS * 4, hipMemcpyDeviceToHost));
+    if (xc[(size_t)g * XC_WORDS + XC_OVERFLOW]) { set_error("chunked extract: soft-clip records of a chunk were dropped"); return STRL_ERR_CAPACITY; }
+    soft_at[(size_t)g + 1] = soft_at[(size_t)g] + xc[(size_t)g * XC_WORDS + XC_SOFT];
+    arena_at[(size_t)g + 1] = arena_at[(size_t)g] + ctxs[g]->front->qarena_used;
+  }
+  STRL_HIP(hipSetDevice(c0->device));
+  hipStream_t st = c0->stream;
+  const uint64_t t1 = std::max<uint64_t>(tot, 1), s1 = std::max<uint64_t>(soft_at[(size_t)n], 1);
+  DevBuf rows, qhash, whole, qref, fragw, soft, arena, tmp, tab;
+  int rc;
+  if ((rc = rows.reserve((size_t)t1 * sizeof(strl_pair_rec))) || (rc = qhash.reserve((size_t)t1 * 8)) || (rc = whole.reserve((size_t)t1 * 4)) ||
+      (rc = qref.reserve((size_t)t1 * 8)) || (rc = fragw.reserve((size_t)t1 * 4)) || (rc = soft.reserve((size_t)s1 * sizeof(strl_soft_rec))) ||
+      (rc = arena.reserve((size_t)arena_at[(size_t)n] + 64)) || (rc = tmp.reserve(std::max<size_t>((size_t)c0->bloom_mask / 8 + 64, (size_t)F0->n_ref + 64))) || (rc = tab.reserve((size_t)std::max<uint64_t>(n_chunks, 1) * 8 + 64)))
+    return rc;
+  // per chunk: the five per-read columns to their place in file order
+  for (uint64_t k = 0; k < n_chunks; ++k) {
+    strl_ctx *cg = ctxs[chunk_owner[k]];
+    const uint64_t m = chunk_records[k], lo = lbase[(size_t)k], go = gbase[(size_t)k];
+    if (!m) continue;
+    if ((rc = copy_between(rows.as<strl_pair_rec>() + go, c0->device, cg->x_rows.as<strl_pair_rec>() + lo, cg->device, (size_t)m * sizeof(strl_pair_rec), st)) ||
+        (rc = copy_between(qhash.as<uint64_t>() + go, c0->device, cg->x_qhash.as<uint64_t>() + lo, cg->device, (size_t)m * 8, st)) ||
+        (rc = copy_between(whole.as<uint32_t>() + go, c0->device, cg->x_whole.as<uint32_t>() + lo, cg->device, (size_t)m * 4, st)) ||
+        (rc = copy_between(qref.as<uint64_t>() + go, c0->device, cg->front->qref.as<uint64_t>() + lo, cg->device, (size_t)m * 8, st)) ||
+        (rc = copy_between(fragw.as<uint32_t>() + go, c0->device, cg->front->fragw.as<uint32_t>() + lo, cg->device, (size_t)m * 4, st)))
+      return rc;
+    const uint64_t ab = arena_at[chunk_owner[k]];
+    if (ab) {
+      hipLaunchKernelGGL(qref_rebase_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, qref.as<uint64_t>() + go, (uint32_t)m, ab);
+      STRL_HIP(hipGetLastError());
+    }
+  }
+  // per context: name arena, soft-clip records (re-based by its chunk table), Bloom bitmap
+  std::vector<uint32_t> tl, tg;
+  for (int g = 0; g < n; ++g) {
+    strl_ctx *cg = ctxs[g];
+    if ((rc = copy_between(arena.as<uint8_t>() + arena_at[(size_t)g], c0->device, cg->front->qarena.p, cg->device, (size_t)cg->front->qarena_used, st))) return rc;
+    const uint64_t ns = soft_at[(size_t)g + 1] - soft_at[(size_t)g];
+    if (ns) {
+      if ((rc = copy_between(soft.as<strl_soft_rec>() + soft_at[(size_t)g], c0->device, cg->x_soft.p, cg->device, (size_t)ns * sizeof(strl_soft_rec), st))) return rc;
+      tl.clear(); tg.clear();
+      for (uint64_t k = 0; k < n_chunks; ++k) if (chunk_owner[k] == (uint32_t)g) { tl.push_back((uint32_t)lbase[(size_t)k]); tg.push_back((uint32_t)gbase[(size_t)k]); }
+      STRL_HIP(hipStreamSynchronize(st));                    // (the table buffer is reused per context)
+      STRL_HIP(hipMemcpy(tab.p, tl.data(), tl.size() * 4, hipMemcpyHostToDevice));
+      STRL_HIP(hipMemcpy(tab.as<uint32_t>() + n_chunks + 8, tg.data(), tg.size() * 4, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(soft_rebase_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, soft.as<strl_soft_rec>() + soft_at[(size_t)g], (uint32_t)ns,
+                         tab.as<uint32_t>(), tab.as<uint32_t>() + n_chunks + 8, (uint32_t)tl.size());
+      STRL_HIP(hipGetLastError());
+    }
+    if (g) {       // contigs that had a primary record (the CLI's "extracting chromosome" lines)
+      const size_t tw = ((size_t)std::min(F0->n_ref, cg->front->n_ref) + 3) / 4;
+      if (tw) {
+        if ((rc = copy_between(tmp.p, c0->device, cg->front->tid_seen.p, cg->device, tw * 4, st))) return rc;
+        hipLaunchKernelGGL(words_or_kernel, dim3(16), dim3(256), 0, st, F0->tid_seen.as<uint32_t>(), tmp.as<uint32_t>(), tw);
+        STRL_HIP(hipGetLastError());
+      }
+    }
+    if (g) {
+      const size_t bw = ((size_t)c0->bloom_mask + 1) / 32;
+      if ((rc = copy_between(tmp.p, c0->device, cg->bloom.p, cg->device, bw * 4, st))) return rc;
+      hipLaunchKernelGGL(words_or_kernel, dim3(1024), dim3(256), 0, st, c0->bloom.as<uint32_t>(), tmp.as<uint32_t>(), bw);
+      STRL_HIP(hipGetLastError());
+    }
+  }
+  uint32_t sum[XC_WORDS] = {0};
+  for (int g = 0; g < n; ++g) for (int w = 0; w < XC_WORDS; ++w) sum[w] += xc[(size_t)g * XC_WORDS + w];
+  STRL_HIP(hipStreamSynchronize(st));
+  STRL_HIP(hipMemcpy(c0->x_cnt.p, sum, XC_WORDS * 4, hipMemcpyHostToDevice));
+  // ctxs[0] takes the gathered state over
+  c0->x_rows.release(); c0->x_qhash.release(); c0->x_whole.release(); c0->x_soft.release();
+  F0->qref.release(); F0->fragw.release(); F0->qarena.release();
+  c0->x_rows = rows; c0->x_qhash = qhash; c0->x_whole = whole; c0->x_soft = soft;
+  F0->qref = qref; F0->fragw = fragw; F0->qarena = arena;
+  F0->qarena_used = arena_at[(size_t)n];
+  c0->x_n = tot;
+  c0->x_soft_cap = s1;
+  c0->x_soft_known = soft_at[(size_t)n]; c0->x_soft_known_at = tot;
+  tmp.release(); tab.release();
+  return STRL_OK;
+}
+
 int strl_extract_begin(strl_ctx *c, uint64_t n_reads_hint) {
   if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
   if (!c->have_opts) { set_error("strl_ctx_set_opts must be called before scoring"); return STRL_ERR_ARG; }
@@ -1487,6 +1628,7 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
     STRL_HIP(hipEventCreateWithFlags(&S.ev_a, hipEventDisableTiming));
     STRL_HIP(hipEventCreateWithFlags(&S.ev_b, hipEventDisableTiming));
     STRL_HIP(hipEventCreateWithFlags(&S.ev_h2d, hipEventDisableTiming));
+    STRL_HIP(hipEventCreateWithFlags(&S.ev_read, hipEventDisableTiming));
     STRL_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_info), 3 * sizeof(strl::FrontInfo), hipHostMallocDefault));
   }
   if ((rc = F->tid_seen.reserve((size_t)n_ref + 16))) return rc;
@@ -1500,7 +1642,17 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
 
 int strl_front_push(strl_ctx *c, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize, uint32_t n_blocks,
                     strl_front_chunk *done, int *n_done) {
+  return strl_front_push_after(c, nullptr, comp, comp_bytes, coff, clen, isize, n_blocks, done, n_done);
+}
+
+// the same when the chunks of ONE file go round-robin over several contexts (`strling extract --gpus N`): `prev` = the
+// context the previous chunk of the file was pushed to (null / c itself: this context) -- the partial record in front of
+// this chunk is taken from there
+int strl_front_push_after(strl_ctx *c, strl_ctx *prev, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize,
+                          uint32_t n_blocks, strl_front_chunk *done, int *n_done) {
   if (!c || !c->front || !c->x_open || (n_blocks && (!comp || !coff || !clen || !isize))) { set_error("strl_front_push: bad argument / no strl_front_begin"); return STRL_ERR_ARG; }
+  if (prev == c) prev = nullptr;
+  if (prev && (!prev->front || prev->front->last_slot < 0)) { set_error("strl_front_push_after: the previous context has no chunk"); return STRL_ERR_ARG; }
   STRL_HIP(hipSetDevice(c->device));
   strl::strl_front *F = c->front;
   if (n_done) *n_done = 0;
@@ -1512,7 +1664,14 @@ int strl_front_push(strl_ctx *c, const uint8_t *comp, uint64_t comp_bytes, const
     if (n_done) *n_done = 1;
   }
   const strl::FrontChunkDesc d{comp, comp_bytes, coff, clen, isize, n_blocks};
-  if ((rc = strl::front_stage_a(c, F, si, d, F->chunks == 0))) return rc;
+  if (prev) {
+    strl::FrontSlot &PS = prev->front->slot[prev->front->last_slot];
+    const strl::FrontCarrySrc cs{PS.infl.as<uint8_t>(), PS.info.as<strl::FrontInfo>(), prev->front->last_end, prev->device, PS.ev_a, PS.ev_read, &PS.read_pending};
+    rc = strl::front_stage_a(c, F, si, d, false, &cs);
+  } else {
+    rc = strl::front_stage_a(c, F, si, d, F->chunks == 0 && !F->not_first);
+  }
+  if (rc) return rc;
   ++F->chunks;
   F->comp_total += comp_bytes;
   F->infl_total += F->slot[si].infl_bytes;

@@ -119,6 +119,22 @@ def test_extract_bin_is_byte_identical_to_oracle(sample, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gpus,blocks", [("2", "3"), ("3", "5"), ("2", "8192"), ("4", "2")])
+def test_extract_on_several_contexts_writes_the_same_bin(sample, gpus, blocks):
+    """strling extract --gpus N: the file's chunks round-robin over N contexts (partial records carried from one context's chunk
+    to the next context's), per-read state gathered on the first, pair logic there: the .bin of the one-GPU run, byte for byte"""
+    one = str(sample["dir"] / "one.bin")
+    r = _run(["extract", "-g", sample["bed"], sample["bam"], one])
+    assert r.returncode == 0, r.stderr
+    out = str(sample["dir"] / f"g{gpus}_{blocks}.bin")
+    r = _run(["extract", "-g", sample["bed"], "-v", "--gpus", gpus, sample["bam"], out], env=dict(os.environ, STRL_CHUNK_BLOCKS=blocks))
+    assert r.returncode == 0, r.stderr
+    if int(blocks) < 100:
+        assert f"over {gpus} contexts" in r.stderr
+    assert open(out, "rb").read() == open(one, "rb").read()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("front", ["device", "host"])
 def test_extract_never_quits_on_a_qname_carried_by_hundreds_of_records(oracle, tmp_path, front):
     """700 primary records under one qname: more than the device join replays (512 items).  The CLI repeats the extraction
