@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs a STRling binary over the verification kit and compares with what the oracle expects.
+#   verify/run_reference.sh /path/to/strling            (reference build: Nim 1.6 + htslib;  or strling_amd/lib/strling)
+# Every case pins one assumption no reference test pins (see verify/README.md for what to change on a FAIL).
+S=${1:?usage: run_reference.sh /path/to/strling}
+D=$(cd "$(dirname "$0")" && pwd)/cases
+T=$(mktemp -d)
+fail=0
+check() {   # name, got, expected, assumption
+  if cmp -s "$2" "$3"; then echo "PASS  $1   ($4)"; else echo "FAIL  $1   ($4)   got: $2   expected: $3"; fail=1; fi
+}
+for c in iupac widths; do
+  "$S" extract -f "$D/ref.fa" -g "$D/ref.fa.str" "$D/$c.bam" "$T/$c.bin" > "$T/$c.log" 2>&1 || echo "      ($c: extract exited non-zero, see $T/$c.log)"
+done
+check iupac  "$T/iupac.bin"  "$D/iupac.expected.bin"  "kmer code of non-ACGT bases = the code of 'A'"
+check widths "$T/widths.bin" "$D/widths.expected.bin" "msgpack4nim writes the smallest integer / string encodings"
+"$S" merge -m 2 -o "$T/ties" "$D/ties.0.bin" "$D/ties.1.bin" > "$T/ties.log" 2>&1
+check ties "$T/ties-bounds.txt" "$D/ties.expected-bounds.txt" "CountTable.largest = first maximum in Nim 1.6 slot order"
+"$S" merge -m 2 -o "$T/many" "$D/manygroups.0.bin" > "$T/many.log" 2>&1
+check manygroups "$T/many-bounds.txt" "$D/manygroups.expected-bounds.txt" "Table[(tid, repeat)] iteration order after growth"
+if [ $fail = 0 ]; then echo "all assumptions confirmed"; else echo "outputs kept in $T (the .tsv beside an expected .bin lists its treads)"; fi
+exit $fail
