@@ -106,10 +106,10 @@ def main():
 
     d = dict(tid=up(soa.tid), pos=up(soa.pos), end=up(soa.end), seq_off=up(soa.seq_off.view(np.int32)), l_seq=up(soa.l_seq.view(np.int16)),
              clip_l=up(soa.clip_l.view(np.int16)), clip_r=up(soa.clip_r.view(np.int16)), mapq=up(soa.mapq), cig=up(soa.cig),
-             seq4=up(soa.seq4), rows=up(rows.view(np.uint8)), qhash=up(qh.view(np.int64)))
+             seq4=up(soa.seq4), rows=up(rows.view(np.uint8)), qhash=up(qh.view(np.int64)), meta=up(soa.meta_rows().view(np.int32)))
     cs = api.CReadSoa(n, d["tid"].data_ptr(), d["pos"].data_ptr(), d["end"].data_ptr(), d["seq_off"].data_ptr(), d["l_seq"].data_ptr(),
                       d["clip_l"].data_ptr(), d["clip_r"].data_ptr(), d["mapq"].data_ptr(), d["cig"].data_ptr(), d["seq4"].data_ptr(),
-                      d["seq4"].numel(), L, api.MEM_DEVICE)
+                      d["seq4"].numel(), L, api.MEM_DEVICE, d["meta"].data_ptr())
     cp = api.CPairSoa(d["rows"].data_ptr(), d["qhash"].data_ptr())
     torch.cuda.synchronize()
     del soa, qh, rows

@@ -89,6 +89,13 @@ typedef struct {
 #define STRL_CIG_LAST_S 4u   /* n_cigar >= 1 and cigar[last] is S */
 #define STRL_CIG_ONE_OP 8u   /* n_cigar == 1 */
 #define STRL_CIG_NONE 16u    /* n_cigar == 0 */
+typedef struct {          /* == words y, z, w of a scorer queue entry */
+  uint32_t seq_off;        /* 16-byte units */
+  uint16_t l_seq, clip_l;
+  uint16_t clip_r;
+  uint8_t cig, mapq;
+  uint32_t pad;
+} strl_read_meta;
 typedef struct {
   uint64_t n;
   const int32_t *tid;      /* [n] */
@@ -105,6 +112,10 @@ typedef struct {
   uint64_t seq4_bytes;     /* including >= 32 bytes of slack */
   uint32_t max_l_seq;
   int32_t mem;             /* STRL_MEM_HOST or STRL_MEM_DEVICE: where ALL pointers above live */
+  const strl_read_meta *meta; /* optional (may be NULL), same memory as the rest: seq_off | l_seq | clip_l | clip_r | cig | mapq of
+                            * read i once more as ONE 16-byte row.  The skip-predicate pass removes ~90 % of the reads without
+                            * looking at these six fields and gathers them for the kept ones: one row = one cache line per kept
+                            * read where the five columns are five.  Host batches get their rows made on the device. */
 } strl_read_soa;
 
 /* What the pair logic (Cache.add, extract.nim:192-248 with to_tread, add_soft, adjust_by) reads of one record, as ONE

@@ -38,7 +38,7 @@ class CReadSoa(C.Structure):
     _fields_ = [("n", C.c_uint64), ("tid", C.c_void_p), ("pos", C.c_void_p), ("end", C.c_void_p), ("seq_off", C.c_void_p),
                 ("l_seq", C.c_void_p), ("clip_l", C.c_void_p), ("clip_r", C.c_void_p), ("mapq", C.c_void_p),
                 ("cig", C.c_void_p), ("seq4", C.c_void_p), ("seq4_bytes", C.c_uint64), ("max_l_seq", C.c_uint32),
-                ("mem", C.c_int32)]
+                ("mem", C.c_int32), ("meta", C.c_void_p)]
 
 
 class CPairSoa(C.Structure):
@@ -290,6 +290,14 @@ class Soa:
         qh = np.zeros(max(self.n, 1), np.uint64)
         _check(load().strl_qname_hash(C.byref(self.rv.c), qh.ctypes.data))
         return rows[:self.n], qh[:self.n]
+
+    def meta_rows(self):
+        """strl_read_meta rows (16 B per read: seq_off | l_seq, clip_l | clip_r, cig, mapq | pad) for strl_read_soa.meta"""
+        m = np.zeros((max(self.n, 1), 4), np.uint32)
+        m[:self.n, 0] = self.seq_off
+        m[:self.n, 1] = self.l_seq.astype(np.uint32) | (self.clip_l.astype(np.uint32) << 16)
+        m[:self.n, 2] = self.clip_r.astype(np.uint32) | (self.cig.astype(np.uint32) << 16) | (self.mapq.astype(np.uint32) << 24)
+        return m[:self.n]
 
     def c_struct(self):
         return CReadSoa(self.n, _ptr(self.tid), _ptr(self.pos), _ptr(self.end), _ptr(self.seq_off), _ptr(self.l_seq),

@@ -70,7 +70,7 @@ struct strl_front {
   DevBuf qref, qarena, fragw, tidflag, tid_seen;   // tid_seen[n_ref]: contigs with a primary record so far
   uint64_t qarena_used = 0;
   // SoA of the chunk being scored (chunk-temporary)
-  DevBuf s_tid, s_pos, s_end, s_seqoff, s_lseq, s_clipl, s_clipr, s_mapq, s_cig, s_seq4;
+  DevBuf s_tid, s_pos, s_end, s_seqoff, s_lseq, s_clipl, s_clipr, s_mapq, s_cig, s_seq4, s_meta;
   double ms_inflate = 0, ms_scan = 0, ms_parse = 0;
   std::vector<hipEvent_t> tev;       // timing events (STRL_FRONT_TIMING)
 };
@@ -102,6 +102,7 @@ struct FrontParseOut {
   uint32_t *seq_off;
   uint16_t *l_seq, *clip_l, *clip_r;
   uint8_t *mapq, *cig, *seq4;
+  uint4 *meta;             // [n] strl_read_meta rows
   strl_pair_rec *rows;     // [n] persistent rows of this chunk's records
   uint64_t *qhash;
   uint64_t *qref;          // [n] (qname arena offset << 8) | length

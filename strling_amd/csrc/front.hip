@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void rec_parse_kernel(ParseParams P) {
     const uint32_t so = P.seqoff[i];
     P.o.seq_off[i] = so; P.o.l_seq[i] = ls16; P.o.clip_l[i] = cl16; P.o.clip_r[i] = cr16;
     P.o.mapq[i] = (uint8_t)mapq; P.o.cig[i] = (uint8_t)cbits;
+    P.o.meta[i] = make_uint4(so, (uint32_t)ls16 | ((uint32_t)cl16 << 16), (uint32_t)cr16 | (cbits << 16) | (mapq << 24), 0u);
     strl_pair_rec row;
     row.tid = tid; row.pos = pos; row.mtid = mtid; row.mpos = mpos; row.end = end;
     row.flag = (uint16_t)flag; row.l_seq = ls16; row.clip_l = cl16; row.clip_r = cr16; row.mapq = (uint8_t)mapq; row.cig = (uint8_t)cbits; row.pad = 0;
@@ -514,7 +515,7 @@ void front_destroy(strl_front *F) {
     if (S.h_uoff) (void)hipHostFree(S.h_uoff);
   }
   for (DevBuf *b : {&F->qref, &F->qarena, &F->fragw, &F->tidflag, &F->tid_seen, &F->s_tid, &F->s_pos, &F->s_end, &F->s_seqoff, &F->s_lseq, &F->s_clipl, &F->s_clipr, &F->s_mapq,
-                    &F->s_cig, &F->s_seq4})
+                    &F->s_cig, &F->s_seq4, &F->s_meta})
     b->release();
   for (hipEvent_t e : F->tev) (void)hipEventDestroy(e);
   if (F->st_a) (void)hipStreamDestroy(F->st_a);

@@ -81,6 +81,7 @@ constexpr int BIN_SHIFT = 12;
 constexpr uint32_t EMPTY = 0xffffffffu;
 
 struct ScoreParams {
+  const uint4 *meta;      // optional: strl_read_meta rows (seq_off | l_seq, clip_l | clip_r, cig, mapq | pad): what a queue entry carries of a read
   uint64_t n;
   const int32_t *tid, *pos, *end;
   const uint32_t *seq_off;
@@ -271,9 +272,14 @@ __global__ __launch_bounds__(256, 4) void classify_kernel(ScoreParams P) {
           const uint32_t i = i0 + 64u * u;
           const uint32_t r = i < cnt ? buf[i] : 0u;
           e[u].x = r;
-          e[u].y = P.seq_off[r];
-          e[u].z = (uint32_t)P.l_seq[r] | ((uint32_t)P.clip_l[r] << 16);
-          e[u].w = (uint32_t)P.clip_r[r] | ((uint32_t)P.cig[r] << 16) | ((uint32_t)P.mapq[r] << 24);
+          if (P.meta) {            // one 16-byte row = one line per kept read (the five columns below: five)
+            const uint4 m = P.meta[r];
+            e[u].y = m.x; e[u].z = m.y; e[u].w = m.z;
+          } else {
+            e[u].y = P.seq_off[r];
+            e[u].z = (uint32_t)P.l_seq[r] | ((uint32_t)P.clip_l[r] << 16);
+            e[u].w = (uint32_t)P.clip_r[r] | ((uint32_t)P.cig[r] << 16) | ((uint32_t)P.mapq[r] << 24);
+          }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -832,7 +838,7 @@ void strl_ctx_destroy(strl_ctx *c) {
   if (c->front) { if (c->front->st_c) (void)hipStreamSynchronize(c->front->st_c); if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a); strl::front_destroy(c->front); c->front = nullptr; }
   strl::DevBuf *bufs[] = {&c->lut, &c->thr, &c->g_tid, &c->g_bins, &c->g_start, &c->g_pmax, &c->queue, &c->soft_queue, &c->counters,
                           &c->soft_tmp, &c->sb_whole, &c->sb_soft, &c->queue_r, &c->soft_dense, &c->sb_state_w, &c->sb_state_s, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
-                          &c->st_mapq, &c->st_cig, &c->st_seq4, &c->st_whole, &c->st_soft, &c->st_text,
+                          &c->st_mapq, &c->st_cig, &c->st_seq4, &c->st_whole, &c->st_soft, &c->st_text, &c->st_meta,
                           &c->p_key0, &c->p_key1, &c->p_val0, &c->p_val1, &c->p_emit, &c->sort_scratch, &c->pair_cnt, &c->bloom, &c->treads,
                           &c->st_mtid, &c->st_mpos, &c->st_flag, &c->st_qhash, &c->x_rows, &c->x_qhash, &c->x_whole, &c->x_soft, &c->x_cnt, &c->g_aux};
   for (auto *b : bufs) b->release();
@@ -1028,6 +1034,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   P.n = n;
   P.tid = s->tid; P.pos = s->pos; P.end = s->end; P.seq_off = s->seq_off; P.l_seq = s->l_seq;
   P.clip_l = s->clip_l; P.clip_r = s->clip_r; P.mapq = s->mapq; P.cig = s->cig; P.seq4 = s->seq4;
+  P.meta = reinterpret_cast<const uint4 *>(s->meta);
   if (!c->g_tid.p && (rc = strl_ctx_set_genome(c, nullptr))) return rc;   // never set: the empty table
   P.g_tid = c->g_tid.as<TidInfo>(); P.g_bins = c->g_bins.as<uint2>(); P.g_iv = c->g_start.as<int2>();
   P.n_tid = c->n_tid;
@@ -1089,6 +1096,14 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
 }
 
 // host-memory batch -> staging buffers in HBM (asynchronous copies on the context stream)
+namespace strl {
+__global__ void meta_rows_kernel(const uint32_t *seq_off, const uint16_t *l_seq, const uint16_t *clip_l, const uint16_t *clip_r, const uint8_t *cig, const uint8_t *mapq,
+                                 uint32_t n, uint4 *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = make_uint4(seq_off[i], (uint32_t)l_seq[i] | ((uint32_t)clip_l[i] << 16), (uint32_t)clip_r[i] | ((uint32_t)cig[i] << 16) | ((uint32_t)mapq[i] << 24), 0u);
+}
+}  // namespace strl
+
 static int stage_batch(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *pp, strl_read_soa *d, strl_pair_soa *dpp) {
   const uint64_t n = s->n;
   *d = *s;
@@ -1105,6 +1120,13 @@ static int stage_batch(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa 
     *x.dst = x.b->p;
   }
   d->mem = STRL_MEM_DEVICE;
+  if ((rc = c->st_meta.reserve(std::max<size_t>((size_t)n * 16, 64)))) return rc;
+  if (n) {
+    hipLaunchKernelGGL(strl::meta_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d->seq_off, d->l_seq, d->clip_l, d->clip_r, d->cig, d->mapq,
+                       (uint32_t)n, c->st_meta.as<uint4>());
+    STRL_HIP(hipGetLastError());
+  }
+  d->meta = c->st_meta.as<strl_read_meta>();
   if (pp) {
     struct { strl::DevBuf *b; const void *src; size_t bytes; const void **dst; } cq[] = {
         {&c->st_mtid, pp->rec, (size_t)n * sizeof(strl_pair_rec), (const void **)&dpp->rec},
@@ -1589,13 +1611,13 @@ static int front_stage_b(strl_ctx *c, strl::strl_front *F, int si) {
   if (F->s_tid.cap < n1 * 4 && ((rc = F->s_tid.reserve(room(n1 * 4))) || (rc = F->s_pos.reserve(room(n1 * 4))) || (rc = F->s_end.reserve(room(n1 * 4))) ||
                                 (rc = F->s_seqoff.reserve(room(n1 * 4))) || (rc = F->s_lseq.reserve(room(n1 * 2))) || (rc = F->s_clipl.reserve(room(n1 * 2))) ||
                                 (rc = F->s_clipr.reserve(room(n1 * 2))) || (rc = F->s_mapq.reserve(room(n1))) || (rc = F->s_cig.reserve(room(n1))) ||
-                                (rc = F->tidflag.reserve(room(n1)))))
+                                (rc = F->tidflag.reserve(room(n1))) || (rc = F->s_meta.reserve(room(n1 * 16)))))
     return rc;
   if (F->s_seq4.cap < seq_bytes && (rc = F->s_seq4.reserve(room(seq_bytes)))) return rc;
   FrontParseOut o;
   o.tid = F->s_tid.as<int32_t>(); o.pos = F->s_pos.as<int32_t>(); o.end = F->s_end.as<int32_t>(); o.seq_off = F->s_seqoff.as<uint32_t>();
   o.l_seq = F->s_lseq.as<uint16_t>(); o.clip_l = F->s_clipl.as<uint16_t>(); o.clip_r = F->s_clipr.as<uint16_t>();
-  o.mapq = F->s_mapq.as<uint8_t>(); o.cig = F->s_cig.as<uint8_t>(); o.seq4 = F->s_seq4.as<uint8_t>();
+  o.mapq = F->s_mapq.as<uint8_t>(); o.cig = F->s_cig.as<uint8_t>(); o.seq4 = F->s_seq4.as<uint8_t>(); o.meta = F->s_meta.as<uint4>();
   o.rows = c->x_rows.as<strl_pair_rec>() + at; o.qhash = c->x_qhash.as<uint64_t>() + at; o.qref = F->qref.as<uint64_t>() + at;
   o.qarena = F->qarena.as<uint8_t>(); o.qarena_at = F->qarena_used; o.fragw = F->fragw.as<uint32_t>() + at; o.tidflag = F->tidflag.as<uint8_t>();
   // (the scan finished: the host waited for it.  The previous chunk's scorer may still read the chunk-temporary columns:
@@ -1606,6 +1628,7 @@ static int front_stage_b(strl_ctx *c, strl::strl_front *F, int si) {
     strl_read_soa d{};
     d.n = n; d.tid = o.tid; d.pos = o.pos; d.end = o.end; d.seq_off = o.seq_off; d.l_seq = o.l_seq; d.clip_l = o.clip_l; d.clip_r = o.clip_r;
     d.mapq = o.mapq; d.cig = o.cig; d.seq4 = o.seq4; d.seq4_bytes = seq_bytes; d.max_l_seq = I.max_l_seq; d.mem = STRL_MEM_DEVICE;
+    d.meta = reinterpret_cast<const strl_read_meta *>(o.meta);
     if ((rc = extract_add_scored(c, &d, at))) return rc;
   }
   STRL_HIP(hipEventRecord(S.ev_b, c->stream));

@@ -59,7 +59,7 @@ def bounds_rows(bounds, targets, row_fn):
     return [row_fn(b, targets[int(b["tid"])][0]) for b in bounds]
 
 
-def device_batch(torch, dev, soa, rows, qh):
+def device_batch(torch, dev, soa, rows, qh, with_meta=True):
     """the arrays of a host batch uploaded to the device -> (CReadSoa, CPairSoa, keep-alive list): device-resident input
     is what makes strl_extract_device overlap a batch's pair logic with the next batch's scorer"""
     from strling_amd import api
@@ -68,9 +68,10 @@ def device_batch(torch, dev, soa, rows, qh):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     d = {k: up(getattr(soa, k)) for k in ("tid", "pos", "end", "seq_off", "l_seq", "clip_l", "clip_r", "mapq", "cig", "seq4")}
     drows, dqh = up(rows.view(np.uint8)), up(qh)
+    d["meta"] = up(soa.meta_rows().view(np.int32)) if with_meta else None
     cs = api.CReadSoa(soa.n, d["tid"].data_ptr(), d["pos"].data_ptr(), d["end"].data_ptr(), d["seq_off"].data_ptr(), d["l_seq"].data_ptr(),
                       d["clip_l"].data_ptr(), d["clip_r"].data_ptr(), d["mapq"].data_ptr(), d["cig"].data_ptr(), d["seq4"].data_ptr(),
-                      d["seq4"].numel(), soa.max_l_seq, api.MEM_DEVICE)
+                      d["seq4"].numel(), soa.max_l_seq, api.MEM_DEVICE, d["meta"].data_ptr() if with_meta else None)
     cp = api.CPairSoa(drows.data_ptr(), dqh.data_ptr())
     torch.cuda.synchronize()
     return cs, cp, [d, drows, dqh]

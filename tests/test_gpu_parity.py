@@ -287,7 +287,8 @@ def test_overlapped_clustering_of_one_batch_and_extract_of_the_next(ctx, oracle,
         if resident:
             import torch
             from helpers import device_batch
-            cs, cp, keep_dev = device_batch(torch, torch.device("cuda", 0), soa, keep[0], keep[1])
+            # (one batch with the packed strl_read_meta rows, one with the five columns only: both gathers of the skip-predicate pass)
+            cs, cp, keep_dev = device_batch(torch, torch.device("cuda", 0), soa, keep[0], keep[1], with_meta=len(batches) % 2 == 0)
             keep = (keep, keep_dev)
         batches.append(dict(rec=rec, g=g, med=med, soa=soa, cs=cs, cp=cp, keep=keep, window=window, mcd=mcd, exp=exp,
                             rows=[oracle.bounds_row(x, "c") for x in eb], unpl=[(r, int(k)) for r, k in eu]))

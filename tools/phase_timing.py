@@ -14,8 +14,10 @@ NAMES = {0: "load(queue+meta+seq->LDS)", 1: "conv 4bit->2bit", 2: "k2 clear+hist
 def build():
     out = os.path.join(ROOT, "tools", "ab", "libstrl_phase.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    src = [os.path.join(ROOT, "strling_amd", "csrc", f) for f in ("score.hip", "cluster.hip", "host_logic.cpp", "call_logic.cpp", "nim_tables.cpp")]
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSTRL_PHASE_TIMING", "-o", out] + src)
+    from strling_amd import build as b
+    src = [os.path.join(ROOT, "strling_amd", "csrc", f) for f in b.SOURCES]
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSTRL_PHASE_TIMING", "-o", out] + src +
+                          ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
     return out
 
 
