@@ -520,11 +520,20 @@ int strl_ctxs_extract_gather(strl_ctx **ctxs, int n, const uint32_t *chunk_owner
 /* flag | (isize in [0, 4095] ? isize : 0xffff) << 16 of records [first, first + n) of the file: what
  * fragment_length_distribution (utils.nim:86-111) reads of a record.  Synchronises the context's stream. */
 int strl_front_fragwords(strl_ctx *ctx, uint64_t first, uint64_t n, uint32_t *out);
+/* ... without waiting: enqueued behind the parse of every chunk handed over so far (strl_front_records of them); `out` must be
+ * page-locked; *done_event is waited for (and released) with strl_event_wait, from any thread. */
+int strl_front_fragwords_async(strl_ctx *ctx, uint64_t first, uint64_t n, uint32_t *out, void **done_event);
+int strl_event_wait(void *event);
+int strl_front_records(strl_ctx *ctx, uint64_t *n);
 /* seen[tid] != 0: the contig has had a primary record so far (extract.nim:310-313 prints a line per large one) */
 int strl_front_tids(strl_ctx *ctx, uint8_t *seen, int32_t n_ref);
 /* qnames of the given records (a tread's qname_id) from the device's name arena: names[qname_off[i], qname_off[i + 1]).
  * STRL_ERR_CAPACITY with *need set when `cap` is too small. */
 int strl_front_qnames(strl_ctx *ctx, const int64_t *record_ids, uint64_t n, uint64_t *qname_off, char *names, uint64_t cap, uint64_t *need);
+/* strl_treads_fetch + strl_front_qnames in one go (no host round trips in between): the treads in .bin order (qname_id = record
+ * index) and names[qname_off[i], qname_off[i + 1]) of tread i.  STRL_ERR_CAPACITY with *n_out / *names_need set when a buffer is too small. */
+int strl_front_treads_named(strl_ctx *ctx, strl_tread *treads, uint64_t cap, uint64_t *n_out, uint64_t *qname_off, char *names, uint64_t names_cap,
+                            uint64_t *names_need);
 /* page-locked host memory for strl_front_push's compressed bytes */
 void *strl_pinned_alloc(uint64_t bytes);
 void strl_pinned_free(void *p);

@@ -572,11 +572,14 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   std::vector<uint8_t *> pin((size_t)2 * G, nullptr), pin_meta((size_t)2 * G, nullptr);   // two per context: [2 g + (its chunk count & 1)]
   const auto t_start = now();
   double t_ctx = 0, t_pin = 0;
+  uint32_t *fw_early = nullptr;          // flag / isize words of the first records (fragment lengths)
+  const uint64_t early_n = 2400000;
   // the HIP runtime, the contexts and the page-locked buffers come up on threads beside the header walk
   std::thread pin_thread([&] {
     const auto c0 = now();
     for (auto &q : pin) q = static_cast<uint8_t *>(strl_pinned_alloc(chunk_bytes + 64));
     for (auto &q : pin_meta) q = static_cast<uint8_t *>(strl_pinned_alloc(chunk_blocks * 16 + 64));
+    fw_early = static_cast<uint32_t *>(strl_pinned_alloc(early_n * 4));     // (allocating page-locked memory inside the loop stalls the device)
     t_pin = secs(c0, now());
   });
   std::thread ctx_thread([&] {
@@ -636,6 +639,33 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   };
   auto mark = [&](int g, size_t before) { for (size_t k = before; k < waiting_at[(size_t)g]; ++k) have[(size_t)waiting[(size_t)g][k]] = 1; };
   std::vector<uint64_t> pushes((size_t)G, 0);
+  // fragment_length_distribution (utils.nim:86-111, extract.nim:281) from the flag / isize words the parse kept of every record.
+  // It needs the first ~2.1 M records only: as soon as they are parsed their words are copied out (behind the parse, no wait)
+  // and a thread makes the histogram beside the rest of the file.
+  struct FragState {
+    uint32_t frag[4096];
+    std::vector<int32_t> skipped;
+    int64_t counted = 0;
+    uint64_t next = 0;         // first record not looked at yet
+    bool done = false;
+  } fs;
+  memset(fs.frag, 0, sizeof fs.frag);
+  auto frag_feed = [&fs](const uint32_t *fw, uint64_t first, uint64_t n) {
+    const int64_t n_reads = 2000000, skip_reads = 100000;
+    for (uint64_t k = 0; k < n && !fs.done; ++k) {
+      const int64_t i = (int64_t)(first + k);
+      const uint32_t f = fw[k] & 0xffffu, is = fw[k] >> 16;
+      if (!(f & 0x2)) continue;
+      if (f & (0x800 | 0x100)) continue;
+      if (is > 4095u) continue;
+      if (i < skip_reads) { fs.skipped.push_back((int32_t)is); continue; }
+      fs.skipped.clear();
+      fs.frag[is]++;
+      if (++fs.counted > n_reads) fs.done = true;
+    }
+    fs.next = first + n;
+  };
+  std::thread frag_thread;
   for (uint64_t ci = 0;; ++ci) {
     const auto ta = now();
     // a short first chunk gets the device going while the second is being copied
@@ -665,8 +695,20 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     got(g, done, n_done);
     mark(g, before);
     account();
+    if (G == 1 && !frag_thread.joinable()) {
+      uint64_t parsed = 0;
+      CHECK(strl_front_records(ctx, &parsed));
+      if (parsed >= early_n) {
+        void *ev = nullptr;
+        if (fw_early) {
+          CHECK(strl_front_fragwords_async(ctx, 0, early_n, fw_early, &ev));
+          frag_thread = std::thread([&, ev] { if (strl_event_wait(ev) == STRL_OK) frag_feed(fw_early, 0, early_n); });
+        }
+      }
+    }
     t_walk += secs(ta, tb); t_copy += secs(tb, tc); t_push += secs(tc, now());
   }
+  if (frag_thread.joinable()) frag_thread.join();
   const auto tf = now();
   for (int g = 0; g < G; ++g) {
     strl_front_chunk done[2];
@@ -692,43 +734,27 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   }
   fprintf(stderr, "[strling] extracting unmapped reads\n");
   nreads += tail_primary;   // the "*" region is counted a second time by the reference's progress counter (extract.nim:326-329)
-  // fragment_length_distribution (utils.nim:86-111, extract.nim:281) from the flag / isize words the parse kept of every record
+  // the rest of the fragment-length pass, if the early part did not finish it (few proper pairs, small files)
   const auto tq = now();
   double t_frag_copy = 0;
-  uint32_t frag[4096];
-  memset(frag, 0, sizeof frag);
   {
-    const int64_t n_reads = 2000000, skip_reads = 100000;
-    std::vector<int32_t> skipped;
     uint32_t *fw = reinterpret_cast<uint32_t *>(pin[0]);          // (page-locked: the copy needs no staging)
     const uint64_t fw_cap = chunk_bytes / 4;
-    int64_t counted = 0;
-    bool done_f = false;
-    uint64_t fw_n = 0;
-    for (uint64_t first = 0; first < n_seen && !done_f; first += fw_n) {
-      fw_n = std::min<uint64_t>({n_seen - first, fw_cap, first == 0 ? (uint64_t)2400000 : (uint64_t)8000000});
+    while (!fs.done && fs.next < n_seen) {
+      const uint64_t first = fs.next, m = std::min<uint64_t>({n_seen - first, fw_cap, (uint64_t)8000000});
       const auto tw0 = now();
-      CHECK(strl_front_fragwords(ctx, first, fw_n, fw));
+      CHECK(strl_front_fragwords(ctx, first, m, fw));
       t_frag_copy += secs(tw0, now());
-      for (size_t k = 0; k < (size_t)fw_n; ++k) {
-        const int64_t i = (int64_t)(first + k);
-        const uint32_t f = fw[k] & 0xffffu, is = fw[k] >> 16;
-        if (!(f & 0x2)) continue;
-        if (f & (0x800 | 0x100)) continue;
-        if (is > 4095u) continue;
-        if (i < skip_reads) { skipped.push_back((int32_t)is); continue; }
-        skipped.clear();
-        frag[is]++;
-        if (++counted > n_reads) { done_f = true; break; }
-      }
+      frag_feed(fw, first, m);
     }
     uint64_t sum = 0;
-    for (int k = 0; k < 4096; ++k) sum += frag[k];
+    for (int k = 0; k < 4096; ++k) sum += fs.frag[k];
     if ((uint32_t)sum == 0) {
       fprintf(stderr, "using first reads in fragment_length_distribution calculation as there were not enough\n");
-      for (int32_t is : skipped) frag[is]++;
+      for (int32_t is : fs.skipped) fs.frag[is]++;
     }
   }
+  uint32_t *frag = fs.frag;
   const int frag_median = strl_frag_median(frag, 0.5);
   if (verbose) {
     fprintf(stderr, "Calculated median fragment length:%d\n", frag_median);
@@ -755,17 +781,30 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     return EXTRACT_AGAIN_ON_HOST;
   }
   if (rc) quit("[strling] %s (status %d)", strl_last_error(), rc);
-  std::vector<strl_tread> treads((size_t)nt + 1);
-  CHECK(strl_treads_fetch(ctx, treads.data(), nt, &nt, nullptr));
-  std::vector<int64_t> ids((size_t)nt);
-  for (uint64_t i = 0; i < nt; ++i) { ids[(size_t)i] = treads[(size_t)i].qname_id; treads[(size_t)i].qname_id = (int64_t)i; }
-  std::vector<uint64_t> qoff((size_t)nt + 1, 0);
-  std::string qn((size_t)nt * 255 + 16, '\0');
-  uint64_t need = 0;
-  CHECK(strl_front_qnames(ctx, ids.data(), nt, qoff.data(), &qn[0], qn.size(), &need));
+  // treads + names through the page-locked chunk buffers (free now): no staging copies; vectors when they are too small
+  std::vector<strl_tread> tv;
+  std::vector<uint64_t> qv;
+  std::string nv;
+  strl_tread *treads_p = reinterpret_cast<strl_tread *>(pin[0]);
+  uint64_t *qoff_p = reinterpret_cast<uint64_t *>(pin[1]);
+  const uint64_t names_room = chunk_bytes > (nt + 1) * 8 + 4096 ? chunk_bytes - (nt + 1) * 8 - 64 : 0;
+  char *names_p = reinterpret_cast<char *>(pin[1]) + (nt + 1) * 8 + 64;
+  if ((nt + 1) * sizeof(strl_tread) > chunk_bytes || names_room < nt * 64) {
+    tv.resize((size_t)nt + 1); qv.resize((size_t)nt + 1); nv.resize((size_t)nt * 255 + 16);
+    treads_p = tv.data(); qoff_p = qv.data(); names_p = &nv[0];
+  }
+  uint64_t need = 0, ngot = 0;
+  rc = strl_front_treads_named(ctx, treads_p, nt + 1, &ngot, qoff_p, names_p, treads_p == tv.data() ? nv.size() : names_room, &need);
+  if (rc == STRL_ERR_CAPACITY && treads_p != tv.data()) {       // names longer than the room behind the offsets: plain vectors
+    tv.resize((size_t)nt + 1); qv.resize((size_t)nt + 1); nv.resize((size_t)need + 16);
+    treads_p = tv.data(); qoff_p = qv.data(); names_p = &nv[0];
+    rc = strl_front_treads_named(ctx, treads_p, nt + 1, &ngot, qoff_p, names_p, nv.size(), &need);
+  }
+  if (rc) quit("[strling] %s (status %d)", strl_last_error(), rc);
+  for (uint64_t i = 0; i < nt; ++i) treads_p[i].qname_id = (int64_t)i;
   const double t_pair = secs(tp0, now());
   fprintf(stderr, "[strling] writing binary file:%s\n", bin.c_str());
-  CHECK(strl_bin_write(bin.c_str(), (float)p, min_mapq, frag, feed.header_text().data(), (int32_t)feed.header_text().size(), treads.data(), nt, qoff.data(), qn.data()));
+  CHECK(strl_bin_write(bin.c_str(), (float)p, min_mapq, frag, feed.header_text().data(), (int32_t)feed.header_text().size(), treads_p, nt, qoff_p, names_p));
   fprintf(stderr, "[strling] finished extraction\n");
   if (verbose) {
     fprintf(stderr, "[strling] %lld reads, %llu STR reads, 0 reads still waiting for a mate\n", (long long)nreads, (unsigned long long)nt);

@@ -359,6 +359,49 @@ __global__ void name_copy_kernel(const uint8_t *arena, const uint64_t *ref, cons
   for (uint32_t j = 0; j < (uint32_t)(r & 255u); ++j) d[j] = s[j];
 }
 
+// names of the resident treads (in .bin order): reference and length per tread, exclusive scan of the lengths (one block),
+// byte copies
+__global__ void tread_name_refs_kernel(const uint64_t *qref, const strl_tread *treads, const uint32_t *n_dev, uint32_t cap, uint64_t *ref, uint32_t *len) {
+  const uint32_t n = min(*n_dev, cap);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t r = qref[(uint64_t)treads[i].qname_id];
+  ref[i] = r;
+  len[i] = (uint32_t)(r & 255u);
+}
+__global__ __launch_bounds__(1024) void name_scan_kernel(const uint32_t *len, const uint32_t *n_dev, uint32_t cap, uint64_t *off) {
+  __shared__ uint64_t part[1024];
+  const uint32_t n = min(*n_dev, cap), t = threadIdx.x;
+  const uint32_t per = (n + 1023u) / 1024u, a = min(n, t * per), b = min(n, a + per);
+  uint64_t s = 0;
+  for (uint32_t i = a; i < b; ++i) s += len[i];
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) { uint64_t run = 0; for (int k = 0; k < 1024; ++k) { const uint64_t v = part[k]; part[k] = run; run += v; } off[n] = run; }
+  __syncthreads();
+  uint64_t run = part[t];
+  for (uint32_t i = a; i < b; ++i) { off[i] = run; run += len[i]; }
+}
+__global__ void tread_name_copy_kernel(const uint8_t *arena, const uint64_t *ref, const uint64_t *off, const uint32_t *n_dev, uint32_t cap, uint8_t *out, uint64_t out_cap) {
+  const uint32_t n = min(*n_dev, cap);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t r = ref[i], o = off[i];
+  const uint32_t l = (uint32_t)(r & 255u);
+  if (o + l > out_cap) return;
+  const uint8_t *s = arena + (r >> 8);
+  for (uint32_t j = 0; j < l; ++j) out[o + j] = s[j];
+}
+int front_tread_names(strl_ctx *c, strl_front *F, const strl_tread *d_treads, const uint32_t *d_n, uint32_t cap, uint64_t *d_ref, uint32_t *d_len, uint64_t *d_off,
+                      uint8_t *d_out, uint64_t out_cap, hipStream_t st) {
+  const unsigned g = (cap + 255) / 256;
+  hipLaunchKernelGGL(tread_name_refs_kernel, dim3(g), dim3(256), 0, st, F->qref.as<uint64_t>(), d_treads, d_n, cap, d_ref, d_len);
+  hipLaunchKernelGGL(name_scan_kernel, dim3(1), dim3(1024), 0, st, d_len, d_n, cap, d_off);
+  hipLaunchKernelGGL(tread_name_copy_kernel, dim3(g), dim3(256), 0, st, F->qarena.as<uint8_t>(), d_ref, d_off, d_n, cap, d_out, out_cap);
+  STRL_HIP(hipGetLastError());
+  return STRL_OK;
+}
+
 static int tick(strl_front *F, hipStream_t st) {   // STRL_FRONT_TIMING: an event behind every stage
   static const bool on = getenv("STRL_FRONT_TIMING") != nullptr;
   if (!on) return STRL_OK;

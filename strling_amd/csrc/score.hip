@@ -1742,6 +1742,32 @@ int strl_front_fragwords(strl_ctx *c, uint64_t first, uint64_t n, uint32_t *out)
   return STRL_OK;
 }
 
+// the same without waiting: the copy is enqueued behind the parse of every chunk handed over so far (`out` page-locked);
+// *done receives an event for strl_event_wait -- from any thread, so the fragment-length histogram of the first two million
+// records can be made beside the rest of the file
+int strl_front_fragwords_async(strl_ctx *c, uint64_t first, uint64_t n, uint32_t *out, void **done) {
+  if (!c || !c->front || !done || (n && !out) || first + n > c->x_n) { set_error("strl_front_fragwords_async: bad range"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  hipEvent_t ev;
+  STRL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  if (n) STRL_HIP(hipMemcpyAsync(out, c->front->fragw.as<uint32_t>() + first, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  STRL_HIP(hipEventRecord(ev, c->stream));
+  *done = ev;
+  return STRL_OK;
+}
+int strl_event_wait(void *event) {
+  if (!event) return STRL_OK;
+  hipEvent_t ev = static_cast<hipEvent_t>(event);
+  STRL_HIP(hipEventSynchronize(ev));
+  (void)hipEventDestroy(ev);
+  return STRL_OK;
+}
+int strl_front_records(strl_ctx *c, uint64_t *n) {
+  if (!c || !n) { set_error("null argument"); return STRL_ERR_ARG; }
+  *n = c->x_n;
+  return STRL_OK;
+}
+
 int strl_front_tids(strl_ctx *c, uint8_t *seen, int32_t n_ref) {
   if (!c || !c->front || n_ref > c->front->n_ref || (n_ref && !seen)) { set_error("strl_front_tids: bad argument"); return STRL_ERR_ARG; }
   STRL_HIP(hipSetDevice(c->device));
@@ -1785,6 +1811,44 @@ int strl_front_qnames(strl_ctx *c, const int64_t *record_ids, uint64_t n, uint64
   }
   d_ids.release(); d_ref.release(); d_off.release(); d_out.release();
   return STRL_OK;
+}
+
+// Treads of the last extract in .bin order WITH their qnames, in one go: strl_treads_fetch + strl_front_qnames without the
+// host round trips in between (references, exclusive scan of the lengths and byte copies are kernels behind the order sort).
+// treads[cap] / qname_off[cap + 1] / names[names_cap] may be page-locked memory (then the copies need no staging).
+// tread.qname_id stays the record index.  STRL_ERR_CAPACITY with *n_out / *names_need set when something does not fit.
+int strl_front_treads_named(strl_ctx *c, strl_tread *treads, uint64_t cap, uint64_t *n_out, uint64_t *qname_off, char *names, uint64_t names_cap, uint64_t *names_need) {
+  if (!c || !c->front || !n_out) { set_error("strl_front_treads_named: bad argument"); return STRL_ERR_ARG; }
+  uint64_t nt = 0;
+  int rc = strl_treads_fetch(c, nullptr, 0, &nt, nullptr);       // orders the treads, checks the error flags
+  *n_out = nt;
+  if (rc) return rc;
+  if (names_need) *names_need = 0;
+  if (!treads) return STRL_OK;
+  if (nt > cap) { set_error("tread capacity %llu too small, need %llu", (unsigned long long)cap, (unsigned long long)nt); return STRL_ERR_CAPACITY; }
+  if (qname_off) qname_off[0] = 0;
+  if (!nt) return STRL_OK;
+  STRL_HIP(hipSetDevice(c->device));
+  strl::DevBuf d_ref, d_len, d_off, d_out;
+  const uint64_t ocap = std::max<uint64_t>(std::min<uint64_t>(names_cap, nt * 255), 16);
+  if ((rc = d_ref.reserve((size_t)nt * 8)) || (rc = d_len.reserve((size_t)nt * 4)) || (rc = d_off.reserve((size_t)(nt + 1) * 8)) || (rc = d_out.reserve((size_t)ocap))) return rc;
+  hipStream_t st = c->stream;
+  if ((rc = strl::front_tread_names(c, c->front, c->treads.as<strl_tread>(), c->n_treads_dev, (uint32_t)nt, d_ref.as<uint64_t>(), d_len.as<uint32_t>(), d_off.as<uint64_t>(),
+                                    d_out.as<uint8_t>(), ocap, st)))
+    return rc;
+  STRL_HIP(hipMemcpyAsync(treads, c->treads.p, (size_t)nt * sizeof(strl_tread), hipMemcpyDeviceToHost, st));
+  uint64_t total = 0;
+  STRL_HIP(hipMemcpyAsync(&total, d_off.as<uint64_t>() + nt, 8, hipMemcpyDeviceToHost, st));
+  if (qname_off) STRL_HIP(hipMemcpyAsync(qname_off, d_off.p, (size_t)(nt + 1) * 8, hipMemcpyDeviceToHost, st));
+  STRL_HIP(hipStreamSynchronize(st));
+  if (names_need) *names_need = total;
+  int ret = STRL_OK;
+  if (qname_off && names) {
+    if (total > names_cap) { set_error("strl_front_treads_named: %llu bytes of names, capacity %llu", (unsigned long long)total, (unsigned long long)names_cap); ret = STRL_ERR_CAPACITY; }
+    else if (total) STRL_HIP(hipMemcpy(names, d_out.p, (size_t)total, hipMemcpyDeviceToHost));
+  }
+  d_ref.release(); d_len.release(); d_off.release(); d_out.release();
+  return ret;
 }
 
 void *strl_pinned_alloc(uint64_t bytes) {
