@@ -28,7 +28,11 @@ struct InflateParams {
   uint8_t *status;           // [n] per block (may be null)
 };
 
-__global__ __launch_bounds__(64) void inflate_kernel(InflateParams P) {
+#ifndef STRL_INFLATE_WAVES
+#define STRL_INFLATE_WAVES 6
+#endif
+// (waves per SIMD: the scalar unit bounds the kernel and half the wave-cycles are spent parked on s_waitcnt -- more waves, not fewer registers per se)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STRL_INFLATE_WAVES, 8))) void inflate_kernel(InflateParams P) {
   __shared__ IwLds lds;
   const uint32_t b = blockIdx.x;
   const int rc = iw_inflate(P.comp, P.coff[b], P.clen[b], P.readable, P.out + P.uoff[b], P.isize[b], lds);

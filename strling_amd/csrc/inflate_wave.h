@@ -21,7 +21,7 @@
 //     branch's arms and the uniformity analysis then marks everything behind the join as divergent (VGPRs, exec masks).
 //     The descriptors also bound every global access to the stream's input and the block's output: corrupt data cannot make
 //     the decoder read or write anywhere else.
-// About 7 KB of LDS per wave (5-6 waves per SIMD), no divergence, every global access coalesced.
+// 6.5 KB of LDS per wave and <= 80 VGPRs: six waves per SIMD; no divergence, every global access coalesced.
 //
 // The same source compiles for the host (STRL_EMU: the 64 lanes become loops) purely so that the CPU-only test-suite can
 // run the decoder logic against zlib; the product never runs that build.
@@ -126,12 +126,12 @@ struct IwLds {
     uint32_t dist_tab[1 << IW_DIST_ROOT];
     struct {
       uint32_t cl_tab[1 << IW_CL_ROOT];
-      uint32_t cl_sorted[32];                          // 19 symbols; [31] = the dummy slot of idle lanes
+      uint16_t cl_sorted[32];                          // 19 symbols; [31] = the dummy slot of idle lanes
       uint32_t cl_limit[16], cl_delta[16], cl_offs[16];
     } cl;
   };
-  uint32_t ll_sorted[288 + 1];                         // [288] / [32]: dummy slots of idle lanes
-  uint32_t d_sorted[32 + 1];
+  uint16_t ll_sorted[288 + 2];                         // symbols ordered by (code length, symbol); [288] / [32]: dummy slots of idle lanes
+  uint16_t d_sorted[32 + 2];
   uint32_t ll_limit[16], ll_delta[16], ll_offs[16];   // per code length 1..15: see iw_build
   uint32_t d_limit[16], d_delta[16], d_offs[16];
   uint8_t lens[320 + 4];                               // code lengths: literal/length symbols, then distance symbols; [320] dummy
@@ -172,14 +172,14 @@ IW_DEV uint32_t iw_cl_order(uint32_t i) {
 // codes first.  With v16 = the next 16 stream bits read most-significant-bit first,
 //   limit[l] = (first code of length l + number of codes of length l) << (16 - l): v16 < limit[l] <=> the code has <= l bits
 //   delta[l] = (index of the first length-l symbol in `sorted`) - (first code of length l)
-//   sorted[] = the symbols ordered by (length, symbol), already as table entries without their length
-// so a code of length l decodes to sorted[(v16 >> (16 - l)) + delta[l]].  tab[] is the direct table for the first ROOT bits
+//   sorted[] = the symbols ordered by (length, symbol)
+// so a code of length l decodes to the symbol sorted[(v16 >> (16 - l)) + delta[l]] (iw_entry_of makes its table entry).  tab[] is the direct table for the first ROOT bits
 // (stream order = least significant bit first): every lane fills entries lane, lane + 64, ... by decoding the entry's own
 // index; longer codes leave 0 there and go through iw_slow.  `dummy` = a slot of sorted[] behind the symbols.
 // Returns 0 for an over-subscribed code, or an incomplete one where zlib refuses it (inftrees.c: incomplete codes are
 // only allowed for a literal/length or distance code consisting of ONE code of length 1; no codes at all is allowed too).
 template <int ROUNDS, int ROOT, int KIND>
-IW_DEV uint32_t iw_build(const IwLane<uint32_t> (&len)[ROUNDS], uint32_t *tab, uint32_t *sorted, uint32_t dummy, uint32_t *limit, uint32_t *delta,
+IW_DEV uint32_t iw_build(const IwLane<uint32_t> (&len)[ROUNDS], uint32_t *tab, uint16_t *sorted, uint32_t dummy, uint32_t *limit, uint32_t *delta,
                          uint32_t *offs) {
   IwLane<uint32_t> rank[ROUNDS];
   IW_FOR_LANES {
@@ -221,7 +221,7 @@ IW_DEV uint32_t iw_build(const IwLane<uint32_t> (&len)[ROUNDS], uint32_t *tab, u
     for (int j = 0; j < ROUNDS; ++j) {
       const uint32_t l = len[j][lane];
       const uint32_t at = l ? offs[l] + rank[j][lane] : dummy;        // (offs[0] is never written: the select keeps it out)
-      sorted[at < dummy ? at : dummy] = iw_entry_of<KIND>((uint32_t)(j * 64 + lane));
+      sorted[at < dummy ? at : dummy] = (uint16_t)(j * 64 + lane);
     }
   }
   IW_SYNC();
@@ -236,7 +236,7 @@ IW_DEV uint32_t iw_build(const IwLane<uint32_t> (&len)[ROUNDS], uint32_t *tab, u
 #pragma unroll
       for (int k = ROOT; k >= 1; --k) l = v16 < lim[k] ? (uint32_t)k : l;
       const uint32_t at = l ? (v16 >> (16u - l)) + delta[l] : dummy;
-      const uint32_t e = sorted[at < dummy ? at : dummy] | l;
+      const uint32_t e = iw_entry_of<KIND>(sorted[at < dummy ? at : dummy]) | l;
       tab[i] = l ? e : 0u;
     }
   }
@@ -245,13 +245,13 @@ IW_DEV uint32_t iw_build(const IwLane<uint32_t> (&len)[ROUNDS], uint32_t *tab, u
 }
 
 // A code longer than the first-level table (or an unused prefix): canonical search over the remaining lengths.  0 = invalid.
-IW_DEV uint32_t iw_slow(uint64_t bb, const uint32_t *limit, const uint32_t *delta, const uint32_t *sorted, uint32_t dummy, int root) {
+template <int KIND> IW_DEV uint32_t iw_slow(uint64_t bb, const uint32_t *limit, const uint32_t *delta, const uint16_t *sorted, uint32_t dummy, int root) {
   const uint32_t v16 = iw_brev((uint32_t)bb) >> 16;
   for (int l = root + 1; l <= 15; ++l) {
     const uint32_t lim = IW_U(limit[l]);
     if (v16 < lim) {
       const uint32_t at = (v16 >> (16 - l)) + IW_U(delta[l]);
-      return IW_U(sorted[at < dummy ? at : dummy]) | (uint32_t)l;
+      return iw_entry_of<KIND>(IW_U(sorted[at < dummy ? at : dummy])) | (uint32_t)l;
     }
   }
   return 0u;
@@ -699,7 +699,7 @@ IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t
         if (code == 7u) { why = IW_ERR_SIZE; break; }
         if (code == 0u) {
           if (!(e & 15u)) {
-            e = iw_slow(br.bb, S.ll_limit, S.ll_delta, S.ll_sorted, 288u, IW_LIT_ROOT);
+            e = iw_slow<IW_LENS>(br.bb, S.ll_limit, S.ll_delta, S.ll_sorted, 288u, IW_LIT_ROOT);
             if (!e) { why = IW_ERR_DATA; break; }
           }
           br.bits(e & 15u);
@@ -719,7 +719,7 @@ IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t
         if (code == 4u) {                                       // distance code: first-level table or the canonical search
           uint32_t d = IW_U(S.dist_tab[(uint32_t)br.bb & ((1u << IW_DIST_ROOT) - 1u)]);
           if (!(d & 15u)) {
-            d = iw_slow(br.bb, S.d_limit, S.d_delta, S.d_sorted, 32u, IW_DIST_ROOT);
+            d = iw_slow<IW_DISTS>(br.bb, S.d_limit, S.d_delta, S.d_sorted, 32u, IW_DIST_ROOT);
             if (!d) { why = IW_ERR_DATA; break; }
           }
           br.bits(d & 15u);
