@@ -26,6 +26,7 @@ extern "C" {
 #define STRL_ERR_IO (-5)
 #define STRL_ERR_FORMAT (-6)
 #define STRL_ERR_ASSERT (-7) /* a doAssert of the reference would have fired (e.g. extract.nim:72) */
+#define STRL_ERR_CRC (-8)    /* a BGZF block inflates, but not to the bytes its CRC-32 names (htslib stops there too) */
 
 #define STRL_MEM_HOST 0
 #define STRL_MEM_DEVICE 1
@@ -492,8 +493,9 @@ int strl_ctx_inflate_ms(strl_ctx *ctx, double *ms);
  *   comp                  the chunk's compressed bytes; PINNED host memory (strl_pinned_alloc) makes the copy asynchronous; it
  *                         may be overwritten once the call after the next one has returned
  *   coff / clen / isize   per block: offset of its DEFLATE payload in comp, payload length, inflated size (BGZF ISIZE)
+ *   crc32                 per block: the CRC-32 its BGZF trailer states (checked on the device like htslib checks it), or NULL
  *   done / n_done         summaries of chunks whose scoring has COMPLETED, in file order (push: 0 or 1, finish: up to 2)
- * Errors: STRL_ERR_FORMAT invalid DEFLATE data / ISIZE / malformed record; STRL_ERR_ARG a record's l_seq > STRL_MAX_READ_LEN. */
+ * Errors: STRL_ERR_FORMAT invalid DEFLATE data / ISIZE / malformed record; STRL_ERR_CRC; STRL_ERR_ARG a record's l_seq > STRL_MAX_READ_LEN. */
 typedef struct {
   uint64_t n_records;       /* records of the chunk (secondary / supplementary included) */
   uint64_t n_primary;       /* those that are neither (the reference's progress counter, extract.nim:309,315) */
@@ -504,7 +506,7 @@ typedef struct {
 } strl_front_chunk;
 int strl_front_begin(strl_ctx *ctx, int32_t n_ref, uint64_t first_record_offset, uint64_t n_reads_hint);
 int strl_front_push(strl_ctx *ctx, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize,
-                    uint32_t n_blocks, strl_front_chunk *done, int *n_done);
+                    const uint32_t *crc32, uint32_t n_blocks, strl_front_chunk *done, int *n_done);
 int strl_front_finish(strl_ctx *ctx, strl_front_chunk done[2], int *n_done);
 /* One file on several GPUs (`strling extract --gpus N`; the reference has no counterpart, extract.nim:275 is one thread): the
  * chunks go round-robin over n contexts, each with its own strl_front_begin (only the context that gets the file's first
@@ -515,7 +517,7 @@ int strl_front_finish(strl_ctx *ctx, strl_front_chunk done[2], int *n_done);
  * ctxs[0] then continues like a one-GPU run: strl_front_fragwords, strl_extract_finish, strl_treads_fetch, strl_front_qnames.
  * chunk_owner[k] / chunk_records[k]: context index and strl_front_chunk.n_records of the file's k-th chunk. */
 int strl_front_push_after(strl_ctx *ctx, strl_ctx *prev, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen,
-                          const uint32_t *isize, uint32_t n_blocks, strl_front_chunk *done, int *n_done);
+                          const uint32_t *isize, const uint32_t *crc32, uint32_t n_blocks, strl_front_chunk *done, int *n_done);
 int strl_ctxs_extract_gather(strl_ctx **ctxs, int n, const uint32_t *chunk_owner, const uint64_t *chunk_records, uint64_t n_chunks);
 /* flag | (isize in [0, 4095] ? isize : 0xffff) << 16 of records [first, first + n) of the file: what
  * fragment_length_distribution (utils.nim:86-111) reads of a record.  Synchronises the context's stream. */

@@ -200,7 +200,7 @@ def load(build_if_missing=True):
     L.strl_inflate_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
     L.strl_ctx_inflate_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.strl_front_begin.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64]
-    L.strl_front_push.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_int)]
+    L.strl_front_push.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_int)]
     L.strl_front_finish.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     L.strl_front_fragwords.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
     L.strl_front_tids.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
@@ -547,7 +547,7 @@ class Context:
         return res
 
     # ---- extract with the BAM front end on the device ---------------------------------------------
-    def extract_bam_device(self, path, chunk_blocks=16384, n_reads_hint=0):
+    def extract_bam_device(self, path, chunk_blocks=16384, n_reads_hint=0, check_crc=True):
         """`strling extract`'s read loop over a BAM FILE with inflate, record scan and parse on the device
         (strl_front_begin / _push / _finish + strl_extract_finish).  The host side here only walks BGZF block headers.
         -> dict(treads, qnames, fragwords, chunks, n_records, n_tail, targets, header)"""
@@ -560,7 +560,7 @@ class Context:
             bsize = struct.unpack_from("<H", raw, o + 16)[0] + 1
             isz = struct.unpack_from("<I", raw, o + bsize - 4)[0]
             if isz:
-                blocks.append((o + 12 + xlen, bsize - 12 - xlen - 8, isz))
+                blocks.append((o + 12 + xlen, bsize - 12 - xlen - 8, isz, struct.unpack_from("<I", raw, o + bsize - 8)[0]))
             o += bsize
         # BAM header: inflate leading blocks on the host until it is complete
         hdr, k = b"", 0
@@ -568,7 +568,7 @@ class Context:
         def need(nbytes):
             nonlocal hdr, k
             while len(hdr) < nbytes and k < len(blocks):
-                po, pl, _ = blocks[k]
+                po, pl = blocks[k][:2]
                 hdr += zlib.decompress(raw[po:po + pl], -15)
                 k += 1
             if len(hdr) < nbytes:
@@ -602,8 +602,9 @@ class Context:
             coff = np.array([b[0] - lo for b in cb], np.uint64)
             clen = np.array([b[1] for b in cb], np.uint32)
             isz = np.array([b[2] for b in cb], np.uint32)
-            keep.append((comp, coff, clen, isz))                # pageable memory: the copy is staged by the runtime
-            _check(self.L.strl_front_push(self.h, comp.ctypes.data, comp.size, _ptr(coff), _ptr(clen), _ptr(isz), len(cb), done, C.byref(nd)))
+            crc = np.array([b[3] for b in cb], np.uint32)
+            keep.append((comp, coff, clen, isz, crc))           # pageable memory: the copy is staged by the runtime
+            _check(self.L.strl_front_push(self.h, comp.ctypes.data, comp.size, _ptr(coff), _ptr(clen), _ptr(isz), _ptr(crc) if check_crc else None, len(cb), done, C.byref(nd)))
             chunks += [_front_chunk(done[i]) for i in range(nd.value)]
             keep = keep[-3:]
         _check(self.L.strl_front_finish(self.h, done, C.byref(nd)))

@@ -42,9 +42,96 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STRL_INFLATE
   }
 }
 
+// ---- CRC-32 of every block's inflated bytes against the BGZF trailer (htslib refuses a block whose CRC differs: bgzf.c) ----
+// One wave per block; lane j runs the table-driven CRC (zero start value) over the j-th KiB of the block, advances its value
+// through the bytes behind its slice with the "2^k zero bytes" operators (the matrices zlib's crc32_combine squares), the lanes
+// XOR together (the CRC is linear), the start value's contribution and the final complement are added at the end.
+constexpr int CRC_SLICE = 1024;
+struct CrcTables { uint32_t tab[256]; uint32_t zop[17][32]; };      // byte table; operator of 2^k zero bytes, column per state bit
+__device__ __forceinline__ uint32_t crc_zeros(const uint32_t (*zop)[32], uint32_t v, uint32_t n_bytes) {
+  for (int k = 0; k < 17 && v; ++k) {
+    if (n_bytes & (1u << k)) {
+      uint32_t r = 0;
+      for (int b = 0; b < 32; ++b) r ^= (v >> b) & 1u ? zop[k][b] : 0u;
+      v = r;
+    }
+  }
+  return v;
+}
+__global__ __launch_bounds__(256) void crc32_kernel(const uint8_t *out, const uint64_t *uoff, const uint32_t *isize, const uint32_t *expect, uint32_t n_blocks,
+                                                     const CrcTables *T, uint8_t *status, uint32_t *err) {
+  __shared__ uint32_t tab[256];
+  __shared__ uint32_t zop[17][32];
+  for (int i = threadIdx.x; i < 256; i += 256) tab[i] = T->tab[i];
+  for (int i = threadIdx.x; i < 17 * 32; i += 256) (&zop[0][0])[i] = (&T->zop[0][0])[i];
+  __syncthreads();
+  const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (b >= n_blocks) return;
+  const uint32_t n = isize[b];
+  const uint8_t *p = out + uoff[b];
+  const uint32_t lo = lane * CRC_SLICE, hi = min(n, lo + CRC_SLICE);
+  uint32_t c = 0;
+  if (lo < n) {
+    uint32_t i = lo;
+    for (; i + 4 <= hi; i += 4) {
+      uint32_t w;
+      __builtin_memcpy(&w, p + i, 4);
+      c ^= w;
+      c = tab[c & 0xffu] ^ (c >> 8);
+      c = tab[c & 0xffu] ^ (c >> 8);
+      c = tab[c & 0xffu] ^ (c >> 8);
+      c = tab[c & 0xffu] ^ (c >> 8);
+    }
+    for (; i < hi; ++i) c = tab[(c ^ p[i]) & 0xffu] ^ (c >> 8);
+    c = crc_zeros(zop, c, n - hi);
+  }
+  if (lane == 0) c ^= crc_zeros(zop, 0xffffffffu, n);        // the all-ones start value, run through the whole block
+  for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d);
+  if (lane == 0 && (~c) != expect[b]) {
+    if (status) status[b] |= (uint8_t)IW_ERR_CRC;
+    if (err) atomicOr(err, (uint32_t)IW_ERR_CRC);
+  }
+}
+
 }  // namespace strl
 
 using namespace strl;
+
+// host: the tables of crc32_kernel (zlib's polynomial 0xedb88320, reflected), made once
+static const CrcTables &crc_tables() {
+  static CrcTables T;
+  static bool done = false;
+  if (!done) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+      T.tab[i] = c;
+    }
+    for (int b = 0; b < 32; ++b) { const uint32_t v = 1u << b; T.zop[0][b] = T.tab[v & 0xffu] ^ (v >> 8); }   // one zero byte
+    for (int k = 1; k < 17; ++k)
+      for (int b = 0; b < 32; ++b) {
+        uint32_t v = T.zop[k - 1][b], r = 0;
+        for (int j = 0; j < 32; ++j) if ((v >> j) & 1u) r ^= T.zop[k - 1][j];
+        T.zop[k][b] = r;
+      }
+    done = true;
+  }
+  return T;
+}
+
+// CRC-32 of the inflated blocks against `d_crc` (the BGZF trailers' values): mismatches set IW_ERR_CRC in d_status
+int strl_crc_device(strl_ctx *c, const uint8_t *d_out, const uint64_t *d_uoff, const uint32_t *d_isize, const uint32_t *d_crc, uint32_t n_blocks, uint8_t *d_status,
+                    uint32_t *d_err, hipStream_t st) {
+  if (!n_blocks) return STRL_OK;
+  if (!c->crc_tab.p) {
+    int rc = c->crc_tab.reserve(sizeof(CrcTables));
+    if (rc) return rc;
+    STRL_HIP(hipMemcpy(c->crc_tab.p, &crc_tables(), sizeof(CrcTables), hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(crc32_kernel, dim3((n_blocks + 3) / 4), dim3(256), 0, st, d_out, d_uoff, d_isize, d_crc, n_blocks, c->crc_tab.as<CrcTables>(), d_status, d_err);
+  STRL_HIP(hipGetLastError());
+  return STRL_OK;
+}
 
 // Inflate n DEFLATE streams (device arrays as in InflateParams); asynchronous on `st`.
 int strl_inflate_device(strl_ctx *c, const uint8_t *d_comp, uint64_t readable, const uint64_t *d_coff, const uint32_t *d_clen, const uint64_t *d_uoff,

@@ -89,7 +89,9 @@ bool BgzfFeed::open(const std::string &path, std::string &err) {
       const uint8_t *f = h + bsize - 4;
       const uint32_t isz = f[0] | (f[1] << 8) | (f[2] << 16) | ((uint32_t)f[3] << 24);
       if (isz > 65536u) { state = 2; werr = "BGZF block inflates to more than 64 KiB"; break; }
-      if (isz) local.push_back(Block{(size_t)(h + 12 + xlen - map_), bsize - 12 - xlen - 8, isz});
+      const uint8_t *cf = h + bsize - 8;
+      const uint32_t crc = cf[0] | (cf[1] << 8) | (cf[2] << 16) | ((uint32_t)cf[3] << 24);
+      if (isz) local.push_back(Block{(size_t)(h + 12 + xlen - map_), bsize - 12 - xlen - 8, isz, crc});
       pos += bsize;
       if (local.size() >= 1024 && !publish()) return;
     }

@@ -23,7 +23,7 @@ class BgzfFeed {
   const std::vector<BamTarget> &targets() const { return targets_; }
   uint64_t first_record_offset() const { return first_off_; }   // bytes into the first block's inflated data
   size_t file_bytes() const { return map_len_; }
-  struct Block { size_t c_off; uint32_t clen, isize; };          // DEFLATE payload at map + c_off
+  struct Block { size_t c_off; uint32_t clen, isize, crc; };     // DEFLATE payload at map + c_off; CRC-32 of the inflated bytes (trailer)
   // Next run of consecutive non-empty blocks: at most max_blocks and max_bytes of file (first block's payload to the last
   // block's end).  Returns the number of blocks (0 at the end of the file), -1 on a malformed file.
   int64_t next(std::vector<Block> &out, size_t max_blocks, size_t max_bytes, std::string &err);

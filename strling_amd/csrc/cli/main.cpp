@@ -295,7 +295,7 @@ static void setup_genome(strl_ctx *ctx, const Args &a, const std::vector<BamTarg
 }
 
 static int extract_front(const Args &a, const std::string &bam, const std::string &bin, double p, uint8_t min_mapq, bool verbose);
-constexpr int EXTRACT_AGAIN_ON_HOST = -77;
+constexpr int EXTRACT_AGAIN_ON_HOST = -77, EXTRACT_AGAIN_HOST_FRONT = -78;
 
 static int extract_main(int argc, char **argv) {
   const char *usage =
@@ -321,8 +321,10 @@ static int extract_main(int argc, char **argv) {
     const char *fe = getenv("STRL_FRONT"), *pe = getenv("STRL_PAIR");
     if (!(fe && strcmp(fe, "host") == 0) && !(pe && strcmp(pe, "host") == 0)) {
       const int r = extract_front(a, bam, bin, p, min_mapq, verbose);
-      if (r != EXTRACT_AGAIN_ON_HOST) return r;
-      setenv("STRL_PAIR", "host", 1);       // the device join passed (hash collision / one qname on hundreds of records): the string-keyed Cache
+      if (r != EXTRACT_AGAIN_ON_HOST && r != EXTRACT_AGAIN_HOST_FRONT) return r;
+      if (r == EXTRACT_AGAIN_ON_HOST) setenv("STRL_PAIR", "host", 1);   // the device join passed (hash collision / one qname on hundreds of records): the string-keyed Cache
+      // (EXTRACT_AGAIN_HOST_FRONT: the device front end refused the file -- a block its decoder does not take, a record of more
+      // than a megabyte: the host reader, whose verdict on the file is zlib's, takes over)
     }
   }
 
@@ -578,7 +580,7 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   std::vector<strl_ctx *> ctxs((size_t)G, nullptr);
   std::vector<int> ctx_rc((size_t)G, 0);
   std::vector<std::string> ctx_err((size_t)G);
-  std::vector<uint8_t *> pin((size_t)2 * G, nullptr), pin_meta((size_t)2 * G, nullptr);   // two per context: [2 g + (its chunk count & 1)]
+  std::vector<uint8_t *> pin((size_t)2 * G, nullptr), pin_meta((size_t)2 * G, nullptr);   // two per context: [2 g + (its chunk count & 1)]; block tables: coff u64 | clen | isize | crc u32
   const auto t_start = now();
   double t_ctx = 0, t_pin = 0;
   uint32_t *fw_early = nullptr;          // flag / isize words of the first records (fragment lengths)
@@ -587,7 +589,7 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   std::thread pin_thread([&] {
     const auto c0 = now();
     for (auto &q : pin) q = static_cast<uint8_t *>(strl_pinned_alloc(chunk_bytes + 64));
-    for (auto &q : pin_meta) q = static_cast<uint8_t *>(strl_pinned_alloc(chunk_blocks * 16 + 64));
+    for (auto &q : pin_meta) q = static_cast<uint8_t *>(strl_pinned_alloc(chunk_blocks * 20 + 64));
     fw_early = static_cast<uint32_t *>(strl_pinned_alloc(early_n * 4));     // (allocating page-locked memory inside the loop stalls the device)
     t_pin = secs(c0, now());
   });
@@ -648,6 +650,22 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   };
   auto mark = [&](int g, size_t before) { for (size_t k = before; k < waiting_at[(size_t)g]; ++k) have[(size_t)waiting[(size_t)g][k]] = 1; };
   std::vector<uint64_t> pushes((size_t)G, 0);
+  std::thread frag_thread;
+  // a file the device front end refuses (STRL_ERR_FORMAT) goes to the host reader instead of ending the run
+  auto give_up_front = [&]() -> int {
+    fprintf(stderr, "[strling] %s: repeating the extraction with the host reader\n", strl_last_error());
+    if (frag_thread.joinable()) frag_thread.join();
+    for (size_t k = 0; k < pin.size(); ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
+    for (strl_ctx *c : ctxs) strl_ctx_destroy(c);
+    return EXTRACT_AGAIN_HOST_FRONT;
+  };
+#define FRONT_CHECK(call)                                                                    \
+  do {                                                                                       \
+    const int rc__ = (call);                                                                 \
+    if (rc__ == STRL_ERR_FORMAT) return give_up_front();                                     \
+    if (rc__ == STRL_ERR_CRC) quit("[strling] error reading %s: %s", bam.c_str(), strl_last_error());   \
+    if (rc__ != STRL_OK) quit("[strling] %s (status %d)", strl_last_error(), rc__);          \
+  } while (0)
   // fragment_length_distribution (utils.nim:86-111, extract.nim:281) from the flag / isize words the parse kept of every record.
   // It needs the first ~2.1 M records only: as soon as they are parsed their words are copied out (behind the parse, no wait)
   // and a thread makes the histogram beside the rest of the file.
@@ -674,7 +692,6 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     }
     fs.next = first + n;
   };
-  std::thread frag_thread;
   for (uint64_t ci = 0;; ++ci) {
     const auto ta = now();
     // a short first chunk gets the device going while the second is being copied
@@ -689,8 +706,8 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     const size_t piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
     copy_pool.parallel_for(pieces, [&](size_t k) { memcpy(dst + k * piece, feed.map() + lo + k * piece, std::min(piece, hi - lo - k * piece)); });
     uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[slot]);
-    uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks;
-    for (size_t k = 0; k < (size_t)nb; ++k) { coff[k] = blks[k].c_off - lo; clen[k] = blks[k].clen; isz[k] = blks[k].isize; }
+    uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks, *crc = isz + chunk_blocks;
+    for (size_t k = 0; k < (size_t)nb; ++k) { coff[k] = blks[k].c_off - lo; clen[k] = blks[k].clen; isz[k] = blks[k].isize; crc[k] = blks[k].crc; }
     const auto tc = now();
     strl_front_chunk done[2];
     int n_done = 0;
@@ -699,7 +716,7 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     chunk_owner.push_back((uint32_t)g);
     waiting[(size_t)g].push_back(ci);
     const size_t before = waiting_at[(size_t)g];
-    CHECK(strl_front_push_after(ctxs[(size_t)g], ci ? ctxs[(size_t)((ci - 1) % (uint64_t)G)] : nullptr, dst, hi - lo, coff, clen, isz, (uint32_t)nb, done, &n_done));
+    FRONT_CHECK(strl_front_push_after(ctxs[(size_t)g], ci ? ctxs[(size_t)((ci - 1) % (uint64_t)G)] : nullptr, dst, hi - lo, coff, clen, isz, crc, (uint32_t)nb, done, &n_done));
     ++pushes[(size_t)g];
     got(g, done, n_done);
     mark(g, before);
@@ -723,7 +740,7 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     strl_front_chunk done[2];
     int n_done = 0;
     const size_t before = waiting_at[(size_t)g];
-    CHECK(strl_front_finish(ctxs[(size_t)g], done, &n_done));
+    FRONT_CHECK(strl_front_finish(ctxs[(size_t)g], done, &n_done));
     got(g, done, n_done);
     mark(g, before);
   }

@@ -158,6 +158,7 @@ struct strl_ctx {
   bool x_soft_pending = false;
   bool x_open = false, x_mode = false;
   bool x_front = false;            // the chunks came through the device front end: qnames of all records sit in its arena
+  strl::DevBuf crc_tab;            // tables of the BGZF CRC-32 check (bgzf.hip)
   strl::DevBuf p_spill;            // pair logic: first items of the hash runs too long for the in-block replay
   bool pg_attr_done = false;
   hipEvent_t pev[6] = {};

@@ -8,7 +8,7 @@ namespace strl {
 constexpr uint32_t FRONT_SEG = 16384;            // bytes of inflated data whose records one lane chains through
 constexpr uint32_t FRONT_CARRY_MAX = 1u << 20;   // room in front of a chunk's inflated bytes for the partial record the previous chunk ended in
 constexpr uint32_t FRONT_NONE = 0xffffffffu;
-constexpr uint32_t FRONT_ERR_INFLATE = 1, FRONT_ERR_RECORD = 2, FRONT_ERR_LSEQ = 4, FRONT_ERR_CARRY = 8;
+constexpr uint32_t FRONT_ERR_INFLATE = 1, FRONT_ERR_RECORD = 2, FRONT_ERR_LSEQ = 4, FRONT_ERR_CARRY = 8, FRONT_ERR_CRC = 16;
 
 // device-resident summary of one chunk; the host reads it back after the record scan and again after the parse
 struct FrontInfo {
@@ -42,7 +42,7 @@ struct FrontSeg {         // one FRONT_SEG-byte segment of the inflated bytes
 
 // buffers of one chunk in flight (the context keeps two)
 struct FrontSlot {
-  DevBuf comp, infl, coff, clen, uoff, isize, status, seg, recoff, seqoff, qoff, info, base3, carry_stage;
+  DevBuf comp, infl, coff, clen, uoff, isize, crc, status, seg, recoff, seqoff, qoff, info, base3, carry_stage;
   uint32_t n_blocks = 0, n_seg = 0;
   uint64_t infl_bytes = 0, comp_bytes = 0;
   hipEvent_t ev_read = nullptr;   // another context copied this slot's tail (multi-GPU carry)
@@ -80,6 +80,7 @@ struct FrontChunkDesc {   // host view of a chunk handed to front_stage_a
   uint64_t comp_bytes;
   const uint64_t *coff;   // [n] offset of each block's DEFLATE payload in comp
   const uint32_t *clen, *isize;
+  const uint32_t *crc;    // [n] CRC-32 of each block's inflated bytes (BGZF trailer), or null: not checked
   uint32_t n_blocks;
 };
 

@@ -20,6 +20,8 @@
 #include "front.h"
 #include "device_util.h"
 
+int strl_crc_device(strl_ctx *c, const uint8_t *d_out, const uint64_t *d_uoff, const uint32_t *d_isize, const uint32_t *d_crc, uint32_t n_blocks, uint8_t *d_status,
+                    uint32_t *d_err, hipStream_t st);
 int strl_inflate_device(strl_ctx *c, const uint8_t *d_comp, uint64_t readable, const uint64_t *d_coff, const uint32_t *d_clen, const uint64_t *d_uoff,
                         const uint32_t *d_isize, uint32_t n_blocks, uint8_t *d_out, uint32_t *d_err, uint8_t *d_status, hipStream_t st);
 
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(1024) void rec_link_kernel(const uint8_t *U, FrontS
     info->max_l_seq = sh_maxl;
     info->all_ok = ok ? 1u : 0u;
     info->slow_segments = sh_slow;
-    info->err |= e | (info->inflate_err ? FRONT_ERR_INFLATE : 0u);
+    info->err |= e | ((info->inflate_err & 3u) ? FRONT_ERR_INFLATE : 0u) | ((info->inflate_err & 4u) ? FRONT_ERR_CRC : 0u);
     info->n_primary = 0; info->last_placed = -1; info->tail_primary = 0;
   }
 }
@@ -442,7 +444,7 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   if (S.comp.cap < readable + 16 && (rc = S.comp.reserve(want(readable + 16)))) return rc;
   if (S.infl.cap < (uint64_t)end + 256 && (rc = S.infl.reserve(want((uint64_t)end + 256)))) return rc;
   if (S.coff.cap < (size_t)nb * 8 && ((rc = S.coff.reserve(want((size_t)nb * 8))) || (rc = S.uoff.reserve(want((size_t)nb * 8))) ||
-                                       (rc = S.clen.reserve(want((size_t)nb * 4))) || (rc = S.isize.reserve(want((size_t)nb * 4))) ||
+                                       (rc = S.clen.reserve(want((size_t)nb * 4))) || (rc = S.isize.reserve(want((size_t)nb * 4))) || (rc = S.crc.reserve(want((size_t)nb * 4))) ||
                                        (rc = S.status.reserve(want(nb)))))
     return rc;
   if (S.seg.cap < (size_t)n_seg * sizeof(FrontSeg) && ((rc = S.seg.reserve(want((size_t)n_seg * sizeof(FrontSeg)))) || (rc = S.base3.reserve(want((size_t)n_seg * 16)))))
@@ -462,6 +464,7 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   STRL_HIP(hipMemcpyAsync(S.uoff.p, uoff, (size_t)nb * 8, hipMemcpyHostToDevice, sc));
   STRL_HIP(hipMemcpyAsync(S.clen.p, d.clen, (size_t)nb * 4, hipMemcpyHostToDevice, sc));
   STRL_HIP(hipMemcpyAsync(S.isize.p, d.isize, (size_t)nb * 4, hipMemcpyHostToDevice, sc));
+  if (d.crc) STRL_HIP(hipMemcpyAsync(S.crc.p, d.crc, (size_t)nb * 4, hipMemcpyHostToDevice, sc));
   STRL_HIP(hipEventRecord(S.ev_h2d, sc));
   STRL_HIP(hipStreamWaitEvent(st, S.ev_h2d, 0));
   FrontInfo &hi = S.h_info[2];
@@ -475,6 +478,9 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   FrontInfo *info = S.info.as<FrontInfo>();
   if ((rc = strl_inflate_device(c, S.comp.as<uint8_t>(), readable, S.coff.as<uint64_t>(), S.clen.as<uint32_t>(), S.uoff.as<uint64_t>(), S.isize.as<uint32_t>(), nb,
                                 S.infl.as<uint8_t>(), &info->inflate_err, S.status.as<uint8_t>(), st)))
+    return rc;
+  if (d.crc && (rc = strl_crc_device(c, S.infl.as<uint8_t>(), S.uoff.as<uint64_t>(), S.isize.as<uint32_t>(), S.crc.as<uint32_t>(), nb, S.status.as<uint8_t>(),
+                                     &info->inflate_err, st)))
     return rc;
   if ((rc = tick(F, st))) return rc;
   if (!first && !carry) {
@@ -549,7 +555,7 @@ int front_copy_names(strl_ctx *c, strl_front *F, const uint64_t *d_ref, const ui
 void front_destroy(strl_front *F) {
   if (!F) return;
   for (FrontSlot &S : F->slot) {
-    for (DevBuf *b : {&S.comp, &S.infl, &S.coff, &S.clen, &S.uoff, &S.isize, &S.status, &S.seg, &S.recoff, &S.seqoff, &S.qoff, &S.info, &S.base3, &S.carry_stage}) b->release();
+    for (DevBuf *b : {&S.comp, &S.infl, &S.coff, &S.clen, &S.uoff, &S.isize, &S.crc, &S.status, &S.seg, &S.recoff, &S.seqoff, &S.qoff, &S.info, &S.base3, &S.carry_stage}) b->release();
     if (S.ev_a) (void)hipEventDestroy(S.ev_a);
     if (S.ev_b) (void)hipEventDestroy(S.ev_b);
     if (S.ev_h2d) (void)hipEventDestroy(S.ev_h2d);

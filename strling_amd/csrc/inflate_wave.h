@@ -109,7 +109,7 @@ IW_DEV void iw_st8(const IwBuf &b, uint32_t off, uint32_t v) { __builtin_amdgcn_
 
 namespace strl {
 
-constexpr int IW_ERR_DATA = 1, IW_ERR_SIZE = 2;
+constexpr int IW_ERR_DATA = 1, IW_ERR_SIZE = 2, IW_ERR_CRC = 4;
 constexpr uint32_t IW_OOB = 0x80000000u;   // an offset no descriptor of this file covers (num_records < 2^31)
 constexpr int IW_LIT_ROOT = 10, IW_DIST_ROOT = 8, IW_CL_ROOT = 7;
 

@@ -840,7 +840,7 @@ void strl_ctx_destroy(strl_ctx *c) {
                           &c->soft_tmp, &c->sb_whole, &c->sb_soft, &c->queue_r, &c->soft_dense, &c->sb_state_w, &c->sb_state_s, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
                           &c->st_mapq, &c->st_cig, &c->st_seq4, &c->st_whole, &c->st_soft, &c->st_text, &c->st_meta,
                           &c->p_key0, &c->p_key1, &c->p_val0, &c->p_val1, &c->p_emit, &c->sort_scratch, &c->pair_cnt, &c->bloom, &c->treads,
-                          &c->st_mtid, &c->st_mpos, &c->st_flag, &c->st_qhash, &c->x_rows, &c->x_qhash, &c->x_whole, &c->x_soft, &c->x_cnt, &c->g_aux};
+                          &c->st_mtid, &c->st_mpos, &c->st_flag, &c->st_qhash, &c->x_rows, &c->x_qhash, &c->x_whole, &c->x_soft, &c->x_cnt, &c->g_aux, &c->crc_tab, &c->p_spill};
   for (auto *b : bufs) b->release();
   for (auto &b : c->c_buf) b.release();
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1594,6 +1594,7 @@ static int front_stage_b(strl_ctx *c, strl::strl_front *F, int si) {
   STRL_HIP(hipEventSynchronize(S.ev_a));
   const FrontInfo I = S.h_info[0];
   if (I.err & FRONT_ERR_INFLATE) { set_error("invalid BGZF block (DEFLATE data or ISIZE)"); return STRL_ERR_FORMAT; }
+  if (I.err & FRONT_ERR_CRC) { set_error("CRC32 checksum mismatch in a BGZF block"); return STRL_ERR_CRC; }
   if (I.err & FRONT_ERR_RECORD) { set_error("malformed BAM record"); return STRL_ERR_FORMAT; }
   if (I.err & FRONT_ERR_CARRY) { set_error("BAM record of more than %u bytes", FRONT_CARRY_MAX); return STRL_ERR_FORMAT; }
   const uint64_t n = I.n_records, at = c->x_n;
@@ -1663,16 +1664,16 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
   return STRL_OK;
 }
 
-int strl_front_push(strl_ctx *c, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize, uint32_t n_blocks,
-                    strl_front_chunk *done, int *n_done) {
-  return strl_front_push_after(c, nullptr, comp, comp_bytes, coff, clen, isize, n_blocks, done, n_done);
+int strl_front_push(strl_ctx *c, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize, const uint32_t *crc32,
+                    uint32_t n_blocks, strl_front_chunk *done, int *n_done) {
+  return strl_front_push_after(c, nullptr, comp, comp_bytes, coff, clen, isize, crc32, n_blocks, done, n_done);
 }
 
 // the same when the chunks of ONE file go round-robin over several contexts (`strling extract --gpus N`): `prev` = the
 // context the previous chunk of the file was pushed to (null / c itself: this context) -- the partial record in front of
 // this chunk is taken from there
 int strl_front_push_after(strl_ctx *c, strl_ctx *prev, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize,
-                          uint32_t n_blocks, strl_front_chunk *done, int *n_done) {
+                          const uint32_t *crc32, uint32_t n_blocks, strl_front_chunk *done, int *n_done) {
   if (!c || !c->front || !c->x_open || (n_blocks && (!comp || !coff || !clen || !isize))) { set_error("strl_front_push: bad argument / no strl_front_begin"); return STRL_ERR_ARG; }
   if (prev == c) prev = nullptr;
   if (prev && (!prev->front || prev->front->last_slot < 0)) { set_error("strl_front_push_after: the previous context has no chunk"); return STRL_ERR_ARG; }
@@ -1686,7 +1687,7 @@ int strl_front_push_after(strl_ctx *c, strl_ctx *prev, const uint8_t *comp, uint
     if ((rc = front_fill_done(c, F->slot[si], done))) return rc;
     if (n_done) *n_done = 1;
   }
-  const strl::FrontChunkDesc d{comp, comp_bytes, coff, clen, isize, n_blocks};
+  const strl::FrontChunkDesc d{comp, comp_bytes, coff, clen, isize, crc32, n_blocks};
   if (prev) {
     strl::FrontSlot &PS = prev->front->slot[prev->front->last_slot];
     const strl::FrontCarrySrc cs{PS.infl.as<uint8_t>(), PS.info.as<strl::FrontInfo>(), prev->front->last_end, prev->device, PS.ev_a, PS.ev_read, &PS.read_pending};

@@ -119,6 +119,19 @@ def test_extract_bin_is_byte_identical_to_oracle(sample, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("what", ["crc", "payload"])
+def test_extract_reports_a_damaged_bgzf_block(sample, what):
+    """a block whose CRC-32 field was changed: the device front end stops like htslib does; a damaged DEFLATE payload: the
+    device refuses the block, the host reader (zlib's verdict) takes over and refuses it too"""
+    from test_front_device import _corrupt
+    bad = str(sample["dir"] / f"bad_{what}.bam")
+    _corrupt(sample["bam"], bad, what)
+    r = _run(["extract", "-g", sample["bed"], bad, str(sample["dir"] / "bad.bin")])
+    assert r.returncode != 0
+    assert ("CRC32" in r.stderr) if what == "crc" else ("repeating the extraction with the host reader" in r.stderr and "error reading" in r.stderr), r.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("gpus,blocks", [("2", "3"), ("3", "5"), ("2", "8192"), ("4", "2")])
 def test_extract_on_several_contexts_writes_the_same_bin(sample, gpus, blocks):
     """strling extract --gpus N: the file's chunks round-robin over N contexts (partial records carried from one context's chunk

@@ -92,3 +92,45 @@ def test_front_end_many_soft_clips_per_chunk(ctx, tmp_path):
     path = str(tmp_path / "s.bam")
     bamio.write_bam(path, rec, level=1, index=False)
     _check(ctx, rec, g, path, 16384, exp)
+
+
+def _corrupt(path, out, what):
+    """copy of a BAM with one byte changed in the second-to-last data block: its CRC-32 field, or its DEFLATE payload"""
+    import struct
+    raw = bytearray(open(path, "rb").read())
+    offs, o = [], 0
+    while o < len(raw):
+        bsize = struct.unpack_from("<H", raw, o + 16)[0] + 1
+        if struct.unpack_from("<I", raw, o + bsize - 4)[0]:
+            offs.append((o, bsize))
+        o += bsize
+    o, bsize = offs[-2]
+    if what == "crc":
+        raw[o + bsize - 8] ^= 0x40
+    else:
+        raw[o + 18 + (bsize - 26) // 2] ^= 0x10
+    open(out, "wb").write(bytes(raw))
+
+
+def test_front_end_checks_the_blocks_crc32(ctx, tmp_path):
+    """htslib refuses a BGZF block whose inflated bytes do not have the CRC-32 of its trailer; so does the device front end --
+    and a damaged DEFLATE payload is reported as a format error (the CLI then lets the host reader, i.e. zlib, judge the file)"""
+    from oracle import oracle as O
+    rec, g = synth.synth_wgs(4000, seed=3, contig_len=400_000)
+    med = O.median(synth.frag_hist(rec))
+    ctx.set_opts(0.8, 40, med)
+    ctx.set_genome(g)
+    good = str(tmp_path / "g.bam")
+    bamio.write_bam(good, rec, level=6, block=20011, index=False)
+    exp = ctx.extract_bam_device(good, chunk_blocks=5)
+    assert exp["n_records"] == rec.n
+    bad = str(tmp_path / "c.bam")
+    _corrupt(good, bad, "crc")
+    with pytest.raises(api.StrlingError) as e:
+        ctx.extract_bam_device(bad, chunk_blocks=5)
+    assert "CRC32" in str(e.value)
+    got = ctx.extract_bam_device(bad, chunk_blocks=5, check_crc=False)        # the bytes themselves are intact
+    assert np.array_equal(got["treads"], exp["treads"])
+    _corrupt(good, bad, "payload")
+    with pytest.raises(api.StrlingError):
+        ctx.extract_bam_device(bad, chunk_blocks=5)
