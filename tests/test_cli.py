@@ -128,7 +128,9 @@ def test_extract_reports_a_damaged_bgzf_block(sample, what):
     _corrupt(sample["bam"], bad, what)
     r = _run(["extract", "-g", sample["bed"], bad, str(sample["dir"] / "bad.bin")])
     assert r.returncode != 0
-    assert ("CRC32" in r.stderr) if what == "crc" else ("repeating the extraction with the host reader" in r.stderr and "error reading" in r.stderr), r.stderr
+    # (a flipped payload bit either breaks the DEFLATE stream -- the device refuses the block, the host reader takes over and zlib
+    # refuses it too -- or leaves a stream that inflates to other bytes of the same size: then the CRC-32 catches it)
+    assert "CRC32" in r.stderr or ("repeating the extraction with the host reader" in r.stderr and "error reading" in r.stderr), r.stderr
 
 
 @pytest.mark.gpu
