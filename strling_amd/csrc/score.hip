@@ -93,6 +93,7 @@ struct ScoreParams {
   const uint2 *g_bins;      // per tid and 4 KiB bin: {#starts below the bin, #starts below the next bin}
   int32_t n_tid;
   const uint16_t *lut;
+  const uint32_t *ta;    // stage A's tables (score_core.h TA_*)
   const uint64_t *thr;
   uint32_t *whole;
   uint4 *queue;        // [n]      scoring queue (classify -> stage A, whole reads)
@@ -113,7 +114,7 @@ struct ScoreParams {
 };
 
 constexpr int LUT_DWORDS = LUT_ENTRIES / 2;
-constexpr int LUT_A_DWORDS = LUT_OFF5 / 2;   // stage A only looks up k <= 4
+constexpr int LUT_A_DWORDS = TA_WORDS;       // stage A reads its own tables (k <= 4)
 constexpr int CL_STAGE = 512;    // queue entries a wave stages in LDS before one bulk append (16 KB per block: 8 blocks per CU)
 constexpr int CL_ILP = 8;        // reads per lane per iteration (independent lookup chains in flight)
 
@@ -490,10 +491,10 @@ __global__ __launch_bounds__(1024) void soft_compact_kernel(ScoreParams P) {
   }
 }
 
-// rows ([row][lane] dwords) of a wave's LDS region: raw SEQ staging, the class bins of k <= 4 + dummy row (24 + 1 for k = 3), long-read hash slots
+// rows ([row][lane] dwords) of a wave's LDS region: raw SEQ staging, the class bins of k <= 4 (24 for k = 3), long-read hash slots
 template <int NW, int SLOTS, int STAGE> constexpr int table_rows() {
   constexpr int raw = 4 * ((16 * NW + 62) / 32);
-  constexpr int need = STAGE == 0 ? 25 : (NW <= 10 ? 0 : SLOTS);
+  constexpr int need = STAGE == 0 ? 24 : (NW <= 10 ? 0 : SLOTS);
   return raw > need ? raw : need;
 }
 
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? 4 : 1) void sco
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   __shared__ __attribute__((aligned(16))) uint32_t lds_st[STATIC_LDS ? LDS_WORDS : 4];
   uint32_t *const lds = STATIC_LDS ? lds_st : lds_dyn;
-  for (int i = threadIdx.x; i < LUTK; i += BLOCK) lds[i] = reinterpret_cast<const uint32_t *>(P.lut)[i];
+  for (int i = threadIdx.x; i < LUTK; i += BLOCK) lds[i] = STAGE == 0 ? P.ta[i] : reinterpret_cast<const uint32_t *>(P.lut)[i];
   for (int i = threadIdx.x; i < 256; i += BLOCK) lds[LUTK + i] = reinterpret_cast<const uint32_t *>(P.lut)[LUT_DWORDS + i];
   __syncthreads();
   const uint16_t *lut = reinterpret_cast<const uint16_t *>(lds);
@@ -629,20 +630,30 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? 4 : 1) void sco
     ScoreState st;
     st.best = cur.best; st.alive = STAGE == 1 && cur.act; st.res0 = cur.res0; st.res1 = cur.res1;
     st.ph_t = __builtin_readcyclecounter();
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {   // rows a lane does not need just receive zeros
-      col[(4 * c + 0) * 64] = pc.s[c].x;
-      col[(4 * c + 1) * 64] = pc.s[c].y;
-      col[(4 * c + 2) * 64] = pc.s[c].z;
-      col[(4 * c + 3) * 64] = pc.s[c].w;
-    }
-    __builtin_amdgcn_wave_barrier();
-    STRL_PH(st, 0);
     Seg<NW> sg;
-    seg_from_raw<NW>(col, clut, cur.s0 & 31, cur.len, sg);
+    const LenBounds lb = STAGE == 0 ? len_bounds(cur.act, cur.len) : LenBounds{0, 0};
+    if (MODE == 0 && STAGE == 0) {
+      // whole reads start on a 16-byte boundary of the SEQ array: converted straight from the prefetched registers
+      uint32_t raw[4 * MAXCH];
+#pragma unroll
+      for (int c = 0; c < MAXCH; ++c) { raw[4 * c] = pc.s[c].x; raw[4 * c + 1] = pc.s[c].y; raw[4 * c + 2] = pc.s[c].z; raw[4 * c + 3] = pc.s[c].w; }
+      STRL_PH(st, 0);
+      seg_from_words<NW>(raw, clut, cur.len, lb, sg);
+    } else {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < MAXCH; ++c) {   // rows a lane does not need just receive zeros
+        col[(4 * c + 0) * 64] = pc.s[c].x;
+        col[(4 * c + 1) * 64] = pc.s[c].y;
+        col[(4 * c + 2) * 64] = pc.s[c].z;
+        col[(4 * c + 3) * 64] = pc.s[c].w;
+      }
+      __builtin_amdgcn_wave_barrier();
+      STRL_PH(st, 0);
+      seg_from_raw<NW>(col, clut, cur.s0 & 31, cur.len, sg);
+    }
     STRL_PH(st, 1);
-    if (STAGE == 0) score_stage_a<NW, SLOTS>(sg, cur.act, wave_tab, lane, lut, pc.t, st);
+    if (STAGE == 0) score_stage_a<NW, SLOTS>(sg, cur.act, wave_tab, lds + LUTW, lane, lds, pc.t, lb, st);
     else score_stage_b<NW, SLOTS>(sg, wave_tab, lane, lut, pc.t, st);
 
     const bool fwd = STAGE == 0 && cur.act && st.alive;
@@ -814,12 +825,14 @@ int strl_ctx_create(int device_ordinal, strl_ctx **out) {
   for (auto &e : c->pev) STRL_HIP(hipEventCreate(&e));
   std::vector<uint16_t> lut;
   build_lut(lut);
-  std::vector<uint32_t> clut;
+  std::vector<uint32_t> clut, ta;
   build_conv_lut(clut);
-  int rc = c->lut.reserve(lut.size() * 2 + clut.size() * 4);
+  build_stage_a_tables(lut, ta);
+  int rc = c->lut.reserve(lut.size() * 2 + clut.size() * 4 + ta.size() * 4);
   if (rc) return rc;
   STRL_HIP(hipMemcpy(c->lut.p, lut.data(), lut.size() * 2, hipMemcpyHostToDevice));
   STRL_HIP(hipMemcpy(static_cast<char *>(c->lut.p) + lut.size() * 2, clut.data(), clut.size() * 4, hipMemcpyHostToDevice));
+  STRL_HIP(hipMemcpy(static_cast<char *>(c->lut.p) + lut.size() * 2 + clut.size() * 4, ta.data(), ta.size() * 4, hipMemcpyHostToDevice));
   rc = c->counters.reserve(CNT_WORDS * 4);
   if (rc) return rc;
   *out = c;
@@ -1039,6 +1052,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   P.g_tid = c->g_tid.as<TidInfo>(); P.g_bins = c->g_bins.as<uint2>(); P.g_iv = c->g_start.as<int2>();
   P.n_tid = c->n_tid;
   P.lut = c->lut.as<uint16_t>(); P.thr = c->thr.as<uint64_t>();
+  P.ta = c->lut.as<uint32_t>() + LUT_DWORDS + 256;
   P.whole = whole; P.queue = c->queue.as<uint4>(); P.soft_flag = c->soft_dense.as<uint8_t>();
   P.soft_queue = c->soft_queue.as<uint4>();
   P.sb_state[0] = c->sb_state_w.as<uint4>(); P.sb_state[1] = c->sb_state_s.as<uint4>();
@@ -1165,6 +1179,7 @@ int strl_index_chrom(strl_ctx *c, const char *seq, uint64_t n_bases, uint32_t wi
   ScoreParams P{};
   P.n = nw; P.seq4 = c->st_seq4.as<uint8_t>();
   P.lut = c->lut.as<uint16_t>(); P.thr = c->thr.as<uint64_t>();
+  P.ta = c->lut.as<uint32_t>() + LUT_DWORDS + 256;
   P.soft_queue = c->soft_queue.as<uint4>(); P.scap = (uint32_t)nw;
   P.sb_state[1] = c->sb_state_s.as<uint4>(); P.sb_queue[1] = c->sb_soft.as<uint4>();
   P.counters = c->counters.as<uint32_t>(); P.soft_out = c->st_soft.as<strl_soft_rec>(); P.soft_cap = (uint32_t)nw;

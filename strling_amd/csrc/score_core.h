@@ -33,6 +33,7 @@ static inline int strl_wave_min(int v) { return v; }
 static inline uint32_t strl_max3(uint32_t a, uint32_t b, uint32_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 static inline uint32_t strl_bfe(uint32_t x, uint32_t off, uint32_t w) { return (x >> off) & ((1u << w) - 1u); }
 static inline uint32_t strl_lds_add(uint32_t *a, uint32_t v) { uint32_t o = *a; *a = o + v; return o; }
+static inline int strl_wave_max(int v) { return v; }
 #else
 #include <hip/hip_runtime.h>
 #define STRL_DEV __device__ __forceinline__
@@ -45,6 +46,11 @@ STRL_DEV bool strl_any(bool p) { return __any(p) != 0; }
 STRL_DEV int strl_wave_min(int v) {   // wave-uniform minimum (butterfly; once per k pass)
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o < v ? o : v; }
+  return __builtin_amdgcn_readfirstlane(v);
+}
+STRL_DEV int strl_wave_max(int v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; }
   return __builtin_amdgcn_readfirstlane(v);
 }
 STRL_DEV uint32_t strl_max3(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }   // v_max3_u32
@@ -81,6 +87,16 @@ template <> struct LutOff<3> { static constexpr int v = LUT_OFF3; };
 template <> struct LutOff<4> { static constexpr int v = LUT_OFF4; };
 template <> struct LutOff<5> { static constexpr int v = LUT_OFF5; };
 template <> struct LutOff<6> { static constexpr int v = LUT_OFF6; };
+
+// Stage A (k = 2, 3, 4) reads its own tables, shaped so that a window costs three vector instructions besides the two LDS
+// operations (u32 words; ROWB = bytes between two rows of a lane's bin column):
+//   TA_K2 [256]  one byte of the 2-bit stream = TWO k = 2 windows -> ROWB * class of the first | ROWB * class of the second << 16
+//   TA_K4 [256]  one byte = one k = 4 window -> ROWB * (class >> 2) | 8 * (class & 3) << 16   (uint8 bins, four per dword)
+//   TA_K3 [16]   64 x uint8: 6-bit window -> class
+//   TA_C  [52]   104 x uint16: class -> the reference's code, k = 2 | 3 | 4 at 0 | 10 | 34
+constexpr int TA_K2 = 0, TA_K4 = 256, TA_K3 = 512, TA_C = 528, TA_WORDS = 580;
+constexpr uint32_t ROWB = 4u * STRL_LANES;
+template <int K> struct TaCls { static constexpr int off = K == 2 ? 0 : K == 3 ? 10 : 34; };
 
 // threshold tables (host-computed with the reference's float64 expressions, so the device does
 // no floating point at all): thr[row][L] = five bytes, byte k-2 = the value for k; rows: 0 = int(L*0.12/k) (utils.nim:251),
@@ -130,6 +146,61 @@ template <int NW> struct Seg {
   int n_N;
   bool has_inv;
 };
+
+// wave-uniform bounds of the segment lengths of the lanes that carry an item (idle lanes: nothing to bound)
+struct LenBounds { int lo, hi; };
+STRL_DEV LenBounds len_bounds(bool active, int len) {
+  LenBounds b;
+  b.lo = strl_wave_min(active ? len : 0x7fffffff);
+  b.hi = strl_wave_max(active ? len : 0);
+  return b;
+}
+
+// Build a Seg whose first base is base 0 of raw[0] (whole reads: SEQ starts on a 16-byte boundary of the batch's SEQ array),
+// straight from the registers the prefetch loaded: no staging through LDS, no funnel shifts.  Words every lane of the wave
+// fills completely (16 (w + 1) <= lb.lo) skip the end-of-read mask.
+template <int NW, int NRAW> STRL_DEV void seg_from_words(const uint32_t (&raw)[NRAW], const uint32_t *clut, int len, const LenBounds &lb, Seg<NW> &sg) {
+  static_assert(NRAW >= 2 * NW, "two raw dwords per word of the 2-bit stream");
+  uint32_t any_f = 0, fl[NW];
+  // all table lookups of a half are in flight together (a branch per word would serialise ten LDS round trips); the second
+  // half is skipped when no lane of the wave reaches it
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int w0 = h ? NW / 2 : 0, w1 = h ? NW : NW / 2;
+#pragma unroll
+    for (int w = w0; w < w1; ++w) { sg.seq[w] = 0; fl[w] = 0; }
+    if (h && 16 * w0 >= lb.hi) continue;   // wave-uniform
+#pragma unroll
+    for (int w = w0; w < w1; ++w) {
+      const uint32_t a = raw[2 * w], b = raw[2 * w + 1];
+      const uint32_t ra = clut[a & 0xffu] | (clut[(a >> 8) & 0xffu] << 4) | (clut[(a >> 16) & 0xffu] << 8) | (clut[a >> 24] << 12);
+      const uint32_t rb = clut[b & 0xffu] | (clut[(b >> 8) & 0xffu] << 4) | (clut[(b >> 16) & 0xffu] << 8) | (clut[b >> 24] << 12);
+      sg.seq[w] = (ra & 0xffffu) | (rb << 16);
+      fl[w] = (ra >> 16) | (rb & 0xffff0000u);
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    if (16 * (w + 1) > lb.lo) {   // wave-uniform: some lane ends inside this word (or before it)
+      const int nv = len - 16 * w;
+      const uint32_t m = nv >= 16 ? 0xffffffffu : nv <= 0 ? 0u : ((1u << (2 * nv)) - 1u);
+      sg.seq[w] &= m;
+      fl[w] &= m;
+    }
+    any_f |= fl[w];
+  }
+  int nn = 0;
+  if (strl_any(any_f != 0)) {   // rare: no lane of the wave has a base that is not ACGT
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { sg.inv[w] = fl[w] & 0x55555555u; nn += strl_popc(fl[w] & 0xAAAAAAAAu); }
+  } else {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sg.inv[w] = 0;
+  }
+  sg.len = len;
+  sg.n_N = nn;
+  sg.has_inv = (any_f & 0x55555555u) != 0;
+}
 
 // Build a Seg from raw BAM-packed dwords staged in this lane's LDS column (`raw[i * STRL_LANES]`
 // is dword i of the staged chunk), starting at base `s0` (< 32) of the chunk.
@@ -185,23 +256,119 @@ template <int K, int NW> STRL_DEV uint32_t window_code(const Seg<NW> &sg, const 
 
 // The count of a k pass is the running count inc() (utils.nim:192-195) would have seen at each window:
 //   newc_i = 1 + #{j < i : code_j == code_i};  count = max_i newc_i;  winner = code at the first i reaching it.
-// Four interchangeable ways to get newc_i, picked per k by what is cheapest on CDNA4:
-//   k = 2,3 : 32-bit bins in LDS ([bin][lane], ds_add_rtn returns the old count), 16 / 64 rows
-//   k = 4   : 256 uint8 bins packed 4 per dword in LDS, 64 rows.  (Counting k = 4 in registers with byte-parallel
-//             equality was tried: 2.6x the VALU instructions of the LDS bins, and integer VALU is the binding
-//             resource of this kernel -- 4 cycles per wave64 op, ~90 % busy -- so it lost.)
+// Ways to get newc_i, picked per k by what is cheapest on CDNA4 (integer VALU issue is what binds the kernel):
+//   k = 2,3 : one 32-bit bin per CLASS (10 / 24 minimum-rotation classes) in LDS, [bin][lane]; ds_add_rtn returns the old count
+//   k = 4   : 70 uint8 bins packed 4 per dword, 18 rows.  (Counting k = 4 in registers with byte-parallel equality was
+//             tried: 2.6x the VALU instructions of the LDS bins.)
 //   k = 5,6 : in registers, one code per VGPR (<= 32 windows for reads <= 160 bases); longer reads fall back to a
 //             per-lane open-addressing table in LDS.
-template <int K, int NW, int SLOTS>
-STRL_DEV void hist_pass(const Seg<NW> &sg, bool active, uint32_t *tab, const uint16_t *lut, int &cmax, uint32_t &imax) {
+//
+// k <= 4 (stage A).  Running arg-max without compare / select chains: inside a batch of 8 windows
+//   key = newc << CS | (7 - j) << (CS - 3) | tag      (tag: which bin -- see below)
+// and one unsigned max picks the largest running count and, among equals, the earliest window; across batches an earlier
+// batch keeps the lead unless a later one has a strictly larger count -- together the code inc() would have kept.
+// What a window costs besides its two LDS operations (table read, ds_add_rtn):
+//   k = 2: the table is indexed by a BYTE of the stream (two windows; sub-dword operand select, one shift for the pair) and
+//          holds the two bins' byte offsets; bin address = offset + column (one add, 16-bit operand select); the bins count in
+//          units of 1 << CS and the tag IS that address -- the byte offset from `bins0`, the first wave's bin region, a
+//          compile-time LDS address that folds into the ds instruction's offset field (a static allocation is at most
+//          64 KB: 16 bits) -- so key = old + constant + address is one three-operand add.
+//   k = 3: 6-bit windows do not align: field extract, uint8 class table, address = class << 8 + column, same key.
+//   k = 4: byte-indexed table -> row offset | shift << 16; increment 1 << shift, address, old >> shift into the top byte
+//          (all with sub-dword operand selects), key = that + (entry + constant): five instructions.
+// Windows past the longest segment of the wave are not executed (lb.hi); batches below the shortest (lb.lo) need no
+// per-lane masks; in between a lane past its own end still counts into its bins -- nothing reads them again -- and only its
+// key is zeroed.
+template <int K, int NW>
+STRL_DEV void hist_pass_a(const Seg<NW> &sg, bool active, uint32_t *bins0, uint32_t col_off, const uint32_t *ta, const LenBounds &lb, int &cmax, uint32_t &imax) {
+  static_assert(K >= 2 && K <= 4, "stage A");
   constexpr uint32_t MASK = (1u << (2 * K)) - 1u;
   constexpr int NWIN = NW * 16 / K;
-  constexpr int B = 8;  // windows per batch: 8 LUT reads, then 8 table updates in flight at once (LDS latency)
+  constexpr int B = 8;                       // three tie-break bits
+  constexpr int CS = K == 4 ? 24 : 19;       // the count field; below it 3 tie-break bits and the tag (16 bits; k = 4: 21)
+  constexpr uint32_t LOW = (1u << CS) - 1u;
+  const int nwin = active ? sg.len / K : 0;
+  const int umin = lb.lo == 0x7fffffff ? 0 : lb.lo / K, umax = lb.hi / K;   // wave-uniform
+  const uint8_t *t3 = reinterpret_cast<const uint8_t *>(ta + TA_K3);
+  cmax = 0;
+  imax = MASK;
+  uint32_t best = 0;
+#pragma unroll
+  for (int b0 = 0; b0 < NWIN; b0 += B) {
+    if (b0 >= umax) continue;                // wave-uniform (not a `break`: the trip count stays a constant and the loop unrolls)
+    uint32_t key[B];
+    auto kc = [](int j) { return (1u << CS) | ((7u - (uint32_t)j) << (CS - 3)); };
+    // window b0 + j of the batch: table entry (shared by two windows at k = 2), then count + key
+    auto entry = [&](int j) -> uint32_t {
+      const int i = b0 + j;
+      if (K == 2) return ta[TA_K2 + ((sg.seq[i >> 3] >> (8 * ((i >> 1) & 3))) & 0xffu)];
+      if (K == 4) return ta[TA_K4 + ((sg.seq[i >> 2] >> (8 * (i & 3))) & 0xffu)];
+      const int bit = 6 * i, w = bit >> 5, sh = bit & 31;
+      const uint32_t lo = sg.seq[w], hi = (w + 1 < NW) ? sg.seq[w + 1] : 0u;
+      return t3[((sh + 6 <= 32) ? (lo >> sh) : strl_funnel_r(lo, hi, sh)) & 63u];
+    };
+    auto count = [&](int j, uint32_t e) -> uint32_t {
+      if (K == 4) {
+        const uint32_t sh = (e >> 16) & 0xffu;
+        uint32_t *bin = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(bins0) + (col_off + (e & 0xffffu)));
+        const uint32_t old = strl_lds_add(bin, 1u << sh);
+        return ((old >> sh) << 24) + (e + kc(j));
+      }
+      const uint32_t at = col_off + (K == 2 ? ((j & 1) ? (e >> 16) : (e & 0xffffu)) : e * ROWB);
+      const uint32_t old = strl_lds_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(bins0) + at), 1u << CS);
+      return old + kc(j) + at;
+    };
+    if (b0 + B <= umin && b0 + B <= NWIN) {    // wave-uniform: every lane has all eight windows
+      uint32_t e[B];
+#pragma unroll
+      for (int j = 0; j < B; ++j) e[j] = (K == 2 && (j & 1)) ? e[j - 1] : entry(j);
+#pragma unroll
+      for (int j = 0; j < B; ++j) key[j] = count(j, e[j]);
+    } else {
+      // two half batches (each with its LDS operations in flight together), the second only if some lane reaches it;
+      // a lane past its own end counts into its bins all the same -- nothing reads them again -- and zeroes its key
+#pragma unroll
+      for (int h = 0; h < B; h += B / 2) {
+        uint32_t e[B / 2];
+#pragma unroll
+        for (int j = 0; j < B / 2; ++j) key[h + j] = 0;
+        if (b0 + h < NWIN && b0 + h < umax) {   // wave-uniform
+#pragma unroll
+          for (int j = 0; j < B / 2; ++j) e[j] = (b0 + h + j >= NWIN) ? 0u : (K == 2 && (j & 1)) ? e[j - 1] : entry(h + j);
+#pragma unroll
+          for (int j = 0; j < B / 2; ++j)
+            if (b0 + h + j < NWIN) {
+              const uint32_t k = count(h + j, e[j]);
+              key[h + j] = (b0 + h + j < nwin) ? k : 0u;
+            }
+        }
+      }
+    }
+    uint32_t bb = key[0] > key[1] ? key[0] : key[1];
+#pragma unroll
+    for (int j = 2; j + 1 < B; j += 2) bb = strl_max3(bb, key[j], key[j + 1]);
+    if (bb > (best | LOW)) best = bb;          // strictly larger count only
+  }
+  if (best) {   // no window at all: count 0, code "all ones" (utils.nim:197-198)
+    const uint16_t *tc = reinterpret_cast<const uint16_t *>(ta + TA_C) + TaCls<K>::off;
+    cmax = (int)(best >> CS);
+    if (K == 4) imax = tc[4u * ((best & 0xffffu) / ROWB) + ((best >> 19) & 3u)];
+    else imax = tc[((best & 0xffffu) - col_off) / ROWB];
+  }
+}
+
+// k = 5, 6 (stage B)
+template <int K, int NW, int SLOTS>
+STRL_DEV void hist_pass(const Seg<NW> &sg, bool active, uint32_t *tab, const uint16_t *lut, int &cmax, uint32_t &imax) {
+  static_assert(K >= 5, "stage B");
+  constexpr uint32_t MASK = (1u << (2 * K)) - 1u;
+  constexpr int NWIN = NW * 16 / K;
+  constexpr int B = 8;
   const uint16_t *lk = lut + LutOff<K>::v;
   const int nwin = active ? sg.len / K : 0;
   cmax = 0;
   imax = MASK;
-  if (K >= 5 && NW <= 10) {
+  if (NW <= 10) {
     uint32_t code[NWIN];
 #pragma unroll
     for (int i = 0; i < NWIN; ++i) code[i] = window_code<K, NW>(sg, lk, i);
@@ -218,84 +385,13 @@ STRL_DEV void hist_pass(const Seg<NW> &sg, bool active, uint32_t *tab, const uin
     }
     return;
   }
-  if (K <= 4) {
-    // Running argmax without compare/select chains: inside a batch of 8 windows key = newc << 15 | (7 - j) << 12 | code and
-    // one unsigned max picks the largest running count and, among equals, the earliest window; across batches an earlier
-    // batch keeps the lead unless a later one has a strictly larger count -- together the code inc() (utils.nim:192-195)
-    // would have kept.  (A single key with the global window index needs ~170 distinct constants, which the compiler
-    // parks in VGPRs for the whole kernel.)  Batches that lie below the shortest live segment of the wave (`umin`,
-    // wave-uniform) need no per-window bounds masks at all: idle lanes count into their own bins, their result is ignored.
-    static_assert(B == 8, "three tie-break bits");
-    const int umin = strl_wave_min(active ? nwin : 0x7fffffff);
-    uint32_t best = 0;
-#pragma unroll
-    for (int b0 = 0; b0 < NWIN; b0 += B) {
-      if (!strl_any(b0 < nwin)) break;  // wave-uniform early exit for short segments
-      uint32_t code[B], key[B], kc[B];
-#pragma unroll
-      for (int j = 0; j < B; ++j) code[j] = (b0 + j < NWIN) ? window_code<K, NW>(sg, lk, b0 + j) : 0u;
-#pragma unroll
-      for (int j = 0; j < B; ++j) kc[j] = (1u << 15) | ((7u - (uint32_t)j) << 12);
-      const bool full = b0 + B <= umin && b0 + B <= NWIN;      // wave-uniform
-      if (K <= 3) {  // 10 / 24 x 32-bit bins (one per class); windows past a lane's end hit a dummy row and get key 0
-        constexpr uint32_t DUMMY = (uint32_t)LutCls<K>::n;
-        uint32_t old[B];
-        // The bins count in units of 1 << 15, so the value the LDS atomic returns already sits in the key's count field
-        // and the key is ONE three-operand add (count field + tie-break constant + class: no overlapping bits).
-        if (full) {
-#pragma unroll
-          for (int j = 0; j < B; ++j) old[j] = strl_lds_add(tab + code[j] * STRL_LANES, 1u << 15);
-#pragma unroll
-          for (int j = 0; j < B; ++j) key[j] = old[j] + kc[j] + code[j];
-        } else {
-#pragma unroll
-          for (int j = 0; j < B; ++j) {
-            old[j] = 0;
-            if (b0 + j < NWIN) old[j] = strl_lds_add(tab + ((b0 + j < nwin) ? code[j] : DUMMY) * STRL_LANES, 1u << 15);
-          }
-#pragma unroll
-          for (int j = 0; j < B; ++j) {
-            const uint32_t k = old[j] + kc[j] + code[j];
-            key[j] = (b0 + j < NWIN && b0 + j < nwin) ? k : 0u;
-          }
-        }
-      } else {  // K == 4: 70 uint8 bins packed 4 per dword (18 rows + dummy); a lane's updates to one bin stay ordered
-        uint32_t old[B], sh[B];
-#pragma unroll
-        for (int j = 0; j < B; ++j) sh[j] = (code[j] & 3u) * 8u;
-        if (full) {
-#pragma unroll
-          for (int j = 0; j < B; ++j) old[j] = strl_lds_add(tab + (code[j] >> 2) * STRL_LANES, 1u << sh[j]);
-#pragma unroll
-          for (int j = 0; j < B; ++j) key[j] = ((strl_bfe(old[j], sh[j], 8) << 15) + kc[j]) | code[j];
-        } else {
-#pragma unroll
-          for (int j = 0; j < B; ++j) {
-            old[j] = 0;
-            if (b0 + j < NWIN) old[j] = strl_lds_add(tab + ((b0 + j < nwin) ? (code[j] >> 2) : 18u) * STRL_LANES, 1u << sh[j]);
-          }
-#pragma unroll
-          for (int j = 0; j < B; ++j) {
-            const uint32_t k = ((strl_bfe(old[j], sh[j], 8) << 15) + kc[j]) | code[j];
-            key[j] = (b0 + j < NWIN && b0 + j < nwin) ? k : 0u;
-          }
-        }
-      }
-      uint32_t bb = key[0] > key[1] ? key[0] : key[1];
-#pragma unroll
-      for (int j = 2; j + 1 < B; j += 2) bb = strl_max3(bb, key[j], key[j + 1]);
-      if (bb > (best | 0x7fffu)) best = bb;      // strictly larger count only
-    }
-    if (best) { cmax = (int)(best >> 15); imax = lut[LutCls<K>::off + (best & 0xfffu)]; }   // no window at all: count 0, code "all ones" (utils.nim:197-198)
-    return;
-  }
 #pragma unroll
   for (int b0 = 0; b0 < NWIN; b0 += B) {
     if (!strl_any(b0 < nwin)) break;  // wave-uniform early exit for short segments
     uint32_t code[B];
 #pragma unroll
     for (int j = 0; j < B; ++j) code[j] = (b0 + j < NWIN) ? window_code<K, NW>(sg, lk, b0 + j) : 0u;
-    {  // k = 5, 6 on long reads: open addressing, entry = (code+1) << 8 | count
+    {  // long reads: open addressing, entry = (code+1) << 8 | count
 #pragma unroll
       for (int j = 0; j < B; ++j) {
         if (b0 + j < NWIN && b0 + j < nwin) {
@@ -415,8 +511,8 @@ struct ScoreState {
   unsigned long long ph_t;  // phase clock (debug builds)
 };
 
-// rows of the wave's table region a k pass touches (direct bins + the dummy row, or the hash slots)
-template <int K, int SLOTS> struct KRows { static constexpr int v = (K == 2) ? 11 : (K == 3) ? 25 : (K == 4) ? 19 : SLOTS; };
+// rows of the wave's table region a k pass touches (one bin per class, or the hash slots)
+template <int K, int SLOTS> struct KRows { static constexpr int v = (K == 2) ? 10 : (K == 3) ? 24 : (K == 4) ? 18 : SLOTS; };
 
 // The lane's thresholds for its segment length.  The host packs the five k-values of one (row, L) into one
 // 64-bit word (one byte each; L <= 510 and p <= 1 keep them <= 255), so an item needs THREE loads, issued with
@@ -433,13 +529,15 @@ STRL_DEV void load_thr(const uint64_t *thr, int row0, int row1, int L, LaneThr &
 }
 template <int K> STRL_DEV int thr_get(uint64_t w) { return (int)((w >> (8 * (K - 2))) & 0xffu); }
 
+// tables: stage A's u32 tables (k <= 4) or the u16 code tables (k = 5, 6)
 template <int K, int NW, int SLOTS>
-STRL_DEV void score_k(const Seg<NW> &sg, ScoreState &st, uint32_t *wave_tab, int lane, const uint16_t *lut, const LaneThr &t) {
+STRL_DEV void score_k(const Seg<NW> &sg, ScoreState &st, uint32_t *wave_tab, int lane, const void *tables, const LaneThr &t, const LenBounds &lb, uint32_t *bins0) {
   if (!strl_any(st.alive)) return;  // wave-uniform
   if (K <= 4 || NW > 10) clear_rows(wave_tab, lane, KRows<K, SLOTS>::v);   // k = 5,6 of short reads count in registers
   int c;
   uint32_t code;
-  hist_pass<K, NW, SLOTS>(sg, st.alive, wave_tab + lane, lut, c, code);
+  if constexpr (K <= 4) hist_pass_a<K, NW>(sg, st.alive, bins0, (uint32_t)((wave_tab - bins0) + lane) * 4u, static_cast<const uint32_t *>(tables), lb, c, code);
+  else hist_pass<K, NW, SLOTS>(sg, st.alive, wave_tab + lane, static_cast<const uint16_t *>(tables), c, code);
   STRL_PH(st, 2 + 2 * (K - 2));
   if (st.alive) {
     int score = c * K;
@@ -475,19 +573,20 @@ STRL_DEV uint32_t reduce_packed(uint32_t r) {
 //            (~12 % of scored 150 bp reads in the S1 mix; 60 % would survive a cut after k = 3).
 //   stage B: k = 5, 6 from a carried (best, res0, res1).
 template <int NW, int SLOTS>
-STRL_DEV void score_stage_a(const Seg<NW> &sg, bool active, uint32_t *wave_tab, int lane, const uint16_t *lut, const LaneThr &t,
-                            ScoreState &st) {
+STRL_DEV void score_stage_a(const Seg<NW> &sg, bool active, uint32_t *wave_tab, uint32_t *bins0, int lane, const uint32_t *ta, const LaneThr &t,
+                            const LenBounds &lb, ScoreState &st) {
   st.best = -1;
   st.alive = active && sg.n_N <= 20;
   st.res0 = st.res1 = 0;
-  score_k<2, NW, SLOTS>(sg, st, wave_tab, lane, lut, t);
-  score_k<3, NW, SLOTS>(sg, st, wave_tab, lane, lut, t);
-  score_k<4, NW, SLOTS>(sg, st, wave_tab, lane, lut, t);
+  score_k<2, NW, SLOTS>(sg, st, wave_tab, lane, ta, t, lb, bins0);
+  score_k<3, NW, SLOTS>(sg, st, wave_tab, lane, ta, t, lb, bins0);
+  score_k<4, NW, SLOTS>(sg, st, wave_tab, lane, ta, t, lb, bins0);
 }
 template <int NW, int SLOTS>
 STRL_DEV void score_stage_b(const Seg<NW> &sg, uint32_t *wave_tab, int lane, const uint16_t *lut, const LaneThr &t, ScoreState &st) {
-  score_k<5, NW, SLOTS>(sg, st, wave_tab, lane, lut, t);
-  score_k<6, NW, SLOTS>(sg, st, wave_tab, lane, lut, t);
+  const LenBounds lb{0, 0};   // (stage A only)
+  score_k<5, NW, SLOTS>(sg, st, wave_tab, lane, lut, t, lb, nullptr);
+  score_k<6, NW, SLOTS>(sg, st, wave_tab, lane, lut, t, lb, nullptr);
 }
 
 }  // namespace strl

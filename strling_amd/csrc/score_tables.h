@@ -38,6 +38,22 @@ inline void build_lut(std::vector<uint16_t> &lut) {
   }
 }
 
+// stage A's tables (score_core.h TA_*), from the same class ids build_lut assigns
+inline void build_stage_a_tables(const std::vector<uint16_t> &lut, std::vector<uint32_t> &ta) {
+  ta.assign(TA_WORDS, 0);
+  for (uint32_t b = 0; b < 256; ++b) {
+    ta[TA_K2 + b] = (uint32_t)lut[LUT_OFF2 + (b & 15u)] * ROWB | ((uint32_t)lut[LUT_OFF2 + (b >> 4)] * ROWB) << 16;
+    const uint32_t c4 = lut[LUT_OFF4 + b];
+    ta[TA_K4 + b] = (c4 >> 2) * ROWB | (8u * (c4 & 3u)) << 16;
+  }
+  uint8_t *t3 = reinterpret_cast<uint8_t *>(ta.data() + TA_K3);
+  for (uint32_t v = 0; v < 64; ++v) t3[v] = (uint8_t)lut[LUT_OFF3 + v];
+  uint16_t *tc = reinterpret_cast<uint16_t *>(ta.data() + TA_C);
+  for (int i = 0; i < 10; ++i) tc[TaCls<2>::off + i] = lut[LUT_C2 + i];
+  for (int i = 0; i < 24; ++i) tc[TaCls<3>::off + i] = lut[LUT_C3 + i];
+  for (int i = 0; i < 70; ++i) tc[TaCls<4>::off + i] = lut[LUT_C4 + i];
+}
+
 inline void build_thr(const strl_opts &o, std::vector<uint64_t> &thr) {
   thr.assign(4 * THR_LMAX, 0);
   const double p = o.proportion_repeat;

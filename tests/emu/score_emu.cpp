@@ -11,11 +11,11 @@ using namespace strl;
 
 static std::vector<uint16_t> g_lut;
 static std::vector<uint64_t> g_thr;
-static std::vector<uint32_t> g_clut;
+static std::vector<uint32_t> g_clut, g_ta;
 static bool g_last_alive = false;
 
 template <int NW, int SLOTS>
-static void run(const uint8_t *seq4, int s0, int len, int row0, int row1, uint32_t *o0, uint32_t *o1) {
+static void run(const uint8_t *seq4, int s0, int len, int row0, int row1, bool whole, uint32_t *o0, uint32_t *o1) {
   static uint32_t tab[SLOTS + 8];   // SLOTS rows + the dummy row
   constexpr int MAXCH = (16 * NW + 62) / 32;
   const int s0l = s0 & 31;
@@ -23,12 +23,19 @@ static void run(const uint8_t *seq4, int s0, int len, int row0, int row1, uint32
   const uint8_t *src = seq4 + (size_t)(s0 >> 5) * 16;
   for (int c = 0; c < MAXCH && c < nch; ++c) memcpy(&tab[4 * c], src + 16 * c, 16);
   Seg<NW> sg;
-  seg_from_raw<NW>(tab, g_clut.data(), s0l, len, sg);
+  const LenBounds lb = len_bounds(true, len);
+  if (whole && s0 == 0) {   // the whole-read kernel converts straight from the loaded registers
+    uint32_t raw[4 * MAXCH];
+    for (int i = 0; i < 4 * MAXCH; ++i) raw[i] = i < 4 * nch ? tab[i] : 0u;
+    seg_from_words<NW>(raw, g_clut.data(), len, lb, sg);
+  } else {
+    seg_from_raw<NW>(tab, g_clut.data(), s0l, len, sg);
+  }
   // run the two stages the way the kernels do: stage A, hand the state over, re-stage the bases, stage B
   ScoreState st;
   LaneThr lt;
   load_thr(g_thr.data(), row0, row1, len, lt);
-  score_stage_a<NW, SLOTS>(sg, true, tab, 0, g_lut.data(), lt, st);
+  score_stage_a<NW, SLOTS>(sg, true, tab, tab, 0, g_ta.data(), lt, lb, st);
   g_last_alive = st.alive;
   if (st.alive) {
     for (int c = 0; c < MAXCH && c < nch; ++c) memcpy(&tab[4 * c], src + 16 * c, 16);
@@ -48,12 +55,13 @@ void emu_set_p(double p) {
   build_lut(g_lut);
   build_thr(o, g_thr);
   build_conv_lut(g_clut);
+  build_stage_a_tables(g_lut, g_ta);
 }
 // mode 0: whole read (threshold p); mode 1: soft clip (p-0.07 / min(p,0.6)).  seq4 must have 32 B slack.
 void emu_score(const uint8_t *seq4, int s0, int len, int mode, int klass, uint32_t *o0, uint32_t *o1) {
   const int r0 = mode == 0 ? 1 : 2, r1 = mode == 0 ? 1 : 3;
-  if (klass == 0) run<10, 64>(seq4, s0, len, r0, r1, o0, o1);
-  else if (klass == 1) run<16, 128>(seq4, s0, len, r0, r1, o0, o1);
-  else run<32, 256>(seq4, s0, len, r0, r1, o0, o1);
+  if (klass == 0) run<10, 64>(seq4, s0, len, r0, r1, mode == 0, o0, o1);
+  else if (klass == 1) run<16, 128>(seq4, s0, len, r0, r1, mode == 0, o0, o1);
+  else run<32, 256>(seq4, s0, len, r0, r1, mode == 0, o0, o1);
 }
 }
