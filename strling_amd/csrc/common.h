@@ -123,6 +123,7 @@ struct strl_ctx {
   bool have_opts = false;
   strl_opts opts{};
   strl::DevBuf lut;  // uint16[LUT_ENTRIES]
+  strl::DevBuf inv_spill;   // score.hip: Seg::inv of the waves that hold a base that is not ACGT
   strl::DevBuf thr;  // uint16[4][5][512]
   // genome STR intervals, per tid sorted by start, with prefix max of stop
   int32_t n_tid = 0;

@@ -34,6 +34,8 @@ static inline uint32_t strl_max3(uint32_t a, uint32_t b, uint32_t c) { return a 
 static inline uint32_t strl_bfe(uint32_t x, uint32_t off, uint32_t w) { return (x >> off) & ((1u << w) - 1u); }
 static inline uint32_t strl_lds_add(uint32_t *a, uint32_t v) { uint32_t o = *a; *a = o + v; return o; }
 static inline int strl_wave_max(int v) { return v; }
+static inline int strl_rank(bool) { return 0; }
+static inline uint32_t strl_thread_at() { return 0; }
 #else
 #include <hip/hip_runtime.h>
 #define STRL_DEV __device__ __forceinline__
@@ -48,6 +50,10 @@ STRL_DEV int strl_wave_min(int v) {   // wave-uniform minimum (butterfly; once p
   for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o < v ? o : v; }
   return __builtin_amdgcn_readfirstlane(v);
 }
+STRL_DEV int strl_rank(bool p) {   // number of lower lanes with p
+  return __popcll(__ballot(p) & ((1ull << (threadIdx.x & 63)) - 1ull));
+}
+STRL_DEV uint32_t strl_thread_at() { return blockIdx.x * blockDim.x + threadIdx.x; }
 STRL_DEV int strl_wave_max(int v) {
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; }
@@ -141,11 +147,53 @@ STRL_DEV void conv8_lut(uint32_t x, const uint32_t *clut, uint32_t &pairs, uint3
 // One segment in registers.
 template <int NW> struct Seg {
   uint32_t seq[NW];  // 2-bit codes, 16 bases per word, zero beyond len
-  uint32_t inv[NW];  // bit 2i set: base i is not ACGT (never matches a literal unit)
+  // inv word w, bit 2i set: base 16 w + i is not ACGT (never matches a literal unit).  Written and read only by the LANES
+  // that hold such a base (has_inv; a per cent of the reads, but every other WAVE has one), so it does not live in NW
+  // registers -- dead weight for every other lane, and registers are what limits the waves per SIMD here (96 instead of
+  // 106: five waves instead of four).  The first INV_SLOTS such lanes of a wave keep theirs in a small LDS area of the wave,
+  // any further ones in a per-thread column of a global spill array.
+  uint32_t *inv_lds;      // the wave's slots, [INV_SLOTS][NW]                                   (wave-uniform)
+  uint32_t *inv;          // global spill, column of thread t at inv[t + w * inv_stride]           (wave-uniform)
+  uint32_t inv_stride;
+  int inv_slot;           // -1: every base of the segment is one of ACGT
   int len;
   int n_N;
-  bool has_inv;
+  STRL_DEV bool has_inv() const { return inv_slot >= 0; }
 };
+
+constexpr int INV_SLOTS = 16;   // (the benchmark's reads carry a sequencer "N" in one of seven: nine lanes of a wave on average)
+template <int NW> STRL_DEV int inv_store(Seg<NW> &sg, bool flagged, const uint32_t (&fl)[NW]) {   // returns the number of 'N' bases
+  const int rank = strl_rank(flagged);
+  sg.inv_slot = flagged ? rank : -1;
+#if defined(STRL_PHASE_TIMING) && !defined(STRL_EMU)
+  {
+    const unsigned long long bm = __ballot(flagged);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&g_phase[20], (unsigned long long)__popcll(bm)); atomicAdd(&g_phase[21], bm ? 1ull : 0ull); atomicAdd(&g_phase[22], 1ull); }
+  }
+#endif
+  int nn = 0;
+  if (flagged) {
+    if (sg.inv_slot < INV_SLOTS) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sg.inv_lds[sg.inv_slot * NW + w] = fl[w] & 0x55555555u;
+    } else {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sg.inv[strl_thread_at() + (uint32_t)w * sg.inv_stride] = fl[w] & 0x55555555u;
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) nn += strl_popc(fl[w] & 0xAAAAAAAAu);
+  }
+  return nn;
+}
+template <int NW> STRL_DEV void inv_load(const Seg<NW> &sg, uint32_t (&v)[NW]) {
+  if (sg.inv_slot < INV_SLOTS) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v[w] = sg.inv_lds[sg.inv_slot * NW + w];
+  } else {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v[w] = sg.inv[strl_thread_at() + (uint32_t)w * sg.inv_stride];
+  }
+}
 
 // wave-uniform bounds of the segment lengths of the lanes that carry an item (idle lanes: nothing to bound)
 struct LenBounds { int lo, hi; };
@@ -189,17 +237,9 @@ template <int NW, int NRAW> STRL_DEV void seg_from_words(const uint32_t (&raw)[N
     }
     any_f |= fl[w];
   }
-  int nn = 0;
-  if (strl_any(any_f != 0)) {   // rare: no lane of the wave has a base that is not ACGT
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { sg.inv[w] = fl[w] & 0x55555555u; nn += strl_popc(fl[w] & 0xAAAAAAAAu); }
-  } else {
-#pragma unroll
-    for (int w = 0; w < NW; ++w) sg.inv[w] = 0;
-  }
+  const int nn = inv_store<NW>(sg, any_f != 0, fl);
   sg.len = len;
   sg.n_N = nn;
-  sg.has_inv = (any_f & 0x55555555u) != 0;
 }
 
 // Build a Seg from raw BAM-packed dwords staged in this lane's LDS column (`raw[i * STRL_LANES]`
@@ -210,8 +250,7 @@ template <int NW> STRL_DEV void seg_from_raw(const uint32_t *raw, const uint32_t
   conv8_lut(raw[dw0 * STRL_LANES], clut, p, f);
   uint32_t cur = p >> (2 * sh), curf = f >> (2 * sh);
   const int fill = 16 - 2 * sh;
-  uint32_t any_f = 0;
-  int nn = 0;
+  uint32_t any_f = 0, fl[NW];
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
     uint32_t sw = 0, fw = 0;
@@ -233,13 +272,12 @@ template <int NW> STRL_DEV void seg_from_raw(const uint32_t *raw, const uint32_t
       }
     }
     sg.seq[w] = sw;
-    sg.inv[w] = fw & 0x55555555u;
+    fl[w] = fw;
     any_f |= fw;
-    nn += strl_popc(fw & 0xAAAAAAAAu);
   }
+  const int nn = inv_store<NW>(sg, any_f != 0, fl);
   sg.len = len;
   sg.n_N = nn;
-  sg.has_inv = (any_f & 0x55555555u) != 0;
 }
 
 // ---- per-k histogram pass (utils.nim:205-211) ---------------------------------------------------
@@ -293,52 +331,57 @@ STRL_DEV void hist_pass_a(const Seg<NW> &sg, bool active, uint32_t *bins0, uint3
   cmax = 0;
   imax = MASK;
   uint32_t best = 0;
+  auto kc = [](int j) { return (1u << CS) | ((7u - (uint32_t)j) << (CS - 3)); };
+  // table entry of window i (shared by two windows at k = 2; a window past the segment reads zero bases: some valid entry)
+  auto entry = [&](int i) -> uint32_t {
+    if (K == 2) return ta[TA_K2 + ((sg.seq[i >> 3] >> (8 * ((i >> 1) & 3))) & 0xffu)];
+    if (K == 4) return ta[TA_K4 + ((sg.seq[i >> 2] >> (8 * (i & 3))) & 0xffu)];
+    const int bit = 6 * i, w = bit >> 5, sh = bit & 31;
+    const uint32_t lo = sg.seq[w], hi = (w + 1 < NW) ? sg.seq[w + 1] : 0u;
+    return t3[((sh + 6 <= 32) ? (lo >> sh) : strl_funnel_r(lo, hi, sh)) & 63u];
+  };
+  auto entries = [&](int b0, uint32_t (&e)[B]) {
+#pragma unroll
+    for (int j = 0; j < B; ++j) e[j] = (b0 + j >= NWIN) ? 0u : (K == 2 && (j & 1)) ? e[j - 1] : entry(b0 + j);
+  };
+  // count + key of window j of a batch
+  auto count = [&](int j, uint32_t e) -> uint32_t {
+    if (K == 4) {
+      const uint32_t sh = (e >> 16) & 0xffu;
+      uint32_t *bin = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(bins0) + (col_off + (e & 0xffffu)));
+      const uint32_t old = strl_lds_add(bin, 1u << sh);
+      return ((old >> sh) << 24) + (e + kc(j));
+    }
+    const uint32_t at = col_off + (K == 2 ? ((j & 1) ? (e >> 16) : (e & 0xffffu)) : e * ROWB);
+    const uint32_t old = strl_lds_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(bins0) + at), 1u << CS);
+    return old + kc(j) + at;
+  };
+  // The table reads run one batch ahead of the counting (issued before the branches of the batch in hand, so that they
+  // overlap its ds_add round trip): one LDS latency per batch instead of two.
+  uint32_t e[B], en[B];
+  entries(0, en);
 #pragma unroll
   for (int b0 = 0; b0 < NWIN; b0 += B) {
+#pragma unroll
+    for (int j = 0; j < B; ++j) e[j] = en[j];
+    if (b0 + B < NWIN) entries(b0 + B, en);
     if (b0 >= umax) continue;                // wave-uniform (not a `break`: the trip count stays a constant and the loop unrolls)
     uint32_t key[B];
-    auto kc = [](int j) { return (1u << CS) | ((7u - (uint32_t)j) << (CS - 3)); };
-    // window b0 + j of the batch: table entry (shared by two windows at k = 2), then count + key
-    auto entry = [&](int j) -> uint32_t {
-      const int i = b0 + j;
-      if (K == 2) return ta[TA_K2 + ((sg.seq[i >> 3] >> (8 * ((i >> 1) & 3))) & 0xffu)];
-      if (K == 4) return ta[TA_K4 + ((sg.seq[i >> 2] >> (8 * (i & 3))) & 0xffu)];
-      const int bit = 6 * i, w = bit >> 5, sh = bit & 31;
-      const uint32_t lo = sg.seq[w], hi = (w + 1 < NW) ? sg.seq[w + 1] : 0u;
-      return t3[((sh + 6 <= 32) ? (lo >> sh) : strl_funnel_r(lo, hi, sh)) & 63u];
-    };
-    auto count = [&](int j, uint32_t e) -> uint32_t {
-      if (K == 4) {
-        const uint32_t sh = (e >> 16) & 0xffu;
-        uint32_t *bin = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(bins0) + (col_off + (e & 0xffffu)));
-        const uint32_t old = strl_lds_add(bin, 1u << sh);
-        return ((old >> sh) << 24) + (e + kc(j));
-      }
-      const uint32_t at = col_off + (K == 2 ? ((j & 1) ? (e >> 16) : (e & 0xffffu)) : e * ROWB);
-      const uint32_t old = strl_lds_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(bins0) + at), 1u << CS);
-      return old + kc(j) + at;
-    };
     if (b0 + B <= umin && b0 + B <= NWIN) {    // wave-uniform: every lane has all eight windows
-      uint32_t e[B];
-#pragma unroll
-      for (int j = 0; j < B; ++j) e[j] = (K == 2 && (j & 1)) ? e[j - 1] : entry(j);
 #pragma unroll
       for (int j = 0; j < B; ++j) key[j] = count(j, e[j]);
     } else {
-      // two half batches (each with its LDS operations in flight together), the second only if some lane reaches it;
-      // a lane past its own end counts into its bins all the same -- nothing reads them again -- and zeroes its key
+      // two half batches, the second only if some lane reaches it; a lane past its own end counts into its bins all the
+      // same -- nothing reads them again -- and zeroes its key
 #pragma unroll
       for (int h = 0; h < B; h += B / 2) {
-        uint32_t e[B / 2];
 #pragma unroll
         for (int j = 0; j < B / 2; ++j) key[h + j] = 0;
         if (b0 + h < NWIN && b0 + h < umax) {   // wave-uniform
 #pragma unroll
-          for (int j = 0; j < B / 2; ++j) e[j] = (b0 + h + j >= NWIN) ? 0u : (K == 2 && (j & 1)) ? e[j - 1] : entry(h + j);
-#pragma unroll
           for (int j = 0; j < B / 2; ++j)
             if (b0 + h + j < NWIN) {
-              const uint32_t k = count(h + j, e[j]);
+              const uint32_t k = count(h + j, e[h + j]);
               key[h + j] = (b0 + h + j < nwin) ? k : 0u;
             }
         }
@@ -416,6 +459,10 @@ template <int K, int NW> STRL_DEV int recount(const Seg<NW> &sg, uint32_t code) 
   uint32_t acc[NW];
 #pragma unroll
   for (int w = 0; w < NW; ++w) acc[w] = 0;
+  // rare per lane (every other wave though): a non-ACGT base inside the window kills the match.  The words are fetched from
+  // the lane's slot first, so that the round trip runs beside the comparison below.
+  uint32_t iv[NW];
+  if (sg.has_inv()) inv_load<NW>(sg, iv);
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     const uint32_t pat = ((code >> (2 * (K - 1 - j))) & 3u) * 0x55555555u;  // unit base j replicated
@@ -425,12 +472,12 @@ template <int K, int NW> STRL_DEV int recount(const Seg<NW> &sg, uint32_t code) 
       acc[w] |= strl_funnel_r(lo, hi, 2 * j) ^ pat;
     }
   }
-  if (sg.has_inv) {  // rare: a non-ACGT base inside the window kills the match
+  if (sg.has_inv()) {
 #pragma unroll
     for (int j = 0; j < K; ++j) {
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
-        const uint32_t lo = sg.inv[w], hi = (w + 1 < NW) ? sg.inv[w + 1] : 0u;
+        const uint32_t lo = iv[w], hi = (w + 1 < NW) ? iv[w + 1] : 0u;
         acc[w] |= strl_funnel_r(lo, hi, 2 * j);
       }
     }

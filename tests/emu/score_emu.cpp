@@ -23,6 +23,11 @@ static void run(const uint8_t *seq4, int s0, int len, int row0, int row1, bool w
   const uint8_t *src = seq4 + (size_t)(s0 >> 5) * 16;
   for (int c = 0; c < MAXCH && c < nch; ++c) memcpy(&tab[4 * c], src + 16 * c, 16);
   Seg<NW> sg;
+  uint32_t inv_mem[NW];
+  static uint32_t inv_lds[INV_SLOTS * NW];
+  sg.inv_lds = inv_lds;
+  sg.inv = inv_mem;
+  sg.inv_stride = 1;
   const LenBounds lb = len_bounds(true, len);
   if (whole && s0 == 0) {   // the whole-read kernel converts straight from the loaded registers
     uint32_t raw[4 * MAXCH];
@@ -40,6 +45,9 @@ static void run(const uint8_t *seq4, int s0, int len, int row0, int row1, bool w
   if (st.alive) {
     for (int c = 0; c < MAXCH && c < nch; ++c) memcpy(&tab[4 * c], src + 16 * c, 16);
     Seg<NW> sg2;
+    sg2.inv_lds = inv_lds;
+    sg2.inv = inv_mem;
+    sg2.inv_stride = 1;
     seg_from_raw<NW>(tab, g_clut.data(), s0l, len, sg2);
     score_stage_b<NW, SLOTS>(sg2, tab, 0, g_lut.data(), lt, st);
   }

@@ -27,7 +27,11 @@ if __name__ == "__main__":
     import numpy as np, torch
     from strling_amd import api, synth
     L = api.load()
-    rec, g = synth.synth_wgs(2 ** 18, seed=1234, with_qnames=False)
+    if os.environ.get("BENCH_DATA"):      # the generator bench.py uses (a slab of a 30x WGS)
+        n = int(os.environ.get("READS", 2 ** 21))
+        rec, g = synth.synth_wgs_30x(max(1, n // 2 ** 17), 2 ** 16, seed=1234)
+    else:
+        rec, g = synth.synth_wgs(int(os.environ.get("READS", 2 ** 18)), seed=1234, with_qnames=False)
     ctx = api.Context(0); ctx.set_opts(0.8, 40, 350); ctx.set_genome(g)
     soa = api.Soa(rec)
     for rep in range(2):
@@ -37,5 +41,7 @@ if __name__ == "__main__":
         L.strl_debug_phase(ph, 0)
     tot = sum(ph)
     print(f"reads {soa.n} scored {st.n_scored} soft {st.n_soft_items}; total wave-cycles {tot/1e6:.1f} M")
+    print(f"  segments with a base that is not ACGT: {ph[20]} lanes, {ph[21]} of {ph[22]} wave-items")
+    tot = sum(ph[:13])
     for i in range(13):
         print(f"  {NAMES[i]:28s} {ph[i]/1e6:10.2f} M  {100*ph[i]/tot:5.1f} %")
