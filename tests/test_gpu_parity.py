@@ -91,6 +91,38 @@ def test_ragged_lengths_and_edge_cases(ctx, oracle):
     assert soft["res_after"].tolist() == [exp_soft[it][1] for it in items]
 
 
+@pytest.mark.parametrize("frac", [1.0, 0.3])
+def test_reads_with_bases_that_are_not_acgt(ctx, oracle, frac):
+    """The masks of such bases live in per-wave LDS slots (16 lanes) with a global spill behind them: with every read of a
+    wave carrying one, both are in use; the repeats make the literal recount (which the masks feed) decide the result."""
+    rng = np.random.default_rng(23)
+    seqs, cig = [], []
+    n = 6000
+    for i in range(n):
+        L = int(rng.choice([100, 150, 150, 150, 151, 250]))
+        u = "".join(rng.choice(list("ACGT"), int(rng.integers(1, 7))))
+        a = int(rng.integers(0, L))
+        s = list("".join(rng.choice(list("ACGT"), a)) + (u * L)[:L - a])
+        if rng.random() < frac:
+            for _ in range(int(rng.choice([1, 1, 1, 2, 5, 19, 22]))):
+                s[int(rng.integers(0, L))] = str(rng.choice(list("NNNNRYKMSWBDHV")))
+        seqs.append("".join(s))
+        c = int(rng.integers(17, L // 2))
+        cig.append([f"{L}M", f"{c}S{L - c}M", f"{L - c}M{c}S"][int(rng.integers(0, 3))])
+    rec = RecordBatch.from_fields(tid=[0] * n, pos=list(range(100, 100 + n)), mtid=[0] * n, mpos=[5] * n, flag=[99] * n,
+                                  mapq=[60] * n, cigars=cig, seqs=seqs, qnames=[f"r{i}" for i in range(n)])
+    opts = oracle.make_opts(350, 0.8, 40)
+    ctx.set_opts(0.8, 40, 350)
+    ctx.set_genome(None)
+    whole, soft, st = ctx.score_reads(rec)
+    exp_whole, exp_soft = oracle_words(oracle, rec, None, opts)
+    assert np.array_equal(whole, exp_whole), [(seqs[i], unpack_result(whole[i]), unpack_result(exp_whole[i])) for i in np.nonzero(whole != exp_whole)[0][:5]]
+    items = soft_items_expected(rec, exp_whole, 40)
+    assert soft["read_side"].tolist() == [(i << 1) | s for i, s in items]
+    assert soft["res_first"].tolist() == [exp_soft[it][0] for it in items]
+    assert soft["res_after"].tolist() == [exp_soft[it][1] for it in items]
+
+
 def test_fresh_context_without_genome(oracle):
     """no strl_ctx_set_genome at all, and an explicit empty table, on a context that never held one: nothing is skipped"""
     rec, _ = synth.synth_wgs(300, seed=3, contig_len=100_000, n_contigs=2)

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-STRL_LIB=tools/ab/libstrl_phase.so timeout 600 python tools/phase_timing.py 2>&1 | tail -16
+timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "not_acgt or ragged" 2>&1 | grep -v "^$" | tail -8
