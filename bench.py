@@ -210,8 +210,8 @@ def main():
 
     # ---- roofline of the slowest launch -----------------------------------------------------------------------------
     # Algorithmic bytes per launch (DESIGN.md "Kernels"):
-    #   classify   13 B of coordinates read + 4 B written (result word or queue slot) per read
-    #   stage A    16 B queue entry + ceil(L/2) B SEQ read + 4 B result written per item
+    #   classify   13 B of coordinates read + 4 B result word written per read, 4 B id written per kept read
+    #   stage A    4 B id + 16 B row gathered + ceil(L/2) B SEQ read, 16 B queue entry + 4 B result written per item
     #   stage B    32 B item + ceil(L/2) B SEQ + 4 B result per item that reaches k = 5
     #   segments   16 B item + the clipped bases (counted as ceil(L/4) B on average) + 16 B result record
     #   compaction 16 B state read per slot + 32 B item written per survivor; soft items: 1 B flag per slot, 16 B entry
@@ -226,8 +226,8 @@ def main():
     n_items = int(min(item_cap, 2.3 * n_treads + st.n_soft_items * 0.4))
     key_passes = (pos_bits + max(n_tid, 1).bit_length() + 15 + 7) // 8
     alg = {
-        "classify_kernel": 17.0 * n,
-        "score_kernel<whole,A>": (20.0 + seq_b) * st.n_scored,
+        "classify_kernel": 17.0 * n + 4.0 * st.n_scored,          # 13 B read + 4 B written per read, 4 B id per kept read
+        "score_kernel<whole,A>": (40.0 + seq_b) * st.n_scored,     # 4 B id + 16 B row gathered + SEQ + 16 B entry + 4 B result written
         "compact_kernel<whole>": 16.0 * st.n_scored + 32.0 * nbw,
         "score_kernel<whole,B>": (36.0 + seq_b) * nbw,
         "soft_compact_kernel": 1.0 * st.n_scored + 32.0 * st.n_soft_items,

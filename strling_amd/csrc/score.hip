@@ -97,7 +97,8 @@ struct ScoreParams {
   uint32_t *inv_spill;   // [NW][threads of the launch]: Seg::inv of the waves that need it
   const uint64_t *thr;
   uint32_t *whole;
-  uint4 *queue;        // [n]      scoring queue (classify -> stage A, whole reads)
+  uint32_t *queue_id;  // [n]      ids of the reads to score (classify -> stage A)
+  uint4 *queue;        // [n]      their 16-byte entries (stage A, which gathers them -> compaction kernels)
   uint8_t *soft_flag;  // [n]      per scored read: bit 0 / 1 = its left / right clip has to be scored (add_soft gates)
   uint4 *soft_queue;   // [scap]   compacted soft-clip items
   uint4 *sb_state[2];  // dense hand-over of stage A: {best | EMPTY, res0, res1, -} per item
@@ -267,28 +268,10 @@ __global__ __launch_bounds__(256, 4) void classify_kernel(ScoreParams P) {
       if (lane == 0) b = atomicAdd(&P.counters[CNT_QUEUE], cnt);
       b = __shfl(b, 0);
       __builtin_amdgcn_wave_barrier();
-      for (uint32_t i0 = lane; i0 < cnt; i0 += 64 * 4) {   // 4 entries per lane per round: 24 gathers in flight, then 4 stores
-        uint4 e[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t i = i0 + 64u * u;
-          const uint32_t r = i < cnt ? buf[i] : 0u;
-          e[u].x = r;
-          if (P.meta) {            // one 16-byte row = one line per kept read (the five columns below: five)
-            const uint4 m = P.meta[r];
-            e[u].y = m.x; e[u].z = m.y; e[u].w = m.z;
-          } else {
-            e[u].y = P.seq_off[r];
-            e[u].z = (uint32_t)P.l_seq[r] | ((uint32_t)P.clip_l[r] << 16);
-            e[u].w = (uint32_t)P.clip_r[r] | ((uint32_t)P.cig[r] << 16) | ((uint32_t)P.mapq[r] << 24);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t i = i0 + 64u * u;
-          if (i < cnt) P.queue[b + i] = e[u];
-        }
-      }
+      // Only the ids leave this kernel: it is the one launch of the step that HBM bounds, and gathering the kept reads' rows
+      // here (8.5 % of the reads: three quarters of every 64-byte line fetched for nothing) was 160 MB of its 800 MB.
+      // Stage A of the scorer, which integer issue bounds, gathers them beside its arithmetic and writes the entries.
+      for (uint32_t i = lane; i < cnt; i += 64) P.queue_id[b + i] = buf[i];
       __builtin_amdgcn_wave_barrier();
       cnt = 0;
     }
@@ -586,18 +569,37 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? (STAGE == 0 ? S
   uint32_t n_items;
   const uint4 *q;
   if (STAGE == 1) { n_items = P.counters[MODE == 0 ? CNT_SBW : CNT_SBS]; q = P.sb_queue[MODE]; }
-  else if (MODE == 0) { n_items = P.counters[CNT_QUEUE]; q = P.queue; }
+  else if (MODE == 0) { n_items = P.counters[CNT_QUEUE]; q = nullptr; }
   else { n_items = min(P.counters[CNT_SOFT], P.scap); q = P.soft_queue; }
   const uint32_t stride = gridDim.x * BLOCK;
 
-  auto fetch = [&](uint32_t item) {
-    Item<MODE, STAGE> it;
-    it.act = item < n_items;
-    uint4 e = make_uint4(0, 0, 0, 0), x = make_uint4(0, 0, 0, 0);
-    if (it.act) {
-      if (STAGE == 0) e = q[item];
-      else { e = q[2 * (uint64_t)item]; x = q[2 * (uint64_t)item + 1]; }
+  // Whole reads, stage A: the queue holds read ids; the lane gathers its read's row (or the six columns) and leaves the
+  // 16-byte entry in P.queue for the two compaction kernels behind this launch.  The id is loaded one item further ahead.
+  constexpr bool BY_ID = MODE == 0 && STAGE == 0;
+  auto load_id = [&](uint32_t item) -> uint32_t { return (BY_ID && item < n_items) ? P.queue_id[item] : 0u; };
+  // What a fetch leaves in registers is the RAW loaded words; they are unpacked when the item's own iteration starts.
+  // (Unpacking at load time puts an s_waitcnt right behind the load: a gather's full latency at the top of every iteration.)
+  struct Raw { uint4 e, x; };
+  auto fetch = [&](uint32_t item, uint32_t rid) -> Raw {
+    Raw r;
+    r.e = make_uint4(0, 0, 0, 0);
+    r.x = make_uint4(0, 0, 0, 0);
+    if (BY_ID) {       // unconditional (an idle lane reads row 0): a conditional load's result is copied at the join -- a use, a wait
+      const uint4 m = P.meta[rid];
+      r.e = make_uint4(rid, m.x, m.y, m.z);
+      return r;
     }
+    if (item < n_items) {
+      if (BY_ID) { }
+      else if (STAGE == 0) r.e = q[item];
+      else { r.e = q[2 * (uint64_t)item]; r.x = q[2 * (uint64_t)item + 1]; }
+    }
+    return r;
+  };
+  auto unpack = [&](const Raw &r, uint32_t item) {
+    Item<MODE, STAGE> it;
+    const uint4 e = r.e, x = r.x;
+    it.act = item < n_items;
     it.id = e.x; it.seq_off = e.y;
     it.L = (int)(e.z & 0xffffu);
     it.slot = STAGE == 0 ? item : x.x;
@@ -626,10 +628,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? (STAGE == 0 ? S
   };
 
   uint32_t base = blockIdx.x * BLOCK + wave * 64;
-  Item<MODE, STAGE> cur = fetch(base + lane), nxt = fetch(base + stride + lane);
+  Raw cur_r = fetch(base + lane, load_id(base + lane)), nxt_r = fetch(base + stride + lane, load_id(base + stride + lane));
+  uint32_t id2 = load_id(base + 2 * stride + lane);
   Pre pc;
   for (; base < n_items; base += stride) {  // wave-uniform
-    const Item<MODE, STAGE> nn = fetch(base + 2 * stride + lane);
+    const Raw nn_r = fetch(base + 2 * stride + lane, id2);
+    id2 = load_id(base + 3 * stride + lane);
+    const Item<MODE, STAGE> cur = unpack(cur_r, base + lane);
     // The SEQ chunks and thresholds of the item are loaded here, not one item ahead: the 30 registers a prefetched item
     // occupies through the whole ladder cost a wave per SIMD (96 registers: five waves), and five waves hide this
     // latency better than a prefetch under four did (measured: 0.213 -> 0.191 ms for stage A of the whole reads).
@@ -667,6 +672,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? (STAGE == 0 ? S
     if (STAGE == 0) score_stage_a<NW, SLOTS>(sg, cur.act, wave_tab, lds + LUTW, lane, lds, pc.t, lb, st);
     else score_stage_b<NW, SLOTS>(sg, wave_tab, lane, lut, pc.t, st);
 
+    if (BY_ID && cur.act)    // the entry the compaction kernels read (stored here with the item's other results: a store beside the
+                             // gather would wait out its latency, one in front of the SEQ loads would make them wait for it)
+      P.queue[base + lane] = make_uint4(cur.id, cur.seq_off, (uint32_t)cur.L | (cur.cl << 16), cur.cr | (cur.cg << 16) | (cur.mq << 24));
     const bool fwd = STAGE == 0 && cur.act && st.alive;
     const bool fin = cur.act && !fwd;
     const uint32_t o0 = reduce_packed(st.res0), o1 = reduce_packed(st.res1);
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? (STAGE == 0 ? S
       }
     }
     STRL_PH(st, 12);
-    cur = nxt; nxt = nn;
+    cur_r = nxt_r; nxt_r = nn_r;
   }
 }
 
@@ -1042,6 +1050,10 @@ static int bloom_reset(strl_ctx *c, uint64_t n) {
   return STRL_OK;
 }
 
+namespace strl {
+__global__ void meta_rows_kernel(const uint32_t *seq_off, const uint16_t *l_seq, const uint16_t *clip_l, const uint16_t *clip_r, const uint8_t *cig, const uint8_t *mapq,
+                                 uint32_t n, uint4 *out);
+}
 static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, strl_soft_rec *soft, uint64_t soft_cap,
                         uint64_t *n_soft, strl_score_stats *stats, bool sync_counts, const strl_pair_soa *pp = nullptr,
                         bool fresh_bloom = true, bool side_busy_ok = false) {
@@ -1055,6 +1067,7 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   const uint64_t n1 = std::max<uint64_t>(n, 1);
   const uint64_t scap = std::max<uint64_t>(std::min<uint64_t>(soft_cap, 2 * n), 1);
   if ((rc = c->queue.reserve((size_t)n1 * 16))) return rc;
+  if ((rc = c->queue_r.reserve((size_t)n1 * 4))) return rc;
   if ((rc = c->soft_dense.reserve((size_t)n1 + 64))) return rc;
   if ((rc = c->soft_queue.reserve((size_t)scap * 16))) return rc;
   if ((rc = c->sb_state_w.reserve((size_t)n1 * 16))) return rc;
@@ -1067,12 +1080,22 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   P.tid = s->tid; P.pos = s->pos; P.end = s->end; P.seq_off = s->seq_off; P.l_seq = s->l_seq;
   P.clip_l = s->clip_l; P.clip_r = s->clip_r; P.mapq = s->mapq; P.cig = s->cig; P.seq4 = s->seq4;
   P.meta = reinterpret_cast<const uint4 *>(s->meta);
+  if (!P.meta) {   // device-resident columns without the packed rows: stage A gathers rows, so they are built here (a pass over the batch:
+                   // callers that care hand over strl_read_soa.meta)
+    if ((rc = c->st_meta.reserve(std::max<size_t>((size_t)n * 16, 64)))) return rc;
+    if (n) {
+      hipLaunchKernelGGL(strl::meta_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, s->seq_off, s->l_seq, s->clip_l, s->clip_r, s->cig, s->mapq,
+                         (uint32_t)n, c->st_meta.as<uint4>());
+      STRL_HIP(hipGetLastError());
+    }
+    P.meta = c->st_meta.as<uint4>();
+  }
   if (!c->g_tid.p && (rc = strl_ctx_set_genome(c, nullptr))) return rc;   // never set: the empty table
   P.g_tid = c->g_tid.as<TidInfo>(); P.g_bins = c->g_bins.as<uint2>(); P.g_iv = c->g_start.as<int2>();
   P.n_tid = c->n_tid;
   P.lut = c->lut.as<uint16_t>(); P.thr = c->thr.as<uint64_t>();
   P.ta = c->lut.as<uint32_t>() + LUT_DWORDS + 256;
-  P.whole = whole; P.queue = c->queue.as<uint4>(); P.soft_flag = c->soft_dense.as<uint8_t>();
+  P.whole = whole; P.queue = c->queue.as<uint4>(); P.queue_id = c->queue_r.as<uint32_t>(); P.soft_flag = c->soft_dense.as<uint8_t>();
   P.soft_queue = c->soft_queue.as<uint4>();
   P.sb_state[0] = c->sb_state_w.as<uint4>(); P.sb_state[1] = c->sb_state_s.as<uint4>();
   P.sb_queue[0] = c->sb_whole.as<uint4>(); P.sb_queue[1] = c->sb_soft.as<uint4>();
