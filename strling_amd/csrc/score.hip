@@ -647,7 +647,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? (STAGE == 0 ? S
     sg.inv_lds = lds + INV_AT + wave * (INV_SLOTS * NW);
     sg.inv = P.inv_spill;
     sg.inv_stride = gridDim.x * BLOCK;
-    const LenBounds lb = STAGE == 0 ? len_bounds(cur.act, cur.len) : LenBounds{0, 0};
+    const LenBounds lb = len_bounds(cur.act, cur.len);
     if (MODE == 0 && STAGE == 0) {
       // whole reads start on a 16-byte boundary of the SEQ array: converted straight from the prefetched registers
       uint32_t raw[4 * MAXCH];
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? (STAGE == 0 ? S
     }
     STRL_PH(st, 1);
     if (STAGE == 0) score_stage_a<NW, SLOTS>(sg, cur.act, wave_tab, lds + LUTW, lane, lds, pc.t, lb, st);
-    else score_stage_b<NW, SLOTS>(sg, wave_tab, lane, lut, pc.t, st);
+    else score_stage_b<NW, SLOTS>(sg, wave_tab, lane, lut, pc.t, lb, st);
 
     if (BY_ID && cur.act)    // the entry the compaction kernels read (stored here with the item's other results: a store beside the
                              // gather would wait out its latency, one in front of the SEQ loads would make them wait for it)

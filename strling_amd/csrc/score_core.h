@@ -455,7 +455,9 @@ STRL_DEV void hist_pass(const Seg<NW> &sg, bool active, uint32_t *tab, const uin
 }
 
 // ---- greedy non-overlapping literal count of the decoded unit (strutils.count, utils.nim:254) ----
-template <int K, int NW> STRL_DEV int recount(const Seg<NW> &sg, uint32_t code) {
+// lo_len: a wave-uniform lower bound of the lengths of the lanes that call (0: unknown) -- words that lie wholly below it
+// need no end-of-read mask.
+template <int K, int NW> STRL_DEV int recount(const Seg<NW> &sg, uint32_t code, int lo_len) {
   uint32_t acc[NW];
 #pragma unroll
   for (int w = 0; w < NW; ++w) acc[w] = 0;
@@ -487,8 +489,10 @@ template <int K, int NW> STRL_DEV int recount(const Seg<NW> &sg, uint32_t code) 
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
     uint32_t x = ~(acc[w] | (acc[w] >> 1)) & 0x55555555u;
-    const int nv = limit - 16 * w;
-    if (nv < 16) x &= (nv <= 0) ? 0u : ((1u << (2 * nv)) - 1u);
+    if (16 * (w + 1) > lo_len - K + 1) {   // wave-uniform
+      const int nv = limit - 16 * w;
+      if (nv < 16) x &= (nv <= 0) ? 0u : ((1u << (2 * nv)) - 1u);
+    }
     m[w] = x;
   }
   int cnt = 0;
@@ -591,7 +595,13 @@ STRL_DEV void score_k(const Seg<NW> &sg, ScoreState &st, uint32_t *wave_tab, int
     if (score <= st.best) {  // utils.nim:250-253
       if (c < thr_get<K>(t.w12)) st.alive = false;  // break
     } else {
-      c = recount<K, NW>(sg, code);  // utils.nim:254
+#if defined(STRL_PHASE_TIMING) && !defined(STRL_EMU)
+      {
+        const unsigned long long bm = __ballot(true);
+        if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)bm) - 1)) { atomicAdd(&g_phase[23 + 2 * (K - 2) - (K > 4 ? 4 : 0)], 1ull); atomicAdd(&g_phase[24 + 2 * (K - 2) - (K > 4 ? 4 : 0)], (unsigned long long)__popcll(bm)); }
+      }
+#endif
+      c = recount<K, NW>(sg, code, lb.lo == 0x7fffffff ? 0 : lb.lo);  // utils.nim:254
       score = c * K;
       if (score >= st.best) {  // :256
         st.best = score;
@@ -630,8 +640,7 @@ STRL_DEV void score_stage_a(const Seg<NW> &sg, bool active, uint32_t *wave_tab, 
   score_k<4, NW, SLOTS>(sg, st, wave_tab, lane, ta, t, lb, bins0);
 }
 template <int NW, int SLOTS>
-STRL_DEV void score_stage_b(const Seg<NW> &sg, uint32_t *wave_tab, int lane, const uint16_t *lut, const LaneThr &t, ScoreState &st) {
-  const LenBounds lb{0, 0};   // (stage A only)
+STRL_DEV void score_stage_b(const Seg<NW> &sg, uint32_t *wave_tab, int lane, const uint16_t *lut, const LaneThr &t, const LenBounds &lb, ScoreState &st) {
   score_k<5, NW, SLOTS>(sg, st, wave_tab, lane, lut, t, lb, nullptr);
   score_k<6, NW, SLOTS>(sg, st, wave_tab, lane, lut, t, lb, nullptr);
 }

@@ -49,7 +49,7 @@ static void run(const uint8_t *seq4, int s0, int len, int row0, int row1, bool w
     sg2.inv = inv_mem;
     sg2.inv_stride = 1;
     seg_from_raw<NW>(tab, g_clut.data(), s0l, len, sg2);
-    score_stage_b<NW, SLOTS>(sg2, tab, 0, g_lut.data(), lt, st);
+    score_stage_b<NW, SLOTS>(sg2, tab, 0, g_lut.data(), lt, lb, st);
   }
   *o0 = reduce_packed(st.res0);
   *o1 = reduce_packed(st.res1);

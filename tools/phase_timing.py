@@ -42,6 +42,7 @@ if __name__ == "__main__":
     tot = sum(ph)
     print(f"reads {soa.n} scored {st.n_scored} soft {st.n_soft_items}; total wave-cycles {tot/1e6:.1f} M")
     print(f"  segments with a base that is not ACGT: {ph[20]} lanes, {ph[21]} of {ph[22]} wave-items")
+    print("  recount executions (waves, lanes) k2 / k3 / k4 (k5, k6 share the k2 / k3 slots):", [(ph[23 + 2 * i], ph[24 + 2 * i]) for i in range(3)])
     tot = sum(ph[:13])
     for i in range(13):
         print(f"  {NAMES[i]:28s} {ph[i]/1e6:10.2f} M  {100*ph[i]/tot:5.1f} %")
