@@ -722,7 +722,9 @@ template <int NW, int SLOTS, int MODE, int STAGE, int BLOCK> static int launch_s
     attr_done = true;
   }
   ScoreParams Q = P;
-  const size_t spill = (size_t)blocks * BLOCK * NW * 4;       // (grows on the first call of a read-length class only)
+  // sized for the largest grid this class is ever launched with, so that it is allocated once per context and class (an
+  // allocation synchronises the device: in the chunked extract every growing chunk would have paid for it)
+  const size_t spill = (size_t)std::max(blocks, 8192) * BLOCK * NW * 4;
   if (ctx->inv_spill.cap < spill) {
     STRL_HIP(hipStreamSynchronize(ctx->stream));
     int rc = ctx->inv_spill.reserve(spill);
