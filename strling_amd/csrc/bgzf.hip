@@ -104,10 +104,9 @@ __global__ __launch_bounds__(256) void crc32_kernel(const uint8_t *out, const ui
 using namespace strl;
 
 // host: the tables of crc32_kernel (zlib's polynomial 0xedb88320, reflected), made once
-static const CrcTables &crc_tables() {
-  static CrcTables T;
-  static bool done = false;
-  if (!done) {
+static CrcTables make_crc_tables() {
+  CrcTables T;
+  {
     for (uint32_t i = 0; i < 256; ++i) {
       uint32_t c = i;
       for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
@@ -127,8 +126,11 @@ static const CrcTables &crc_tables() {
         for (int j = 0; j < 32; ++j) if ((x >> j) & 1u) r ^= T.zop[8][j];
         T.adv[t][v] = r;
       }
-    done = true;
   }
+  return T;
+}
+static const CrcTables &crc_tables() {
+  static const CrcTables T = make_crc_tables();   // (initialised once, thread-safe: contexts of several feeding threads share it)
   return T;
 }
 

@@ -716,11 +716,9 @@ template <int NW, int SLOTS, int MODE, int STAGE, int BLOCK> static int launch_s
   auto kfn = score_kernel<NW, SLOTS, MODE, STAGE, BLOCK>;
   size_t shmem = (size_t)((STAGE == 0 ? LUT_A_DWORDS : LUT_DWORDS) + 256) * 4 + (size_t)(BLOCK / 64) * (table_rows<NW, SLOTS, STAGE>() * 64 + INV_SLOTS * NW) * 4;
   if (shmem <= 65536) shmem = 0;      // the kernel allocates it statically (see STATIC_LDS there)
-  static bool attr_done = false;
-  if (!attr_done && shmem) {
-    STRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr_done = true;
-  }
+  // (only the long-read classes allocate dynamically; set on every such launch: the attribute belongs to the current DEVICE,
+  // and contexts of one process may sit on different ones)
+  if (shmem) STRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   ScoreParams Q = P;
   // sized for the largest grid this class is ever launched with, so that it is allocated once per context and class (an
   // allocation synchronises the device: in the chunked extract every growing chunk would have paid for it)
