@@ -244,11 +244,17 @@ def main():
         "cluster_sweep": 16.0 * n_treads,
         "cluster_bounds": 8.0 * n_treads + 44.0 * len(bounds),
     }
+    if L <= 160 and not os.environ.get("STRL_SPLIT_SEGMENTS"):
+        # segments of the short-read class: stage A and B in ONE launch (no hand-over, no compaction, one fetch of the bases);
+        # the library reports it in stage A's slot, the two slots behind it hold nothing but the gap between two events
+        ms["score_kernel<segment,A+B>"] = ms.pop("score_kernel<segment,A>") + ms.pop("compact_kernel<segment>") + ms.pop("score_kernel<segment,B>")
+        alg["score_kernel<segment,A+B>"] = alg.pop("score_kernel<segment,A>")      # 16 B item + the clipped bases + 16 B result record
+        alg.pop("compact_kernel<segment>"); alg.pop("score_kernel<segment,B>")
     grouped = ("pair_join_sort", "pair_order", "cluster_keys_sort_groups", "cluster_sweep", "cluster_bounds")   # several launches each
     kernels = {k: (ms[k], alg[k]) for k in ms if k not in grouped}
     groups = {"classify_kernel": ms["classify_kernel"],
               "score_kernel<whole>": ms["score_kernel<whole,A>"] + ms["compact_kernel<whole>"] + ms["score_kernel<whole,B>"],
-              "score_kernel<soft>": ms["soft_compact_kernel"] + ms["score_kernel<segment,A>"] + ms["compact_kernel<segment>"] + ms["score_kernel<segment,B>"],
+              "score_kernel<soft>": ms["soft_compact_kernel"] + sum(v for k, v in ms.items() if "segment" in k),
               "pair_logic": sum(pair_ms.values()), "cluster_pass": sum(cl_ms.values())}
     groups.update({k: ms[k] for k in grouped})
     dom = max(kernels, key=lambda k: kernels[k][0])     # slowest single launch
@@ -258,7 +264,7 @@ def main():
     tj, pick = {}, {}
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")))["kernels"]
-        pick = {"classify_kernel": "classify_kernel", "score_kernel<whole,A>": "<10, 64, 0, 0", "score_kernel<segment,A>": "<10, 64, 1, 0",
+        pick = {"classify_kernel": "classify_kernel", "score_kernel<whole,A>": "<10, 64, 0, 0", "score_kernel<segment,A>": "<10, 64, 1, 0", "score_kernel<segment,A+B>": "<10, 64, 1, 2",
                 "pair_probe_kernel": "pair_probe_kernel", "pair_groups_kernel": "pair_groups_kernel"}
         if dom in pick and n == 2 ** 25 and L == 150:
             traffic = sum(v["hbm_bytes_corrected"] for name, v in tj.items() if pick[dom] in name) or None

@@ -535,6 +535,8 @@ template <int MODE, int STAGE> struct Item {
   bool act;
 };
 
+// STAGE 2 (segments of the short-read class): both stages in one launch -- 98 % of the clipped ends reach k = 5 anyway, so the
+//          hand-over, the compaction and the second fetch + conversion of the segment buy nothing there.
 // STAGE 0: k = 2..4 on queued items; a lane whose ladder goes on leaves (best, res0, res1) in the dense
 //          hand-over array.  STAGE 1: k = 5, 6 on the compacted survivors.  Whoever finishes an item writes its
 //          result and the item's two soft-clip slots.  The loop is software-pipelined: while item i runs
@@ -545,21 +547,29 @@ template <int MODE, int STAGE> struct Item {
 #endif
 template <int NW, int SLOTS, int MODE, int STAGE, int BLOCK>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? (STAGE == 0 ? STRL_SCORE_OCC : 4) : 1) void score_kernel(ScoreParams P) {
-  constexpr int LUTK = STAGE == 0 ? LUT_A_DWORDS : LUT_DWORDS;   // k-mer tables this stage looks up
+  constexpr int L56 = (LUT_ENTRIES - LUT_OFF5) / 2;                                                // dwords of the k = 5, 6 code tables
+  constexpr int LUTK = STAGE == 0 ? LUT_A_DWORDS : STAGE == 1 ? LUT_DWORDS : LUT_A_DWORDS + L56;   // k-mer tables this stage looks up
   constexpr int LUTW = LUTK + 256;                                  // + the byte -> 2-bit conversion table
+  constexpr int NSLOT = STAGE == 2 ? INV_SLOTS / 2 : INV_SLOTS;     // (the fused kernel's four blocks must fit a CU's LDS)
   // Statically sized LDS where it fits the 64 KB a static allocation may have: the tables then sit at compile-time
   // addresses that fold into the ds_* offset fields (with a dynamic allocation every table access paid a `v_add 0` for
   // the unknown base: ~100 VALU instructions per read in a kernel that is bound by exactly those).
   constexpr int INV_AT = LUTW + (BLOCK / 64) * table_rows<NW, SLOTS, STAGE>() * 64;   // Seg::inv_lds of the block's waves
-  constexpr int LDS_WORDS = INV_AT + (BLOCK / 64) * INV_SLOTS * NW;
+  constexpr int LDS_WORDS = INV_AT + (BLOCK / 64) * NSLOT * NW;
   constexpr bool STATIC_LDS = (size_t)LDS_WORDS * 4 <= 65536;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   __shared__ __attribute__((aligned(16))) uint32_t lds_st[STATIC_LDS ? LDS_WORDS : 4];
   uint32_t *const lds = STATIC_LDS ? lds_st : lds_dyn;
-  for (int i = threadIdx.x; i < LUTK; i += BLOCK) lds[i] = STAGE == 0 ? P.ta[i] : reinterpret_cast<const uint32_t *>(P.lut)[i];
+  if (STAGE == 2) {
+    for (int i = threadIdx.x; i < LUT_A_DWORDS; i += BLOCK) lds[i] = P.ta[i];
+    for (int i = threadIdx.x; i < L56; i += BLOCK) lds[LUT_A_DWORDS + i] = reinterpret_cast<const uint32_t *>(P.lut)[LUT_OFF5 / 2 + i];
+  } else {
+    for (int i = threadIdx.x; i < LUTK; i += BLOCK) lds[i] = STAGE == 0 ? P.ta[i] : reinterpret_cast<const uint32_t *>(P.lut)[i];
+  }
   for (int i = threadIdx.x; i < 256; i += BLOCK) lds[LUTK + i] = reinterpret_cast<const uint32_t *>(P.lut)[LUT_DWORDS + i];
   __syncthreads();
-  const uint16_t *lut = reinterpret_cast<const uint16_t *>(lds);
+  // (stage B indexes `lut + LutOff<5 | 6>`: in the fused kernel only those two tables are resident, behind stage A's)
+  const uint16_t *lut = STAGE == 2 ? reinterpret_cast<const uint16_t *>(lds + LUT_A_DWORDS) - LUT_OFF5 : reinterpret_cast<const uint16_t *>(lds);
   const uint32_t *clut = lds + LUTK;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t *wave_tab = lds + LUTW + wave * (table_rows<NW, SLOTS, STAGE>() * 64);
@@ -591,7 +601,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? (STAGE == 0 ? S
     }
     if (item < n_items) {
       if (BY_ID) { }
-      else if (STAGE == 0) r.e = q[item];
+      else if (STAGE != 1) r.e = q[item];
       else { r.e = q[2 * (uint64_t)item]; r.x = q[2 * (uint64_t)item + 1]; }
     }
     return r;
@@ -602,8 +612,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? (STAGE == 0 ? S
     it.act = item < n_items;
     it.id = e.x; it.seq_off = e.y;
     it.L = (int)(e.z & 0xffffu);
-    it.slot = STAGE == 0 ? item : x.x;
-    it.best = STAGE == 0 ? -1 : (int)x.y;
+    it.slot = STAGE != 1 ? item : x.x;
+    it.best = STAGE != 1 ? -1 : (int)x.y;
     it.res0 = x.z; it.res1 = x.w;
     if (MODE == 0) {
       it.cl = e.z >> 16; it.cr = e.w & 0xffffu; it.cg = (e.w >> 16) & 0xffu; it.mq = e.w >> 24;
@@ -644,7 +654,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? (STAGE == 0 ? S
     st.best = cur.best; st.alive = STAGE == 1 && cur.act; st.res0 = cur.res0; st.res1 = cur.res1;
     st.ph_t = __builtin_readcyclecounter();
     Seg<NW> sg;
-    sg.inv_lds = lds + INV_AT + wave * (INV_SLOTS * NW);
+    sg.inv_lds = lds + INV_AT + wave * (NSLOT * NW);
+    sg.inv_nslots = NSLOT;
     sg.inv = P.inv_spill;
     sg.inv_stride = gridDim.x * BLOCK;
     const LenBounds lb = len_bounds(cur.act, cur.len);
@@ -669,8 +680,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? (STAGE == 0 ? S
       seg_from_raw<NW>(col, clut, cur.s0 & 31, cur.len, sg);
     }
     STRL_PH(st, 1);
-    if (STAGE == 0) score_stage_a<NW, SLOTS>(sg, cur.act, wave_tab, lds + LUTW, lane, lds, pc.t, lb, st);
-    else score_stage_b<NW, SLOTS>(sg, wave_tab, lane, lut, pc.t, lb, st);
+    if (STAGE != 1) score_stage_a<NW, SLOTS>(sg, cur.act, wave_tab, lds + LUTW, lane, lds, pc.t, lb, st);
+    if (STAGE != 0) score_stage_b<NW, SLOTS>(sg, wave_tab, lane, lut, pc.t, lb, st);
 
     if (BY_ID && cur.act)    // the entry the compaction kernels read (stored here with the item's other results: a store beside the
                              // gather would wait out its latency, one in front of the SEQ loads would make them wait for it)
@@ -714,7 +725,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? (STAGE == 0 ? S
 // ---- host side of this translation unit -------------------------------------------------------
 template <int NW, int SLOTS, int MODE, int STAGE, int BLOCK> static int launch_score(strl_ctx *ctx, const ScoreParams &P, int blocks) {
   auto kfn = score_kernel<NW, SLOTS, MODE, STAGE, BLOCK>;
-  size_t shmem = (size_t)((STAGE == 0 ? LUT_A_DWORDS : LUT_DWORDS) + 256) * 4 + (size_t)(BLOCK / 64) * (table_rows<NW, SLOTS, STAGE>() * 64 + INV_SLOTS * NW) * 4;
+  size_t shmem = (size_t)((STAGE == 0 ? LUT_A_DWORDS : STAGE == 1 ? LUT_DWORDS : LUT_A_DWORDS + (LUT_ENTRIES - LUT_OFF5) / 2) + 256) * 4 +
+                 (size_t)(BLOCK / 64) * (table_rows<NW, SLOTS, STAGE>() * 64 + (STAGE == 2 ? INV_SLOTS / 2 : INV_SLOTS) * NW) * 4;
   if (shmem <= 65536) shmem = 0;      // the kernel allocates it statically (see STATIC_LDS there)
   // (only the long-read classes allocate dynamically; set on every such launch: the attribute belongs to the current DEVICE,
   // and contexts of one process may sit on different ones)
@@ -746,6 +758,14 @@ template <int MODE> static int launch_score_class(strl_ctx *ctx, const ScorePara
   static const int env_a = getenv("STRL_GRID_A") ? atoi(getenv("STRL_GRID_A")) : 0, env_b = getenv("STRL_GRID_B") ? atoi(getenv("STRL_GRID_B")) : 0;
   const int ga = env_a > 0 ? env_a : (int)std::min<uint64_t>(8192, std::max<uint64_t>(256, (upper + 255) / 256));
   const int gb = env_b > 0 ? env_b : std::max(256, ga / 2);
+  static const bool split_segments = getenv("STRL_SPLIT_SEGMENTS") != nullptr;
+  if constexpr (MODE == 1) {
+    if (max_l <= 160 && !split_segments) {        // segments of the short-read class: one fused launch
+      if ((rc = launch_score<10, 64, MODE, 2, 256>(ctx, P, ga))) return rc;
+      if (ev) { STRL_HIP(hipEventRecord(ev[0], ctx->stream)); STRL_HIP(hipEventRecord(ev[1], ctx->stream)); }
+      return STRL_OK;
+    }
+  }
   if (max_l <= 160) rc = launch_score<10, 64, MODE, 0, 256>(ctx, P, ga);
   else if (max_l <= 256) rc = launch_score<16, 128, MODE, 0, 256>(ctx, P, std::max(256, ga / 4));
   else rc = launch_score<32, 256, MODE, 0, 64>(ctx, P, std::max(512, ga / 2));

@@ -155,6 +155,7 @@ template <int NW> struct Seg {
   uint32_t *inv_lds;      // the wave's slots, [INV_SLOTS][NW]                                   (wave-uniform)
   uint32_t *inv;          // global spill, column of thread t at inv[t + w * inv_stride]           (wave-uniform)
   uint32_t inv_stride;
+  int inv_nslots;         // LDS slots of the wave (<= INV_SLOTS)                                  (wave-uniform)
   int inv_slot;           // -1: every base of the segment is one of ACGT
   int len;
   int n_N;
@@ -173,7 +174,7 @@ template <int NW> STRL_DEV int inv_store(Seg<NW> &sg, bool flagged, const uint32
 #endif
   int nn = 0;
   if (flagged) {
-    if (sg.inv_slot < INV_SLOTS) {
+    if (sg.inv_slot < sg.inv_nslots) {
 #pragma unroll
       for (int w = 0; w < NW; ++w) sg.inv_lds[sg.inv_slot * NW + w] = fl[w] & 0x55555555u;
     } else {
@@ -186,7 +187,7 @@ template <int NW> STRL_DEV int inv_store(Seg<NW> &sg, bool flagged, const uint32
   return nn;
 }
 template <int NW> STRL_DEV void inv_load(const Seg<NW> &sg, uint32_t (&v)[NW]) {
-  if (sg.inv_slot < INV_SLOTS) {
+  if (sg.inv_slot < sg.inv_nslots) {
 #pragma unroll
     for (int w = 0; w < NW; ++w) v[w] = sg.inv_lds[sg.inv_slot * NW + w];
   } else {

@@ -28,6 +28,7 @@ static void run(const uint8_t *seq4, int s0, int len, int row0, int row1, bool w
   sg.inv_lds = inv_lds;
   sg.inv = inv_mem;
   sg.inv_stride = 1;
+  sg.inv_nslots = INV_SLOTS;
   const LenBounds lb = len_bounds(true, len);
   if (whole && s0 == 0) {   // the whole-read kernel converts straight from the loaded registers
     uint32_t raw[4 * MAXCH];
@@ -48,6 +49,7 @@ static void run(const uint8_t *seq4, int s0, int len, int row0, int row1, bool w
     sg2.inv_lds = inv_lds;
     sg2.inv = inv_mem;
     sg2.inv_stride = 1;
+    sg2.inv_nslots = INV_SLOTS;
     seg_from_raw<NW>(tab, g_clut.data(), s0l, len, sg2);
     score_stage_b<NW, SLOTS>(sg2, tab, 0, g_lut.data(), lt, lb, st);
   }
