@@ -3,7 +3,7 @@
 // (~16 Ki blocks, ~1 GB inflated) goes through
 //   inflate_kernel   (bgzf.hip)      one wave per BGZF block
 //   carry_kernel                     the partial record the previous chunk ended in is copied in front of this chunk's bytes
-//   rec_guess_kernel                 one lane per 16 KiB segment: first offset from which a chain of plausible BAM records runs
+//   rec_guess_kernel                 one wave per 16 KiB segment: first offset from which a chain of plausible BAM records runs
 //   rec_walk_kernel                  one lane per segment: follow block_size from the segment's (guessed) start to its end:
 //                                    record count, SEQ / qname byte sums, where the chain leaves the segment
 //   rec_link_kernel                  one block: every walk must arrive EXACTLY at the next segment's guessed start (checked in
@@ -95,32 +95,40 @@ __global__ void carry_stage_kernel(const uint8_t *stage, uint32_t stage_len, uin
   }
 }
 
-__global__ __launch_bounds__(64) void rec_guess_kernel(const uint8_t *U, const FrontInfo *info, FrontSeg *seg, uint32_t n_seg, int32_t n_ref) {
-  const uint32_t s = blockIdx.x * 64u + threadIdx.x;
+// One WAVE per segment: the 64 lanes test 64 consecutive candidate offsets at a time (a cheap range test of block_size, which
+// 98 % of the candidates fail, then the chain of four plausible records) and the lowest one that passes is the guess -- the
+// same answer as a lane scanning the segment byte by byte, in two or three rounds instead of ~150 dependent steps.
+__global__ __launch_bounds__(256) void rec_guess_kernel(const uint8_t *U, const FrontInfo *info, FrontSeg *seg, uint32_t n_seg, int32_t n_ref) {
+  const uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   if (s >= n_seg) return;
   const uint32_t start0 = info->start0, end = info->end, s0 = start0 / FRONT_SEG;
   uint32_t g = FRONT_NONE;
   if (s > s0) {
     const uint64_t from = (uint64_t)s * FRONT_SEG, lim = min((uint64_t)end, from + FRONT_SEG);
-    for (uint64_t o = from; o < lim && g == FRONT_NONE; ++o) {
-      // cheap first test on the candidate's block_size before the full chain
-      if (o + 36 > end) break;
-      const uint32_t bs = ld32u(U + o);
-      if (bs < 32u || bs > (1u << 26)) continue;
-      uint64_t c = o, nx = 0;
-      int n_ok = 0;
-      bool good = true;
-      while (n_ok < 4) {
-        const int r = rec_plausible(U, c, end, n_ref, nx);
-        if (r == 0) { good = false; break; }
-        if (r < 0) { good = n_ok >= 1; break; }     // ran into the end of the data: one whole plausible record is all there is
-        ++n_ok;
-        c = nx;
+    for (uint64_t o0 = from; o0 < lim; o0 += 64) {      // wave-uniform
+      const uint64_t o = o0 + lane;
+      bool good = false;
+      if (o < lim && o + 36 <= end) {
+        const uint32_t bs = ld32u(U + o);
+        if (!(bs < 32u || bs > (1u << 26))) {
+          uint64_t c = o, nx = 0;
+          int n_ok = 0;
+          good = true;
+          while (n_ok < 4) {
+            const int r = rec_plausible(U, c, end, n_ref, nx);
+            if (r == 0) { good = false; break; }
+            if (r < 0) { good = n_ok >= 1; break; }     // ran into the end of the data: one whole plausible record is all there is
+            ++n_ok;
+            c = nx;
+          }
+        }
       }
-      if (good) g = (uint32_t)o;
+      const unsigned long long m = __ballot(good);
+      if (m) { g = (uint32_t)(o0 + (uint64_t)(__ffsll((long long)m) - 1)); break; }
+      if (o0 + 64 + 36 > end) break;                    // (the sequential scan stops at the first offset too close to the end)
     }
   }
-  seg[s].guess = g;
+  if (lane == 0) seg[s].guess = g;
 }
 
 __global__ __launch_bounds__(64) void rec_walk_kernel(const uint8_t *U, const FrontInfo *info, FrontSeg *seg, uint32_t n_seg) {
@@ -506,7 +514,7 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
     STRL_HIP(hipGetLastError());
   }
   const unsigned gb = (n_seg + 63) / 64;
-  hipLaunchKernelGGL(rec_guess_kernel, dim3(gb), dim3(64), 0, st, S.infl.as<uint8_t>(), info, S.seg.as<FrontSeg>(), n_seg, (int32_t)F->n_ref);
+  hipLaunchKernelGGL(rec_guess_kernel, dim3((n_seg + 3) / 4), dim3(256), 0, st, S.infl.as<uint8_t>(), info, S.seg.as<FrontSeg>(), n_seg, (int32_t)F->n_ref);
   STRL_HIP(hipGetLastError());
   hipLaunchKernelGGL(rec_walk_kernel, dim3(gb), dim3(64), 0, st, S.infl.as<uint8_t>(), info, S.seg.as<FrontSeg>(), n_seg);
   STRL_HIP(hipGetLastError());
