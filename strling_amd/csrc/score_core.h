@@ -135,10 +135,16 @@ STRL_HD void conv8(uint32_t x, uint32_t &pairs, uint32_t &flags) {
   }
 }
 
+// The table below is indexed by a SWIZZLED byte, b ^ ((b >> 3) & 0x1f) (a bijection on bytes; four bytes of a dword at once:
+// x ^ ((x >> 3) & 0x1f1f1f1f)): the sixteen byte values two ACGT bases can take -- 0x11 ... 0x88, nearly every lookup -- fall
+// into banks 1, 2, 4, 8 three times over when the byte itself is the index; swizzled they hit sixteen different banks.
+STRL_HD uint32_t conv_swizzle(uint32_t x) { return x ^ ((x >> 3) & 0x1f1f1f1fu); }
+
 // Same conversion through a 256-entry table indexed by one BAM byte (two bases): entry bits 0-3 = the two 2-bit
 // codes, bits 16-19 = their flag pairs.  Four lookups + three shift-ors replace ~35 bit-trick ops per dword, and
 // the integer VALU is the binding resource of the scorer.  (conv8 above stays as the table's specification.)
 STRL_DEV void conv8_lut(uint32_t x, const uint32_t *clut, uint32_t &pairs, uint32_t &flags) {
+  x = conv_swizzle(x);
   const uint32_t r = clut[x & 0xffu] | (clut[(x >> 8) & 0xffu] << 4) | (clut[(x >> 16) & 0xffu] << 8) | (clut[x >> 24] << 12);
   pairs = r & 0xffffu;
   flags = r >> 16;
@@ -221,7 +227,7 @@ template <int NW, int NRAW> STRL_DEV void seg_from_words(const uint32_t (&raw)[N
     if (h && 16 * w0 >= lb.hi) continue;   // wave-uniform
 #pragma unroll
     for (int w = w0; w < w1; ++w) {
-      const uint32_t a = raw[2 * w], b = raw[2 * w + 1];
+      const uint32_t a = conv_swizzle(raw[2 * w]), b = conv_swizzle(raw[2 * w + 1]);
       const uint32_t ra = clut[a & 0xffu] | (clut[(a >> 8) & 0xffu] << 4) | (clut[(a >> 16) & 0xffu] << 8) | (clut[a >> 24] << 12);
       const uint32_t rb = clut[b & 0xffu] | (clut[(b >> 8) & 0xffu] << 4) | (clut[(b >> 16) & 0xffu] << 8) | (clut[b >> 24] << 12);
       sg.seq[w] = (ra & 0xffffu) | (rb << 16);

@@ -77,7 +77,7 @@ inline void build_conv_lut(std::vector<uint32_t> &t) {
   for (uint32_t b = 0; b < 256; ++b) {
     uint32_t pairs, flags;
     conv8(b, pairs, flags);          // the byte sits in the low byte of the dword: bases 0 and 1
-    t[b] = (pairs & 0xfu) | ((flags & 0xfu) << 16);
+    t[conv_swizzle(b) & 0xffu] = (pairs & 0xfu) | ((flags & 0xfu) << 16);     // (indexed by the swizzled byte: score_core.h)
   }
 }
 

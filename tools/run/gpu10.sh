@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_index.py tests/test_product_kats.py tests/test_front_device.py -x -q -m gpu 2>&1 | grep -v "^$" | grep -i "passed\|failed\|error" | tail -3
-timeout 300 python tests/fuzz/fuzz_parity.py 60 2>&1 | tail -1
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_index.py tests/test_product_kats.py -x -q -m gpu 2>&1 | grep -v "^$" | grep -i "passed\|failed\|error" | tail -3
 bash tools/run/ab.sh tools/ab/lib_cur.so strling_amd/lib/libstrling_amd.so
