@@ -45,20 +45,26 @@ STRL_DEV uint32_t strl_funnel_r(uint32_t lo, uint32_t hi, uint32_t s) { return _
 STRL_DEV int strl_ffs(uint32_t x) { return __ffs((int)x); }
 STRL_DEV int strl_popc(uint32_t x) { return __popc(x); }
 STRL_DEV bool strl_any(bool p) { return __any(p) != 0; }
-STRL_DEV int strl_wave_min(int v) {   // wave-uniform minimum (butterfly; once per k pass)
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o < v ? o : v; }
-  return __builtin_amdgcn_readfirstlane(v);
+// Wave-uniform minimum / maximum, in converged code (every lane of the wave active).  Six DPP-modified min / max instructions
+// (pairs, quads, mirrored halves of 8 and 16 lanes, then lane 15 / 31 broadcast into the next rows) leave the result in lane 63;
+// the __shfl_xor butterfly is six ds_bpermute round trips through the LDS, each waited for.
+template <bool MIN> STRL_DEV int strl_wave_red(int v) {
+  auto op = [](int a, int b) { return MIN ? (a < b ? a : b) : (a > b ? a : b); };
+  const int idn = MIN ? 0x7fffffff : (int)0x80000000;
+  v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x140, 0xf, 0xf, false));   // row_mirror
+  v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
+  v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
 }
+STRL_DEV int strl_wave_min(int v) { return strl_wave_red<true>(v); }
 STRL_DEV int strl_rank(bool p) {   // number of lower lanes with p
   return __popcll(__ballot(p) & ((1ull << (threadIdx.x & 63)) - 1ull));
 }
 STRL_DEV uint32_t strl_thread_at() { return blockIdx.x * blockDim.x + threadIdx.x; }
-STRL_DEV int strl_wave_max(int v) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; }
-  return __builtin_amdgcn_readfirstlane(v);
-}
+STRL_DEV int strl_wave_max(int v) { return strl_wave_red<false>(v); }
 STRL_DEV uint32_t strl_max3(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }   // v_max3_u32
 STRL_DEV uint32_t strl_bfe(uint32_t x, uint32_t off, uint32_t w) { return __builtin_amdgcn_ubfe(x, off, w); }
 STRL_DEV uint32_t strl_lds_add(uint32_t *a, uint32_t v) { return atomicAdd(a, v); }  // lane-private: ds_add_rtn_u32
