@@ -471,3 +471,28 @@ def test_chunked_extract_matches_oracle(ctx, oracle, cuts):
     ok, why = treads_equal(got, exp)
     assert ok and len(exp) > 300, why
     assert st.n_reads == rec.n and st.n_scored + st.n_skipped == rec.n
+
+
+def test_segment_scorer_fused_and_split_launches_agree(tmp_path):
+    """Soft-clip segments of the short-read class are scored by ONE launch (both stages); STRL_SPLIT_SEGMENTS=1 selects the three
+    launches (stage A, survivor compaction, stage B) the long-read classes still use.  Same records out of both, in a
+    process each (the switch is read once)."""
+    import subprocess, sys
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from strling_amd import api, synth\n"
+        "rec, g = synth.synth_wgs(20000, seed=77, contig_len=3_000_000)\n"
+        "c = api.Context(0); c.set_opts(0.8, 40, 350); c.set_genome(g)\n"
+        "whole, soft, st = c.score_reads(rec)\n"
+        "np.save(sys.argv[1] + '_w.npy', whole); np.save(sys.argv[1] + '_s.npy', soft)\n"
+    ) % os.path.dirname(HERE)
+    outs = []
+    for name, env in (("fused", {}), ("split", {"STRL_SPLIT_SEGMENTS": "1"})):
+        base = str(tmp_path / name)
+        e = dict(os.environ, **env)
+        e.pop("STRL_SPLIT_SEGMENTS", None) if not env else None
+        subprocess.run([sys.executable, "-c", script, base], check=True, env=e)
+        outs.append((np.load(base + "_w.npy"), np.load(base + "_s.npy")))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert len(outs[0][1]) > 100 and outs[0][1].tobytes() == outs[1][1].tobytes()
