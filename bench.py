@@ -45,6 +45,16 @@ def main():
     ap.add_argument("--cache", default="", help="directory to keep the generated batch in (profiling runs reload it instead of forking generators)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: become N ranks (one per GPU) under torch.distributed.run, the launch the
+        # driver's own N > 1 command makes.  exec: the ranks' single JSON line is this process' output.
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        sys.stdout.flush()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -80,10 +90,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    local = local % torch.cuda.device_count()       # (a 2-rank dry run on a 1-GPU box maps both ranks to cuda:0)
+    n_dev = torch.cuda.device_count()
+    shared_device = world > n_dev                   # more ranks than GPUs (a 2-rank dry run on a 1-GPU box): ranks share devices
+    local = local % n_dev
     torch.cuda.set_device(local)
+    backend = None
     if world > 1:
-        backend = os.environ.get("BENCH_BACKEND", "nccl")   # nccl == RCCL on ROCm; gloo only for dry runs of the N > 1 path
+        # nccl == RCCL on ROCm.  RCCL refuses two ranks on one device, so ranks that share a device rendezvous over gloo and
+        # exchange through the host: a dry run of the N > 1 code path, not a measurement of the collective
+        backend = os.environ.get("BENCH_BACKEND", "gloo" if shared_device else "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -127,12 +142,21 @@ def main():
     treads, st = ctx.treads_fetch()
     n_treads = int(treads.size)
 
+    def agree(flag):
+        """min over the ranks of a host-side flag (a CPU tensor under gloo, a device tensor under nccl)"""
+        t = torch.tensor([int(flag)], device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item())
+
     exchange = None
     if world > 1:
         from strling_amd import dist as sdist
         # the collective inside the library (comm.hip: ncclAllGather on the tail's stream, the entry point the CLI's --gpus N
-        # uses too); STRL_TORCH_COMM=1, or a failure here, keeps torch.distributed's all_gather_into_tensor
-        for cls in ([] if os.environ.get("STRL_TORCH_COMM") else [sdist.NativeClusterExchange]) + [sdist.DeviceClusterExchange]:
+        # uses too); STRL_TORCH_COMM=1, or ranks that share a device, keep torch.distributed's all_gather_into_tensor.
+        # ncclCommInitRank is itself a collective: a rank that cannot take part would leave the others hanging inside it, so
+        # the ranks agree on every precondition BEFORE anybody calls it (round-3 advisor finding).
+        native_ok = agree(backend == "nccl" and not shared_device and not os.environ.get("STRL_TORCH_COMM") and hasattr(ctx, "comm_init"))
+        for cls in ([sdist.NativeClusterExchange] if native_ok else []) + [sdist.DeviceClusterExchange]:
             try:
                 exchange = cls(ctx, world, rank, n_treads, dev)
                 exchange.step(n_tid * 1, window, 5, max_clip_dist, pos_bits)
@@ -141,14 +165,10 @@ def main():
             except Exception as e:                    # keep the shard-only measurement if the collective is unavailable
                 print(f"[bench] rank {rank}: {cls.__name__} unavailable: {e}", file=sys.stderr)
                 exchange, ok1 = None, 0
-            ok_all = torch.tensor([ok1], device=dev)
-            dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)      # all ranks must take the same path
-            if int(ok_all.item()) == 1:
+            if agree(ok1) == 1:                       # all ranks must take the same path
                 break
             exchange = None
-        ok = torch.tensor([1 if exchange is not None else 0], device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)     # all ranks must agree, or the collective would hang
-        if int(ok.item()) == 0:
+        if agree(exchange is not None) == 0:          # all ranks must agree, or the collective would hang
             exchange = None
 
     def step():
@@ -187,7 +207,7 @@ def main():
         if not verified:
             raise SystemExit("bench.py: the pipelined steps did not reproduce the synchronous pass' treads / bounds")
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -347,6 +367,8 @@ def main():
             "value": round(total_reads / el, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32 integer", "data": "synthetic",
+            "exchange": "none" if exchange is None else ("native" if type(exchange).__name__ == "NativeClusterExchange" else "torch"),
+            "rccl_ranks": world if (exchange is not None and backend == "nccl") else 0, "backend": backend, "devices_visible": n_dev,
             "config": {"workload": f"{world}xMI355X: 30x 150 bp PE synthetic WGS, k=2-6 repeat-unit scorer + soft-clip scan + device pair logic + on-GPU radix-sort/segmented clustering (BASELINE.json configs[1]+[2])",
                        "reads_per_gpu": n, "read_len": L, "unique_reads_per_gpu": n, "tiles": 1, "generate_s": round(t_gen, 1),
                        "skipped_frac": round(st.n_skipped / n, 4), "scored_reads": int(st.n_scored), "soft_items": int(st.n_soft_items),

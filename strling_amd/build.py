@@ -32,21 +32,49 @@ def _stale(target, srcs):
     return any(os.path.exists(s) and os.path.getmtime(s) > t for s in srcs)
 
 
+def _compile_objects(names, objdir, deps_common, force, verbose):
+    """one hipcc -c per translation unit, stale ones only, side by side (the kernels are independent TUs: no -fgpu-rdc)"""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+    objs, jobs = [], []
+    for s in names:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace("/", "_") + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + deps_common):
+            cmd = [hipcc] + FLAGS + ["-c", "-o", obj, src]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 2)) as ex:
+            list(ex.map(run, jobs))
+    return objs, bool(jobs)
+
+
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
-    if force or _stale(LIB, deps):
-        cmd = [_hipcc()] + FLAGS + ["-shared", "-o", LIB] + srcs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    objdir = os.path.join(LIBDIR, "obj")
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs, fresh = _compile_objects([s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))], objdir, hdrs, force, verbose)
+    if fresh or force or _stale(LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]   # RCCL is bound at first use (comm.hip)
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=CSRC)
     cli_srcs = [os.path.join(CSRC, s) for s in CLI_SOURCES]
-    if all(os.path.exists(s) for s in cli_srcs) and (force or _stale(CLI, cli_srcs + deps + [LIB])):
-        cmd = [_hipcc()] + FLAGS + ["-o", CLI] + cli_srcs + ["-L" + LIBDIR, "-lstrling_amd", "-lz", "-Wl,-rpath,$ORIGIN"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd, cwd=CSRC)
+    if all(os.path.exists(s) for s in cli_srcs):
+        cobjs, cfresh = _compile_objects(CLI_SOURCES, objdir, hdrs, force, verbose)
+        if cfresh or force or _stale(CLI, cobjs + [LIB]):
+            cmd = [_hipcc(), "-o", CLI] + cobjs + ["-L" + LIBDIR, "-lstrling_amd", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd, cwd=CSRC)
     return LIB
 
 

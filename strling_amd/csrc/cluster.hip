@@ -737,8 +737,12 @@ static int cluster_collect(strl_ctx *c, const std::vector<std::pair<uint64_t, ui
   hipStream_t st = c->stream;
   uint32_t cnt[CC_WORDS];
   uint32_t n_dev = 0;
+  uint32_t part_err = 0;
   STRL_HIP(hipMemcpyAsync(cnt, B[B_CNT].p, CC_WORDS * 4, hipMemcpyDeviceToHost, st));
+  if (R.part_err) STRL_HIP(hipMemcpyAsync(&part_err, R.part_err, 4, hipMemcpyDeviceToHost, st));
   STRL_HIP(hipStreamSynchronize(st));
+  // (also the asynchronous exchange paths, which never look at the flag themselves: round-3 advisor finding)
+  if (part_err) { set_error("strl_cluster_gathered: a rank sent more treads than `pad`"); return STRL_ERR_CAPACITY; }
   n_dev = cnt[CC_NSEEN];
   if (n_dev > R.n_max) { set_error("clustering: %u treads, capacity %u", n_dev, R.n_max); return STRL_ERR_CAPACITY; }
   const uint32_t err = cnt[CC_ERR];
@@ -1068,6 +1072,7 @@ extern "C" int strl_cluster_gathered(strl_ctx *c, const strl_tread *gathered, co
   R.kbits = bits_for((uint64_t)n_tid) + 15;
   R.composite = R.pos_bits + R.kbits <= 64;
   R.treads = B[B_TREADS].as<strl_tread>(); R.d_n = cnt + CC_N;
+  R.part_err = aux + 1;
   if ((rc = cluster_device_pass(c, R.treads, R.d_n, st))) return rc;
   if (on_side) {
     STRL_HIP(hipEventRecord(c->ev_side_done, c->stream2));
@@ -1075,10 +1080,6 @@ extern "C" int strl_cluster_gathered(strl_ctx *c, const strl_tread *gathered, co
     return STRL_OK;
   }
   if (!out && !n_out && !stats && !n_unplaced) return STRL_OK;
-  uint32_t perr = 0;
-  STRL_HIP(hipMemcpyAsync(&perr, aux + 1, 4, hipMemcpyDeviceToHost, st));
-  STRL_HIP(hipStreamSynchronize(st));
-  if (perr) { set_error("strl_cluster_gathered: a rank sent more treads than `pad`"); return STRL_ERR_CAPACITY; }
   return cluster_collect(c, {}, out, cap, n_out, unplaced, unplaced_cap, n_unplaced, stats);
 }
 

@@ -7,7 +7,8 @@
 //     different devices; when contexts SHARE a device (RCCL refuses two ranks on one device; also how the path is tested
 //     on a one-GPU box) the same exchange is made with device-to-device copies ordered by events.
 // The reference has no counterpart: it is single-threaded per sample (merge.nim:52,89 is its only sharding knob).
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is not linked, see `Rccl` below
+#include <dlfcn.h>
 #include <string.h>
 #include <algorithm>
 #include "common.h"
@@ -25,10 +26,65 @@ struct strl_comm {
   int world = 1, rank = 0;
   std::vector<strl_ctx *> peers;        // one process, shared devices: the group's contexts (copies instead of RCCL)
   bool owner = false;                   // this context's comm object owns `peers`' bookkeeping (rank 0 of a local group)
-  struct Set { hipStream_t st = nullptr; DevBuf t_local, t_all, c_all; hipEvent_t ready = nullptr; };
+  struct Set {
+    hipStream_t st = nullptr;
+    DevBuf t_local, t_all, c_all;
+    hipEvent_t ready = nullptr;      // shared devices: the send buffer is complete (recorded on the sender's stream)
+    hipEvent_t copied = nullptr;     // shared devices: THIS rank's copies out of its peers' send buffers are done (recorded on its stream)
+    bool copied_pending = false;
+  };
   std::vector<Set *> sets;              // exchange buffers per tail stream (a step's buffers outlive its asynchronous clustering)
   uint32_t pad = 0;
 };
+
+// RCCL is bound at the first use, not at link time (round-3 advisor finding): a one-GPU build / run needs no librccl at
+// all, and inside a process that already holds one (torch ships its own librccl.so) THAT copy is used instead of loading a
+// second RCCL from /opt/rocm beside it.
+struct Rccl {
+  decltype(&::ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&::ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&::ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&::ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&::ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&::ncclAllGather) AllGather = nullptr;
+  decltype(&::ncclGroupStart) GroupStart = nullptr;
+  decltype(&::ncclGroupEnd) GroupEnd = nullptr;
+  std::string origin, error;
+  bool ok = false;
+};
+static Rccl &rccl() {
+  static Rccl R = [] {
+    Rccl r;
+    void *h = nullptr;
+    const char *env = getenv("STRL_RCCL_LIB");
+    const char *loaded[] = {"librccl.so.1", "librccl.so"};
+    const char *fresh[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    if (env && *env) { h = dlopen(env, RTLD_NOW | RTLD_GLOBAL); r.origin = env; }
+    for (const char *n : loaded) if (!h && (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) r.origin = std::string(n) + " (already in the process)";
+    if (!h && dlsym(RTLD_DEFAULT, "ncclAllGather")) { h = RTLD_DEFAULT; r.origin = "symbols already in the process"; }
+    for (const char *n : fresh) if (!h && (h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) r.origin = n;
+    if (!h) { r.error = "RCCL not found (librccl.so; set STRL_RCCL_LIB)"; return r; }
+#define STRL_RCCL_SYM(name) r.name = reinterpret_cast<decltype(r.name)>(dlsym(h, "nccl" #name)); if (!r.name) { r.error = "RCCL symbol nccl" #name " missing in " + r.origin; return r; }
+    STRL_RCCL_SYM(GetErrorString) STRL_RCCL_SYM(GetUniqueId) STRL_RCCL_SYM(CommInitRank) STRL_RCCL_SYM(CommInitAll)
+    STRL_RCCL_SYM(CommDestroy) STRL_RCCL_SYM(AllGather) STRL_RCCL_SYM(GroupStart) STRL_RCCL_SYM(GroupEnd)
+#undef STRL_RCCL_SYM
+    r.ok = true;
+    return r;
+  }();
+  return R;
+}
+#define STRL_NEED_RCCL()                                                         \
+  do {                                                                           \
+    if (!rccl().ok) { strl::set_error("%s", rccl().error.c_str()); return STRL_ERR_HIP; } \
+  } while (0)
+#define ncclGetErrorString rccl().GetErrorString
+#define ncclGetUniqueId rccl().GetUniqueId
+#define ncclCommInitRank rccl().CommInitRank
+#define ncclCommInitAll rccl().CommInitAll
+#define ncclCommDestroy rccl().CommDestroy
+#define ncclAllGather rccl().AllGather
+#define ncclGroupStart rccl().GroupStart
+#define ncclGroupEnd rccl().GroupEnd
 
 #define STRL_NCCL(call)                                                                             \
   do {                                                                                              \
@@ -44,9 +100,10 @@ void comm_destroy(strl_comm *m) {
   for (auto *s : m->sets) {
     s->t_local.release(); s->t_all.release(); s->c_all.release();
     if (s->ready) (void)hipEventDestroy(s->ready);
+    if (s->copied) (void)hipEventDestroy(s->copied);
     delete s;
   }
-  if (m->nccl) (void)ncclCommDestroy(m->nccl);
+  if (m->nccl && rccl().ok) (void)ncclCommDestroy(m->nccl);
   delete m;
 }
 
@@ -56,6 +113,7 @@ static strl_comm::Set *set_for(strl_comm *m, hipStream_t st, uint32_t pad) {
   if (!s) { s = new strl_comm::Set(); s->st = st; m->sets.push_back(s); }
   if (s->t_local.reserve((size_t)pad * sizeof(strl_tread)) || s->t_all.reserve((size_t)m->world * pad * sizeof(strl_tread)) || s->c_all.reserve((size_t)m->world * 4 + 64)) return nullptr;
   if (!s->ready && hipEventCreateWithFlags(&s->ready, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (!s->copied && hipEventCreateWithFlags(&s->copied, hipEventDisableTiming) != hipSuccess) return nullptr;
   return s;
 }
 
@@ -71,6 +129,12 @@ static int gather_prepare(strl_ctx *c, uint32_t pad, strl_comm::Set **set, hipSt
   if (!s) s = c->stream;
   strl_comm::Set *S = set_for(m, s, pad);
   if (!S) { set_error("exchange buffers: out of memory"); return STRL_ERR_HIP; }
+  // shared devices: the peers of the previous step read this rank's send buffer on THEIR streams -- the refill waits for them
+  // (round-3 advisor finding: only the sender -> reader `ready` event existed)
+  for (strl_ctx *q : m->peers)
+    if (q && q != c && q->comm)
+      for (auto *x : q->comm->sets)
+        if (x->copied_pending) STRL_HIP(hipStreamWaitEvent(s, x->copied, 0));
   const size_t mbytes = (size_t)std::min<uint64_t>(pad, cap) * sizeof(strl_tread);
   if (mbytes) STRL_HIP(hipMemcpyAsync(S->t_local.p, treads, mbytes, hipMemcpyDeviceToDevice, s));
   *set = S; *st = s;
@@ -84,6 +148,7 @@ extern "C" {
 int strl_comm_unique_id(uint8_t id[STRL_COMM_ID_BYTES]) {
   static_assert(sizeof(ncclUniqueId) <= STRL_COMM_ID_BYTES, "ncclUniqueId larger than STRL_COMM_ID_BYTES");
   if (!id) { set_error("null argument"); return STRL_ERR_ARG; }
+  STRL_NEED_RCCL();
   ncclUniqueId u;
   STRL_NCCL(ncclGetUniqueId(&u));
   memset(id, 0, STRL_COMM_ID_BYTES);
@@ -95,6 +160,7 @@ int strl_ctx_comm_init(strl_ctx *c, int world, int rank, const uint8_t id[STRL_C
   if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !id)) { set_error("strl_ctx_comm_init: bad argument"); return STRL_ERR_ARG; }
   STRL_HIP(hipSetDevice(c->device));
   if (c->comm) { comm_destroy(c->comm); c->comm = nullptr; }
+  STRL_NEED_RCCL();
   strl_comm *m = new strl_comm();
   m->world = world; m->rank = rank;
   ncclUniqueId u;
@@ -116,6 +182,7 @@ int strl_ctxs_comm_init(strl_ctx **ctxs, int n) {
   }
   std::vector<ncclComm_t> comms((size_t)n, nullptr);
   if (distinct && n > 1) {
+    STRL_NEED_RCCL();
     std::vector<int> devs((size_t)n);
     for (int i = 0; i < n; ++i) devs[(size_t)i] = ctxs[i]->device;
     STRL_NCCL(ncclCommInitAll(comms.data(), n, devs.data()));
@@ -176,8 +243,8 @@ int strl_ctxs_cluster_exchange(strl_ctx **ctxs, int n, uint32_t pad, int mode, i
     if ((rc = gather_prepare(ctxs[i], pad, &S[(size_t)i], &st[(size_t)i], &count[(size_t)i]))) return rc;
     ctxs[i]->comm->pad = pad;
   }
-  const bool rccl = ctxs[0]->comm->nccl != nullptr;
-  if (rccl) {
+  const bool use_rccl = ctxs[0]->comm->nccl != nullptr;
+  if (use_rccl) {
     STRL_NCCL(ncclGroupStart());
     for (int i = 0; i < n; ++i) {
       STRL_NCCL(ncclAllGather(S[(size_t)i]->t_local.p, S[(size_t)i]->t_all.p, (size_t)pad * sizeof(strl_tread), ncclUint8, ctxs[i]->comm->nccl, st[(size_t)i]));
@@ -195,6 +262,8 @@ int strl_ctxs_cluster_exchange(strl_ctx **ctxs, int n, uint32_t pad, int mode, i
                                 hipMemcpyDeviceToDevice, st[(size_t)i]));
         STRL_HIP(hipMemcpyAsync(S[(size_t)i]->c_all.as<uint32_t>() + p, count[(size_t)p], 4, hipMemcpyDeviceToDevice, st[(size_t)i]));
       }
+      STRL_HIP(hipEventRecord(S[(size_t)i]->copied, st[(size_t)i]));
+      S[(size_t)i]->copied_pending = true;
     }
   }
   for (int i = 0; i < n; ++i)

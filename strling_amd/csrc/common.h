@@ -65,6 +65,7 @@ struct ClusterRun {
   const uint32_t *d_n = nullptr;        // device
   const uint32_t *perm = nullptr;       // device: sorted index -> input index
   const uint64_t *first_key = nullptr;  // device: per-tread key that orders first appearances (nullptr: the input index)
+  const uint32_t *part_err = nullptr;   // device: error word of the owner partition in front of the pass (a rank sent more treads than `pad`)
   // members of the bounds the last pass returned: [first, first + count) in sorted order; `kept` maps the
   // uploaded (filtered) treads back to the caller's indices when merge mode dropped unplaced ones
   std::vector<uint32_t> b_first, b_count, kept;

@@ -45,8 +45,9 @@ struct FrontSlot {
   DevBuf comp, infl, coff, clen, uoff, isize, crc, status, seg, recoff, seqoff, qoff, info, base3, carry_stage;
   uint32_t n_blocks = 0, n_seg = 0;
   uint64_t infl_bytes = 0, comp_bytes = 0;
-  hipEvent_t ev_read = nullptr;   // another context copied this slot's tail (multi-GPU carry)
-  bool read_pending = false;
+  hipEvent_t ev_carry = nullptr;  // owned (created on this context's device): recorded behind THIS slot's copy of another context's tail
+  hipEvent_t wait_read = nullptr; // not owned: the ev_carry of the context that copied this slot's tail (multi-GPU carry); an event is
+  bool read_pending = false;      // recorded on a stream of its own device only, a wait on it is legal from any device
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_h2d = nullptr;   // record scan done | parse + scoring done (slot reusable) | compressed bytes on the device
   bool b_pending = false, a_pending = false;
   FrontInfo *h_info = nullptr;   // pinned: [0] as of the record scan, [1] as of the parse, [2] the initial values
@@ -92,7 +93,7 @@ struct FrontCarrySrc {
   uint32_t end;          // end of the inflated bytes in that slot
   int device;
   hipEvent_t ev_a;
-  hipEvent_t ev_read;    // recorded by the reader behind its copy: the owner waits for it before it overwrites the slot
+  hipEvent_t *wait_read; // the reader stores ITS event (recorded behind its copy) here: the owner waits for it before it overwrites the slot
   bool *read_pending;
 };
 

@@ -447,7 +447,7 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   const uint64_t readable = (d.comp_bytes + 3) & ~(uint64_t)3;
   const uint64_t rec_cap = tot / 36 + 16;          // no record is shorter than 36 bytes
   if (S.b_pending) STRL_HIP(hipStreamWaitEvent(st, S.ev_b, 0));
-  if (S.read_pending) { STRL_HIP(hipStreamWaitEvent(st, S.ev_read, 0)); S.read_pending = false; }   // another context took its carry from this slot
+  if (S.read_pending) { STRL_HIP(hipStreamWaitEvent(st, S.wait_read, 0)); S.read_pending = false; }   // another context took its carry from this slot
   auto want = [](uint64_t need) { return (size_t)(need + need / 4 + 4096); };   // head-room: later chunks rarely reallocate
   if (S.comp.cap < readable + 16 && (rc = S.comp.reserve(want(readable + 16)))) return rc;
   if (S.infl.cap < (uint64_t)end + 256 && (rc = S.infl.reserve(want((uint64_t)end + 256)))) return rc;
@@ -508,7 +508,8 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
       STRL_HIP(hipMemcpyPeerAsync(stg, c->device, carry->infl + (carry->end - stage_len), carry->device, stage_len, st));
       STRL_HIP(hipMemcpyPeerAsync(stg + FRONT_CARRY_MAX + 64, c->device, carry->info, carry->device, sizeof(FrontInfo), st));
     }
-    STRL_HIP(hipEventRecord(carry->ev_read, st));
+    STRL_HIP(hipEventRecord(S.ev_carry, st));          // this context's own event, on its own stream (round-3 advisor finding)
+    *carry->wait_read = S.ev_carry;
     *carry->read_pending = true;
     hipLaunchKernelGGL(carry_stage_kernel, dim3(1), dim3(1024), 0, st, stg, stage_len, carry->end, S.infl.as<uint8_t>(), info);
     STRL_HIP(hipGetLastError());
@@ -567,7 +568,7 @@ void front_destroy(strl_front *F) {
     if (S.ev_a) (void)hipEventDestroy(S.ev_a);
     if (S.ev_b) (void)hipEventDestroy(S.ev_b);
     if (S.ev_h2d) (void)hipEventDestroy(S.ev_h2d);
-    if (S.ev_read) (void)hipEventDestroy(S.ev_read);
+    if (S.ev_carry) (void)hipEventDestroy(S.ev_carry);
     if (S.h_info) (void)hipHostFree(S.h_info);
     if (S.h_uoff) (void)hipHostFree(S.h_uoff);
   }

@@ -1729,7 +1729,7 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
     STRL_HIP(hipEventCreateWithFlags(&S.ev_a, hipEventDisableTiming));
     STRL_HIP(hipEventCreateWithFlags(&S.ev_b, hipEventDisableTiming));
     STRL_HIP(hipEventCreateWithFlags(&S.ev_h2d, hipEventDisableTiming));
-    STRL_HIP(hipEventCreateWithFlags(&S.ev_read, hipEventDisableTiming));
+    STRL_HIP(hipEventCreateWithFlags(&S.ev_carry, hipEventDisableTiming));
     STRL_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_info), 3 * sizeof(strl::FrontInfo), hipHostMallocDefault));
   }
   if ((rc = F->tid_seen.reserve((size_t)n_ref + 16))) return rc;
@@ -1767,7 +1767,7 @@ int strl_front_push_after(strl_ctx *c, strl_ctx *prev, const uint8_t *comp, uint
   const strl::FrontChunkDesc d{comp, comp_bytes, coff, clen, isize, crc32, n_blocks};
   if (prev) {
     strl::FrontSlot &PS = prev->front->slot[prev->front->last_slot];
-    const strl::FrontCarrySrc cs{PS.infl.as<uint8_t>(), PS.info.as<strl::FrontInfo>(), prev->front->last_end, prev->device, PS.ev_a, PS.ev_read, &PS.read_pending};
+    const strl::FrontCarrySrc cs{PS.infl.as<uint8_t>(), PS.info.as<strl::FrontInfo>(), prev->front->last_end, prev->device, PS.ev_a, &PS.wait_read, &PS.read_pending};
     rc = strl::front_stage_a(c, F, si, d, false, &cs);
   } else {
     rc = strl::front_stage_a(c, F, si, d, F->chunks == 0 && !F->not_first);
