@@ -12,7 +12,8 @@ every rank clusters the (tid, unit) groups it owns (strling_amd/dist.py, SURVEY 
 
 Prints ONE JSON line on rank 0: value = reads of ALL ranks / max-rank time; `roofline` for the slowest kernel launch
 (HIP events on the kernels' own stream); `cpu_baseline` = the oracle's extract + cluster over the same stages, 1 thread;
-`end_to_end` = `strling extract` + `strling call`-style clustering from a BAM file on this box (host decode included).
+`end_to_end` = the `strling extract` -> `strling call` / `strling merge` processes on a BAM FILE on this box (zlib level 6, qualities,
+aux tags, .bai), whole-process wall clock, with a share of the .bin and of -bounds.txt checked against the oracle.
 """
 import argparse
 import json
@@ -458,18 +459,21 @@ def cpu_baseline_e2e(oracle_reads_per_s):
                       f"extract/cluster rate, combined per read (1 / (1/inflate + 1/loop)); the like-for-like denominator of end_to_end"}
 
 
-def end_to_end(n_pairs):
-    """`strling extract` from a BAM file written to local disk (page cache warm), wall clock, all host threads."""
+def end_to_end(n_pairs, check_slabs=4):
+    """`strling extract` -> .bin -> `strling call` and `strling merge`, from a coordinate-sorted, indexed BAM of 2 * n_pairs distinct
+    reads (zlib level 6, binned random qualities, aux tags) written to local disk / shm (page cache warm): wall clock of whole
+    processes, all host threads; a share of the outputs checked against the oracle (tools/e2e_bench.py)."""
     from strling_amd import build
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import e2e_bench
     inp = e2e_bench.make_input(n_pairs)
     try:
-        return e2e_bench.run(inp, build.CLI)
+        res = e2e_bench.run(inp, build.CLI)
+        if check_slabs and "error" not in res:
+            res["check"] = e2e_bench.check(inp, e2e_bench.pick_slabs(inp["n_slabs"], check_slabs), call=res.get("call_rc") == 0)
+        return res
     finally:
-        for k in ("bam", "bed", "out"):
-            if os.path.exists(inp[k]):
-                os.remove(inp[k])
+        e2e_bench.cleanup(inp)
 
 
 if __name__ == "__main__":

@@ -26,6 +26,8 @@ extern "C" {
 #define STRL_ERR_IO (-5)
 #define STRL_ERR_FORMAT (-6)
 #define STRL_ERR_ASSERT (-7) /* a doAssert of the reference would have fired (e.g. extract.nim:72) */
+#define STRL_ERR_LIMIT (-9)  /* more records than one device pass over a whole input takes (2^31 - 16: record indices travel in 31 bits);
+                                * the reference has no such cap (extract.nim:308) -- the CLI routes such a file to the streaming host Cache */
 #define STRL_ERR_CRC (-8)    /* a BGZF block inflates, but not to the bytes its CRC-32 names (htslib stops there too) */
 
 #define STRL_MEM_HOST 0
@@ -46,6 +48,9 @@ void strl_ctx_destroy(strl_ctx *ctx);
 /* The HIP stream (hipStream_t) all kernels of this context are launched on. */
 void *strl_ctx_stream(strl_ctx *ctx);
 int strl_ctx_sync(strl_ctx *ctx);
+/* Free / total memory of the context's device right now (hipMemGetInfo).  No counterpart in the reference (a host program);
+ * `strling extract -v` prints what the whole-file resident state takes. */
+int strl_ctx_mem_info(strl_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* ---- Options (utils.nim:119-127; extract.nim:255-256,299-300) ---- */
 typedef struct {

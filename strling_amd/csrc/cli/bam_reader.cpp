@@ -107,6 +107,7 @@ bool BamReader::open(const std::string &path, std::string &err) {
   close();
   f_ = fopen(path.c_str(), "rb");
   if (!f_) { err = "couldn't open bam"; return false; }   // extract.nim:276
+  path_ = path;
   eof_ = false; next_block_ = 0; upos_ = 0; ubuf_.clear();
   char magic[4];
   int32_t l_text = 0, n_ref = 0;
@@ -125,6 +126,16 @@ bool BamReader::open(const std::string &path, std::string &err) {
     nm.pop_back();
     targets_.push_back(BamTarget{nm, (uint32_t)l_ref});
   }
+  return true;
+}
+
+bool BamReader::open_like(const BamReader &o, std::string &err) {
+  close();
+  f_ = fopen(o.path_.c_str(), "rb");
+  if (!f_) { err = "couldn't open bam"; return false; }
+  path_ = o.path_;
+  eof_ = false; next_block_ = 0; upos_ = 0; ubuf_.clear();
+  text_ = o.text_; targets_ = o.targets_; lin_ = o.lin_; ref_beg_ = o.ref_beg_;
   return true;
 }
 

@@ -54,6 +54,9 @@ class BamReader {
  public:
   ~BamReader();
   bool open(const std::string &path, std::string &err);
+  // a second handle on a file another reader has open (header, targets and index are copied from it, not parsed again):
+  // `strling call` reads the regions of its bounds on several threads, one reader each
+  bool open_like(const BamReader &other, std::string &err);
   void close();
   const std::string &header_text() const { return text_; }
   const std::vector<BamTarget> &targets() const { return targets_; }
@@ -77,6 +80,7 @@ class BamReader {
   bool fill(std::string &err);                       // inflate the next BGZF block into ubuf_
   bool get(void *dst, size_t n, std::string &err);   // copy n decompressed bytes, crossing blocks
   FILE *f_ = nullptr;
+  std::string path_;
   std::vector<uint8_t> cbuf_, ubuf_;
   size_t upos_ = 0;
   uint64_t block_start_ = 0, next_block_ = 0;

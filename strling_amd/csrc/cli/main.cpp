@@ -380,9 +380,10 @@ static int extract_main(int argc, char **argv) {
   double t_read = 0, t_soa = 0, t_score = 0, t_pair = 0;   // -v: where the wall time of the loop goes
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  bool over_limit = false;   // more records than one device pass takes: the file goes to the streaming host Cache (STRL_ERR_LIMIT)
   auto run_batch = [&](RecordBatch &b) {
     const size_t n = b.size();
-    if (!n) return;
+    if (!n || over_limit) return;
     const auto ta = now();
     strl_records rec = b.view();
     end.resize(n); so.resize(n); ls.resize(n); cl.resize(n); cr.resize(n); cig.resize(n);
@@ -420,7 +421,9 @@ static int extract_main(int argc, char **argv) {
       t_score += secs(tb, tc); t_pair += secs(tc, now());
     } else {
       const strl_pair_soa pp{rows.data(), qh.data()};
-      CHECK(strl_extract_add(ctx, &soa, &pp));
+      const int rc_add = strl_extract_add(ctx, &soa, &pp);
+      if (rc_add == STRL_ERR_LIMIT) { over_limit = true; return; }
+      if (rc_add) quit("[strling] %s (status %d)", strl_last_error(), rc_add);
       CHECK(strl_ctx_sync(ctx));                       // the batch's buffers are reused by the decoder
       QChunk q;
       q.first = n_seen;
@@ -488,6 +491,15 @@ static int extract_main(int argc, char **argv) {
       ++nreads;
     }
     run_batch(b);
+    if (over_limit) {
+      { std::lock_guard<std::mutex> lk(mu); stop = true; }
+      cv.notify_all();
+      producer.join();
+      fprintf(stderr, "[strling] %s: repeating the extraction with the host pair logic\n", strl_last_error());
+      strl_ctx_destroy(ctx);
+      setenv("STRL_PAIR", "host", 1);
+      return extract_main(argc, argv);
+    }
     {
       std::lock_guard<std::mutex> lk(mu);
       --filled;
@@ -659,10 +671,19 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     for (strl_ctx *c : ctxs) strl_ctx_destroy(c);
     return EXTRACT_AGAIN_HOST_FRONT;
   };
+  // more records than one device pass takes (2^31 - 16; the reference has no cap, extract.nim:308): the streaming host Cache
+  auto over_limit = [&]() -> int {
+    fprintf(stderr, "[strling] %s: repeating the extraction with the host pair logic\n", strl_last_error());
+    if (frag_thread.joinable()) frag_thread.join();
+    for (size_t k = 0; k < pin.size(); ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
+    for (strl_ctx *c : ctxs) strl_ctx_destroy(c);
+    return EXTRACT_AGAIN_ON_HOST;
+  };
 #define FRONT_CHECK(call)                                                                    \
   do {                                                                                       \
     const int rc__ = (call);                                                                 \
     if (rc__ == STRL_ERR_FORMAT) return give_up_front();                                     \
+    if (rc__ == STRL_ERR_LIMIT) return over_limit();                                         \
     if (rc__ == STRL_ERR_CRC) quit("[strling] error reading %s: %s", bam.c_str(), strl_last_error());   \
     if (rc__ != STRL_OK) quit("[strling] %s (status %d)", strl_last_error(), rc__);          \
   } while (0)
@@ -748,7 +769,7 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   if (G > 1) {
     std::vector<uint64_t> recs(summary.size());
     for (size_t k = 0; k < summary.size(); ++k) recs[k] = summary[k].n_records;
-    CHECK(strl_ctxs_extract_gather(ctxs.data(), G, chunk_owner.data(), recs.data(), recs.size()));
+    FRONT_CHECK(strl_ctxs_extract_gather(ctxs.data(), G, chunk_owner.data(), recs.data(), recs.size()));
     if (verbose) fprintf(stderr, "[strling] %zu chunks over %d contexts on %d device(s); per-read state gathered on the first\n", summary.size(), G, std::min(G, std::max(1, strl_device_count())));
   }
   const double t_drain = secs(tf, now());
@@ -837,6 +858,11 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     fprintf(stderr, "[strling] seconds: total %.3f  waiting for block headers %.3f  copying compressed bytes %.3f  enqueueing + waiting for the device %.3f  "
                     "draining the device %.3f  fragment lengths %.3f (copy %.3f, set_opts %.3f)  pair logic + names %.3f  (device front end; %llu scan segments walked twice)\n",
             secs(t0, now()), t_walk, t_copy, t_push, t_drain, t_frag, t_frag_copy, t_setopts, t_pair, (unsigned long long)slow_segments);
+  }
+  if (verbose) {
+    uint64_t mf = 0, mt = 0;
+    if (strl_ctx_mem_info(ctx, &mf, &mt) == STRL_OK)
+      fprintf(stderr, "[strling] device memory in use at the end (all chunks' per-read state resident): %.2f GB of %.1f GB\n", (double)(mt - mf) / 1e9, (double)mt / 1e9);
   }
   if (verbose)
     fprintf(stderr, "[strling] seconds before the loop: %.3f to the open context (device context %.3f, page-locked buffers %.3f: two threads beside the header walk), "
@@ -1177,38 +1203,83 @@ static int call_main(int argc, char **argv) {
   fputs("#chrom\tleft\tright\trepeatunit\tallele1_est\tallele2_est\tanchored_reads\tspanning_reads\tspanning_pairs\texpected_spanning_pairs\t"
         "spanning_pairs_pctl\tleft_clips\tright_clips\tunplaced_pairs\tdepth\tsum_str_counts\n", gt_fh);                          // genotyper.nim:54
 
-  // evidence + genotype of one bound (call.nim:196-218 / :237-255): indexed region read, spanners(), genotype(), one row
+  // evidence + genotype of one bound (call.nim:196-218 / :237-255): indexed region read, spanners(), genotype(), one row.
+  // The reference walks its bounds one after the other; a bound's evidence depends on nothing but the bound, its reads and
+  // the file, so the bounds are worked on by a pool of threads (a reader each) and their rows written in the reference's order.
   std::vector<strl_call> calls;
-  std::vector<strl_support> sup;
-  RecordBatch region;
-  char row[2048];
-  auto evidence = [&](const strl_bounds &b, const char *name, const strl_tread *reads, uint64_t n_reads) {
-    region.clear();
-    const int64_t wl = (int64_t)b.left - window, wr = (int64_t)b.right + window;
-    if (rd.read_region(region, b.tid, std::max<int64_t>(0, wl), wr, err) < 0) quit("[strling] error reading %s: %s", bam.c_str(), err.c_str());
-    const strl_records rv = region.view();
-    sup.resize(2 * region.size() + 16);
-    strl_span_summary sm{};
-    CHECK(strl_spanners(&rv, region.isize.data(), &b, window, frag, min_mapq, sup.data(), sup.size(), &sm));
-    if (sm.n_support > 5000) return;                                                // spans.len > 5_000
-    if (sm.median_depth == -1) return;
-    strl_call c{};
-    CHECK(strl_genotype(&b, reads, n_reads, qoff.data(), qnames.data(), sup.data(), sm.n_support, &copts, (double)sm.median_depth, &c));
-    c.expected_spanning_fragments = sm.expected_spanners;
-    calls.push_back(c);
-    strl_locus L{};
-    L.b = b;
-    if (name) snprintf(L.name, sizeof L.name, "%s", name);
-    locus_row(row, sizeof row, L, rd.targets()[(size_t)b.tid].name.c_str());
-    fprintf(bounds_fh, "%s\t%d\n", row, sm.median_depth);
+  struct Task { strl_bounds b; const char *name; const std::vector<uint32_t> *idx; uint64_t i0, i1; const strl_tread *src; };
+  struct Done { bool keep = false; strl_call c; std::string row; int depth = 0; };
+  struct Worker { BamReader rd; RecordBatch region; std::vector<strl_support> sup; std::vector<strl_tread> cl; bool open = false; };
+  const int n_workers = std::max(1, std::min(decode_threads(), 32));
+  std::vector<std::unique_ptr<Worker>> workers;
+  for (int k = 0; k < n_workers; ++k) workers.emplace_back(new Worker());
+  ThreadPool ev_pool(n_workers);
+  double t_evidence = 0;
+  auto run_tasks = [&](const std::vector<Task> &tasks) {
+    if (tasks.empty()) return;
+    const auto te0 = std::chrono::steady_clock::now();
+    std::vector<Done> done(tasks.size());
+    std::mutex wm;
+    std::vector<int> free_w;
+    for (int k = n_workers - 1; k >= 0; --k) free_w.push_back(k);
+    std::atomic<bool> failed{false};
+    std::string fail_msg;
+    const size_t per = 8, n_blocks = (tasks.size() + per - 1) / per;
+    ev_pool.parallel_for(n_blocks, [&](size_t blk) {
+      int wi;
+      { std::lock_guard<std::mutex> lk(wm); wi = free_w.back(); free_w.pop_back(); }
+      Worker &w = *workers[(size_t)wi];
+      std::string werr;
+      auto fail = [&](const std::string &m) { std::lock_guard<std::mutex> lk(wm); if (!failed.exchange(true)) fail_msg = m; };
+      if (!w.open) { if (!w.rd.open_like(rd, werr)) fail("couldn't open bam"); else w.open = true; }
+      char row[2048];
+      for (size_t j = blk * per; j < std::min(tasks.size(), (blk + 1) * per) && !failed.load() && w.open; ++j) {
+        const Task &t = tasks[j];
+        const strl_bounds &b = t.b;
+        w.region.clear();
+        const int64_t wl = (int64_t)b.left - window, wr = (int64_t)b.right + window;
+        if (w.rd.read_region(w.region, b.tid, std::max<int64_t>(0, wl), wr, werr) < 0) { fail("[strling] error reading " + bam + ": " + werr); break; }
+        const strl_records rv = w.region.view();
+        w.sup.resize(2 * w.region.size() + 16);
+        strl_span_summary sm{};
+        if (strl_spanners(&rv, w.region.isize.data(), &b, window, frag, min_mapq, w.sup.data(), w.sup.size(), &sm) != STRL_OK) { fail(std::string("[strling] ") + strl_last_error()); break; }
+        if (sm.n_support > 5000) continue;                                              // spans.len > 5_000
+        if (sm.median_depth == -1) continue;
+        w.cl.clear();
+        for (uint64_t k = t.i0; k < t.i1; ++k) w.cl.push_back(t.src[(*t.idx)[(size_t)k]]);
+        Done &d = done[j];
+        memset(&d.c, 0, sizeof d.c);
+        if (strl_genotype(&b, w.cl.data(), w.cl.size(), qoff.data(), qnames.data(), w.sup.data(), sm.n_support, &copts, (double)sm.median_depth, &d.c) != STRL_OK) {
+          fail(std::string("[strling] ") + strl_last_error());
+          break;
+        }
+        d.c.expected_spanning_fragments = sm.expected_spanners;
+        strl_locus L{};
+        L.b = b;
+        if (t.name) snprintf(L.name, sizeof L.name, "%s", t.name);
+        locus_row(row, sizeof row, L, rd.targets()[(size_t)b.tid].name.c_str());
+        d.row = row;
+        d.depth = sm.median_depth;
+        d.keep = true;
+      }
+      { std::lock_guard<std::mutex> lk(wm); free_w.push_back(wi); }
+    });
+    if (failed.load()) quit("%s", fail_msg.c_str());
+    for (const Done &d : done) {
+      if (!d.keep) continue;
+      calls.push_back(d.c);
+      fprintf(bounds_fh, "%s\t%d\n", d.row.c_str(), d.depth);
+    }
+    t_evidence += std::chrono::duration<double>(std::chrono::steady_clock::now() - te0).count();
   };
   const uint64_t nt = (uint64_t)info.n_reads;
-  std::vector<strl_tread> cl;
   const std::vector<strl_tread> taken_copy = treads;   // assigned reads are genotyped with the split they came with
 
   // loci handed in with -l / -b are genotyped first and take their reads out of the table (call.nim:150-218)
+  std::vector<strl_locus> given;
+  std::vector<uint32_t> assigned;
   {
-    std::vector<strl_locus> loci, given;
+    std::vector<strl_locus> loci;
     if (a.flag("loci")) { loci = parse_bed(a.get("loci", ""), rd.targets(), (uint32_t)window); fprintf(stderr, "Read %zu loci from %s\n", loci.size(), a.get("loci", "").c_str()); }
     if (a.flag("bounds")) { given = parse_bounds(a.get("bounds", ""), rd.targets()); fprintf(stderr, "Read %zu bounds from %s\n", given.size(), a.get("bounds", "").c_str()); }
     for (strl_locus &bound : given)                                                  // loci overwrite the bound they overlap (:160-169)
@@ -1222,22 +1293,24 @@ static int call_main(int argc, char **argv) {
     for (const strl_locus &l : loci) given.push_back(l);
     if (!given.empty()) {
       std::vector<uint64_t> aoff(given.size() + 1);
-      std::vector<uint32_t> assigned((size_t)std::max<uint64_t>(nt, 1));
+      assigned.resize((size_t)std::max<uint64_t>(nt, 1));
       CHECK(strl_assign_reads_loci(treads.data(), nt, STRL_MODE_CALL, given.data(), given.size(), aoff.data(), assigned.data(), assigned.size()));
       // the reads keep the split they had: strl_assign_reads_loci only re-marks its own copies in `treads`
+      std::vector<Task> tasks;
       for (size_t j = 0; j < given.size(); ++j) {
         const strl_locus &L = given[j];
         if (L.b.right - L.b.left > 1000u) { fprintf(stderr, "large bounds: %s:%u-%u skipping\n", rd.targets()[(size_t)L.b.tid].name.c_str(), L.b.left, L.b.right); continue; }
-        cl.clear();
-        for (uint64_t k = aoff[j]; k < aoff[j + 1]; ++k) cl.push_back(taken_copy[assigned[(size_t)k]]);
-        evidence(L.b, L.name, cl.data(), cl.size());
+        tasks.push_back(Task{L.b, L.name, &assigned, aoff[j], aoff[j + 1], taken_copy.data()});
       }
+      run_tasks(tasks);
     }
   }
 
   // discovery: group, sort, cluster, bounds on the device (call.nim:118-130,221-235)
+  const auto tc0 = std::chrono::steady_clock::now();
   strl_ctx *ctx = nullptr;
   CHECK(strl_ctx_create(0, &ctx));
+  const auto tc1 = std::chrono::steady_clock::now();
   const uint16_t max_clip_dist = (uint16_t)(0.5 * (double)frag_median);             // call.nim:232
   std::vector<strl_bounds> bounds(std::max<size_t>((size_t)nt, 16));
   std::vector<strl_unplaced> unplaced(std::max<size_t>((size_t)nt, 16));
@@ -1249,11 +1322,17 @@ static int call_main(int argc, char **argv) {
   CHECK(strl_cluster_members(ctx, moff.data(), nullptr, 0, &nm));
   std::vector<uint32_t> members((size_t)std::max<uint64_t>(nm, 1));
   CHECK(strl_cluster_members(ctx, moff.data(), members.data(), members.size(), &nm));
-  for (uint64_t j = 0; j < nb; ++j) {
-    cl.clear();
-    for (uint64_t k = moff[(size_t)j]; k < moff[(size_t)j + 1]; ++k) cl.push_back(treads[members[(size_t)k]]);
-    evidence(bounds[(size_t)j], nullptr, cl.data(), cl.size());
+  const auto tc2 = std::chrono::steady_clock::now();
+  {
+    std::vector<Task> tasks;
+    tasks.reserve((size_t)nb);
+    for (uint64_t j = 0; j < nb; ++j) tasks.push_back(Task{bounds[(size_t)j], nullptr, &members, moff[(size_t)j], moff[(size_t)j + 1], treads.data()});
+    run_tasks(tasks);
   }
+  if (verbose)
+    fprintf(stderr, "[strling] seconds: device context %.3f  clustering (upload, sort, sweep, bounds, members) %.3f  evidence + genotypes of %llu bounds on %d threads %.3f\n",
+            std::chrono::duration<double>(tc1 - tc0).count(), std::chrono::duration<double>(tc2 - tc1).count(), (unsigned long long)nb, n_workers, t_evidence);
+  char row[2048];
   std::vector<uint64_t> order(std::max<size_t>(calls.size(), 1)), uorder(std::max<size_t>((size_t)nu, 1));
   CHECK(strl_calls_finish(calls.data(), calls.size(), unplaced.data(), nu, order.data()));   // :264-278
   for (size_t k = 0; k < calls.size(); ++k) {

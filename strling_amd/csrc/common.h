@@ -1,6 +1,7 @@
 // common.h -- internal declarations shared by the C-ABI translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
@@ -70,6 +71,17 @@ struct ClusterRun {
   // uploaded (filtered) treads back to the caller's indices when merge mode dropped unplaced ones
   std::vector<uint32_t> b_first, b_count, kept;
 };
+
+// Records one device pass over a whole input takes (join items and soft-clip records name a record in 31 bits).
+// STRL_RECORD_LIMIT lowers it (tests of the route the CLI takes beyond it).
+inline uint64_t strl_record_limit() {
+  static const uint64_t v = [] {
+    const char *e = getenv("STRL_RECORD_LIMIT");
+    const unsigned long long x = e ? strtoull(e, nullptr, 10) : 0;
+    return x > 0 && x < 0x7ffffff0ull ? (uint64_t)x : (uint64_t)0x7ffffff0ull;
+  }();
+  return v;
+}
 
 namespace strl { struct strl_front; struct strl_comm; void comm_destroy(strl_comm *m); }
 struct strl_ctx;

@@ -735,7 +735,7 @@ int strl_pair_order(strl_ctx *c, hipStream_t on_stream) {
 // c->treads[0, *c->n_treads).
 int strl_pair_device(strl_ctx *c, uint64_t n, const strl_pair_soa *pp, const uint32_t *whole, const strl_soft_rec *soft,
                      const uint32_t *d_n_soft, uint64_t soft_cap, int64_t n_tail, uint64_t item_cap, uint64_t tread_cap, hipStream_t on_stream) {
-  if (n > 0x7ffffff0ull) { set_error("pair logic: at most 2^31 - 16 records"); return STRL_ERR_ARG; }
+  if (n > strl_record_limit()) { set_error("pair logic: more than %llu records in one device pass", (unsigned long long)strl_record_limit()); return STRL_ERR_LIMIT; }
   if (n_tail < 0 || (uint64_t)n_tail > n) { set_error("strl_pair_device: n_tail must be in [0, n]"); return STRL_ERR_ARG; }
   if (item_cap > 0x7ffffff0ull || tread_cap > 0x7ffffff0ull) { set_error("pair capacities too large"); return STRL_ERR_ARG; }
   hipStream_t st = on_stream ? on_stream : c->stream;

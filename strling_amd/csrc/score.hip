@@ -846,6 +846,16 @@ int strl_device_count(void) {
   return n;
 }
 
+int strl_ctx_mem_info(strl_ctx *c, uint64_t *free_bytes, uint64_t *total_bytes) {
+  if (!c) { set_error("null context"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  size_t f = 0, t = 0;
+  STRL_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return STRL_OK;
+}
+
 int strl_ctx_create(int device_ordinal, strl_ctx **out) {
   if (!out) { set_error("ctx out pointer is NULL"); return STRL_ERR_ARG; }
   *out = nullptr;
@@ -1411,7 +1421,7 @@ int strl_ctxs_extract_gather(strl_ctx **ctxs, int n, const uint32_t *chunk_owner
   }
   for (int g = 0; g < n; ++g)
     if (local_n[(size_t)g] != ctxs[g]->x_n) { set_error("strl_ctxs_extract_gather: context %d holds %llu records, its chunks say %llu", g, (unsigned long long)ctxs[g]->x_n, (unsigned long long)local_n[(size_t)g]); return STRL_ERR_ARG; }
-  if (tot > 0x7ffffff0ull) { set_error("chunked extract: more than 2^31 - 16 records"); return STRL_ERR_ARG; }
+  if (tot > strl_record_limit()) { set_error("chunked extract: more than %llu records in one device pass", (unsigned long long)strl_record_limit()); return STRL_ERR_LIMIT; }
   // totals of the soft-clip records, the name arenas, the counters
   std::vector<uint32_t> xc((size_t)n * XC_WORDS);
   std::vector<uint64_t> soft_at((size_t)n + 1, 0), arena_at((size_t)n + 1, 0);
@@ -1572,7 +1582,7 @@ int strl_extract_add(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa *p
   STRL_HIP(hipSetDevice(c->device));
   const uint64_t n = s->n, at = c->x_n;
   if (!n) return STRL_OK;
-  if (at + n > 0x7ffffff0ull) { set_error("chunked extract: more than 2^31 - 16 records"); return STRL_ERR_ARG; }
+  if (at + n > strl_record_limit()) { set_error("chunked extract: more than %llu records in one device pass", (unsigned long long)strl_record_limit()); return STRL_ERR_LIMIT; }
   int rc;
   if ((rc = c->x_rows.grow((size_t)(at + n) * sizeof(strl_pair_rec), (size_t)at * sizeof(strl_pair_rec), c->stream)) ||
       (rc = c->x_qhash.grow((size_t)(at + n) * 8, (size_t)at * 8, c->stream)) || (rc = c->x_whole.grow((size_t)(at + n) * 4, (size_t)at * 4, c->stream)))
@@ -1675,7 +1685,7 @@ static int front_stage_b(strl_ctx *c, strl::strl_front *F, int si) {
   if (I.err & FRONT_ERR_RECORD) { set_error("malformed BAM record"); return STRL_ERR_FORMAT; }
   if (I.err & FRONT_ERR_CARRY) { set_error("BAM record of more than %u bytes", FRONT_CARRY_MAX); return STRL_ERR_FORMAT; }
   const uint64_t n = I.n_records, at = c->x_n;
-  if (at + n > 0x7ffffff0ull) { set_error("chunked extract: more than 2^31 - 16 records"); return STRL_ERR_ARG; }
+  if (at + n > strl_record_limit()) { set_error("chunked extract: more than %llu records in one device pass", (unsigned long long)strl_record_limit()); return STRL_ERR_LIMIT; }
   if (I.max_l_seq > (uint32_t)STRL_MAX_READ_LEN) { set_error("a record's l_seq %u is outside [0, %d]", I.max_l_seq, STRL_MAX_READ_LEN); return STRL_ERR_ARG; }
   int rc;
   const uint64_t n1 = std::max<uint64_t>(n, 1);

@@ -175,6 +175,26 @@ def test_extract_never_quits_on_a_qname_carried_by_hundreds_of_records(oracle, t
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("front", ["device", "host"])
+def test_extract_beyond_the_record_limit_of_a_device_pass(sample, oracle, front):
+    """A file with more records than one device pass over a whole input takes (2^31 - 16; here lowered through the test hook
+    STRL_RECORD_LIMIT) is not refused -- the reference has no cap (extract.nim:308) -- but goes to the streaming host Cache:
+    same .bin as the oracle."""
+    rec, g = sample["rec"], sample["g"]
+    out = str(sample["dir"] / f"limit_{front}.bin")
+    env = dict(os.environ, STRL_RECORD_LIMIT=str(rec.n // 2), STRL_CHUNK_BLOCKS="64")
+    if front == "host":
+        env["STRL_FRONT"] = "host"
+    r = _run(["extract", "-g", sample["bed"], "--batch", "5000", sample["bam"], out], env=env)
+    assert r.returncode == 0, r.stderr
+    assert "records in one device pass: repeating the extraction with the host pair logic" in r.stderr
+    frag = synth.frag_hist(rec)
+    exp_t = oracle.extract(rec, g, oracle.make_opts(oracle.median(frag), 0.8, 40))
+    exp = oracle.bin_write(0.8, 40, frag, sample["hdr"].rstrip("\0"), exp_t, rec.qname_off, rec.qnames)
+    assert open(out, "rb").read() == exp
+
+
+@pytest.mark.gpu
 def test_merge_bounds_match_oracle(sample, oracle, tmp_path):
     """strling merge BIN... -> -bounds.txt identical (rows and row order) to the oracle's merge clustering."""
     bins, all_t, frag_sum = [], [], np.zeros(4096, np.uint64)

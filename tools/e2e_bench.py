@@ -1,74 +1,239 @@
-"""End-to-end `strling extract` rate (BAM bytes -> .bin) on a synthetic BAM, with the CLI's own phase breakdown.
-usage: python tools/e2e_bench.py [n_pairs] [threads...]     (GPU box)
-As a module: make_input(n_pairs) before the GPU runtime starts in this process (it forks), run(paths, cli, threads)."""
+"""End to end at the size BASELINE.json names: `strling extract` -> `.bin` -> `strling call` / `strling merge` on a synthetic
+coordinate-sorted, indexed BAM of N distinct 150 bp reads of a 30x sample -- zlib level 6, binned random base qualities, aux
+tags (bamio.write_bam_slabs) -- with the CLI's own phase breakdown, and a check of a deterministic share of the outputs
+against the oracle (test infrastructure: the oracle is the checker, never the thing timed).
+
+usage: python tools/e2e_bench.py [n_pairs] [--dir D] [--check-slabs K] [--level L] [--keep]        (GPU box)
+As a module (bench.py): make_input(n_pairs) BEFORE the GPU runtime starts in this process (it forks), run(inp, cli),
+check(inp, res, slabs)."""
 import json
 import os
+import re
 import subprocess
 import sys
 import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
-
-def make_input(n_pairs, d=None, level=1):
-    """-> dict(bam, bed, out, reads, bam_MB, make_s).  S1 mix, distinct reads, coordinate sorted, no index."""
-    from strling_amd import bamio, synth
-    d = d or os.environ.get("TMPDIR", "/tmp")
-    bam, bed, out = f"{d}/e2e_{n_pairs}.bam", f"{d}/e2e_{n_pairs}.str", f"{d}/e2e_{n_pairs}.bin"
-    t0 = time.time()
-    chunks = max(1, min(64, n_pairs // 65536))
-    rec, g = synth.synth_wgs_30x(chunks, n_pairs // chunks, seed=99)
-    bamio.write_bam_parallel(bam, rec, level=level)
-    bamio.write_genome_bed(bed, g, rec.targets)
-    return {"bam": bam, "bed": bed, "out": out, "reads": rec.n, "bam_MB": round(os.path.getsize(bam) / 1e6, 1), "make_s": round(time.time() - t0, 1)}
+PAIRS_PER_SLAB = 1 << 18      # the slab bench.py's resident batch is made of (64 of them = 2^25 reads)
 
 
-def run(inp, cli, threads=(0,)):
-    """runs `strling extract -v` on the prepared input once per thread count (0 = the CLI's default) -> end_to_end block"""
-    quota = None
+def work_dir(need_bytes):
+    """a directory with room for the file: TMPDIR / /tmp if its filesystem has it, else /dev/shm (RAM-backed; the GPU box has
+    79 GB of disk and 1.5 TB of shm)"""
+    cands = [os.environ.get("STRL_E2E_DIR"), os.environ.get("TMPDIR", "/tmp"), "/dev/shm"]
+    for d in cands:
+        if not d or not os.path.isdir(d):
+            continue
+        st = os.statvfs(d)
+        if st.f_bavail * st.f_frsize > need_bytes * 1.3 + (4 << 30):
+            return d
+    return cands[1]
+
+
+def make_input(n_pairs, d=None, level=6, seed=99, quals=True, aux=True, progress=False):
+    """-> dict(bam, bed, out, prefix, reads, n_slabs, ...).  S1 mix, distinct reads, coordinate sorted, .bai + ref.fasta.str."""
+    from strling_amd import bamio
+    n_slabs = max(1, n_pairs // PAIRS_PER_SLAB)
+    pairs = n_pairs // n_slabs
+    d = d or work_dir(n_pairs * 2 * 115)
+    tag = f"e2e_{n_pairs}_{level}"
+    bam, bed = f"{d}/{tag}.bam", f"{d}/{tag}.str"
+    pr = (lambda k, n, s: print(f"[e2e] slab {k}/{n} {s:.0f} s", file=sys.stderr, flush=True) if k % 64 == 0 else None) if progress else None
+    r = bamio.write_bam_slabs(bam, n_slabs, pairs, seed=seed, level=level, quals=quals, aux=aux, index=True, bed=bed, progress=pr)
+    return {"bam": bam, "bed": bed, "out": f"{d}/{tag}.bin", "prefix": f"{d}/{tag}", "reads": r["reads"], "n_slabs": n_slabs, "pairs_per_slab": pairs,
+            "seed": seed, "level": level, "bam_MB": round(r["bytes"] / 1e6, 1), "make_s": round(r["seconds"], 1), "make_procs": r["procs"], "dir": d,
+            "targets": r["targets"],
+            "input": f"{r['reads']} distinct reads in {n_slabs} slabs of a 30x sample, coordinate sorted + unmapped tail, zlib level {level}, "
+                     f"{'binned random' if quals else 'absent'} qualities, {'NM MD AS XS RG' if aux else 'no'} aux tags"}
+
+
+def _quota():
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        quota = None if q == "max" else round(int(q) / int(per), 1)
+        return None if q == "max" else round(int(q) / int(per), 1)
     except Exception:
-        pass
-    res = {"unit": "reads/s", "reads": inp["reads"], "bam_MB": inp["bam_MB"], "host_threads_available": os.cpu_count(), "cgroup_cpu_quota": quota,
-           "runs": []}
-    for t in threads:
+        return None
+
+
+def _timed(cmd, env):
+    t = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    return r, time.time() - t
+
+
+def run(inp, cli, threads=(0,), call=True, merge=True, repeats=1):
+    """`strling extract -v` once per thread count (0 = the CLI's default), then `strling call` and `strling merge` on the
+    .bin -> the end_to_end block of bench.py's line"""
+    res = {"unit": "reads/s", "reads": inp["reads"], "bam_MB": inp["bam_MB"], "input": inp.get("input"), "make_s": inp.get("make_s"),
+           "host_threads_available": os.cpu_count(), "cgroup_cpu_quota": _quota(), "runs": []}
+    for t in list(threads) * repeats:
         env = dict(os.environ, STRL_DECODE_TIMING="1", STRL_FRONT_TIMING="1")
         if t:
             env["STRL_THREADS"] = str(t)
-        t1 = time.time()
-        r = subprocess.run([cli, "extract", "-v", "-g", inp["bed"], inp["bam"], inp["out"]], capture_output=True, text=True, env=env)
-        wall = time.time() - t1
-        line = [l for l in r.stderr.splitlines() if "seconds: total" in l]
-        dec = [l.split("decode seconds:")[1].strip() for l in r.stderr.splitlines() if "decode seconds:" in l]
+        r, wall = _timed([cli, "extract", "-v", "-g", inp["bed"], inp["bam"], inp["out"]], env)
+        err = r.stderr.splitlines()
+        line = [l for l in err if "seconds: total" in l]
         loop_s = float(line[-1].split("total")[1].split()[0]) if line else None
         front = None
-        fl = [l for l in r.stderr.splitlines() if "device front end, ms over" in l]
+        fl = [l for l in err if "device front end, ms over" in l]
         if fl:
-            import re
             m = re.search(r"over (\d+) chunks: copies to the device ([\d.]+)  inflate ([\d.]+)  record scan ([\d.]+)  \(([\d.]+) MB compressed -> ([\d.]+) MB inflated", fl[-1])
             if m:
                 ch, h2d, inf, scan, cmb, imb = (float(x) for x in m.groups())
                 front = {"chunks": int(ch), "copy_ms": h2d, "inflate_ms": inf, "record_scan_ms": scan, "compressed_MB": cmb, "inflated_MB": imb,
-                         "inflate_GBps": round(imb / inf, 1) if inf else None,
-                         "note": "HIP events on the front end's own stream (copies overlap the previous chunk's inflate): BGZF inflate, record-boundary scan "
-                                 "and BAM parse run on the device; the host walks block headers and copies compressed bytes"}
-        res["runs"].append({"decode_threads": t or "default: min(64, 1.5 x CPU quota)", "rc": r.returncode, "wall_s": round(wall, 3),
-                            "reads_per_s_wall": round(inp["reads"] / wall), "loop_s": loop_s,
-                            "reads_per_s_loop": round(inp["reads"] / loop_s) if loop_s else None, "decode": dec, "device_front_end": front,
-                            "phases": line[-1].split("seconds:")[1].strip() if line else r.stderr[-300:]})
-    best = max(res["runs"], key=lambda x: x["reads_per_s_wall"])
+                         "inflate_GBps": round(imb / inf, 1) if inf else None}
+        mem = [l for l in err if "device memory in use" in l]
+        mem_gb = float(re.search(r": ([\d.]+) GB of", mem[-1]).group(1)) if mem else None
+        n_str = [l for l in err if " STR reads, " in l]
+        run_ = {"decode_threads": t or "default", "rc": r.returncode, "wall_s": round(wall, 3), "reads_per_s_wall": round(inp["reads"] / wall),
+                "loop_s": loop_s, "reads_per_s_loop": round(inp["reads"] / loop_s) if loop_s else None, "device_front_end": front,
+                "device_mem_GB": mem_gb, "str_reads": int(n_str[-1].split(" reads, ")[1].split()[0]) if n_str else None,
+                "phases": line[-1].split("seconds:")[1].strip() if line else r.stderr[-400:]}
+        if r.returncode != 0:
+            run_["stderr_tail"] = r.stderr[-600:]
+        res["runs"].append(run_)
+    ok = [x for x in res["runs"] if x["rc"] == 0]
+    if not ok:
+        res["error"] = "strling extract failed"
+        return res
+    best = max(ok, key=lambda x: x["reads_per_s_wall"])
     res["value"] = best["reads_per_s_wall"]
-    res["note"] = ("`strling extract` BAM file (page cache) -> .bin, whole process wall clock incl. start-up (HIP context, page-locked buffers), copies of the "
-                   "compressed bytes, BGZF inflate + record scan + parse + scorer + pair logic on the device, fragment lengths, .bin writing; reads_per_s_loop "
-                   "excludes process start-up and the .bin write")
+    res["extract_s"] = best["wall_s"]
+    res["bin_MB"] = round(os.path.getsize(inp["out"]) / 1e6, 1)
+    env = dict(os.environ)
+    if call:
+        r, wall = _timed([cli, "call", "-v", "-o", inp["prefix"], inp["bam"], inp["out"]], env)
+        res["call_s"] = round(wall, 3)
+        res["call_rc"] = r.returncode
+        if r.returncode == 0:
+            res["call_bounds_rows"] = sum(1 for _ in open(inp["prefix"] + "-bounds.txt")) - 1
+            res["call_genotype_rows"] = sum(1 for _ in open(inp["prefix"] + "-genotype.txt")) - 1
+            ph = [l for l in r.stderr.splitlines() if "seconds:" in l]
+            if ph:
+                res["call_phases"] = ph[-1].split("seconds:")[1].strip()
+            res["extract_plus_call_s"] = round(res["extract_s"] + wall, 3)
+            res["reads_per_s_extract_plus_call"] = round(inp["reads"] / (res["extract_s"] + wall))
+        else:
+            res["call_stderr_tail"] = r.stderr[-600:]
+    if merge:
+        r, wall = _timed([cli, "merge", "-o", inp["prefix"] + "-joint", inp["out"]], env)
+        res["merge_s"] = round(wall, 3)
+        res["merge_rc"] = r.returncode
+        if r.returncode == 0:
+            res["merge_bounds_rows"] = sum(1 for _ in open(inp["prefix"] + "-joint-bounds.txt")) - 1
+        else:
+            res["merge_stderr_tail"] = r.stderr[-600:]
+    res["note"] = ("`strling extract` BAM file (page cache) -> .bin: whole process wall clock incl. start-up (HIP context, page-locked buffers), copies of the "
+                   "compressed bytes, BGZF inflate + CRC + record scan + parse + scorer + pair logic on the device, fragment lengths, .bin writing; "
+                   "reads_per_s_loop excludes process start-up and the .bin write.  call_s / merge_s: whole `strling call` (clustering on the device, "
+                   ".bai region reads + spanning evidence + genotypes on the host) and `strling merge` processes on that .bin")
     return res
 
 
+def _slab_check(a):
+    """oracle over ONE slab regenerated from its seed: its treads in .bin order, its `call` bounds rows"""
+    c, n_slabs, pairs, seed, frag, want_call = a
+    import numpy as np
+    from oracle import oracle as O
+    from strling_amd import bamio
+    rec, g = bamio.slab_records(c, n_slabs, pairs, seed)
+    med = O.median(frag)
+    t = O.extract(rec, g, O.make_opts(med, 0.8, 40))
+    names = [rec.qname(int(i)) for i in t["qname_id"]]
+    rows = None
+    if want_call:
+        b, _, _ = O.call(t, rec, frag)
+        mine = {rec.targets[2 * c][0], rec.targets[2 * c + 1][0]}
+        rows = sorted(l for l in b.splitlines()[1:] if l.split("\t")[0] in mine)
+    keep = ("tid", "position", "repeat", "flag", "split", "mapping_quality", "repeat_count", "align_length")
+    return c, {f: np.ascontiguousarray(t[f]) for f in keep}, names, rows, rec.n
+
+
+def check(inp, slabs, call=True, procs=None):
+    """The .bin's treads of the chosen slabs (every tread whose qname belongs to one of them, in file order) against the oracle
+    run over those slabs alone -- qname groups never interact, so a slab's treads are a subsequence of the file's -- and the
+    `-bounds.txt` rows on those slabs' contigs against the oracle's `call` over the slab (depth column included)."""
+    import multiprocessing as mp
+    import numpy as np
+    from strling_amd import api
+    t0 = time.time()
+    b = api.bin_read(inp["out"])
+    t, qo, qn = b["treads"], b["qname_off"].astype(np.int64), np.frombuffer(b["qnames"], np.uint8)
+    # qname "q<pair id>": slab = pair id // pairs_per_slab
+    pid = np.zeros(len(t), np.int64)
+    ln = qo[1:] - qo[:-1]
+    for k in range(1, int(ln.max()) if len(t) else 0):
+        has = ln > k
+        pid[has] = pid[has] * 10 + (qn[qo[:-1][has] + k] - 48)
+    slab_of = pid // inp["pairs_per_slab"]
+    frag = b["frag"]
+    rows_by_chrom = {}
+    if call and os.path.exists(inp["prefix"] + "-bounds.txt"):
+        for l in open(inp["prefix"] + "-bounds.txt").read().splitlines()[1:]:
+            rows_by_chrom.setdefault(l.split("\t")[0], []).append(l)
+    jobs = [(c, inp["n_slabs"], inp["pairs_per_slab"], inp["seed"], frag, bool(rows_by_chrom)) for c in slabs]
+    procs = procs or max(1, min(len(jobs), int(_quota() or os.cpu_count() or 1)))
+    bad, n_t, n_rows, n_reads = [], 0, 0, 0
+    with mp.get_context("spawn").Pool(procs) as pool:
+        for c, exp, names, rows, n in pool.imap_unordered(_slab_check, jobs):
+            sel = np.nonzero(slab_of == c)[0]
+            n_reads += n
+            n_t += len(names)
+            ok = sel.size == len(names)
+            if ok:
+                for f, v in exp.items():
+                    ok = ok and np.array_equal(t[f][sel], v)
+                got_names = [qn[qo[i]:qo[i + 1]].tobytes() for i in sel]
+                ok = ok and got_names == names
+            if not ok:
+                bad.append(f"slab {c}: treads differ ({sel.size} vs {len(names)})")
+            if rows is not None:
+                tg = inp["targets"]
+                got = sorted(rows_by_chrom.get(tg[2 * c][0], []) + rows_by_chrom.get(tg[2 * c + 1][0], []))
+                n_rows += len(rows)
+                if got != rows:
+                    bad.append(f"slab {c}: bounds rows differ ({len(got)} vs {len(rows)})")
+    return {"slabs": len(slabs), "reads_checked": n_reads, "treads_checked": n_t, "bounds_rows_checked": n_rows, "mismatches": bad[:8], "ok": not bad,
+            "seconds": round(time.time() - t0, 1),
+            "what": "every tread of the .bin whose qname belongs to one of the checked slabs, field by field and in order, against the oracle's extract "
+                    "over the slab regenerated from its seed; the `strling call` -bounds.txt rows on those slabs' contigs (depth column included) "
+                    "against the oracle's call over the slab"}
+
+
+def pick_slabs(n_slabs, k):
+    """a deterministic spread of k slabs over the file (first, last, evenly between)"""
+    k = max(1, min(k, n_slabs))
+    return sorted({int(round(j * (n_slabs - 1) / max(1, k - 1))) for j in range(k)})
+
+
+def cleanup(inp):
+    for p in (inp["bam"], inp["bam"] + ".bai", inp["bed"], inp["out"], inp["prefix"] + "-bounds.txt", inp["prefix"] + "-genotype.txt",
+              inp["prefix"] + "-unplaced.txt", inp["prefix"] + "-joint-bounds.txt"):
+        if os.path.exists(p):
+            os.remove(p)
+
+
 if __name__ == "__main__":
+    import argparse
     from strling_amd import build
-    n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 400_000
-    threads = [int(x) for x in sys.argv[2:]] or [0]
-    inp = make_input(n_pairs)
-    print(json.dumps(run(inp, build.CLI, threads)))
+    ap = argparse.ArgumentParser()
+    ap.add_argument("n_pairs", type=int, nargs="?", default=1 << 22)
+    ap.add_argument("--dir", default=None)
+    ap.add_argument("--level", type=int, default=6)
+    ap.add_argument("--check-slabs", type=int, default=8)
+    ap.add_argument("--repeats", type=int, default=1)
+    ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    inp = make_input(a.n_pairs, d=a.dir, level=a.level, progress=True)
+    print(f"[e2e] wrote {inp['bam']} ({inp['bam_MB']} MB, {inp['reads']} reads) in {inp['make_s']} s", file=sys.stderr, flush=True)
+    res = run(inp, build.CLI, repeats=a.repeats)
+    if a.check_slabs and "error" not in res:
+        res["check"] = check(inp, pick_slabs(inp["n_slabs"], a.check_slabs), call=res.get("call_rc") == 0)
+    if not a.keep:
+        cleanup(inp)
+    s = json.dumps(res)
+    if a.out:
+        open(a.out, "w").write(s + "\n")
+    print(s)
