@@ -1,0 +1,9 @@
+#!/bin/bash
+# timing experiments on the inflate kernel (results of the nowait / nocopy variants are WRONG by construction)
+mkdir -p gpurun_out/r4
+export TMPDIR=/tmp
+for v in "" _nowait _nocopy _w8; do
+  echo "== variant '$v'"
+  STRL_BENCH_NOCHECK=1 STRL_LIB=$PWD/strling_amd/lib/libstrling_amd$v.so timeout 600 python tools/inflate_bench.py 524288 32768 2>&1 | grep "GB/s"
+done > gpurun_out/r4/inflate_exp1.txt 2>&1
+cat gpurun_out/r4/inflate_exp1.txt

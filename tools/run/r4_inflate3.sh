@@ -1,0 +1,8 @@
+#!/bin/bash
+mkdir -p gpurun_out/r4
+export TMPDIR=/tmp
+for v in "" _r9w6 _r9w7 _r9w8; do
+  echo "== variant '$v'"
+  STRL_LIB=$PWD/strling_amd/lib/libstrling_amd$v.so timeout 600 python tools/inflate_bench.py 524288 32768 2>&1 | grep "GB/s\|Error\|error"
+done > gpurun_out/r4/inflate_exp2.txt 2>&1
+cat gpurun_out/r4/inflate_exp2.txt
