@@ -112,7 +112,7 @@ namespace strl {
 constexpr int IW_ERR_DATA = 1, IW_ERR_SIZE = 2, IW_ERR_CRC = 4;
 constexpr uint32_t IW_OOB = 0x80000000u;   // an offset no descriptor of this file covers (num_records < 2^31)
 #ifndef IW_LIT_ROOT_BITS
-#define IW_LIT_ROOT_BITS 10
+#define IW_LIT_ROOT_BITS 9     // measured: 9 bits (2 KB, 4.4 KB of LDS per wave) 95.6 / 70.7 GB/s, 10 bits 87.9 / 64.2 (profiles/r04/inflate_hybrid.txt)
 #endif
 constexpr int IW_LIT_ROOT = IW_LIT_ROOT_BITS, IW_DIST_ROOT = 8, IW_CL_ROOT = 7;
 
@@ -250,8 +250,8 @@ IW_DEV uint32_t iw_build(const IwLane<uint32_t> (&len)[ROUNDS], uint32_t *tab, u
 }
 
 // A code longer than the first-level table (or an unused prefix): canonical search over the remaining lengths.  0 = invalid.
-template <int KIND> IW_DEV uint32_t iw_slow(uint32_t bb, const uint32_t *limit, const uint32_t *delta, const uint16_t *sorted, uint32_t dummy, int root) {
-  const uint32_t v16 = iw_brev(bb) >> 16;
+template <int KIND> IW_DEV uint32_t iw_slow(uint64_t bb, const uint32_t *limit, const uint32_t *delta, const uint16_t *sorted, uint32_t dummy, int root) {
+  const uint32_t v16 = iw_brev((uint32_t)bb) >> 16;
   for (int l = root + 1; l <= 15; ++l) {
     const uint32_t lim = IW_U(limit[l]);
     if (v16 < lim) {
@@ -262,15 +262,14 @@ template <int KIND> IW_DEV uint32_t iw_slow(uint32_t bb, const uint32_t *limit, 
   return 0u;
 }
 
-// The compressed stream as the wave sees it: 64 dwords per lane-register, the next 64 prefetched.  The bit buffer is two
-// consecutive dwords of the stream (lo, hi) and a bit offset into them: consuming n bits is `sh += n`; once sh >= 32 the
-// buffer advances by a dword (lo = hi, hi = the next dword of the window).  sh < 32 <=> at least 33 unread bits.
+// The compressed stream as the wave sees it: 64 dwords per lane-register, the next 64 prefetched.
 struct IwBits {
   IwBuf in;                    // the stream piece from its dword-aligned origin on, bounds-checked
   uint32_t w0, widx;           // dword index of cur[lane 0]; next dword of cur to enter the bit buffer
   uint32_t skip;               // bytes between the origin and the first byte of the stream piece this reader was started on
   IwLane<uint32_t> cur, nxt;
-  uint32_t lo, hi, sh;
+  uint64_t bb;
+  uint32_t nbits;
 
   IW_DEV void load(IwLane<uint32_t> &r, uint32_t first) {
     IW_FOR_LANES { r[lane] = iw_ld32(in, 4u * (first + (uint32_t)lane)); }
@@ -280,19 +279,18 @@ struct IwBits {
     const uint64_t a = off & ~(uint64_t)3;
     skip = (uint32_t)(off & 3u);
     in = iw_make_buf(comp + a, readable > a ? readable - a : 0);
-    w0 = 0;
+    w0 = 0; widx = 0; bb = 0; nbits = 0;
     load(cur, 0);
     load(nxt, 64);
-    lo = iw_readlane(cur, 0);
-    hi = iw_readlane(cur, 1);
-    widx = 2;
-    sh = 8u * skip;
+    refill();
+    bb >>= 8u * skip;
+    nbits -= 8u * skip;
   }
-  IW_DEV void refill() {            // afterwards sh < 32: at least 33 unread bits
-    if (sh >= 32u) {
-      lo = hi;
-      hi = iw_readlane(cur, widx);
-      sh -= 32u;
+  IW_DEV void refill() {            // afterwards nbits >= 33
+    if (nbits <= 32u) {
+      const uint32_t w = iw_readlane(cur, widx);
+      bb |= (uint64_t)w << nbits;
+      nbits += 32u;
       if (++widx == 64u) rotate();
     }
   }
@@ -302,16 +300,16 @@ struct IwBits {
     widx = 0;
     load(nxt, w0 + 64u);
   }
-  IW_DEV uint32_t peek() const { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }   // the next 64 - sh (<= 32 returned) unread bits
-  IW_DEV uint32_t bits(uint32_t n) {   // n <= 16 (0 allowed); the caller keeps sh + n <= 64 (refill() guarantees 33 bits)
-    const uint32_t v = peek() & ((1u << n) - 1u);
-    sh += n;
+  IW_DEV uint32_t bits(uint32_t n) {   // n <= 16 (0 allowed); the caller keeps nbits >= n
+    const uint32_t v = (uint32_t)bb & ((1u << n) - 1u);
+    bb >>= n;
+    nbits -= n;
     return v;
   }
-  // bytes from the origin to the next unread bit (exact once the position is a multiple of 8)
-  IW_DEV uint32_t byte_pos() const { return 4u * (w0 + widx - 2u) + (sh >> 3); }
+  // bytes from the origin to the next unread bit (exact once nbits is a multiple of 8)
+  IW_DEV uint32_t byte_pos() const { return 4u * (w0 + widx) - (nbits >> 3); }
   // bits consumed since init
-  IW_DEV uint64_t consumed() const { return 32ull * (w0 + widx - 2u) + sh - 8ull * skip; }
+  IW_DEV uint64_t consumed() const { return 32ull * (w0 + widx) - nbits - 8ull * skip; }
 };
 
 // Output of one stream: literals wait in a lane register (lane = position mod 64) for one coalesced store.
@@ -385,29 +383,39 @@ struct IwOut {
 //   code 5: a match (L, D) the fast copy does not take: it overlaps itself (D < L) or fails a check (caller decides)
 //   code 6: as 4, and the input window is used up
 //   code 7: the output position passed ISIZE
-// On the device this is hand-written ISA, and it runs on the VECTOR unit.  hipcc keeps the wave-uniform decoder state in scalar
-// registers: its own loop cost 55 scalar instructions per literal and ~150 per match, the hand-written scalar loop of round 3
-// 16 and 45 -- and the scalar unit (ONE instruction per cycle per CU, shared by all its waves) was what bounded the kernel
-// (profiles/r03/inflate_pmc_final.txt: SQ_INSTS_SALU 1.5e10 against SQ_INSTS_VALU 4.6e9, 81 GB/s).  The four SIMDs of a CU
-// issue two wave64 vector instructions per cycle between them and had next to nothing to do.  So the uniform state -- the two
-// dwords of the bit buffer, the bit offset, the table entry and its fields -- now lives in VGPRs (every lane computes the
-// same value), conditions go through VCC (v_cmp + s_cbranch_vccz: no SALU instruction), and the scalar unit keeps only the
-// output position and the window index: a literal costs 10 vector + 3 scalar instructions, a match ~38 + 6.
-// The copy of a match is software-pipelined as before: its bytes are LOADED when the match is decoded and STORED when the
-// next match (or an exit) comes around; every store is issued before any later load, so a later match that reads these
-// bytes sees them.  A literal is placed with v_cndmask under (lane == position mod 64): no v_writelane, no M0.
+// On the device this is hand-written ISA.  hipcc keeps the wave-uniform decoder state in scalar registers and turns the loop
+// into a state machine of 64-bit flag registers: 55 scalar instructions per literal, ~150 per match (36 GB/s).  Three hand-written
+// forms were measured on the same blocks (profiles/r04/inflate_symbols.txt, inflate_hybrid.txt, inflate_pmc_valu.txt):
+//   round 3, everything on the scalar unit   16 scalar + 3 vector per literal, 45 + 9 per match        81 / 59 GB/s
+//   everything on the vector unit             3 + 10,  6 + 38 (uniform values in VGPRs, branches on VCC)  88 / 64 GB/s
+//   split between the two (this one)          7 + 8,  22 + 25                                           88 / 64 GB/s
+// i.e. the unit does not matter (the round-3 reading "the scalar unit bounds the kernel" was wrong): a literal takes a wave
+// ~300 cycles and a match ~950 with six waves per SIMD whatever the mix, ~15 cycles per instruction of the wave's own
+// in-order stream -- the dependent chain index -> LDS lookup -> fields -> shift -> next index, one issue turn per instruction,
+// with 61 % of the wave-cycles parked on s_waitcnt.  Removing the copy's waits altogether gives 100 GB/s, the copy itself
+// 97 (inflate_exp_waits.txt); header parse + table build are 3.6 % (inflate_exp_header_only.txt).  What did pay: a 9-bit first
+// level (+9 %).  The split form is kept: fewest registers, no M0.
+//   scalar: the 64-bit bit buffer and its shifts, the table index, the length code's fields, the output position;
+//   vector: the bit count, the table address + lookup, the literal's placement, the distance code's fields, the checks against
+//           the vector-held distance, the copy;
+// values cross where an operand may sit in either file (a vector instruction reads one scalar register for free) and through
+// v_readfirstlane otherwise (the table entry, the bits the distance code used).
+// The copy of a match is software-pipelined: its bytes are LOADED when the match is decoded and STORED when the next match (or an
+// exit) comes around -- the load latency passes while the next symbols are decoded; every store is issued before any later
+// load, so a later match that reads these bytes sees them.  bb lives in s[90:91]; s92..s95, vcc are scratch (no M0).
 #ifdef STRL_EMU
 IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t *dist_tab, uint32_t &e, uint32_t &code, uint32_t &L, uint32_t &D) {
   for (;;) {
-    if (br.sh >= 32u) {
-      br.lo = br.hi;
-      br.hi = iw_readlane(br.cur, br.widx);
-      br.sh -= 32u;
+    if (br.nbits <= 32u) {
+      const uint32_t w = iw_readlane(br.cur, br.widx);
+      br.bb |= (uint64_t)w << br.nbits;
+      br.nbits += 32u;
       if (++br.widx == 64u) { code = 1; return; }
     }
-    e = lit_tab[br.peek() & ((1u << IW_LIT_ROOT) - 1u)];
+    e = lit_tab[(uint32_t)br.bb & ((1u << IW_LIT_ROOT) - 1u)];
     if (e & IW_FAST_LIT) {
-      br.sh += e & 15u;
+      br.bb >>= e & 15u;
+      br.nbits -= e & 15u;
       iw_writelane(o.pend, o.pos & 63u, iw_val(e) & 255u);
       ++o.pos;
       if (!(o.pos & 63u)) {
@@ -419,13 +427,13 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
     if ((e & (3u << 8)) != IW_KIND_BASE) { code = 0; return; }       // (an entry of 0 -- not in the table -- has kind 0)
     br.bits(e & 15u);
     L = iw_val(e) + br.bits((e >> 4) & 15u);
-    if (br.sh >= 32u) {
-      br.lo = br.hi;
-      br.hi = iw_readlane(br.cur, br.widx);
-      br.sh -= 32u;
+    if (br.nbits <= 32u) {
+      const uint32_t w = iw_readlane(br.cur, br.widx);
+      br.bb |= (uint64_t)w << br.nbits;
+      br.nbits += 32u;
       if (++br.widx == 64u) { code = 6; return; }
     }
-    const uint32_t d = dist_tab[br.peek() & ((1u << IW_DIST_ROOT) - 1u)];
+    const uint32_t d = dist_tab[(uint32_t)br.bb & ((1u << IW_DIST_ROOT) - 1u)];
     if (!(d & 15u)) { code = 4; return; }
     br.bits(d & 15u);
     D = iw_val(d) + br.bits((d >> 4) & 15u);
@@ -446,42 +454,35 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
 #define IW_EXP_COPY "buffer_store_byte %[pdata], %[paddr], %[rsrc], 0 offen\n\t" "buffer_load_ubyte %[pdata], %[vt1], %[rsrc], 0 offen\n\t"
 #endif
 IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t *dist_tab, uint32_t &e, uint32_t &code, uint32_t &L, uint32_t &D) {
-  uint32_t vlo, vhi, vsh, vw, ve, vn, vt0, vt1, vL, vD;
+  uint32_t vnb, ve, vn, vt0, vt1, vD, vsrc;
   const uint32_t vlit = (uint32_t)reinterpret_cast<uintptr_t>(lit_tab);     // LDS byte addresses (low half of the flat address)
   const uint32_t vdist = (uint32_t)reinterpret_cast<uintptr_t>(dist_tab);
   const uint32_t vlane = threadIdx.x;
   asm volatile(
-      "v_mov_b32_e32 %[vlo], %[lo]\n\t"
-      "v_mov_b32_e32 %[vhi], %[hi]\n\t"
-      "v_mov_b32_e32 %[vsh], %[sh]\n\t"
-      "v_mov_b32_e32 %[vL], %[L]\n\t"
+      "v_mov_b32_e32 %[vnb], %[nb]\n\t"
       "v_mov_b32_e32 %[vD], %[D]\n\t"
-      "v_mov_b32_e32 %[ve], 0\n"
-      // ---- next symbol: advance the bit buffer by a dword if 32 bits are used up, first-level literal/length lookup
+      "v_mov_b32_e32 %[ve], 0\n\t"
+      "s_mov_b32 %[e], 0\n"
+      // ---- next symbol: first-level literal/length lookup (the refill sits out of line)
       "L_iw_loop_%=:\n\t"
-      "v_cmp_gt_u32_e32 vcc, 32, %[vsh]\n\t"
-      "s_cbranch_vccnz L_iw_have_%=\n\t"
-      "v_readlane_b32 s92, %[cur], %[wi]\n\t"
-      "v_mov_b32_e32 %[vlo], %[vhi]\n\t"
-      "v_subrev_u32_e32 %[vsh], 32, %[vsh]\n\t"
-      "s_add_u32 %[wi], %[wi], 1\n\t"
-      "v_mov_b32_e32 %[vhi], s92\n\t"
-      "s_cmp_eq_u32 %[wi], 64\n\t"
-      "s_cbranch_scc1 L_iw_window_%=\n"
+      "v_cmp_lt_u32_e32 vcc, 32, %[vnb]\n\t"
+      "s_cbranch_vccz L_iw_refill_%=\n"
       "L_iw_have_%=:\n\t"
-      "v_alignbit_b32 %[vw], %[vhi], %[vlo], %[vsh]\n\t"
-      "v_and_b32_e32 %[vt0], %[litmask], %[vw]\n\t"
-      "v_lshl_add_u32 %[vt0], %[vt0], 2, %[vlit]\n\t"
+      "s_and_b32 s92, s90, %[litmask]\n\t"
+      "v_lshl_add_u32 %[vt0], s92, 2, %[vlit]\n\t"
       "ds_read_b32 %[ve], %[vt0]\n\t"
-      "s_and_b32 s92, %[pos], 63\n\t"
+      "s_and_b32 s93, %[pos], 63\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
-      "v_cmp_gt_i32_e32 vcc, 0, %[ve]\n\t"
+      "v_readfirstlane_b32 %[e], %[ve]\n\t"
       "v_and_b32_e32 %[vn], 15, %[ve]\n\t"
-      "s_cbranch_vccz L_iw_notlit_%=\n\t"
+      "v_cmp_eq_u32_e32 vcc, s93, %[vlane]\n\t"
+      "s_bitcmp1_b32 %[e], 31\n\t"
+      "s_cbranch_scc0 L_iw_notlit_%=\n\t"
       // ---- literal: into the staging register, lane = position mod 64
-      "v_cmp_eq_u32_e32 vcc, s92, %[vlane]\n\t"
+      "s_and_b32 s92, %[e], 15\n\t"
       "v_bfe_u32 %[vt0], %[ve], 16, 8\n\t"
-      "v_add_u32_e32 %[vsh], %[vsh], %[vn]\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], s92\n\t"
+      "v_sub_u32_e32 %[vnb], %[vnb], %[vn]\n\t"
       "s_add_u32 %[pos], %[pos], 1\n\t"
       "v_cndmask_b32_e32 %[pend], %[pend], %[vt0], vcc\n\t"
       "s_and_b32 s92, %[pos], 63\n\t"
@@ -500,52 +501,63 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "s_cbranch_scc0 L_iw_loop_%=\n\t"
       "s_mov_b32 %[code], 7\n\t"
       "s_branch L_iw_end_%=\n"
-      // ---- not a literal: a length code of the first-level table, or something for the caller
-      "L_iw_notlit_%=:\n\t"
-      "v_and_b32_e32 %[vt0], 0x300, %[ve]\n\t"
-      "v_cmp_eq_u32_e32 vcc, 0x100, %[vt0]\n\t"
-      "s_cbranch_vccz L_iw_other_%=\n\t"
-      "v_bfe_u32 %[vt1], %[ve], 4, 4\n\t"
-      "v_lshrrev_b32_e32 %[vt0], %[vn], %[vw]\n\t"
-      "v_bfe_u32 %[vL], %[ve], 16, 15\n\t"
-      "v_bfe_u32 %[vt0], %[vt0], 0, %[vt1]\n\t"
-      "v_add3_u32 %[vsh], %[vsh], %[vn], %[vt1]\n\t"
-      "v_add_u32_e32 %[vL], %[vL], %[vt0]\n\t"
-      // advance, first-level distance lookup
-      "v_cmp_gt_u32_e32 vcc, 32, %[vsh]\n\t"
-      "s_cbranch_vccnz L_iw_have2_%=\n\t"
+      // ---- 32 more bits into the buffer (every fourth symbol or so)
+      "L_iw_refill_%=:\n\t"
       "v_readlane_b32 s92, %[cur], %[wi]\n\t"
-      "v_mov_b32_e32 %[vlo], %[vhi]\n\t"
-      "v_subrev_u32_e32 %[vsh], 32, %[vsh]\n\t"
+      "v_readfirstlane_b32 s94, %[vnb]\n\t"
+      "s_mov_b32 s93, 0\n\t"
       "s_add_u32 %[wi], %[wi], 1\n\t"
-      "v_mov_b32_e32 %[vhi], s92\n\t"
+      "v_add_u32_e32 %[vnb], 32, %[vnb]\n\t"
+      "s_lshl_b64 s[92:93], s[92:93], s94\n\t"
+      "s_or_b64 s[90:91], s[90:91], s[92:93]\n\t"
       "s_cmp_eq_u32 %[wi], 64\n\t"
-      "s_cbranch_scc1 L_iw_windowL_%=\n"
+      "s_cbranch_scc0 L_iw_have_%=\n\t"
+      "s_mov_b32 %[code], 1\n\t"
+      "s_branch L_iw_end_%=\n"
+      // ---- not a literal: a length code of the first-level table (its fields on the scalar unit), or something for the caller
+      "L_iw_notlit_%=:\n\t"
+      "s_and_b32 s93, %[e], 0x300\n\t"
+      "s_cmp_eq_u32 s93, 0x100\n\t"
+      "s_cbranch_scc0 L_iw_other_%=\n\t"
+      "s_and_b32 s92, %[e], 15\n\t"
+      "s_bfe_u32 s93, %[e], 0x40004\n\t"
+      "s_lshr_b32 s94, s90, s92\n\t"
+      "s_bfm_b32 s95, s93, 0\n\t"
+      "s_bfe_u32 %[L], %[e], 0xf0010\n\t"
+      "s_and_b32 s94, s94, s95\n\t"
+      "s_add_u32 s92, s92, s93\n\t"
+      "s_add_u32 %[L], %[L], s94\n\t"
+      "v_subrev_u32_e32 %[vnb], s92, %[vnb]\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], s92\n\t"
+      "v_cmp_lt_u32_e32 vcc, 32, %[vnb]\n\t"
+      "s_cbranch_vccz L_iw_refill2_%=\n"
+      // first-level distance lookup, its fields on the vector unit
       "L_iw_have2_%=:\n\t"
-      "v_alignbit_b32 %[vw], %[vhi], %[vlo], %[vsh]\n\t"
-      "v_and_b32_e32 %[vt0], 0xff, %[vw]\n\t"
-      "v_lshl_add_u32 %[vt0], %[vt0], 2, %[vdist]\n\t"
+      "s_and_b32 s92, s90, 0xff\n\t"
+      "v_lshl_add_u32 %[vt0], s92, 2, %[vdist]\n\t"
       "ds_read_b32 %[ve], %[vt0]\n\t"
+      "s_add_u32 s93, %[pos], %[L]\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
       "v_and_b32_e32 %[vn], 15, %[ve]\n\t"
-      "v_cmp_ne_u32_e32 vcc, 0, %[vn]\n\t"
-      "s_cbranch_vccz L_iw_distslow_%=\n\t"
       "v_bfe_u32 %[vt1], %[ve], 4, 4\n\t"
-      "v_lshrrev_b32_e32 %[vt0], %[vn], %[vw]\n\t"
+      "v_cmp_ne_u32_e32 vcc, 0, %[vn]\n\t"
+      "v_lshrrev_b32_e64 %[vt0], %[vn], s90\n\t"
+      "s_cbranch_vccz L_iw_distslow_%=\n\t"
       "v_lshrrev_b32_e32 %[vD], 16, %[ve]\n\t"
       "v_bfe_u32 %[vt0], %[vt0], 0, %[vt1]\n\t"
-      "v_add3_u32 %[vsh], %[vsh], %[vn], %[vt1]\n\t"
+      "v_add_u32_e32 %[vn], %[vn], %[vt1]\n\t"
       "v_add_u32_e32 %[vD], %[vD], %[vt0]\n\t"
+      "v_readfirstlane_b32 s92, %[vn]\n\t"
+      "v_sub_u32_e32 %[vnb], %[vnb], %[vn]\n\t"
       // the fast copy takes D >= L, D <= pos, pos + L <= isize (L >= 3 by the table)
-      "v_cmp_lt_u32_e32 vcc, %[vD], %[vL]\n\t"
-      "v_add_u32_e32 %[vt0], %[pos], %[vL]\n\t"
+      "v_cmp_gt_u32_e32 vcc, %[L], %[vD]\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], s92\n\t"
       "s_cbranch_vccnz L_iw_match5_%=\n\t"
       "v_cmp_lt_u32_e32 vcc, %[pos], %[vD]\n\t"
-      "v_readfirstlane_b32 %[L], %[vL]\n\t"
+      "s_cmp_gt_u32 s93, %[isize]\n\t"
       "s_cbranch_vccnz L_iw_match5_%=\n\t"
-      "v_cmp_lt_u32_e32 vcc, %[isize], %[vt0]\n\t"
-      "v_sub_u32_e32 %[vw], %[pos], %[vD]\n\t"
-      "s_cbranch_vccnz L_iw_match5_%=\n\t"
+      "s_cbranch_scc1 L_iw_match5_%=\n\t"
+      "v_sub_u32_e32 %[vsrc], %[pos], %[vD]\n\t"
       // staged literals first (the match may read them)
       "s_cmp_lt_u32 %[fpos], %[pos]\n\t"
       "s_cbranch_scc0 L_iw_copy_%=\n\t"
@@ -557,30 +569,46 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "v_or_b32_e32 %[vt1], s94, %[vlane]\n\t"
       "v_cndmask_b32_e32 %[vt1], %[voob], %[vt1], vcc\n\t"
       "buffer_store_byte %[pend], %[vt1], %[rsrc], 0 offen\n"
-      // rounds of 64 bytes: store what the previous round / match loaded, load this round's bytes (vw = pos - D)
+      // the first 64 bytes: store what the previous match loaded, load this match's bytes (a lane beyond L loads a byte nobody
+      // uses -- the descriptor bounds it -- and its store address is out of range)
       "L_iw_copy_%=:\n\t"
-      "s_mov_b32 s94, 0\n"
-      "L_iw_round_%=:\n\t"
-      "v_add_u32_e32 %[vt0], s94, %[vlane]\n\t"
-      "v_cmp_gt_u32_e32 vcc, %[L], %[vt0]\n\t"
-      "v_add_u32_e32 %[vt1], %[vw], %[vt0]\n\t"
-      "v_add_u32_e32 %[vt0], %[pos], %[vt0]\n\t"
-      "v_cndmask_b32_e32 %[vt1], %[voob], %[vt1], vcc\n\t"
-      "v_cndmask_b32_e32 %[vt0], %[voob], %[vt0], vcc\n\t"
+      "v_cmp_gt_u32_e32 vcc, %[L], %[vlane]\n\t"
+      "v_add_u32_e32 %[vt1], %[vsrc], %[vlane]\n\t"
+      "v_add_u32_e32 %[vt0], %[pos], %[vlane]\n\t"
       IW_EXP_WAIT
       IW_EXP_COPY
-      "v_mov_b32_e32 %[paddr], %[vt0]\n\t"
-      "s_add_u32 s94, s94, 64\n\t"
-      "s_cmp_lt_u32 s94, %[L]\n\t"
-      "s_cbranch_scc1 L_iw_round_%=\n\t"
+      "v_cndmask_b32_e32 %[paddr], %[voob], %[vt0], vcc\n\t"
+      "s_cmp_gt_u32 %[L], 64\n\t"
+      "s_cbranch_scc1 L_iw_more_%=\n"
+      "L_iw_copied_%=:\n\t"
       "s_add_u32 %[pos], %[pos], %[L]\n\t"
       "s_mov_b32 %[fpos], %[pos]\n\t"
       "s_branch L_iw_loop_%=\n"
-      // ---- exits
-      "L_iw_window_%=:\n\t"
-      "s_mov_b32 %[code], 1\n\t"
-      "s_branch L_iw_end_%=\n"
-      "L_iw_windowL_%=:\n\t"
+      // ---- rarer paths
+      "L_iw_more_%=:\n\t"
+      "s_mov_b32 s94, 64\n"
+      "L_iw_round_%=:\n\t"
+      "v_add_u32_e32 %[vt0], s94, %[vlane]\n\t"
+      "v_cmp_gt_u32_e32 vcc, %[L], %[vt0]\n\t"
+      "v_add_u32_e32 %[vt1], %[vsrc], %[vt0]\n\t"
+      "v_add_u32_e32 %[vt0], %[pos], %[vt0]\n\t"
+      IW_EXP_WAIT
+      IW_EXP_COPY
+      "v_cndmask_b32_e32 %[paddr], %[voob], %[vt0], vcc\n\t"
+      "s_add_u32 s94, s94, 64\n\t"
+      "s_cmp_lt_u32 s94, %[L]\n\t"
+      "s_cbranch_scc1 L_iw_round_%=\n\t"
+      "s_branch L_iw_copied_%=\n"
+      "L_iw_refill2_%=:\n\t"
+      "v_readlane_b32 s92, %[cur], %[wi]\n\t"
+      "v_readfirstlane_b32 s94, %[vnb]\n\t"
+      "s_mov_b32 s93, 0\n\t"
+      "s_add_u32 %[wi], %[wi], 1\n\t"
+      "v_add_u32_e32 %[vnb], 32, %[vnb]\n\t"
+      "s_lshl_b64 s[92:93], s[92:93], s94\n\t"
+      "s_or_b64 s[90:91], s[90:91], s[92:93]\n\t"
+      "s_cmp_eq_u32 %[wi], 64\n\t"
+      "s_cbranch_scc0 L_iw_have2_%=\n\t"
       "s_mov_b32 %[code], 6\n\t"
       "s_branch L_iw_end_%=\n"
       "L_iw_distslow_%=:\n\t"
@@ -591,21 +619,16 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "s_branch L_iw_end_%=\n"
       "L_iw_other_%=:\n\t"
       "s_mov_b32 %[code], 0\n"
-      // the caller may read or write the output itself: nothing stays pending; the uniform state goes back to scalar registers
+      // the caller may read or write the output itself: nothing stays pending; the vector-held state goes back to scalar registers
       "L_iw_end_%=:\n\t"
       "s_waitcnt vmcnt(0)\n\t"
       "buffer_store_byte %[pdata], %[paddr], %[rsrc], 0 offen\n\t"
       "v_mov_b32_e32 %[paddr], %[voob]\n\t"
-      "v_readfirstlane_b32 %[lo], %[vlo]\n\t"
-      "v_readfirstlane_b32 %[hi], %[vhi]\n\t"
-      "v_readfirstlane_b32 %[sh], %[vsh]\n\t"
-      "v_readfirstlane_b32 %[e], %[ve]\n\t"
-      "v_readfirstlane_b32 %[L], %[vL]\n\t"
+      "v_readfirstlane_b32 %[nb], %[vnb]\n\t"
       "v_readfirstlane_b32 %[D], %[vD]\n\t"
-      : [lo] "+s"(br.lo), [hi] "+s"(br.hi), [sh] "+s"(br.sh), [wi] "+s"(br.widx), [pos] "+s"(o.pos), [fpos] "+s"(o.fpos), [pend] "+v"(o.pend.x),
+      : "+{s[90:91]}"(br.bb), [nb] "+s"(br.nbits), [wi] "+s"(br.widx), [pos] "+s"(o.pos), [fpos] "+s"(o.fpos), [pend] "+v"(o.pend.x),
         [pdata] "+v"(o.pdata.x), [paddr] "+v"(o.paddr.x), [e] "=&s"(e), [code] "=&s"(code), [L] "+s"(L), [D] "+s"(D),
-        [vlo] "=&v"(vlo), [vhi] "=&v"(vhi), [vsh] "=&v"(vsh), [vw] "=&v"(vw), [ve] "=&v"(ve), [vn] "=&v"(vn), [vt0] "=&v"(vt0), [vt1] "=&v"(vt1),
-        [vL] "=&v"(vL), [vD] "=&v"(vD)
+        [vnb] "=&v"(vnb), [ve] "=&v"(ve), [vn] "=&v"(vn), [vt0] "=&v"(vt0), [vt1] "=&v"(vt1), [vD] "=&v"(vD), [vsrc] "=&v"(vsrc)
       : [cur] "v"(br.cur.x), [vlit] "v"(vlit), [vdist] "v"(vdist), [vlane] "v"(vlane), [voob] "v"(IW_OOB), [isize] "s"(o.isize), [rsrc] "s"(o.out.r),
         [litmask] "i"((1 << IW_LIT_ROOT) - 1)
       : "s92", "s93", "s94", "s95", "vcc", "scc", "memory");
@@ -629,7 +652,7 @@ IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t
     const uint32_t bfinal = br.bits(1), btype = br.bits(2);
     if (btype == 3u) return IW_ERR_DATA;
     if (btype == 0u) {
-      br.bits((0u - br.sh) & 7u);                               // to the next byte boundary
+      br.bits(br.nbits & 7u);                                   // to the next byte boundary
       br.refill();
       const uint32_t len = br.bits(16);
       br.refill();
@@ -671,7 +694,7 @@ IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t
         uint32_t i = 0, prev = 0;
         while (i < n) {
           br.refill();
-          const uint32_t e = IW_U(S.cl.cl_tab[br.peek() & ((1u << IW_CL_ROOT) - 1u)]);
+          const uint32_t e = IW_U(S.cl.cl_tab[(uint32_t)br.bb & ((1u << IW_CL_ROOT) - 1u)]);
           if (!(e & 15u)) return IW_ERR_DATA;
           br.bits(e & 15u);
           const uint32_t s = iw_val(e);
@@ -726,7 +749,7 @@ IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t
         if (code == 7u) { why = IW_ERR_SIZE; break; }
         if (code == 0u) {
           if (!(e & 15u)) {
-            e = iw_slow<IW_LENS>(br.peek(), S.ll_limit, S.ll_delta, S.ll_sorted, 288u, IW_LIT_ROOT);
+            e = iw_slow<IW_LENS>(br.bb, S.ll_limit, S.ll_delta, S.ll_sorted, 288u, IW_LIT_ROOT);
             if (!e) { why = IW_ERR_DATA; break; }
           }
           br.bits(e & 15u);
@@ -745,9 +768,9 @@ IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t
         }
         if (code == 6u) { br.rotate(); code = 4u; }
         if (code == 4u) {                                       // distance code: first-level table or the canonical search
-          uint32_t d = IW_U(S.dist_tab[br.peek() & ((1u << IW_DIST_ROOT) - 1u)]);
+          uint32_t d = IW_U(S.dist_tab[(uint32_t)br.bb & ((1u << IW_DIST_ROOT) - 1u)]);
           if (!(d & 15u)) {
-            d = iw_slow<IW_DISTS>(br.peek(), S.d_limit, S.d_delta, S.d_sorted, 32u, IW_DIST_ROOT);
+            d = iw_slow<IW_DISTS>(br.bb, S.d_limit, S.d_delta, S.d_sorted, 32u, IW_DIST_ROOT);
             if (!d) { why = IW_ERR_DATA; break; }
           }
           br.bits(d & 15u);
