@@ -2,7 +2,7 @@
 // htslib on one thread; SURVEY section 8f N3.
 //
 // A BAM file is a sequence of independent BGZF blocks (RFC 1951 DEFLATE streams of <= 64 KiB each).
-//   inflate_kernel : ONE WAVE per BGZF block (inflate_wave.h): wave-uniform symbol loop on the scalar unit, first-level
+//   inflate_kernel : ONE WAVE per BGZF block (inflate_wave.h): wave-uniform symbol loop split between the scalar and the vector unit, first-level
 //                    Huffman tables in LDS built by the 64 lanes together, input through a lane-register window, literals
 //                    through a lane register, LZ77 matches copied by the whole wave.  stored / fixed / dynamic blocks,
 //                    multi-block streams.  A block the decoder refuses is flagged in status[] (the host hands exactly those
@@ -153,7 +153,8 @@ int strl_inflate_device(strl_ctx *c, const uint8_t *d_comp, uint64_t readable, c
                         const uint32_t *d_isize, uint32_t n_blocks, uint8_t *d_out, uint32_t *d_err, uint8_t *d_status, hipStream_t st) {
   if (!n_blocks) return STRL_OK;
   InflateParams P{d_comp, readable & ~(uint64_t)3, d_coff, d_clen, d_uoff, d_isize, n_blocks, d_out, d_err, d_status};
-  hipLaunchKernelGGL(inflate_kernel, dim3(n_blocks), dim3(64), 0, st, P);
+  static const unsigned lds_pad = getenv("STRL_INFLATE_LDS_PAD") ? (unsigned)atoi(getenv("STRL_INFLATE_LDS_PAD")) : 0u;   // (occupancy experiments: unused dynamic LDS)
+  hipLaunchKernelGGL(inflate_kernel, dim3(n_blocks), dim3(64), lds_pad, st, P);
   STRL_HIP(hipGetLastError());
   return STRL_OK;
 }

@@ -393,8 +393,10 @@ struct IwOut {
 // ~300 cycles and a match ~950 with six waves per SIMD whatever the mix, ~15 cycles per instruction of the wave's own
 // in-order stream -- the dependent chain index -> LDS lookup -> fields -> shift -> next index, one issue turn per instruction,
 // with 61 % of the wave-cycles parked on s_waitcnt.  Removing the copy's waits altogether gives 100 GB/s, the copy itself
-// 97 (inflate_exp_waits.txt); header parse + table build are 3.6 % (inflate_exp_header_only.txt).  What did pay: a 9-bit first
-// level (+9 %).  The split form is kept: fewest registers, no M0.
+// 97 (inflate_exp_waits.txt); header parse + table build are 3.6 % (inflate_exp_header_only.txt).  Throughput follows the
+// waves per CU almost linearly up to 28 and is flat beyond (inflate_occupancy.txt: 4 / 8 / 16 / 24 / 28 / 32 waves: 22 / 40 / 70 /
+// 87 / 95 / 95 GB/s), so what did pay is a 9-bit first level: 4.4 KB of LDS per wave instead of 6.4, 28 waves instead of 24
+// (+9 %).  The split form is kept: fewest registers, no M0.
 //   scalar: the 64-bit bit buffer and its shifts, the table index, the length code's fields, the output position;
 //   vector: the bit count, the table address + lookup, the literal's placement, the distance code's fields, the checks against
 //           the vector-held distance, the copy;
