@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--e2e-pairs", type=int, default=2 ** 23, help="pairs of the BAM file the end-to-end leg decodes")
+    ap.add_argument("--e2e-pairs", type=int, default=2 ** 26, help="pairs of the BAM file the end-to-end leg runs `strling extract` / `call` / `merge` on (2^26 pairs = 1.3e8 reads, ~2 min to write at zlib level 6 on 16 cores; the 2^29-read run is profiles/r04/e2e_full.json)")
     ap.add_argument("--cache", default="", help="directory to keep the generated batch in (profiling runs reload it instead of forking generators)")
     args = ap.parse_args()
 
@@ -67,6 +67,16 @@ def main():
             e2e = end_to_end(args.e2e_pairs)
         except Exception as e:
             e2e = {"error": str(e)[:300]}
+
+    # the same on the whole-genome sized file (2^29 reads): measured by tools/e2e_bench.py on the GPU box, committed, quoted here
+    e2e_full = None
+    if rank == 0 and world == 1:
+        try:
+            e2e_full = json.load(open(os.path.join(ROOT, "profiles", "r04", "e2e_full.json")))
+            e2e_full = {k: e2e_full[k] for k in e2e_full if k not in ("note",)}
+            e2e_full["from_committed_profile"] = "profiles/r04/e2e_full.json (python tools/e2e_bench.py 268435456 --check-slabs 64 --repeats 2 on the GPU box; ~8 min to write the file)"
+        except Exception:
+            e2e_full = None
 
     # ---- synthetic S1 batch: DISTINCT reads, generated before the GPU runtime starts (worker processes fork) ----
     from strling_amd import synth
@@ -353,6 +363,11 @@ def main():
         try:
             cpu_nproc = cpu_baseline_nproc(max(4.0, args.cpu_seconds / 2))
             cpu_e2e = cpu_baseline_e2e(cpu["value"])
+            for blk in (e2e, e2e_full):
+                if blk and blk.get("reads_per_s_extract_plus_call") and cpu_e2e:
+                    blk["vs_cpu_baseline_e2e_extract_plus_call"] = round(blk["reads_per_s_extract_plus_call"] / cpu_e2e["with_call"], 1)
+                if blk and blk.get("value") and cpu_e2e and blk is not e2e:
+                    blk["vs_cpu_baseline_e2e_wall"] = round(blk["value"] / cpu_e2e["value"], 1)
             if e2e and "runs" in e2e and cpu_e2e:
                 e2e["vs_cpu_baseline_e2e_wall"] = round(e2e["value"] / cpu_e2e["value"], 1)
                 best = max(e2e["runs"], key=lambda x: x["reads_per_s_wall"])
@@ -382,7 +397,7 @@ def main():
                        "parallelism": (f"records sharded over {world} GPU(s), no data-path collective" if exchange is None else
                                        f"records sharded over {world} GPUs; per step one RCCL all-gather of the tread arrays [{type(exchange).__name__}] "
                                        f"({exchange.pad * 32} B per rank) before clustering, every rank clusters the (tid, unit) groups it owns")},
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_nproc": cpu_nproc, "cpu_baseline_e2e": cpu_e2e, "end_to_end": e2e,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_nproc": cpu_nproc, "cpu_baseline_e2e": cpu_e2e, "end_to_end": e2e, "end_to_end_full_size": e2e_full,
         }
         print(json.dumps(out))
     if world > 1:
@@ -433,15 +448,17 @@ def cpu_baseline_nproc(seconds):
 
 def cpu_baseline_e2e(oracle_reads_per_s):
     """what the reference's threads=0 run does per read, on one core: inflate the BGZF blocks with zlib, then the extract loop.
-    Inflate is timed on the blocks of a synthetic BAM (same writer as end_to_end), the loop rate is cpu_baseline's; record
-    parsing (htslib bam_read1) is not charged."""
+    Inflate is timed on the blocks of a synthetic BAM written like end_to_end's (zlib level 6, binned qualities, aux tags), the
+    loop rate is cpu_baseline's; record parsing (htslib bam_read1) is not charged.  `with_call` adds what `strling call` does on
+    the .bin per read of the file (the oracle's call over an in-memory slab: its region reads cost no inflate, the reference's do)."""
     import zlib
-    from strling_amd import bamio, synth
+    from strling_amd import bamio
+    from oracle import oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import inflate_bench
-    rec, _ = synth.synth_wgs_30x(1, 2 ** 16, seed=77)
-    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "cpu_e2e_sample.bam")
-    bamio.write_bam(path, rec, level=1, index=False)
+    d = os.environ.get("TMPDIR", "/tmp")
+    path = os.path.join(d, "cpu_e2e_sample.bam")
+    info = bamio.write_bam_slabs(path, 1, 2 ** 16, seed=77, level=6, quals=True, aux=True, index=False, procs=1)
     streams, sizes = inflate_bench.bam_blocks(path)
     os.remove(path)
     t0 = time.perf_counter()
@@ -451,12 +468,26 @@ def cpu_baseline_e2e(oracle_reads_per_s):
             zlib.decompress(s_, -15)
         n += 1
     t_inf = (time.perf_counter() - t0) / n
-    inflate_rps = rec.n / t_inf
+    inflate_rps = info["reads"] / t_inf
     value = 1.0 / (1.0 / inflate_rps + 1.0 / oracle_reads_per_s)
-    return {"value": round(value, 1), "unit": "reads/s", "cores": 1, "kind": "port",
-            "parts": {"zlib_inflate_reads_per_s": round(inflate_rps, 1), "zlib_inflate_GBps": round(sum(sizes) / t_inf / 1e9, 3), "extract_loop_reads_per_s": oracle_reads_per_s},
-            "sample": f"single thread: zlib inflate of the {len(streams)} BGZF blocks of a {rec.n}-read synthetic BAM (level 1, the end_to_end writer) + cpu_baseline's "
-                      f"extract/cluster rate, combined per read (1 / (1/inflate + 1/loop)); the like-for-like denominator of end_to_end"}
+    # `strling call` on the CPU: cluster + evidence + genotypes over the slab's own treads
+    rec, g = bamio.slab_records(0, 1, 2 ** 16, 77)
+    from strling_amd import synth
+    frag = synth.frag_hist(rec)
+    t = O.extract(rec, g, O.make_opts(O.median(frag), 0.8, 40))
+    t1 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t1 < 2.0:
+        O.call(t, rec, frag)
+        k += 1
+    call_s_per_read = (time.perf_counter() - t1) / k / rec.n
+    with_call = 1.0 / (1.0 / value + call_s_per_read)
+    return {"value": round(value, 1), "unit": "reads/s", "cores": 1, "kind": "port", "with_call": round(with_call, 1),
+            "parts": {"zlib_inflate_reads_per_s": round(inflate_rps, 1), "zlib_inflate_GBps": round(sum(sizes) / t_inf / 1e9, 3), "extract_loop_reads_per_s": oracle_reads_per_s,
+                      "call_s_per_read": call_s_per_read},
+            "sample": f"single thread: zlib inflate of the {len(streams)} BGZF blocks of a {info['reads']}-read synthetic BAM (zlib level 6, binned qualities, aux tags: the "
+                      f"end_to_end writer) + cpu_baseline's extract/cluster rate, combined per read (1 / (1/inflate + 1/loop)); the like-for-like denominator of "
+                      f"end_to_end.  with_call: + the oracle's `call` (cluster, spanning evidence, genotypes) per read of the file"}
 
 
 def end_to_end(n_pairs, check_slabs=4):

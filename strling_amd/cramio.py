@@ -1,0 +1,549 @@
+"""CRAM 3.0 writer for tests (pure Python; htslib / samtools are not available here).
+
+Writes a spec-conformant CRAM v3.0 (CRAMv3.pdf: file definition, containers, slices, blocks, the compression header's
+preservation / data-series / tag maps, the record layout of section 10, rANS 4x8 of section 13) from a records.RecordBatch
+and a reference, so that the `strling` CLI's CRAM reader (csrc/cli/cram_reader.cpp: `strling extract -f FASTA x.cram`,
+extract.nim:253,278-279) can be exercised end to end.  Deliberately VARIED rather than compact: data series go through
+EXTERNAL blocks stored raw / gzip / rANS order 0 / rANS order 1 in rotation and through the core bit stream (HUFFMAN with one
+and with several symbols, BETA, GAMMA, SUBEXP), pairs inside a slice are linked "mate downstream", pairs across slices are
+"detached", bases come from the reference plus substitution / base / insertion / soft-clip / deletion / skip features.
+Test infrastructure: nothing here is used by the product.
+"""
+import gzip
+import struct
+import zlib
+
+import numpy as np
+
+NT16 = "=ACMGRSVTWYHKDBN"
+EOF_V3 = bytes.fromhex("0f000000ffffffff0fe0454f4600000000010005bdd94f0001000606010001000100ee63014b")
+
+
+def itf8(v):
+    v &= 0xFFFFFFFF
+    if v < 0x80:
+        return bytes([v])
+    if v < 0x4000:
+        return bytes([0x80 | (v >> 8), v & 0xFF])
+    if v < 0x200000:
+        return bytes([0xC0 | (v >> 16), (v >> 8) & 0xFF, v & 0xFF])
+    if v < 0x10000000:
+        return bytes([0xE0 | (v >> 24), (v >> 16) & 0xFF, (v >> 8) & 0xFF, v & 0xFF])
+    return bytes([0xF0 | ((v >> 28) & 0x0F), (v >> 20) & 0xFF, (v >> 12) & 0xFF, (v >> 4) & 0xFF, v & 0x0F])
+
+
+def ltf8(v):
+    v &= (1 << 64) - 1
+    if v < 0x80:
+        return bytes([v])
+    for n in range(1, 8):                      # n extra bytes
+        if v < (1 << (7 * (n + 1))):
+            lead = (0xFF << (8 - n)) & 0xFF
+            return bytes([lead | (v >> (8 * n))]) + (v & ((1 << (8 * n)) - 1)).to_bytes(n, "big")
+    return bytes([0xFF]) + v.to_bytes(8, "big")
+
+
+# ---- rANS 4x8 (CRAMv3 section 13; the encoder mirrors the decoder's interleaving: states 0..3 take symbols i, i+1, i+2, i+3) ----
+RANS_L = 1 << 23
+TF = 12
+
+
+def _norm_freqs(cnt):
+    """counts -> frequencies summing to 4096, every present symbol >= 1"""
+    tot = int(cnt.sum())
+    F = np.zeros(256, np.int64)
+    if tot == 0:
+        return F
+    nz = np.nonzero(cnt)[0]
+    F[nz] = np.maximum(1, (cnt[nz].astype(np.int64) * 4096) // tot)
+    d = 4096 - int(F.sum())
+    big = int(nz[np.argmax(F[nz])])
+    F[big] += d
+    if F[big] < 1:                                # (pathological: hundreds of rare symbols) take from others instead
+        F[big] = 1
+        d = 4096 - int(F.sum())
+        for s in sorted(nz, key=lambda s: -F[s]):
+            take = min(int(F[s]) - 1, -d)
+            F[s] -= take
+            d += take
+            if d == 0:
+                break
+    assert F.sum() == 4096 and (F[nz] >= 1).all()
+    return F
+
+
+def _freq_table(F):
+    """the run-length coded symbol / frequency list of one context"""
+    out = bytearray()
+    syms = [int(s) for s in np.nonzero(F)[0]]
+    rle = 0
+    for k, s in enumerate(syms):
+        if rle:
+            rle -= 1
+        else:
+            out.append(s)
+            if k and syms[k - 1] == s - 1:
+                run = 0
+                while k + 1 + run < len(syms) and syms[k + 1 + run] == s + 1 + run:
+                    run += 1
+                out.append(run)
+                rle = run
+        f = int(F[s])
+        if f < 128:
+            out.append(f)
+        else:
+            out += bytes([128 | (f >> 8), f & 0xFF])
+    out.append(0)
+    return bytes(out)
+
+
+def _put(x, emit, start, freq):
+    x_max = ((RANS_L >> TF) << 8) * freq
+    while x >= x_max:
+        emit.append(x & 0xFF)
+        x >>= 8
+    return ((x // freq) << TF) + (x % freq) + start
+
+
+def rans_encode(data, order):
+    data = bytes(data)
+    n = len(data)
+    if order == 1 and n < 4:
+        order = 0
+    a = np.frombuffer(data, np.uint8)
+    emit = []                                         # bytes in the order the (backwards writing) encoder produces them
+    R = [RANS_L] * 4
+    if order == 0:
+        F = _norm_freqs(np.bincount(a, minlength=256))
+        C = np.concatenate([[0], np.cumsum(F)[:-1]])
+        table = _freq_table(F)
+        tail = n & 3
+        for k in range(tail - 1, -1, -1):             # the last n & 3 symbols belong to states 0 .. tail-1
+            s = data[n - tail + k]
+            R[k] = _put(R[k], emit, int(C[s]), int(F[s]))
+        for i in range(n - tail, 0, -4):
+            for k in (3, 2, 1, 0):
+                s = data[i - 4 + k]
+                R[k] = _put(R[k], emit, int(C[s]), int(F[s]))
+    else:
+        q = n >> 2
+        cnt = np.zeros((256, 256), np.int64)
+        prev = np.concatenate([[0], a[:-1]]).astype(np.int64)
+        for k in range(4):                            # every quarter starts in context 0
+            prev[k * q] = 0
+        np.add.at(cnt, (prev, a), 1)
+        Fs = {c: _norm_freqs(cnt[c]) for c in np.nonzero(cnt.sum(axis=1))[0]}
+        Cs = {c: np.concatenate([[0], np.cumsum(F)[:-1]]) for c, F in Fs.items()}
+        table = bytearray()
+        ctxs = sorted(int(c) for c in Fs)
+        rle = 0
+        for k, c in enumerate(ctxs):
+            if rle:
+                rle -= 1
+            else:
+                table.append(c)
+                if k and ctxs[k - 1] == c - 1:
+                    run = 0
+                    while k + 1 + run < len(ctxs) and ctxs[k + 1 + run] == c + 1 + run:
+                        run += 1
+                    table.append(run)
+                    rle = run
+            table += _freq_table(Fs[c])
+        table.append(0)
+        table = bytes(table)
+        # the remainder behind the four quarters belongs to state 3
+        for i in range(n - 1, 4 * q - 1, -1):
+            c = int(prev[i])
+            R[3] = _put(R[3], emit, int(Cs[c][data[i]]), int(Fs[c][data[i]]))
+        for j in range(q - 1, -1, -1):
+            for k in (3, 2, 1, 0):
+                i = k * q + j
+                c = int(prev[i])
+                R[k] = _put(R[k], emit, int(Cs[c][data[i]]), int(Fs[c][data[i]]))
+    for k in (3, 2, 1, 0):                            # flush: state 0 ends up first in the stream
+        x = R[k]
+        emit += [(x >> 24) & 0xFF, (x >> 16) & 0xFF, (x >> 8) & 0xFF, x & 0xFF]
+    body = table + bytes(reversed(emit))
+    return bytes([order]) + struct.pack("<II", len(body), n) + body
+
+
+# ---- blocks, encodings ----------------------------------------------------------------------------------------------
+RAW, GZIP, RANS = 0, 1, 4
+FILE_HEADER, COMPRESSION_HEADER, SLICE_HEADER, EXTERNAL_DATA, CORE_DATA = 0, 1, 2, 4, 5
+
+
+def block(method, content_type, content_id, raw):
+    raw = bytes(raw)
+    if method == GZIP:
+        data = gzip.compress(raw, 6, mtime=0)
+    elif method == (RANS, 0):
+        data, method = rans_encode(raw, 0), RANS
+    elif method == (RANS, 1):
+        data, method = rans_encode(raw, 1), RANS
+    else:
+        data, method = raw, RAW
+    b = bytes([method, content_type]) + itf8(content_id) + itf8(len(data)) + itf8(len(raw)) + data
+    return b + struct.pack("<I", zlib.crc32(b) & 0xFFFFFFFF)
+
+
+def enc_external(cid):
+    return itf8(1) + itf8(len(itf8(cid))) + itf8(cid)
+
+
+def enc_stop(stop, cid):
+    p = bytes([stop]) + itf8(cid)
+    return itf8(5) + itf8(len(p)) + p
+
+
+def enc_len(len_enc, val_enc):
+    p = len_enc + val_enc
+    return itf8(4) + itf8(len(p)) + p
+
+
+def enc_huffman(symbols, lengths):
+    p = itf8(len(symbols)) + b"".join(itf8(s) for s in symbols) + itf8(len(lengths)) + b"".join(itf8(l) for l in lengths)
+    return itf8(3) + itf8(len(p)) + p
+
+
+def enc_beta(offset, nbits):
+    p = itf8(offset) + itf8(nbits)
+    return itf8(6) + itf8(len(p)) + p
+
+
+def enc_gamma(offset):
+    p = itf8(offset)
+    return itf8(9) + itf8(len(p)) + p
+
+
+def enc_subexp(offset, k):
+    p = itf8(offset) + itf8(k)
+    return itf8(7) + itf8(len(p)) + p
+
+
+class Bits:
+    """the core data block: most significant bit first"""
+
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def put(self, v, nbits):
+        for k in range(nbits - 1, -1, -1):
+            self.acc = (self.acc << 1) | ((v >> k) & 1)
+            self.n += 1
+            if self.n == 8:
+                self.out.append(self.acc)
+                self.acc, self.n = 0, 0
+
+    def done(self):
+        if self.n:
+            self.out.append(self.acc << (8 - self.n))
+            self.acc, self.n = 0, 0
+        return bytes(self.out)
+
+
+def canonical_codes(symbols, lengths):
+    """CRAM / DEFLATE-style canonical codes: by (length, symbol value)"""
+    order = sorted(range(len(symbols)), key=lambda i: (lengths[i], symbols[i]))
+    codes, code, prev = {}, 0, lengths[order[0]]
+    for i in order:
+        code <<= lengths[i] - prev
+        prev = lengths[i]
+        codes[symbols[i]] = (code, lengths[i])
+        code += 1
+    return codes
+
+
+def huffman_lengths(freq):
+    """code lengths of a Huffman code over {symbol: count} (package-free: plain tree merge)"""
+    import heapq
+    if len(freq) == 1:
+        return {next(iter(freq)): 0}
+    h = [(c, i, (s,)) for i, (s, c) in enumerate(sorted(freq.items()))]
+    heapq.heapify(h)
+    depth = {s: 0 for s in freq}
+    k = len(h)
+    while len(h) > 1:
+        a, b = heapq.heappop(h), heapq.heappop(h)
+        for s in a[2] + b[2]:
+            depth[s] += 1
+        heapq.heappush(h, (a[0] + b[0], k, a[2] + b[2]))
+        k += 1
+    return depth
+
+
+# content ids of the external blocks
+CID = dict(BF=1, RL=3, AP=4, RN=6, MF=7, NS=8, NP=9, TS=10, NF=11, FC=14, FP=15, BS=17, IN=18, IN_LEN=19, SC=20, HC=21, PD=22, RS=23, BA=25, QS=26, RI=27)
+METHODS = [RAW, GZIP, (RANS, 0), (RANS, 1)]
+SUBST_ALT = {"A": "CGTN", "C": "AGTN", "G": "ACTN", "T": "ACGN", "N": "ACGT"}
+
+
+def _ref_len(cig):
+    return sum(int(c) >> 4 for c in cig if (int(c) & 15) in (0, 2, 3, 7, 8))
+
+
+def _seq(rec, i):
+    so, L = int(rec.seq_off[i]), int(rec.l_seq[i])
+    b = rec.seq4[so:so + (L + 1) // 2]
+    s = np.empty(2 * b.size, np.uint8)
+    s[0::2], s[1::2] = b >> 4, b & 15
+    return "".join(NT16[int(x)] for x in s[:L])
+
+
+def make_reference(rec, seed=1):
+    """a reference the synthetic reads partly agree with: every position takes the base of the first mapped read that covers it
+    with an M operation (other reads disagree there and get substitution features), the rest is random"""
+    rng = np.random.default_rng(seed)
+    refs = [np.frombuffer(bytes(rng.choice(list(b"ACGT"), ln)), np.uint8).copy() for _, ln in rec.targets]
+    done = [np.zeros(ln, bool) for _, ln in rec.targets]
+    for i in range(rec.n):
+        t = int(rec.tid[i])
+        if t < 0 or int(rec.flag[i]) & 4:
+            continue
+        s = _seq(rec, i)
+        rp, qp = int(rec.pos[i]), 0
+        for c in rec.cigar[int(rec.cigar_off[i]):int(rec.cigar_off[i + 1])]:
+            op, ln = int(c) & 15, int(c) >> 4
+            if op in (0, 7, 8):
+                for k in range(ln):
+                    if 0 <= rp + k < refs[t].size and not done[t][rp + k] and s[qp + k] in "ACGT":
+                        refs[t][rp + k] = ord(s[qp + k])
+                        done[t][rp + k] = True
+                rp += ln; qp += ln
+            elif op in (1, 4):
+                qp += ln
+            elif op in (2, 3):
+                rp += ln
+    return [r.tobytes() for r in refs]
+
+
+def write_fasta(path, targets, refs, width=60):
+    with open(path, "wb") as f, open(path + ".fai", "w") as fai:
+        for (name, ln), seq in zip(targets, refs):
+            f.write(b">" + name.encode() + b"\n")
+            off = f.tell()
+            for o in range(0, len(seq), width):
+                f.write(seq[o:o + width] + b"\n")
+            fai.write(f"{name}\t{ln}\t{off}\t{width}\t{width + 1}\n")
+
+
+def _pair_tlen(a, b):
+    """template length of two records of one slice as the reader derives it: span from the leftmost start to the rightmost end;
+    positive for the record that starts first (the one flagged first-in-pair when they start together)"""
+    left, right = min(a["pos"], b["pos"]), max(a["end"], b["end"])
+    t = right - left + 1
+    if a["pos"] < b["pos"] or (a["pos"] == b["pos"] and a["flag"] & 0x40):
+        return t, -t
+    return -t, t
+
+
+def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_per_container=2, read_names=True, index=True, ap_delta=True):
+    """records of `rec` (coordinate sorted, unmapped tail last) -> CRAM 3.0 + .crai.  refs[tid] = reference bytes (ACGTN)."""
+    from .bamio import sam_header
+    text = (header_text if header_text is not None else sam_header(rec.targets)).encode()
+    out = bytearray(b"CRAM" + bytes([3, 0]) + b"strling-test".ljust(20, b"\0"))
+
+    def container(ref_id, start, span, n_rec, counter, bases, blocks, landmarks):
+        body = b"".join(blocks)
+        h = itf8(ref_id) + itf8(start) + itf8(span) + itf8(n_rec) + ltf8(counter) + ltf8(bases) + itf8(len(blocks)) + itf8(len(landmarks)) + \
+            b"".join(itf8(x) for x in landmarks)
+        h = struct.pack("<i", len(body)) + h
+        return h + struct.pack("<I", zlib.crc32(h) & 0xFFFFFFFF) + body
+
+    out += container(0, 0, 0, 0, 0, 0, [block(RAW, FILE_HEADER, 0, struct.pack("<i", len(text)) + text)], [0])
+
+    # slices: runs of records on one reference (unmapped tail: -1)
+    slices, i = [], 0
+    while i < rec.n:
+        t = int(rec.tid[i])
+        j = i
+        while j < rec.n and j - i < records_per_slice and int(rec.tid[j]) == t:
+            j += 1
+        slices.append((i, j))
+        i = j
+    crai, counter, method_rot = [], 0, 0
+    for c0 in range(0, len(slices), slices_per_container):
+        group = slices[c0:c0 + slices_per_container]
+        # ---- records of the container as dictionaries ----
+        recs = []
+        for (a, b) in group:
+            rs = []
+            for i in range(a, b):
+                cig = rec.cigar[int(rec.cigar_off[i]):int(rec.cigar_off[i + 1])]
+                unm = bool(int(rec.flag[i]) & 4)
+                pos1 = int(rec.pos[i]) + 1 if int(rec.tid[i]) >= 0 else 0
+                rs.append(dict(i=i, tid=int(rec.tid[i]), pos=pos1, end=pos1 if unm else pos1 + max(_ref_len(cig), 1) - 1,
+                               flag=int(rec.flag[i]), mapq=int(rec.mapq[i]), L=int(rec.l_seq[i]), cig=cig, seq=_seq(rec, i), name=rec.qname(i),
+                               mtid=int(rec.mtid[i]), mpos=int(rec.mpos[i]) + 1 if int(rec.mtid[i]) >= 0 else 0,
+                               tlen=int(rec.isize[i]) if rec.isize is not None else 0, cf=0, nf=0))
+            # pairs inside the slice whose mate fields are what the reader would derive: "mate downstream"; everything else detached
+            by_name = {}
+            for k, r in enumerate(rs):
+                by_name.setdefault(r["name"], []).append(k)
+            for r in rs:
+                r["cf"] = 2 if r["flag"] & 1 else 0
+            for ks in by_name.values():
+                if len(ks) != 2:
+                    continue
+                x, y = rs[ks[0]], rs[ks[1]]
+                if not (x["flag"] & 1 and y["flag"] & 1) or (x["flag"] | y["flag"]) & 0x900 or x["tid"] < 0:
+                    continue
+                tx, ty = _pair_tlen(x, y)
+                ok = (x["mtid"], x["mpos"], y["mtid"], y["mpos"]) == (y["tid"], y["pos"], x["tid"], x["pos"]) and (x["tlen"], y["tlen"]) == (tx, ty)
+                for p, q in ((x, y), (y, x)):
+                    ok = ok and bool(p["flag"] & 0x20) == bool(q["flag"] & 0x10) and bool(p["flag"] & 0x8) == bool(q["flag"] & 0x4)
+                if ok:
+                    x["cf"], x["nf"], y["cf"] = 4, ks[1] - ks[0] - 1, 0
+            recs.append(rs)
+        # ---- compression header ----
+        cf_freq = {}
+        for rs in recs:
+            for r in rs:
+                cf_freq[r["cf"]] = cf_freq.get(r["cf"], 0) + 1
+        cf_len = huffman_lengths(cf_freq)
+        cf_syms = sorted(cf_len)
+        cf_codes = canonical_codes(cf_syms, [cf_len[s] for s in cf_syms]) if len(cf_syms) > 1 else {cf_syms[0]: (0, 0)}
+        pres = b"RN" + bytes([1 if read_names else 0]) + b"AP" + bytes([1 if ap_delta else 0]) + b"RR" + bytes([1]) + b"SM" + bytes([0x1B] * 5) + \
+            b"TD" + itf8(1) + b"\0"
+        pres = itf8(5) + pres
+        ds = {
+            "BF": enc_external(CID["BF"]), "CF": enc_huffman(cf_syms, [cf_len[s] for s in cf_syms]), "RI": enc_external(CID["RI"]),
+            "RL": enc_external(CID["RL"]), "AP": enc_external(CID["AP"]), "RG": enc_huffman([-1], [0]),
+            "RN": enc_stop(0, CID["RN"]), "MF": enc_external(CID["MF"]), "NS": enc_external(CID["NS"]), "NP": enc_external(CID["NP"]),
+            "TS": enc_external(CID["TS"]), "NF": enc_external(CID["NF"]), "TL": enc_huffman([0], [0]), "FN": enc_gamma(1),
+            "FC": enc_external(CID["FC"]), "FP": enc_external(CID["FP"]), "DL": enc_subexp(0, 2), "BS": enc_external(CID["BS"]),
+            "IN": enc_len(enc_external(CID["IN_LEN"]), enc_external(CID["IN"])), "SC": enc_stop(0, CID["SC"]), "HC": enc_external(CID["HC"]),
+            "PD": enc_external(CID["PD"]), "RS": enc_external(CID["RS"]), "MQ": enc_beta(0, 8), "BA": enc_external(CID["BA"]), "QS": enc_external(CID["QS"]),
+        }
+        dsm = itf8(len(ds)) + b"".join(k.encode() + v for k, v in ds.items())
+        tagm = itf8(0)
+        comp_hdr = block(GZIP if c0 % 2 else RAW, COMPRESSION_HEADER, 0, itf8(len(pres)) + pres + itf8(len(dsm)) + dsm + itf8(len(tagm)) + tagm)
+        # ---- slices ----
+        blocks, landmarks, at = [comp_hdr], [], len(comp_hdr)
+        n_rec_c, bases_c = 0, 0
+        c_start, c_end = None, 0
+        slice_meta = []
+        for (a, b), rs in zip(group, recs):
+            ext = {k: bytearray() for k in set(CID.values())}
+            bits = Bits()
+            tid = rs[0]["tid"]
+            mapped = [r for r in rs if r["tid"] >= 0]
+            s_start = min((r["pos"] for r in mapped), default=0)
+            s_end = max((max(r["end"], r["pos"]) for r in mapped), default=0)
+            prev_pos = s_start
+            for r in rs:
+                ext[CID["BF"]] += itf8(r["flag"])
+                code, nb = cf_codes[r["cf"]]
+                bits.put(code, nb)
+                ext[CID["RL"]] += itf8(r["L"])
+                ext[CID["AP"]] += itf8(r["pos"] - prev_pos if ap_delta else r["pos"])
+                prev_pos = r["pos"] if ap_delta else prev_pos
+                if read_names:
+                    ext[CID["RN"]] += r["name"] + b"\0"
+                if r["cf"] & 2:
+                    mf = (1 if r["flag"] & 0x20 else 0) | (2 if r["flag"] & 0x8 else 0)
+                    ext[CID["MF"]] += itf8(mf)
+                    if not read_names:
+                        ext[CID["RN"]] += r["name"] + b"\0"
+                    ext[CID["NS"]] += itf8(r["mtid"])
+                    ext[CID["NP"]] += itf8(r["mpos"])
+                    ext[CID["TS"]] += itf8(r["tlen"])
+                elif r["cf"] & 4:
+                    ext[CID["NF"]] += itf8(r["nf"])
+                # (TL: a one-symbol code, no bits; no tags)
+                if not r["flag"] & 4:
+                    feats = []
+                    ref = refs[r["tid"]]
+                    rp, qp = r["pos"] - 1, 0
+                    for c in r["cig"]:
+                        op, ln = int(c) & 15, int(c) >> 4
+                        if op in (0, 7, 8):
+                            for k in range(ln):
+                                rb = chr(ref[rp + k]).upper() if 0 <= rp + k < len(ref) else "N"
+                                qb = r["seq"][qp + k]
+                                if qb != rb:
+                                    if qb in "ACGTN" and rb in "ACGTN" and qb in SUBST_ALT[rb]:
+                                        feats.append((qp + k + 1, "X", SUBST_ALT[rb].index(qb)))
+                                    else:
+                                        feats.append((qp + k + 1, "B", qb))
+                            rp += ln; qp += ln
+                        elif op == 1:
+                            feats.append((qp + 1, "I", r["seq"][qp:qp + ln])); qp += ln
+                        elif op == 4:
+                            feats.append((qp + 1, "S", r["seq"][qp:qp + ln])); qp += ln
+                        elif op == 2:
+                            feats.append((qp + 1, "D", ln)); rp += ln
+                        elif op == 3:
+                            feats.append((qp + 1, "N", ln)); rp += ln
+                        elif op == 5:
+                            feats.append((qp + 1, "H", ln))
+                        elif op == 6:
+                            feats.append((qp + 1, "P", ln))
+                    # FN: gamma, offset 1
+                    v = len(feats) + 1
+                    nbv = v.bit_length()
+                    bits.put(0, nbv - 1); bits.put(v, nbv)
+                    last = 0
+                    for fp, code, val in feats:
+                        ext[CID["FC"]].append(ord(code))
+                        ext[CID["FP"]] += itf8(fp - last)
+                        last = fp
+                        if code == "X":
+                            ext[CID["BS"]].append(val)
+                        elif code == "B":
+                            ext[CID["BA"]].append(ord(val)); ext[CID["QS"]].append(0xFF)
+                        elif code == "I":
+                            ext[CID["IN_LEN"]] += itf8(len(val)); ext[CID["IN"]] += val.encode()
+                        elif code == "S":
+                            ext[CID["SC"]] += val.encode() + b"\0"
+                        elif code == "D":                     # SUBEXP, offset 0, k = 2
+                            v = val
+                            if v < 4:
+                                bits.put(0, 1); bits.put(v, 2)
+                            else:
+                                b_ = v.bit_length() - 1
+                                u = b_ - 2 + 1
+                                bits.put((1 << u) - 1, u); bits.put(0, 1); bits.put(v & ((1 << b_) - 1), b_)
+                        elif code == "N":
+                            ext[CID["RS"]] += itf8(val)
+                        elif code == "H":
+                            ext[CID["HC"]] += itf8(val)
+                        elif code == "P":
+                            ext[CID["PD"]] += itf8(val)
+                    bits.put(r["mapq"], 8)                    # MQ: BETA, 8 bits
+                else:
+                    ext[CID["BA"]] += r["seq"].encode()
+                bases_c += r["L"]
+            used = sorted(k for k, v in ext.items() if v)
+            eblocks = []
+            for k in used:
+                eblocks.append(block(METHODS[method_rot % 4], EXTERNAL_DATA, k, ext[k]))
+                method_rot += 1
+            core = block(RAW, CORE_DATA, 0, bits.done())
+            span = s_end - s_start + 1 if tid >= 0 and s_start else 0
+            sh = itf8(tid) + itf8(s_start if tid >= 0 else 0) + itf8(span) + itf8(len(rs)) + ltf8(counter) + itf8(1 + len(eblocks)) + \
+                itf8(len(used)) + b"".join(itf8(k) for k in used) + itf8(-1) + bytes(16)
+            shb = block(RAW, SLICE_HEADER, 0, sh)
+            landmarks.append(at)
+            sl_bytes = shb + core + b"".join(eblocks)
+            slice_meta.append((tid, s_start if tid >= 0 else 0, span, at, len(sl_bytes)))
+            blocks += [shb, core] + eblocks
+            at += len(sl_bytes)
+            counter += len(rs)
+            n_rec_c += len(rs)
+            if tid >= 0:
+                c_start = s_start if c_start is None else min(c_start, s_start)
+                c_end = max(c_end, s_end)
+        tids = {m[0] for m in slice_meta}
+        c_tid = tids.pop() if len(tids) == 1 else -2
+        coff = len(out)
+        out += container(c_tid, (c_start or 0) if c_tid >= 0 else 0, (c_end - c_start + 1) if c_tid >= 0 and c_start else 0, n_rec_c, counter - n_rec_c, bases_c,
+                         blocks, landmarks)
+        for tid, st, sp, lm, sz in slice_meta:
+            crai.append(f"{tid}\t{st}\t{sp}\t{coff}\t{lm}\t{sz}\n")
+    out += EOF_V3
+    with open(path, "wb") as f:
+        f.write(out)
+    if index:
+        with open(path + ".crai", "wb") as f:
+            f.write(gzip.compress("".join(crai).encode(), 6, mtime=0))
+    return text.decode()

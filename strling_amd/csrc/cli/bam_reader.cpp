@@ -1,6 +1,7 @@
 // bam_reader.cpp -- see bam_reader.h.  BGZF = concatenated gzip members with a BC extra field carrying the
 // compressed block size (SAM spec 4.1); each is inflated into a <= 64 KiB buffer (fast_inflate.cpp, zlib behind it).
 #include "bam_reader.h"
+#include "cram_reader.h"
 #include "fast_inflate.h"
 #include <fcntl.h>
 #include <stdlib.h>
@@ -17,6 +18,8 @@
 #include <thread>
 
 namespace strl {
+
+std::string g_cram_fasta;
 
 // One BGZF block: cli/fast_inflate.cpp first, zlib when it declines (zlib's verdict on a bad stream is the one reported).
 // c[clen .. clen + 8) must be readable: it is the block's CRC32 + ISIZE trailer.  STRL_INFLATE=zlib forces zlib.
@@ -105,6 +108,15 @@ bool BamReader::get(void *dst, size_t n, std::string &err) {
 
 bool BamReader::open(const std::string &path, std::string &err) {
   close();
+  cram_.reset();
+  if (CramFile::is_cram(path)) {
+    cram_.reset(new CramFile());
+    if (!cram_->open(path, g_cram_fasta, 1, err)) { cram_.reset(); return false; }
+    path_ = path;
+    text_ = cram_->header_text();
+    targets_ = cram_->targets();
+    return true;
+  }
   f_ = fopen(path.c_str(), "rb");
   if (!f_) { err = "couldn't open bam"; return false; }   // extract.nim:276
   path_ = path;
@@ -131,6 +143,13 @@ bool BamReader::open(const std::string &path, std::string &err) {
 
 bool BamReader::open_like(const BamReader &o, std::string &err) {
   close();
+  if (o.cram_) {                       // a reader of its own on the same CRAM (the index is parsed again: small)
+    cram_.reset(new CramFile());
+    if (!cram_->open(o.path_, g_cram_fasta, 1, err) || !cram_->load_index(err)) { cram_.reset(); return false; }
+    path_ = o.path_; text_ = o.text_; targets_ = o.targets_;
+    lin_.assign(1, {});
+    return true;
+  }
   f_ = fopen(o.path_.c_str(), "rb");
   if (!f_) { err = "couldn't open bam"; return false; }
   path_ = o.path_;
@@ -151,6 +170,11 @@ bool BamReader::seek(Pos p, std::string &err) {
 
 // BAI (SAM spec 5.2): magic, n_ref, per reference { n_bin, { bin, n_chunk, { beg, end } }, n_intv, ioffset[] }
 bool BamReader::load_index(const std::string &bam_path, std::string &err) {
+  if (cram_) {
+    if (!cram_->load_index(err)) return false;
+    lin_.assign(1, {});                // has_index()
+    return true;
+  }
   FILE *f = fopen((bam_path + ".bai").c_str(), "rb");
   if (!f && bam_path.size() > 4) f = fopen((bam_path.substr(0, bam_path.size() - 4) + ".bai").c_str(), "rb");
   if (!f) { err = "no .bai index next to " + bam_path; return false; }
@@ -189,6 +213,7 @@ bool BamReader::load_index(const std::string &bam_path, std::string &err) {
 }
 
 int64_t BamReader::read_region(RecordBatch &b, int32_t tid, int64_t beg, int64_t end, std::string &err) {
+  if (cram_) return cram_->read_region(b, tid, beg, end, err);
   if (tid < 0 || (size_t)tid >= ref_beg_.size() || ref_beg_[(size_t)tid] == 0 || end <= beg) return 0;
   const std::vector<uint64_t> &lin = lin_[(size_t)tid];
   // smallest offset of a record overlapping the 16 KiB window of `beg`; empty windows (0) fall back to the nearest
@@ -203,6 +228,10 @@ int64_t BamReader::read_region(RecordBatch &b, int32_t tid, int64_t beg, int64_t
 }
 
 int64_t BamReader::read_until(RecordBatch &b, int64_t max_records, int32_t stop_tid, int32_t stop_pos, std::string &err) {
+  if (cram_) {
+    if (stop_tid != INT32_MIN) { err = "read_until on a CRAM"; return -1; }
+    return cram_->read(b, max_records, err);
+  }
   int64_t n = 0;
   std::vector<uint8_t> rec;
   while (n < max_records) {
@@ -329,6 +358,14 @@ void BamStream::close() {
 
 bool BamStream::open(const std::string &path, int threads, std::string &err) {
   close();
+  cram_.reset();
+  if (CramFile::is_cram(path)) {       // extract.nim:278-279: the same open() takes a CRAM (with the FASTA it was written against)
+    cram_.reset(new CramFile());
+    if (!cram_->open(path, g_cram_fasta, threads, err)) { cram_.reset(); return false; }
+    text_ = cram_->header_text();
+    targets_ = cram_->targets();
+    return true;
+  }
   {   // header text + targets with the plain reader; it also tells where the first record starts
     BamReader hdr;
     if (!hdr.open(path, err)) return false;
@@ -599,6 +636,7 @@ bool BamStream::load_chunk(std::string &err) {
 }
 
 int64_t BamStream::read(RecordBatch &b, int64_t max_records, std::string &err) {
+  if (cram_) return cram_->read(b, max_records, err);
   int64_t n = 0;
   while (n < max_records) {
     if (rec_next_ == crecs_.size()) {

@@ -21,6 +21,11 @@
 
 namespace strl {
 
+class CramFile;
+// `-f FASTA` of the command line: a CRAM needs the reference it was written against (extract.nim:278-279, call.nim:90); the
+// readers below hand a file that starts with "CRAM" to cram_reader.h's CramFile and behave the same otherwise
+extern std::string g_cram_fasta;
+
 struct BamTarget {
   std::string name;
   uint32_t length;
@@ -81,6 +86,7 @@ class BamReader {
   bool get(void *dst, size_t n, std::string &err);   // copy n decompressed bytes, crossing blocks
   FILE *f_ = nullptr;
   std::string path_;
+  std::shared_ptr<CramFile> cram_;
   std::vector<uint8_t> cbuf_, ubuf_;
   size_t upos_ = 0;
   uint64_t block_start_ = 0, next_block_ = 0;
@@ -121,6 +127,7 @@ class BamStream {
  private:
   struct RecMeta { uint64_t off; int32_t l_seq; uint16_t n_cigar; uint8_t l_qname; };
   bool load_chunk(std::string &err);
+  std::shared_ptr<CramFile> cram_;
   const uint8_t *map_ = nullptr;
   size_t map_len_ = 0, cpos_ = 0;
   // The superchunk being LOADED (inflate + record scan, load_chunk, on a thread of its own) ...

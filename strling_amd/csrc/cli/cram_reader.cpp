@@ -1,0 +1,935 @@
+// cram_reader.cpp -- see cram_reader.h.  Follows the CRAM format specification version 3.0 (CRAMv3.pdf): section 6 (file
+// definition), 7 (container header), 8 (blocks, compression header, slice header, core / external data), 10 (record layout),
+// 13 (rANS 4x8), and hts-specs' description of ITF8 / LTF8.  Where the specification leaves the derived fields of linked mates
+// to the implementation (template length, mate flags), htslib's cram_decode.c behaviour is restated from its documentation
+// (leftmost start to rightmost end, positive for the leftmost record) -- unverifiable here, no htslib in this image.
+#include "cram_reader.h"
+#include <fcntl.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+#include <algorithm>
+#include <map>
+
+namespace strl {
+namespace {
+
+struct Rd {
+  const uint8_t *p, *e;
+  bool ok = true;
+  uint8_t u8() { if (p >= e) { ok = false; return 0; } return *p++; }
+  int32_t i32() { if (e - p < 4) { ok = false; p = e; return 0; } int32_t v; memcpy(&v, p, 4); p += 4; return v; }
+  int32_t itf8() {
+    const uint32_t b0 = u8();
+    if (b0 < 0x80) return (int32_t)b0;
+    if (b0 < 0xC0) return (int32_t)(((b0 & 0x3F) << 8) | u8());
+    if (b0 < 0xE0) { const uint32_t b1 = u8(), b2 = u8(); return (int32_t)(((b0 & 0x1F) << 16) | (b1 << 8) | b2); }
+    if (b0 < 0xF0) { const uint32_t b1 = u8(), b2 = u8(), b3 = u8(); return (int32_t)(((b0 & 0x0F) << 24) | (b1 << 16) | (b2 << 8) | b3); }
+    const uint32_t b1 = u8(), b2 = u8(), b3 = u8(), b4 = u8();
+    return (int32_t)(((b0 & 0x0F) << 28) | (b1 << 20) | (b2 << 12) | (b3 << 4) | (b4 & 0x0F));
+  }
+  int64_t ltf8() {
+    const uint32_t b0 = u8();
+    int extra = 0;
+    while (extra < 8 && (b0 & (0x80u >> extra))) ++extra;
+    uint64_t v = extra >= 7 ? 0 : (b0 & (0x7Fu >> extra));
+    for (int k = 0; k < extra; ++k) v = (v << 8) | u8();
+    return (int64_t)v;
+  }
+  void skip(size_t n) { if ((size_t)(e - p) < n) { ok = false; p = e; } else p += n; }
+};
+
+struct Block {
+  int method = 0, type = 0, id = 0;
+  uint32_t csize = 0, rsize = 0;
+  const uint8_t *data = nullptr;
+};
+
+bool read_block(Rd &r, Block &b) {
+  b.method = r.u8(); b.type = r.u8(); b.id = r.itf8();
+  b.csize = (uint32_t)r.itf8(); b.rsize = (uint32_t)r.itf8();
+  b.data = r.p;
+  r.skip(b.csize);
+  r.skip(4);      // CRC-32 (checked by `strling` only through the decoded content's consistency)
+  return r.ok;
+}
+
+// ---- rANS 4x8, CRAMv3 section 13 ----------------------------------------------------------------------------------------
+constexpr uint32_t RANS_L = 1u << 23;
+struct RansTab { uint16_t F[256], C[256]; uint8_t R[4096]; bool used = false; };
+
+bool rans_read_table(Rd &r, RansTab &t) {
+  memset(t.F, 0, sizeof t.F);
+  memset(t.C, 0, sizeof t.C);
+  t.used = true;
+  uint32_t x = 0;
+  int rle = 0;
+  uint32_t j = r.u8();
+  do {
+    uint32_t f = r.u8();
+    if (f >= 128) f = ((f & 127) << 8) | r.u8();
+    if (x + f > 4096 || !r.ok) return false;
+    t.F[j] = (uint16_t)f; t.C[j] = (uint16_t)x;
+    memset(t.R + x, (int)j, f);
+    x += f;
+    if (!rle && r.p < r.e && j + 1 == *r.p) { j = r.u8(); rle = r.u8(); }
+    else if (rle) { --rle; ++j; if (j > 255) return false; }
+    else j = r.u8();
+  } while (j && r.ok);
+  if (x < 4096) memset(t.R + x, 0, 4096 - x);      // (a table that does not sum to 4096: the slots decode to symbol 0 like htslib's)
+  return r.ok;
+}
+
+inline void rans_renorm(uint32_t &R, Rd &r) { while (R < RANS_L && r.p < r.e) R = (R << 8) | *r.p++; }
+
+bool rans_decode(const uint8_t *in, size_t in_len, std::vector<uint8_t> &out, size_t expect, std::string &err) {
+  if (in_len < 9) { err = "truncated rANS block"; return false; }
+  const int order = in[0];
+  uint32_t csz, usz;
+  memcpy(&csz, in + 1, 4); memcpy(&usz, in + 5, 4);
+  if ((size_t)csz + 9 > in_len || usz != expect || order > 1) { err = "malformed rANS block"; return false; }
+  out.resize(usz);
+  if (!usz) return true;
+  Rd r{in + 9, in + 9 + csz};
+  uint32_t R[4];
+  if (order == 0) {
+    static thread_local RansTab t;
+    if (!rans_read_table(r, t)) { err = "malformed rANS frequency table"; return false; }
+    for (int k = 0; k < 4; ++k) R[k] = (uint32_t)r.i32();
+    const size_t end4 = usz & ~(size_t)3;
+    for (size_t i = 0; i < end4; i += 4) {
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t m = R[k] & 4095u;
+        const uint8_t c = t.R[m];
+        out[i + (size_t)k] = c;
+        R[k] = t.F[c] * (R[k] >> 12) + m - t.C[c];
+      }
+      for (int k = 0; k < 4; ++k) rans_renorm(R[k], r);
+    }
+    for (size_t k = 0; k < (usz & 3); ++k) out[end4 + k] = t.R[R[k] & 4095u];
+  } else {
+    static thread_local std::vector<RansTab> T;
+    T.resize(256);
+    for (auto &t : T) t.used = false;
+    int rle = 0;
+    uint32_t i = r.u8();
+    do {
+      if (!rans_read_table(r, T[i])) { err = "malformed rANS order-1 table"; return false; }
+      if (!rle && r.p < r.e && i + 1 == *r.p) { i = r.u8(); rle = r.u8(); }
+      else if (rle) { --rle; ++i; if (i > 255) { err = "malformed rANS order-1 table"; return false; } }
+      else i = r.u8();
+    } while (i && r.ok);
+    for (int k = 0; k < 4; ++k) R[k] = (uint32_t)r.i32();
+    const size_t q = usz >> 2;
+    size_t at[4] = {0, q, 2 * q, 3 * q};
+    uint8_t l[4] = {0, 0, 0, 0};
+    for (size_t j = 0; j < q; ++j) {
+      for (int k = 0; k < 4; ++k) {
+        const RansTab &t = T[l[k]];
+        if (!t.used) { err = "rANS order-1 stream uses a context without a table"; return false; }
+        const uint32_t m = R[k] & 4095u;
+        const uint8_t c = t.R[m];
+        out[at[k]++] = c;
+        R[k] = t.F[c] * (R[k] >> 12) + m - t.C[c];
+        l[k] = c;
+      }
+      for (int k = 0; k < 4; ++k) rans_renorm(R[k], r);
+    }
+    for (; at[3] < usz;) {
+      const RansTab &t = T[l[3]];
+      if (!t.used) { err = "rANS order-1 stream uses a context without a table"; return false; }
+      const uint32_t m = R[3] & 4095u;
+      const uint8_t c = t.R[m];
+      out[at[3]++] = c;
+      R[3] = t.F[c] * (R[3] >> 12) + m - t.C[c];
+      rans_renorm(R[3], r);
+      l[3] = c;
+    }
+  }
+  if (!r.ok) { err = "truncated rANS data"; return false; }
+  return true;
+}
+
+bool block_data(const Block &b, std::vector<uint8_t> &out, std::string &err) {
+  switch (b.method) {
+    case 0:
+      out.assign(b.data, b.data + b.csize);
+      return true;
+    case 1: {
+      out.resize(b.rsize);
+      z_stream z;
+      memset(&z, 0, sizeof z);
+      if (inflateInit2(&z, 15 + 32) != Z_OK) { err = "zlib"; return false; }
+      z.next_in = const_cast<Bytef *>(b.data); z.avail_in = b.csize;
+      z.next_out = out.data(); z.avail_out = b.rsize;
+      const int rc = b.rsize ? inflate(&z, Z_FINISH) : Z_STREAM_END;
+      const bool ok = (rc == Z_STREAM_END || (rc == Z_OK && z.avail_out == 0)) && z.total_out == b.rsize;
+      inflateEnd(&z);
+      if (!ok) err = "corrupt gzip block in the CRAM";
+      return ok;
+    }
+    case 2: err = "the CRAM holds bzip2-compressed blocks: not supported by this build (re-encode with `samtools view -C --output-fmt-option use_bzip2=0`)"; return false;
+    case 3: err = "the CRAM holds lzma-compressed blocks: not supported by this build (re-encode with `samtools view -C --output-fmt-option use_lzma=0`)"; return false;
+    case 4: return rans_decode(b.data, b.csize, out, b.rsize, err);
+    default: err = "the CRAM holds blocks of compression method " + std::to_string(b.method) + " (CRAM 3.1 codecs): only CRAM 3.0 raw / gzip / rANS 4x8 are supported"; return false;
+  }
+}
+
+// ---- encodings ----------------------------------------------------------------------------------------------------------
+struct Enc {
+  int codec = 0;                // 0 NULL 1 EXTERNAL 3 HUFFMAN 4 BYTE_ARRAY_LEN 5 BYTE_ARRAY_STOP 6 BETA 7 SUBEXP 9 GAMMA
+  int ext = -1;
+  int32_t offset = 0, nbits = 0, k = 0;
+  uint8_t stop = 0;
+  std::vector<int32_t> sym;     // HUFFMAN: symbols ordered by (length, value)
+  std::vector<int> len;
+  std::vector<uint32_t> code;
+  std::shared_ptr<Enc> len_enc, val_enc;
+};
+
+bool parse_encoding(Rd &r, Enc &e, std::string &err) {
+  e.codec = r.itf8();
+  const int32_t n = r.itf8();
+  if (!r.ok || n < 0 || (size_t)n > (size_t)(r.e - r.p)) { err = "malformed encoding"; return false; }
+  Rd p{r.p, r.p + n};
+  r.skip((size_t)n);
+  switch (e.codec) {
+    case 0: return true;
+    case 1: e.ext = p.itf8(); return p.ok;
+    case 3: {
+      const int32_t ns = p.itf8();
+      std::vector<int32_t> s((size_t)std::max(ns, 0));
+      for (auto &x : s) x = p.itf8();
+      const int32_t nl = p.itf8();
+      if (nl != ns || !p.ok || ns <= 0) { err = "malformed HUFFMAN encoding"; return false; }
+      std::vector<int> l((size_t)nl);
+      for (auto &x : l) x = p.itf8();
+      std::vector<int> order((size_t)ns);
+      for (int i = 0; i < ns; ++i) order[(size_t)i] = i;
+      std::sort(order.begin(), order.end(), [&](int a, int b) { return l[(size_t)a] != l[(size_t)b] ? l[(size_t)a] < l[(size_t)b] : s[(size_t)a] < s[(size_t)b]; });
+      uint32_t code = 0;
+      int prev = l[(size_t)order[0]];
+      for (int i : order) {
+        if (l[(size_t)i] > 31 || l[(size_t)i] < 0) { err = "HUFFMAN code longer than 31 bits"; return false; }
+        code <<= (l[(size_t)i] - prev);
+        prev = l[(size_t)i];
+        e.sym.push_back(s[(size_t)i]); e.len.push_back(l[(size_t)i]); e.code.push_back(code);
+        ++code;
+      }
+      return p.ok;
+    }
+    case 4: {
+      e.len_enc.reset(new Enc()); e.val_enc.reset(new Enc());
+      return parse_encoding(p, *e.len_enc, err) && parse_encoding(p, *e.val_enc, err);
+    }
+    case 5: e.stop = p.u8(); e.ext = p.itf8(); return p.ok;
+    case 6: e.offset = p.itf8(); e.nbits = p.itf8(); return p.ok && e.nbits >= 0 && e.nbits <= 32;
+    case 7: e.offset = p.itf8(); e.k = p.itf8(); return p.ok && e.k >= 0 && e.k < 32;
+    case 9: e.offset = p.itf8(); return p.ok;
+    case 2: case 8: err = "the CRAM uses a GOLOMB / GOLOMB_RICE encoding (deprecated in CRAM 3.0): not supported by this build"; return false;
+    default: err = "the CRAM uses encoding " + std::to_string(e.codec) + ": only the CRAM 3.0 encodings are supported"; return false;
+  }
+}
+
+struct Ext { std::vector<uint8_t> d; size_t at = 0; };
+struct Ctx {
+  std::map<int, Ext> ext;
+  std::vector<uint8_t> core;
+  size_t bit = 0;               // next bit of the core block (most significant first)
+  bool ok = true;
+  std::string err;
+  uint32_t bits(int n) {
+    uint32_t v = 0;
+    for (int k = 0; k < n; ++k) {
+      const size_t by = bit >> 3;
+      if (by >= core.size()) { fail("the core data block ends inside a record"); return 0; }
+      v = (v << 1) | ((core[by] >> (7 - (bit & 7))) & 1u);
+      ++bit;
+    }
+    return v;
+  }
+  void fail(const std::string &m) { if (ok) { ok = false; err = m; } }
+  Ext *stream(int id) {
+    auto it = ext.find(id);
+    if (it == ext.end()) { fail("the slice has no external block " + std::to_string(id)); return nullptr; }
+    return &it->second;
+  }
+  int32_t ext_itf8(int id) {
+    Ext *s = stream(id);
+    if (!s) return 0;
+    Rd r{s->d.data() + s->at, s->d.data() + s->d.size()};
+    const int32_t v = r.itf8();
+    if (!r.ok) fail("external block " + std::to_string(id) + " ends inside a record");
+    s->at = (size_t)(r.p - s->d.data());
+    return v;
+  }
+  int ext_byte(int id) {
+    Ext *s = stream(id);
+    if (!s) return 0;
+    if (s->at >= s->d.size()) { fail("external block " + std::to_string(id) + " ends inside a record"); return 0; }
+    return s->d[s->at++];
+  }
+};
+
+int32_t dec_int(const Enc &e, Ctx &c) {
+  switch (e.codec) {
+    case 1: return c.ext_itf8(e.ext);
+    case 3: {
+      if (e.sym.size() == 1 && e.len[0] == 0) return e.sym[0];
+      uint32_t code = 0;
+      int len = 0;
+      size_t i = 0;
+      while (i < e.sym.size() && c.ok) {
+        const int need = e.len[i] - len;
+        if (need > 0) { code = (code << need) | c.bits(need); len = e.len[i]; }
+        for (; i < e.sym.size() && e.len[i] == len; ++i) if (e.code[i] == code) return e.sym[i];
+      }
+      c.fail("invalid HUFFMAN code in the core data block");
+      return 0;
+    }
+    case 6: return (int32_t)c.bits(e.nbits) - e.offset;
+    case 7: {
+      int u = 0;
+      while (c.ok && c.bits(1)) ++u;
+      int32_t v;
+      if (u == 0) v = (int32_t)c.bits(e.k);
+      else { const int b = u + e.k - 1; if (b > 31) { c.fail("SUBEXP value too long"); return 0; } v = (int32_t)((1u << b) | c.bits(b)); }
+      return v - e.offset;
+    }
+    case 9: {
+      int n = 0;
+      while (c.ok && !c.bits(1)) { if (++n > 31) { c.fail("GAMMA value too long"); return 0; } }
+      return (int32_t)((1u << n) | c.bits(n)) - e.offset;
+    }
+    case 0: return 0;
+    default: c.fail("an integer series uses a byte-array encoding"); return 0;
+  }
+}
+inline int dec_byte(const Enc &e, Ctx &c) { return e.codec == 1 ? c.ext_byte(e.ext) : (dec_int(e, c) & 0xFF); }
+void dec_bytes(const Enc &e, Ctx &c, std::string &out) {
+  out.clear();
+  if (e.codec == 5) {
+    Ext *s = c.stream(e.ext);
+    if (!s) return;
+    const uint8_t *b = s->d.data() + s->at, *end = s->d.data() + s->d.size();
+    const uint8_t *q = static_cast<const uint8_t *>(memchr(b, e.stop, (size_t)(end - b)));
+    if (!q) { c.fail("BYTE_ARRAY_STOP without its stop byte"); return; }
+    out.assign(reinterpret_cast<const char *>(b), (size_t)(q - b));
+    s->at += (size_t)(q - b) + 1;
+  } else if (e.codec == 4) {
+    const int32_t n = dec_int(*e.len_enc, c);
+    if (n < 0 || n > (1 << 28)) { c.fail("byte array of negative length"); return; }
+    if (e.val_enc->codec == 1) {
+      Ext *s = c.stream(e.val_enc->ext);
+      if (!s) return;
+      if (s->d.size() - s->at < (size_t)n) { c.fail("byte array reaches past its external block"); return; }
+      out.assign(reinterpret_cast<const char *>(s->d.data() + s->at), (size_t)n);
+      s->at += (size_t)n;
+    } else {
+      for (int32_t k = 0; k < n && c.ok; ++k) out.push_back((char)dec_byte(*e.val_enc, c));
+    }
+  } else if (e.codec != 0) {
+    c.fail("a byte-array series uses encoding " + std::to_string(e.codec));
+  }
+}
+
+struct CompHeader {
+  bool rn = true, ap_delta = true, rr = true;
+  uint8_t sm[5] = {0x1B, 0x1B, 0x1B, 0x1B, 0x1B};
+  std::vector<std::vector<int32_t>> td;       // tag lines: tag keys (c1 << 16 | c2 << 8 | type)
+  std::map<std::string, Enc> ds;
+  std::map<int32_t, Enc> tags;
+  const Enc &get(const char *k) const { static const Enc none; auto it = ds.find(k); return it == ds.end() ? none : it->second; }
+};
+
+bool parse_comp_header(const std::vector<uint8_t> &d, CompHeader &h, std::string &err) {
+  Rd r{d.data(), d.data() + d.size()};
+  {
+    const int32_t sz = r.itf8();
+    Rd m{r.p, r.p + std::max(sz, 0)};
+    r.skip((size_t)std::max(sz, 0));
+    const int32_t n = m.itf8();
+    for (int32_t i = 0; i < n && m.ok; ++i) {
+      const char k0 = (char)m.u8(), k1 = (char)m.u8();
+      if (k0 == 'R' && k1 == 'N') h.rn = m.u8() != 0;
+      else if (k0 == 'A' && k1 == 'P') h.ap_delta = m.u8() != 0;
+      else if (k0 == 'R' && k1 == 'R') h.rr = m.u8() != 0;
+      else if (k0 == 'S' && k1 == 'M') { for (int j = 0; j < 5; ++j) h.sm[j] = m.u8(); }
+      else if (k0 == 'T' && k1 == 'D') {
+        const int32_t len = m.itf8();
+        if (len < 0 || (size_t)len > (size_t)(m.e - m.p)) { err = "malformed tag dictionary"; return false; }
+        const uint8_t *b = m.p, *e = m.p + len;
+        m.skip((size_t)len);
+        std::vector<int32_t> line;
+        for (const uint8_t *q = b; q < e;) {
+          if (*q == 0) { h.td.push_back(line); line.clear(); ++q; continue; }
+          if (e - q < 3) { err = "malformed tag dictionary"; return false; }
+          line.push_back((q[0] << 16) | (q[1] << 8) | q[2]);
+          q += 3;
+        }
+        if (!line.empty()) h.td.push_back(line);
+      } else { err = std::string("unknown preservation map key ") + k0 + k1; return false; }
+    }
+    if (!m.ok) { err = "malformed preservation map"; return false; }
+  }
+  {
+    const int32_t sz = r.itf8();
+    Rd m{r.p, r.p + std::max(sz, 0)};
+    r.skip((size_t)std::max(sz, 0));
+    const int32_t n = m.itf8();
+    for (int32_t i = 0; i < n && m.ok; ++i) {
+      std::string k(2, ' ');
+      k[0] = (char)m.u8(); k[1] = (char)m.u8();
+      if (!parse_encoding(m, h.ds[k], err)) { if (err.empty()) err = "malformed data series encoding " + k; return false; }
+    }
+    if (!m.ok) { err = "malformed data series encoding map"; return false; }
+  }
+  {
+    const int32_t sz = r.itf8();
+    Rd m{r.p, r.p + std::max(sz, 0)};
+    r.skip((size_t)std::max(sz, 0));
+    const int32_t n = m.itf8();
+    for (int32_t i = 0; i < n && m.ok; ++i) {
+      const int32_t k = m.itf8();
+      if (!parse_encoding(m, h.tags[k], err)) { if (err.empty()) err = "malformed tag encoding"; return false; }
+    }
+    if (!m.ok) { err = "malformed tag encoding map"; return false; }
+  }
+  if (!r.ok) { err = "malformed compression header"; return false; }
+  return true;
+}
+
+const char NT16[] = "=ACMGRSVTWYHKDBN";
+struct Nib { uint8_t t[256]; Nib() { memset(t, 15, sizeof t); for (int i = 0; i < 16; ++i) { t[(uint8_t)NT16[i]] = (uint8_t)i; t[(uint8_t)tolower(NT16[i])] = (uint8_t)i; } } };
+const Nib NIB;
+
+struct Rec {
+  int32_t flag, cf, ref, pos, aend, rl, mapq = 0, mf = 0, ns = -1, np = 0, ts = 0, nf = -1;
+  int32_t mtid = -1, mpos = -1, isize = 0;
+  bool mate_set = false;
+  uint64_t gen = 0;            // number of the record a generated name is made of (linked mates share it)
+  size_t name_at, name_len, cig_at, cig_n, seq_at;
+};
+
+inline char subst(const uint8_t sm[5], char ref, int code) {
+  static const char *alt[5] = {"CGTN", "AGTN", "ACTN", "ACGN", "ACGT"};
+  int r;
+  switch (ref) { case 'A': r = 0; break; case 'C': r = 1; break; case 'G': r = 2; break; case 'T': r = 3; break; default: r = 4; }
+  for (int j = 0; j < 4; ++j) if (((sm[r] >> (6 - 2 * j)) & 3) == code) return alt[r][j];
+  return 'N';
+}
+
+void append_batch(RecordBatch &b, RecordBatch &a) {
+  const size_t n = a.size();
+  if (!n) return;
+  const uint32_t c0 = (uint32_t)b.cigar.size();
+  const uint64_t q0 = b.qnames.size();
+  const size_t s0 = (b.seq4.size() + 15) & ~(size_t)15;
+  b.tid.insert(b.tid.end(), a.tid.begin(), a.tid.end()); b.pos.insert(b.pos.end(), a.pos.begin(), a.pos.end());
+  b.mtid.insert(b.mtid.end(), a.mtid.begin(), a.mtid.end()); b.mpos.insert(b.mpos.end(), a.mpos.begin(), a.mpos.end());
+  b.isize.insert(b.isize.end(), a.isize.begin(), a.isize.end()); b.l_seq.insert(b.l_seq.end(), a.l_seq.begin(), a.l_seq.end());
+  b.flag.insert(b.flag.end(), a.flag.begin(), a.flag.end()); b.mapq.insert(b.mapq.end(), a.mapq.begin(), a.mapq.end());
+  b.cigar.insert(b.cigar.end(), a.cigar.begin(), a.cigar.end());
+  for (size_t i = 1; i <= n; ++i) b.cigar_off.push_back(a.cigar_off[i] + c0);
+  b.qnames += a.qnames;
+  for (size_t i = 1; i <= n; ++i) b.qname_off.push_back(a.qname_off[i] + q0);
+  b.seq4.resize(s0 + a.seq4.size(), 0);
+  memcpy(b.seq4.data() + s0, a.seq4.data(), a.seq4.size());
+  for (size_t i = 0; i < n; ++i) b.seq_off.push_back(a.seq_off[i] + s0);
+}
+
+}  // namespace
+
+// ---- reference ----------------------------------------------------------------------------------------------------------
+bool RefCache::open(const std::string &fasta, std::string &err) {
+  path_ = fasta;
+  FILE *f = fopen((fasta + ".fai").c_str(), "r");
+  if (f) {
+    char name[1024];
+    unsigned long long len, off;
+    unsigned lb, lw;
+    char line[4096];
+    while (fgets(line, sizeof line, f))
+      if (sscanf(line, "%1023[^\t]\t%llu\t%llu\t%u\t%u", name, &len, &off, &lb, &lw) == 5) fai_.push_back({name, Fai{len, off, lb, lw}});
+    fclose(f);
+  }
+  FILE *t = fopen(fasta.c_str(), "rb");
+  if (!t) { err = "couldn't open fasta " + fasta; return false; }
+  uint8_t m[2] = {0, 0};
+  const size_t got = fread(m, 1, 2, t);
+  fclose(t);
+  if (got == 2 && m[0] == 0x1f && m[1] == 0x8b) fai_.clear();     // compressed: no random access without a .gzi -- read it once
+  return true;
+}
+
+bool RefCache::load_all(std::string &err) {
+  gzFile in = gzopen(path_.c_str(), "rb");
+  if (!in) { err = "couldn't open fasta " + path_; return false; }
+  gzbuffer(in, 1 << 20);
+  std::string name, *cur = nullptr;
+  std::vector<char> buf(1 << 16);
+  std::shared_ptr<std::string> seq;
+  auto flush = [&] { if (seq) loaded_.push_back({name, seq}); };
+  while (gzgets(in, buf.data(), (int)buf.size())) {
+    char *s = buf.data();
+    size_t n = strlen(s);
+    const bool whole = n && s[n - 1] == '\n';
+    while (n && (s[n - 1] == '\n' || s[n - 1] == '\r')) --n;
+    if (s[0] == '>' && !cur_line_continues_) {
+      flush();
+      size_t k = 1;
+      while (k < n && !isspace((unsigned char)s[k])) ++k;
+      name.assign(s + 1, k - 1);
+      seq.reset(new std::string());
+      cur = seq.get();
+    } else if (cur) {
+      for (size_t k = 0; k < n; ++k) { const char ch = (char)toupper((unsigned char)s[k]); cur->push_back(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' ? ch : 'N'); }
+    }
+    cur_line_continues_ = !whole;
+  }
+  flush();
+  gzclose(in);
+  all_loaded_ = true;
+  return true;
+}
+
+std::shared_ptr<const std::string> RefCache::get(const std::string &name, std::string &err) {
+  std::lock_guard<std::mutex> lk(mu_);
+  for (auto &p : loaded_) if (p.first == name) return p.second;
+  if (all_loaded_) return nullptr;
+  if (fai_.empty()) {
+    if (!load_all(err)) return nullptr;
+    for (auto &p : loaded_) if (p.first == name) return p.second;
+    return nullptr;
+  }
+  for (auto &e : fai_) {
+    if (e.first != name) continue;
+    FILE *f = fopen(path_.c_str(), "rb");
+    if (!f) { err = "couldn't open fasta " + path_; return nullptr; }
+    const Fai &x = e.second;
+    const uint64_t lines = x.line_bases ? (x.len + x.line_bases - 1) / x.line_bases : 0;
+    const uint64_t bytes = x.line_bases ? x.len + lines * (x.line_width - x.line_bases) : 0;
+    std::string raw((size_t)bytes, '\0');
+    fseeko(f, (off_t)x.off, SEEK_SET);
+    const size_t got = bytes ? fread(&raw[0], 1, (size_t)bytes, f) : 0;
+    fclose(f);
+    std::shared_ptr<std::string> seq(new std::string());
+    seq->reserve((size_t)x.len);
+    for (size_t k = 0; k < got && seq->size() < x.len; ++k) {
+      const char ch = raw[k];
+      if (ch == '\n' || ch == '\r') continue;
+      const char u = (char)toupper((unsigned char)ch);
+      seq->push_back(u == 'A' || u == 'C' || u == 'G' || u == 'T' ? u : 'N');
+    }
+    loaded_.push_back({name, seq});
+    return seq;
+  }
+  return nullptr;
+}
+
+// ---- file ---------------------------------------------------------------------------------------------------------------
+CramFile::~CramFile() {
+  if (map_) munmap(const_cast<uint8_t *>(map_), map_len_);
+  delete pool_;
+}
+
+bool CramFile::is_cram(const std::string &path) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  char m[4] = {0, 0, 0, 0};
+  const size_t got = fread(m, 1, 4, f);
+  fclose(f);
+  return got == 4 && memcmp(m, "CRAM", 4) == 0;
+}
+
+bool CramFile::parse_container_header(uint64_t off, Container &c, std::string &err) const {
+  if (off + 8 > map_len_) { err = "truncated CRAM container"; return false; }
+  Rd r{map_ + off, map_ + map_len_};
+  c.off = off;
+  c.len = (uint32_t)r.i32();
+  c.ref_id = r.itf8();
+  r.itf8(); r.itf8();
+  c.n_records = r.itf8();
+  c.counter = (uint64_t)r.ltf8();
+  r.ltf8();
+  r.itf8();
+  const int32_t nl = r.itf8();
+  c.landmarks.clear();
+  for (int32_t k = 0; k < nl && r.ok; ++k) c.landmarks.push_back(r.itf8());
+  r.skip(4);
+  if (!r.ok) { err = "truncated CRAM container header"; return false; }
+  c.data_off = (uint64_t)(r.p - map_);
+  if (c.data_off + c.len > map_len_) { err = "CRAM container reaches past the end of the file"; return false; }
+  return true;
+}
+
+bool CramFile::open(const std::string &path, const std::string &fasta, int threads, std::string &err) {
+  path_ = path;
+  const int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) { err = "couldn't open bam"; return false; }
+  struct stat st;
+  if (fstat(fd, &st) != 0 || st.st_size < 26) { ::close(fd); err = "not a CRAM file"; return false; }
+  map_len_ = (size_t)st.st_size;
+  void *m = mmap(nullptr, map_len_, PROT_READ, MAP_PRIVATE, fd, 0);
+  ::close(fd);
+  if (m == MAP_FAILED) { map_ = nullptr; err = "mmap failed"; return false; }
+  map_ = static_cast<const uint8_t *>(m);
+  if (memcmp(map_, "CRAM", 4) != 0) { err = "not a CRAM file"; return false; }
+  if (map_[4] != 3 || map_[5] != 0) {
+    err = "CRAM version " + std::to_string(map_[4]) + "." + std::to_string(map_[5]) + ": this build reads CRAM 3.0 (samtools view -C --output-fmt-option version=3.0)";
+    return false;
+  }
+  Container c;
+  if (!parse_container_header(26, c, err)) return false;
+  {
+    Rd r{map_ + c.data_off, map_ + c.data_off + c.len};
+    Block b;
+    if (!read_block(r, b) || b.type != 0) { err = "CRAM without a file header block"; return false; }
+    std::vector<uint8_t> d;
+    if (!block_data(b, d, err)) return false;
+    if (d.size() < 4) { err = "truncated CRAM file header"; return false; }
+    int32_t l;
+    memcpy(&l, d.data(), 4);
+    if (l < 0 || (size_t)l + 4 > d.size()) { err = "truncated CRAM file header"; return false; }
+    text_.assign(reinterpret_cast<const char *>(d.data() + 4), (size_t)l);
+    while (!text_.empty() && text_.back() == '\0') text_.pop_back();
+  }
+  // @SQ lines -> targets (the order of the header is the order of the reference ids)
+  for (size_t i = 0; i < text_.size();) {
+    size_t j = text_.find('\n', i);
+    if (j == std::string::npos) j = text_.size();
+    if (text_.compare(i, 4, "@SQ\t") == 0) {
+      std::string name;
+      uint32_t ln = 0;
+      for (size_t a = i + 4; a < j;) {
+        size_t b2 = text_.find('\t', a);
+        if (b2 == std::string::npos || b2 > j) b2 = j;
+        if (text_.compare(a, 3, "SN:") == 0) name = text_.substr(a + 3, b2 - a - 3);
+        else if (text_.compare(a, 3, "LN:") == 0) ln = (uint32_t)strtoul(text_.c_str() + a + 3, nullptr, 10);
+        a = b2 + 1;
+      }
+      targets_.push_back(BamTarget{name, ln});
+    }
+    i = j + 1;
+  }
+  next_off_ = c.data_off + c.len;
+  threads_ = std::max(1, threads);
+  if (fasta.empty()) { err = "CRAM input needs the reference it was written against: give it with -f FASTA"; return false; }
+  return ref_.open(fasta, err);
+}
+
+bool CramFile::decode_container(const Container &c, int64_t only_landmark, RecordBatch &out, std::string &err) {
+  Rd r{map_ + c.data_off, map_ + c.data_off + c.len};
+  Block hb;
+  if (!read_block(r, hb) || hb.type != 1) { err = "CRAM container without a compression header"; return false; }
+  std::vector<uint8_t> hd;
+  CompHeader H;
+  if (!block_data(hb, hd, err) || !parse_comp_header(hd, H, err)) return false;
+  const Enc &eBF = H.get("BF"), &eCF = H.get("CF"), &eRI = H.get("RI"), &eRL = H.get("RL"), &eAP = H.get("AP"), &eRG = H.get("RG"), &eRN = H.get("RN"),
+            &eMF = H.get("MF"), &eNS = H.get("NS"), &eNP = H.get("NP"), &eTS = H.get("TS"), &eNF = H.get("NF"), &eTL = H.get("TL"), &eFN = H.get("FN"),
+            &eFC = H.get("FC"), &eFP = H.get("FP"), &eDL = H.get("DL"), &eBB = H.get("BB"), &eQQ = H.get("QQ"), &eBS = H.get("BS"), &eIN = H.get("IN"),
+            &eRS = H.get("RS"), &ePD = H.get("PD"), &eHC = H.get("HC"), &eSC = H.get("SC"), &eMQ = H.get("MQ"), &eBA = H.get("BA"), &eQS = H.get("QS");
+  std::vector<size_t> starts;
+  if (only_landmark >= 0) starts.push_back((size_t)only_landmark);
+  else for (int32_t l : c.landmarks) starts.push_back((size_t)l);
+  std::string names, seqs, tmp;
+  std::vector<uint32_t> cig;
+  std::vector<Rec> recs;
+  for (size_t sl : starts) {
+    if (sl >= c.len) { err = "CRAM slice landmark outside its container"; return false; }
+    Rd s{map_ + c.data_off + sl, map_ + c.data_off + c.len};
+    Block sb;
+    if (!read_block(s, sb) || sb.type != 2) { err = "CRAM slice without a slice header block"; return false; }
+    std::vector<uint8_t> sd;
+    if (!block_data(sb, sd, err)) return false;
+    Rd h{sd.data(), sd.data() + sd.size()};
+    const int32_t s_ref = h.itf8(), s_start = h.itf8();
+    h.itf8();
+    const int32_t s_nrec = h.itf8();
+    h.ltf8();
+    const int32_t s_nblocks = h.itf8();
+    const int32_t n_ids = h.itf8();
+    for (int32_t k = 0; k < n_ids && h.ok; ++k) h.itf8();
+    const int32_t embedded = h.itf8();
+    if (!h.ok || s_nrec < 0 || s_nblocks < 0) { err = "malformed CRAM slice header"; return false; }
+    if (embedded >= 0) { err = "the CRAM slice embeds its reference: not supported by this build (samtools view -C --output-fmt-option embed_ref=0)"; return false; }
+    Ctx X;
+    for (int32_t k = 0; k < s_nblocks; ++k) {
+      Block b;
+      if (!read_block(s, b)) { err = "truncated CRAM slice"; return false; }
+      if (b.type == 5) { if (!block_data(b, X.core, err)) return false; }
+      else if (b.type == 4) { if (!block_data(b, X.ext[b.id].d, err)) return false; }
+    }
+    std::shared_ptr<const std::string> ref;
+    int32_t ref_of = -3;
+    auto need_ref = [&](int32_t id) -> bool {
+      if (id == ref_of) return true;
+      ref.reset();
+      ref_of = id;
+      if (id < 0 || (size_t)id >= targets_.size()) return true;
+      ref = ref_.get(targets_[(size_t)id].name, err);
+      if (!ref && H.rr) { if (err.empty()) err = "reference sequence " + targets_[(size_t)id].name + " of the CRAM is not in the FASTA"; return false; }
+      return true;
+    };
+    const size_t first = recs.size();
+    int32_t prev_pos = s_start;
+    for (int32_t i = 0; i < s_nrec && X.ok; ++i) {
+      Rec R;
+      R.flag = dec_int(eBF, X);
+      R.cf = dec_int(eCF, X);
+      R.ref = s_ref == -2 ? dec_int(eRI, X) : s_ref;
+      R.rl = dec_int(eRL, X);
+      const int32_t ap = dec_int(eAP, X);
+      R.pos = H.ap_delta ? prev_pos + ap : ap;
+      if (H.ap_delta) prev_pos = R.pos;
+      dec_int(eRG, X);
+      R.name_at = names.size();
+      bool have_name = false;
+      if (H.rn) { dec_bytes(eRN, X, tmp); names += tmp; have_name = true; }
+      if (R.cf & 2) {
+        R.mf = dec_int(eMF, X);
+        if (!H.rn) { dec_bytes(eRN, X, tmp); names += tmp; have_name = true; }
+        R.ns = dec_int(eNS, X); R.np = dec_int(eNP, X); R.ts = dec_int(eTS, X);
+      } else if (R.cf & 4) {
+        R.nf = dec_int(eNF, X);
+      }
+      if (!have_name) { names += "\x01"; R.gen = c.counter + recs.size(); }     // placeholder: a generated name, shared with a linked mate
+      R.name_len = names.size() - R.name_at;
+      const int32_t tl = dec_int(eTL, X);
+      if (tl < 0 || (size_t)tl >= std::max<size_t>(H.td.size(), 1) ) { X.fail("tag line index outside the dictionary"); break; }
+      if (!H.td.empty())
+        for (int32_t key : H.td[(size_t)tl]) {
+          auto it = H.tags.find(key);
+          if (it == H.tags.end()) { X.fail("a tag without an encoding"); break; }
+          dec_bytes(it->second, X, tmp);        // tag values are not used by strling
+        }
+      if (R.rl < 0 || R.rl > (1 << 24)) { X.fail("implausible read length"); break; }
+      R.seq_at = seqs.size();
+      seqs.resize(R.seq_at + (size_t)R.rl, 'N');
+      R.cig_at = cig.size();
+      char *sq = &seqs[0] + R.seq_at;
+      int32_t ref_used = 0;
+      auto push = [&](uint32_t op, uint32_t len) {
+        if (!len) return;
+        if (cig.size() > R.cig_at && (cig.back() & 15u) == op) cig.back() += len << 4;
+        else cig.push_back((len << 4) | op);
+      };
+      if (!(R.flag & 4)) {
+        if (!need_ref(R.ref)) return false;
+        const int32_t fn = dec_int(eFN, X);
+        int32_t qpos = 0, fpos = 0;
+        int64_t rpos = (int64_t)R.pos - 1;
+        auto match_to = [&](int32_t upto) {          // reference bases for read positions [qpos, upto)
+          const int32_t n = upto - qpos;
+          if (n <= 0) return;
+          for (int32_t k = 0; k < n; ++k) {
+            const int64_t rp = rpos + k;
+            sq[qpos + k] = ref && rp >= 0 && (size_t)rp < ref->size() ? (*ref)[(size_t)rp] : 'N';
+          }
+          push(0, (uint32_t)n);
+          rpos += n; qpos += n; ref_used += n;
+        };
+        for (int32_t f = 0; f < fn && X.ok; ++f) {
+          const int code = dec_byte(eFC, X);
+          fpos += dec_int(eFP, X);
+          if (fpos < 1 || fpos > R.rl + 1) { X.fail("read feature outside its read"); break; }
+          if (!ref && H.rr && code != 'b' && code != 'B' && fpos - 1 > qpos) { /* matches against a missing reference */ }
+          match_to(fpos - 1);
+          switch (code) {
+            case 'X': {
+              const int bs = dec_byte(eBS, X);
+              if (qpos >= R.rl) { X.fail("read feature outside its read"); break; }
+              const char rb = ref && rpos >= 0 && (size_t)rpos < ref->size() ? (*ref)[(size_t)rpos] : 'N';
+              sq[qpos] = subst(H.sm, rb, bs & 3);
+              push(0, 1); ++rpos; ++qpos; ++ref_used;
+              break;
+            }
+            case 'B': {
+              const int ba = dec_byte(eBA, X);
+              dec_byte(eQS, X);
+              if (qpos >= R.rl) { X.fail("read feature outside its read"); break; }
+              sq[qpos] = (char)ba;
+              push(0, 1); ++rpos; ++qpos; ++ref_used;
+              break;
+            }
+            case 'b': {
+              dec_bytes(eBB, X, tmp);
+              if (qpos + (int32_t)tmp.size() > R.rl) { X.fail("read feature outside its read"); break; }
+              memcpy(sq + qpos, tmp.data(), tmp.size());
+              push(0, (uint32_t)tmp.size()); rpos += (int64_t)tmp.size(); qpos += (int32_t)tmp.size(); ref_used += (int32_t)tmp.size();
+              break;
+            }
+            case 'Q': dec_byte(eQS, X); break;
+            case 'q': dec_bytes(eQQ, X, tmp); break;
+            case 'i': {
+              const int ba = dec_byte(eBA, X);
+              if (qpos >= R.rl) { X.fail("read feature outside its read"); break; }
+              sq[qpos] = (char)ba;
+              push(1, 1); ++qpos;
+              break;
+            }
+            case 'I': case 'S': {
+              dec_bytes(code == 'I' ? eIN : eSC, X, tmp);
+              if (qpos + (int32_t)tmp.size() > R.rl) { X.fail("read feature outside its read"); break; }
+              memcpy(sq + qpos, tmp.data(), tmp.size());
+              push(code == 'I' ? 1u : 4u, (uint32_t)tmp.size()); qpos += (int32_t)tmp.size();
+              break;
+            }
+            case 'D': { const int32_t n = dec_int(eDL, X); if (n < 0) { X.fail("negative deletion"); break; } push(2, (uint32_t)n); rpos += n; ref_used += n; break; }
+            case 'N': { const int32_t n = dec_int(eRS, X); if (n < 0) { X.fail("negative reference skip"); break; } push(3, (uint32_t)n); rpos += n; ref_used += n; break; }
+            case 'H': { const int32_t n = dec_int(eHC, X); if (n < 0) { X.fail("negative hard clip"); break; } push(5, (uint32_t)n); break; }
+            case 'P': { const int32_t n = dec_int(ePD, X); if (n < 0) { X.fail("negative padding"); break; } push(6, (uint32_t)n); break; }
+            default: X.fail(std::string("unknown read feature code '") + (char)code + "'");
+          }
+        }
+        match_to(R.rl);
+        R.mapq = dec_int(eMQ, X);
+        if (R.cf & 1) for (int32_t k = 0; k < R.rl && X.ok; ++k) dec_byte(eQS, X);
+      } else {
+        if (eBA.codec == 1) {
+          Ext *st = X.stream(eBA.ext);
+          if (st && st->d.size() - st->at >= (size_t)R.rl) { memcpy(sq, st->d.data() + st->at, (size_t)R.rl); st->at += (size_t)R.rl; }
+          else X.fail("unmapped read's bases reach past their external block");
+        } else {
+          for (int32_t k = 0; k < R.rl && X.ok; ++k) sq[k] = (char)dec_byte(eBA, X);
+        }
+        if (R.cf & 1) for (int32_t k = 0; k < R.rl && X.ok; ++k) dec_byte(eQS, X);
+      }
+      R.cig_n = cig.size() - R.cig_at;
+      R.aend = (R.flag & 4) ? R.pos : R.pos + std::max(ref_used, 1) - 1;
+      recs.push_back(R);
+    }
+    if (!X.ok) { err = "CRAM: " + X.err; return false; }
+    // mates inside the slice (CRAMv3 section 10.5: "mate downstream", NF = records to skip to the next fragment)
+    for (size_t i = first; i < recs.size(); ++i) {
+      Rec &a = recs[i];
+      if (a.cf & 2) {
+        a.mtid = a.ns; a.mpos = a.np - 1; a.isize = a.ts;
+        a.flag |= (a.mf & 1 ? 0x20 : 0) | (a.mf & 2 ? 0x8 : 0);
+        a.mate_set = true;
+      } else if ((a.cf & 4) && a.nf >= 0) {
+        const size_t j = i + (size_t)a.nf + 1;
+        if (j >= recs.size()) { err = "CRAM: a mate link points outside its slice"; return false; }
+        Rec &b = recs[j];
+        a.mtid = b.ref; a.mpos = b.pos - 1; b.mtid = a.ref; b.mpos = a.pos - 1;
+        a.flag |= (b.flag & 0x10 ? 0x20 : 0) | (b.flag & 0x4 ? 0x8 : 0);
+        b.flag |= (a.flag & 0x10 ? 0x20 : 0) | (a.flag & 0x4 ? 0x8 : 0);
+        if (a.ref == b.ref && a.ref >= 0) {
+          const int32_t left = std::min(a.pos, b.pos), right = std::max(a.aend, b.aend), t = right - left + 1;
+          const bool a_first = a.pos < b.pos || (a.pos == b.pos && (a.flag & 0x40));
+          a.isize = a_first ? t : -t; b.isize = a_first ? -t : t;
+        }
+        a.mate_set = b.mate_set = true;
+        if (names[a.name_at] == '\x01' && a.name_len == 1 && names[b.name_at] == '\x01' && b.name_len == 1) b.gen = a.gen;      // share the generated name
+      }
+    }
+  }
+  // ---- the records into the batch ----
+  out.clear();
+  for (size_t i = 0; i < recs.size(); ++i) {
+    const Rec &R = recs[i];
+    out.tid.push_back(R.ref < 0 ? -1 : R.ref);
+    out.pos.push_back(R.pos - 1);
+    out.mtid.push_back(R.mate_set ? R.mtid : -1);
+    out.mpos.push_back(R.mate_set ? R.mpos : -1);
+    out.isize.push_back(R.isize);
+    out.l_seq.push_back(R.rl);
+    out.flag.push_back((uint16_t)R.flag);
+    out.mapq.push_back((uint8_t)R.mapq);
+    if (R.name_len == 1 && names[R.name_at] == '\x01') {
+      char g[48];
+      const int n = snprintf(g, sizeof g, "cram.%llu", (unsigned long long)R.gen);
+      out.qnames.append(g, (size_t)n);
+    } else out.qnames.append(names, R.name_at, R.name_len);
+    out.qname_off.push_back(out.qnames.size());
+    out.cigar.insert(out.cigar.end(), cig.begin() + (long)R.cig_at, cig.begin() + (long)(R.cig_at + R.cig_n));
+    out.cigar_off.push_back((uint32_t)out.cigar.size());
+    const size_t so = (out.seq4.size() + 15) & ~(size_t)15, sb = ((size_t)R.rl + 1) / 2;
+    out.seq4.resize(so + sb, 0);
+    const char *sq = seqs.data() + R.seq_at;
+    for (int32_t k = 0; k < R.rl; ++k) out.seq4[so + (size_t)(k >> 1)] |= (uint8_t)(NIB.t[(uint8_t)sq[k]] << ((k & 1) ? 0 : 4));
+    out.seq_off.push_back(so);
+  }
+  return true;
+}
+
+int64_t CramFile::read(RecordBatch &b, int64_t max_records, std::string &err) {
+  if (eof_) return 0;
+  if (!pool_) pool_ = new ThreadPool(threads_);
+  int64_t got = 0;
+  while (got < max_records && !eof_) {
+    std::vector<Container> cs;
+    int64_t planned = 0;
+    while ((int)cs.size() < threads_ * 2 && got + planned < max_records) {
+      if (next_off_ + 26 > map_len_) { eof_ = true; break; }
+      Container c;
+      if (!parse_container_header(next_off_, c, err)) return -1;
+      next_off_ = c.data_off + c.len;
+      if (c.n_records <= 0 || c.landmarks.empty()) continue;       // the EOF container, empty containers
+      planned += c.n_records;
+      cs.push_back(std::move(c));
+    }
+    if (cs.empty()) break;
+    std::vector<RecordBatch> parts(cs.size());
+    std::vector<std::string> errs(cs.size());
+    std::vector<int> ok(cs.size(), 1);
+    pool_->parallel_for(cs.size(), [&](size_t k) { ok[k] = decode_container(cs[k], -1, parts[k], errs[k]) ? 1 : 0; });
+    for (size_t k = 0; k < cs.size(); ++k) {
+      if (!ok[k]) { err = errs[k]; return -1; }
+      got += (int64_t)parts[k].size();
+      append_batch(b, parts[k]);
+    }
+  }
+  return got;
+}
+
+bool CramFile::load_index(std::string &err) {
+  gzFile in = gzopen((path_ + ".crai").c_str(), "rb");
+  if (!in) { err = "no .crai index next to " + path_; return false; }
+  char line[512];
+  while (gzgets(in, line, (int)sizeof line)) {
+    long long tid, st, sp, co, so, sz;
+    if (sscanf(line, "%lld\t%lld\t%lld\t%lld\t%lld\t%lld", &tid, &st, &sp, &co, &so, &sz) == 6)
+      crai_.push_back(CraiEntry{(int32_t)tid, st, sp, (uint64_t)co, (uint32_t)so, (uint32_t)sz});
+  }
+  gzclose(in);
+  have_index_ = true;
+  return true;
+}
+
+int64_t CramFile::read_region(RecordBatch &b, int32_t tid, int64_t beg, int64_t end, std::string &err) {
+  int64_t n = 0;
+  RecordBatch part;
+  for (const CraiEntry &e : crai_) {
+    if (e.tid != tid) continue;
+    const int64_t s0 = e.start - 1, s1 = s0 + std::max<int64_t>(e.span, 1);     // 0-based, half open
+    if (s0 >= end || s1 <= beg) continue;
+    Container c;
+    if (!parse_container_header(e.c_off, c, err)) return -1;
+    if (!decode_container(c, (int64_t)e.s_off, part, err)) return -1;
+    RecordBatch keep;
+    // records that start before `end` (the consumers apply the overlap filter themselves, like for a BAM region read)
+    size_t upto = 0;
+    while (upto < part.size() && !(part.tid[upto] == tid && part.pos[upto] >= end)) ++upto;
+    if (upto == part.size()) { n += (int64_t)part.size(); append_batch(b, part); continue; }
+    for (size_t i = 0; i < upto; ++i) {
+      keep.tid.push_back(part.tid[i]); keep.pos.push_back(part.pos[i]); keep.mtid.push_back(part.mtid[i]); keep.mpos.push_back(part.mpos[i]);
+      keep.isize.push_back(part.isize[i]); keep.l_seq.push_back(part.l_seq[i]); keep.flag.push_back(part.flag[i]); keep.mapq.push_back(part.mapq[i]);
+      keep.qnames.append(part.qnames, (size_t)part.qname_off[i], (size_t)(part.qname_off[i + 1] - part.qname_off[i]));
+      keep.qname_off.push_back(keep.qnames.size());
+      keep.cigar.insert(keep.cigar.end(), part.cigar.begin() + part.cigar_off[i], part.cigar.begin() + part.cigar_off[i + 1]);
+      keep.cigar_off.push_back((uint32_t)keep.cigar.size());
+      const size_t so = (keep.seq4.size() + 15) & ~(size_t)15, sb = ((size_t)part.l_seq[i] + 1) / 2;
+      keep.seq4.resize(so + sb, 0);
+      memcpy(keep.seq4.data() + so, part.seq4.data() + part.seq_off[i], sb);
+      keep.seq_off.push_back(so);
+    }
+    n += (int64_t)keep.size();
+    append_batch(b, keep);
+  }
+  return n;
+}
+
+}  // namespace strl

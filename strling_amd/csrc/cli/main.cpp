@@ -25,6 +25,7 @@
 #include "../../../include/strling_amd.h"
 #include "bam_reader.h"
 #include "bgzf_feed.h"
+#include "cram_reader.h"
 
 using namespace strl;
 
@@ -132,6 +133,12 @@ static int cpu_quota() {   // CPUs this process may actually use: the cgroup CPU
   if (quota > 0 && period > 0) hw = (unsigned)std::min<long long>(hw, std::max<long long>(1, (quota + period - 1) / period));
   return (int)hw;
 }
+// open() failed: the reference's message for a file it cannot open; a CRAM the reader refuses says why
+static void quit_open(const std::string &path, const std::string &err) {
+  if (CramFile::is_cram(path) && !err.empty()) quit("[strling] %s: %s", path.c_str(), err.c_str());
+  quit("couldn't open bam");
+}
+
 static int decode_threads() {
   const char *e = getenv("STRL_THREADS");
   if (e && atoi(e) > 0) return atoi(e);
@@ -148,7 +155,7 @@ static void fragment_length_distribution(const std::string &bam, uint32_t frag[4
   memset(frag, 0, 4096 * sizeof(uint32_t));
   BamStream rd;
   std::string err;
-  if (!rd.open(bam, decode_threads(), err)) quit("couldn't open bam");
+  if (!rd.open(bam, decode_threads(), err)) quit_open(bam, err);
   RecordBatch b;
   std::vector<int32_t> skipped;
   int64_t i = -1, counted = 0;
@@ -315,7 +322,9 @@ static int extract_main(int argc, char **argv) {
   const uint8_t min_mapq = (uint8_t)atoi(a.get("min-mapq", "40").c_str());
   const bool verbose = a.flag("verbose");
   const int64_t batch = atoll(a.get("batch", "1048576").c_str());
-  {
+  g_cram_fasta = a.get("fasta", "");
+  const bool is_cram = CramFile::is_cram(bam);     // decoded by host threads (cli/cram_reader.cpp); scoring + pairing on the device as for a BAM
+  if (!is_cram) {
     // Default: the whole BAM front end on the device (inflate, record scan, parse: strl_front_*).  STRL_FRONT=host keeps the
     // host reader (threads inflate and parse, the device scores); STRL_PAIR=host (the host's streaming Cache) implies it.
     const char *fe = getenv("STRL_FRONT"), *pe = getenv("STRL_PAIR");
@@ -347,7 +356,7 @@ static int extract_main(int argc, char **argv) {
   }
   BamStream rd;
   std::string err;
-  if (!rd.open(bam, decode_threads(), err)) quit("couldn't open bam");
+  if (!rd.open(bam, decode_threads(), err)) quit_open(bam, err);
   ctx_thread.join();
   g_bg_init = nullptr;
   if (ctx_rc) quit("[strling] %s (status %d)", ctx_err.c_str(), ctx_rc);
@@ -628,9 +637,18 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   const double t_open = secs(t_start, now());
   strl_opts opts{0, p, min_mapq};              // the fragment-length median is only needed by the pair logic: set before strl_extract_finish
   for (strl_ctx *c : ctxs) CHECK(strl_ctx_set_opts(c, &opts));
+  const auto tg0 = now();
   setup_genome(ctx, a, feed.targets(), std::vector<strl_ctx *>(ctxs.begin() + 1, ctxs.end()));
+  const double t_genome = secs(tg0, now());
   const int32_t n_ref = (int32_t)feed.targets().size();
-  for (strl_ctx *c : ctxs) CHECK(strl_front_begin(c, n_ref, feed.first_record_offset(), feed.file_bytes() / 48 / (size_t)G));
+  // Reads the per-read state is sized for at the start (it grows geometrically beyond): a record of 150 bases with qualities
+  // and a few tags takes 90 - 110 bytes of a level-6 BAM, 60 - 70 without qualities.  (The first sizing was file bytes / 48:
+  // 124 GB of device memory and seconds of set-up for a 57 GB file of 5.4e8 reads.)
+  static const char *env_hint = getenv("STRL_READS_HINT");
+  const uint64_t reads_hint = env_hint ? strtoull(env_hint, nullptr, 10) : feed.file_bytes() / 88 / (size_t)G;
+  const auto tb0 = now();
+  for (strl_ctx *c : ctxs) CHECK(strl_front_begin(c, n_ref, feed.first_record_offset(), reads_hint));
+  const double t_begin = secs(tb0, now());
 
   fprintf(stderr, "[strling] collecting str-like reads\n");
   const auto t0 = now();
@@ -851,7 +869,9 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   for (uint64_t i = 0; i < nt; ++i) treads_p[i].qname_id = (int64_t)i;
   const double t_pair = secs(tp0, now());
   fprintf(stderr, "[strling] writing binary file:%s\n", bin.c_str());
+  const auto tw0 = now();
   CHECK(strl_bin_write(bin.c_str(), (float)p, min_mapq, frag, feed.header_text().data(), (int32_t)feed.header_text().size(), treads_p, nt, qoff_p, names_p));
+  const double t_write = secs(tw0, now());
   fprintf(stderr, "[strling] finished extraction\n");
   if (verbose) {
     fprintf(stderr, "[strling] %lld reads, %llu STR reads, 0 reads still waiting for a mate\n", (long long)nreads, (unsigned long long)nt);
@@ -866,7 +886,8 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   }
   if (verbose)
     fprintf(stderr, "[strling] seconds before the loop: %.3f to the open context (device context %.3f, page-locked buffers %.3f: two threads beside the header walk), "
-                    "genome + front end set-up %.3f\n", t_open, t_ctx, t_pin, secs(t_start, t0) - t_open);
+                    "genome table %.3f, per-read state for %llu reads %.3f; writing the .bin %.3f; whole run %.3f\n", t_open, t_ctx, t_pin, t_genome, (unsigned long long)reads_hint, t_begin, t_write,
+            secs(t_start, now()));
   // the process ends here: the driver reclaims device and page-locked memory faster than freeing them piece by piece would
   // (STRL_TEARDOWN=1 frees them explicitly)
   if (getenv("STRL_TEARDOWN")) {
@@ -1169,6 +1190,7 @@ static int call_main(int argc, char **argv) {
   const uint8_t min_mapq = (uint8_t)atoi(a.get("min-mapq", "40").c_str());
   const bool verbose = a.flag("verbose");
 
+  g_cram_fasta = a.get("fasta", "");
   uint32_t frag[4096];
   fragment_length_distribution(bam, frag);                                          // call.nim:92
   const int frag_median = strl_frag_median(frag, 0.5);
@@ -1178,7 +1200,7 @@ static int call_main(int argc, char **argv) {
   }
   BamReader rd;
   std::string err;
-  if (!rd.open(bam, err) || !rd.load_index(bam, err)) quit("couldn't open bam");    // index=true, call.nim:101-102
+  if (!rd.open(bam, err) || !rd.load_index(bam, err)) quit_open(bam, err);    // index=true, call.nim:101-102
   const int window = strl_frag_median(frag, 0.99);                                  // call.nim:109
   const strl_call_opts copts{frag_median, min_support, min_clip, min_clip_total};
 
@@ -1357,12 +1379,13 @@ static int call_main(int argc, char **argv) {
 // `strling _dump BAM`: SAM-like text of every record as the reader decoded it (reader self-check; needs no GPU)
 static int dump_main(int argc, char **argv) {
   if (argc < 3) quit("usage: strling _dump BAM [stream [BATCH]]");
+  if (getenv("STRL_CRAM_FASTA")) g_cram_fasta = getenv("STRL_CRAM_FASTA");
   const bool stream = argc > 3 && std::string(argv[3]) == "stream";   // the multi-threaded whole-file reader instead of the plain one
   const int64_t batch = argc > 4 ? atoll(argv[4]) : 4096;
   BamReader rd;
   BamStream rs;
   std::string err;
-  if (stream ? !rs.open(argv[2], decode_threads(), err) : !rd.open(argv[2], err)) quit("couldn't open bam");
+  if (stream ? !rs.open(argv[2], decode_threads(), err) : !rd.open(argv[2], err)) quit_open(argv[2], err);
   fputs((stream ? rs.header_text() : rd.header_text()).c_str(), stdout);
   RecordBatch b;
   for (;;) {
@@ -1422,6 +1445,7 @@ static int region_main(int argc, char **argv) {
   if (argc < 6) quit("usage: strling _region BAM TID BEG END");
   BamReader rd;
   std::string err;
+  if (getenv("STRL_CRAM_FASTA")) g_cram_fasta = getenv("STRL_CRAM_FASTA");
   if (!rd.open(argv[2], err) || !rd.load_index(argv[2], err)) quit("couldn't open bam: %s", err.c_str());
   const int32_t tid = atoi(argv[3]);
   const int64_t beg = atoll(argv[4]), end = atoll(argv[5]);

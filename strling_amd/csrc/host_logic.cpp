@@ -15,6 +15,7 @@
 #include <string_view>
 #include <unordered_map>
 #include <unordered_set>
+#include <atomic>
 #include <vector>
 #include "common.h"
 
@@ -636,21 +637,48 @@ int strl_bin_write(const char *path, float proportion_repeat, uint8_t min_mapq, 
   b.append(sam_header, (size_t)header_len);
   const int32_t n32 = (int32_t)n;
   b.append((const char *)&n32, 4);
-  for (uint64_t i = 0; i < n; ++i) {                        // pack_type, cluster.nim:38-50
-    const strl_tread &t = treads[i];
-    mp_int(b, t.tid);
-    mp_uint(b, t.position);
-    b.push_back((char)0x96);
-    for (int j = 0; j < 6; ++j) mp_uint(b, (uint8_t)t.repeat[j]);
-    mp_uint(b, t.flag);
-    mp_uint(b, t.split);
-    mp_uint(b, t.mapping_quality);
-    mp_uint(b, t.repeat_count);
-    mp_uint(b, t.align_length);
-    const uint64_t q0 = qname_off[t.qname_id], q1 = qname_off[t.qname_id + 1];
-    mp_uint(b, q1 - q0);
-    mp_str(b, qnames + q0, (size_t)(q1 - q0));
-    if (b.size() > (1u << 20)) { if (fwrite(b.data(), 1, b.size(), f) != b.size()) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; } b.clear(); }
+  auto pack = [&](std::string &o, uint64_t i0, uint64_t i1) {   // pack_type, cluster.nim:38-50
+    for (uint64_t i = i0; i < i1; ++i) {
+      const strl_tread &t = treads[i];
+      mp_int(o, t.tid);
+      mp_uint(o, t.position);
+      o.push_back((char)0x96);
+      for (int j = 0; j < 6; ++j) mp_uint(o, (uint8_t)t.repeat[j]);
+      mp_uint(o, t.flag);
+      mp_uint(o, t.split);
+      mp_uint(o, t.mapping_quality);
+      mp_uint(o, t.repeat_count);
+      mp_uint(o, t.align_length);
+      const uint64_t q0 = qname_off[t.qname_id], q1 = qname_off[t.qname_id + 1];
+      mp_uint(o, q1 - q0);
+      mp_str(o, qnames + q0, (size_t)(q1 - q0));
+    }
+  };
+  // a whole genome leaves millions of treads (~30 bytes each): their records are packed by a few threads, range by range,
+  // and written in order (the bytes are the sequential writer's)
+  const unsigned hw = std::thread::hardware_concurrency();
+  const uint64_t per = 1 << 16;
+  const unsigned n_thr = n < 4 * per ? 1u : std::min<unsigned>({hw ? hw : 1u, 16u, (unsigned)((n + per - 1) / per)});
+  if (n_thr <= 1) {
+    for (uint64_t i0 = 0; i0 < n; i0 += per) {
+      pack(b, i0, std::min(n, i0 + per));
+      if (fwrite(b.data(), 1, b.size(), f) != b.size()) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; }
+      b.clear();
+    }
+  } else {
+    if (fwrite(b.data(), 1, b.size(), f) != b.size()) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; }
+    b.clear();
+    const uint64_t n_parts = (n + per - 1) / per;
+    std::vector<std::string> parts((size_t)n_parts);
+    std::atomic<uint64_t> next{0};
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < n_thr; ++k)
+      th.emplace_back([&] {
+        for (uint64_t q; (q = next.fetch_add(1)) < n_parts;) { parts[(size_t)q].reserve((size_t)per * 40); pack(parts[(size_t)q], q * per, std::min(n, (q + 1) * per)); }
+      });
+    for (auto &t : th) t.join();
+    for (const std::string &o : parts)
+      if (fwrite(o.data(), 1, o.size(), f) != o.size()) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; }
   }
   if (fwrite(b.data(), 1, b.size(), f) != b.size()) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; }
   fclose(f);

@@ -389,12 +389,12 @@ def test_merge_diff_refs(oracle, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cram_input_gets_the_reference_error(tmp_path):
-    """CRAM needs htslib's codec stack, which this build does not have: `couldn't open bam` like extract.nim:276"""
+def test_damaged_cram_input_is_refused_with_a_reason(tmp_path):
+    """a file that says CRAM but holds nothing readable: exit code 1 and the reason (tests/test_cram.py covers real CRAM input)"""
     p = str(tmp_path / "x.cram")
     open(p, "wb").write(b"CRAM\x03\x00" + b"\0" * 64)
     r = _run(["extract", p, str(tmp_path / "x.bin")])
-    assert r.returncode == 1 and "couldn't open bam" in r.stderr
+    assert r.returncode == 1 and "x.cram: CRAM without a file header block" in r.stderr
 
 
 def test_malformed_bgzf_blocks_are_rejected(tmp_path):

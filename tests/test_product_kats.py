@@ -75,3 +75,37 @@ def test_bounds_kats_on_a_bare_cluster_including_left_most_right_most(ctx, k):
     for f, v in k.get("expect", {}).items():
         assert int(b[f]) == v, (f, int(b[f]), v)
     assert int(b["left"]) < int(b["right"])
+
+
+def test_bin_writer_packs_large_tread_sets_on_several_threads(tmp_path):
+    """more than 2^18 treads: strl_bin_write packs ranges of them on a few threads -- the bytes stay the sequential writer's (the oracle's)"""
+    import numpy as np
+    from oracle import oracle as O
+    from strling_amd import api
+    rng = np.random.default_rng(11)
+    n = 300_000
+    t = np.zeros(n, api.TREAD_DTYPE)
+    t["tid"] = rng.integers(-1, 3000, n)
+    t["position"] = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    units = np.array([b"A", b"AC", b"CAG", b"AAAG", b"AACCT", b"ACGTCA"])
+    t["repeat"] = units[rng.integers(0, 6, n)]
+    t["flag"] = rng.integers(0, 4096, n)
+    t["split"] = rng.integers(0, 6, n)
+    t["mapping_quality"] = rng.integers(0, 61, n)
+    t["repeat_count"] = rng.integers(0, 256, n)
+    t["align_length"] = rng.integers(0, 256, n)
+    t["qname_id"] = np.arange(n)
+    names = [b"q%d" % int(x) for x in rng.integers(0, 10 ** 9, n)]
+    qoff = np.zeros(n + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(x) for x in names])
+    qn = b"".join(names)
+    frag = rng.integers(0, 1000, 4096).astype(np.uint32)
+    p = str(tmp_path / "big.bin")
+    api.bin_write(p, 0.8, 40, frag, "@HD\tVN:1.6\n", t, qoff, qn)
+    ot = np.zeros(n, O.TREAD_DTYPE)
+    for f in ot.dtype.names:
+        if f in t.dtype.names:
+            ot[f] = t[f]
+    assert open(p, "rb").read() == O.bin_write(0.8, 40, frag, "@HD\tVN:1.6\n", ot, qoff, qn)
+    back = api.bin_read(p)
+    assert np.array_equal(back["treads"]["position"], t["position"]) and back["qnames"] == qn
