@@ -501,7 +501,7 @@ def end_to_end(n_pairs, check_slabs=4):
     try:
         res = e2e_bench.run(inp, build.CLI)
         if check_slabs and "error" not in res:
-            res["check"] = e2e_bench.check(inp, e2e_bench.pick_slabs(inp["n_slabs"], check_slabs), call=res.get("call_rc") == 0)
+            res["check"] = e2e_bench.check_in_subprocess(inp, e2e_bench.pick_slabs(inp["n_slabs"], check_slabs), call=res.get("call_rc") == 0)
         return res
     finally:
         e2e_bench.cleanup(inp)

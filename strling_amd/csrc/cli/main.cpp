@@ -833,12 +833,14 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   const auto tp0 = now();
   uint64_t nt = 0;
   int rc = 0;
+  double t_finish = 0;
   auto cap_of = [](uint64_t v) { return std::min<uint64_t>(v, 0x7ffffff0ull); };
   for (int attempt = 0; attempt < 2; ++attempt) {
     CHECK(strl_extract_finish(ctx, n_tail, attempt ? cap_of(3 * n_seen + 16) : 0, attempt ? cap_of(8 * n_seen + 16) : 0));
     rc = strl_treads_fetch(ctx, nullptr, 0, &nt, nullptr);
     if (rc != STRL_ERR_CAPACITY) break;
   }
+  t_finish = secs(tp0, now());
   if (rc == STRL_ERR_FORMAT) {
     fprintf(stderr, "[strling] %s: repeating the extraction with the host pair logic\n", strl_last_error());
     for (size_t k = 0; k < pin.size(); ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
@@ -854,13 +856,16 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   uint64_t *qoff_p = reinterpret_cast<uint64_t *>(pin[1]);
   const uint64_t names_room = chunk_bytes > (nt + 1) * 8 + 4096 ? chunk_bytes - (nt + 1) * 8 - 64 : 0;
   char *names_p = reinterpret_cast<char *>(pin[1]) + (nt + 1) * 8 + 64;
-  if ((nt + 1) * sizeof(strl_tread) > chunk_bytes || names_room < nt * 64) {
-    tv.resize((size_t)nt + 1); qv.resize((size_t)nt + 1); nv.resize((size_t)nt * 255 + 16);
+  // (names: the room behind the offsets serves unless the names average more than 24 bytes -- then the call reports what it
+  // needs and is repeated with vectors; sizing for the 255-byte maximum made a whole genome's 8e6 treads zero-fill 2 GB)
+  if ((nt + 1) * sizeof(strl_tread) > chunk_bytes || names_room < nt * 24) {
+    tv.resize((size_t)nt + 1); qv.resize((size_t)nt + 1);
+    nv.resize((size_t)std::min<uint64_t>(nt * 255, std::max<uint64_t>(nt * 32, 1 << 20)) + 16);
     treads_p = tv.data(); qoff_p = qv.data(); names_p = &nv[0];
   }
   uint64_t need = 0, ngot = 0;
   rc = strl_front_treads_named(ctx, treads_p, nt + 1, &ngot, qoff_p, names_p, treads_p == tv.data() ? nv.size() : names_room, &need);
-  if (rc == STRL_ERR_CAPACITY && treads_p != tv.data()) {       // names longer than the room behind the offsets: plain vectors
+  if (rc == STRL_ERR_CAPACITY) {       // names longer than the room given: plain vectors of the size the call reported
     tv.resize((size_t)nt + 1); qv.resize((size_t)nt + 1); nv.resize((size_t)need + 16);
     treads_p = tv.data(); qoff_p = qv.data(); names_p = &nv[0];
     rc = strl_front_treads_named(ctx, treads_p, nt + 1, &ngot, qoff_p, names_p, nv.size(), &need);
@@ -876,8 +881,8 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   if (verbose) {
     fprintf(stderr, "[strling] %lld reads, %llu STR reads, 0 reads still waiting for a mate\n", (long long)nreads, (unsigned long long)nt);
     fprintf(stderr, "[strling] seconds: total %.3f  waiting for block headers %.3f  copying compressed bytes %.3f  enqueueing + waiting for the device %.3f  "
-                    "draining the device %.3f  fragment lengths %.3f (copy %.3f, set_opts %.3f)  pair logic + names %.3f  (device front end; %llu scan segments walked twice)\n",
-            secs(t0, now()), t_walk, t_copy, t_push, t_drain, t_frag, t_frag_copy, t_setopts, t_pair, (unsigned long long)slow_segments);
+                    "draining the device %.3f  fragment lengths %.3f (copy %.3f, set_opts %.3f)  pair logic + names %.3f (pair logic over all reads + .bin order %.3f)  (device front end; %llu scan segments walked twice)\n",
+            secs(t0, now()), t_walk, t_copy, t_push, t_drain, t_frag, t_frag_copy, t_setopts, t_pair, t_finish, (unsigned long long)slow_segments);
   }
   if (verbose) {
     uint64_t mf = 0, mt = 0;

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_fields():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--reads-per-gpu",
-                        str(2 ** 21), "--cpu-seconds", "1"], capture_output=True, text=True, cwd=ROOT)
+                        str(2 ** 21), "--cpu-seconds", "1", "--e2e-pairs", str(2 ** 20)], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-800:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -28,6 +28,9 @@ def test_bench_line_has_the_contract_fields():
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
     assert rf["kernel"] in rf["kernel_ms"] and rf["kernel_ms"][rf["kernel"]] == max(rf["kernel_ms"].values())
+    e2e = d["end_to_end"]
+    assert e2e["reads"] == 2 ** 21 and e2e["call_rc"] == 0 and e2e["merge_rc"] == 0 and e2e["check"]["ok"] and e2e["check"]["treads_checked"] > 1000
+    assert e2e["value"] > 1e6 and e2e["reads_per_s_extract_plus_call"] > 1e5 and e2e["runs"][0]["device_mem_GB"] > 0
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k

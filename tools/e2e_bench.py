@@ -203,6 +203,21 @@ def check(inp, slabs, call=True, procs=None):
                     "against the oracle's call over the slab"}
 
 
+def check_in_subprocess(inp, slabs, call=True):
+    """check() in a process of its own: the caller (bench.py) has not started the GPU runtime yet and forks generators later --
+    loading the library (bin_read) into it first made its later hipInit find no device"""
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump({"inp": inp, "slabs": list(slabs), "call": bool(call)}, f)
+        path = f.name
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--check-json", path], capture_output=True, text=True)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if r.returncode == 0 and lines else {"ok": False, "error": (r.stderr or r.stdout)[-400:]}
+    finally:
+        os.remove(path)
+
+
 def pick_slabs(n_slabs, k):
     """a deterministic spread of k slabs over the file (first, last, evenly between)"""
     k = max(1, min(k, n_slabs))
@@ -227,7 +242,12 @@ if __name__ == "__main__":
     ap.add_argument("--repeats", type=int, default=1)
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--out", default="")
+    ap.add_argument("--check-json", default="", help="(internal) run check() on the input described by this file and print its result")
     a = ap.parse_args()
+    if a.check_json:
+        j = json.load(open(a.check_json))
+        print(json.dumps(check(j["inp"], j["slabs"], call=j["call"])))
+        sys.exit(0)
     inp = make_input(a.n_pairs, d=a.dir, level=a.level, progress=True)
     print(f"[e2e] wrote {inp['bam']} ({inp['bam_MB']} MB, {inp['reads']} reads) in {inp['make_s']} s", file=sys.stderr, flush=True)
     res = run(inp, build.CLI, repeats=a.repeats)
