@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-PROFILE_ROUND = "r03"     # profiles/<round>/traffic.json, pmc_counters.json: the PMC passes the roofline block quotes
+PROFILE_ROUND = "r04"     # profiles/<round>/traffic.json, pmc_counters.json: the PMC passes the roofline block quotes
 
 
 def main():
@@ -323,9 +323,9 @@ def main():
     c_ach = c_bytes / (c_ms * 1e-3) / 1e9 if c_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                "traffic_note": "HBM bytes per launch of that kernel from profiles/r03/traffic.json (PMC, same workload)",
+                "traffic_note": f"HBM bytes per launch of that kernel from profiles/{PROFILE_ROUND}/traffic.json (rocprofv3 PMC passes of the same workload and build, committed; not measured in this run)", "from_committed_profile": True,
                 "valu_issue_frac": valu_frac,
-                "valu_note": "SQ_INSTS_VALU (profiles/r03/pmc_counters.json) x 4 cycles / (launch time x 1024 SIMDs x 2.4 GHz): the scorer launches are bound by integer VALU issue, not by HBM",
+                "valu_note": f"SQ_INSTS_VALU (profiles/{PROFILE_ROUND}/pmc_counters.json, committed) x 4 cycles / (launch time x 1024 SIMDs x 2.4 GHz): the scorer launches are bound by integer VALU issue, not by HBM",
                 "hbm_bound_launch": {"kernel": "classify_kernel", "achieved": round(c_ach, 2), "frac": round(c_ach / HBM_PEAK_GBPS, 5), "traffic": c_traffic,
                                      "note": "slowest launch that HBM traffic bounds (13 B read + 4 B written per read, algorithmic)"},
                 "times_note": "kernel_ms / group_ms: un-overlapped launch times from instrumented steps (HIP events, one stream); ms_per_step is the "
