@@ -560,9 +560,36 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "s_cbranch_vccnz L_iw_match5_%=\n\t"
       "s_cbranch_scc1 L_iw_match5_%=\n\t"
       "v_sub_u32_e32 %[vsrc], %[pos], %[vD]\n\t"
-      // staged literals first (the match may read them)
+      // Staged literals [fpos, pos): their store must be issued before a load that reads them -- a match whose source reaches
+      // into them (pos - D + L > fpos: rare, distances are hundreds of bytes) flushes first.  Otherwise the copy goes first and
+      // the flush behind it: the copy's wait then covers loads and stores of the PREVIOUS match only, not a store issued a
+      // moment ago (removing the copy's waits altogether measured +13 %, profiles/r04/inflate_exp_waits.txt).
       "s_cmp_lt_u32 %[fpos], %[pos]\n\t"
       "s_cbranch_scc0 L_iw_copy_%=\n\t"
+      "v_add_u32_e32 %[vt0], %[L], %[vsrc]\n\t"
+      "v_cmp_lt_u32_e32 vcc, %[fpos], %[vt0]\n\t"
+      "s_cbranch_vccnz L_iw_flushfirst_%=\n\t"
+      // the first 64 bytes of the copy, then the staged literals
+      "v_cmp_gt_u32_e32 vcc, %[L], %[vlane]\n\t"
+      "v_add_u32_e32 %[vt1], %[vsrc], %[vlane]\n\t"
+      "v_add_u32_e32 %[vt0], %[pos], %[vlane]\n\t"
+      IW_EXP_WAIT
+      IW_EXP_COPY
+      "v_cndmask_b32_e32 %[paddr], %[voob], %[vt0], vcc\n\t"
+      "s_and_b32 s92, %[fpos], 63\n\t"
+      "s_sub_u32 s95, %[pos], %[fpos]\n\t"
+      "s_andn2_b32 s94, %[fpos], 63\n\t"
+      "v_subrev_u32_e32 %[vt0], s92, %[vlane]\n\t"
+      "v_cmp_gt_u32_e32 vcc, s95, %[vt0]\n\t"
+      "v_or_b32_e32 %[vt1], s94, %[vlane]\n\t"
+      "v_cndmask_b32_e32 %[vt1], %[voob], %[vt1], vcc\n\t"
+      "buffer_store_byte %[pend], %[vt1], %[rsrc], 0 offen\n\t"
+      "s_cmp_gt_u32 %[L], 64\n\t"
+      "s_cbranch_scc1 L_iw_more_%=\n\t"
+      "s_add_u32 %[pos], %[pos], %[L]\n\t"
+      "s_mov_b32 %[fpos], %[pos]\n\t"
+      "s_branch L_iw_loop_%=\n"
+      "L_iw_flushfirst_%=:\n\t"
       "s_and_b32 s92, %[fpos], 63\n\t"
       "s_sub_u32 s95, %[pos], %[fpos]\n\t"
       "s_andn2_b32 s94, %[fpos], 63\n\t"

@@ -37,7 +37,7 @@ def loci_bed(rows, targets, k0):
 
 
 t0 = time.time()
-n_call = n_merge = n_rows = 0
+n_call = n_merge = n_rows = n_cram = 0
 with tempfile.TemporaryDirectory() as d:
     while time.time() - t0 < budget:
         seed = int(rng.integers(1, 1 << 30))
@@ -51,14 +51,25 @@ with tempfile.TemporaryDirectory() as d:
         if rng.random() < 0.7:          # ---- extract -> call ----
             rec, g = synth.synth_wgs(n_pairs, seed=seed, **kw)
             bam, bed, binp, pre = (os.path.join(d, x) for x in ("s.bam", "g.str", "s.bin", "o"))
-            bamio.write_bam(bam, rec)
+            fa_args = []
+            if n_pairs == 3000 and rng.random() < 0.5:     # the same records as a CRAM (random slice / container shapes): same files expected
+                from strling_amd import cramio
+                bam = os.path.join(d, "s.cram")
+                refs = cramio.make_reference(rec, seed=seed)
+                cramio.write_fasta(os.path.join(d, "ref.fa"), rec.targets, refs)
+                cramio.write_cram(bam, rec, refs, records_per_slice=int(rng.choice([97, 500, 4000])), slices_per_container=int(rng.choice([1, 3])),
+                                  ap_delta=bool(rng.random() < 0.7))
+                fa_args = ["-f", os.path.join(d, "ref.fa")]
+                n_cram += 1
+            else:
+                bamio.write_bam(bam, rec)
             bamio.write_genome_bed(bed, g, rec.targets)
-            run(["extract", "-g", bed, "-q", str(q), bam, binp])
+            run(["extract"] + fa_args + ["-g", bed, "-q", str(q), bam, binp])
             frag = synth.frag_hist(rec)
             tr = O.extract(rec, g, O.make_opts(O.median(frag), 0.8, q))
             kwc = dict(min_support=m, min_mapq=q, min_clip=c, min_clip_total=t)
             eb, eg, eu = O.call(tr, rec, frag, **kwc)
-            args = ["call", "-m", str(m), "-q", str(q), "-c", str(c), "-t", str(t), "-o", pre]
+            args = ["call"] + fa_args + ["-m", str(m), "-q", str(q), "-c", str(c), "-t", str(t), "-o", pre]
             extra = {}
             rows = ["\t".join(l.split("\t")[:11]) for l in eb.splitlines()[1:]]
             if rows and rng.random() < 0.5:
@@ -107,4 +118,4 @@ with tempfile.TemporaryDirectory() as d:
             assert open(os.path.join(d, "j-bounds.txt")).read() == exp, ("merge", tag)
             n_merge += 1
             n_rows += exp.count("\n") - 1
-print(f"fuzz_call ok: {n_call} extract->call runs, {n_merge} merges, {n_rows} bounds rows identical to the oracle in {time.time() - t0:.0f} s")
+print(f"fuzz_call ok: {n_call} extract->call runs ({n_cram} of them from CRAM), {n_merge} merges, {n_rows} bounds rows identical to the oracle in {time.time() - t0:.0f} s")
