@@ -293,7 +293,7 @@ def make_reference(rec, seed=1):
     """a reference the synthetic reads partly agree with: every position takes the base of the first mapped read that covers it
     with an M operation (other reads disagree there and get substitution features), the rest is random"""
     rng = np.random.default_rng(seed)
-    refs = [np.frombuffer(bytes(rng.choice(list(b"ACGT"), ln)), np.uint8).copy() for _, ln in rec.targets]
+    refs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), ln).astype(np.uint8) for _, ln in rec.targets]
     done = [np.zeros(ln, bool) for _, ln in rec.targets]
     for i in range(rec.n):
         t = int(rec.tid[i])

@@ -653,7 +653,7 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
     const int32_t n_ids = h.itf8();
     for (int32_t k = 0; k < n_ids && h.ok; ++k) h.itf8();
     const int32_t embedded = h.itf8();
-    if (!h.ok || s_nrec < 0 || s_nblocks < 0) { err = "malformed CRAM slice header"; return false; }
+    if (!h.ok || s_nrec < 0 || s_nblocks < 0 || s_nrec > (1 << 24) || s_nblocks > (1 << 16)) { err = "malformed CRAM slice header"; return false; }
     if (embedded >= 0) { err = "the CRAM slice embeds its reference: not supported by this build (samtools view -C --output-fmt-option embed_ref=0)"; return false; }
     Ctx X;
     for (int32_t k = 0; k < s_nblocks; ++k) {

@@ -112,7 +112,7 @@ namespace strl {
 constexpr int IW_ERR_DATA = 1, IW_ERR_SIZE = 2, IW_ERR_CRC = 4;
 constexpr uint32_t IW_OOB = 0x80000000u;   // an offset no descriptor of this file covers (num_records < 2^31)
 #ifndef IW_LIT_ROOT_BITS
-#define IW_LIT_ROOT_BITS 9     // measured: 9 bits (2 KB, 4.4 KB of LDS per wave) 95.6 / 70.7 GB/s, 10 bits 87.9 / 64.2 (profiles/r04/inflate_hybrid.txt)
+#define IW_LIT_ROOT_BITS 9     // measured: 9 bits (2 KB, 4.4 KB of LDS per wave: 28 waves per CU) 95.6 / 70.7 GB/s, 10 bits 87.9 / 64.2 (profiles/r04/inflate_hybrid.txt)
 #endif
 constexpr int IW_LIT_ROOT = IW_LIT_ROOT_BITS, IW_DIST_ROOT = 8, IW_CL_ROOT = 7;
 

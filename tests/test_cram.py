@@ -74,6 +74,7 @@ def cram_sample(tmp_path_factory):
     d = tmp_path_factory.mktemp("cram")
     rec, g = synth.synth_wgs(1500, seed=21, n_contigs=3, contig_len=40_000, indel_frac=0.05, soft_frac=0.08)
     refs = cramio.make_reference(rec, seed=2)
+    assert [len(r) for r in refs] == [40_000] * 3
     fa = str(d / "ref.fa")
     cramio.write_fasta(fa, rec.targets, refs)
     cram = str(d / "s.cram")
@@ -140,6 +141,26 @@ def test_cram_variants_and_refusals(cram_sample, tmp_path):
     p31 = str(tmp_path / "v31.cram"); open(p31, "wb").write(data)
     r = _run(["_dump", p31], env=env)
     assert r.returncode == 1 and "CRAM version 3.1" in r.stderr
+
+
+def test_damaged_cram_never_crashes_the_reader(cram_sample, tmp_path):
+    """single-byte damage anywhere in the file: the reader reports or decodes something, it never dies on a signal"""
+    data = open(cram_sample["cram"], "rb").read()
+    env = dict(os.environ, STRL_CRAM_FASTA=cram_sample["fa"])
+    rng = np.random.default_rng(5)
+    p = str(tmp_path / "bad.cram")
+    n_err = 0
+    for k in range(120):
+        b = bytearray(data)
+        at = int(rng.integers(26, len(b) - 40))
+        b[at] ^= int(rng.integers(1, 256))
+        if k % 3 == 0:
+            del b[at + 1:at + 1 + int(rng.integers(1, 9))]          # and a few bytes missing behind it
+        open(p, "wb").write(b)
+        r = subprocess.run([CLI, "_dump", p], capture_output=True, env=env)
+        assert r.returncode in (0, 1), (k, at, r.returncode, r.stderr[-200:])
+        n_err += r.returncode
+    assert n_err > 10
 
 
 def test_crai_region_reads(cram_sample):
