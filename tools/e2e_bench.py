@@ -87,11 +87,13 @@ def run(inp, cli, threads=(0,), call=True, merge=True, repeats=1):
         mem_gb = float(re.search(r": ([\d.]+) GB of", mem[-1]).group(1)) if mem else None
         n_str = [l for l in err if " STR reads, " in l]
         su = [l for l in err if "seconds before the loop" in l]
+        um = [l for l in err if "file mapping released in" in l]
         run_ = {"decode_threads": t or "default", "rc": r.returncode, "wall_s": round(wall, 3), "reads_per_s_wall": round(inp["reads"] / wall),
                 "loop_s": loop_s, "reads_per_s_loop": round(inp["reads"] / loop_s) if loop_s else None, "device_front_end": front,
                 "device_mem_GB": mem_gb, "str_reads": int(n_str[-1].split(" reads, ")[1].split()[0]) if n_str else None,
                 "phases": line[-1].split("seconds:")[1].strip() if line else r.stderr[-400:],
-                "outside_the_loop": su[-1].split("seconds before the loop:")[1].strip() if su else None}
+                "outside_the_loop": su[-1].split("seconds before the loop:")[1].strip() if su else None,
+                "unmap_s": float(um[-1].split("released in")[1].split()[0]) if um else None}
         if r.returncode != 0:
             run_["stderr_tail"] = r.stderr[-600:]
         res["runs"].append(run_)
