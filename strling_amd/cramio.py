@@ -336,8 +336,12 @@ def _pair_tlen(a, b):
     return -t, t
 
 
-def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_per_container=2, read_names=True, index=True, ap_delta=True):
-    """records of `rec` (coordinate sorted, unmapped tail last) -> CRAM 3.0 + .crai.  refs[tid] = reference bytes (ACGTN)."""
+def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_per_container=2, read_names=True, index=True, ap_delta=True,
+               multi_ref=False, qualities=False, tags=False):
+    """records of `rec` (coordinate sorted, unmapped tail last) -> CRAM 3.0 + .crai.  refs[tid] = reference bytes (ACGTN).
+    multi_ref: slices run across reference boundaries (slice reference id -2, RI per record); qualities: every record carries its
+    quality array (CF bit 1, QS per base); tags: every record carries NM:C and MD:Z (tag dictionary + tag encoding map: values
+    the reader must walk past)."""
     from .bamio import sam_header
     text = (header_text if header_text is not None else sam_header(rec.targets)).encode()
     out = bytearray(b"CRAM" + bytes([3, 0]) + b"strling-test".ljust(20, b"\0"))
@@ -356,7 +360,7 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
     while i < rec.n:
         t = int(rec.tid[i])
         j = i
-        while j < rec.n and j - i < records_per_slice and int(rec.tid[j]) == t:
+        while j < rec.n and j - i < records_per_slice and (multi_ref or int(rec.tid[j]) == t):
             j += 1
         slices.append((i, j))
         i = j
@@ -380,7 +384,7 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
             for k, r in enumerate(rs):
                 by_name.setdefault(r["name"], []).append(k)
             for r in rs:
-                r["cf"] = 2 if r["flag"] & 1 else 0
+                r["cf"] = (2 if r["flag"] & 1 else 0) | (1 if qualities else 0)
             for ks in by_name.values():
                 if len(ks) != 2:
                     continue
@@ -392,7 +396,8 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
                 for p, q in ((x, y), (y, x)):
                     ok = ok and bool(p["flag"] & 0x20) == bool(q["flag"] & 0x10) and bool(p["flag"] & 0x8) == bool(q["flag"] & 0x4)
                 if ok:
-                    x["cf"], x["nf"], y["cf"] = 4, ks[1] - ks[0] - 1, 0
+                    q1 = 1 if qualities else 0
+                    x["cf"], x["nf"], y["cf"] = 4 | q1, ks[1] - ks[0] - 1, q1
             recs.append(rs)
         # ---- compression header ----
         cf_freq = {}
@@ -403,7 +408,7 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
         cf_syms = sorted(cf_len)
         cf_codes = canonical_codes(cf_syms, [cf_len[s] for s in cf_syms]) if len(cf_syms) > 1 else {cf_syms[0]: (0, 0)}
         pres = b"RN" + bytes([1 if read_names else 0]) + b"AP" + bytes([1 if ap_delta else 0]) + b"RR" + bytes([1]) + b"SM" + bytes([0x1B] * 5) + \
-            b"TD" + itf8(1) + b"\0"
+            b"TD" + (itf8(7) + b"NMCMDZ\0" if tags else itf8(1) + b"\0")
         pres = itf8(5) + pres
         ds = {
             "BF": enc_external(CID["BF"]), "CF": enc_huffman(cf_syms, [cf_len[s] for s in cf_syms]), "RI": enc_external(CID["RI"]),
@@ -415,7 +420,8 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
             "PD": enc_external(CID["PD"]), "RS": enc_external(CID["RS"]), "MQ": enc_beta(0, 8), "BA": enc_external(CID["BA"]), "QS": enc_external(CID["QS"]),
         }
         dsm = itf8(len(ds)) + b"".join(k.encode() + v for k, v in ds.items())
-        tagm = itf8(0)
+        NM_KEY, MD_KEY = (ord("N") << 16) | (ord("M") << 8) | ord("C"), (ord("M") << 16) | (ord("D") << 8) | ord("Z")
+        tagm = itf8(2) + itf8(NM_KEY) + enc_len(enc_huffman([1], [0]), enc_external(40)) + itf8(MD_KEY) + enc_stop(9, 41) if tags else itf8(0)
         comp_hdr = block(GZIP if c0 % 2 else RAW, COMPRESSION_HEADER, 0, itf8(len(pres)) + pres + itf8(len(dsm)) + dsm + itf8(len(tagm)) + tagm)
         # ---- slices ----
         blocks, landmarks, at = [comp_hdr], [], len(comp_hdr)
@@ -423,17 +429,19 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
         c_start, c_end = None, 0
         slice_meta = []
         for (a, b), rs in zip(group, recs):
-            ext = {k: bytearray() for k in set(CID.values())}
+            ext = {k: bytearray() for k in set(CID.values()) | {40, 41}}
             bits = Bits()
-            tid = rs[0]["tid"]
+            tid = rs[0]["tid"] if len({r["tid"] for r in rs}) == 1 else -2
             mapped = [r for r in rs if r["tid"] >= 0]
-            s_start = min((r["pos"] for r in mapped), default=0)
-            s_end = max((max(r["end"], r["pos"]) for r in mapped), default=0)
+            s_start = min((r["pos"] for r in mapped), default=0) if tid != -2 else 0
+            s_end = max((max(r["end"], r["pos"]) for r in mapped), default=0) if tid != -2 else 0
             prev_pos = s_start
             for r in rs:
                 ext[CID["BF"]] += itf8(r["flag"])
                 code, nb = cf_codes[r["cf"]]
                 bits.put(code, nb)
+                if tid == -2:
+                    ext[CID["RI"]] += itf8(r["tid"])
                 ext[CID["RL"]] += itf8(r["L"])
                 ext[CID["AP"]] += itf8(r["pos"] - prev_pos if ap_delta else r["pos"])
                 prev_pos = r["pos"] if ap_delta else prev_pos
@@ -449,7 +457,10 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
                     ext[CID["TS"]] += itf8(r["tlen"])
                 elif r["cf"] & 4:
                     ext[CID["NF"]] += itf8(r["nf"])
-                # (TL: a one-symbol code, no bits; no tags)
+                # (TL: a one-symbol code, no bits: every record uses tag line 0)
+                if tags:
+                    ext[40].append(r["L"] & 0x7F)                       # NM:C, one byte (its length through a one-symbol HUFFMAN code)
+                    ext[41] += str(r["L"]).encode() + b"\t"             # MD:Z ... stop byte 9
                 if not r["flag"] & 4:
                     feats = []
                     ref = refs[r["tid"]]
@@ -512,6 +523,8 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
                     bits.put(r["mapq"], 8)                    # MQ: BETA, 8 bits
                 else:
                     ext[CID["BA"]] += r["seq"].encode()
+                if r["cf"] & 1:
+                    ext[CID["QS"]] += bytes((7 * k + r["L"]) % 41 for k in range(r["L"]))
                 bases_c += r["L"]
             used = sorted(k for k, v in ext.items() if v)
             eblocks = []
@@ -520,12 +533,23 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
                 method_rot += 1
             core = block(RAW, CORE_DATA, 0, bits.done())
             span = s_end - s_start + 1 if tid >= 0 and s_start else 0
+            if tid == -2:
+                mp = [r for r in rs if r["tid"] >= 0]          # the index lists a multi-reference slice once per reference it holds
+                multi_lines = []
+                for t2 in sorted({r["tid"] for r in mp}):
+                    rr = [r for r in mp if r["tid"] == t2]
+                    a2, b2 = min(r["pos"] for r in rr), max(max(r["end"], r["pos"]) for r in rr)
+                    multi_lines.append((t2, a2, b2 - a2 + 1))
             sh = itf8(tid) + itf8(s_start if tid >= 0 else 0) + itf8(span) + itf8(len(rs)) + ltf8(counter) + itf8(1 + len(eblocks)) + \
                 itf8(len(used)) + b"".join(itf8(k) for k in used) + itf8(-1) + bytes(16)
             shb = block(RAW, SLICE_HEADER, 0, sh)
             landmarks.append(at)
             sl_bytes = shb + core + b"".join(eblocks)
-            slice_meta.append((tid, s_start if tid >= 0 else 0, span, at, len(sl_bytes)))
+            if tid == -2:
+                for t2, a2, sp2 in multi_lines:
+                    slice_meta.append((t2, a2, sp2, at, len(sl_bytes)))
+            else:
+                slice_meta.append((tid, s_start if tid >= 0 else 0, span, at, len(sl_bytes)))
             blocks += [shb, core] + eblocks
             at += len(sl_bytes)
             counter += len(rs)
@@ -534,7 +558,7 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
                 c_start = s_start if c_start is None else min(c_start, s_start)
                 c_end = max(c_end, s_end)
         tids = {m[0] for m in slice_meta}
-        c_tid = tids.pop() if len(tids) == 1 else -2
+        c_tid = tids.pop() if len(tids) == 1 and not multi_ref else -2
         coff = len(out)
         out += container(c_tid, (c_start or 0) if c_tid >= 0 else 0, (c_end - c_start + 1) if c_tid >= 0 and c_start else 0, n_rec_c, counter - n_rec_c, bases_c,
                          blocks, landmarks)

@@ -910,11 +910,10 @@ int64_t CramFile::read_region(RecordBatch &b, int32_t tid, int64_t beg, int64_t 
     if (!parse_container_header(e.c_off, c, err)) return -1;
     if (!decode_container(c, (int64_t)e.s_off, part, err)) return -1;
     RecordBatch keep;
-    // records that start before `end` (the consumers apply the overlap filter themselves, like for a BAM region read)
-    size_t upto = 0;
-    while (upto < part.size() && !(part.tid[upto] == tid && part.pos[upto] >= end)) ++upto;
-    if (upto == part.size()) { n += (int64_t)part.size(); append_batch(b, part); continue; }
-    for (size_t i = 0; i < upto; ++i) {
+    // records of `tid` that start before `end` (a multi-reference slice holds other references' records too; the consumers
+    // apply the overlap filter themselves, like for a BAM region read)
+    for (size_t i = 0; i < part.size(); ++i) {
+      if (part.tid[i] != tid || part.pos[i] >= end) continue;
       keep.tid.push_back(part.tid[i]); keep.pos.push_back(part.pos[i]); keep.mtid.push_back(part.mtid[i]); keep.mpos.push_back(part.mpos[i]);
       keep.isize.push_back(part.isize[i]); keep.l_seq.push_back(part.l_seq[i]); keep.flag.push_back(part.flag[i]); keep.mapq.push_back(part.mapq[i]);
       keep.qnames.append(part.qnames, (size_t)part.qname_off[i], (size_t)(part.qname_off[i + 1] - part.qname_off[i]));

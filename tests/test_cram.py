@@ -123,7 +123,9 @@ def test_cram_variants_and_refusals(cram_sample, tmp_path):
     env = dict(os.environ, STRL_CRAM_FASTA=cram_sample["fa"])
     base = _run(["_dump", cram_sample["cram"]], env=env).stdout
     # absolute positions, names only on detached records, other slice / container shapes: the same records
-    for k, kw in enumerate((dict(ap_delta=False), dict(records_per_slice=37, slices_per_container=5), dict(records_per_slice=100000, slices_per_container=1))):
+    for k, kw in enumerate((dict(ap_delta=False), dict(records_per_slice=37, slices_per_container=5), dict(records_per_slice=100000, slices_per_container=1),
+                            dict(multi_ref=True, records_per_slice=700), dict(qualities=True), dict(tags=True, read_names=True, records_per_slice=123),
+                            dict(multi_ref=True, qualities=True, tags=True, ap_delta=False))):
         p = str(tmp_path / f"v{k}.cram")
         cramio.write_cram(p, rec, refs, index=False, **kw)
         r = _run(["_dump", p], env=env)
@@ -163,9 +165,11 @@ def test_damaged_cram_never_crashes_the_reader(cram_sample, tmp_path):
     assert n_err > 10
 
 
-def test_crai_region_reads(cram_sample):
+def test_crai_region_reads(cram_sample, tmp_path):
     rec = cram_sample["rec"]
     env = dict(os.environ, STRL_CRAM_FASTA=cram_sample["fa"])
+    multi = str(tmp_path / "multi.cram")          # slices that run across references: the index lists them once per reference
+    cramio.write_cram(multi, rec, cram_sample["refs"], multi_ref=True, records_per_slice=900)
     stop = np.array([int(rec.pos[i]) + max(1, sum(int(c) >> 4 for c in rec.cigar[int(rec.cigar_off[i]):int(rec.cigar_off[i + 1])] if (int(c) & 15) in (0, 2, 3, 7, 8)))
                      if not int(rec.flag[i]) & 4 else int(rec.pos[i]) + 1 for i in range(rec.n)])
     for tid, beg, end in ((0, 1000, 1400), (1, 0, 300), (2, 30_000, 30_400), (1, 20_000, 20_050)):
@@ -173,6 +177,8 @@ def test_crai_region_reads(cram_sample):
         b = _run(["_region", cram_sample["bam"], str(tid), str(beg), str(end)])
         assert a.returncode == 0 and b.returncode == 0, a.stderr
         assert a.stdout == b.stdout and (len(a.stdout.splitlines()) > 3 or tid == 1)
+        m = _run(["_region", multi, str(tid), str(beg), str(end)], env=env)
+        assert m.returncode == 0 and m.stdout == b.stdout, m.stderr
 
 
 @pytest.mark.gpu
