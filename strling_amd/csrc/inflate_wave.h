@@ -521,25 +521,28 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "s_and_b32 s93, %[e], 0x300\n\t"
       "s_cmp_eq_u32 s93, 0x100\n\t"
       "s_cbranch_scc0 L_iw_other_%=\n\t"
+      // the distance code starts len + extra bits further on, both known from the entry: its lookup is issued at once and
+      // is in flight while the length is put together
       "s_and_b32 s92, %[e], 15\n\t"
       "s_bfe_u32 s93, %[e], 0x40004\n\t"
+      "s_add_u32 s95, s92, s93\n\t"
+      "s_lshr_b32 s94, s90, s95\n\t"
+      "s_and_b32 s94, s94, 0xff\n\t"
+      "v_lshl_add_u32 %[vt0], s94, 2, %[vdist]\n\t"
+      "ds_read_b32 %[ve], %[vt0]\n\t"
       "s_lshr_b32 s94, s90, s92\n\t"
-      "s_bfm_b32 s95, s93, 0\n\t"
+      "s_bfm_b32 s92, s93, 0\n\t"
       "s_bfe_u32 %[L], %[e], 0xf0010\n\t"
-      "s_and_b32 s94, s94, s95\n\t"
-      "s_add_u32 s92, s92, s93\n\t"
+      "s_and_b32 s94, s94, s92\n\t"
       "s_add_u32 %[L], %[L], s94\n\t"
-      "v_subrev_u32_e32 %[vnb], s92, %[vnb]\n\t"
-      "s_lshr_b64 s[90:91], s[90:91], s92\n\t"
+      "v_subrev_u32_e32 %[vnb], s95, %[vnb]\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], s95\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
       "v_cmp_lt_u32_e32 vcc, 32, %[vnb]\n\t"
       "s_cbranch_vccz L_iw_refill2_%=\n"
-      // first-level distance lookup, its fields on the vector unit
+      // (32 more bits, if they were needed, have come in on top: the entry read above stands) the distance code's fields
       "L_iw_have2_%=:\n\t"
-      "s_and_b32 s92, s90, 0xff\n\t"
-      "v_lshl_add_u32 %[vt0], s92, 2, %[vdist]\n\t"
-      "ds_read_b32 %[ve], %[vt0]\n\t"
       "s_add_u32 s93, %[pos], %[L]\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
       "v_and_b32_e32 %[vn], 15, %[ve]\n\t"
       "v_bfe_u32 %[vt1], %[ve], 4, 4\n\t"
       "v_cmp_ne_u32_e32 vcc, 0, %[vn]\n\t"
