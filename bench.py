@@ -83,7 +83,8 @@ def main():
     t_gen = time.perf_counter()
     n_chunks = max(1, min(args.chunks, args.reads_per_gpu // 2048))
     pairs_per_chunk = max(1, args.reads_per_gpu // 2 // n_chunks)
-    procs = max(1, min(n_chunks, (os.cpu_count() or 2) // max(1, min(world, 8)) - 2))
+    cpus = _cpu_quota() or (os.cpu_count() or 2)       # the container's CPU quota, not the box's thread count: N ranks share it
+    procs = max(1, min(n_chunks, int(cpus * 1.5) // max(1, world)))
     cache = os.path.join(args.cache, f"s1x30_{args.reads_per_gpu}_{n_chunks}_{rank}.pkl") if args.cache else ""
     if cache and os.path.exists(cache):
         import pickle
