@@ -565,6 +565,10 @@ typedef struct {
 } strl_bin_info;
 int strl_bin_read(const char *path, strl_bin_info *info, char *sam_header, strl_tread *treads, uint64_t *qname_off,
                   char *qnames);
+/* The header part alone (unpack.nim:61-110 up to n_reads), without walking the records: info->qnames_bytes receives an UPPER
+ * BOUND of the names' bytes (what is left of the file), so that one strl_bin_read call with buffers of these sizes reads a .bin of
+ * millions of treads in a single pass. */
+int strl_bin_peek(const char *path, strl_bin_info *info);
 /* one -bounds.txt row (cluster.nim:262-266), without newline; returns length or <0 */
 int strl_bounds_row(char *buf, int cap, const strl_bounds *b, const char *chrom);
 

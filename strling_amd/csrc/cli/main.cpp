@@ -1053,13 +1053,20 @@ static int merge_main(int argc, char **argv) {
   const bool verbose = a.flag("verbose");
   const std::string prefix = a.get("output-prefix", "strling");
 
+  // the HIP runtime + the first device context come up beside the reading of the .bin files
+  const int gpus_early = std::max(1, atoi(a.get("gpus", "1").c_str()));
+  strl_ctx *ctx_early = nullptr;
+  int ctx_early_rc = 0;
+  std::string ctx_early_err;
+  std::thread ctx_thread([&] { if (gpus_early == 1) { ctx_early_rc = strl_ctx_create(0, &ctx_early); if (ctx_early_rc) ctx_early_err = strl_last_error(); } });
+  g_bg_init = &ctx_thread;
   uint32_t frag[4096] = {0};
   std::vector<strl_tread> all;
   for (size_t si = 0; si < a.pos.size(); ++si) {
     const std::string &path = a.pos[si];
     if (verbose) fprintf(stderr, "[strling] reading bin file: %s\n", path.c_str());
     strl_bin_info info;
-    CHECK(strl_bin_read(path.c_str(), &info, nullptr, nullptr, nullptr, nullptr));
+    CHECK(strl_bin_peek(path.c_str(), &info));        // sizes from the header (names: an upper bound): the records are walked once
     std::string hdr((size_t)info.header_len, '\0');
     std::vector<strl_tread> t((size_t)std::max(1, info.n_reads));
     std::vector<uint64_t> qo((size_t)info.n_reads + 1);
@@ -1107,8 +1114,11 @@ static int merge_main(int argc, char **argv) {
   std::vector<strl_bounds> bounds(std::max<size_t>(all.size(), 16));
   uint64_t nb = 0, nu = 0;
   const int gpus = std::max(1, atoi(a.get("gpus", "1").c_str()));
+  ctx_thread.join();
+  g_bg_init = nullptr;
   if (gpus == 1) {
-    CHECK(strl_ctx_create(0, &ctx));
+    if (ctx_early_rc) quit("[strling] %s (status %d)", ctx_early_err.c_str(), ctx_early_rc);
+    ctx = ctx_early;
     CHECK(strl_cluster(ctx, all.data(), all.size(), STRL_MODE_MERGE, (uint32_t)window, min_support, min_clip, min_clip_total, max_clip_dist,
                        bounds.data(), bounds.size(), &nb, nullptr, 0, &nu, nullptr));
   } else {
@@ -1201,6 +1211,32 @@ static int call_main(int argc, char **argv) {
   const bool verbose = a.flag("verbose");
 
   g_cram_fasta = a.get("fasta", "");
+  const auto t_call0 = std::chrono::steady_clock::now();
+  // three things that do not depend on each other, side by side: the HIP runtime + device context (0.2 - 0.4 s of driver work),
+  // the .bin of extract (call.nim:118-123; a whole genome's is a quarter of a gigabyte of msgpack), the fragment lengths
+  strl_ctx *ctx = nullptr;
+  int ctx_rc = 0;
+  std::string ctx_err;
+  std::thread ctx_thread([&] { ctx_rc = strl_ctx_create(0, &ctx); if (ctx_rc) ctx_err = strl_last_error(); });
+  g_bg_init = &ctx_thread;
+  strl_bin_info info;
+  std::string hdr;
+  std::vector<strl_tread> treads;
+  std::vector<uint64_t> qoff;
+  std::vector<char> qnames;
+  int bin_rc = 0;
+  std::string bin_err;
+  std::thread bin_thread([&] {
+    bin_rc = strl_bin_peek(bin.c_str(), &info);          // sizes from the header (names: an upper bound): the records are walked once
+    if (!bin_rc) {
+      hdr.assign((size_t)info.header_len, '\0');
+      treads.resize((size_t)std::max(1, info.n_reads));
+      qoff.resize((size_t)info.n_reads + 1);
+      qnames.resize((size_t)info.qnames_bytes + 1);
+      bin_rc = strl_bin_read(bin.c_str(), &info, &hdr[0], treads.data(), qoff.data(), qnames.data());
+    }
+    if (bin_rc) bin_err = strl_last_error();
+  });
   uint32_t frag[4096];
   fragment_length_distribution(bam, frag);                                          // call.nim:92
   const int frag_median = strl_frag_median(frag, 0.5);
@@ -1210,18 +1246,16 @@ static int call_main(int argc, char **argv) {
   }
   BamReader rd;
   std::string err;
-  if (!rd.open(bam, err) || !rd.load_index(bam, err)) quit_open(bam, err);    // index=true, call.nim:101-102
+  const bool opened = rd.open(bam, err) && rd.load_index(bam, err);                   // index=true, call.nim:101-102
+  bin_thread.join();
+  ctx_thread.join();
+  g_bg_init = nullptr;
+  if (!opened) quit_open(bam, err);
+  if (bin_rc) quit("[strling] %s (status %d)", bin_err.c_str(), bin_rc);
+  if (ctx_rc) quit("[strling] %s (status %d)", ctx_err.c_str(), ctx_rc);
+  const double t_start_up = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call0).count();
   const int window = strl_frag_median(frag, 0.99);                                  // call.nim:109
   const strl_call_opts copts{frag_median, min_support, min_clip, min_clip_total};
-
-  // the .bin of extract (call.nim:118-123)
-  strl_bin_info info;
-  CHECK(strl_bin_read(bin.c_str(), &info, nullptr, nullptr, nullptr, nullptr));
-  std::string hdr((size_t)info.header_len, '\0');
-  std::vector<strl_tread> treads((size_t)std::max(1, info.n_reads));
-  std::vector<uint64_t> qoff((size_t)info.n_reads + 1);
-  std::vector<char> qnames((size_t)info.qnames_bytes + 1);
-  CHECK(strl_bin_read(bin.c_str(), &info, &hdr[0], treads.data(), qoff.data(), qnames.data()));
   {
     const std::vector<BamTarget> tg = targets_from_header(hdr);
     bool same = tg.size() == rd.targets().size();
@@ -1340,9 +1374,7 @@ static int call_main(int argc, char **argv) {
 
   // discovery: group, sort, cluster, bounds on the device (call.nim:118-130,221-235)
   const auto tc0 = std::chrono::steady_clock::now();
-  strl_ctx *ctx = nullptr;
-  CHECK(strl_ctx_create(0, &ctx));
-  const auto tc1 = std::chrono::steady_clock::now();
+  const auto tc1 = tc0;
   const uint16_t max_clip_dist = (uint16_t)(0.5 * (double)frag_median);             // call.nim:232
   std::vector<strl_bounds> bounds(std::max<size_t>((size_t)nt, 16));
   std::vector<strl_unplaced> unplaced(std::max<size_t>((size_t)nt, 16));
@@ -1362,8 +1394,8 @@ static int call_main(int argc, char **argv) {
     run_tasks(tasks);
   }
   if (verbose)
-    fprintf(stderr, "[strling] seconds: device context %.3f  clustering (upload, sort, sweep, bounds, members) %.3f  evidence + genotypes of %llu bounds on %d threads %.3f\n",
-            std::chrono::duration<double>(tc1 - tc0).count(), std::chrono::duration<double>(tc2 - tc1).count(), (unsigned long long)nb, n_workers, t_evidence);
+    fprintf(stderr, "[strling] seconds: device context + .bin + fragment lengths + index, side by side %.3f  clustering (upload, sort, sweep, bounds, members) %.3f  evidence + genotypes of %llu bounds on %d threads %.3f\n",
+            t_start_up, std::chrono::duration<double>(tc2 - tc1).count(), (unsigned long long)nb, n_workers, t_evidence);
   char row[2048];
   std::vector<uint64_t> order(std::max<size_t>(calls.size(), 1)), uorder(std::max<size_t>((size_t)nu, 1));
   CHECK(strl_calls_finish(calls.data(), calls.size(), unplaced.data(), nu, order.data()));   // :264-278

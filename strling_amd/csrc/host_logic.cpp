@@ -720,6 +720,37 @@ struct Rd {
 };
 }  // namespace
 
+int strl_bin_peek(const char *path, strl_bin_info *info) {
+  if (!path || !info) { set_error("null argument"); return STRL_ERR_ARG; }
+  FILE *f = fopen(path, "rb");
+  if (!f) { set_error("[strling] unable to open %s for reading. please check path", path); return STRL_ERR_IO; }
+  fseek(f, 0, SEEK_END);
+  const long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  const size_t fixed = 3 + 2 + 9 + 4 + 1 + 4096 * 4 + 4;
+  std::vector<uint8_t> buf(fixed);
+  if (sz < (long)fixed + 4 || fread(buf.data(), 1, fixed, f) != fixed || memcmp(buf.data(), "STR", 3) != 0) {
+    fclose(f);
+    set_error("[strling] expected bin file to start with \"STR\"");
+    return STRL_ERR_FORMAT;
+  }
+  int16_t fmt;
+  memcpy(&fmt, buf.data() + 3, 2);
+  if (fmt != 0) { fclose(f); set_error("[strling] this bin file was generated using a different format"); return STRL_ERR_FORMAT; }
+  size_t o = 3 + 2 + 9;
+  memcpy(&info->proportion_repeat, buf.data() + o, 4); o += 4;
+  info->min_mapq = buf[o++];
+  memcpy(info->frag, buf.data() + o, 4096 * 4); o += 4096 * 4;
+  memcpy(&info->header_len, buf.data() + o, 4);
+  int32_t n = 0;
+  const bool ok = info->header_len >= 0 && (long)fixed + info->header_len + 4 <= sz && fseek(f, (long)fixed + info->header_len, SEEK_SET) == 0 && fread(&n, 1, 4, f) == 4;
+  fclose(f);
+  if (!ok || n < 0) { set_error("truncated bin header"); return STRL_ERR_FORMAT; }
+  info->n_reads = n;
+  info->qnames_bytes = (uint64_t)sz - fixed - (uint64_t)info->header_len - 4;
+  return STRL_OK;
+}
+
 int strl_bin_read(const char *path, strl_bin_info *info, char *sam_header, strl_tread *treads, uint64_t *qname_off, char *qnames) {
   if (!path || !info) { set_error("null argument"); return STRL_ERR_ARG; }
   FILE *f = fopen(path, "rb");
@@ -767,18 +798,19 @@ int strl_bin_read(const char *path, strl_bin_info *info, char *sam_header, strl_
     if (L > 0) {                                                                     // :51-54 (qname read only when L > 0)
       sl = rd.strhdr();
       if (!rd.ok || rd.p + sl > rd.e) { rd.ok = false; break; }
-      if (qnames) memcpy(qnames + qbytes, rd.p, sl);
+      if (qnames && i < (int64_t)info->n_reads) memcpy(qnames + qbytes, rd.p, sl);
       rd.p += sl;
     }
     if (!rd.ok) break;
     t.qname_id = i;
-    if (treads) treads[i] = t;
-    if (qname_off) qname_off[i] = qbytes;
+    // (buffers are sized from the header's n_reads, strl_bin_peek: records beyond it are counted -- the mismatch is an error below -- not stored)
+    if (treads && i < (int64_t)info->n_reads) treads[i] = t;
+    if (qname_off && i < (int64_t)info->n_reads) qname_off[i] = qbytes;
     qbytes += sl;
     ++i;
   }
   if (!rd.ok) { set_error("malformed msgpack record %lld in %s", (long long)i, path); return STRL_ERR_FORMAT; }
-  if (qname_off) qname_off[i] = qbytes;
+  if (qname_off && i <= (int64_t)info->n_reads) qname_off[i] = qbytes;
   if (i != info->n_reads) { set_error("[strling] expected %d got %lld", info->n_reads, (long long)i); return STRL_ERR_FORMAT; }   // :130-131
   info->qnames_bytes = qbytes;
   return STRL_OK;
