@@ -637,6 +637,10 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
   std::string names, seqs, tmp;
   std::vector<uint32_t> cig;
   std::vector<Rec> recs;
+  {   // (growing these record by record from several threads at once made them fight over the process' address-space lock)
+    const size_t nr = (size_t)std::max(c.n_records, 0);
+    recs.reserve(nr); names.reserve(nr * 24); seqs.reserve(nr * 152); cig.reserve(nr * 3);
+  }
   for (size_t sl : starts) {
     if (sl >= c.len) { err = "CRAM slice landmark outside its container"; return false; }
     Rd s{map_ + c.data_off + sl, map_ + c.data_off + c.len};
@@ -828,6 +832,10 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
   }
   // ---- the records into the batch ----
   out.clear();
+  out.tid.reserve(recs.size()); out.pos.reserve(recs.size()); out.mtid.reserve(recs.size()); out.mpos.reserve(recs.size()); out.isize.reserve(recs.size());
+  out.l_seq.reserve(recs.size()); out.flag.reserve(recs.size()); out.mapq.reserve(recs.size()); out.qname_off.reserve(recs.size() + 1);
+  out.cigar_off.reserve(recs.size() + 1); out.seq_off.reserve(recs.size()); out.cigar.reserve(cig.size()); out.qnames.reserve(names.size() + 16);
+  out.seq4.reserve(seqs.size() / 2 + 16 * recs.size() + 64);
   for (size_t i = 0; i < recs.size(); ++i) {
     const Rec &R = recs[i];
     out.tid.push_back(R.ref < 0 ? -1 : R.ref);
@@ -875,7 +883,14 @@ int64_t CramFile::read(RecordBatch &b, int64_t max_records, std::string &err) {
     std::vector<RecordBatch> parts(cs.size());
     std::vector<std::string> errs(cs.size());
     std::vector<int> ok(cs.size(), 1);
-    pool_->parallel_for(cs.size(), [&](size_t k) { ok[k] = decode_container(cs[k], -1, parts[k], errs[k]) ? 1 : 0; });
+    static const bool dbg = getenv("STRL_CRAM_DEBUG") != nullptr;
+    pool_->parallel_for(cs.size(), [&](size_t k) {
+      timespec t0, t1;
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      ok[k] = decode_container(cs[k], -1, parts[k], errs[k]) ? 1 : 0;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if (dbg) fprintf(stderr, "[cram] container %zu of %zu: %d records in %.3f s (started at %.3f)\n", k, cs.size(), cs[k].n_records, (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec), (double)(t0.tv_sec % 1000) + 1e-9 * (double)t0.tv_nsec);
+    });
     for (size_t k = 0; k < cs.size(); ++k) {
       if (!ok[k]) { err = errs[k]; return -1; }
       got += (int64_t)parts[k].size();

@@ -1451,6 +1451,7 @@ static int dump_main(int argc, char **argv) {
 // strling _decode BAM [BATCH]: the multi-threaded reader alone (inflate + record scan + parse into batches), for timing
 static int decode_main(int argc, char **argv) {
   if (argc < 3) quit("usage: strling _decode BAM [BATCH]");
+  if (getenv("STRL_CRAM_FASTA")) g_cram_fasta = getenv("STRL_CRAM_FASTA");
   const int64_t batch = argc > 3 ? atoll(argv[3]) : 1048576;
   BamStream rs;
   std::string err;
