@@ -236,6 +236,7 @@ bool parse_encoding(Rd &r, Enc &e, std::string &err) {
 struct Ext { std::vector<uint8_t> d; size_t at = 0; };
 struct Ctx {
   std::map<int, Ext> ext;
+  Ext *fast[128] = {nullptr};   // content ids below 128 (all that htslib and the test writer use), looked up once per block
   std::vector<uint8_t> core;
   size_t bit = 0;               // next bit of the core block (most significant first)
   bool ok = true;
@@ -252,6 +253,7 @@ struct Ctx {
   }
   void fail(const std::string &m) { if (ok) { ok = false; err = m; } }
   Ext *stream(int id) {
+    if (id >= 0 && id < 128 && fast[id]) return fast[id];
     auto it = ext.find(id);
     if (it == ext.end()) { fail("the slice has no external block " + std::to_string(id)); return nullptr; }
     return &it->second;
@@ -666,6 +668,7 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
       if (b.type == 5) { if (!block_data(b, X.core, err)) return false; }
       else if (b.type == 4) { if (!block_data(b, X.ext[b.id].d, err)) return false; }
     }
+    for (auto &kv : X.ext) if (kv.first >= 0 && kv.first < 128) X.fast[kv.first] = &kv.second;
     std::shared_ptr<const std::string> ref;
     int32_t ref_of = -3;
     auto need_ref = [&](int32_t id) -> bool {
