@@ -2,7 +2,6 @@
 #include "bgzf_feed.h"
 #include <fcntl.h>
 #include <string.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
@@ -16,8 +15,18 @@ void BgzfFeed::close() {
   cv_.notify_all();
   if (walker_.joinable()) walker_.join();
   stop_ = false; state_ = 0; blks_.clear(); taken_ = 0; werr_.clear();
-  if (map_) munmap(const_cast<uint8_t *>(map_), map_len_);
-  map_ = nullptr; map_len_ = 0;
+  if (fd_ >= 0) ::close(fd_);
+  fd_ = -1; map_len_ = 0;
+}
+
+bool BgzfFeed::read_at(void *dst, size_t off, size_t n) const {
+  uint8_t *d = static_cast<uint8_t *>(dst);
+  while (n) {
+    const ssize_t got = pread(fd_, d, n, (off_t)off);
+    if (got <= 0) return false;
+    d += got; off += (size_t)got; n -= (size_t)got;
+  }
+  return true;
 }
 
 bool BgzfFeed::open(const std::string &path, std::string &err) {
@@ -32,16 +41,12 @@ bool BgzfFeed::open(const std::string &path, std::string &err) {
     start = (size_t)p.block_off;
     first_off_ = p.in_block;
   }
-  const int fd = ::open(path.c_str(), O_RDONLY);
-  if (fd < 0) { err = "couldn't open bam"; return false; }
+  fd_ = ::open(path.c_str(), O_RDONLY);
+  if (fd_ < 0) { err = "couldn't open bam"; return false; }
   struct stat st;
-  if (fstat(fd, &st) != 0) { ::close(fd); err = "couldn't stat bam"; return false; }
+  if (fstat(fd_, &st) != 0) { ::close(fd_); fd_ = -1; err = "couldn't stat bam"; return false; }
   map_len_ = (size_t)st.st_size;
-  void *m = map_len_ ? mmap(nullptr, map_len_, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
-  ::close(fd);
-  if (map_len_ && m == MAP_FAILED) { map_len_ = 0; err = "couldn't map bam"; return false; }
-  map_ = static_cast<const uint8_t *>(m);
-  if (map_len_) madvise(const_cast<uint8_t *>(map_), map_len_, MADV_SEQUENTIAL);
+  (void)posix_fadvise(fd_, 0, 0, POSIX_FADV_SEQUENTIAL);
   walker_ = std::thread([this, start] {
     size_t pos = start;
     std::vector<Block> local;
@@ -56,28 +61,28 @@ bool BgzfFeed::open(const std::string &path, std::string &err) {
       cv_.wait(lk, [&] { return stop_ || state != 0 || blks_.size() - taken_ < (1u << 17); });   // stay <= ~2 GB of BAM ahead
       return !stop_;
     };
-#ifndef MADV_POPULATE_READ
-#define MADV_POPULATE_READ 22
-#endif
-    size_t mapped = (pos / 4096) * 4096;
+    // h = the 18 fixed bytes of the header of the block at pos (the next block's arrive with this block's trailer: one pread)
+    uint8_t h[18], tail[8 + 18];
+    bool have = pos + 18 <= map_len_ && read_at(h, pos, 18);
     while (state == 0) {
       if (pos >= map_len_) { state = 1; break; }
-      if (pos + ((size_t)32 << 20) > mapped && mapped < map_len_) {
-        // page-table entries for the next piece of the mapping with ONE call (the copy threads would otherwise take a
-        // fault per page on the shared address space)
-        const size_t len = std::min<size_t>((size_t)128 << 20, map_len_ - mapped);
-        if (madvise(const_cast<uint8_t *>(map_) + mapped, len, MADV_POPULATE_READ) != 0) (void)madvise(const_cast<uint8_t *>(map_) + mapped, len, MADV_WILLNEED);
-        mapped += len;
-      }
-      if (pos + 18 > map_len_) { state = 2; werr = "truncated BGZF header"; break; }
-      const uint8_t *h = map_ + pos;
+      if (!have) { state = 2; werr = "truncated BGZF header"; break; }
       if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { state = 2; werr = "not a BGZF block"; break; }
       const uint32_t xlen = h[10] | (h[11] << 8);
       if (pos + 12 + xlen > map_len_) { state = 2; werr = "truncated BGZF header"; break; }
+      uint8_t extra_buf[256];
+      std::vector<uint8_t> extra_big;
+      const uint8_t *extra = h + 12;                       // the BC subfield is first in every BGZF writer: the 18 bytes hold it
+      if (xlen > 6) {
+        uint8_t *e = extra_buf;
+        if (xlen > sizeof extra_buf) { extra_big.resize(xlen); e = extra_big.data(); }
+        if (!read_at(e, pos + 12, xlen)) { state = 2; werr = "truncated BGZF header"; break; }
+        extra = e;
+      }
       uint32_t bsize = 0;
       bool bad_extra = false;
       for (uint32_t o = 0; o + 4 <= xlen;) {
-        const uint8_t *x = h + 12 + o;
+        const uint8_t *x = extra + o;
         const uint32_t sl = x[2] | (x[3] << 8);
         if (o + 4 + sl > xlen) { bad_extra = true; break; }
         if (x[0] == 'B' && x[1] == 'C' && sl == 2) bsize = (x[4] | (x[5] << 8)) + 1u;
@@ -86,13 +91,16 @@ bool BgzfFeed::open(const std::string &path, std::string &err) {
       if (bad_extra) { state = 2; werr = "malformed BGZF extra field"; break; }
       if (!bsize || bsize < 12 + xlen + 8) { state = 2; werr = "BGZF block without BC field"; break; }
       if (pos + bsize > map_len_) { state = 2; werr = "truncated BGZF block"; break; }
-      const uint8_t *f = h + bsize - 4;
-      const uint32_t isz = f[0] | (f[1] << 8) | (f[2] << 16) | ((uint32_t)f[3] << 24);
+      const size_t next = pos + bsize;
+      const size_t want = std::min<size_t>(8 + 18, map_len_ - (next - 8));
+      if (!read_at(tail, next - 8, want)) { state = 2; werr = "truncated BGZF block"; break; }
+      const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
+      const uint32_t isz = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
       if (isz > 65536u) { state = 2; werr = "BGZF block inflates to more than 64 KiB"; break; }
-      const uint8_t *cf = h + bsize - 8;
-      const uint32_t crc = cf[0] | (cf[1] << 8) | (cf[2] << 16) | ((uint32_t)cf[3] << 24);
-      if (isz) local.push_back(Block{(size_t)(h + 12 + xlen - map_), bsize - 12 - xlen - 8, isz, crc});
-      pos += bsize;
+      if (isz) local.push_back(Block{pos + 12 + xlen, bsize - 12 - xlen - 8, isz, crc});
+      have = want == 8 + 18;
+      if (have) memcpy(h, tail + 8, 18);
+      pos = next;
       if (local.size() >= 1024 && !publish()) return;
     }
     (void)publish();

@@ -1,6 +1,8 @@
-// bgzf_feed.h -- the host side of the device BAM front end (strl_front_*): the file is mapped, a thread walks the BGZF block
-// headers (18 bytes per ~16 KB block) ahead of the consumer, and the consumer copies whole runs of blocks -- compressed --
-// into page-locked buffers for the GPU.  No inflate, no record ever touched on the host (extract.nim:275-329 does both
+// bgzf_feed.h -- the host side of the device BAM front end (strl_front_*): a thread walks the BGZF block headers ahead of the
+// consumer (one 26-byte pread per block: the trailer of a block and the header of the next sit side by side), and the consumer
+// reads whole runs of blocks -- compressed -- straight into page-locked buffers for the GPU (pread on several threads).  The file
+// is NOT mapped: a 57 GB mapping cost 2 s of page-table population in front of a cold run and 0.9 s to release at exit
+// (profiles/r04/e2e_full_mmap.json).  No inflate, no record ever touched on the host (extract.nim:275-329 does both
 // through htslib on one thread).
 #pragma once
 #include <stdint.h>
@@ -23,15 +25,16 @@ class BgzfFeed {
   const std::vector<BamTarget> &targets() const { return targets_; }
   uint64_t first_record_offset() const { return first_off_; }   // bytes into the first block's inflated data
   size_t file_bytes() const { return map_len_; }
-  struct Block { size_t c_off; uint32_t clen, isize, crc; };     // DEFLATE payload at map + c_off; CRC-32 of the inflated bytes (trailer)
+  // n bytes of the file at offset off into dst (any thread); false on a short read
+  bool read_at(void *dst, size_t off, size_t n) const;
+  struct Block { size_t c_off; uint32_t clen, isize, crc; };     // DEFLATE payload at file offset c_off; CRC-32 of the inflated bytes (trailer)
   // Next run of consecutive non-empty blocks: at most max_blocks and max_bytes of file (first block's payload to the last
   // block's end).  Returns the number of blocks (0 at the end of the file), -1 on a malformed file.
   int64_t next(std::vector<Block> &out, size_t max_blocks, size_t max_bytes, std::string &err);
-  const uint8_t *map() const { return map_; }
 
  private:
-  const uint8_t *map_ = nullptr;
-  size_t map_len_ = 0;
+  int fd_ = -1;
+  size_t map_len_ = 0;          // file size
   uint64_t first_off_ = 0;
   std::string text_;
   std::vector<BamTarget> targets_;

@@ -743,7 +743,9 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     const size_t slot = (size_t)2 * g + (size_t)(pushes[(size_t)g] & 1);
     uint8_t *dst = pin[slot];
     const size_t piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
-    copy_pool.parallel_for(pieces, [&](size_t k) { memcpy(dst + k * piece, feed.map() + lo + k * piece, std::min(piece, hi - lo - k * piece)); });
+    std::atomic<int> short_reads{0};
+    copy_pool.parallel_for(pieces, [&](size_t k) { if (!feed.read_at(dst + k * piece, lo + k * piece, std::min(piece, hi - lo - k * piece))) ++short_reads; });
+    if (short_reads.load()) quit("[strling] error reading %s: short read", bam.c_str());
     uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[slot]);
     uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks, *crc = isz + chunk_blocks;
     for (size_t k = 0; k < (size_t)nb; ++k) { coff[k] = blks[k].c_off - lo; clen[k] = blks[k].clen; isz[k] = blks[k].isize; crc[k] = blks[k].crc; }
@@ -893,11 +895,6 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     fprintf(stderr, "[strling] seconds before the loop: %.3f to the open context (device context %.3f, page-locked buffers %.3f: two threads beside the header walk), "
                     "genome table %.3f, per-read state for %llu reads %.3f; writing the .bin %.3f; whole run %.3f\n", t_open, t_ctx, t_pin, t_genome, (unsigned long long)reads_hint, t_begin, t_write,
             secs(t_start, now()));
-  if (verbose) {     // (what the exit pays for anyway, named: a 57 GB mapping of a tmpfs file took a second to release)
-    const auto tm0 = now();
-    feed.close();
-    fprintf(stderr, "[strling] file mapping released in %.3f s; the rest of the exit (device memory, page-locked buffers) is the driver's\n", secs(tm0, now()));
-  }
   // the process ends here: the driver reclaims device and page-locked memory faster than freeing them piece by piece would
   // (STRL_TEARDOWN=1 frees them explicitly)
   if (getenv("STRL_TEARDOWN")) {

@@ -155,7 +155,10 @@ __global__ __launch_bounds__(1024) void rec_link_kernel(const uint8_t *U, FrontS
   for (uint32_t s = t; s < n_seg; s += nt) {
     const FrontSeg r = seg[s];
     if (r.entry == FRONT_NONE) continue;
-    if ((r.flags & 1u) || r.exit >= end) { atomicAdd(&sh_stop, 1u); continue; }
+    // (a chain that arrives where fewer than 36 bytes are left -- a partial header, possibly in a fresh segment nobody could guess
+    // a start in -- ends there: the chunk's carry begins at that offset.  Round-3 advisor: this used to count as a mismatch and sent
+    // one lane down the whole chain.)
+    if ((r.flags & 1u) || r.exit >= end || r.exit + 36u > end) { atomicAdd(&sh_stop, 1u); continue; }
     if (atomicExch(&reached[r.exit / FRONT_SEG], r.exit) != FRONT_NONE) atomicOr(&sh_bad, 1u);
   }
   __syncthreads();
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(1024) void rec_link_kernel(const uint8_t *U, FrontS
     maxl = max(maxl, r.max_l_seq);
     if (r.entry != FRONT_NONE) {
       if (r.flags & 2u) err |= FRONT_ERR_RECORD;
-      if (r.flags & 1u) carry = r.exit;
+      if ((r.flags & 1u) || (r.exit < end && r.exit + 36u > end)) carry = r.exit;
     }
   }
   sh_part[0][t] = s_cnt; sh_part[1][t] = s_seq; sh_part[2][t] = s_qn;
