@@ -652,7 +652,9 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
 
   fprintf(stderr, "[strling] collecting str-like reads\n");
   const auto t0 = now();
-  ThreadPool copy_pool(std::min(decode_threads(), 12));
+  // threads that read the compressed bytes into the page-locked buffers: 12 keep one device fed (0.8 - 1.1 s per 57 GB beside a
+  // 3 s loop); several devices take what the CPU quota gives
+  ThreadPool copy_pool(std::min(decode_threads(), G > 1 ? 48 : 12));
   std::vector<BgzfFeed::Block> blks;
   int64_t nreads = 0, n_tail = 0, tail_primary = 0;
   uint64_t n_seen = 0, slow_segments = 0;
