@@ -513,6 +513,22 @@ int strl_front_begin(strl_ctx *ctx, int32_t n_ref, uint64_t first_record_offset,
 int strl_front_push(strl_ctx *ctx, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize,
                     const uint32_t *crc32, uint32_t n_blocks, strl_front_chunk *done, int *n_done);
 int strl_front_finish(strl_ctx *ctx, strl_front_chunk done[2], int *n_done);
+/* Optional, for a caller that reads the file one chunk ahead (the CLI; the loop of extract.nim:308 has no counterpart):
+ *   strl_front_reserve   (after _begin) sizes the buffers of both chunks in flight for chunks of up to max_blocks blocks and
+ *                        max_comp_bytes compressed bytes, so none is reallocated in the middle of the file
+ *   strl_front_stage     starts the copy to the device of the chunk the NEXT push of this context will hand over (which must
+ *                        pass the same pointers and sizes).  `comp` and the tables then live one call longer: until the
+ *                        second push after that one has returned
+ *   strl_front_enqueue_after + strl_front_collect = strl_front_push_after in two halves: the first queues the chunk's copy
+ *                        (unless staged), inflate and record scan and returns the summary of the chunk two back; the second
+ *                        waits for the PREVIOUS chunk's record scan and queues its parse + scoring.  Between them the caller
+ *                        stages the chunk after this one: its copy is then in the device's queue before the wait, not behind it. */
+int strl_front_reserve(strl_ctx *ctx, uint32_t max_blocks, uint64_t max_comp_bytes);
+int strl_front_stage(strl_ctx *ctx, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize,
+                     const uint32_t *crc32, uint32_t n_blocks);
+int strl_front_enqueue_after(strl_ctx *ctx, strl_ctx *prev, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen,
+                             const uint32_t *isize, const uint32_t *crc32, uint32_t n_blocks, strl_front_chunk *done, int *n_done);
+int strl_front_collect(strl_ctx *ctx);
 /* One file on several GPUs (`strling extract --gpus N`; the reference has no counterpart, extract.nim:275 is one thread): the
  * chunks go round-robin over n contexts, each with its own strl_front_begin (only the context that gets the file's first
  * chunk uses first_record_offset).  strl_front_push_after: like strl_front_push, `prev` = the context the file's previous

@@ -601,7 +601,10 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   std::vector<strl_ctx *> ctxs((size_t)G, nullptr);
   std::vector<int> ctx_rc((size_t)G, 0);
   std::vector<std::string> ctx_err((size_t)G);
-  std::vector<uint8_t *> pin((size_t)2 * G, nullptr), pin_meta((size_t)2 * G, nullptr);   // two per context: [2 g + (its chunk count & 1)]; block tables: coff u64 | clen | isize | crc u32
+  // three per context: [3 g + (its chunk count % 3)] -- chunk k+1 is read from the file while chunk k is handed over, and chunk k-1's
+  // copy to the device may still be going.  Block tables: coff u64 | clen | isize | crc u32
+  const size_t RING = 3;
+  std::vector<uint8_t *> pin(RING * G, nullptr), pin_meta(RING * G, nullptr);
   const auto t_start = now();
   double t_ctx = 0, t_pin = 0;
   uint32_t *fw_early = nullptr;          // flag / isize words of the first records (fragment lengths)
@@ -609,9 +612,12 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   // the HIP runtime, the contexts and the page-locked buffers come up on threads beside the header walk
   std::thread pin_thread([&] {
     const auto c0 = now();
-    for (auto &q : pin) q = static_cast<uint8_t *>(strl_pinned_alloc(chunk_bytes + 64));
+    std::vector<std::thread> each;            // (the time is the kernel's, faulting and locking the pages: a thread per buffer)
+    for (size_t k = 1; k < pin.size(); ++k) each.emplace_back([&, k] { pin[k] = static_cast<uint8_t *>(strl_pinned_alloc(chunk_bytes + 64)); });
+    pin[0] = static_cast<uint8_t *>(strl_pinned_alloc(chunk_bytes + 64));
     for (auto &q : pin_meta) q = static_cast<uint8_t *>(strl_pinned_alloc(chunk_blocks * 20 + 64));
     fw_early = static_cast<uint32_t *>(strl_pinned_alloc(early_n * 4));     // (allocating page-locked memory inside the loop stalls the device)
+    for (auto &t : each) t.join();
     t_pin = secs(c0, now());
   });
   std::thread ctx_thread([&] {
@@ -647,7 +653,10 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   static const char *env_hint = getenv("STRL_READS_HINT");
   const uint64_t reads_hint = env_hint ? strtoull(env_hint, nullptr, 10) : feed.file_bytes() / 88 / (size_t)G;
   const auto tb0 = now();
-  for (strl_ctx *c : ctxs) CHECK(strl_front_begin(c, n_ref, feed.first_record_offset(), reads_hint));
+  for (strl_ctx *c : ctxs) {
+    CHECK(strl_front_begin(c, n_ref, feed.first_record_offset(), reads_hint));
+    CHECK(strl_front_reserve(c, (uint32_t)chunk_blocks, chunk_bytes));
+  }
   const double t_begin = secs(tb0, now());
 
   fprintf(stderr, "[strling] collecting str-like reads\n");
@@ -658,7 +667,7 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   std::vector<BgzfFeed::Block> blks;
   int64_t nreads = 0, n_tail = 0, tail_primary = 0;
   uint64_t n_seen = 0, slow_segments = 0;
-  double t_walk = 0, t_copy = 0, t_push = 0;
+  double t_walk = 0, t_copy = 0, t_push = 0, t_stage_wait = 0;
   // summaries arrive per context in the order of ITS chunks; the file order is what counts
   std::vector<strl_front_chunk> summary;                 // by chunk of the file
   std::vector<uint32_t> chunk_owner;
@@ -682,10 +691,11 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   };
   auto mark = [&](int g, size_t before) { for (size_t k = before; k < waiting_at[(size_t)g]; ++k) have[(size_t)waiting[(size_t)g][k]] = 1; };
   std::vector<uint64_t> pushes((size_t)G, 0);
-  std::thread frag_thread;
+  std::thread frag_thread, ahead;          // ahead: reads the next chunk's bytes (below)
   // a file the device front end refuses (STRL_ERR_FORMAT) goes to the host reader instead of ending the run
   auto give_up_front = [&]() -> int {
     fprintf(stderr, "[strling] %s: repeating the extraction with the host reader\n", strl_last_error());
+    if (ahead.joinable()) ahead.join();
     if (frag_thread.joinable()) frag_thread.join();
     for (size_t k = 0; k < pin.size(); ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
     for (strl_ctx *c : ctxs) strl_ctx_destroy(c);
@@ -694,6 +704,7 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   // more records than one device pass takes (2^31 - 16; the reference has no cap, extract.nim:308): the streaming host Cache
   auto over_limit = [&]() -> int {
     fprintf(stderr, "[strling] %s: repeating the extraction with the host pair logic\n", strl_last_error());
+    if (ahead.joinable()) ahead.join();
     if (frag_thread.joinable()) frag_thread.join();
     for (size_t k = 0; k < pin.size(); ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
     for (strl_ctx *c : ctxs) strl_ctx_destroy(c);
@@ -733,24 +744,50 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     }
     fs.next = first + n;
   };
-  for (uint64_t ci = 0;; ++ci) {
+  // One chunk ahead: while chunk k is handed to the device (strl_front_push_after returns when chunk k-1 has been inflated and
+  // scanned), a thread walks the headers of chunk k+1 and reads its bytes.  (Reading only after the push had returned put
+  // the read AND the copy to the device between "chunk k-1 done" and "chunk k+1 may start": 0.40 s of 3.03 s with the
+  // inflate stream idle on the 57 GB file.)
+  struct Staged {
+    int64_t nb = 0;
+    size_t lo = 0, hi = 0, slot = 0;
+    int g = 0;
+    std::string err;
+    bool short_read = false;
+  } cur, nxt;
+  std::vector<uint64_t> staged((size_t)G, 0);
+  auto stage = [&](uint64_t ci, Staged &S) {
     const auto ta = now();
     // a short first chunk gets the device going while the second is being copied
-    const int64_t nb = feed.next(blks, ci == 0 ? std::min<size_t>(chunk_blocks, 2048) : chunk_blocks, chunk_bytes, err);
-    if (nb < 0) quit("[strling] error reading %s: %s", bam.c_str(), err.c_str());
-    if (nb == 0) break;
+    S.nb = feed.next(blks, ci == 0 ? std::min<size_t>(chunk_blocks, 2048) : chunk_blocks, chunk_bytes, S.err);
+    if (S.nb <= 0) return;
     const auto tb = now();
-    const int g = (int)(ci % (uint64_t)G);
-    const size_t lo = blks.front().c_off, hi = blks.back().c_off + blks.back().clen;
-    const size_t slot = (size_t)2 * g + (size_t)(pushes[(size_t)g] & 1);
-    uint8_t *dst = pin[slot];
-    const size_t piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
+    S.g = (int)(ci % (uint64_t)G);
+    S.lo = blks.front().c_off; S.hi = blks.back().c_off + blks.back().clen;
+    S.slot = RING * (size_t)S.g + (size_t)(staged[(size_t)S.g]++ % RING);
+    uint8_t *dst = pin[S.slot];
+    const size_t lo = S.lo, hi = S.hi, piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
     std::atomic<int> short_reads{0};
     copy_pool.parallel_for(pieces, [&](size_t k) { if (!feed.read_at(dst + k * piece, lo + k * piece, std::min(piece, hi - lo - k * piece))) ++short_reads; });
-    if (short_reads.load()) quit("[strling] error reading %s: short read", bam.c_str());
-    uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[slot]);
+    S.short_read = short_reads.load() != 0;
+    uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[S.slot]);
     uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks, *crc = isz + chunk_blocks;
-    for (size_t k = 0; k < (size_t)nb; ++k) { coff[k] = blks[k].c_off - lo; clen[k] = blks[k].clen; isz[k] = blks[k].isize; crc[k] = blks[k].crc; }
+    for (size_t k = 0; k < (size_t)S.nb; ++k) { coff[k] = blks[k].c_off - lo; clen[k] = blks[k].clen; isz[k] = blks[k].isize; crc[k] = blks[k].crc; }
+    t_walk += secs(ta, tb); t_copy += secs(tb, now());
+  };
+  stage(0, cur);
+  for (uint64_t ci = 0;; ++ci) {
+    const int64_t nb = cur.nb;
+    if (nb < 0) quit("[strling] error reading %s: %s", bam.c_str(), cur.err.c_str());
+    if (nb == 0) break;
+    if (cur.short_read) quit("[strling] error reading %s: short read", bam.c_str());
+    const int g = cur.g;
+    const size_t lo = cur.lo, hi = cur.hi;
+    uint8_t *dst = pin[cur.slot];
+    uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[cur.slot]);
+    uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks, *crc = isz + chunk_blocks;
+    nxt = Staged{};
+    ahead = std::thread([&, ci] { stage(ci + 1, nxt); });
     const auto tc = now();
     strl_front_chunk done[2];
     int n_done = 0;
@@ -759,10 +796,21 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     chunk_owner.push_back((uint32_t)g);
     waiting[(size_t)g].push_back(ci);
     const size_t before = waiting_at[(size_t)g];
-    FRONT_CHECK(strl_front_push_after(ctxs[(size_t)g], ci ? ctxs[(size_t)((ci - 1) % (uint64_t)G)] : nullptr, dst, hi - lo, coff, clen, isz, crc, (uint32_t)nb, done, &n_done));
+    FRONT_CHECK(strl_front_enqueue_after(ctxs[(size_t)g], ci ? ctxs[(size_t)((ci - 1) % (uint64_t)G)] : nullptr, dst, hi - lo, coff, clen, isz, crc, (uint32_t)nb, done, &n_done));
     ++pushes[(size_t)g];
     got(g, done, n_done);
     mark(g, before);
+    // the next chunk's bytes are read by now (or nearly): its copy goes into the device's queue BEFORE this thread waits for the
+    // previous chunk's record scan -- behind that wait it started half an inflate late
+    const auto td0 = now();
+    ahead.join();
+    t_stage_wait += secs(td0, now());
+    if (nxt.nb > 0 && !nxt.short_read) {
+      uint64_t *ncoff = reinterpret_cast<uint64_t *>(pin_meta[nxt.slot]);
+      uint32_t *nclen = reinterpret_cast<uint32_t *>(ncoff + chunk_blocks), *nisz = nclen + chunk_blocks, *ncrc = nisz + chunk_blocks;
+      FRONT_CHECK(strl_front_stage(ctxs[(size_t)nxt.g], pin[nxt.slot], nxt.hi - nxt.lo, ncoff, nclen, nisz, ncrc, (uint32_t)nxt.nb));
+    }
+    FRONT_CHECK(strl_front_collect(ctxs[(size_t)g]));
     account();
     if (G == 1 && !frag_thread.joinable()) {
       uint64_t parsed = 0;
@@ -775,7 +823,8 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
         }
       }
     }
-    t_walk += secs(ta, tb); t_copy += secs(tb, tc); t_push += secs(tc, now());
+    cur = nxt;
+    t_push += secs(tc, now());
   }
   if (frag_thread.joinable()) frag_thread.join();
   const auto tf = now();
@@ -884,9 +933,9 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   fprintf(stderr, "[strling] finished extraction\n");
   if (verbose) {
     fprintf(stderr, "[strling] %lld reads, %llu STR reads, 0 reads still waiting for a mate\n", (long long)nreads, (unsigned long long)nt);
-    fprintf(stderr, "[strling] seconds: total %.3f  waiting for block headers %.3f  copying compressed bytes %.3f  enqueueing + waiting for the device %.3f  "
+    fprintf(stderr, "[strling] seconds: total %.3f  (beside the device: block headers %.3f, reading compressed bytes %.3f)  enqueueing + waiting for the device %.3f  waiting for the next chunk's bytes %.3f  "
                     "draining the device %.3f  fragment lengths %.3f (copy %.3f, set_opts %.3f)  pair logic + names %.3f (pair logic over all reads + .bin order %.3f)  (device front end; %llu scan segments walked twice)\n",
-            secs(t0, now()), t_walk, t_copy, t_push, t_drain, t_frag, t_frag_copy, t_setopts, t_pair, t_finish, (unsigned long long)slow_segments);
+            secs(t0, now()), t_walk, t_copy, t_push - t_stage_wait, t_stage_wait, t_drain, t_frag, t_frag_copy, t_setopts, t_pair, t_finish, (unsigned long long)slow_segments);
   }
   if (verbose) {
     uint64_t mf = 0, mt = 0;

@@ -49,17 +49,26 @@ struct FrontSlot {
   hipEvent_t wait_read = nullptr; // not owned: the ev_carry of the context that copied this slot's tail (multi-GPU carry); an event is
   bool read_pending = false;      // recorded on a stream of its own device only, a wait on it is legal from any device
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_h2d = nullptr;   // record scan done | parse + scoring done (slot reusable) | compressed bytes on the device
-  bool b_pending = false, a_pending = false;
+  hipEvent_t ev_i = nullptr, ev_cd = nullptr;                     // inflate + CRC done (compressed bytes and block tables reusable) | the partial record in front of this chunk taken from the previous slot
+  bool b_pending = false, a_pending = false, i_pending = false, cd_pending = false, h2d_pending = false;
+  bool staged = false;            // front_copy has run for the slot's next chunk (strl_front_stage); the push must hand over the same chunk
+  const uint8_t *staged_comp = nullptr;
+  uint64_t staged_bytes = 0, staged_tot = 0;
+  uint32_t staged_blocks = 0;
   FrontInfo *h_info = nullptr;   // pinned: [0] as of the record scan, [1] as of the parse, [2] the initial values
   uint64_t *h_uoff = nullptr;    // pinned: output offsets of the blocks
   uint32_t h_uoff_cap = 0;
 };
 
 struct strl_front {
-  hipStream_t st_a = nullptr;        // inflate + record scan
+  hipStream_t st_i = nullptr;        // inflate + CRC, lowest priority: a launch fills every CU for ~17 ms; the scan, parse and scorer kernels of the
+                                     // neighbouring chunks take the slots its waves give up
+  hipStream_t st_a = nullptr;        // record scan (behind the chunk's inflate, beside the next chunk's)
   hipStream_t st_c = nullptr;        // copies of the compressed bytes to the device: the next chunk's copy runs beside this chunk's inflate
   FrontSlot slot[2];
   int n_ref = 0;
+  uint32_t hint_blocks = 0;          // front_reserve: blocks per chunk the buffers were sized for
+  uint64_t b_issued = 0;             // chunks whose parse + scoring have been enqueued (strl_front_collect)
   uint64_t first_off = 0;            // offset of the first record in the first chunk's inflated bytes
   uint64_t chunks = 0;               // chunks pushed so far
   bool not_first = false;            // (multi-GPU) this context's first chunk is not the file's first
@@ -99,6 +108,8 @@ struct FrontCarrySrc {
 
 // front.hip
 int front_stage_a(strl_ctx *c, strl_front *F, int slot, const FrontChunkDesc &d, bool first, const FrontCarrySrc *carry = nullptr);
+int front_copy(strl_ctx *c, strl_front *F, int slot, const FrontChunkDesc &d);
+int front_reserve(strl_ctx *c, strl_front *F, uint32_t max_blocks, uint64_t max_comp_bytes);
 struct FrontParseOut {
   int32_t *tid, *pos, *end;
   uint32_t *seq_off;

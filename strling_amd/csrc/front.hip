@@ -276,6 +276,8 @@ __global__ __launch_bounds__(256) void rec_parse_kernel(ParseParams P) {
   const bool act = i < P.n;
   bool primary = false;
   int32_t placed_idx = -1;
+  const uint8_t *seq_src = nullptr;
+  uint32_t seq_so = 0, seq_nb = 0;
   if (act) {
     const uint32_t q = P.recoff[i];
     const uint8_t *R = P.U + q;
@@ -312,15 +314,8 @@ __global__ __launch_bounds__(256) void rec_parse_kernel(ParseParams P) {
     row.tid = tid; row.pos = pos; row.mtid = mtid; row.mpos = mpos; row.end = end;
     row.flag = (uint16_t)flag; row.l_seq = ls16; row.clip_l = cl16; row.clip_r = cr16; row.mapq = (uint8_t)mapq; row.cig = (uint8_t)cbits; row.pad = 0;
     P.o.rows[i] = row;
-    // SEQ as it sits in the record (4-bit codes), to a 16-byte aligned slot; the bytes behind it in the last dword zeroed
-    const uint32_t nb = (l_seq + 1u) / 2u;
-    uint32_t *dst = reinterpret_cast<uint32_t *>(P.o.seq4 + (uint64_t)so * 16u);
-    for (uint32_t j = 0; j * 4u < nb; ++j) {
-      uint32_t w = ld32u(sq + 4u * j);
-      const uint32_t left = nb - 4u * j;
-      if (left < 4u) w &= (1u << (8u * left)) - 1u;
-      dst[j] = w;
-    }
+    // (SEQ: copied by the whole wave behind this block, one record at a time)
+    seq_src = sq; seq_so = so; seq_nb = (l_seq + 1u) / 2u;
     // qname: bytes into the arena, FNV-1a hash like strl_qname_hash (the Cache of extract.nim:198,245 is keyed by it)
     const uint32_t ql = l_qname ? l_qname - 1u : 0u;
     const uint64_t qat = P.o.qarena_at + P.qoff[i];
@@ -339,6 +334,30 @@ __global__ __launch_bounds__(256) void rec_parse_kernel(ParseParams P) {
     P.o.tidflag[i] = (uint8_t)((primary ? 1u : 0u) | (tid >= 0 ? 2u : 0u));
     if (tid >= 0) placed_idx = (int32_t)i;
     if (primary && tid >= 0 && tid < P.n_ref) P.tid_seen[tid] = 1;
+  }
+  // SEQ as it sits in the record (4-bit codes), to a 16-byte aligned slot; the bytes behind it in the last dword zeroed.
+  // Copied by the WAVE, record by record: the lanes take consecutive dwords of one record (two cache lines read, two written
+  // per record).  A lane copying its own record dword by dword made every load and every store instruction of the wave touch
+  // 64 different lines, four bytes of each: the parse was a quarter of the device time of `strling extract`
+  // (profiles/r04/e2e_kernel_stats.csv: 7.2 ms per 4.2e6 records, 0.26 TB/s).
+  {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t src64 = (uint64_t)reinterpret_cast<uintptr_t>(seq_src);
+    const uint32_t src_lo = (uint32_t)src64, src_hi = (uint32_t)(src64 >> 32);
+    const unsigned long long have = __ballot(seq_nb != 0u);
+    for (unsigned long long m = have; m; m &= m - 1ull) {       // wave-uniform
+      const int r = __ffsll((long long)m) - 1;
+      const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane((int)seq_nb, r), so = (uint32_t)__builtin_amdgcn_readlane((int)seq_so, r);
+      const uint8_t *sq = reinterpret_cast<const uint8_t *>((uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)src_hi, r) << 32) |
+                                                                          (uint32_t)__builtin_amdgcn_readlane((int)src_lo, r)));
+      uint32_t *dst = reinterpret_cast<uint32_t *>(P.o.seq4 + (uint64_t)so * 16u);
+      for (uint32_t j = lane; j * 4u < nb; j += 64u) {
+        uint32_t w = ld32u(sq + 4u * j);
+        const uint32_t left = nb - 4u * j;
+        if (left < 4u) w &= (1u << (8u * left)) - 1u;
+        dst[j] = w;
+      }
+    }
   }
   // chunk summary: one atomic per wave
   const uint64_t pm = __ballot(primary);
@@ -425,17 +444,20 @@ static int tick(strl_front *F, hipStream_t st) {   // STRL_FRONT_TIMING: an even
   return STRL_OK;
 }
 
-// H2D of the chunk's compressed bytes + block table, inflate, record scan; asynchronous on F->st_a.  The slot's previous
-// occupant must have been parsed (ev_b) before its buffers are overwritten: waited for on the device.
-int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, bool first, const FrontCarrySrc *carry) {
+// H2D of the chunk's compressed bytes + block table (st_c), inflate + CRC (st_i), record scan (st_a); asynchronous.  The slot's
+// previous occupant must have been parsed (ev_b) before its buffers are overwritten, and the chunk between them must have
+// taken its partial first record from that occupant's tail (ev_cd): waited for on the device.  The scan of chunk k runs beside
+// the inflate of chunk k+1 (it was 1.65 ms of every 19 on one stream).
+// the st_c part: block tables + compressed bytes to the device.  Needs only that the slot's previous inflate + CRC are done
+// (ev_i, waited for on the device), so it can be queued a whole chunk early (strl_front_stage).
+int front_copy(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d) {
   FrontSlot &S = F->slot[si];
-  FrontSlot &Pv = F->slot[si ^ 1];
-  hipStream_t st = F->st_a;
   int rc;
   const uint32_t nb = d.n_blocks;
+  if (S.h2d_pending) { STRL_HIP(hipEventSynchronize(S.ev_h2d)); S.h2d_pending = false; }   // h_uoff is the source of the slot's previous copy (long done)
   if (S.h_uoff_cap < nb) {     // (page-locked: the copy below must not block this thread)
-    if (S.h_uoff) { STRL_HIP(hipStreamSynchronize(F->st_c)); (void)hipHostFree(S.h_uoff); S.h_uoff = nullptr; }
-    S.h_uoff_cap = nb + nb / 4 + 1024;
+    if (S.h_uoff) { (void)hipHostFree(S.h_uoff); S.h_uoff = nullptr; }
+    S.h_uoff_cap = std::max(nb + nb / 4 + 1024, F->hint_blocks);
     STRL_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_uoff), (size_t)S.h_uoff_cap * 8, hipHostMallocDefault));
   }
   uint64_t *uoff = S.h_uoff;
@@ -446,29 +468,17 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
     tot += d.isize[i];
   }
   if (tot + FRONT_CARRY_MAX > 0xf0000000ull) { set_error("chunk inflates to %llu bytes (limit 3.7 GB)", (unsigned long long)tot); return STRL_ERR_ARG; }
-  const uint32_t end = (uint32_t)(FRONT_CARRY_MAX + tot), n_seg = (end + FRONT_SEG - 1) / FRONT_SEG;
   const uint64_t readable = (d.comp_bytes + 3) & ~(uint64_t)3;
-  const uint64_t rec_cap = tot / 36 + 16;          // no record is shorter than 36 bytes
-  if (S.b_pending) STRL_HIP(hipStreamWaitEvent(st, S.ev_b, 0));
-  if (S.read_pending) { STRL_HIP(hipStreamWaitEvent(st, S.wait_read, 0)); S.read_pending = false; }   // another context took its carry from this slot
   auto want = [](uint64_t need) { return (size_t)(need + need / 4 + 4096); };   // head-room: later chunks rarely reallocate
   if (S.comp.cap < readable + 16 && (rc = S.comp.reserve(want(readable + 16)))) return rc;
-  if (S.infl.cap < (uint64_t)end + 256 && (rc = S.infl.reserve(want((uint64_t)end + 256)))) return rc;
   if (S.coff.cap < (size_t)nb * 8 && ((rc = S.coff.reserve(want((size_t)nb * 8))) || (rc = S.uoff.reserve(want((size_t)nb * 8))) ||
                                        (rc = S.clen.reserve(want((size_t)nb * 4))) || (rc = S.isize.reserve(want((size_t)nb * 4))) || (rc = S.crc.reserve(want((size_t)nb * 4))) ||
                                        (rc = S.status.reserve(want(nb)))))
     return rc;
-  if (S.seg.cap < (size_t)n_seg * sizeof(FrontSeg) && ((rc = S.seg.reserve(want((size_t)n_seg * sizeof(FrontSeg)))) || (rc = S.base3.reserve(want((size_t)n_seg * 16)))))
-    return rc;
-  if (S.recoff.cap < rec_cap * 4 && ((rc = S.recoff.reserve(want(rec_cap * 4))) || (rc = S.seqoff.reserve(want(rec_cap * 4))) || (rc = S.qoff.reserve(want(rec_cap * 4)))))
-    return rc;
-  if ((rc = S.info.reserve(sizeof(FrontInfo)))) return rc;
-  S.n_blocks = nb; S.n_seg = n_seg; S.infl_bytes = tot; S.comp_bytes = d.comp_bytes;
-  if ((rc = tick(F, st))) return rc;
-  // the copies go on a stream of their own: they only have to wait until the slot's previous inflate + scan (which read
+  // the copies go on a stream of their own: they only have to wait until the slot's previous inflate + CRC (which read
   // these buffers) are done, and this chunk's inflate waits for them
   hipStream_t sc = F->st_c;
-  if (S.a_pending) STRL_HIP(hipStreamWaitEvent(sc, S.ev_a, 0));
+  if (S.i_pending) STRL_HIP(hipStreamWaitEvent(sc, S.ev_i, 0));
   STRL_HIP(hipMemcpyAsync(S.comp.p, d.comp, d.comp_bytes, hipMemcpyHostToDevice, sc));
   STRL_HIP(hipMemsetAsync(static_cast<uint8_t *>(S.comp.p) + d.comp_bytes, 0, 16, sc));
   STRL_HIP(hipMemcpyAsync(S.coff.p, d.coff, (size_t)nb * 8, hipMemcpyHostToDevice, sc));
@@ -477,26 +487,83 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   STRL_HIP(hipMemcpyAsync(S.isize.p, d.isize, (size_t)nb * 4, hipMemcpyHostToDevice, sc));
   if (d.crc) STRL_HIP(hipMemcpyAsync(S.crc.p, d.crc, (size_t)nb * 4, hipMemcpyHostToDevice, sc));
   STRL_HIP(hipEventRecord(S.ev_h2d, sc));
-  STRL_HIP(hipStreamWaitEvent(st, S.ev_h2d, 0));
+  S.h2d_pending = true;
+  S.staged = true; S.staged_comp = d.comp; S.staged_bytes = d.comp_bytes; S.staged_blocks = nb; S.staged_tot = tot;
+  return STRL_OK;
+}
+
+// buffers of both slots for chunks of up to max_blocks blocks / max_comp_bytes compressed bytes, before the first chunk: a slot
+// that grows in the middle of the file (the short first chunk's, two chunks later) frees its buffers -- a device-wide wait
+int front_reserve(strl_ctx *c, strl_front *F, uint32_t max_blocks, uint64_t max_comp_bytes) {
+  int rc;
+  F->hint_blocks = max_blocks;
+  const uint64_t tot = (uint64_t)max_blocks * 65280u, end = FRONT_CARRY_MAX + tot, n_seg = (end + FRONT_SEG - 1) / FRONT_SEG, rec_cap = tot / 36 + 16;
+  if (end > 0xf0000000ull) { set_error("chunks of %u blocks inflate to more than 3.7 GB", max_blocks); return STRL_ERR_ARG; }
+  for (FrontSlot &S : F->slot) {
+    if ((rc = S.comp.reserve((size_t)max_comp_bytes + 64)) || (rc = S.infl.reserve((size_t)end + 256)) || (rc = S.coff.reserve((size_t)max_blocks * 8)) ||
+        (rc = S.uoff.reserve((size_t)max_blocks * 8)) || (rc = S.clen.reserve((size_t)max_blocks * 4)) || (rc = S.isize.reserve((size_t)max_blocks * 4)) ||
+        (rc = S.crc.reserve((size_t)max_blocks * 4)) || (rc = S.status.reserve(max_blocks)) || (rc = S.seg.reserve((size_t)n_seg * sizeof(FrontSeg))) ||
+        (rc = S.base3.reserve((size_t)n_seg * 16)) || (rc = S.recoff.reserve((size_t)rec_cap * 4)) || (rc = S.seqoff.reserve((size_t)rec_cap * 4)) ||
+        (rc = S.qoff.reserve((size_t)rec_cap * 4)))
+      return rc;
+  }
+  return STRL_OK;
+}
+
+int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, bool first, const FrontCarrySrc *carry) {
+  FrontSlot &S = F->slot[si];
+  FrontSlot &Pv = F->slot[si ^ 1];
+  hipStream_t st = F->st_a, sti = F->st_i;
+  int rc;
+  const uint32_t nb = d.n_blocks;
+  if (S.staged && (S.staged_comp != d.comp || S.staged_bytes != d.comp_bytes || S.staged_blocks != nb)) {
+    set_error("strl_front_push: not the chunk handed to strl_front_stage");
+    return STRL_ERR_ARG;
+  }
+  if (!S.staged && (rc = front_copy(c, F, si, d))) return rc;
+  S.staged = false;
+  const uint64_t tot = S.staged_tot;
+  const uint32_t end = (uint32_t)(FRONT_CARRY_MAX + tot), n_seg = (end + FRONT_SEG - 1) / FRONT_SEG;
+  const uint64_t readable = (d.comp_bytes + 3) & ~(uint64_t)3;
+  const uint64_t rec_cap = tot / 36 + 16;          // no record is shorter than 36 bytes
+  if (S.b_pending) STRL_HIP(hipStreamWaitEvent(sti, S.ev_b, 0));
+  if (S.read_pending) { STRL_HIP(hipStreamWaitEvent(sti, S.wait_read, 0)); S.read_pending = false; }   // another context took its carry from this slot
+  if (Pv.cd_pending) STRL_HIP(hipStreamWaitEvent(sti, Pv.ev_cd, 0));                                   // the previous chunk took its carry from this slot
+  auto want = [](uint64_t need) { return (size_t)(need + need / 4 + 4096); };   // head-room: later chunks rarely reallocate
+  if (S.infl.cap < (uint64_t)end + 256 && (rc = S.infl.reserve(want((uint64_t)end + 256)))) return rc;
+  if (S.seg.cap < (size_t)n_seg * sizeof(FrontSeg) && ((rc = S.seg.reserve(want((size_t)n_seg * sizeof(FrontSeg)))) || (rc = S.base3.reserve(want((size_t)n_seg * 16)))))
+    return rc;
+  if (S.recoff.cap < rec_cap * 4 && ((rc = S.recoff.reserve(want(rec_cap * 4))) || (rc = S.seqoff.reserve(want(rec_cap * 4))) || (rc = S.qoff.reserve(want(rec_cap * 4)))))
+    return rc;
+  if ((rc = S.info.reserve(sizeof(FrontInfo)))) return rc;
+  S.n_blocks = nb; S.n_seg = n_seg; S.infl_bytes = tot; S.comp_bytes = d.comp_bytes;
+  if ((rc = tick(F, sti))) return rc;
+  STRL_HIP(hipStreamWaitEvent(sti, S.ev_h2d, 0));
   FrontInfo &hi = S.h_info[2];
   memset(&hi, 0, sizeof hi);
   hi.start0 = (uint32_t)(FRONT_CARRY_MAX + (first ? F->first_off : 0));
   hi.end = end;
   hi.last_placed = -1;
-  STRL_HIP(hipMemcpyAsync(S.info.p, &hi, sizeof hi, hipMemcpyHostToDevice, st));
-  STRL_HIP(hipMemsetAsync(static_cast<uint8_t *>(S.infl.p) + end, 0, 256, st));      // the parse may load a dword across the end
-  if ((rc = tick(F, st))) return rc;
+  STRL_HIP(hipMemcpyAsync(S.info.p, &hi, sizeof hi, hipMemcpyHostToDevice, sti));
+  STRL_HIP(hipMemsetAsync(static_cast<uint8_t *>(S.infl.p) + end, 0, 256, sti));      // the parse may load a dword across the end
+  if ((rc = tick(F, sti))) return rc;
   FrontInfo *info = S.info.as<FrontInfo>();
   if ((rc = strl_inflate_device(c, S.comp.as<uint8_t>(), readable, S.coff.as<uint64_t>(), S.clen.as<uint32_t>(), S.uoff.as<uint64_t>(), S.isize.as<uint32_t>(), nb,
-                                S.infl.as<uint8_t>(), &info->inflate_err, S.status.as<uint8_t>(), st)))
+                                S.infl.as<uint8_t>(), &info->inflate_err, S.status.as<uint8_t>(), sti)))
     return rc;
   if (d.crc && (rc = strl_crc_device(c, S.infl.as<uint8_t>(), S.uoff.as<uint64_t>(), S.isize.as<uint32_t>(), S.crc.as<uint32_t>(), nb, S.status.as<uint8_t>(),
-                                     &info->inflate_err, st)))
+                                     &info->inflate_err, sti)))
     return rc;
-  if ((rc = tick(F, st))) return rc;
+  if ((rc = tick(F, sti))) return rc;
+  STRL_HIP(hipEventRecord(S.ev_i, sti));
+  S.i_pending = true;
+  STRL_HIP(hipStreamWaitEvent(st, S.ev_i, 0));
+  S.cd_pending = false;
   if (!first && !carry) {
     hipLaunchKernelGGL(carry_kernel, dim3(1), dim3(1024), 0, st, Pv.infl.as<uint8_t>(), Pv.info.as<FrontInfo>(), S.infl.as<uint8_t>(), info);
     STRL_HIP(hipGetLastError());
+    STRL_HIP(hipEventRecord(S.ev_cd, st));       // the next inflate into Pv's buffers waits for this
+    S.cd_pending = true;
   } else if (!first) {
     // the previous chunk lives in another context (possibly on another device): its tail and its summary come over by a copy
     // behind its record scan, then the carry is cut out locally
@@ -571,6 +638,8 @@ void front_destroy(strl_front *F) {
     if (S.ev_a) (void)hipEventDestroy(S.ev_a);
     if (S.ev_b) (void)hipEventDestroy(S.ev_b);
     if (S.ev_h2d) (void)hipEventDestroy(S.ev_h2d);
+    if (S.ev_i) (void)hipEventDestroy(S.ev_i);
+    if (S.ev_cd) (void)hipEventDestroy(S.ev_cd);
     if (S.ev_carry) (void)hipEventDestroy(S.ev_carry);
     if (S.h_info) (void)hipHostFree(S.h_info);
     if (S.h_uoff) (void)hipHostFree(S.h_uoff);
@@ -580,6 +649,7 @@ void front_destroy(strl_front *F) {
     b->release();
   for (hipEvent_t e : F->tev) (void)hipEventDestroy(e);
   if (F->st_a) (void)hipStreamDestroy(F->st_a);
+  if (F->st_i) (void)hipStreamDestroy(F->st_i);
   if (F->st_c) (void)hipStreamDestroy(F->st_c);
   delete F;
 }

@@ -905,7 +905,7 @@ void strl_ctx_destroy(strl_ctx *c) {
   if (c->comm) { strl::comm_destroy(c->comm); c->comm = nullptr; }
   if (c->x_soft_seen_ev) (void)hipEventDestroy(c->x_soft_seen_ev);
   if (c->x_soft_seen) (void)hipHostFree(c->x_soft_seen);
-  if (c->front) { if (c->front->st_c) (void)hipStreamSynchronize(c->front->st_c); if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a); strl::front_destroy(c->front); c->front = nullptr; }
+  if (c->front) { if (c->front->st_c) (void)hipStreamSynchronize(c->front->st_c); if (c->front->st_i) (void)hipStreamSynchronize(c->front->st_i); if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a); strl::front_destroy(c->front); c->front = nullptr; }
   strl::DevBuf *bufs[] = {&c->lut, &c->thr, &c->g_tid, &c->g_bins, &c->g_start, &c->g_pmax, &c->queue, &c->soft_queue, &c->counters,
                           &c->soft_tmp, &c->sb_whole, &c->sb_soft, &c->queue_r, &c->soft_dense, &c->sb_state_w, &c->sb_state_s, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
                           &c->st_mapq, &c->st_cig, &c->st_seq4, &c->st_whole, &c->st_soft, &c->st_text, &c->st_meta,
@@ -1728,17 +1728,28 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
   if (!c || n_ref < 0) { set_error("bad argument"); return STRL_ERR_ARG; }
   int rc = strl_extract_begin(c, n_reads_hint);
   if (rc) return rc;
-  if (c->front) { if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a); strl::front_destroy(c->front); c->front = nullptr; }
+  if (c->front) {
+    if (c->front->st_i) (void)hipStreamSynchronize(c->front->st_i);
+    if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a);
+    strl::front_destroy(c->front); c->front = nullptr;
+  }
   strl::strl_front *F = new strl::strl_front();
   c->front = F;
   c->x_front = true;
   F->n_ref = n_ref; F->first_off = first_record_offset;
-  STRL_HIP(hipStreamCreateWithFlags(&F->st_a, hipStreamNonBlocking));
+  {
+    int least = 0, greatest = 0;          // (numerically: least >= greatest; equal where the device has one level)
+    STRL_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    STRL_HIP(hipStreamCreateWithPriority(&F->st_i, hipStreamNonBlocking, least));
+    STRL_HIP(hipStreamCreateWithPriority(&F->st_a, hipStreamNonBlocking, greatest));
+  }
   STRL_HIP(hipStreamCreateWithFlags(&F->st_c, hipStreamNonBlocking));
   for (strl::FrontSlot &S : F->slot) {
     STRL_HIP(hipEventCreateWithFlags(&S.ev_a, hipEventDisableTiming));
     STRL_HIP(hipEventCreateWithFlags(&S.ev_b, hipEventDisableTiming));
     STRL_HIP(hipEventCreateWithFlags(&S.ev_h2d, hipEventDisableTiming));
+    STRL_HIP(hipEventCreateWithFlags(&S.ev_i, hipEventDisableTiming));
+    STRL_HIP(hipEventCreateWithFlags(&S.ev_cd, hipEventDisableTiming));
     STRL_HIP(hipEventCreateWithFlags(&S.ev_carry, hipEventDisableTiming));
     STRL_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_info), 3 * sizeof(strl::FrontInfo), hipHostMallocDefault));
   }
@@ -1761,6 +1772,47 @@ int strl_front_push(strl_ctx *c, const uint8_t *comp, uint64_t comp_bytes, const
 // this chunk is taken from there
 int strl_front_push_after(strl_ctx *c, strl_ctx *prev, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize,
                           const uint32_t *crc32, uint32_t n_blocks, strl_front_chunk *done, int *n_done) {
+  const int rc = strl_front_enqueue_after(c, prev, comp, comp_bytes, coff, clen, isize, crc32, n_blocks, done, n_done);
+  return rc ? rc : strl_front_collect(c);
+}
+
+// the two halves of a push, for a caller that has something to do between them (strl_front_stage of the chunk after this
+// one): enqueue = this chunk's copy (unless staged) + inflate + record scan, and the summary of the chunk two back;
+// collect = wait for the PREVIOUS chunk's record scan, enqueue its parse + scoring
+int strl_front_collect(strl_ctx *c) {
+  if (!c || !c->front) { set_error("strl_front_collect without strl_front_begin"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  strl::strl_front *F = c->front;
+  int rc;
+  while (F->b_issued + 1 < F->chunks) {
+    if ((rc = front_stage_b(c, F, (int)(F->b_issued & 1)))) return rc;
+    ++F->b_issued;
+  }
+  return STRL_OK;
+}
+
+int strl_front_reserve(strl_ctx *c, uint32_t max_blocks, uint64_t max_comp_bytes) {
+  if (!c || !c->front || !max_blocks) { set_error("strl_front_reserve: bad argument / no strl_front_begin"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  // (the parse columns and the scorer's per-chunk queues are left to their first full chunk: reserving them here too cost
+  // 40 - 60 ms of hipMalloc before the loop against 8 ms of one late inflate inside it)
+  return strl::front_reserve(c, c->front, max_blocks, max_comp_bytes);
+}
+
+// starts the copy to the device of the chunk the NEXT strl_front_push / _enqueue_after of this context will hand over
+int strl_front_stage(strl_ctx *c, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize, const uint32_t *crc32,
+                     uint32_t n_blocks) {
+  if (!c || !c->front || !c->x_open || !n_blocks || !comp || !coff || !clen || !isize) { set_error("strl_front_stage: bad argument / no strl_front_begin"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  strl::strl_front *F = c->front;
+  const int si = (int)(F->chunks & 1);
+  if (F->slot[si].staged) { set_error("strl_front_stage: a chunk is staged already"); return STRL_ERR_ARG; }
+  const strl::FrontChunkDesc d{comp, comp_bytes, coff, clen, isize, crc32, n_blocks};
+  return strl::front_copy(c, F, si, d);
+}
+
+int strl_front_enqueue_after(strl_ctx *c, strl_ctx *prev, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize,
+                             const uint32_t *crc32, uint32_t n_blocks, strl_front_chunk *done, int *n_done) {
   if (!c || !c->front || !c->x_open || (n_blocks && (!comp || !coff || !clen || !isize))) { set_error("strl_front_push: bad argument / no strl_front_begin"); return STRL_ERR_ARG; }
   if (prev == c) prev = nullptr;
   if (prev && (!prev->front || prev->front->last_slot < 0)) { set_error("strl_front_push_after: the previous context has no chunk"); return STRL_ERR_ARG; }
@@ -1770,10 +1822,8 @@ int strl_front_push_after(strl_ctx *c, strl_ctx *prev, const uint8_t *comp, uint
   if (!n_blocks) return STRL_OK;
   const int si = (int)(F->chunks & 1);
   int rc;
-  if (F->slot[si].b_pending) {           // the chunk before the previous one: its slot is reused now
-    if ((rc = front_fill_done(c, F->slot[si], done))) return rc;
-    if (n_done) *n_done = 1;
-  }
+  if ((rc = strl_front_collect(c))) return rc;        // (a caller that left it out: the slot's previous occupant must have been handed to the scorer)
+  const bool reuse = F->slot[si].b_pending;          // the chunk before the previous one: its slot is reused now
   const strl::FrontChunkDesc d{comp, comp_bytes, coff, clen, isize, crc32, n_blocks};
   if (prev) {
     strl::FrontSlot &PS = prev->front->slot[prev->front->last_slot];
@@ -1783,10 +1833,17 @@ int strl_front_push_after(strl_ctx *c, strl_ctx *prev, const uint8_t *comp, uint
     rc = strl::front_stage_a(c, F, si, d, F->chunks == 0 && !F->not_first);
   }
   if (rc) return rc;
+  // The summary of the slot's previous occupant is waited for AFTER this chunk's work has been queued (the device waits for
+  // that parse itself, ev_b).  The other order kept this chunk's copy to the device from being queued until the parse two
+  // chunks back had finished -- it runs beside an inflate that leaves it few wave slots, up to 16 ms -- and every second
+  // inflate started 7 ms late (profiles/r04/extract_timeline_before.txt).
+  if (reuse) {
+    if ((rc = front_fill_done(c, F->slot[si], done))) return rc;
+    if (n_done) *n_done = 1;
+  }
   ++F->chunks;
   F->comp_total += comp_bytes;
   F->infl_total += F->slot[si].infl_bytes;
-  if (F->chunks >= 2 && (rc = front_stage_b(c, F, si ^ 1))) return rc;
   return STRL_OK;
 }
 
@@ -1798,7 +1855,8 @@ int strl_front_finish(strl_ctx *c, strl_front_chunk done[2], int *n_done) {
   int rc, k = 0;
   if (!F->chunks) return STRL_OK;
   const int last = (int)((F->chunks - 1) & 1);
-  if ((rc = front_stage_b(c, F, last))) return rc;
+  for (; F->b_issued < F->chunks; ++F->b_issued)
+    if ((rc = front_stage_b(c, F, (int)(F->b_issued & 1)))) return rc;
   for (int si : {last ^ 1, last}) {
     if (!F->slot[si].b_pending) continue;
     if ((rc = front_fill_done(c, F->slot[si], done ? &done[k] : nullptr))) return rc;

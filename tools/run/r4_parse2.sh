@@ -1,0 +1,22 @@
+#!/bin/bash
+# round 4: next chunk read ahead + wave-cooperative SEQ copy: tests, e2e, kernel timeline
+mkdir -p gpurun_out/r4
+R=${GRAFT_REPO_ROOT:-/root/repo}
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_front_device.py tests/test_cli.py tests/test_bgzf_device.py -m gpu -x -q > gpurun_out/r4/parse5_tests.log 2>&1
+tail -5 gpurun_out/r4/parse5_tests.log
+N=${PAIRS:-33554432}
+timeout 1500 python tools/e2e_bench.py $N --dir /tmp --repeats 3 --check-slabs 4 --keep --out gpurun_out/r4/parse5_e2e.json > gpurun_out/r4/parse5_e2e.log 2>&1
+python - <<'P'
+import json
+j=json.load(open('gpurun_out/r4/parse5_e2e.json'))
+for r in j['runs']: print(r['wall_s'], r['loop_s'], r['device_front_end'], r['phases'][:330], '|', r['outside_the_loop'][:200])
+print(j['check']['ok'], j['call_s'], j['merge_s'])
+P
+CLI=$R/strling_amd/lib/strling
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r4/parse5_kt -o run -- $CLI extract -v -g /tmp/e2e_${N}_6.str /tmp/e2e_${N}_6.bam /tmp/e2e_prof.bin > $R/gpurun_out/r4/parse5_kt.log 2>&1
+f=$(find $R/gpurun_out/r4/parse5_kt -name 'run_kernel_trace.csv' | head -1)
+python $R/tools/trace_timeline.py $f > $R/gpurun_out/r4/parse5_timeline.txt 2>&1
+cat $R/gpurun_out/r4/parse5_timeline.txt
+find $R/gpurun_out/r4/parse5_kt -name 'run_kernel_trace.csv' -delete; find $R/gpurun_out/r4/parse5_kt -name '*agent_info*' -delete
