@@ -49,8 +49,8 @@ struct FrontSlot {
   hipEvent_t wait_read = nullptr; // not owned: the ev_carry of the context that copied this slot's tail (multi-GPU carry); an event is
   bool read_pending = false;      // recorded on a stream of its own device only, a wait on it is legal from any device
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_h2d = nullptr;   // record scan done | parse + scoring done (slot reusable) | compressed bytes on the device
-  hipEvent_t ev_i = nullptr, ev_cd = nullptr;                     // inflate + CRC done (compressed bytes and block tables reusable) | the partial record in front of this chunk taken from the previous slot
-  bool b_pending = false, a_pending = false, i_pending = false, cd_pending = false, h2d_pending = false;
+  hipEvent_t ev_i = nullptr;                                      // inflate + CRC done (compressed bytes and block tables reusable)
+  bool b_pending = false, a_pending = false, i_pending = false, h2d_pending = false;
   bool staged = false;            // front_copy has run for the slot's next chunk (strl_front_stage); the push must hand over the same chunk
   const uint8_t *staged_comp = nullptr;
   uint64_t staged_bytes = 0, staged_tot = 0;
@@ -61,8 +61,11 @@ struct FrontSlot {
 };
 
 struct strl_front {
-  hipStream_t st_i = nullptr;        // inflate + CRC, lowest priority: a launch fills every CU for ~17 ms; the scan, parse and scorer kernels of the
-                                     // neighbouring chunks take the slots its waves give up
+  hipStream_t st_i[2] = {nullptr, nullptr};   // inflate + CRC of the chunk in slot 0 / 1, lowest priority: a launch fills every CU for ~17 ms; the scan,
+                                     // parse and scorer kernels of the neighbouring chunks take the slots its waves give up.  Two streams: chunk k+1's inflate
+                                     // needs nothing of chunk k (its partial first record comes through carry_buf, behind the inflate), so its waves take the
+                                     // slots chunk k's last waves leave -- one stream had the device drain to a handful of waves between launches
+  DevBuf carry_buf[2];               // [slot]: u32 length (64-byte header) + the partial record the slot's chunk ended in, written behind its record scan
   hipStream_t st_a = nullptr;        // record scan (behind the chunk's inflate, beside the next chunk's)
   hipStream_t st_c = nullptr;        // copies of the compressed bytes to the device: the next chunk's copy runs beside this chunk's inflate
   FrontSlot slot[2];

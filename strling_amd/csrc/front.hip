@@ -76,14 +76,18 @@ __device__ void walk_segment(const uint8_t *U, uint32_t e, uint64_t seg_end, uin
 }
 
 // the partial record behind the last complete one of the previous chunk goes in front of this chunk's bytes
-__global__ void carry_kernel(const uint8_t *prev_infl, const FrontInfo *prev, uint8_t *infl, FrontInfo *info) {
-  const uint32_t len = prev->carry_len <= FRONT_CARRY_MAX ? prev->carry_len : 0u, off = prev->carry_off;
-  for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) infl[FRONT_CARRY_MAX - len + i] = prev_infl[off + i];
+// behind the record scan of a chunk: its trailing partial record + length into the slot's carry buffer.  The next chunk takes it
+// from there (carry_kernel), not from this chunk's inflated bytes: those may then be overwritten as soon as the parse is done
+__global__ void carry_out_kernel(const uint8_t *infl, const FrontInfo *info, uint8_t *buf) {
+  const uint32_t len = info->carry_len <= FRONT_CARRY_MAX ? info->carry_len : 0u, off = info->carry_off;
+  for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) buf[64 + i] = infl[off + i];
+  if (threadIdx.x == 0) *reinterpret_cast<uint32_t *>(buf) = len;
+}
+__global__ void carry_kernel(const uint8_t *prev_buf, uint8_t *infl, FrontInfo *info) {
+  const uint32_t len = *reinterpret_cast<const uint32_t *>(prev_buf);
+  for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) infl[FRONT_CARRY_MAX - len + i] = prev_buf[64 + i];
   if (threadIdx.x == 0) info->start0 = FRONT_CARRY_MAX - len;
 }
-
-// ... the same when the previous chunk sits in another context: `stage` holds the last stage_len bytes of its inflated data
-// (copied over by the copy engine), then that slot's FrontInfo
 __global__ void carry_stage_kernel(const uint8_t *stage, uint32_t stage_len, uint32_t prev_end, uint8_t *infl, FrontInfo *info) {
   const FrontInfo *prev = reinterpret_cast<const FrontInfo *>(stage + FRONT_CARRY_MAX + 64);
   const uint32_t len = prev->carry_len <= stage_len ? prev->carry_len : 0u;
@@ -445,9 +449,9 @@ static int tick(strl_front *F, hipStream_t st) {   // STRL_FRONT_TIMING: an even
 }
 
 // H2D of the chunk's compressed bytes + block table (st_c), inflate + CRC (st_i), record scan (st_a); asynchronous.  The slot's
-// previous occupant must have been parsed (ev_b) before its buffers are overwritten, and the chunk between them must have
-// taken its partial first record from that occupant's tail (ev_cd): waited for on the device.  The scan of chunk k runs beside
-// the inflate of chunk k+1 (it was 1.65 ms of every 19 on one stream).
+// previous occupant must have been parsed (ev_b) before its buffers are overwritten: waited for on the device.  Nothing else
+// orders the inflates of consecutive chunks (each slot has a stream): the scan of chunk k, and the last waves of its inflate,
+// run beside the inflate of chunk k+1.
 // the st_c part: block tables + compressed bytes to the device.  Needs only that the slot's previous inflate + CRC are done
 // (ev_i, waited for on the device), so it can be queued a whole chunk early (strl_front_stage).
 int front_copy(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d) {
@@ -512,8 +516,7 @@ int front_reserve(strl_ctx *c, strl_front *F, uint32_t max_blocks, uint64_t max_
 
 int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, bool first, const FrontCarrySrc *carry) {
   FrontSlot &S = F->slot[si];
-  FrontSlot &Pv = F->slot[si ^ 1];
-  hipStream_t st = F->st_a, sti = F->st_i;
+  hipStream_t st = F->st_a, sti = F->st_i[si];
   int rc;
   const uint32_t nb = d.n_blocks;
   if (S.staged && (S.staged_comp != d.comp || S.staged_bytes != d.comp_bytes || S.staged_blocks != nb)) {
@@ -528,7 +531,6 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   const uint64_t rec_cap = tot / 36 + 16;          // no record is shorter than 36 bytes
   if (S.b_pending) STRL_HIP(hipStreamWaitEvent(sti, S.ev_b, 0));
   if (S.read_pending) { STRL_HIP(hipStreamWaitEvent(sti, S.wait_read, 0)); S.read_pending = false; }   // another context took its carry from this slot
-  if (Pv.cd_pending) STRL_HIP(hipStreamWaitEvent(sti, Pv.ev_cd, 0));                                   // the previous chunk took its carry from this slot
   auto want = [](uint64_t need) { return (size_t)(need + need / 4 + 4096); };   // head-room: later chunks rarely reallocate
   if (S.infl.cap < (uint64_t)end + 256 && (rc = S.infl.reserve(want((uint64_t)end + 256)))) return rc;
   if (S.seg.cap < (size_t)n_seg * sizeof(FrontSeg) && ((rc = S.seg.reserve(want((size_t)n_seg * sizeof(FrontSeg)))) || (rc = S.base3.reserve(want((size_t)n_seg * 16)))))
@@ -558,12 +560,10 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   STRL_HIP(hipEventRecord(S.ev_i, sti));
   S.i_pending = true;
   STRL_HIP(hipStreamWaitEvent(st, S.ev_i, 0));
-  S.cd_pending = false;
+  if ((rc = F->carry_buf[si].reserve((size_t)FRONT_CARRY_MAX + 64))) return rc;
   if (!first && !carry) {
-    hipLaunchKernelGGL(carry_kernel, dim3(1), dim3(1024), 0, st, Pv.infl.as<uint8_t>(), Pv.info.as<FrontInfo>(), S.infl.as<uint8_t>(), info);
+    hipLaunchKernelGGL(carry_kernel, dim3(1), dim3(1024), 0, st, F->carry_buf[si ^ 1].as<uint8_t>(), S.infl.as<uint8_t>(), info);
     STRL_HIP(hipGetLastError());
-    STRL_HIP(hipEventRecord(S.ev_cd, st));       // the next inflate into Pv's buffers waits for this
-    S.cd_pending = true;
   } else if (!first) {
     // the previous chunk lives in another context (possibly on another device): its tail and its summary come over by a copy
     // behind its record scan, then the carry is cut out locally
@@ -594,6 +594,8 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   STRL_HIP(hipGetLastError());
   hipLaunchKernelGGL(rec_emit_kernel, dim3(gb), dim3(64), 0, st, S.infl.as<uint8_t>(), info, S.seg.as<FrontSeg>(), n_seg, base3, S.recoff.as<uint32_t>(),
                      S.seqoff.as<uint32_t>(), S.qoff.as<uint32_t>());
+  STRL_HIP(hipGetLastError());
+  hipLaunchKernelGGL(carry_out_kernel, dim3(1), dim3(1024), 0, st, S.infl.as<uint8_t>(), info, F->carry_buf[si].as<uint8_t>());
   STRL_HIP(hipGetLastError());
   if ((rc = tick(F, st))) return rc;
   STRL_HIP(hipMemcpyAsync(S.h_info, S.info.p, sizeof(FrontInfo), hipMemcpyDeviceToHost, st));
@@ -639,7 +641,6 @@ void front_destroy(strl_front *F) {
     if (S.ev_b) (void)hipEventDestroy(S.ev_b);
     if (S.ev_h2d) (void)hipEventDestroy(S.ev_h2d);
     if (S.ev_i) (void)hipEventDestroy(S.ev_i);
-    if (S.ev_cd) (void)hipEventDestroy(S.ev_cd);
     if (S.ev_carry) (void)hipEventDestroy(S.ev_carry);
     if (S.h_info) (void)hipHostFree(S.h_info);
     if (S.h_uoff) (void)hipHostFree(S.h_uoff);
@@ -649,7 +650,8 @@ void front_destroy(strl_front *F) {
     b->release();
   for (hipEvent_t e : F->tev) (void)hipEventDestroy(e);
   if (F->st_a) (void)hipStreamDestroy(F->st_a);
-  if (F->st_i) (void)hipStreamDestroy(F->st_i);
+  for (hipStream_t q : F->st_i) if (q) (void)hipStreamDestroy(q);
+  for (DevBuf &b : F->carry_buf) b.release();
   if (F->st_c) (void)hipStreamDestroy(F->st_c);
   delete F;
 }

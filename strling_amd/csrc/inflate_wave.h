@@ -286,8 +286,8 @@ struct IwBits {
     bb >>= 8u * skip;
     nbits -= 8u * skip;
   }
-  IW_DEV void refill() {            // afterwards nbits >= 33
-    if (nbits <= 32u) {
+  IW_DEV void refill() {            // afterwards 32 <= nbits <= 63 (iw_run keeps a sentinel bit above the valid ones)
+    if (nbits < 32u) {
       const uint32_t w = iw_readlane(cur, widx);
       bb |= (uint64_t)w << nbits;
       nbits += 32u;
@@ -321,12 +321,12 @@ struct IwOut {
   IW_DEV void flush() {
     if (fpos < pos) {
       const uint32_t lo = fpos & 63u, n = pos - fpos, w = fpos & ~63u;
-      IW_FOR_LANES { iw_st8(out, (uint32_t)lane - lo < n ? w + (uint32_t)lane : IW_OOB, pend[lane]); }
+      IW_FOR_LANES { iw_st8(out, (uint32_t)lane - lo < n ? w + (uint32_t)lane : IW_OOB, pend[lane] >> 16); }   // a literal waits as its table entry: the byte is bits 23:16
       fpos = pos;
     }
   }
   IW_DEV void literal(uint32_t b) {   // caller checked pos < isize
-    iw_writelane(pend, pos & 63u, b);
+    iw_writelane(pend, pos & 63u, b << 16);
     ++pos;
     if ((pos & 63u) == 0u) flush();
   }
@@ -408,7 +408,7 @@ struct IwOut {
 #ifdef STRL_EMU
 IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t *dist_tab, uint32_t &e, uint32_t &code, uint32_t &L, uint32_t &D) {
   for (;;) {
-    if (br.nbits <= 32u) {
+    if (br.nbits < 32u) {
       const uint32_t w = iw_readlane(br.cur, br.widx);
       br.bb |= (uint64_t)w << br.nbits;
       br.nbits += 32u;
@@ -418,7 +418,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
     if (e & IW_FAST_LIT) {
       br.bb >>= e & 15u;
       br.nbits -= e & 15u;
-      iw_writelane(o.pend, o.pos & 63u, iw_val(e) & 255u);
+      iw_writelane(o.pend, o.pos & 63u, e);
       ++o.pos;
       if (!(o.pos & 63u)) {
         o.flush();
@@ -429,7 +429,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
     if ((e & (3u << 8)) != IW_KIND_BASE) { code = 0; return; }       // (an entry of 0 -- not in the table -- has kind 0)
     br.bits(e & 15u);
     L = iw_val(e) + br.bits((e >> 4) & 15u);
-    if (br.nbits <= 32u) {
+    if (br.nbits < 32u) {
       const uint32_t w = iw_readlane(br.cur, br.widx);
       br.bb |= (uint64_t)w << br.nbits;
       br.nbits += 32u;
@@ -456,61 +456,94 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
 #define IW_EXP_COPY "buffer_store_byte %[pdata], %[paddr], %[rsrc], 0 offen\n\t" "buffer_load_ubyte %[pdata], %[vt1], %[rsrc], 0 offen\n\t"
 #endif
 IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t *dist_tab, uint32_t &e, uint32_t &code, uint32_t &L, uint32_t &D) {
-  uint32_t vnb, ve, vn, vt0, vt1, vD, vsrc;
+  uint32_t ve, vn, vt0, vt1, vD, vsrc;
   const uint32_t vlit = (uint32_t)reinterpret_cast<uintptr_t>(lit_tab);     // LDS byte addresses (low half of the flat address)
   const uint32_t vdist = (uint32_t)reinterpret_cast<uintptr_t>(dist_tab);
   const uint32_t vlane = threadIdx.x;
   asm volatile(
-      "v_mov_b32_e32 %[vnb], %[nb]\n\t"
+      // the bit buffer carries a sentinel bit above its valid bits (nbits <= 63): "fewer than 32 valid bits" is "high word zero"
+      "s_mov_b32 s94, 1\n\t"
+      "s_mov_b32 s95, 0\n\t"
+      "s_lshl_b64 s[94:95], s[94:95], %[nb]\n\t"
+      "s_mov_b32 m0, %[pos]\n\t"
+      "s_or_b64 s[90:91], s[90:91], s[94:95]\n\t"
       "v_mov_b32_e32 %[vD], %[D]\n\t"
       "v_mov_b32_e32 %[ve], 0\n\t"
       "s_mov_b32 %[e], 0\n"
-      // ---- next symbol: first-level literal/length lookup (the refill sits out of line)
+      // ---- next symbol: first-level literal/length lookup (the refill sits out of line).  >= 32 valid bits here; a first-level
+      // code has <= 9: three literals are decoded per check (23, 14 bits left for the second and third lookup); anything that is
+      // not a literal in the second or third place comes back here first
       "L_iw_loop_%=:\n\t"
-      "v_cmp_lt_u32_e32 vcc, 32, %[vnb]\n\t"
-      "s_cbranch_vccz L_iw_refill_%=\n"
+      "s_cmp_eq_u32 s91, 0\n\t"
+      "s_cbranch_scc1 L_iw_refill_%=\n"
       "L_iw_have_%=:\n\t"
       "s_and_b32 s92, s90, %[litmask]\n\t"
       "v_lshl_add_u32 %[vt0], s92, 2, %[vlit]\n\t"
       "ds_read_b32 %[ve], %[vt0]\n\t"
-      "s_and_b32 s93, %[pos], 63\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
       "v_readfirstlane_b32 %[e], %[ve]\n\t"
-      "v_and_b32_e32 %[vn], 15, %[ve]\n\t"
-      "v_cmp_eq_u32_e32 vcc, s93, %[vlane]\n\t"
       "s_bitcmp1_b32 %[e], 31\n\t"
       "s_cbranch_scc0 L_iw_notlit_%=\n\t"
-      // ---- literal: into the staging register, lane = position mod 64
-      "s_and_b32 s92, %[e], 15\n\t"
-      "v_bfe_u32 %[vt0], %[ve], 16, 8\n\t"
-      "s_lshr_b64 s[90:91], s[90:91], s92\n\t"
-      "v_sub_u32_e32 %[vnb], %[vnb], %[vn]\n\t"
-      "s_add_u32 %[pos], %[pos], 1\n\t"
-      "v_cndmask_b32_e32 %[pend], %[pend], %[vt0], vcc\n\t"
-      "s_and_b32 s92, %[pos], 63\n\t"
-      "s_cbranch_scc1 L_iw_loop_%=\n\t"
+      // a literal: the shift takes the code length from the entry's low six bits (a literal has no extra bits); the ENTRY goes
+      // into the staging register, lane = position mod 64 (the byte is its bits 23:16: shifted down when the register is stored)
+      "s_lshr_b64 s[90:91], s[90:91], %[e]\n\t"
+      "v_writelane_b32 %[pend], %[e], m0\n\t"
+      "s_add_u32 m0, m0, 1\n\t"
+      "s_and_b32 s92, m0, 63\n\t"
+      "s_cbranch_scc0 L_iw_full_%=\n\t"
+      "s_and_b32 s92, s90, %[litmask]\n\t"
+      "v_lshl_add_u32 %[vt0], s92, 2, %[vlit]\n\t"
+      "ds_read_b32 %[ve], %[vt0]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_readfirstlane_b32 %[e], %[ve]\n\t"
+      "s_bitcmp1_b32 %[e], 31\n\t"
+      "s_cbranch_scc0 L_iw_loop_%=\n\t"
+      // a literal: the shift takes the code length from the entry's low six bits (a literal has no extra bits); the ENTRY goes
+      // into the staging register, lane = position mod 64 (the byte is its bits 23:16: shifted down when the register is stored)
+      "s_lshr_b64 s[90:91], s[90:91], %[e]\n\t"
+      "v_writelane_b32 %[pend], %[e], m0\n\t"
+      "s_add_u32 m0, m0, 1\n\t"
+      "s_and_b32 s92, m0, 63\n\t"
+      "s_cbranch_scc0 L_iw_full_%=\n\t"
+      "s_and_b32 s92, s90, %[litmask]\n\t"
+      "v_lshl_add_u32 %[vt0], s92, 2, %[vlit]\n\t"
+      "ds_read_b32 %[ve], %[vt0]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_readfirstlane_b32 %[e], %[ve]\n\t"
+      "s_bitcmp1_b32 %[e], 31\n\t"
+      "s_cbranch_scc0 L_iw_loop_%=\n\t"
+      // a literal: the shift takes the code length from the entry's low six bits (a literal has no extra bits); the ENTRY goes
+      // into the staging register, lane = position mod 64 (the byte is its bits 23:16: shifted down when the register is stored)
+      "s_lshr_b64 s[90:91], s[90:91], %[e]\n\t"
+      "v_writelane_b32 %[pend], %[e], m0\n\t"
+      "s_add_u32 m0, m0, 1\n\t"
+      "s_and_b32 s92, m0, 63\n\t"
+      "s_cbranch_scc1 L_iw_loop_%=\n"
       // 64 positions full: one coalesced store of the staged bytes [fpos, pos)
+      "L_iw_full_%=:\n\t"
       "s_and_b32 s92, %[fpos], 63\n\t"
-      "s_sub_u32 s95, %[pos], %[fpos]\n\t"
+      "s_sub_u32 s95, m0, %[fpos]\n\t"
       "s_andn2_b32 s94, %[fpos], 63\n\t"
       "v_subrev_u32_e32 %[vt0], s92, %[vlane]\n\t"
+      "v_lshrrev_b32_e32 %[vn], 16, %[pend]\n\t"
       "v_cmp_gt_u32_e32 vcc, s95, %[vt0]\n\t"
       "v_or_b32_e32 %[vt1], s94, %[vlane]\n\t"
       "v_cndmask_b32_e32 %[vt1], %[voob], %[vt1], vcc\n\t"
-      "buffer_store_byte %[pend], %[vt1], %[rsrc], 0 offen\n\t"
-      "s_mov_b32 %[fpos], %[pos]\n\t"
-      "s_cmp_gt_u32 %[pos], %[isize]\n\t"
+      "buffer_store_byte %[vn], %[vt1], %[rsrc], 0 offen\n\t"
+      "s_mov_b32 %[fpos], m0\n\t"
+      "s_cmp_gt_u32 m0, %[isize]\n\t"
       "s_cbranch_scc0 L_iw_loop_%=\n\t"
       "s_mov_b32 %[code], 7\n\t"
       "s_branch L_iw_end_%=\n"
-      // ---- 32 more bits into the buffer (every fourth symbol or so)
+      // ---- 32 more bits into the buffer (every fourth symbol or so): the sentinel's position is the bit count
       "L_iw_refill_%=:\n\t"
+      "s_flbit_i32_b32 s94, s90\n\t"
       "v_readlane_b32 s92, %[cur], %[wi]\n\t"
-      "v_readfirstlane_b32 s94, %[vnb]\n\t"
-      "s_mov_b32 s93, 0\n\t"
-      "s_add_u32 %[wi], %[wi], 1\n\t"
-      "v_add_u32_e32 %[vnb], 32, %[vnb]\n\t"
+      "s_sub_u32 s94, 31, s94\n\t"
+      "s_mov_b32 s93, 1\n\t"
+      "s_bitset0_b32 s90, s94\n\t"
       "s_lshl_b64 s[92:93], s[92:93], s94\n\t"
+      "s_add_u32 %[wi], %[wi], 1\n\t"
       "s_or_b64 s[90:91], s[90:91], s[92:93]\n\t"
       "s_cmp_eq_u32 %[wi], 64\n\t"
       "s_cbranch_scc0 L_iw_have_%=\n\t"
@@ -535,14 +568,13 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "s_bfe_u32 %[L], %[e], 0xf0010\n\t"
       "s_and_b32 s94, s94, s92\n\t"
       "s_add_u32 %[L], %[L], s94\n\t"
-      "v_subrev_u32_e32 %[vnb], s95, %[vnb]\n\t"
       "s_lshr_b64 s[90:91], s[90:91], s95\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
-      "v_cmp_lt_u32_e32 vcc, 32, %[vnb]\n\t"
-      "s_cbranch_vccz L_iw_refill2_%=\n"
+      "s_cmp_eq_u32 s91, 0\n\t"
+      "s_cbranch_scc1 L_iw_refill2_%=\n"
       // (32 more bits, if they were needed, have come in on top: the entry read above stands) the distance code's fields
       "L_iw_have2_%=:\n\t"
-      "s_add_u32 s93, %[pos], %[L]\n\t"
+      "s_add_u32 s93, m0, %[L]\n\t"
       "v_and_b32_e32 %[vn], 15, %[ve]\n\t"
       "v_bfe_u32 %[vt1], %[ve], 4, 4\n\t"
       "v_cmp_ne_u32_e32 vcc, 0, %[vn]\n\t"
@@ -553,21 +585,20 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "v_add_u32_e32 %[vn], %[vn], %[vt1]\n\t"
       "v_add_u32_e32 %[vD], %[vD], %[vt0]\n\t"
       "v_readfirstlane_b32 s92, %[vn]\n\t"
-      "v_sub_u32_e32 %[vnb], %[vnb], %[vn]\n\t"
       // the fast copy takes D >= L, D <= pos, pos + L <= isize (L >= 3 by the table)
       "v_cmp_gt_u32_e32 vcc, %[L], %[vD]\n\t"
       "s_lshr_b64 s[90:91], s[90:91], s92\n\t"
       "s_cbranch_vccnz L_iw_match5_%=\n\t"
-      "v_cmp_lt_u32_e32 vcc, %[pos], %[vD]\n\t"
+      "v_cmp_lt_u32_e32 vcc, m0, %[vD]\n\t"
       "s_cmp_gt_u32 s93, %[isize]\n\t"
       "s_cbranch_vccnz L_iw_match5_%=\n\t"
       "s_cbranch_scc1 L_iw_match5_%=\n\t"
-      "v_sub_u32_e32 %[vsrc], %[pos], %[vD]\n\t"
+      "v_sub_u32_e32 %[vsrc], m0, %[vD]\n\t"
       // Staged literals [fpos, pos): their store must be issued before a load that reads them -- a match whose source reaches
       // into them (pos - D + L > fpos: rare, distances are hundreds of bytes) flushes first.  Otherwise the copy goes first and
       // the flush behind it: the copy's wait then covers loads and stores of the PREVIOUS match only, not a store issued a
       // moment ago (removing the copy's waits altogether measured +13 %, profiles/r04/inflate_exp_waits.txt).
-      "s_cmp_lt_u32 %[fpos], %[pos]\n\t"
+      "s_cmp_lt_u32 %[fpos], m0\n\t"
       "s_cbranch_scc0 L_iw_copy_%=\n\t"
       "v_add_u32_e32 %[vt0], %[L], %[vsrc]\n\t"
       "v_cmp_lt_u32_e32 vcc, %[fpos], %[vt0]\n\t"
@@ -575,46 +606,48 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       // the first 64 bytes of the copy, then the staged literals
       "v_cmp_gt_u32_e32 vcc, %[L], %[vlane]\n\t"
       "v_add_u32_e32 %[vt1], %[vsrc], %[vlane]\n\t"
-      "v_add_u32_e32 %[vt0], %[pos], %[vlane]\n\t"
+      "v_add_u32_e32 %[vt0], m0, %[vlane]\n\t"
       IW_EXP_WAIT
       IW_EXP_COPY
       "v_cndmask_b32_e32 %[paddr], %[voob], %[vt0], vcc\n\t"
       "s_and_b32 s92, %[fpos], 63\n\t"
-      "s_sub_u32 s95, %[pos], %[fpos]\n\t"
+      "s_sub_u32 s95, m0, %[fpos]\n\t"
       "s_andn2_b32 s94, %[fpos], 63\n\t"
       "v_subrev_u32_e32 %[vt0], s92, %[vlane]\n\t"
+      "v_lshrrev_b32_e32 %[vn], 16, %[pend]\n\t"
       "v_cmp_gt_u32_e32 vcc, s95, %[vt0]\n\t"
       "v_or_b32_e32 %[vt1], s94, %[vlane]\n\t"
       "v_cndmask_b32_e32 %[vt1], %[voob], %[vt1], vcc\n\t"
-      "buffer_store_byte %[pend], %[vt1], %[rsrc], 0 offen\n\t"
+      "buffer_store_byte %[vn], %[vt1], %[rsrc], 0 offen\n\t"
       "s_cmp_gt_u32 %[L], 64\n\t"
       "s_cbranch_scc1 L_iw_more_%=\n\t"
-      "s_add_u32 %[pos], %[pos], %[L]\n\t"
-      "s_mov_b32 %[fpos], %[pos]\n\t"
+      "s_add_u32 m0, m0, %[L]\n\t"
+      "s_mov_b32 %[fpos], m0\n\t"
       "s_branch L_iw_loop_%=\n"
       "L_iw_flushfirst_%=:\n\t"
       "s_and_b32 s92, %[fpos], 63\n\t"
-      "s_sub_u32 s95, %[pos], %[fpos]\n\t"
+      "s_sub_u32 s95, m0, %[fpos]\n\t"
       "s_andn2_b32 s94, %[fpos], 63\n\t"
       "v_subrev_u32_e32 %[vt0], s92, %[vlane]\n\t"
+      "v_lshrrev_b32_e32 %[vn], 16, %[pend]\n\t"
       "v_cmp_gt_u32_e32 vcc, s95, %[vt0]\n\t"
       "v_or_b32_e32 %[vt1], s94, %[vlane]\n\t"
       "v_cndmask_b32_e32 %[vt1], %[voob], %[vt1], vcc\n\t"
-      "buffer_store_byte %[pend], %[vt1], %[rsrc], 0 offen\n"
+      "buffer_store_byte %[vn], %[vt1], %[rsrc], 0 offen\n"
       // the first 64 bytes: store what the previous match loaded, load this match's bytes (a lane beyond L loads a byte nobody
       // uses -- the descriptor bounds it -- and its store address is out of range)
       "L_iw_copy_%=:\n\t"
       "v_cmp_gt_u32_e32 vcc, %[L], %[vlane]\n\t"
       "v_add_u32_e32 %[vt1], %[vsrc], %[vlane]\n\t"
-      "v_add_u32_e32 %[vt0], %[pos], %[vlane]\n\t"
+      "v_add_u32_e32 %[vt0], m0, %[vlane]\n\t"
       IW_EXP_WAIT
       IW_EXP_COPY
       "v_cndmask_b32_e32 %[paddr], %[voob], %[vt0], vcc\n\t"
       "s_cmp_gt_u32 %[L], 64\n\t"
       "s_cbranch_scc1 L_iw_more_%=\n"
       "L_iw_copied_%=:\n\t"
-      "s_add_u32 %[pos], %[pos], %[L]\n\t"
-      "s_mov_b32 %[fpos], %[pos]\n\t"
+      "s_add_u32 m0, m0, %[L]\n\t"
+      "s_mov_b32 %[fpos], m0\n\t"
       "s_branch L_iw_loop_%=\n"
       // ---- rarer paths
       "L_iw_more_%=:\n\t"
@@ -623,7 +656,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "v_add_u32_e32 %[vt0], s94, %[vlane]\n\t"
       "v_cmp_gt_u32_e32 vcc, %[L], %[vt0]\n\t"
       "v_add_u32_e32 %[vt1], %[vsrc], %[vt0]\n\t"
-      "v_add_u32_e32 %[vt0], %[pos], %[vt0]\n\t"
+      "v_add_u32_e32 %[vt0], m0, %[vt0]\n\t"
       IW_EXP_WAIT
       IW_EXP_COPY
       "v_cndmask_b32_e32 %[paddr], %[voob], %[vt0], vcc\n\t"
@@ -632,12 +665,13 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "s_cbranch_scc1 L_iw_round_%=\n\t"
       "s_branch L_iw_copied_%=\n"
       "L_iw_refill2_%=:\n\t"
+      "s_flbit_i32_b32 s94, s90\n\t"
       "v_readlane_b32 s92, %[cur], %[wi]\n\t"
-      "v_readfirstlane_b32 s94, %[vnb]\n\t"
-      "s_mov_b32 s93, 0\n\t"
-      "s_add_u32 %[wi], %[wi], 1\n\t"
-      "v_add_u32_e32 %[vnb], 32, %[vnb]\n\t"
+      "s_sub_u32 s94, 31, s94\n\t"
+      "s_mov_b32 s93, 1\n\t"
+      "s_bitset0_b32 s90, s94\n\t"
       "s_lshl_b64 s[92:93], s[92:93], s94\n\t"
+      "s_add_u32 %[wi], %[wi], 1\n\t"
       "s_or_b64 s[90:91], s[90:91], s[92:93]\n\t"
       "s_cmp_eq_u32 %[wi], 64\n\t"
       "s_cbranch_scc0 L_iw_have2_%=\n\t"
@@ -651,19 +685,23 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "s_branch L_iw_end_%=\n"
       "L_iw_other_%=:\n\t"
       "s_mov_b32 %[code], 0\n"
-      // the caller may read or write the output itself: nothing stays pending; the vector-held state goes back to scalar registers
+      // the caller may read or write the output itself: nothing stays pending; position, bit count (the sentinel's place) and the
+      // vector-held distance go back to their registers, the sentinel is taken out
       "L_iw_end_%=:\n\t"
       "s_waitcnt vmcnt(0)\n\t"
       "buffer_store_byte %[pdata], %[paddr], %[rsrc], 0 offen\n\t"
       "v_mov_b32_e32 %[paddr], %[voob]\n\t"
-      "v_readfirstlane_b32 %[nb], %[vnb]\n\t"
+      "s_flbit_i32_b64 s92, s[90:91]\n\t"
+      "s_mov_b32 %[pos], m0\n\t"
+      "s_sub_u32 %[nb], 63, s92\n\t"
       "v_readfirstlane_b32 %[D], %[vD]\n\t"
+      "s_bitset0_b64 s[90:91], %[nb]\n\t"
       : "+{s[90:91]}"(br.bb), [nb] "+s"(br.nbits), [wi] "+s"(br.widx), [pos] "+s"(o.pos), [fpos] "+s"(o.fpos), [pend] "+v"(o.pend.x),
         [pdata] "+v"(o.pdata.x), [paddr] "+v"(o.paddr.x), [e] "=&s"(e), [code] "=&s"(code), [L] "+s"(L), [D] "+s"(D),
-        [vnb] "=&v"(vnb), [ve] "=&v"(ve), [vn] "=&v"(vn), [vt0] "=&v"(vt0), [vt1] "=&v"(vt1), [vD] "=&v"(vD), [vsrc] "=&v"(vsrc)
+        [ve] "=&v"(ve), [vn] "=&v"(vn), [vt0] "=&v"(vt0), [vt1] "=&v"(vt1), [vD] "=&v"(vD), [vsrc] "=&v"(vsrc)
       : [cur] "v"(br.cur.x), [vlit] "v"(vlit), [vdist] "v"(vdist), [vlane] "v"(vlane), [voob] "v"(IW_OOB), [isize] "s"(o.isize), [rsrc] "s"(o.out.r),
         [litmask] "i"((1 << IW_LIT_ROOT) - 1)
-      : "s92", "s93", "s94", "s95", "vcc", "scc", "memory");
+      : "s92", "s93", "s94", "s95", "vcc", "scc", "memory");   // (m0: written too; a reserved register cannot be listed -- the compiler has no use of it in this kernel, tools/check_m0.sh)
 }
 #endif
 
@@ -787,7 +825,7 @@ IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t
           br.bits(e & 15u);
           const uint32_t kind = e & (3u << 8);
           if (kind == 0u) {                                     // a literal with a code longer than the first-level table
-            iw_writelane(o.pend, o.pos & 63u, iw_val(e) & 255u);
+            iw_writelane(o.pend, o.pos & 63u, e);
             ++o.pos;
             if ((o.pos & 63u) == 0u) o.flush();
             continue;

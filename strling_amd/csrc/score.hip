@@ -905,7 +905,7 @@ void strl_ctx_destroy(strl_ctx *c) {
   if (c->comm) { strl::comm_destroy(c->comm); c->comm = nullptr; }
   if (c->x_soft_seen_ev) (void)hipEventDestroy(c->x_soft_seen_ev);
   if (c->x_soft_seen) (void)hipHostFree(c->x_soft_seen);
-  if (c->front) { if (c->front->st_c) (void)hipStreamSynchronize(c->front->st_c); if (c->front->st_i) (void)hipStreamSynchronize(c->front->st_i); if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a); strl::front_destroy(c->front); c->front = nullptr; }
+  if (c->front) { if (c->front->st_c) (void)hipStreamSynchronize(c->front->st_c); for (hipStream_t q : c->front->st_i) if (q) (void)hipStreamSynchronize(q); if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a); strl::front_destroy(c->front); c->front = nullptr; }
   strl::DevBuf *bufs[] = {&c->lut, &c->thr, &c->g_tid, &c->g_bins, &c->g_start, &c->g_pmax, &c->queue, &c->soft_queue, &c->counters,
                           &c->soft_tmp, &c->sb_whole, &c->sb_soft, &c->queue_r, &c->soft_dense, &c->sb_state_w, &c->sb_state_s, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
                           &c->st_mapq, &c->st_cig, &c->st_seq4, &c->st_whole, &c->st_soft, &c->st_text, &c->st_meta,
@@ -1729,7 +1729,7 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
   int rc = strl_extract_begin(c, n_reads_hint);
   if (rc) return rc;
   if (c->front) {
-    if (c->front->st_i) (void)hipStreamSynchronize(c->front->st_i);
+    for (hipStream_t q : c->front->st_i) if (q) (void)hipStreamSynchronize(q);
     if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a);
     strl::front_destroy(c->front); c->front = nullptr;
   }
@@ -1740,7 +1740,7 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
   {
     int least = 0, greatest = 0;          // (numerically: least >= greatest; equal where the device has one level)
     STRL_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    STRL_HIP(hipStreamCreateWithPriority(&F->st_i, hipStreamNonBlocking, least));
+    for (hipStream_t &q : F->st_i) STRL_HIP(hipStreamCreateWithPriority(&q, hipStreamNonBlocking, least));
     STRL_HIP(hipStreamCreateWithPriority(&F->st_a, hipStreamNonBlocking, greatest));
   }
   STRL_HIP(hipStreamCreateWithFlags(&F->st_c, hipStreamNonBlocking));
@@ -1749,7 +1749,6 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
     STRL_HIP(hipEventCreateWithFlags(&S.ev_b, hipEventDisableTiming));
     STRL_HIP(hipEventCreateWithFlags(&S.ev_h2d, hipEventDisableTiming));
     STRL_HIP(hipEventCreateWithFlags(&S.ev_i, hipEventDisableTiming));
-    STRL_HIP(hipEventCreateWithFlags(&S.ev_cd, hipEventDisableTiming));
     STRL_HIP(hipEventCreateWithFlags(&S.ev_carry, hipEventDisableTiming));
     STRL_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_info), 3 * sizeof(strl::FrontInfo), hipHostMallocDefault));
   }
@@ -1866,13 +1865,18 @@ int strl_front_finish(strl_ctx *c, strl_front_chunk done[2], int *n_done) {
   static const bool timing = getenv("STRL_FRONT_TIMING") != nullptr;
   if (timing && F->tev.size() >= 5) {       // per chunk: [0] start [1] copies queued [2] inflate done [3] ... scan done
     STRL_HIP(hipStreamSynchronize(F->st_a));
-    double h2d = 0, inf = 0, scan = 0;
-    for (size_t i = 0; i + 4 < F->tev.size() + 1 && i + 3 < F->tev.size(); i += 4) {
-      float a = 0, b = 0, d = 0;
+    for (hipStream_t q : F->st_i) STRL_HIP(hipStreamSynchronize(q));
+    // inflate: the time at least one chunk's inflate was running (consecutive chunks' launches overlap); the other two: sums
+    double h2d = 0, inf = 0, scan = 0, open_until = 0;
+    for (size_t i = 0; i + 3 < F->tev.size(); i += 4) {
+      float a = 0, b0 = 0, b1 = 0, d = 0;
       (void)hipEventElapsedTime(&a, F->tev[i], F->tev[i + 1]);
-      (void)hipEventElapsedTime(&b, F->tev[i + 1], F->tev[i + 2]);
+      (void)hipEventElapsedTime(&b0, F->tev[1], F->tev[i + 1]);
+      (void)hipEventElapsedTime(&b1, F->tev[1], F->tev[i + 2]);
       (void)hipEventElapsedTime(&d, F->tev[i + 2], F->tev[i + 3]);
-      h2d += a; inf += b; scan += d;
+      h2d += a; scan += d;
+      const double lo = std::max<double>(b0, open_until);
+      if (b1 > lo) { inf += b1 - lo; open_until = b1; }
     }
     fprintf(stderr, "[strling] device front end, ms over %llu chunks: copies to the device %.1f  inflate %.1f  record scan %.1f  (%.1f MB compressed -> %.1f MB inflated)\n",
             (unsigned long long)F->chunks, h2d, inf, scan, (double)F->comp_total / 1e6, (double)F->infl_total / 1e6);
