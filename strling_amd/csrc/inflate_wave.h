@@ -117,9 +117,11 @@ constexpr uint32_t IW_OOB = 0x80000000u;   // an offset no descriptor of this fi
 constexpr int IW_LIT_ROOT = IW_LIT_ROOT_BITS, IW_DIST_ROOT = 8, IW_CL_ROOT = 7;
 
 // Table entry (u32): [3:0] code length (0 = "not in the first-level table": canonical search / invalid), [7:4] extra bits,
-// [9:8] kind (0 literal / plain value, 1 base value of a length or distance code, 2 end of block, 3 a symbol that is part of the
-// code but never valid), [30:16] value (<= 24577), [31] literal: the sign bit is what the symbol loop tests.
-constexpr uint32_t IW_KIND_BASE = 1u << 8, IW_KIND_EOB = 2u << 8, IW_KIND_BAD = 3u << 8;
+// [9:8] kind (0 literal / plain value, 1 base value of a length or distance code, 2 end of block), [14:10] code length + extra
+// bits, [15] a symbol that is part of the code but never valid, [30:16] value (<= 24577), [31] literal: the sign bit is what
+// the symbol loop tests.
+constexpr uint32_t IW_KIND_BASE = 1u << 8, IW_KIND_EOB = 2u << 8, IW_KIND_BAD = 1u << 15;   // (BAD: kind bits 0 -- tested before them)
+IW_DEV uint32_t iw_with_total(uint32_t e, uint32_t l) { return e | l | ((l + ((e >> 4) & 15u)) << 10); }   // code length + the bits the symbol consumes in all
 constexpr uint32_t IW_FAST_LIT = 1u << 31;   // set in literal entries
 IW_DEV uint32_t iw_val(uint32_t e) { return (e >> 16) & 0x7fffu; }
 
@@ -241,7 +243,7 @@ IW_DEV uint32_t iw_build(const IwLane<uint32_t> (&len)[ROUNDS], uint32_t *tab, u
 #pragma unroll
       for (int k = ROOT; k >= 1; --k) l = v16 < lim[k] ? (uint32_t)k : l;
       const uint32_t at = l ? (v16 >> (16u - l)) + delta[l] : dummy;
-      const uint32_t e = iw_entry_of<KIND>(sorted[at < dummy ? at : dummy]) | l;
+      const uint32_t e = iw_with_total(iw_entry_of<KIND>(sorted[at < dummy ? at : dummy]), l);
       tab[i] = l ? e : 0u;
     }
   }
@@ -256,7 +258,7 @@ template <int KIND> IW_DEV uint32_t iw_slow(uint64_t bb, const uint32_t *limit, 
     const uint32_t lim = IW_U(limit[l]);
     if (v16 < lim) {
       const uint32_t at = (v16 >> (16 - l)) + IW_U(delta[l]);
-      return iw_entry_of<KIND>(IW_U(sorted[at < dummy ? at : dummy])) | (uint32_t)l;
+      return iw_with_total(iw_entry_of<KIND>(IW_U(sorted[at < dummy ? at : dummy])), (uint32_t)l);
     }
   }
   return 0u;
@@ -315,18 +317,21 @@ struct IwBits {
 // Output of one stream: literals wait in a lane register (lane = position mod 64) for one coalesced store.
 struct IwOut {
   IwBuf out;                      // the block's output [0, isize), bounds-checked
-  uint32_t isize, pos, fpos;      // next output position; first position still waiting in `pend`
+  uint32_t isize, pos;            // next output position
+  // Literals wait in `pend` as their table entries (bit 31 set, the byte in bits 23:16), lane = position mod 64, until the
+  // position leaves their 64-byte window (or a match reads from it): every staged literal lies in [(pos - 1) & ~63, pos).
   IwLane<uint32_t> pend;
   IwLane<uint32_t> pdata, paddr;  // (device, iw_run) bytes a match has loaded and where they go; IW_OOB: nothing pending
   IW_DEV void flush() {
-    if (fpos < pos) {
-      const uint32_t lo = fpos & 63u, n = pos - fpos, w = fpos & ~63u;
-      IW_FOR_LANES { iw_st8(out, (uint32_t)lane - lo < n ? w + (uint32_t)lane : IW_OOB, pend[lane] >> 16); }   // a literal waits as its table entry: the byte is bits 23:16
-      fpos = pos;
+    const uint32_t w = (pos - 1u) & ~63u;
+    IW_FOR_LANES {
+      const uint32_t v = pend[lane];
+      iw_st8(out, (v >> 31) ? w + (uint32_t)lane : IW_OOB, v >> 16);
+      pend[lane] = 0;
     }
   }
   IW_DEV void literal(uint32_t b) {   // caller checked pos < isize
-    iw_writelane(pend, pos & 63u, b << 16);
+    iw_writelane(pend, pos & 63u, (b << 16) | IW_FAST_LIT);
     ++pos;
     if ((pos & 63u) == 0u) flush();
   }
@@ -358,7 +363,6 @@ struct IwOut {
       }
     }
     pos += L;
-    fpos = pos;
   }
   // `n` bytes from the compressed stream itself (a stored block), starting `p` bytes behind the reader's origin
   IW_DEV void raw(const IwBuf &in, uint32_t p, uint32_t n) {
@@ -371,7 +375,6 @@ struct IwOut {
       }
     }
     pos += n;
-    fpos = pos;
   }
 };
 
@@ -384,27 +387,35 @@ struct IwOut {
 //   code 6: as 4, and the input window is used up
 //   code 7: the output position passed ISIZE
 // On the device this is hand-written ISA.  hipcc keeps the wave-uniform decoder state in scalar registers and turns the loop
-// into a state machine of 64-bit flag registers: 55 scalar instructions per literal, ~150 per match (36 GB/s).  Three hand-written
-// forms were measured on the same blocks (profiles/r04/inflate_symbols.txt, inflate_hybrid.txt, inflate_pmc_valu.txt):
-//   round 3, everything on the scalar unit   16 scalar + 3 vector per literal, 45 + 9 per match        81 / 59 GB/s
-//   everything on the vector unit             3 + 10,  6 + 38 (uniform values in VGPRs, branches on VCC)  88 / 64 GB/s
-//   split between the two (this one)          7 + 8,  22 + 25                                           88 / 64 GB/s
-// i.e. the unit does not matter (the round-3 reading "the scalar unit bounds the kernel" was wrong): a literal takes a wave
-// ~300 cycles and a match ~950 with six waves per SIMD whatever the mix, ~15 cycles per instruction of the wave's own
-// in-order stream -- the dependent chain index -> LDS lookup -> fields -> shift -> next index, one issue turn per instruction,
-// with 61 % of the wave-cycles parked on s_waitcnt.  Removing the copy's waits altogether gives 100 GB/s, the copy itself
-// 97 (inflate_exp_waits.txt); header parse + table build are 3.6 % (inflate_exp_header_only.txt).  Throughput follows the
-// waves per CU almost linearly up to 28 and is flat beyond (inflate_occupancy.txt: 4 / 8 / 16 / 24 / 28 / 32 waves: 22 / 40 / 70 /
-// 87 / 95 / 95 GB/s), so what did pay is a 9-bit first level: 4.4 KB of LDS per wave instead of 6.4, 28 waves instead of 24
-// (+9 %).  The split form is kept: fewest registers, no M0.
-//   scalar: the 64-bit bit buffer and its shifts, the table index, the length code's fields, the output position;
-//   vector: the bit count, the table address + lookup, the literal's placement, the distance code's fields, the checks against
-//           the vector-held distance, the copy;
+// into a state machine of 64-bit flag registers: 55 scalar instructions per literal, ~150 per match (36 GB/s).
+// What bounds the hand-written forms (level-1 blocks with constant qualities / level-6 blocks with binned random qualities):
+//   * The data is match-dominated (tools/ubench/deflate_stats.py: per output byte 0.16 literals and 0.11 matches of mean
+//     length 7.4 in the level-6 blocks; 0.10 and 0.085 of mean length 10.6 in the level-1 blocks), and a CU issues one
+//     scalar-port instruction (scalar ALU, branch, s_waitcnt) and one wave64 vector instruction a cycle, whatever the waves.
+//     The counters of each form (profiles/r04/inflate_pmc_*.txt) give the port's load = instructions / (CUs x kernel cycles):
+//       round 3, all scalar              16 scalar + 3 vector per literal, 45 + 9 per match               81 / 59 GB/s
+//       all vector                        3 + 10, 6 + 38                                                   88 / 64
+//       split (bit buffer, length fields, output position scalar; the rest vector)   scalar 70 %, vector 66 %   88 / 64 -> 107 / 80 with
+//                                         9-bit tables, the copy ahead of the literal store, the distance lookup issued early
+//       literals by v_writelane, sentinel bit buffer, three literals per refill check: vector -30 %, scalar +5 %: 75 % / 47 %   108 / 81
+//       literals staged across matches (no store per match): the same counts on the scalar side                 109 / 81
+//       this form: length and distance put together on the vector unit, one branch for a match's checks: 63 % / 68 %   117 / 87
+//     Neither port gets past ~70 %: a wave is parked on s_waitcnt for half its cycles (LDS lookups, the copy's loads) and each
+//     SIMD holds seven of them.  Every step that took instructions off the busier port paid; taking them off the other did not
+//     (-30 % vector instructions: +1 %), and more waves do not either (6 / 7 / 8 per SIMD: the same; profiles/r04/inflate_vmatch_waves.txt).
+//   * Earlier readings, kept for the record: throughput follows the waves per CU up to 24 (inflate_occupancy.txt); a 9-bit first
+//     level (4.4 KB of LDS per wave) beat 10 bits by 9 %; removing the copy's waits altogether gives +13 %, header parse + table
+//     build are 3.6 % (inflate_exp_waits.txt, inflate_exp_header_only.txt).
+//   scalar: the 64-bit bit buffer (a sentinel bit above its valid bits: "fewer than 32" is "high word zero"; no bit count), its
+//           shifts by the entry's own fields, the table index, the output position (in m0: v_writelane's lane select);
+//   vector: the table address + lookup, the literal's placement (v_writelane of the entry), length and distance from their
+//           entries' fields (every lane the same value), the checks of a match folded into one sign test, the copy;
 // values cross where an operand may sit in either file (a vector instruction reads one scalar register for free) and through
-// v_readfirstlane otherwise (the table entry, the bits the distance code used).
+// v_readfirstlane otherwise (the table entry, the bits the distance code used, the position behind the match).
 // The copy of a match is software-pipelined: its bytes are LOADED when the match is decoded and STORED when the next match (or an
 // exit) comes around -- the load latency passes while the next symbols are decoded; every store is issued before any later
-// load, so a later match that reads these bytes sees them.  bb lives in s[90:91]; s92..s95, vcc are scratch (no M0).
+// load, so a later match that reads these bytes sees them.  bb lives in s[90:91]; s92..s95, vcc are scratch; m0 is saved and
+// restored around the loop.
 #ifdef STRL_EMU
 IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t *dist_tab, uint32_t &e, uint32_t &code, uint32_t &L, uint32_t &D) {
   for (;;) {
@@ -456,7 +467,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
 #define IW_EXP_COPY "buffer_store_byte %[pdata], %[paddr], %[rsrc], 0 offen\n\t" "buffer_load_ubyte %[pdata], %[vt1], %[rsrc], 0 offen\n\t"
 #endif
 IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t *dist_tab, uint32_t &e, uint32_t &code, uint32_t &L, uint32_t &D) {
-  uint32_t ve, vn, vt0, vt1, vD, vsrc;
+  uint32_t ve, vn, vt0, vt1, vt2, vD, vL, vsrc, m0save;
   const uint32_t vlit = (uint32_t)reinterpret_cast<uintptr_t>(lit_tab);     // LDS byte addresses (low half of the flat address)
   const uint32_t vdist = (uint32_t)reinterpret_cast<uintptr_t>(dist_tab);
   const uint32_t vlane = threadIdx.x;
@@ -465,9 +476,11 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "s_mov_b32 s94, 1\n\t"
       "s_mov_b32 s95, 0\n\t"
       "s_lshl_b64 s[94:95], s[94:95], %[nb]\n\t"
+      "s_mov_b32 %[m0save], m0\n\t"
       "s_mov_b32 m0, %[pos]\n\t"
       "s_or_b64 s[90:91], s[90:91], s[94:95]\n\t"
       "v_mov_b32_e32 %[vD], %[D]\n\t"
+      "v_mov_b32_e32 %[vL], %[L]\n\t"
       "v_mov_b32_e32 %[ve], 0\n\t"
       "s_mov_b32 %[e], 0\n"
       // ---- next symbol: first-level literal/length lookup (the refill sits out of line).  >= 32 valid bits here; a first-level
@@ -519,18 +532,15 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "s_add_u32 m0, m0, 1\n\t"
       "s_and_b32 s92, m0, 63\n\t"
       "s_cbranch_scc1 L_iw_loop_%=\n"
-      // 64 positions full: one coalesced store of the staged bytes [fpos, pos)
+      // the position has left a 64-byte window: one store of the literals staged in it (the lanes whose entry has bit 31)
       "L_iw_full_%=:\n\t"
-      "s_and_b32 s92, %[fpos], 63\n\t"
-      "s_sub_u32 s95, m0, %[fpos]\n\t"
-      "s_andn2_b32 s94, %[fpos], 63\n\t"
-      "v_subrev_u32_e32 %[vt0], s92, %[vlane]\n\t"
-      "v_lshrrev_b32_e32 %[vn], 16, %[pend]\n\t"
-      "v_cmp_gt_u32_e32 vcc, s95, %[vt0]\n\t"
+      "s_sub_u32 s94, m0, 64\n\t"
+      "v_cmp_gt_i32_e32 vcc, 0, %[pend]\n\t"
       "v_or_b32_e32 %[vt1], s94, %[vlane]\n\t"
+      "v_lshrrev_b32_e32 %[vn], 16, %[pend]\n\t"
       "v_cndmask_b32_e32 %[vt1], %[voob], %[vt1], vcc\n\t"
       "buffer_store_byte %[vn], %[vt1], %[rsrc], 0 offen\n\t"
-      "s_mov_b32 %[fpos], m0\n\t"
+      "v_mov_b32_e32 %[pend], 0\n\t"
       "s_cmp_gt_u32 m0, %[isize]\n\t"
       "s_cbranch_scc0 L_iw_loop_%=\n\t"
       "s_mov_b32 %[code], 7\n\t"
@@ -549,121 +559,106 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "s_cbranch_scc0 L_iw_have_%=\n\t"
       "s_mov_b32 %[code], 1\n\t"
       "s_branch L_iw_end_%=\n"
-      // ---- not a literal: a length code of the first-level table (its fields on the scalar unit), or something for the caller
+      // ---- not a literal: a length code of the first-level table, or something for the caller.  What bounds this kernel is the
+      // scalar issue port (scalar ALU + branches + waits: one a cycle per CU, 75 % busy -- profiles/r04/inflate_pmc_window.txt): the
+      // length and the distance are put together on the vector unit (every lane the same value), the scalar unit only shifts the bit
+      // buffer by the entry's "all bits" field and forms the distance table's index; the checks of a match share one branch.
       "L_iw_notlit_%=:\n\t"
-      "s_and_b32 s93, %[e], 0x300\n\t"
-      "s_cmp_eq_u32 s93, 0x100\n\t"
+      "s_bitcmp1_b32 %[e], 8\n\t"
       "s_cbranch_scc0 L_iw_other_%=\n\t"
-      // the distance code starts len + extra bits further on, both known from the entry: its lookup is issued at once and
-      // is in flight while the length is put together
-      "s_and_b32 s92, %[e], 15\n\t"
-      "s_bfe_u32 s93, %[e], 0x40004\n\t"
-      "s_add_u32 s95, s92, s93\n\t"
-      "s_lshr_b32 s94, s90, s95\n\t"
-      "s_and_b32 s94, s94, 0xff\n\t"
+      "v_and_b32_e32 %[vt1], 15, %[ve]\n\t"
+      "s_bfe_u32 s95, %[e], 0x5000a\n\t"
+      "v_bfe_u32 %[vt0], %[ve], 4, 4\n\t"
+      "v_lshrrev_b32_e64 %[vL], %[vt1], s90\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], s95\n\t"
+      "v_lshrrev_b32_e32 %[vt1], 16, %[ve]\n\t"
+      "s_and_b32 s94, s90, 0xff\n\t"
+      "v_bfe_u32 %[vL], %[vL], 0, %[vt0]\n\t"
       "v_lshl_add_u32 %[vt0], s94, 2, %[vdist]\n\t"
       "ds_read_b32 %[ve], %[vt0]\n\t"
-      "s_lshr_b32 s94, s90, s92\n\t"
-      "s_bfm_b32 s92, s93, 0\n\t"
-      "s_bfe_u32 %[L], %[e], 0xf0010\n\t"
-      "s_and_b32 s94, s94, s92\n\t"
-      "s_add_u32 %[L], %[L], s94\n\t"
-      "s_lshr_b64 s[90:91], s[90:91], s95\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_add_u32_e32 %[vL], %[vL], %[vt1]\n\t"
       "s_cmp_eq_u32 s91, 0\n\t"
       "s_cbranch_scc1 L_iw_refill2_%=\n"
-      // (32 more bits, if they were needed, have come in on top: the entry read above stands) the distance code's fields
+      // (32 more bits, if they were needed, have come in on top: the entry being read stands) the distance code's fields
       "L_iw_have2_%=:\n\t"
-      "s_add_u32 s93, m0, %[L]\n\t"
+      "v_add_u32_e32 %[vt2], m0, %[vL]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
       "v_and_b32_e32 %[vn], 15, %[ve]\n\t"
       "v_bfe_u32 %[vt1], %[ve], 4, 4\n\t"
-      "v_cmp_ne_u32_e32 vcc, 0, %[vn]\n\t"
       "v_lshrrev_b32_e64 %[vt0], %[vn], s90\n\t"
-      "s_cbranch_vccz L_iw_distslow_%=\n\t"
       "v_lshrrev_b32_e32 %[vD], 16, %[ve]\n\t"
       "v_bfe_u32 %[vt0], %[vt0], 0, %[vt1]\n\t"
-      "v_add_u32_e32 %[vn], %[vn], %[vt1]\n\t"
+      "v_bfe_u32 %[vt1], %[ve], 10, 5\n\t"
       "v_add_u32_e32 %[vD], %[vD], %[vt0]\n\t"
-      "v_readfirstlane_b32 s92, %[vn]\n\t"
-      // the fast copy takes D >= L, D <= pos, pos + L <= isize (L >= 3 by the table)
-      "v_cmp_gt_u32_e32 vcc, %[L], %[vD]\n\t"
-      "s_lshr_b64 s[90:91], s[90:91], s92\n\t"
-      "s_cbranch_vccnz L_iw_match5_%=\n\t"
-      "v_cmp_lt_u32_e32 vcc, m0, %[vD]\n\t"
-      "s_cmp_gt_u32 s93, %[isize]\n\t"
-      "s_cbranch_vccnz L_iw_match5_%=\n\t"
-      "s_cbranch_scc1 L_iw_match5_%=\n\t"
+      "v_readfirstlane_b32 s92, %[vt1]\n\t"
+      "v_readfirstlane_b32 s93, %[vt2]\n\t"
+      // the fast copy takes a first-level distance code (the entry of any other is 0: D = 0 < L), D >= L, D <= pos,
+      // pos + L <= isize (L >= 3 by the table): each difference wraps to a value with the sign bit when its condition fails
       "v_sub_u32_e32 %[vsrc], m0, %[vD]\n\t"
-      // Staged literals [fpos, pos): their store must be issued before a load that reads them -- a match whose source reaches
-      // into them (pos - D + L > fpos: rare, distances are hundreds of bytes) flushes first.  Otherwise the copy goes first and
-      // the flush behind it: the copy's wait then covers loads and stores of the PREVIOUS match only, not a store issued a
-      // moment ago (removing the copy's waits altogether measured +13 %, profiles/r04/inflate_exp_waits.txt).
-      "s_cmp_lt_u32 %[fpos], m0\n\t"
-      "s_cbranch_scc0 L_iw_copy_%=\n\t"
-      "v_add_u32_e32 %[vt0], %[L], %[vsrc]\n\t"
-      "v_cmp_lt_u32_e32 vcc, %[fpos], %[vt0]\n\t"
-      "s_cbranch_vccnz L_iw_flushfirst_%=\n\t"
-      // the first 64 bytes of the copy, then the staged literals
-      "v_cmp_gt_u32_e32 vcc, %[L], %[vlane]\n\t"
-      "v_add_u32_e32 %[vt1], %[vsrc], %[vlane]\n\t"
-      "v_add_u32_e32 %[vt0], m0, %[vlane]\n\t"
-      IW_EXP_WAIT
-      IW_EXP_COPY
-      "v_cndmask_b32_e32 %[paddr], %[voob], %[vt0], vcc\n\t"
-      "s_and_b32 s92, %[fpos], 63\n\t"
-      "s_sub_u32 s95, m0, %[fpos]\n\t"
-      "s_andn2_b32 s94, %[fpos], 63\n\t"
-      "v_subrev_u32_e32 %[vt0], s92, %[vlane]\n\t"
-      "v_lshrrev_b32_e32 %[vn], 16, %[pend]\n\t"
-      "v_cmp_gt_u32_e32 vcc, s95, %[vt0]\n\t"
-      "v_or_b32_e32 %[vt1], s94, %[vlane]\n\t"
-      "v_cndmask_b32_e32 %[vt1], %[voob], %[vt1], vcc\n\t"
-      "buffer_store_byte %[vn], %[vt1], %[rsrc], 0 offen\n\t"
-      "s_cmp_gt_u32 %[L], 64\n\t"
-      "s_cbranch_scc1 L_iw_more_%=\n\t"
-      "s_add_u32 m0, m0, %[L]\n\t"
-      "s_mov_b32 %[fpos], m0\n\t"
-      "s_branch L_iw_loop_%=\n"
-      "L_iw_flushfirst_%=:\n\t"
-      "s_and_b32 s92, %[fpos], 63\n\t"
-      "s_sub_u32 s95, m0, %[fpos]\n\t"
-      "s_andn2_b32 s94, %[fpos], 63\n\t"
-      "v_subrev_u32_e32 %[vt0], s92, %[vlane]\n\t"
-      "v_lshrrev_b32_e32 %[vn], 16, %[pend]\n\t"
-      "v_cmp_gt_u32_e32 vcc, s95, %[vt0]\n\t"
-      "v_or_b32_e32 %[vt1], s94, %[vlane]\n\t"
-      "v_cndmask_b32_e32 %[vt1], %[voob], %[vt1], vcc\n\t"
-      "buffer_store_byte %[vn], %[vt1], %[rsrc], 0 offen\n"
+      "v_sub_u32_e32 %[vt0], %[vD], %[vL]\n\t"
+      "v_sub_u32_e32 %[vt2], %[isize], %[vt2]\n\t"
+      "v_or3_b32 %[vt0], %[vt0], %[vsrc], %[vt2]\n\t"
+      "s_andn2_b32 s94, m0, 63\n\t"
+      "v_add_u32_e32 %[vt1], %[vL], %[vsrc]\n\t"
+      "v_cmp_gt_i32_e32 vcc, 0, %[vt0]\n\t"
+      "s_cbranch_vccnz L_iw_hard_%=\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], s92\n\t"
+      // Staged literals lie in [W, pos), W = pos & ~63, and stay staged across matches: they are stored when the position leaves
+      // the window (flushing before every match was 3 scalar + 5 vector instructions and a store per match, in data with a match
+      // every 8.7 bytes).  A match whose source reaches into the window (pos - D + L > W) has them stored first.
+      "v_cmp_lt_u32_e32 vcc, s94, %[vt1]\n\t"
+      "s_cbranch_vccnz L_iw_flushfirst_%=\n"
       // the first 64 bytes: store what the previous match loaded, load this match's bytes (a lane beyond L loads a byte nobody
       // uses -- the descriptor bounds it -- and its store address is out of range)
       "L_iw_copy_%=:\n\t"
-      "v_cmp_gt_u32_e32 vcc, %[L], %[vlane]\n\t"
+      "v_cmp_gt_u32_e32 vcc, %[vL], %[vlane]\n\t"
       "v_add_u32_e32 %[vt1], %[vsrc], %[vlane]\n\t"
       "v_add_u32_e32 %[vt0], m0, %[vlane]\n\t"
       IW_EXP_WAIT
       IW_EXP_COPY
       "v_cndmask_b32_e32 %[paddr], %[voob], %[vt0], vcc\n\t"
-      "s_cmp_gt_u32 %[L], 64\n\t"
-      "s_cbranch_scc1 L_iw_more_%=\n"
-      "L_iw_copied_%=:\n\t"
-      "s_add_u32 m0, m0, %[L]\n\t"
-      "s_mov_b32 %[fpos], m0\n\t"
+      "s_xor_b32 s92, s93, m0\n\t"
+      "s_cmp_gt_u32 s92, 63\n\t"
+      "s_cbranch_scc1 L_iw_cross_%=\n\t"
+      "s_mov_b32 m0, s93\n\t"
       "s_branch L_iw_loop_%=\n"
-      // ---- rarer paths
-      "L_iw_more_%=:\n\t"
-      "s_mov_b32 s94, 64\n"
+      // the match ends in another window: more rounds of the copy if it is longer than 64 bytes, then the literals staged in
+      // this window are stored
+      "L_iw_cross_%=:\n\t"
+      "s_sub_u32 s95, s93, m0\n\t"
+      "s_mov_b32 s94, 64\n\t"
+      "s_cmp_gt_u32 s95, 64\n\t"
+      "s_cbranch_scc0 L_iw_copied_%=\n"
       "L_iw_round_%=:\n\t"
       "v_add_u32_e32 %[vt0], s94, %[vlane]\n\t"
-      "v_cmp_gt_u32_e32 vcc, %[L], %[vt0]\n\t"
+      "v_cmp_gt_u32_e32 vcc, s95, %[vt0]\n\t"
       "v_add_u32_e32 %[vt1], %[vsrc], %[vt0]\n\t"
       "v_add_u32_e32 %[vt0], m0, %[vt0]\n\t"
       IW_EXP_WAIT
       IW_EXP_COPY
       "v_cndmask_b32_e32 %[paddr], %[voob], %[vt0], vcc\n\t"
       "s_add_u32 s94, s94, 64\n\t"
-      "s_cmp_lt_u32 s94, %[L]\n\t"
-      "s_cbranch_scc1 L_iw_round_%=\n\t"
-      "s_branch L_iw_copied_%=\n"
+      "s_cmp_lt_u32 s94, s95\n\t"
+      "s_cbranch_scc1 L_iw_round_%=\n"
+      "L_iw_copied_%=:\n\t"
+      "s_andn2_b32 s94, m0, 63\n\t"
+      "v_cmp_gt_i32_e32 vcc, 0, %[pend]\n\t"
+      "v_or_b32_e32 %[vt1], s94, %[vlane]\n\t"
+      "v_lshrrev_b32_e32 %[vn], 16, %[pend]\n\t"
+      "v_cndmask_b32_e32 %[vt1], %[voob], %[vt1], vcc\n\t"
+      "buffer_store_byte %[vn], %[vt1], %[rsrc], 0 offen\n\t"
+      "v_mov_b32_e32 %[pend], 0\n\t"
+      "s_mov_b32 m0, s93\n\t"
+      "s_branch L_iw_loop_%=\n"
+      "L_iw_flushfirst_%=:\n\t"
+      "v_cmp_gt_i32_e32 vcc, 0, %[pend]\n\t"
+      "v_or_b32_e32 %[vt1], s94, %[vlane]\n\t"
+      "v_lshrrev_b32_e32 %[vn], 16, %[pend]\n\t"
+      "v_cndmask_b32_e32 %[vt1], %[voob], %[vt1], vcc\n\t"
+      "buffer_store_byte %[vn], %[vt1], %[rsrc], 0 offen\n\t"
+      "v_mov_b32_e32 %[pend], 0\n\t"
+      "s_branch L_iw_copy_%=\n"
+      // ---- rarer paths
       "L_iw_refill2_%=:\n\t"
       "s_flbit_i32_b32 s94, s90\n\t"
       "v_readlane_b32 s92, %[cur], %[wi]\n\t"
@@ -675,33 +670,38 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "s_or_b64 s[90:91], s[90:91], s[92:93]\n\t"
       "s_cmp_eq_u32 %[wi], 64\n\t"
       "s_cbranch_scc0 L_iw_have2_%=\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
       "s_mov_b32 %[code], 6\n\t"
       "s_branch L_iw_end_%=\n"
-      "L_iw_distslow_%=:\n\t"
+      // a check failed: a distance code outside the first-level table (nothing of it consumed), or a match for the caller
+      "L_iw_hard_%=:\n\t"
+      "v_cmp_eq_u32_e32 vcc, 0, %[vn]\n\t"
       "s_mov_b32 %[code], 4\n\t"
-      "s_branch L_iw_end_%=\n"
-      "L_iw_match5_%=:\n\t"
+      "s_cbranch_vccnz L_iw_end_%=\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], s92\n\t"
       "s_mov_b32 %[code], 5\n\t"
       "s_branch L_iw_end_%=\n"
       "L_iw_other_%=:\n\t"
       "s_mov_b32 %[code], 0\n"
       // the caller may read or write the output itself: nothing stays pending; position, bit count (the sentinel's place) and the
-      // vector-held distance go back to their registers, the sentinel is taken out
+      // vector-held length and distance go back to their registers, the sentinel is taken out
       "L_iw_end_%=:\n\t"
       "s_waitcnt vmcnt(0)\n\t"
       "buffer_store_byte %[pdata], %[paddr], %[rsrc], 0 offen\n\t"
       "v_mov_b32_e32 %[paddr], %[voob]\n\t"
       "s_flbit_i32_b64 s92, s[90:91]\n\t"
       "s_mov_b32 %[pos], m0\n\t"
+      "s_mov_b32 m0, %[m0save]\n\t"
       "s_sub_u32 %[nb], 63, s92\n\t"
       "v_readfirstlane_b32 %[D], %[vD]\n\t"
+      "v_readfirstlane_b32 %[L], %[vL]\n\t"
       "s_bitset0_b64 s[90:91], %[nb]\n\t"
-      : "+{s[90:91]}"(br.bb), [nb] "+s"(br.nbits), [wi] "+s"(br.widx), [pos] "+s"(o.pos), [fpos] "+s"(o.fpos), [pend] "+v"(o.pend.x),
-        [pdata] "+v"(o.pdata.x), [paddr] "+v"(o.paddr.x), [e] "=&s"(e), [code] "=&s"(code), [L] "+s"(L), [D] "+s"(D),
-        [ve] "=&v"(ve), [vn] "=&v"(vn), [vt0] "=&v"(vt0), [vt1] "=&v"(vt1), [vD] "=&v"(vD), [vsrc] "=&v"(vsrc)
+      : "+{s[90:91]}"(br.bb), [nb] "+s"(br.nbits), [wi] "+s"(br.widx), [pos] "+s"(o.pos), [pend] "+v"(o.pend.x),
+        [pdata] "+v"(o.pdata.x), [paddr] "+v"(o.paddr.x), [e] "=&s"(e), [code] "=&s"(code), [L] "+s"(L), [D] "+s"(D), [m0save] "=&s"(m0save),
+        [ve] "=&v"(ve), [vn] "=&v"(vn), [vt0] "=&v"(vt0), [vt1] "=&v"(vt1), [vt2] "=&v"(vt2), [vD] "=&v"(vD), [vL] "=&v"(vL), [vsrc] "=&v"(vsrc)
       : [cur] "v"(br.cur.x), [vlit] "v"(vlit), [vdist] "v"(vdist), [vlane] "v"(vlane), [voob] "v"(IW_OOB), [isize] "s"(o.isize), [rsrc] "s"(o.out.r),
         [litmask] "i"((1 << IW_LIT_ROOT) - 1)
-      : "s92", "s93", "s94", "s95", "vcc", "scc", "memory");   // (m0: written too; a reserved register cannot be listed -- the compiler has no use of it in this kernel, tools/check_m0.sh)
+      : "s92", "s93", "s94", "s95", "vcc", "scc", "memory");   // (m0: holds the output position inside; a reserved register cannot be listed as clobbered, so it is saved and restored)
 }
 #endif
 
@@ -715,7 +715,7 @@ IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t
   uint64_t origin = off & ~(uint64_t)3;   // where the reader's origin sits in comp
   IwOut o;
   o.out = iw_make_buf(out, isize);
-  o.isize = isize; o.pos = 0; o.fpos = 0;
+  o.isize = isize; o.pos = 0;
   IW_FOR_LANES { o.pend[lane] = 0; o.pdata[lane] = 0; o.paddr[lane] = IW_OOB; }
   for (;;) {
     br.refill();
@@ -822,6 +822,7 @@ IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t
             e = iw_slow<IW_LENS>(br.bb, S.ll_limit, S.ll_delta, S.ll_sorted, 288u, IW_LIT_ROOT);
             if (!e) { why = IW_ERR_DATA; break; }
           }
+          if (e & IW_KIND_BAD) { why = IW_ERR_DATA; break; }        // a length symbol that is never valid (286, 287)
           br.bits(e & 15u);
           const uint32_t kind = e & (3u << 8);
           if (kind == 0u) {                                     // a literal with a code longer than the first-level table
@@ -831,7 +832,7 @@ IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t
             continue;
           }
           if (kind == IW_KIND_EOB) break;
-          if (kind != IW_KIND_BASE) { why = IW_ERR_DATA; break; }   // a length symbol that is never valid (286, 287)
+          if (kind != IW_KIND_BASE) { why = IW_ERR_DATA; break; }
           L = iw_val(e) + br.bits((e >> 4) & 15u);
           br.refill();
           code = 4u;
