@@ -587,13 +587,15 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double>(y - x).count(); };
   static const char *env_blocks = getenv("STRL_CHUNK_BLOCKS");     // tests: tiny chunks put records across chunk borders
-  // Chunk = one inflate launch: 8192 blocks (~0.5 GB inflated) keep a 1 GB file's pipeline fine-grained (ten chunks; fill, drain
-  // and the page-locked buffers all grow with the chunk); a whole-genome BAM takes 24576 (fewer, fuller launches: measured
-  // 72 -> 60 ms of inflate per 4.6 GB)
+  // Chunk = one inflate launch: 8192 blocks (~0.5 GB inflated) keep a 1 GB file's pipeline fine-grained (fill, drain and the
+  // page-locked buffers all grow with the chunk); a whole-genome BAM takes 16384.  Consecutive chunks' inflates overlap (two
+  // streams), so a launch's tail costs nothing and larger chunks no longer inflate faster (6.7e7-read file, loop seconds at
+  // 8192 / 16384 / 24576 / 32768 blocks: 0.40 / 0.36 / 0.37 / 0.37) -- but three page-locked buffers of 24576 blocks took
+  // 0.39 - 0.44 s to allocate, longer than the device context beside them (0.30 s at 16384; profiles/r04/extract_chunk_sweep.txt)
   size_t auto_blocks = 8192;
   {
     struct stat st;
-    if (stat(bam.c_str(), &st) == 0) auto_blocks = std::min<size_t>(24576, std::max<size_t>(8192, (size_t)st.st_size / 16384 / 12));
+    if (stat(bam.c_str(), &st) == 0) auto_blocks = std::min<size_t>(16384, std::max<size_t>(8192, (size_t)st.st_size / 16384 / 12));
   }
   const size_t chunk_blocks = env_blocks && atoi(env_blocks) > 0 ? (size_t)atoi(env_blocks) : auto_blocks;
   const size_t chunk_bytes = std::max<size_t>((size_t)1 << 20, chunk_blocks * 20000);       // compressed bytes one chunk may span

@@ -571,12 +571,11 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "v_bfe_u32 %[vt0], %[ve], 4, 4\n\t"
       "v_lshrrev_b32_e64 %[vL], %[vt1], s90\n\t"
       "s_lshr_b64 s[90:91], s[90:91], s95\n\t"
-      "v_lshrrev_b32_e32 %[vt1], 16, %[ve]\n\t"
       "s_and_b32 s94, s90, 0xff\n\t"
       "v_bfe_u32 %[vL], %[vL], 0, %[vt0]\n\t"
       "v_lshl_add_u32 %[vt0], s94, 2, %[vdist]\n\t"
+      "v_add_u32_sdwa %[vL], %[vL], %[ve] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"   // + the entry's value (its high half)
       "ds_read_b32 %[ve], %[vt0]\n\t"
-      "v_add_u32_e32 %[vL], %[vL], %[vt1]\n\t"
       "s_cmp_eq_u32 s91, 0\n\t"
       "s_cbranch_scc1 L_iw_refill2_%=\n"
       // (32 more bits, if they were needed, have come in on top: the entry being read stands) the distance code's fields
@@ -586,10 +585,9 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "v_and_b32_e32 %[vn], 15, %[ve]\n\t"
       "v_bfe_u32 %[vt1], %[ve], 4, 4\n\t"
       "v_lshrrev_b32_e64 %[vt0], %[vn], s90\n\t"
-      "v_lshrrev_b32_e32 %[vD], 16, %[ve]\n\t"
       "v_bfe_u32 %[vt0], %[vt0], 0, %[vt1]\n\t"
       "v_bfe_u32 %[vt1], %[ve], 10, 5\n\t"
-      "v_add_u32_e32 %[vD], %[vD], %[vt0]\n\t"
+      "v_add_u32_sdwa %[vD], %[vt0], %[ve] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
       "v_readfirstlane_b32 s92, %[vt1]\n\t"
       "v_readfirstlane_b32 s93, %[vt2]\n\t"
       // the fast copy takes a first-level distance code (the entry of any other is 0: D = 0 < L), D >= L, D <= pos,

@@ -16,7 +16,7 @@ print(j['check']['ok'], j['call_s'], j['merge_s'])
 P
 CLI=$R/strling_amd/lib/strling
 cd /tmp
-for B in 6144 8192 12288 16384 24576 32768; do
+for B in ${SWEEP:-}; do
   for k in 1 2; do
     sleep 2
     STRL_CHUNK_BLOCKS=$B $CLI extract -v -g /tmp/e2e_${N}_6.str /tmp/e2e_${N}_6.bam /tmp/e2e_sweep.bin 2>&1 | grep "seconds: total\|open context" | sed "s/^/blocks $B: /" | cut -c1-420
