@@ -517,8 +517,9 @@ int strl_front_finish(strl_ctx *ctx, strl_front_chunk done[2], int *n_done);
  *   strl_front_reserve   (after _begin) sizes the buffers of both chunks in flight for chunks of up to max_blocks blocks and
  *                        max_comp_bytes compressed bytes, so none is reallocated in the middle of the file
  *   strl_front_stage     starts the copy to the device of the chunk the NEXT push of this context will hand over (which must
- *                        pass the same pointers and sizes).  `comp` and the tables then live one call longer: until the
- *                        second push after that one has returned
+ *                        pass the same pointers and sizes) -- or, when that one is staged already, of the chunk after it: up to
+ *                        two chunks may be staged, in file order.  `comp` and the tables of a staged chunk live until the
+ *                        second push after its own has returned
  *   strl_front_enqueue_after + strl_front_collect = strl_front_push_after in two halves: the first queues the chunk's copy
  *                        (unless staged), inflate and record scan and returns the summary of the chunk two back; the second
  *                        waits for the PREVIOUS chunk's record scan and queues its parse + scoring.  Between them the caller

@@ -603,9 +603,10 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   std::vector<strl_ctx *> ctxs((size_t)G, nullptr);
   std::vector<int> ctx_rc((size_t)G, 0);
   std::vector<std::string> ctx_err((size_t)G);
-  // three per context: [3 g + (its chunk count % 3)] -- chunk k+1 is read from the file while chunk k is handed over, and chunk k-1's
-  // copy to the device may still be going.  Block tables: coff u64 | clen | isize | crc u32
-  const size_t RING = 3;
+  // four per context: [4 g + (its chunk count % 4)] -- while chunk k is handed over, chunk k+2 is read from the file, chunk k+1's
+  // copy to the device has just been queued and chunk k's may still be going; the buffer chunk k+2 takes is chunk k-2's, whose
+  // record scan this thread has waited for.  Block tables: coff u64 | clen | isize | crc u32
+  const size_t RING = 4;
   std::vector<uint8_t *> pin(RING * G, nullptr), pin_meta(RING * G, nullptr);
   const auto t_start = now();
   double t_ctx = 0, t_pin = 0;
@@ -746,20 +747,24 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     }
     fs.next = first + n;
   };
-  // One chunk ahead: while chunk k is handed to the device (strl_front_push_after returns when chunk k-1 has been inflated and
-  // scanned), a thread walks the headers of chunk k+1 and reads its bytes.  (Reading only after the push had returned put
-  // the read AND the copy to the device between "chunk k-1 done" and "chunk k+1 may start": 0.40 s of 3.03 s with the
-  // inflate stream idle on the 57 GB file.)
+  // Two chunks ahead: while chunk k is handed to the device (strl_front_collect returns when chunk k-1 has been inflated and
+  // scanned), a thread walks the headers of chunk k+2 and reads its bytes, and chunk k+1 -- read during the previous turn --
+  // has its copy to the device queued first thing.  (Reading only after the push had returned put the read AND the copy
+  // between "chunk k-1 done" and "chunk k+1 may start": 0.40 s of 3.03 s with the inflate stream idle on the 57 GB file;
+  // reading one ahead and queueing the copy when the read was done still left it 0.3 s late in all: a 323 MB chunk takes
+  // 5 ms to read and 6.5 ms to copy, an inflate 12.)
   struct Staged {
     int64_t nb = 0;
     size_t lo = 0, hi = 0, slot = 0;
     int g = 0;
     std::string err;
     bool short_read = false;
-  } cur, nxt;
+  };
+  Staged ring[3];                 // chunk c in ring[c % 3]: handed over | copy queued | being read
   std::vector<uint64_t> staged((size_t)G, 0);
   auto stage = [&](uint64_t ci, Staged &S) {
     const auto ta = now();
+    S = Staged{};
     // a short first chunk gets the device going while the second is being copied
     S.nb = feed.next(blks, ci == 0 ? std::min<size_t>(chunk_blocks, 2048) : chunk_blocks, chunk_bytes, S.err);
     if (S.nb <= 0) return;
@@ -777,8 +782,17 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     for (size_t k = 0; k < (size_t)S.nb; ++k) { coff[k] = blks[k].c_off - lo; clen[k] = blks[k].clen; isz[k] = blks[k].isize; crc[k] = blks[k].crc; }
     t_walk += secs(ta, tb); t_copy += secs(tb, now());
   };
-  stage(0, cur);
+  auto queue_copy = [&](const Staged &S) -> int {     // the chunk's copy to the device, ahead of its turn
+    uint64_t *ncoff = reinterpret_cast<uint64_t *>(pin_meta[S.slot]);
+    uint32_t *nclen = reinterpret_cast<uint32_t *>(ncoff + chunk_blocks), *nisz = nclen + chunk_blocks, *ncrc = nisz + chunk_blocks;
+    return strl_front_stage(ctxs[(size_t)S.g], pin[S.slot], S.hi - S.lo, ncoff, nclen, nisz, ncrc, (uint32_t)S.nb);
+  };
+  stage(0, ring[0]);
+  if (ring[0].nb > 0 && !ring[0].short_read) FRONT_CHECK(queue_copy(ring[0]));
+  if (ring[0].nb > 0) stage(1, ring[1]);
   for (uint64_t ci = 0;; ++ci) {
+    const Staged cur = ring[ci % 3];
+    Staged &nxt = ring[(ci + 1) % 3];
     const int64_t nb = cur.nb;
     if (nb < 0) quit("[strling] error reading %s: %s", bam.c_str(), cur.err.c_str());
     if (nb == 0) break;
@@ -788,8 +802,9 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     uint8_t *dst = pin[cur.slot];
     uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[cur.slot]);
     uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks, *crc = isz + chunk_blocks;
-    nxt = Staged{};
-    ahead = std::thread([&, ci] { stage(ci + 1, nxt); });
+    if (nxt.nb > 0) ahead = std::thread([&, ci] { stage(ci + 2, ring[(ci + 2) % 3]); });
+    else ring[(ci + 2) % 3] = Staged{};
+    if (nxt.nb > 0 && !nxt.short_read) FRONT_CHECK(queue_copy(nxt));
     const auto tc = now();
     strl_front_chunk done[2];
     int n_done = 0;
@@ -802,16 +817,6 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     ++pushes[(size_t)g];
     got(g, done, n_done);
     mark(g, before);
-    // the next chunk's bytes are read by now (or nearly): its copy goes into the device's queue BEFORE this thread waits for the
-    // previous chunk's record scan -- behind that wait it started half an inflate late
-    const auto td0 = now();
-    ahead.join();
-    t_stage_wait += secs(td0, now());
-    if (nxt.nb > 0 && !nxt.short_read) {
-      uint64_t *ncoff = reinterpret_cast<uint64_t *>(pin_meta[nxt.slot]);
-      uint32_t *nclen = reinterpret_cast<uint32_t *>(ncoff + chunk_blocks), *nisz = nclen + chunk_blocks, *ncrc = nisz + chunk_blocks;
-      FRONT_CHECK(strl_front_stage(ctxs[(size_t)nxt.g], pin[nxt.slot], nxt.hi - nxt.lo, ncoff, nclen, nisz, ncrc, (uint32_t)nxt.nb));
-    }
     FRONT_CHECK(strl_front_collect(ctxs[(size_t)g]));
     account();
     if (G == 1 && !frag_thread.joinable()) {
@@ -825,7 +830,9 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
         }
       }
     }
-    cur = nxt;
+    const auto td0 = now();
+    if (ahead.joinable()) ahead.join();
+    t_stage_wait += secs(td0, now());
     t_push += secs(tc, now());
   }
   if (frag_thread.joinable()) frag_thread.join();

@@ -14,7 +14,11 @@
 //                    lowered thresholds (extract.nim:207-211 and :241-244).
 #include <stdarg.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <algorithm>
+#include <mutex>
+#include <thread>
+#include <vector>
 #include "common.h"
 #include "front.h"
 #include "device_util.h"
@@ -1798,14 +1802,16 @@ int strl_front_reserve(strl_ctx *c, uint32_t max_blocks, uint64_t max_comp_bytes
   return strl::front_reserve(c, c->front, max_blocks, max_comp_bytes);
 }
 
-// starts the copy to the device of the chunk the NEXT strl_front_push / _enqueue_after of this context will hand over
+// starts the copy to the device of the chunk the NEXT strl_front_push / _enqueue_after of this context will hand over -- or, if that
+// one is staged already, of the chunk after it
 int strl_front_stage(strl_ctx *c, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize, const uint32_t *crc32,
                      uint32_t n_blocks) {
   if (!c || !c->front || !c->x_open || !n_blocks || !comp || !coff || !clen || !isize) { set_error("strl_front_stage: bad argument / no strl_front_begin"); return STRL_ERR_ARG; }
   STRL_HIP(hipSetDevice(c->device));
   strl::strl_front *F = c->front;
-  const int si = (int)(F->chunks & 1);
-  if (F->slot[si].staged) { set_error("strl_front_stage: a chunk is staged already"); return STRL_ERR_ARG; }
+  int si = (int)(F->chunks & 1);
+  if (F->slot[si].staged) si ^= 1;          // the next push's chunk is staged: this is the one behind it (the caller stages in file order)
+  if (F->slot[si].staged) { set_error("strl_front_stage: two chunks are staged already"); return STRL_ERR_ARG; }
   const strl::FrontChunkDesc d{comp, comp_bytes, coff, clen, isize, crc32, n_blocks};
   return strl::front_copy(c, F, si, d);
 }
@@ -2001,11 +2007,52 @@ int strl_front_treads_named(strl_ctx *c, strl_tread *treads, uint64_t cap, uint6
   return ret;
 }
 
+// Page-locked host memory.  hipHostMalloc takes 0.25 s per GB here (4 KB pages faulted and pinned one by one: 0.36 s for the four
+// chunk buffers of `strling extract`, longer than creating the device context beside it).  An anonymous mapping advised to use
+// 2 MB pages, touched by a few threads and then registered takes 0.012 s for the same 1.3 GB, and copies from it run at 57 GB/s
+// instead of 36 - 50 (tools/ubench/pin_probe.hip, profiles/r04/pin_probe.txt).  hipHostMalloc is the fallback.
+namespace {
+struct PinnedMap { void *base; size_t len; };
+std::mutex g_pinned_mu;
+std::vector<std::pair<void *, PinnedMap>> g_pinned;      // registered mappings by the pointer handed out
+}  // namespace
 void *strl_pinned_alloc(uint64_t bytes) {
+  const size_t huge = (size_t)2 << 20;
+  if (bytes >= huge && !getenv("STRL_PINNED_PLAIN")) {
+    const size_t len = (((size_t)bytes + huge - 1) & ~(huge - 1)) + huge;
+    void *base = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (base != MAP_FAILED) {
+      char *a = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(base) + huge - 1) & ~(uintptr_t)(huge - 1));
+      const size_t span = len - huge;
+      (void)madvise(a, span, MADV_HUGEPAGE);
+      const size_t T = std::min<size_t>(8, std::max<size_t>(1, span >> 26));      // a thread per 64 MB, up to 8
+      std::vector<std::thread> th;
+      for (size_t k = 0; k < T; ++k)
+        th.emplace_back([=] { for (size_t o = span / T * k, e = k + 1 == T ? span : span / T * (k + 1); o < e; o += 4096) a[o] = 0; });
+      for (auto &x : th) x.join();
+      if (hipHostRegister(a, span, hipHostRegisterDefault) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        g_pinned.push_back({a, PinnedMap{base, len}});
+        return a;
+      }
+      (void)hipGetLastError();
+      (void)munmap(base, len);
+    }
+  }
   void *p = nullptr;
   if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
   return p;
 }
-void strl_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
+void strl_pinned_free(void *p) {
+  if (!p) return;
+  PinnedMap m{nullptr, 0};
+  {
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    for (size_t i = 0; i < g_pinned.size(); ++i)
+      if (g_pinned[i].first == p) { m = g_pinned[i].second; g_pinned.erase(g_pinned.begin() + (long)i); break; }
+  }
+  if (m.base) { (void)hipHostUnregister(p); (void)munmap(m.base, m.len); }
+  else (void)hipHostFree(p);
+}
 
 }  // extern "C"
