@@ -102,6 +102,16 @@ def run(inp, cli, threads=(0,), call=True, merge=True, repeats=1):
                 "device_mem_GB": mem_gb, "str_reads": int(n_str[-1].split(" reads, ")[1].split()[0]) if n_str else None,
                 "phases": line[-1].split("seconds:")[1].strip() if line else r.stderr[-400:],
                 "outside_the_loop": su[-1].split("seconds before the loop:")[1].strip() if su else None}
+        # the progress lines ("<primary reads so far> <rate> reads/sec", one per chunk summary): seconds between consecutive chunks
+        at = []
+        for l in err:
+            m = re.match(r"^(\d+) ([\d.]+) reads/sec$", l.strip())
+            if m and float(m.group(2)) > 0:
+                at.append(int(m.group(1)) / float(m.group(2)))
+        if len(at) > 4:
+            d = sorted(1e3 * (b - a) for a, b in zip(at, at[1:]))
+            run_["chunk_summaries"] = {"n": len(at), "first_at_ms": round(1e3 * at[0], 1), "last_at_ms": round(1e3 * at[-1], 1),
+                                       "between_ms": {"min": round(d[0], 1), "median": round(d[len(d) // 2], 1), "p90": round(d[int(len(d) * 0.9)], 1), "max": round(d[-1], 1)}}
         if r.returncode != 0:
             run_["stderr_tail"] = r.stderr[-600:]
         res["runs"].append(run_)

@@ -25,6 +25,6 @@ done > $R/gpurun_out/r4/${T}_sweep.txt 2>&1
 cat $R/gpurun_out/r4/${T}_sweep.txt | cut -c1-260
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r4/${T}_kt -o run -- $CLI extract -v -g /tmp/e2e_${N}_6.str /tmp/e2e_${N}_6.bam /tmp/e2e_prof.bin > $R/gpurun_out/r4/${T}_kt.log 2>&1
 f=$(find $R/gpurun_out/r4/${T}_kt -name 'run_kernel_trace.csv' | head -1)
-python $R/tools/trace_timeline.py $f > $R/gpurun_out/r4/${T}_timeline.txt 2>&1
+python $R/tools/trace_timeline.py $f 60 > $R/gpurun_out/r4/${T}_timeline.txt 2>&1
 grep -v "^   +" $R/gpurun_out/r4/${T}_timeline.txt
 find $R/gpurun_out/r4/${T}_kt -name 'run_kernel_trace.csv' -delete; find $R/gpurun_out/r4/${T}_kt -name '*agent_info*' -delete

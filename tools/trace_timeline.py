@@ -28,6 +28,9 @@ def main(path):
     print(f"{'kernel':42s} {'calls':>6s} {'total ms':>9s} {'alone ms':>9s}")
     for n, t in tot.most_common(14):
         print(f"{n:42s} {cnt[n]:6d} {t / 1e6:9.2f} {alone[n] / 1e6:9.2f}")
+    print("the first launches (ms from the first):")
+    for e in ev[:int(sys.argv[2]) if len(sys.argv) > 2 else 0]:
+        print(f"   {(e[0] - t0) / 1e6:8.2f} .. {(e[1] - t0) / 1e6:8.2f}  {e[2]}  q{e[3]}")
     inf = [e for e in ev if e[2].startswith("inflate_kernel")]
     if len(inf) > 2:
         gaps = [(inf[i + 1][0] - inf[i][1]) / 1e6 for i in range(len(inf) - 1)]
