@@ -486,6 +486,26 @@ int strl_inflate_blocks(strl_ctx *ctx, const uint8_t *comp, uint64_t comp_bytes,
 /* HIP-event time (ms) of the inflate kernel of the last strl_inflate_blocks call (copies excluded). */
 int strl_ctx_inflate_ms(strl_ctx *ctx, double *ms);
 
+/* ---- `strling call`'s evidence reads on the device (replaces the per-bound `for aln in ibam.query(tid, left - window,
+ * right + window)` of call.nim:196-218 / collect.nim:132-141, i.e. htslib's indexed iterator: bgzf seek + inflate + bam_read1
+ * from the .bai linear-index offset up to the first record at or behind `end`) for many bounds at once.
+ * The host looks the regions up in the index and hands over, per region, the consecutive BGZF blocks from the linear-index
+ * offset on (first_block .. first_block + n_blocks - 1 of the block arrays, which are laid out as for strl_inflate_blocks;
+ * crc32 = the blocks' trailers, may be NULL) and in_block = where inside the first block's inflated bytes the index points.
+ * On return out[out_off[r], out_off[r] + out_len[r]) holds region r's BAM records (block_size-prefixed, back to back, file
+ * order) from the first record that may reach past `beg` up to, not including, the first record with another refID or
+ * pos >= end -- a superset of htslib's iterator filter (tid equal, pos < end, bam_endpos > beg), which strl_spanners applies.
+ * status[r] = 0: complete; 1: the blocks handed over end before such a record (or do not parse): read that region on the host.
+ * out_cap = the sum over the regions of their blocks' ISIZE + 32 bytes per region always suffices.  STRL_ERR_FORMAT / STRL_ERR_CRC as for the front end. */
+typedef struct {
+  uint32_t first_block, n_blocks;
+  uint32_t in_block;
+  int32_t tid, beg, end;
+} strl_region_req;
+int strl_regions_fetch(strl_ctx *ctx, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize,
+                       const uint32_t *crc32, uint32_t n_blocks, const strl_region_req *req, uint32_t n_regions, uint8_t *out, uint64_t out_cap,
+                       uint64_t *out_off, uint64_t *out_len, uint8_t *status);
+
 /* ---- `strling extract` with the whole BAM front end on the device (replaces extract.nim:275-329: bam open / `for aln in ibam`
  * / `query("*")`, i.e. htslib's inflate + bam_read1 + the hts-nim accessors, for the whole file).  The host walks the BGZF
  * block headers and hands over compressed bytes; inflate, record boundaries, record parsing, the fragment-length words and

@@ -79,6 +79,7 @@ SOFT_DTYPE = np.dtype([("read_side", "<u4"), ("res_first", "<u4"), ("res_after",
 TREAD_DTYPE = np.dtype([("tid", "<i4"), ("position", "<u4"), ("repeat", "S6"), ("flag", "<u2"), ("split", "u1"),
                         ("mapping_quality", "u1"), ("repeat_count", "u1"), ("align_length", "u1"), ("qname_id", "<i8")],
                        align=True)
+REGION_REQ_DTYPE = np.dtype([("first_block", "<u4"), ("n_blocks", "<u4"), ("in_block", "<u4"), ("tid", "<i4"), ("beg", "<i4"), ("end", "<i4")])
 BOUNDS_DTYPE = np.dtype([("tid", "<i4"), ("left", "<u4"), ("left_most", "<u4"), ("right", "<u4"), ("right_most", "<u4"),
                          ("center_mass", "<u4"), ("n_left", "<u2"), ("n_right", "<u2"), ("n_total", "<u2"),
                          ("repeat", "S7")], align=True)
@@ -117,7 +118,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
            "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order",
-           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered", "strl_inflate_blocks", "strl_ctx_inflate_ms", "strl_front_begin", "strl_front_push", "strl_front_push_after", "strl_front_reserve", "strl_front_stage", "strl_front_enqueue_after", "strl_front_collect", "strl_ctxs_extract_gather", "strl_front_finish", "strl_front_fragwords", "strl_front_fragwords_async", "strl_event_wait", "strl_front_records", "strl_front_tids", "strl_front_qnames", "strl_front_treads_named", "strl_pinned_alloc", "strl_pinned_free", "strl_comm_unique_id", "strl_ctx_comm_init", "strl_ctxs_comm_init", "strl_ctx_comm_info", "strl_cluster_exchange", "strl_ctxs_cluster_exchange", "strl_exchange_treads", "strl_ctx_set_treads", "strl_cluster_collect", "strl_ctx_tail_stream", "strl_ctx_mem_info", "strl_bin_peek"]
+           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered", "strl_inflate_blocks", "strl_ctx_inflate_ms", "strl_regions_fetch", "strl_front_begin", "strl_front_push", "strl_front_push_after", "strl_front_reserve", "strl_front_stage", "strl_front_enqueue_after", "strl_front_collect", "strl_ctxs_extract_gather", "strl_front_finish", "strl_front_fragwords", "strl_front_fragwords_async", "strl_event_wait", "strl_front_records", "strl_front_tids", "strl_front_qnames", "strl_front_treads_named", "strl_pinned_alloc", "strl_pinned_free", "strl_comm_unique_id", "strl_ctx_comm_init", "strl_ctxs_comm_init", "strl_ctx_comm_info", "strl_cluster_exchange", "strl_ctxs_cluster_exchange", "strl_exchange_treads", "strl_ctx_set_treads", "strl_cluster_collect", "strl_ctx_tail_stream", "strl_ctx_mem_info", "strl_bin_peek"]
 
 
 def lib_path():
@@ -199,6 +200,8 @@ def load(build_if_missing=True):
                                         C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(ClusterStats)]
     L.strl_inflate_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
     L.strl_ctx_inflate_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.strl_regions_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                     C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.strl_front_begin.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64]
     L.strl_front_push.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_int)]
     L.strl_front_finish.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
@@ -530,6 +533,27 @@ class Context:
         good = C.c_int(0)
         _check(self.L.strl_bounds_bare(self.h, p.ctypes.data, sp.ctypes.data, p.size, min_clip, min_clip_total, max_clip_dist, out.ctypes.data, C.byref(good)))
         return out[0], bool(good.value)
+
+    def regions_fetch(self, streams, sizes, regions, crcs=None):
+        """strl_regions_fetch: `streams` / `sizes` = raw DEFLATE payloads + ISIZE of BGZF blocks; regions = list of
+        (first_block, n_blocks, in_block, tid, beg, end) -> list of (record bytes, status)"""
+        comp = np.frombuffer(b"".join(streams) + b"\0" * 8, np.uint8)
+        clen = np.array([len(x) for x in streams], np.uint32)
+        coff = np.zeros(len(streams), np.uint64)
+        coff[1:] = np.cumsum(clen[:-1], dtype=np.uint64)
+        isz = np.asarray(sizes, np.uint32)
+        req = np.zeros(len(regions), REGION_REQ_DTYPE)
+        for k, r in enumerate(regions):
+            req[k] = tuple(r)
+        cap = sum(int(isz[r[0]:r[0] + r[1]].sum()) + 32 for r in regions) + 64
+        out = np.zeros(cap, np.uint8)
+        off = np.zeros(len(regions), np.uint64)
+        ln = np.zeros(len(regions), np.uint64)
+        st = np.zeros(len(regions), np.uint8)
+        crc = None if crcs is None else np.asarray(crcs, np.uint32)
+        _check(self.L.strl_regions_fetch(self.h, comp.ctypes.data, int(clen.sum()), _ptr(coff), _ptr(clen), _ptr(isz), None if crc is None else _ptr(crc), len(streams),
+                                         req.ctypes.data, len(regions), out.ctypes.data, cap, _ptr(off), _ptr(ln), _ptr(st)))
+        return [(out[int(o):int(o) + int(n)].tobytes(), int(x)) for o, n, x in zip(off, ln, st)]
 
     def inflate_blocks(self, streams, sizes):
         """raw DEFLATE streams (list of bytes) with their inflated sizes -> list of inflated bytes (strl_inflate_blocks)"""

@@ -99,6 +99,64 @@ __global__ __launch_bounds__(256) void crc32_kernel(const uint8_t *out, const ui
   }
 }
 
+// ---- `strling call`'s evidence reads (call.nim:196-218: one bam.query(tid, left - window, right + window) per bound) for many
+// bounds at once.  The host finds each region's BGZF blocks through the .bai linear index (a region's blocks are consecutive in
+// the file and inflate to one contiguous piece of `u`); after the inflate ONE LANE per region walks its records from the index
+// offset on -- htslib's iterator does the same walk -- and notes the byte range from the first record that can reach past `beg`
+// to the first record at or behind `end` (or on another reference); a second launch copies exactly those bytes out.  What goes
+// back to the host is the tenth of the inflated bytes the query returns, not all the index makes one read.
+struct RegionWalk { uint64_t start, stop; };
+__device__ __forceinline__ uint32_t rg_ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__global__ __launch_bounds__(64) void region_walk_kernel(const uint8_t *u, const uint64_t *uoff, const uint32_t *isize, const strl_region_req *req, uint32_t n,
+                                                          RegionWalk *range, uint8_t *status) {
+  const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+  if (r >= n) return;
+  const strl_region_req q = req[r];
+  const uint32_t last = q.first_block + q.n_blocks - 1u;
+  const uint64_t base = uoff[q.first_block], lim = uoff[last] + isize[last];
+  uint64_t p = base + q.in_block, keep = ~0ull;
+  uint8_t st = 1;                                      // the inflated bytes end before a record that stops the query: the host reads this one itself
+  while (p + 36 <= lim) {
+    const uint32_t bs = rg_ld32(u + p);
+    if (bs < 32u || bs > (1u << 28)) break;            // not a record (st stays 1: the host's reader gives the verdict)
+    const int32_t ref = (int32_t)rg_ld32(u + p + 4), pos = (int32_t)rg_ld32(u + p + 8);
+    if (ref != q.tid || pos >= q.end) { st = 0; break; }
+    if (p + 4 + bs > lim) break;
+    if (keep == ~0ull) {
+      // an upper bound of bam_endpos: every cigar operation counted as if it consumed the reference (a record that is dropped
+      // here cannot overlap; one that is kept for nothing is filtered by strl_spanners like on the host path)
+      const uint32_t l_name = u[p + 12], n_cig = rg_ld32(u + p + 16) & 0xffffu;
+      int64_t span = 1;
+      if (36ull + l_name + 4ull * n_cig <= 4ull + bs)
+        for (uint32_t k = 0; k < n_cig; ++k) span += rg_ld32(u + p + 36 + l_name + 4u * k) >> 4;
+      else span = 1ll << 40;                           // malformed: keep it, the host's parser reports it
+      if ((int64_t)pos + span > (int64_t)q.beg) keep = p;
+    }
+    p += 4ull + bs;
+  }
+  if (st == 0 && keep == ~0ull) keep = p;
+  range[r] = RegionWalk{st ? 0ull : keep, st ? 0ull : p};
+  status[r] = st;
+}
+// a block per region: bytes [start, stop) of `u` to out + off[r]; off[r] = start (mod 16), so the body moves in 16-byte pieces
+__global__ __launch_bounds__(256) void region_copy_kernel(const uint8_t *u, const RegionWalk *range, const uint64_t *off, uint32_t n, uint8_t *out) {
+  for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
+    const uint64_t s = range[r].start, e = range[r].stop;
+    if (e <= s) continue;
+    const uint8_t *src = u + s;
+    uint8_t *dst = out + off[r];
+    const uint64_t len = e - s;
+    uint64_t head = (16u - (uint32_t)(s & 15u)) & 15u;
+    if (head > len) head = len;
+    const uint64_t body = (len - head) >> 4, tail0 = head + (body << 4);
+    if (threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src + head);
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst + head);
+    for (uint64_t i = threadIdx.x; i < body; i += 256) d4[i] = s4[i];
+    if (tail0 + threadIdx.x < len) dst[tail0 + threadIdx.x] = src[tail0 + threadIdx.x];
+  }
+}
+
 }  // namespace strl
 
 using namespace strl;
@@ -211,5 +269,78 @@ extern "C" int strl_inflate_blocks(strl_ctx *c, const uint8_t *comp, uint64_t co
 extern "C" int strl_ctx_inflate_ms(strl_ctx *c, double *ms) {
   if (!c || !ms) return STRL_ERR_ARG;
   *ms = c->inflate_ms;
+  return STRL_OK;
+}
+
+// C ABI: the records of many region queries of one BAM (call.nim:196-218), inflated and cut out on the device.
+extern "C" int strl_regions_fetch(strl_ctx *c, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen, const uint32_t *isize,
+                                  const uint32_t *crc32, uint32_t n_blocks, const strl_region_req *req, uint32_t n_regions, uint8_t *out, uint64_t out_cap,
+                                  uint64_t *out_off, uint64_t *out_len, uint8_t *status) {
+  if (!c || (n_blocks && (!comp || !coff || !clen || !isize)) || (n_regions && (!req || !out_off || !out_len || !status)) || (out_cap && !out)) { set_error("null argument"); return STRL_ERR_ARG; }
+  if (!n_regions) return STRL_OK;
+  STRL_HIP(hipSetDevice(c->device));
+  std::vector<uint64_t> uoff(n_blocks);
+  uint64_t tot = 0;
+  for (uint32_t i = 0; i < n_blocks; ++i) {
+    if (coff[i] + clen[i] > comp_bytes) { set_error("block %u reaches past the compressed buffer", i); return STRL_ERR_ARG; }
+    if (isize[i] > 65536u) { set_error("block %u: ISIZE %u", i, isize[i]); return STRL_ERR_FORMAT; }
+    uoff[i] = tot;
+    tot += isize[i];
+  }
+  for (uint32_t r = 0; r < n_regions; ++r)
+    if (!req[r].n_blocks || (uint64_t)req[r].first_block + req[r].n_blocks > n_blocks) { set_error("region %u names blocks that were not handed over", r); return STRL_ERR_ARG; }
+  DevBuf d_comp, d_meta, d_u, d_out, d_rq;
+  struct Rel { DevBuf *b[5]; ~Rel() { for (DevBuf *x : b) x->release(); } } rel{{&d_comp, &d_meta, &d_u, &d_out, &d_rq}};
+  int rc;
+  const uint64_t readable = (comp_bytes + 3) & ~(uint64_t)3;
+  const size_t meta = (size_t)n_blocks * (8 + 8 + 4 + 4 + 4) + 64;
+  const size_t rq_bytes = (size_t)n_regions * (sizeof(strl_region_req) + sizeof(RegionWalk) + 8 + 1) + 64;
+  if ((rc = d_comp.reserve(readable + 16)) || (rc = d_meta.reserve(meta)) || (rc = d_u.reserve(tot + 64)) || (rc = d_rq.reserve(rq_bytes))) return rc;
+  uint64_t *m_coff = d_meta.as<uint64_t>(), *m_uoff = m_coff + n_blocks;
+  uint32_t *m_clen = reinterpret_cast<uint32_t *>(m_uoff + n_blocks), *m_isize = m_clen + n_blocks, *m_crc = m_isize + n_blocks, *m_err = m_crc + n_blocks;
+  RegionWalk *d_range = d_rq.as<RegionWalk>();
+  uint64_t *d_off = reinterpret_cast<uint64_t *>(d_range + n_regions);
+  strl_region_req *d_req = reinterpret_cast<strl_region_req *>(d_off + n_regions);
+  uint8_t *d_status = reinterpret_cast<uint8_t *>(d_req + n_regions);
+  hipStream_t st = c->stream;
+  STRL_HIP(hipMemcpyAsync(d_comp.p, comp, comp_bytes, hipMemcpyHostToDevice, st));
+  STRL_HIP(hipMemsetAsync(static_cast<uint8_t *>(d_comp.p) + comp_bytes, 0, 16, st));
+  STRL_HIP(hipMemcpyAsync(m_coff, coff, (size_t)n_blocks * 8, hipMemcpyHostToDevice, st));
+  STRL_HIP(hipMemcpyAsync(m_uoff, uoff.data(), (size_t)n_blocks * 8, hipMemcpyHostToDevice, st));
+  STRL_HIP(hipMemcpyAsync(m_clen, clen, (size_t)n_blocks * 4, hipMemcpyHostToDevice, st));
+  STRL_HIP(hipMemcpyAsync(m_isize, isize, (size_t)n_blocks * 4, hipMemcpyHostToDevice, st));
+  if (crc32) STRL_HIP(hipMemcpyAsync(m_crc, crc32, (size_t)n_blocks * 4, hipMemcpyHostToDevice, st));
+  STRL_HIP(hipMemcpyAsync(d_req, req, (size_t)n_regions * sizeof(strl_region_req), hipMemcpyHostToDevice, st));
+  STRL_HIP(hipMemsetAsync(m_err, 0, 4, st));
+  if ((rc = strl_inflate_device(c, d_comp.as<uint8_t>(), readable, m_coff, m_clen, m_uoff, m_isize, n_blocks, d_u.as<uint8_t>(), m_err, nullptr, st))) return rc;
+  if (crc32 && (rc = strl_crc_device(c, d_u.as<uint8_t>(), m_uoff, m_isize, m_crc, n_blocks, nullptr, m_err, st))) return rc;
+  hipLaunchKernelGGL(region_walk_kernel, dim3((n_regions + 63) / 64), dim3(64), 0, st, d_u.as<uint8_t>(), m_uoff, m_isize, d_req, n_regions, d_range, d_status);
+  STRL_HIP(hipGetLastError());
+  std::vector<RegionWalk> range(n_regions);
+  uint32_t err = 0;
+  STRL_HIP(hipMemcpyAsync(&err, m_err, 4, hipMemcpyDeviceToHost, st));
+  STRL_HIP(hipMemcpyAsync(range.data(), d_range, (size_t)n_regions * sizeof(RegionWalk), hipMemcpyDeviceToHost, st));
+  STRL_HIP(hipMemcpyAsync(status, d_status, n_regions, hipMemcpyDeviceToHost, st));
+  STRL_HIP(hipStreamSynchronize(st));
+  if (err & IW_ERR_CRC) { set_error("a BGZF block inflates, but not to the bytes its CRC-32 names"); return STRL_ERR_CRC; }
+  if (err) { set_error("device inflate: %s", (err & IW_ERR_DATA) ? "invalid DEFLATE data" : "inflated size differs from the block's ISIZE"); return STRL_ERR_FORMAT; }
+  // where each region's bytes go: back to back, every piece starting at its source's offset modulo 16 (16-byte copies)
+  uint64_t at = 0;
+  for (uint32_t r = 0; r < n_regions; ++r) {
+    const uint64_t len = range[r].stop - range[r].start;
+    if (len) at = ((at + 15) & ~(uint64_t)15) + (range[r].start & 15u);
+    out_off[r] = at;
+    out_len[r] = len;
+    at += len;
+  }
+  if (at > out_cap) { set_error("region records: %llu bytes, room for %llu", (unsigned long long)at, (unsigned long long)out_cap); return STRL_ERR_CAPACITY; }
+  if (at) {
+    if ((rc = d_out.reserve(at + 64))) return rc;
+    STRL_HIP(hipMemcpyAsync(d_off, out_off, (size_t)n_regions * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(region_copy_kernel, dim3(std::min<uint32_t>(n_regions, 4096u)), dim3(256), 0, st, d_u.as<uint8_t>(), d_range, d_off, n_regions, d_out.as<uint8_t>());
+    STRL_HIP(hipGetLastError());
+    STRL_HIP(hipMemcpyAsync(out, d_out.p, at, hipMemcpyDeviceToHost, st));
+    STRL_HIP(hipStreamSynchronize(st));
+  }
   return STRL_OK;
 }

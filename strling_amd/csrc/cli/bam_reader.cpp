@@ -227,6 +227,65 @@ int64_t BamReader::read_region(RecordBatch &b, int32_t tid, int64_t beg, int64_t
   return read_until(b, INT64_MAX, tid, (int32_t)std::min<int64_t>(end, INT32_MAX), err);
 }
 
+bool BamReader::region_span(int32_t tid, int64_t beg, int64_t end, uint64_t &c_beg, uint32_t &in_block, uint64_t &c_hint) const {
+  if (cram_ || tid < 0 || (size_t)tid >= ref_beg_.size() || ref_beg_[(size_t)tid] == 0 || end <= beg) return false;
+  const std::vector<uint64_t> &lin = lin_[(size_t)tid];
+  uint64_t off = 0;                                    // as read_region
+  int64_t w = beg >> 14;
+  if (w >= (int64_t)lin.size()) w = (int64_t)lin.size() - 1;
+  for (; w >= 0 && off == 0; --w) off = lin[(size_t)w];
+  if (off == 0) off = ref_beg_[(size_t)tid];
+  uint64_t hint = 0;
+  for (size_t v = (size_t)((end - 1) >> 14) + 1; v < lin.size() && hint == 0; ++v) hint = lin[v];
+  if (hint == 0 || (hint >> 16) < (off >> 16)) return false;
+  c_beg = off >> 16;
+  in_block = (uint32_t)(off & 0xffff);
+  c_hint = hint >> 16;
+  return true;
+}
+
+// one record (block_size bytes at p, behind its length field) into the batch
+static bool append_record(RecordBatch &b, const uint8_t *p, int32_t bs, std::string &err) {
+  int32_t refID, pos, l_seq, next_ref, next_pos, tlen;
+  uint8_t l_read_name, mapq;
+  uint16_t n_cigar, flag;
+  memcpy(&refID, p, 4); memcpy(&pos, p + 4, 4);
+  l_read_name = p[8]; mapq = p[9];
+  memcpy(&n_cigar, p + 12, 2); memcpy(&flag, p + 14, 2); memcpy(&l_seq, p + 16, 4);
+  memcpy(&next_ref, p + 20, 4); memcpy(&next_pos, p + 24, 4); memcpy(&tlen, p + 28, 4);
+  const size_t need = 32 + (size_t)l_read_name + 4u * n_cigar + (size_t)(l_seq + 1) / 2;
+  if (l_seq < 0 || need > (size_t)bs) { err = "corrupt BAM record"; return false; }
+  b.tid.push_back(refID); b.pos.push_back(pos); b.mtid.push_back(next_ref); b.mpos.push_back(next_pos);
+  b.isize.push_back(tlen); b.l_seq.push_back(l_seq); b.flag.push_back(flag); b.mapq.push_back(mapq);
+  const char *qn = reinterpret_cast<const char *>(p + 32);
+  b.qnames.append(qn, l_read_name ? (size_t)l_read_name - 1 : 0);
+  b.qname_off.push_back(b.qnames.size());
+  const uint8_t *cg = p + 32 + l_read_name;
+  for (int j = 0; j < n_cigar; ++j) { uint32_t c; memcpy(&c, cg + 4 * j, 4); b.cigar.push_back(c); }
+  b.cigar_off.push_back((uint32_t)b.cigar.size());
+  const size_t so = (b.seq4.size() + 15) & ~(size_t)15;
+  const size_t sb = (size_t)(l_seq + 1) / 2;
+  b.seq4.resize(so + sb, 0);
+  memcpy(b.seq4.data() + so, cg + 4u * n_cigar, sb);
+  b.seq_off.push_back(so);
+  return true;
+}
+
+int64_t BamReader::append_records(RecordBatch &b, const uint8_t *p, size_t n, std::string &err) {
+  int64_t k = 0;
+  size_t at = 0;
+  while (at < n) {
+    int32_t bs = 0;
+    if (at + 4 > n) { err = "truncated BAM record"; return -1; }
+    memcpy(&bs, p + at, 4);
+    if (bs < 32 || at + 4 + (size_t)bs > n) { err = "corrupt BAM record"; return -1; }
+    if (!append_record(b, p + at + 4, bs, err)) return -1;
+    at += 4 + (size_t)bs;
+    ++k;
+  }
+  return k;
+}
+
 int64_t BamReader::read_until(RecordBatch &b, int64_t max_records, int32_t stop_tid, int32_t stop_pos, std::string &err) {
   if (cram_) {
     if (stop_tid != INT32_MIN) { err = "read_until on a CRAM"; return -1; }
@@ -245,29 +304,10 @@ int64_t BamReader::read_until(RecordBatch &b, int64_t max_records, int32_t stop_
     rec.resize((size_t)bs);
     if (!get(rec.data(), (size_t)bs, err)) return -1;
     const uint8_t *p = rec.data();
-    int32_t refID, pos, l_seq, next_ref, next_pos, tlen;
-    uint8_t l_read_name, mapq;
-    uint16_t n_cigar, flag;
+    int32_t refID, pos;
     memcpy(&refID, p, 4); memcpy(&pos, p + 4, 4);
-    l_read_name = p[8]; mapq = p[9];
-    memcpy(&n_cigar, p + 12, 2); memcpy(&flag, p + 14, 2); memcpy(&l_seq, p + 16, 4);
-    memcpy(&next_ref, p + 20, 4); memcpy(&next_pos, p + 24, 4); memcpy(&tlen, p + 28, 4);
-    const size_t need = 32 + (size_t)l_read_name + 4u * n_cigar + (size_t)(l_seq + 1) / 2;
-    if (l_seq < 0 || need > (size_t)bs) { err = "corrupt BAM record"; return -1; }
     if (stop_tid != INT32_MIN && (refID != stop_tid || pos >= stop_pos)) break;
-    b.tid.push_back(refID); b.pos.push_back(pos); b.mtid.push_back(next_ref); b.mpos.push_back(next_pos);
-    b.isize.push_back(tlen); b.l_seq.push_back(l_seq); b.flag.push_back(flag); b.mapq.push_back(mapq);
-    const char *qn = reinterpret_cast<const char *>(p + 32);
-    b.qnames.append(qn, l_read_name ? (size_t)l_read_name - 1 : 0);
-    b.qname_off.push_back(b.qnames.size());
-    const uint8_t *cg = p + 32 + l_read_name;
-    for (int j = 0; j < n_cigar; ++j) { uint32_t c; memcpy(&c, cg + 4 * j, 4); b.cigar.push_back(c); }
-    b.cigar_off.push_back((uint32_t)b.cigar.size());
-    const size_t so = (b.seq4.size() + 15) & ~(size_t)15;
-    const size_t sb = (size_t)(l_seq + 1) / 2;
-    b.seq4.resize(so + sb, 0);
-    memcpy(b.seq4.data() + so, cg + 4u * n_cigar, sb);
-    b.seq_off.push_back(so);
+    if (!append_record(b, p, bs, err)) return -1;
     ++n;
   }
   return n;

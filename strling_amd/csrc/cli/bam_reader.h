@@ -76,6 +76,18 @@ class BamReader {
   bool load_index(const std::string &bam_path, std::string &err);
   bool has_index() const { return !lin_.empty(); }
   int64_t read_region(RecordBatch &b, int32_t tid, int64_t beg, int64_t end, std::string &err);
+  // Where read_region(tid, beg, end) starts and, as far as the linear index can tell, where it is over -- for callers that
+  // inflate the blocks of many regions elsewhere (strl_regions_fetch): c_beg = file offset of the BGZF block the walk starts
+  // in, in_block = the first record's offset in that block's inflated bytes, c_hint = file offset of the block holding the
+  // first record that overlaps a LATER 16 KiB window than `end - 1` lies in (the walk ends in that block or the one behind
+  // it unless a record spans more than a window).  false: the region holds nothing / the index has no later window (BAM
+  // files only; the caller then uses read_region).
+  bool region_span(int32_t tid, int64_t beg, int64_t end, uint64_t &c_beg, uint32_t &in_block, uint64_t &c_hint) const;
+  bool is_cram() const { return (bool)cram_; }
+  const std::string &path() const { return path_; }
+  // BAM records in memory (block_size-prefixed, back to back: what read_until walks through the BGZF layer) appended to `b`.
+  // Returns the number appended, -1 on a malformed record.
+  static int64_t append_records(RecordBatch &b, const uint8_t *p, size_t n, std::string &err);
   // position of the NEXT record, to come back to it later (used to revisit the unmapped tail)
   struct Pos { uint64_t block_off; uint32_t in_block; };
   Pos tell() const { return Pos{block_start_, (uint32_t)upos_}; }

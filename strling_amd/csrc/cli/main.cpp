@@ -12,10 +12,13 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <fcntl.h>
 #include <zlib.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <map>
 #include <sys/stat.h>
@@ -971,6 +974,20 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   _exit(0);
 }
 
+// The end of a `strling` process whose outputs are closed: the driver reclaims device and page-locked memory faster than the
+// runtime's own shutdown does piece by piece (~0.15 s and more with gigabytes mapped).  Under a profiler the normal exit path is
+// kept -- its tool library writes its files from an exit handler -- and STRL_TEARDOWN=1 asks for it explicitly.
+static int end_process(strl_ctx *ctx) {
+  const char *pre = getenv("LD_PRELOAD");
+  if (getenv("STRL_TEARDOWN") || (pre && strstr(pre, "rocprof")) || getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_LIBRARY_CTOR")) {
+    if (ctx) strl_ctx_destroy(ctx);
+    return 0;
+  }
+  fflush(stdout);
+  fflush(stderr);
+  _exit(0);
+}
+
 // ---- loci given on the command line: cluster.nim:96-169, call.nim:160-183 --------------------------------------------------------
 static int get_tid(const std::string &name, const std::vector<BamTarget> &targets) {      // utils.nim:214-218
   for (size_t t = 0; t < targets.size(); ++t) if (targets[t].name == name) return (int)t;
@@ -1110,6 +1127,7 @@ static int merge_main(int argc, char **argv) {
   const bool verbose = a.flag("verbose");
   const std::string prefix = a.get("output-prefix", "strling");
 
+  const auto tm0 = std::chrono::steady_clock::now();
   // the HIP runtime + the first device context come up beside the reading of the .bin files
   const int gpus_early = std::max(1, atoi(a.get("gpus", "1").c_str()));
   strl_ctx *ctx_early = nullptr;
@@ -1168,11 +1186,13 @@ static int merge_main(int argc, char **argv) {
     CHECK(strl_assign_reads_loci(all.data(), all.size(), STRL_MODE_MERGE, loci.data(), loci.size(), aoff.data(), nullptr, 0));
   }
   strl_ctx *ctx = nullptr;
-  std::vector<strl_bounds> bounds(std::max<size_t>(all.size(), 16));
+  rvec<strl_bounds> bounds(std::max<size_t>(all.size(), 16));      // (left uninitialised: rows [0, nb) are written by the pass)
   uint64_t nb = 0, nu = 0;
   const int gpus = std::max(1, atoi(a.get("gpus", "1").c_str()));
+  const auto tm1 = std::chrono::steady_clock::now();
   ctx_thread.join();
   g_bg_init = nullptr;
+  const auto tm2 = std::chrono::steady_clock::now();
   if (gpus == 1) {
     if (ctx_early_rc) quit("[strling] %s (status %d)", ctx_early_err.c_str(), ctx_early_rc);
     ctx = ctx_early;
@@ -1219,6 +1239,7 @@ static int merge_main(int argc, char **argv) {
     for (int r = 1; r < gpus; ++r) strl_ctx_destroy(ctxs[(size_t)r]);
     ctx = ctxs[0];
   }
+  const auto tm3 = std::chrono::steady_clock::now();
   const std::string outp = prefix + "-bounds.txt";
   FILE *fo = fopen(outp.c_str(), "w");
   if (!fo) quit("couldn't open output file");
@@ -1236,9 +1257,13 @@ static int merge_main(int argc, char **argv) {
     fputc('\n', fo);
   }
   fclose(fo);
-  if (verbose) fprintf(stderr, "[strling] Wrote merged str bounds to %s\n", outp.c_str());
-  strl_ctx_destroy(ctx);
-  return 0;
+  if (verbose) {
+    fprintf(stderr, "[strling] Wrote merged str bounds to %s\n", outp.c_str());
+    fprintf(stderr, "[strling] seconds: .bin files (beside the device context) %.3f  waiting for the device context %.3f  clustering %.3f  rows %.3f\n",
+            std::chrono::duration<double>(tm1 - tm0).count(), std::chrono::duration<double>(tm2 - tm1).count(), std::chrono::duration<double>(tm3 - tm2).count(),
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - tm3).count());
+  }
+  return end_process(ctx);
 }
 
 // call.nim:51-285
@@ -1338,6 +1363,60 @@ static int call_main(int argc, char **argv) {
   for (int k = 0; k < n_workers; ++k) workers.emplace_back(new Worker());
   ThreadPool ev_pool(n_workers);
   double t_evidence = 0;
+  std::atomic<uint64_t> ns_region{0}, ns_rules{0};      // summed over the workers: region reads (seek + inflate + parse) / spanners + genotype
+  // What a worker does with a bound once its region's records are in w.region: spanners(), genotype(), the row.
+  auto rules = [&](Worker &w, const Task &t, Done &d, std::string &werr) -> bool {
+    const strl_bounds &b = t.b;
+    char row[2048];
+    const strl_records rv = w.region.view();
+    w.sup.resize(2 * w.region.size() + 16);
+    strl_span_summary sm{};
+    if (strl_spanners(&rv, w.region.isize.data(), &b, window, frag, min_mapq, w.sup.data(), w.sup.size(), &sm) != STRL_OK) { werr = std::string("[strling] ") + strl_last_error(); return false; }
+    if (sm.n_support > 5000) return true;                                              // spans.len > 5_000
+    if (sm.median_depth == -1) return true;
+    w.cl.clear();
+    for (uint64_t k = t.i0; k < t.i1; ++k) w.cl.push_back(t.src[(*t.idx)[(size_t)k]]);
+    memset(&d.c, 0, sizeof d.c);
+    if (strl_genotype(&b, w.cl.data(), w.cl.size(), qoff.data(), qnames.data(), w.sup.data(), sm.n_support, &copts, (double)sm.median_depth, &d.c) != STRL_OK) {
+      werr = std::string("[strling] ") + strl_last_error();
+      return false;
+    }
+    d.c.expected_spanning_fragments = sm.expected_spanners;
+    strl_locus L{};
+    L.b = b;
+    if (t.name) snprintf(L.name, sizeof L.name, "%s", t.name);
+    locus_row(row, sizeof row, L, rd.targets()[(size_t)b.tid].name.c_str());
+    d.row = row;
+    d.depth = sm.median_depth;
+    d.keep = true;
+    return true;
+  };
+  // The regions of many bounds through the device (strl_regions_fetch): the .bai linear index gives every region's run of
+  // BGZF blocks; their compressed bytes are read into page-locked memory, inflated on the GPU -- which also cuts out the
+  // records the query returns -- and the workers are left with parsing a few hundred records and the rules per bound.  The
+  // host path inflates ~10 blocks per bound on a CPU (2 - 3 ms): that was the whole evidence step.  Batches of ~2 GB of
+  // inflated bytes; batch i + 1 is read and inflated while the workers are on batch i.  STRL_CALL_REGIONS=host keeps the
+  // host path; a region whose blocks the index cannot bound, and CRAM input, take it by themselves.
+  struct RegionPlan { bool ok = false; uint64_t c_beg = 0, c_end = 0; uint32_t in_block = 0; std::vector<uint32_t> hdr, bsize, isz, crc; };
+  struct Batch {
+    size_t t0 = 0, t1 = 0;
+    std::vector<uint32_t> which;            // tasks of [t0, t1) that go through the device
+    std::vector<uint64_t> coff, out_off, out_len;
+    std::vector<uint32_t> clen, isize, crc;
+    std::vector<strl_region_req> req;
+    std::vector<uint8_t> status;
+    uint64_t comp_bytes = 0, inflated = 0;
+    int rc = 0;
+    std::string err;
+  };
+  const char *regions_env = getenv("STRL_CALL_REGIONS");
+  const bool device_regions = !rd.is_cram() && !(regions_env && !strcmp(regions_env, "host"));
+  const uint64_t batch_inflated = getenv("STRL_CALL_BATCH_MB") ? (uint64_t)atoll(getenv("STRL_CALL_BATCH_MB")) << 20 : (uint64_t)2048 << 20;
+  int region_fd = -1;
+  uint8_t *pin_comp[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
+  uint64_t pin_comp_cap[2] = {0, 0}, pin_out_cap[2] = {0, 0};
+  double t_plan = 0, t_fetch = 0, t_wait_fetch = 0;
+  uint64_t n_dev_regions = 0, n_host_regions = 0, dev_comp_bytes = 0, dev_inflated = 0, dev_kept = 0;
   auto run_tasks = [&](const std::vector<Task> &tasks) {
     if (tasks.empty()) return;
     const auto te0 = std::chrono::steady_clock::now();
@@ -1347,46 +1426,184 @@ static int call_main(int argc, char **argv) {
     for (int k = n_workers - 1; k >= 0; --k) free_w.push_back(k);
     std::atomic<bool> failed{false};
     std::string fail_msg;
-    const size_t per = 8, n_blocks = (tasks.size() + per - 1) / per;
-    ev_pool.parallel_for(n_blocks, [&](size_t blk) {
+    auto fail = [&](const std::string &m) { std::lock_guard<std::mutex> lk(wm); if (!failed.exchange(true)) fail_msg = m; };
+    // one bound on the host: indexed region read by the worker's own reader, then the rules
+    auto host_task = [&](Worker &w, size_t j) -> bool {
+      const Task &t = tasks[j];
+      std::string werr;
+      if (!w.open) { if (!w.rd.open_like(rd, werr)) { fail("couldn't open bam"); return false; } w.open = true; }
+      w.region.clear();
+      const int64_t wl = (int64_t)t.b.left - window, wr = (int64_t)t.b.right + window;
+      const auto tw0 = std::chrono::steady_clock::now();
+      if (w.rd.read_region(w.region, t.b.tid, std::max<int64_t>(0, wl), wr, werr) < 0) { fail("[strling] error reading " + bam + ": " + werr); return false; }
+      const auto tw1 = std::chrono::steady_clock::now();
+      ns_region += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(tw1 - tw0).count();
+      const bool ok = rules(w, t, done[j], werr);
+      ns_rules += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tw1).count();
+      if (!ok) fail(werr);
+      return ok;
+    };
+    auto with_worker = [&](const std::function<void(Worker &)> &fn) {
       int wi;
       { std::lock_guard<std::mutex> lk(wm); wi = free_w.back(); free_w.pop_back(); }
-      Worker &w = *workers[(size_t)wi];
-      std::string werr;
-      auto fail = [&](const std::string &m) { std::lock_guard<std::mutex> lk(wm); if (!failed.exchange(true)) fail_msg = m; };
-      if (!w.open) { if (!w.rd.open_like(rd, werr)) fail("couldn't open bam"); else w.open = true; }
-      char row[2048];
-      for (size_t j = blk * per; j < std::min(tasks.size(), (blk + 1) * per) && !failed.load() && w.open; ++j) {
-        const Task &t = tasks[j];
-        const strl_bounds &b = t.b;
-        w.region.clear();
-        const int64_t wl = (int64_t)b.left - window, wr = (int64_t)b.right + window;
-        if (w.rd.read_region(w.region, b.tid, std::max<int64_t>(0, wl), wr, werr) < 0) { fail("[strling] error reading " + bam + ": " + werr); break; }
-        const strl_records rv = w.region.view();
-        w.sup.resize(2 * w.region.size() + 16);
-        strl_span_summary sm{};
-        if (strl_spanners(&rv, w.region.isize.data(), &b, window, frag, min_mapq, w.sup.data(), w.sup.size(), &sm) != STRL_OK) { fail(std::string("[strling] ") + strl_last_error()); break; }
-        if (sm.n_support > 5000) continue;                                              // spans.len > 5_000
-        if (sm.median_depth == -1) continue;
-        w.cl.clear();
-        for (uint64_t k = t.i0; k < t.i1; ++k) w.cl.push_back(t.src[(*t.idx)[(size_t)k]]);
-        Done &d = done[j];
-        memset(&d.c, 0, sizeof d.c);
-        if (strl_genotype(&b, w.cl.data(), w.cl.size(), qoff.data(), qnames.data(), w.sup.data(), sm.n_support, &copts, (double)sm.median_depth, &d.c) != STRL_OK) {
-          fail(std::string("[strling] ") + strl_last_error());
-          break;
-        }
-        d.c.expected_spanning_fragments = sm.expected_spanners;
-        strl_locus L{};
-        L.b = b;
-        if (t.name) snprintf(L.name, sizeof L.name, "%s", t.name);
-        locus_row(row, sizeof row, L, rd.targets()[(size_t)b.tid].name.c_str());
-        d.row = row;
-        d.depth = sm.median_depth;
-        d.keep = true;
-      }
+      fn(*workers[(size_t)wi]);
       { std::lock_guard<std::mutex> lk(wm); free_w.push_back(wi); }
-    });
+    };
+    const size_t per = 8;
+    if (!device_regions) {
+      ev_pool.parallel_for((tasks.size() + per - 1) / per, [&](size_t blk) {
+        with_worker([&](Worker &w) {
+          for (size_t j = blk * per; j < std::min(tasks.size(), (blk + 1) * per) && !failed.load(); ++j) if (!host_task(w, j)) break;
+        });
+      });
+    } else {
+      // ---- plan: every region's run of blocks (index lookup + a walk over the block headers, 18 + 8 bytes read per block)
+      const auto tp0 = std::chrono::steady_clock::now();
+      if (region_fd < 0) region_fd = open(bam.c_str(), O_RDONLY);
+      if (region_fd < 0) quit("couldn't open bam");
+      std::vector<RegionPlan> plan(tasks.size());
+      ev_pool.parallel_for((tasks.size() + 63) / 64, [&](size_t blk) {
+        for (size_t j = blk * 64; j < std::min(tasks.size(), (blk + 1) * 64); ++j) {
+          const Task &t = tasks[j];
+          RegionPlan &P = plan[j];
+          const int64_t wl = std::max<int64_t>(0, (int64_t)t.b.left - window), wr = (int64_t)t.b.right + window;
+          uint64_t c_hint = 0;
+          if (!rd.region_span(t.b.tid, wl, std::min<int64_t>(wr, INT32_MAX), P.c_beg, P.in_block, c_hint)) continue;
+          uint64_t o = P.c_beg;
+          int beyond = 0;
+          bool good = true;
+          uint64_t infl = 0;
+          while (beyond < 2 && infl < ((uint64_t)8 << 20) && P.bsize.size() < 4096) {   // up to the hinted block and the one behind it (a window of 30x data is ~1 MB)
+            uint8_t h[18], tr[8];
+            if (pread(region_fd, h, 18, (off_t)o) != 18) break;                       // end of the file
+            const uint32_t xlen = h[10] | (h[11] << 8);
+            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4) || xlen != 6 || h[12] != 'B' || h[13] != 'C') { good = false; break; }   // (other layouts: the host reader copes)
+            const uint32_t bsize = (h[16] | (h[17] << 8)) + 1u;
+            if (bsize < 26 || pread(region_fd, tr, 8, (off_t)(o + bsize - 8)) != 8) { good = false; break; }
+            uint32_t crc, isz;
+            memcpy(&crc, tr, 4); memcpy(&isz, tr + 4, 4);
+            if (isz > 65536u) { good = false; break; }
+            P.hdr.push_back(18); P.bsize.push_back(bsize); P.isz.push_back(isz); P.crc.push_back(crc);
+            infl += isz;
+            if (o >= c_hint) ++beyond;
+            o += bsize;
+          }
+          P.c_end = o;
+          // the first block must hold the index offset; a run that did not reach the hinted block goes to the host reader
+          P.ok = good && beyond >= 1 && !P.bsize.empty() && P.in_block <= P.isz[0];
+        }
+      });
+      t_plan += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();
+      // ---- batches of consecutive tasks
+      std::vector<Batch> batches;
+      for (size_t j = 0; j < tasks.size();) {
+        Batch B;
+        B.t0 = j;
+        while (j < tasks.size() && (B.inflated < batch_inflated || B.which.empty())) {
+          const RegionPlan &P = plan[j];
+          if (P.ok) {
+            strl_region_req q{};
+            q.first_block = (uint32_t)B.clen.size(); q.n_blocks = (uint32_t)P.bsize.size(); q.in_block = P.in_block;
+            q.tid = tasks[j].b.tid;
+            q.beg = (int32_t)std::max<int64_t>(0, (int64_t)tasks[j].b.left - window);
+            q.end = (int32_t)std::min<int64_t>((int64_t)tasks[j].b.right + window, INT32_MAX);
+            uint64_t o = 0;
+            for (size_t k = 0; k < P.bsize.size(); ++k) {
+              B.coff.push_back(B.comp_bytes + o + P.hdr[k]);
+              B.clen.push_back(P.bsize[k] - P.hdr[k] - 8);
+              B.isize.push_back(P.isz[k]);
+              B.crc.push_back(P.crc[k]);
+              B.inflated += P.isz[k];
+              o += P.bsize[k];
+            }
+            B.comp_bytes += (o + 15) & ~(uint64_t)15;
+            B.req.push_back(q);
+            B.which.push_back((uint32_t)j);
+          }
+          ++j;
+        }
+        B.t1 = j;
+        batches.push_back(std::move(B));
+      }
+      // ---- fetch (reads + device) of batch i + 1 beside the workers' batch i
+      ThreadPool io_pool(std::max(2, std::min(n_workers / 3, 8)));
+      auto fetch = [&](size_t bi) {
+        Batch &B = batches[bi];
+        const int s = (int)(bi & 1);
+        if (B.which.empty()) return;
+        const auto tf0 = std::chrono::steady_clock::now();
+        if (pin_comp_cap[s] < B.comp_bytes + 64) {
+          if (pin_comp[s]) strl_pinned_free(pin_comp[s]);
+          pin_comp_cap[s] = B.comp_bytes + B.comp_bytes / 8 + 64;
+          pin_comp[s] = static_cast<uint8_t *>(strl_pinned_alloc(pin_comp_cap[s]));
+        }
+        if (pin_out_cap[s] < B.inflated + 32 * B.which.size() + 64) {      // (every region's piece is padded to its source's offset modulo 16)
+          if (pin_out[s]) strl_pinned_free(pin_out[s]);
+          pin_out_cap[s] = B.inflated + B.inflated / 8 + 32 * B.which.size() + 64;
+          pin_out[s] = static_cast<uint8_t *>(strl_pinned_alloc(pin_out_cap[s]));
+        }
+        if (!pin_comp[s] || !pin_out[s]) { B.rc = STRL_ERR_HIP; B.err = "page-locked memory for the region reads"; return; }
+        std::atomic<bool> io_bad{false};
+        io_pool.parallel_for((B.which.size() + 15) / 16, [&](size_t blk) {
+          for (size_t k = blk * 16; k < std::min(B.which.size(), (blk + 1) * 16); ++k) {
+            const RegionPlan &P = plan[B.which[k]];
+            const uint64_t at = B.coff[B.req[k].first_block] - P.hdr[0], len = P.c_end - P.c_beg;
+            uint64_t got = 0;
+            while (got < len) {
+              const ssize_t r = pread(region_fd, pin_comp[s] + at + got, (size_t)(len - got), (off_t)(P.c_beg + got));
+              if (r <= 0) { io_bad = true; break; }
+              got += (uint64_t)r;
+            }
+          }
+        });
+        if (io_bad.load()) { B.rc = STRL_ERR_IO; B.err = "reading " + bam; return; }
+        B.out_off.assign(B.which.size(), 0); B.out_len.assign(B.which.size(), 0); B.status.assign(B.which.size(), 1);
+        B.rc = strl_regions_fetch(ctx, pin_comp[s], B.comp_bytes, B.coff.data(), B.clen.data(), B.isize.data(), B.crc.data(), (uint32_t)B.clen.size(), B.req.data(),
+                                  (uint32_t)B.req.size(), pin_out[s], pin_out_cap[s], B.out_off.data(), B.out_len.data(), B.status.data());
+        if (B.rc) B.err = strl_last_error();
+        t_fetch += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
+      };
+      std::thread fetcher;
+      if (!batches.empty()) fetcher = std::thread(fetch, 0);
+      for (size_t bi = 0; bi < batches.size() && !failed.load(); ++bi) {
+        const auto tq0 = std::chrono::steady_clock::now();
+        fetcher.join();
+        t_wait_fetch += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count();
+        Batch &B = batches[bi];
+        if (B.rc == STRL_ERR_FORMAT || B.rc == STRL_ERR_CRC || B.rc == STRL_ERR_CAPACITY) {
+          // a block the device decoder does not take (or damaged data): the host reader, zlib behind it, has the last word on every region of the batch
+          B.status.assign(B.which.size(), 1);
+          B.rc = 0;
+        }
+        if (B.rc) quit("[strling] error reading %s: %s (status %d)", bam.c_str(), B.err.c_str(), B.rc);
+        if (bi + 1 < batches.size()) fetcher = std::thread(fetch, bi + 1);
+        const int s = (int)(bi & 1);
+        // position of every task of the batch among its device regions (-1: host)
+        std::vector<int64_t> slot(B.t1 - B.t0, -1);
+        for (size_t k = 0; k < B.which.size(); ++k) {
+          if (B.status[k] == 0) { slot[B.which[k] - B.t0] = (int64_t)k; ++n_dev_regions; dev_kept += B.out_len[k]; }
+        }
+        dev_comp_bytes += B.comp_bytes; dev_inflated += B.inflated;
+        ev_pool.parallel_for((B.t1 - B.t0 + per - 1) / per, [&](size_t blk) {
+          with_worker([&](Worker &w) {
+            for (size_t j = B.t0 + blk * per; j < std::min(B.t1, B.t0 + (blk + 1) * per) && !failed.load(); ++j) {
+              const int64_t k = slot[j - B.t0];
+              if (k < 0) { { std::lock_guard<std::mutex> lk(wm); ++n_host_regions; } if (!host_task(w, j)) break; continue; }
+              std::string werr;
+              w.region.clear();
+              const auto tw0 = std::chrono::steady_clock::now();
+              if (BamReader::append_records(w.region, pin_out[s] + B.out_off[(size_t)k], (size_t)B.out_len[(size_t)k], werr) < 0) { fail("[strling] error reading " + bam + ": " + werr); break; }
+              const auto tw1 = std::chrono::steady_clock::now();
+              ns_region += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(tw1 - tw0).count();
+              const bool ok = rules(w, tasks[j], done[j], werr);
+              ns_rules += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tw1).count();
+              if (!ok) { fail(werr); break; }
+            }
+          });
+        });
+      }
+      if (fetcher.joinable()) fetcher.join();
+    }
     if (failed.load()) quit("%s", fail_msg.c_str());
     for (const Done &d : done) {
       if (!d.keep) continue;
@@ -1396,7 +1613,7 @@ static int call_main(int argc, char **argv) {
     t_evidence += std::chrono::duration<double>(std::chrono::steady_clock::now() - te0).count();
   };
   const uint64_t nt = (uint64_t)info.n_reads;
-  const std::vector<strl_tread> taken_copy = treads;   // assigned reads are genotyped with the split they came with
+  std::vector<strl_tread> taken_copy;                  // assigned reads are genotyped with the split they came with (copied only when loci are given)
 
   // loci handed in with -l / -b are genotyped first and take their reads out of the table (call.nim:150-218)
   std::vector<strl_locus> given;
@@ -1415,6 +1632,7 @@ static int call_main(int argc, char **argv) {
         }
     for (const strl_locus &l : loci) given.push_back(l);
     if (!given.empty()) {
+      taken_copy = treads;
       std::vector<uint64_t> aoff(given.size() + 1);
       assigned.resize((size_t)std::max<uint64_t>(nt, 1));
       CHECK(strl_assign_reads_loci(treads.data(), nt, STRL_MODE_CALL, given.data(), given.size(), aoff.data(), assigned.data(), assigned.size()));
@@ -1433,8 +1651,8 @@ static int call_main(int argc, char **argv) {
   const auto tc0 = std::chrono::steady_clock::now();
   const auto tc1 = tc0;
   const uint16_t max_clip_dist = (uint16_t)(0.5 * (double)frag_median);             // call.nim:232
-  std::vector<strl_bounds> bounds(std::max<size_t>((size_t)nt, 16));
-  std::vector<strl_unplaced> unplaced(std::max<size_t>((size_t)nt, 16));
+  rvec<strl_bounds> bounds(std::max<size_t>((size_t)nt, 16));        // (left uninitialised: the pass writes rows [0, nb) / [0, nu))
+  rvec<strl_unplaced> unplaced(std::max<size_t>((size_t)nt, 16));
   uint64_t nb = 0, nu = 0;
   CHECK(strl_cluster(ctx, treads.data(), nt, STRL_MODE_CALL, (uint32_t)window, min_support, min_clip, min_clip_total, max_clip_dist, bounds.data(),
                      bounds.size(), &nb, unplaced.data(), unplaced.size(), &nu, nullptr));
@@ -1451,8 +1669,11 @@ static int call_main(int argc, char **argv) {
     run_tasks(tasks);
   }
   if (verbose)
-    fprintf(stderr, "[strling] seconds: device context + .bin + fragment lengths + index, side by side %.3f  clustering (upload, sort, sweep, bounds, members) %.3f  evidence + genotypes of %llu bounds on %d threads %.3f\n",
-            t_start_up, std::chrono::duration<double>(tc2 - tc1).count(), (unsigned long long)nb, n_workers, t_evidence);
+    fprintf(stderr, "[strling] seconds: device context + .bin + fragment lengths + index, side by side %.3f  clustering (upload, sort, sweep, bounds, members) %.3f  evidence + genotypes of %llu bounds on %d threads %.3f (summed over the threads: region records %.3f, spanners + genotype %.3f; regions through the device %llu, on the host %llu: "
+            "index + block headers %.3f, reads + device fetch %.3f of which the workers waited %.3f, %.1f MB compressed -> %.1f MB inflated -> %.1f MB of records)  since the start %.3f\n",
+            t_start_up, std::chrono::duration<double>(tc2 - tc1).count(), (unsigned long long)nb, n_workers, t_evidence, (double)ns_region.load() * 1e-9, (double)ns_rules.load() * 1e-9,
+            (unsigned long long)n_dev_regions, (unsigned long long)n_host_regions, t_plan, t_fetch, t_wait_fetch, (double)dev_comp_bytes / 1e6, (double)dev_inflated / 1e6, (double)dev_kept / 1e6,
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call0).count());
   char row[2048];
   std::vector<uint64_t> order(std::max<size_t>(calls.size(), 1)), uorder(std::max<size_t>((size_t)nu, 1));
   CHECK(strl_calls_finish(calls.data(), calls.size(), unplaced.data(), nu, order.data()));   // :264-278
@@ -1471,8 +1692,7 @@ static int call_main(int argc, char **argv) {
     fprintf(stderr, "Main results file:\n");
     fprintf(stderr, "wrote genotypes to %s\n", pg.c_str());
   }
-  strl_ctx_destroy(ctx);
-  return 0;
+  return end_process(ctx);
 }
 
 // `strling _dump BAM`: SAM-like text of every record as the reader decoded it (reader self-check; needs no GPU)

@@ -1100,8 +1100,14 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
   bool any_skipped = false;
   int32_t max_tid = -1;
   uint32_t max_pos = 0;
-  ft.reserve(n_in);
-  for (uint64_t i = 0; i < n_in; ++i) {
+  // (the usual input -- `call` without -l / -b, `merge`'s reads the CLI has filtered already -- drops nothing: one pass to see
+  // that, and the caller's array is uploaded as it is instead of a copy of a whole genome's quarter gigabyte of treads)
+  bool drops = false;
+  for (uint64_t i = 0; i < n_in && !drops; ++i) drops = treads[i].tid < 0 ? (mode == STRL_MODE_MERGE || treads[i].tid < -1 || treads[i].split == STRL_SOFT_TAKEN) : treads[i].split == STRL_SOFT_TAKEN;
+  if (!drops) {
+    for (uint64_t i = 0; i < n_in; ++i) { max_tid = std::max(max_tid, treads[i].tid); max_pos = std::max(max_pos, treads[i].position); }
+  } else ft.reserve(n_in);
+  for (uint64_t i = 0; drops && i < n_in; ++i) {
     const strl_tread &t = treads[i];
     if (mode == STRL_MODE_MERGE && t.tid < 0) { any_skipped = true; continue; }   // unpack_file(drop_unplaced=true), merge.nim:101
     if (t.tid < -1) { set_error("tread %llu: tid %d", (unsigned long long)i, t.tid); return STRL_ERR_ARG; }
@@ -1121,7 +1127,8 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
     kept.push_back((uint32_t)i);
   }
   if (!any_skipped) kept.clear();                     // identity
-  const uint64_t n64 = ft.size();
+  const strl_tread *up = drops ? ft.data() : treads;
+  const uint64_t n64 = drops ? ft.size() : n_in;
   if (n64 > 0x7ffffff0ull) { set_error("too many treads"); return STRL_ERR_ARG; }
   const uint32_t n = (uint32_t)n64;
   if (stats) stats->n_treads = n;
@@ -1131,7 +1138,7 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
   int rc;
   if ((rc = B[B_TREADS].reserve((size_t)n * sizeof(strl_tread))) || (rc = B[B_CNT].reserve(CC_WORDS * 4))) return rc;
   hipStream_t st = c->stream;
-  STRL_HIP(hipMemcpyAsync(B[B_TREADS].p, ft.data(), (size_t)n * sizeof(strl_tread), hipMemcpyHostToDevice, st));
+  STRL_HIP(hipMemcpyAsync(B[B_TREADS].p, up, (size_t)n * sizeof(strl_tread), hipMemcpyHostToDevice, st));
   STRL_HIP(hipMemcpyAsync(B[B_CNT].p, &n, 4, hipMemcpyHostToDevice, st));
   c->cl_where = 0;
   ClusterRun &R = c->cl_run;

@@ -139,11 +139,14 @@ def run(inp, cli, threads=(0,), call=True, merge=True, repeats=1):
         else:
             res["call_stderr_tail"] = r.stderr[-600:]
     if merge:
-        r, wall = _timed([cli, "merge", "-o", inp["prefix"] + "-joint", inp["out"]], env)
+        r, wall = _timed([cli, "merge", "-v", "-o", inp["prefix"] + "-joint", inp["out"]], env)
         res["merge_s"] = round(wall, 3)
         res["merge_rc"] = r.returncode
         if r.returncode == 0:
             res["merge_bounds_rows"] = sum(1 for _ in open(inp["prefix"] + "-joint-bounds.txt")) - 1
+            ph = [l for l in r.stderr.splitlines() if "seconds:" in l]
+            if ph:
+                res["merge_phases"] = ph[-1].split("seconds:")[1].strip()
         else:
             res["merge_stderr_tail"] = r.stderr[-600:]
     res["note"] = ("`strling extract` BAM file (page cache) -> .bin: whole process wall clock incl. start-up (HIP context, page-locked buffers), copies of the "
