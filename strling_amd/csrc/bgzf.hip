@@ -107,36 +107,65 @@ __global__ __launch_bounds__(256) void crc32_kernel(const uint8_t *out, const ui
 // back to the host is the tenth of the inflated bytes the query returns, not all the index makes one read.
 struct RegionWalk { uint64_t start, stop; };
 __device__ __forceinline__ uint32_t rg_ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
-__global__ __launch_bounds__(64) void region_walk_kernel(const uint8_t *u, const uint64_t *uoff, const uint32_t *isize, const strl_region_req *req, uint32_t n,
+// One WAVE per region.  The walk is serial (a record's place follows from the length of the one before it) and, lane per
+// region straight out of global memory, every step was a dependent miss: 5 - 6 ms for ~4600 records.  Here the wave copies a
+// 4 KiB window of the stream into LDS with one coalesced load per KiB and every lane walks the ~13 records inside it out of
+// LDS (all lanes the same values: nothing diverges); a record whose cigar does not fit the window is read from global memory.
+constexpr uint32_t RW_WIN = 4096;
+__global__ __launch_bounds__(64) void region_walk_kernel(const uint8_t *u, uint64_t u_readable, const uint64_t *uoff, const uint32_t *isize, const strl_region_req *req, uint32_t n,
                                                           RegionWalk *range, uint8_t *status) {
-  const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) uint8_t win[RW_WIN];
+  const uint32_t r = blockIdx.x, lane = threadIdx.x;
   if (r >= n) return;
   const strl_region_req q = req[r];
   const uint32_t last = q.first_block + q.n_blocks - 1u;
   const uint64_t base = uoff[q.first_block], lim = uoff[last] + isize[last];
-  uint64_t p = base + q.in_block, keep = ~0ull;
+  uint64_t p = base + q.in_block, keep = ~0ull, w0 = 0, w1 = 0;      // the window holds u[w0, w1)
+  auto load_win = [&](uint64_t at) {
+    __builtin_amdgcn_wave_barrier();
+    w0 = at & ~(uint64_t)15;
+    w1 = w0 + RW_WIN < u_readable ? w0 + RW_WIN : u_readable;        // (u is allocated 64 bytes past the last block; bytes past `lim` are never interpreted)
+#pragma unroll
+    for (uint32_t k = 0; k < RW_WIN / 1024; ++k) {
+      const uint64_t o = w0 + 1024ull * k + 16ull * lane;
+      if (o + 16 <= w1) *reinterpret_cast<uint4 *>(win + 1024u * k + 16u * lane) = *reinterpret_cast<const uint4 *>(u + o);
+    }
+    w1 &= ~(uint64_t)15;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
   uint8_t st = 1;                                      // the inflated bytes end before a record that stops the query: the host reads this one itself
   while (p + 36 <= lim) {
-    const uint32_t bs = rg_ld32(u + p);
+    if (p < w0 || p + 36 > w1) {
+      load_win(p);
+      if (p + 36 > w1) break;
+    }
+    const uint8_t *h = win + (p - w0);
+    const uint32_t bs = rg_ld32(h);
     if (bs < 32u || bs > (1u << 28)) break;            // not a record (st stays 1: the host's reader gives the verdict)
-    const int32_t ref = (int32_t)rg_ld32(u + p + 4), pos = (int32_t)rg_ld32(u + p + 8);
+    const int32_t ref = (int32_t)rg_ld32(h + 4), pos = (int32_t)rg_ld32(h + 8);
     if (ref != q.tid || pos >= q.end) { st = 0; break; }
     if (p + 4 + bs > lim) break;
     if (keep == ~0ull) {
       // an upper bound of bam_endpos: every cigar operation counted as if it consumed the reference (a record that is dropped
       // here cannot overlap; one that is kept for nothing is filtered by strl_spanners like on the host path)
-      const uint32_t l_name = u[p + 12], n_cig = rg_ld32(u + p + 16) & 0xffffu;
+      const uint32_t l_name = h[12], n_cig = rg_ld32(h + 16) & 0xffffu;
+      const uint64_t need = 36ull + l_name + 4ull * n_cig;
       int64_t span = 1;
-      if (36ull + l_name + 4ull * n_cig <= 4ull + bs)
-        for (uint32_t k = 0; k < n_cig; ++k) span += rg_ld32(u + p + 36 + l_name + 4u * k) >> 4;
-      else span = 1ll << 40;                           // malformed: keep it, the host's parser reports it
+      if (need <= 4ull + bs) {
+        if (p + need > w1 && need <= RW_WIN - 16) { load_win(p); h = win + (p - w0); }
+        if (p + need <= w1) for (uint32_t k = 0; k < n_cig; ++k) span += rg_ld32(h + 36 + l_name + 4u * k) >> 4;
+        else for (uint32_t k = 0; k < n_cig; ++k) span += rg_ld32(u + p + 36 + l_name + 4u * k) >> 4;      // (a cigar of a thousand operations)
+      } else span = 1ll << 40;                         // malformed: keep it, the host's parser reports it
       if ((int64_t)pos + span > (int64_t)q.beg) keep = p;
     }
     p += 4ull + bs;
   }
   if (st == 0 && keep == ~0ull) keep = p;
-  range[r] = RegionWalk{st ? 0ull : keep, st ? 0ull : p};
-  status[r] = st;
+  if (lane == 0) {
+    range[r] = RegionWalk{st ? 0ull : keep, st ? 0ull : p};
+    status[r] = st;
+  }
 }
 // a block per region: bytes [start, stop) of `u` to out + off[r]; off[r] = start (mod 16), so the body moves in 16-byte pieces
 __global__ __launch_bounds__(256) void region_copy_kernel(const uint8_t *u, const RegionWalk *range, const uint64_t *off, uint32_t n, uint8_t *out) {
@@ -289,8 +318,24 @@ extern "C" int strl_regions_fetch(strl_ctx *c, const uint8_t *comp, uint64_t com
   }
   for (uint32_t r = 0; r < n_regions; ++r)
     if (!req[r].n_blocks || (uint64_t)req[r].first_block + req[r].n_blocks > n_blocks) { set_error("region %u names blocks that were not handed over", r); return STRL_ERR_ARG; }
-  DevBuf d_comp, d_meta, d_u, d_out, d_rq;
-  struct Rel { DevBuf *b[5]; ~Rel() { for (DevBuf *x : b) x->release(); } } rel{{&d_comp, &d_meta, &d_u, &d_out, &d_rq}};
+  // a slot of the context: its stream, its buffers (kept between calls: freeing gigabytes synchronises the device)
+  strl_ctx::RegionSlot *slot = nullptr;
+  {
+    std::unique_lock<std::mutex> lk(c->rg_mu);
+    c->rg_cv.wait(lk, [&] { return !c->rg[0].busy || !c->rg[1].busy; });
+    slot = !c->rg[0].busy ? &c->rg[0] : &c->rg[1];
+    slot->busy = true;
+    if (crc32 && !c->crc_tab.p) {                       // (made once, by whichever call comes first)
+      if (c->crc_tab.reserve(sizeof(CrcTables)) != STRL_OK || hipMemcpy(c->crc_tab.p, &crc_tables(), sizeof(CrcTables), hipMemcpyHostToDevice) != hipSuccess) {
+        slot->busy = false;
+        set_error("CRC tables");
+        return STRL_ERR_HIP;
+      }
+    }
+  }
+  struct Rel { strl_ctx *c; strl_ctx::RegionSlot *s; ~Rel() { { std::lock_guard<std::mutex> lk(c->rg_mu); s->busy = false; } c->rg_cv.notify_all(); } } rel{c, slot};
+  if (!slot->st) STRL_HIP(hipStreamCreateWithFlags(&slot->st, hipStreamNonBlocking));
+  DevBuf &d_comp = slot->comp, &d_meta = slot->meta, &d_u = slot->u, &d_out = slot->out, &d_rq = slot->rq;
   int rc;
   const uint64_t readable = (comp_bytes + 3) & ~(uint64_t)3;
   const size_t meta = (size_t)n_blocks * (8 + 8 + 4 + 4 + 4) + 64;
@@ -302,7 +347,7 @@ extern "C" int strl_regions_fetch(strl_ctx *c, const uint8_t *comp, uint64_t com
   uint64_t *d_off = reinterpret_cast<uint64_t *>(d_range + n_regions);
   strl_region_req *d_req = reinterpret_cast<strl_region_req *>(d_off + n_regions);
   uint8_t *d_status = reinterpret_cast<uint8_t *>(d_req + n_regions);
-  hipStream_t st = c->stream;
+  hipStream_t st = slot->st;
   STRL_HIP(hipMemcpyAsync(d_comp.p, comp, comp_bytes, hipMemcpyHostToDevice, st));
   STRL_HIP(hipMemsetAsync(static_cast<uint8_t *>(d_comp.p) + comp_bytes, 0, 16, st));
   STRL_HIP(hipMemcpyAsync(m_coff, coff, (size_t)n_blocks * 8, hipMemcpyHostToDevice, st));
@@ -314,7 +359,7 @@ extern "C" int strl_regions_fetch(strl_ctx *c, const uint8_t *comp, uint64_t com
   STRL_HIP(hipMemsetAsync(m_err, 0, 4, st));
   if ((rc = strl_inflate_device(c, d_comp.as<uint8_t>(), readable, m_coff, m_clen, m_uoff, m_isize, n_blocks, d_u.as<uint8_t>(), m_err, nullptr, st))) return rc;
   if (crc32 && (rc = strl_crc_device(c, d_u.as<uint8_t>(), m_uoff, m_isize, m_crc, n_blocks, nullptr, m_err, st))) return rc;
-  hipLaunchKernelGGL(region_walk_kernel, dim3((n_regions + 63) / 64), dim3(64), 0, st, d_u.as<uint8_t>(), m_uoff, m_isize, d_req, n_regions, d_range, d_status);
+  hipLaunchKernelGGL(region_walk_kernel, dim3(n_regions), dim3(64), 0, st, d_u.as<uint8_t>(), (tot + 64) & ~(uint64_t)15, m_uoff, m_isize, d_req, n_regions, d_range, d_status);
   STRL_HIP(hipGetLastError());
   std::vector<RegionWalk> range(n_regions);
   uint32_t err = 0;

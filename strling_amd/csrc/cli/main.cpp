@@ -1266,6 +1266,39 @@ static int merge_main(int argc, char **argv) {
   return end_process(ctx);
 }
 
+// The run of BGZF blocks the walk of one region query (BamReader::read_region) passes through, as far as the .bai linear
+// index can bound it: from the block of the index offset of `beg`'s window up to the block that holds the first record
+// overlapping a later window than `end`'s -- and the one behind it --, their sizes read from the block headers and trailers
+// (18 + 8 bytes per block).  ok = false: the index does not bound the region, the file is laid out unusually (other extra
+// subfields than BC), the run is longer than 8 MB: such a region is read by the host reader.
+struct RegionPlan { bool ok = false; uint64_t c_beg = 0, c_end = 0; uint32_t in_block = 0; std::vector<uint32_t> hdr, bsize, isz, crc; };
+static void plan_region(const BamReader &rd, int fd, int32_t tid, int64_t beg, int64_t end, RegionPlan &P) {
+  uint64_t c_hint = 0;
+  P.ok = false;
+  if (!rd.region_span(tid, beg, end, P.c_beg, P.in_block, c_hint)) return;
+  uint64_t o = P.c_beg, infl = 0;
+  int beyond = 0;
+  bool good = true;
+  while (beyond < 2 && infl < ((uint64_t)8 << 20) && P.bsize.size() < 4096) {   // (a window of 30x data is ~1 MB)
+    uint8_t h[18], tr[8];
+    if (pread(fd, h, 18, (off_t)o) != 18) break;                                  // end of the file
+    const uint32_t xlen = h[10] | (h[11] << 8);
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4) || xlen != 6 || h[12] != 'B' || h[13] != 'C') { good = false; break; }
+    const uint32_t bsize = (h[16] | (h[17] << 8)) + 1u;
+    if (bsize < 26 || pread(fd, tr, 8, (off_t)(o + bsize - 8)) != 8) { good = false; break; }
+    uint32_t crc, isz;
+    memcpy(&crc, tr, 4); memcpy(&isz, tr + 4, 4);
+    if (isz > 65536u) { good = false; break; }
+    P.hdr.push_back(18); P.bsize.push_back(bsize); P.isz.push_back(isz); P.crc.push_back(crc);
+    infl += isz;
+    if (o >= c_hint) ++beyond;
+    o += bsize;
+  }
+  P.c_end = o;
+  // the first block must hold the index offset; a run that did not reach the hinted block goes to the host reader
+  P.ok = good && beyond >= 1 && !P.bsize.empty() && P.in_block <= P.isz[0];
+}
+
 // call.nim:51-285
 static int call_main(int argc, char **argv) {
   const char *usage =
@@ -1394,10 +1427,9 @@ static int call_main(int argc, char **argv) {
   // The regions of many bounds through the device (strl_regions_fetch): the .bai linear index gives every region's run of
   // BGZF blocks; their compressed bytes are read into page-locked memory, inflated on the GPU -- which also cuts out the
   // records the query returns -- and the workers are left with parsing a few hundred records and the rules per bound.  The
-  // host path inflates ~10 blocks per bound on a CPU (2 - 3 ms): that was the whole evidence step.  Batches of ~2 GB of
-  // inflated bytes; batch i + 1 is read and inflated while the workers are on batch i.  STRL_CALL_REGIONS=host keeps the
+  // host path inflates ~10 blocks per bound on a CPU (2 - 3 ms): that was the whole evidence step.  Batches of 384 MB of
+  // inflated bytes (128 ... 768 MB measured alike); one batch is being read while two are on the device and one with the workers.  STRL_CALL_REGIONS=host keeps the
   // host path; a region whose blocks the index cannot bound, and CRAM input, take it by themselves.
-  struct RegionPlan { bool ok = false; uint64_t c_beg = 0, c_end = 0; uint32_t in_block = 0; std::vector<uint32_t> hdr, bsize, isz, crc; };
   struct Batch {
     size_t t0 = 0, t1 = 0;
     std::vector<uint32_t> which;            // tasks of [t0, t1) that go through the device
@@ -1411,11 +1443,12 @@ static int call_main(int argc, char **argv) {
   };
   const char *regions_env = getenv("STRL_CALL_REGIONS");
   const bool device_regions = !rd.is_cram() && !(regions_env && !strcmp(regions_env, "host"));
-  const uint64_t batch_inflated = getenv("STRL_CALL_BATCH_MB") ? (uint64_t)atoll(getenv("STRL_CALL_BATCH_MB")) << 20 : (uint64_t)2048 << 20;
+  const uint64_t batch_inflated = getenv("STRL_CALL_BATCH_MB") ? (uint64_t)atoll(getenv("STRL_CALL_BATCH_MB")) << 20 : (uint64_t)384 << 20;
   int region_fd = -1;
-  uint8_t *pin_comp[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
-  uint64_t pin_comp_cap[2] = {0, 0}, pin_out_cap[2] = {0, 0};
-  double t_plan = 0, t_fetch = 0, t_wait_fetch = 0;
+  constexpr size_t NSETS = 4;      // batches in flight: one being read, two on the device (its two region slots), one with the workers
+  uint8_t *pin_comp[NSETS] = {}, *pin_out[NSETS] = {};
+  uint64_t pin_comp_cap[NSETS] = {}, pin_out_cap[NSETS] = {};
+  double t_plan = 0, t_fetch = 0, t_wait_fetch = 0, t_pin = 0, t_pread = 0;
   uint64_t n_dev_regions = 0, n_host_regions = 0, dev_comp_bytes = 0, dev_inflated = 0, dev_kept = 0;
   auto run_tasks = [&](const std::vector<Task> &tasks) {
     if (tasks.empty()) return;
@@ -1467,30 +1500,7 @@ static int call_main(int argc, char **argv) {
           const Task &t = tasks[j];
           RegionPlan &P = plan[j];
           const int64_t wl = std::max<int64_t>(0, (int64_t)t.b.left - window), wr = (int64_t)t.b.right + window;
-          uint64_t c_hint = 0;
-          if (!rd.region_span(t.b.tid, wl, std::min<int64_t>(wr, INT32_MAX), P.c_beg, P.in_block, c_hint)) continue;
-          uint64_t o = P.c_beg;
-          int beyond = 0;
-          bool good = true;
-          uint64_t infl = 0;
-          while (beyond < 2 && infl < ((uint64_t)8 << 20) && P.bsize.size() < 4096) {   // up to the hinted block and the one behind it (a window of 30x data is ~1 MB)
-            uint8_t h[18], tr[8];
-            if (pread(region_fd, h, 18, (off_t)o) != 18) break;                       // end of the file
-            const uint32_t xlen = h[10] | (h[11] << 8);
-            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4) || xlen != 6 || h[12] != 'B' || h[13] != 'C') { good = false; break; }   // (other layouts: the host reader copes)
-            const uint32_t bsize = (h[16] | (h[17] << 8)) + 1u;
-            if (bsize < 26 || pread(region_fd, tr, 8, (off_t)(o + bsize - 8)) != 8) { good = false; break; }
-            uint32_t crc, isz;
-            memcpy(&crc, tr, 4); memcpy(&isz, tr + 4, 4);
-            if (isz > 65536u) { good = false; break; }
-            P.hdr.push_back(18); P.bsize.push_back(bsize); P.isz.push_back(isz); P.crc.push_back(crc);
-            infl += isz;
-            if (o >= c_hint) ++beyond;
-            o += bsize;
-          }
-          P.c_end = o;
-          // the first block must hold the index offset; a run that did not reach the hinted block goes to the host reader
-          P.ok = good && beyond >= 1 && !P.bsize.empty() && P.in_block <= P.isz[0];
+          plan_region(rd, region_fd, t.b.tid, wl, std::min<int64_t>(wr, INT32_MAX), P);
         }
       });
       t_plan += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();
@@ -1525,59 +1535,94 @@ static int call_main(int argc, char **argv) {
         B.t1 = j;
         batches.push_back(std::move(B));
       }
-      // ---- fetch (reads + device) of batch i + 1 beside the workers' batch i
+      // ---- three stages side by side over NSETS buffer sets: a reader (compressed bytes of batch i + 2 into page-locked
+      // memory), the device (strl_regions_fetch of batch i + 1), the workers (batch i)
       ThreadPool io_pool(std::max(2, std::min(n_workers / 3, 8)));
-      auto fetch = [&](size_t bi) {
-        Batch &B = batches[bi];
-        const int s = (int)(bi & 1);
-        if (B.which.empty()) return;
-        const auto tf0 = std::chrono::steady_clock::now();
-        if (pin_comp_cap[s] < B.comp_bytes + 64) {
-          if (pin_comp[s]) strl_pinned_free(pin_comp[s]);
-          pin_comp_cap[s] = B.comp_bytes + B.comp_bytes / 8 + 64;
-          pin_comp[s] = static_cast<uint8_t *>(strl_pinned_alloc(pin_comp_cap[s]));
-        }
-        if (pin_out_cap[s] < B.inflated + 32 * B.which.size() + 64) {      // (every region's piece is padded to its source's offset modulo 16)
-          if (pin_out[s]) strl_pinned_free(pin_out[s]);
-          pin_out_cap[s] = B.inflated + B.inflated / 8 + 32 * B.which.size() + 64;
-          pin_out[s] = static_cast<uint8_t *>(strl_pinned_alloc(pin_out_cap[s]));
-        }
-        if (!pin_comp[s] || !pin_out[s]) { B.rc = STRL_ERR_HIP; B.err = "page-locked memory for the region reads"; return; }
-        std::atomic<bool> io_bad{false};
-        io_pool.parallel_for((B.which.size() + 15) / 16, [&](size_t blk) {
-          for (size_t k = blk * 16; k < std::min(B.which.size(), (blk + 1) * 16); ++k) {
-            const RegionPlan &P = plan[B.which[k]];
-            const uint64_t at = B.coff[B.req[k].first_block] - P.hdr[0], len = P.c_end - P.c_beg;
-            uint64_t got = 0;
-            while (got < len) {
-              const ssize_t r = pread(region_fd, pin_comp[s] + at + got, (size_t)(len - got), (off_t)(P.c_beg + got));
-              if (r <= 0) { io_bad = true; break; }
-              got += (uint64_t)r;
+      std::mutex pm;
+      std::condition_variable pcv;
+      size_t n_read = 0, n_done = 0;                     // batches that left the reader / the workers
+      std::vector<char> fetched(batches.size(), 0);      // ... the device (two threads, alternate batches)
+      bool stop_stages = false;
+      auto read_stage = [&] {
+        for (size_t bi = 0; bi < batches.size(); ++bi) {
+          { std::unique_lock<std::mutex> lk(pm); pcv.wait(lk, [&] { return stop_stages || bi < n_done + NSETS; }); if (stop_stages) return; }
+          Batch &B = batches[bi];
+          const int s = (int)(bi % NSETS);
+          if (!B.which.empty()) {
+            const auto tr0 = std::chrono::steady_clock::now();
+            const uint64_t want_out = B.inflated / 3 + 32 * B.which.size() + (1 << 20);   // what a query returns is a fifth of what the index makes one read; more: STRL_ERR_CAPACITY -> host reader
+            if (pin_comp_cap[s] < B.comp_bytes + 64) {
+              if (pin_comp[s]) strl_pinned_free(pin_comp[s]);
+              pin_comp_cap[s] = B.comp_bytes + B.comp_bytes / 4 + 64;
+              pin_comp[s] = static_cast<uint8_t *>(strl_pinned_alloc(pin_comp_cap[s]));
             }
+            if (pin_out_cap[s] < want_out) {
+              if (pin_out[s]) strl_pinned_free(pin_out[s]);
+              pin_out_cap[s] = want_out + want_out / 4;
+              pin_out[s] = static_cast<uint8_t *>(strl_pinned_alloc(pin_out_cap[s]));
+            }
+            const auto tr1 = std::chrono::steady_clock::now();
+            t_pin += std::chrono::duration<double>(tr1 - tr0).count();
+            if (!pin_comp[s] || !pin_out[s]) { B.rc = STRL_ERR_HIP; B.err = "page-locked memory for the region reads"; }
+            else {
+              std::atomic<bool> io_bad{false};
+              io_pool.parallel_for((B.which.size() + 15) / 16, [&](size_t blk) {
+                for (size_t k = blk * 16; k < std::min(B.which.size(), (blk + 1) * 16); ++k) {
+                  const RegionPlan &P = plan[B.which[k]];
+                  const uint64_t at = B.coff[B.req[k].first_block] - P.hdr[0], len = P.c_end - P.c_beg;
+                  uint64_t got = 0;
+                  while (got < len) {
+                    const ssize_t r = pread(region_fd, pin_comp[s] + at + got, (size_t)(len - got), (off_t)(P.c_beg + got));
+                    if (r <= 0) { io_bad = true; break; }
+                    got += (uint64_t)r;
+                  }
+                }
+              });
+              if (io_bad.load()) { B.rc = STRL_ERR_IO; B.err = "reading " + bam; }
+            }
+            t_pread += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr1).count();
           }
-        });
-        if (io_bad.load()) { B.rc = STRL_ERR_IO; B.err = "reading " + bam; return; }
-        B.out_off.assign(B.which.size(), 0); B.out_len.assign(B.which.size(), 0); B.status.assign(B.which.size(), 1);
-        B.rc = strl_regions_fetch(ctx, pin_comp[s], B.comp_bytes, B.coff.data(), B.clen.data(), B.isize.data(), B.crc.data(), (uint32_t)B.clen.size(), B.req.data(),
-                                  (uint32_t)B.req.size(), pin_out[s], pin_out_cap[s], B.out_off.data(), B.out_len.data(), B.status.data());
-        if (B.rc) B.err = strl_last_error();
-        t_fetch += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
+          { std::lock_guard<std::mutex> lk(pm); n_read = bi + 1; }
+          pcv.notify_all();
+        }
       };
-      std::thread fetcher;
-      if (!batches.empty()) fetcher = std::thread(fetch, 0);
+      auto device_stage = [&](size_t first) {
+        for (size_t bi = first; bi < batches.size(); bi += 2) {
+          { std::unique_lock<std::mutex> lk(pm); pcv.wait(lk, [&] { return stop_stages || bi < n_read; }); if (stop_stages) return; }
+          Batch &B = batches[bi];
+          const int s = (int)(bi % NSETS);
+          if (!B.which.empty() && !B.rc) {
+            const auto tf0 = std::chrono::steady_clock::now();
+            B.out_off.assign(B.which.size(), 0); B.out_len.assign(B.which.size(), 0); B.status.assign(B.which.size(), 1);
+            B.rc = strl_regions_fetch(ctx, pin_comp[s], B.comp_bytes, B.coff.data(), B.clen.data(), B.isize.data(), B.crc.data(), (uint32_t)B.clen.size(), B.req.data(),
+                                      (uint32_t)B.req.size(), pin_out[s], pin_out_cap[s], B.out_off.data(), B.out_len.data(), B.status.data());
+            if (B.rc) B.err = strl_last_error();
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
+            { std::lock_guard<std::mutex> lk(pm); t_fetch += dt; }
+          }
+          { std::lock_guard<std::mutex> lk(pm); fetched[bi] = 1; }
+          pcv.notify_all();
+        }
+      };
+      std::thread reader(read_stage), fetcher(device_stage, (size_t)0), fetcher2(device_stage, (size_t)1);
       for (size_t bi = 0; bi < batches.size() && !failed.load(); ++bi) {
         const auto tq0 = std::chrono::steady_clock::now();
-        fetcher.join();
+        { std::unique_lock<std::mutex> lk(pm); pcv.wait(lk, [&] { return fetched[bi] != 0; }); }
         t_wait_fetch += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count();
         Batch &B = batches[bi];
         if (B.rc == STRL_ERR_FORMAT || B.rc == STRL_ERR_CRC || B.rc == STRL_ERR_CAPACITY) {
-          // a block the device decoder does not take (or damaged data): the host reader, zlib behind it, has the last word on every region of the batch
+          // a block the device decoder does not take, damaged data, more records than the buffer was sized for: the host
+          // reader, zlib behind it, has the last word on every region of the batch
           B.status.assign(B.which.size(), 1);
           B.rc = 0;
         }
-        if (B.rc) quit("[strling] error reading %s: %s (status %d)", bam.c_str(), B.err.c_str(), B.rc);
-        if (bi + 1 < batches.size()) fetcher = std::thread(fetch, bi + 1);
-        const int s = (int)(bi & 1);
+        if (B.rc) {
+          { std::lock_guard<std::mutex> lk(pm); stop_stages = true; }
+          pcv.notify_all();
+          reader.join(); fetcher.join(); fetcher2.join();
+          quit("[strling] error reading %s: %s (status %d)", bam.c_str(), B.err.c_str(), B.rc);
+        }
+        const int s = (int)(bi % NSETS);
         // position of every task of the batch among its device regions (-1: host)
         std::vector<int64_t> slot(B.t1 - B.t0, -1);
         for (size_t k = 0; k < B.which.size(); ++k) {
@@ -1601,8 +1646,14 @@ static int call_main(int argc, char **argv) {
             }
           });
         });
+        { std::lock_guard<std::mutex> lk(pm); n_done = bi + 1; }
+        pcv.notify_all();
       }
-      if (fetcher.joinable()) fetcher.join();
+      { std::lock_guard<std::mutex> lk(pm); stop_stages = true; }
+      pcv.notify_all();
+      reader.join();
+      fetcher.join();
+      fetcher2.join();
     }
     if (failed.load()) quit("%s", fail_msg.c_str());
     for (const Done &d : done) {
@@ -1670,9 +1721,9 @@ static int call_main(int argc, char **argv) {
   }
   if (verbose)
     fprintf(stderr, "[strling] seconds: device context + .bin + fragment lengths + index, side by side %.3f  clustering (upload, sort, sweep, bounds, members) %.3f  evidence + genotypes of %llu bounds on %d threads %.3f (summed over the threads: region records %.3f, spanners + genotype %.3f; regions through the device %llu, on the host %llu: "
-            "index + block headers %.3f, reads + device fetch %.3f of which the workers waited %.3f, %.1f MB compressed -> %.1f MB inflated -> %.1f MB of records)  since the start %.3f\n",
+            "index + block headers %.3f, page-locked buffers %.3f, reads %.3f, device fetch %.3f (two at a time), the workers waited %.3f for them, %.1f MB compressed -> %.1f MB inflated -> %.1f MB of records)  since the start %.3f\n",
             t_start_up, std::chrono::duration<double>(tc2 - tc1).count(), (unsigned long long)nb, n_workers, t_evidence, (double)ns_region.load() * 1e-9, (double)ns_rules.load() * 1e-9,
-            (unsigned long long)n_dev_regions, (unsigned long long)n_host_regions, t_plan, t_fetch, t_wait_fetch, (double)dev_comp_bytes / 1e6, (double)dev_inflated / 1e6, (double)dev_kept / 1e6,
+            (unsigned long long)n_dev_regions, (unsigned long long)n_host_regions, t_plan, t_pin, t_pread, t_fetch, t_wait_fetch, (double)dev_comp_bytes / 1e6, (double)dev_inflated / 1e6, (double)dev_kept / 1e6,
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call0).count());
   char row[2048];
   std::vector<uint64_t> order(std::max<size_t>(calls.size(), 1)), uorder(std::max<size_t>((size_t)nu, 1));
@@ -1762,7 +1813,7 @@ static int decode_main(int argc, char **argv) {
 }
 
 static int region_main(int argc, char **argv) {
-  if (argc < 6) quit("usage: strling _region BAM TID BEG END");
+  if (argc < 6) quit("usage: strling _region BAM TID BEG END [plan]");
   BamReader rd;
   std::string err;
   if (getenv("STRL_CRAM_FASTA")) g_cram_fasta = getenv("STRL_CRAM_FASTA");
@@ -1770,7 +1821,60 @@ static int region_main(int argc, char **argv) {
   const int32_t tid = atoi(argv[3]);
   const int64_t beg = atoll(argv[4]), end = atoll(argv[5]);
   RecordBatch b;
-  const int64_t got = rd.read_region(b, tid, beg, end, err);
+  int64_t got = -1;
+  if (argc > 6 && !strcmp(argv[6], "plan")) {
+    // what `strling call` does for the bounds' evidence, with zlib in the place of the device: the region's run of blocks from
+    // the index (plan_region), inflated, walked by strl_regions_fetch's rule (keep from the first record whose cigar could
+    // reach past `beg`, stop at the first record on another reference or at / behind `end`), parsed by append_records
+    const int fd = open(argv[2], O_RDONLY);
+    if (fd < 0) quit("couldn't open bam");
+    RegionPlan P;
+    plan_region(rd, fd, tid, beg, end, P);
+    if (!P.ok) { fprintf(stderr, "plan: host reader\n"); got = rd.read_region(b, tid, beg, end, err); }
+    else {
+      std::vector<uint8_t> comp((size_t)(P.c_end - P.c_beg)), u;
+      if (pread(fd, comp.data(), comp.size(), (off_t)P.c_beg) != (ssize_t)comp.size()) quit("short read");
+      size_t o = 0;
+      for (size_t k = 0; k < P.bsize.size(); ++k) {
+        const size_t at = u.size();
+        u.resize(at + P.isz[k]);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) quit("zlib");
+        zs.next_in = comp.data() + o + P.hdr[k]; zs.avail_in = P.bsize[k] - P.hdr[k] - 8;
+        zs.next_out = u.data() + at; zs.avail_out = P.isz[k];
+        if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.total_out != P.isz[k]) quit("inflate");
+        inflateEnd(&zs);
+        if ((uint32_t)crc32(0, u.data() + at, P.isz[k]) != P.crc[k]) quit("crc");
+        o += P.bsize[k];
+      }
+      size_t p = P.in_block, keep = SIZE_MAX;
+      bool stopped = false;
+      while (p + 36 <= u.size()) {
+        int32_t bs, ref, pos;
+        memcpy(&bs, &u[p], 4); memcpy(&ref, &u[p + 4], 4); memcpy(&pos, &u[p + 8], 4);
+        if (bs < 32) break;
+        if (ref != tid || pos >= end) { stopped = true; break; }
+        if (p + 4 + (size_t)bs > u.size()) break;
+        if (keep == SIZE_MAX) {
+          const uint32_t l_name = u[p + 12];
+          uint16_t n_cig;
+          memcpy(&n_cig, &u[p + 16], 2);
+          int64_t span = 1;
+          for (uint32_t k = 0; k < n_cig; ++k) { uint32_t c; memcpy(&c, &u[p + 36 + l_name + 4 * k], 4); span += c >> 4; }
+          if ((int64_t)pos + span > beg) keep = p;
+        }
+        p += 4 + (size_t)bs;
+      }
+      if (!stopped) { fprintf(stderr, "plan: blocks end before the query does, host reader\n"); got = rd.read_region(b, tid, beg, end, err); }
+      else {
+        if (keep == SIZE_MAX) keep = p;
+        fprintf(stderr, "plan: %zu blocks, %zu inflated bytes, records in [%zu, %zu)\n", P.bsize.size(), u.size(), keep, p);
+        got = BamReader::append_records(b, u.data() + keep, p - keep, err);
+      }
+    }
+    close(fd);
+  } else got = rd.read_region(b, tid, beg, end, err);
   if (got < 0) quit("[strling] error reading %s: %s", argv[2], err.c_str());
   int64_t kept = 0;
   for (size_t i = 0; i < b.size(); ++i) {

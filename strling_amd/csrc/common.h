@@ -1,5 +1,7 @@
 // common.h -- internal declarations shared by the C-ABI translation units.
 #pragma once
+#include <condition_variable>
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>
@@ -173,6 +175,12 @@ struct strl_ctx {
   bool x_open = false, x_mode = false;
   bool x_front = false;            // the chunks came through the device front end: qnames of all records sit in its arena
   strl::DevBuf crc_tab;            // tables of the BGZF CRC-32 check (bgzf.hip)
+  // strl_regions_fetch (bgzf.hip): two calls of different host threads run side by side, each on its slot's stream with its
+  // slot's buffers (kept between calls) -- the copies of one batch of regions pass beside the inflate of the other
+  struct RegionSlot { hipStream_t st = nullptr; strl::DevBuf comp, meta, u, out, rq; bool busy = false; };
+  RegionSlot rg[2];
+  std::mutex rg_mu;
+  std::condition_variable rg_cv;
   strl::DevBuf p_spill;            // pair logic: first items of the hash runs too long for the in-block replay
   bool pg_attr_done = false;
   hipEvent_t pev[6] = {};

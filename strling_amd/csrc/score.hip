@@ -916,6 +916,10 @@ void strl_ctx_destroy(strl_ctx *c) {
                           &c->p_key0, &c->p_key1, &c->p_val0, &c->p_val1, &c->p_emit, &c->sort_scratch, &c->pair_cnt, &c->bloom, &c->treads,
                           &c->st_mtid, &c->st_mpos, &c->st_flag, &c->st_qhash, &c->x_rows, &c->x_qhash, &c->x_whole, &c->x_soft, &c->x_cnt, &c->g_aux, &c->crc_tab, &c->p_spill};
   for (auto *b : bufs) b->release();
+  for (auto &r : c->rg) {
+    if (r.st) { (void)hipStreamSynchronize(r.st); (void)hipStreamDestroy(r.st); }
+    r.comp.release(); r.meta.release(); r.u.release(); r.out.release(); r.rq.release();
+  }
   for (auto &b : c->c_buf) b.release();
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->pev) if (e) (void)hipEventDestroy(e);

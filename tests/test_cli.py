@@ -102,6 +102,29 @@ def test_indexed_region_reads(tmp_path):
     assert sum(1 for t, b, e in regions if np.any((rec.tid == t) & (rec.pos < e) & (stop > b))) > 15
 
 
+@pytest.mark.parametrize("block", [0xFF00, 2500])
+def test_planned_region_reads(tmp_path, block):
+    """the host half of `strling call`'s evidence reads on the device -- index span, run of blocks from their headers, the walk
+    rule of strl_regions_fetch (zlib standing in for the GPU), the in-memory record parser -- returns htslib's records too"""
+    rec, _ = synth.synth_wgs(5000, seed=4, n_contigs=3, contig_len=200_000)
+    bam = str(tmp_path / "r.bam")
+    bamio.write_bam(bam, rec, block=block, level=6)
+    stop = np.array([int(rec.pos[i]) + bamio._ref_len(rec, i) for i in range(rec.n)])
+    rng = np.random.default_rng(2)
+    regions = [(0, 0, 500), (2, 199_000, 200_500), (1, 16_300, 16_400), (1, 150_000, 150_001), (0, 100_000, 140_000), (2, 0, 1), (1, 16_000, 33_000)]
+    regions += [(int(rng.integers(0, 3)), int(a), int(a) + int(rng.integers(1, 3000))) for a in rng.integers(0, 199_000, 25)]
+    planned = 0
+    for tid, beg, end in regions:
+        r = _run(["_region", bam, str(tid), str(beg), str(end), "plan"])
+        assert r.returncode == 0, r.stderr
+        planned += "plan: " in r.stderr and "host reader" not in r.stderr
+        got = [tuple(l.split("\t")) for l in r.stdout.splitlines()]
+        sel = np.nonzero((rec.tid == tid) & (rec.pos < end) & (stop > beg))[0]
+        exp = [(rec.qname(i).decode(), str(int(rec.pos[i])), str(int(rec.flag[i]))) for i in sel]
+        assert got == exp, (tid, beg, end, r.stderr)
+    assert planned >= 20
+
+
 @pytest.mark.gpu
 def test_extract_bin_is_byte_identical_to_oracle(sample, oracle):
     """strling extract BAM BIN  ==  the oracle's extract + .bin writer, byte for byte (several GPU batches)."""
