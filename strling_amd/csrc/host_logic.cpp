@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <unistd.h>
 #include <algorithm>
 #include <condition_variable>
 #include <functional>
@@ -677,8 +678,30 @@ int strl_bin_write(const char *path, float proportion_repeat, uint8_t min_mapq, 
         for (uint64_t q; (q = next.fetch_add(1)) < n_parts;) { parts[(size_t)q].reserve((size_t)per * 40); pack(parts[(size_t)q], q * per, std::min(n, (q + 1) * per)); }
       });
     for (auto &t : th) t.join();
-    for (const std::string &o : parts)
-      if (fwrite(o.data(), 1, o.size(), f) != o.size()) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; }
+    // ... and written by the same number of threads, every part at its place (a quarter of a gigabyte through one fwrite loop
+    // was 0.15 s behind a 2.5 s extract)
+    fflush(f);
+    const off_t base = ftello(f);
+    std::vector<off_t> at((size_t)n_parts + 1, base);
+    for (uint64_t q = 0; q < n_parts; ++q) at[(size_t)q + 1] = at[(size_t)q] + (off_t)parts[(size_t)q].size();
+    const int fd = fileno(f);
+    std::atomic<bool> bad{false};
+    next = 0;
+    th.clear();
+    for (unsigned k = 0; k < n_thr; ++k)
+      th.emplace_back([&] {
+        for (uint64_t q; (q = next.fetch_add(1)) < n_parts;) {
+          const std::string &o = parts[(size_t)q];
+          size_t done = 0;
+          while (done < o.size()) {
+            const ssize_t w = pwrite(fd, o.data() + done, o.size() - done, at[(size_t)q] + (off_t)done);
+            if (w <= 0) { bad = true; break; }
+            done += (size_t)w;
+          }
+        }
+      });
+    for (auto &t : th) t.join();
+    if (bad.load() || fseeko(f, at[(size_t)n_parts], SEEK_SET) != 0) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; }
   }
   if (fwrite(b.data(), 1, b.size(), f) != b.size()) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; }
   fclose(f);

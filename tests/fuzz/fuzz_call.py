@@ -17,7 +17,14 @@ CLI = build.CLI
 
 
 def run(args):
-    r = subprocess.run([CLI] + args, capture_output=True, text=True)
+    env = dict(os.environ)
+    if args[0] == "call":        # the evidence reads through the device in batches of one region / 1 MB / the default, or on the host
+        mode = int(rng.integers(0, 4))
+        if mode == 3:
+            env["STRL_CALL_REGIONS"] = "host"
+        elif mode < 2:
+            env["STRL_CALL_BATCH_MB"] = str(mode)
+    r = subprocess.run([CLI] + args, capture_output=True, text=True, env=env)
     assert r.returncode == 0, (args, r.stderr[-600:])
     return r
 
@@ -42,7 +49,7 @@ with tempfile.TemporaryDirectory() as d:
     while time.time() - t0 < budget:
         seed = int(rng.integers(1, 1 << 30))
         nc = int(rng.choice([2, 3, 5]))
-        kw = dict(n_contigs=nc, contig_len=int(rng.choice([20_000, 40_000, 80_000])), str_frac=float(rng.choice([0.01, 0.05, 0.15])),
+        kw = dict(n_contigs=nc, contig_len=int(rng.choice([20_000, 40_000, 80_000, 160_000])), str_frac=float(rng.choice([0.01, 0.05, 0.15])),
                   soft_frac=float(rng.choice([0.03, 0.15])), unmapped_frac=float(rng.choice([0.005, 0.03])))
         n_pairs = int(rng.choice([3000, 6000, 12000]))
         m, q = int(rng.choice([2, 3, 5])), int(rng.choice([0, 20, 40]))
@@ -62,7 +69,7 @@ with tempfile.TemporaryDirectory() as d:
                 fa_args = ["-f", os.path.join(d, "ref.fa")]
                 n_cram += 1
             else:
-                bamio.write_bam(bam, rec)
+                bamio.write_bam(bam, rec, block=int(rng.choice([0xFF00, 0xFF00, 3000, 700])), level=int(rng.choice([1, 6])))   # (small blocks: many per 16 KiB index window, records across block ends)
             bamio.write_genome_bed(bed, g, rec.targets)
             run(["extract"] + fa_args + ["-g", bed, "-q", str(q), bam, binp])
             frag = synth.frag_hist(rec)

@@ -158,3 +158,22 @@ def test_bounds_row(oracle):
         ob[f] = b[f]
     assert oracle.bounds_row(ob[0], "chr1") == row
     assert len(row.split("\t")) == 11                                    # parse_boundsline requires 11 fields (cluster.nim:146)
+
+
+def test_bin_writer_threads_bytes(tmp_path, batch, oracle):
+    """past 2^18 treads strl_bin_write packs and writes in parts on several threads: the bytes are the sequential writer's"""
+    rec, g = batch
+    exp = oracle.extract(rec, g, oracle.make_opts(350, 0.8, 40))
+    assert len(exp) > 20
+    reps = (300_000 + len(exp) - 1) // len(exp)
+    big = np.concatenate([exp] * reps)
+    frag = synth.frag_hist(rec)
+    hdr = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in rec.targets)
+    t = np.zeros(len(big), api.TREAD_DTYPE)
+    for f in t.dtype.names:
+        t[f] = big[f]
+    path = str(tmp_path / "big.bin")
+    api.bin_write(path, 0.8, 40, frag, hdr, t, rec.qname_off, rec.qnames)
+    assert open(path, "rb").read() == oracle.bin_write(0.8, 40, frag, hdr, big, rec.qname_off, rec.qnames)
+    back = api.bin_read(path)
+    assert len(back["treads"]) == len(big) and np.array_equal(back["treads"]["position"], big["position"])
