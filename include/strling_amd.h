@@ -496,7 +496,8 @@ int strl_ctx_inflate_ms(strl_ctx *ctx, double *ms);
  * order) from the first record that may reach past `beg` up to, not including, the first record with another refID or
  * pos >= end -- a superset of htslib's iterator filter (tid equal, pos < end, bam_endpos > beg), which strl_spanners applies.
  * status[r] = 0: complete; 1: the blocks handed over end before such a record (or do not parse): read that region on the host.
- * out_cap = the sum over the regions of their blocks' ISIZE + 32 bytes per region always suffices.  STRL_ERR_FORMAT / STRL_ERR_CRC as for the front end. */
+ * out_cap = the sum over the regions of their blocks' ISIZE + 32 bytes per region always suffices; STRL_ERR_CAPACITY leaves the
+ * bytes needed in out_off[0].  STRL_ERR_FORMAT / STRL_ERR_CRC as for the front end. */
 typedef struct {
   uint32_t first_block, n_blocks;
   uint32_t in_block;

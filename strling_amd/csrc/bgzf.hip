@@ -378,7 +378,11 @@ extern "C" int strl_regions_fetch(strl_ctx *c, const uint8_t *comp, uint64_t com
     out_len[r] = len;
     at += len;
   }
-  if (at > out_cap) { set_error("region records: %llu bytes, room for %llu", (unsigned long long)at, (unsigned long long)out_cap); return STRL_ERR_CAPACITY; }
+  if (at > out_cap) {            // (out_off[0] = the bytes needed: a caller that sized `out` by a guess asks again with that much)
+    out_off[0] = at;
+    set_error("region records: %llu bytes, room for %llu", (unsigned long long)at, (unsigned long long)out_cap);
+    return STRL_ERR_CAPACITY;
+  }
   if (at) {
     if ((rc = d_out.reserve(at + 64))) return rc;
     STRL_HIP(hipMemcpyAsync(d_off, out_off, (size_t)n_regions * 8, hipMemcpyHostToDevice, st));

@@ -1550,7 +1550,9 @@ static int call_main(int argc, char **argv) {
           const int s = (int)(bi % NSETS);
           if (!B.which.empty()) {
             const auto tr0 = std::chrono::steady_clock::now();
-            const uint64_t want_out = B.inflated / 3 + 32 * B.which.size() + (1 << 20);   // what a query returns is a fifth of what the index makes one read; more: STRL_ERR_CAPACITY -> host reader
+            // what the queries return is a fifth to a half of what the index makes one read (narrow / wide bounds): sized by a
+            // guess, and by what it took if the guess proves short (STRL_ERR_CAPACITY: one more call with the bytes it names)
+            const uint64_t want_out = (uint64_t)((double)B.inflated * 0.6) + 32 * B.which.size() + (1 << 20);
             if (pin_comp_cap[s] < B.comp_bytes + 64) {
               if (pin_comp[s]) strl_pinned_free(pin_comp[s]);
               pin_comp_cap[s] = B.comp_bytes + B.comp_bytes / 4 + 64;
@@ -1596,6 +1598,15 @@ static int call_main(int argc, char **argv) {
             B.out_off.assign(B.which.size(), 0); B.out_len.assign(B.which.size(), 0); B.status.assign(B.which.size(), 1);
             B.rc = strl_regions_fetch(ctx, pin_comp[s], B.comp_bytes, B.coff.data(), B.clen.data(), B.isize.data(), B.crc.data(), (uint32_t)B.clen.size(), B.req.data(),
                                       (uint32_t)B.req.size(), pin_out[s], pin_out_cap[s], B.out_off.data(), B.out_len.data(), B.status.data());
+            if (B.rc == STRL_ERR_CAPACITY && !B.out_off.empty() && B.out_off[0] > pin_out_cap[s]) {
+              const uint64_t need = B.out_off[0] + B.out_off[0] / 16 + 64;
+              strl_pinned_free(pin_out[s]);
+              pin_out[s] = static_cast<uint8_t *>(strl_pinned_alloc(need));
+              pin_out_cap[s] = pin_out[s] ? need : 0;
+              if (pin_out[s])
+                B.rc = strl_regions_fetch(ctx, pin_comp[s], B.comp_bytes, B.coff.data(), B.clen.data(), B.isize.data(), B.crc.data(), (uint32_t)B.clen.size(), B.req.data(),
+                                          (uint32_t)B.req.size(), pin_out[s], pin_out_cap[s], B.out_off.data(), B.out_len.data(), B.status.data());
+            }
             if (B.rc) B.err = strl_last_error();
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
             { std::lock_guard<std::mutex> lk(pm); t_fetch += dt; }
