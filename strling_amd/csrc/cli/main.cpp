@@ -1143,9 +1143,9 @@ static int merge_main(int argc, char **argv) {
     strl_bin_info info;
     CHECK(strl_bin_peek(path.c_str(), &info));        // sizes from the header (names: an upper bound): the records are walked once
     std::string hdr((size_t)info.header_len, '\0');
-    std::vector<strl_tread> t((size_t)std::max(1, info.n_reads));
-    std::vector<uint64_t> qo((size_t)info.n_reads + 1);
-    std::vector<char> qn((size_t)info.qnames_bytes + 1);
+    rvec<strl_tread> t((size_t)std::max(1, info.n_reads));         // (left uninitialised: strl_bin_read fills them, on several threads for a big file)
+    rvec<uint64_t> qo((size_t)info.n_reads + 1);
+    rvec<char> qn((size_t)info.qnames_bytes + 1);
     CHECK(strl_bin_read(path.c_str(), &info, &hdr[0], t.data(), qo.data(), qn.data()));
     const std::vector<BamTarget> tg = targets_from_header(hdr);
     if (targets.empty()) targets = tg;                                            // merge.nim:104-105
@@ -1336,9 +1336,9 @@ static int call_main(int argc, char **argv) {
   g_bg_init = &ctx_thread;
   strl_bin_info info;
   std::string hdr;
-  std::vector<strl_tread> treads;
-  std::vector<uint64_t> qoff;
-  std::vector<char> qnames;
+  rvec<strl_tread> treads;                             // (rvec: resize leaves the elements uninitialised -- strl_bin_read fills them)
+  rvec<uint64_t> qoff;
+  rvec<char> qnames;
   int bin_rc = 0;
   std::string bin_err;
   std::thread bin_thread([&] {
@@ -1675,7 +1675,7 @@ static int call_main(int argc, char **argv) {
     t_evidence += std::chrono::duration<double>(std::chrono::steady_clock::now() - te0).count();
   };
   const uint64_t nt = (uint64_t)info.n_reads;
-  std::vector<strl_tread> taken_copy;                  // assigned reads are genotyped with the split they came with (copied only when loci are given)
+  rvec<strl_tread> taken_copy;                         // assigned reads are genotyped with the split they came with (copied only when loci are given)
 
   // loci handed in with -l / -b are genotyped first and take their reads out of the table (call.nim:150-218)
   std::vector<strl_locus> given;

@@ -4,8 +4,10 @@
 // HIP kernels produced; none of it scores reads.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <sys/mman.h>
 #include <algorithm>
 #include <condition_variable>
 #include <functional>
@@ -778,12 +780,50 @@ int strl_bin_read(const char *path, strl_bin_info *info, char *sam_header, strl_
   if (!path || !info) { set_error("null argument"); return STRL_ERR_ARG; }
   FILE *f = fopen(path, "rb");
   if (!f) { set_error("[strling] unable to open %s for reading. please check path", path); return STRL_ERR_IO; }
-  std::vector<uint8_t> buf;
   fseek(f, 0, SEEK_END);
   const long sz = ftell(f);
   fseek(f, 0, SEEK_SET);
-  buf.resize((size_t)std::max(0L, sz));
-  if (sz > 0 && fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); set_error("short read from %s", path); return STRL_ERR_IO; }
+  // (a whole genome's .bin is a quarter of a gigabyte: read in pieces by a few threads into memory nobody zeroes first)
+  // ... mapped with huge pages where the kernel grants them (MADV_HUGEPAGE: a hundred faults instead of sixty thousand)
+  struct Bytes {
+    uint8_t *p = nullptr; size_t n = 0, mapped = 0; void *base = nullptr;
+    uint8_t *data() { return p; }
+    size_t size() const { return n; }
+    uint8_t &operator[](size_t i) { return p[i]; }
+    ~Bytes() { if (base) munmap(base, mapped); else delete[] p; }
+  } buf;
+  buf.n = (size_t)std::max(0L, sz);
+  if (buf.n >= ((size_t)8 << 20)) {
+    const size_t huge = (size_t)2 << 20;
+    buf.mapped = ((buf.n + 16 + huge - 1) & ~(huge - 1)) + huge;
+    void *m = mmap(nullptr, buf.mapped, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m != MAP_FAILED) {
+      buf.base = m;
+      buf.p = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(m) + huge - 1) & ~(uintptr_t)(huge - 1));
+      (void)madvise(buf.p, buf.mapped - huge, MADV_HUGEPAGE);
+    }
+  }
+  if (!buf.p) buf.p = new uint8_t[buf.n + 16];
+  {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t T = buf.n < ((size_t)32 << 20) ? 1 : std::min<size_t>({hw ? hw : 1u, 8u, buf.n >> 24});
+    const int fd = fileno(f);
+    std::atomic<bool> bad{false};
+    auto part = [&](size_t k) {
+      size_t a = buf.n / T * k;
+      const size_t e = k + 1 == T ? buf.n : buf.n / T * (k + 1);
+      while (a < e) {
+        const ssize_t r = pread(fd, buf.data() + a, e - a, (off_t)a);
+        if (r <= 0) { bad = true; return; }
+        a += (size_t)r;
+      }
+    };
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < T; ++k) th.emplace_back(part, k);
+    part(0);
+    for (auto &t : th) t.join();
+    if (bad.load()) { fclose(f); set_error("short read from %s", path); return STRL_ERR_IO; }
+  }
   fclose(f);
   const size_t fixed = 3 + 2 + 9 + 4 + 1 + 4096 * 4 + 4;
   if (buf.size() < fixed + 4 || memcmp(buf.data(), "STR", 3) != 0) {                // unpack.nim:61-62
@@ -802,6 +842,121 @@ int strl_bin_read(const char *path, strl_bin_info *info, char *sam_header, strl_
   if (sam_header) memcpy(sam_header, buf.data() + o, (size_t)info->header_len);
   o += (size_t)info->header_len;
   memcpy(&info->n_reads, buf.data() + o, 4); o += 4;
+  // One record (unpack_type, unpack.nim:36-55) at rd.p; `strict` also asks for what the writers guarantee (value ranges, the name's
+  // length equal to its length field): that is how a thread that starts in the middle of the file recognises a record start.
+  auto one = [](Rd &rd, strl_tread &t, const uint8_t *&name, size_t &sl, bool strict) -> bool {
+    const int64_t tid = rd.integer(), pos = rd.integer();
+    t.tid = (int32_t)tid;
+    t.position = (uint32_t)pos;
+    if (!rd.ok || rd.p >= rd.e || *rd.p++ != 0x96) return false;
+    int64_t v[11];
+    for (int j = 0; j < 11; ++j) v[j] = rd.integer();
+    for (int j = 0; j < 6; ++j) t.repeat[j] = (char)v[j];
+    t.flag = (uint16_t)v[6]; t.split = (uint8_t)v[7]; t.mapping_quality = (uint8_t)v[8]; t.repeat_count = (uint8_t)v[9]; t.align_length = (uint8_t)v[10];
+    const uint64_t L = (uint64_t)rd.integer();
+    sl = 0;
+    name = rd.p;
+    if (L > 0) {                                                                     // :51-54 (qname read only when L > 0)
+      sl = rd.strhdr();
+      if (!rd.ok || rd.p + sl > rd.e) return false;
+      name = rd.p;
+      rd.p += sl;
+    }
+    if (!rd.ok) return false;
+    if (strict) {
+      if (tid < -1 || tid > INT32_MAX || pos < 0 || pos > (int64_t)UINT32_MAX || sl != L || L > 255) return false;
+      for (int j = 0; j < 6; ++j) if (v[j] != 0 && v[j] != 'A' && v[j] != 'C' && v[j] != 'G' && v[j] != 'T') return false;
+      if (v[6] < 0 || v[6] > 65535) return false;
+      for (int j = 7; j < 11; ++j) if (v[j] < 0 || v[j] > 255) return false;
+    }
+    return true;
+  };
+  // A whole genome's records (8e6, 0.4 s of dependent token decoding on one thread) are parsed by several threads: thread k starts at
+  // the first offset at or behind its share's start where EIGHT records in a row parse strictly, and parses up to the first record
+  // boundary at or behind the next share's start.  The guess is verified, not trusted: only if every thread ended exactly where
+  // the next one started (and the last one at the end of the file, and the count is the header's) are the parts put together --
+  // by induction from the true first record every boundary then is a true one.  Anything else: the sequential walk below.
+  const size_t body0 = o;
+  bool done_parallel = false;
+  const char *seq_env = getenv("STRL_BIN_READ");            // "seq": the sequential walk whatever the size (tests)
+  if (treads && qname_off && qnames && buf.size() - body0 >= ((size_t)32 << 20) && info->n_reads > 0 && !(seq_env && !strcmp(seq_env, "seq"))) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t K = std::min<size_t>({hw ? hw : 1u, 16u, (buf.size() - body0) >> 22});
+    if (K >= 2) {
+      // (two passes per share -- count, then parse into place -- instead of per-thread copies: the second pass costs a thread
+      // 30 ms, a few hundred megabytes of freshly mapped temporaries cost page faults by the ten thousand)
+      struct Part { size_t start = 0, end = 0; bool ok = false; uint64_t n = 0, name_bytes = 0; };
+      std::vector<Part> parts(K);
+      const uint8_t *base = buf.data(), *fend = buf.data() + buf.size();
+      auto share = [&](size_t k) { return body0 + (buf.size() - body0) / K * k; };
+      auto work = [&](size_t k) {
+        Part &P = parts[k];
+        const size_t lo = share(k), hi = k + 1 == K ? buf.size() : share(k + 1);
+        size_t s0 = lo;
+        if (k > 0) {
+          bool found = false;
+          for (; s0 < hi && s0 < lo + 4096 && !found; ++s0) {
+            Rd r{base + s0, fend};
+            bool good = true;
+            for (int q = 0; q < 8 && good && r.p < r.e; ++q) { strl_tread t{}; const uint8_t *nm; size_t sl; good = one(r, t, nm, sl, true); }
+            if (good) { found = true; break; }
+          }
+          if (!found) return;
+        }
+        P.start = s0;
+        Rd r{base + s0, fend};
+        while (r.p < r.e && (size_t)(r.p - base) < hi) {
+          strl_tread t{};
+          const uint8_t *nm;
+          size_t sl;
+          if (!one(r, t, nm, sl, false)) return;
+          ++P.n;
+          P.name_bytes += sl;
+        }
+        P.end = (size_t)(r.p - base);
+        P.ok = true;
+      };
+      std::vector<std::thread> th;
+      for (size_t k = 1; k < K; ++k) th.emplace_back(work, k);
+      work(0);
+      for (auto &t : th) t.join();
+      bool linked = true;
+      uint64_t total = 0;
+      for (size_t k = 0; k < K && linked; ++k) {
+        linked = parts[k].ok && parts[k].end == (k + 1 == K ? buf.size() : parts[k + 1].start);
+        total += parts[k].n;
+      }
+      if (linked && total == (uint64_t)info->n_reads) {
+        std::vector<uint64_t> r0(K + 1, 0), q0(K + 1, 0);
+        for (size_t k = 0; k < K; ++k) { r0[k + 1] = r0[k] + parts[k].n; q0[k + 1] = q0[k] + parts[k].name_bytes; }
+        auto place = [&](size_t k) {
+          const Part &P = parts[k];
+          Rd r{base + P.start, base + P.end};
+          uint64_t i = r0[k], qb = q0[k];
+          while (r.p < r.e) {
+            strl_tread t{};
+            const uint8_t *nm;
+            size_t sl;
+            if (!one(r, t, nm, sl, false)) break;          // (cannot happen: the same bytes parsed a moment ago)
+            t.qname_id = (int64_t)i;
+            treads[i] = t;
+            qname_off[i] = qb;
+            memcpy(qnames + qb, nm, sl);
+            ++i;
+            qb += sl;
+          }
+        };
+        th.clear();
+        for (size_t k = 1; k < K; ++k) th.emplace_back(place, k);
+        place(0);
+        for (auto &t : th) t.join();
+        qname_off[total] = q0[K];
+        info->qnames_bytes = q0[K];
+        done_parallel = true;
+      }
+    }
+  }
+  if (done_parallel) return STRL_OK;
   Rd rd{buf.data() + o, buf.data() + buf.size()};
   uint64_t qbytes = 0;
   int64_t i = 0;

@@ -177,3 +177,39 @@ def test_bin_writer_threads_bytes(tmp_path, batch, oracle):
     assert open(path, "rb").read() == oracle.bin_write(0.8, 40, frag, hdr, big, rec.qname_off, rec.qnames)
     back = api.bin_read(path)
     assert len(back["treads"]) == len(big) and np.array_equal(back["treads"]["position"], big["position"])
+
+
+def test_bin_reader_parts_equal_sequential(tmp_path, batch, oracle):
+    """a .bin past 32 MB is parsed in parts by several threads (record starts guessed, then verified by linking the parts):
+    the same arrays as the sequential walk, for ragged names too; a damaged file gets the sequential walk's verdict"""
+    import subprocess
+    import sys
+    rec, g = batch
+    exp = oracle.extract(rec, g, oracle.make_opts(350, 0.8, 40))
+    reps = (1_800_000 + len(exp) - 1) // len(exp)
+    big = np.concatenate([exp] * reps)
+    t = np.zeros(len(big), api.TREAD_DTYPE)
+    for f in t.dtype.names:
+        t[f] = big[f]
+    rng = np.random.default_rng(5)
+    t["position"] = rng.integers(0, 1 << 32, len(t), dtype=np.uint64).astype(np.uint32)      # every width of msgpack integer
+    t["tid"] = rng.integers(-1, 70000, len(t)).astype(np.int32)
+    frag = synth.frag_hist(rec)
+    path = str(tmp_path / "big.bin")
+    api.bin_write(path, 0.8, 40, frag, "@HD\tVN:1.6\n", t, rec.qname_off, rec.qnames)
+    assert os.path.getsize(path) > (36 << 20)
+    a = api.bin_read(path)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from strling_amd import api; b = api.bin_read(%r); "
+            "np.save(%r, b['treads']); np.save(%r, b['qname_off']); open(%r, 'wb').write(b['qnames'])")
+    outs = [str(tmp_path / x) for x in ("t.npy", "q.npy", "n.bin")]
+    r = subprocess.run([sys.executable, "-c", code % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path, *outs)],
+                       env=dict(os.environ, STRL_BIN_READ="seq"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(a["treads"], np.load(outs[0])) and np.array_equal(a["qname_off"], np.load(outs[1])) and a["qnames"] == open(outs[2], "rb").read()
+    assert np.array_equal(a["treads"]["position"], t["position"]) and np.array_equal(a["treads"]["tid"], t["tid"])
+    assert np.array_equal(a["treads"]["qname_id"], np.arange(len(t)))
+    raw = bytearray(open(path, "rb").read())
+    raw[len(raw) // 2] ^= 0x55                                       # somewhere inside a record
+    open(path, "wb").write(raw[: len(raw) - 7])                      # ... and a truncated tail
+    with pytest.raises(api.StrlingError):
+        api.bin_read(path)
