@@ -5,6 +5,7 @@
 #pragma once
 #include <limits.h>
 #include <stdint.h>
+#include <sys/mman.h>
 #include <stdio.h>
 #include <functional>
 #include <memory>
@@ -40,6 +41,44 @@ template <class T> struct default_init_allocator : std::allocator<T> {
   template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
 };
 template <class T> using rvec = std::vector<T, default_init_allocator<T>>;
+
+// ... and for the few arrays of a quarter of a gigabyte (a whole genome's treads and their names): the same, in a mapping of
+// its own with MADV_HUGEPAGE -- a hundred page faults instead of a hundred thousand when several threads fill it at once
+// (transparent huge pages are "madvise" on the machines this runs on).  Smaller requests go to the heap.
+template <class T> struct huge_allocator {
+  using value_type = T;
+  huge_allocator() = default;
+  template <class U> huge_allocator(const huge_allocator<U> &) {}
+  template <class U> struct rebind { using other = huge_allocator<U>; };
+  static constexpr size_t HUGE = (size_t)2 << 20, MIN_BYTES = (size_t)8 << 20;
+  T *allocate(size_t n) {
+    const size_t bytes = n * sizeof(T);
+    if (bytes >= MIN_BYTES) {
+      const size_t len = (bytes + HUGE - 1) & ~(HUGE - 1);
+      void *m = mmap(nullptr, len + HUGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+      if (m != MAP_FAILED) {
+        // keep the mapping 2 MB aligned by trimming its ends
+        const uintptr_t a = (reinterpret_cast<uintptr_t>(m) + HUGE - 1) & ~(uintptr_t)(HUGE - 1);
+        if (a > reinterpret_cast<uintptr_t>(m)) munmap(m, a - reinterpret_cast<uintptr_t>(m));
+        const uintptr_t end = reinterpret_cast<uintptr_t>(m) + len + HUGE;
+        if (end > a + len) munmap(reinterpret_cast<void *>(a + len), end - (a + len));
+        (void)madvise(reinterpret_cast<void *>(a), len, MADV_HUGEPAGE);
+        return reinterpret_cast<T *>(a);
+      }
+    }
+    return static_cast<T *>(::operator new(bytes));
+  }
+  void deallocate(T *p, size_t n) {
+    const size_t bytes = n * sizeof(T);
+    if (bytes >= MIN_BYTES && (reinterpret_cast<uintptr_t>(p) & (HUGE - 1)) == 0) { munmap(p, (bytes + HUGE - 1) & ~(HUGE - 1)); return; }
+    ::operator delete(p);
+  }
+  template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+  template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+  template <class U> bool operator==(const huge_allocator<U> &) const { return true; }
+  template <class U> bool operator!=(const huge_allocator<U> &) const { return false; }
+};
+template <class T> using hvec = std::vector<T, huge_allocator<T>>;
 
 // One batch of records in the strl_records layout (owning storage).
 struct RecordBatch {

@@ -1136,17 +1136,21 @@ static int merge_main(int argc, char **argv) {
   std::thread ctx_thread([&] { if (gpus_early == 1) { ctx_early_rc = strl_ctx_create(0, &ctx_early); if (ctx_early_rc) ctx_early_err = strl_last_error(); } });
   g_bg_init = &ctx_thread;
   uint32_t frag[4096] = {0};
-  std::vector<strl_tread> all;
+  hvec<strl_tread> all;                                 // (huge pages, uninitialised: strl_bin_read fills a sample's share on several threads)
   for (size_t si = 0; si < a.pos.size(); ++si) {
     const std::string &path = a.pos[si];
     if (verbose) fprintf(stderr, "[strling] reading bin file: %s\n", path.c_str());
     strl_bin_info info;
     CHECK(strl_bin_peek(path.c_str(), &info));        // sizes from the header (names: an upper bound): the records are walked once
     std::string hdr((size_t)info.header_len, '\0');
-    rvec<strl_tread> t((size_t)std::max(1, info.n_reads));         // (left uninitialised: strl_bin_read fills them, on several threads for a big file)
-    rvec<uint64_t> qo((size_t)info.n_reads + 1);
-    rvec<char> qn((size_t)info.qnames_bytes + 1);
-    CHECK(strl_bin_read(path.c_str(), &info, &hdr[0], t.data(), qo.data(), qn.data()));
+    // the sample's treads are read straight behind the ones held so far and the dropped ones squeezed out in place: no second
+    // copy of a whole genome's quarter gigabyte (names are not kept: merge.nim:118-125 replaces them by the sample's index)
+    const size_t old_n = all.size();
+    all.resize(old_n + (size_t)std::max(1, info.n_reads));
+    strl_tread *t = all.data() + old_n;
+    hvec<uint64_t> qo((size_t)info.n_reads + 1);
+    hvec<char> qn((size_t)info.qnames_bytes + 1);
+    CHECK(strl_bin_read(path.c_str(), &info, &hdr[0], t, qo.data(), qn.data()));
     const std::vector<BamTarget> tg = targets_from_header(hdr);
     if (targets.empty()) targets = tg;                                            // merge.nim:104-105
     else {
@@ -1164,9 +1168,10 @@ static int merge_main(int argc, char **argv) {
       if (have_req && t[(size_t)k].tid != requested_tid) continue;                 // unpack.nim:126 requested_tid
       if (t[(size_t)k].tid < 0) continue;                                          // unpack_file(drop_unplaced=true)
       t[(size_t)k].qname_id = (int64_t)si;                                         // merge.nim:118-125: qname := sample index
-      all.push_back(t[(size_t)k]);
+      if (kept != (uint64_t)k) t[(size_t)kept] = t[(size_t)k];
       ++kept;
     }
+    all.resize(old_n + (size_t)kept);
     fprintf(stderr, "[strling] read %llu STR reads from file: %s\n", (unsigned long long)kept, path.c_str());
   }
   if (verbose) {
@@ -1332,13 +1337,14 @@ static int call_main(int argc, char **argv) {
   strl_ctx *ctx = nullptr;
   int ctx_rc = 0;
   std::string ctx_err;
-  std::thread ctx_thread([&] { ctx_rc = strl_ctx_create(0, &ctx); if (ctx_rc) ctx_err = strl_last_error(); });
+  double t_up_ctx = 0, t_up_bin = 0, t_up_bam = 0;
+  std::thread ctx_thread([&] { ctx_rc = strl_ctx_create(0, &ctx); if (ctx_rc) ctx_err = strl_last_error(); t_up_ctx = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call0).count(); });
   g_bg_init = &ctx_thread;
   strl_bin_info info;
   std::string hdr;
-  rvec<strl_tread> treads;                             // (rvec: resize leaves the elements uninitialised -- strl_bin_read fills them)
-  rvec<uint64_t> qoff;
-  rvec<char> qnames;
+  hvec<strl_tread> treads;                             // (hvec: huge pages, resize leaves the elements uninitialised -- strl_bin_read fills them on several threads)
+  hvec<uint64_t> qoff;
+  hvec<char> qnames;
   int bin_rc = 0;
   std::string bin_err;
   std::thread bin_thread([&] {
@@ -1351,6 +1357,7 @@ static int call_main(int argc, char **argv) {
       bin_rc = strl_bin_read(bin.c_str(), &info, &hdr[0], treads.data(), qoff.data(), qnames.data());
     }
     if (bin_rc) bin_err = strl_last_error();
+    t_up_bin = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call0).count();
   });
   uint32_t frag[4096];
   fragment_length_distribution(bam, frag);                                          // call.nim:92
@@ -1362,6 +1369,7 @@ static int call_main(int argc, char **argv) {
   BamReader rd;
   std::string err;
   const bool opened = rd.open(bam, err) && rd.load_index(bam, err);                   // index=true, call.nim:101-102
+  t_up_bam = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call0).count();
   bin_thread.join();
   ctx_thread.join();
   g_bg_init = nullptr;
@@ -1675,7 +1683,7 @@ static int call_main(int argc, char **argv) {
     t_evidence += std::chrono::duration<double>(std::chrono::steady_clock::now() - te0).count();
   };
   const uint64_t nt = (uint64_t)info.n_reads;
-  rvec<strl_tread> taken_copy;                         // assigned reads are genotyped with the split they came with (copied only when loci are given)
+  hvec<strl_tread> taken_copy;                         // assigned reads are genotyped with the split they came with (copied only when loci are given)
 
   // loci handed in with -l / -b are genotyped first and take their reads out of the table (call.nim:150-218)
   std::vector<strl_locus> given;
@@ -1731,9 +1739,9 @@ static int call_main(int argc, char **argv) {
     run_tasks(tasks);
   }
   if (verbose)
-    fprintf(stderr, "[strling] seconds: device context + .bin + fragment lengths + index, side by side %.3f  clustering (upload, sort, sweep, bounds, members) %.3f  evidence + genotypes of %llu bounds on %d threads %.3f (summed over the threads: region records %.3f, spanners + genotype %.3f; regions through the device %llu, on the host %llu: "
+    fprintf(stderr, "[strling] seconds: device context + .bin + fragment lengths + index, side by side %.3f (%.3f | %.3f | %.3f)  clustering (upload, sort, sweep, bounds, members) %.3f  evidence + genotypes of %llu bounds on %d threads %.3f (summed over the threads: region records %.3f, spanners + genotype %.3f; regions through the device %llu, on the host %llu: "
             "index + block headers %.3f, page-locked buffers %.3f, reads %.3f, device fetch %.3f (two at a time), the workers waited %.3f for them, %.1f MB compressed -> %.1f MB inflated -> %.1f MB of records)  since the start %.3f\n",
-            t_start_up, std::chrono::duration<double>(tc2 - tc1).count(), (unsigned long long)nb, n_workers, t_evidence, (double)ns_region.load() * 1e-9, (double)ns_rules.load() * 1e-9,
+            t_start_up, t_up_ctx, t_up_bin, t_up_bam, std::chrono::duration<double>(tc2 - tc1).count(), (unsigned long long)nb, n_workers, t_evidence, (double)ns_region.load() * 1e-9, (double)ns_rules.load() * 1e-9,
             (unsigned long long)n_dev_regions, (unsigned long long)n_host_regions, t_plan, t_pin, t_pread, t_fetch, t_wait_fetch, (double)dev_comp_bytes / 1e6, (double)dev_inflated / 1e6, (double)dev_kept / 1e6,
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call0).count());
   char row[2048];

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <vector>
 #include "common.h"
 #include "nim_tables.h"
@@ -735,6 +736,9 @@ static int cluster_collect(strl_ctx *c, const std::vector<std::pair<uint64_t, ui
   ClusterRun &R = c->cl_run;
   strl::DevBuf *B = c->c_buf;
   hipStream_t st = c->stream;
+  const bool tm = getenv("STRL_CLUSTER_TIMING") != nullptr;
+  const auto tm0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) { if (tm) fprintf(stderr, "[cluster_collect] %s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tm0).count()); };
   uint32_t cnt[CC_WORDS];
   uint32_t n_dev = 0;
   uint32_t part_err = 0;
@@ -780,6 +784,8 @@ static int cluster_collect(strl_ctx *c, const std::vector<std::pair<uint64_t, ui
     }
     STRL_HIP(hipStreamSynchronize(st));
   }
+  lap("counters + candidates + group tables on the host");
+  if (tm) fprintf(stderr, "[cluster_collect] %u treads, %u groups, %u candidates\n", n_dev, n_groups, n_cand);
   // candidates arrive in arbitrary order: by (group, first read) they are the clusters of a group in position order
   std::vector<uint32_t> cidx(n_cand);
   for (uint32_t k = 0; k < n_cand; ++k) cidx[k] = k;
@@ -796,6 +802,7 @@ static int cluster_collect(strl_ctx *c, const std::vector<std::pair<uint64_t, ui
     }
     cl_lo[n_groups] = ci;
   }
+  lap("candidates sorted");
   // Table keys in insertion order = first appearance in the caller's array, counting the place-holding treads too
   struct KeyEnt { uint64_t key; uint64_t first; int32_t g; };
   std::vector<KeyEnt> ents;
@@ -825,7 +832,9 @@ static int cluster_collect(strl_ctx *c, const std::vector<std::pair<uint64_t, ui
     key_unit(ents[q].key, rep);
     hcodes[q] = nim::hash_tid_rep((int32_t)(ents[q].key >> 15) - 1, rep);
   }
+  lap("group keys hashed");
   const std::vector<int64_t> order = nim::table_slot_order(hcodes, 8192);           // newTable(8192): call.nim:118, merge.nim:92
+  lap("table order");
   uint64_t no = 0, nu = 0;
   for (int64_t q : order) {
     if (ents[(size_t)q].g < 0) continue;                                              // every read of the group went to a locus
@@ -855,6 +864,7 @@ static int cluster_collect(strl_ctx *c, const std::vector<std::pair<uint64_t, ui
         ++no;
       }
   }
+  lap("rows written");
   if (n_out) *n_out = no;
   if (n_unplaced) *n_unplaced = nu;
   if (stats) stats->n_bounds = no;
@@ -1089,6 +1099,9 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
                             strl_cluster_stats *stats) {
   if (c) { const int rcj = side_join(c); if (rcj) return rcj; }
   if (!c || (!treads && n_in) || (!out && cap)) { set_error("null argument"); return STRL_ERR_ARG; }
+  const bool tm = getenv("STRL_CLUSTER_TIMING") != nullptr;      // host-side phases of this call on stderr
+  const auto tm0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) { if (tm) fprintf(stderr, "[strl_cluster] %s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tm0).count()); };
   if (n_out) *n_out = 0;
   if (n_unplaced) *n_unplaced = 0;
   if (stats) memset(stats, 0, sizeof *stats);
@@ -1133,6 +1146,7 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
   const uint32_t n = (uint32_t)n64;
   if (stats) stats->n_treads = n;
   if (n == 0) return STRL_OK;                        // (only ghosts left: nothing to cluster, nothing to report)
+  lap("host scan done");
   // ---- upload, one device pass, results ---------------------------------------------------------------
   strl::DevBuf *B = c->c_buf;
   int rc;
@@ -1153,6 +1167,12 @@ extern "C" int strl_cluster(strl_ctx *c, const strl_tread *treads, uint64_t n_in
   if (!R.composite) R.pos_bits = 32;
   R.kept.swap(kept);
   R.treads = B[B_TREADS].as<strl_tread>(); R.d_n = B[B_CNT].as<uint32_t>() + CC_N;
+  lap("upload enqueued");
+  if (tm) { STRL_HIP(hipStreamSynchronize(st)); lap("upload done"); }
   if ((rc = cluster_device_pass(c, R.treads, R.d_n))) return rc;
-  return cluster_collect(c, ghosts, out, cap, n_out, unplaced, unplaced_cap, n_unplaced, stats);
+  lap("device pass enqueued");
+  if (tm) { STRL_HIP(hipStreamSynchronize(st)); lap("device pass done"); }
+  rc = cluster_collect(c, ghosts, out, cap, n_out, unplaced, unplaced_cap, n_unplaced, stats);
+  lap("rows collected");
+  return rc;
 }
