@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <functional>
 #include <memory>
+#include <new>
 #include <type_traits>
 #include <utility>
 #include <condition_variable>
@@ -65,12 +66,13 @@ template <class T> struct huge_allocator {
         (void)madvise(reinterpret_cast<void *>(a), len, MADV_HUGEPAGE);
         return reinterpret_cast<T *>(a);
       }
+      throw std::bad_alloc();        // (never the heap for a size deallocate() unmaps)
     }
     return static_cast<T *>(::operator new(bytes));
   }
   void deallocate(T *p, size_t n) {
     const size_t bytes = n * sizeof(T);
-    if (bytes >= MIN_BYTES && (reinterpret_cast<uintptr_t>(p) & (HUGE - 1)) == 0) { munmap(p, (bytes + HUGE - 1) & ~(HUGE - 1)); return; }
+    if (bytes >= MIN_BYTES) { munmap(p, (bytes + HUGE - 1) & ~(HUGE - 1)); return; }
     ::operator delete(p);
   }
   template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
