@@ -123,7 +123,7 @@ bool BamReader::open(const std::string &path, std::string &err) {
   eof_ = false; next_block_ = 0; upos_ = 0; ubuf_.clear();
   char magic[4];
   int32_t l_text = 0, n_ref = 0;
-  if (!get(magic, 4, err) || memcmp(magic, "BAM\1", 4) != 0) { err = "not a BAM file (CRAM is not supported by this build)"; return false; }
+  if (!get(magic, 4, err) || memcmp(magic, "BAM\1", 4) != 0) { err = "not a BAM file"; return false; }
   if (!get(&l_text, 4, err) || l_text < 0) return false;
   text_.resize((size_t)l_text);
   if (l_text && !get(&text_[0], (size_t)l_text, err)) return false;

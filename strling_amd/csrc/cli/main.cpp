@@ -1940,8 +1940,9 @@ static int index_main(int argc, char **argv) {
 
 int main(int argc, char **argv) {
   const char *top =
-      "strling version: 0.6.0 (MI355X-native hot path)\n\nCommands:\n  extract  :   extract informative STR reads from a BAM (CRAM is not supported by this build).\n"
-      "  merge    :   merge putitive STR loci from multiple samples.\n  call     :   call STRs.\n  index    :   identify large STRs in the reference genome.\n";
+      "strling version: 0.6.0 (MI355X-native hot path)\n\nCommands:\n  extract  :   extract informative STR reads from a BAM/CRAM. This is a required first step.\n"
+      "  merge    :   merge putitive STR loci from multiple samples. Only required for joint calling.\n  call     :   call STRs\n"
+      "  index    :   identify large STRs in the reference genome, to produce ref.fasta.str.\n";      // strling.nim:19-22 (pull_region, a debugging writer, is out of scope)
   if (argc < 2) { fputs(top, stdout); return 1; }
   const std::string cmd = argv[1];
   if (cmd == "extract") return extract_main(argc, argv);
