@@ -151,8 +151,8 @@ def run(inp, cli, threads=(0,), call=True, merge=True, repeats=1):
             res["merge_stderr_tail"] = r.stderr[-600:]
     res["note"] = ("`strling extract` BAM file (page cache) -> .bin: whole process wall clock incl. start-up (HIP context, page-locked buffers), copies of the "
                    "compressed bytes, BGZF inflate + CRC + record scan + parse + scorer + pair logic on the device, fragment lengths, .bin writing; "
-                   "reads_per_s_loop excludes process start-up and the .bin write.  call_s / merge_s: whole `strling call` (clustering on the device, "
-                   ".bai region reads + spanning evidence + genotypes on the host) and `strling merge` processes on that .bin")
+                   "reads_per_s_loop excludes process start-up and the .bin write.  call_s / merge_s: whole `strling call` (clustering on the device, the bounds' "
+                   ".bai region reads inflated and cut out on the device, spanning evidence + genotypes on the host's threads) and `strling merge` processes on that .bin")
     return res
 
 
