@@ -42,7 +42,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--e2e-pairs", type=int, default=2 ** 26, help="pairs of the BAM file the end-to-end leg runs `strling extract` / `call` / `merge` on (2^26 pairs = 1.3e8 reads, ~2 min to write at zlib level 6 on 16 cores; the 2^29-read run is profiles/r04/e2e_full.json)")
+    ap.add_argument("--e2e-pairs", type=int, default=0, help="pairs of the BAM file the end-to-end leg runs `strling extract` / `call` / `merge` on.  0 = choose: 2^28 pairs (5.4e8 reads, "
+                    "the 30x sample BASELINE.json names; ~8 min to write at zlib level 6 on 16 cores) when the box has the room (>= 75 GB free in the work directory, >= 12 CPUs) and N = 1, "
+                    "else 2^26 pairs (1.3e8 reads, ~2 min to write); the line's end_to_end.input says which ran")
     ap.add_argument("--cache", default="", help="directory to keep the generated batch in (profiling runs reload it instead of forking generators)")
     args = ap.parse_args()
 
@@ -62,21 +64,26 @@ def main():
 
     # ---- end to end first (it forks generators and runs the CLI, which wants the GPU to itself): BAM file -> .bin -----
     e2e = None
-    if rank == 0 and world == 1 and not args.no_e2e:
+    if rank == 0 and not args.no_e2e:
+        # N > 1: rank 0 runs `strling extract --gpus N` (ONE process, a context per device, a contiguous share of the file each)
+        # on all N devices while the other ranks wait at the rendezvous below -- they have not touched their device yet
         try:
-            e2e = end_to_end(args.e2e_pairs)
+            e2e = end_to_end(args.e2e_pairs or pick_e2e_pairs(world), gpus=world)
         except Exception as e:
             e2e = {"error": str(e)[:300]}
 
-    # the same on the whole-genome sized file (2^29 reads): measured by tools/e2e_bench.py on the GPU box, committed, quoted here
+    # When this run's own end_to_end leg was NOT the whole-genome sized file (no room / N > 1), the builder's last run of that size
+    # is quoted -- under a key that says it is a quotation, not a measurement of this run
     e2e_full = None
-    if rank == 0 and world == 1:
-        try:
-            e2e_full = json.load(open(os.path.join(ROOT, "profiles", "r04", "e2e_full.json")))
-            e2e_full = {k: e2e_full[k] for k in e2e_full if k not in ("note",)}
-            e2e_full["from_committed_profile"] = "profiles/r04/e2e_full.json (python tools/e2e_bench.py 268435456 --check-slabs 64 --repeats 2 on the GPU box; ~8 min to write the file)"
-        except Exception:
-            e2e_full = None
+    if rank == 0 and world == 1 and not (e2e and e2e.get("reads", 0) >= 5e8):
+        for rnd in ("r05", "r04"):
+            try:
+                e2e_full = json.load(open(os.path.join(ROOT, "profiles", rnd, "e2e_full.json")))
+                e2e_full = {k: e2e_full[k] for k in e2e_full if k not in ("note",)}
+                e2e_full["from_committed_profile"] = f"profiles/{rnd}/e2e_full.json (python tools/e2e_bench.py 268435456 --check-slabs 64 --repeats 2 on the GPU box; ~8 min to write the file): NOT measured in this run"
+                break
+            except Exception:
+                e2e_full = None
 
     # ---- synthetic S1 batch: DISTINCT reads, generated before the GPU runtime starts (worker processes fork) ----
     from strling_amd import synth
@@ -108,13 +115,15 @@ def main():
     torch.cuda.set_device(local)
     backend = None
     if world > 1:
+        import datetime
+        # (rank 0 arrives late: it has run the end-to-end leg on all devices first)
         # nccl == RCCL on ROCm.  RCCL refuses two ranks on one device, so ranks that share a device rendezvous over gloo and
         # exchange through the host: a dry run of the N > 1 code path, not a measurement of the collective
         backend = os.environ.get("BENCH_BACKEND", "gloo" if shared_device else "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(minutes=40))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(minutes=40))
     dev = torch.device("cuda", local)
 
     soa = api.Soa(rec)
@@ -398,7 +407,7 @@ def main():
                        "parallelism": (f"records sharded over {world} GPU(s), no data-path collective" if exchange is None else
                                        f"records sharded over {world} GPUs; per step one RCCL all-gather of the tread arrays [{type(exchange).__name__}] "
                                        f"({exchange.pad * 32} B per rank) before clustering, every rank clusters the (tid, unit) groups it owns")},
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_nproc": cpu_nproc, "cpu_baseline_e2e": cpu_e2e, "end_to_end": e2e, "end_to_end_full_size": e2e_full,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_nproc": cpu_nproc, "cpu_baseline_e2e": cpu_e2e, "end_to_end": e2e, "quoted_not_measured_end_to_end_full_size": e2e_full,
         }
         print(json.dumps(out))
     if world > 1:
@@ -491,7 +500,20 @@ def cpu_baseline_e2e(oracle_reads_per_s):
                       f"end_to_end.  with_call: + the oracle's `call` (cluster, spanning evidence, genotypes) per read of the file"}
 
 
-def end_to_end(n_pairs, check_slabs=4):
+def pick_e2e_pairs(world):
+    """2^28 pairs (5.4e8 reads: the 30x sample of BASELINE.json's metric, a 57 GB BAM) when this is the one-GPU run and the box
+    has the room and the cores to write it in ~8 minutes; else 2^26 pairs"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_bench
+    if world > 1 or os.environ.get("BENCH_E2E_SMALL"):
+        return 2 ** 26
+    cpus = _cpu_quota() or (os.cpu_count() or 1)
+    d = e2e_bench.work_dir(2 ** 28 * 2 * 115)
+    st = os.statvfs(d)
+    return 2 ** 28 if (st.f_bavail * st.f_frsize >= 75e9 and cpus >= 12) else 2 ** 26
+
+
+def end_to_end(n_pairs, check_slabs=4, gpus=1):
     """`strling extract` -> .bin -> `strling call` and `strling merge`, from a coordinate-sorted, indexed BAM of 2 * n_pairs distinct
     reads (zlib level 6, binned random qualities, aux tags) written to local disk / shm (page cache warm): wall clock of whole
     processes, all host threads; a share of the outputs checked against the oracle (tools/e2e_bench.py)."""
@@ -500,7 +522,7 @@ def end_to_end(n_pairs, check_slabs=4):
     import e2e_bench
     inp = e2e_bench.make_input(n_pairs)
     try:
-        res = e2e_bench.run(inp, build.CLI, repeats=2)      # the first process behind the writer reads a cold file
+        res = e2e_bench.run(inp, build.CLI, repeats=2, gpus=gpus)      # the first process behind the writer reads a cold file
         if check_slabs and "error" not in res:
             res["check"] = e2e_bench.check_in_subprocess(inp, e2e_bench.pick_slabs(inp["n_slabs"], check_slabs), call=res.get("call_rc") == 0)
         return res

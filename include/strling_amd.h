@@ -562,6 +562,22 @@ int strl_front_collect(strl_ctx *ctx);
 int strl_front_push_after(strl_ctx *ctx, strl_ctx *prev, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *coff, const uint32_t *clen,
                           const uint32_t *isize, const uint32_t *crc32, uint32_t n_blocks, strl_front_chunk *done, int *n_done);
 int strl_ctxs_extract_gather(strl_ctx **ctxs, int n, const uint32_t *chunk_owner, const uint64_t *chunk_records, uint64_t n_chunks);
+/* The other way to spread one file (`strling extract --gpus N`, the default when the BAM has an index; extract.nim:308-329 is
+ * one loop over the whole file): every context takes ONE CONTIGUOUS SHARE of the blocks, both ends at record starts the .bai
+ * names, so a share is a BAM of its own -- strl_front_begin with the first record's offset in the share's first block, plain
+ * strl_front_push (no `prev`, nothing carried between contexts, each context fed by its own host thread), and
+ *   strl_front_trim_next   before the share's LAST chunk is handed over (strl_front_stage or the push itself): its last
+ *                          tail_bytes inflated bytes -- the part of the last block behind the next share's first record --
+ *                          are not the share's (the block is inflated and CRC-checked whole; the record scan ends in front of them);
+ *   strl_front_tail_bytes  after strl_front_finish: bytes behind the last complete record of the last chunk.  0 for a share
+ *                          that ended exactly where the next begins (anything else: the index lied; the caller repeats the
+ *                          extraction chunk by chunk, strl_front_push_after).
+ * strl_ctxs_extract_gather then takes the shares in order (chunk_owner non-decreasing). */
+int strl_front_trim_next(strl_ctx *ctx, uint32_t tail_bytes);
+int strl_front_tail_bytes(strl_ctx *ctx, uint32_t *tail_bytes);
+/* Host waits of this context's front end (record scan, parse) block in the kernel instead of spinning: for N feeding threads
+ * that share fewer than 2 N CPUs.  Call before strl_front_begin. */
+int strl_ctx_blocking_waits(strl_ctx *ctx, int on);
 /* flag | (isize in [0, 4095] ? isize : 0xffff) << 16 of records [first, first + n) of the file: what
  * fragment_length_distribution (utils.nim:86-111) reads of a record.  Synchronises the context's stream. */
 int strl_front_fragwords(strl_ctx *ctx, uint64_t first, uint64_t n, uint32_t *out);

@@ -10,6 +10,7 @@ and with several symbols, BETA, GAMMA, SUBEXP), pairs inside a slice are linked 
 Test infrastructure: nothing here is used by the product.
 """
 import gzip
+import hashlib
 import struct
 import zlib
 
@@ -336,8 +337,28 @@ def _pair_tlen(a, b):
     return -t, t
 
 
+def _chain_fields(xs):
+    """what the reader derives for the records of ONE template linked into a chain inside a slice (htslib, cram_decode_slice_xref):
+    every record's mate is the next of the chain, the last one's the first; the template length spans the leftmost start to the
+    rightmost end of all of them, positive for a leftmost record (several leftmost: the first-in-pair one), zero when the chain
+    touches two references or the record or its mate is unmapped.  -> [(mtid, mpos, tlen, mate reverse, mate unmapped)]"""
+    left = min(x["pos"] for x in xs)
+    left_cnt = sum(1 for x in xs if x["pos"] == left)
+    right = max(x["end"] for x in xs)
+    one_ref = len({x["tid"] for x in xs}) == 1
+    t = right - left + 1
+    out = []
+    for j, x in enumerate(xs):
+        m = xs[(j + 1) % len(xs)]
+        tl = 0 if not one_ref else (t if x["pos"] == left and (left_cnt == 1 or x["flag"] & 0x40) else -t)
+        if (m["flag"] & 4) or (x["flag"] & 4):
+            tl = 0
+        out.append((m["tid"], m["pos"], tl, bool(m["flag"] & 0x10), bool(m["flag"] & 0x4)))
+    return out
+
+
 def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_per_container=2, read_names=True, index=True, ap_delta=True,
-               multi_ref=False, qualities=False, tags=False):
+               multi_ref=False, qualities=False, tags=False, slice_md5=True, stats=None):
     """records of `rec` (coordinate sorted, unmapped tail last) -> CRAM 3.0 + .crai.  refs[tid] = reference bytes (ACGTN).
     multi_ref: slices run across reference boundaries (slice reference id -2, RI per record); qualities: every record carries its
     quality array (CF bit 1, QS per base); tags: every record carries NM:C and MD:Z (tag dictionary + tag encoding map: values
@@ -386,18 +407,23 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
             for r in rs:
                 r["cf"] = (2 if r["flag"] & 1 else 0) | (1 if qualities else 0)
             for ks in by_name.values():
-                if len(ks) != 2:
+                if len(ks) < 2:
                     continue
-                x, y = rs[ks[0]], rs[ks[1]]
-                if not (x["flag"] & 1 and y["flag"] & 1) or (x["flag"] | y["flag"]) & 0x900 or x["tid"] < 0:
+                xs = [rs[k] for k in ks]
+                if not all(x["flag"] & 1 for x in xs) or xs[0]["tid"] < 0:
                     continue
-                tx, ty = _pair_tlen(x, y)
-                ok = (x["mtid"], x["mpos"], y["mtid"], y["mpos"]) == (y["tid"], y["pos"], x["tid"], x["pos"]) and (x["tlen"], y["tlen"]) == (tx, ty)
-                for p, q in ((x, y), (y, x)):
-                    ok = ok and bool(p["flag"] & 0x20) == bool(q["flag"] & 0x10) and bool(p["flag"] & 0x8) == bool(q["flag"] & 0x4)
+                if len(ks) == 2 and (xs[0]["flag"] | xs[1]["flag"]) & 0x900:
+                    continue
+                ok = all((x["mtid"], x["mpos"], x["tlen"], bool(x["flag"] & 0x20), bool(x["flag"] & 0x8)) == d for x, d in zip(xs, _chain_fields(xs)))
                 if ok:
+                    if stats is not None:
+                        stats[len(xs)] = stats.get(len(xs), 0) + 1       # chains written, by length
                     q1 = 1 if qualities else 0
-                    x["cf"], x["nf"], y["cf"] = 4 | q1, ks[1] - ks[0] - 1, q1
+                    for j, x in enumerate(xs):
+                        if j + 1 < len(xs):
+                            x["cf"], x["nf"] = 4 | q1, ks[j + 1] - ks[j] - 1
+                        else:
+                            x["cf"] = q1
             recs.append(rs)
         # ---- compression header ----
         cf_freq = {}
@@ -540,8 +566,10 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
                     rr = [r for r in mp if r["tid"] == t2]
                     a2, b2 = min(r["pos"] for r in rr), max(max(r["end"], r["pos"]) for r in rr)
                     multi_lines.append((t2, a2, b2 - a2 + 1))
+            # the MD5 of the reference bases the slice spans (CRAMv3 section 8.5); multi-reference and unmapped slices carry zeros
+            md5 = hashlib.md5(bytes(refs[tid][s_start - 1:s_start - 1 + span]).upper()).digest() if tid >= 0 and span and slice_md5 else bytes(16)
             sh = itf8(tid) + itf8(s_start if tid >= 0 else 0) + itf8(span) + itf8(len(rs)) + ltf8(counter) + itf8(1 + len(eblocks)) + \
-                itf8(len(used)) + b"".join(itf8(k) for k in used) + itf8(-1) + bytes(16)
+                itf8(len(used)) + b"".join(itf8(k) for k in used) + itf8(-1) + md5
             shb = block(RAW, SLICE_HEADER, 0, sh)
             landmarks.append(at)
             sl_bytes = shb + core + b"".join(eblocks)

@@ -333,7 +333,19 @@ extern "C" int strl_regions_fetch(strl_ctx *c, const uint8_t *comp, uint64_t com
       }
     }
   }
-  struct Rel { strl_ctx *c; strl_ctx::RegionSlot *s; ~Rel() { { std::lock_guard<std::mutex> lk(c->rg_mu); s->busy = false; } c->rg_cv.notify_all(); } } rel{c, slot};
+  // (the slot's stream is drained before the slot -- and the stack memory its copies read and write: uoff, err, range -- is given
+  // up, whichever way the function is left: an early error return must not leave DMA pending on destroyed memory; round-4 advisor)
+  struct Rel {
+    strl_ctx *c; strl_ctx::RegionSlot *s;
+    ~Rel() {
+      if (s->st) (void)hipStreamSynchronize(s->st);
+      { std::lock_guard<std::mutex> lk(c->rg_mu); s->busy = false; }
+      c->rg_cv.notify_all();
+    }
+  };
+  std::vector<RegionWalk> range(n_regions);          // declared ahead of `rel`: destroyed after its destructor has drained the stream
+  uint32_t err = 0;
+  Rel rel{c, slot};
   if (!slot->st) STRL_HIP(hipStreamCreateWithFlags(&slot->st, hipStreamNonBlocking));
   DevBuf &d_comp = slot->comp, &d_meta = slot->meta, &d_u = slot->u, &d_out = slot->out, &d_rq = slot->rq;
   int rc;
@@ -361,8 +373,6 @@ extern "C" int strl_regions_fetch(strl_ctx *c, const uint8_t *comp, uint64_t com
   if (crc32 && (rc = strl_crc_device(c, d_u.as<uint8_t>(), m_uoff, m_isize, m_crc, n_blocks, nullptr, m_err, st))) return rc;
   hipLaunchKernelGGL(region_walk_kernel, dim3(n_regions), dim3(64), 0, st, d_u.as<uint8_t>(), (tot + 64) & ~(uint64_t)15, m_uoff, m_isize, d_req, n_regions, d_range, d_status);
   STRL_HIP(hipGetLastError());
-  std::vector<RegionWalk> range(n_regions);
-  uint32_t err = 0;
   STRL_HIP(hipMemcpyAsync(&err, m_err, 4, hipMemcpyDeviceToHost, st));
   STRL_HIP(hipMemcpyAsync(range.data(), d_range, (size_t)n_regions * sizeof(RegionWalk), hipMemcpyDeviceToHost, st));
   STRL_HIP(hipMemcpyAsync(status, d_status, n_regions, hipMemcpyDeviceToHost, st));

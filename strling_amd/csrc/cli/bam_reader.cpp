@@ -145,7 +145,7 @@ bool BamReader::open_like(const BamReader &o, std::string &err) {
   close();
   if (o.cram_) {                       // a reader of its own on the same CRAM (the index is parsed again: small)
     cram_.reset(new CramFile());
-    if (!cram_->open(o.path_, g_cram_fasta, 1, err) || !cram_->load_index(err)) { cram_.reset(); return false; }
+    if (!cram_->open(o.path_, g_cram_fasta, 1, err, o.cram_->ref_cache()) || !cram_->load_index(err)) { cram_.reset(); return false; }     // (one reference cache for all of them)
     path_ = o.path_; text_ = o.text_; targets_ = o.targets_;
     lin_.assign(1, {});
     return true;

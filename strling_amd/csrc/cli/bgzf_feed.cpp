@@ -14,9 +14,18 @@ void BgzfFeed::close() {
   { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
   cv_.notify_all();
   if (walker_.joinable()) walker_.join();
-  stop_ = false; state_ = 0; blks_.clear(); taken_ = 0; werr_.clear();
+  stop_ = false; state_ = 0; blks_.clear(); taken_ = 0; werr_.clear(); trim_ = 0;
   if (fd_ >= 0) ::close(fd_);
   fd_ = -1; map_len_ = 0;
+}
+
+void BgzfFeed::halt() {
+  { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+  cv_.notify_all();
+  if (walker_.joinable()) walker_.join();
+  stop_ = false;
+  std::lock_guard<std::mutex> lk(mu_);
+  state_ = 1; blks_.clear(); taken_ = 0;
 }
 
 bool BgzfFeed::read_at(void *dst, size_t off, size_t n) const {
@@ -46,8 +55,71 @@ bool BgzfFeed::open(const std::string &path, std::string &err) {
   struct stat st;
   if (fstat(fd_, &st) != 0) { ::close(fd_); fd_ = -1; err = "couldn't stat bam"; return false; }
   map_len_ = (size_t)st.st_size;
+  path_ = path;
   (void)posix_fadvise(fd_, 0, 0, POSIX_FADV_SEQUENTIAL);
-  walker_ = std::thread([this, start] {
+  start_ = start;
+  walk_from(start, 0, 0);
+  return true;
+}
+
+bool BgzfFeed::open_share(const BgzfFeed &whole, uint64_t start_coff, uint32_t first_off, uint64_t end_coff, uint32_t end_uoff, std::string &err) {
+  close();
+  if (whole.fd_ < 0 || start_coff >= whole.map_len_ || (end_coff && (end_coff < start_coff || end_coff >= whole.map_len_))) { err = "bad share"; return false; }
+  fd_ = ::open(whole.path_.c_str(), O_RDONLY);
+  if (fd_ < 0) { err = "couldn't open bam"; return false; }
+  map_len_ = whole.map_len_;
+  path_ = whole.path_;
+  text_ = whole.text_;
+  targets_ = whole.targets_;
+  first_off_ = first_off;
+  start_ = start_coff;
+  walk_from((size_t)start_coff, end_coff, end_uoff);
+  return true;
+}
+
+// BAI (SAM spec 5.2): every ioffset of the linear indices and every chunk start of the bins is the virtual offset of a record
+std::vector<uint64_t> BgzfFeed::split_points(const std::string &path) {
+  std::vector<uint64_t> v;
+  FILE *f = fopen((path + ".bai").c_str(), "rb");
+  if (!f && path.size() > 4) f = fopen((path.substr(0, path.size() - 4) + ".bai").c_str(), "rb");
+  if (!f) return v;
+  auto rd = [&](void *p, size_t n) { return fread(p, 1, n, f) == n; };
+  char magic[4];
+  int32_t n_ref = 0;
+  bool ok = rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && n_ref >= 0;
+  std::vector<uint64_t> buf;
+  for (int32_t r = 0; ok && r < n_ref; ++r) {
+    int32_t n_bin = 0;
+    ok = rd(&n_bin, 4) && n_bin >= 0;
+    for (int32_t k = 0; ok && k < n_bin; ++k) {
+      uint32_t bin = 0;
+      int32_t n_chunk = 0;
+      ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0 && n_chunk < (1 << 28);
+      if (!ok) break;
+      buf.resize((size_t)n_chunk * 2);
+      ok = n_chunk == 0 || rd(buf.data(), (size_t)n_chunk * 16);
+      if (ok && bin != 37450) for (int32_t c = 0; c < n_chunk; ++c) v.push_back(buf[(size_t)c * 2]);   // 37450: the metadata pseudo-bin
+    }
+    int32_t n_intv = 0;
+    ok = ok && rd(&n_intv, 4) && n_intv >= 0;
+    if (ok && n_intv) {
+      buf.resize((size_t)n_intv);
+      ok = rd(buf.data(), (size_t)n_intv * 8);
+      if (ok) for (uint64_t x : buf) if (x) v.push_back(x);
+    }
+  }
+  fclose(f);
+  if (!ok) { v.clear(); return v; }
+  std::sort(v.begin(), v.end());
+  v.erase(std::unique(v.begin(), v.end()), v.end());
+  return v;
+}
+
+// the header walker: from the block at `start` to the end of the file, or (end_coff != 0) to the share's end -- the block at
+// end_coff is included when end_uoff > 0 (its first end_uoff bytes are the share's; trim_ = the rest)
+void BgzfFeed::walk_from(size_t start, uint64_t end_coff, uint32_t end_uoff) {
+  trim_ = 0;
+  walker_ = std::thread([this, start, end_coff, end_uoff] {
     size_t pos = start;
     std::vector<Block> local;
     int state = 0;
@@ -65,7 +137,11 @@ bool BgzfFeed::open(const std::string &path, std::string &err) {
     uint8_t h[18], tail[8 + 18];
     bool have = pos + 18 <= map_len_ && read_at(h, pos, 18);
     while (state == 0) {
-      if (pos >= map_len_) { state = 1; break; }
+      if (pos >= map_len_) { state = end_coff ? 2 : 1; if (end_coff) werr = "the index names an offset behind the last BGZF block"; break; }
+      if (end_coff && pos >= end_coff) {
+        if (pos > end_coff) { state = 2; werr = "the index names an offset that is not a BGZF block's"; break; }
+        if (end_uoff == 0) { state = 1; break; }
+      }
       if (!have) { state = 2; werr = "truncated BGZF header"; break; }
       if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { state = 2; werr = "not a BGZF block"; break; }
       const uint32_t xlen = h[10] | (h[11] << 8);
@@ -97,6 +173,13 @@ bool BgzfFeed::open(const std::string &path, std::string &err) {
       const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
       const uint32_t isz = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
       if (isz > 65536u) { state = 2; werr = "BGZF block inflates to more than 64 KiB"; break; }
+      if (end_coff && pos == end_coff) {               // the share's last block: the record boundary lies inside it
+        if (end_uoff > isz) { state = 2; werr = "the index names an offset behind its block's end"; break; }
+        if (isz) local.push_back(Block{pos + 12 + xlen, bsize - 12 - xlen - 8, isz, crc});
+        trim_ = isz - end_uoff;                        // (published with state_ under the lock below)
+        state = 1;
+        break;
+      }
       if (isz) local.push_back(Block{pos + 12 + xlen, bsize - 12 - xlen - 8, isz, crc});
       have = want == 8 + 18;
       if (have) memcpy(h, tail + 8, 18);
@@ -105,10 +188,9 @@ bool BgzfFeed::open(const std::string &path, std::string &err) {
     }
     (void)publish();
   });
-  return true;
 }
 
-int64_t BgzfFeed::next(std::vector<Block> &out, size_t max_blocks, size_t max_bytes, std::string &err) {
+int64_t BgzfFeed::next(std::vector<Block> &out, size_t max_blocks, size_t max_bytes, std::string &err, bool *last) {
   out.clear();
   std::unique_lock<std::mutex> lk(mu_);
   for (;;) {
@@ -126,6 +208,10 @@ int64_t BgzfFeed::next(std::vector<Block> &out, size_t max_blocks, size_t max_by
     }
     if (state_ == 1) break;
     cv_.wait(lk);
+  }
+  if (last) {      // is anything behind this run?  (waits for the walker's next batch or its end)
+    while (taken_ == blks_.size() && state_ == 0) { cv_.notify_all(); cv_.wait(lk); }
+    *last = taken_ == blks_.size();
   }
   if (taken_ > (1u << 16)) { blks_.erase(blks_.begin(), blks_.begin() + (long)taken_); taken_ = 0; }
   lk.unlock();

@@ -20,20 +20,39 @@ class BgzfFeed {
   ~BgzfFeed();
   // header text + targets (read with the plain reader), maps the file, starts the walker at the block the first record is in
   bool open(const std::string &path, std::string &err);
+  // One contiguous SHARE of a file another feed has open (`strling extract --gpus N`: a share per context, each with its own
+  // header walker): blocks from the one at file offset start_coff up to the record boundary at the virtual offset
+  // (end_coff, end_uoff) -- the block at end_coff is the share's last when end_uoff > 0, and its bytes from end_uoff on belong
+  // to the next share (tail_trim()).  end_coff = 0: to the end of the file.  first_off = offset of the share's first record
+  // in its first block's inflated bytes.  Both ends are record starts taken from the .bai (split_points).
+  bool open_share(const BgzfFeed &whole, uint64_t start_coff, uint32_t first_off, uint64_t end_coff, uint32_t end_uoff, std::string &err);
   void close();
+  // Virtual offsets (coffset << 16 | uoffset) of record starts named by the .bai next to `path` (linear index + bin chunk
+  // starts), ascending and distinct; empty when there is no usable index.
+  static std::vector<uint64_t> split_points(const std::string &path);
+  // inflated bytes at the end of the share's last block that belong to the next share (known once next() has said `last`)
+  uint32_t tail_trim() const { return trim_; }
+  const std::string &path() const { return path_; }
   const std::string &header_text() const { return text_; }
   const std::vector<BamTarget> &targets() const { return targets_; }
   uint64_t first_record_offset() const { return first_off_; }   // bytes into the first block's inflated data
+  uint64_t first_block_offset() const { return start_; }        // file offset of that block
+  void halt();                                                  // stops the header walker (the file stays open: read_at, open_share)
   size_t file_bytes() const { return map_len_; }
   // n bytes of the file at offset off into dst (any thread); false on a short read
   bool read_at(void *dst, size_t off, size_t n) const;
   struct Block { size_t c_off; uint32_t clen, isize, crc; };     // DEFLATE payload at file offset c_off; CRC-32 of the inflated bytes (trailer)
   // Next run of consecutive non-empty blocks: at most max_blocks and max_bytes of file (first block's payload to the last
   // block's end).  Returns the number of blocks (0 at the end of the file), -1 on a malformed file.
-  int64_t next(std::vector<Block> &out, size_t max_blocks, size_t max_bytes, std::string &err);
+  // *last (if given): this run reaches the end of the file / share (the call waits until the walker can tell).
+  int64_t next(std::vector<Block> &out, size_t max_blocks, size_t max_bytes, std::string &err, bool *last = nullptr);
 
  private:
+  void walk_from(size_t start, uint64_t end_coff, uint32_t end_uoff);
   int fd_ = -1;
+  std::string path_;
+  uint32_t trim_ = 0;
+  uint64_t start_ = 0;
   size_t map_len_ = 0;          // file size
   uint64_t first_off_ = 0;
   std::string text_;

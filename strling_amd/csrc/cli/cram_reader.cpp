@@ -47,14 +47,78 @@ struct Block {
   const uint8_t *data = nullptr;
 };
 
-bool read_block(Rd &r, Block &b) {
+// CRAMv3 section 8: every block ends in the CRC-32 of all its bytes before it; htslib refuses a block whose checksum differs
+// (cram_read_block), so a flipped byte in an external block is an error here too, not silently other bases
+bool read_block(Rd &r, Block &b, std::string *err = nullptr) {
+  const uint8_t *start = r.p;
   b.method = r.u8(); b.type = r.u8(); b.id = r.itf8();
   b.csize = (uint32_t)r.itf8(); b.rsize = (uint32_t)r.itf8();
   b.data = r.p;
   r.skip(b.csize);
-  r.skip(4);      // CRC-32 (checked by `strling` only through the decoded content's consistency)
-  return r.ok;
+  const uint8_t *end = r.p;
+  const uint32_t want = (uint32_t)r.i32();
+  if (!r.ok) return false;
+  if ((uint32_t)crc32(0L, start, (uInt)(end - start)) != want) { if (err) *err = "CRAM block CRC32 mismatch"; return false; }
+  return true;
 }
+
+// ---- MD5 (RFC 1321): the slice header's checksum of the reference bases the slice was written against ----------------------
+struct Md5 {
+  uint32_t h[4] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u};
+  uint8_t buf[64];
+  uint64_t n = 0;
+  static uint32_t rol(uint32_t x, int c) { return (x << c) | (x >> (32 - c)); }
+  void block(const uint8_t *p) {
+    static const uint32_t K[64] = {
+        0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122,
+        0xfd987193, 0xa679438e, 0x49b40821, 0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6,
+        0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a, 0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60,
+        0xbebfbc70, 0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665, 0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039,
+        0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+    static const int S[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20,
+                              4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
+    uint32_t w[16];
+    memcpy(w, p, 64);
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3];
+    for (int i = 0; i < 64; ++i) {
+      uint32_t f;
+      int g;
+      if (i < 16) { f = (b & c) | (~b & d); g = i; }
+      else if (i < 32) { f = (d & b) | (~d & c); g = (5 * i + 1) & 15; }
+      else if (i < 48) { f = b ^ c ^ d; g = (3 * i + 5) & 15; }
+      else { f = c ^ (b | ~d); g = (7 * i) & 15; }
+      const uint32_t t = d;
+      d = c; c = b;
+      b = b + rol(a + f + K[i] + w[g], S[i]);
+      a = t;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d;
+  }
+  void update(const uint8_t *p, size_t len) {
+    size_t fill = (size_t)(n & 63);
+    n += len;
+    if (fill) {
+      const size_t take = std::min(len, 64 - fill);
+      memcpy(buf + fill, p, take);
+      p += take; len -= take; fill += take;
+      if (fill < 64) return;
+      block(buf);
+    }
+    for (; len >= 64; p += 64, len -= 64) block(p);
+    if (len) memcpy(buf, p, len);
+  }
+  void finish(uint8_t out[16]) {
+    const uint64_t bits = n * 8;
+    const uint8_t pad = 0x80;
+    update(&pad, 1);
+    const uint8_t z = 0;
+    while ((n & 63) != 56) update(&z, 1);
+    uint8_t l[8];
+    memcpy(l, &bits, 8);
+    update(l, 8);
+    memcpy(out, h, 16);
+  }
+};
 
 // ---- rANS 4x8, CRAMv3 section 13 ----------------------------------------------------------------------------------------
 constexpr uint32_t RANS_L = 1u << 23;
@@ -153,6 +217,7 @@ bool rans_decode(const uint8_t *in, size_t in_len, std::vector<uint8_t> &out, si
 }
 
 bool block_data(const Block &b, std::vector<uint8_t> &out, std::string &err) {
+  if (b.rsize > (1u << 30)) { err = "CRAM block of more than 1 GiB"; return false; }      // (before anything is allocated for a hostile size field)
   switch (b.method) {
     case 0:
       out.assign(b.data, b.data + b.csize);
@@ -200,7 +265,8 @@ bool parse_encoding(Rd &r, Enc &e, std::string &err) {
     case 1: e.ext = p.itf8(); return p.ok;
     case 3: {
       const int32_t ns = p.itf8();
-      std::vector<int32_t> s((size_t)std::max(ns, 0));
+      if (!p.ok || ns < 0 || (size_t)ns > (size_t)(p.e - p.p)) { err = "malformed HUFFMAN encoding"; return false; }     // (a symbol takes a byte at least)
+      std::vector<int32_t> s((size_t)ns);
       for (auto &x : s) x = p.itf8();
       const int32_t nl = p.itf8();
       if (nl != ns || !p.ok || ns <= 0) { err = "malformed HUFFMAN encoding"; return false; }
@@ -350,8 +416,9 @@ bool parse_comp_header(const std::vector<uint8_t> &d, CompHeader &h, std::string
   Rd r{d.data(), d.data() + d.size()};
   {
     const int32_t sz = r.itf8();
-    Rd m{r.p, r.p + std::max(sz, 0)};
-    r.skip((size_t)std::max(sz, 0));
+    if (!r.ok || sz < 0 || (size_t)sz > (size_t)(r.e - r.p)) { err = "malformed CRAM compression header (preservation map)"; return false; }
+    Rd m{r.p, r.p + sz};
+    r.skip((size_t)sz);
     const int32_t n = m.itf8();
     for (int32_t i = 0; i < n && m.ok; ++i) {
       const char k0 = (char)m.u8(), k1 = (char)m.u8();
@@ -378,8 +445,9 @@ bool parse_comp_header(const std::vector<uint8_t> &d, CompHeader &h, std::string
   }
   {
     const int32_t sz = r.itf8();
-    Rd m{r.p, r.p + std::max(sz, 0)};
-    r.skip((size_t)std::max(sz, 0));
+    if (!r.ok || sz < 0 || (size_t)sz > (size_t)(r.e - r.p)) { err = "malformed CRAM compression header (encoding map)"; return false; }
+    Rd m{r.p, r.p + sz};
+    r.skip((size_t)sz);
     const int32_t n = m.itf8();
     for (int32_t i = 0; i < n && m.ok; ++i) {
       std::string k(2, ' ');
@@ -390,8 +458,9 @@ bool parse_comp_header(const std::vector<uint8_t> &d, CompHeader &h, std::string
   }
   {
     const int32_t sz = r.itf8();
-    Rd m{r.p, r.p + std::max(sz, 0)};
-    r.skip((size_t)std::max(sz, 0));
+    if (!r.ok || sz < 0 || (size_t)sz > (size_t)(r.e - r.p)) { err = "malformed CRAM compression header (encoding map)"; return false; }
+    Rd m{r.p, r.p + sz};
+    r.skip((size_t)sz);
     const int32_t n = m.itf8();
     for (int32_t i = 0; i < n && m.ok; ++i) {
       const int32_t k = m.itf8();
@@ -487,7 +556,7 @@ bool RefCache::load_all(std::string &err) {
       seq.reset(new std::string());
       cur = seq.get();
     } else if (cur) {
-      for (size_t k = 0; k < n; ++k) { const char ch = (char)toupper((unsigned char)s[k]); cur->push_back(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' ? ch : 'N'); }
+      for (size_t k = 0; k < n; ++k) cur->push_back((char)toupper((unsigned char)s[k]));
     }
     cur_line_continues_ = !whole;
   }
@@ -499,7 +568,12 @@ bool RefCache::load_all(std::string &err) {
 
 std::shared_ptr<const std::string> RefCache::get(const std::string &name, std::string &err) {
   std::lock_guard<std::mutex> lk(mu_);
-  for (auto &p : loaded_) if (p.first == name) return p.second;
+  for (size_t k = 0; k < loaded_.size(); ++k)
+    if (loaded_[k].first == name) {
+      std::shared_ptr<const std::string> r = loaded_[k].second;
+      if (!all_loaded_ && k + 1 != loaded_.size()) std::rotate(loaded_.begin() + (long)k, loaded_.begin() + (long)k + 1, loaded_.end());     // used last
+      return r;
+    }
   if (all_loaded_) return nullptr;
   if (fai_.empty()) {
     if (!load_all(err)) return nullptr;
@@ -522,10 +596,10 @@ std::shared_ptr<const std::string> RefCache::get(const std::string &name, std::s
     for (size_t k = 0; k < got && seq->size() < x.len; ++k) {
       const char ch = raw[k];
       if (ch == '\n' || ch == '\r') continue;
-      const char u = (char)toupper((unsigned char)ch);
-      seq->push_back(u == 'A' || u == 'C' || u == 'G' || u == 'T' ? u : 'N');
+      seq->push_back((char)toupper((unsigned char)ch));
     }
     loaded_.push_back({name, seq});
+    if (loaded_.size() > keep_) loaded_.erase(loaded_.begin());      // (readers that still use the oldest hold their own reference to it)
     return seq;
   }
   return nullptr;
@@ -559,15 +633,18 @@ bool CramFile::parse_container_header(uint64_t off, Container &c, std::string &e
   r.itf8();
   const int32_t nl = r.itf8();
   c.landmarks.clear();
+  if (nl < 0 || (size_t)nl > (size_t)(r.e - r.p)) { err = "malformed CRAM container header"; return false; }
   for (int32_t k = 0; k < nl && r.ok; ++k) c.landmarks.push_back(r.itf8());
-  r.skip(4);
+  const uint8_t *hdr_end = r.p;
+  const uint32_t want = (uint32_t)r.i32();
   if (!r.ok) { err = "truncated CRAM container header"; return false; }
+  if ((uint32_t)crc32(0L, map_ + off, (uInt)(hdr_end - (map_ + off))) != want) { err = "CRAM container header CRC32 mismatch"; return false; }
   c.data_off = (uint64_t)(r.p - map_);
   if (c.data_off + c.len > map_len_) { err = "CRAM container reaches past the end of the file"; return false; }
   return true;
 }
 
-bool CramFile::open(const std::string &path, const std::string &fasta, int threads, std::string &err) {
+bool CramFile::open(const std::string &path, const std::string &fasta, int threads, std::string &err, std::shared_ptr<RefCache> share) {
   path_ = path;
   const int fd = ::open(path.c_str(), O_RDONLY);
   if (fd < 0) { err = "couldn't open bam"; return false; }
@@ -588,7 +665,7 @@ bool CramFile::open(const std::string &path, const std::string &fasta, int threa
   {
     Rd r{map_ + c.data_off, map_ + c.data_off + c.len};
     Block b;
-    if (!read_block(r, b) || b.type != 0) { err = "CRAM without a file header block"; return false; }
+    if (!read_block(r, b, &err) || b.type != 0) { if (err.empty()) err = "CRAM without a file header block"; return false; }
     std::vector<uint8_t> d;
     if (!block_data(b, d, err)) return false;
     if (d.size() < 4) { err = "truncated CRAM file header"; return false; }
@@ -619,13 +696,15 @@ bool CramFile::open(const std::string &path, const std::string &fasta, int threa
   next_off_ = c.data_off + c.len;
   threads_ = std::max(1, threads);
   if (fasta.empty()) { err = "CRAM input needs the reference it was written against: give it with -f FASTA"; return false; }
-  return ref_.open(fasta, err);
+  if (share) { ref_ = share; return true; }
+  ref_.reset(new RefCache());
+  return ref_->open(fasta, err);
 }
 
 bool CramFile::decode_container(const Container &c, int64_t only_landmark, RecordBatch &out, std::string &err) {
   Rd r{map_ + c.data_off, map_ + c.data_off + c.len};
   Block hb;
-  if (!read_block(r, hb) || hb.type != 1) { err = "CRAM container without a compression header"; return false; }
+  if (!read_block(r, hb, &err) || hb.type != 1) { if (err.empty()) err = "CRAM container without a compression header"; return false; }
   std::vector<uint8_t> hd;
   CompHeader H;
   if (!block_data(hb, hd, err) || !parse_comp_header(hd, H, err)) return false;
@@ -647,12 +726,11 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
     if (sl >= c.len) { err = "CRAM slice landmark outside its container"; return false; }
     Rd s{map_ + c.data_off + sl, map_ + c.data_off + c.len};
     Block sb;
-    if (!read_block(s, sb) || sb.type != 2) { err = "CRAM slice without a slice header block"; return false; }
+    if (!read_block(s, sb, &err) || sb.type != 2) { if (err.empty()) err = "CRAM slice without a slice header block"; return false; }
     std::vector<uint8_t> sd;
     if (!block_data(sb, sd, err)) return false;
     Rd h{sd.data(), sd.data() + sd.size()};
-    const int32_t s_ref = h.itf8(), s_start = h.itf8();
-    h.itf8();
+    const int32_t s_ref = h.itf8(), s_start = h.itf8(), s_span = h.itf8();
     const int32_t s_nrec = h.itf8();
     h.ltf8();
     const int32_t s_nblocks = h.itf8();
@@ -661,10 +739,32 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
     const int32_t embedded = h.itf8();
     if (!h.ok || s_nrec < 0 || s_nblocks < 0 || s_nrec > (1 << 24) || s_nblocks > (1 << 16)) { err = "malformed CRAM slice header"; return false; }
     if (embedded >= 0) { err = "the CRAM slice embeds its reference: not supported by this build (samtools view -C --output-fmt-option embed_ref=0)"; return false; }
+    uint8_t s_md5[16] = {0};
+    for (int k = 0; k < 16; ++k) s_md5[k] = h.u8();
+    if (!h.ok) { err = "truncated CRAM slice header"; return false; }
+    // The MD5 of the reference bases the slice spans, as the writer saw them (CRAMv3 section 8.5): a FASTA that differs there
+    // (another build, a patched contig) would give other bases for every matching position -- htslib fails the slice, so do we
+    if (s_ref >= 0 && (size_t)s_ref < targets_.size() && s_span > 0 && H.rr) {
+      bool any = false;
+      for (uint8_t x : s_md5) any = any || x;
+      if (any) {
+        std::shared_ptr<const std::string> rs = ref_->get(targets_[(size_t)s_ref].name, err);
+        if (!rs) { if (err.empty()) err = "reference sequence " + targets_[(size_t)s_ref].name + " of the CRAM is not in the FASTA"; return false; }
+        const size_t a = (size_t)std::max(s_start - 1, 0), b = std::min(rs->size(), a + (size_t)s_span);
+        uint8_t got[16];
+        Md5 m;
+        if (b > a) m.update(reinterpret_cast<const uint8_t *>(rs->data()) + a, b - a);
+        m.finish(got);
+        if (memcmp(got, s_md5, 16) != 0) {
+          err = "the FASTA is not the reference this CRAM was written against: MD5 mismatch on " + targets_[(size_t)s_ref].name + ":" + std::to_string(s_start) + "-" + std::to_string(s_start + s_span - 1);
+          return false;
+        }
+      }
+    }
     Ctx X;
     for (int32_t k = 0; k < s_nblocks; ++k) {
       Block b;
-      if (!read_block(s, b)) { err = "truncated CRAM slice"; return false; }
+      if (!read_block(s, b, &err)) { if (err.empty()) err = "truncated CRAM slice"; return false; }
       if (b.type == 5) { if (!block_data(b, X.core, err)) return false; }
       else if (b.type == 4) { if (!block_data(b, X.ext[b.id].d, err)) return false; }
     }
@@ -676,7 +776,7 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
       ref.reset();
       ref_of = id;
       if (id < 0 || (size_t)id >= targets_.size()) return true;
-      ref = ref_.get(targets_[(size_t)id].name, err);
+      ref = ref_->get(targets_[(size_t)id].name, err);
       if (!ref && H.rr) { if (err.empty()) err = "reference sequence " + targets_[(size_t)id].name + " of the CRAM is not in the FASTA"; return false; }
       return true;
     };
@@ -809,28 +909,69 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
       recs.push_back(R);
     }
     if (!X.ok) { err = "CRAM: " + X.err; return false; }
-    // mates inside the slice (CRAMv3 section 10.5: "mate downstream", NF = records to skip to the next fragment)
-    for (size_t i = first; i < recs.size(); ++i) {
-      Rec &a = recs[i];
-      if (a.cf & 2) {
-        a.mtid = a.ns; a.mpos = a.np - 1; a.isize = a.ts;
-        a.flag |= (a.mf & 1 ? 0x20 : 0) | (a.mf & 2 ? 0x8 : 0);
-        a.mate_set = true;
-      } else if ((a.cf & 4) && a.nf >= 0) {
+    // Mates inside the slice (CRAMv3 section 10.5: "mate downstream", NF = records to skip to the next fragment), the way
+    // htslib's cram_decode_slice_xref resolves them: the NF links form a CHAIN (a template may have supplementary records in
+    // it), every record's mate is the next of its chain and the last one's is the first; the template length spans the
+    // leftmost start to the rightmost end of the whole chain, positive for the leftmost record (ties: the first-in-pair
+    // one), zero when the chain touches two references or the record or its mate is unmapped.
+    const size_t n_slice = recs.size() - first;
+    std::vector<int64_t> mate_line(n_slice, -1);
+    std::vector<uint8_t> tlen_set(n_slice, 0);
+    for (size_t i = 0; i < n_slice; ++i) {
+      const Rec &a = recs[first + i];
+      if (!(a.cf & 2) && (a.cf & 4) && a.nf >= 0) {
         const size_t j = i + (size_t)a.nf + 1;
-        if (j >= recs.size()) { err = "CRAM: a mate link points outside its slice"; return false; }
-        Rec &b = recs[j];
-        a.mtid = b.ref; a.mpos = b.pos - 1; b.mtid = a.ref; b.mpos = a.pos - 1;
-        a.flag |= (b.flag & 0x10 ? 0x20 : 0) | (b.flag & 0x4 ? 0x8 : 0);
-        b.flag |= (a.flag & 0x10 ? 0x20 : 0) | (a.flag & 0x4 ? 0x8 : 0);
-        if (a.ref == b.ref && a.ref >= 0) {
-          const int32_t left = std::min(a.pos, b.pos), right = std::max(a.aend, b.aend), t = right - left + 1;
-          const bool a_first = a.pos < b.pos || (a.pos == b.pos && (a.flag & 0x40));
-          a.isize = a_first ? t : -t; b.isize = a_first ? -t : t;
-        }
-        a.mate_set = b.mate_set = true;
-        if (names[a.name_at] == '\x01' && a.name_len == 1 && names[b.name_at] == '\x01' && b.name_len == 1) b.gen = a.gen;      // share the generated name
+        if (j >= n_slice) { err = "CRAM: a mate link points outside its slice"; return false; }
+        mate_line[i] = (int64_t)j;
       }
+    }
+    for (size_t i = 0; i < n_slice; ++i) {
+      Rec &a = recs[first + i];
+      if (a.cf & 2) {                 // detached: mate fields stored with the record
+        a.mtid = a.ns; a.mpos = a.np - 1; a.isize = a.ts;
+        if (a.mf & 1) a.flag |= 0x1 | 0x20;
+        if (a.mf & 2) a.flag |= 0x8;
+        if (!(a.flag & 0x1)) a.mtid = -1;
+        a.mate_set = true;
+        continue;
+      }
+      if (mate_line[i] < 0) continue;
+      if (!tlen_set[i]) {
+        size_t id2 = i;
+        int32_t aleft = a.pos, aright = a.aend, ref = a.ref;
+        int left_cnt = 0;
+        for (;;) {
+          const Rec &r2 = recs[first + id2];
+          if (aleft > r2.pos) { aleft = r2.pos; left_cnt = 1; }
+          else if (aleft == r2.pos) ++left_cnt;
+          if (aright < r2.aend) aright = r2.aend;
+          if (mate_line[id2] == -1) { mate_line[id2] = (int64_t)i; break; }     // the chain's last record: its mate is the first
+          if (mate_line[id2] <= (int64_t)id2) { err = "CRAM: a mate link points backwards"; return false; }
+          id2 = (size_t)mate_line[id2];
+          if (recs[first + id2].ref != ref) ref = -1;
+          if (id2 == i) break;
+        }
+        const int32_t tlen = aright - aleft + 1;
+        id2 = i;
+        do {
+          Rec &r2 = recs[first + id2];
+          if (ref == -1) r2.isize = 0;
+          else if (r2.pos == aleft) r2.isize = (left_cnt == 1 || (r2.flag & 0x40)) ? tlen : -tlen;
+          else r2.isize = -tlen;
+          tlen_set[id2] = 1;
+          id2 = (size_t)mate_line[id2];
+        } while (id2 != i);
+      }
+      const Rec &m = recs[first + (size_t)mate_line[i]];
+      a.mpos = m.pos - 1; a.mtid = m.ref;
+      a.flag |= 0x1;
+      if (m.flag & 0x4) { a.flag |= 0x8; a.isize = 0; }
+      if (a.flag & 0x4) a.isize = 0;
+      if (m.flag & 0x10) a.flag |= 0x20;
+      a.mate_set = true;
+      // a generated name is shared along the chain
+      Rec &mm = recs[first + (size_t)mate_line[i]];
+      if ((size_t)mate_line[i] > i && names[a.name_at] == '\x01' && a.name_len == 1 && names[mm.name_at] == '\x01' && mm.name_len == 1) mm.gen = a.gen;
     }
   }
   // ---- the records into the batch ----
@@ -846,7 +987,8 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
     out.mtid.push_back(R.mate_set ? R.mtid : -1);
     out.mpos.push_back(R.mate_set ? R.mpos : -1);
     out.isize.push_back(R.isize);
-    out.l_seq.push_back(R.rl);
+    const int32_t rl_out = (R.cf & 8) ? 0 : R.rl;       // CRAM_FLAG_NO_SEQ: the record has no bases ("*"), whatever RL says
+    out.l_seq.push_back(rl_out);
     out.flag.push_back((uint16_t)R.flag);
     out.mapq.push_back((uint8_t)R.mapq);
     if (R.name_len == 1 && names[R.name_at] == '\x01') {
@@ -857,10 +999,10 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
     out.qname_off.push_back(out.qnames.size());
     out.cigar.insert(out.cigar.end(), cig.begin() + (long)R.cig_at, cig.begin() + (long)(R.cig_at + R.cig_n));
     out.cigar_off.push_back((uint32_t)out.cigar.size());
-    const size_t so = (out.seq4.size() + 15) & ~(size_t)15, sb = ((size_t)R.rl + 1) / 2;
+    const size_t so = (out.seq4.size() + 15) & ~(size_t)15, sb = ((size_t)rl_out + 1) / 2;
     out.seq4.resize(so + sb, 0);
     const char *sq = seqs.data() + R.seq_at;
-    for (int32_t k = 0; k < R.rl; ++k) out.seq4[so + (size_t)(k >> 1)] |= (uint8_t)(NIB.t[(uint8_t)sq[k]] << ((k & 1) ? 0 : 4));
+    for (int32_t k = 0; k < rl_out; ++k) out.seq4[so + (size_t)(k >> 1)] |= (uint8_t)(NIB.t[(uint8_t)sq[k]] << ((k & 1) ? 0 : 4));
     out.seq_off.push_back(so);
   }
   return true;
@@ -874,10 +1016,17 @@ int64_t CramFile::read(RecordBatch &b, int64_t max_records, std::string &err) {
     std::vector<Container> cs;
     int64_t planned = 0;
     while ((int)cs.size() < threads_ * 2 && got + planned < max_records) {
-      if (next_off_ + 26 > map_len_) { eof_ = true; break; }
+      if (next_off_ >= map_len_) {
+        eof_ = true;
+        // CRAMv3 section 9: the file ends in the EOF container; htslib warns about a file without one ("EOF marker is absent"),
+        // a file cut between two containers looks complete otherwise -- refuse it
+        if (!saw_eof_container_) { err = "the CRAM does not end in its EOF container: the file is truncated"; return -1; }
+        break;
+      }
       Container c;
       if (!parse_container_header(next_off_, c, err)) return -1;
       next_off_ = c.data_off + c.len;
+      saw_eof_container_ = c.n_records == 0 && c.ref_id == -1 && next_off_ == map_len_;
       if (c.n_records <= 0 || c.landmarks.empty()) continue;       // the EOF container, empty containers
       planned += c.n_records;
       cs.push_back(std::move(c));
@@ -913,20 +1062,47 @@ bool CramFile::load_index(std::string &err) {
       crai_.push_back(CraiEntry{(int32_t)tid, st, sp, (uint64_t)co, (uint32_t)so, (uint32_t)sz});
   }
   gzclose(in);
+  // (tid, start) order + the running maximum end per tid: a region's slices are found by a binary search and a short walk
+  // back (a whole-genome .crai has ~3e5 slices; `call` asks ~1e5 times)
+  std::stable_sort(crai_.begin(), crai_.end(), [](const CraiEntry &a, const CraiEntry &b) { return a.tid != b.tid ? a.tid < b.tid : a.start < b.start; });
+  crai_max_end_.resize(crai_.size());
+  for (size_t k = 0; k < crai_.size(); ++k) {
+    const int64_t e = crai_[k].start - 1 + std::max<int64_t>(crai_[k].span, 1);
+    crai_max_end_[k] = k && crai_[k - 1].tid == crai_[k].tid ? std::max(crai_max_end_[k - 1], e) : e;
+  }
   have_index_ = true;
   return true;
 }
 
 int64_t CramFile::read_region(RecordBatch &b, int32_t tid, int64_t beg, int64_t end, std::string &err) {
   int64_t n = 0;
-  RecordBatch part;
-  for (const CraiEntry &e : crai_) {
-    if (e.tid != tid) continue;
+  // entries of `tid` whose start lies before `end`: [lo, hi); of those, the ones reaching past `beg` sit at the end of the run --
+  // walking back stops where the running maximum end no longer reaches `beg`
+  const auto first = std::lower_bound(crai_.begin(), crai_.end(), tid, [](const CraiEntry &e, int32_t t) { return e.tid < t; });
+  auto hi = first;
+  {
+    auto cnt = crai_.end() - first;
+    while (cnt > 0) {                   // first entry of another tid, or starting at / behind `end`
+      auto step = cnt / 2;
+      auto mid = hi + step;
+      if (mid->tid == tid && mid->start - 1 < end) { hi = mid + 1; cnt -= step + 1; } else cnt = step;
+    }
+  }
+  size_t lo = (size_t)(hi - crai_.begin());
+  const size_t f = (size_t)(first - crai_.begin()), h = lo;
+  while (lo > f && crai_max_end_[lo - 1] > beg) --lo;
+  for (size_t k = lo; k < h; ++k) {
+    const CraiEntry &e = crai_[k];
     const int64_t s0 = e.start - 1, s1 = s0 + std::max<int64_t>(e.span, 1);     // 0-based, half open
     if (s0 >= end || s1 <= beg) continue;
-    Container c;
-    if (!parse_container_header(e.c_off, c, err)) return -1;
-    if (!decode_container(c, (int64_t)e.s_off, part, err)) return -1;
+    if (e.c_off != last_c_off_ || e.s_off != last_s_off_) {          // consecutive bounds fall into the same slice: decoded once
+      Container c;
+      if (!parse_container_header(e.c_off, c, err)) return -1;
+      last_c_off_ = ~0ull;
+      if (!decode_container(c, (int64_t)e.s_off, last_slice_, err)) return -1;
+      last_c_off_ = e.c_off; last_s_off_ = e.s_off;
+    }
+    const RecordBatch &part = last_slice_;
     RecordBatch keep;
     // records of `tid` that start before `end` (a multi-reference slice holds other references' records too; the consumers
     // apply the overlap filter themselves, like for a BAM region read)

@@ -22,6 +22,8 @@ class RefCache {
  public:
   bool open(const std::string &fasta, std::string &err);
   // nullptr if the FASTA has no such sequence
+  // (bases upper-cased, IUPAC codes kept: what htslib hands out and what the slices' MD5s are made of).  One cache serves every
+  // reader of the FASTA (`strling call`'s workers share it); a FASTA with a .fai keeps the few contigs used last, not the genome
   std::shared_ptr<const std::string> get(const std::string &name, std::string &err);
 
  private:
@@ -30,6 +32,7 @@ class RefCache {
   std::vector<std::pair<std::string, Fai>> fai_;
   std::vector<std::pair<std::string, std::shared_ptr<const std::string>>> loaded_;
   bool all_loaded_ = false, cur_line_continues_ = false;
+  size_t keep_ = 6;             // contigs kept when they can be read again (a .fai): callers move along the genome together
   std::mutex mu_;
   bool load_all(std::string &err);
 };
@@ -38,7 +41,9 @@ class CramFile {
  public:
   ~CramFile();
   static bool is_cram(const std::string &path);
-  bool open(const std::string &path, const std::string &fasta, int threads, std::string &err);
+  // share: the reference cache of another reader of the same FASTA (open_like); null = a cache of its own
+  bool open(const std::string &path, const std::string &fasta, int threads, std::string &err, std::shared_ptr<RefCache> share = nullptr);
+  std::shared_ptr<RefCache> ref_cache() const { return ref_; }
   const std::string &header_text() const { return text_; }
   const std::vector<BamTarget> &targets() const { return targets_; }
   // sequential read, file order: appends up to ~max_records records (whole containers); 0 at the end, -1 on error
@@ -58,13 +63,18 @@ class CramFile {
   size_t map_len_ = 0;
   std::string path_, text_;
   std::vector<BamTarget> targets_;
-  RefCache ref_;
+  std::shared_ptr<RefCache> ref_;
   uint64_t next_off_ = 0;       // next container of the sequential read
   bool eof_ = false;
   int threads_ = 1;
   ThreadPool *pool_ = nullptr;
-  std::vector<CraiEntry> crai_;
-  bool have_index_ = false;
+  std::vector<CraiEntry> crai_;                 // sorted by (tid, start)
+  std::vector<int64_t> crai_max_end_;           // running maximum of start + span within a tid: where a backward scan may stop
+  bool have_index_ = false, saw_eof_container_ = false;
+  // the slice a region read decoded last (consecutive bounds fall into the same slice)
+  uint64_t last_c_off_ = ~0ull;
+  uint32_t last_s_off_ = 0;
+  RecordBatch last_slice_;
 };
 
 }  // namespace strl

@@ -305,7 +305,7 @@ static void setup_genome(strl_ctx *ctx, const Args &a, const std::vector<BamTarg
 }
 
 static int extract_front(const Args &a, const std::string &bam, const std::string &bin, double p, uint8_t min_mapq, bool verbose);
-constexpr int EXTRACT_AGAIN_ON_HOST = -77, EXTRACT_AGAIN_HOST_FRONT = -78;
+constexpr int EXTRACT_AGAIN_ON_HOST = -77, EXTRACT_AGAIN_HOST_FRONT = -78, EXTRACT_AGAIN_BY_CHUNKS = -79;
 
 static int extract_main(int argc, char **argv) {
   const char *usage =
@@ -332,7 +332,13 @@ static int extract_main(int argc, char **argv) {
     // host reader (threads inflate and parse, the device scores); STRL_PAIR=host (the host's streaming Cache) implies it.
     const char *fe = getenv("STRL_FRONT"), *pe = getenv("STRL_PAIR");
     if (!(fe && strcmp(fe, "host") == 0) && !(pe && strcmp(pe, "host") == 0)) {
-      const int r = extract_front(a, bam, bin, p, min_mapq, verbose);
+      int r = extract_front(a, bam, bin, p, min_mapq, verbose);
+      // (EXTRACT_AGAIN_BY_CHUNKS: --gpus N found the .bai's record starts not to be record starts; the same front end again,
+      // chunk by chunk over the contexts, which needs no index)
+      if (r == EXTRACT_AGAIN_BY_CHUNKS) {
+        setenv("STRL_SHARES", "0", 1);
+        r = extract_front(a, bam, bin, p, min_mapq, verbose);
+      }
       if (r != EXTRACT_AGAIN_ON_HOST && r != EXTRACT_AGAIN_HOST_FRONT) return r;
       if (r == EXTRACT_AGAIN_ON_HOST) setenv("STRL_PAIR", "host", 1);   // the device join passed (hash collision / one qname on hundreds of records): the string-keyed Cache
       // (EXTRACT_AGAIN_HOST_FRONT: the device front end refused the file -- a block its decoder does not take, a record of more
@@ -586,6 +592,23 @@ static int extract_main(int argc, char **argv) {
 // page-locked buffers; inflate, record scan, parse, scorer, pair logic all run on the GPU (extract.nim:275-348).
 // --gpus N: the file's chunks go round-robin over N contexts (one per device, round-robin over the devices there are);
 // what the pair logic needs of every record is gathered on the first one at the end (strl_ctxs_extract_gather).
+// `extract --gpus G`: where the file is cut into contiguous shares, as virtual offsets (coffset << 16 | uoffset).  cut[0] = the
+// first record; every further cut is a record start the .bai names, the first one at or behind g / G of the bytes behind the
+// header.  Fewer than G entries when the index has too few points (a contig-free tail, a tiny file); one entry: no shares.
+static std::vector<uint64_t> share_cuts(const BgzfFeed &feed, const std::string &bam, int G) {
+  std::vector<uint64_t> cut;
+  const std::vector<uint64_t> pts = BgzfFeed::split_points(bam);
+  const uint64_t lo = feed.first_block_offset(), span = feed.file_bytes() - lo;
+  cut.push_back((lo << 16) | feed.first_record_offset());
+  for (int g = 1; g < G; ++g) {
+    const uint64_t want = (lo + (uint64_t)((double)span * g / G)) << 16;
+    auto it = std::lower_bound(pts.begin(), pts.end(), std::max(want, cut.back() + 1));
+    if (it == pts.end()) break;
+    cut.push_back(*it);
+  }
+  return cut;
+}
+
 static int extract_front(const Args &a, const std::string &bam, const std::string &bin, double p, uint8_t min_mapq, bool verbose) {
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double>(y - x).count(); };
@@ -600,9 +623,16 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     struct stat st;
     if (stat(bam.c_str(), &st) == 0) auto_blocks = std::min<size_t>(16384, std::max<size_t>(8192, (size_t)st.st_size / 16384 / 12));
   }
+  const int G = std::max(1, atoi(a.get("gpus", "1").c_str()));
+  // --gpus N: every context takes one contiguous share of the file (below) unless STRL_SHARES=0 / there is no usable .bai
+  const char *env_shares = getenv("STRL_SHARES");        // (read per call: extract_main sets it to 0 for the chunk-by-chunk repeat)
+  bool use_shares = G > 1 && !(env_shares && strcmp(env_shares, "0") == 0);
+  if (use_shares) {
+    struct stat st;
+    if (stat(bam.c_str(), &st) == 0) auto_blocks = std::min<size_t>(16384, std::max<size_t>(4096, (size_t)st.st_size / (size_t)G / 16384 / 12));
+  }
   const size_t chunk_blocks = env_blocks && atoi(env_blocks) > 0 ? (size_t)atoi(env_blocks) : auto_blocks;
   const size_t chunk_bytes = std::max<size_t>((size_t)1 << 20, chunk_blocks * 20000);       // compressed bytes one chunk may span
-  const int G = std::max(1, atoi(a.get("gpus", "1").c_str()));
   std::vector<strl_ctx *> ctxs((size_t)G, nullptr);
   std::vector<int> ctx_rc((size_t)G, 0);
   std::vector<std::string> ctx_err((size_t)G);
@@ -659,8 +689,22 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   static const char *env_hint = getenv("STRL_READS_HINT");
   const uint64_t reads_hint = env_hint ? strtoull(env_hint, nullptr, 10) : feed.file_bytes() / 88 / (size_t)G;
   const auto tb0 = now();
-  for (strl_ctx *c : ctxs) {
-    CHECK(strl_front_begin(c, n_ref, feed.first_record_offset(), reads_hint));
+  // Shares of the file, one per context: [cut[g], cut[g + 1]) in virtual offsets, every cut a record start the .bai names
+  // (the one nearest to g / G of the bytes behind the header).  extract.nim:308-329 is one loop over the file in file order;
+  // the shares are gathered in that order afterwards (strl_ctxs_extract_gather), so nothing downstream can tell.
+  std::vector<uint64_t> cut;
+  if (use_shares) {
+    cut = share_cuts(feed, bam, G);
+    if (cut.size() < 2) {
+      use_shares = false;
+      if (verbose) fprintf(stderr, "[strling] no .bai record starts to cut the file at: its chunks go over the contexts in turn\n");
+    }
+  }
+  const int n_shares = use_shares ? (int)cut.size() : 0;
+  for (size_t g = 0; g < ctxs.size(); ++g) {
+    strl_ctx *c = ctxs[g];
+    if (G > 1) CHECK(strl_ctx_blocking_waits(c, 1));       // N feeding threads: waits sleep instead of spinning
+    CHECK(strl_front_begin(c, n_ref, use_shares && g < cut.size() ? (cut[g] & 0xffff) : feed.first_record_offset(), reads_hint));
     CHECK(strl_front_reserve(c, (uint32_t)chunk_blocks, chunk_bytes));
   }
   const double t_begin = secs(tb0, now());
@@ -790,6 +834,153 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     uint32_t *nclen = reinterpret_cast<uint32_t *>(ncoff + chunk_blocks), *nisz = nclen + chunk_blocks, *ncrc = nisz + chunk_blocks;
     return strl_front_stage(ctxs[(size_t)S.g], pin[S.slot], S.hi - S.lo, ncoff, nclen, nisz, ncrc, (uint32_t)S.nb);
   };
+  auto tf = now();
+  if (use_shares) {
+    // One feeding thread per share, each with its own header walker, its own ring of page-locked buffers, its own copy
+    // threads and its own context: the pipeline of the one-GPU loop below, N times side by side.  Nothing is carried from a
+    // share to the next; what makes that exact is checked when the shares are done (a share must end exactly where the
+    // next begins).
+    feed.halt();
+    struct Share {
+      BgzfFeed fd;
+      std::vector<strl_front_chunk> sums;
+      int rc = 0;
+      bool fallback = false;
+      std::string err;
+      uint32_t tail = 0;
+      double t_walk = 0, t_copy = 0, t_wait = 0, t_all = 0;
+      uint64_t bytes = 0, chunks = 0;
+    };
+    std::vector<Share> shares((size_t)n_shares);
+    for (int g = 0; g < n_shares; ++g) {
+      const uint64_t end = g + 1 < n_shares ? cut[(size_t)g + 1] : 0;
+      if (!shares[(size_t)g].fd.open_share(feed, cut[(size_t)g] >> 16, (uint32_t)(cut[(size_t)g] & 0xffff), end >> 16, (uint32_t)(end & 0xffff), err)) quit("[strling] %s", err.c_str());
+    }
+    static const bool feed_only = getenv("STRL_FEED_ONLY") != nullptr;     // measurement: the host side alone, no device stage
+    const int per_share = std::max(2, std::min(12, decode_threads() / n_shares));
+    auto feeder = [&](int g) {
+      Share &Z = shares[(size_t)g];
+      strl_ctx *cx = ctxs[(size_t)g];
+      const auto z0 = now();
+      ThreadPool pool(per_share);
+      std::vector<BgzfFeed::Block> bl;
+      struct St { int64_t nb = 0; size_t lo = 0, hi = 0, slot = 0; bool last = false, short_read = false; std::string err; };
+      St ring[3];
+      uint64_t staged = 0;
+      auto stage = [&](uint64_t ci, St &S) {
+        const auto ta = now();
+        S = St{};
+        S.nb = Z.fd.next(bl, ci == 0 ? std::min<size_t>(chunk_blocks, 2048) : chunk_blocks, chunk_bytes, S.err, &S.last);
+        if (S.nb <= 0) return;
+        const auto tb = now();
+        S.lo = bl.front().c_off; S.hi = bl.back().c_off + bl.back().clen;
+        S.slot = RING * (size_t)g + (size_t)(staged++ % RING);
+        uint8_t *dst = pin[S.slot];
+        const size_t lo = S.lo, hi = S.hi, piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
+        std::atomic<int> short_reads{0};
+        pool.parallel_for(pieces, [&](size_t k) { if (!Z.fd.read_at(dst + k * piece, lo + k * piece, std::min(piece, hi - lo - k * piece))) ++short_reads; });
+        S.short_read = short_reads.load() != 0;
+        uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[S.slot]);
+        uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks, *crc = isz + chunk_blocks;
+        for (size_t k = 0; k < (size_t)S.nb; ++k) { coff[k] = bl[k].c_off - lo; clen[k] = bl[k].clen; isz[k] = bl[k].isize; crc[k] = bl[k].crc; }
+        Z.t_walk += secs(ta, tb); Z.t_copy += secs(tb, now());
+        Z.bytes += hi - lo; ++Z.chunks;
+      };
+      auto fail = [&](int rc) { Z.rc = rc; Z.err = strl_last_error(); };
+      auto tables = [&](const St &S, uint64_t *&coff, uint32_t *&clen, uint32_t *&isz, uint32_t *&crc) {
+        coff = reinterpret_cast<uint64_t *>(pin_meta[S.slot]);
+        clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks); isz = clen + chunk_blocks; crc = isz + chunk_blocks;
+      };
+      auto queue_copy = [&](const St &S) -> int {     // the chunk's copy to the device, ahead of its turn
+        uint64_t *coff; uint32_t *clen, *isz, *crc;
+        tables(S, coff, clen, isz, crc);
+        int rc = S.last && Z.fd.tail_trim() ? strl_front_trim_next(cx, Z.fd.tail_trim()) : 0;
+        return rc ? rc : strl_front_stage(cx, pin[S.slot], S.hi - S.lo, coff, clen, isz, crc, (uint32_t)S.nb);
+      };
+      std::thread ahead;
+      int rc = 0;
+      stage(0, ring[0]);
+      if (!feed_only && ring[0].nb > 0 && !ring[0].short_read && (rc = queue_copy(ring[0]))) { fail(rc); return; }
+      if (ring[0].nb > 0) stage(1, ring[1]);
+      for (uint64_t ci = 0;; ++ci) {
+        const St cur = ring[ci % 3];
+        St &nxt = ring[(ci + 1) % 3];
+        if (cur.nb < 0) { Z.fallback = true; Z.err = cur.err; break; }     // (a damaged file says so again in the chunk-by-chunk run)
+        if (cur.nb == 0) break;
+        if (cur.short_read) { Z.rc = STRL_ERR_ARG; Z.err = "short read"; break; }
+        if (nxt.nb > 0) ahead = std::thread([&, ci] { stage(ci + 2, ring[(ci + 2) % 3]); });
+        else ring[(ci + 2) % 3] = St{};
+        if (!feed_only) {
+          if (nxt.nb > 0 && !nxt.short_read && (rc = queue_copy(nxt))) { fail(rc); break; }
+          uint64_t *coff; uint32_t *clen, *isz, *crc;
+          tables(cur, coff, clen, isz, crc);
+          strl_front_chunk done[2];
+          int n_done = 0;
+          const auto tc = now();
+          if ((rc = strl_front_enqueue_after(cx, nullptr, pin[cur.slot], cur.hi - cur.lo, coff, clen, isz, crc, (uint32_t)cur.nb, done, &n_done))) { fail(rc); break; }
+          for (int k = 0; k < n_done; ++k) Z.sums.push_back(done[k]);
+          if ((rc = strl_front_collect(cx))) { fail(rc); break; }
+          Z.t_wait += secs(tc, now());
+        }
+        if (ahead.joinable()) ahead.join();
+      }
+      if (ahead.joinable()) ahead.join();
+      if (!feed_only && !Z.rc && !Z.fallback) {
+        strl_front_chunk done[2];
+        int n_done = 0;
+        if ((rc = strl_front_finish(cx, done, &n_done))) fail(rc);
+        else {
+          for (int k = 0; k < n_done; ++k) Z.sums.push_back(done[k]);
+          if ((rc = strl_front_tail_bytes(cx, &Z.tail))) fail(rc);
+        }
+      }
+      Z.t_all = secs(z0, now());
+    };
+    std::vector<std::thread> feeders;
+    for (int g = 1; g < n_shares; ++g) feeders.emplace_back(feeder, g);
+    feeder(0);
+    for (auto &t : feeders) t.join();
+    tf = now();
+    if (feed_only) {
+      uint64_t bytes = 0;
+      for (const Share &Z : shares) bytes += Z.bytes;
+      const double dt = secs(t0, now());
+      fprintf(stderr, "[strling] feed only: %d shares, %d copy threads each (+ walker, + read-ahead), %.3f s, %.2f GB of BAM, %.2f GB/s\n", n_shares, per_share, dt, (double)bytes / 1e9, (double)bytes / 1e9 / dt);
+      for (int g = 0; g < n_shares; ++g)
+        fprintf(stderr, "[strling]   share %d: %.2f GB in %llu chunks, %.3f s (block headers %.3f, reading compressed bytes %.3f)\n", g, (double)shares[(size_t)g].bytes / 1e9,
+                (unsigned long long)shares[(size_t)g].chunks, shares[(size_t)g].t_all, shares[(size_t)g].t_walk, shares[(size_t)g].t_copy);
+      fflush(stderr);
+      _exit(0);
+    }
+    bool again = false;
+    for (int g = 0; g < n_shares; ++g) {
+      const Share &Z = shares[(size_t)g];
+      if (Z.rc == STRL_ERR_FORMAT || Z.rc == STRL_ERR_LIMIT || Z.fallback || (g + 1 < n_shares && Z.tail)) again = true;
+      else if (Z.rc == STRL_ERR_CRC) quit("[strling] error reading %s: %s", bam.c_str(), Z.err.c_str());
+      else if (Z.rc) quit("[strling] %s (status %d)", Z.err.c_str(), Z.rc);
+    }
+    if (again) {
+      // a share that did not end on the next one's first record (a stale index), a block or record the device front end
+      // refuses, too many records for one pass: the chunk-by-chunk run sorts out which, with its own ways out
+      for (int g = 0; g < n_shares; ++g)
+        if (shares[(size_t)g].rc || shares[(size_t)g].fallback || (g + 1 < n_shares && shares[(size_t)g].tail))
+          fprintf(stderr, "[strling] share %d of %d: %s; repeating the extraction chunk by chunk\n", g, n_shares,
+                  shares[(size_t)g].rc || shares[(size_t)g].fallback ? shares[(size_t)g].err.c_str() : "the .bai's record start is not where the share's records end");
+      for (Share &Z : shares) Z.fd.close();
+      for (size_t k = 0; k < pin.size(); ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
+      for (strl_ctx *c : ctxs) strl_ctx_destroy(c);
+      return EXTRACT_AGAIN_BY_CHUNKS;
+    }
+    for (int g = 0; g < n_shares; ++g)
+      for (const strl_front_chunk &d : shares[(size_t)g].sums) { summary.push_back(d); have.push_back(1); chunk_owner.push_back((uint32_t)g); }
+    account();
+    for (int g = 0; g < n_shares; ++g) { t_walk += shares[(size_t)g].t_walk; t_copy += shares[(size_t)g].t_copy; t_push += shares[(size_t)g].t_wait; }
+    if (verbose)
+      for (int g = 0; g < n_shares; ++g)
+        fprintf(stderr, "[strling] share %d: %.2f GB of BAM from offset %llu, %zu chunks, %.3f s (block headers %.3f, reading compressed bytes %.3f, enqueueing + waiting for the device %.3f)\n", g,
+                (double)shares[(size_t)g].bytes / 1e9, (unsigned long long)(cut[(size_t)g] >> 16), shares[(size_t)g].sums.size(), shares[(size_t)g].t_all, shares[(size_t)g].t_walk,
+                shares[(size_t)g].t_copy, shares[(size_t)g].t_wait);
+  } else {
   stage(0, ring[0]);
   if (ring[0].nb > 0 && !ring[0].short_read) FRONT_CHECK(queue_copy(ring[0]));
   if (ring[0].nb > 0) stage(1, ring[1]);
@@ -839,7 +1030,7 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     t_push += secs(tc, now());
   }
   if (frag_thread.joinable()) frag_thread.join();
-  const auto tf = now();
+  tf = now();
   for (int g = 0; g < G; ++g) {
     strl_front_chunk done[2];
     int n_done = 0;
@@ -849,11 +1040,14 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     mark(g, before);
   }
   account();
+  }   // (chunk by chunk)
+  const auto tf2 = now();
   if (G > 1) {
     std::vector<uint64_t> recs(summary.size());
     for (size_t k = 0; k < summary.size(); ++k) recs[k] = summary[k].n_records;
     FRONT_CHECK(strl_ctxs_extract_gather(ctxs.data(), G, chunk_owner.data(), recs.data(), recs.size()));
-    if (verbose) fprintf(stderr, "[strling] %zu chunks over %d contexts on %d device(s); per-read state gathered on the first\n", summary.size(), G, std::min(G, std::max(1, strl_device_count())));
+    if (verbose) fprintf(stderr, "[strling] %zu chunks over %d contexts on %d device(s)%s; per-read state gathered on the first in %.3f s\n", summary.size(), G, std::min(G, std::max(1, strl_device_count())),
+                         use_shares ? ", a contiguous share of the file each" : " in turn", secs(tf2, now()));
   }
   const double t_drain = secs(tf, now());
   {   // extract.nim:310-313: one line per large contig that has reads (here: once the whole file has been through)
@@ -1938,6 +2132,42 @@ static int index_main(int argc, char **argv) {
   return 0;
 }
 
+// strling _shares BAM G  (tests): the shares `extract --gpus G` cuts the file into -- per share its first record's virtual
+// offset, its blocks, their inflated bytes, the bytes of its last block that are the next share's -- as the walkers deliver them
+static int shares_main(int argc, char **argv) {
+  if (argc < 4) quit("usage: strling _shares BAM G [max_blocks]");
+  const std::string bam = argv[2];
+  const int G = std::max(1, atoi(argv[3]));
+  const size_t max_blocks = argc > 4 ? (size_t)atoll(argv[4]) : 4096;
+  BgzfFeed feed;
+  std::string err;
+  if (!feed.open(bam, err)) quit("[strling] %s", err.c_str());
+  feed.halt();
+  const std::vector<uint64_t> cut = share_cuts(feed, bam, G);
+  printf("shares\t%zu\n", cut.size());
+  for (size_t g = 0; g < cut.size(); ++g) {
+    const uint64_t end = g + 1 < cut.size() ? cut[g + 1] : 0;
+    BgzfFeed fd;
+    if (!fd.open_share(feed, cut[g] >> 16, (uint32_t)(cut[g] & 0xffff), end >> 16, (uint32_t)(end & 0xffff), err)) quit("[strling] %s", err.c_str());
+    std::vector<BgzfFeed::Block> bl;
+    uint64_t nb = 0, isz = 0, runs = 0, first_c = 0, last_end = 0;
+    bool last = false, saw_last = false;
+    for (;;) {
+      const int64_t n = fd.next(bl, max_blocks, (size_t)1 << 30, err, &last);
+      if (n < 0) { printf("share\t%zu\terror\t%s\n", g, err.c_str()); break; }
+      if (n == 0) break;
+      if (saw_last) quit("[strling] blocks behind the run that was called the last");
+      if (!nb) first_c = bl.front().c_off;
+      for (const auto &b : bl) { ++nb; isz += b.isize; last_end = b.c_off + b.clen + 8; }
+      ++runs;
+      saw_last = last;
+    }
+    printf("share\t%zu\t%llu\t%u\t%llu\t%llu\t%u\t%llu\t%llu\t%llu\t%d\n", g, (unsigned long long)(cut[g] >> 16), (unsigned)(cut[g] & 0xffff), (unsigned long long)nb,
+           (unsigned long long)isz, fd.tail_trim(), (unsigned long long)runs, (unsigned long long)first_c, (unsigned long long)last_end, saw_last ? 1 : 0);
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const char *top =
       "strling version: 0.6.0 (MI355X-native hot path)\n\nCommands:\n  extract  :   extract informative STR reads from a BAM/CRAM. This is a required first step.\n"
@@ -1952,6 +2182,7 @@ int main(int argc, char **argv) {
   if (cmd == "_dump") return dump_main(argc, argv);
   if (cmd == "_decode") return decode_main(argc, argv);
   if (cmd == "_region") return region_main(argc, argv);
+  if (cmd == "_shares") return shares_main(argc, argv);
   if (cmd == "pull_region")
     quit("[strling] `%s` is not part of this build (the MI355X path covers index, extract, merge and call; see DESIGN.md section 9)", cmd.c_str());
   fputs(top, stdout);

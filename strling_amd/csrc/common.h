@@ -131,6 +131,7 @@ struct strl_ctx {
   TailSet alt[N_SETS - 1];         // the other tail sets (see TailSet), most recently used first
   int cl_where = 0;                // the last clustering pass lives in: 0 = the current tail set, k = alt[k - 1]
   bool timing = false;
+  bool blocking_waits = false;     // strl_ctx_blocking_waits: the front end's events are created with hipEventBlockingSync
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> ring;   // 4 events per recorded strl_score_reads launch
   uint64_t ring_pos = 0;

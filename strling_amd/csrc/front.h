@@ -55,6 +55,7 @@ struct FrontSlot {
   const uint8_t *staged_comp = nullptr;
   uint64_t staged_bytes = 0, staged_tot = 0;
   uint32_t staged_blocks = 0;
+  uint32_t staged_trim = 0;       // inflated bytes at the end of the staged chunk that belong to the next share (strl_front_trim_next)
   FrontInfo *h_info = nullptr;   // pinned: [0] as of the record scan, [1] as of the parse, [2] the initial values
   uint64_t *h_uoff = nullptr;    // pinned: output offsets of the blocks
   uint32_t h_uoff_cap = 0;
@@ -79,6 +80,7 @@ struct strl_front {
   uint32_t last_end = 0;             // end of its inflated bytes
   uint64_t comp_total = 0, infl_total = 0;   // bytes handed over / inflated so far
   int pending = -1;                  // slot whose stage B has not been enqueued yet
+  uint32_t next_trim = 0;            // strl_front_trim_next: taken by the next front_copy
   // per-read state of all chunks (beside x_rows / x_qhash / x_whole of the chunked extract)
   DevBuf qref, qarena, fragw, tidflag, tid_seen;   // tid_seen[n_ref]: contigs with a primary record so far
   uint64_t qarena_used = 0;

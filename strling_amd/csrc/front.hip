@@ -492,7 +492,10 @@ int front_copy(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d) {
   if (d.crc) STRL_HIP(hipMemcpyAsync(S.crc.p, d.crc, (size_t)nb * 4, hipMemcpyHostToDevice, sc));
   STRL_HIP(hipEventRecord(S.ev_h2d, sc));
   S.h2d_pending = true;
+  if (F->next_trim > tot || (F->next_trim && F->next_trim > d.isize[nb - 1])) { set_error("strl_front_trim_next: more bytes than the chunk's last block holds"); return STRL_ERR_ARG; }
   S.staged = true; S.staged_comp = d.comp; S.staged_bytes = d.comp_bytes; S.staged_blocks = nb; S.staged_tot = tot;
+  S.staged_trim = F->next_trim;
+  F->next_trim = 0;
   return STRL_OK;
 }
 
@@ -526,13 +529,14 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   if (!S.staged && (rc = front_copy(c, F, si, d))) return rc;
   S.staged = false;
   const uint64_t tot = S.staged_tot;
-  const uint32_t end = (uint32_t)(FRONT_CARRY_MAX + tot), n_seg = (end + FRONT_SEG - 1) / FRONT_SEG;
+  // (a share's last chunk: the record scan ends in front of the bytes that are the next share's; the buffers hold the whole blocks)
+  const uint32_t end_full = (uint32_t)(FRONT_CARRY_MAX + tot), end = end_full - S.staged_trim, n_seg = (end + FRONT_SEG - 1) / FRONT_SEG;
   const uint64_t readable = (d.comp_bytes + 3) & ~(uint64_t)3;
   const uint64_t rec_cap = tot / 36 + 16;          // no record is shorter than 36 bytes
   if (S.b_pending) STRL_HIP(hipStreamWaitEvent(sti, S.ev_b, 0));
   if (S.read_pending) { STRL_HIP(hipStreamWaitEvent(sti, S.wait_read, 0)); S.read_pending = false; }   // another context took its carry from this slot
   auto want = [](uint64_t need) { return (size_t)(need + need / 4 + 4096); };   // head-room: later chunks rarely reallocate
-  if (S.infl.cap < (uint64_t)end + 256 && (rc = S.infl.reserve(want((uint64_t)end + 256)))) return rc;
+  if (S.infl.cap < (uint64_t)end_full + 256 && (rc = S.infl.reserve(want((uint64_t)end_full + 256)))) return rc;
   if (S.seg.cap < (size_t)n_seg * sizeof(FrontSeg) && ((rc = S.seg.reserve(want((size_t)n_seg * sizeof(FrontSeg)))) || (rc = S.base3.reserve(want((size_t)n_seg * 16)))))
     return rc;
   if (S.recoff.cap < rec_cap * 4 && ((rc = S.recoff.reserve(want(rec_cap * 4))) || (rc = S.seqoff.reserve(want(rec_cap * 4))) || (rc = S.qoff.reserve(want(rec_cap * 4)))))
@@ -547,7 +551,7 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   hi.end = end;
   hi.last_placed = -1;
   STRL_HIP(hipMemcpyAsync(S.info.p, &hi, sizeof hi, hipMemcpyHostToDevice, sti));
-  STRL_HIP(hipMemsetAsync(static_cast<uint8_t *>(S.infl.p) + end, 0, 256, sti));      // the parse may load a dword across the end
+  STRL_HIP(hipMemsetAsync(static_cast<uint8_t *>(S.infl.p) + end_full, 0, 256, sti));      // the parse may load a dword across the end
   if ((rc = tick(F, sti))) return rc;
   FrontInfo *info = S.info.as<FrontInfo>();
   if ((rc = strl_inflate_device(c, S.comp.as<uint8_t>(), readable, S.coff.as<uint64_t>(), S.clen.as<uint32_t>(), S.uoff.as<uint64_t>(), S.isize.as<uint32_t>(), nb,

@@ -1449,51 +1449,75 @@ int strl_ctxs_extract_gather(strl_ctx **ctxs, int n, const uint32_t *chunk_owner
       (rc = qref.reserve((size_t)t1 * 8)) || (rc = fragw.reserve((size_t)t1 * 4)) || (rc = soft.reserve((size_t)s1 * sizeof(strl_soft_rec))) ||
       (rc = arena.reserve((size_t)arena_at[(size_t)n] + 64)) || (rc = tmp.reserve(std::max<size_t>((size_t)c0->bloom_mask / 8 + 64, (size_t)F0->n_ref + 64))) || (rc = tab.reserve((size_t)std::max<uint64_t>(n_chunks, 1) * 8 + 64)))
     return rc;
-  // per chunk: the five per-read columns to their place in file order
+  // Runs of consecutive chunks of one owner (a share = one run) are contiguous on both sides: one copy per column.  A
+  // context's columns, names and soft-clip records travel on ITS stream -- each source device drives its own link to the first,
+  // the links work side by side -- and the first context's stream waits for one event per source before it re-bases.
+  struct Run { uint32_t owner; uint64_t lo, go, m; };
+  std::vector<Run> runs;
   for (uint64_t k = 0; k < n_chunks; ++k) {
-    strl_ctx *cg = ctxs[chunk_owner[k]];
-    const uint64_t m = chunk_records[k], lo = lbase[(size_t)k], go = gbase[(size_t)k];
+    const uint64_t m = chunk_records[k];
     if (!m) continue;
-    if ((rc = copy_between(rows.as<strl_pair_rec>() + go, c0->device, cg->x_rows.as<strl_pair_rec>() + lo, cg->device, (size_t)m * sizeof(strl_pair_rec), st)) ||
-        (rc = copy_between(qhash.as<uint64_t>() + go, c0->device, cg->x_qhash.as<uint64_t>() + lo, cg->device, (size_t)m * 8, st)) ||
-        (rc = copy_between(whole.as<uint32_t>() + go, c0->device, cg->x_whole.as<uint32_t>() + lo, cg->device, (size_t)m * 4, st)) ||
-        (rc = copy_between(qref.as<uint64_t>() + go, c0->device, cg->front->qref.as<uint64_t>() + lo, cg->device, (size_t)m * 8, st)) ||
-        (rc = copy_between(fragw.as<uint32_t>() + go, c0->device, cg->front->fragw.as<uint32_t>() + lo, cg->device, (size_t)m * 4, st)))
-      return rc;
-    const uint64_t ab = arena_at[chunk_owner[k]];
-    if (ab) {
-      hipLaunchKernelGGL(qref_rebase_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, qref.as<uint64_t>() + go, (uint32_t)m, ab);
-      STRL_HIP(hipGetLastError());
-    }
+    if (!runs.empty() && runs.back().owner == chunk_owner[k] && runs.back().lo + runs.back().m == lbase[(size_t)k] && runs.back().go + runs.back().m == gbase[(size_t)k]) runs.back().m += m;
+    else runs.push_back(Run{chunk_owner[k], lbase[(size_t)k], gbase[(size_t)k], m});
   }
-  // per context: name arena, soft-clip records (re-based by its chunk table), Bloom bitmap
-  std::vector<uint32_t> tl, tg;
+  std::vector<hipEvent_t> src_done((size_t)n, nullptr);
+  auto drop_events = [&] { for (hipEvent_t e : src_done) if (e) (void)hipEventDestroy(e); };
+  std::vector<std::vector<uint32_t>> tls((size_t)n), tgs((size_t)n);
   for (int g = 0; g < n; ++g) {
     strl_ctx *cg = ctxs[g];
-    if ((rc = copy_between(arena.as<uint8_t>() + arena_at[(size_t)g], c0->device, cg->front->qarena.p, cg->device, (size_t)cg->front->qarena_used, st))) return rc;
+    STRL_HIP(hipSetDevice(cg->device));
+    hipStream_t sg = cg->stream;
+    for (const Run &r : runs) {
+      if (r.owner != (uint32_t)g) continue;
+      if ((rc = copy_between(rows.as<strl_pair_rec>() + r.go, c0->device, cg->x_rows.as<strl_pair_rec>() + r.lo, cg->device, (size_t)r.m * sizeof(strl_pair_rec), sg)) ||
+          (rc = copy_between(qhash.as<uint64_t>() + r.go, c0->device, cg->x_qhash.as<uint64_t>() + r.lo, cg->device, (size_t)r.m * 8, sg)) ||
+          (rc = copy_between(whole.as<uint32_t>() + r.go, c0->device, cg->x_whole.as<uint32_t>() + r.lo, cg->device, (size_t)r.m * 4, sg)) ||
+          (rc = copy_between(qref.as<uint64_t>() + r.go, c0->device, cg->front->qref.as<uint64_t>() + r.lo, cg->device, (size_t)r.m * 8, sg)) ||
+          (rc = copy_between(fragw.as<uint32_t>() + r.go, c0->device, cg->front->fragw.as<uint32_t>() + r.lo, cg->device, (size_t)r.m * 4, sg))) { drop_events(); return rc; }
+    }
+    if ((rc = copy_between(arena.as<uint8_t>() + arena_at[(size_t)g], c0->device, cg->front->qarena.p, cg->device, (size_t)cg->front->qarena_used, sg))) { drop_events(); return rc; }
+    const uint64_t ns = soft_at[(size_t)g + 1] - soft_at[(size_t)g];
+    if (ns && (rc = copy_between(soft.as<strl_soft_rec>() + soft_at[(size_t)g], c0->device, cg->x_soft.p, cg->device, (size_t)ns * sizeof(strl_soft_rec), sg))) { drop_events(); return rc; }
+    if (g) {      // (an event of the SOURCE's device on the source's stream; the wait below is the cross-device half, which is legal)
+      STRL_HIP(hipEventCreateWithFlags(&src_done[(size_t)g], hipEventDisableTiming));
+      STRL_HIP(hipEventRecord(src_done[(size_t)g], sg));
+    }
+  }
+  STRL_HIP(hipSetDevice(c0->device));
+  // re-basing on the first context, behind each source's copies
+  size_t tab_at = 0;
+  for (int g = 0; g < n; ++g) {
+    strl_ctx *cg = ctxs[g];
+    if (g) STRL_HIP(hipStreamWaitEvent(st, src_done[(size_t)g], 0));
+    const uint64_t ab = arena_at[(size_t)g];
+    if (ab)
+      for (const Run &r : runs) {
+        if (r.owner != (uint32_t)g) continue;
+        hipLaunchKernelGGL(qref_rebase_kernel, dim3((unsigned)((r.m + 255) / 256)), dim3(256), 0, st, qref.as<uint64_t>() + r.go, (uint32_t)r.m, ab);
+        STRL_HIP(hipGetLastError());
+      }
     const uint64_t ns = soft_at[(size_t)g + 1] - soft_at[(size_t)g];
     if (ns) {
-      if ((rc = copy_between(soft.as<strl_soft_rec>() + soft_at[(size_t)g], c0->device, cg->x_soft.p, cg->device, (size_t)ns * sizeof(strl_soft_rec), st))) return rc;
-      tl.clear(); tg.clear();
+      std::vector<uint32_t> &tl = tls[(size_t)g], &tg = tgs[(size_t)g];      // this context's chunks: first local / first global record
       for (uint64_t k = 0; k < n_chunks; ++k) if (chunk_owner[k] == (uint32_t)g) { tl.push_back((uint32_t)lbase[(size_t)k]); tg.push_back((uint32_t)gbase[(size_t)k]); }
-      STRL_HIP(hipStreamSynchronize(st));                    // (the table buffer is reused per context)
-      STRL_HIP(hipMemcpy(tab.p, tl.data(), tl.size() * 4, hipMemcpyHostToDevice));
-      STRL_HIP(hipMemcpy(tab.as<uint32_t>() + n_chunks + 8, tg.data(), tg.size() * 4, hipMemcpyHostToDevice));
+      STRL_HIP(hipMemcpyAsync(tab.as<uint32_t>() + tab_at, tl.data(), tl.size() * 4, hipMemcpyHostToDevice, st));
+      STRL_HIP(hipMemcpyAsync(tab.as<uint32_t>() + n_chunks + 8 + tab_at, tg.data(), tg.size() * 4, hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(soft_rebase_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, soft.as<strl_soft_rec>() + soft_at[(size_t)g], (uint32_t)ns,
-                         tab.as<uint32_t>(), tab.as<uint32_t>() + n_chunks + 8, (uint32_t)tl.size());
+                         tab.as<uint32_t>() + tab_at, tab.as<uint32_t>() + n_chunks + 8 + tab_at, (uint32_t)tl.size());
       STRL_HIP(hipGetLastError());
+      tab_at += tl.size();
     }
     if (g) {       // contigs that had a primary record (the CLI's "extracting chromosome" lines)
       const size_t tw = ((size_t)std::min(F0->n_ref, cg->front->n_ref) + 3) / 4;
       if (tw) {
-        if ((rc = copy_between(tmp.p, c0->device, cg->front->tid_seen.p, cg->device, tw * 4, st))) return rc;
+        if ((rc = copy_between(tmp.p, c0->device, cg->front->tid_seen.p, cg->device, tw * 4, st))) { drop_events(); return rc; }
         hipLaunchKernelGGL(words_or_kernel, dim3(16), dim3(256), 0, st, F0->tid_seen.as<uint32_t>(), tmp.as<uint32_t>(), tw);
         STRL_HIP(hipGetLastError());
       }
     }
     if (g) {
       const size_t bw = ((size_t)c0->bloom_mask + 1) / 32;
-      if ((rc = copy_between(tmp.p, c0->device, cg->bloom.p, cg->device, bw * 4, st))) return rc;
+      if ((rc = copy_between(tmp.p, c0->device, cg->bloom.p, cg->device, bw * 4, st))) { drop_events(); return rc; }
       hipLaunchKernelGGL(words_or_kernel, dim3(1024), dim3(256), 0, st, c0->bloom.as<uint32_t>(), tmp.as<uint32_t>(), bw);
       STRL_HIP(hipGetLastError());
     }
@@ -1501,6 +1525,7 @@ int strl_ctxs_extract_gather(strl_ctx **ctxs, int n, const uint32_t *chunk_owner
   uint32_t sum[XC_WORDS] = {0};
   for (int g = 0; g < n; ++g) for (int w = 0; w < XC_WORDS; ++w) sum[w] += xc[(size_t)g * XC_WORDS + w];
   STRL_HIP(hipStreamSynchronize(st));
+  drop_events();
   STRL_HIP(hipMemcpy(c0->x_cnt.p, sum, XC_WORDS * 4, hipMemcpyHostToDevice));
   // ctxs[0] takes the gathered state over
   c0->x_rows.release(); c0->x_qhash.release(); c0->x_whole.release(); c0->x_soft.release();
@@ -1752,9 +1777,10 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
     STRL_HIP(hipStreamCreateWithPriority(&F->st_a, hipStreamNonBlocking, greatest));
   }
   STRL_HIP(hipStreamCreateWithFlags(&F->st_c, hipStreamNonBlocking));
+  const unsigned host_waited = hipEventDisableTiming | (c->blocking_waits ? hipEventBlockingSync : 0u);   // ev_a, ev_b: what the feeding thread waits for
   for (strl::FrontSlot &S : F->slot) {
-    STRL_HIP(hipEventCreateWithFlags(&S.ev_a, hipEventDisableTiming));
-    STRL_HIP(hipEventCreateWithFlags(&S.ev_b, hipEventDisableTiming));
+    STRL_HIP(hipEventCreateWithFlags(&S.ev_a, host_waited));
+    STRL_HIP(hipEventCreateWithFlags(&S.ev_b, host_waited));
     STRL_HIP(hipEventCreateWithFlags(&S.ev_h2d, hipEventDisableTiming));
     STRL_HIP(hipEventCreateWithFlags(&S.ev_i, hipEventDisableTiming));
     STRL_HIP(hipEventCreateWithFlags(&S.ev_carry, hipEventDisableTiming));
@@ -1795,6 +1821,28 @@ int strl_front_collect(strl_ctx *c) {
     if ((rc = front_stage_b(c, F, (int)(F->b_issued & 1)))) return rc;
     ++F->b_issued;
   }
+  return STRL_OK;
+}
+
+int strl_ctx_blocking_waits(strl_ctx *c, int on) {
+  if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
+  c->blocking_waits = on != 0;
+  return STRL_OK;
+}
+
+int strl_front_trim_next(strl_ctx *c, uint32_t tail_bytes) {
+  if (!c || !c->front || !c->x_open) { set_error("strl_front_trim_next without strl_front_begin"); return STRL_ERR_ARG; }
+  if (tail_bytes > 65536u) { set_error("strl_front_trim_next: more than a BGZF block"); return STRL_ERR_ARG; }
+  c->front->next_trim = tail_bytes;
+  return STRL_OK;
+}
+
+// bytes behind the last complete record of the last chunk handed over (after strl_front_finish: every scan has been waited for)
+int strl_front_tail_bytes(strl_ctx *c, uint32_t *tail_bytes) {
+  if (!c || !c->front || !tail_bytes) { set_error("strl_front_tail_bytes: bad argument"); return STRL_ERR_ARG; }
+  strl::strl_front *F = c->front;
+  if (F->b_issued < F->chunks) { set_error("strl_front_tail_bytes before strl_front_finish"); return STRL_ERR_ARG; }
+  *tail_bytes = F->last_slot < 0 ? 0u : F->slot[F->last_slot].h_info[0].carry_len;
   return STRL_OK;
 }
 

@@ -157,19 +157,98 @@ def test_extract_reports_a_damaged_bgzf_block(sample, what):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shares", ["1", "0"])
 @pytest.mark.parametrize("gpus,blocks", [("2", "3"), ("3", "5"), ("2", "8192"), ("4", "2")])
-def test_extract_on_several_contexts_writes_the_same_bin(sample, gpus, blocks):
-    """strling extract --gpus N: the file's chunks round-robin over N contexts (partial records carried from one context's chunk
-    to the next context's), per-read state gathered on the first, pair logic there: the .bin of the one-GPU run, byte for byte"""
+def test_extract_on_several_contexts_writes_the_same_bin(sample, gpus, blocks, shares):
+    """strling extract --gpus N, both ways of spreading the file: a contiguous share per context cut at record starts the .bai
+    names (every context a feeding thread of its own, nothing carried between contexts) or, STRL_SHARES=0 / no index, the
+    file's chunks round-robin over N contexts (partial records carried from one context's chunk to the next context's);
+    per-read state gathered on the first, pair logic there: the .bin of the one-GPU run, byte for byte"""
     one = str(sample["dir"] / "one.bin")
     r = _run(["extract", "-g", sample["bed"], sample["bam"], one])
     assert r.returncode == 0, r.stderr
-    out = str(sample["dir"] / f"g{gpus}_{blocks}.bin")
-    r = _run(["extract", "-g", sample["bed"], "-v", "--gpus", gpus, sample["bam"], out], env=dict(os.environ, STRL_CHUNK_BLOCKS=blocks))
+    out = str(sample["dir"] / f"g{gpus}_{blocks}_{shares}.bin")
+    r = _run(["extract", "-g", sample["bed"], "-v", "--gpus", gpus, sample["bam"], out], env=dict(os.environ, STRL_CHUNK_BLOCKS=blocks, STRL_SHARES=shares))
     assert r.returncode == 0, r.stderr
-    if int(blocks) < 100:
-        assert f"over {gpus} contexts" in r.stderr
+    if shares == "1":
+        assert f"over {gpus} contexts" in r.stderr and "a contiguous share of the file each" in r.stderr, r.stderr
+        assert r.stderr.count("[strling] share ") == int(gpus), r.stderr
+    elif int(blocks) < 100:
+        assert f"over {gpus} contexts" in r.stderr and "in turn" in r.stderr
     assert open(out, "rb").read() == open(one, "rb").read()
+
+
+@pytest.fixture(scope="module")
+def small_blocks(tmp_path_factory):
+    """the same kind of sample in BGZF blocks of 1500 bytes: records straddle blocks, a share holds hundreds of blocks"""
+    d = tmp_path_factory.mktemp("cli_sb")
+    rec, g = synth.synth_wgs(5000, seed=33, contig_len=600_000)
+    bam = str(d / "sb.bam")
+    bamio.write_bam(bam, rec, block=1500)
+    bed = str(d / "ref.fa.str")
+    bamio.write_genome_bed(bed, g, rec.targets)
+    one = str(d / "one.bin")
+    return dict(dir=d, bam=bam, bed=bed, one=one)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpus,blocks", [("2", "64"), ("3", "7"), ("5", "16"), ("8", "3")])
+def test_extract_shares_cut_inside_blocks(small_blocks, gpus, blocks):
+    """shares whose ends fall INSIDE a BGZF block (the block is inflated by both neighbours; the first stops in front of the
+    record the second starts at) and whose chunks end inside records: same .bin"""
+    sb = small_blocks
+    if not os.path.exists(sb["one"]):
+        r = _run(["extract", "-g", sb["bed"], sb["bam"], sb["one"]])
+        assert r.returncode == 0, r.stderr
+    out = str(sb["dir"] / f"g{gpus}_{blocks}.bin")
+    r = _run(["extract", "-g", sb["bed"], "-v", "--gpus", gpus, sb["bam"], out], env=dict(os.environ, STRL_CHUNK_BLOCKS=blocks))
+    assert r.returncode == 0, r.stderr
+    assert "a contiguous share of the file each" in r.stderr, r.stderr
+    assert open(out, "rb").read() == open(sb["one"], "rb").read()
+
+
+def _shift_bai(src, dst, delta):
+    """a .bai whose linear-index offsets point `delta` bytes behind the record starts (a stale / foreign index)"""
+    import struct
+    b = bytearray(open(src, "rb").read())
+    o = 4
+    n_ref, = struct.unpack_from("<i", b, o); o += 4
+    for _ in range(n_ref):
+        n_bin, = struct.unpack_from("<i", b, o); o += 4
+        for _ in range(n_bin):
+            _, n_chunk = struct.unpack_from("<Ii", b, o); o += 8
+            for c in range(n_chunk):
+                v, = struct.unpack_from("<Q", b, o)
+                struct.pack_into("<Q", b, o, v + delta)
+                o += 16
+        n_intv, = struct.unpack_from("<i", b, o); o += 4
+        for k in range(n_intv):
+            v, = struct.unpack_from("<Q", b, o + 8 * k)
+            if v:
+                struct.pack_into("<Q", b, o + 8 * k, v + delta)
+        o += 8 * n_intv
+    open(dst, "wb").write(bytes(b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("delta", [1, 7 << 16])
+def test_extract_shares_with_a_lying_index_fall_back_to_chunks(small_blocks, tmp_path, delta):
+    """the .bai's record starts are NOT record starts (shifted by a byte) or not even block starts (shifted by 7 file bytes):
+    a share does not end where the next begins / its walker finds no BGZF header -- noticed, and the extraction is repeated
+    chunk by chunk; the .bin is the one-GPU run's all the same"""
+    import shutil
+    sb = small_blocks
+    if not os.path.exists(sb["one"]):
+        r = _run(["extract", "-g", sb["bed"], sb["bam"], sb["one"]])
+        assert r.returncode == 0, r.stderr
+    bam = str(tmp_path / "lie.bam")
+    shutil.copy(sb["bam"], bam)
+    _shift_bai(sb["bam"] + ".bai", bam + ".bai", delta)
+    out = str(tmp_path / "lie.bin")
+    r = _run(["extract", "-g", sb["bed"], "-v", "--gpus", "3", bam, out], env=dict(os.environ, STRL_CHUNK_BLOCKS="16"))
+    assert r.returncode == 0, r.stderr
+    assert "repeating the extraction chunk by chunk" in r.stderr and "in turn" in r.stderr, r.stderr
+    assert open(out, "rb").read() == open(sb["one"], "rb").read()
 
 
 @pytest.mark.gpu
@@ -473,3 +552,70 @@ def test_stream_reader_is_the_same_for_every_engine_and_shape(tmp_path):
         line = [l for l in r.stderr.splitlines() if "decoded" in l][-1]
         assert f"decoded {rec.n} records" in line, line
         assert f"(checksum {want})" in line, (env, line)
+
+
+def _bam_layout(path):
+    """(block file offset, inflated offset, inflated size) of every data block, the inflated bytes, every record start in them"""
+    import struct
+    import zlib
+    raw = open(path, "rb").read()
+    blocks, infl, o = [], bytearray(), 0
+    while o < len(raw):
+        xlen = struct.unpack_from("<H", raw, o + 10)[0]
+        bsize = struct.unpack_from("<H", raw, o + 16)[0] + 1
+        data = zlib.decompress(raw[o + 12 + xlen:o + bsize - 8], -15)
+        blocks.append((o, len(infl), len(data)))
+        infl += data
+        o += bsize
+    l_text, = struct.unpack_from("<i", infl, 4)
+    q = 8 + l_text
+    n_ref, = struct.unpack_from("<i", infl, q)
+    q += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", infl, q)
+        q += 8 + l_name
+    starts = set()
+    while q < len(infl):
+        starts.add(q)
+        q += 4 + struct.unpack_from("<i", infl, q)[0]
+    return blocks, starts
+
+
+@pytest.mark.parametrize("G,max_blocks", [(2, 4096), (3, 5), (7, 64), (16, 1)])
+def test_shares_tile_the_file_at_record_starts(tmp_path, G, max_blocks):
+    """`extract --gpus G` cuts the file at record starts the .bai names: every cut IS a record start (checked against a walk of
+    the inflated file), the shares' blocks tile the file's data blocks with the block a cut falls into delivered to both
+    neighbours, and the bytes a share leaves to the next add up (CPU: the header walkers alone, `strling _shares`)"""
+    rec, g = synth.synth_wgs(3000, seed=5, contig_len=300_000)
+    bam = str(tmp_path / "t.bam")
+    bamio.write_bam(bam, rec, block=1200)
+    blocks, starts = _bam_layout(bam)
+    by_off = {b[0]: b for b in blocks}
+    r = _run(["_shares", bam, str(G), str(max_blocks)])
+    assert r.returncode == 0, r.stderr
+    rows = [l.split("\t") for l in r.stdout.strip().split("\n")]
+    n = int(rows[0][1])
+    assert 2 <= n <= G and len(rows) == n + 1
+    total = 0
+    prev_end_uoff = None
+    for k, row in enumerate(rows[1:]):
+        assert row[0] == "share" and int(row[1]) == k and row[2] != "error", row
+        coff, uoff, nb, isz, trim, runs, first_c, last_end, saw_last = (int(x) for x in row[2:])
+        assert saw_last == 1
+        b = by_off[coff]
+        assert b[1] + uoff in starts, "a cut that is not a record start"
+        assert first_c == coff + 18                      # the share's first block is the one the cut names
+        if prev_end_uoff is not None:
+            assert uoff == prev_end_uoff                  # where the previous share stopped inside the shared block
+        own = isz - uoff - trim
+        total += own
+        if k + 1 < n:
+            ncoff, nuoff = int(rows[k + 2][2]), int(rows[k + 2][3])
+            nb_ = by_off[ncoff]
+            assert b[1] + uoff + own == nb_[1] + nuoff    # the share ends exactly at the next cut
+            assert trim == (nb_[2] - nuoff if nuoff else 0)
+            prev_end_uoff = nuoff
+        else:
+            assert trim == 0
+    first = by_off[int(rows[1][2])]
+    assert first[1] + int(rows[1][3]) + total == blocks[-1][1] + blocks[-1][2]   # first record .. end of the data

@@ -146,9 +146,13 @@ def test_cram_variants_and_refusals(cram_sample, tmp_path):
 
 
 def test_damaged_cram_never_crashes_the_reader(cram_sample, tmp_path):
-    """single-byte damage anywhere in the file: the reader reports or decodes something, it never dies on a signal"""
+    """single-byte damage anywhere in the file: the reader never dies on a signal, and -- every byte of a CRAM 3.0 file lies
+    under a CRC-32 (container headers, blocks) that the reader checks like htslib does -- it either REPORTS the damage or
+    hands out exactly the undamaged file's records (the 20 bytes of the file id and padding nobody reads)"""
     data = open(cram_sample["cram"], "rb").read()
     env = dict(os.environ, STRL_CRAM_FASTA=cram_sample["fa"])
+    good = subprocess.run([CLI, "_dump", cram_sample["cram"]], capture_output=True, env=env)
+    assert good.returncode == 0
     rng = np.random.default_rng(5)
     p = str(tmp_path / "bad.cram")
     n_err = 0
@@ -160,9 +164,67 @@ def test_damaged_cram_never_crashes_the_reader(cram_sample, tmp_path):
             del b[at + 1:at + 1 + int(rng.integers(1, 9))]          # and a few bytes missing behind it
         open(p, "wb").write(b)
         r = subprocess.run([CLI, "_dump", p], capture_output=True, env=env)
-        assert r.returncode in (0, 1), (k, at, r.returncode, r.stderr[-200:])
+        assert r.returncode == 1 or (r.returncode == 0 and r.stdout == good.stdout), (k, at, r.returncode, r.stderr[-200:])
         n_err += r.returncode
-    assert n_err > 10
+    assert n_err > 100
+
+
+def test_cram_checksums_and_reference_identity(cram_sample, tmp_path):
+    """what htslib checks and a reader that skipped it would get silently wrong: a flipped byte inside an external block's
+    payload (block CRC-32), a FASTA that is not the one the file was written against (slice MD5), a file cut between two
+    containers (no EOF container)"""
+    import struct
+    env = dict(os.environ, STRL_CRAM_FASTA=cram_sample["fa"])
+    data = open(cram_sample["cram"], "rb").read()
+    # a payload byte of the LAST block in front of the EOF container: raw or compressed, its CRC no longer matches
+    b = bytearray(data)
+    b[len(b) - 38 - 4 - 3] ^= 0x20
+    p = str(tmp_path / "flip.cram"); open(p, "wb").write(b)
+    r = _run(["_dump", p], env=env)
+    assert r.returncode == 1 and "CRC32 mismatch" in r.stderr, r.stderr[-300:]
+    # the same contigs, one base changed in the middle of the first: every slice over it fails its MD5, named
+    refs = [bytearray(x) for x in cram_sample["refs"]]
+    refs[0][20_000] = ord("A") if refs[0][20_000] != ord("A") else ord("C")
+    other = str(tmp_path / "other.fa")
+    cramio.write_fasta(other, cram_sample["rec"].targets, [bytes(x) for x in refs])
+    r = _run(["_dump", cram_sample["cram"]], env=dict(os.environ, STRL_CRAM_FASTA=other))
+    assert r.returncode == 1 and "MD5 mismatch" in r.stderr and cram_sample["rec"].targets[0][0] in r.stderr, r.stderr[-300:]
+    # lower-case and IUPAC bases in the FASTA: upper-cased for the MD5 and for the reads (htslib's behaviour)
+    low = str(tmp_path / "low.fa")
+    cramio.write_fasta(low, cram_sample["rec"].targets, [bytes(x).lower() for x in cram_sample["refs"]])
+    r = _run(["_dump", cram_sample["cram"]], env=dict(os.environ, STRL_CRAM_FASTA=low))
+    assert r.returncode == 0 and r.stdout == _run(["_dump", cram_sample["cram"]], env=env).stdout
+    # cut behind a whole container: every remaining container is intact, only the EOF container is missing
+    cut = str(tmp_path / "cut.cram"); open(cut, "wb").write(data[:-38])
+    r = _run(["_dump", cut], env=env)
+    assert r.returncode == 1 and "EOF container" in r.stderr, r.stderr[-300:]
+    # a hostile size field in the compression header's map must not read past the block
+    assert struct.calcsize("<i") == 4
+
+
+def test_cram_mate_chain_of_three(tmp_path):
+    """three records of one template linked in a chain inside a slice (NF -> NF -> end): mates go round the chain, the
+    template length spans all three (htslib's cram_decode_slice_xref; the pairwise resolution of round 4 got the middle one wrong)"""
+    from strling_amd.records import RecordBatch
+    seq = "ACGT" * 25
+    # A (first in pair, leftmost) -> B -> C -> A; positions 100, 300, 700; all forward, 100M
+    tl = 700 + 100 - 100
+    rec = RecordBatch.from_fields([0, 0, 0, 0], [100, 300, 700, 5000], [0, 0, 0, -1], [300, 700, 100, -1], [0x41, 0x81, 0x881, 0], [60, 60, 60, 60], ["100M"] * 4, [seq] * 4,
+                                  ["t", "t", "t", "solo"], isize=[tl, -tl, -tl, 0], targets=[("chr1", 20000)])
+    refs = cramio.make_reference(rec, seed=3)
+    fa = str(tmp_path / "r.fa")
+    cramio.write_fasta(fa, rec.targets, refs)
+    p = str(tmp_path / "chain.cram")
+    st = {}
+    cramio.write_cram(p, rec, refs, index=False, read_names=True, stats=st)
+    assert st == {3: 1}            # written as ONE chain of three, not as detached records
+    raw = open(p, "rb").read()
+    r = _run(["_dump", p], env=dict(os.environ, STRL_CRAM_FASTA=fa))
+    assert r.returncode == 0, r.stderr
+    body = [l.split("\t") for l in r.stdout.split("\n") if l and not l.startswith("@")]
+    got = [(f[0], int(f[1]), int(f[3]), int(f[6]), int(f[7]), int(f[8])) for f in body]
+    assert got == [("t", 0x41, 100, 0, 300, tl), ("t", 0x81, 300, 0, 700, -tl), ("t", 0x881, 700, 0, 100, -tl), ("solo", 0, 5000, -1, -1, 0)], got
+    assert len(raw) > 0
 
 
 def test_crai_region_reads(cram_sample, tmp_path):

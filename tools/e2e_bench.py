@@ -70,18 +70,21 @@ def _timed(cmd, env):
     return r, time.time() - t
 
 
-def run(inp, cli, threads=(0,), call=True, merge=True, repeats=1):
+def run(inp, cli, threads=(0,), call=True, merge=True, repeats=1, gpus=1, extra_env=None):
     """`strling extract -v` once per thread count (0 = the CLI's default), then `strling call` and `strling merge` on the
-    .bin -> the end_to_end block of bench.py's line"""
+    .bin -> the end_to_end block of bench.py's line.  gpus > 1: `strling extract --gpus N` / `strling merge --gpus N` (one process,
+    N contexts: a contiguous share of the file per device, each fed by its own host threads)."""
     global SETTLE_S
     SETTLE_S = 1.0 + 4.0 * min(1.0, inp["bam_MB"] / 50000.0)
     res = {"unit": "reads/s", "reads": inp["reads"], "bam_MB": inp["bam_MB"], "settle_s_before_each_process": round(SETTLE_S, 1), "input": inp.get("input"), "make_s": inp.get("make_s"),
-           "host_threads_available": os.cpu_count(), "cgroup_cpu_quota": _quota(), "runs": []}
+           "host_threads_available": os.cpu_count(), "cgroup_cpu_quota": _quota(), "gpus": gpus, "runs": []}
+    g_args = ["--gpus", str(gpus)] if gpus > 1 else []
     for t in list(threads) * repeats:
         env = dict(os.environ, STRL_DECODE_TIMING="1", STRL_FRONT_TIMING="1")
+        env.update(extra_env or {})
         if t:
             env["STRL_THREADS"] = str(t)
-        r, wall = _timed([cli, "extract", "-v", "-g", inp["bed"], inp["bam"], inp["out"]], env)
+        r, wall = _timed([cli, "extract", "-v", "-g", inp["bed"]] + g_args + [inp["bam"], inp["out"]], env)
         err = r.stderr.splitlines()
         line = [l for l in err if "seconds: total" in l]
         loop_s = float(line[-1].split("total")[1].split()[0]) if line else None
@@ -97,7 +100,9 @@ def run(inp, cli, threads=(0,), call=True, merge=True, repeats=1):
         mem_gb = float(re.search(r": ([\d.]+) GB of", mem[-1]).group(1)) if mem else None
         n_str = [l for l in err if " STR reads, " in l]
         su = [l for l in err if "seconds before the loop" in l]
-        run_ = {"decode_threads": t or "default", "rc": r.returncode, "wall_s": round(wall, 3), "reads_per_s_wall": round(inp["reads"] / wall),
+        sh = [l.split("[strling] ")[1] for l in err if l.startswith("[strling] share ")]
+        gl = [l.split("[strling] ")[1] for l in err if "per-read state gathered" in l]
+        run_ = {"decode_threads": t or "default", "rc": r.returncode, "shares": sh or None, "gather": gl[-1] if gl else None, "wall_s": round(wall, 3), "reads_per_s_wall": round(inp["reads"] / wall),
                 "loop_s": loop_s, "reads_per_s_loop": round(inp["reads"] / loop_s) if loop_s else None, "device_front_end": front,
                 "device_mem_GB": mem_gb, "str_reads": int(n_str[-1].split(" reads, ")[1].split()[0]) if n_str else None,
                 "phases": line[-1].split("seconds:")[1].strip() if line else r.stderr[-400:],
@@ -139,7 +144,7 @@ def run(inp, cli, threads=(0,), call=True, merge=True, repeats=1):
         else:
             res["call_stderr_tail"] = r.stderr[-600:]
     if merge:
-        r, wall = _timed([cli, "merge", "-v", "-o", inp["prefix"] + "-joint", inp["out"]], env)
+        r, wall = _timed([cli, "merge", "-v"] + g_args + ["-o", inp["prefix"] + "-joint", inp["out"]], env)
         res["merge_s"] = round(wall, 3)
         res["merge_rc"] = r.returncode
         if r.returncode == 0:
@@ -264,6 +269,7 @@ if __name__ == "__main__":
     ap.add_argument("--check-slabs", type=int, default=8)
     ap.add_argument("--repeats", type=int, default=1)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--out", default="")
     ap.add_argument("--check-json", default="", help="(internal) run check() on the input described by this file and print its result")
     a = ap.parse_args()
@@ -273,7 +279,7 @@ if __name__ == "__main__":
         sys.exit(0)
     inp = make_input(a.n_pairs, d=a.dir, level=a.level, progress=True)
     print(f"[e2e] wrote {inp['bam']} ({inp['bam_MB']} MB, {inp['reads']} reads) in {inp['make_s']} s", file=sys.stderr, flush=True)
-    res = run(inp, build.CLI, repeats=a.repeats)
+    res = run(inp, build.CLI, repeats=a.repeats, gpus=a.gpus)
     if a.check_slabs and "error" not in res:
         res["check"] = check(inp, pick_slabs(inp["n_slabs"], a.check_slabs), call=res.get("call_rc") == 0)
     if not a.keep:

@@ -18,13 +18,10 @@ check widths "$T/widths.bin" "$D/widths.expected.bin" "msgpack4nim writes the sm
 check ties "$T/ties-bounds.txt" "$D/ties.expected-bounds.txt" "CountTable.largest = first maximum in Nim 1.6 slot order"
 "$S" merge -m 2 -o "$T/many" "$D/manygroups.0.bin" > "$T/many.log" 2>&1
 check manygroups "$T/many-bounds.txt" "$D/manygroups.expected-bounds.txt" "Table[(tid, repeat)] iteration order after growth"
-if [ $fail = 0 ]; then echo "all assumptions confirmed"; else echo "outputs kept in $T (the .tsv beside an expected .bin lists its treads)"; fi
-exit $fail
-
-# ---- CRAM (round 4): the reader of strling_amd against a CRAM that SAMTOOLS wrote.  Needs samtools on PATH; skipped otherwise.
+# ---- CRAM: the reader of strling_amd against a CRAM that SAMTOOLS wrote (ahead of the verdict below: round 4 had put it behind `exit`).  Needs samtools on PATH; skipped otherwise.
 # verify/run_reference.sh /path/to/strling_amd/lib/strling  -> the .bin of `extract` on widths.cram must equal widths.expected.bin
 if command -v samtools > /dev/null 2>&1; then
-  for opt in "version=3.0" "version=3.0,no_ref" "version=3.0,seqs_per_slice=100"; do
+  for opt in "version=3.0" "version=3.0,no_ref" "version=3.0,seqs_per_slice=100" "version=3.1" "version=3.1,seqs_per_slice=100"; do
     samtools view -C -T "$D/ref.fa" --output-fmt-option "$opt" -o "$T/widths.cram" "$D/widths.bam" && samtools index "$T/widths.cram"
     "$S" extract -f "$D/ref.fa" -g "$D/ref.fa.str" "$T/widths.cram" "$T/widths.cram.bin" > "$T/widths.cram.log" 2>&1
     check "cram[$opt]" "$T/widths.cram.bin" "$D/widths.expected.bin" "the CRAM 3.0 reader (own code, so far only checked against its own writer) reads htslib's files"
@@ -32,3 +29,5 @@ if command -v samtools > /dev/null 2>&1; then
 else
   echo "SKIP  cram   (samtools not on PATH: the CRAM reader stays checked against strling_amd/cramio.py's files only)"
 fi
+if [ $fail = 0 ]; then echo "all assumptions confirmed"; else echo "outputs kept in $T (the .tsv beside an expected .bin lists its treads)"; fi
+exit $fail
