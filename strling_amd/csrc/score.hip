@@ -1443,12 +1443,32 @@ int strl_ctxs_extract_gather(strl_ctx **ctxs, int n, const uint32_t *chunk_owner
   STRL_HIP(hipSetDevice(c0->device));
   hipStream_t st = c0->stream;
   const uint64_t t1 = std::max<uint64_t>(tot, 1), s1 = std::max<uint64_t>(soft_at[(size_t)n], 1);
+  // Shares (the first context holds the FIRST records of the file, all of them, and nothing else): its columns stay where
+  // they are and the other contexts' shares are appended behind them -- no second copy of the per-read state, no copy of the
+  // first share, and no allocation when strl_front_begin sized the first context for the whole file (the CLI does).
+  bool in_place = true;
+  {
+    uint64_t own = 0;
+    for (uint64_t k = 0; k < n_chunks; ++k) {
+      if (chunk_owner[k] == 0) { if (gbase[(size_t)k] != lbase[(size_t)k]) in_place = false; own += chunk_records[k]; }
+    }
+    if (own != local_n[0]) in_place = false;
+  }
   DevBuf rows, qhash, whole, qref, fragw, soft, arena, tmp, tab;
   int rc;
-  if ((rc = rows.reserve((size_t)t1 * sizeof(strl_pair_rec))) || (rc = qhash.reserve((size_t)t1 * 8)) || (rc = whole.reserve((size_t)t1 * 4)) ||
-      (rc = qref.reserve((size_t)t1 * 8)) || (rc = fragw.reserve((size_t)t1 * 4)) || (rc = soft.reserve((size_t)s1 * sizeof(strl_soft_rec))) ||
-      (rc = arena.reserve((size_t)arena_at[(size_t)n] + 64)) || (rc = tmp.reserve(std::max<size_t>((size_t)c0->bloom_mask / 8 + 64, (size_t)F0->n_ref + 64))) || (rc = tab.reserve((size_t)std::max<uint64_t>(n_chunks, 1) * 8 + 64)))
+  if (in_place) {
+    const uint64_t n0 = local_n[0];
+    if ((rc = c0->x_rows.grow((size_t)t1 * sizeof(strl_pair_rec), (size_t)n0 * sizeof(strl_pair_rec), st)) || (rc = c0->x_qhash.grow((size_t)t1 * 8, (size_t)n0 * 8, st)) ||
+        (rc = c0->x_whole.grow((size_t)t1 * 4, (size_t)n0 * 4, st)) || (rc = F0->qref.grow((size_t)t1 * 8, (size_t)n0 * 8, st)) || (rc = F0->fragw.grow((size_t)t1 * 4, (size_t)n0 * 4, st)) ||
+        (rc = c0->x_soft.grow((size_t)s1 * sizeof(strl_soft_rec), (size_t)soft_at[1] * sizeof(strl_soft_rec), st)) ||
+        (rc = F0->qarena.grow((size_t)arena_at[(size_t)n] + 64, (size_t)arena_at[1], st)))
+      return rc;
+    rows = c0->x_rows; qhash = c0->x_qhash; whole = c0->x_whole; qref = F0->qref; fragw = F0->fragw; soft = c0->x_soft; arena = F0->qarena;     // (views: ownership stays with the context)
+  } else if ((rc = rows.reserve((size_t)t1 * sizeof(strl_pair_rec))) || (rc = qhash.reserve((size_t)t1 * 8)) || (rc = whole.reserve((size_t)t1 * 4)) ||
+             (rc = qref.reserve((size_t)t1 * 8)) || (rc = fragw.reserve((size_t)t1 * 4)) || (rc = soft.reserve((size_t)s1 * sizeof(strl_soft_rec))) ||
+             (rc = arena.reserve((size_t)arena_at[(size_t)n] + 64)))
     return rc;
+  if ((rc = tmp.reserve(std::max<size_t>((size_t)c0->bloom_mask / 8 + 64, (size_t)F0->n_ref + 64))) || (rc = tab.reserve((size_t)std::max<uint64_t>(n_chunks, 1) * 8 + 64))) return rc;
   // Runs of consecutive chunks of one owner (a share = one run) are contiguous on both sides: one copy per column.  A
   // context's columns, names and soft-clip records travel on ITS stream -- each source device drives its own link to the first,
   // the links work side by side -- and the first context's stream waits for one event per source before it re-bases.
@@ -1467,6 +1487,7 @@ int strl_ctxs_extract_gather(strl_ctx **ctxs, int n, const uint32_t *chunk_owner
     strl_ctx *cg = ctxs[g];
     STRL_HIP(hipSetDevice(cg->device));
     hipStream_t sg = cg->stream;
+    if (g == 0 && in_place) continue;            // its records, names and soft-clip records are where they belong already
     for (const Run &r : runs) {
       if (r.owner != (uint32_t)g) continue;
       if ((rc = copy_between(rows.as<strl_pair_rec>() + r.go, c0->device, cg->x_rows.as<strl_pair_rec>() + r.lo, cg->device, (size_t)r.m * sizeof(strl_pair_rec), sg)) ||
@@ -1497,7 +1518,7 @@ int strl_ctxs_extract_gather(strl_ctx **ctxs, int n, const uint32_t *chunk_owner
         STRL_HIP(hipGetLastError());
       }
     const uint64_t ns = soft_at[(size_t)g + 1] - soft_at[(size_t)g];
-    if (ns) {
+    if (ns && !(g == 0 && in_place)) {
       std::vector<uint32_t> &tl = tls[(size_t)g], &tg = tgs[(size_t)g];      // this context's chunks: first local / first global record
       for (uint64_t k = 0; k < n_chunks; ++k) if (chunk_owner[k] == (uint32_t)g) { tl.push_back((uint32_t)lbase[(size_t)k]); tg.push_back((uint32_t)gbase[(size_t)k]); }
       STRL_HIP(hipMemcpyAsync(tab.as<uint32_t>() + tab_at, tl.data(), tl.size() * 4, hipMemcpyHostToDevice, st));
@@ -1528,13 +1549,15 @@ int strl_ctxs_extract_gather(strl_ctx **ctxs, int n, const uint32_t *chunk_owner
   drop_events();
   STRL_HIP(hipMemcpy(c0->x_cnt.p, sum, XC_WORDS * 4, hipMemcpyHostToDevice));
   // ctxs[0] takes the gathered state over
-  c0->x_rows.release(); c0->x_qhash.release(); c0->x_whole.release(); c0->x_soft.release();
-  F0->qref.release(); F0->fragw.release(); F0->qarena.release();
-  c0->x_rows = rows; c0->x_qhash = qhash; c0->x_whole = whole; c0->x_soft = soft;
-  F0->qref = qref; F0->fragw = fragw; F0->qarena = arena;
+  if (!in_place) {
+    c0->x_rows.release(); c0->x_qhash.release(); c0->x_whole.release(); c0->x_soft.release();
+    F0->qref.release(); F0->fragw.release(); F0->qarena.release();
+    c0->x_rows = rows; c0->x_qhash = qhash; c0->x_whole = whole; c0->x_soft = soft;
+    F0->qref = qref; F0->fragw = fragw; F0->qarena = arena;
+  }
   F0->qarena_used = arena_at[(size_t)n];
   c0->x_n = tot;
-  c0->x_soft_cap = s1;
+  c0->x_soft_cap = in_place ? c0->x_soft.cap / sizeof(strl_soft_rec) : s1;
   c0->x_soft_known = soft_at[(size_t)n]; c0->x_soft_known_at = tot;
   tmp.release(); tab.release();
   return STRL_OK;
