@@ -168,8 +168,279 @@ def rans_encode(data, order):
     return bytes([order]) + struct.pack("<II", len(body), n) + body
 
 
+
+# ---- CRAM 3.1 codecs (CRAMcodecs sections 3 and 5): test encoders for cli/cram_codecs.cpp ----------------------------
+def u7(v):
+    """variable-length integer, most significant 7-bit group first"""
+    out = [v & 0x7F]
+    v >>= 7
+    while v:
+        out.append(0x80 | (v & 0x7F))
+        v >>= 7
+    return bytes(reversed(out))
+
+
+def _alphabet(syms):
+    """the run-length coded list of the symbols that occur (as in _freq_table, without the frequencies)"""
+    out = bytearray()
+    syms = sorted(int(x) for x in syms)
+    rle = 0
+    for k, x in enumerate(syms):
+        if rle:
+            rle -= 1
+            continue
+        out.append(x)
+        if k and syms[k - 1] == x - 1:
+            run = 0
+            while k + 1 + run < len(syms) and syms[k + 1 + run] == x + 1 + run:
+                run += 1
+            out.append(run)
+            rle = run
+    out.append(0)
+    return bytes(out)
+
+
+def _norm_to(cnt, bits):
+    """counts -> frequencies summing to 2^bits (every present symbol >= 1)"""
+    F = _norm_freqs(np.asarray(cnt, np.int64))
+    if bits == 12:
+        return F
+    tot, want = 4096, 1 << bits
+    nz = np.nonzero(F)[0]
+    G = np.zeros(256, np.int64)
+    G[nz] = np.maximum(1, F[nz] * want // tot)
+    d = want - int(G.sum())
+    order = sorted(nz, key=lambda x: -G[x])
+    k = 0
+    while d:
+        x = order[k % len(order)]
+        step = 1 if d > 0 else (-1 if G[x] > 1 else 0)
+        G[x] += step
+        d -= step
+        k += 1
+    return G
+
+
+def _put16(x, emit, start, freq, shift):
+    x_max = (((1 << 15) >> shift) << 16) * freq
+    while x >= x_max:
+        emit.append(x & 0xFFFF)
+        x >>= 16
+    return ((x // freq) << shift) + (x % freq) + start
+
+
+def _nx16_order0(data, N):
+    a = np.frombuffer(data, np.uint8)
+    n = len(data)
+    F = _norm_freqs(np.bincount(a, minlength=256))
+    C = np.concatenate([[0], np.cumsum(F)[:-1]])
+    present = np.nonzero(F)[0]
+    table = _alphabet(present) + b"".join(u7(int(F[x])) for x in present)
+    emit, R = [], [1 << 15] * N
+    for i in range(n - 1, -1, -1):
+        k = i % N
+        x = data[i]
+        R[k] = _put16(R[k], emit, int(C[x]), int(F[x]), 12)
+    return table + b"".join(struct.pack("<I", R[k]) for k in range(N)) + b"".join(struct.pack("<H", w) for w in reversed(emit))
+
+
+def _nx16_order1(data, N, shift=12, compress_table=False):
+    a = np.frombuffer(data, np.uint8)
+    n = len(data)
+    seg = n // N
+    prev = np.concatenate([[0], a[:-1]]).astype(np.int64)
+    for k in range(N):
+        if k * seg < n:
+            prev[k * seg] = 0
+    cnt = np.zeros((256, 256), np.int64)
+    np.add.at(cnt, (prev, a.astype(np.int64)), 1)
+    alpha = sorted(set(int(x) for x in np.nonzero(cnt.sum(axis=1))[0]) | set(int(x) for x in np.nonzero(cnt.sum(axis=0))[0]) | {0})
+    Fs, Cs = {}, {}
+    tab = bytearray(_alphabet(alpha))
+    for c in alpha:
+        F = _norm_to(cnt[c], shift) if cnt[c].sum() else np.zeros(256, np.int64)
+        Fs[c], Cs[c] = F, np.concatenate([[0], np.cumsum(F)[:-1]])
+        run = 0
+        for k, x in enumerate(alpha):
+            if run:
+                run -= 1
+                continue
+            tab += u7(int(F[x]))
+            if not F[x]:
+                while k + 1 + run < len(alpha) and F[alpha[k + 1 + run]] == 0 and run < 255:
+                    run += 1
+                tab.append(run)
+    emit, R = [], [1 << 15] * N
+    for i in range(n - 1, seg * N - 1, -1):
+        c = int(prev[i])
+        R[N - 1] = _put16(R[N - 1], emit, int(Cs[c][data[i]]), int(Fs[c][data[i]]), shift)
+    for j in range(seg - 1, -1, -1):
+        for k in range(N - 1, -1, -1):
+            i = k * seg + j
+            c = int(prev[i])
+            R[k] = _put16(R[k], emit, int(Cs[c][data[i]]), int(Fs[c][data[i]]), shift)
+    if compress_table:
+        ct = _nx16_order0(bytes(tab), 4)
+        head = bytes([(shift << 4) | 1]) + u7(len(tab)) + u7(len(ct)) + ct
+    else:
+        head = bytes([shift << 4]) + bytes(tab)
+    return head + b"".join(struct.pack("<I", R[k]) for k in range(N)) + b"".join(struct.pack("<H", w) for w in reversed(emit))
+
+
+def rans_nx16_encode(data, order=0, x32=False, pack=False, rle=False, stripe=0, cat=False, nosz=False, shift=12, compress_table=False):
+    """one rANS Nx16 stream: flags | size | [PACK map, packed size] | [RLE metadata, literal count] | payload"""
+    data = bytes(data)
+    flags = (order & 1) | (4 if x32 else 0) | (8 if stripe else 0) | (0x10 if nosz else 0) | (0x20 if cat else 0)
+    out = bytearray()
+    if stripe:
+        subs = [rans_nx16_encode(data[j::stripe], order=order, x32=x32, nosz=True, pack=pack, rle=rle, shift=shift) for j in range(stripe)]
+        out = bytearray([flags]) + (b"" if nosz else u7(len(data))) + bytes([stripe]) + b"".join(u7(len(x)) for x in subs) + b"".join(subs)
+        return bytes(out)
+    cur = data
+    meta = bytearray()
+    if pack:
+        syms = sorted(set(cur))
+        if len(syms) <= 16:
+            flags |= 0x80
+            idx = {x: k for k, x in enumerate(syms)}
+            bits = 0 if len(syms) <= 1 else 1 if len(syms) <= 2 else 2 if len(syms) <= 4 else 4
+            if bits:
+                per = 8 // bits
+                packed = bytearray()
+                for i in range(0, len(cur), per):
+                    v = 0
+                    for k, x in enumerate(cur[i:i + per]):
+                        v |= idx[x] << (bits * k)
+                    packed.append(v)
+                cur = bytes(packed)
+            else:
+                cur = b""
+            meta += bytes([len(syms)]) + bytes(syms) + u7(len(cur))
+    rep = set()                                    # symbols worth a run length: those that ever repeat (none: no RLE -- a count of 0 means 256)
+    for i in range(1, len(cur)):
+        if cur[i] == cur[i - 1]:
+            rep.add(cur[i])
+    if rle and rep:
+        flags |= 0x40
+        lits, runs = bytearray(), bytearray()
+        i = 0
+        while i < len(cur):
+            x = cur[i]
+            j = i + 1
+            if x in rep:
+                while j < len(cur) and cur[j] == x:
+                    j += 1
+                runs += u7(j - i - 1)
+            lits.append(x)
+            i = j
+        rsyms = sorted(rep)
+        rmeta = bytes([len(rsyms) & 0xFF]) + bytes(rsyms) + bytes(runs)
+        if len(rmeta) > 64:
+            crm = _nx16_order0(rmeta, 4)
+            meta += u7(len(rmeta) * 2) + u7(len(lits)) + u7(len(crm)) + crm
+        else:
+            meta += u7(len(rmeta) * 2 + 1) + u7(len(lits)) + rmeta
+        cur = bytes(lits)
+    N = 32 if x32 else 4
+    if cat or not cur:
+        flags |= 0x20
+        body = cur
+    elif order & 1 and len(cur) >= N:
+        body = _nx16_order1(cur, N, shift, compress_table)
+    else:
+        flags &= ~1
+        body = _nx16_order0(cur, N)
+    return bytes([flags]) + (b"" if nosz else u7(len(data))) + bytes(meta) + body
+
+
+T_TYPE, T_ALPHA, T_CHAR, T_DIGITS0, T_DZLEN, T_DUP, T_DIFF, T_DIGITS, T_DELTA, T_DELTA0, T_MATCH, T_NOP, T_END = range(13)
+
+
+def _tokens(name):
+    """a name cut into runs of digits (at most 9, so the value fits 32 bits) and the text between them"""
+    out, i = [], 0
+    while i < len(name):
+        if 48 <= name[i] <= 57:
+            j = i
+            while j < len(name) and 48 <= name[j] <= 57 and j - i < 9:
+                j += 1
+            out.append(("d", name[i:j]))
+        else:
+            j = i
+            while j < len(name) and not 48 <= name[j] <= 57:
+                j += 1
+            out.append(("a", name[i:j]))
+        i = j
+    return out
+
+
+def tok3_encode(names, stream_kw=None, dup_streams=True):
+    """the name tokeniser's layout (CRAMcodecs section 5): names (bytes, no NUL) -> block payload.  Every name is coded against
+    the previous one: whole-name duplicates, per-position MATCH / DELTA / DELTA0, otherwise its own token."""
+    stream_kw = stream_kw or {}
+    S = {}                                         # (position, type) -> bytearray
+
+    def put(pos, typ, b):
+        S.setdefault((pos, typ), bytearray()).extend(b)
+
+    prev_tok, prev_name = None, None
+    for c, name in enumerate(names):
+        if prev_name is not None and name == prev_name:
+            put(0, T_TYPE, bytes([T_DUP]))
+            put(0, T_DUP, struct.pack("<I", 1))
+            continue
+        put(0, T_TYPE, bytes([T_DIFF]))
+        put(0, T_DIFF, struct.pack("<I", 1 if c else 0))
+        toks = _tokens(name)
+        for k, (kind, txt) in enumerate(toks):
+            pos = k + 1
+            pt = prev_tok[k] if prev_tok is not None and k < len(prev_tok) else None
+            if pt is not None and pt == (kind, txt):
+                put(pos, T_TYPE, bytes([T_MATCH]))
+            elif kind == "d":
+                v = int(txt)
+                lead0 = len(txt) > 1 and txt[0] == 48
+                p_is_d = pt is not None and pt[0] == "d"
+                p_lead0 = p_is_d and len(pt[1]) > 1 and pt[1][0] == 48
+                near = p_is_d and 0 <= v - int(pt[1]) < 256
+                if near and lead0 and p_lead0 and len(pt[1]) == len(txt):
+                    put(pos, T_TYPE, bytes([T_DELTA0])); put(pos, T_DELTA0, bytes([v - int(pt[1])]))
+                elif near and not lead0 and not p_lead0:
+                    put(pos, T_TYPE, bytes([T_DELTA])); put(pos, T_DELTA, bytes([v - int(pt[1])]))
+                elif lead0:
+                    put(pos, T_TYPE, bytes([T_DIGITS0])); put(pos, T_DIGITS0, struct.pack("<I", v)); put(pos, T_DZLEN, bytes([len(txt)]))
+                else:
+                    put(pos, T_TYPE, bytes([T_DIGITS])); put(pos, T_DIGITS, struct.pack("<I", v))
+            elif len(txt) == 1:
+                put(pos, T_TYPE, bytes([T_CHAR])); put(pos, T_CHAR, txt)
+            else:
+                put(pos, T_TYPE, bytes([T_ALPHA])); put(pos, T_ALPHA, txt + b"\0")
+        put(len(toks) + 1, T_TYPE, bytes([T_END]))
+        prev_tok, prev_name = toks, name
+    ulen = sum(len(x) + 1 for x in names)
+    out = bytearray(struct.pack("<IIB", ulen, len(names), 0))
+    seen = {}
+    npos = max(p for p, _ in S) + 1
+    for pos in range(npos):
+        first = True
+        for typ in range(13):
+            if (pos, typ) not in S:
+                continue
+            data = bytes(S[(pos, typ)])
+            tt = typ | (0x80 if first else 0)
+            first = False
+            if dup_streams and data in seen and seen[data] != (pos, typ):
+                out += bytes([tt | 0x40, seen[data][0], seen[data][1]])
+                continue
+            seen.setdefault(data, (pos, typ))
+            comp = rans_nx16_encode(data, **stream_kw)
+            out += bytes([tt]) + u7(len(comp)) + comp
+    return bytes(out)
+
+
 # ---- blocks, encodings ----------------------------------------------------------------------------------------------
 RAW, GZIP, RANS = 0, 1, 4
+RANSNX16, TOK3 = 5, 8
 FILE_HEADER, COMPRESSION_HEADER, SLICE_HEADER, EXTERNAL_DATA, CORE_DATA = 0, 1, 2, 4, 5
 
 
@@ -181,6 +452,11 @@ def block(method, content_type, content_id, raw):
         data, method = rans_encode(raw, 0), RANS
     elif method == (RANS, 1):
         data, method = rans_encode(raw, 1), RANS
+    elif isinstance(method, tuple) and method[0] == RANSNX16:
+        data, method = rans_nx16_encode(raw, **method[1]), RANSNX16
+    elif method == TOK3:
+        names = raw.split(b"\0")[:-1] if raw else []
+        data, method = (tok3_encode(names), TOK3) if names else (raw, RAW)
     else:
         data, method = raw, RAW
     b = bytes([method, content_type]) + itf8(content_id) + itf8(len(data)) + itf8(len(raw)) + data
@@ -275,6 +551,8 @@ def huffman_lengths(freq):
 # content ids of the external blocks
 CID = dict(BF=1, RL=3, AP=4, RN=6, MF=7, NS=8, NP=9, TS=10, NF=11, FC=14, FP=15, BS=17, IN=18, IN_LEN=19, SC=20, HC=21, PD=22, RS=23, BA=25, QS=26, RI=27)
 METHODS = [RAW, GZIP, (RANS, 0), (RANS, 1)]
+METHODS_31 = [(RANSNX16, dict(order=0)), (RANSNX16, dict(order=1)), (RANSNX16, dict(order=1, x32=True)), (RANSNX16, dict(order=0, pack=True, rle=True)),
+              (RANSNX16, dict(order=0, stripe=4)), (RANSNX16, dict(order=1, compress_table=True, shift=10)), (RANSNX16, dict(cat=True))]
 SUBST_ALT = {"A": "CGTN", "C": "AGTN", "G": "ACTN", "T": "ACGN", "N": "ACGT"}
 
 
@@ -315,6 +593,47 @@ def make_reference(rec, seed=1):
             elif op in (2, 3):
                 rp += ln
     return [r.tobytes() for r in refs]
+
+
+def reads_from_reference(rec, refs, mismatch=0.004, seed=1):
+    """rewrites the bases of `rec` (in place) so that its mapped reads READ LIKE A SEQUENCER'S against `refs`: every base under an
+    M / = / X operation is the reference's, except a fraction `mismatch` of them; clipped and inserted bases stay what they were.
+    What a real CRAM holds -- a read feature or two per record, not a hundred -- for decode-rate measurements."""
+    rng = np.random.default_rng(seed)
+    code = np.zeros(256, np.uint8)
+    for k, ch in enumerate(b"=ACMGRSVTWYHKDBN"):
+        code[ch] = k
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    refa = [np.frombuffer(r, np.uint8) for r in refs]
+    for i in range(rec.n):
+        t = int(rec.tid[i])
+        if t < 0 or int(rec.flag[i]) & 4:
+            continue
+        L, so = int(rec.l_seq[i]), int(rec.seq_off[i])
+        nib = np.empty(L + (L & 1), np.uint8)
+        packed = rec.seq4[so:so + (L + 1) // 2]
+        nib[0::2] = packed >> 4
+        nib[1::2] = packed & 15
+        rp, qp = int(rec.pos[i]), 0
+        for c in rec.cigar[int(rec.cigar_off[i]):int(rec.cigar_off[i + 1])]:
+            op, ln = int(c) & 15, int(c) >> 4
+            if op in (0, 7, 8):
+                a, b = max(rp, 0), min(rp + ln, refa[t].size)
+                if b > a:
+                    seg = refa[t][a:b].copy()
+                    mm = np.nonzero(rng.random(b - a) < mismatch)[0]
+                    if mm.size:
+                        seg[mm] = acgt[(np.searchsorted(acgt, seg[mm]) + 1 + rng.integers(0, 3, mm.size)) % 4]
+                    nib[qp + (a - rp):qp + (b - rp)] = code[seg]
+                rp += ln; qp += ln
+            elif op in (1, 4):
+                qp += ln
+            elif op in (2, 3):
+                rp += ln
+        rec.seq4[so:so + (L + 1) // 2] = (nib[0::2] << 4) | nib[1::2]
+        if L & 1:
+            rec.seq4[so + L // 2] &= 0xF0
+    return rec
 
 
 def write_fasta(path, targets, refs, width=60):
@@ -358,14 +677,16 @@ def _chain_fields(xs):
 
 
 def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_per_container=2, read_names=True, index=True, ap_delta=True,
-               multi_ref=False, qualities=False, tags=False, slice_md5=True, stats=None):
+               multi_ref=False, qualities=False, tags=False, slice_md5=True, stats=None, repeat=1, version=(3, 0)):
     """records of `rec` (coordinate sorted, unmapped tail last) -> CRAM 3.0 + .crai.  refs[tid] = reference bytes (ACGTN).
     multi_ref: slices run across reference boundaries (slice reference id -2, RI per record); qualities: every record carries its
     quality array (CF bit 1, QS per base); tags: every record carries NM:C and MD:Z (tag dictionary + tag encoding map: values
     the reader must walk past)."""
     from .bamio import sam_header
     text = (header_text if header_text is not None else sam_header(rec.targets)).encode()
-    out = bytearray(b"CRAM" + bytes([3, 0]) + b"strling-test".ljust(20, b"\0"))
+    out = bytearray(b"CRAM" + bytes(version) + b"strling-test".ljust(20, b"\0"))
+    # version 3.1: the external blocks rotate through the rANS Nx16 variants too, the read names go through the name tokeniser
+    methods = METHODS if tuple(version) == (3, 0) else METHODS + METHODS_31
 
     def container(ref_id, start, span, n_rec, counter, bases, blocks, landmarks):
         body = b"".join(blocks)
@@ -376,6 +697,7 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
 
     out += container(0, 0, 0, 0, 0, 0, [block(RAW, FILE_HEADER, 0, struct.pack("<i", len(text)) + text)], [0])
 
+    data_at = len(out)
     # slices: runs of records on one reference (unmapped tail: -1)
     slices, i = [], 0
     while i < rec.n:
@@ -555,7 +877,10 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
             used = sorted(k for k, v in ext.items() if v)
             eblocks = []
             for k in used:
-                eblocks.append(block(METHODS[method_rot % 4], EXTERNAL_DATA, k, ext[k]))
+                m = methods[method_rot % len(methods)]
+                if tuple(version) != (3, 0) and k == CID["RN"] and read_names:
+                    m = TOK3
+                eblocks.append(block(m, EXTERNAL_DATA, k, ext[k]))
                 method_rot += 1
             core = block(RAW, CORE_DATA, 0, bits.done())
             span = s_end - s_start + 1 if tid >= 0 and s_start else 0
@@ -592,6 +917,15 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
                          blocks, landmarks)
         for tid, st, sp, lm, sz in slice_meta:
             crai.append(f"{tid}\t{st}\t{sp}\t{coff}\t{lm}\t{sz}\n")
+    if repeat > 1:                      # (benchmarks only: the data containers again and again; such a file is not sorted and gets no index)
+        body = bytes(out[data_at:])
+        index = False
+        with open(path, "wb") as f:
+            f.write(out[:data_at])
+            for _ in range(repeat):
+                f.write(body)
+            f.write(EOF_V3)
+        return text.decode()
     out += EOF_V3
     with open(path, "wb") as f:
         f.write(out)

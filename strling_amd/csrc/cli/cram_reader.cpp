@@ -4,6 +4,7 @@
 // to the implementation (template length, mate flags), htslib's cram_decode.c behaviour is restated from its documentation
 // (leftmost start to rightmost end, positive for the leftmost record) -- unverifiable here, no htslib in this image.
 #include "cram_reader.h"
+#include "cram_codecs.h"
 #include <fcntl.h>
 #include <string.h>
 #include <sys/mman.h>
@@ -238,7 +239,11 @@ bool block_data(const Block &b, std::vector<uint8_t> &out, std::string &err) {
     case 2: err = "the CRAM holds bzip2-compressed blocks: not supported by this build (re-encode with `samtools view -C --output-fmt-option use_bzip2=0`)"; return false;
     case 3: err = "the CRAM holds lzma-compressed blocks: not supported by this build (re-encode with `samtools view -C --output-fmt-option use_lzma=0`)"; return false;
     case 4: return rans_decode(b.data, b.csize, out, b.rsize, err);
-    default: err = "the CRAM holds blocks of compression method " + std::to_string(b.method) + " (CRAM 3.1 codecs): only CRAM 3.0 raw / gzip / rANS 4x8 are supported"; return false;
+    case 5: return cram_rans_nx16_decode(b.data, b.csize, b.rsize, out, err);        // CRAM 3.1 (cram_codecs.cpp)
+    case 8: return cram_tok3_decode(b.data, b.csize, b.rsize, out, err);
+    case 6: err = "the CRAM holds blocks compressed with the adaptive arithmetic coder (CRAM 3.1 `small` / `archive` profiles): not supported by this build (re-encode with `samtools view -C` at the default profile)"; return false;
+    case 7: err = "the CRAM holds fqzcomp blocks in a series other than the qualities: not supported by this build"; return false;    // (quality blocks are never decompressed)
+    default: err = "the CRAM holds blocks of unknown compression method " + std::to_string(b.method); return false;
   }
 }
 
@@ -299,7 +304,20 @@ bool parse_encoding(Rd &r, Enc &e, std::string &err) {
   }
 }
 
-struct Ext { std::vector<uint8_t> d; size_t at = 0; };
+// an external block of the slice: its bytes are decompressed when somebody first reads them -- the blocks of series strling
+// never looks at (qualities, tag values: half a file's bytes) are not decompressed at all
+// the external blocks an encoding reads; false when it (also) reads bits of the core data block
+bool enc_ids(const Enc &e, std::vector<int> &ids) {
+  switch (e.codec) {
+    case 0: return true;
+    case 1: case 5: ids.push_back(e.ext); return true;
+    case 3: return e.sym.size() == 1 && e.len[0] == 0;        // a one-symbol code takes no bits
+    case 4: return e.len_enc && e.val_enc && enc_ids(*e.len_enc, ids) && enc_ids(*e.val_enc, ids);
+    default: return false;
+  }
+}
+
+struct Ext { std::vector<uint8_t> d; size_t at = 0; Block src; bool have = true; };
 struct Ctx {
   std::map<int, Ext> ext;
   Ext *fast[128] = {nullptr};   // content ids below 128 (all that htslib and the test writer use), looked up once per block
@@ -319,10 +337,19 @@ struct Ctx {
   }
   void fail(const std::string &m) { if (ok) { ok = false; err = m; } }
   Ext *stream(int id) {
-    if (id >= 0 && id < 128 && fast[id]) return fast[id];
-    auto it = ext.find(id);
-    if (it == ext.end()) { fail("the slice has no external block " + std::to_string(id)); return nullptr; }
-    return &it->second;
+    Ext *s = nullptr;
+    if (id >= 0 && id < 128 && fast[id]) s = fast[id];
+    else {
+      auto it = ext.find(id);
+      if (it == ext.end()) { fail("the slice has no external block " + std::to_string(id)); return nullptr; }
+      s = &it->second;
+    }
+    if (!s->have) {
+      std::string e;
+      if (!block_data(s->src, s->d, e)) { fail(e); return nullptr; }
+      s->have = true;
+    }
+    return s;
   }
   int32_t ext_itf8(int id) {
     Ext *s = stream(id);
@@ -656,8 +683,8 @@ bool CramFile::open(const std::string &path, const std::string &fasta, int threa
   if (m == MAP_FAILED) { map_ = nullptr; err = "mmap failed"; return false; }
   map_ = static_cast<const uint8_t *>(m);
   if (memcmp(map_, "CRAM", 4) != 0) { err = "not a CRAM file"; return false; }
-  if (map_[4] != 3 || map_[5] != 0) {
-    err = "CRAM version " + std::to_string(map_[4]) + "." + std::to_string(map_[5]) + ": this build reads CRAM 3.0 (samtools view -C --output-fmt-option version=3.0)";
+  if (map_[4] != 3 || map_[5] > 1) {
+    err = "CRAM version " + std::to_string(map_[4]) + "." + std::to_string(map_[5]) + ": this build reads CRAM 3.0 and 3.1 (samtools view -C --output-fmt-option version=3.0)";
     return false;
   }
   Container c;
@@ -715,10 +742,33 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
   std::vector<size_t> starts;
   if (only_landmark >= 0) starts.push_back((size_t)only_landmark);
   else for (int32_t l : c.landmarks) starts.push_back((size_t)l);
-  std::string names, seqs, tmp;
-  std::vector<uint32_t> cig;
-  std::vector<Rec> recs;
-  {   // (growing these record by record from several threads at once made them fight over the process' address-space lock)
+  // Series strling never looks at -- qualities, tag values, read groups -- are walked past only when they must be: a series
+  // that takes no bits of the core block and whose external blocks no needed series shares is not decoded at all (its blocks
+  // are then never decompressed either: Ctx::stream).  That is every CRAM htslib writes.
+  std::vector<int> needed_ids;
+  for (const Enc *e : {&eBF, &eCF, &eRI, &eRL, &eAP, &eRN, &eMF, &eNS, &eNP, &eTS, &eNF, &eTL, &eFN, &eFC, &eFP, &eDL, &eBB, &eBS, &eIN, &eRS, &ePD, &eHC, &eSC, &eMQ, &eBA})
+    (void)enc_ids(*e, needed_ids);
+  auto skippable = [&](const Enc &e) {
+    std::vector<int> ids;
+    if (!enc_ids(e, ids)) return false;
+    for (int id : ids) if (std::find(needed_ids.begin(), needed_ids.end(), id) != needed_ids.end()) return false;
+    return true;
+  };
+  const bool skip_qs = skippable(eQS), skip_qq = skippable(eQQ), skip_rg = skippable(eRG);
+  std::vector<std::vector<const Enc *>> tag_walk(H.td.size());        // per tag line: the tag encodings that have to be walked
+  for (size_t t = 0; t < H.td.size(); ++t)
+    for (int32_t key : H.td[t]) {
+      auto it = H.tags.find(key);
+      if (it == H.tags.end()) { err = "CRAM: a tag without an encoding"; return false; }
+      if (!skippable(it->second)) tag_walk[t].push_back(&it->second);
+    }
+  // (scratch of the calling thread, kept between containers: growing fresh vectors record by record from several threads at
+  // once made them fight over the process' address-space lock)
+  static thread_local std::string names, seqs, tmp;
+  static thread_local std::vector<uint32_t> cig;
+  static thread_local std::vector<Rec> recs;
+  names.clear(); seqs.clear(); cig.clear(); recs.clear();
+  {
     const size_t nr = (size_t)std::max(c.n_records, 0);
     recs.reserve(nr); names.reserve(nr * 24); seqs.reserve(nr * 152); cig.reserve(nr * 3);
   }
@@ -766,7 +816,7 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
       Block b;
       if (!read_block(s, b, &err)) { if (err.empty()) err = "truncated CRAM slice"; return false; }
       if (b.type == 5) { if (!block_data(b, X.core, err)) return false; }
-      else if (b.type == 4) { if (!block_data(b, X.ext[b.id].d, err)) return false; }
+      else if (b.type == 4) { Ext &x = X.ext[b.id]; x.src = b; x.have = false; x.at = 0; }
     }
     for (auto &kv : X.ext) if (kv.first >= 0 && kv.first < 128) X.fast[kv.first] = &kv.second;
     std::shared_ptr<const std::string> ref;
@@ -791,7 +841,7 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
       const int32_t ap = dec_int(eAP, X);
       R.pos = H.ap_delta ? prev_pos + ap : ap;
       if (H.ap_delta) prev_pos = R.pos;
-      dec_int(eRG, X);
+      if (!skip_rg) dec_int(eRG, X);
       R.name_at = names.size();
       bool have_name = false;
       if (H.rn) { dec_bytes(eRN, X, tmp); names += tmp; have_name = true; }
@@ -807,11 +857,7 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
       const int32_t tl = dec_int(eTL, X);
       if (tl < 0 || (size_t)tl >= std::max<size_t>(H.td.size(), 1) ) { X.fail("tag line index outside the dictionary"); break; }
       if (!H.td.empty())
-        for (int32_t key : H.td[(size_t)tl]) {
-          auto it = H.tags.find(key);
-          if (it == H.tags.end()) { X.fail("a tag without an encoding"); break; }
-          dec_bytes(it->second, X, tmp);        // tag values are not used by strling
-        }
+        for (const Enc *te : tag_walk[(size_t)tl]) dec_bytes(*te, X, tmp);        // tag values are not used by strling
       if (R.rl < 0 || R.rl > (1 << 24)) { X.fail("implausible read length"); break; }
       R.seq_at = seqs.size();
       seqs.resize(R.seq_at + (size_t)R.rl, 'N');
@@ -831,9 +877,9 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
         auto match_to = [&](int32_t upto) {          // reference bases for read positions [qpos, upto)
           const int32_t n = upto - qpos;
           if (n <= 0) return;
-          for (int32_t k = 0; k < n; ++k) {
-            const int64_t rp = rpos + k;
-            sq[qpos + k] = ref && rp >= 0 && (size_t)rp < ref->size() ? (*ref)[(size_t)rp] : 'N';
+          {   // the part of [rpos, rpos + n) the reference covers in one copy, 'N' around it (seqs was filled with 'N')
+            const int64_t lo = std::max<int64_t>(rpos, 0), hi = ref ? std::min<int64_t>(rpos + n, (int64_t)ref->size()) : lo;
+            if (hi > lo) memcpy(sq + qpos + (lo - rpos), ref->data() + lo, (size_t)(hi - lo));
           }
           push(0, (uint32_t)n);
           rpos += n; qpos += n; ref_used += n;
@@ -855,7 +901,7 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
             }
             case 'B': {
               const int ba = dec_byte(eBA, X);
-              dec_byte(eQS, X);
+              if (!skip_qs) dec_byte(eQS, X);
               if (qpos >= R.rl) { X.fail("read feature outside its read"); break; }
               sq[qpos] = (char)ba;
               push(0, 1); ++rpos; ++qpos; ++ref_used;
@@ -868,8 +914,8 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
               push(0, (uint32_t)tmp.size()); rpos += (int64_t)tmp.size(); qpos += (int32_t)tmp.size(); ref_used += (int32_t)tmp.size();
               break;
             }
-            case 'Q': dec_byte(eQS, X); break;
-            case 'q': dec_bytes(eQQ, X, tmp); break;
+            case 'Q': if (!skip_qs) dec_byte(eQS, X); break;
+            case 'q': if (!skip_qq) dec_bytes(eQQ, X, tmp); break;
             case 'i': {
               const int ba = dec_byte(eBA, X);
               if (qpos >= R.rl) { X.fail("read feature outside its read"); break; }
@@ -893,7 +939,7 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
         }
         match_to(R.rl);
         R.mapq = dec_int(eMQ, X);
-        if (R.cf & 1) for (int32_t k = 0; k < R.rl && X.ok; ++k) dec_byte(eQS, X);
+        if ((R.cf & 1) && !skip_qs) for (int32_t k = 0; k < R.rl && X.ok; ++k) dec_byte(eQS, X);
       } else {
         if (eBA.codec == 1) {
           Ext *st = X.stream(eBA.ext);
@@ -902,7 +948,7 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
         } else {
           for (int32_t k = 0; k < R.rl && X.ok; ++k) sq[k] = (char)dec_byte(eBA, X);
         }
-        if (R.cf & 1) for (int32_t k = 0; k < R.rl && X.ok; ++k) dec_byte(eQS, X);
+        if ((R.cf & 1) && !skip_qs) for (int32_t k = 0; k < R.rl && X.ok; ++k) dec_byte(eQS, X);
       }
       R.cig_n = cig.size() - R.cig_at;
       R.aend = (R.flag & 4) ? R.pos : R.pos + std::max(ref_used, 1) - 1;
@@ -1002,7 +1048,13 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
     const size_t so = (out.seq4.size() + 15) & ~(size_t)15, sb = ((size_t)rl_out + 1) / 2;
     out.seq4.resize(so + sb, 0);
     const char *sq = seqs.data() + R.seq_at;
-    for (int32_t k = 0; k < rl_out; ++k) out.seq4[so + (size_t)(k >> 1)] |= (uint8_t)(NIB.t[(uint8_t)sq[k]] << ((k & 1) ? 0 : 4));
+    {
+      uint8_t *d4 = out.seq4.data() + so;
+      const uint8_t *u = reinterpret_cast<const uint8_t *>(sq);
+      int32_t k = 0;
+      for (; k + 1 < rl_out; k += 2) d4[k >> 1] = (uint8_t)((NIB.t[u[k]] << 4) | NIB.t[u[k + 1]]);
+      if (k < rl_out) d4[k >> 1] = (uint8_t)(NIB.t[u[k]] << 4);
+    }
     out.seq_off.push_back(so);
   }
   return true;
@@ -1032,7 +1084,8 @@ int64_t CramFile::read(RecordBatch &b, int64_t max_records, std::string &err) {
       cs.push_back(std::move(c));
     }
     if (cs.empty()) break;
-    std::vector<RecordBatch> parts(cs.size());
+    if (parts_.size() < cs.size()) parts_.resize(cs.size());          // (kept between calls: their storage is reused)
+    std::vector<RecordBatch> &parts = parts_;
     std::vector<std::string> errs(cs.size());
     std::vector<int> ok(cs.size(), 1);
     static const bool dbg = getenv("STRL_CRAM_DEBUG") != nullptr;
@@ -1043,11 +1096,31 @@ int64_t CramFile::read(RecordBatch &b, int64_t max_records, std::string &err) {
       clock_gettime(CLOCK_MONOTONIC, &t1);
       if (dbg) fprintf(stderr, "[cram] container %zu of %zu: %d records in %.3f s (started at %.3f)\n", k, cs.size(), cs[k].n_records, (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec), (double)(t0.tv_sec % 1000) + 1e-9 * (double)t0.tv_nsec);
     });
-    for (size_t k = 0; k < cs.size(); ++k) {
-      if (!ok[k]) { err = errs[k]; return -1; }
-      got += (int64_t)parts[k].size();
-      append_batch(b, parts[k]);
-    }
+    for (size_t k = 0; k < cs.size(); ++k) if (!ok[k]) { err = errs[k]; return -1; }
+    // the containers' records behind one another in `b`: the arrays grow once, every thread copies its container into place
+    struct At { size_t rec, cig, qn, seq; };
+    std::vector<At> at(cs.size() + 1);
+    at[0] = At{b.size(), b.cigar.size(), b.qnames.size(), (b.seq4.size() + 15) & ~(size_t)15};
+    for (size_t k = 0; k < cs.size(); ++k)
+      at[k + 1] = At{at[k].rec + parts[k].size(), at[k].cig + parts[k].cigar.size(), at[k].qn + parts[k].qnames.size(), (at[k].seq + parts[k].seq4.size() + 15) & ~(size_t)15};
+    const At &e = at[cs.size()];
+    b.tid.resize(e.rec); b.pos.resize(e.rec); b.mtid.resize(e.rec); b.mpos.resize(e.rec); b.isize.resize(e.rec); b.l_seq.resize(e.rec); b.flag.resize(e.rec); b.mapq.resize(e.rec);
+    b.cigar_off.resize(e.rec + 1); b.qname_off.resize(e.rec + 1); b.seq_off.resize(e.rec);
+    b.cigar.resize(e.cig); b.qnames.resize(e.qn); b.seq4.resize(e.seq);
+    pool_->parallel_for(cs.size(), [&](size_t k) {
+      const RecordBatch &a = parts[k];
+      const size_t n = a.size(), r0 = at[k].rec;
+      if (!n) return;
+      memcpy(b.tid.data() + r0, a.tid.data(), n * 4); memcpy(b.pos.data() + r0, a.pos.data(), n * 4); memcpy(b.mtid.data() + r0, a.mtid.data(), n * 4);
+      memcpy(b.mpos.data() + r0, a.mpos.data(), n * 4); memcpy(b.isize.data() + r0, a.isize.data(), n * 4); memcpy(b.l_seq.data() + r0, a.l_seq.data(), n * 4);
+      memcpy(b.flag.data() + r0, a.flag.data(), n * 2); memcpy(b.mapq.data() + r0, a.mapq.data(), n);
+      for (size_t i = 1; i <= n; ++i) { b.cigar_off[r0 + i] = a.cigar_off[i] + (uint32_t)at[k].cig; b.qname_off[r0 + i] = a.qname_off[i] + at[k].qn; }
+      for (size_t i = 0; i < n; ++i) b.seq_off[r0 + i] = a.seq_off[i] + at[k].seq;
+      if (!a.cigar.empty()) memcpy(b.cigar.data() + at[k].cig, a.cigar.data(), a.cigar.size() * 4);
+      if (!a.qnames.empty()) memcpy(&b.qnames[at[k].qn], a.qnames.data(), a.qnames.size());
+      if (!a.seq4.empty()) memcpy(b.seq4.data() + at[k].seq, a.seq4.data(), a.seq4.size());
+    });
+    got += (int64_t)(e.rec - at[0].rec);
   }
   return got;
 }

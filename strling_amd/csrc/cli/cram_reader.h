@@ -75,6 +75,7 @@ class CramFile {
   uint64_t last_c_off_ = ~0ull;
   uint32_t last_s_off_ = 0;
   RecordBatch last_slice_;
+  std::vector<RecordBatch> parts_;               // read(): the containers decoded side by side
 };
 
 }  // namespace strl

@@ -29,6 +29,7 @@
 #include "bam_reader.h"
 #include "bgzf_feed.h"
 #include "cram_reader.h"
+#include "cram_codecs.h"
 
 using namespace strl;
 
@@ -1999,7 +2000,8 @@ static int dump_main(int argc, char **argv) {
 // iterator filter (reader self-check; needs no GPU)
 // strling _decode BAM [BATCH]: the multi-threaded reader alone (inflate + record scan + parse into batches), for timing
 static int decode_main(int argc, char **argv) {
-  if (argc < 3) quit("usage: strling _decode BAM [BATCH]");
+  if (argc < 3) quit("usage: strling _decode BAM [BATCH] [nosum]");
+  const bool nosum = argc > 4 && strcmp(argv[4], "nosum") == 0;      // rate measurements: the single-threaded checksum below is left out
   if (getenv("STRL_CRAM_FASTA")) g_cram_fasta = getenv("STRL_CRAM_FASTA");
   const int64_t batch = argc > 3 ? atoll(argv[3]) : 1048576;
   BamStream rs;
@@ -2018,7 +2020,7 @@ static int decode_main(int argc, char **argv) {
     // order-sensitive checksum over every field of every record (FNV-1a over the values, not over the batch layout: the
     // same file must give the same sum whatever the batch size, thread count, superchunk size or inflate engine)
     auto mix = [&](uint64_t v) { sum = (sum ^ v) * 0x100000001b3ull; };
-    for (size_t i = 0; i < (size_t)got; ++i) {
+    for (size_t i = 0; i < (nosum ? 0 : (size_t)got); ++i) {
       mix((uint64_t)(uint32_t)b.tid[i]); mix((uint64_t)(uint32_t)b.pos[i]); mix((uint64_t)(uint32_t)b.mtid[i]); mix((uint64_t)(uint32_t)b.mpos[i]);
       mix((uint64_t)(uint32_t)b.isize[i]); mix(b.flag[i]); mix(b.mapq[i]); mix((uint64_t)(uint32_t)b.l_seq[i]);
       for (uint32_t c = b.cigar_off[i]; c < b.cigar_off[i + 1]; ++c) mix(b.cigar[c]);
@@ -2140,6 +2142,26 @@ static int index_main(int argc, char **argv) {
   return 0;
 }
 
+// strling _codec nx16|tok3 IN OUT EXPECTED_SIZE  (tests): one CRAM 3.1 block payload through cli/cram_codecs.cpp
+static int codec_main(int argc, char **argv) {
+  if (argc < 6) quit("usage: strling _codec nx16|tok3 IN OUT EXPECTED_SIZE");
+  FILE *f = fopen(argv[3], "rb");
+  if (!f) quit("couldn't open %s", argv[3]);
+  std::vector<uint8_t> in, out;
+  uint8_t buf[65536];
+  size_t got;
+  while ((got = fread(buf, 1, sizeof buf, f)) > 0) in.insert(in.end(), buf, buf + got);
+  fclose(f);
+  std::string err;
+  const size_t expect = (size_t)strtoull(argv[5], nullptr, 10);
+  const bool ok = strcmp(argv[2], "tok3") == 0 ? cram_tok3_decode(in.data(), in.size(), expect, out, err) : cram_rans_nx16_decode(in.data(), in.size(), expect, out, err);
+  if (!ok) quit("[strling] %s", err.c_str());
+  f = fopen(argv[4], "wb");
+  if (!f || (out.size() && fwrite(out.data(), 1, out.size(), f) != out.size())) quit("couldn't write %s", argv[4]);
+  fclose(f);
+  return 0;
+}
+
 // strling _shares BAM G  (tests): the shares `extract --gpus G` cuts the file into -- per share its first record's virtual
 // offset, its blocks, their inflated bytes, the bytes of its last block that are the next share's -- as the walkers deliver them
 static int shares_main(int argc, char **argv) {
@@ -2191,6 +2213,7 @@ int main(int argc, char **argv) {
   if (cmd == "_decode") return decode_main(argc, argv);
   if (cmd == "_region") return region_main(argc, argv);
   if (cmd == "_shares") return shares_main(argc, argv);
+  if (cmd == "_codec") return codec_main(argc, argv);
   if (cmd == "pull_region")
     quit("[strling] `%s` is not part of this build (the MI355X path covers index, extract, merge and call; see DESIGN.md section 9)", cmd.c_str());
   fputs(top, stdout);

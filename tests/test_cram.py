@@ -125,7 +125,10 @@ def test_cram_variants_and_refusals(cram_sample, tmp_path):
     # absolute positions, names only on detached records, other slice / container shapes: the same records
     for k, kw in enumerate((dict(ap_delta=False), dict(records_per_slice=37, slices_per_container=5), dict(records_per_slice=100000, slices_per_container=1),
                             dict(multi_ref=True, records_per_slice=700), dict(qualities=True), dict(tags=True, read_names=True, records_per_slice=123),
-                            dict(multi_ref=True, qualities=True, tags=True, ap_delta=False))):
+                            dict(multi_ref=True, qualities=True, tags=True, ap_delta=False),
+                            # CRAM 3.1: rANS Nx16 in every variant over the external blocks, the read names through the name tokeniser
+                            dict(version=(3, 1)), dict(version=(3, 1), records_per_slice=97, slices_per_container=3, qualities=True, tags=True),
+                            dict(version=(3, 1), multi_ref=True, ap_delta=False))):
         p = str(tmp_path / f"v{k}.cram")
         cramio.write_cram(p, rec, refs, index=False, **kw)
         r = _run(["_dump", p], env=env)
@@ -137,12 +140,13 @@ def test_cram_variants_and_refusals(cram_sample, tmp_path):
     cramio.write_fasta(other, [("zzz", 50)], [b"A" * 50])
     r = _run(["_dump", cram_sample["cram"]], env=dict(os.environ, STRL_CRAM_FASTA=other))
     assert r.returncode == 1 and "is not in the FASTA" in r.stderr
-    # CRAM 3.1 / 2.1 headers, a bzip2 block: refused with the reason
-    data = bytearray(open(cram_sample["cram"], "rb").read())
-    data[5] = 1
-    p31 = str(tmp_path / "v31.cram"); open(p31, "wb").write(data)
-    r = _run(["_dump", p31], env=env)
-    assert r.returncode == 1 and "CRAM version 3.1" in r.stderr
+    # CRAM 4.0 / 2.1 headers: refused with the reason
+    for ver in ((4, 0), (2, 1), (3, 2)):
+        data = bytearray(open(cram_sample["cram"], "rb").read())
+        data[4], data[5] = ver
+        pv = str(tmp_path / "vx.cram"); open(pv, "wb").write(data)
+        r = _run(["_dump", pv], env=env)
+        assert r.returncode == 1 and f"CRAM version {ver[0]}.{ver[1]}" in r.stderr
 
 
 def test_damaged_cram_never_crashes_the_reader(cram_sample, tmp_path):
@@ -249,7 +253,10 @@ def test_extract_and_call_on_cram_equal_the_bam_run(cram_sample, oracle):
     rec, g = cram_sample["rec"], cram_sample["g"]
     d = cram_sample["dir"]
     outs = {}
-    for kind in ("cram", "bam"):
+    cram31 = str(d / "s31.cram")
+    cramio.write_cram(cram31, rec, cram_sample["refs"], records_per_slice=173, slices_per_container=3, version=(3, 1), qualities=True, tags=True)
+    cram_sample = dict(cram_sample, cram31=cram31)
+    for kind in ("cram", "cram31", "bam"):
         out = str(d / f"{kind}.bin")
         r = _run(["extract", "-f", cram_sample["fa"], "-g", cram_sample["bed"], cram_sample[kind], out])
         assert r.returncode == 0, r.stderr
@@ -258,8 +265,8 @@ def test_extract_and_call_on_cram_equal_the_bam_run(cram_sample, oracle):
         r = _run(["call", "-f", cram_sample["fa"], "-m", "2", "-o", pre, cram_sample[kind], out])
         assert r.returncode == 0, r.stderr
         outs[kind + "_call"] = [open(pre + s).read() for s in ("-bounds.txt", "-genotype.txt", "-unplaced.txt")]
-    assert outs["cram"] == outs["bam"]
-    assert outs["cram_call"] == outs["bam_call"] and outs["cram_call"][0].count("\n") > 2
+    assert outs["cram"] == outs["bam"] and outs["cram31"] == outs["bam"]
+    assert outs["cram_call"] == outs["bam_call"] and outs["cram_call"][0].count("\n") > 2 and outs["cram31_call"] == outs["bam_call"]
     frag = synth.frag_hist(rec)
     exp_t = oracle.extract(rec, g, oracle.make_opts(oracle.median(frag), 0.8, 40))
     assert outs["cram"] == oracle.bin_write(0.8, 40, frag, cram_sample["hdr"].rstrip("\0"), exp_t, rec.qname_off, rec.qnames)
