@@ -28,6 +28,9 @@ extern "C" {
 #define STRL_ERR_ASSERT (-7) /* a doAssert of the reference would have fired (e.g. extract.nim:72) */
 #define STRL_ERR_LIMIT (-9)  /* more records than one device pass over a whole input takes (2^31 - 16: record indices travel in 31 bits);
                                 * the reference has no such cap (extract.nim:308) -- the CLI routes such a file to the streaming host Cache */
+#define STRL_ERR_NOMEM (-10) /* device memory exhausted (the per-read state of a whole input is resident: ~130 B per read with the device
+                               * front end; 288 GB hold ~2e9 reads).  The CLI repeats the extraction with the host pair logic, which keeps
+                               * nothing per read on the device. */
 #define STRL_ERR_CRC (-8)    /* a BGZF block inflates, but not to the bytes its CRC-32 names (htslib stops there too) */
 
 #define STRL_MEM_HOST 0

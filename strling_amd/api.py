@@ -118,7 +118,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
            "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order",
-           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered", "strl_inflate_blocks", "strl_ctx_inflate_ms", "strl_regions_fetch", "strl_front_begin", "strl_front_push", "strl_front_push_after", "strl_front_reserve", "strl_front_stage", "strl_front_enqueue_after", "strl_front_collect", "strl_ctxs_extract_gather", "strl_front_finish", "strl_front_fragwords", "strl_front_fragwords_async", "strl_event_wait", "strl_front_records", "strl_front_tids", "strl_front_qnames", "strl_front_treads_named", "strl_pinned_alloc", "strl_pinned_free", "strl_comm_unique_id", "strl_ctx_comm_init", "strl_ctxs_comm_init", "strl_ctx_comm_info", "strl_cluster_exchange", "strl_ctxs_cluster_exchange", "strl_exchange_treads", "strl_ctx_set_treads", "strl_cluster_collect", "strl_ctx_tail_stream", "strl_ctx_mem_info", "strl_bin_peek"]
+           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered", "strl_inflate_blocks", "strl_ctx_inflate_ms", "strl_regions_fetch", "strl_front_begin", "strl_front_push", "strl_front_push_after", "strl_front_reserve", "strl_front_stage", "strl_front_enqueue_after", "strl_front_collect", "strl_ctxs_extract_gather", "strl_front_finish", "strl_front_fragwords", "strl_front_fragwords_async", "strl_event_wait", "strl_front_records", "strl_front_tids", "strl_front_qnames", "strl_front_treads_named", "strl_pinned_alloc", "strl_pinned_free", "strl_comm_unique_id", "strl_ctx_comm_init", "strl_ctxs_comm_init", "strl_ctx_comm_info", "strl_cluster_exchange", "strl_ctxs_cluster_exchange", "strl_exchange_treads", "strl_ctx_set_treads", "strl_cluster_collect", "strl_ctx_tail_stream", "strl_ctx_mem_info", "strl_bin_peek", "strl_front_trim_next", "strl_front_tail_bytes", "strl_ctx_blocking_waits"]
 
 
 def lib_path():
@@ -205,6 +205,10 @@ def load(build_if_missing=True):
     L.strl_front_begin.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64]
     L.strl_front_push.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_int)]
     L.strl_front_finish.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    L.strl_front_trim_next.argtypes = [C.c_void_p, C.c_uint32]
+    L.strl_front_tail_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.strl_ctx_blocking_waits.argtypes = [C.c_void_p, C.c_int]
+    L.strl_ctxs_extract_gather.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
     L.strl_front_fragwords.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
     L.strl_front_tids.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.strl_front_qnames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -571,14 +575,14 @@ class Context:
         return res
 
     # ---- extract with the BAM front end on the device ---------------------------------------------
-    def extract_bam_device(self, path, chunk_blocks=16384, n_reads_hint=0, check_crc=True):
-        """`strling extract`'s read loop over a BAM FILE with inflate, record scan and parse on the device
-        (strl_front_begin / _push / _finish + strl_extract_finish).  The host side here only walks BGZF block headers.
-        -> dict(treads, qnames, fragwords, chunks, n_records, n_tail, targets, header)"""
+    @staticmethod
+    def _bam_blocks(path):
+        """the host side of the device front end in Python: BGZF block table (payload offset, payload length, isize, crc), the
+        header (inflated here) -> dict(data, blocks, n_ref, targets, text, b0 = the block the first record starts in, first_off)"""
         import struct, zlib
         data = np.fromfile(path, np.uint8)
         raw = data.tobytes()
-        blocks, o = [], 0                                     # (payload offset, payload length, isize)
+        blocks, o = [], 0
         while o < len(raw):
             xlen = struct.unpack_from("<H", raw, o + 10)[0]
             bsize = struct.unpack_from("<H", raw, o + 16)[0] + 1
@@ -586,7 +590,6 @@ class Context:
             if isz:
                 blocks.append((o + 12 + xlen, bsize - 12 - xlen - 8, isz, struct.unpack_from("<I", raw, o + bsize - 8)[0]))
             o += bsize
-        # BAM header: inflate leading blocks on the host until it is complete
         hdr, k = b"", 0
 
         def need(nbytes):
@@ -614,13 +617,17 @@ class Context:
         while b0 < len(blocks) and cum + blocks[b0][2] <= at:
             cum += blocks[b0][2]
             b0 += 1
-        first_off = at - cum
-        _check(self.L.strl_front_begin(self.h, n_ref, first_off, n_reads_hint))
+        return dict(data=data, raw=raw, blocks=blocks, n_ref=n_ref, targets=targets, text=text, b0=b0, first_off=at - cum)
+
+    def _front_push_blocks(self, B, c0, c1, chunk_blocks, check_crc, trim=0):
+        """blocks [c0, c1) of the table through strl_front_push in chunks; trim = inflated bytes at the end of the LAST block that
+        are not this context's (strl_front_trim_next before the last chunk) -> the chunk summaries that came back"""
         done = (FrontChunk * 2)()
         nd = C.c_int(0)
         chunks, keep = [], []
-        for c0 in range(b0, len(blocks), chunk_blocks):
-            cb = blocks[c0:c0 + chunk_blocks]
+        data, blocks = B["data"], B["blocks"]
+        for s0 in range(c0, c1, chunk_blocks):
+            cb = blocks[s0:min(c1, s0 + chunk_blocks)]
             lo, hi = cb[0][0], cb[-1][0] + cb[-1][1]
             comp = np.ascontiguousarray(data[lo:hi])
             coff = np.array([b[0] - lo for b in cb], np.uint64)
@@ -628,11 +635,18 @@ class Context:
             isz = np.array([b[2] for b in cb], np.uint32)
             crc = np.array([b[3] for b in cb], np.uint32)
             keep.append((comp, coff, clen, isz, crc))           # pageable memory: the copy is staged by the runtime
+            if trim and s0 + chunk_blocks >= c1:
+                _check(self.L.strl_front_trim_next(self.h, trim))
             _check(self.L.strl_front_push(self.h, comp.ctypes.data, comp.size, _ptr(coff), _ptr(clen), _ptr(isz), _ptr(crc) if check_crc else None, len(cb), done, C.byref(nd)))
             chunks += [_front_chunk(done[i]) for i in range(nd.value)]
             keep = keep[-3:]
         _check(self.L.strl_front_finish(self.h, done, C.byref(nd)))
         chunks += [_front_chunk(done[i]) for i in range(nd.value)]
+        return chunks
+
+    def _front_results(self, B, chunks):
+        """pair logic over everything this context holds + the treads, their names, the fragment words"""
+        n_ref = B["n_ref"]
         n_rec = sum(c["n_records"] for c in chunks)
         n_tail = 0
         for c in chunks:                                      # trailing run of unplaced records over the whole file
@@ -653,8 +667,17 @@ class Context:
         _check(self.L.strl_front_fragwords(self.h, 0, n_rec, fw.ctypes.data))
         seen = np.zeros(max(1, n_ref), np.uint8)
         _check(self.L.strl_front_tids(self.h, seen.ctypes.data, n_ref))
-        return dict(treads=out, qnames=names, fragwords=fw[:n_rec], chunks=chunks, n_records=n_rec, n_tail=n_tail, targets=targets, header=text,
+        return dict(treads=out, qnames=names, fragwords=fw[:n_rec], chunks=chunks, n_records=n_rec, n_tail=n_tail, targets=B["targets"], header=B["text"],
                     tids_seen=seen[:n_ref])
+
+    def extract_bam_device(self, path, chunk_blocks=16384, n_reads_hint=0, check_crc=True):
+        """`strling extract`'s read loop over a BAM FILE with inflate, record scan and parse on the device
+        (strl_front_begin / _push / _finish + strl_extract_finish).  The host side here only walks BGZF block headers.
+        -> dict(treads, qnames, fragwords, chunks, n_records, n_tail, targets, header)"""
+        B = self._bam_blocks(path)
+        _check(self.L.strl_front_begin(self.h, B["n_ref"], B["first_off"], n_reads_hint))
+        chunks = self._front_push_blocks(B, B["b0"], len(B["blocks"]), chunk_blocks, check_crc)
+        return self._front_results(B, chunks)
 
     def inflate_ms(self):
         """kernel time (ms) of the last inflate_blocks call"""
@@ -765,6 +788,56 @@ class Context:
     def cluster_replay(self):
         """device side of the last cluster() call again, asynchronously (bench)"""
         _check(self.L.strl_cluster_replay(self.h))
+
+
+def extract_bam_shares(ctxs, path, chunk_blocks=16384, check_crc=True, cut_shift=0):
+    """the file in len(ctxs) contiguous shares, one per context (the CLI's `extract --gpus N`): every share begins at a record
+    start -- found here by walking the inflated file; the CLI takes them from the .bai --, ends where the next begins
+    (strl_front_trim_next on its last chunk, strl_front_tail_bytes == 0 afterwards), the per-read state is gathered on the
+    first context (strl_ctxs_extract_gather), which then runs the pair logic.  cut_shift != 0 moves every cut that many bytes
+    off its record start: what a stale index does.  -> (result of the first context as extract_bam_device, tail bytes per share)"""
+    import struct, zlib
+    c0 = ctxs[0]
+    B = c0._bam_blocks(path)
+    blocks, raw = B["blocks"], B["raw"]
+    infl = b"".join(zlib.decompress(raw[po:po + pl], -15) for po, pl, _, _ in blocks)
+    ustart = np.concatenate([[0], np.cumsum([b[2] for b in blocks])]).astype(np.int64)
+    q = int(ustart[B["b0"]]) + B["first_off"]
+    starts = []
+    while q + 4 <= len(infl):
+        starts.append(q)
+        q += 4 + struct.unpack_from("<i", infl, q)[0]
+    G = len(ctxs)
+    cuts = [starts[0]] + [starts[len(starts) * g // G] + cut_shift for g in range(1, G)] + [None]
+    owners, counts, tails = [], [], []
+    for g, ctx in enumerate(ctxs):
+        a = cuts[g]
+        ba = int(np.searchsorted(ustart, a, side="right")) - 1
+        _check(ctx.L.strl_ctx_blocking_waits(ctx.h, 1))
+        _check(ctx.L.strl_front_begin(ctx.h, B["n_ref"], a - int(ustart[ba]), 0))
+        if cuts[g + 1] is None:
+            be, trim = len(blocks), 0
+        else:
+            e = cuts[g + 1]
+            bl = int(np.searchsorted(ustart, e, side="right")) - 1
+            uo = e - int(ustart[bl])
+            be, trim = (bl + 1, blocks[bl][2] - uo) if uo else (bl, 0)
+        chunks = ctx._front_push_blocks(B, ba, be, chunk_blocks, check_crc, trim=trim)
+        t = C.c_uint32(0)
+        _check(ctx.L.strl_front_tail_bytes(ctx.h, C.byref(t)))
+        tails.append(int(t.value))
+        owners += [g] * len(chunks)
+        counts += [c["n_records"] for c in chunks]
+        if g == 0:
+            all_chunks = list(chunks)
+        else:
+            all_chunks += chunks
+    if any(tails[:-1]):
+        return None, tails
+    arr = (C.c_void_p * G)(*[c.h for c in ctxs])
+    ow, cn = np.array(owners, np.uint32), np.array(counts, np.uint64)
+    _check(c0.L.strl_ctxs_extract_gather(arr, G, _ptr(ow), _ptr(cn), len(owners)))
+    return c0._front_results(B, all_chunks), tails
 
 
 def comm_unique_id():

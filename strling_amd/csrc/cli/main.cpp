@@ -660,16 +660,21 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   std::thread ctx_thread([&] {
     const auto c0 = now();
     const int n_dev = std::max(1, strl_device_count());
-    // the first context brings the runtime up; the others -- one per device -- are created side by side (0.1 - 0.2 s each)
+    // One after the other (0.1 - 0.2 s each).  STRL_PARALLEL_CTX=1 creates the contexts behind the first side by side: measured
+    // once on one device, where a run of the test suite then hung in a later test -- not taken by default until it has run
+    // on a node with a device per context.
+    static const bool par = getenv("STRL_PARALLEL_CTX") != nullptr;
     auto make = [&](int g) {
       ctx_rc[(size_t)g] = strl_ctx_create(g % n_dev, &ctxs[(size_t)g]);
       if (ctx_rc[(size_t)g]) ctx_err[(size_t)g] = strl_last_error();
     };
     make(0);
-    if (!ctx_rc[0]) {
+    if (!ctx_rc[0] && par) {
       std::vector<std::thread> more;
       for (int g = 1; g < G; ++g) more.emplace_back(make, g);
       for (auto &t : more) t.join();
+    } else {
+      for (int g = 1; g < G && !ctx_rc[(size_t)g - 1]; ++g) make(g);
     }
     t_ctx = secs(c0, now());
   });
@@ -713,8 +718,15 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     strl_ctx *c = ctxs[g];
     if (G > 1) CHECK(strl_ctx_blocking_waits(c, 1));       // N feeding threads: waits sleep instead of spinning
     // (shares: the first context is sized for the whole file -- the other shares' per-read state is appended to its own in the end)
-    CHECK(strl_front_begin(c, n_ref, use_shares && g < cut.size() ? (cut[g] & 0xffff) : feed.first_record_offset(), use_shares && g == 0 ? reads_hint * (uint64_t)G : reads_hint));
-    CHECK(strl_front_reserve(c, (uint32_t)chunk_blocks, chunk_bytes));
+    int brc = strl_front_begin(c, n_ref, use_shares && g < cut.size() ? (cut[g] & 0xffff) : feed.first_record_offset(), use_shares && g == 0 ? reads_hint * (uint64_t)G : reads_hint);
+    if (!brc) brc = strl_front_reserve(c, (uint32_t)chunk_blocks, chunk_bytes);
+    if (brc == STRL_ERR_NOMEM) {
+      fprintf(stderr, "[strling] %s: repeating the extraction with the host pair logic\n", strl_last_error());
+      for (size_t k = 0; k < pin.size(); ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
+      for (strl_ctx *cc : ctxs) strl_ctx_destroy(cc);
+      return EXTRACT_AGAIN_ON_HOST;
+    }
+    CHECK(brc);
   }
   const double t_begin = secs(tb0, now());
 
@@ -760,7 +772,9 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     for (strl_ctx *c : ctxs) strl_ctx_destroy(c);
     return EXTRACT_AGAIN_HOST_FRONT;
   };
-  // more records than one device pass takes (2^31 - 16; the reference has no cap, extract.nim:308): the streaming host Cache
+  // more records than one device pass takes (2^31 - 16; the reference has no cap, extract.nim:308), or more than the device's
+  // memory holds the per-read state of (STRL_ERR_NOMEM: ~130 B per read): the streaming host Cache, which keeps nothing per
+  // read on the device
   auto over_limit = [&]() -> int {
     fprintf(stderr, "[strling] %s: repeating the extraction with the host pair logic\n", strl_last_error());
     if (ahead.joinable()) ahead.join();
@@ -773,7 +787,7 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   do {                                                                                       \
     const int rc__ = (call);                                                                 \
     if (rc__ == STRL_ERR_FORMAT) return give_up_front();                                     \
-    if (rc__ == STRL_ERR_LIMIT) return over_limit();                                         \
+    if (rc__ == STRL_ERR_LIMIT || rc__ == STRL_ERR_NOMEM) return over_limit();              \
     if (rc__ == STRL_ERR_CRC) quit("[strling] error reading %s: %s", bam.c_str(), strl_last_error());   \
     if (rc__ != STRL_OK) quit("[strling] %s (status %d)", strl_last_error(), rc__);          \
   } while (0)
@@ -961,10 +975,11 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
       fflush(stderr);
       _exit(0);
     }
-    bool again = false;
+    bool again = false, nomem = false;
     for (int g = 0; g < n_shares; ++g) {
       const Share &Z = shares[(size_t)g];
-      if (Z.rc == STRL_ERR_FORMAT || Z.rc == STRL_ERR_LIMIT || Z.fallback || (g + 1 < n_shares && Z.tail)) again = true;
+      if (Z.rc == STRL_ERR_NOMEM) nomem = true;
+      if (Z.rc == STRL_ERR_FORMAT || Z.rc == STRL_ERR_LIMIT || Z.rc == STRL_ERR_NOMEM || Z.fallback || (g + 1 < n_shares && Z.tail)) again = true;
       else if (Z.rc == STRL_ERR_CRC) quit("[strling] error reading %s: %s", bam.c_str(), Z.err.c_str());
       else if (Z.rc) quit("[strling] %s (status %d)", Z.err.c_str(), Z.rc);
     }
@@ -978,7 +993,7 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
       for (Share &Z : shares) Z.fd.close();
       for (size_t k = 0; k < pin.size(); ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
       for (strl_ctx *c : ctxs) strl_ctx_destroy(c);
-      return EXTRACT_AGAIN_BY_CHUNKS;
+      return nomem ? EXTRACT_AGAIN_ON_HOST : EXTRACT_AGAIN_BY_CHUNKS;      // (out of device memory: the chunk-by-chunk run would need as much)
     }
     for (int g = 0; g < n_shares; ++g)
       for (const strl_front_chunk &d : shares[(size_t)g].sums) { summary.push_back(d); have.push_back(1); chunk_owner.push_back((uint32_t)g); }
@@ -1104,12 +1119,14 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   double t_finish = 0;
   auto cap_of = [](uint64_t v) { return std::min<uint64_t>(v, 0x7ffffff0ull); };
   for (int attempt = 0; attempt < 2; ++attempt) {
-    CHECK(strl_extract_finish(ctx, n_tail, attempt ? cap_of(3 * n_seen + 16) : 0, attempt ? cap_of(8 * n_seen + 16) : 0));
+    rc = strl_extract_finish(ctx, n_tail, attempt ? cap_of(3 * n_seen + 16) : 0, attempt ? cap_of(8 * n_seen + 16) : 0);
+    if (rc == STRL_ERR_NOMEM) break;
+    CHECK(rc);
     rc = strl_treads_fetch(ctx, nullptr, 0, &nt, nullptr);
     if (rc != STRL_ERR_CAPACITY) break;
   }
   t_finish = secs(tp0, now());
-  if (rc == STRL_ERR_FORMAT) {
+  if (rc == STRL_ERR_FORMAT || rc == STRL_ERR_NOMEM) {
     fprintf(stderr, "[strling] %s: repeating the extraction with the host pair logic\n", strl_last_error());
     for (size_t k = 0; k < pin.size(); ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
     for (strl_ctx *c : ctxs) strl_ctx_destroy(c);

@@ -2,6 +2,10 @@
 // the structure-of-arrays batch + pair rows + qname hashes the scorer and the pair logic consume, with no host parsing.
 #pragma once
 #include "common.h"
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
 
 namespace strl {
 
@@ -61,7 +65,22 @@ struct FrontSlot {
   uint32_t h_uoff_cap = 0;
 };
 
+// The per-read state of a whole-genome file (80 B per read: rows, hashes, scorer words, name references, fragment words, names)
+// is tens of gigabytes of hipMalloc -- 0.15 s for 1.6e8 reads, 0.6 s for 6.5e8, in front of the first chunk.  strl_front_begin
+// allocates it for the first eighth of the hint and leaves the full-size buffers to a thread; the front end moves over to them
+// (a device copy of what is filled so far) when they are ready or when the small ones are full.
+struct FrontBigAlloc {
+  std::thread th;
+  std::atomic<int> done{0};
+  int rc = 0;
+  std::string err;
+  DevBuf rows, qhash, whole, qref, fragw, qarena;
+};
+
 struct strl_front {
+  FrontBigAlloc *big = nullptr;
+  uint64_t small_reads = 0;          // reads the synchronously allocated buffers hold
+  std::vector<DevBuf> trash;         // the small buffers after the move (kernels in flight may still read them): freed with the front end
   hipStream_t st_i[2] = {nullptr, nullptr};   // inflate + CRC of the chunk in slot 0 / 1, lowest priority: a launch fills every CU for ~17 ms; the scan,
                                      // parse and scorer kernels of the neighbouring chunks take the slots its waves give up.  Two streams: chunk k+1's inflate
                                      // needs nothing of chunk k (its partial first record comes through carry_buf, behind the inflate), so its waves take the

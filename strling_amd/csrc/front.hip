@@ -519,7 +519,10 @@ int front_reserve(strl_ctx *c, strl_front *F, uint32_t max_blocks, uint64_t max_
 
 int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, bool first, const FrontCarrySrc *carry) {
   FrontSlot &S = F->slot[si];
-  hipStream_t st = F->st_a, sti = F->st_i[si];
+  // STRL_FRONT_SERIAL (profiling): inflate, CRC and record scan of every chunk on the context's ONE stream, behind the previous
+  // chunk's parse and scorer -- no launch runs beside another, so a kernel trace attributes each kernel its own time
+  static const bool serial = getenv("STRL_FRONT_SERIAL") != nullptr;
+  hipStream_t st = serial ? c->stream : F->st_a, sti = serial ? c->stream : F->st_i[si];
   int rc;
   const uint32_t nb = d.n_blocks;
   if (S.staged && (S.staged_comp != d.comp || S.staged_bytes != d.comp_bytes || S.staged_blocks != nb)) {
@@ -639,6 +642,14 @@ int front_copy_names(strl_ctx *c, strl_front *F, const uint64_t *d_ref, const ui
 
 void front_destroy(strl_front *F) {
   if (!F) return;
+  if (F->big) {
+    if (F->big->th.joinable()) F->big->th.join();
+    for (DevBuf *b : {&F->big->rows, &F->big->qhash, &F->big->whole, &F->big->qref, &F->big->fragw, &F->big->qarena}) b->release();
+    delete F->big;
+    F->big = nullptr;
+  }
+  for (DevBuf &b : F->trash) b.release();
+  F->trash.clear();
   for (FrontSlot &S : F->slot) {
     for (DevBuf *b : {&S.comp, &S.infl, &S.coff, &S.clen, &S.uoff, &S.isize, &S.crc, &S.status, &S.seg, &S.recoff, &S.seqoff, &S.qoff, &S.info, &S.base3, &S.carry_stage}) b->release();
     if (S.ev_a) (void)hipEventDestroy(S.ev_a);

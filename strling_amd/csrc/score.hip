@@ -16,6 +16,7 @@
 #include <string.h>
 #include <sys/mman.h>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -35,34 +36,59 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+// Device memory: every buffer of the library comes from here.  A failed allocation is STRL_ERR_NOMEM with the sizes in the
+// message, not a bare HIP error; STRL_DEVICE_MEM_LIMIT_MB (tests) makes the library refuse to go past that much.
+static std::atomic<uint64_t> g_dev_bytes{0};
+static int dev_alloc(void **p, size_t want) {
+  static const uint64_t cap = getenv("STRL_DEVICE_MEM_LIMIT_MB") ? strtoull(getenv("STRL_DEVICE_MEM_LIMIT_MB"), nullptr, 10) << 20 : 0;
+  hipError_t e = hipSuccess;
+  if (cap && g_dev_bytes.load() + want > cap) e = hipErrorOutOfMemory;
+  else e = hipMalloc(p, want);
+  if (e == hipSuccess) { g_dev_bytes += want; return STRL_OK; }
+  (void)hipGetLastError();
+  size_t fr = 0, tot = 0;
+  (void)hipMemGetInfo(&fr, &tot);
+  set_error("out of device memory: %.2f GB more wanted, %.2f GB held by this process, %.2f of %.1f GB free on the device (%s)", (double)want / 1e9, (double)g_dev_bytes.load() / 1e9,
+            (double)fr / 1e9, (double)tot / 1e9, e == hipErrorOutOfMemory ? "the input's per-read state does not fit" : hipGetErrorString(e));
+  return e == hipErrorOutOfMemory ? STRL_ERR_NOMEM : STRL_ERR_HIP;
+}
+static void dev_free(void *p, size_t cap) {
+  if (!p) return;
+  (void)hipFree(p);
+  g_dev_bytes -= cap;
+}
+
 int DevBuf::reserve(size_t bytes) {
   if (bytes <= cap && p) return STRL_OK;
-  if (p) (void)hipFree(p);
+  dev_free(p, cap);
   p = nullptr;
   cap = 0;
   size_t want = bytes + bytes / 8 + 256;
-  STRL_HIP(hipMalloc(&p, want));
+  const int rc = dev_alloc(&p, want);
+  if (rc) { p = nullptr; return rc; }
   cap = want;
   return STRL_OK;
 }
 int DevBuf::grow(size_t bytes, size_t keep_bytes, hipStream_t st) {
   if (bytes <= cap && p) return STRL_OK;
   void *np = nullptr;
-  const size_t want = std::max(bytes + bytes / 8 + 256, cap * 2);
-  STRL_HIP(hipMalloc(&np, want));
+  size_t want = std::max(bytes + bytes / 8 + 256, cap * 2);
+  int rc = dev_alloc(&np, want);
+  if (rc == STRL_ERR_NOMEM && want > bytes + 256) { want = bytes + 256; rc = dev_alloc(&np, want); }     // (no room to double: exactly what is asked for)
+  if (rc) return rc;
   if (p && keep_bytes) {
     STRL_HIP(hipMemcpyAsync(np, p, std::min(keep_bytes, cap), hipMemcpyDeviceToDevice, st));
     STRL_HIP(hipStreamSynchronize(st));
   } else if (p) {
     STRL_HIP(hipStreamSynchronize(st));
   }
-  if (p) (void)hipFree(p);
+  dev_free(p, cap);
   p = np;
   cap = want;
   return STRL_OK;
 }
 void DevBuf::release() {
-  if (p) (void)hipFree(p);
+  dev_free(p, cap);
   p = nullptr;
   cap = 0;
 }
@@ -1563,14 +1589,18 @@ int strl_ctxs_extract_gather(strl_ctx **ctxs, int n, const uint32_t *chunk_owner
   return STRL_OK;
 }
 
-int strl_extract_begin(strl_ctx *c, uint64_t n_reads_hint) {
+// n_now: reads the big per-read columns are sized for right away (0: the hint); the front end passes a fraction and has the
+// rest allocated beside its first chunks (FrontBigAlloc)
+static int extract_begin_sized(strl_ctx *c, uint64_t n_reads_hint, uint64_t n_now);
+int strl_extract_begin(strl_ctx *c, uint64_t n_reads_hint) { return extract_begin_sized(c, n_reads_hint, 0); }
+static int extract_begin_sized(strl_ctx *c, uint64_t n_reads_hint, uint64_t n_now) {
   if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
   if (!c->have_opts) { set_error("strl_ctx_set_opts must be called before scoring"); return STRL_ERR_ARG; }
   STRL_HIP(hipSetDevice(c->device));
   int rc;
-  const uint64_t hint = std::max<uint64_t>(n_reads_hint, 1 << 20);
-  if ((rc = c->x_rows.grow((size_t)hint * sizeof(strl_pair_rec), 0, c->stream)) || (rc = c->x_qhash.grow((size_t)hint * 8, 0, c->stream)) ||
-      (rc = c->x_whole.grow((size_t)hint * 4, 0, c->stream)) || (rc = c->x_soft.grow((size_t)(hint / 8 + 65536) * sizeof(strl_soft_rec), 0, c->stream)) ||
+  const uint64_t hint = std::max<uint64_t>(n_reads_hint, 1 << 20), first = n_now ? std::min(n_now, hint) : hint;
+  if ((rc = c->x_rows.grow((size_t)first * sizeof(strl_pair_rec), 0, c->stream)) || (rc = c->x_qhash.grow((size_t)first * 8, 0, c->stream)) ||
+      (rc = c->x_whole.grow((size_t)first * 4, 0, c->stream)) || (rc = c->x_soft.grow((size_t)(hint / 8 + 65536) * sizeof(strl_soft_rec), 0, c->stream)) ||
       (rc = c->x_cnt.reserve(XC_WORDS * 4)))
     return rc;
   STRL_HIP(hipMemsetAsync(c->x_cnt.p, 0, XC_WORDS * 4, c->stream));
@@ -1729,6 +1759,35 @@ static int front_fill_done(strl_ctx *c, strl::FrontSlot &S, strl_front_chunk *do
   return STRL_OK;
 }
 
+// the full-size per-read buffers are there (or the small ones are full: then this waits for them): what the chunks so far have
+// filled is copied over on the context's stream -- behind every kernel that wrote it -- and the small buffers are kept until the
+// front end goes (nothing waits for them to be free)
+static int front_adopt_big(strl_ctx *c, strl::strl_front *F, uint64_t at) {
+  strl::FrontBigAlloc *B = F->big;
+  if (!B) return STRL_OK;
+  if (B->th.joinable()) B->th.join();
+  F->big = nullptr;
+  if (B->rc) {
+    set_error("%s", B->err.c_str());
+    const int rc = B->rc;
+    for (strl::DevBuf *b : {&B->rows, &B->qhash, &B->whole, &B->qref, &B->fragw, &B->qarena}) b->release();
+    delete B;
+    return rc;
+  }
+  struct Mv { strl::DevBuf *cur, *big; size_t used; };
+  const Mv mv[6] = {{&c->x_rows, &B->rows, (size_t)at * sizeof(strl_pair_rec)}, {&c->x_qhash, &B->qhash, (size_t)at * 8}, {&c->x_whole, &B->whole, (size_t)at * 4},
+                    {&F->qref, &B->qref, (size_t)at * 8}, {&F->fragw, &B->fragw, (size_t)at * 4}, {&F->qarena, &B->qarena, (size_t)F->qarena_used}};
+  for (const Mv &m : mv) {
+    if (m.big->cap <= m.cur->cap) { m.big->release(); continue; }        // (the small one grew past it meanwhile)
+    if (m.used) STRL_HIP(hipMemcpyAsync(m.big->p, m.cur->p, std::min(m.used, m.cur->cap), hipMemcpyDeviceToDevice, c->stream));
+    F->trash.push_back(*m.cur);
+    *m.cur = *m.big;
+    m.big->p = nullptr; m.big->cap = 0;
+  }
+  delete B;
+  return STRL_OK;
+}
+
 // parse + score the chunk in slot si (its record scan was enqueued earlier): waits on the HOST for the scan's counts -- the
 // next chunk's inflate is already queued behind it, so the device does not idle
 static int front_stage_b(strl_ctx *c, strl::strl_front *F, int si) {
@@ -1745,6 +1804,7 @@ static int front_stage_b(strl_ctx *c, strl::strl_front *F, int si) {
   if (I.max_l_seq > (uint32_t)STRL_MAX_READ_LEN) { set_error("a record's l_seq %u is outside [0, %d]", I.max_l_seq, STRL_MAX_READ_LEN); return STRL_ERR_ARG; }
   int rc;
   const uint64_t n1 = std::max<uint64_t>(n, 1);
+  if (F->big && (F->big->done.load(std::memory_order_acquire) || at + n1 > F->small_reads || F->qarena_used + I.qname_bytes + 16 > F->qarena.cap) && (rc = front_adopt_big(c, F, at))) return rc;
   if ((rc = c->x_rows.grow((size_t)(at + n1) * sizeof(strl_pair_rec), (size_t)at * sizeof(strl_pair_rec), c->stream)) ||
       (rc = c->x_qhash.grow((size_t)(at + n1) * 8, (size_t)at * 8, c->stream)) || (rc = c->x_whole.grow((size_t)(at + n1) * 4, (size_t)at * 4, c->stream)) ||
       (rc = F->qref.grow((size_t)(at + n1) * 8, (size_t)at * 8, c->stream)) || (rc = F->fragw.grow((size_t)(at + n1) * 4, (size_t)at * 4, c->stream)) ||
@@ -1782,7 +1842,10 @@ static int front_stage_b(strl_ctx *c, strl::strl_front *F, int si) {
 
 int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, uint64_t n_reads_hint) {
   if (!c || n_ref < 0) { set_error("bad argument"); return STRL_ERR_ARG; }
-  int rc = strl_extract_begin(c, n_reads_hint);
+  const uint64_t hint = std::max<uint64_t>(n_reads_hint, 1 << 20);
+  static const bool sync_alloc = getenv("STRL_SYNC_ALLOC") != nullptr;
+  const uint64_t small = (sync_alloc || hint <= (1ull << 25)) ? hint : std::max<uint64_t>(1ull << 24, hint / 8);
+  int rc = extract_begin_sized(c, n_reads_hint, small);
   if (rc) return rc;
   if (c->front) {
     for (hipStream_t q : c->front->st_i) if (q) (void)hipStreamSynchronize(q);
@@ -1811,9 +1874,29 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
   }
   if ((rc = F->tid_seen.reserve((size_t)n_ref + 16))) return rc;
   STRL_HIP(hipMemsetAsync(F->tid_seen.p, 0, (size_t)n_ref + 16, c->stream));
-  const uint64_t hint = std::max<uint64_t>(n_reads_hint, 1 << 20);
-  if ((rc = F->qref.grow((size_t)hint * 8, 0, c->stream)) || (rc = F->fragw.grow((size_t)hint * 4, 0, c->stream)) || (rc = F->qarena.grow((size_t)hint * 24, 0, c->stream)))
+  if ((rc = F->qref.grow((size_t)small * 8, 0, c->stream)) || (rc = F->fragw.grow((size_t)small * 4, 0, c->stream)) || (rc = F->qarena.grow((size_t)small * 24, 0, c->stream)))
     return rc;
+  F->small_reads = small;
+  if (small < hint) {        // the full-size buffers: allocated beside the first chunks (front.h, FrontBigAlloc)
+    strl::FrontBigAlloc *B = new strl::FrontBigAlloc();
+    F->big = B;
+    const int dev = c->device;
+    B->th = std::thread([B, dev, hint] {
+      auto one = [&](strl::DevBuf &b, size_t bytes) {
+        if (hipSetDevice(dev) != hipSuccess) return (int)STRL_ERR_HIP;
+        return b.reserve(bytes);
+      };
+      // (side by side: the driver takes several allocations at once)
+      int r[6] = {0, 0, 0, 0, 0, 0};
+      std::thread t1([&] { r[0] = one(B->rows, (size_t)hint * sizeof(strl_pair_rec)); });
+      std::thread t2([&] { r[1] = one(B->qarena, (size_t)hint * 24); });
+      std::thread t3([&] { r[2] = one(B->qhash, (size_t)hint * 8); r[3] = one(B->qref, (size_t)hint * 8); });
+      r[4] = one(B->whole, (size_t)hint * 4); r[5] = one(B->fragw, (size_t)hint * 4);
+      t1.join(); t2.join(); t3.join();
+      for (int x : r) if (x && !B->rc) { B->rc = x; B->err = strl_last_error(); }
+      B->done.store(1, std::memory_order_release);
+    });
+  }
   STRL_HIP(hipStreamSynchronize(c->stream));
   return STRL_OK;
 }
@@ -1937,6 +2020,7 @@ int strl_front_finish(strl_ctx *c, strl_front_chunk done[2], int *n_done) {
   const int last = (int)((F->chunks - 1) & 1);
   for (; F->b_issued < F->chunks; ++F->b_issued)
     if ((rc = front_stage_b(c, F, (int)(F->b_issued & 1)))) return rc;
+  if (F->big && (rc = front_adopt_big(c, F, c->x_n))) return rc;        // (a file shorter than its hint: the thread is joined here at the latest)
   for (int si : {last ^ 1, last}) {
     if (!F->slot[si].b_pending) continue;
     if ((rc = front_fill_done(c, F->slot[si], done ? &done[k] : nullptr))) return rc;

@@ -619,3 +619,21 @@ def test_shares_tile_the_file_at_record_starts(tmp_path, G, max_blocks):
             assert trim == 0
     first = by_off[int(rows[1][2])]
     assert first[1] + int(rows[1][3]) + total == blocks[-1][1] + blocks[-1][2]   # first record .. end of the data
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("limit_mb,hint", [("700", "10000000")])
+def test_extract_out_of_device_memory_takes_the_host_pair_logic(sample, limit_mb, hint):
+    """the per-read state of a whole input is resident on the device (~130 B per read: a 288 GB device holds ~2e9 reads); past
+    that -- simulated here with STRL_DEVICE_MEM_LIMIT_MB: 700 MB against the state of 1e7 reads (the host pair logic's own
+    batches take ~100 MB) -- the CLI says what ran out and repeats the extraction with the streaming host Cache, which keeps nothing per read
+    on the device: same .bin, no HIP error text, exit code 0"""
+    one = str(sample["dir"] / "one.bin")
+    r = _run(["extract", "-g", sample["bed"], sample["bam"], one])
+    assert r.returncode == 0, r.stderr
+    out = str(sample["dir"] / f"nomem{limit_mb}.bin")
+    env = dict(os.environ, STRL_DEVICE_MEM_LIMIT_MB=limit_mb, STRL_READS_HINT=hint, STRL_CHUNK_BLOCKS="4")
+    r = _run(["extract", "-g", sample["bed"], sample["bam"], out], env=env)
+    assert r.returncode == 0, r.stderr
+    assert "out of device memory" in r.stderr and "repeating the extraction with the host pair logic" in r.stderr, r.stderr
+    assert open(out, "rb").read() == open(one, "rb").read()

@@ -134,3 +134,48 @@ def test_front_end_checks_the_blocks_crc32(ctx, tmp_path):
     _corrupt(good, bad, "payload")
     with pytest.raises(api.StrlingError):
         ctx.extract_bam_device(bad, chunk_blocks=5)
+
+
+@pytest.mark.parametrize("n_ctx,block,chunk_blocks", [(2, 0xFF00, 16384), (3, 4099, 7), (5, 1500, 33)])
+def test_shares_through_the_abi_against_the_oracle(tmp_path, n_ctx, block, chunk_blocks):
+    """`extract --gpus N` as a host of the C ABI drives it: a contiguous share of the file per context, every share starting at a
+    record start and ending where the next begins (strl_front_trim_next / strl_front_tail_bytes), the per-read state appended on
+    the first context (strl_ctxs_extract_gather) -- the treads of the oracle over the whole file, field by field and in order;
+    cuts moved off the record starts are noticed (a share's tail is not empty, or its records are refused as malformed)"""
+    from oracle import oracle as O
+    rec, g = synth.synth_wgs(7000, seed=77 + n_ctx, contig_len=700_000)
+    med = O.median(synth.frag_hist(rec))
+    exp = O.extract(rec, g, O.make_opts(med, 0.8, 40))
+    path = str(tmp_path / "sh.bam")
+    bamio.write_bam(path, rec, level=1, block=block, index=False)
+    ctxs = [api.Context(0) for _ in range(n_ctx)]
+    try:
+        for c in ctxs:
+            c.set_opts(0.8, 40, med)
+            c.set_genome(g)
+        got, tails = api.extract_bam_shares(ctxs, path, chunk_blocks=chunk_blocks)
+        assert tails[:-1] == [0] * (n_ctx - 1) and got is not None
+        assert got["n_records"] == rec.n
+        for f in FIELDS:
+            assert np.array_equal(got["treads"][f], exp[f]), f
+        assert got["qnames"] == [rec.qname(int(i)) for i in exp["qname_id"]]
+        isz = rec.isize if rec.isize is not None else np.zeros(rec.n, np.int32)
+        fw = rec.flag.astype(np.uint32) | (np.where((isz >= 0) & (isz <= 4095), isz, 0xffff).astype(np.uint32) << 16)
+        assert np.array_equal(got["fragwords"], fw)
+    finally:
+        for c in ctxs:
+            c.close()
+    # a cut that is NOT a record start
+    ctxs = [api.Context(0) for _ in range(2)]
+    try:
+        for c in ctxs:
+            c.set_opts(0.8, 40, med)
+            c.set_genome(g)
+        try:
+            got, tails = api.extract_bam_shares(ctxs, path, chunk_blocks=chunk_blocks, cut_shift=5)
+            assert got is None and tails[0] != 0
+        except api.StrlingError as e:
+            assert "malformed BAM record" in str(e) or "more than" in str(e)
+    finally:
+        for c in ctxs:
+            c.close()
