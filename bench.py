@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-PROFILE_ROUND = "r04"     # profiles/<round>/traffic.json, pmc_counters.json: the PMC passes the roofline block quotes
+PROFILE_ROUND = "r05"     # profiles/<round>/traffic.json, pmc_counters.json: the PMC passes the roofline block quotes
 
 
 def main():

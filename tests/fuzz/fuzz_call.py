@@ -12,8 +12,10 @@ from strling_amd import bamio, build, synth
 from oracle import oracle as O
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-rng = np.random.default_rng(77)
+master = int(sys.argv[2]) if len(sys.argv) > 2 else 77
+rng = np.random.default_rng(master)
 CLI = build.CLI
+print(f"fuzz_call: master seed {master}, budget {budget:.0f} s (every case's own seed and parameters are in its assertion message; a progress line per 25 cases)", flush=True)
 
 
 def run(args):
@@ -44,7 +46,7 @@ def loci_bed(rows, targets, k0):
 
 
 t0 = time.time()
-n_call = n_merge = n_rows = n_cram = 0
+n_call = n_merge = n_rows = n_cram = n_gpus_runs = 0
 with tempfile.TemporaryDirectory() as d:
     while time.time() - t0 < budget:
         seed = int(rng.integers(1, 1 << 30))
@@ -65,13 +67,16 @@ with tempfile.TemporaryDirectory() as d:
                 refs = cramio.make_reference(rec, seed=seed)
                 cramio.write_fasta(os.path.join(d, "ref.fa"), rec.targets, refs)
                 cramio.write_cram(bam, rec, refs, records_per_slice=int(rng.choice([97, 500, 4000])), slices_per_container=int(rng.choice([1, 3])),
-                                  ap_delta=bool(rng.random() < 0.7))
+                                  ap_delta=bool(rng.random() < 0.7), version=(3, 1) if rng.random() < 0.5 else (3, 0), qualities=bool(rng.random() < 0.3),
+                                  tags=bool(rng.random() < 0.3))
                 fa_args = ["-f", os.path.join(d, "ref.fa")]
                 n_cram += 1
             else:
                 bamio.write_bam(bam, rec, block=int(rng.choice([0xFF00, 0xFF00, 3000, 700])), level=int(rng.choice([1, 6])))   # (small blocks: many per 16 KiB index window, records across block ends)
             bamio.write_genome_bed(bed, g, rec.targets)
-            run(["extract"] + fa_args + ["-g", bed, "-q", str(q), bam, binp])
+            gp = int(rng.choice([1, 1, 2, 3, 5])) if not fa_args else 1      # BAM input: also over several contexts (shares cut at the .bai's record starts)
+            run(["extract"] + fa_args + (["--gpus", str(gp)] if gp > 1 else []) + ["-g", bed, "-q", str(q), bam, binp])
+            n_gpus_runs += gp > 1
             frag = synth.frag_hist(rec)
             tr = O.extract(rec, g, O.make_opts(O.median(frag), 0.8, q))
             kwc = dict(min_support=m, min_mapq=q, min_clip=c, min_clip_total=t)
@@ -95,6 +100,8 @@ with tempfile.TemporaryDirectory() as d:
             for suf, exp in (("-bounds.txt", eb), ("-genotype.txt", eg), ("-unplaced.txt", eu)):
                 assert open(pre + suf).read() == exp, (suf, tag, extra.keys())
             n_call += 1
+            if n_call % 25 == 0:
+                print(f"  {n_call} extract->call runs, {n_merge} merges, {time.time() - t0:.0f} s, last: {tag}", flush=True)
             n_rows += eb.count("\n") - 1
         else:                            # ---- three samples -> merge ----
             bins, parts, frags, targets = [], [], [], None
@@ -125,4 +132,4 @@ with tempfile.TemporaryDirectory() as d:
             assert open(os.path.join(d, "j-bounds.txt")).read() == exp, ("merge", tag)
             n_merge += 1
             n_rows += exp.count("\n") - 1
-print(f"fuzz_call ok: {n_call} extract->call runs ({n_cram} of them from CRAM), {n_merge} merges, {n_rows} bounds rows identical to the oracle in {time.time() - t0:.0f} s")
+print(f"fuzz_call ok (master seed {master}): {n_call} extract->call runs ({n_cram} of them from CRAM 3.0 / 3.1, {n_gpus_runs} with --gpus 2 / 3 / 5), {n_merge} merges, {n_rows} bounds rows identical to the oracle in {time.time() - t0:.0f} s")

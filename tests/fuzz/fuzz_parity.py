@@ -12,8 +12,10 @@ from oracle import oracle as O
 from helpers import oracle_words, soft_items_expected, treads_equal
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+master = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
 ctx = api.Context(0)
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(master)
+print(f"fuzz_parity: master seed {master}, budget {budget:.0f} s (every case's own seed and parameters are in its assertion message; a progress line per 100 cases)", flush=True)
 t0 = time.time()
 n_cases = n_reads = n_treads = n_bounds = n_asserts = 0
 while time.time() - t0 < budget:
@@ -66,6 +68,8 @@ while time.time() - t0 < budget:
             assert np.array_equal(b[f], eb[f]), ("bounds", f, tag, mode)
         n_bounds += len(b)
     n_cases += 1
+    if n_cases % 100 == 0:
+        print(f"  {n_cases} cases, {time.time() - t0:.0f} s, last: {tag}", flush=True)
     n_reads += rec.n
     n_treads += len(exp)
-print(f"fuzz ok: {n_asserts} reference-assert cases (count >= 256), {n_cases} cases, {n_reads} reads, {n_treads} treads, {n_bounds} bounds in {time.time() - t0:.0f} s")
+print(f"fuzz ok (master seed {master}): {n_asserts} reference-assert cases (count >= 256), {n_cases} cases, {n_reads} reads, {n_treads} treads, {n_bounds} bounds in {time.time() - t0:.0f} s")
