@@ -637,3 +637,28 @@ def test_extract_out_of_device_memory_takes_the_host_pair_logic(sample, limit_mb
     assert r.returncode == 0, r.stderr
     assert "out of device memory" in r.stderr and "repeating the extraction with the host pair logic" in r.stderr, r.stderr
     assert open(out, "rb").read() == open(one, "rb").read()
+
+
+@pytest.mark.gpu
+def test_extract_gpus_without_an_index_and_on_a_tiny_file(sample, tmp_path):
+    """--gpus N where shares cannot be cut: a BAM without a .bai goes over the contexts chunk by chunk (`in turn`); a file of one
+    block has no second record start in its index worth a share -- both give the one-GPU .bin"""
+    import shutil
+    one = str(sample["dir"] / "one.bin")
+    r = _run(["extract", "-g", sample["bed"], sample["bam"], one])
+    assert r.returncode == 0, r.stderr
+    bam = str(tmp_path / "noindex.bam")
+    shutil.copy(sample["bam"], bam)
+    out = str(tmp_path / "noindex.bin")
+    r = _run(["extract", "-g", sample["bed"], "-v", "--gpus", "3", bam, out], env=dict(os.environ, STRL_CHUNK_BLOCKS="4"))
+    assert r.returncode == 0, r.stderr
+    assert "no .bai record starts to cut the file at" in r.stderr and "in turn" in r.stderr, r.stderr
+    assert open(out, "rb").read() == open(one, "rb").read()
+    rec, g = synth.synth_wgs(60, seed=3, contig_len=50_000)
+    tiny, bed = str(tmp_path / "tiny.bam"), str(tmp_path / "tiny.str")
+    bamio.write_bam(tiny, rec)
+    bamio.write_genome_bed(bed, g, rec.targets)
+    r1 = _run(["extract", "-g", bed, tiny, str(tmp_path / "t1.bin")])
+    r4 = _run(["extract", "-g", bed, "-v", "--gpus", "4", tiny, str(tmp_path / "t4.bin")])
+    assert r1.returncode == 0 and r4.returncode == 0, r4.stderr
+    assert open(str(tmp_path / "t4.bin"), "rb").read() == open(str(tmp_path / "t1.bin"), "rb").read()

@@ -57,6 +57,7 @@ def _quota():
 
 
 SETTLE_S = 0.0      # set by run(): pause in front of every timed process
+PROCESS_TIMEOUT_S = 900
 
 
 def _timed(cmd, env):
@@ -66,7 +67,10 @@ def _timed(cmd, env):
     if SETTLE_S:
         time.sleep(SETTLE_S)
     t = time.time()
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=PROCESS_TIMEOUT_S)
+    except subprocess.TimeoutExpired as e:        # (a process that hangs must not hang the bench line with it)
+        r = subprocess.CompletedProcess(cmd, 124, stdout="", stderr=f"{(e.stderr or b'').decode(errors='replace') if isinstance(e.stderr, bytes) else (e.stderr or '')}\n[e2e] killed after {PROCESS_TIMEOUT_S} s")
     return r, time.time() - t
 
 
