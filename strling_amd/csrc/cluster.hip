@@ -23,6 +23,7 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <vector>
 #include "common.h"
 #include "nim_tables.h"
@@ -827,10 +828,19 @@ static int cluster_collect(strl_ctx *c, const std::vector<std::pair<uint64_t, ui
     for (uint32_t j = 0; j < len; ++j) rep[j] = "CATG"[(code >> (2 * (len - 1 - j))) & 3u];
   };
   std::vector<uint64_t> hcodes(ents.size());
-  for (size_t q = 0; q < ents.size(); ++q) {
-    char rep[7];
-    key_unit(ents[q].key, rep);
-    hcodes[q] = nim::hash_tid_rep((int32_t)(ents[q].key >> 15) - 1, rep);
+  {   // (a whole genome has ~1e6 groups: the Nim hash of every key, on a few threads)
+    auto part = [&](size_t a, size_t b) {
+      for (size_t q = a; q < b; ++q) {
+        char rep[7];
+        key_unit(ents[q].key, rep);
+        hcodes[q] = nim::hash_tid_rep((int32_t)(ents[q].key >> 15) - 1, rep);
+      }
+    };
+    const size_t nt = ents.size() > 200000 ? 8 : 1, per = (ents.size() + nt - 1) / nt;
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < nt; ++k) th.emplace_back(part, std::min(ents.size(), k * per), std::min(ents.size(), (k + 1) * per));
+    part(0, std::min(ents.size(), per));
+    for (auto &t : th) t.join();
   }
   lap("group keys hashed");
   const std::vector<int64_t> order = nim::table_slot_order(hcodes, 8192);           // newTable(8192): call.nim:118, merge.nim:92
