@@ -1843,7 +1843,11 @@ static int front_stage_b(strl_ctx *c, strl::strl_front *F, int si) {
 int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, uint64_t n_reads_hint) {
   if (!c || n_ref < 0) { set_error("bad argument"); return STRL_ERR_ARG; }
   const uint64_t hint = std::max<uint64_t>(n_reads_hint, 1 << 20);
-  static const bool sync_alloc = getenv("STRL_SYNC_ALLOC") != nullptr;
+  // (STRL_ASYNC_ALLOC=1: the full-size buffers on a thread beside the first chunks, front.h.  Measured: 0.15 -> 0.03 s in front of
+  // the loop at 1.3e8 reads, but the loop pays for it -- at 5.4e8 reads 2.60 s against 2.41 s with everything allocated up
+  // front, wall 2.99 against 2.80 s (profiles/r05/full_size_shares.log): allocating tens of gigabytes beside running kernels
+  // slows the launches down by more than it hides.  Off by default.)
+  static const bool sync_alloc = getenv("STRL_ASYNC_ALLOC") == nullptr;
   const uint64_t small = (sync_alloc || hint <= (1ull << 25)) ? hint : std::max<uint64_t>(1ull << 24, hint / 8);
   int rc = extract_begin_sized(c, n_reads_hint, small);
   if (rc) return rc;
