@@ -14,7 +14,7 @@ LIB = os.path.join(LIBDIR, "libstrling_amd.so")
 CLI = os.path.join(LIBDIR, "strling")
 SOURCES = ["score.hip", "pair.hip", "sort.hip", "cluster.hip", "bgzf.hip", "front.hip", "comm.hip", "host_logic.cpp", "call_logic.cpp", "nim_tables.cpp"]
 CLI_SOURCES = ["cli/main.cpp", "cli/bam_reader.cpp", "cli/fast_inflate.cpp", "cli/bgzf_feed.cpp", "cli/cram_reader.cpp", "cli/cram_codecs.cpp"]
-HEADERS = ["common.h", "device_util.h", "sort.h", "inflate_wave.h", "front.h", "score_core.h", "score_tables.h", "nim_tables.h", "cli/bam_reader.h", "cli/fast_inflate.h", "cli/bgzf_feed.h", "cli/cram_reader.h", "cli/cram_codecs.h", "../../include/strling_amd.h"]
+HEADERS = ["common.h", "device_util.h", "sort.h", "inflate_wave.h", "inflate_group.h", "front.h", "score_core.h", "score_tables.h", "nim_tables.h", "cli/bam_reader.h", "cli/fast_inflate.h", "cli/bgzf_feed.h", "cli/cram_reader.h", "cli/cram_codecs.h", "../../include/strling_amd.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "device_util.h"
 #include "inflate_wave.h"
+#include "inflate_group.h"
 
 namespace strl {
 
@@ -26,10 +27,19 @@ struct InflateParams {
   uint8_t *out;
   uint32_t *err;             // [1] IW_ERR_* flags of all blocks
   uint8_t *status;           // [n] per block (may be null)
+  uint64_t out_bytes;        // bytes of `out` the blocks lie in (the grouped form bounds its stores by it; 0: not known)
+  uint8_t *work;             // the grouped form's workspace: IG_WORK_STRIDE bytes a block
+  uint64_t work_bytes;
 };
 
 #ifndef STRL_INFLATE_WAVES
 #define STRL_INFLATE_WAVES 6
+#endif
+#ifndef STRL_IG_WAVES
+#define STRL_IG_WAVES 3                    // waves per SIMD the grouped form's registers are held to (G = 8)
+#endif
+#ifndef STRL_INFLATE_GROUP_DEFAULT
+#define STRL_INFLATE_GROUP_DEFAULT 0     // which form runs when STRL_INFLATE_FORM is not set
 #endif
 // (waves per SIMD: the scalar unit bounds the kernel and half the wave-cycles are spent parked on s_waitcnt -- more waves, not fewer registers per se)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STRL_INFLATE_WAVES, 8))) void inflate_kernel(InflateParams P) {
@@ -39,6 +49,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STRL_INFLATE
   if (threadIdx.x == 0) {
     if (P.status) P.status[b] = (uint8_t)rc;
     if (rc) atomicOr(P.err, (uint32_t)rc);
+  }
+}
+
+// The grouped form (inflate_group.h): G lanes per block, 64 / G blocks per wave; one wave per workgroup, twelve workgroups per
+// CU at G = 8 (13 KB of LDS each, <= 168 registers).  32-bit offsets into the buffer descriptors: the host only launches it for
+// < 2 GiB each.
+template <int G>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 8 ? STRL_IG_WAVES : 1, 8))) void inflate_group_kernel(InflateParams P) {
+  __shared__ IgLds<G> lds[64 / G];
+  const int lane = (int)threadIdx.x, grp = lane / G, sub = lane % G;
+  const uint32_t b = blockIdx.x * (uint32_t)(64 / G) + (uint32_t)grp;
+  // (the match copies load dwords at byte offsets: their descriptor reaches three bytes past the output; every caller's buffer has >= 16 behind it)
+  const IwBuf in = iw_make_buf(P.comp, P.readable), out = iw_make_buf(P.out, P.out_bytes), out_ld = iw_make_buf(P.out, P.out_bytes + 3);
+  const IwBuf work = iw_make_buf(P.work, P.work_bytes);
+  if (b < P.n_blocks) {
+    const int rc = ig_inflate<G>(in, (uint32_t)P.coff[b], P.clen[b], out, out_ld, (uint32_t)P.uoff[b], P.isize[b], work, b * IG_WORK_STRIDE, lds[grp], sub);
+    if (sub == 0) {
+      if (P.status) P.status[b] = (uint8_t)rc;
+      if (rc) atomicOr(P.err, (uint32_t)rc);
+    }
   }
 }
 
@@ -236,12 +266,40 @@ int strl_crc_device(strl_ctx *c, const uint8_t *d_out, const uint64_t *d_uoff, c
 }
 
 // Inflate n DEFLATE streams (device arrays as in InflateParams); asynchronous on `st`.
+// Which form a launch takes: 0 = the wave form, else the lanes per block of the grouped form.
+// STRL_INFLATE_FORM = wave | group (G lanes per block, STRL_INFLATE_G = 4 | 8 | 16)
+int strl_inflate_form() {
+  static const int form_g = [] {
+    const char *f = getenv("STRL_INFLATE_FORM"), *g = getenv("STRL_INFLATE_G");
+    if (f && !strcmp(f, "wave")) return 0;
+    if (f && strcmp(f, "group")) return 0;
+    if (!f && !STRL_INFLATE_GROUP_DEFAULT) return 0;
+    const int G = g ? atoi(g) : 8;
+    return G == 4 || G == 16 ? G : 8;
+  }();
+  return form_g;
+}
+// The grouped form's workspace for n_blocks blocks (0 bytes when the wave form runs): the caller keeps it beside the launch's
+// other buffers -- one per stream that may hold a launch.
+size_t strl_inflate_work_bytes(uint32_t n_blocks) { return strl_inflate_form() ? (size_t)n_blocks * IG_WORK_STRIDE + 64 : 0; }
+
+// out_bytes: the bytes of d_out the blocks' outputs lie in; d_work / work_bytes: strl_inflate_work_bytes(n_blocks) of device
+// memory.  Without either (0 / null) the wave form, which needs neither, is launched.
 int strl_inflate_device(strl_ctx *c, const uint8_t *d_comp, uint64_t readable, const uint64_t *d_coff, const uint32_t *d_clen, const uint64_t *d_uoff,
-                        const uint32_t *d_isize, uint32_t n_blocks, uint8_t *d_out, uint32_t *d_err, uint8_t *d_status, hipStream_t st) {
+                        const uint32_t *d_isize, uint32_t n_blocks, uint8_t *d_out, uint32_t *d_err, uint8_t *d_status, hipStream_t st, uint64_t out_bytes,
+                        uint8_t *d_work, size_t work_bytes) {
   if (!n_blocks) return STRL_OK;
-  InflateParams P{d_comp, readable & ~(uint64_t)3, d_coff, d_clen, d_uoff, d_isize, n_blocks, d_out, d_err, d_status};
+  InflateParams P{d_comp, readable & ~(uint64_t)3, d_coff, d_clen, d_uoff, d_isize, n_blocks, d_out, d_err, d_status, out_bytes, d_work, work_bytes};
   static const unsigned lds_pad = getenv("STRL_INFLATE_LDS_PAD") ? (unsigned)atoi(getenv("STRL_INFLATE_LDS_PAD")) : 0u;   // (occupancy experiments: unused dynamic LDS)
-  hipLaunchKernelGGL(inflate_kernel, dim3(n_blocks), dim3(64), lds_pad, st, P);
+  const int form_g = strl_inflate_form();
+  if (form_g && out_bytes && out_bytes < 0x7ffffff0ull && readable < 0x7ffffff0ull && d_work && work_bytes >= (size_t)n_blocks * IG_WORK_STRIDE) {
+    const unsigned per = 64u / (unsigned)form_g, grid = (n_blocks + per - 1) / per;
+    if (form_g == 4) hipLaunchKernelGGL(inflate_group_kernel<4>, dim3(grid), dim3(64), lds_pad, st, P);
+    else if (form_g == 16) hipLaunchKernelGGL(inflate_group_kernel<16>, dim3(grid), dim3(64), lds_pad, st, P);
+    else hipLaunchKernelGGL(inflate_group_kernel<8>, dim3(grid), dim3(64), lds_pad, st, P);
+  } else {
+    hipLaunchKernelGGL(inflate_kernel, dim3(n_blocks), dim3(64), lds_pad, st, P);
+  }
   STRL_HIP(hipGetLastError());
   return STRL_OK;
 }
@@ -259,11 +317,11 @@ extern "C" int strl_inflate_blocks(strl_ctx *c, const uint8_t *comp, uint64_t co
     tot += isize[i];
   }
   if (tot > out_bytes) { set_error("output buffer too small: %llu needed", (unsigned long long)tot); return STRL_ERR_CAPACITY; }
-  DevBuf d_comp, d_meta, d_out;
+  DevBuf d_comp, d_meta, d_out, d_work;
   int rc;
-  const size_t meta = (size_t)n_blocks * (8 + 4 + 8 + 4) + 64;
+  const size_t meta = (size_t)n_blocks * (8 + 4 + 8 + 4) + 64, work = strl_inflate_work_bytes(n_blocks);
   const uint64_t readable = (comp_bytes + 3) & ~(uint64_t)3;
-  if ((rc = d_comp.reserve(readable + 16)) || (rc = d_meta.reserve(meta)) || (rc = d_out.reserve(tot + 16))) return rc;
+  if ((rc = d_comp.reserve(readable + 16)) || (rc = d_meta.reserve(meta)) || (rc = d_out.reserve(tot + 16)) || (work && (rc = d_work.reserve(work)))) return rc;
   uint64_t *m_coff = d_meta.as<uint64_t>(), *m_uoff = m_coff + n_blocks;
   uint32_t *m_clen = reinterpret_cast<uint32_t *>(m_uoff + n_blocks), *m_isize = m_clen + n_blocks, *m_err = m_isize + n_blocks;
   hipStream_t st = c->stream;
@@ -278,7 +336,7 @@ extern "C" int strl_inflate_blocks(strl_ctx *c, const uint8_t *comp, uint64_t co
   STRL_HIP(hipEventCreate(&e0));
   STRL_HIP(hipEventCreate(&e1));
   STRL_HIP(hipEventRecord(e0, st));
-  if ((rc = strl_inflate_device(c, d_comp.as<uint8_t>(), readable, m_coff, m_clen, m_uoff, m_isize, n_blocks, d_out.as<uint8_t>(), m_err, nullptr, st))) return rc;
+  if ((rc = strl_inflate_device(c, d_comp.as<uint8_t>(), readable, m_coff, m_clen, m_uoff, m_isize, n_blocks, d_out.as<uint8_t>(), m_err, nullptr, st, tot, d_work.as<uint8_t>(), work))) return rc;
   STRL_HIP(hipEventRecord(e1, st));
   uint32_t err = 0;
   STRL_HIP(hipMemcpyAsync(&err, m_err, 4, hipMemcpyDeviceToHost, st));
@@ -289,7 +347,7 @@ extern "C" int strl_inflate_blocks(strl_ctx *c, const uint8_t *comp, uint64_t co
   c->inflate_ms = ms;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  d_comp.release(); d_meta.release(); d_out.release();
+  d_comp.release(); d_meta.release(); d_out.release(); d_work.release();
   if (err) { set_error("device inflate: %s", (err & IW_ERR_DATA) ? "invalid DEFLATE data" : "inflated size differs from the block's ISIZE"); return STRL_ERR_FORMAT; }
   return STRL_OK;
 }
@@ -347,12 +405,13 @@ extern "C" int strl_regions_fetch(strl_ctx *c, const uint8_t *comp, uint64_t com
   uint32_t err = 0;
   Rel rel{c, slot};
   if (!slot->st) STRL_HIP(hipStreamCreateWithFlags(&slot->st, hipStreamNonBlocking));
-  DevBuf &d_comp = slot->comp, &d_meta = slot->meta, &d_u = slot->u, &d_out = slot->out, &d_rq = slot->rq;
+  DevBuf &d_comp = slot->comp, &d_meta = slot->meta, &d_u = slot->u, &d_out = slot->out, &d_rq = slot->rq, &d_work = slot->work;
   int rc;
   const uint64_t readable = (comp_bytes + 3) & ~(uint64_t)3;
   const size_t meta = (size_t)n_blocks * (8 + 8 + 4 + 4 + 4) + 64;
   const size_t rq_bytes = (size_t)n_regions * (sizeof(strl_region_req) + sizeof(RegionWalk) + 8 + 1) + 64;
-  if ((rc = d_comp.reserve(readable + 16)) || (rc = d_meta.reserve(meta)) || (rc = d_u.reserve(tot + 64)) || (rc = d_rq.reserve(rq_bytes))) return rc;
+  const size_t work = strl_inflate_work_bytes(n_blocks);
+  if ((rc = d_comp.reserve(readable + 16)) || (rc = d_meta.reserve(meta)) || (rc = d_u.reserve(tot + 64)) || (rc = d_rq.reserve(rq_bytes)) || (work && (rc = d_work.reserve(work)))) return rc;
   uint64_t *m_coff = d_meta.as<uint64_t>(), *m_uoff = m_coff + n_blocks;
   uint32_t *m_clen = reinterpret_cast<uint32_t *>(m_uoff + n_blocks), *m_isize = m_clen + n_blocks, *m_crc = m_isize + n_blocks, *m_err = m_crc + n_blocks;
   RegionWalk *d_range = d_rq.as<RegionWalk>();
@@ -369,7 +428,7 @@ extern "C" int strl_regions_fetch(strl_ctx *c, const uint8_t *comp, uint64_t com
   if (crc32) STRL_HIP(hipMemcpyAsync(m_crc, crc32, (size_t)n_blocks * 4, hipMemcpyHostToDevice, st));
   STRL_HIP(hipMemcpyAsync(d_req, req, (size_t)n_regions * sizeof(strl_region_req), hipMemcpyHostToDevice, st));
   STRL_HIP(hipMemsetAsync(m_err, 0, 4, st));
-  if ((rc = strl_inflate_device(c, d_comp.as<uint8_t>(), readable, m_coff, m_clen, m_uoff, m_isize, n_blocks, d_u.as<uint8_t>(), m_err, nullptr, st))) return rc;
+  if ((rc = strl_inflate_device(c, d_comp.as<uint8_t>(), readable, m_coff, m_clen, m_uoff, m_isize, n_blocks, d_u.as<uint8_t>(), m_err, nullptr, st, tot, d_work.as<uint8_t>(), work))) return rc;
   if (crc32 && (rc = strl_crc_device(c, d_u.as<uint8_t>(), m_uoff, m_isize, m_crc, n_blocks, nullptr, m_err, st))) return rc;
   hipLaunchKernelGGL(region_walk_kernel, dim3(n_regions), dim3(64), 0, st, d_u.as<uint8_t>(), (tot + 64) & ~(uint64_t)15, m_uoff, m_isize, d_req, n_regions, d_range, d_status);
   STRL_HIP(hipGetLastError());

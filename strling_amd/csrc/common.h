@@ -178,7 +178,7 @@ struct strl_ctx {
   strl::DevBuf crc_tab;            // tables of the BGZF CRC-32 check (bgzf.hip)
   // strl_regions_fetch (bgzf.hip): two calls of different host threads run side by side, each on its slot's stream with its
   // slot's buffers (kept between calls) -- the copies of one batch of regions pass beside the inflate of the other
-  struct RegionSlot { hipStream_t st = nullptr; strl::DevBuf comp, meta, u, out, rq; bool busy = false; };
+  struct RegionSlot { hipStream_t st = nullptr; strl::DevBuf comp, meta, u, out, rq, work; bool busy = false; };
   RegionSlot rg[2];
   std::mutex rg_mu;
   std::condition_variable rg_cv;

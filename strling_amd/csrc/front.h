@@ -46,7 +46,7 @@ struct FrontSeg {         // one FRONT_SEG-byte segment of the inflated bytes
 
 // buffers of one chunk in flight (the context keeps two)
 struct FrontSlot {
-  DevBuf comp, infl, coff, clen, uoff, isize, crc, status, seg, recoff, seqoff, qoff, info, base3, carry_stage;
+  DevBuf comp, infl, coff, clen, uoff, isize, crc, status, seg, recoff, seqoff, qoff, info, base3, carry_stage, iwork;   // (iwork: the grouped inflate's workspace)
   uint32_t n_blocks = 0, n_seg = 0;
   uint64_t infl_bytes = 0, comp_bytes = 0;
   hipEvent_t ev_carry = nullptr;  // owned (created on this context's device): recorded behind THIS slot's copy of another context's tail

@@ -23,7 +23,9 @@
 int strl_crc_device(strl_ctx *c, const uint8_t *d_out, const uint64_t *d_uoff, const uint32_t *d_isize, const uint32_t *d_crc, uint32_t n_blocks, uint8_t *d_status,
                     uint32_t *d_err, hipStream_t st);
 int strl_inflate_device(strl_ctx *c, const uint8_t *d_comp, uint64_t readable, const uint64_t *d_coff, const uint32_t *d_clen, const uint64_t *d_uoff,
-                        const uint32_t *d_isize, uint32_t n_blocks, uint8_t *d_out, uint32_t *d_err, uint8_t *d_status, hipStream_t st);
+                        const uint32_t *d_isize, uint32_t n_blocks, uint8_t *d_out, uint32_t *d_err, uint8_t *d_status, hipStream_t st, uint64_t out_bytes,
+                        uint8_t *d_work, size_t work_bytes);
+size_t strl_inflate_work_bytes(uint32_t n_blocks);
 
 namespace strl {
 
@@ -545,6 +547,8 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   if (S.recoff.cap < rec_cap * 4 && ((rc = S.recoff.reserve(want(rec_cap * 4))) || (rc = S.seqoff.reserve(want(rec_cap * 4))) || (rc = S.qoff.reserve(want(rec_cap * 4)))))
     return rc;
   if ((rc = S.info.reserve(sizeof(FrontInfo)))) return rc;
+  const size_t iwork = strl_inflate_work_bytes(nb);
+  if (S.iwork.cap < iwork && (rc = S.iwork.reserve(want(iwork)))) return rc;
   S.n_blocks = nb; S.n_seg = n_seg; S.infl_bytes = tot; S.comp_bytes = d.comp_bytes;
   if ((rc = tick(F, sti))) return rc;
   STRL_HIP(hipStreamWaitEvent(sti, S.ev_h2d, 0));
@@ -558,7 +562,7 @@ int front_stage_a(strl_ctx *c, strl_front *F, int si, const FrontChunkDesc &d, b
   if ((rc = tick(F, sti))) return rc;
   FrontInfo *info = S.info.as<FrontInfo>();
   if ((rc = strl_inflate_device(c, S.comp.as<uint8_t>(), readable, S.coff.as<uint64_t>(), S.clen.as<uint32_t>(), S.uoff.as<uint64_t>(), S.isize.as<uint32_t>(), nb,
-                                S.infl.as<uint8_t>(), &info->inflate_err, S.status.as<uint8_t>(), sti)))
+                                S.infl.as<uint8_t>(), &info->inflate_err, S.status.as<uint8_t>(), sti, end_full, S.iwork.as<uint8_t>(), iwork)))
     return rc;
   if (d.crc && (rc = strl_crc_device(c, S.infl.as<uint8_t>(), S.uoff.as<uint64_t>(), S.isize.as<uint32_t>(), S.crc.as<uint32_t>(), nb, S.status.as<uint8_t>(),
                                      &info->inflate_err, sti)))
@@ -651,7 +655,7 @@ void front_destroy(strl_front *F) {
   for (DevBuf &b : F->trash) b.release();
   F->trash.clear();
   for (FrontSlot &S : F->slot) {
-    for (DevBuf *b : {&S.comp, &S.infl, &S.coff, &S.clen, &S.uoff, &S.isize, &S.crc, &S.status, &S.seg, &S.recoff, &S.seqoff, &S.qoff, &S.info, &S.base3, &S.carry_stage}) b->release();
+    for (DevBuf *b : {&S.comp, &S.infl, &S.coff, &S.clen, &S.uoff, &S.isize, &S.crc, &S.status, &S.seg, &S.recoff, &S.seqoff, &S.qoff, &S.info, &S.base3, &S.carry_stage, &S.iwork}) b->release();
     if (S.ev_a) (void)hipEventDestroy(S.ev_a);
     if (S.ev_b) (void)hipEventDestroy(S.ev_b);
     if (S.ev_h2d) (void)hipEventDestroy(S.ev_h2d);

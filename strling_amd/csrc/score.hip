@@ -944,7 +944,7 @@ void strl_ctx_destroy(strl_ctx *c) {
   for (auto *b : bufs) b->release();
   for (auto &r : c->rg) {
     if (r.st) { (void)hipStreamSynchronize(r.st); (void)hipStreamDestroy(r.st); }
-    r.comp.release(); r.meta.release(); r.u.release(); r.out.release(); r.rq.release();
+    r.comp.release(); r.meta.release(); r.u.release(); r.out.release(); r.rq.release(); r.work.release();
   }
   for (auto &b : c->c_buf) b.release();
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);

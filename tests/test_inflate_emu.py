@@ -13,17 +13,33 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module")
-def emu():
+class _Form:
+    """one decoder form of the shim: `wave` = inflate_wave.h (a wave per stream), `group` = inflate_group.h (G lanes per stream; G = 1 here)"""
+    def __init__(self, lib, prefix):
+        self.emu_inflate = getattr(lib, prefix + "inflate")
+        self.emu_inflate_at = getattr(lib, prefix + "inflate_at")
+        self.emu_inflate.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]
+        self.emu_inflate_at.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32]
+
+
+def _lib():
     so = os.path.join(HERE, "emu", "libinflate_emu.so")
     src = os.path.join(HERE, "emu", "inflate_emu.cpp")
-    core = os.path.join(HERE, "..", "strling_amd", "csrc", "inflate_wave.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(core)):
+    cores = [os.path.join(HERE, "..", "strling_amd", "csrc", f) for f in ("inflate_wave.h", "inflate_group.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + cores):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
-    L = C.CDLL(so)
-    L.emu_inflate.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]
-    L.emu_inflate_at.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32]
-    return L
+    return C.CDLL(so)
+
+
+@pytest.fixture(scope="module", params=["wave", "group"])
+def emu(request):
+    return _Form(_lib(), "emu_" if request.param == "wave" else "emu_group_")
+
+
+def test_group_form_lds_fits_twelve_waves_per_cu():
+    """inflate_group.h's budget: a wave of eight 8-lane groups in 1/12 of a CU's 160 KB"""
+    L = _lib()
+    assert L.emu_group_lds_bytes(8) * 8 * 12 <= 160 * 1024, L.emu_group_lds_bytes(8)
 
 
 def deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, flush_every=0):

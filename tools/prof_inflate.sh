@@ -11,10 +11,12 @@ for d in ("/tmp/ibp", "/tmp/ibq"):
     for f in glob.glob(d + "/**/run_counter_collection.csv", recursive=True):
         per = defaultdict(float)
         for r in csv.DictReader(open(f)):
-            if "inflate_kernel" in r["Kernel_Name"]:
+            if "inflate_" in r["Kernel_Name"]:
                 per[(r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+        # (two inputs, three launches each: the first three dispatches are the level-1 blocks, the last three the level-6 ones)
+        disps = sorted({int(d) for d, _ in per})
         for (disp, c), v in per.items():
-            acc[c].append(v)
+            acc[("L1 " if disps.index(int(disp)) < len(disps) // 2 else "L6 ") + c].append(v)
     for c, v in sorted(acc.items()):
         print(c.ljust(24), "%.4g" % (sum(v) / len(v)))
 PY
