@@ -44,3 +44,34 @@ def test_inflate_many_blocks_and_bad_data(ctx):
         ctx.inflate_blocks(bad, [len(p) for p in plain])
     with pytest.raises(api.StrlingError):                                    # wrong ISIZE
         ctx.inflate_blocks(streams, [len(p) + (1 if i == 9 else 0) for i, p in enumerate(plain)])
+
+
+@pytest.mark.parametrize("lanes", [8, 4, 16])
+def test_grouped_form_matches_zlib(lanes):
+    """the second form of the decoder (inflate_group.h: `lanes` lanes per stream, 64 / lanes streams per wave; chosen by
+    STRL_INFLATE_FORM when the library is first used, hence a process of its own): the vectors above, the long codes and far
+    matches of the CPU suite, corrupt streams refused"""
+    import os, subprocess, sys
+    code = (
+        "import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, zlib, test_bgzf_device as T, test_inflate_emu as E\n"
+        "from strling_amd import api\n"
+        "c = api.Context(0)\n"
+        "T.test_inflate_matches_zlib_for_every_block_type(c)\n"
+        "T.test_inflate_many_blocks_and_bad_data(c)\n"
+        "rng = np.random.default_rng(11)\n"
+        "p = 0.5 ** np.arange(1, 257)\n"
+        "blocks = [bytes(rng.choice(256, 60000, p=p / p.sum()).astype(np.uint8))]\n"
+        "far = bytes(rng.integers(0, 256, 400, dtype=np.uint8))\n"
+        "blocks.append(far + bytes(32768 - 400) + far + blocks[0][:3000] + far)\n"
+        "for d in range(1, 70):\n"
+        "    u = bytes(rng.integers(0, 256, d, dtype=np.uint8))\n"
+        "    blocks.append((u * (900 // d + 2))[:900] + bytes(rng.integers(0, 256, 30, dtype=np.uint8)))\n"
+        "S = [E.deflate(b, level=l) for b in blocks for l in (1, 6, 9)]\n"
+        "P = [b for b in blocks for l in (1, 6, 9)]\n"
+        "assert c.inflate_blocks(S, [len(x) for x in P]) == P\n"
+        "print('grouped form ok', len(S))\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    env = dict(os.environ, STRL_INFLATE_FORM="group", STRL_INFLATE_G=str(lanes))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "grouped form ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
