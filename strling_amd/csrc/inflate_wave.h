@@ -26,6 +26,7 @@
 // The same source compiles for the host (STRL_EMU: the 64 lanes become loops) purely so that the CPU-only test-suite can
 // run the decoder logic against zlib; the product never runs that build.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef STRL_EMU
@@ -254,6 +255,7 @@ IW_DEV uint32_t iw_build(const IwLane<uint32_t> (&len)[ROUNDS], uint32_t *tab, u
 // A code longer than the first-level table (or an unused prefix): canonical search over the remaining lengths.  0 = invalid.
 template <int KIND> IW_DEV uint32_t iw_slow(uint64_t bb, const uint32_t *limit, const uint32_t *delta, const uint16_t *sorted, uint32_t dummy, int root) {
   const uint32_t v16 = iw_brev((uint32_t)bb) >> 16;
+#ifdef STRL_EMU
   for (int l = root + 1; l <= 15; ++l) {
     const uint32_t lim = IW_U(limit[l]);
     if (v16 < lim) {
@@ -262,6 +264,19 @@ template <int KIND> IW_DEV uint32_t iw_slow(uint64_t bb, const uint32_t *limit, 
     }
   }
   return 0u;
+#else
+  // One in twenty symbols of a level-6 BAM block comes here (tools: IG_STATS count, profiles/r05/inflate_group/README.md: 719 long
+  // literals and 159 long distance codes per block), and the walk over the lengths was an LDS round trip each, up to six in a row.
+  // Lane k takes length root + 1 + k: every limit and delta in ONE round trip, the first length whose limit holds by a ballot.
+  const int lane = (int)threadIdx.x, n = 15 - root;
+  const int idx = root + 1 + (lane < n ? lane : 0);
+  const uint32_t lim = limit[idx], del = delta[idx];
+  const uint64_t m = __ballot(lane < n && v16 < lim);
+  if (!m) return 0u;
+  const int k = __ffsll((long long)m) - 1, l = root + 1 + k;
+  const uint32_t at = (v16 >> (16 - l)) + (uint32_t)__builtin_amdgcn_readlane((int)del, k);
+  return iw_with_total(iw_entry_of<KIND>(IW_U(sorted[at < dummy ? at : dummy])), (uint32_t)l);
+#endif
 }
 
 // The compressed stream as the wave sees it: 64 dwords per lane-register, the next 64 prefetched.
@@ -417,7 +432,8 @@ struct IwOut {
 // load, so a later match that reads these bytes sees them.  bb lives in s[90:91]; s92..s95, vcc are scratch; m0 is saved and
 // restored around the loop.
 #ifdef STRL_EMU
-IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t *dist_tab, uint32_t &e, uint32_t &code, uint32_t &L, uint32_t &D) {
+IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> &llim, const IwLane<uint32_t> &ldel, uint32_t &e, uint32_t &code, uint32_t &L, uint32_t &D) {
+  const uint32_t *lit_tab = S.lit_tab, *dist_tab = S.dist_tab;
   for (;;) {
     if (br.nbits < 32u) {
       const uint32_t w = iw_readlane(br.cur, br.widx);
@@ -437,7 +453,28 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       }
       continue;
     }
-    if ((e & (3u << 8)) != IW_KIND_BASE) { code = 0; return; }       // (an entry of 0 -- not in the table -- has kind 0)
+    if (!(e & 15u)) {                                                // a code longer than the first-level table: a literal stays in the loop
+      const uint32_t v16 = iw_brev((uint32_t)br.bb) >> 16;
+      int k = 0;
+      while (k < 15 - IW_LIT_ROOT && !(v16 < llim[k])) ++k;
+      if (k < 15 - IW_LIT_ROOT) {
+        const uint32_t l = (uint32_t)(IW_LIT_ROOT + 1 + k), at = (v16 >> (16u - l)) + ldel[k], s = S.ll_sorted[at < 288u ? at : 288u];
+        if (s < 256u) {
+          br.bb >>= l;
+          br.nbits -= l;
+          iw_writelane(o.pend, o.pos & 63u, (s << 16) | IW_FAST_LIT | l);
+          ++o.pos;
+          if (!(o.pos & 63u)) {
+            o.flush();
+            if (o.pos > o.isize) { code = 7; return; }
+          }
+          continue;
+        }
+      }
+      code = 0;
+      return;
+    }
+    if ((e & (3u << 8)) != IW_KIND_BASE) { code = 0; return; }
     br.bits(e & 15u);
     L = iw_val(e) + br.bits((e >> 4) & 15u);
     if (br.nbits < 32u) {
@@ -446,8 +483,16 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       br.nbits += 32u;
       if (++br.widx == 64u) { code = 6; return; }
     }
-    const uint32_t d = dist_tab[(uint32_t)br.bb & ((1u << IW_DIST_ROOT) - 1u)];
-    if (!(d & 15u)) { code = 4; return; }
+    uint32_t d = dist_tab[(uint32_t)br.bb & ((1u << IW_DIST_ROOT) - 1u)];
+    if (!(d & 15u)) {                                                // a distance code longer than the first level: lanes 8.. of llim / ldel
+      const uint32_t v16 = iw_brev((uint32_t)br.bb) >> 16;
+      int k = 0;
+      while (k < 15 - IW_DIST_ROOT && !(v16 < llim[8 + k])) ++k;
+      if (k == 15 - IW_DIST_ROOT) { code = 4; return; }
+      const uint32_t l = (uint32_t)(IW_DIST_ROOT + 1 + k), at = (v16 >> (16u - l)) + ldel[8 + k], sym = S.d_sorted[at < 32u ? at : 32u];
+      if (sym > 29u) { code = 4; return; }
+      d = iw_with_total(iw_entry_of<IW_DISTS>(sym), l);
+    }
     br.bits(d & 15u);
     D = iw_val(d) + br.bits((d >> 4) & 15u);
     if (D < L || D > o.pos || o.pos + L > o.isize) { code = 5; return; }
@@ -466,7 +511,8 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
 #else
 #define IW_EXP_COPY "buffer_store_byte %[pdata], %[paddr], %[rsrc], 0 offen\n\t" "buffer_load_ubyte %[pdata], %[vt1], %[rsrc], 0 offen\n\t"
 #endif
-IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t *dist_tab, uint32_t &e, uint32_t &code, uint32_t &L, uint32_t &D) {
+IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> &llim, const IwLane<uint32_t> &ldel, uint32_t &e, uint32_t &code, uint32_t &L, uint32_t &D) {
+  const uint32_t *lit_tab = S.lit_tab, *dist_tab = S.dist_tab;
   uint32_t ve, vn, vt0, vt1, vt2, vD, vL, vsrc, m0save;
   const uint32_t vlit = (uint32_t)reinterpret_cast<uintptr_t>(lit_tab);     // LDS byte addresses (low half of the flat address)
   const uint32_t vdist = (uint32_t)reinterpret_cast<uintptr_t>(dist_tab);
@@ -496,9 +542,10 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       "s_waitcnt lgkmcnt(0)\n\t"
       "v_readfirstlane_b32 %[e], %[ve]\n\t"
       "s_bitcmp1_b32 %[e], 31\n\t"
-      "s_cbranch_scc0 L_iw_notlit_%=\n\t"
+      "s_cbranch_scc0 L_iw_notlit_%=\n"
       // a literal: the shift takes the code length from the entry's low six bits (a literal has no extra bits); the ENTRY goes
       // into the staging register, lane = position mod 64 (the byte is its bits 23:16: shifted down when the register is stored)
+      "L_iw_lit1_%=:\n\t"
       "s_lshr_b64 s[90:91], s[90:91], %[e]\n\t"
       "v_writelane_b32 %[pend], %[e], m0\n\t"
       "s_add_u32 m0, m0, 1\n\t"
@@ -581,7 +628,8 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       // (32 more bits, if they were needed, have come in on top: the entry being read stands) the distance code's fields
       "L_iw_have2_%=:\n\t"
       "v_add_u32_e32 %[vt2], m0, %[vL]\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_waitcnt lgkmcnt(0)\n"
+      "L_iw_have2b_%=:\n\t"
       "v_and_b32_e32 %[vn], 15, %[ve]\n\t"
       "v_bfe_u32 %[vt1], %[ve], 4, 4\n\t"
       "v_lshrrev_b32_e64 %[vt0], %[vn], s90\n\t"
@@ -674,12 +722,90 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
       // a check failed: a distance code outside the first-level table (nothing of it consumed), or a match for the caller
       "L_iw_hard_%=:\n\t"
       "v_cmp_eq_u32_e32 vcc, 0, %[vn]\n\t"
-      "s_mov_b32 %[code], 4\n\t"
-      "s_cbranch_vccnz L_iw_end_%=\n\t"
+      "s_cbranch_vccnz L_iw_longd_%=\n\t"
       "s_lshr_b64 s[90:91], s[90:91], s92\n\t"
       "s_mov_b32 %[code], 5\n\t"
       "s_branch L_iw_end_%=\n"
+      // a distance code longer than the first level (nothing of it consumed; >= 32 valid bits): lanes 8 + k of vlim / vdel hold limit and
+      // delta of length DROOT + 1 + k.  The symbol's table entry is put together here (RFC 1951 3.2.5 in closed form, like iw_entry_of)
+      // and the distance decoded from it by the code above; an invalid code (30, 31, none at all) leaves for the caller as before.
+      "L_iw_longd_%=:\n\t"
+      "s_brev_b32 s92, s90\n\t"
+      "s_lshr_b32 s92, s92, 16\n\t"
+      "v_cmp_lt_u32_e32 vcc, s92, %[vlim]\n\t"
+      "s_lshr_b32 s93, vcc_lo, 8\n\t"
+      "s_and_b32 s93, s93, 0x7f\n\t"
+      "s_cbranch_scc0 L_iw_exit4_%=\n\t"
+      "s_ff1_i32_b32 s93, s93\n\t"
+      "s_add_u32 s94, s93, 8\n\t"
+      "s_sub_u32 s95, %[ndlong], s93\n\t"
+      "v_readlane_b32 s94, %[vdel], s94\n\t"
+      "s_lshr_b32 s92, s92, s95\n\t"
+      "s_add_u32 s92, s92, s94\n\t"
+      "s_min_u32 s92, s92, 32\n\t"
+      "v_lshl_add_u32 %[vt0], s92, 1, %[vlit]\n\t"
+      "ds_read_u16 %[ve], %[vt0] offset:%[dsoff]\n\t"
+      "s_add_u32 s93, s93, %[droot1]\n\t"                          // the code's length
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_readfirstlane_b32 s92, %[ve]\n\t"                       // the distance symbol
+      "s_cmp_gt_u32 s92, 29\n\t"
+      "s_cbranch_scc1 L_iw_exit4_%=\n\t"
+      "s_add_u32 s94, s92, 1\n\t"                                 // symbols 0..3: distance 1 + s, no extra bits
+      "s_mov_b32 s95, 0\n\t"
+      "s_cmp_lt_u32 s92, 4\n\t"
+      "s_cbranch_scc1 L_iw_longd_entry_%=\n\t"
+      "s_sub_u32 s95, s92, 2\n\t"
+      "s_lshr_b32 s95, s95, 1\n\t"                                // extra bits e = (s - 2) / 2
+      "s_and_b32 s94, s92, 1\n\t"
+      "s_add_u32 s94, s94, 2\n\t"
+      "s_lshl_b32 s94, s94, s95\n\t"
+      "s_add_u32 s94, s94, 1\n"                                    // base ((2 + s % 2) << e) + 1
+      "L_iw_longd_entry_%=:\n\t"
+      "s_lshl_b32 s94, s94, 16\n\t"                               // [30:16] base | [14:10] length + extra | [9:8] kind 1 | [7:4] extra | [3:0] length
+      "s_add_u32 s92, s93, s95\n\t"
+      "s_lshl_b32 s92, s92, 10\n\t"
+      "s_lshl_b32 s95, s95, 4\n\t"
+      "s_or_b32 s94, s94, s92\n\t"
+      "s_or_b32 s94, s94, s95\n\t"
+      "s_or_b32 s94, s94, s93\n\t"
+      "s_bitset1_b32 s94, 8\n\t"
+      "v_mov_b32_e32 %[ve], s94\n\t"
+      "v_add_u32_e32 %[vt2], m0, %[vL]\n\t"
+      "s_branch L_iw_have2b_%=\n"
+      "L_iw_exit4_%=:\n\t"
+      "s_mov_b32 %[code], 4\n\t"
+      "s_branch L_iw_end_%=\n"
+      // ---- not a length code of the first level either.  A length field of 0 is a code LONGER than the first level: one symbol in
+      // twenty-five of a level-6 BAM block, nearly all of them literals (profiles/r05/inflate_group/README.md), and leaving the loop
+      // for each cost ~3 symbols' time.  Lane k of vlim / vdel holds limit and delta of length ROOT + 1 + k: one compare finds the
+      // length, one lookup the symbol; a literal joins the first literal block with an entry made up for it, anything else (a long
+      // length code, the end of the block, no code at all) leaves for the caller with nothing consumed -- as before.
       "L_iw_other_%=:\n\t"
+      "s_and_b32 s92, %[e], 15\n\t"
+      "s_cbranch_scc1 L_iw_exit0_%=\n\t"
+      "s_brev_b32 s92, s90\n\t"
+      "s_lshr_b32 s92, s92, 16\n\t"
+      "v_cmp_lt_u32_e32 vcc, s92, %[vlim]\n\t"
+      "s_and_b32 s93, vcc_lo, 0x3f\n\t"                           // (lanes 8.. are the distance code's)
+      "s_cbranch_scc0 L_iw_exit0_%=\n\t"
+      "s_ff1_i32_b32 s93, s93\n\t"
+      "s_sub_u32 s95, %[nlong], s93\n\t"
+      "v_readlane_b32 s94, %[vdel], s93\n\t"
+      "s_lshr_b32 s92, s92, s95\n\t"
+      "s_add_u32 s92, s92, s94\n\t"
+      "s_min_u32 s92, s92, 0x120\n\t"
+      "v_lshl_add_u32 %[vt0], s92, 1, %[vlit]\n\t"
+      "ds_read_u16 %[ve], %[vt0] offset:%[soff]\n\t"
+      "s_add_u32 s93, s93, %[root1]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_readfirstlane_b32 s92, %[ve]\n\t"
+      "s_cmpk_lt_u32 s92, 0x100\n\t"
+      "s_cbranch_scc0 L_iw_exit0_%=\n\t"
+      "s_lshl_b32 s92, s92, 16\n\t"
+      "s_or_b32 %[e], s92, s93\n\t"
+      "s_bitset1_b32 %[e], 31\n\t"
+      "s_branch L_iw_lit1_%=\n"
+      "L_iw_exit0_%=:\n\t"
       "s_mov_b32 %[code], 0\n"
       // the caller may read or write the output itself: nothing stays pending; position, bit count (the sentinel's place) and the
       // vector-held length and distance go back to their registers, the sentinel is taken out
@@ -698,7 +824,8 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const uint32_t *lit_tab, const uint32_t
         [pdata] "+v"(o.pdata.x), [paddr] "+v"(o.paddr.x), [e] "=&s"(e), [code] "=&s"(code), [L] "+s"(L), [D] "+s"(D), [m0save] "=&s"(m0save),
         [ve] "=&v"(ve), [vn] "=&v"(vn), [vt0] "=&v"(vt0), [vt1] "=&v"(vt1), [vt2] "=&v"(vt2), [vD] "=&v"(vD), [vL] "=&v"(vL), [vsrc] "=&v"(vsrc)
       : [cur] "v"(br.cur.x), [vlit] "v"(vlit), [vdist] "v"(vdist), [vlane] "v"(vlane), [voob] "v"(IW_OOB), [isize] "s"(o.isize), [rsrc] "s"(o.out.r),
-        [litmask] "i"((1 << IW_LIT_ROOT) - 1)
+        [litmask] "i"((1 << IW_LIT_ROOT) - 1), [vlim] "v"(llim.x), [vdel] "v"(ldel.x), [nlong] "i"(15 - IW_LIT_ROOT), [root1] "i"(IW_LIT_ROOT + 1),
+        [soff] "i"(offsetof(IwLds, ll_sorted)), [dsoff] "i"(offsetof(IwLds, d_sorted)), [ndlong] "i"(15 - IW_DIST_ROOT), [droot1] "i"(IW_DIST_ROOT + 1)
       : "s92", "s93", "s94", "s95", "vcc", "scc", "memory");   // (m0: holds the output position inside; a reserved register cannot be listed as clobbered, so it is saved and restored)
 }
 #endif
@@ -810,9 +937,20 @@ IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t
       // The symbol loop: literals and plain matches in iw_run, what it hands back here.
       uint32_t why = 0;      // IW_ERR_* when the loop ends for another reason than the end-of-block code
       uint32_t L = 0, D = 0;
+      // iw_run's long codes: lane k holds limit and delta of literal/length code length ROOT + 1 + k, lane 8 + k those of distance
+      // code length DROOT + 1 + k
+      static_assert(15 - IW_LIT_ROOT <= 8 && 15 - IW_DIST_ROOT <= 7, "lanes 0..7 and 8..14");
+      IwLane<uint32_t> llim, ldel;
+      IW_FOR_LANES {
+        const bool is_l = lane < 15 - IW_LIT_ROOT, is_d = lane >= 8 && lane < 8 + 15 - IW_DIST_ROOT;
+        const int il = is_l ? IW_LIT_ROOT + 1 + lane : 0, id = is_d ? IW_DIST_ROOT + 1 + lane - 8 : 0;
+        const uint32_t a = S.ll_limit[il], b = S.ll_delta[il], c = S.d_limit[id], d = S.d_delta[id];
+        llim[lane] = is_l ? a : is_d ? c : 0u;
+        ldel[lane] = is_l ? b : is_d ? d : 0u;
+      }
       for (;;) {
         uint32_t e, code;
-        iw_run(br, o, S.lit_tab, S.dist_tab, e, code, L, D);
+        iw_run(br, o, S, llim, ldel, e, code, L, D);
         if (code == 1u) { br.rotate(); continue; }
         if (code == 7u) { why = IW_ERR_SIZE; break; }
         if (code == 0u) {

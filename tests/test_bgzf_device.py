@@ -46,11 +46,12 @@ def test_inflate_many_blocks_and_bad_data(ctx):
         ctx.inflate_blocks(streams, [len(p) + (1 if i == 9 else 0) for i, p in enumerate(plain)])
 
 
-@pytest.mark.parametrize("lanes", [8, 4, 16])
-def test_grouped_form_matches_zlib(lanes):
-    """the second form of the decoder (inflate_group.h: `lanes` lanes per stream, 64 / lanes streams per wave; chosen by
-    STRL_INFLATE_FORM when the library is first used, hence a process of its own): the vectors above, the long codes and far
-    matches of the CPU suite, corrupt streams refused"""
+@pytest.mark.parametrize("form,lanes", [("wave", 64), ("group", 8), ("group", 4), ("group", 16)])
+def test_both_forms_long_codes_and_periodic_matches(form, lanes):
+    """both forms of the decoder -- the wave form (inflate_wave.h) and the grouped one (inflate_group.h: `lanes` lanes per stream,
+    64 / lanes streams per wave; chosen by STRL_INFLATE_FORM when the library is first used, hence a process of its own): the
+    vectors above, the 10..15-bit literal and distance codes and the periodic matches of the CPU suite (the symbol loops decode
+    long codes in line), corrupt streams refused"""
     import os, subprocess, sys
     code = (
         "import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
@@ -70,8 +71,8 @@ def test_grouped_form_matches_zlib(lanes):
         "S = [E.deflate(b, level=l) for b in blocks for l in (1, 6, 9)]\n"
         "P = [b for b in blocks for l in (1, 6, 9)]\n"
         "assert c.inflate_blocks(S, [len(x) for x in P]) == P\n"
-        "print('grouped form ok', len(S))\n"
+        "print('form ok', len(S))\n"
     ) % (os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-    env = dict(os.environ, STRL_INFLATE_FORM="group", STRL_INFLATE_G=str(lanes))
+    env = dict(os.environ, STRL_INFLATE_FORM=form, STRL_INFLATE_G=str(lanes))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "grouped form ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "form ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
