@@ -119,9 +119,12 @@ constexpr int IW_LIT_ROOT = IW_LIT_ROOT_BITS, IW_DIST_ROOT = 8, IW_CL_ROOT = 7;
 
 // Table entry (u32): [3:0] code length (0 = "not in the first-level table": canonical search / invalid), [7:4] extra bits,
 // [9:8] kind (0 literal / plain value, 1 base value of a length or distance code, 2 end of block), [14:10] code length + extra
-// bits, [15] a symbol that is part of the code but never valid, [30:16] value (<= 24577), [31] literal: the sign bit is what
+// bits, [15] a length with its extra bits resolved (IW_LEN_DONE), [30:16] value (<= 24577), [31] literal: the sign bit is what
 // the symbol loop tests.
-constexpr uint32_t IW_KIND_BASE = 1u << 8, IW_KIND_EOB = 2u << 8, IW_KIND_BAD = 1u << 15;   // (BAD: kind bits 0 -- tested before them)
+constexpr uint32_t IW_KIND_BASE = 1u << 8, IW_KIND_EOB = 2u << 8, IW_KIND_BAD = 3u << 8;
+// [15] (literal/length table, first level) a length whose extra bits are already in the value: the index held them (code + extra
+// bits <= the index bits); [7:4] is 0 and [3:0] = [14:10] = code + extra bits, so every reader of the plain format decodes it too.
+constexpr uint32_t IW_LEN_DONE = 1u << 15;
 IW_DEV uint32_t iw_with_total(uint32_t e, uint32_t l) { return e | l | ((l + ((e >> 4) & 15u)) << 10); }   // code length + the bits the symbol consumes in all
 constexpr uint32_t IW_FAST_LIT = 1u << 31;   // set in literal entries
 IW_DEV uint32_t iw_val(uint32_t e) { return (e >> 16) & 0x7fffu; }
@@ -244,7 +247,14 @@ IW_DEV uint32_t iw_build(const IwLane<uint32_t> (&len)[ROUNDS], uint32_t *tab, u
 #pragma unroll
       for (int k = ROOT; k >= 1; --k) l = v16 < lim[k] ? (uint32_t)k : l;
       const uint32_t at = l ? (v16 >> (16u - l)) + delta[l] : dummy;
-      const uint32_t e = iw_with_total(iw_entry_of<KIND>(sorted[at < dummy ? at : dummy]), l);
+      uint32_t e = iw_with_total(iw_entry_of<KIND>(sorted[at < dummy ? at : dummy]), l);
+      if (KIND == IW_LENS) {
+        // a length code whose extra bits lie inside the index: the entry names the length itself (nearly every match of a BAM
+        // block: lengths up to 34 have <= 2 extra bits behind 4..7-bit codes) -- the symbol loop then needs no field of it but two
+        const uint32_t x = (e >> 4) & 15u, done = (uint32_t)((e & (IW_FAST_LIT | (3u << 8))) == IW_KIND_BASE && l + x <= (uint32_t)ROOT);
+        const uint32_t L = iw_val(e) + ((i >> l) & ((1u << x) - 1u)), t = l + x;
+        e = done ? (L << 16) | IW_KIND_BASE | IW_LEN_DONE | (t << 10) | t : e;
+      }
       tab[i] = l ? e : 0u;
     }
   }
@@ -611,17 +621,15 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       // length and the distance are put together on the vector unit (every lane the same value), the scalar unit only shifts the bit
       // buffer by the entry's "all bits" field and forms the distance table's index; the checks of a match share one branch.
       "L_iw_notlit_%=:\n\t"
-      "s_bitcmp1_b32 %[e], 8\n\t"
-      "s_cbranch_scc0 L_iw_other_%=\n\t"
-      "v_and_b32_e32 %[vt1], 15, %[ve]\n\t"
-      "s_bfe_u32 s95, %[e], 0x5000a\n\t"
-      "v_bfe_u32 %[vt0], %[ve], 4, 4\n\t"
-      "v_lshrrev_b32_e64 %[vL], %[vt1], s90\n\t"
+      // a length whose extra bits the table's index held (IW_LEN_DONE: nearly every match): the entry's high half IS the length, its low
+      // four bits what the symbol consumes -- one vector instruction where the plain format below takes five
+      "s_bitcmp1_b32 %[e], 15\n\t"
+      "s_cbranch_scc0 L_iw_lenx_%=\n\t"
+      "v_lshrrev_b32_e32 %[vL], 16, %[ve]\n\t"
+      "s_and_b32 s95, %[e], 15\n\t"
       "s_lshr_b64 s[90:91], s[90:91], s95\n\t"
       "s_and_b32 s94, s90, 0xff\n\t"
-      "v_bfe_u32 %[vL], %[vL], 0, %[vt0]\n\t"
       "v_lshl_add_u32 %[vt0], s94, 2, %[vdist]\n\t"
-      "v_add_u32_sdwa %[vL], %[vL], %[ve] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"   // + the entry's value (its high half)
       "ds_read_b32 %[ve], %[vt0]\n\t"
       "s_cmp_eq_u32 s91, 0\n\t"
       "s_cbranch_scc1 L_iw_refill2_%=\n"
@@ -775,6 +783,24 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "L_iw_exit4_%=:\n\t"
       "s_mov_b32 %[code], 4\n\t"
       "s_branch L_iw_end_%=\n"
+      // ---- a length code of the first level in the plain format (its extra bits reach past the index): length = value + extra bits
+      "L_iw_lenx_%=:\n\t"
+      "s_bfe_u32 s92, %[e], 0x20008\n\t"
+      "s_cmp_eq_u32 s92, 1\n\t"
+      "s_cbranch_scc0 L_iw_other_%=\n\t"
+      "v_and_b32_e32 %[vt1], 15, %[ve]\n\t"
+      "s_bfe_u32 s95, %[e], 0x5000a\n\t"
+      "v_bfe_u32 %[vt0], %[ve], 4, 4\n\t"
+      "v_lshrrev_b32_e64 %[vL], %[vt1], s90\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], s95\n\t"
+      "s_and_b32 s94, s90, 0xff\n\t"
+      "v_bfe_u32 %[vL], %[vL], 0, %[vt0]\n\t"
+      "v_lshl_add_u32 %[vt0], s94, 2, %[vdist]\n\t"
+      "v_add_u32_sdwa %[vL], %[vL], %[ve] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"   // + the entry's value (its high half)
+      "ds_read_b32 %[ve], %[vt0]\n\t"
+      "s_cmp_eq_u32 s91, 0\n\t"
+      "s_cbranch_scc1 L_iw_refill2_%=\n\t"
+      "s_branch L_iw_have2_%=\n"
       // ---- not a length code of the first level either.  A length field of 0 is a code LONGER than the first level: one symbol in
       // twenty-five of a level-6 BAM block, nearly all of them literals (profiles/r05/inflate_group/README.md), and leaving the loop
       // for each cost ~3 symbols' time.  Lane k of vlim / vdel holds limit and delta of length ROOT + 1 + k: one compare finds the
@@ -958,7 +984,7 @@ IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t
             e = iw_slow<IW_LENS>(br.bb, S.ll_limit, S.ll_delta, S.ll_sorted, 288u, IW_LIT_ROOT);
             if (!e) { why = IW_ERR_DATA; break; }
           }
-          if (e & IW_KIND_BAD) { why = IW_ERR_DATA; break; }        // a length symbol that is never valid (286, 287)
+          if ((e & (3u << 8)) == IW_KIND_BAD) { why = IW_ERR_DATA; break; }   // a length symbol that is never valid (286, 287)
           br.bits(e & 15u);
           const uint32_t kind = e & (3u << 8);
           if (kind == 0u) {                                     // a literal with a code longer than the first-level table
