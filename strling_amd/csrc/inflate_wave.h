@@ -538,7 +538,69 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "v_mov_b32_e32 %[vD], %[D]\n\t"
       "v_mov_b32_e32 %[vL], %[L]\n\t"
       "v_mov_b32_e32 %[ve], 0\n\t"
-      "s_mov_b32 %[e], 0\n"
+      "s_mov_b32 %[e], 0\n\t"
+      "s_branch L_iw_loop_%=\n"
+      // (the match path sits IN FRONT of the loop's head: the position behind a copied match falls through into the next lookup, where it
+      // took a branch -- one taken branch less per match on a scalar port that is 71 % busy)
+      // ---- not a literal: a length code of the first-level table, or something for the caller.  What bounds this kernel is the
+      // scalar issue port (scalar ALU + branches + waits: one a cycle per CU, 75 % busy -- profiles/r04/inflate_pmc_window.txt): the
+      // length and the distance are put together on the vector unit (every lane the same value), the scalar unit only shifts the bit
+      // buffer by the entry's "all bits" field and forms the distance table's index; the checks of a match share one branch.
+      "L_iw_notlit_%=:\n\t"
+      // a length whose extra bits the table's index held (IW_LEN_DONE: nearly every match): the entry's high half IS the length, its low
+      // four bits what the symbol consumes -- one vector instruction where the plain format below takes five
+      "s_bitcmp1_b32 %[e], 15\n\t"
+      "s_cbranch_scc0 L_iw_lenx_%=\n\t"
+      "v_lshrrev_b32_e32 %[vL], 16, %[ve]\n\t"
+      "s_and_b32 s95, %[e], 15\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], s95\n\t"
+      "s_and_b32 s94, s90, 0xff\n\t"
+      "v_lshl_add_u32 %[vt0], s94, 2, %[vdist]\n\t"
+      "ds_read_b32 %[ve], %[vt0]\n\t"
+      "s_cmp_eq_u32 s91, 0\n\t"
+      "s_cbranch_scc1 L_iw_refill2_%=\n"
+      // (32 more bits, if they were needed, have come in on top: the entry being read stands) the distance code's fields
+      "L_iw_have2_%=:\n\t"
+      "v_add_u32_e32 %[vt2], m0, %[vL]\n\t"
+      "s_waitcnt lgkmcnt(0)\n"
+      "L_iw_have2b_%=:\n\t"
+      "v_and_b32_e32 %[vn], 15, %[ve]\n\t"
+      "v_bfe_u32 %[vt1], %[ve], 4, 4\n\t"
+      "v_lshrrev_b32_e64 %[vt0], %[vn], s90\n\t"
+      "v_bfe_u32 %[vt0], %[vt0], 0, %[vt1]\n\t"
+      "v_bfe_u32 %[vt1], %[ve], 10, 5\n\t"
+      "v_add_u32_sdwa %[vD], %[vt0], %[ve] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+      "v_readfirstlane_b32 s92, %[vt1]\n\t"
+      "v_readfirstlane_b32 s93, %[vt2]\n\t"
+      // the fast copy takes a first-level distance code (the entry of any other is 0: D = 0 < L), D >= L, D <= pos,
+      // pos + L <= isize (L >= 3 by the table): each difference wraps to a value with the sign bit when its condition fails
+      "v_sub_u32_e32 %[vsrc], m0, %[vD]\n\t"
+      "v_sub_u32_e32 %[vt0], %[vD], %[vL]\n\t"
+      "v_sub_u32_e32 %[vt2], %[isize], %[vt2]\n\t"
+      "v_or3_b32 %[vt0], %[vt0], %[vsrc], %[vt2]\n\t"
+      "s_andn2_b32 s94, m0, 63\n\t"
+      "v_add_u32_e32 %[vt1], %[vL], %[vsrc]\n\t"
+      "v_cmp_gt_i32_e32 vcc, 0, %[vt0]\n\t"
+      "s_cbranch_vccnz L_iw_hard_%=\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], s92\n\t"
+      // Staged literals lie in [W, pos), W = pos & ~63, and stay staged across matches: they are stored when the position leaves
+      // the window (flushing before every match was 3 scalar + 5 vector instructions and a store per match, in data with a match
+      // every 8.7 bytes).  A match whose source reaches into the window (pos - D + L > W) has them stored first.
+      "v_cmp_lt_u32_e32 vcc, s94, %[vt1]\n\t"
+      "s_cbranch_vccnz L_iw_flushfirst_%=\n"
+      // the first 64 bytes: store what the previous match loaded, load this match's bytes (a lane beyond L loads a byte nobody
+      // uses -- the descriptor bounds it -- and its store address is out of range)
+      "L_iw_copy_%=:\n\t"
+      "v_cmp_gt_u32_e32 vcc, %[vL], %[vlane]\n\t"
+      "v_add_u32_e32 %[vt1], %[vsrc], %[vlane]\n\t"
+      "v_add_u32_e32 %[vt0], m0, %[vlane]\n\t"
+      IW_EXP_WAIT
+      IW_EXP_COPY
+      "v_cndmask_b32_e32 %[paddr], %[voob], %[vt0], vcc\n\t"
+      "s_xor_b32 s92, s93, m0\n\t"
+      "s_cmp_gt_u32 s92, 63\n\t"
+      "s_cbranch_scc1 L_iw_cross_%=\n\t"
+      "s_mov_b32 m0, s93\n"
       // ---- next symbol: first-level literal/length lookup (the refill sits out of line).  >= 32 valid bits here; a first-level
       // code has <= 9: three literals are decoded per check (23, 14 bits left for the second and third lookup); anything that is
       // not a literal in the second or third place comes back here first
@@ -616,66 +678,6 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "s_cbranch_scc0 L_iw_have_%=\n\t"
       "s_mov_b32 %[code], 1\n\t"
       "s_branch L_iw_end_%=\n"
-      // ---- not a literal: a length code of the first-level table, or something for the caller.  What bounds this kernel is the
-      // scalar issue port (scalar ALU + branches + waits: one a cycle per CU, 75 % busy -- profiles/r04/inflate_pmc_window.txt): the
-      // length and the distance are put together on the vector unit (every lane the same value), the scalar unit only shifts the bit
-      // buffer by the entry's "all bits" field and forms the distance table's index; the checks of a match share one branch.
-      "L_iw_notlit_%=:\n\t"
-      // a length whose extra bits the table's index held (IW_LEN_DONE: nearly every match): the entry's high half IS the length, its low
-      // four bits what the symbol consumes -- one vector instruction where the plain format below takes five
-      "s_bitcmp1_b32 %[e], 15\n\t"
-      "s_cbranch_scc0 L_iw_lenx_%=\n\t"
-      "v_lshrrev_b32_e32 %[vL], 16, %[ve]\n\t"
-      "s_and_b32 s95, %[e], 15\n\t"
-      "s_lshr_b64 s[90:91], s[90:91], s95\n\t"
-      "s_and_b32 s94, s90, 0xff\n\t"
-      "v_lshl_add_u32 %[vt0], s94, 2, %[vdist]\n\t"
-      "ds_read_b32 %[ve], %[vt0]\n\t"
-      "s_cmp_eq_u32 s91, 0\n\t"
-      "s_cbranch_scc1 L_iw_refill2_%=\n"
-      // (32 more bits, if they were needed, have come in on top: the entry being read stands) the distance code's fields
-      "L_iw_have2_%=:\n\t"
-      "v_add_u32_e32 %[vt2], m0, %[vL]\n\t"
-      "s_waitcnt lgkmcnt(0)\n"
-      "L_iw_have2b_%=:\n\t"
-      "v_and_b32_e32 %[vn], 15, %[ve]\n\t"
-      "v_bfe_u32 %[vt1], %[ve], 4, 4\n\t"
-      "v_lshrrev_b32_e64 %[vt0], %[vn], s90\n\t"
-      "v_bfe_u32 %[vt0], %[vt0], 0, %[vt1]\n\t"
-      "v_bfe_u32 %[vt1], %[ve], 10, 5\n\t"
-      "v_add_u32_sdwa %[vD], %[vt0], %[ve] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
-      "v_readfirstlane_b32 s92, %[vt1]\n\t"
-      "v_readfirstlane_b32 s93, %[vt2]\n\t"
-      // the fast copy takes a first-level distance code (the entry of any other is 0: D = 0 < L), D >= L, D <= pos,
-      // pos + L <= isize (L >= 3 by the table): each difference wraps to a value with the sign bit when its condition fails
-      "v_sub_u32_e32 %[vsrc], m0, %[vD]\n\t"
-      "v_sub_u32_e32 %[vt0], %[vD], %[vL]\n\t"
-      "v_sub_u32_e32 %[vt2], %[isize], %[vt2]\n\t"
-      "v_or3_b32 %[vt0], %[vt0], %[vsrc], %[vt2]\n\t"
-      "s_andn2_b32 s94, m0, 63\n\t"
-      "v_add_u32_e32 %[vt1], %[vL], %[vsrc]\n\t"
-      "v_cmp_gt_i32_e32 vcc, 0, %[vt0]\n\t"
-      "s_cbranch_vccnz L_iw_hard_%=\n\t"
-      "s_lshr_b64 s[90:91], s[90:91], s92\n\t"
-      // Staged literals lie in [W, pos), W = pos & ~63, and stay staged across matches: they are stored when the position leaves
-      // the window (flushing before every match was 3 scalar + 5 vector instructions and a store per match, in data with a match
-      // every 8.7 bytes).  A match whose source reaches into the window (pos - D + L > W) has them stored first.
-      "v_cmp_lt_u32_e32 vcc, s94, %[vt1]\n\t"
-      "s_cbranch_vccnz L_iw_flushfirst_%=\n"
-      // the first 64 bytes: store what the previous match loaded, load this match's bytes (a lane beyond L loads a byte nobody
-      // uses -- the descriptor bounds it -- and its store address is out of range)
-      "L_iw_copy_%=:\n\t"
-      "v_cmp_gt_u32_e32 vcc, %[vL], %[vlane]\n\t"
-      "v_add_u32_e32 %[vt1], %[vsrc], %[vlane]\n\t"
-      "v_add_u32_e32 %[vt0], m0, %[vlane]\n\t"
-      IW_EXP_WAIT
-      IW_EXP_COPY
-      "v_cndmask_b32_e32 %[paddr], %[voob], %[vt0], vcc\n\t"
-      "s_xor_b32 s92, s93, m0\n\t"
-      "s_cmp_gt_u32 s92, 63\n\t"
-      "s_cbranch_scc1 L_iw_cross_%=\n\t"
-      "s_mov_b32 m0, s93\n\t"
-      "s_branch L_iw_loop_%=\n"
       // the match ends in another window: more rounds of the copy if it is longer than 64 bytes, then the literals staged in
       // this window are stored
       "L_iw_cross_%=:\n\t"
