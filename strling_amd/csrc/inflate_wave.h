@@ -614,22 +614,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "s_waitcnt lgkmcnt(0)\n\t"
       "v_readfirstlane_b32 %[e], %[ve]\n\t"
       "s_bitcmp1_b32 %[e], 31\n\t"
-      "s_cbranch_scc0 L_iw_notlit_%=\n"
-      // a literal: the shift takes the code length from the entry's low six bits (a literal has no extra bits); the ENTRY goes
-      // into the staging register, lane = position mod 64 (the byte is its bits 23:16: shifted down when the register is stored)
-      "L_iw_lit1_%=:\n\t"
-      "s_lshr_b64 s[90:91], s[90:91], %[e]\n\t"
-      "v_writelane_b32 %[pend], %[e], m0\n\t"
-      "s_add_u32 m0, m0, 1\n\t"
-      "s_and_b32 s92, m0, 63\n\t"
-      "s_cbranch_scc0 L_iw_full_%=\n\t"
-      "s_and_b32 s92, s90, %[litmask]\n\t"
-      "v_lshl_add_u32 %[vt0], s92, 2, %[vlit]\n\t"
-      "ds_read_b32 %[ve], %[vt0]\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "v_readfirstlane_b32 %[e], %[ve]\n\t"
-      "s_bitcmp1_b32 %[e], 31\n\t"
-      "s_cbranch_scc0 L_iw_loop_%=\n\t"
+      "s_cbranch_scc0 L_iw_notlit_%=\n\t"
       // a literal: the shift takes the code length from the entry's low six bits (a literal has no extra bits); the ENTRY goes
       // into the staging register, lane = position mod 64 (the byte is its bits 23:16: shifted down when the register is stored)
       "s_lshr_b64 s[90:91], s[90:91], %[e]\n\t"
@@ -646,6 +631,21 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "s_cbranch_scc0 L_iw_loop_%=\n\t"
       // a literal: the shift takes the code length from the entry's low six bits (a literal has no extra bits); the ENTRY goes
       // into the staging register, lane = position mod 64 (the byte is its bits 23:16: shifted down when the register is stored)
+      "s_lshr_b64 s[90:91], s[90:91], %[e]\n\t"
+      "v_writelane_b32 %[pend], %[e], m0\n\t"
+      "s_add_u32 m0, m0, 1\n\t"
+      "s_and_b32 s92, m0, 63\n\t"
+      "s_cbranch_scc0 L_iw_full_%=\n\t"
+      "s_and_b32 s92, s90, %[litmask]\n\t"
+      "v_lshl_add_u32 %[vt0], s92, 2, %[vlit]\n\t"
+      "ds_read_b32 %[ve], %[vt0]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_readfirstlane_b32 %[e], %[ve]\n\t"
+      "s_bitcmp1_b32 %[e], 31\n\t"
+      "s_cbranch_scc0 L_iw_loop_%=\n"
+      // a literal: the shift takes the code length from the entry's low six bits (a literal has no extra bits); the ENTRY goes
+      // into the staging register, lane = position mod 64 (the byte is its bits 23:16: shifted down when the register is stored)
+      "L_iw_lit3_%=:\n\t"
       "s_lshr_b64 s[90:91], s[90:91], %[e]\n\t"
       "v_writelane_b32 %[pend], %[e], m0\n\t"
       "s_add_u32 m0, m0, 1\n\t"
@@ -806,7 +806,8 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       // ---- not a length code of the first level either.  A length field of 0 is a code LONGER than the first level: one symbol in
       // twenty-five of a level-6 BAM block, nearly all of them literals (profiles/r05/inflate_group/README.md), and leaving the loop
       // for each cost ~3 symbols' time.  Lane k of vlim / vdel holds limit and delta of length ROOT + 1 + k: one compare finds the
-      // length, one lookup the symbol; a literal joins the first literal block with an entry made up for it, anything else (a long
+      // length, one lookup the symbol; a literal joins the LAST of the three literal blocks with an entry made up for it (the one that
+      // goes back to the refill check: up to 15 bits are gone, the next lookups' nine are no longer certain), anything else (a long
       // length code, the end of the block, no code at all) leaves for the caller with nothing consumed -- as before.
       "L_iw_other_%=:\n\t"
       "s_and_b32 s92, %[e], 15\n\t"
@@ -832,7 +833,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "s_lshl_b32 s92, s92, 16\n\t"
       "s_or_b32 %[e], s92, s93\n\t"
       "s_bitset1_b32 %[e], 31\n\t"
-      "s_branch L_iw_lit1_%=\n"
+      "s_branch L_iw_lit3_%=\n"
       "L_iw_exit0_%=:\n\t"
       "s_mov_b32 %[code], 0\n"
       // the caller may read or write the output itself: nothing stays pending; position, bit count (the sentinel's place) and the

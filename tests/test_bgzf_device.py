@@ -70,6 +70,9 @@ def test_both_forms_long_codes_and_periodic_matches(form, lanes):
         "    blocks.append((u * (900 // d + 2))[:900] + bytes(rng.integers(0, 256, 30, dtype=np.uint8)))\n"
         "S = [E.deflate(b, level=l) for b in blocks for l in (1, 6, 9)]\n"
         "P = [b for b in blocks for l in (1, 6, 9)]\n"
+        "for k in range(40):\n"
+        "    b = E.long_then_short_literals(rng)\n"
+        "    S.append(E.deflate(b, level=6, strategy=zlib.Z_HUFFMAN_ONLY)); P.append(b)\n"
         "assert c.inflate_blocks(S, [len(x) for x in P]) == P\n"
         "print('form ok', len(S))\n"
     ) % (os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

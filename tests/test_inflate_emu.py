@@ -122,6 +122,34 @@ def test_inflate_core_long_codes_and_far_matches(emu):
             assert emu.emu_inflate(s, len(s), out, len(data)) == 0 and out.raw[:len(data)] == data, (len(data), lvl)
 
 
+def long_then_short_literals(rng, n=65000):
+    """bytes whose Huffman code has a chain of 10..15-bit literals (eighteen values occurring once, twice, four times, ...) beside 9-bit ones
+    (216 values, ~150 times each) and 4-bit ones; every rare value stands in front of 9-bit ones.  Compressed with
+    Z_HUFFMAN_ONLY every symbol is a literal: the bit budget of a decoder that looks several literals up per refill check
+    (15 + 9 bits gone, the third lookup's nine no longer there)"""
+    vals = rng.permutation(256).astype(np.uint8)
+    tail = [1] * 8 + [2] * 4 + [4] * 2 + [8, 16, 32, 64]           # (the eight singletons end up seven levels below the 9-bit values: 15 bits)
+    counts = [(n - 216 * 150 - sum(tail)) // 8] * 8 + [150] * 216 + tail
+    counts[0] += n - sum(counts)
+    data = np.repeat(vals[:len(counts)], counts)
+    rng.shuffle(data)
+    mid = vals[8:224]
+    for t in np.nonzero(np.isin(data, vals[224:224 + len(tail)]))[0]:
+        if t + 3 < n:
+            data[t + 1:t + 3] = rng.choice(mid, 2)
+    return bytes(data)
+
+
+def test_inflate_core_long_literal_then_short_ones(emu):
+    rng = np.random.default_rng(15)
+    for k in range(6):
+        data = long_then_short_literals(rng)
+        for kw in (dict(level=6, strategy=zlib.Z_HUFFMAN_ONLY), dict(level=6), dict(level=1)):
+            s = deflate(data, **kw)
+            out = C.create_string_buffer(len(data) + 1)
+            assert emu.emu_inflate(s, len(s), out, len(data)) == 0 and out.raw[:len(data)] == data, (k, kw)
+
+
 def _zlib_ok(stream, n):
     try:
         d = zlib.decompressobj(-15)
