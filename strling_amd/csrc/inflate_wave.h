@@ -539,6 +539,8 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "v_mov_b32_e32 %[vL], %[L]\n\t"
       "v_mov_b32_e32 %[ve], 0\n\t"
       "s_mov_b32 %[e], 0\n\t"
+      "s_mov_b32 s97, 1\n\t"
+      "s_sub_u32 %[wi], %[wi], 64\n\t"
       "s_branch L_iw_loop_%=\n"
       // (the match path sits IN FRONT of the loop's head: the position behind a copied match falls through into the next lookup, where it
       // took a branch -- one taken branch less per match on a scalar port that is 71 % busy)
@@ -667,14 +669,12 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       // ---- 32 more bits into the buffer (every fourth symbol or so): the sentinel's position is the bit count
       "L_iw_refill_%=:\n\t"
       "s_flbit_i32_b32 s94, s90\n\t"
-      "v_readlane_b32 s92, %[cur], %[wi]\n\t"
+      "v_readlane_b32 s96, %[cur], %[wi]\n\t"                   // (the lane select is the register's low six bits: wi counts -64 .. -1)
       "s_sub_u32 s94, 31, s94\n\t"
-      "s_mov_b32 s93, 1\n\t"
       "s_bitset0_b32 s90, s94\n\t"
-      "s_lshl_b64 s[92:93], s[92:93], s94\n\t"
-      "s_add_u32 %[wi], %[wi], 1\n\t"
+      "s_lshl_b64 s[92:93], s[96:97], s94\n\t"                    // s97 = 1 throughout: the new sentinel
       "s_or_b64 s[90:91], s[90:91], s[92:93]\n\t"
-      "s_cmp_eq_u32 %[wi], 64\n\t"
+      "s_add_u32 %[wi], %[wi], 1\n\t"                           // carries when the window's 64th dword has gone in
       "s_cbranch_scc0 L_iw_have_%=\n\t"
       "s_mov_b32 %[code], 1\n\t"
       "s_branch L_iw_end_%=\n"
@@ -717,14 +717,12 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       // ---- rarer paths
       "L_iw_refill2_%=:\n\t"
       "s_flbit_i32_b32 s94, s90\n\t"
-      "v_readlane_b32 s92, %[cur], %[wi]\n\t"
+      "v_readlane_b32 s96, %[cur], %[wi]\n\t"                   // (the lane select is the register's low six bits: wi counts -64 .. -1)
       "s_sub_u32 s94, 31, s94\n\t"
-      "s_mov_b32 s93, 1\n\t"
       "s_bitset0_b32 s90, s94\n\t"
-      "s_lshl_b64 s[92:93], s[92:93], s94\n\t"
-      "s_add_u32 %[wi], %[wi], 1\n\t"
+      "s_lshl_b64 s[92:93], s[96:97], s94\n\t"                    // s97 = 1 throughout: the new sentinel
       "s_or_b64 s[90:91], s[90:91], s[92:93]\n\t"
-      "s_cmp_eq_u32 %[wi], 64\n\t"
+      "s_add_u32 %[wi], %[wi], 1\n\t"                           // carries when the window's 64th dword has gone in
       "s_cbranch_scc0 L_iw_have2_%=\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
       "s_mov_b32 %[code], 6\n\t"
@@ -839,6 +837,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       // the caller may read or write the output itself: nothing stays pending; position, bit count (the sentinel's place) and the
       // vector-held length and distance go back to their registers, the sentinel is taken out
       "L_iw_end_%=:\n\t"
+      "s_add_u32 %[wi], %[wi], 64\n\t"
       "s_waitcnt vmcnt(0)\n\t"
       "buffer_store_byte %[pdata], %[paddr], %[rsrc], 0 offen\n\t"
       "v_mov_b32_e32 %[paddr], %[voob]\n\t"
@@ -855,7 +854,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       : [cur] "v"(br.cur.x), [vlit] "v"(vlit), [vdist] "v"(vdist), [vlane] "v"(vlane), [voob] "v"(IW_OOB), [isize] "s"(o.isize), [rsrc] "s"(o.out.r),
         [litmask] "i"((1 << IW_LIT_ROOT) - 1), [vlim] "v"(llim.x), [vdel] "v"(ldel.x), [nlong] "i"(15 - IW_LIT_ROOT), [root1] "i"(IW_LIT_ROOT + 1),
         [soff] "i"(offsetof(IwLds, ll_sorted)), [dsoff] "i"(offsetof(IwLds, d_sorted)), [ndlong] "i"(15 - IW_DIST_ROOT), [droot1] "i"(IW_DIST_ROOT + 1)
-      : "s92", "s93", "s94", "s95", "vcc", "scc", "memory");   // (m0: holds the output position inside; a reserved register cannot be listed as clobbered, so it is saved and restored)
+      : "s92", "s93", "s94", "s95", "s96", "s97", "vcc", "scc", "memory");   // (m0: holds the output position inside; a reserved register cannot be listed as clobbered, so it is saved and restored)
 }
 #endif
 
