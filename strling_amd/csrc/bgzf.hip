@@ -43,7 +43,9 @@ struct InflateParams {
 #endif
 // (waves per SIMD: the scalar unit bounds the kernel and half the wave-cycles are spent parked on s_waitcnt -- more waves, not fewer registers per se)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STRL_INFLATE_WAVES, 8))) void inflate_kernel(InflateParams P) {
-  __shared__ IwLds lds;
+  // (iw_run forms a table entry's address by a bit-field insert into the table's own address: the tables sit on multiples of their size)
+  __shared__ __attribute__((aligned(4u << IW_LIT_ROOT))) IwLds lds;
+  static_assert(offsetof(IwLds, lit_tab) == 0 && offsetof(IwLds, dist_tab) % (4u << IW_DIST_ROOT) == 0, "table alignment");
   const uint32_t b = blockIdx.x;
   const int rc = iw_inflate(P.comp, P.coff[b], P.clen[b], P.readable, P.out + P.uoff[b], P.isize[b], lds);
   if (threadIdx.x == 0) {

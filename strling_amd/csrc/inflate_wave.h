@@ -313,8 +313,8 @@ struct IwBits {
     bb >>= 8u * skip;
     nbits -= 8u * skip;
   }
-  IW_DEV void refill() {            // afterwards 32 <= nbits <= 63 (iw_run keeps a sentinel bit above the valid ones)
-    if (nbits < 32u) {
+  IW_DEV void refill() {            // afterwards 30 <= nbits <= 61 (iw_run keeps the buffer two bits up and a sentinel bit above the valid ones)
+    if (nbits < 30u) {
       const uint32_t w = iw_readlane(cur, widx);
       bb |= (uint64_t)w << nbits;
       nbits += 32u;
@@ -528,13 +528,17 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
   const uint32_t vdist = (uint32_t)reinterpret_cast<uintptr_t>(dist_tab);
   const uint32_t vlane = threadIdx.x;
   asm volatile(
-      // the bit buffer carries a sentinel bit above its valid bits (nbits <= 63): "fewer than 32 valid bits" is "high word zero"
+      // the bit buffer carries a sentinel bit above its valid bits and sits TWO BITS UP inside the loop (nbits <= 61 on entry): "high
+      // word zero" is "fewer than 30 valid bits", and the low word's bits [10:2] / [9:2] ARE a table entry's byte offset -- one v_bfi
+      // into the table's address (the tables sit on multiples of their size) where a scalar AND and a vector shift-add stood: one
+      // scalar instruction less per lookup, on the port that binds
       "s_mov_b32 s94, 1\n\t"
       "s_mov_b32 s95, 0\n\t"
       "s_lshl_b64 s[94:95], s[94:95], %[nb]\n\t"
       "s_mov_b32 %[m0save], m0\n\t"
       "s_mov_b32 m0, %[pos]\n\t"
       "s_or_b64 s[90:91], s[90:91], s[94:95]\n\t"
+      "s_lshl_b64 s[90:91], s[90:91], 2\n\t"                      // (inside the loop the buffer sits two bits up: see the lookups)
       "v_mov_b32_e32 %[vD], %[D]\n\t"
       "v_mov_b32_e32 %[vL], %[L]\n\t"
       "v_mov_b32_e32 %[ve], 0\n\t"
@@ -556,8 +560,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "v_lshrrev_b32_e32 %[vL], 16, %[ve]\n\t"
       "s_and_b32 s95, %[e], 15\n\t"
       "s_lshr_b64 s[90:91], s[90:91], s95\n\t"
-      "s_and_b32 s94, s90, 0xff\n\t"
-      "v_lshl_add_u32 %[vt0], s94, 2, %[vdist]\n\t"
+      "v_bfi_b32 %[vt0], %[vmdist], s90, %[vdist]\n\t"
       "ds_read_b32 %[ve], %[vt0]\n\t"
       "s_cmp_eq_u32 s91, 0\n\t"
       "s_cbranch_scc1 L_iw_refill2_%=\n"
@@ -569,7 +572,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "v_and_b32_e32 %[vn], 15, %[ve]\n\t"
       "v_bfe_u32 %[vt1], %[ve], 4, 4\n\t"
       "v_lshrrev_b32_e64 %[vt0], %[vn], s90\n\t"
-      "v_bfe_u32 %[vt0], %[vt0], 0, %[vt1]\n\t"
+      "v_bfe_u32 %[vt0], %[vt0], 2, %[vt1]\n\t"
       "v_bfe_u32 %[vt1], %[ve], 10, 5\n\t"
       "v_add_u32_sdwa %[vD], %[vt0], %[ve] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
       "v_readfirstlane_b32 s92, %[vt1]\n\t"
@@ -603,15 +606,14 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "s_cmp_gt_u32 s92, 63\n\t"
       "s_cbranch_scc1 L_iw_cross_%=\n\t"
       "s_mov_b32 m0, s93\n"
-      // ---- next symbol: first-level literal/length lookup (the refill sits out of line).  >= 32 valid bits here; a first-level
-      // code has <= 9: three literals are decoded per check (23, 14 bits left for the second and third lookup); anything that is
+      // ---- next symbol: first-level literal/length lookup (the refill sits out of line).  >= 30 valid bits here; a first-level
+      // code has <= 9: three literals are decoded per check (21, 12 bits left for the second and third lookup); anything that is
       // not a literal in the second or third place comes back here first
       "L_iw_loop_%=:\n\t"
       "s_cmp_eq_u32 s91, 0\n\t"
       "s_cbranch_scc1 L_iw_refill_%=\n"
       "L_iw_have_%=:\n\t"
-      "s_and_b32 s92, s90, %[litmask]\n\t"
-      "v_lshl_add_u32 %[vt0], s92, 2, %[vlit]\n\t"
+      "v_bfi_b32 %[vt0], %[vmlit], s90, %[vlit]\n\t"
       "ds_read_b32 %[ve], %[vt0]\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
       "v_readfirstlane_b32 %[e], %[ve]\n\t"
@@ -624,8 +626,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "s_add_u32 m0, m0, 1\n\t"
       "s_and_b32 s92, m0, 63\n\t"
       "s_cbranch_scc0 L_iw_full_%=\n\t"
-      "s_and_b32 s92, s90, %[litmask]\n\t"
-      "v_lshl_add_u32 %[vt0], s92, 2, %[vlit]\n\t"
+      "v_bfi_b32 %[vt0], %[vmlit], s90, %[vlit]\n\t"
       "ds_read_b32 %[ve], %[vt0]\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
       "v_readfirstlane_b32 %[e], %[ve]\n\t"
@@ -638,8 +639,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "s_add_u32 m0, m0, 1\n\t"
       "s_and_b32 s92, m0, 63\n\t"
       "s_cbranch_scc0 L_iw_full_%=\n\t"
-      "s_and_b32 s92, s90, %[litmask]\n\t"
-      "v_lshl_add_u32 %[vt0], s92, 2, %[vlit]\n\t"
+      "v_bfi_b32 %[vt0], %[vmlit], s90, %[vlit]\n\t"
       "ds_read_b32 %[ve], %[vt0]\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
       "v_readfirstlane_b32 %[e], %[ve]\n\t"
@@ -738,7 +738,8 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       // delta of length DROOT + 1 + k.  The symbol's table entry is put together here (RFC 1951 3.2.5 in closed form, like iw_entry_of)
       // and the distance decoded from it by the code above; an invalid code (30, 31, none at all) leaves for the caller as before.
       "L_iw_longd_%=:\n\t"
-      "s_brev_b32 s92, s90\n\t"
+      "s_lshr_b32 s92, s90, 2\n\t"
+      "s_brev_b32 s92, s92\n\t"
       "s_lshr_b32 s92, s92, 16\n\t"
       "v_cmp_lt_u32_e32 vcc, s92, %[vlim]\n\t"
       "s_lshr_b32 s93, vcc_lo, 8\n\t"
@@ -793,9 +794,8 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "v_bfe_u32 %[vt0], %[ve], 4, 4\n\t"
       "v_lshrrev_b32_e64 %[vL], %[vt1], s90\n\t"
       "s_lshr_b64 s[90:91], s[90:91], s95\n\t"
-      "s_and_b32 s94, s90, 0xff\n\t"
-      "v_bfe_u32 %[vL], %[vL], 0, %[vt0]\n\t"
-      "v_lshl_add_u32 %[vt0], s94, 2, %[vdist]\n\t"
+      "v_bfe_u32 %[vL], %[vL], 2, %[vt0]\n\t"
+      "v_bfi_b32 %[vt0], %[vmdist], s90, %[vdist]\n\t"
       "v_add_u32_sdwa %[vL], %[vL], %[ve] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"   // + the entry's value (its high half)
       "ds_read_b32 %[ve], %[vt0]\n\t"
       "s_cmp_eq_u32 s91, 0\n\t"
@@ -810,7 +810,8 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "L_iw_other_%=:\n\t"
       "s_and_b32 s92, %[e], 15\n\t"
       "s_cbranch_scc1 L_iw_exit0_%=\n\t"
-      "s_brev_b32 s92, s90\n\t"
+      "s_lshr_b32 s92, s90, 2\n\t"
+      "s_brev_b32 s92, s92\n\t"
       "s_lshr_b32 s92, s92, 16\n\t"
       "v_cmp_lt_u32_e32 vcc, s92, %[vlim]\n\t"
       "s_and_b32 s93, vcc_lo, 0x3f\n\t"                           // (lanes 8.. are the distance code's)
@@ -841,6 +842,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "s_waitcnt vmcnt(0)\n\t"
       "buffer_store_byte %[pdata], %[paddr], %[rsrc], 0 offen\n\t"
       "v_mov_b32_e32 %[paddr], %[voob]\n\t"
+      "s_lshr_b64 s[90:91], s[90:91], 2\n\t"
       "s_flbit_i32_b64 s92, s[90:91]\n\t"
       "s_mov_b32 %[pos], m0\n\t"
       "s_mov_b32 m0, %[m0save]\n\t"
@@ -852,7 +854,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
         [pdata] "+v"(o.pdata.x), [paddr] "+v"(o.paddr.x), [e] "=&s"(e), [code] "=&s"(code), [L] "+s"(L), [D] "+s"(D), [m0save] "=&s"(m0save),
         [ve] "=&v"(ve), [vn] "=&v"(vn), [vt0] "=&v"(vt0), [vt1] "=&v"(vt1), [vt2] "=&v"(vt2), [vD] "=&v"(vD), [vL] "=&v"(vL), [vsrc] "=&v"(vsrc)
       : [cur] "v"(br.cur.x), [vlit] "v"(vlit), [vdist] "v"(vdist), [vlane] "v"(vlane), [voob] "v"(IW_OOB), [isize] "s"(o.isize), [rsrc] "s"(o.out.r),
-        [litmask] "i"((1 << IW_LIT_ROOT) - 1), [vlim] "v"(llim.x), [vdel] "v"(ldel.x), [nlong] "i"(15 - IW_LIT_ROOT), [root1] "i"(IW_LIT_ROOT + 1),
+        [vmlit] "v"(((1u << IW_LIT_ROOT) - 1u) << 2), [vmdist] "v"(((1u << IW_DIST_ROOT) - 1u) << 2), [vlim] "v"(llim.x), [vdel] "v"(ldel.x), [nlong] "i"(15 - IW_LIT_ROOT), [root1] "i"(IW_LIT_ROOT + 1),
         [soff] "i"(offsetof(IwLds, ll_sorted)), [dsoff] "i"(offsetof(IwLds, d_sorted)), [ndlong] "i"(15 - IW_DIST_ROOT), [droot1] "i"(IW_DIST_ROOT + 1)
       : "s92", "s93", "s94", "s95", "s96", "s97", "vcc", "scc", "memory");   // (m0: holds the output position inside; a reserved register cannot be listed as clobbered, so it is saved and restored)
 }
