@@ -556,7 +556,8 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       // a length whose extra bits the table's index held (IW_LEN_DONE: nearly every match): the entry's high half IS the length, its low
       // four bits what the symbol consumes -- one vector instruction where the plain format below takes five
       "s_bitcmp1_b32 %[e], 15\n\t"
-      "s_cbranch_scc0 L_iw_lenx_%=\n\t"
+      "s_cbranch_scc0 L_iw_lenx_%=\n"
+      "L_iw_lendone_%=:\n\t"
       "v_lshrrev_b32_e32 %[vL], 16, %[ve]\n\t"
       "s_and_b32 s95, %[e], 15\n\t"
       "s_lshr_b64 s[90:91], s[90:91], s95\n\t"
@@ -607,8 +608,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "s_cbranch_scc1 L_iw_cross_%=\n\t"
       "s_mov_b32 m0, s93\n"
       // ---- next symbol: first-level literal/length lookup (the refill sits out of line).  >= 30 valid bits here; a first-level
-      // code has <= 9: three literals are decoded per check (21, 12 bits left for the second and third lookup); anything that is
-      // not a literal in the second or third place comes back here first
+      // code has <= 9: three literals are decoded per check (21, 12 bits left for the second and third lookup)
       "L_iw_loop_%=:\n\t"
       "s_cmp_eq_u32 s91, 0\n\t"
       "s_cbranch_scc1 L_iw_refill_%=\n"
@@ -631,7 +631,7 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "s_waitcnt lgkmcnt(0)\n\t"
       "v_readfirstlane_b32 %[e], %[ve]\n\t"
       "s_bitcmp1_b32 %[e], 31\n\t"
-      "s_cbranch_scc0 L_iw_loop_%=\n\t"
+      "s_cbranch_scc0 L_iw_second_%=\n\t"
       // a literal: the shift takes the code length from the entry's low six bits (a literal has no extra bits); the ENTRY goes
       // into the staging register, lane = position mod 64 (the byte is its bits 23:16: shifted down when the register is stored)
       "s_lshr_b64 s[90:91], s[90:91], %[e]\n\t"
@@ -666,6 +666,13 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "s_cbranch_scc0 L_iw_loop_%=\n\t"
       "s_mov_b32 %[code], 7\n\t"
       "s_branch L_iw_end_%=\n"
+      // a length with resolved extra bits in the SECOND place goes straight on with the entry in hand: >= 21 valid bits were there, <= 9 go,
+      // and the distance table's index -- formed in front of the refill check -- needs 8 of the 12 left.  (Not from the third place:
+      // 12 - 9 bits are not an index.)  A match behind one literal, the commonest sequence of a BAM block, no longer pays a second lookup.
+      "L_iw_second_%=:\n\t"
+      "s_bitcmp1_b32 %[e], 15\n\t"
+      "s_cbranch_scc1 L_iw_lendone_%=\n\t"
+      "s_branch L_iw_loop_%=\n"
       // ---- 32 more bits into the buffer (every fourth symbol or so): the sentinel's position is the bit count
       "L_iw_refill_%=:\n\t"
       "s_flbit_i32_b32 s94, s90\n\t"
