@@ -574,16 +574,17 @@ IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> 
       "v_bfe_u32 %[vt1], %[ve], 4, 4\n\t"
       "v_lshrrev_b32_e64 %[vt0], %[vn], s90\n\t"
       "v_bfe_u32 %[vt0], %[vt0], 2, %[vt1]\n\t"
-      "v_bfe_u32 %[vt1], %[ve], 10, 5\n\t"
       "v_add_u32_sdwa %[vD], %[vt0], %[ve] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
-      "v_readfirstlane_b32 s92, %[vt1]\n\t"
+      "v_readfirstlane_b32 s92, %[ve]\n\t"
       "v_readfirstlane_b32 s93, %[vt2]\n\t"
-      // the fast copy takes a first-level distance code (the entry of any other is 0: D = 0 < L), D >= L, D <= pos,
-      // pos + L <= isize (L >= 3 by the table): each difference wraps to a value with the sign bit when its condition fails
+      "s_bfe_u32 s92, s92, 0x5000a\n\t"                           // the bits the distance takes in all (on the scalar unit: the vector one is the busier now)
+      // the fast copy takes a first-level distance code (the entry of any other is 0: D = 0 < L), D >= L, D <= pos: each
+      // difference wraps to a value with the sign bit when its condition fails.  (pos + L <= isize is NOT checked here any more:
+      // the block's descriptor drops every store behind isize, the flush of a window and the end of the stream compare the
+      // position with isize -- a stream that is too long is refused a little later, and a vector instruction per match is gone)
       "v_sub_u32_e32 %[vsrc], m0, %[vD]\n\t"
       "v_sub_u32_e32 %[vt0], %[vD], %[vL]\n\t"
-      "v_sub_u32_e32 %[vt2], %[isize], %[vt2]\n\t"
-      "v_or3_b32 %[vt0], %[vt0], %[vsrc], %[vt2]\n\t"
+      "v_or_b32_e32 %[vt0], %[vt0], %[vsrc]\n\t"
       "s_andn2_b32 s94, m0, 63\n\t"
       "v_add_u32_e32 %[vt1], %[vL], %[vsrc]\n\t"
       "v_cmp_gt_i32_e32 vcc, 0, %[vt0]\n\t"
