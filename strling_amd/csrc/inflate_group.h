@@ -10,22 +10,23 @@
 //     values (replicated, so no cross-lane traffic at all: the state is plain per-thread registers, the code plain per-thread
 //     C++ without a line of assembly); they differ only in which byte of a match they copy, which symbols of a code-length
 //     list they sort and which table entries they fill.  One vector instruction now advances eight streams.
-//   * what made "a stream per lane" impossible was LDS: here a stream has 2.4 KB (16-bit first-level literal/length entries with
-//     the length's extra bits resolved where code + extra bits fit the 9 index bits; 7-bit distance table; the canonical
-//     search's arrays for longer codes; a 64-byte input ring), a wave 19.5 KB: eight waves per CU = 64 streams per CU.
+//   * what made "a stream per lane" impossible was LDS: here a stream has 1.7 KB (16-bit first-level literal/length entries with
+//     the length's extra bits resolved where code + extra bits fit the 9 index bits; 7-bit distance table; the long lengths'
+//     bounds; a 64-byte input ring -- the canonical search's sorted symbols live in a global workspace), a wave 13 KB: twelve
+//     waves per CU by LDS = 96 streams per CU (measured: eight waves are faster than twelve, profiles/r05/inflate_group/).
 //   * a step of a group is "up to two literals and a match, or three literals", written without branches between the groups'
 //     cases (a group whose next symbol is not a literal looks the same entry up again and consumes nothing); the match half is
 //     decoded into temporaries and committed only when it is the common case (first-level codes, extra bits resolved, distance
 //     within the output) -- anything else leaves the symbol to a general one-symbol routine on the next turn.
-//   * input: the group's lanes load one dword each of a 4 G-byte window four windows ahead (one coalesced request), park it in
+//   * input: the group's lanes load one dword each of a 4 G-byte window a window ahead (one coalesced request), park it in
 //     the LDS ring, and every lane reads the dword it is about to need one refill ahead: no global latency in the symbol chain.
 //   * output: a literal is one byte store of one lane; a match is copied G bytes a round, up to four rounds LOADED at the top
 //     of a turn of the loop and STORED at its bottom, behind the lookups and stores of the literals that follow the match (the
 //     L2 round trip passes under them; nothing in flight is carried around the loop: a register a load is still writing must
 //     not meet the copies a compiler puts on a loop's back edge); periodic matches (distance < length) read byte k from
 //     src + k mod D like inflate_wave.h: only bytes written before.  The ring's next window is requested and parked the same way.
-//   * all global accesses go through two bounds-checked buffer descriptors (the launch's compressed bytes, the launch's
-//     output) with 32-bit offsets; a lane that has nothing to load or store gets an offset outside them.  Per stream, the
+//   * all global accesses go through bounds-checked buffer descriptors (the launch's compressed bytes, the launch's output,
+//     the workspace) with 32-bit offsets; a lane that has nothing to load or store gets an offset outside them.  Per stream, the
 //     decoder checks pos + L <= ISIZE and D <= pos itself: corrupt data never reaches a neighbour's bytes.
 // The same source compiles for the host (STRL_EMU: G = 1, one "lane") so that the CPU-only test-suite runs the decoder logic
 // against zlib; the product never runs that build.

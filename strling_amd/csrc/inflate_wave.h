@@ -14,14 +14,15 @@
 //     byte k of a match is out[pos - D + k mod D], which only reads bytes written BEFORE the match;
 //   * Huffman tables are built by the 64 lanes together: per-length ranks by ballots, then every lane fills its share of the
 //     direct-lookup tables entry by entry through a canonical decode of the entry's own index (no scattered replication);
-//     10-bit first level for literal/length codes, 8-bit for distances, longer codes fall back to a canonical search.
+//     9-bit first level for literal/length codes, 8-bit for distances; longer codes go through a canonical search -- inside the
+//     symbol loop for literals and distances (round 5), in the C++ around it for the rest.
 //   * there is NOT ONE lane-dependent branch in the kernel: lanes that have nothing to load or store in a step get an
 //     out-of-range offset into a bounds-checked buffer descriptor (the hardware drops the access) or a dummy LDS slot.
 //     This is what keeps the symbol loop scalar: with a divergent `if` anywhere near it LLVM sinks uniform code into the
 //     branch's arms and the uniformity analysis then marks everything behind the join as divergent (VGPRs, exec masks).
 //     The descriptors also bound every global access to the stream's input and the block's output: corrupt data cannot make
 //     the decoder read or write anywhere else.
-// 6.5 KB of LDS per wave and <= 80 VGPRs: six waves per SIMD; no divergence, every global access coalesced.
+// 4.4 KB of LDS per wave and 80 VGPRs: six waves per SIMD; no divergence, every global access coalesced.
 //
 // The same source compiles for the host (STRL_EMU: the 64 lanes become loops) purely so that the CPU-only test-suite can
 // run the decoder logic against zlib; the product never runs that build.
@@ -403,11 +404,12 @@ struct IwOut {
   }
 };
 
-// The symbol loop proper: literals and plain matches (first-level codes, distance >= length), everything rarer handed back.
-//   code 0: `e` is the entry of a symbol that is neither (nothing consumed; >= 33 bits in the buffer): end of block, a code
-//           longer than the first-level table, an invalid length symbol
+// The symbol loop proper: literals and plain matches (distance >= length) -- codes longer than the first-level tables included
+// since round 5 --, everything rarer handed back.
+//   code 0: `e` is the entry of a symbol that is neither (nothing consumed; >= 20 bits in the buffer): end of block, a long
+//           LENGTH code (or no code at all), an invalid length symbol
 //   code 1: the 256-byte input window is used up (rotate it and come back)
-//   code 4: a match of length L whose distance code is not in the first-level table (L consumed; >= 33 bits in the buffer)
+//   code 4: a match of length L whose distance code is invalid or no code at all (L consumed; >= 30 bits in the buffer)
 //   code 5: a match (L, D) the fast copy does not take: it overlaps itself (D < L) or fails a check (caller decides)
 //   code 6: as 4, and the input window is used up
 //   code 7: the output position passed ISIZE
@@ -424,16 +426,21 @@ struct IwOut {
 //                                         9-bit tables, the copy ahead of the literal store, the distance lookup issued early
 //       literals by v_writelane, sentinel bit buffer, three literals per refill check: vector -30 %, scalar +5 %: 75 % / 47 %   108 / 81
 //       literals staged across matches (no store per match): the same counts on the scalar side                 109 / 81
-//       this form: length and distance put together on the vector unit, one branch for a match's checks: 63 % / 68 %   117 / 87
+//       round 4's form: length and distance put together on the vector unit, one branch for a match's checks: 63 % / 68 %   117 / 87
+//       round 5 (profiles/r05/inflate_long_codes.txt has the ledger): the codes longer than the first-level tables decoded IN the loop
+//       (a level-6 block has ~880 among 17 600 symbols, and each had left the loop for the C++ around it: ~3 symbols' time), length
+//       entries with the extra bits resolved by the table's index, the match path in front of the loop's head, a refill of 8 scalar
+//       instructions, table addresses by one v_bfi from a buffer kept two bits up, no second lookup for a length behind one literal,
+//       one field on the scalar unit: scalar instructions -27 %, vector -20 %, both ports ~70 % of a shorter launch   144 / 107
 //     Neither port gets past ~70 %: a wave is parked on s_waitcnt for half its cycles (LDS lookups, the copy's loads) and each
 //     SIMD holds seven of them.  Every step that took instructions off the busier port paid; taking them off the other did not
 //     (-30 % vector instructions: +1 %), and more waves do not either (6 / 7 / 8 per SIMD: the same; profiles/r04/inflate_vmatch_waves.txt).
 //   * Earlier readings, kept for the record: throughput follows the waves per CU up to 24 (inflate_occupancy.txt); a 9-bit first
 //     level (4.4 KB of LDS per wave) beat 10 bits by 9 %; removing the copy's waits altogether gives +13 %, header parse + table
 //     build are 3.6 % (inflate_exp_waits.txt, inflate_exp_header_only.txt).
-//   scalar: the 64-bit bit buffer (a sentinel bit above its valid bits: "fewer than 32" is "high word zero"; no bit count), its
-//           shifts by the entry's own fields, the table index, the output position (in m0: v_writelane's lane select);
-//   vector: the table address + lookup, the literal's placement (v_writelane of the entry), length and distance from their
+//   scalar: the 64-bit bit buffer (a sentinel bit above its valid bits, the whole two bits up: "fewer than 30" is "high word zero";
+//           no bit count), its shifts by the entry's own fields, the output position (in m0: v_writelane's lane select);
+//   vector: the table address (a bit-field insert of the buffer's low word into the table's own address) + lookup, the literal's placement (v_writelane of the entry), length and distance from their
 //           entries' fields (every lane the same value), the checks of a match folded into one sign test, the copy;
 // values cross where an operand may sit in either file (a vector instruction reads one scalar register for free) and through
 // v_readfirstlane otherwise (the table entry, the bits the distance code used, the position behind the match).
