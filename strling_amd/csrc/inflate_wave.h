@@ -448,7 +448,153 @@ struct IwOut {
 // exit) comes around -- the load latency passes while the next symbols are decoded; every store is issued before any later
 // load, so a later match that reads these bytes sees them.  bb lives in s[90:91]; s92..s95, vcc are scratch; m0 is saved and
 // restored around the loop.
-#ifdef STRL_EMU
+#if defined(STRL_EMU) && !defined(IW_EMU_PLAIN)
+// The host build's twin of the hand-written loop below, label for label: the same sentinel bit buffer two bits up, the same three
+// unrolled lookups and their bit budget, the same shortcuts, the pending copy, the exits.  (The plain C loop further down -- a
+// refill check per symbol, no unrolling -- accepted two budget mistakes of round 5 that only the GPU then showed: a decoder that
+// is tested on the CPU has to take the device's steps.  -DIW_EMU_PLAIN builds the plain loop instead.)
+IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> &llim, const IwLane<uint32_t> &ldel, uint32_t &e, uint32_t &code, uint32_t &L, uint32_t &D) {
+  constexpr uint32_t LM = (1u << IW_LIT_ROOT) - 1u, DM = (1u << IW_DIST_ROOT) - 1u;
+  uint64_t bb = (br.bb | (1ull << br.nbits)) << 2;
+  uint32_t m0 = o.pos, wi = br.widx - 64u, ve = 0, vL = L, vD = D, vn = 0, vt1 = 0, vt2 = 0, vsrc = 0, s92 = 0, s93 = 0, s94 = 0, s95 = 0;
+  e = 0;
+  auto lo = [&]() { return (uint32_t)bb; };
+  auto hi0 = [&]() { return (uint32_t)(bb >> 32) == 0u; };
+  auto flush_pend = [&](uint32_t base) {                        // the staged literals (entries with bit 31) of the window at `base`
+    for (int lane = 0; lane < 64; ++lane) {
+      const uint32_t v = o.pend[lane];
+      iw_st8(o.out, (v >> 31) ? (base | (uint32_t)lane) : IW_OOB, v >> 16);
+      o.pend[lane] = 0;
+    }
+  };
+  auto copy_round = [&](uint32_t k0, uint32_t n) {              // store what the previous round loaded, load this round's bytes
+    for (int lane = 0; lane < 64; ++lane) iw_st8(o.out, o.paddr[lane], o.pdata[lane]);
+    for (int lane = 0; lane < 64; ++lane) {
+      const uint32_t k = k0 + (uint32_t)lane;
+      o.pdata[lane] = iw_ld8(o.out, vsrc + k);
+      o.paddr[lane] = n > k ? m0 + k : IW_OOB;
+    }
+  };
+  auto refill = [&]() -> bool {                                 // true: the window's last dword has gone in
+    const uint32_t p = 31u - (uint32_t)__builtin_clz(lo());
+    const uint64_t w = (1ull << 32) | iw_readlane(br.cur, wi & 63u);
+    bb = (bb & ~(1ull << p)) | (w << p);
+    return ++wi == 0u;
+  };
+  auto v16 = [&]() { return iw_brev(lo() >> 2) >> 16; };
+  goto loop;
+notlit:
+  if (!(e & IW_LEN_DONE)) goto lenx;
+lendone:
+  vL = ve >> 16;
+  bb >>= (e & 15u);
+  ve = S.dist_tab[(lo() >> 2) & DM];
+  if (hi0()) goto refill2;
+have2:
+  vt2 = m0 + vL;
+have2b:
+  vn = ve & 15u;
+  vt1 = (ve >> 4) & 15u;
+  vD = (((lo() >> vn) >> 2) & ((1u << vt1) - 1u)) + (ve >> 16);
+  s92 = (ve >> 10) & 31u;
+  s93 = vt2;
+  vsrc = m0 - vD;
+  s94 = m0 & ~63u;
+  vt1 = vL + vsrc;
+  if ((int32_t)((vD - vL) | vsrc) < 0) goto hard;
+  bb >>= s92;
+  if (s94 < vt1) { flush_pend(s94); }                          // (L_iw_flushfirst)
+  copy_round(0, vL);
+  if ((s93 ^ m0) > 63u) goto cross;
+  m0 = s93;
+loop:
+  if (hi0()) goto refill1;
+have:
+  ve = S.lit_tab[(lo() >> 2) & LM]; e = ve;
+  if (!(e & IW_FAST_LIT)) goto notlit;
+  bb >>= (e & 63u); iw_writelane(o.pend, m0 & 63u, e); ++m0;
+  if (!(m0 & 63u)) goto full;
+  ve = S.lit_tab[(lo() >> 2) & LM]; e = ve;
+  if (!(e & IW_FAST_LIT)) goto second;
+  bb >>= (e & 63u); iw_writelane(o.pend, m0 & 63u, e); ++m0;
+  if (!(m0 & 63u)) goto full;
+  ve = S.lit_tab[(lo() >> 2) & LM]; e = ve;
+  if (!(e & IW_FAST_LIT)) goto loop;
+lit3:
+  bb >>= (e & 63u); iw_writelane(o.pend, m0 & 63u, e); ++m0;
+  if (m0 & 63u) goto loop;
+full:
+  flush_pend(m0 - 64u);
+  if (!(m0 > o.isize)) goto loop;
+  code = 7; goto end;
+second:
+  if (e & IW_LEN_DONE) goto lendone;
+  goto loop;
+refill1:
+  if (!refill()) goto have;
+  code = 1; goto end;
+cross:
+  s95 = s93 - m0;
+  for (s94 = 64; s95 > 64u && s94 < s95; s94 += 64u) copy_round(s94, s95);
+  flush_pend(m0 & ~63u);
+  m0 = s93;
+  goto loop;
+refill2:
+  if (!refill()) goto have2;
+  code = 6; goto end;
+hard:
+  if (vn == 0u) goto longd;
+  bb >>= s92;
+  code = 5; goto end;
+longd: {
+    const uint32_t v = v16();
+    int k = 0;
+    while (k < 15 - IW_DIST_ROOT && !(v < llim[8 + k])) ++k;
+    if (k == 15 - IW_DIST_ROOT) goto exit4;
+    const uint32_t l = (uint32_t)(IW_DIST_ROOT + 1 + k);
+    uint32_t at = (v >> (uint32_t)(15 - IW_DIST_ROOT - k)) + ldel[8 + k];
+    at = at < 32u ? at : 32u;
+    const uint32_t sym = S.d_sorted[at];
+    if (sym > 29u) goto exit4;
+    ve = iw_with_total(iw_entry_of<IW_DISTS>(sym), l);
+    vt2 = m0 + vL;
+    goto have2b;
+  }
+exit4:
+  code = 4; goto end;
+lenx:
+  if ((e & (3u << 8)) != IW_KIND_BASE) goto other;
+  vL = (((lo() >> (ve & 15u)) >> 2) & ((1u << ((ve >> 4) & 15u)) - 1u)) + (ve >> 16);
+  bb >>= ((e >> 10) & 31u);
+  ve = S.dist_tab[(lo() >> 2) & DM];
+  if (hi0()) goto refill2;
+  goto have2;
+other: {
+    if (e & 15u) goto exit0;
+    const uint32_t v = v16();
+    int k = 0;
+    while (k < 15 - IW_LIT_ROOT && !(v < llim[k])) ++k;
+    if (k == 15 - IW_LIT_ROOT) goto exit0;
+    uint32_t at = (v >> (uint32_t)(15 - IW_LIT_ROOT - k)) + ldel[k];
+    at = at < 288u ? at : 288u;
+    const uint32_t sym = S.ll_sorted[at];
+    if (!(sym < 256u)) goto exit0;
+    e = (sym << 16) | (uint32_t)(IW_LIT_ROOT + 1 + k) | IW_FAST_LIT;
+    goto lit3;
+  }
+exit0:
+  code = 0;
+end:
+  br.widx = wi + 64u;
+  for (int lane = 0; lane < 64; ++lane) { iw_st8(o.out, o.paddr[lane], o.pdata[lane]); o.paddr[lane] = IW_OOB; }
+  bb >>= 2;
+  br.nbits = 63u - (uint32_t)__builtin_clzll(bb);
+  br.bb = bb & ~(1ull << br.nbits);
+  o.pos = m0;
+  L = vL; D = vD;
+  (void)vt1; (void)s95;
+}
+#elif defined(STRL_EMU)
 IW_DEV void iw_run(IwBits &br, IwOut &o, const IwLds &S, const IwLane<uint32_t> &llim, const IwLane<uint32_t> &ldel, uint32_t &e, uint32_t &code, uint32_t &L, uint32_t &D) {
   const uint32_t *lit_tab = S.lit_tab, *dist_tab = S.dist_tab;
   for (;;) {
@@ -996,6 +1142,10 @@ IW_DEV int iw_inflate(const uint8_t *comp, uint64_t off, uint32_t clen, uint64_t
       for (;;) {
         uint32_t e, code;
         iw_run(br, o, S, llim, ldel, e, code, L, D);
+        // (The loop no longer compares a match's end with isize: stores behind isize are dropped by the block's descriptor.  What
+        // BOUNDS it is this: it comes back here every 256 bytes of input at the latest -- code 1 / 6 --, and a position past isize ends
+        // the stream.  Without that a truncated stream, read as zeros past its end, whose zero bits are a match would never stop.)
+        if ((code == 1u || code == 6u) && o.pos > isize) { why = IW_ERR_SIZE; break; }
         if (code == 1u) { br.rotate(); continue; }
         if (code == 7u) { why = IW_ERR_SIZE; break; }
         if (code == 0u) {
