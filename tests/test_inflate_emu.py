@@ -174,6 +174,7 @@ def test_inflate_core_rejects_bad_streams(emu):
     assert bad == 40                                                          # garbage never decodes to exactly 20000 bytes
 
 
+@pytest.mark.timeout(300)
 def test_inflate_core_corrupt_streams_get_zlibs_verdict(emu):
     """bit flips and truncations of valid streams (dynamic, fixed and stored blocks): the decoder stays inside its buffers
     (the shim checks the poison on both sides) and accepts a stream only if zlib inflates it to exactly ISIZE bytes with the
@@ -199,3 +200,39 @@ def test_inflate_core_corrupt_streams_get_zlibs_verdict(emu):
                 n_acc += 1
                 assert _zlib_ok(b, len(base)) and out.raw[:len(base)] == zlib.decompress(b, -15), (kw, t)
     assert n_acc < 400
+
+
+@pytest.mark.timeout(600)
+def test_inflate_core_random_shapes_valid_and_damaged(emu):
+    """the device fuzzer's block shapes (tests/fuzz/fuzz_inflate.py: geometric alphabets, long-then-short literals, runs, periodic
+    text, BAM-like records, far matches) x level / strategy / flush points through the host build -- which takes the device loop's
+    steps --, every third stream also bit-flipped or truncated: the decoder returns (a decoder that does not is a hung GPU), keeps
+    inside its buffers, and accepts only what zlib inflates to the same bytes"""
+    import importlib.util, types
+    src = open(os.path.join(HERE, "fuzz", "fuzz_inflate.py")).read().replace("from strling_amd import api\n", "")
+    fz = types.ModuleType("fuzz_inflate_shapes")
+    fz.__dict__["__file__"] = os.path.join(HERE, "fuzz", "fuzz_inflate.py")
+    exec(compile(src, "fuzz_inflate_shapes", "exec"), fz.__dict__)
+    rng = np.random.default_rng(77)
+    for n in range(700):
+        b = fz.block(rng)
+        kw = dict(level=int(rng.integers(0, 10)))
+        k = int(rng.integers(0, 6))
+        if k == 1: kw["strategy"] = zlib.Z_HUFFMAN_ONLY
+        elif k == 2: kw["strategy"] = zlib.Z_RLE
+        elif k == 3: kw["strategy"] = zlib.Z_FIXED
+        elif k == 4: kw["flush_every"] = int(rng.integers(200, 20000))
+        st = deflate(b, **kw)
+        out = C.create_string_buffer(len(b) + 1)
+        assert emu.emu_inflate_at(st, len(st), n % 8, out, len(b)) == 0 and out.raw[:len(b)] == b, (n, kw)
+        if n % 3 == 0 and len(st) > 8:
+            c = bytearray(st)
+            for _ in range(int(rng.integers(1, 4))):
+                c[int(rng.integers(0, len(c)))] ^= 1 << int(rng.integers(0, 8))
+            if rng.random() < 0.3:
+                c = c[:int(rng.integers(1, len(c)))]
+            c = bytes(c)
+            rc = emu.emu_inflate_at(c, len(c), 0, out, len(b))
+            assert rc in (0, 1, 2, 3), rc
+            if rc == 0:
+                assert _zlib_ok(c, len(b)) and out.raw[:len(b)] == zlib.decompress(c, -15), n
