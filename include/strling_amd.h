@@ -36,8 +36,13 @@ extern "C" {
 #define STRL_MEM_HOST 0
 #define STRL_MEM_DEVICE 1
 
-/* longest read the scorer accepts (uint8 histogram counters of utils.nim:113-117 would wrap beyond it) */
-#define STRL_MAX_READ_LEN 510
+/* Longest read the KERNELS score: a lane's byte-wide class counters are exact while no class can be seen more than 255 times.
+ * The reference's uint8 histograms (utils.nim:113-117) simply wrap beyond that (utils.nim:192-195), so a longer read is scored by
+ * the library's host twin of the scorer with that arithmetic (csrc/host_score.cpp) and its words are merged into the device's
+ * results by record index -- every scoring entry point does so by itself.  STRL_MAX_READ_LEN is what the 16-bit length
+ * columns of strl_read_soa / strl_pair_rec hold; a longer record is STRL_ERR_ARG. */
+#define STRL_DEVICE_READ_LEN 510
+#define STRL_MAX_READ_LEN 65534
 
 typedef struct strl_ctx strl_ctx;
 
@@ -195,6 +200,12 @@ int strl_index_chrom(strl_ctx *ctx, const char *seq, uint64_t n_bases, uint32_t 
 typedef struct { uint64_t start, stop; char unit[8]; } strl_region;
 int strl_index_regions(const char *seq, uint64_t n_bases, const uint32_t *words, uint64_t n_windows, uint32_t window,
                        uint32_t step, strl_region *out, uint64_t cap, uint64_t *n_out);
+
+/* The host twin of the scorer (csrc/host_score.cpp): utils.get_repeat (utils.nim:236-271) on ONE read given as text (what
+ * hts-nim's aln.sequence returns: "=ACMGRSVTWYHKDBN" letters), of any length, with the reference's own arithmetic -- uint8
+ * histogram bins that wrap (utils.nim:192-195), float64 thresholds.  *word = the packed unit/count word.  No device is
+ * touched.  This is what scores records of more than STRL_DEVICE_READ_LEN bases inside every scoring entry point. */
+int strl_score_read_host(const char *seq, int32_t l_seq, double proportion_repeat, uint32_t *word);
 
 /* Kernel timing with HIP events recorded on the context stream around every kernel of
  * strl_score_reads (a ring of 256 launches).  enable_timing(ctx, 1) resets the ring;
@@ -524,7 +535,8 @@ int strl_regions_fetch(strl_ctx *ctx, const uint8_t *comp, uint64_t comp_bytes, 
  *   coff / clen / isize   per block: offset of its DEFLATE payload in comp, payload length, inflated size (BGZF ISIZE)
  *   crc32                 per block: the CRC-32 its BGZF trailer states (checked on the device like htslib checks it), or NULL
  *   done / n_done         summaries of chunks whose scoring has COMPLETED, in file order (push: 0 or 1, finish: up to 2)
- * Errors: STRL_ERR_FORMAT invalid DEFLATE data / ISIZE / malformed record; STRL_ERR_CRC; STRL_ERR_ARG a record's l_seq > STRL_MAX_READ_LEN. */
+ * Errors: STRL_ERR_FORMAT invalid DEFLATE data / ISIZE / malformed record; STRL_ERR_CRC; STRL_ERR_ARG a record's l_seq > STRL_MAX_READ_LEN (records of
+ * more than STRL_DEVICE_READ_LEN bases are scored by the host twin, host_score.cpp). */
 typedef struct {
   uint64_t n_records;       /* records of the chunk (secondary / supplementary included) */
   uint64_t n_primary;       /* those that are neither (the reference's progress counter, extract.nim:309,315) */

@@ -12,10 +12,15 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libstrling_amd.so")
 CLI = os.path.join(LIBDIR, "strling")
-SOURCES = ["score.hip", "pair.hip", "sort.hip", "cluster.hip", "bgzf.hip", "front.hip", "comm.hip", "host_logic.cpp", "call_logic.cpp", "nim_tables.cpp"]
+SOURCES = ["score.hip", "pair.hip", "sort.hip", "cluster.hip", "bgzf.hip", "front.hip", "comm.hip", "host_logic.cpp", "host_score.cpp", "call_logic.cpp", "nim_tables.cpp"]
 CLI_SOURCES = ["cli/main.cpp", "cli/bam_reader.cpp", "cli/fast_inflate.cpp", "cli/bgzf_feed.cpp", "cli/cram_reader.cpp", "cli/cram_codecs.cpp"]
-HEADERS = ["common.h", "device_util.h", "sort.h", "inflate_wave.h", "inflate_group.h", "front.h", "score_core.h", "score_tables.h", "nim_tables.h", "cli/bam_reader.h", "cli/fast_inflate.h", "cli/bgzf_feed.h", "cli/cram_reader.h", "cli/cram_codecs.h", "../../include/strling_amd.h"]
+HEADERS = ["common.h", "device_util.h", "sort.h", "inflate_wave.h", "inflate_group.h", "front.h", "score_core.h", "score_tables.h", "nim_tables.h", "host_score.h", "cli/bam_reader.h", "cli/fast_inflate.h", "cli/bgzf_feed.h", "cli/cram_reader.h", "cli/cram_codecs.h", "../../include/strling_amd.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+# the grouped form of the device inflate (csrc/inflate_group.h): an experiment that measured slower (profiles/r05/inflate_group/);
+# not in the shipped library unless asked for
+WITH_INFLATE_GROUP = os.environ.get("STRL_WITH_INFLATE_GROUP") == "1"
+if WITH_INFLATE_GROUP:
+    FLAGS = FLAGS + ["-DSTRL_WITH_INFLATE_GROUP"]
 
 
 def _hipcc():

@@ -12,7 +12,13 @@
 #include "common.h"
 #include "device_util.h"
 #include "inflate_wave.h"
+// The grouped form of the decoder (inflate_group.h: a block per 8 lanes) measured slower than the wave form everywhere it was
+// tried (profiles/r05/inflate_group/): it is an experiment, kept with its logs and its CPU tests, and NOT part of the shipped
+// library -- a second decoder of untrusted input nobody benefits from.  `STRL_WITH_INFLATE_GROUP=1 python -m strling_amd.build`
+// compiles it in (then STRL_INFLATE_FORM=group selects it at run time).
+#ifdef STRL_WITH_INFLATE_GROUP
 #include "inflate_group.h"
+#endif
 
 namespace strl {
 
@@ -54,6 +60,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STRL_INFLATE
   }
 }
 
+#ifdef STRL_WITH_INFLATE_GROUP
 // The grouped form (inflate_group.h): G lanes per block, 64 / G blocks per wave; one wave per workgroup, twelve workgroups per
 // CU at G = 8 (13 KB of LDS each, <= 168 registers).  32-bit offsets into the buffer descriptors: the host only launches it for
 // < 2 GiB each.
@@ -73,6 +80,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 8 ? STR
     }
   }
 }
+#endif
 
 // ---- CRC-32 of every block's inflated bytes against the BGZF trailer (htslib refuses a block whose CRC differs: bgzf.c) ----
 // The CRC is linear over GF(2): CRC(M) = sum over the dwords w_i of M of  w_i * x^(8 * bytes behind w_i)  (+ the start value's
@@ -271,6 +279,9 @@ int strl_crc_device(strl_ctx *c, const uint8_t *d_out, const uint64_t *d_uoff, c
 // Which form a launch takes: 0 = the wave form, else the lanes per block of the grouped form.
 // STRL_INFLATE_FORM = wave | group (G lanes per block, STRL_INFLATE_G = 4 | 8 | 16)
 int strl_inflate_form() {
+#ifndef STRL_WITH_INFLATE_GROUP
+  return 0;
+#else
   static const int form_g = [] {
     const char *f = getenv("STRL_INFLATE_FORM"), *g = getenv("STRL_INFLATE_G");
     if (f && !strcmp(f, "wave")) return 0;
@@ -280,10 +291,18 @@ int strl_inflate_form() {
     return G == 4 || G == 16 ? G : 8;
   }();
   return form_g;
+#endif
 }
 // The grouped form's workspace for n_blocks blocks (0 bytes when the wave form runs): the caller keeps it beside the launch's
 // other buffers -- one per stream that may hold a launch.
-size_t strl_inflate_work_bytes(uint32_t n_blocks) { return strl_inflate_form() ? (size_t)n_blocks * IG_WORK_STRIDE + 64 : 0; }
+size_t strl_inflate_work_bytes(uint32_t n_blocks) {
+#ifdef STRL_WITH_INFLATE_GROUP
+  return strl_inflate_form() ? (size_t)n_blocks * IG_WORK_STRIDE + 64 : 0;
+#else
+  (void)n_blocks;
+  return 0;
+#endif
+}
 
 // out_bytes: the bytes of d_out the blocks' outputs lie in; d_work / work_bytes: strl_inflate_work_bytes(n_blocks) of device
 // memory.  Without either (0 / null) the wave form, which needs neither, is launched.
@@ -293,13 +312,16 @@ int strl_inflate_device(strl_ctx *c, const uint8_t *d_comp, uint64_t readable, c
   if (!n_blocks) return STRL_OK;
   InflateParams P{d_comp, readable & ~(uint64_t)3, d_coff, d_clen, d_uoff, d_isize, n_blocks, d_out, d_err, d_status, out_bytes, d_work, work_bytes};
   static const unsigned lds_pad = getenv("STRL_INFLATE_LDS_PAD") ? (unsigned)atoi(getenv("STRL_INFLATE_LDS_PAD")) : 0u;   // (occupancy experiments: unused dynamic LDS)
+#ifdef STRL_WITH_INFLATE_GROUP
   const int form_g = strl_inflate_form();
   if (form_g && out_bytes && out_bytes < 0x7ffffff0ull && readable < 0x7ffffff0ull && d_work && work_bytes >= (size_t)n_blocks * IG_WORK_STRIDE) {
     const unsigned per = 64u / (unsigned)form_g, grid = (n_blocks + per - 1) / per;
     if (form_g == 4) hipLaunchKernelGGL(inflate_group_kernel<4>, dim3(grid), dim3(64), lds_pad, st, P);
     else if (form_g == 16) hipLaunchKernelGGL(inflate_group_kernel<16>, dim3(grid), dim3(64), lds_pad, st, P);
     else hipLaunchKernelGGL(inflate_group_kernel<8>, dim3(grid), dim3(64), lds_pad, st, P);
-  } else {
+  } else
+#endif
+  {
     hipLaunchKernelGGL(inflate_kernel, dim3(n_blocks), dim3(64), lds_pad, st, P);
   }
   STRL_HIP(hipGetLastError());

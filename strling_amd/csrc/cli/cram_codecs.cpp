@@ -33,6 +33,9 @@ struct In {
 
 constexpr uint32_t RANS16_L = 1u << 15;
 constexpr size_t MAX_OUT = (size_t)1 << 30;
+// what one rANS Nx16 stream may claim to expand to right now: MAX_OUT for a block (whose size the container states), far less for
+// the sub-streams of a name tokeniser block, which state their own (cram_tok3_decode)
+thread_local size_t g_stream_cap = MAX_OUT;
 
 // the symbols that occur: sym, then either the next symbol or -- when that is sym + 1 -- a count of further consecutive ones
 bool read_alphabet(In &r, bool A[256]) {
@@ -185,7 +188,7 @@ bool rans_nx16(In &r, size_t expect, bool have_expect, std::vector<uint8_t> &out
     len = r.u7();
     if (have_expect && len != expect) { err = "rANS Nx16 block: the stream's own size differs from the block's"; return false; }
   } else if (!have_expect) { err = "rANS Nx16 stream without a size"; return false; }
-  if (!r.ok || len > MAX_OUT) { err = "malformed rANS Nx16 block"; return false; }
+  if (!r.ok || len > g_stream_cap) { err = "malformed rANS Nx16 block"; return false; }
   const int N = (flags & 0x04) ? 32 : 4;
   if (flags & 0x08) {                     // STRIPE: byte i of the output comes from sub-stream i mod X
     const uint32_t X = r.u8();
@@ -216,7 +219,7 @@ bool rans_nx16(In &r, size_t expect, bool have_expect, std::vector<uint8_t> &out
     }
     for (uint32_t i = 0; i < nsym; ++i) P[i] = r.u8();
     len = r.u7();
-    if (!r.ok || len > MAX_OUT) { err = "malformed rANS Nx16 PACK header"; return false; }
+    if (!r.ok || len > g_stream_cap) { err = "malformed rANS Nx16 PACK header"; return false; }
   }
   // RLE metadata: which symbols carry run lengths, the run lengths, and the size of the literal stream
   const size_t rle_len = len;
@@ -226,7 +229,7 @@ bool rans_nx16(In &r, size_t expect, bool have_expect, std::vector<uint8_t> &out
   if (flags & 0x40) {
     const uint32_t mlen = r.u7();
     len = r.u7();
-    if (!r.ok || len > MAX_OUT) { err = "malformed rANS Nx16 RLE header"; return false; }
+    if (!r.ok || len > g_stream_cap) { err = "malformed rANS Nx16 RLE header"; return false; }
     if (mlen & 1) {
       const size_t ml = mlen / 2;
       if (ml > (size_t)(r.e - r.p)) { err = "truncated rANS Nx16 RLE metadata"; return false; }
@@ -313,6 +316,12 @@ bool cram_tok3_decode(const uint8_t *in, size_t in_len, size_t expect, std::vect
   const uint32_t ulen = r.u32le(), n_names = r.u32le();
   const uint8_t use_arith = r.u8();
   if (!r.ok || ulen != expect || ulen > MAX_OUT) { err = "malformed name tokeniser block"; return false; }
+  // every name costs at least its NUL: a count beyond the block's size is a hostile header, and everything below is sized by it
+  if (n_names > ulen) { err = "malformed name tokeniser block (more names than bytes)"; return false; }
+  // A token stream holds at most a byte or a 32-bit number per name, or the names' own text: nothing useful is longer than this,
+  // and a stream that claims more from its few input bytes is refused before anything is allocated for it.
+  struct CapGuard { size_t was; ~CapGuard() { g_stream_cap = was; } } guard{g_stream_cap};
+  g_stream_cap = std::min<size_t>(MAX_OUT, (size_t)ulen + 4 * (size_t)n_names + 64);
   if (use_arith) {
     err = "the CRAM's read names are compressed with the adaptive arithmetic coder (CRAM 3.1 `archive` / `small` profiles): not supported by this build "
           "(re-encode with `samtools view -C --output-fmt-option version=3.1` at the default profile, or `version=3.0`)";
@@ -325,7 +334,7 @@ bool cram_tok3_decode(const uint8_t *in, size_t in_len, size_t expect, std::vect
     const uint8_t tt = r.u8();
     const int type = tt & 15;
     if (tt & 128) {
-      ++tnum;
+      if (++tnum > 128) { err = "name tokeniser block: more than 128 token positions"; return false; }
       S.emplace_back(16);
       if (type != T_TYPE) {               // every name has this token type at this position, except that from the second on it is "match"
         Stream &ts = S[(size_t)tnum][T_TYPE];

@@ -217,7 +217,21 @@ bool rans_decode(const uint8_t *in, size_t in_len, std::vector<uint8_t> &out, si
   return true;
 }
 
+static bool block_data_unguarded(const Block &b, std::vector<uint8_t> &out, std::string &err);
+// (a size field that passes every check and still cannot be allocated is a malformed file, not the end of the process:
+// "false + err on anything malformed" holds for memory too)
 bool block_data(const Block &b, std::vector<uint8_t> &out, std::string &err) {
+  try {
+    return block_data_unguarded(b, out, err);
+  } catch (const std::bad_alloc &) {
+    err = "CRAM block whose size fields ask for more memory than there is";
+    return false;
+  } catch (const std::length_error &) {
+    err = "CRAM block with an impossible size field";
+    return false;
+  }
+}
+static bool block_data_unguarded(const Block &b, std::vector<uint8_t> &out, std::string &err) {
   if (b.rsize > (1u << 30)) { err = "CRAM block of more than 1 GiB"; return false; }      // (before anything is allocated for a hostile size field)
   switch (b.method) {
     case 0:
@@ -729,6 +743,17 @@ bool CramFile::open(const std::string &path, const std::string &fasta, int threa
 }
 
 bool CramFile::decode_container(const Container &c, int64_t only_landmark, RecordBatch &out, std::string &err) {
+  try {
+    return decode_container_body(c, only_landmark, out, err);
+  } catch (const std::bad_alloc &) {
+    err = "CRAM container whose size fields ask for more memory than there is";
+  } catch (const std::length_error &) {
+    err = "CRAM container with an impossible size field";
+  }
+  return false;
+}
+
+bool CramFile::decode_container_body(const Container &c, int64_t only_landmark, RecordBatch &out, std::string &err) {
   Rd r{map_ + c.data_off, map_ + c.data_off + c.len};
   Block hb;
   if (!read_block(r, hb, &err) || hb.type != 1) { if (err.empty()) err = "CRAM container without a compression header"; return false; }
@@ -748,19 +773,40 @@ bool CramFile::decode_container(const Container &c, int64_t only_landmark, Recor
   std::vector<int> needed_ids;
   for (const Enc *e : {&eBF, &eCF, &eRI, &eRL, &eAP, &eRN, &eMF, &eNS, &eNP, &eTS, &eNF, &eTL, &eFN, &eFC, &eFP, &eDL, &eBB, &eBS, &eIN, &eRS, &ePD, &eHC, &eSC, &eMQ, &eBA})
     (void)enc_ids(*e, needed_ids);
+  // ... decided as a fixpoint: a candidate that must be walked (it takes core bits, or shares a block with something walked) makes
+  // the blocks IT reads walked ones too -- a skipped series that shared one of them would leave that block's cursor behind.
+  // (htslib never writes such a layout; the format allows it.)
+  std::vector<const Enc *> cand{&eQS, &eQQ, &eRG};
+  for (size_t t = 0; t < H.td.size(); ++t)
+    for (int32_t key : H.td[t]) {
+      auto it = H.tags.find(key);
+      if (it == H.tags.end()) { err = "CRAM: a tag without an encoding"; return false; }
+      if (std::find(cand.begin(), cand.end(), &it->second) == cand.end()) cand.push_back(&it->second);
+    }
+  std::vector<uint8_t> walked(cand.size(), 0);
+  for (bool again = true; again;) {
+    again = false;
+    for (size_t k = 0; k < cand.size(); ++k) {
+      if (walked[k]) continue;
+      std::vector<int> ids;
+      bool must = !enc_ids(*cand[k], ids);
+      for (int id : ids) if (std::find(needed_ids.begin(), needed_ids.end(), id) != needed_ids.end()) must = true;
+      if (!must) continue;
+      walked[k] = 1;
+      again = true;
+      for (int id : ids) if (std::find(needed_ids.begin(), needed_ids.end(), id) == needed_ids.end()) needed_ids.push_back(id);
+    }
+  }
   auto skippable = [&](const Enc &e) {
-    std::vector<int> ids;
-    if (!enc_ids(e, ids)) return false;
-    for (int id : ids) if (std::find(needed_ids.begin(), needed_ids.end(), id) != needed_ids.end()) return false;
-    return true;
+    const size_t k = (size_t)(std::find(cand.begin(), cand.end(), &e) - cand.begin());
+    return k < cand.size() && !walked[k];
   };
   const bool skip_qs = skippable(eQS), skip_qq = skippable(eQQ), skip_rg = skippable(eRG);
   std::vector<std::vector<const Enc *>> tag_walk(H.td.size());        // per tag line: the tag encodings that have to be walked
   for (size_t t = 0; t < H.td.size(); ++t)
     for (int32_t key : H.td[t]) {
-      auto it = H.tags.find(key);
-      if (it == H.tags.end()) { err = "CRAM: a tag without an encoding"; return false; }
-      if (!skippable(it->second)) tag_walk[t].push_back(&it->second);
+      const Enc &te = H.tags.find(key)->second;
+      if (!skippable(te)) tag_walk[t].push_back(&te);
     }
   // (scratch of the calling thread, kept between containers: growing fresh vectors record by record from several threads at
   // once made them fight over the process' address-space lock)
@@ -1072,7 +1118,14 @@ int64_t CramFile::read(RecordBatch &b, int64_t max_records, std::string &err) {
         eof_ = true;
         // CRAMv3 section 9: the file ends in the EOF container; htslib warns about a file without one ("EOF marker is absent"),
         // a file cut between two containers looks complete otherwise -- refuse it
-        if (!saw_eof_container_) { err = "the CRAM does not end in its EOF container: the file is truncated"; return -1; }
+        // -- htslib's verdict, and so the reference's: a warning, and the records that are there are processed.  STRL_CRAM_STRICT_EOF=1
+        // makes it an error (a file cut exactly between two containers looks complete otherwise).
+        if (!saw_eof_container_) {
+          static const bool strict = getenv("STRL_CRAM_STRICT_EOF") != nullptr;
+          if (strict) { err = "the CRAM does not end in its EOF container: the file is truncated"; return -1; }
+          if (!warned_eof_) fprintf(stderr, "[W::cram] EOF marker is absent. The input is probably truncated\n");
+          warned_eof_ = true;
+        }
         break;
       }
       Container c;

@@ -59,6 +59,7 @@ class CramFile {
   bool parse_container_header(uint64_t off, Container &c, std::string &err) const;
   // decode the slices of one container (all of them, or the one at `only_landmark`) into `out`
   bool decode_container(const Container &c, int64_t only_landmark, RecordBatch &out, std::string &err);
+  bool decode_container_body(const Container &c, int64_t only_landmark, RecordBatch &out, std::string &err);
   const uint8_t *map_ = nullptr;
   size_t map_len_ = 0;
   std::string path_, text_;
@@ -70,7 +71,7 @@ class CramFile {
   ThreadPool *pool_ = nullptr;
   std::vector<CraiEntry> crai_;                 // sorted by (tid, start)
   std::vector<int64_t> crai_max_end_;           // running maximum of start + span within a tid: where a backward scan may stop
-  bool have_index_ = false, saw_eof_container_ = false;
+  bool have_index_ = false, saw_eof_container_ = false, warned_eof_ = false;
   // the slice a region read decoded last (consecutive bounds fall into the same slice)
   uint64_t last_c_off_ = ~0ull;
   uint32_t last_s_off_ = 0;

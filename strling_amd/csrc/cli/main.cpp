@@ -604,7 +604,7 @@ static std::vector<uint64_t> share_cuts(const BgzfFeed &feed, const std::string 
   for (int g = 1; g < G; ++g) {
     const uint64_t want = (lo + (uint64_t)((double)span * g / G)) << 16;
     auto it = std::lower_bound(pts.begin(), pts.end(), std::max(want, cut.back() + 1));
-    if (it == pts.end()) break;
+    if (it == pts.end() || (*it >> 16) >= feed.file_bytes()) break;     // (an index of a longer / another file: no cut there)
     cut.push_back(*it);
   }
   return cut;
@@ -877,7 +877,15 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     std::vector<Share> shares((size_t)n_shares);
     for (int g = 0; g < n_shares; ++g) {
       const uint64_t end = g + 1 < n_shares ? cut[(size_t)g + 1] : 0;
-      if (!shares[(size_t)g].fd.open_share(feed, cut[(size_t)g] >> 16, (uint32_t)(cut[(size_t)g] & 0xffff), end >> 16, (uint32_t)(end & 0xffff), err)) quit("[strling] %s", err.c_str());
+      if (!shares[(size_t)g].fd.open_share(feed, cut[(size_t)g] >> 16, (uint32_t)(cut[(size_t)g] & 0xffff), end >> 16, (uint32_t)(end & 0xffff), err)) {
+        // an offset of the index that is no block of THIS file (a stale .bai): like every later check, the way out is the
+        // chunk-by-chunk run, which needs no index -- `--gpus 1` reads the file fine
+        fprintf(stderr, "[strling] share %d of %d: %s; repeating the extraction chunk by chunk\n", g, n_shares, err.c_str());
+        for (Share &Z : shares) Z.fd.close();
+        for (size_t k = 0; k < pin.size(); ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
+        for (strl_ctx *c : ctxs) strl_ctx_destroy(c);
+        return EXTRACT_AGAIN_BY_CHUNKS;
+      }
     }
     static const bool feed_only = getenv("STRL_FEED_ONLY") != nullptr;     // measurement: the host side alone, no device stage
     const int per_share = std::max(2, std::min(12, decode_threads() / n_shares));

@@ -149,6 +149,8 @@ struct strl_ctx {
   strl::DevBuf queue, soft_queue, counters, soft_tmp, sb_whole, sb_soft, soft_dense, sb_state_w, sb_state_s, queue_r;
   // staging for host-memory batches
   strl::DevBuf st_tid, st_pos, st_end, st_seqoff, st_lseq, st_clipl, st_clipr, st_mapq, st_cig, st_seq4, st_whole, st_soft, st_text, st_meta;
+  // reads the host twin scores (score.hip long_reads_pass): their list, their SEQ bytes / the words that come back
+  strl::DevBuf long_list, long_seq;
   // clustering scratch
   strl::DevBuf c_buf[16];
   ClusterRun cl_run;

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void rec_parse_kernel(ParseParams P) {
         }
     }
     const int32_t end = (int32_t)((int64_t)pos + (rl ? rl : 1));
-    if (l_seq > (uint32_t)STRL_MAX_READ_LEN) atomicOr(&P.info->err, FRONT_ERR_LSEQ);
+    if (l_seq > (uint32_t)STRL_MAX_READ_LEN) atomicOr(&P.info->err, FRONT_ERR_LSEQ);   // (what the 16-bit columns hold; beyond STRL_DEVICE_READ_LEN: the host twin)
     const uint16_t ls16 = (uint16_t)min(l_seq, 65535u), cl16 = (uint16_t)min(cl, 65535u), cr16 = (uint16_t)min(cr, 65535u);
     P.o.tid[i] = tid; P.o.pos[i] = pos; P.o.end[i] = end;
     const uint32_t so = P.seqoff[i];

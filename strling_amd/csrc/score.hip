@@ -21,6 +21,7 @@
 #include <thread>
 #include <vector>
 #include "common.h"
+#include "host_score.h"
 #include "front.h"
 #include "device_util.h"
 #include "score_core.h"
@@ -647,6 +648,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && NW <= 10) ? (STAGE == 0 ? S
     it.res0 = x.z; it.res1 = x.w;
     if (MODE == 0) {
       it.cl = e.z >> 16; it.cr = e.w & 0xffffu; it.cg = (e.w >> 16) & 0xffu; it.mq = e.w >> 24;
+      // a read of more bases than a lane's byte counters are exact for is the host twin's (long_reads_pass below): here it
+      // is an empty read without clipped ends -- no word that counts, no soft-clip items -- whose entry keeps the device busy
+      // for one turn of the ladder
+      if (it.L > STRL_DEVICE_READ_LEN) { it.L = 0; it.cl = 0; it.cr = 0; }
       it.len = it.L; it.s0 = 0;
     } else {
       it.cl = it.cr = it.cg = it.mq = 0;
@@ -938,7 +943,7 @@ void strl_ctx_destroy(strl_ctx *c) {
   if (c->front) { if (c->front->st_c) (void)hipStreamSynchronize(c->front->st_c); for (hipStream_t q : c->front->st_i) if (q) (void)hipStreamSynchronize(q); if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a); strl::front_destroy(c->front); c->front = nullptr; }
   strl::DevBuf *bufs[] = {&c->lut, &c->thr, &c->g_tid, &c->g_bins, &c->g_start, &c->g_pmax, &c->queue, &c->soft_queue, &c->counters,
                           &c->soft_tmp, &c->sb_whole, &c->sb_soft, &c->queue_r, &c->soft_dense, &c->sb_state_w, &c->sb_state_s, &c->st_tid, &c->st_pos, &c->st_end, &c->st_seqoff, &c->st_lseq, &c->st_clipl, &c->st_clipr,
-                          &c->st_mapq, &c->st_cig, &c->st_seq4, &c->st_whole, &c->st_soft, &c->st_text, &c->st_meta,
+                          &c->st_mapq, &c->st_cig, &c->st_seq4, &c->st_whole, &c->st_soft, &c->st_text, &c->st_meta, &c->long_list, &c->long_seq,
                           &c->p_key0, &c->p_key1, &c->p_val0, &c->p_val1, &c->p_emit, &c->sort_scratch, &c->pair_cnt, &c->bloom, &c->treads,
                           &c->st_mtid, &c->st_mpos, &c->st_flag, &c->st_qhash, &c->x_rows, &c->x_qhash, &c->x_whole, &c->x_soft, &c->x_cnt, &c->g_aux, &c->crc_tab, &c->p_spill};
   for (auto *b : bufs) b->release();
@@ -1118,6 +1123,114 @@ namespace strl {
 __global__ void meta_rows_kernel(const uint32_t *seq_off, const uint16_t *l_seq, const uint16_t *clip_l, const uint16_t *clip_r, const uint8_t *cig, const uint8_t *mapq,
                                  uint32_t n, uint4 *out);
 }
+// Reads of more than STRL_DEVICE_READ_LEN bases (extract.nim:36-40 scores any length; the reference's uint8 histograms wrap,
+// utils.nim:192-195): behind the batch's launches the device lists them (index, row, skipped or not), packs their SEQ bytes,
+// the host twin of the scorer (host_score.cpp) scores them on a few threads, and two small launches put the words where the
+// kernels would have put them -- whole[], the Bloom mark, soft-clip records behind the device's own.  Synchronises the stream:
+// only batches that hold such a read pay for it.
+namespace strl {
+__global__ void long_scan_kernel(const uint4 *meta, const uint32_t *whole, uint32_t n, uint4 *out, uint32_t *cnt) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4 m = meta[i];
+  if ((m.y & 0xffffu) <= (uint32_t)STRL_DEVICE_READ_LEN) return;
+  const uint32_t k = atomicAdd(cnt, 1u);
+  out[k] = make_uint4(i | ((whole[i] & STRL_RES_SKIPPED) ? 0x80000000u : 0u), m.x, m.y, m.z);
+}
+// one wave per listed read: its SEQ bytes to off[k] of a dense buffer, as dwords (slots and offsets are 16-byte aligned)
+__global__ __launch_bounds__(64) void long_gather_kernel(const uint8_t *seq4, const uint4 *list, const uint64_t *off, uint8_t *out) {
+  const uint4 e = list[blockIdx.x];
+  const uint32_t nb = ((e.z & 0xffffu) + 1u) / 2u, nd = (nb + 3u) / 4u;
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(seq4 + (uint64_t)e.y * 16u);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(out + off[blockIdx.x]);
+  for (uint32_t j = threadIdx.x; j < nd; j += 64u) dst[j] = src[j];
+}
+__global__ void long_patch_kernel(const uint32_t *ids, const uint32_t *words, uint32_t n, uint32_t *whole, const uint64_t *qhash, uint32_t *bloom, uint32_t bloom_mask) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t id = ids[k], w = words[k];
+  whole[id] = w;
+  if (bloom && STRL_RES_COUNT(w)) bloom_set(bloom, bloom_mask, fmix64(qhash[id]));
+}
+__global__ __launch_bounds__(1024) void long_soft_kernel(const strl_soft_rec *src, uint32_t n, strl_soft_rec *dst, uint32_t cap, uint32_t *counters) {
+  __shared__ uint32_t base_sh;
+  if (threadIdx.x == 0) base_sh = atomicAdd(&counters[CNT_SOFT], n);     // (one block, behind the segment scorer: the only writer now)
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+    if (base_sh + i < cap) dst[base_sh + i] = src[i];
+}
+}  // namespace strl
+
+static int long_reads_pass(strl_ctx *c, const ScoreParams &P, uint64_t scap) {
+  const uint32_t n = (uint32_t)P.n;
+  int rc;
+  if ((rc = c->long_list.reserve((size_t)n * 16 + 64))) return rc;
+  uint32_t *cnt = c->long_list.as<uint32_t>() + (size_t)n * 4;            // the counter behind the list
+  STRL_HIP(hipMemsetAsync(cnt, 0, 4, c->stream));
+  hipLaunchKernelGGL(strl::long_scan_kernel, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, P.meta, P.whole, n, c->long_list.as<uint4>(), cnt);
+  STRL_HIP(hipGetLastError());
+  uint32_t n_long = 0;
+  STRL_HIP(hipMemcpyAsync(&n_long, cnt, 4, hipMemcpyDeviceToHost, c->stream));
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  if (!n_long) return STRL_OK;
+  std::vector<uint4> list(n_long);
+  STRL_HIP(hipMemcpy(list.data(), c->long_list.p, (size_t)n_long * 16, hipMemcpyDeviceToHost));
+  std::vector<uint64_t> off((size_t)n_long + 1);
+  uint64_t total = 0;
+  for (uint32_t k = 0; k < n_long; ++k) { off[k] = total; total += ((((list[k].z & 0xffffu) + 1u) / 2u) + 15u) & ~15ull; }
+  off[n_long] = total;
+  if ((rc = c->long_seq.reserve((size_t)total + (size_t)(n_long + 1) * 8 + 64))) return rc;
+  uint64_t *d_off = reinterpret_cast<uint64_t *>(c->long_seq.as<uint8_t>() + total);      // (total is a multiple of 16)
+  STRL_HIP(hipMemcpyAsync(d_off, off.data(), (size_t)(n_long + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(strl::long_gather_kernel, dim3(n_long), dim3(64), 0, c->stream, P.seq4, c->long_list.as<uint4>(), d_off, c->long_seq.as<uint8_t>());
+  STRL_HIP(hipGetLastError());
+  std::vector<uint8_t> seq((size_t)total + 16);
+  STRL_HIP(hipMemcpyAsync(seq.data(), c->long_seq.p, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  std::vector<uint32_t> ids(n_long), words(n_long);
+  std::vector<strl_soft_rec> soft((size_t)n_long * 2);
+  std::vector<uint8_t> n_soft(n_long, 0);
+  const strl_opts o = c->opts;
+  auto run = [&](uint32_t k0, uint32_t k1) {
+    for (uint32_t k = k0; k < k1; ++k) {
+      const uint4 e = list[k];
+      const uint32_t id = e.x & 0x7fffffffu;
+      int ns = 0;
+      uint32_t w = 0;
+      strl::host_score_long_read(seq.data() + off[k], e.z & 0xffffu, e.z >> 16, e.w & 0xffffu, (e.w >> 16) & 0xffu, e.w >> 24, o, (e.x >> 31) != 0, id, w, &soft[(size_t)k * 2], ns);
+      ids[k] = id;
+      words[k] = (e.x >> 31) ? (uint32_t)STRL_RES_SKIPPED : w;
+      n_soft[k] = (uint8_t)ns;
+    }
+  };
+  const uint32_t workers = (uint32_t)std::min<uint64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), n_long / 64 + 1);
+  if (workers <= 1) run(0, n_long);
+  else {
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < workers; ++t) th.emplace_back(run, (uint32_t)((uint64_t)n_long * t / workers), (uint32_t)((uint64_t)n_long * (t + 1) / workers));
+    for (auto &t : th) t.join();
+  }
+  std::vector<strl_soft_rec> dense;
+  for (uint32_t k = 0; k < n_long; ++k)
+    for (int q = 0; q < n_soft[k]; ++q) dense.push_back(soft[(size_t)k * 2 + q]);
+  const size_t b_ids = ((size_t)n_long * 4 + 15) & ~(size_t)15, b_soft = dense.size() * sizeof(strl_soft_rec);
+  if ((rc = c->long_seq.reserve(2 * b_ids + b_soft + 64))) return rc;
+  uint8_t *base = c->long_seq.as<uint8_t>();
+  STRL_HIP(hipMemcpyAsync(base, ids.data(), (size_t)n_long * 4, hipMemcpyHostToDevice, c->stream));
+  STRL_HIP(hipMemcpyAsync(base + b_ids, words.data(), (size_t)n_long * 4, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(strl::long_patch_kernel, dim3((n_long + 255u) / 256u), dim3(256), 0, c->stream, reinterpret_cast<const uint32_t *>(base),
+                     reinterpret_cast<const uint32_t *>(base + b_ids), n_long, P.whole, P.qhash, P.bloom, P.bloom_mask);
+  STRL_HIP(hipGetLastError());
+  if (!dense.empty() && scap && P.soft_out) {
+    STRL_HIP(hipMemcpyAsync(base + 2 * b_ids, dense.data(), b_soft, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(strl::long_soft_kernel, dim3(1), dim3(1024), 0, c->stream, reinterpret_cast<const strl_soft_rec *>(base + 2 * b_ids), (uint32_t)dense.size(), P.soft_out,
+                       (uint32_t)std::min<uint64_t>(scap, P.soft_cap), P.counters);
+    STRL_HIP(hipGetLastError());
+  }
+  STRL_HIP(hipStreamSynchronize(c->stream));       // (the host vectors above are the copies' sources)
+  return STRL_OK;
+}
+
 static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, strl_soft_rec *soft, uint64_t soft_cap,
                         uint64_t *n_soft, strl_score_stats *stats, bool sync_counts, const strl_pair_soa *pp = nullptr,
                         bool fresh_bloom = true, bool side_busy_ok = false) {
@@ -1127,6 +1240,9 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
   if (!side_busy_ok) { const int rcj = side_join(c); if (rcj) return rcj; }
   if (n > 0x3fffffffull) { set_error("batch too large (%llu reads; limit 2^30-1)", (unsigned long long)n); return STRL_ERR_ARG; }
   if (s->max_l_seq > STRL_MAX_READ_LEN) { set_error("read of %u bases exceeds STRL_MAX_READ_LEN=%d", s->max_l_seq, STRL_MAX_READ_LEN); return STRL_ERR_ARG; }
+  // reads of more than STRL_DEVICE_READ_LEN bases: the kernels pass them by, the host twin scores them behind the launches
+  const bool long_reads = s->max_l_seq > (uint32_t)STRL_DEVICE_READ_LEN;
+  const uint32_t class_l = std::min<uint32_t>(s->max_l_seq, STRL_DEVICE_READ_LEN);
   int rc;
   const uint64_t n1 = std::max<uint64_t>(n, 1);
   const uint64_t scap = std::max<uint64_t>(std::min<uint64_t>(soft_cap, 2 * n), 1);
@@ -1184,16 +1300,17 @@ static int score_device(strl_ctx *c, const strl_read_soa *s, uint32_t *whole, st
     STRL_HIP(hipGetLastError());
   }
   if (tev) STRL_HIP(hipEventRecord(tev[1], c->stream));
-  if (n) { if ((rc = launch_score_class<0>(c, P, s->max_l_seq, tev ? tev + 2 : nullptr))) return rc; }
+  if (n) { if ((rc = launch_score_class<0>(c, P, class_l, tev ? tev + 2 : nullptr))) return rc; }
   else if (tev) { STRL_HIP(hipEventRecord(tev[2], c->stream)); STRL_HIP(hipEventRecord(tev[3], c->stream)); }
   if (tev) STRL_HIP(hipEventRecord(tev[4], c->stream));
   if (n && soft_cap) {
     hipLaunchKernelGGL(soft_compact_kernel, dim3(1024), dim3(1024), 0, c->stream, P);
     STRL_HIP(hipGetLastError());
     if (tev) STRL_HIP(hipEventRecord(tev[5], c->stream));
-    if ((rc = launch_score_class<1>(c, P, s->max_l_seq, tev ? tev + 6 : nullptr))) return rc;
+    if ((rc = launch_score_class<1>(c, P, class_l, tev ? tev + 6 : nullptr))) return rc;
   } else if (tev) { for (int k = 5; k <= 7; ++k) STRL_HIP(hipEventRecord(tev[k], c->stream)); }
   if (tev) STRL_HIP(hipEventRecord(tev[8], c->stream));
+  if (n && long_reads && (rc = long_reads_pass(c, P, soft_cap ? scap : 0))) return rc;
   if (sync_counts) {
     uint32_t raw[CNT_WORDS];
     STRL_HIP(hipMemcpyAsync(raw, c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1751,7 +1868,7 @@ static int front_fill_done(strl_ctx *c, strl::FrontSlot &S, strl_front_chunk *do
   STRL_HIP(hipEventSynchronize(S.ev_b));
   S.b_pending = false;
   const strl::FrontInfo &I = S.h_info[1];
-  if (I.err & strl::FRONT_ERR_LSEQ) { set_error("a record's l_seq is outside [0, %d]", STRL_MAX_READ_LEN); return STRL_ERR_ARG; }
+  if (I.err & strl::FRONT_ERR_LSEQ) { set_error("a record's l_seq is outside [0, %d]", STRL_MAX_READ_LEN); return STRL_ERR_ARG; }   // (kept: stage B refuses the chunk before the parse)
   if (done) {
     done->n_records = I.n_records; done->n_primary = I.n_primary; done->last_placed = I.last_placed; done->tail_primary = I.tail_primary;
     done->max_l_seq = I.max_l_seq; done->scan_slow_segments = I.slow_segments;
@@ -1802,7 +1919,7 @@ static int front_stage_b(strl_ctx *c, strl::strl_front *F, int si) {
   const uint64_t n = I.n_records, at = c->x_n;
   if (at + n > strl_record_limit()) { set_error("chunked extract: more than %llu records in one device pass", (unsigned long long)strl_record_limit()); return STRL_ERR_LIMIT; }
   if (I.max_l_seq > (uint32_t)STRL_MAX_READ_LEN) { set_error("a record's l_seq %u is outside [0, %d]", I.max_l_seq, STRL_MAX_READ_LEN); return STRL_ERR_ARG; }
-  int rc;
+  int rc;       // (records of STRL_DEVICE_READ_LEN < l_seq <= STRL_MAX_READ_LEN bases: scored by the host twin inside score_device)
   const uint64_t n1 = std::max<uint64_t>(n, 1);
   if (F->big && (F->big->done.load(std::memory_order_acquire) || at + n1 > F->small_reads || F->qarena_used + I.qname_bytes + 16 > F->qarena.cap) && (rc = front_adopt_big(c, F, at))) return rc;
   if ((rc = c->x_rows.grow((size_t)(at + n1) * sizeof(strl_pair_rec), (size_t)at * sizeof(strl_pair_rec), c->stream)) ||

@@ -105,3 +105,23 @@ def test_tok3_refuses_damage_and_arith(tmp_path):
     b[8] = 1                                         # "streams use the arithmetic coder"
     r, _ = _decode("tok3", bytes(b), len(want), tmp_path)
     assert r.returncode == 1 and "arithmetic coder" in r.stderr
+
+
+def test_tok3_hostile_header_is_an_error_not_an_abort(tmp_path):
+    """round-5 advisor: a 9-byte name tokeniser payload that claims 2^32 - 1 names sized three vectors by that count
+    (std::bad_alloc, process aborted); a token stream that claims a gigabyte from a few bytes likewise.  Both are refused."""
+    import struct
+    r, _ = _decode("tok3", struct.pack("<IIB", 10, 0xFFFFFFFF, 0), 10, tmp_path)
+    assert r.returncode == 1 and "more names than bytes" in r.stderr, (r.returncode, r.stderr[-200:])
+    # one token position whose TYPE stream is a stored (CAT) rANS Nx16 stream claiming 2^29 bytes
+    def u7(v):
+        out = [v & 0x7f]
+        v >>= 7
+        while v:
+            out.insert(0, (v & 0x7f) | 0x80)
+            v >>= 7
+        return bytes(out)
+    stream = bytes([0x20]) + u7(1 << 29) + b"\0" * 8
+    payload = struct.pack("<IIB", 40, 2, 0) + bytes([0x80 | 0]) + u7(len(stream)) + stream
+    r, _ = _decode("tok3", payload, 40, tmp_path)
+    assert r.returncode == 1 and "malformed" in r.stderr, (r.returncode, r.stderr[-200:])
