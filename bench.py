@@ -29,7 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-PROFILE_ROUND = "r05"     # profiles/<round>/traffic.json, pmc_counters.json: the PMC passes the roofline block quotes
+# profiles/<round>/traffic.json, pmc_counters.json: the PMC passes the roofline block quotes -- this round's when they were collected
+PROFILE_ROUND = next((r for r in ("r06", "r05") if os.path.exists(os.path.join(ROOT, "profiles", r, "traffic.json"))), "r06")
 
 
 def main():
@@ -407,6 +408,7 @@ def main():
                        "parallelism": (f"records sharded over {world} GPU(s), no data-path collective" if exchange is None else
                                        f"records sharded over {world} GPUs; per step one RCCL all-gather of the tread arrays [{type(exchange).__name__}] "
                                        f"({exchange.pad * 32} B per rank) before clustering, every rank clusters the (tid, unit) groups it owns")},
+            "build": build_info(),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_nproc": cpu_nproc, "cpu_baseline_e2e": cpu_e2e, "end_to_end": e2e, "quoted_not_measured_end_to_end_full_size": e2e_full,
         }
         print(json.dumps(out))
@@ -505,29 +507,91 @@ def pick_e2e_pairs(world):
     has the room and the cores to write it in ~8 minutes; else 2^26 pairs"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import e2e_bench
-    if world > 1 or os.environ.get("BENCH_E2E_SMALL"):
+    if os.environ.get("BENCH_E2E_SMALL"):
         return 2 ** 26
+    # (N > 1 takes the same full-size file: the 1.3e8-read one is start-up bound even on one GPU -- a curve over it would measure
+    # process start, not the shares.  The file is cached in the work directory: a 1 / 2 / 4 / 8 sweep on one node writes it once.)
     cpus = _cpu_quota() or (os.cpu_count() or 1)
     d = e2e_bench.work_dir(2 ** 28 * 2 * 115)
     st = os.statvfs(d)
     return 2 ** 28 if (st.f_bavail * st.f_frsize >= 75e9 and cpus >= 12) else 2 ** 26
 
 
-def end_to_end(n_pairs, check_slabs=4, gpus=1):
+def end_to_end(n_pairs, check_slabs=0, gpus=1):
     """`strling extract` -> .bin -> `strling call` and `strling merge`, from a coordinate-sorted, indexed BAM of 2 * n_pairs distinct
     reads (zlib level 6, binned random qualities, aux tags) written to local disk / shm (page cache warm): wall clock of whole
-    processes, all host threads; a share of the outputs checked against the oracle (tools/e2e_bench.py)."""
+    processes, all host threads; a share of the outputs checked against the oracle (tools/e2e_bench.py).  gpus > 1: the same
+    with `--gpus N` (one process, a share of the file per device), the host feed alone, N concurrent per-sample replicas
+    (`--device k`), and the strong scaling against the N = 1 figures kept beside the cached input."""
     from strling_amd import build
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import e2e_bench
     inp = e2e_bench.make_input(n_pairs)
+    full = inp["reads"] >= 5e8
+    check_slabs = check_slabs or (16 if full else 4)      # 16 of 1024 slabs at the headline size (~10 s), 4 of 256 below it
     try:
         res = e2e_bench.run(inp, build.CLI, repeats=2, gpus=gpus)      # the first process behind the writer reads a cold file
+        res["input_reused_from_cache"] = bool(inp.get("reused_cached_input"))
+        if "error" not in res:
+            if gpus == 1:
+                e2e_bench.n1_record(inp, res)
+            else:
+                n1 = e2e_bench.n1_record(inp)
+                if n1 and n1.get("extract_s") and n1.get("reads") == inp["reads"]:
+                    res["strong_scaling_vs_n1"] = {"n1_extract_s": n1["extract_s"], "wall": round(n1["extract_s"] / res["extract_s"], 3),
+                                                   "loop": round(res["reads_per_s_loop"] / n1["reads_per_s_loop"], 3) if res.get("reads_per_s_loop") and n1.get("reads_per_s_loop") else None,
+                                                   "note": "this run's `extract --gpus N` against the N = 1 run of the same cached file on this node (wall: whole processes; loop: inside the loop)"}
+                try:
+                    res["feed_only"] = e2e_bench.feed_only(inp, build.CLI, gpus)
+                except Exception as e:
+                    res["feed_only"] = {"error": str(e)[:200]}
+                try:
+                    res["replicas"] = e2e_bench.replicas(inp, build.CLI, gpus, _visible_devices())
+                except Exception as e:
+                    res["replicas"] = {"error": str(e)[:200]}
         if check_slabs and "error" not in res:
             res["check"] = e2e_bench.check_in_subprocess(inp, e2e_bench.pick_slabs(inp["n_slabs"], check_slabs), call=res.get("call_rc") == 0)
         return res
     finally:
-        e2e_bench.cleanup(inp)
+        # the input stays cached for the next N of a sweep / the next run, unless BENCH_E2E_CLEAN=1
+        e2e_bench.cleanup(inp, keep_input=not os.environ.get("BENCH_E2E_CLEAN"))
+
+
+def _visible_devices():
+    """GPUs this process may use, WITHOUT starting the HIP runtime in it (the generators fork later): rocm-smi / the env"""
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(k)
+        if v:
+            return max(1, len([x for x in v.split(",") if x.strip()]))
+    try:
+        return max(1, len([d for d in os.listdir("/sys/class/kfd/kfd/topology/nodes")
+                           if int(open(f"/sys/class/kfd/kfd/topology/nodes/{d}/properties").read().split("simd_count")[1].split()[0]) > 0]))
+    except Exception:
+        return 1
+
+
+def build_info():
+    """what the line was measured on: the compiler that built the library, whether the shipped .so is newer than its sources"""
+    from strling_amd import build as b
+    info = {"lib": os.path.relpath(b.LIB, ROOT)}
+    try:
+        info["lib_mtime"] = int(os.path.getmtime(b.LIB))
+        new = []
+        for target, names in ((b.LIB, b.SOURCES + b.HEADERS), (b.CLI, b.CLI_SOURCES + b.HEADERS)):
+            for s_ in names:
+                src = os.path.join(b.CSRC, s_)
+                if os.path.exists(src) and os.path.exists(target) and os.path.getmtime(src) > os.path.getmtime(target):
+                    new.append(os.path.relpath(src, ROOT))
+        info["sources_newer_than_their_binary"] = sorted(set(new))      # empty: build() had nothing to recompile
+        info["with_inflate_group"] = b.WITH_INFLATE_GROUP
+    except Exception as e:
+        info["error"] = str(e)[:100]
+    try:
+        v = subprocess.run([b._hipcc(), "--version"], capture_output=True, text=True, timeout=30).stdout.splitlines()
+        info["hipcc"] = "; ".join(l.strip() for l in v[:2])
+    except Exception as e:
+        info["hipcc"] = f"unavailable ({str(e)[:60]})"
+    return info
 
 
 if __name__ == "__main__":

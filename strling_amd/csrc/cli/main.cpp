@@ -34,6 +34,16 @@
 using namespace strl;
 
 static std::thread *g_bg_init = nullptr;   // device bring-up running beside the first host pass; exit() waits for it
+static std::function<void()> g_bg_abort;   // ... after telling it to stop waiting for what the quitting thread will never publish
+// --device K (or STRL_DEVICE=K): the device the first context of this process sits on; --gpus N takes K, K + 1, ... (mod the
+// devices there are).  A pipeline that runs one `strling` process per sample (pipelines/bpipe.config:4) gives every process its
+// own GPU this way.
+static int g_device0 = 0;
+static void set_device0(const std::string &v) {
+  const char *e = getenv("STRL_DEVICE");
+  g_device0 = std::max(0, atoi(!v.empty() ? v.c_str() : (e ? e : "0")));
+}
+static int device_of(int g) { return (g_device0 + g) % std::max(1, strl_device_count()); }
 
 [[noreturn]] static void quit(const char *fmt, ...) {   // Nim `quit msg`: message on stderr, exit code 1
   va_list ap;
@@ -41,6 +51,7 @@ static std::thread *g_bg_init = nullptr;   // device bring-up running beside the
   vfprintf(stderr, fmt, ap);
   va_end(ap);
   fputc('\n', stderr);
+  if (g_bg_abort) g_bg_abort();
   if (g_bg_init && g_bg_init->joinable() && g_bg_init->get_id() != std::this_thread::get_id()) g_bg_init->join();
   exit(1);
 }
@@ -284,7 +295,9 @@ static Genome read_genome_bed(const std::string &path, const std::vector<BamTarg
 
 // genome_repeats, genome_strs.nim:107-146: existing file, or build it from the FASTA (into a temporary file when
 // no -g was given).  An existing -g is accepted without -f here; the reference insists on opening the FASTA first.
-static void setup_genome(strl_ctx *ctx, const Args &a, const std::vector<BamTarget> &targets, const std::vector<strl_ctx *> &more = {}) {
+// The host half: the table read and flattened per tid.  `need_ctx` hands over a context when the table has to be BUILT (the
+// window scorer runs on the device); with an existing file no device is touched.
+template <typename F> static Genome genome_host_half(const Args &a, const std::vector<BamTarget> &targets, F need_ctx) {
   std::string bed_path = a.get("genome-repeats", "");
   const bool is_tmp = bed_path.empty();
   if (is_tmp) {
@@ -293,13 +306,18 @@ static void setup_genome(strl_ctx *ctx, const Args &a, const std::vector<BamTarg
   }
   if (is_tmp || !file_exists(bed_path)) {
     if (!a.flag("fasta")) quit("[strling] couldn't open fasta %s make sure file is present and has a .fai index", a.get("fasta", "").c_str());
+    strl_ctx *ctx = need_ctx();                  // (with its options set: the window scorer reads -p)
     build_genome_index(ctx, a.get("fasta", ""), bed_path);
   } else {
     fprintf(stderr, "[strling] using existing file %s for genome repeats\n", bed_path.c_str());
   }
-  const Genome g = read_genome_bed(bed_path, targets);
+  Genome g = read_genome_bed(bed_path, targets);
   fprintf(stderr, "[strling] got STR repeats from genome into an interval tree\n");
   if (is_tmp) remove(bed_path.c_str());
+  return g;
+}
+static void setup_genome(strl_ctx *ctx, const Args &a, const std::vector<BamTarget> &targets, const std::vector<strl_ctx *> &more = {}) {
+  const Genome g = genome_host_half(a, targets, [&] { return ctx; });
   strl_genome_str gs{(int32_t)targets.size(), g.has.data(), g.off.data(), g.st.data(), g.en.data()};
   CHECK(strl_ctx_set_genome(ctx, &gs));
   for (strl_ctx *m : more) CHECK(strl_ctx_set_genome(m, &gs));
@@ -315,12 +333,14 @@ static int extract_main(int argc, char **argv) {
       "  -g, --genome-repeats=GENOME_REPEATS\n                             optional path to genome repeats file. if it does not exist, it will be created\n"
       "  -p, --proportion-repeat=PROPORTION_REPEAT\n                             proportion of read that is repetitive to be considered as STR (default: 0.8)\n"
       "  -q, --min-mapq=MIN_MAPQ    minimum mapping quality (does not apply to STR reads) (default: 40)\n"
-      "  --gpus=N                   spread the file's chunks over N GPUs (inflate, parse and scoring there; the pair logic on the first) (default: 1)\n"
+      "  --gpus=N                   spread the file over N GPUs (a contiguous share each: inflate, parse and scoring there; the pair logic on the first) (default: 1)\n"
+      "  --device=K                 the GPU this process uses (the first of --gpus N) (default: 0; STRL_DEVICE)\n"
       "  -v, --verbose\n  -h, --help                 Show this help\n";
   if (argc <= 2) { fputs(usage, stdout); return 0; }
   const Args a = parse(argc, argv, 2, {{"fasta", 'f', true}, {"genome-repeats", 'g', true}, {"proportion-repeat", 'p', true},
-                                       {"min-mapq", 'q', true}, {"verbose", 'v', false}, {"batch", 'B', true}, {"gpus", 'G', true}}, usage);
+                                       {"min-mapq", 'q', true}, {"verbose", 'v', false}, {"batch", 'B', true}, {"gpus", 'G', true}, {"device", 'D', true}}, usage);
   if (a.pos.size() != 2) quit("expected 2 arguments (bam, bin)\n%s", usage);
+  set_device0(a.get("device", ""));
   const std::string bam = a.pos[0], bin = a.pos[1];
   const double p = atof(a.get("proportion-repeat", "0.8").c_str());
   const uint8_t min_mapq = (uint8_t)atoi(a.get("min-mapq", "40").c_str());
@@ -353,7 +373,7 @@ static int extract_main(int argc, char **argv) {
   int ctx_rc = 0;
   std::string ctx_err;
   std::thread ctx_thread([&] {
-    ctx_rc = strl_ctx_create(0, &ctx);
+    ctx_rc = strl_ctx_create(device_of(0), &ctx);
     if (ctx_rc) ctx_err = strl_last_error();     // (the error text is thread-local in the library)
   });
   g_bg_init = &ctx_thread;
@@ -657,43 +677,92 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     for (auto &t : each) t.join();
     t_pin = secs(c0, now());
   });
-  std::thread ctx_thread([&] {
-    const auto c0 = now();
-    const int n_dev = std::max(1, strl_device_count());
-    // One after the other (0.1 - 0.2 s each).  STRL_PARALLEL_CTX=1 creates the contexts behind the first side by side: measured
-    // once on one device, where a run of the test suite then hung in a later test -- not taken by default until it has run
-    // on a node with a device per context.
-    static const bool par = getenv("STRL_PARALLEL_CTX") != nullptr;
-    auto make = [&](int g) {
-      ctx_rc[(size_t)g] = strl_ctx_create(g % n_dev, &ctxs[(size_t)g]);
-      if (ctx_rc[(size_t)g]) ctx_err[(size_t)g] = strl_last_error();
+  // Bring-up, one thread per context, side by side (round 6; before: one after the other, 0.1 - 0.2 s each, then options, genome
+  // table and per-read state of every context in turn on the main thread -- more than a second of fixed cost at 8 contexts):
+  //   create the context (the first HIP call of the process starts the runtime: one thread does that alone, the others wait
+  //   for it and then run side by side) -> options -> [the genome table's host half is ready] -> genome table -> [the file's
+  //   header is walked, the shares are cut] -> per-read state + front-end buffers of THIS context.
+  // The main thread walks the header and parses the BED meanwhile and only waits where it needs a context.
+  // STRL_SERIAL_CTX=1: the contexts one after the other, as before.
+  strl_opts opts{0, p, min_mapq};              // the fragment-length median is only needed by the pair logic: set before strl_extract_finish
+  struct BringUp {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool runtime_up = false, genome_ready = false, plan_ready = false, give_up = false;
+    std::vector<uint8_t> created, done;
+    strl_genome_str gs{};
+    int32_t n_ref = 0;
+    std::vector<uint64_t> first_off, hint;
+    std::vector<double> t_create, t_state;
+  } bu;
+  bu.created.assign((size_t)G, 0); bu.done.assign((size_t)G, 0);
+  bu.first_off.assign((size_t)G, 0); bu.hint.assign((size_t)G, 0);
+  bu.t_create.assign((size_t)G, 0.0); bu.t_state.assign((size_t)G, 0.0);
+  static const bool serial_ctx = getenv("STRL_SERIAL_CTX") != nullptr;
+  auto bring_up = [&](int g) {
+    auto wait_for = [&](auto pred) {             // -> false: the main thread gave up (an error exit is under way)
+      std::unique_lock<std::mutex> lk(bu.mu);
+      bu.cv.wait(lk, [&] { return pred() || bu.give_up; });
+      return !bu.give_up;
     };
-    make(0);
-    if (!ctx_rc[0] && par) {
-      std::vector<std::thread> more;
-      for (int g = 1; g < G; ++g) more.emplace_back(make, g);
-      for (auto &t : more) t.join();
-    } else {
-      for (int g = 1; g < G && !ctx_rc[(size_t)g - 1]; ++g) make(g);
+    auto finish = [&](int rc) {
+      if (rc) { ctx_rc[(size_t)g] = rc; ctx_err[(size_t)g] = strl_last_error(); }
+      { std::lock_guard<std::mutex> lk(bu.mu); bu.created[(size_t)g] = 1; bu.done[(size_t)g] = 1; bu.runtime_up = true; }
+      bu.cv.notify_all();
+    };
+    if (g > 0 && !wait_for([&] { return serial_ctx ? bu.created[(size_t)g - 1] != 0 : bu.runtime_up; })) return finish(0);
+    const auto c0 = now();
+    if (g == 0) {
+      (void)strl_device_count();               // the runtime starts here, on one thread
+      { std::lock_guard<std::mutex> lk(bu.mu); bu.runtime_up = true; }
+      bu.cv.notify_all();
     }
-    t_ctx = secs(c0, now());
-  });
-  g_bg_init = &ctx_thread;
+    int rc = strl_ctx_create(device_of(g), &ctxs[(size_t)g]);
+    bu.t_create[(size_t)g] = secs(c0, now());
+    if (rc) return finish(rc);
+    strl_ctx *c = ctxs[(size_t)g];
+    if ((rc = strl_ctx_set_opts(c, &opts))) return finish(rc);
+    if (G > 1 && (rc = strl_ctx_blocking_waits(c, 1))) return finish(rc);       // N feeding threads: waits sleep instead of spinning
+    { std::lock_guard<std::mutex> lk(bu.mu); bu.created[(size_t)g] = 1; }       // (usable: created, options set)
+    bu.cv.notify_all();
+    if (!wait_for([&] { return bu.genome_ready; })) return finish(0);
+    if ((rc = strl_ctx_set_genome(c, &bu.gs))) return finish(rc);
+    if (!wait_for([&] { return bu.plan_ready; })) return finish(0);
+    const auto c1 = now();
+    rc = strl_front_begin(c, bu.n_ref, bu.first_off[(size_t)g], bu.hint[(size_t)g]);
+    if (!rc) rc = strl_front_reserve(c, (uint32_t)chunk_blocks, chunk_bytes);
+    bu.t_state[(size_t)g] = secs(c1, now());
+    finish(rc);
+  };
+  std::vector<std::thread> bring_threads;
+  for (int g = 0; g < G; ++g) bring_threads.emplace_back(bring_up, g);
+  // (an error exit -- quit() -- first tells the bring-up threads to give up where they wait, then waits for ONE background
+  // thread: this one, which collects them all, so that no thread is inside the HIP runtime when the exit handlers run)
+  std::thread reaper([&] { for (auto &t : bring_threads) t.join(); });
+  g_bg_init = &reaper;
+  g_bg_abort = [&bu] { { std::lock_guard<std::mutex> lk(bu.mu); bu.give_up = true; } bu.cv.notify_all(); };
   BgzfFeed feed;
   std::string err;
   const bool opened = feed.open(bam, err);
-  ctx_thread.join();
-  pin_thread.join();
-  g_bg_init = nullptr;
   if (!opened) quit("couldn't open bam");
-  for (int g = 0; g < G; ++g) if (ctx_rc[(size_t)g]) quit("[strling] %s (status %d)", ctx_err[(size_t)g].c_str(), ctx_rc[(size_t)g]);
-  for (size_t k = 0; k < pin.size(); ++k) if (!pin[k] || !pin_meta[k]) quit("[strling] could not allocate page-locked memory");
-  strl_ctx *ctx = ctxs[0];
   const double t_open = secs(t_start, now());
-  strl_opts opts{0, p, min_mapq};              // the fragment-length median is only needed by the pair logic: set before strl_extract_finish
-  for (strl_ctx *c : ctxs) CHECK(strl_ctx_set_opts(c, &opts));
+  // the genome table's host half (the BED read and flattened per tid; built from the FASTA on the first context when there is none)
   const auto tg0 = now();
-  setup_genome(ctx, a, feed.targets(), std::vector<strl_ctx *>(ctxs.begin() + 1, ctxs.end()));
+  auto wait_created = [&](int g) {
+    std::unique_lock<std::mutex> lk(bu.mu);
+    bu.cv.wait(lk, [&] { return bu.created[(size_t)g] != 0; });
+  };
+  const Genome genome = genome_host_half(a, feed.targets(), [&]() -> strl_ctx * {
+    wait_created(0);
+    if (ctx_rc[0]) quit("[strling] %s (status %d)", ctx_err[0].c_str(), ctx_rc[0]);
+    return ctxs[0];
+  });
+  {
+    std::lock_guard<std::mutex> lk(bu.mu);
+    bu.gs = strl_genome_str{(int32_t)feed.targets().size(), genome.has.data(), genome.off.data(), genome.st.data(), genome.en.data()};
+    bu.genome_ready = true;
+  }
+  bu.cv.notify_all();
   const double t_genome = secs(tg0, now());
   const int32_t n_ref = (int32_t)feed.targets().size();
   // Reads the per-read state is sized for at the start (it grows geometrically beyond): a record of 150 bases with qualities
@@ -701,7 +770,6 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   // 124 GB of device memory and seconds of set-up for a 57 GB file of 5.4e8 reads.)
   static const char *env_hint = getenv("STRL_READS_HINT");
   const uint64_t reads_hint = env_hint ? strtoull(env_hint, nullptr, 10) : feed.file_bytes() / 88 / (size_t)G;
-  const auto tb0 = now();
   // Shares of the file, one per context: [cut[g], cut[g + 1]) in virtual offsets, every cut a record start the .bai names
   // (the one nearest to g / G of the bytes behind the header).  extract.nim:308-329 is one loop over the file in file order;
   // the shares are gathered in that order afterwards (strl_ctxs_extract_gather), so nothing downstream can tell.
@@ -714,21 +782,49 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     }
   }
   const int n_shares = use_shares ? (int)cut.size() : 0;
-  for (size_t g = 0; g < ctxs.size(); ++g) {
-    strl_ctx *c = ctxs[g];
-    if (G > 1) CHECK(strl_ctx_blocking_waits(c, 1));       // N feeding threads: waits sleep instead of spinning
-    // (shares: the first context is sized for the whole file -- the other shares' per-read state is appended to its own in the end)
-    int brc = strl_front_begin(c, n_ref, use_shares && g < cut.size() ? (cut[g] & 0xffff) : feed.first_record_offset(), use_shares && g == 0 ? reads_hint * (uint64_t)G : reads_hint);
-    if (!brc) brc = strl_front_reserve(c, (uint32_t)chunk_blocks, chunk_bytes);
-    if (brc == STRL_ERR_NOMEM) {
-      fprintf(stderr, "[strling] %s: repeating the extraction with the host pair logic\n", strl_last_error());
+  {
+    std::lock_guard<std::mutex> lk(bu.mu);
+    bu.n_ref = n_ref;
+    for (int g = 0; g < G; ++g) {
+      // (shares: the first context is sized for the whole file -- the other shares' per-read state is appended to its own in the end)
+      bu.first_off[(size_t)g] = use_shares && (size_t)g < cut.size() ? (cut[(size_t)g] & 0xffff) : feed.first_record_offset();
+      bu.hint[(size_t)g] = use_shares && g == 0 ? reads_hint * (uint64_t)G : reads_hint;
+    }
+    bu.plan_ready = true;
+  }
+  bu.cv.notify_all();
+  // everything below needs the contexts' buffers; the threads that feed a share only wait for THEIR context (below), the
+  // one-context loop for the one there is
+  auto wait_done = [&](int g) {
+    std::unique_lock<std::mutex> lk(bu.mu);
+    bu.cv.wait(lk, [&] { return bu.done[(size_t)g] != 0; });
+  };
+  bool brought_up = false;
+  double t_begin = 0;
+  auto bring_up_finish = [&]() -> int {        // -> 0, or EXTRACT_AGAIN_ON_HOST
+    if (brought_up) return 0;
+    brought_up = true;
+    const auto tb0 = now();
+    for (int g = 0; g < G; ++g) wait_done(g);
+    if (reaper.joinable()) reaper.join();
+    pin_thread.join();
+    g_bg_init = nullptr; g_bg_abort = nullptr;
+    t_begin = secs(tb0, now());
+    for (double v : bu.t_create) t_ctx = std::max(t_ctx, v);
+    bool nomem = false;
+    for (int g = 0; g < G; ++g) if (ctx_rc[(size_t)g] == STRL_ERR_NOMEM) nomem = true;
+    if (nomem) {
+      for (int g = 0; g < G; ++g) if (ctx_rc[(size_t)g] == STRL_ERR_NOMEM) { fprintf(stderr, "[strling] %s: repeating the extraction with the host pair logic\n", ctx_err[(size_t)g].c_str()); break; }
       for (size_t k = 0; k < pin.size(); ++k) { strl_pinned_free(pin[k]); strl_pinned_free(pin_meta[k]); }
-      for (strl_ctx *cc : ctxs) strl_ctx_destroy(cc);
+      for (strl_ctx *cc : ctxs) if (cc) strl_ctx_destroy(cc);
       return EXTRACT_AGAIN_ON_HOST;
     }
-    CHECK(brc);
-  }
-  const double t_begin = secs(tb0, now());
+    for (int g = 0; g < G; ++g) if (ctx_rc[(size_t)g]) quit("[strling] %s (status %d)", ctx_err[(size_t)g].c_str(), ctx_rc[(size_t)g]);
+    for (size_t k = 0; k < pin.size(); ++k) if (!pin[k] || !pin_meta[k]) quit("[strling] could not allocate page-locked memory");
+    return 0;
+  };
+  { const int br = bring_up_finish(); if (br) return br; }
+  strl_ctx *ctx = ctxs[0];
 
   fprintf(stderr, "[strling] collecting str-like reads\n");
   const auto t0 = now();
@@ -1183,9 +1279,13 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
       fprintf(stderr, "[strling] device memory in use at the end (all chunks' per-read state resident): %.2f GB of %.1f GB\n", (double)(mt - mf) / 1e9, (double)mt / 1e9);
   }
   if (verbose)
-    fprintf(stderr, "[strling] seconds before the loop: %.3f to the open context (device context %.3f, page-locked buffers %.3f: two threads beside the header walk), "
-                    "genome table %.3f, per-read state for %llu reads %.3f; writing the .bin %.3f; whole run %.3f\n", t_open, t_ctx, t_pin, t_genome, (unsigned long long)reads_hint, t_begin, t_write,
-            secs(t_start, now()));
+  {
+    double t_state = 0;
+    for (double v : bu.t_state) t_state = std::max(t_state, v);
+    fprintf(stderr, "[strling] seconds before the loop: header walk %.3f, genome table (host half) %.3f, then waiting for the bring-up threads %.3f -- beside all that, a thread "
+                    "per context: slowest context + its options %.3f, slowest per-read state for %llu reads + front-end buffers %.3f; page-locked buffers %.3f; writing the .bin %.3f; whole run %.3f\n",
+            t_open, t_genome, t_begin, t_ctx, (unsigned long long)reads_hint, t_state, t_pin, t_write, secs(t_start, now()));
+  }
   // the process ends here: the driver reclaims device and page-locked memory faster than freeing them piece by piece would
   // (STRL_TEARDOWN=1 frees them explicitly)
   if (getenv("STRL_TEARDOWN")) {
@@ -1330,7 +1430,8 @@ static int merge_main(int argc, char **argv) {
   if (argc <= 2) { fputs(usage, stdout); return 0; }
   const Args a = parse(argc, argv, 2, {{"fasta", 'f', true}, {"window", 'w', true}, {"min-support", 'm', true}, {"chromosome", 'C', true},
                                        {"min-clip", 'c', true}, {"min-clip-total", 't', true}, {"min-mapq", 'q', true}, {"bed", 'l', true},
-                                       {"output-prefix", 'o', true}, {"diff-refs", 'd', false}, {"verbose", 'v', false}, {"gpus", 'G', true}}, usage);
+                                       {"output-prefix", 'o', true}, {"diff-refs", 'd', false}, {"verbose", 'v', false}, {"gpus", 'G', true}, {"device", 'D', true}}, usage);
+  set_device0(a.get("device", ""));
   if (a.flag("bed") && !file_exists(a.get("bed", ""))) quit("couldn't open bed file");     // merge.nim:80-82
   const bool allow_diff = a.flag("diff-refs");
   std::vector<BamTarget> targets;
@@ -1361,7 +1462,7 @@ static int merge_main(int argc, char **argv) {
   strl_ctx *ctx_early = nullptr;
   int ctx_early_rc = 0;
   std::string ctx_early_err;
-  std::thread ctx_thread([&] { if (gpus_early == 1) { ctx_early_rc = strl_ctx_create(0, &ctx_early); if (ctx_early_rc) ctx_early_err = strl_last_error(); } });
+  std::thread ctx_thread([&] { if (gpus_early == 1) { ctx_early_rc = strl_ctx_create(device_of(0), &ctx_early); if (ctx_early_rc) ctx_early_err = strl_last_error(); } });
   g_bg_init = &ctx_thread;
   uint32_t frag[4096] = {0};
   hvec<strl_tread> all;                                 // (huge pages, uninitialised: strl_bin_read fills a sample's share on several threads)
@@ -1438,7 +1539,7 @@ static int merge_main(int argc, char **argv) {
     // back in the reference's order of the groups (first appearance, Nim table order: strl_group_order).
     const int n_dev = std::max(1, strl_device_count());
     std::vector<strl_ctx *> ctxs((size_t)gpus, nullptr);
-    for (int r = 0; r < gpus; ++r) CHECK(strl_ctx_create(r % n_dev, &ctxs[(size_t)r]));
+    for (int r = 0; r < gpus; ++r) CHECK(strl_ctx_create(device_of(r), &ctxs[(size_t)r]));
     CHECK(strl_ctxs_comm_init(ctxs.data(), gpus));
     const size_t per = (all.size() + (size_t)gpus - 1) / (size_t)gpus;
     for (int r = 0; r < gpus; ++r) {
@@ -1547,8 +1648,9 @@ static int call_main(int argc, char **argv) {
   if (argc <= 2) { fputs(usage, stdout); return 0; }
   const Args a = parse(argc, argv, 2, {{"fasta", 'f', true}, {"min-support", 'm', true}, {"min-clip", 'c', true}, {"min-clip-total", 't', true},
                                        {"min-mapq", 'q', true}, {"loci", 'l', true}, {"bounds", 'b', true}, {"output-prefix", 'o', true},
-                                       {"verbose", 'v', false}}, usage);
+                                       {"verbose", 'v', false}, {"device", 'D', true}}, usage);
   if (a.pos.size() != 2) quit("expected 2 arguments (bam, bin)\n%s", usage);
+  set_device0(a.get("device", ""));
   if (a.flag("loci") && !file_exists(a.get("loci", ""))) quit("couldn't open loci file");          // call.nim:81-87
   if (a.flag("bounds") && !file_exists(a.get("bounds", ""))) quit("couldn't open bounds file");
   const std::string bam = a.pos[0], bin = a.pos[1], prefix = a.get("output-prefix", "strling");
@@ -1566,7 +1668,7 @@ static int call_main(int argc, char **argv) {
   int ctx_rc = 0;
   std::string ctx_err;
   double t_up_ctx = 0, t_up_bin = 0, t_up_bam = 0;
-  std::thread ctx_thread([&] { ctx_rc = strl_ctx_create(0, &ctx); if (ctx_rc) ctx_err = strl_last_error(); t_up_ctx = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call0).count(); });
+  std::thread ctx_thread([&] { ctx_rc = strl_ctx_create(device_of(0), &ctx); if (ctx_rc) ctx_err = strl_last_error(); t_up_ctx = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call0).count(); });
   g_bg_init = &ctx_thread;
   strl_bin_info info;
   std::string hdr;

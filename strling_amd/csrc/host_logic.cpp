@@ -9,6 +9,7 @@
 #include <unistd.h>
 #include <sys/mman.h>
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -599,30 +600,10 @@ int strl_frag_median(const uint32_t frag[4096], double pct) {  // utils.nim:139-
   return 4096;
 }
 
-// ---- msgpack subset used by the .bin records (msgpack4nim picks the smallest encoding) ----------
-static void mp_uint(std::string &b, uint64_t v) {
-  if (v < 128) b.push_back((char)v);
-  else if (v < 256) { b.push_back((char)0xcc); b.push_back((char)v); }
-  else if (v < 65536) { b.push_back((char)0xcd); b.push_back((char)(v >> 8)); b.push_back((char)v); }
-  else { b.push_back((char)0xce); for (int s = 24; s >= 0; s -= 8) b.push_back((char)(v >> s)); }
-}
-static void mp_int(std::string &b, int32_t v) {
-  if (v >= 0) { mp_uint(b, (uint64_t)v); return; }
-  if (v >= -32) b.push_back((char)v);
-  else if (v >= -128) { b.push_back((char)0xd0); b.push_back((char)v); }
-  else if (v >= -32768) { b.push_back((char)0xd1); b.push_back((char)((uint16_t)v >> 8)); b.push_back((char)v); }
-  else { b.push_back((char)0xd2); const uint32_t u = (uint32_t)v; for (int s = 24; s >= 0; s -= 8) b.push_back((char)(u >> s)); }
-}
-static void mp_str(std::string &b, const char *p, size_t l) {
-  if (l < 32) b.push_back((char)(0xa0 | l));
-  else if (l < 256) { b.push_back((char)0xd9); b.push_back((char)l); }
-  else if (l < 65536) { b.push_back((char)0xda); b.push_back((char)(l >> 8)); b.push_back((char)l); }
-  else { b.push_back((char)0xdb); for (int s = 24; s >= 0; s -= 8) b.push_back((char)(l >> s)); }
-  b.append(p, l);
-}
-
+// ---- the .bin writer: msgpack subset of the records, msgpack4nim picks the smallest encoding of every value (cluster.nim:38-50) ----
 int strl_bin_write(const char *path, float proportion_repeat, uint8_t min_mapq, const uint32_t frag[4096], const char *sam_header,
                    int32_t header_len, const strl_tread *treads, uint64_t n, const uint64_t *qname_off, const char *qnames) {
+  const auto t_begin = std::chrono::steady_clock::now();
   FILE *f = fopen(path, "wb");
   if (!f) { set_error("[strling] couldnt open binary output file %s", path); return STRL_ERR_IO; }
   std::string b;
@@ -640,69 +621,122 @@ int strl_bin_write(const char *path, float proportion_repeat, uint8_t min_mapq, 
   b.append(sam_header, (size_t)header_len);
   const int32_t n32 = (int32_t)n;
   b.append((const char *)&n32, 4);
-  auto pack = [&](std::string &o, uint64_t i0, uint64_t i1) {   // pack_type, cluster.nim:38-50
-    for (uint64_t i = i0; i < i1; ++i) {
-      const strl_tread &t = treads[i];
-      mp_int(o, t.tid);
-      mp_uint(o, t.position);
-      o.push_back((char)0x96);
-      for (int j = 0; j < 6; ++j) mp_uint(o, (uint8_t)t.repeat[j]);
-      mp_uint(o, t.flag);
-      mp_uint(o, t.split);
-      mp_uint(o, t.mapping_quality);
-      mp_uint(o, t.repeat_count);
-      mp_uint(o, t.align_length);
-      const uint64_t q0 = qname_off[t.qname_id], q1 = qname_off[t.qname_id + 1];
-      mp_uint(o, q1 - q0);
-      mp_str(o, qnames + q0, (size_t)(q1 - q0));
+  // pack_type, cluster.nim:38-50, through a raw cursor: a tread is ~35 values of one to five bytes, and appending them to a
+  // std::string one push_back at a time (a capacity check each) was 0.4 - 0.7 us a tread -- the packing, not the file system,
+  // was what `writing the .bin` took (0.24 - 0.29 s for a whole genome's 8e6 treads on 16 threads)
+  struct W {
+    static inline uint8_t *u(uint8_t *o, uint64_t v) {
+      if (v < 128) { *o++ = (uint8_t)v; return o; }
+      if (v < 256) { o[0] = 0xcc; o[1] = (uint8_t)v; return o + 2; }
+      if (v < 65536) { o[0] = 0xcd; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)v; return o + 3; }
+      o[0] = 0xce; o[1] = (uint8_t)(v >> 24); o[2] = (uint8_t)(v >> 16); o[3] = (uint8_t)(v >> 8); o[4] = (uint8_t)v;
+      return o + 5;
+    }
+    static inline uint8_t *i(uint8_t *o, int32_t v) {
+      if (v >= 0) return u(o, (uint64_t)v);
+      if (v >= -32) { *o++ = (uint8_t)v; return o; }
+      if (v >= -128) { o[0] = 0xd0; o[1] = (uint8_t)v; return o + 2; }
+      if (v >= -32768) { o[0] = 0xd1; o[1] = (uint8_t)((uint16_t)v >> 8); o[2] = (uint8_t)v; return o + 3; }
+      const uint32_t x = (uint32_t)v;
+      o[0] = 0xd2; o[1] = (uint8_t)(x >> 24); o[2] = (uint8_t)(x >> 16); o[3] = (uint8_t)(x >> 8); o[4] = (uint8_t)x;
+      return o + 5;
+    }
+    static inline uint8_t *str(uint8_t *o, const char *p, size_t l) {
+      if (l < 32) *o++ = (uint8_t)(0xa0 | l);
+      else if (l < 256) { o[0] = 0xd9; o[1] = (uint8_t)l; o += 2; }
+      else if (l < 65536) { o[0] = 0xda; o[1] = (uint8_t)(l >> 8); o[2] = (uint8_t)l; o += 3; }
+      else { o[0] = 0xdb; o[1] = (uint8_t)(l >> 24); o[2] = (uint8_t)(l >> 16); o[3] = (uint8_t)(l >> 8); o[4] = (uint8_t)l; o += 5; }
+      memcpy(o, p, l);
+      return o + l;
     }
   };
-  // a whole genome leaves millions of treads (~30 bytes each): their records are packed by a few threads, range by range,
-  // and written in order (the bytes are the sequential writer's)
+  constexpr size_t FIXED_MAX = 5 + 5 + 1 + 6 * 2 + 3 + 2 + 2 + 2 + 2 + 5 + 5;     // every value of a tread at its widest, without the name's bytes
+  auto pack = [&](uint8_t *o, uint64_t i0, uint64_t i1) -> uint8_t * {
+    for (uint64_t i = i0; i < i1; ++i) {
+      const strl_tread &t = treads[i];
+      o = W::i(o, t.tid);
+      o = W::u(o, t.position);
+      *o++ = 0x96;
+      for (int j = 0; j < 6; ++j) o = W::u(o, (uint8_t)t.repeat[j]);
+      o = W::u(o, t.flag);
+      o = W::u(o, t.split);
+      o = W::u(o, t.mapping_quality);
+      o = W::u(o, t.repeat_count);
+      o = W::u(o, t.align_length);
+      const uint64_t q0 = qname_off[t.qname_id], q1 = qname_off[t.qname_id + 1];
+      o = W::u(o, q1 - q0);
+      o = W::str(o, qnames + q0, (size_t)(q1 - q0));
+    }
+    return o;
+  };
+  auto room = [&](uint64_t i0, uint64_t i1) {          // bytes the treads [i0, i1) take at most
+    size_t names = 0;
+    for (uint64_t i = i0; i < i1; ++i) names += (size_t)(qname_off[treads[i].qname_id + 1] - qname_off[treads[i].qname_id]);
+    return (size_t)(i1 - i0) * FIXED_MAX + names;
+  };
+  // A whole genome leaves millions of treads (~35 bytes each).  Ranges of 2^16 treads are packed by a few threads into a
+  // buffer each thread keeps (warm: no fresh pages per range) and written straight to their place in the file -- the sizes of
+  // all ranges are known beforehand from a first, cheap pass of the same code.  The bytes are the sequential writer's.
   const unsigned hw = std::thread::hardware_concurrency();
   const uint64_t per = 1 << 16;
   const unsigned n_thr = n < 4 * per ? 1u : std::min<unsigned>({hw ? hw : 1u, 16u, (unsigned)((n + per - 1) / per)});
+  if (fwrite(b.data(), 1, b.size(), f) != b.size()) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; }
+  b.clear();
   if (n_thr <= 1) {
+    std::vector<uint8_t> buf;
     for (uint64_t i0 = 0; i0 < n; i0 += per) {
-      pack(b, i0, std::min(n, i0 + per));
-      if (fwrite(b.data(), 1, b.size(), f) != b.size()) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; }
-      b.clear();
+      const uint64_t i1 = std::min(n, i0 + per);
+      buf.resize(room(i0, i1));
+      const size_t len = (size_t)(pack(buf.data(), i0, i1) - buf.data());
+      if (fwrite(buf.data(), 1, len, f) != len) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; }
     }
   } else {
-    if (fwrite(b.data(), 1, b.size(), f) != b.size()) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; }
-    b.clear();
     const uint64_t n_parts = (n + per - 1) / per;
-    std::vector<std::string> parts((size_t)n_parts);
+    std::vector<off_t> at((size_t)n_parts + 1, 0);
     std::atomic<uint64_t> next{0};
     std::vector<std::thread> th;
-    for (unsigned k = 0; k < n_thr; ++k)
+    for (unsigned k = 0; k < n_thr; ++k)          // pass 1: every range's size (packed into the thread's buffer, not kept)
       th.emplace_back([&] {
-        for (uint64_t q; (q = next.fetch_add(1)) < n_parts;) { parts[(size_t)q].reserve((size_t)per * 40); pack(parts[(size_t)q], q * per, std::min(n, (q + 1) * per)); }
+        std::vector<uint8_t> buf;
+        for (uint64_t q; (q = next.fetch_add(1)) < n_parts;) {
+          const uint64_t i0 = q * per, i1 = std::min(n, i0 + per);
+          const size_t need = room(i0, i1);
+          if (buf.size() < need) buf.resize(need + need / 8);
+          at[(size_t)q + 1] = (off_t)(pack(buf.data(), i0, i1) - buf.data());
+        }
       });
     for (auto &t : th) t.join();
-    // ... and written by the same number of threads, every part at its place (a quarter of a gigabyte through one fwrite loop
-    // was 0.15 s behind a 2.5 s extract)
+    const auto t_packed = std::chrono::steady_clock::now();
     fflush(f);
-    const off_t base = ftello(f);
-    std::vector<off_t> at((size_t)n_parts + 1, base);
-    for (uint64_t q = 0; q < n_parts; ++q) at[(size_t)q + 1] = at[(size_t)q] + (off_t)parts[(size_t)q].size();
+    at[0] = ftello(f);
+    for (uint64_t q = 0; q < n_parts; ++q) at[(size_t)q + 1] += at[(size_t)q];
     const int fd = fileno(f);
+    // (the file at its final size first: the ranges then land in allocated space instead of each growing the file)
+    if (ftruncate(fd, at[(size_t)n_parts]) != 0) { /* not fatal: pwrite extends the file as it goes */ }
     std::atomic<bool> bad{false};
     next = 0;
     th.clear();
-    for (unsigned k = 0; k < n_thr; ++k)
+    for (unsigned k = 0; k < n_thr; ++k)          // pass 2: packed again (the buffer is warm) and written where the range belongs
       th.emplace_back([&] {
+        std::vector<uint8_t> buf;
         for (uint64_t q; (q = next.fetch_add(1)) < n_parts;) {
-          const std::string &o = parts[(size_t)q];
+          const uint64_t i0 = q * per, i1 = std::min(n, i0 + per);
+          const size_t need = room(i0, i1);
+          if (buf.size() < need) buf.resize(need + need / 8);
+          const size_t len = (size_t)(pack(buf.data(), i0, i1) - buf.data());
+          if ((off_t)len != at[(size_t)q + 1] - at[(size_t)q]) { bad = true; break; }
           size_t done = 0;
-          while (done < o.size()) {
-            const ssize_t w = pwrite(fd, o.data() + done, o.size() - done, at[(size_t)q] + (off_t)done);
+          while (done < len) {
+            const ssize_t w = pwrite(fd, buf.data() + done, len - done, at[(size_t)q] + (off_t)done);
             if (w <= 0) { bad = true; break; }
             done += (size_t)w;
           }
         }
       });
     for (auto &t : th) t.join();
+    if (getenv("STRL_BIN_TIMING"))
+      fprintf(stderr, "[strling] .bin: %u threads, sizes %.3f s, packing + writing %.3f s\n", n_thr, std::chrono::duration<double>(t_packed - t_begin).count(),
+              std::chrono::duration<double>(std::chrono::steady_clock::now() - t_packed).count());
     if (bad.load() || fseeko(f, at[(size_t)n_parts], SEEK_SET) != 0) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; }
   }
   if (fwrite(b.data(), 1, b.size(), f) != b.size()) { fclose(f); set_error("short write to %s", path); return STRL_ERR_IO; }

@@ -2310,7 +2310,7 @@ void *strl_pinned_alloc(uint64_t bytes) {
       for (size_t k = 0; k < T; ++k)
         th.emplace_back([=] { for (size_t o = span / T * k, e = k + 1 == T ? span : span / T * (k + 1); o < e; o += 4096) a[o] = 0; });
       for (auto &x : th) x.join();
-      if (hipHostRegister(a, span, hipHostRegisterDefault) == hipSuccess) {
+      if (hipHostRegister(a, span, hipHostRegisterPortable) == hipSuccess) {      // (portable: contexts on every device of the process copy from it)
         std::lock_guard<std::mutex> lk(g_pinned_mu);
         g_pinned.push_back({a, PinnedMap{base, len}});
         return a;

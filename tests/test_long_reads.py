@@ -109,7 +109,7 @@ def _mix_long(rec, rng, n_long, lengths=(511, 600, 1000, 2500, 7000)):
         elif shape in (2, 3, 4):   # clipped on the left / right / both, the clip a repeat
             cl = int(rng.choice([5, 17, 80, 300, min(600, L - 20)])) if shape in (2, 4) else 0
             cr = int(rng.choice([9, 17, 120, 400, min(700, L - cl - 10)])) if shape in (3, 4) else 0
-            cl, cr = min(cl, 250 * len(unit)), min(cr, 250 * len(unit))
+            cl, cr = min(cl, 250 * len(unit), L // 2 - 5), min(cr, 250 * len(unit), L // 2 - 5)
             mid = L - cl - cr
             seqs[i] = _tract(rng, unit, cl, 0.98) + _random_read(rng, mid) + _tract(rng, unit, cr, 0.98)
             cigs[i] = ([(cl << 4) | S] if cl else []) + [(mid << 4) | M] + ([(cr << 4) | S] if cr else [])

@@ -31,21 +31,43 @@ def work_dir(need_bytes):
     return cands[1]
 
 
-def make_input(n_pairs, d=None, level=6, seed=99, quals=True, aux=True, progress=False):
-    """-> dict(bam, bed, out, prefix, reads, n_slabs, ...).  S1 mix, distinct reads, coordinate sorted, .bai + ref.fasta.str."""
+def make_input(n_pairs, d=None, level=6, seed=99, quals=True, aux=True, progress=False, reuse=True):
+    """-> dict(bam, bed, out, prefix, reads, n_slabs, ...).  S1 mix, distinct reads, coordinate sorted, .bai + ref.fasta.str.
+    The file is CACHED in the work directory: a side-car <tag>.input.json written behind the .bai names its size, seed, level and the
+    BAM's byte count; a later call with the same parameters (the next N of a 1 / 2 / 4 / 8 sweep on one node; a second bench
+    run) finds it and writes nothing.  cleanup() removes outputs only, unless asked for the input too."""
     from strling_amd import bamio
     n_slabs = max(1, n_pairs // PAIRS_PER_SLAB)
     pairs = n_pairs // n_slabs
     d = d or work_dir(n_pairs * 2 * 115)
     tag = f"e2e_{n_pairs}_{level}"
-    bam, bed = f"{d}/{tag}.bam", f"{d}/{tag}.str"
+    bam, bed, side = f"{d}/{tag}.bam", f"{d}/{tag}.str", f"{d}/{tag}.input.json"
+    key = {"n_pairs": n_pairs, "level": level, "seed": seed, "quals": bool(quals), "aux": bool(aux), "writer": 2}
+    if reuse and os.path.exists(side):
+        try:
+            j = json.load(open(side))
+            if j.get("key") == key and os.path.getsize(bam) == j["bam_bytes"] and os.path.exists(bam + ".bai") and os.path.exists(bed):
+                inp = j["inp"]
+                inp["reused_cached_input"] = True
+                return inp
+        except Exception:
+            pass
+    if os.path.exists(side):
+        os.remove(side)
     pr = (lambda k, n, s: print(f"[e2e] slab {k}/{n} {s:.0f} s", file=sys.stderr, flush=True) if k % 64 == 0 else None) if progress else None
     r = bamio.write_bam_slabs(bam, n_slabs, pairs, seed=seed, level=level, quals=quals, aux=aux, index=True, bed=bed, progress=pr)
-    return {"bam": bam, "bed": bed, "out": f"{d}/{tag}.bin", "prefix": f"{d}/{tag}", "reads": r["reads"], "n_slabs": n_slabs, "pairs_per_slab": pairs,
-            "seed": seed, "level": level, "bam_MB": round(r["bytes"] / 1e6, 1), "make_s": round(r["seconds"], 1), "make_procs": r["procs"], "dir": d,
-            "targets": r["targets"],
-            "input": f"{r['reads']} distinct reads in {n_slabs} slabs of a 30x sample, coordinate sorted + unmapped tail, zlib level {level}, "
-                     f"{'binned random' if quals else 'absent'} qualities, {'NM MD AS XS RG' if aux else 'no'} aux tags"}
+    inp = {"bam": bam, "bed": bed, "out": f"{d}/{tag}.bin", "prefix": f"{d}/{tag}", "reads": r["reads"], "n_slabs": n_slabs, "pairs_per_slab": pairs,
+           "seed": seed, "level": level, "bam_MB": round(r["bytes"] / 1e6, 1), "make_s": round(r["seconds"], 1), "make_procs": r["procs"], "dir": d,
+           "targets": r["targets"], "tag": tag,
+           "input": f"{r['reads']} distinct reads in {n_slabs} slabs of a 30x sample, coordinate sorted + unmapped tail, zlib level {level}, "
+                    f"{'binned random' if quals else 'absent'} qualities, {'NM MD AS XS RG' if aux else 'no'} aux tags"}
+    try:
+        with open(side + ".tmp", "w") as f:
+            json.dump({"key": key, "bam_bytes": os.path.getsize(bam), "inp": inp}, f)
+        os.replace(side + ".tmp", side)
+    except Exception:
+        pass
+    return inp
 
 
 def _quota():
@@ -131,6 +153,12 @@ def run(inp, cli, threads=(0,), call=True, merge=True, repeats=1, gpus=1, extra_
     best = max(ok, key=lambda x: x["reads_per_s_wall"])
     res["value"] = best["reads_per_s_wall"]
     res["extract_s"] = best["wall_s"]
+    res["reads_per_s_loop"] = best.get("reads_per_s_loop")
+    # the FIRST run reads a file no process has read since it was written (or since the cache was filled): what a user sees on a
+    # file that is not in the page cache is this number, not the best one
+    res["first_run_wall_s"] = res["runs"][0]["wall_s"]
+    res["first_run_note"] = ("the first extract process behind the writer" if not inp.get("reused_cached_input") else
+                             "the first extract process of this bench run on a cached input file (page cache state unknown)")
     res["bin_MB"] = round(os.path.getsize(inp["out"]) / 1e6, 1)
     env = dict(os.environ)
     if call:
@@ -163,6 +191,66 @@ def run(inp, cli, threads=(0,), call=True, merge=True, repeats=1, gpus=1, extra_
                    "reads_per_s_loop excludes process start-up and the .bin write.  call_s / merge_s: whole `strling call` (clustering on the device, the bounds' "
                    ".bai region reads inflated and cut out on the device, spanning evidence + genotypes on the host's threads) and `strling merge` processes on that .bin")
     return res
+
+
+def feed_only(inp, cli, gpus):
+    """the host side of `extract --gpus N` alone (STRL_FEED_ONLY=1: header walkers + copy threads into the page-locked rings, no
+    device stage): what the feeding threads of N shares sustain on this box's CPUs"""
+    if gpus < 2:
+        return None
+    env = dict(os.environ, STRL_FEED_ONLY="1")
+    r, wall = _timed([cli, "extract", "-v", "-g", inp["bed"], "--gpus", str(gpus), inp["bam"], inp["out"] + ".feed"], env)
+    m = re.search(r"feed only: (\d+) shares, (\d+) copy threads each.*?, ([\d.]+) s, ([\d.]+) GB of BAM, ([\d.]+) GB/s", r.stderr)
+    if not m:
+        return {"rc": r.returncode, "stderr_tail": r.stderr[-300:]}
+    return {"shares": int(m.group(1)), "copy_threads_per_share": int(m.group(2)), "feed_s": float(m.group(3)), "GB": float(m.group(4)), "GBps": float(m.group(5)),
+            "reads_per_s": round(inp["reads"] / float(m.group(3))), "process_wall_s": round(wall, 3)}
+
+
+def replicas(inp, cli, n, devices):
+    """N concurrent `strling extract --device k` processes, one per GPU, each on a whole sample of its own -- how the reference's
+    pipelines scale (one single-threaded process per sample: pipelines/bpipe.config:4, strling-joint-bychrom.groovy:8-14) and
+    BASELINE configs[4]'s real shape.  Every replica reads the same file (its own .bin out); aggregate = N x reads / the slowest
+    process' wall."""
+    import threading
+    if SETTLE_S:
+        time.sleep(SETTLE_S)
+    outs = [inp["out"] + f".rep{k}" for k in range(n)]
+    res = [None] * n
+
+    def one(k):
+        env = dict(os.environ)
+        # the box's CPUs are shared: every replica takes its share of the decode / copy threads
+        q = _quota() or os.cpu_count() or 1
+        env["STRL_THREADS"] = str(max(2, int(q // n)))
+        t = time.time()
+        try:
+            r = subprocess.run([cli, "extract", "-v", "-g", inp["bed"], "--device", str(k % max(1, devices)), inp["bam"], outs[k]], capture_output=True, text=True, env=env,
+                               timeout=PROCESS_TIMEOUT_S)
+            rc, err = r.returncode, r.stderr
+        except subprocess.TimeoutExpired:
+            rc, err = 124, "timeout"
+        wall = time.time() - t
+        line = [l for l in err.splitlines() if "seconds: total" in l]
+        res[k] = {"device": k % max(1, devices), "rc": rc, "wall_s": round(wall, 3), "loop_s": float(line[-1].split("total")[1].split()[0]) if line else None}
+
+    th = [threading.Thread(target=one, args=(k,)) for k in range(n)]
+    t0 = time.time()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.time() - t0
+    same = None
+    if all(r["rc"] == 0 for r in res) and os.path.exists(inp["out"]):
+        ref = open(inp["out"], "rb").read() if os.path.getsize(inp["out"]) < (1 << 31) else None
+        same = all(os.path.getsize(o) == os.path.getsize(inp["out"]) for o in outs) and (ref is None or all(open(o, "rb").read() == ref for o in outs))
+    for o in outs:
+        if os.path.exists(o):
+            os.remove(o)
+    return {"replicas": n, "devices": devices, "wall_s": round(wall, 3), "aggregate_reads_per_s": round(n * inp["reads"] / wall) if all(r["rc"] == 0 for r in res) else None,
+            "per_replica": res, "bins_identical_to_the_single_run": same,
+            "what": "N concurrent `strling extract --device k` processes (one sample each, here the same file; STRL_THREADS = CPU quota / N each): N x reads / the slowest process' wall clock"}
 
 
 def _slab_check(a):
@@ -256,11 +344,30 @@ def pick_slabs(n_slabs, k):
     return sorted({int(round(j * (n_slabs - 1) / max(1, k - 1))) for j in range(k)})
 
 
-def cleanup(inp):
-    for p in (inp["bam"], inp["bam"] + ".bai", inp["bed"], inp["out"], inp["prefix"] + "-bounds.txt", inp["prefix"] + "-genotype.txt",
-              inp["prefix"] + "-unplaced.txt", inp["prefix"] + "-joint-bounds.txt"):
+def cleanup(inp, keep_input=False):
+    """outputs always; the input file (BAM, .bai, BED, side-car) unless it is to stay cached for the next run"""
+    ps = [inp["out"], inp["out"] + ".feed", inp["prefix"] + "-bounds.txt", inp["prefix"] + "-genotype.txt", inp["prefix"] + "-unplaced.txt", inp["prefix"] + "-joint-bounds.txt"]
+    if not keep_input:
+        ps += [inp["bam"], inp["bam"] + ".bai", inp["bed"], inp["prefix"] + ".input.json"]
+    for p in ps:
         if os.path.exists(p):
             os.remove(p)
+
+
+def n1_record(inp, res=None):
+    """the N = 1 figures of this input, kept beside the cached file: a later N > 1 run of the sweep quotes its strong scaling
+    against them (bench.py end_to_end.strong_scaling_vs_n1)"""
+    path = inp["prefix"] + ".n1.json"
+    if res is not None:
+        try:
+            json.dump({"extract_s": res.get("extract_s"), "reads_per_s_wall": res.get("value"), "reads_per_s_loop": res.get("reads_per_s_loop"), "reads": inp["reads"]}, open(path, "w"))
+        except Exception:
+            pass
+        return None
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
 
 
 if __name__ == "__main__":
@@ -274,6 +381,8 @@ if __name__ == "__main__":
     ap.add_argument("--repeats", type=int, default=1)
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--replicas", type=int, default=0, help="also run N concurrent `extract --device k` processes (one per GPU)")
+    ap.add_argument("--feed-only", action="store_true", help="also time the host side of --gpus N alone")
     ap.add_argument("--out", default="")
     ap.add_argument("--check-json", default="", help="(internal) run check() on the input described by this file and print its result")
     a = ap.parse_args()
@@ -284,10 +393,14 @@ if __name__ == "__main__":
     inp = make_input(a.n_pairs, d=a.dir, level=a.level, progress=True)
     print(f"[e2e] wrote {inp['bam']} ({inp['bam_MB']} MB, {inp['reads']} reads) in {inp['make_s']} s", file=sys.stderr, flush=True)
     res = run(inp, build.CLI, repeats=a.repeats, gpus=a.gpus)
+    if a.feed_only:
+        res["feed_only"] = feed_only(inp, build.CLI, a.gpus)
+    if a.replicas:
+        import torch
+        res["replicas"] = replicas(inp, build.CLI, a.replicas, max(1, torch.cuda.device_count()))
     if a.check_slabs and "error" not in res:
         res["check"] = check(inp, pick_slabs(inp["n_slabs"], a.check_slabs), call=res.get("call_rc") == 0)
-    if not a.keep:
-        cleanup(inp)
+    cleanup(inp, keep_input=a.keep)
     s = json.dumps(res)
     if a.out:
         open(a.out, "w").write(s + "\n")
