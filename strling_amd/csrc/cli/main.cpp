@@ -38,6 +38,8 @@ static std::function<void()> g_bg_abort;   // ... after telling it to stop waiti
 // --device K (or STRL_DEVICE=K): the device the first context of this process sits on; --gpus N takes K, K + 1, ... (mod the
 // devices there are).  A pipeline that runs one `strling` process per sample (pipelines/bpipe.config:4) gives every process its
 // own GPU this way.
+static double since_exec();
+static double g_main_at = -1;      // seconds between exec and main()
 static int g_device0 = 0;
 static void set_device0(const std::string &v) {
   const char *e = getenv("STRL_DEVICE");
@@ -650,7 +652,11 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   bool use_shares = G > 1 && !(env_shares && strcmp(env_shares, "0") == 0);
   if (use_shares) {
     struct stat st;
-    if (stat(bam.c_str(), &st) == 0) auto_blocks = std::min<size_t>(16384, std::max<size_t>(4096, (size_t)st.st_size / (size_t)G / 16384 / 12));
+    // (a share's ring is four page-locked buffers of a chunk each, and page-locking goes through the driver at ~20 GB/s whatever
+    // the number of threads (profiles/r06/feed_probe_shm.log): 8 shares x 4 x 16384 blocks were 10 GB = half a second and more of
+    // every start; 4096 blocks -- a 2.5 ms inflate launch of 4096 workgroups -- keep 8 rings at 2.6 GB)
+    const size_t cap = G >= 4 ? 4096 : 8192;
+    if (stat(bam.c_str(), &st) == 0) auto_blocks = std::min<size_t>(cap, std::max<size_t>(2048, (size_t)st.st_size / (size_t)G / 16384 / 12));
   }
   const size_t chunk_blocks = env_blocks && atoi(env_blocks) > 0 ? (size_t)atoi(env_blocks) : auto_blocks;
   const size_t chunk_bytes = std::max<size_t>((size_t)1 << 20, chunk_blocks * 20000);       // compressed bytes one chunk may span
@@ -666,17 +672,6 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   double t_ctx = 0, t_pin = 0;
   uint32_t *fw_early = nullptr;          // flag / isize words of the first records (fragment lengths)
   const uint64_t early_n = 2400000;
-  // the HIP runtime, the contexts and the page-locked buffers come up on threads beside the header walk
-  std::thread pin_thread([&] {
-    const auto c0 = now();
-    std::vector<std::thread> each;            // (the time is the kernel's, faulting and locking the pages: a thread per buffer)
-    for (size_t k = 1; k < pin.size(); ++k) each.emplace_back([&, k] { pin[k] = static_cast<uint8_t *>(strl_pinned_alloc(chunk_bytes + 64)); });
-    pin[0] = static_cast<uint8_t *>(strl_pinned_alloc(chunk_bytes + 64));
-    for (auto &q : pin_meta) q = static_cast<uint8_t *>(strl_pinned_alloc(chunk_blocks * 20 + 64));
-    fw_early = static_cast<uint32_t *>(strl_pinned_alloc(early_n * 4));     // (allocating page-locked memory inside the loop stalls the device)
-    for (auto &t : each) t.join();
-    t_pin = secs(c0, now());
-  });
   // Bring-up, one thread per context, side by side (round 6; before: one after the other, 0.1 - 0.2 s each, then options, genome
   // table and per-read state of every context in turn on the main thread -- more than a second of fixed cost at 8 contexts):
   //   create the context (the first HIP call of the process starts the runtime: one thread does that alone, the others wait
@@ -688,7 +683,7 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   struct BringUp {
     std::mutex mu;
     std::condition_variable cv;
-    bool runtime_up = false, genome_ready = false, plan_ready = false, give_up = false;
+    bool runtime_up = false, genome_ready = false, plan_ready = false, pin_done = false, give_up = false;
     std::vector<uint8_t> created, done;
     strl_genome_str gs{};
     int32_t n_ref = 0;
@@ -698,6 +693,19 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   bu.created.assign((size_t)G, 0); bu.done.assign((size_t)G, 0);
   bu.first_off.assign((size_t)G, 0); bu.hint.assign((size_t)G, 0);
   bu.t_create.assign((size_t)G, 0.0); bu.t_state.assign((size_t)G, 0.0);
+  // the HIP runtime, the contexts and the page-locked buffers come up on threads beside the header walk
+  std::thread pin_thread([&] {
+    const auto c0 = now();
+    std::vector<std::thread> each;            // (the time is the kernel's, faulting and locking the pages: a thread per buffer)
+    for (size_t k = 1; k < pin.size(); ++k) each.emplace_back([&, k] { pin[k] = static_cast<uint8_t *>(strl_pinned_alloc(chunk_bytes + 64)); });
+    pin[0] = static_cast<uint8_t *>(strl_pinned_alloc(chunk_bytes + 64));
+    for (auto &q : pin_meta) q = static_cast<uint8_t *>(strl_pinned_alloc(chunk_blocks * 20 + 64));
+    fw_early = static_cast<uint32_t *>(strl_pinned_alloc(early_n * 4));     // (allocating page-locked memory inside the loop stalls the device)
+    for (auto &t : each) t.join();
+    t_pin = secs(c0, now());
+    { std::lock_guard<std::mutex> lk(bu.mu); bu.pin_done = true; }
+    bu.cv.notify_all();
+  });
   static const bool serial_ctx = getenv("STRL_SERIAL_CTX") != nullptr;
   auto bring_up = [&](int g) {
     auto wait_for = [&](auto pred) {             // -> false: the main thread gave up (an error exit is under way)
@@ -727,7 +735,9 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     bu.cv.notify_all();
     if (!wait_for([&] { return bu.genome_ready; })) return finish(0);
     if ((rc = strl_ctx_set_genome(c, &bu.gs))) return finish(rc);
-    if (!wait_for([&] { return bu.plan_ready; })) return finish(0);
+    // (the per-read state -- tens of gigabytes of device memory -- only once the page-locked buffers are there: allocated while
+    // the driver still locks pages it took 0.16 - 0.44 s instead of 0.03, profiles/r06/bringup_one_device_g1.log)
+    if (!wait_for([&] { return bu.plan_ready && bu.pin_done; })) return finish(0);
     const auto c1 = now();
     rc = strl_front_begin(c, bu.n_ref, bu.first_off[(size_t)g], bu.hint[(size_t)g]);
     if (!rc) rc = strl_front_reserve(c, (uint32_t)chunk_blocks, chunk_bytes);
@@ -1285,6 +1295,8 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     fprintf(stderr, "[strling] seconds before the loop: header walk %.3f, genome table (host half) %.3f, then waiting for the bring-up threads %.3f -- beside all that, a thread "
                     "per context: slowest context + its options %.3f, slowest per-read state for %llu reads + front-end buffers %.3f; page-locked buffers %.3f; writing the .bin %.3f; whole run %.3f\n",
             t_open, t_genome, t_begin, t_ctx, (unsigned long long)reads_hint, t_state, t_pin, t_write, secs(t_start, now()));
+    fprintf(stderr, "[strling] process: main() entered %.2f s after exec, now %.2f s after exec (what the caller's clock adds behind this line is the kernel "
+                    "reclaiming the process' device and page-locked memory)\n", g_main_at, since_exec());
   }
   // the process ends here: the driver reclaims device and page-locked memory faster than freeing them piece by piece would
   // (STRL_TEARDOWN=1 frees them explicitly)
@@ -2325,7 +2337,26 @@ static int shares_main(int argc, char **argv) {
   return 0;
 }
 
+// seconds since the kernel started this process (its start time in /proc/self/stat against the uptime clock; 10 ms ticks):
+// what -v reports of the time in front of main() -- the loader mapping the HIP runtime and this program's device code
+static double since_exec() {
+  FILE *f = fopen("/proc/self/stat", "r");
+  if (!f) return -1;
+  char buf[2048];
+  const size_t n = fread(buf, 1, sizeof buf - 1, f);
+  fclose(f);
+  buf[n] = 0;
+  const char *q = strrchr(buf, ')');          // (the command name may hold spaces)
+  if (!q) return -1;
+  unsigned long long start = 0;
+  int field = 2;
+  for (const char *t = q + 1; *t && field < 22; ++t) if (*t == ' ') { if (++field == 22) start = strtoull(t + 1, nullptr, 10); }
+  timespec ts;
+  if (!start || clock_gettime(CLOCK_BOOTTIME, &ts) != 0) return -1;
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec - (double)start / (double)sysconf(_SC_CLK_TCK);
+}
 int main(int argc, char **argv) {
+  g_main_at = since_exec();
   const char *top =
       "strling version: 0.6.0 (MI355X-native hot path)\n\nCommands:\n  extract  :   extract informative STR reads from a BAM/CRAM. This is a required first step.\n"
       "  merge    :   merge putitive STR loci from multiple samples. Only required for joint calling.\n  call     :   call STRs\n"

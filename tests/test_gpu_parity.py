@@ -146,8 +146,15 @@ def test_empty_batch(ctx):
     assert b.size == 0
 
 
-def test_read_longer_than_limit_is_refused(ctx):
-    rec = RecordBatch.from_fields([0], [1], [0], [1], [99], [60], ["600M"], ["A" * 600], ["x"])
+def test_read_longer_than_the_kernels_take_is_scored_and_one_beyond_the_columns_is_refused(ctx):
+    """more than STRL_DEVICE_READ_LEN (510) bases: the host twin of the scorer (tests/test_long_reads.py); more than
+    STRL_MAX_READ_LEN (65534, what the 16-bit length columns hold): STRL_ERR_ARG"""
+    ctx.set_opts(0.8, 40, 350)
+    ctx.set_genome(None)
+    rec = RecordBatch.from_fields([0], [1], [0], [1], [99], [60], ["600M"], ["AC" * 300], ["x"])
+    whole, _, _ = ctx.score_reads(rec)
+    assert unpack_result(whole[0]) == ("CA", 299, False)
+    rec = RecordBatch.from_fields([0], [1], [0], [1], [99], [60], ["65535M"], ["A" * 65535], ["x"])
     with pytest.raises(api.StrlingError):
         ctx.score_reads(rec)
 

@@ -4,6 +4,7 @@
 //   pread     T threads pread() a chunk into a page-locked buffer, then one hipMemcpyAsync (the shipped way)
 //   register  the file mmap()ed read-only; every chunk of the mapping is hipHostRegister()ed (by a helper thread, one chunk
 //             ahead of the copy), DMAed straight from the page cache, unregistered -- no CPU copy
+//   mmapcopy  like pread, but the copy is a user-space memcpy from the file's mapping
 //   pageable  hipMemcpyAsync straight from the unregistered mapping (the runtime stages it itself)
 //   direct    O_DIRECT reads into the page-locked buffer (a file that is NOT in the page cache), then the DMA
 // usage: feed_probe FILE [chunk_MB=320] [max_GB=16] [threads=12] [modes=pread,register,pageable,direct]
@@ -40,7 +41,7 @@ int main(int argc, char **argv) {
   const size_t chunk = (size_t)(argc > 2 ? atoi(argv[2]) : 320) << 20;
   const double max_gb = argc > 3 ? atof(argv[3]) : 16.0;
   const int T = argc > 4 ? atoi(argv[4]) : 12;
-  const std::string modes = argc > 5 ? argv[5] : "pread,register,pageable,direct";
+  const std::string modes = argc > 5 ? argv[5] : "pread,mmapcopy,register,pageable,direct";
   const int fd = open(path, O_RDONLY);
   if (fd < 0) { perror("open"); return 1; }
   struct stat st;
@@ -130,6 +131,34 @@ int main(int argc, char **argv) {
     if (!bad) printf("register : flags %#x, %d registering thread(s): %.3f s = %.1f GB/s to the device (register %.3f s = %.1f GB/s per thread, copy + wait %.3f s = %.1f GB/s, unregister %.3f s)\n", flags, R, dt,
                      total / 1e9 / dt, sr, total / 1e9 / sr, t_copy_wait, total / 1e9 / t_copy_wait, su);
     else printf("register : flags %#x: not possible on this box (see stderr)\n", flags);
+    munmap(map, total);
+  }
+
+  if (modes.find("mmapcopy") != std::string::npos) {
+    // the CPU copy in user space: memcpy from the file's mapping into the page-locked ring (glibc streams large copies past
+    // the cache), instead of the kernel's copy_to_user inside pread
+    void *map = mmap(nullptr, total, PROT_READ, MAP_SHARED, fd, 0);
+    uint8_t *m = (uint8_t *)map;
+    uint8_t *ring[2] = {(uint8_t *)pinned(chunk), (uint8_t *)pinned(chunk)};
+    hipEvent_t ev[2];
+    for (auto &e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    double t_read = 0;
+    const double t0 = now();
+    for (size_t c = 0; c < n_chunks; ++c) {
+      if (c >= 2) CK(hipEventSynchronize(ev[c & 1]));
+      const double a = now();
+      std::vector<std::thread> th;
+      const size_t piece = (size_t)4 << 20, pieces = chunk / piece;
+      std::atomic<size_t> next{0};
+      for (int t = 0; t < T; ++t) th.emplace_back([&] { for (size_t k; (k = next.fetch_add(1)) < pieces;) memcpy(ring[c & 1] + k * piece, m + c * chunk + k * piece, piece); });
+      for (auto &x : th) x.join();
+      t_read += now() - a;
+      CK(hipMemcpyAsync(dev[c & 1], ring[c & 1], chunk, hipMemcpyHostToDevice, s));
+      CK(hipEventRecord(ev[c & 1], s));
+    }
+    CK(hipStreamSynchronize(s));
+    const double dt = now() - t0;
+    printf("mmapcopy : %.3f s = %.1f GB/s to the device (memcpy from the mapping alone %.3f s = %.1f GB/s on %d threads)\n", dt, total / 1e9 / dt, t_read, total / 1e9 / t_read, T);
     munmap(map, total);
   }
 
