@@ -10,4 +10,7 @@ namespace strl {
 bool cram_rans_nx16_decode(const uint8_t *in, size_t in_len, size_t expect, std::vector<uint8_t> &out, std::string &err);
 bool cram_tok3_decode(const uint8_t *in, size_t in_len, size_t expect, std::vector<uint8_t> &out, std::string &err);
 
+// test hooks (cram_reader.cpp): "rans4x8" block, "itf8" / "ltf8" value lists -> decimal lines
+bool cram_selftest_decode(const std::string &kind, const uint8_t *in, size_t in_len, size_t expect, std::vector<uint8_t> &out, std::string &err);
+
 }  // namespace strl

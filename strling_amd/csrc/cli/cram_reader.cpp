@@ -554,6 +554,23 @@ void append_batch(RecordBatch &b, RecordBatch &a) {
 
 }  // namespace
 
+// Test hooks (`strling _codec`): the reader's own primitives on bytes a test wrote out by hand from the specification's text --
+// rANS 4x8 blocks (CRAMv3 section 13), ITF8 / LTF8 values (section 2.3) -- so that they are pinned by something other than this
+// repository's writer.  itf8 / ltf8: every value of the input, one decimal per line.
+bool cram_selftest_decode(const std::string &kind, const uint8_t *in, size_t in_len, size_t expect, std::vector<uint8_t> &out, std::string &err) {
+  if (kind == "rans4x8") return rans_decode(in, in_len, out, expect, err);
+  if (kind == "itf8" || kind == "ltf8") {
+    Rd r{in, in + in_len};
+    std::string text;
+    while (r.p < r.e && r.ok) text += std::to_string(kind == "itf8" ? (long long)r.itf8() : (long long)r.ltf8()) + "\n";
+    if (!r.ok) { err = "truncated " + kind + " value"; return false; }
+    out.assign(text.begin(), text.end());
+    return true;
+  }
+  err = "unknown codec kind " + kind;
+  return false;
+}
+
 // ---- reference ----------------------------------------------------------------------------------------------------------
 bool RefCache::open(const std::string &fasta, std::string &err) {
   path_ = fasta;

@@ -2283,7 +2283,7 @@ static int index_main(int argc, char **argv) {
 
 // strling _codec nx16|tok3 IN OUT EXPECTED_SIZE  (tests): one CRAM 3.1 block payload through cli/cram_codecs.cpp
 static int codec_main(int argc, char **argv) {
-  if (argc < 6) quit("usage: strling _codec nx16|tok3 IN OUT EXPECTED_SIZE");
+  if (argc < 6) quit("usage: strling _codec nx16|tok3|rans4x8|itf8|ltf8 IN OUT EXPECTED_SIZE");
   FILE *f = fopen(argv[3], "rb");
   if (!f) quit("couldn't open %s", argv[3]);
   std::vector<uint8_t> in, out;
@@ -2293,7 +2293,10 @@ static int codec_main(int argc, char **argv) {
   fclose(f);
   std::string err;
   const size_t expect = (size_t)strtoull(argv[5], nullptr, 10);
-  const bool ok = strcmp(argv[2], "tok3") == 0 ? cram_tok3_decode(in.data(), in.size(), expect, out, err) : cram_rans_nx16_decode(in.data(), in.size(), expect, out, err);
+  const std::string kind = argv[2];
+  const bool ok = kind == "tok3" ? cram_tok3_decode(in.data(), in.size(), expect, out, err)
+                  : kind == "nx16" ? cram_rans_nx16_decode(in.data(), in.size(), expect, out, err)
+                                   : cram_selftest_decode(kind, in.data(), in.size(), expect, out, err);
   if (!ok) quit("[strling] %s", err.c_str());
   f = fopen(argv[4], "wb");
   if (!f || (out.size() && fwrite(out.data(), 1, out.size(), f) != out.size())) quit("couldn't write %s", argv[4]);

@@ -125,3 +125,287 @@ def test_tok3_hostile_header_is_an_error_not_an_abort(tmp_path):
     payload = struct.pack("<IIB", 40, 2, 0) + bytes([0x80 | 0]) + u7(len(stream)) + stream
     r, _ = _decode("tok3", payload, 40, tmp_path)
     assert r.returncode == 1 and "malformed" in r.stderr, (r.returncode, r.stderr[-200:])
+
+
+# ---- vectors that strling_amd/cramio.py did NOT produce ----------------------------------------------------------------------
+# Round-5 review: every CRAM codec test decoded what this repository's own writer (cramio.py) had encoded.  Below: (a) literal
+# bytes assembled by hand from the formats' published definitions (CRAMv3 section 2.3 ITF8 / LTF8, section 13 rANS 4x8; CRAMcodecs
+# section 3 rANS Nx16 framing, section 5 name tokeniser framing), (b) streams of minimal encoders written INSIDE this test file from
+# the specification's formulas, sharing no code with cramio.py.  Still the same reader of the specification: a file htslib wrote
+# remains the missing pin (README "unverified").
+def _u7(v):
+    out = [v & 0x7F]
+    v >>= 7
+    while v:
+        out.insert(0, (v & 0x7F) | 0x80)
+        v >>= 7
+    return bytes(out)
+
+
+def _values(kind, payload, tmp_path):
+    r, got = _decode(kind, payload, 0, tmp_path)
+    assert r.returncode == 0, r.stderr[-200:]
+    return [int(x) for x in got.decode().split()]
+
+
+def test_itf8_and_ltf8_edge_table(tmp_path):
+    """CRAMv3 2.3: the number of leading one bits of the first byte = the number of bytes that follow; the 5-byte ITF8 form keeps
+    only the low 4 bits of its last byte.  Values are read as signed 32 / 64 bit."""
+    itf8 = [(b"\x00", 0), (b"\x7f", 127), (b"\x80\x80", 128), (b"\xbf\xff", 16383), (b"\xc0\x40\x00", 16384), (b"\xdf\xff\xff", 2097151),
+            (b"\xe0\x20\x00\x00", 2097152), (b"\xef\xff\xff\xff", 268435455), (b"\xf1\x00\x00\x00\x00", 268435456),
+            (b"\xff\xff\xff\xff\x0f", -1), (b"\xf8\x00\x00\x00\x00", -(1 << 31)), (b"\xf7\xff\xff\xff\x0f", (1 << 31) - 1)]
+    assert _values("itf8", b"".join(b for b, _ in itf8), tmp_path) == [v for _, v in itf8]
+    ltf8 = [(b"\x00", 0), (b"\x7f", 127), (b"\x80\x80", 128), (b"\xc0\x40\x00", 16384), (b"\xfe" + b"\xff" * 7, (1 << 56) - 1),
+            (b"\xff\x01" + b"\x00" * 7, 1 << 56), (b"\xff" * 9, -1), (b"\xf0\x80\x00\x00\x00", 1 << 31)]
+    assert _values("ltf8", b"".join(b for b, _ in ltf8), tmp_path) == [v for _, v in ltf8]
+    r, _ = _decode("itf8", b"\xe0\x20", 0, tmp_path)      # cut inside a value
+    assert r.returncode == 1
+
+
+def _rans4x8_table(freqs):
+    """CRAMv3 13: symbol, frequency (one byte below 128, else 0x80 | high byte, low byte); a symbol that follows its predecessor
+    directly is announced once, with the number of FURTHER consecutive symbols behind it; 0 ends the table"""
+    syms = sorted(freqs)
+    out, rle = bytearray(), 0
+    for k, sy in enumerate(syms):
+        if rle:
+            rle -= 1
+        else:
+            out.append(sy)
+            if k and syms[k - 1] == sy - 1:
+                run = 0
+                while k + run + 1 < len(syms) and syms[k + run + 1] == sy + run + 1:
+                    run += 1
+                out.append(run)
+                rle = run
+        f = freqs[sy]
+        out += bytes([f]) if f < 128 else bytes([0x80 | (f >> 8), f & 0xFF])
+    out.append(0)
+    return bytes(out)
+
+
+def _rans4x8_o0(data, freqs):
+    """a minimal rANS 4x8 order-0 ENCODER from the section's formulas: four states, symbol i on state i mod 4, x' = (x div f) * 4096 +
+    x mod f + C, a byte leaves a state while x >= (2^23 / 4096 * 256) * f; bytes come out in reverse"""
+    C, acc = {}, 0
+    for sy in sorted(freqs):
+        C[sy] = acc
+        acc += freqs[sy]
+    assert acc == 4096
+    R = [1 << 23] * 4
+    emitted = bytearray()
+
+    def put(k, sy):
+        f = freqs[sy]
+        x = R[k]
+        while x >= ((1 << 23) >> 12 << 8) * f:
+            emitted.append(x & 0xFF)
+            x >>= 8
+        R[k] = (x // f << 12) + x % f + C[sy]
+
+    n = len(data)
+    for k in reversed(range(n & 3)):
+        put(k, data[(n & ~3) + k])
+    for i in reversed(range(n & ~3)):
+        put(i & 3, data[i])
+    body = _rans4x8_table(freqs) + b"".join(x.to_bytes(4, "little") for x in R) + bytes(reversed(emitted))
+    return bytes([0]) + len(body).to_bytes(4, "little") + n.to_bytes(4, "little") + body
+
+
+def test_rans4x8_order0_vectors_written_by_hand(tmp_path):
+    # one symbol with the whole range: x' = x, no byte is ever emitted, the four states stay 2^23 -- every byte below follows
+    # from the section's text alone
+    lit = bytes.fromhex("00" "14000000" "07000000" "41" "9000" "00" + "00008000" * 4)
+    assert _rans4x8_o0(b"AAAAAAA", {0x41: 4096}) == lit
+    r, got = _decode("rans4x8", lit, 7, tmp_path)
+    assert r.returncode == 0 and got == b"AAAAAAA", r.stderr[-200:]
+    # two symbols, three quarters / one quarter: x0 = 2^23 + ... computed by the in-file encoder; the literal pins it
+    enc = _rans4x8_o0(b"ACAAACAC" * 3 + b"AA", {0x41: 3072, 0x43: 1024})
+    assert enc[:9] == bytes([0]) + (len(enc) - 9).to_bytes(4, "little") + (26).to_bytes(4, "little") and enc[9:16] == bytes.fromhex("418c00438400" "00")
+    r, got = _decode("rans4x8", enc, 26, tmp_path)
+    assert r.returncode == 0 and got == b"ACAAACAC" * 3 + b"AA", r.stderr[-200:]
+    # consecutive symbols (the table's run-length form), skewed frequencies, every length mod 4, many renormalisation bytes
+    rng = np.random.default_rng(3)
+    freqs = {0x41: 2000, 0x42: 1000, 0x43: 500, 0x44: 300, 0x47: 200, 0x54: 90, 0x55: 5, 0x00: 1}
+    assert _rans4x8_table(freqs)[:8] == bytes([0x00, 0x01, 0x41, 0x87, 0xD0, 0x42, 0x02, 0x83])      # A, then B announced with 2 more behind it
+    syms = np.array(sorted(freqs), np.uint8)
+    p = np.array([freqs[int(s_)] for s_ in syms], float) / 4096
+    for n in (1, 2, 3, 4, 5, 63, 64, 1000, 4099):
+        data = bytes(rng.choice(syms, n, p=p))
+        r, got = _decode("rans4x8", _rans4x8_o0(data, freqs), n, tmp_path)
+        assert r.returncode == 0 and got == data, (n, r.stderr[-200:])
+
+
+def _rans4x8_o1(data, ctx_freqs):
+    """order 1 (section 13.2): a table per context symbol (the contexts listed with the same run-length form), four states that each
+    code a QUARTER of the data (the fourth also the remainder), the context of a quarter's first symbol is 0"""
+    n, q = len(data), len(data) >> 2
+    C = {}
+    for c, fr in ctx_freqs.items():
+        acc = 0
+        for sy in sorted(fr):
+            C[(c, sy)] = acc
+            acc += fr[sy]
+        assert acc <= 4096
+    R = [1 << 23] * 4
+    emitted = bytearray()
+
+    def put(k, c, sy):
+        f = ctx_freqs[c][sy]
+        x = R[k]
+        while x >= ((1 << 23) >> 12 << 8) * f:
+            emitted.append(x & 0xFF)
+            x >>= 8
+        R[k] = (x // f << 12) + x % f + C[(c, sy)]
+
+    for i in reversed(range(4 * q, n)):                 # the remainder: state 3, behind its quarter
+        put(3, data[i - 1], data[i])
+    for j in reversed(range(q)):
+        for k in (3, 2, 1, 0):
+            i = k * q + j
+            put(k, data[i - 1] if j else 0, data[i])
+    ctxs = sorted(ctx_freqs)
+    tab, rle = bytearray(), 0
+    for k, c in enumerate(ctxs):
+        if rle:
+            rle -= 1
+        else:
+            tab.append(c)
+            if k and ctxs[k - 1] == c - 1:
+                run = 0
+                while k + run + 1 < len(ctxs) and ctxs[k + run + 1] == c + run + 1:
+                    run += 1
+                tab.append(run)
+                rle = run
+        tab += _rans4x8_table(ctx_freqs[c])
+    tab.append(0)
+    body = bytes(tab) + b"".join(x.to_bytes(4, "little") for x in R) + bytes(reversed(emitted))
+    return bytes([1]) + len(body).to_bytes(4, "little") + n.to_bytes(4, "little") + body
+
+
+def test_rans4x8_order1_streams_of_an_encoder_written_from_the_specification(tmp_path):
+    rng = np.random.default_rng(8)
+    for n in (4, 5, 7, 64, 1001, 5000):
+        data = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n, p=[0.5, 0.2, 0.2, 0.1]))
+        q = n >> 2
+        counts = {}
+        for i in range(n):
+            c = 0 if (i < 4 * q and i % q == 0) else data[i - 1]      # a quarter starts in context 0; the remainder continues the fourth
+            counts.setdefault(c, {}).setdefault(data[i], 0)
+            counts[c][data[i]] += 1
+        ctx_freqs = {}
+        for c, cn in counts.items():        # frequencies scaled to 4095 at most, every used symbol >= 1
+            tot = sum(cn.values())
+            fr = {sy: max(1, v * 4000 // tot) for sy, v in cn.items()}
+            ctx_freqs[c] = fr
+        r, got = _decode("rans4x8", _rans4x8_o1(data, ctx_freqs), n, tmp_path)
+        assert r.returncode == 0 and got == data, (n, r.stderr[-300:])
+
+
+def test_rans_nx16_framing_assembled_by_hand(tmp_path):
+    """CRAMcodecs 3: the flag byte (0x20 CAT = stored, 0x40 RLE, 0x80 PACK, 0x08 STRIPE, 0x10 NOSZ), sizes as uint7, PACK's symbol map
+    and LSB-first packing, RLE's metadata (symbols that carry runs, run lengths as uint7) -- with stored payloads, so that every byte
+    below is written out by hand"""
+    # stored
+    r, got = _decode("nx16", bytes([0x20]) + _u7(5) + b"hello", 5, tmp_path)
+    assert r.returncode == 0 and got == b"hello"
+    # PACK, two symbols -> one bit each, first symbol in bit 0: "ABBABBBA" + "AB" -> 0b10110110 = 0x76 ... 0b10 = 0x02
+    data = b"ABBABBBAAB"
+    pk = bytes([0x20 | 0x80]) + _u7(10) + bytes([2, 0x41, 0x42]) + _u7(2) + bytes([0b01110110, 0b00000010])
+    r, got = _decode("nx16", pk, 10, tmp_path)
+    assert r.returncode == 0 and got == data, (got, r.stderr[-200:])
+    # PACK, four symbols -> two bits each
+    pk4 = bytes([0xA0]) + _u7(5) + bytes([4]) + b"ACGT" + _u7(2) + bytes([0b11100100, 0b00000010])      # A C G T | G
+    r, got = _decode("nx16", pk4, 5, tmp_path)
+    assert r.returncode == 0 and got == b"ACGTG", (got, r.stderr[-200:])
+    # PACK with ONE symbol: nothing is stored but the length
+    r, got = _decode("nx16", bytes([0xA0]) + _u7(6) + bytes([1, 0x5A]) + _u7(0), 6, tmp_path)
+    assert r.returncode == 0 and got == b"ZZZZZZ"
+    # RLE: "aaaabccccc" = literals "abc", 'a' and 'c' carry runs (3 and 4 more); metadata stored raw (its length field is odd)
+    meta = bytes([2, 0x61, 0x63]) + _u7(3) + _u7(4)
+    rl = bytes([0x20 | 0x40]) + _u7(10) + _u7(len(meta) * 2 + 1) + _u7(3) + meta + b"abc"
+    r, got = _decode("nx16", rl, 10, tmp_path)
+    assert r.returncode == 0 and got == b"aaaabccccc", (got, r.stderr[-200:])
+    # STRIPE over two stored sub-streams: byte i of the output comes from sub-stream i mod 2
+    s0, s1 = bytes([0x20]) + _u7(3) + b"ace", bytes([0x20]) + _u7(2) + b"bd"
+    st = bytes([0x08]) + _u7(5) + bytes([2]) + _u7(len(s0)) + _u7(len(s1)) + s0 + s1
+    r, got = _decode("nx16", st, 5, tmp_path)
+    assert r.returncode == 0 and got == b"abcde", (got, r.stderr[-200:])
+
+
+def _nx16_o0(data, freqs):
+    """rANS Nx16 order 0, N = 4 (CRAMcodecs 3.1-3.2): alphabet (run-length form), frequencies as uint7 summing to 4096, 16-bit
+    renormalisation with the lower bound 2^15, symbol i on state i mod 4 (the last n mod 4 symbols on states 0.. without a turn)"""
+    syms = sorted(freqs)
+    alpha, rle = bytearray(), 0
+    for k, sy in enumerate(syms):
+        if rle:
+            rle -= 1
+            continue
+        alpha.append(sy)
+        if k and syms[k - 1] == sy - 1:
+            run = 0
+            while k + run + 1 < len(syms) and syms[k + run + 1] == sy + run + 1:
+                run += 1
+            alpha.append(run)
+            rle = run
+    alpha.append(0)
+    C, acc = {}, 0
+    for sy in syms:
+        C[sy] = acc
+        acc += freqs[sy]
+    assert acc == 4096
+    R = [1 << 15] * 4
+    emitted = []
+
+    def put(k, sy):
+        f = freqs[sy]
+        x = R[k]
+        if x >= ((1 << 15) >> 12 << 16) * f:
+            emitted.append(x & 0xFFFF)
+            x >>= 16
+        R[k] = (x // f << 12) + x % f + C[sy]
+
+    n = len(data)
+    full = n - n % 4
+    for k in reversed(range(n - full)):
+        put(k, data[full + k])
+    for i in reversed(range(full)):
+        put(i & 3, data[i])
+    return (bytes([0x00]) + _u7(n) + bytes(alpha) + b"".join(_u7(freqs[sy]) for sy in syms) + b"".join(x.to_bytes(4, "little") for x in R)
+            + b"".join(w.to_bytes(2, "little") for w in reversed(emitted)))
+
+
+def test_rans_nx16_order0_streams_of_an_encoder_written_from_the_specification(tmp_path):
+    rng = np.random.default_rng(12)
+    freqs = {0x00: 6, 0x41: 2000, 0x42: 1000, 0x43: 500, 0x44: 300, 0x47: 200, 0x54: 90}
+    syms = np.array(sorted(freqs), np.uint8)
+    p = np.array([freqs[int(s_)] for s_ in syms], float) / 4096
+    for n in (1, 3, 4, 6, 64, 1000, 4099):
+        data = bytes(rng.choice(syms, n, p=p))
+        r, got = _decode("nx16", _nx16_o0(data, freqs), n, tmp_path)
+        assert r.returncode == 0 and got == data, (n, r.stderr[-200:])
+
+
+def test_name_tokeniser_block_assembled_by_hand(tmp_path):
+    """CRAMcodecs 5: header (uncompressed size, number of names, arithmetic-coder flag), then per token position its type stream and
+    value streams, each a (here: stored) rANS Nx16 stream behind a byte `new position | duplicate | type` and a uint7 length.  Names
+    "A1", "A2", "A2": DIFF 0 / ALPHA "A" / DIGITS 1 / END; DIFF 1 / MATCH / DELTA 1 / END; DUP 1."""
+    TYPE, ALPHA, DUP, DIFF, DIGITS, DELTA, MATCH, END = 0, 1, 5, 6, 7, 8, 10, 12
+
+    def stream(first, typ, payload):
+        s = bytes([0x20]) + _u7(len(payload)) + payload
+        return bytes([(0x80 if first else 0) | typ]) + _u7(len(s)) + s
+
+    u32 = lambda v: v.to_bytes(4, "little")
+    blk = (u32(9) + u32(3) + bytes([0])
+           + stream(True, TYPE, bytes([DIFF, DIFF, DUP])) + stream(False, DIFF, u32(0) + u32(1)) + stream(False, DUP, u32(1))
+           + stream(True, TYPE, bytes([ALPHA, MATCH])) + stream(False, ALPHA, b"A\0")
+           + stream(True, TYPE, bytes([DIGITS, DELTA])) + stream(False, DIGITS, u32(1)) + stream(False, DELTA, bytes([1]))
+           + stream(True, TYPE, bytes([END, END])))
+    r, got = _decode("tok3", blk, 9, tmp_path)
+    assert r.returncode == 0 and got == b"A1\0A2\0A2\0", (got, r.stderr[-300:])
+    # the same with position 3's type stream left out: "every name has END here"
+    blk2 = blk[:blk.rindex(stream(True, TYPE, bytes([END, END])))] + stream(True, END, b"")
+    r, got = _decode("tok3", blk2, 9, tmp_path)
+    assert r.returncode in (0, 1)          # (an END value stream is nothing the format writes: either verdict, never a signal)
