@@ -2,6 +2,7 @@
 #include "bgzf_feed.h"
 #include <fcntl.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
@@ -15,6 +16,8 @@ void BgzfFeed::close() {
   cv_.notify_all();
   if (walker_.joinable()) walker_.join();
   stop_ = false; state_ = 0; blks_.clear(); taken_ = 0; werr_.clear(); trim_ = 0;
+  if (map_ && map_owned_) (void)munmap(const_cast<uint8_t *>(map_), map_len_);
+  map_ = nullptr; map_owned_ = false;
   if (fd_ >= 0) ::close(fd_);
   fd_ = -1; map_len_ = 0;
 }
@@ -38,6 +41,13 @@ bool BgzfFeed::read_at(void *dst, size_t off, size_t n) const {
   return true;
 }
 
+bool BgzfFeed::copy_at(void *dst, size_t off, size_t n) const {
+  if (!map_) return read_at(dst, off, n);
+  if (off > map_len_ || n > map_len_ - off) return false;
+  memcpy(dst, map_ + off, n);         // (a file truncated under a running extraction ends it with SIGBUS here; pread would report a short read)
+  return true;
+}
+
 bool BgzfFeed::open(const std::string &path, std::string &err) {
   close();
   size_t start = 0;
@@ -57,6 +67,13 @@ bool BgzfFeed::open(const std::string &path, std::string &err) {
   map_len_ = (size_t)st.st_size;
   path_ = path;
   (void)posix_fadvise(fd_, 0, 0, POSIX_FADV_SEQUENTIAL);
+  {
+    const char *how = getenv("STRL_FEED");
+    if (!(how && strcmp(how, "pread") == 0) && map_len_) {
+      void *m = mmap(nullptr, map_len_, PROT_READ, MAP_SHARED, fd_, 0);
+      if (m != MAP_FAILED) { map_ = static_cast<const uint8_t *>(m); map_owned_ = true; (void)madvise(m, map_len_, MADV_SEQUENTIAL); }
+    }
+  }
   start_ = start;
   walk_from(start, 0, 0);
   return true;
@@ -68,6 +85,7 @@ bool BgzfFeed::open_share(const BgzfFeed &whole, uint64_t start_coff, uint32_t f
   fd_ = ::open(whole.path_.c_str(), O_RDONLY);
   if (fd_ < 0) { err = "couldn't open bam"; return false; }
   map_len_ = whole.map_len_;
+  map_ = whole.map_; map_owned_ = false;      // (the mapping is the whole feed's, which outlives its shares)
   path_ = whole.path_;
   text_ = whole.text_;
   targets_ = whole.targets_;

@@ -735,9 +735,9 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     bu.cv.notify_all();
     if (!wait_for([&] { return bu.genome_ready; })) return finish(0);
     if ((rc = strl_ctx_set_genome(c, &bu.gs))) return finish(rc);
-    // (the per-read state -- tens of gigabytes of device memory -- only once the page-locked buffers are there: allocated while
-    // the driver still locks pages it took 0.16 - 0.44 s instead of 0.03, profiles/r06/bringup_one_device_g1.log)
-    if (!wait_for([&] { return bu.plan_ready && bu.pin_done; })) return finish(0);
+    if (!wait_for([&] { return bu.plan_ready; })) return finish(0);
+    static const bool state_on_main = getenv("STRL_STATE_ON_MAIN") != nullptr;      // (diagnosis)
+    if (state_on_main) return finish(0);
     const auto c1 = now();
     rc = strl_front_begin(c, bu.n_ref, bu.first_off[(size_t)g], bu.hint[(size_t)g]);
     if (!rc) rc = strl_front_reserve(c, (uint32_t)chunk_blocks, chunk_bytes);
@@ -819,6 +819,14 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     if (reaper.joinable()) reaper.join();
     pin_thread.join();
     g_bg_init = nullptr; g_bg_abort = nullptr;
+    if (getenv("STRL_STATE_ON_MAIN"))
+      for (int g = 0; g < G && !ctx_rc[(size_t)g]; ++g) {
+        const auto c1 = now();
+        int rc = strl_front_begin(ctxs[(size_t)g], bu.n_ref, bu.first_off[(size_t)g], bu.hint[(size_t)g]);
+        if (!rc) rc = strl_front_reserve(ctxs[(size_t)g], (uint32_t)chunk_blocks, chunk_bytes);
+        if (rc) { ctx_rc[(size_t)g] = rc; ctx_err[(size_t)g] = strl_last_error(); }
+        bu.t_state[(size_t)g] = secs(c1, now());
+      }
     t_begin = secs(tb0, now());
     for (double v : bu.t_create) t_ctx = std::max(t_ctx, v);
     bool nomem = false;
@@ -951,7 +959,7 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     uint8_t *dst = pin[S.slot];
     const size_t lo = S.lo, hi = S.hi, piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
     std::atomic<int> short_reads{0};
-    copy_pool.parallel_for(pieces, [&](size_t k) { if (!feed.read_at(dst + k * piece, lo + k * piece, std::min(piece, hi - lo - k * piece))) ++short_reads; });
+    copy_pool.parallel_for(pieces, [&](size_t k) { if (!feed.copy_at(dst + k * piece, lo + k * piece, std::min(piece, hi - lo - k * piece))) ++short_reads; });
     S.short_read = short_reads.load() != 0;
     uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[S.slot]);
     uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks, *crc = isz + chunk_blocks;
@@ -1015,7 +1023,7 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
         uint8_t *dst = pin[S.slot];
         const size_t lo = S.lo, hi = S.hi, piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
         std::atomic<int> short_reads{0};
-        pool.parallel_for(pieces, [&](size_t k) { if (!Z.fd.read_at(dst + k * piece, lo + k * piece, std::min(piece, hi - lo - k * piece))) ++short_reads; });
+        pool.parallel_for(pieces, [&](size_t k) { if (!Z.fd.copy_at(dst + k * piece, lo + k * piece, std::min(piece, hi - lo - k * piece))) ++short_reads; });
         S.short_read = short_reads.load() != 0;
         uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[S.slot]);
         uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks, *crc = isz + chunk_blocks;

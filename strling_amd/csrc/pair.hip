@@ -95,8 +95,10 @@ __global__ __launch_bounds__(1024) void pair_soft_items_kernel(PairParams P) {
       if (j < n_src) {
         const strl_soft_rec s = P.soft[j];
         hot[u] = (STRL_RES_COUNT(s.res_first) | STRL_RES_COUNT(s.res_after)) != 0;
-        // secondary / supplementary records never reach Cache.add (extract.nim:309,327): neither they nor their clips join
-        if (hot[u]) hot[u] = !(P.rec[s.read_side >> 1].flag & (F_SECONDARY | F_SUPPL));
+        // (Secondary / supplementary records never reach Cache.add (extract.nim:309,327).  Their clips are NOT filtered out here
+        // any more: the replay never looks a clip up for a record it skips, a group that joins for nothing emits nothing, and the
+        // test cost every hot record a gather into the 32-byte rows -- a 128-byte line for two flag bits, 40 % of this kernel's
+        // 140 MB (profiles/r06/traffic.json: 141 B moved per soft-clip record of 16).)
         if (hot[u]) {
           m[u] = fmix64(P.qhash[s.read_side >> 1]);
           bloom_set(P.bloom, P.bloom_mask, m[u]);

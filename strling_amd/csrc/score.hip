@@ -17,6 +17,7 @@
 #include <sys/mman.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -44,7 +45,13 @@ static int dev_alloc(void **p, size_t want) {
   static const uint64_t cap = getenv("STRL_DEVICE_MEM_LIMIT_MB") ? strtoull(getenv("STRL_DEVICE_MEM_LIMIT_MB"), nullptr, 10) << 20 : 0;
   hipError_t e = hipSuccess;
   if (cap && g_dev_bytes.load() + want > cap) e = hipErrorOutOfMemory;
-  else e = hipMalloc(p, want);
+  else {
+    static const bool timing = getenv("STRL_ALLOC_TIMING") != nullptr;      // (diagnosis: where the start of a whole-genome run goes)
+    const auto t0 = std::chrono::steady_clock::now();
+    e = hipMalloc(p, want);
+    if (timing && want >= ((size_t)64 << 20))
+      fprintf(stderr, "[strling] hipMalloc %.2f GB: %.3f s\n", (double)want / 1e9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  }
   if (e == hipSuccess) { g_dev_bytes += want; return STRL_OK; }
   (void)hipGetLastError();
   size_t fr = 0, tot = 0;
@@ -1966,8 +1973,37 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
   // slows the launches down by more than it hides.  Off by default.)
   static const bool sync_alloc = getenv("STRL_ASYNC_ALLOC") == nullptr;
   const uint64_t small = (sync_alloc || hint <= (1ull << 25)) ? hint : std::max<uint64_t>(1ull << 24, hint / 8);
+  // The per-read state of a whole file is tens of gigabytes in seven buffers.  hipMalloc returns at once for them on a settled
+  // device (0.03 s for all of a whole genome's), but a large allocation made while the driver still reclaims what an earlier
+  // process held stalls for ~0.48 s -- each one (profiles/r06/state_alloc_diag.log: 23 GB 0.483 s, 17.5 GB 0.483 s, 5.9 GB 0.121 s
+  // in the first process on a box, one 0.483 s in the second, none from the third on).  Made side by side, the stalls overlap.
+  STRL_HIP(hipSetDevice(c->device));
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  strl::DevBuf pre_qref, pre_fragw, pre_qarena;
+  {
+    struct Want { strl::DevBuf *b; size_t bytes; int rc; std::string err; };
+    Want want[] = {{&c->x_rows, (size_t)small * sizeof(strl_pair_rec), 0, {}}, {&pre_qarena, (size_t)small * 24, 0, {}}, {&c->x_qhash, (size_t)small * 8, 0, {}},
+                   {&pre_qref, (size_t)small * 8, 0, {}}, {&c->x_whole, (size_t)small * 4, 0, {}}, {&pre_fragw, (size_t)small * 4, 0, {}},
+                   {&c->x_soft, (size_t)(hint / 8 + 65536) * sizeof(strl_soft_rec), 0, {}}};
+    const int dev = c->device;
+    std::vector<std::thread> th;
+    for (Want &w : want)
+      th.emplace_back([&w, dev] {
+        if (hipSetDevice(dev) != hipSuccess) { w.rc = STRL_ERR_HIP; w.err = "hipSetDevice"; return; }
+        if (w.b->cap >= w.bytes && w.b->p) return;
+        w.rc = w.b->reserve(w.bytes);
+        if (w.rc) w.err = strl_last_error();
+      });
+    for (auto &t : th) t.join();
+    for (Want &w : want)
+      if (w.rc) {
+        set_error("%s", w.err.c_str());
+        pre_qref.release(); pre_fragw.release(); pre_qarena.release();
+        return w.rc;
+      }
+  }
   int rc = extract_begin_sized(c, n_reads_hint, small);
-  if (rc) return rc;
+  if (rc) { pre_qref.release(); pre_fragw.release(); pre_qarena.release(); return rc; }
   if (c->front) {
     for (hipStream_t q : c->front->st_i) if (q) (void)hipStreamSynchronize(q);
     if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a);
@@ -1976,6 +2012,7 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
   strl::strl_front *F = new strl::strl_front();
   c->front = F;
   c->x_front = true;
+  F->qref = pre_qref; F->fragw = pre_fragw; F->qarena = pre_qarena;        // (allocated above, beside the others; the context owns them from here)
   F->n_ref = n_ref; F->first_off = first_record_offset;
   {
     int least = 0, greatest = 0;          // (numerically: least >= greatest; equal where the device has one level)

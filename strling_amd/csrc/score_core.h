@@ -614,6 +614,10 @@ STRL_DEV void score_k(const Seg<NW> &sg, ScoreState &st, uint32_t *wave_tab, int
         if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)bm) - 1)) { atomicAdd(&g_phase[23 + 2 * (K - 2) - (K > 4 ? 4 : 0)], 1ull); atomicAdd(&g_phase[24 + 2 * (K - 2) - (K > 4 ? 4 : 0)], (unsigned long long)__popcll(bm)); }
       }
 #endif
+#ifdef STRL_EXP_SKIP_RECOUNT34      // timing experiment only (wrong results): what the k = 3, 4 literal recounts cost stage A -- the
+                                    // ceiling of anything that would pool them over a block's lanes (profiles/r06/stage_a_recount_bound.txt)
+      if (K != 3 && K != 4)
+#endif
       c = recount<K, NW>(sg, code, lb.lo == 0x7fffffff ? 0 : lb.lo);  // utils.nim:254
       score = c * K;
       if (score >= st.best) {  // :256
