@@ -439,7 +439,7 @@ def tok3_encode(names, stream_kw=None, dup_streams=True):
 
 
 # ---- blocks, encodings ----------------------------------------------------------------------------------------------
-RAW, GZIP, RANS = 0, 1, 4
+RAW, GZIP, BZIP2, LZMA, RANS = 0, 1, 2, 3, 4
 RANSNX16, TOK3 = 5, 8
 FILE_HEADER, COMPRESSION_HEADER, SLICE_HEADER, EXTERNAL_DATA, CORE_DATA = 0, 1, 2, 4, 5
 
@@ -448,6 +448,12 @@ def block(method, content_type, content_id, raw):
     raw = bytes(raw)
     if method == GZIP:
         data = gzip.compress(raw, 6, mtime=0)
+    elif method == BZIP2:
+        import bz2
+        data = bz2.compress(raw, 9)
+    elif method == LZMA:
+        import lzma
+        data = lzma.compress(raw, format=lzma.FORMAT_XZ)
     elif method == (RANS, 0):
         data, method = rans_encode(raw, 0), RANS
     elif method == (RANS, 1):
@@ -677,7 +683,7 @@ def _chain_fields(xs):
 
 
 def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_per_container=2, read_names=True, index=True, ap_delta=True,
-               multi_ref=False, qualities=False, tags=False, slice_md5=True, stats=None, repeat=1, version=(3, 0)):
+               multi_ref=False, qualities=False, tags=False, slice_md5=True, stats=None, repeat=1, version=(3, 0), block_methods=None, embed_ref=False):
     """records of `rec` (coordinate sorted, unmapped tail last) -> CRAM 3.0 + .crai.  refs[tid] = reference bytes (ACGTN).
     multi_ref: slices run across reference boundaries (slice reference id -2, RI per record); qualities: every record carries its
     quality array (CF bit 1, QS per base); tags: every record carries NM:C and MD:Z (tag dictionary + tag encoding map: values
@@ -687,6 +693,8 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
     out = bytearray(b"CRAM" + bytes(version) + b"strling-test".ljust(20, b"\0"))
     # version 3.1: the external blocks rotate through the rANS Nx16 variants too, the read names go through the name tokeniser
     methods = METHODS if tuple(version) == (3, 0) else METHODS + METHODS_31
+    if block_methods:                   # (tests: the methods the external blocks rotate through, e.g. bzip2 / lzma)
+        methods = list(block_methods)
 
     def container(ref_id, start, span, n_rec, counter, bases, blocks, landmarks):
         body = b"".join(blocks)
@@ -893,8 +901,13 @@ def write_cram(path, rec, refs, header_text=None, records_per_slice=300, slices_
                     multi_lines.append((t2, a2, b2 - a2 + 1))
             # the MD5 of the reference bases the slice spans (CRAMv3 section 8.5); multi-reference and unmapped slices carry zeros
             md5 = hashlib.md5(bytes(refs[tid][s_start - 1:s_start - 1 + span]).upper()).digest() if tid >= 0 and span and slice_md5 else bytes(16)
+            emb_id = -1
+            if embed_ref and tid >= 0 and span:      # samtools' embed_ref: the bases the slice spans travel in an external block of their own
+                emb_id = 250
+                eblocks.append(block(GZIP, EXTERNAL_DATA, emb_id, bytes(refs[tid][s_start - 1:s_start - 1 + span])))
+                used = used + [emb_id]
             sh = itf8(tid) + itf8(s_start if tid >= 0 else 0) + itf8(span) + itf8(len(rs)) + ltf8(counter) + itf8(1 + len(eblocks)) + \
-                itf8(len(used)) + b"".join(itf8(k) for k in used) + itf8(-1) + md5
+                itf8(len(used)) + b"".join(itf8(k) for k in used) + itf8(emb_id) + md5
             shb = block(RAW, SLICE_HEADER, 0, sh)
             landmarks.append(at)
             sl_bytes = shb + core + b"".join(eblocks)

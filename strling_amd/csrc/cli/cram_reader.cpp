@@ -5,6 +5,7 @@
 // (leftmost start to rightmost end, positive for the leftmost record) -- unverifiable here, no htslib in this image.
 #include "cram_reader.h"
 #include "cram_codecs.h"
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <string.h>
 #include <sys/mman.h>
@@ -250,8 +251,38 @@ static bool block_data_unguarded(const Block &b, std::vector<uint8_t> &out, std:
       if (!ok) err = "corrupt gzip block in the CRAM";
       return ok;
     }
-    case 2: err = "the CRAM holds bzip2-compressed blocks: not supported by this build (re-encode with `samtools view -C --output-fmt-option use_bzip2=0`)"; return false;
-    case 3: err = "the CRAM holds lzma-compressed blocks: not supported by this build (re-encode with `samtools view -C --output-fmt-option use_lzma=0`)"; return false;
+    case 2: {
+      // bzip2 / lzma blocks (samtools' use_bzip2 / use_lzma, the `archive` profile): through the system's libbz2 / liblzma, bound
+      // at first use -- the image has the libraries without their headers, so the two entry points are declared here from the
+      // libraries' documented, stable C interfaces
+      typedef int (*bz_fn)(char *, unsigned int *, char *, unsigned int, int, int);
+      static bz_fn fn = [] {
+        void *h = nullptr;
+        for (const char *n : {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"}) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        return h ? reinterpret_cast<bz_fn>(dlsym(h, "BZ2_bzBuffToBuffDecompress")) : nullptr;
+      }();
+      if (!fn) { err = "the CRAM holds bzip2-compressed blocks and libbz2 is not on this system (re-encode with `samtools view -C --output-fmt-option use_bzip2=0`)"; return false; }
+      out.resize(b.rsize);
+      unsigned int got = b.rsize;
+      const int rc = b.rsize ? fn(reinterpret_cast<char *>(out.data()), &got, reinterpret_cast<char *>(const_cast<uint8_t *>(b.data)), b.csize, 0, 0) : 0;
+      if (rc != 0 || got != b.rsize) { err = "corrupt bzip2 block in the CRAM"; return false; }
+      return true;
+    }
+    case 3: {
+      typedef int (*lz_fn)(uint64_t *, uint32_t, const void *, const uint8_t *, size_t *, size_t, uint8_t *, size_t *, size_t);   // lzma_stream_buffer_decode
+      static lz_fn fn = [] {
+        void *h = nullptr;
+        for (const char *n : {"liblzma.so.5", "liblzma.so"}) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        return h ? reinterpret_cast<lz_fn>(dlsym(h, "lzma_stream_buffer_decode")) : nullptr;
+      }();
+      if (!fn) { err = "the CRAM holds lzma-compressed blocks and liblzma is not on this system (re-encode with `samtools view -C --output-fmt-option use_lzma=0`)"; return false; }
+      out.resize(b.rsize);
+      uint64_t memlimit = (uint64_t)2 << 30;
+      size_t in_pos = 0, out_pos = 0;
+      const int rc = b.rsize ? fn(&memlimit, 0, nullptr, b.data, &in_pos, b.csize, out.data(), &out_pos, b.rsize) : 0;
+      if (rc != 0 || out_pos != b.rsize) { err = "corrupt lzma block in the CRAM"; return false; }      // (0 = LZMA_OK)
+      return true;
+    }
     case 4: return rans_decode(b.data, b.csize, out, b.rsize, err);
     case 5: return cram_rans_nx16_decode(b.data, b.csize, b.rsize, out, err);        // CRAM 3.1 (cram_codecs.cpp)
     case 8: return cram_tok3_decode(b.data, b.csize, b.rsize, out, err);
@@ -851,13 +882,14 @@ bool CramFile::decode_container_body(const Container &c, int64_t only_landmark, 
     for (int32_t k = 0; k < n_ids && h.ok; ++k) h.itf8();
     const int32_t embedded = h.itf8();
     if (!h.ok || s_nrec < 0 || s_nblocks < 0 || s_nrec > (1 << 24) || s_nblocks > (1 << 16)) { err = "malformed CRAM slice header"; return false; }
-    if (embedded >= 0) { err = "the CRAM slice embeds its reference: not supported by this build (samtools view -C --output-fmt-option embed_ref=0)"; return false; }
+    // (embedded >= 0: the slice carries the reference bases it spans in the external block of that content id -- samtools'
+    // embed_ref; taken from there below instead of the FASTA, which such a file needs none of)
     uint8_t s_md5[16] = {0};
     for (int k = 0; k < 16; ++k) s_md5[k] = h.u8();
     if (!h.ok) { err = "truncated CRAM slice header"; return false; }
     // The MD5 of the reference bases the slice spans, as the writer saw them (CRAMv3 section 8.5): a FASTA that differs there
     // (another build, a patched contig) would give other bases for every matching position -- htslib fails the slice, so do we
-    if (s_ref >= 0 && (size_t)s_ref < targets_.size() && s_span > 0 && H.rr) {
+    if (embedded < 0 && s_ref >= 0 && (size_t)s_ref < targets_.size() && s_span > 0 && H.rr) {
       bool any = false;
       for (uint8_t x : s_md5) any = any || x;
       if (any) {
@@ -883,11 +915,33 @@ bool CramFile::decode_container_body(const Container &c, int64_t only_landmark, 
     }
     for (auto &kv : X.ext) if (kv.first >= 0 && kv.first < 128) X.fast[kv.first] = &kv.second;
     std::shared_ptr<const std::string> ref;
+    int64_t ref_off = 0;           // 0-based reference position of ref's first base (an embedded reference starts at the slice's)
     int32_t ref_of = -3;
+    std::shared_ptr<std::string> emb;
+    if (embedded >= 0) {
+      if (s_ref < 0) { err = "CRAM slice with an embedded reference but no single reference sequence"; return false; }
+      auto it = X.ext.find(embedded);
+      if (it == X.ext.end()) { err = "CRAM slice names an embedded-reference block it does not hold"; return false; }
+      std::vector<uint8_t> eb;
+      if (!block_data(it->second.src, eb, err)) return false;
+      emb = std::make_shared<std::string>(eb.begin(), eb.end());
+      for (char &ch : *emb) if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+      uint8_t got[16];
+      bool any = false;
+      for (uint8_t x : s_md5) any = any || x;
+      if (any) {                     // (the slice's MD5 covers the bases it spans: here the embedded ones)
+        Md5 m;
+        m.update(reinterpret_cast<const uint8_t *>(emb->data()), std::min<size_t>(emb->size(), (size_t)std::max(s_span, 0)));
+        m.finish(got);
+        if (memcmp(got, s_md5, 16) != 0) { err = "CRAM slice: MD5 mismatch on its embedded reference"; return false; }
+      }
+    }
     auto need_ref = [&](int32_t id) -> bool {
       if (id == ref_of) return true;
       ref.reset();
       ref_of = id;
+      ref_off = 0;
+      if (emb && id == s_ref) { ref = emb; ref_off = (int64_t)s_start - 1; return true; }
       if (id < 0 || (size_t)id >= targets_.size()) return true;
       ref = ref_->get(targets_[(size_t)id].name, err);
       if (!ref && H.rr) { if (err.empty()) err = "reference sequence " + targets_[(size_t)id].name + " of the CRAM is not in the FASTA"; return false; }
@@ -941,8 +995,8 @@ bool CramFile::decode_container_body(const Container &c, int64_t only_landmark, 
           const int32_t n = upto - qpos;
           if (n <= 0) return;
           {   // the part of [rpos, rpos + n) the reference covers in one copy, 'N' around it (seqs was filled with 'N')
-            const int64_t lo = std::max<int64_t>(rpos, 0), hi = ref ? std::min<int64_t>(rpos + n, (int64_t)ref->size()) : lo;
-            if (hi > lo) memcpy(sq + qpos + (lo - rpos), ref->data() + lo, (size_t)(hi - lo));
+            const int64_t lo = std::max<int64_t>(rpos, ref_off), hi = ref ? std::min<int64_t>(rpos + n, ref_off + (int64_t)ref->size()) : lo;
+            if (hi > lo) memcpy(sq + qpos + (lo - rpos), ref->data() + (lo - ref_off), (size_t)(hi - lo));
           }
           push(0, (uint32_t)n);
           rpos += n; qpos += n; ref_used += n;
@@ -957,7 +1011,7 @@ bool CramFile::decode_container_body(const Container &c, int64_t only_landmark, 
             case 'X': {
               const int bs = dec_byte(eBS, X);
               if (qpos >= R.rl) { X.fail("read feature outside its read"); break; }
-              const char rb = ref && rpos >= 0 && (size_t)rpos < ref->size() ? (*ref)[(size_t)rpos] : 'N';
+              const char rb = ref && rpos >= ref_off && (size_t)(rpos - ref_off) < ref->size() ? (*ref)[(size_t)(rpos - ref_off)] : 'N';
               sq[qpos] = subst(H.sm, rb, bs & 3);
               push(0, 1); ++rpos; ++qpos; ++ref_used;
               break;

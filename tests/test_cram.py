@@ -128,10 +128,21 @@ def test_cram_variants_and_refusals(cram_sample, tmp_path):
                             dict(multi_ref=True, qualities=True, tags=True, ap_delta=False),
                             # CRAM 3.1: rANS Nx16 in every variant over the external blocks, the read names through the name tokeniser
                             dict(version=(3, 1)), dict(version=(3, 1), records_per_slice=97, slices_per_container=3, qualities=True, tags=True),
-                            dict(version=(3, 1), multi_ref=True, ap_delta=False))):
+                            dict(version=(3, 1), multi_ref=True, ap_delta=False),
+                            # bzip2 and lzma blocks (samtools' use_bzip2 / use_lzma, the archive profile): the system's libbz2 / liblzma
+                            dict(block_methods=[cramio.BZIP2, cramio.LZMA, cramio.RAW], records_per_slice=211),
+                            dict(version=(3, 1), block_methods=[cramio.LZMA, cramio.BZIP2, cramio.GZIP], qualities=True, tags=True))):
         p = str(tmp_path / f"v{k}.cram")
         cramio.write_cram(p, rec, refs, index=False, **kw)
         r = _run(["_dump", p], env=env)
+        assert r.returncode == 0 and r.stdout == base, (kw, r.stderr[-300:])
+    # embedded reference (samtools' embed_ref): the slices carry the bases they span, the FASTA's own bases are never looked at
+    wrong = str(tmp_path / "wrong.fa")
+    cramio.write_fasta(wrong, rec.targets, [bytes(b"ACGT"[(k * 7 + 1) % 4] for k in range(len(x))) for x in refs])
+    for k, kw in enumerate((dict(embed_ref=True), dict(embed_ref=True, version=(3, 1), records_per_slice=150, ap_delta=False))):
+        p = str(tmp_path / f"emb{k}.cram")
+        cramio.write_cram(p, rec, refs, index=False, **kw)
+        r = _run(["_dump", p], env=dict(os.environ, STRL_CRAM_FASTA=wrong))
         assert r.returncode == 0 and r.stdout == base, (kw, r.stderr[-300:])
     # no reference given / a reference without the contigs
     r = _run(["_dump", cram_sample["cram"]], env={k: v for k, v in os.environ.items() if k != "STRL_CRAM_FASTA"})
