@@ -48,6 +48,12 @@ bool BgzfFeed::copy_at(void *dst, size_t off, size_t n) const {
   return true;
 }
 
+void BgzfFeed::done_with(size_t off, size_t n) const {
+  if (!map_ || !n) return;
+  const size_t page = 4096, lo = (off + page - 1) & ~(page - 1), hi = (off + n) & ~(page - 1);
+  if (hi > lo) (void)madvise(const_cast<uint8_t *>(map_) + lo, hi - lo, MADV_DONTNEED);
+}
+
 bool BgzfFeed::open(const std::string &path, std::string &err) {
   close();
   size_t start = 0;

@@ -959,7 +959,11 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     uint8_t *dst = pin[S.slot];
     const size_t lo = S.lo, hi = S.hi, piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
     std::atomic<int> short_reads{0};
-    copy_pool.parallel_for(pieces, [&](size_t k) { if (!feed.copy_at(dst + k * piece, lo + k * piece, std::min(piece, hi - lo - k * piece))) ++short_reads; });
+    copy_pool.parallel_for(pieces, [&](size_t k) {
+      const size_t at = lo + k * piece, len = std::min(piece, hi - lo - k * piece);
+      if (!feed.copy_at(dst + k * piece, at, len)) ++short_reads;
+      feed.done_with(at, len);
+    });
     S.short_read = short_reads.load() != 0;
     uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[S.slot]);
     uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks, *crc = isz + chunk_blocks;
@@ -1023,7 +1027,11 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
         uint8_t *dst = pin[S.slot];
         const size_t lo = S.lo, hi = S.hi, piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
         std::atomic<int> short_reads{0};
-        pool.parallel_for(pieces, [&](size_t k) { if (!Z.fd.copy_at(dst + k * piece, lo + k * piece, std::min(piece, hi - lo - k * piece))) ++short_reads; });
+        pool.parallel_for(pieces, [&](size_t k) {
+          const size_t at = lo + k * piece, len = std::min(piece, hi - lo - k * piece);
+          if (!Z.fd.copy_at(dst + k * piece, at, len)) ++short_reads;
+          Z.fd.done_with(at, len);
+        });
         S.short_read = short_reads.load() != 0;
         uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[S.slot]);
         uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks, *crc = isz + chunk_blocks;

@@ -142,6 +142,21 @@ def test_extract_bin_is_byte_identical_to_oracle(sample, oracle):
 
 
 @pytest.mark.gpu
+def test_extract_device_option_and_both_feeds_write_the_same_bin(sample):
+    """--device K / STRL_DEVICE (one `strling` process per sample, each on its own GPU: pipelines/bpipe.config:4): ordinals wrap
+    around the devices there are; the compressed bytes copied out of the file's mapping (default) or read with pread
+    (STRL_FEED=pread): one .bin"""
+    outs = []
+    for k, (args, env) in enumerate(((["--device", "0"], {}), (["--device", "5"], {}), ([], {"STRL_DEVICE": "3"}), ([], {"STRL_FEED": "pread"}),
+                                     (["--gpus", "2", "--device", "1"], {}))):
+        out = str(sample["dir"] / f"dev{k}.bin")
+        r = _run(["extract", "-g", sample["bed"]] + args + [sample["bam"], out], env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        outs.append(open(out, "rb").read())
+    assert all(o == outs[0] for o in outs) and len(outs[0]) > 1000
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("what", ["crc", "payload"])
 def test_extract_reports_a_damaged_bgzf_block(sample, what):
     """a block whose CRC-32 field was changed: the device front end stops like htslib does; a damaged DEFLATE payload: the
