@@ -695,14 +695,22 @@ int strl_bin_write(const char *path, float proportion_repeat, uint8_t min_mapq, 
     std::vector<off_t> at((size_t)n_parts + 1, 0);
     std::atomic<uint64_t> next{0};
     std::vector<std::thread> th;
-    for (unsigned k = 0; k < n_thr; ++k)          // pass 1: every range's size (packed into the thread's buffer, not kept)
+    auto usz = [](uint64_t v) -> size_t { return v < 128 ? 1 : v < 256 ? 2 : v < 65536 ? 3 : 5; };
+    auto isz = [&](int32_t v) -> size_t { return v >= 0 ? usz((uint64_t)v) : v >= -32 ? 1 : v >= -128 ? 2 : v >= -32768 ? 3 : 5; };
+    for (unsigned k = 0; k < n_thr; ++k)          // pass 1: every range's size, by arithmetic (pass 2 checks it against what it packs)
       th.emplace_back([&] {
-        std::vector<uint8_t> buf;
         for (uint64_t q; (q = next.fetch_add(1)) < n_parts;) {
           const uint64_t i0 = q * per, i1 = std::min(n, i0 + per);
-          const size_t need = room(i0, i1);
-          if (buf.size() < need) buf.resize(need + need / 8);
-          at[(size_t)q + 1] = (off_t)(pack(buf.data(), i0, i1) - buf.data());
+          size_t bytes = 0;
+          for (uint64_t i = i0; i < i1; ++i) {
+            const strl_tread &t = treads[i];
+            const uint64_t ql = qname_off[t.qname_id + 1] - qname_off[t.qname_id];
+            size_t b = isz(t.tid) + usz(t.position) + 1 + usz(t.flag) + usz(t.split) + usz(t.mapping_quality) + usz(t.repeat_count) + usz(t.align_length) + usz(ql) +
+                       (ql < 32 ? 1 : ql < 256 ? 2 : ql < 65536 ? 3 : 5) + (size_t)ql;
+            for (int j = 0; j < 6; ++j) b += usz((uint8_t)t.repeat[j]);
+            bytes += b;
+          }
+          at[(size_t)q + 1] = (off_t)bytes;
         }
       });
     for (auto &t : th) t.join();
