@@ -959,11 +959,8 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     uint8_t *dst = pin[S.slot];
     const size_t lo = S.lo, hi = S.hi, piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
     std::atomic<int> short_reads{0};
-    copy_pool.parallel_for(pieces, [&](size_t k) {
-      const size_t at = lo + k * piece, len = std::min(piece, hi - lo - k * piece);
-      if (!feed.copy_at(dst + k * piece, at, len)) ++short_reads;
-      feed.done_with(at, len);
-    });
+    copy_pool.parallel_for(pieces, [&](size_t k) { if (!feed.copy_at(dst + k * piece, lo + k * piece, std::min(piece, hi - lo - k * piece))) ++short_reads; });
+    feed.done_with(lo, hi - lo);        // (once per chunk, by this thread: per 4 MB piece it was a round of TLB shoot-downs per piece on every copying CPU)
     S.short_read = short_reads.load() != 0;
     uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[S.slot]);
     uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks, *crc = isz + chunk_blocks;
@@ -1027,11 +1024,8 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
         uint8_t *dst = pin[S.slot];
         const size_t lo = S.lo, hi = S.hi, piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
         std::atomic<int> short_reads{0};
-        pool.parallel_for(pieces, [&](size_t k) {
-          const size_t at = lo + k * piece, len = std::min(piece, hi - lo - k * piece);
-          if (!Z.fd.copy_at(dst + k * piece, at, len)) ++short_reads;
-          Z.fd.done_with(at, len);
-        });
+        pool.parallel_for(pieces, [&](size_t k) { if (!Z.fd.copy_at(dst + k * piece, lo + k * piece, std::min(piece, hi - lo - k * piece))) ++short_reads; });
+        Z.fd.done_with(lo, hi - lo);
         S.short_read = short_reads.load() != 0;
         uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[S.slot]);
         uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks, *crc = isz + chunk_blocks;
@@ -1102,6 +1096,8 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
       for (int g = 0; g < n_shares; ++g)
         fprintf(stderr, "[strling]   share %d: %.2f GB in %llu chunks, %.3f s (block headers %.3f, reading compressed bytes %.3f)\n", g, (double)shares[(size_t)g].bytes / 1e9,
                 (unsigned long long)shares[(size_t)g].chunks, shares[(size_t)g].t_all, shares[(size_t)g].t_walk, shares[(size_t)g].t_copy);
+      fprintf(stderr, "[strling] feed only: waited %.3f s for the bring-up threads (slowest context %.3f, page-locked buffers %.3f); main() entered %.2f s after exec, now %.2f s after exec\n", t_begin, t_ctx,
+              t_pin, g_main_at, since_exec());
       fflush(stderr);
       _exit(0);
     }
