@@ -118,7 +118,7 @@ EXPORTS = ["strl_version", "strl_last_error", "strl_device_count", "strl_ctx_cre
            "strl_pairer_result", "strl_qname_hash", "strl_extract", "strl_cluster", "strl_cluster_replay", "strl_frag_median",
            "strl_bin_write", "strl_bin_read", "strl_bounds_row", "strl_cluster_members", "strl_spanners", "strl_genotype",
            "strl_calls_finish", "strl_unplaced_order", "strl_call_row", "strl_canonical_repeat", "strl_assign_reads_loci", "strl_group_order",
-           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered", "strl_inflate_blocks", "strl_ctx_inflate_ms", "strl_regions_fetch", "strl_front_begin", "strl_front_push", "strl_front_push_after", "strl_front_reserve", "strl_front_stage", "strl_front_enqueue_after", "strl_front_collect", "strl_ctxs_extract_gather", "strl_front_finish", "strl_front_fragwords", "strl_front_fragwords_async", "strl_event_wait", "strl_front_records", "strl_front_tids", "strl_front_qnames", "strl_front_treads_named", "strl_pinned_alloc", "strl_pinned_free", "strl_comm_unique_id", "strl_ctx_comm_init", "strl_ctxs_comm_init", "strl_ctx_comm_info", "strl_cluster_exchange", "strl_ctxs_cluster_exchange", "strl_exchange_treads", "strl_ctx_set_treads", "strl_cluster_collect", "strl_ctx_tail_stream", "strl_ctx_mem_info", "strl_bin_peek", "strl_front_trim_next", "strl_front_tail_bytes", "strl_ctx_blocking_waits", "strl_score_read_host"]
+           "strl_extract_device", "strl_treads_fetch", "strl_ctx_pair_times", "strl_sort_pairs", "strl_cluster_resident", "strl_ctx_cluster_times", "strl_pair_rows", "strl_extract_begin", "strl_extract_add", "strl_extract_finish", "strl_pair_rule", "strl_bounds_bare", "strl_ctx_treads_device", "strl_cluster_gathered", "strl_inflate_blocks", "strl_ctx_inflate_ms", "strl_regions_fetch", "strl_front_begin", "strl_front_push", "strl_front_push_after", "strl_front_reserve", "strl_front_stage", "strl_front_enqueue_after", "strl_front_collect", "strl_ctxs_extract_gather", "strl_front_finish", "strl_front_fragwords", "strl_front_fragwords_async", "strl_event_wait", "strl_front_records", "strl_front_tids", "strl_front_qnames", "strl_front_treads_named", "strl_pinned_alloc", "strl_pinned_free", "strl_comm_unique_id", "strl_ctx_comm_init", "strl_ctxs_comm_init", "strl_ctx_comm_info", "strl_cluster_exchange", "strl_ctxs_cluster_exchange", "strl_exchange_treads", "strl_ctx_set_treads", "strl_cluster_collect", "strl_ctx_tail_stream", "strl_ctx_mem_info", "strl_bin_peek", "strl_front_trim_next", "strl_front_tail_bytes", "strl_ctx_blocking_waits", "strl_score_read_host", "strl_front_end"]
 
 
 def lib_path():

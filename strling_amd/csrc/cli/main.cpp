@@ -1629,6 +1629,87 @@ static int merge_main(int argc, char **argv) {
 // overlapping a later window than `end`'s -- and the one behind it --, their sizes read from the block headers and trailers
 // (18 + 8 bytes per block).  ok = false: the index does not bound the region, the file is laid out unusually (other extra
 // subfields than BC), the run is longer than 8 MB: such a region is read by the host reader.
+// fragment_length_distribution (utils.nim:86-111; call.nim:92) through the device front end: the first ~2.2 M records' flag / isize
+// words come from the parse kernel (the words `strling extract` makes its histogram from), so the host inflates nothing -- on
+// 16 CPUs the host's inflate of that sample was 3 of the 4.7 CPU-seconds `strling call`'s start-up consists of (context, `.bin`
+// and sample side by side: ~0.3 s each; the context alone is 0.11 s).  pin / pin_meta: three page-locked chunk buffers of
+// chunk_blocks blocks each (allocated beside the context).  false: the caller takes the host's pass (the verdict on a file the
+// front end refuses is the host reader's).
+static bool fragment_lengths_on_device(strl_ctx *ctx, const std::string &bam, uint32_t frag[4096], uint8_t *const pin[3], uint8_t *const pin_meta[3], size_t chunk_blocks,
+                                       size_t chunk_bytes, std::string &why) {
+  const int64_t n_reads = 2000000, skip_reads = 100000;
+  memset(frag, 0, 4096 * sizeof(uint32_t));
+  BgzfFeed feed;
+  std::string err;
+  if (!feed.open(bam, err)) { why = err; return false; }
+  strl_opts o{0, 0.8, 40};                                  // (the chunks are scored too -- a few milliseconds nobody looks at)
+  auto fail = [&](const char *what) { why = std::string(what) + ": " + strl_last_error(); (void)strl_front_end(ctx); return false; };
+  if (strl_ctx_set_opts(ctx, &o) || strl_front_begin(ctx, (int32_t)feed.targets().size(), feed.first_record_offset(), 3u << 20) ||
+      strl_front_reserve(ctx, (uint32_t)chunk_blocks, chunk_bytes))
+    return fail("front end");
+  std::vector<int32_t> skipped;
+  int64_t counted = 0;
+  uint64_t next = 0;
+  bool done = false;
+  std::vector<uint32_t> fw;
+  auto take = [&](uint64_t upto) -> bool {                    // the words of records [next, upto)
+    while (next < upto && !done) {
+      const uint64_t m = std::min<uint64_t>(upto - next, 1u << 20);
+      fw.resize((size_t)m);
+      if (strl_front_fragwords(ctx, next, m, fw.data())) return false;
+      for (uint64_t k = 0; k < m && !done; ++k) {
+        const int64_t i = (int64_t)(next + k);
+        const uint32_t f = fw[(size_t)k] & 0xffffu, is = fw[(size_t)k] >> 16;
+        if (!(f & 0x2)) continue;
+        if (f & (0x800 | 0x100)) continue;
+        if (is > 4095u) continue;
+        if (i < skip_reads) { skipped.push_back((int32_t)is); continue; }
+        skipped.clear();
+        frag[is]++;
+        if (++counted > n_reads) done = true;
+      }
+      next += m;
+    }
+    return true;
+  };
+  ThreadPool pool(std::min(decode_threads(), 12));
+  std::vector<BgzfFeed::Block> bl;
+  bool last = false;
+  for (uint64_t ci = 0; !done; ++ci) {
+    const int64_t nb = feed.next(bl, chunk_blocks, chunk_bytes, err, &last);
+    if (nb < 0) { why = err; (void)strl_front_end(ctx); return false; }
+    if (nb == 0) break;
+    uint8_t *dst = pin[ci % 3];
+    const size_t lo = bl.front().c_off, hi = bl.back().c_off + bl.back().clen, piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
+    std::atomic<int> short_reads{0};
+    pool.parallel_for(pieces, [&](size_t k) { if (!feed.copy_at(dst + k * piece, lo + k * piece, std::min(piece, hi - lo - k * piece))) ++short_reads; });
+    feed.done_with(lo, hi - lo);
+    if (short_reads.load()) { why = "short read"; (void)strl_front_end(ctx); return false; }
+    uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[ci % 3]);
+    uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks, *crc = isz + chunk_blocks;
+    for (size_t k = 0; k < (size_t)nb; ++k) { coff[k] = bl[k].c_off - lo; clen[k] = bl[k].clen; isz[k] = bl[k].isize; crc[k] = bl[k].crc; }
+    strl_front_chunk dn[2];
+    int n_dn = 0;
+    if (strl_front_push(ctx, dst, hi - lo, coff, clen, isz, crc, (uint32_t)nb, dn, &n_dn)) return fail("front end");
+    uint64_t parsed = 0;
+    if (strl_front_records(ctx, &parsed) || !take(parsed)) return fail("front end");
+  }
+  if (!done) {                                              // the file ended first: what is still in the pipeline
+    strl_front_chunk dn[2];
+    int n_dn = 0;
+    uint64_t parsed = 0;
+    if (strl_front_finish(ctx, dn, &n_dn) || strl_front_records(ctx, &parsed) || !take(parsed)) return fail("front end");
+  }
+  if (strl_front_end(ctx)) { why = strl_last_error(); return false; }
+  uint64_t sum = 0;
+  for (int k = 0; k < 4096; ++k) sum += frag[k];
+  if ((uint32_t)sum == 0) {
+    fprintf(stderr, "using first reads in fragment_length_distribution calculation as there were not enough\n");
+    for (int32_t is : skipped) frag[is]++;
+  }
+  return true;
+}
+
 struct RegionPlan { bool ok = false; uint64_t c_beg = 0, c_end = 0; uint32_t in_block = 0; std::vector<uint32_t> hdr, bsize, isz, crc; };
 static void plan_region(const BamReader &rd, int fd, int32_t tid, int64_t beg, int64_t end, RegionPlan &P) {
   uint64_t c_hint = 0;
@@ -1713,19 +1794,42 @@ static int call_main(int argc, char **argv) {
     if (bin_rc) bin_err = strl_last_error();
     t_up_bin = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call0).count();
   });
+  // The fragment-length sample (call.nim:92): through the device front end once the context is up (a BAM; STRL_CALL_FRAG=host and
+  // CRAM input keep the host's pass, which also is the way out when the front end refuses the file).  Its three page-locked
+  // chunk buffers come up beside the context.
   uint32_t frag[4096];
-  fragment_length_distribution(bam, frag);                                          // call.nim:92
+  const char *frag_env = getenv("STRL_CALL_FRAG");
+  bool frag_on_device = !CramFile::is_cram(bam) && !(frag_env && !strcmp(frag_env, "host"));
+  const size_t fr_blocks = 4096, fr_bytes = fr_blocks * 20000;
+  uint8_t *fr_pin[3] = {nullptr, nullptr, nullptr}, *fr_meta[3] = {nullptr, nullptr, nullptr};
+  std::thread fr_pin_thread;
+  if (frag_on_device)
+    fr_pin_thread = std::thread([&] {
+      for (int k = 0; k < 3; ++k) { fr_pin[k] = static_cast<uint8_t *>(strl_pinned_alloc(fr_bytes + 64)); fr_meta[k] = static_cast<uint8_t *>(strl_pinned_alloc(fr_blocks * 20 + 64)); }
+    });
+  if (!frag_on_device) fragment_length_distribution(bam, frag);                       // call.nim:92
+  BamReader rd;
+  std::string err;
+  const bool opened = rd.open(bam, err) && rd.load_index(bam, err);                   // index=true, call.nim:101-102
+  ctx_thread.join();
+  if (fr_pin_thread.joinable()) fr_pin_thread.join();
+  if (frag_on_device && opened && !ctx_rc) {
+    bool have = true;
+    for (int k = 0; k < 3; ++k) have = have && fr_pin[k] && fr_meta[k];
+    std::string why = "page-locked memory";
+    if (!have || !fragment_lengths_on_device(ctx, bam, frag, fr_pin, fr_meta, fr_blocks, fr_bytes, why)) {
+      if (verbose) fprintf(stderr, "[strling] fragment lengths on the host (%s)\n", why.c_str());
+      fragment_length_distribution(bam, frag);
+    }
+  } else if (frag_on_device) fragment_length_distribution(bam, frag);                 // (errors of the open / the context are reported below)
+  for (int k = 0; k < 3; ++k) { if (fr_pin[k]) strl_pinned_free(fr_pin[k]); if (fr_meta[k]) strl_pinned_free(fr_meta[k]); }
   const int frag_median = strl_frag_median(frag, 0.5);
   if (verbose) {
     fprintf(stderr, "Calculated median fragment length:%d\n", frag_median);
     fprintf(stderr, "10th, 90th percentile of fragment length:%d %d\n", strl_frag_median(frag, 0.1), strl_frag_median(frag, 0.9));
   }
-  BamReader rd;
-  std::string err;
-  const bool opened = rd.open(bam, err) && rd.load_index(bam, err);                   // index=true, call.nim:101-102
   t_up_bam = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call0).count();
   bin_thread.join();
-  ctx_thread.join();
   g_bg_init = nullptr;
   if (!opened) quit_open(bam, err);
   if (bin_rc) quit("[strling] %s (status %d)", bin_err.c_str(), bin_rc);
@@ -2093,7 +2197,7 @@ static int call_main(int argc, char **argv) {
     run_tasks(tasks);
   }
   if (verbose)
-    fprintf(stderr, "[strling] seconds: device context + .bin + fragment lengths + index, side by side %.3f (%.3f | %.3f | %.3f)  clustering (upload, sort, sweep, bounds, members) %.3f  evidence + genotypes of %llu bounds on %d threads %.3f (summed over the threads: region records %.3f, spanners + genotype %.3f; regions through the device %llu, on the host %llu: "
+    fprintf(stderr, "[strling] seconds: device context + .bin + index side by side, the fragment-length sample behind the context %.3f (context %.3f | .bin %.3f | context + sample + index %.3f)  clustering (upload, sort, sweep, bounds, members) %.3f  evidence + genotypes of %llu bounds on %d threads %.3f (summed over the threads: region records %.3f, spanners + genotype %.3f; regions through the device %llu, on the host %llu: "
             "index + block headers %.3f, page-locked buffers %.3f, reads %.3f, device fetch %.3f (two at a time), the workers waited %.3f for them, %.1f MB compressed -> %.1f MB inflated -> %.1f MB of records)  since the start %.3f\n",
             t_start_up, t_up_ctx, t_up_bin, t_up_bam, std::chrono::duration<double>(tc2 - tc1).count(), (unsigned long long)nb, n_workers, t_evidence, (double)ns_region.load() * 1e-9, (double)ns_rules.load() * 1e-9,
             (unsigned long long)n_dev_regions, (unsigned long long)n_host_regions, t_plan, t_pin, t_pread, t_fetch, t_wait_fetch, (double)dev_comp_bytes / 1e6, (double)dev_inflated / 1e6, (double)dev_kept / 1e6,

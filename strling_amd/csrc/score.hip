@@ -2235,6 +2235,24 @@ int strl_event_wait(void *event) {
   (void)hipEventDestroy(ev);
   return STRL_OK;
 }
+// the front end and the per-read state of the extraction it fed are given up (the context stays): a caller that used the front
+// end for a PREFIX of a file -- `strling call`'s fragment-length sample, call.nim:92 -- and goes on to other work on the context
+int strl_front_end(strl_ctx *c) {
+  if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
+  STRL_HIP(hipSetDevice(c->device));
+  if (c->front) {
+    for (hipStream_t q : c->front->st_i) if (q) (void)hipStreamSynchronize(q);
+    if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a);
+    if (c->front->st_c) (void)hipStreamSynchronize(c->front->st_c);
+  }
+  STRL_HIP(hipStreamSynchronize(c->stream));
+  { const int rcj = side_join(c); if (rcj) return rcj; }
+  if (c->front) { strl::front_destroy(c->front); c->front = nullptr; }
+  for (strl::DevBuf *b : {&c->x_rows, &c->x_qhash, &c->x_whole, &c->x_soft}) b->release();
+  c->x_open = false; c->x_mode = false; c->x_front = false; c->x_n = 0; c->x_soft_cap = 0;
+  return STRL_OK;
+}
+
 int strl_front_records(strl_ctx *c, uint64_t *n) {
   if (!c || !n) { set_error("null argument"); return STRL_ERR_ARG; }
   *n = c->x_n;

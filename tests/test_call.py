@@ -297,3 +297,33 @@ def test_htt_simulation_end_to_end(oracle, tmp_path):
     assert open(prefix + "-unplaced.txt").read() == exp_u
     rows = [l.split("\t") for l in exp_b.splitlines()[1:]]
     assert any(r[0] == "4" and r[3] == "CAG" and abs(int(r[1]) - 100_057) <= 60 for r in rows)
+
+
+@pytest.mark.gpu
+def test_call_fragment_lengths_through_the_device_equal_the_host_pass(oracle, tmp_path):
+    """`strling call`'s fragment-length sample (call.nim:92; utils.nim:86-111: the first 100 000 records skipped, then 2 000 000
+    proper pairs) comes from the device front end's parse since round 6 (STRL_CALL_FRAG=host: the host reader's pass).  A file of
+    2.6e5 records -- past the skipped prefix, several front-end chunks -- gives the same histogram either way (= the generator's),
+    and the same three output files."""
+    rec, g = synth.synth_wgs(130_000, seed=31, n_contigs=3, contig_len=4_000_000)
+    bam, bed, binp = (str(tmp_path / x) for x in ("s.bam", "ref.fa.str", "s.bin"))
+    bamio.write_bam(bam, rec)
+    bamio.write_genome_bed(bed, g, rec.targets)
+    r = subprocess.run([CLI, "extract", "-g", bed, bam, binp], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    outs = {}
+    for how in ("device", "host"):
+        prefix = str(tmp_path / how)
+        env = dict(os.environ, STRL_CHUNK_BLOCKS="0")
+        if how == "host":
+            env["STRL_CALL_FRAG"] = "host"
+        r = subprocess.run([CLI, "call", "-v", "-o", prefix, bam, binp], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        med = [l for l in r.stderr.splitlines() if l.startswith("Calculated median fragment length") or l.startswith("10th, 90th")]
+        outs[how] = (med, open(prefix + "-bounds.txt").read(), open(prefix + "-genotype.txt").read(), open(prefix + "-unplaced.txt").read())
+        assert "fragment lengths on the host" not in r.stderr, r.stderr      # (the device pass did not fall back)
+    assert outs["device"] == outs["host"] and len(outs["device"][0]) == 2
+    f = rec.flag
+    ok = ((f & 0x2) != 0) & ((f & 0x900) == 0) & (rec.isize >= 0) & (rec.isize <= 4095) & (np.arange(rec.n) >= 100_000)
+    frag = np.bincount(rec.isize[ok], minlength=4096).astype(np.uint32)
+    assert int(ok.sum()) > 50_000 and f"Calculated median fragment length:{oracle.median(frag)}" in outs["device"][0][0]
