@@ -601,9 +601,10 @@ int strl_front_fragwords(strl_ctx *ctx, uint64_t first, uint64_t n, uint32_t *ou
 int strl_front_fragwords_async(strl_ctx *ctx, uint64_t first, uint64_t n, uint32_t *out, void **done_event);
 int strl_event_wait(void *event);
 int strl_front_records(strl_ctx *ctx, uint64_t *n);
-/* Gives up the front end and the per-read state of the extraction it fed; the context stays usable.  For a caller that ran the
- * front end over a PREFIX of a file -- `strling call`'s fragment-length sample (call.nim:92, utils.nim:86-111: the first ~2.1 M
- * records) -- and goes on to cluster and fetch regions on the same context.  Waits for the front end's streams. */
+/* Gives up the extraction the front end fed; the context stays usable (its front-end buffers stay allocated until the context
+ * goes or the next strl_front_begin).  For a caller that ran the front end over a PREFIX of a file -- `strling call`'s
+ * fragment-length sample (call.nim:92, utils.nim:86-111: the first ~2.1 M records with a positive template length) -- and goes on to
+ * cluster and fetch regions on the same context.  Everything the front end had in flight has completed on return. */
 int strl_front_end(strl_ctx *ctx);
 /* seen[tid] != 0: the contig has had a primary record so far (extract.nim:310-313 prints a line per large one) */
 int strl_front_tids(strl_ctx *ctx, uint8_t *seen, int32_t n_ref);

@@ -843,6 +843,11 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   };
   { const int br = bring_up_finish(); if (br) return br; }
   strl_ctx *ctx = ctxs[0];
+  if (verbose) {
+    std::string devs;
+    for (int g = 0; g < G; ++g) devs += (g ? " " : "") + std::to_string(device_of(g));
+    fprintf(stderr, "[strling] %d context(s) on device(s) %s of %d\n", G, devs.c_str(), std::max(1, strl_device_count()));
+  }
 
   fprintf(stderr, "[strling] collecting str-like reads\n");
   const auto t0 = now();
@@ -1639,9 +1644,13 @@ static bool fragment_lengths_on_device(strl_ctx *ctx, const std::string &bam, ui
                                        size_t chunk_bytes, std::string &why) {
   const int64_t n_reads = 2000000, skip_reads = 100000;
   memset(frag, 0, 4096 * sizeof(uint32_t));
+  const bool tm = getenv("STRL_FRAG_TIMING") != nullptr;
+  const auto tm0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) { if (tm) fprintf(stderr, "[fragment lengths] %s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tm0).count()); };
   BgzfFeed feed;
   std::string err;
   if (!feed.open(bam, err)) { why = err; return false; }
+  lap("file open, header walked");
   strl_opts o{0, 0.8, 40};                                  // (the chunks are scored too -- a few milliseconds nobody looks at)
   auto fail = [&](const char *what) { why = std::string(what) + ": " + strl_last_error(); (void)strl_front_end(ctx); return false; };
   if (strl_ctx_set_opts(ctx, &o) || strl_front_begin(ctx, (int32_t)feed.targets().size(), feed.first_record_offset(), 3u << 20) ||
@@ -1672,35 +1681,56 @@ static bool fragment_lengths_on_device(strl_ctx *ctx, const std::string &bam, ui
     }
     return true;
   };
+  lap("front end begun, buffers reserved");
   ThreadPool pool(std::min(decode_threads(), 12));
+  // chunk ci + 1 is read (header walk, copy out of the file's mapping) by a thread beside the push of chunk ci and the wait for
+  // chunk ci - 1's parse: one after the other the seven chunks of a sample took 12 ms each, 3 of them the device's
+  struct St { int64_t nb = 0; size_t lo = 0, hi = 0; bool short_read = false; std::string err; };
+  St ring[3];
   std::vector<BgzfFeed::Block> bl;
-  bool last = false;
-  for (uint64_t ci = 0; !done; ++ci) {
-    const int64_t nb = feed.next(bl, chunk_blocks, chunk_bytes, err, &last);
-    if (nb < 0) { why = err; (void)strl_front_end(ctx); return false; }
-    if (nb == 0) break;
+  auto stage = [&](uint64_t ci, St &S) {
+    S = St{};
+    S.nb = feed.next(bl, chunk_blocks, chunk_bytes, S.err);
+    if (S.nb <= 0) return;
     uint8_t *dst = pin[ci % 3];
-    const size_t lo = bl.front().c_off, hi = bl.back().c_off + bl.back().clen, piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
+    S.lo = bl.front().c_off; S.hi = bl.back().c_off + bl.back().clen;
+    const size_t lo = S.lo, hi = S.hi, piece = (size_t)4 << 20, pieces = (hi - lo + piece - 1) / piece;
     std::atomic<int> short_reads{0};
     pool.parallel_for(pieces, [&](size_t k) { if (!feed.copy_at(dst + k * piece, lo + k * piece, std::min(piece, hi - lo - k * piece))) ++short_reads; });
     feed.done_with(lo, hi - lo);
-    if (short_reads.load()) { why = "short read"; (void)strl_front_end(ctx); return false; }
+    S.short_read = short_reads.load() != 0;
     uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[ci % 3]);
     uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks, *crc = isz + chunk_blocks;
-    for (size_t k = 0; k < (size_t)nb; ++k) { coff[k] = bl[k].c_off - lo; clen[k] = bl[k].clen; isz[k] = bl[k].isize; crc[k] = bl[k].crc; }
+    for (size_t k = 0; k < (size_t)S.nb; ++k) { coff[k] = bl[k].c_off - lo; clen[k] = bl[k].clen; isz[k] = bl[k].isize; crc[k] = bl[k].crc; }
+  };
+  stage(0, ring[0]);
+  std::thread ahead;
+  bool file_ended = false;
+  for (uint64_t ci = 0; !done; ++ci) {
+    const St cur = ring[ci % 3];
+    if (cur.nb < 0 || cur.short_read) { why = cur.nb < 0 ? cur.err : "short read"; (void)strl_front_end(ctx); return false; }
+    if (cur.nb == 0) { file_ended = true; break; }
+    ahead = std::thread([&, ci] { stage(ci + 1, ring[(ci + 1) % 3]); });
+    uint64_t *coff = reinterpret_cast<uint64_t *>(pin_meta[ci % 3]);
+    uint32_t *clen = reinterpret_cast<uint32_t *>(coff + chunk_blocks), *isz = clen + chunk_blocks, *crc = isz + chunk_blocks;
     strl_front_chunk dn[2];
     int n_dn = 0;
-    if (strl_front_push(ctx, dst, hi - lo, coff, clen, isz, crc, (uint32_t)nb, dn, &n_dn)) return fail("front end");
     uint64_t parsed = 0;
-    if (strl_front_records(ctx, &parsed) || !take(parsed)) return fail("front end");
+    const bool ok = !strl_front_push(ctx, pin[ci % 3], cur.hi - cur.lo, coff, clen, isz, crc, (uint32_t)cur.nb, dn, &n_dn) && !strl_front_records(ctx, &parsed) && take(parsed);
+    ahead.join();
+    if (!ok) return fail("front end");
+    lap("chunk pushed, words of the parsed records taken");
   }
+  (void)file_ended;
   if (!done) {                                              // the file ended first: what is still in the pipeline
     strl_front_chunk dn[2];
     int n_dn = 0;
     uint64_t parsed = 0;
     if (strl_front_finish(ctx, dn, &n_dn) || strl_front_records(ctx, &parsed) || !take(parsed)) return fail("front end");
   }
+  lap("sample complete");
   if (strl_front_end(ctx)) { why = strl_last_error(); return false; }
+  lap("front end given up");
   uint64_t sum = 0;
   for (int k = 0; k < 4096; ++k) sum += frag[k];
   if ((uint32_t)sum == 0) {
@@ -1822,7 +1852,7 @@ static int call_main(int argc, char **argv) {
       fragment_length_distribution(bam, frag);
     }
   } else if (frag_on_device) fragment_length_distribution(bam, frag);                 // (errors of the open / the context are reported below)
-  for (int k = 0; k < 3; ++k) { if (fr_pin[k]) strl_pinned_free(fr_pin[k]); if (fr_meta[k]) strl_pinned_free(fr_meta[k]); }
+  // (the three page-locked buffers are left to the end of the process: unlocking them here would stall the device in front of the clustering)
   const int frag_median = strl_frag_median(frag, 0.5);
   if (verbose) {
     fprintf(stderr, "Calculated median fragment length:%d\n", frag_median);
@@ -1916,7 +1946,22 @@ static int call_main(int argc, char **argv) {
   uint64_t pin_comp_cap[NSETS] = {}, pin_out_cap[NSETS] = {};
   double t_plan = 0, t_fetch = 0, t_wait_fetch = 0, t_pin = 0, t_pread = 0;
   uint64_t n_dev_regions = 0, n_host_regions = 0, dev_comp_bytes = 0, dev_inflated = 0, dev_kept = 0;
+  // the batches' page-locked buffers come up beside the clustering (its device pass is 3 ms; the rest is the host's): sized for a
+  // batch of the default size, grown by the reader if a batch needs more -- they were 0.03 s in front of the first batches
+  std::thread region_pin_thread;
+  if (device_regions)
+    region_pin_thread = std::thread([&] {
+      for (size_t k = 0; k < NSETS; ++k) {
+        pin_comp_cap[k] = batch_inflated / 2 + (16 << 20);
+        pin_out_cap[k] = (uint64_t)((double)batch_inflated * 0.75) + (16 << 20);
+        pin_comp[k] = static_cast<uint8_t *>(strl_pinned_alloc(pin_comp_cap[k]));
+        pin_out[k] = static_cast<uint8_t *>(strl_pinned_alloc(pin_out_cap[k]));
+        if (!pin_comp[k]) pin_comp_cap[k] = 0;
+        if (!pin_out[k]) pin_out_cap[k] = 0;
+      }
+    });
   auto run_tasks = [&](const std::vector<Task> &tasks) {
+    if (region_pin_thread.joinable()) region_pin_thread.join();
     if (tasks.empty()) return;
     const auto te0 = std::chrono::steady_clock::now();
     std::vector<Done> done(tasks.size());

@@ -2235,8 +2235,9 @@ int strl_event_wait(void *event) {
   (void)hipEventDestroy(ev);
   return STRL_OK;
 }
-// the front end and the per-read state of the extraction it fed are given up (the context stays): a caller that used the front
-// end for a PREFIX of a file -- `strling call`'s fragment-length sample, call.nim:92 -- and goes on to other work on the context
+// the extraction the front end fed is given up (the context stays; the buffers stay allocated until the context goes or the next
+// strl_front_begin): a caller that used the front end for a PREFIX of a file -- `strling call`'s fragment-length sample,
+// call.nim:92 -- and goes on to other work on the context.  Everything the front end had in flight has completed on return.
 int strl_front_end(strl_ctx *c) {
   if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
   STRL_HIP(hipSetDevice(c->device));
@@ -2247,9 +2248,9 @@ int strl_front_end(strl_ctx *c) {
   }
   STRL_HIP(hipStreamSynchronize(c->stream));
   { const int rcj = side_join(c); if (rcj) return rcj; }
-  if (c->front) { strl::front_destroy(c->front); c->front = nullptr; }
-  for (strl::DevBuf *b : {&c->x_rows, &c->x_qhash, &c->x_whole, &c->x_soft}) b->release();
-  c->x_open = false; c->x_mode = false; c->x_front = false; c->x_n = 0; c->x_soft_cap = 0;
+  // (nothing is freed here: every hipFree synchronises the device -- 24 ms for the front end's twenty-odd buffers, in front of the
+  // caller's next phase.  The buffers go with the context, or with the next strl_front_begin.)
+  c->x_open = false; c->x_mode = false; c->x_n = 0;
   return STRL_OK;
 }
 

@@ -150,8 +150,9 @@ def test_extract_device_option_and_both_feeds_write_the_same_bin(sample):
     for k, (args, env) in enumerate(((["--device", "0"], {}), (["--device", "5"], {}), ([], {"STRL_DEVICE": "3"}), ([], {"STRL_FEED": "pread"}),
                                      (["--gpus", "2", "--device", "1"], {}))):
         out = str(sample["dir"] / f"dev{k}.bin")
-        r = _run(["extract", "-g", sample["bed"]] + args + [sample["bam"], out], env=dict(os.environ, **env))
+        r = _run(["extract", "-v", "-g", sample["bed"]] + args + [sample["bam"], out], env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr
+        assert "context(s) on device(s)" in r.stderr
         outs.append(open(out, "rb").read())
     assert all(o == outs[0] for o in outs) and len(outs[0]) > 1000
 

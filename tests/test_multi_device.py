@@ -141,3 +141,29 @@ def test_file_leg_of_a_two_rank_bench_on_whatever_devices_there_are():
         assert chk["ok"], chk
     finally:
         e2e_bench.cleanup(inp)
+
+
+@need2
+def test_one_process_per_sample_on_its_own_device(sample):
+    """pipelines/bpipe.config:4: one `strling` process per sample.  `--device K` / STRL_DEVICE put a process' context on device K
+    (`--gpus N --device K`: K, K + 1, ...); two concurrent extractions on two devices both write the one-device .bin; the
+    replica leg of bench.py (tools/e2e_bench.py::replicas) over the real devices"""
+    n = _n_dev()
+    procs = []
+    for k in range(min(n, 8)):
+        out = str(sample["dir"] / f"rep{k}.bin")
+        procs.append((k, out, subprocess.Popen([CLI, "extract", "-g", sample["bed"], "-v", "--device", str(k), sample["bam"], out], stderr=subprocess.PIPE, text=True)))
+    for k, out, p in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err
+        assert f"1 context(s) on device(s) {k} of {n}" in err, err
+        assert open(out, "rb").read() == open(sample["one"], "rb").read()
+    out = str(sample["dir"] / "g2d1.bin")
+    r = _run(["extract", "-g", sample["bed"], "-v", "--gpus", "2", "--device", str(n - 1), sample["bam"], out])
+    assert r.returncode == 0 and f"2 context(s) on device(s) {n - 1} 0 of {n}" in r.stderr, r.stderr
+    assert open(out, "rb").read() == open(sample["one"], "rb").read()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_bench
+    inp = dict(bam=sample["bam"], bed=sample["bed"], out=sample["one"], reads=sample["rec"].n)
+    res = e2e_bench.replicas(inp, CLI, min(n, 8), n)
+    assert res["bins_identical_to_the_single_run"] and res["aggregate_reads_per_s"] and {r["device"] for r in res["per_replica"]} == set(range(min(n, 8)))

@@ -4,18 +4,18 @@
 # replicas on the one device, and the front end's kernel trace (as it runs, and with every launch alone on the device)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R && export TMPDIR=/tmp
-O=gpurun_out/r6f; mkdir -p $O
+O=gpurun_out/r6g; mkdir -p $O
 CLI=$R/strling_amd/lib/strling
 timeout 2400 python -m pytest tests -q -m gpu > $O/gpu_tests_final.txt 2>&1; grep -E 'passed|failed' $O/gpu_tests_final.txt | tail -2
 timeout 2400 python bench.py > $O/bench_default_full_size.json 2> $O/bench_default_full_size.err
 python - <<'PY'
 import json
 try:
-    j = json.loads(open('gpurun_out/r6f/bench_default_full_size.json').read().strip().splitlines()[-1]); e = j['end_to_end']
+    j = json.loads(open('gpurun_out/r6g/bench_default_full_size.json').read().strip().splitlines()[-1]); e = j['end_to_end']
     print('bench: value', j['value'], 'ms', j['ms_per_step'], 'frac', j['roofline']['frac'], 'traffic', j['roofline']['traffic'], '| e2e reads', e['reads'], 'extract_s', e.get('extract_s'), 'first', e.get('first_run_wall_s'), 'call', e.get('call_s'), 'merge', e.get('merge_s'), 'x+c', e.get('extract_plus_call_s'), 'check', (e.get('check') or {}).get('ok'), (e.get('check') or {}).get('slabs'), 'vs cpu', e.get('vs_cpu_baseline_e2e_wall'), e.get('vs_cpu_baseline_e2e_extract_plus_call'))
     for r in e['runs']: print('  run', r['wall_s'], r['loop_s'], r['outside_the_loop'][:330])
 except Exception as ex:
-    print('bench failed', ex); print(open('gpurun_out/r6f/bench_default_full_size.err').read()[-1500:])
+    print('bench failed', ex); print(open('gpurun_out/r6g/bench_default_full_size.err').read()[-1500:])
 PY
 B=$(ls /tmp/e2e_268435456_6.bam /dev/shm/e2e_268435456_6.bam 2>/dev/null | head -1); S=${B%.bam}.str
 if [ -n "$B" ]; then
@@ -28,6 +28,12 @@ if [ -n "$B" ]; then
     done
   done
   cmp $D/x_mmap.bin $D/x_pread.bin && echo ".bin identical (mmap feed, pread feed)"
+  for how in device host device; do
+    sleep 5; echo "== call, STRL_CALL_FRAG=$how"
+    ( time STRL_CALL_FRAG=$how STRL_FRAG_TIMING=1 STRL_CLUSTER_TIMING=1 STRL_BIN_TIMING=1 timeout 300 $CLI call -v -o $D/c_$how $B $D/x_mmap.bin ) 2>&1 | grep -E 'seconds:|real|strl_bin_read|cluster_collect\]|strl_cluster\]|on the host|fragment lengths\]' | cut -c1-700
+  done
+  for f in bounds genotype unplaced; do cmp $D/c_device-$f.txt $D/c_host-$f.txt && echo "call $f identical (sample on the device / on the host)"; done
+  for rep in 1 2; do sleep 5; echo "== merge, run $rep"; ( time STRL_CLUSTER_TIMING=1 STRL_BIN_TIMING=1 timeout 300 $CLI merge -v -o $D/m $D/x_mmap.bin ) 2>&1 | grep -E 'seconds:|real|strl_bin_read' | cut -c1-400; done
   for g in 4 8; do
     for how in mmap pread; do
       sleep 5; echo "== feed only, $g shares, STRL_FEED=$how"
@@ -40,7 +46,7 @@ if [ -n "$B" ]; then
     cmp $D/x_mmap.bin $D/x_g$g.bin && echo ".bin identical (--gpus $g)"
   done
   } > $O/full_size_feed_and_shares.log 2>&1
-  cat $O/full_size_feed_and_shares.log | grep -E '^==|real|feed only|identical|seconds before' | cut -c1-330
+  cat $O/full_size_feed_and_shares.log | grep -E '^==|real|feed only|identical|seconds before|seconds: device context' | cut -c1-420
   rm -f $D/x_g*.bin $D/f.bin
   # two per-sample replicas on the one device (the leg bench.py runs at N > 1 with a device each)
   python - > $O/replicas_two_on_one_device.json 2> $O/replicas.err <<PY
