@@ -16,6 +16,7 @@ void BgzfFeed::close() {
   cv_.notify_all();
   if (walker_.joinable()) walker_.join();
   stop_ = false; state_ = 0; blks_.clear(); taken_ = 0; werr_.clear(); trim_ = 0;
+  stop_zapper();                   // (before the mapping goes: the thread names addresses inside it)
   if (map_ && map_owned_) (void)munmap(const_cast<uint8_t *>(map_), map_len_);
   map_ = nullptr; map_owned_ = false;
   if (fd_ >= 0) ::close(fd_);
@@ -51,7 +52,31 @@ bool BgzfFeed::copy_at(void *dst, size_t off, size_t n) const {
 void BgzfFeed::done_with(size_t off, size_t n) const {
   if (!map_ || !n) return;
   const size_t page = 4096, lo = (off + page - 1) & ~(page - 1), hi = (off + n) & ~(page - 1);
-  if (hi > lo) (void)madvise(const_cast<uint8_t *>(map_) + lo, hi - lo, MADV_DONTNEED);
+  if (hi <= lo) return;
+  std::lock_guard<std::mutex> lk(zmu_);
+  zq_.push_back({lo, hi - lo});
+  if (!zapper_.joinable())
+    zapper_ = std::thread([this] {
+      for (;;) {
+        std::vector<std::pair<size_t, size_t>> todo;
+        {
+          std::unique_lock<std::mutex> lk2(zmu_);
+          zcv_.wait(lk2, [&] { return zstop_ || !zq_.empty(); });
+          if (zstop_) return;                 // (what is left goes with the mapping)
+          todo.swap(zq_);
+        }
+        for (const auto &r : todo) (void)madvise(const_cast<uint8_t *>(map_) + r.first, r.second, MADV_DONTNEED);
+      }
+    });
+  zcv_.notify_one();
+}
+
+void BgzfFeed::stop_zapper() {
+  { std::lock_guard<std::mutex> lk(zmu_); zstop_ = true; }
+  zcv_.notify_all();
+  if (zapper_.joinable()) zapper_.join();
+  std::lock_guard<std::mutex> lk(zmu_);
+  zstop_ = false; zq_.clear();
 }
 
 bool BgzfFeed::open(const std::string &path, std::string &err) {

@@ -49,6 +49,9 @@ class BgzfFeed {
   // a file mapping drops the translations, the page cache keeps the pages).  Without this the process ended with 57 GB worth of
   // translations to tear down: +0.8 s between the last line of `strling extract` and its caller getting control back
   // (profiles/r06/full_size_feed_and_shares.log: real 3.30 s against 2.49 s with pread, both 2.3 s inside).
+  // (Done by a thread of the feed's own, in the background: MADV_DONTNEED costs ~90 ns a page -- 7 ms per 328 MB chunk on the
+  // thread that stages the next chunk made the feed the bottleneck of a one-device run (loop 2.0 -> 2.5 s); inside the copy threads it
+  // took an eighth off the rate of eight CPU-bound shares.)
   void done_with(size_t off, size_t n) const;
   struct Block { size_t c_off; uint32_t clen, isize, crc; };     // DEFLATE payload at file offset c_off; CRC-32 of the inflated bytes (trailer)
   // Next run of consecutive non-empty blocks: at most max_blocks and max_bytes of file (first block's payload to the last
@@ -65,6 +68,13 @@ class BgzfFeed {
   size_t map_len_ = 0;          // file size
   const uint8_t *map_ = nullptr;   // read-only mapping of the whole file (copy_at), or null
   bool map_owned_ = false;
+  // ranges whose translations are to be dropped, and the thread that drops them
+  mutable std::thread zapper_;
+  mutable std::mutex zmu_;
+  mutable std::condition_variable zcv_;
+  mutable std::vector<std::pair<size_t, size_t>> zq_;
+  mutable bool zstop_ = false;
+  void stop_zapper();
   uint64_t first_off_ = 0;
   std::string text_;
   std::vector<BamTarget> targets_;
