@@ -530,7 +530,7 @@ def end_to_end(n_pairs, check_slabs=0, gpus=1):
     full = inp["reads"] >= 5e8
     check_slabs = check_slabs or (16 if full else 4)      # 16 of 1024 slabs at the headline size (~10 s), 4 of 256 below it
     try:
-        res = e2e_bench.run(inp, build.CLI, repeats=2, gpus=gpus)      # the first process behind the writer reads a cold file
+        res = e2e_bench.run(inp, build.CLI, repeats=3 if full else 2, gpus=gpus)      # the first process behind the writer reads a cold file
         res["input_reused_from_cache"] = bool(inp.get("reused_cached_input"))
         if "error" not in res:
             if gpus == 1:

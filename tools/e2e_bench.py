@@ -101,7 +101,10 @@ def run(inp, cli, threads=(0,), call=True, merge=True, repeats=1, gpus=1, extra_
     .bin -> the end_to_end block of bench.py's line.  gpus > 1: `strling extract --gpus N` / `strling merge --gpus N` (one process,
     N contexts: a contiguous share of the file per device, each fed by its own host threads)."""
     global SETTLE_S
-    SETTLE_S = 1.0 + 4.0 * min(1.0, inp["bam_MB"] / 50000.0)
+    # (5 s were not always enough at the headline size: the driver clears what the previous process held -- 84 GB at ~48 GB/s -- and
+    # a process whose large allocations arrive before that is done pays for the clearing itself, 0.5 s in front of its loop
+    # (profiles/r06/state_alloc_diag.log, bench_default_full_size_r6h.json))
+    SETTLE_S = 1.0 + 7.0 * min(1.0, inp["bam_MB"] / 50000.0)
     res = {"unit": "reads/s", "reads": inp["reads"], "bam_MB": inp["bam_MB"], "settle_s_before_each_process": round(SETTLE_S, 1), "input": inp.get("input"), "make_s": inp.get("make_s"),
            "host_threads_available": os.cpu_count(), "cgroup_cpu_quota": _quota(), "gpus": gpus, "runs": []}
     g_args = ["--gpus", str(gpus)] if gpus > 1 else []
