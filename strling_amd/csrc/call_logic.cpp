@@ -68,6 +68,35 @@ double expected_spanning_probability(const float cd[4096], int64_t start, int64_
   if (dist < 0 || dist > 4095) return 0;
   return (double)(1.0f - cd[dist]);
 }
+// What spanners() derives from the fragment-length histogram alone -- the smoothed cumulative distribution (spanning.nim:7-20:
+// 4096 x 23 additions) and the prefix sums percentile() walks (utils.nim:129-137) -- kept per thread for the histogram it was made
+// from: `strling call` asks for thousands of bounds with ONE histogram, and making them per bound (and the sum per spanning
+// fragment) was a fifth of the function.  The values are the ones the functions below compute.
+struct FragTables {
+  uint32_t frag[4096];
+  float cd[4096];
+  uint64_t prefix[4096];       // prefix[i] = frag[0] + .. + frag[i]
+  bool have = false;
+};
+void cumulative(const uint32_t frag[4096], float cd[4096]);
+const FragTables &frag_tables(const uint32_t frag[4096]) {
+  thread_local FragTables T;
+  if (!T.have || memcmp(T.frag, frag, sizeof T.frag) != 0) {
+    memcpy(T.frag, frag, sizeof T.frag);
+    cumulative(frag, T.cd);
+    uint64_t run = 0;
+    for (int i = 0; i < 4096; ++i) { run += frag[i]; T.prefix[i] = run; }
+    T.have = true;
+  }
+  return T;
+}
+// utils.nim:129-137 (total and partial sum wrap in uint32 / accumulate in int64 exactly like the loop this replaces)
+double percentile_cached(const FragTables &T, int64_t fragment_length) {
+  const uint32_t total = (uint32_t)T.prefix[4095];
+  const int64_t upto = std::min<int64_t>(std::max<int64_t>(fragment_length, 0), 4095);
+  const int64_t s = (int64_t)T.prefix[(size_t)upto];
+  return (double)s / (double)std::max<uint32_t>(1u, total);
+}
 // utils.nim:129-137
 double percentile(const uint32_t frag[4096], int64_t fragment_length) {
   uint32_t total = 0;
@@ -197,10 +226,35 @@ int strl_spanners(const strl_records *r, const int32_t *isize, const strl_bounds
   const int max_size = 5000;
   const int64_t window_left = (int64_t)b->left - window, window_right = (int64_t)b->right + window;
   const int64_t beg = std::max<int64_t>(0, window_left), end = window_right;
-  float cd[4096];
-  cumulative(frag, cd);
+  const FragTables &FT = frag_tables(frag);
+  const float *cd = FT.cd;
   std::vector<int64_t> depths((size_t)(window_right - window_left), 0);
-  std::unordered_map<std::string_view, size_t> exp_ix, pair_ix;
+  // One open-addressed index of the region's qnames for both of the reference's tables (the expected-spanner values and the
+  // pairs), keyed by the Nim hash each table's slot order needs anyway: two std::unordered_map<string_view> look-ups and two
+  // murmur hashes per record were a third of this function's 200 ns a record (3.3 CPU-seconds of `strling call` on a genome).
+  struct Name { std::string_view qn; uint64_t hc; int32_t exp_id, pair_id; };
+  std::vector<Name> names;
+  std::vector<int32_t> slot(1024, -1);
+  auto name_of = [&](std::string_view qn) -> Name & {
+    const uint64_t hc = nim::hash_bytes(reinterpret_cast<const uint8_t *>(qn.data()), (int)qn.size());
+    if (2 * (names.size() + 1) > slot.size()) {
+      std::vector<int32_t> bigger(slot.size() * 4, -1);
+      for (size_t k = 0; k < names.size(); ++k) {
+        size_t at = (size_t)(names[k].hc * 0x9E3779B97F4A7C15ull >> 20) & (bigger.size() - 1);
+        while (bigger[at] >= 0) at = (at + 1) & (bigger.size() - 1);
+        bigger[at] = (int32_t)k;
+      }
+      slot.swap(bigger);
+    }
+    size_t at = (size_t)(hc * 0x9E3779B97F4A7C15ull >> 20) & (slot.size() - 1);
+    for (; slot[at] >= 0; at = (at + 1) & (slot.size() - 1)) {
+      Name &nm = names[(size_t)slot[at]];
+      if (nm.hc == hc && nm.qn == qn) return nm;
+    }
+    slot[at] = (int32_t)names.size();
+    names.push_back(Name{qn, hc, -1, -1});
+    return names.back();
+  };
   std::vector<double> exp_val;
   std::vector<uint64_t> exp_hc, pair_hc;
   struct Pair { int64_t first, second; int n; };
@@ -217,13 +271,14 @@ int strl_spanners(const strl_records *r, const int32_t *isize, const strl_bounds
     if (r->mapq[i] < min_mapq) continue;                                            // :143
     const std::string_view qn = R.qname(i);
     const double prob = expected_spanning_probability(cd, start, stop, (f & F_REVERSE) != 0, b->left, b->right);
+    Name *nm = nullptr;
     if (prob > 0) {                                                                  // :145-152
-      auto it = exp_ix.find(qn);
-      if (it != exp_ix.end()) exp_val[it->second] = 0.5 * (exp_val[it->second] + prob);
+      nm = &name_of(qn);
+      if (nm->exp_id >= 0) exp_val[(size_t)nm->exp_id] = 0.5 * (exp_val[(size_t)nm->exp_id] + prob);
       else {
-        exp_ix.emplace(qn, exp_val.size());
+        nm->exp_id = (int32_t)exp_val.size();
         exp_val.push_back(prob);
-        exp_hc.push_back(nim::hash_bytes(reinterpret_cast<const uint8_t *>(qn.data()), (int)qn.size()));
+        exp_hc.push_back(nm->hc);
       }
     }
     depths[(size_t)std::max<int64_t>(0, start - window_left - 1)] += 1;              // :154-155
@@ -232,12 +287,12 @@ int strl_spanners(const strl_records *r, const int32_t *isize, const strl_bounds
     if (overlapping_read(R, i, *b, s)) emit(s);                                      // :157-159
     if (r->tid[i] != r->mtid[i]) continue;
     if (std::abs((int64_t)isize[i]) > max_size) continue;
-    auto it = pair_ix.find(qn);
-    if (it != pair_ix.end()) { Pair &p = pairs[it->second]; if (p.n == 1) p.second = i; ++p.n; }
+    if (!nm) nm = &name_of(qn);
+    if (nm->pair_id >= 0) { Pair &p = pairs[(size_t)nm->pair_id]; if (p.n == 1) p.second = i; ++p.n; }
     else {
-      pair_ix.emplace(qn, pairs.size());
+      nm->pair_id = (int32_t)pairs.size();
       pairs.push_back(Pair{i, -1, 1});
-      pair_hc.push_back(nim::hash_bytes(reinterpret_cast<const uint8_t *>(qn.data()), (int)qn.size()));
+      pair_hc.push_back(nm->hc);
     }
     if (pairs.size() > 20000) { sum->median_depth = -1; sum->expected_spanners = 0; sum->n_support = 0; return STRL_OK; }   // :171-174
   }
@@ -253,7 +308,7 @@ int strl_spanners(const strl_records *r, const int32_t *isize, const strl_bounds
       strl_support s{};
       s.type = STRL_SPANNING_FRAGMENT;
       s.fragment_length = std::max<uint32_t>(1u, (uint32_t)std::abs((int64_t)isize[p.first]));
-      s.fragment_percentile = percentile(frag, (int64_t)s.fragment_length);
+      s.fragment_percentile = percentile_cached(FT, (int64_t)s.fragment_length);
       s.rec = p.first;
       emit(s);
     }
