@@ -1287,7 +1287,10 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
     rc = strl_front_treads_named(ctx, treads_p, nt + 1, &ngot, qoff_p, names_p, nv.size(), &need);
   }
   if (rc) quit("[strling] %s (status %d)", strl_last_error(), rc);
-  for (uint64_t i = 0; i < nt; ++i) treads_p[i].qname_id = (int64_t)i;
+  {   // (the .bin writer wants the name's index, not the record's: 8e6 strided stores, by the feed's idle copy threads)
+    const uint64_t per = 1 << 17;
+    copy_pool.parallel_for((size_t)((nt + per - 1) / per), [&](size_t q) { for (uint64_t i = q * per, e = std::min(nt, i + per); i < e; ++i) treads_p[i].qname_id = (int64_t)i; });
+  }
   const double t_pair = secs(tp0, now());
   fprintf(stderr, "[strling] writing binary file:%s\n", bin.c_str());
   const auto tw0 = now();

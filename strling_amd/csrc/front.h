@@ -152,7 +152,8 @@ int front_parse(strl_ctx *c, strl_front *F, int slot, uint32_t n, const FrontPar
 int front_gather_names(strl_ctx *c, strl_front *F, const uint32_t *d_ids, uint32_t n, uint64_t *d_ref_out, hipStream_t st);
 int front_copy_names(strl_ctx *c, strl_front *F, const uint64_t *d_ref, const uint64_t *d_dst_off, uint32_t n, uint8_t *d_out, hipStream_t st);
 int front_tread_names(strl_ctx *c, strl_front *F, const strl_tread *d_treads, const uint32_t *d_n, uint32_t cap, uint64_t *d_ref, uint32_t *d_len, uint64_t *d_off,
-                      uint8_t *d_out, uint64_t out_cap, hipStream_t st);
+                      uint8_t *d_out, uint64_t out_cap, uint64_t *d_tile_sums, hipStream_t st);
+size_t front_name_tiles(uint32_t cap);      // words of d_tile_sums for `cap` names
 void front_destroy(strl_front *F);
 
 }  // namespace strl

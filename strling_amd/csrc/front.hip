@@ -407,18 +407,47 @@ __global__ void tread_name_refs_kernel(const uint64_t *qref, const strl_tread *t
   ref[i] = r;
   len[i] = (uint32_t)(r & 255u);
 }
-__global__ __launch_bounds__(1024) void name_scan_kernel(const uint32_t *len, const uint32_t *n_dev, uint32_t cap, uint64_t *off) {
+// Exclusive scan of the name lengths: tiles of 2048 lengths, a workgroup each (sums, then the tile sums scanned by one
+// workgroup, then every tile placed).  (Until round 6 ONE workgroup did it, each thread walking a contiguous 1/1024th of the
+// lengths -- 64 cache lines per wave and load, 7800 dependent turns twice over for a genome's 8e6 names: most of the 0.043 s
+// `strling extract` spent between the pair pass and the .bin.)
+constexpr uint32_t NAME_TILE = 2048;
+__global__ __launch_bounds__(256) void name_tile_sums_kernel(const uint32_t *len, const uint32_t *n_dev, uint32_t cap, uint64_t *tile_sum) {
+  __shared__ uint32_t wsum[4];
+  const uint32_t n = min(*n_dev, cap), t = threadIdx.x, base = blockIdx.x * NAME_TILE;
+  uint32_t s = 0;                                               // (a tile's lengths sum to < 2048 * 256)
+  for (uint32_t j = 0; j < NAME_TILE / 256; ++j) { const uint32_t i = base + j * 256 + t; if (i < n) s += len[i]; }
+  for (int d = 32; d; d >>= 1) s += __shfl_down(s, d, 64);
+  if ((t & 63) == 0) wsum[t >> 6] = s;
+  __syncthreads();
+  if (t == 0) tile_sum[blockIdx.x] = (uint64_t)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(1024) void name_tile_scan_kernel(uint64_t *tile_sum, uint32_t n_tiles_cap, const uint32_t *n_dev, uint32_t cap, uint64_t *off) {
   __shared__ uint64_t part[1024];
   const uint32_t n = min(*n_dev, cap), t = threadIdx.x;
-  const uint32_t per = (n + 1023u) / 1024u, a = min(n, t * per), b = min(n, a + per);
+  const uint32_t nt = min((n + NAME_TILE - 1) / NAME_TILE, n_tiles_cap);
+  const uint32_t per = (nt + 1023u) / 1024u, a = min(nt, t * per), b = min(nt, a + per);
   uint64_t s = 0;
-  for (uint32_t i = a; i < b; ++i) s += len[i];
+  for (uint32_t i = a; i < b; ++i) s += tile_sum[i];
   part[t] = s;
   __syncthreads();
   if (t == 0) { uint64_t run = 0; for (int k = 0; k < 1024; ++k) { const uint64_t v = part[k]; part[k] = run; run += v; } off[n] = run; }
   __syncthreads();
   uint64_t run = part[t];
-  for (uint32_t i = a; i < b; ++i) { off[i] = run; run += len[i]; }
+  for (uint32_t i = a; i < b; ++i) { const uint64_t v = tile_sum[i]; tile_sum[i] = run; run += v; }
+}
+__global__ __launch_bounds__(256) void name_tile_place_kernel(const uint32_t *len, const uint32_t *n_dev, uint32_t cap, const uint64_t *tile_sum, uint64_t *off) {
+  __shared__ uint32_t wsum[4];
+  const uint32_t n = min(*n_dev, cap), t = threadIdx.x, base = blockIdx.x * NAME_TILE + t * (NAME_TILE / 256);
+  uint32_t l[NAME_TILE / 256], s = 0;                            // a thread's eight lengths are neighbours: 32 bytes in, 64 out
+  for (uint32_t j = 0; j < NAME_TILE / 256; ++j) { l[j] = base + j < n ? len[base + j] : 0u; s += l[j]; }
+  uint32_t incl = s;
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if ((int)(t & 63) >= d) incl += v; }
+  if ((t & 63) == 63) wsum[t >> 6] = incl;
+  __syncthreads();
+  uint64_t run = tile_sum[blockIdx.x] + (incl - s);
+  for (uint32_t w = 0; w < (t >> 6); ++w) run += wsum[w];
+  for (uint32_t j = 0; j < NAME_TILE / 256; ++j) { if (base + j < n) off[base + j] = run; run += l[j]; }
 }
 __global__ void tread_name_copy_kernel(const uint8_t *arena, const uint64_t *ref, const uint64_t *off, const uint32_t *n_dev, uint32_t cap, uint8_t *out, uint64_t out_cap) {
   const uint32_t n = min(*n_dev, cap);
@@ -430,11 +459,14 @@ __global__ void tread_name_copy_kernel(const uint8_t *arena, const uint64_t *ref
   const uint8_t *s = arena + (r >> 8);
   for (uint32_t j = 0; j < l; ++j) out[o + j] = s[j];
 }
+size_t front_name_tiles(uint32_t cap) { return ((size_t)cap + NAME_TILE - 1) / NAME_TILE + 1; }
 int front_tread_names(strl_ctx *c, strl_front *F, const strl_tread *d_treads, const uint32_t *d_n, uint32_t cap, uint64_t *d_ref, uint32_t *d_len, uint64_t *d_off,
-                      uint8_t *d_out, uint64_t out_cap, hipStream_t st) {
-  const unsigned g = (cap + 255) / 256;
+                      uint8_t *d_out, uint64_t out_cap, uint64_t *d_tile_sums, hipStream_t st) {
+  const unsigned g = (cap + 255) / 256, tiles = (cap + NAME_TILE - 1) / NAME_TILE;       // d_tile_sums: front_name_tiles(cap) words
   hipLaunchKernelGGL(tread_name_refs_kernel, dim3(g), dim3(256), 0, st, F->qref.as<uint64_t>(), d_treads, d_n, cap, d_ref, d_len);
-  hipLaunchKernelGGL(name_scan_kernel, dim3(1), dim3(1024), 0, st, d_len, d_n, cap, d_off);
+  hipLaunchKernelGGL(name_tile_sums_kernel, dim3(tiles), dim3(256), 0, st, d_len, d_n, cap, d_tile_sums);
+  hipLaunchKernelGGL(name_tile_scan_kernel, dim3(1), dim3(1024), 0, st, d_tile_sums, tiles, d_n, cap, d_off);
+  hipLaunchKernelGGL(name_tile_place_kernel, dim3(tiles), dim3(256), 0, st, d_len, d_n, cap, d_tile_sums, d_off);
   hipLaunchKernelGGL(tread_name_copy_kernel, dim3(g), dim3(256), 0, st, F->qarena.as<uint8_t>(), d_ref, d_off, d_n, cap, d_out, out_cap);
   STRL_HIP(hipGetLastError());
   return STRL_OK;

@@ -27,6 +27,7 @@
 #include "device_util.h"
 #include "score_core.h"
 #include "score_tables.h"
+#include "sort.h"
 
 namespace strl {
 
@@ -1982,9 +1983,20 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
   strl::DevBuf pre_qref, pre_fragw, pre_qarena;
   {
     struct Want { strl::DevBuf *b; size_t bytes; int rc; std::string err; };
+    // ... and with them what the pair pass over the whole file takes at the END (strl_extract_finish -> strl_pair_device: join items,
+    // emission keys, treads, the sort's scratch -- 4 GB for a genome).  Allocated there, behind the loop, they made that pass 0.05 -
+    // 0.09 s in this round's earlier lines (0.016 s in round 5's); in place beforehand it is 0.016 - 0.017 s in six runs of six
+    // (profiles/r06/pair_prealloc_full_size.log).  Sized as that call sizes them for `hint` reads, so that it finds them in place
+    const uint64_t p_icap = std::max<uint64_t>(std::min<uint64_t>(hint / 8 + 65536, 3 * hint + 16), 1024), p_ecap = std::max<uint64_t>(std::min<uint64_t>(hint / 16 + 65536, 8 * hint + 16), 1024);
+    int p_ebits = 3;
+    while (p_ebits < 40 && ((2 * hint) >> (p_ebits - 2))) ++p_ebits;
+    const size_t p_sb = std::max(radix_sort_scratch_bytes((uint32_t)p_icap, 32), radix_sort_scratch_bytes((uint32_t)p_ecap, p_ebits));
+    const size_t p_max = (size_t)std::max(p_icap, p_ecap);
     Want want[] = {{&c->x_rows, (size_t)small * sizeof(strl_pair_rec), 0, {}}, {&pre_qarena, (size_t)small * 24, 0, {}}, {&c->x_qhash, (size_t)small * 8, 0, {}},
                    {&pre_qref, (size_t)small * 8, 0, {}}, {&c->x_whole, (size_t)small * 4, 0, {}}, {&pre_fragw, (size_t)small * 4, 0, {}},
-                   {&c->x_soft, (size_t)(hint / 8 + 65536) * sizeof(strl_soft_rec), 0, {}}};
+                   {&c->x_soft, (size_t)(hint / 8 + 65536) * sizeof(strl_soft_rec), 0, {}},
+                   {&c->p_key0, p_max * 8, 0, {}}, {&c->p_key1, p_max * 8, 0, {}}, {&c->p_val0, p_max * 4, 0, {}}, {&c->p_val1, p_max * 4, 0, {}},
+                   {&c->p_emit, (size_t)p_ecap * sizeof(strl_tread), 0, {}}, {&c->treads, (size_t)p_ecap * sizeof(strl_tread) + 64, 0, {}}, {&c->sort_scratch, p_sb, 0, {}}};
     const int dev = c->device;
     std::vector<std::thread> th;
     for (Want &w : want)
@@ -2321,25 +2333,47 @@ int strl_front_treads_named(strl_ctx *c, strl_tread *treads, uint64_t cap, uint6
   if (qname_off) qname_off[0] = 0;
   if (!nt) return STRL_OK;
   STRL_HIP(hipSetDevice(c->device));
-  strl::DevBuf d_ref, d_len, d_off, d_out;
+  // Work space: the pair pass's own scratch.  Once the treads are ordered (strl_treads_fetch above, on this stream) the join /
+  // emission keys and values, and the unordered treads, are dead until the next pair pass rewrites them -- and an allocation of
+  // its own is four hipMalloc + four hipFree, each of which waits for the device.  A buffer of its own only for what does not fit.
+  strl::DevBuf own[5];
   const uint64_t ocap = std::max<uint64_t>(std::min<uint64_t>(names_cap, nt * 255), 16);
-  if ((rc = d_ref.reserve((size_t)nt * 8)) || (rc = d_len.reserve((size_t)nt * 4)) || (rc = d_off.reserve((size_t)(nt + 1) * 8)) || (rc = d_out.reserve((size_t)ocap))) return rc;
-  hipStream_t st = c->stream;
-  if ((rc = strl::front_tread_names(c, c->front, c->treads.as<strl_tread>(), c->n_treads_dev, (uint32_t)nt, d_ref.as<uint64_t>(), d_len.as<uint32_t>(), d_off.as<uint64_t>(),
-                                    d_out.as<uint8_t>(), ocap, st)))
+  auto room = [&](strl::DevBuf &scratch, strl::DevBuf &mine, size_t bytes, void **p) -> int {
+    if (scratch.p && scratch.cap >= bytes) { *p = scratch.p; return STRL_OK; }
+    const int r = mine.reserve(bytes);
+    *p = mine.p;
+    return r;
+  };
+  void *p_ref = nullptr, *p_len = nullptr, *p_off = nullptr, *p_out = nullptr, *p_tiles = nullptr;
+  if ((rc = room(c->p_key0, own[0], (size_t)nt * 8, &p_ref)) || (rc = room(c->p_val0, own[1], (size_t)nt * 4, &p_len)) ||
+      (rc = room(c->p_key1, own[2], (size_t)(nt + 1) * 8, &p_off)) || (rc = room(c->p_emit, own[3], (size_t)ocap, &p_out)) ||
+      (rc = room(c->p_val1, own[4], strl::front_name_tiles((uint32_t)nt) * 8, &p_tiles)))
     return rc;
+  hipStream_t st = c->stream;
+  static const bool lap_on = getenv("STRL_FRONT_TIMING") != nullptr;
+  const auto lap0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!lap_on) return;
+    (void)hipStreamSynchronize(st);
+    fprintf(stderr, "[strl_front_treads_named] %s at %.4f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - lap0).count());
+  };
+  if ((rc = strl::front_tread_names(c, c->front, c->treads.as<strl_tread>(), c->n_treads_dev, (uint32_t)nt, static_cast<uint64_t *>(p_ref), static_cast<uint32_t *>(p_len),
+                                    static_cast<uint64_t *>(p_off), static_cast<uint8_t *>(p_out), ocap, static_cast<uint64_t *>(p_tiles), st)))
+    return rc;
+  lap("references, offsets and name bytes on the device");
   STRL_HIP(hipMemcpyAsync(treads, c->treads.p, (size_t)nt * sizeof(strl_tread), hipMemcpyDeviceToHost, st));
   uint64_t total = 0;
-  STRL_HIP(hipMemcpyAsync(&total, d_off.as<uint64_t>() + nt, 8, hipMemcpyDeviceToHost, st));
-  if (qname_off) STRL_HIP(hipMemcpyAsync(qname_off, d_off.p, (size_t)(nt + 1) * 8, hipMemcpyDeviceToHost, st));
+  STRL_HIP(hipMemcpyAsync(&total, static_cast<uint64_t *>(p_off) + nt, 8, hipMemcpyDeviceToHost, st));
+  if (qname_off) STRL_HIP(hipMemcpyAsync(qname_off, p_off, (size_t)(nt + 1) * 8, hipMemcpyDeviceToHost, st));
   STRL_HIP(hipStreamSynchronize(st));
   if (names_need) *names_need = total;
   int ret = STRL_OK;
   if (qname_off && names) {
     if (total > names_cap) { set_error("strl_front_treads_named: %llu bytes of names, capacity %llu", (unsigned long long)total, (unsigned long long)names_cap); ret = STRL_ERR_CAPACITY; }
-    else if (total) STRL_HIP(hipMemcpy(names, d_out.p, (size_t)total, hipMemcpyDeviceToHost));
+    else if (total) STRL_HIP(hipMemcpy(names, p_out, (size_t)total, hipMemcpyDeviceToHost));
   }
-  d_ref.release(); d_len.release(); d_off.release(); d_out.release();
+  lap("treads, offsets and names on the host");
+  for (strl::DevBuf &b : own) b.release();
   return ret;
 }
 

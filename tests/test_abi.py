@@ -213,3 +213,41 @@ def test_bin_reader_parts_equal_sequential(tmp_path, batch, oracle):
     open(path, "wb").write(raw[: len(raw) - 7])                      # ... and a truncated tail
     with pytest.raises(api.StrlingError):
         api.bin_read(path)
+
+
+def test_bin_reader_parts_survive_a_made_up_first_record(tmp_path):
+    """a share that starts on the last two bytes of a record's 4-byte position parses them as tid + position, finds the array
+    marker and is in step from there: eight strict records, the first made up.  The parts still link (round 6: this guess sent
+    whole-genome files down the sequential walk); the file is built so that share 1 starts exactly there"""
+    import subprocess
+    import sys
+    hw = len(os.sched_getaffinity(0))
+    if hw < 2:
+        pytest.skip("one CPU: the reader does not split the file")
+    header = "@HD\tVN:1.6\n"
+    body0 = 3 + 2 + 9 + 4 + 1 + 4096 * 4 + 4 + len(header) + 4
+    S = 42                                                           # every record: 1 + 5 + 1 + 6 + 3 + 4 + 1 + 1 + 20 bytes
+    K = min(hw, 16, (S * 900_000) >> 22)                             # the reader's number of parts (host_logic.cpp)
+    n = next(m for m in range(900_000, 905_000) if any(1 <= ((S * m) // K * k) % S <= 4 for k in range(1, K)))   # a share starts on 0xce .. b1
+    rng = np.random.default_rng(9)
+    t = np.zeros(n, api.TREAD_DTYPE)
+    t["tid"] = rng.integers(0, 100, n)
+    t["position"] = (rng.integers(1, 65536, n) << 16) | (rng.integers(0, 128, n) << 8) | rng.integers(0, 128, n)   # 0xce + 4 bytes, the last two < 0x80
+    t["repeat"] = np.array([b"AC", b"AGC", b"AAAAG", b"AACCCT"], "S6")[rng.integers(0, 4, n)]
+    t["flag"] = rng.integers(256, 4096, n)
+    t["split"] = rng.integers(0, 3, n); t["mapping_quality"] = rng.integers(0, 61, n)
+    t["repeat_count"] = rng.integers(0, 100, n); t["align_length"] = rng.integers(0, 128, n)
+    t["qname_id"] = np.arange(n)
+    qo = np.arange(n + 1, dtype=np.uint64) * 20
+    qn = rng.integers(97, 123, 20 * n, dtype=np.uint8).tobytes()
+    path = str(tmp_path / "made_up.bin")
+    api.bin_write(path, 0.8, 40, np.zeros(4096, np.uint32), header, t, qo, qn)
+    assert os.path.getsize(path) == body0 + S * n
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from strling_amd import api; b = api.bin_read(%r); "
+            "np.save(%r, b['treads']); np.save(%r, b['qname_off']); open(%r, 'wb').write(b['qnames'])")
+    outs = [str(tmp_path / x) for x in ("t.npy", "q.npy", "n.bin")]
+    r = subprocess.run([sys.executable, "-c", code % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path, *outs)],
+                       env=dict(os.environ, STRL_BIN_TIMING="1"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "records parsed into place" in r.stderr, r.stderr          # the parts linked: no sequential walk
+    assert np.array_equal(np.load(outs[0]), t) and np.array_equal(np.load(outs[1]), qo) and open(outs[2], "rb").read() == qn
