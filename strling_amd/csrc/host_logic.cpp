@@ -925,10 +925,12 @@ int strl_bin_read(const char *path, strl_bin_info *info, char *sam_header, strl_
   // by induction from the true first record every boundary then is a true one.  Anything else: the sequential walk below.
   const size_t body0 = o;
   bool done_parallel = false;
-  const char *seq_env = getenv("STRL_BIN_READ");            // "seq": the sequential walk whatever the size (tests)
-  if (treads && qname_off && qnames && buf.size() - body0 >= ((size_t)32 << 20) && info->n_reads > 0 && !(seq_env && !strcmp(seq_env, "seq"))) {
+  const char *seq_env = getenv("STRL_BIN_READ");            // "seq": the sequential walk whatever the size; "parts=K": K parts whatever the size (tests)
+  const size_t forced_parts = seq_env && !strncmp(seq_env, "parts=", 6) ? (size_t)std::min(64, std::max(0, atoi(seq_env + 6))) : 0;
+  if (treads && qname_off && qnames && (buf.size() - body0 >= ((size_t)32 << 20) || (forced_parts >= 2 && buf.size() - body0 >= forced_parts)) && info->n_reads > 0 &&
+      !(seq_env && !strcmp(seq_env, "seq"))) {
     const unsigned hw = std::thread::hardware_concurrency();
-    const size_t K = std::min<size_t>({hw ? hw : 1u, 16u, (buf.size() - body0) >> 22});
+    const size_t K = forced_parts >= 2 ? forced_parts : std::min<size_t>({hw ? hw : 1u, 16u, (buf.size() - body0) >> 22});
     if (K >= 2) {
       // (two passes per share -- count, then parse into place -- instead of per-thread copies: the second pass costs a thread
       // 30 ms, a few hundred megabytes of freshly mapped temporaries cost page faults by the ten thousand)

@@ -251,3 +251,40 @@ def test_bin_reader_parts_survive_a_made_up_first_record(tmp_path):
     assert r.returncode == 0, r.stderr
     assert "records parsed into place" in r.stderr, r.stderr          # the parts linked: no sequential walk
     assert np.array_equal(np.load(outs[0]), t) and np.array_equal(np.load(outs[1]), qo) and open(outs[2], "rb").read() == qn
+
+
+def test_bin_reader_parts_on_small_files_equal_sequential(tmp_path, capfd, monkeypatch):
+    """the guess-and-link reader forced onto small files (STRL_BIN_READ=parts=K): every width of integer, names of 0..40 bytes,
+    names of 1..40 bytes, shares of a few records -- always the sequential walk's arrays, and the parts link in most files (the rest fall back)"""
+    rng = np.random.default_rng(77)
+    linked = cases = 0
+    for seed in range(60):
+        n = int(rng.integers(50, 3000))
+        t = np.zeros(n, api.TREAD_DTYPE)
+        t["tid"] = rng.integers(-1, [3, 200, 70000][seed % 3], n)
+        hi = [1 << 7, 1 << 16, 1 << 32][seed % 3]
+        t["position"] = rng.integers(0, hi, n, dtype=np.uint64).astype(np.uint32)
+        t["repeat"] = np.array([b"A", b"AC", b"AGC", b"AAAG", b"AAAAG", b"AACCCT"], "S6")[rng.integers(0, 6, n)]
+        t["flag"] = rng.integers(0, 4096, n)
+        t["split"] = rng.integers(0, 3, n); t["mapping_quality"] = rng.integers(0, 255, n)
+        t["repeat_count"] = rng.integers(0, 256, n); t["align_length"] = rng.integers(0, 256, n)
+        t["qname_id"] = np.arange(n)
+        lens = rng.integers(1, 41, n).astype(np.uint64)   # (an empty name: written as the reference writes it, refused as it refuses it)
+        qo = np.zeros(n + 1, np.uint64); qo[1:] = np.cumsum(lens)
+        qn = rng.integers(33, 127, int(qo[-1]), dtype=np.uint8).tobytes()
+        path = str(tmp_path / f"s{seed}.bin")
+        api.bin_write(path, 0.8, 40, np.zeros(4096, np.uint32), "@HD\tVN:1.6\n", t, qo, qn)
+        monkeypatch.setenv("STRL_BIN_READ", "seq")
+        a = api.bin_read(path)
+        assert np.array_equal(a["treads"], t) and np.array_equal(a["qname_off"], qo) and a["qnames"] == qn
+        for K in (2, int(rng.integers(3, 17))):
+            monkeypatch.setenv("STRL_BIN_READ", f"parts={K}")
+            monkeypatch.setenv("STRL_BIN_TIMING", "1")
+            capfd.readouterr()
+            b = api.bin_read(path)
+            err = capfd.readouterr().err
+            monkeypatch.delenv("STRL_BIN_TIMING")
+            cases += 1
+            linked += "records parsed into place" in err
+            assert np.array_equal(b["treads"], t) and np.array_equal(b["qname_off"], qo) and b["qnames"] == qn, (seed, K)
+    assert linked >= cases * 0.8, (linked, cases)
