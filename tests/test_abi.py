@@ -254,8 +254,8 @@ def test_bin_reader_parts_survive_a_made_up_first_record(tmp_path):
 
 
 def test_bin_reader_parts_on_small_files_equal_sequential(tmp_path, capfd, monkeypatch):
-    """the guess-and-link reader forced onto small files (STRL_BIN_READ=parts=K): every width of integer, names of 0..40 bytes,
-    names of 1..40 bytes, shares of a few records -- always the sequential walk's arrays, and the parts link in most files (the rest fall back)"""
+    """the guess-and-link reader forced onto small files (STRL_BIN_READ=parts=K): every width of integer, names of 1..40 bytes,
+    shares of a few records -- always the sequential walk's arrays, and the parts link in most files (the rest fall back)"""
     rng = np.random.default_rng(77)
     linked = cases = 0
     for seed in range(60):
