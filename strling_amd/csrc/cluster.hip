@@ -962,6 +962,7 @@ extern "C" int strl_cluster_resident(strl_ctx *c, int mode, int32_t n_tid, int p
   const bool async = !out && !n_out && !stats && !n_unplaced;     // results stay on the device
   const bool on_side = c && async && !c->timing && !no_overlap;   // the side stream runs its work in order: no join needed
   if (c && !on_side) { const int rcj = side_join(c); if (rcj) return rcj; }
+  if (on_side) { const int rcs = side_streams(c); if (rcs) return rcs; }
   if (!c) { set_error("null argument"); return STRL_ERR_ARG; }
   if (!c->n_treads_dev) { set_error("strl_cluster_resident: no strl_extract_device call on this context"); return STRL_ERR_ARG; }
   if (mode != STRL_MODE_CALL) { set_error("strl_cluster_resident clusters the treads of one sample (STRL_MODE_CALL)"); return STRL_ERR_ARG; }

@@ -88,6 +88,7 @@ inline uint64_t strl_record_limit() {
 namespace strl { struct strl_front; struct strl_comm; void comm_destroy(strl_comm *m); }
 struct strl_ctx;
 int side_join(strl_ctx *c);   // main stream waits for the side streams' pending work (score.hip)
+int side_streams(strl_ctx *c);   // the side streams of the overlapped mode, made at its first use (score.hip)
 void rotate_tail(strl_ctx *c);  // make the least recently used set of pair-logic / clustering state the current one (score.hip)
 constexpr int N_SETS = 2;        // batches in flight on a context: buffer sets of the scorer's output and of the tail (3 measured no faster than 2)
 

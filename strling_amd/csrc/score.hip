@@ -844,6 +844,14 @@ int side_join(strl_ctx *c) {
   return STRL_OK;
 }
 
+int side_streams(strl_ctx *c) {
+  if (c->stream2) return STRL_OK;
+  STRL_HIP(hipSetDevice(c->device));
+  STRL_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  for (auto &a : c->alt) if (!a.stream2) STRL_HIP(hipStreamCreateWithFlags(&a.stream2, hipStreamNonBlocking));
+  return STRL_OK;
+}
+
 static void swap_tail_with(strl_ctx *c, TailSet &a) {
   for (int i = 0; i < 16; ++i) std::swap(c->c_buf[i], a.c_buf[i]);
   std::swap(c->cl_run, a.cl_run);
@@ -908,33 +916,46 @@ int strl_ctx_create(int device_ordinal, strl_ctx **out) {
     return STRL_ERR_NO_DEVICE;
   }
   if (device_ordinal < 0 || device_ordinal >= n) { set_error("device ordinal %d out of range (%d devices)", device_ordinal, n); return STRL_ERR_ARG; }
+  static const bool lap_on = getenv("STRL_CTX_TIMING") != nullptr;
+  const auto lap0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) { if (lap_on) fprintf(stderr, "[strl_ctx_create] %s at %.4f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - lap0).count()); };
+  lap("device count known (the runtime is up)");
   STRL_HIP(hipSetDevice(device_ordinal));
   strl_ctx *c = new strl_ctx();
   c->device = device_ordinal;
+  lap("hipSetDevice");
   STRL_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  STRL_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-  for (auto &a : c->alt) {
-    STRL_HIP(hipStreamCreateWithFlags(&a.stream2, hipStreamNonBlocking));
-    STRL_HIP(hipEventCreateWithFlags(&a.ev_side_done, hipEventDisableTiming));
-  }
+  lap("first stream");
+  // (the side streams -- one per tail set, for the overlapped batches of strl_extract_device / an asynchronous clustering -- are
+  // made when that mode is first asked for, side_streams(): a stream is ~9.5 ms here, and `strling extract / call / merge`,
+  // which never overlap batches that way, waited for three of them at every start)
+  for (auto &a : c->alt) STRL_HIP(hipEventCreateWithFlags(&a.ev_side_done, hipEventDisableTiming));
   STRL_HIP(hipEventCreateWithFlags(&c->ev_main_done, hipEventDisableTiming));
   STRL_HIP(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
   STRL_HIP(hipEventCreateWithFlags(&c->ev_head_done, hipEventDisableTiming));
   for (auto &e : c->ev_set_free) STRL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : c->ev) STRL_HIP(hipEventCreate(&e));
   for (auto &e : c->pev) STRL_HIP(hipEventCreate(&e));
+  lap("streams and events");
   std::vector<uint16_t> lut;
   build_lut(lut);
   std::vector<uint32_t> clut, ta;
   build_conv_lut(clut);
   build_stage_a_tables(lut, ta);
+  lap("scorer tables built on the host");
   int rc = c->lut.reserve(lut.size() * 2 + clut.size() * 4 + ta.size() * 4);
   if (rc) return rc;
-  STRL_HIP(hipMemcpy(c->lut.p, lut.data(), lut.size() * 2, hipMemcpyHostToDevice));
-  STRL_HIP(hipMemcpy(static_cast<char *>(c->lut.p) + lut.size() * 2, clut.data(), clut.size() * 4, hipMemcpyHostToDevice));
-  STRL_HIP(hipMemcpy(static_cast<char *>(c->lut.p) + lut.size() * 2 + clut.size() * 4, ta.data(), ta.size() * 4, hipMemcpyHostToDevice));
+  lap("first hipMalloc");
+  {   // (one copy for the three tables: each synchronous copy out of pageable memory is ~3 ms at a process' start)
+    std::vector<uint8_t> all(lut.size() * 2 + clut.size() * 4 + ta.size() * 4);
+    memcpy(all.data(), lut.data(), lut.size() * 2);
+    memcpy(all.data() + lut.size() * 2, clut.data(), clut.size() * 4);
+    memcpy(all.data() + lut.size() * 2 + clut.size() * 4, ta.data(), ta.size() * 4);
+    STRL_HIP(hipMemcpy(c->lut.p, all.data(), all.size(), hipMemcpyHostToDevice));
+  }
   rc = c->counters.reserve(CNT_WORDS * 4);
   if (rc) return rc;
+  lap("tables on the device");
   *out = c;
   return STRL_OK;
 }
@@ -1477,6 +1498,7 @@ int strl_extract_device(strl_ctx *c, const strl_read_soa *s, const strl_pair_soa
   static const bool no_overlap = getenv("STRL_NO_OVERLAP") != nullptr;
   const bool overlap = s->mem == STRL_MEM_DEVICE && !c->timing && !no_overlap;
   if (overlap) {
+    if ((rc = side_streams(c))) return rc;
     rotate_head(c);                 // the scorer's output of this batch: the least recently used set
     rotate_tail(c);                 // this batch's pair logic and clustering: likewise, on that set's own side stream
     if ((rc = c->counters.reserve(CNT_WORDS * 4))) return rc;
@@ -1981,6 +2003,10 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
   STRL_HIP(hipSetDevice(c->device));
   STRL_HIP(hipStreamSynchronize(c->stream));
   strl::DevBuf pre_qref, pre_fragw, pre_qarena;
+  // ... and the front end's four streams beside them: a stream is ~9.5 ms of the runtime's time here (profiles/r06/ctx_laps.log),
+  // made one after the other behind the allocations they were most of this call
+  hipStream_t pre_st[4] = {nullptr, nullptr, nullptr, nullptr};       // inflate 0, inflate 1, record scan, copies
+  int pre_st_rc[4] = {0, 0, 0, 0};
   {
     struct Want { strl::DevBuf *b; size_t bytes; int rc; std::string err; };
     // ... and with them what the pair pass over the whole file takes at the END (strl_extract_finish -> strl_pair_device: join items,
@@ -2006,16 +2032,33 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
         w.rc = w.b->reserve(w.bytes);
         if (w.rc) w.err = strl_last_error();
       });
+    int least = 0, greatest = 0;          // (numerically: least >= greatest; equal where the device has one level)
+    STRL_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    for (int k = 0; k < 4; ++k)
+      th.emplace_back([&pre_st, &pre_st_rc, k, dev, least, greatest] {
+        hipError_t e = hipSetDevice(dev);
+        if (e == hipSuccess) e = k == 3 ? hipStreamCreateWithFlags(&pre_st[k], hipStreamNonBlocking) : hipStreamCreateWithPriority(&pre_st[k], hipStreamNonBlocking, k == 2 ? greatest : least);
+        pre_st_rc[k] = (int)e;
+      });
     for (auto &t : th) t.join();
+    auto drop_streams = [&] { for (hipStream_t &q : pre_st) if (q) { (void)hipStreamDestroy(q); q = nullptr; } };
+    for (int k = 0; k < 4; ++k)
+      if (pre_st_rc[k]) {
+        set_error("hipStreamCreate: %s", hipGetErrorString((hipError_t)pre_st_rc[k]));
+        drop_streams();
+        pre_qref.release(); pre_fragw.release(); pre_qarena.release();
+        return STRL_ERR_HIP;
+      }
     for (Want &w : want)
       if (w.rc) {
         set_error("%s", w.err.c_str());
+        drop_streams();
         pre_qref.release(); pre_fragw.release(); pre_qarena.release();
         return w.rc;
       }
   }
   int rc = extract_begin_sized(c, n_reads_hint, small);
-  if (rc) { pre_qref.release(); pre_fragw.release(); pre_qarena.release(); return rc; }
+  if (rc) { for (hipStream_t q : pre_st) if (q) (void)hipStreamDestroy(q); pre_qref.release(); pre_fragw.release(); pre_qarena.release(); return rc; }
   if (c->front) {
     for (hipStream_t q : c->front->st_i) if (q) (void)hipStreamSynchronize(q);
     if (c->front->st_a) (void)hipStreamSynchronize(c->front->st_a);
@@ -2026,13 +2069,7 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
   c->x_front = true;
   F->qref = pre_qref; F->fragw = pre_fragw; F->qarena = pre_qarena;        // (allocated above, beside the others; the context owns them from here)
   F->n_ref = n_ref; F->first_off = first_record_offset;
-  {
-    int least = 0, greatest = 0;          // (numerically: least >= greatest; equal where the device has one level)
-    STRL_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    for (hipStream_t &q : F->st_i) STRL_HIP(hipStreamCreateWithPriority(&q, hipStreamNonBlocking, least));
-    STRL_HIP(hipStreamCreateWithPriority(&F->st_a, hipStreamNonBlocking, greatest));
-  }
-  STRL_HIP(hipStreamCreateWithFlags(&F->st_c, hipStreamNonBlocking));
+  F->st_i[0] = pre_st[0]; F->st_i[1] = pre_st[1]; F->st_a = pre_st[2]; F->st_c = pre_st[3];   // (made above, beside the allocations)
   const unsigned host_waited = hipEventDisableTiming | (c->blocking_waits ? hipEventBlockingSync : 0u);   // ev_a, ev_b: what the feeding thread waits for
   for (strl::FrontSlot &S : F->slot) {
     STRL_HIP(hipEventCreateWithFlags(&S.ev_a, host_waited));
