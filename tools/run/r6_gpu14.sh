@@ -3,11 +3,9 @@
 # (which overlaps batches on the side streams), the context's laps on a small file, wall on the 1.3e8-read file
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R && export TMPDIR=/tmp
-O=gpurun_out/r6q; mkdir -p $O
+O=gpurun_out/r6r; mkdir -p $O
 CLI=$R/strling_amd/lib/strling
-timeout 1500 python -m pytest tests -q -m gpu > $O/gpu_tests.txt 2>&1; grep -E 'passed|failed' $O/gpu_tests.txt | tail -2
-timeout 900 python bench.py --no-e2e > $O/bench_step.json 2> $O/bench_step.err; python -c "
-import json; j=json.loads(open('$O/bench_step.json').read().strip().splitlines()[-1]); print('bench step', j['value'], j['ms_per_step'], j['roofline']['frac'])"
+timeout 900 python -m pytest tests/test_cli.py tests/test_front_device.py tests/test_call.py tests/test_multi_device.py -q -m gpu > $O/gpu_tests.txt 2>&1; grep -E 'passed|failed' $O/gpu_tests.txt | tail -2
 python - > $O/make.log 2>&1 <<'PY'
 import sys; sys.path.insert(0, 'tools'); sys.path.insert(0, '.')
 import e2e_bench
