@@ -165,10 +165,17 @@ def write_bai(path, rec, rec_off, block_off, block):
     n_ref = len(rec.targets)
     bins = [dict() for _ in range(n_ref)]
     lin = [dict() for _ in range(n_ref)]
+    meta = [None] * n_ref                 # [first offset, end offset, n_mapped, n_unmapped] (the pseudo-bin 37450 of samtools index)
+    no_coor = 0
     for i in range(rec.n):
         t = int(rec.tid[i])
         if t < 0:
+            no_coor += 1
             continue
+        if meta[t] is None:
+            meta[t] = [voff(rec_off[i]), 0, 0, 0]
+        meta[t][1] = voff(rec_off[i + 1])
+        meta[t][3 if int(rec.flag[i]) & 4 else 2] += 1
         beg = int(rec.pos[i])
         end = beg + _ref_len(rec, i)
         v0, v1 = voff(rec_off[i]), voff(rec_off[i + 1])
@@ -181,15 +188,18 @@ def write_bai(path, rec, rec_off, block_off, block):
             lin[t].setdefault(w, v0)
     out = bytearray(b"BAI\1" + struct.pack("<i", n_ref))
     for t in range(n_ref):
-        out += struct.pack("<i", len(bins[t]))
+        out += struct.pack("<i", len(bins[t]) + (meta[t] is not None))
         for b, chunks in sorted(bins[t].items()):
             out += struct.pack("<Ii", b, len(chunks))
             for v0, v1 in chunks:
                 out += struct.pack("<QQ", v0, v1)
+        if meta[t] is not None:
+            out += struct.pack("<IiQQQQ", 37450, 2, *meta[t])
         n_intv = (max(lin[t]) + 1) if lin[t] else 0
         out += struct.pack("<i", n_intv)
         for w in range(n_intv):
             out += struct.pack("<Q", lin[t].get(w, 0))       # empty windows stay 0, as in files written by older tools
+    out += struct.pack("<Q", no_coor)                        # n_no_coor, as samtools writes it
     with open(path, "wb") as f:
         f.write(out)
 
@@ -332,7 +342,8 @@ def _slab_worker(a):
             for d in range(int((w1 - w0).max()) + 1):                  # a read spans one or two windows
                 ok = w0 + d <= w1
                 np.minimum.at(lin, (w0 + d)[ok], ro[ok])
-            idx.append((chunk_bin, chunk_beg.astype(np.uint64), chunk_end.astype(np.uint64), lin))
+            n_unm = int(((rec.flag[a0:a1].astype(np.int64) & 4) != 0).sum())
+            idx.append((chunk_bin, chunk_beg.astype(np.uint64), chunk_end.astype(np.uint64), lin, (int(rec_off[a0]), int(rec_off[a1]), a1 - a0 - n_unm, n_unm)))
     tail = raw[cut:].tobytes()
     genome = [(int(s), int(e)) for s, e in zip(g.iv_start, g.iv_stop)], [int(x) - int(g.iv_off[2 * c]) for x in g.iv_off[2 * c:2 * c + 3]]
     return c, comp.tobytes(), csize, idx, tail, rec.n, m, genome
@@ -362,7 +373,7 @@ def write_bam_slabs(path, n_slabs, pairs_per_slab, seed=1234, level=6, quals=Tru
         hdr += struct.pack("<i", len(nb)) + nb + struct.pack("<i", length)
     procs = procs or max(1, min(n_slabs, int(_cpu_budget())))
     jobs = [(c, n_slabs, pairs_per_slab, seed, level, block, quals, aux, index) for c in range(n_slabs)]
-    tails, n_reads = [], 0
+    tails, n_reads, n_placed = [], 0, 0
     bai = [None] * (2 * n_slabs)
     bedf = open(bed, "w") if bed else None
     with open(path, "wb") as f:
@@ -386,12 +397,14 @@ def write_bam_slabs(path, n_slabs, pairs_per_slab, seed=1234, level=6, quals=Tru
                 for j, part in enumerate(idx):
                     if part is None:
                         continue
-                    cb, beg, end, lin = part
+                    cb, beg, end, lin, (m_beg, m_end, n_map, n_unm) = part
                     # an end offset on a block border belongs to the NEXT block (offset 0), like htslib's bgzf_tell
                     have = lin != np.iinfo(np.uint64).max
                     lv = np.zeros(lin.size, np.uint64)
                     lv[have] = voff(lin[have])
-                    bai[2 * c + j] = (cb, voff(beg), voff(end), lv)
+                    mv = voff(np.array([m_beg, m_end], np.uint64))
+                    bai[2 * c + j] = (cb, voff(beg), voff(end), lv, (int(mv[0]), int(mv[1]), n_map, n_unm))
+                    n_placed += n_map + n_unm
             if bedf:
                 ivs, off = genome
                 for t in range(2):
@@ -419,14 +432,16 @@ def write_bam_slabs(path, n_slabs, pairs_per_slab, seed=1234, level=6, quals=Tru
             if bai[t] is None:
                 out += struct.pack("<ii", 0, 0)
                 continue
-            cb, beg, end, lv = bai[t]
+            cb, beg, end, lv, meta = bai[t]
             ub, first = np.unique(cb, return_index=True)          # chunks of a bin are contiguous in cb (sorted by bin)
             counts = np.diff(np.append(first, cb.size))
-            out += struct.pack("<i", ub.size)
+            out += struct.pack("<i", ub.size + 1)
             for b, o, k in zip(ub.tolist(), first.tolist(), counts.tolist()):
                 out += struct.pack("<Ii", b, k)
                 out += np.stack([beg[o:o + k], end[o:o + k]], axis=1).astype("<u8").tobytes()
+            out += struct.pack("<IiQQQQ", 37450, 2, *meta)        # the metadata pseudo-bin of `samtools index`: file span, mapped / unmapped counts
             out += struct.pack("<i", lv.size) + lv.astype("<u8").tobytes()
+        out += struct.pack("<Q", n_reads - n_placed)              # n_no_coor
         with open(path + ".bai", "wb") as f:
             f.write(out)
     return {"reads": n_reads, "bytes": total, "targets": targets, "seconds": time.time() - t0, "procs": procs}

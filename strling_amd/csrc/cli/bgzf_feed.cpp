@@ -164,6 +164,45 @@ std::vector<uint64_t> BgzfFeed::split_points(const std::string &path) {
   return v;
 }
 
+bool BgzfFeed::indexed_records(const std::string &path, uint64_t &n) {
+  n = 0;
+  FILE *f = fopen((path + ".bai").c_str(), "rb");
+  if (!f && path.size() > 4) f = fopen((path.substr(0, path.size() - 4) + ".bai").c_str(), "rb");
+  if (!f) return false;
+  auto rd = [&](void *p, size_t k) { return fread(p, 1, k, f) == k; };
+  char magic[4];
+  int32_t n_ref = 0;
+  bool ok = rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && n_ref >= 0;
+  uint64_t total = 0;
+  std::vector<uint64_t> buf;
+  for (int32_t r = 0; ok && r < n_ref; ++r) {
+    int32_t n_bin = 0;
+    ok = rd(&n_bin, 4) && n_bin >= 0;
+    bool meta = false;
+    for (int32_t k = 0; ok && k < n_bin; ++k) {
+      uint32_t bin = 0;
+      int32_t n_chunk = 0;
+      ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0 && n_chunk < (1 << 28);
+      if (!ok) break;
+      buf.resize((size_t)n_chunk * 2);
+      ok = n_chunk == 0 || rd(buf.data(), (size_t)n_chunk * 16);
+      if (ok && bin == 37450) {
+        if (n_chunk != 2) ok = false;
+        else { total += buf[2] + buf[3]; meta = true; }      // chunk 1 = (n_mapped, n_unmapped)
+      }
+    }
+    if (ok && n_bin > 0 && !meta) ok = false;                 // a reference with records and no counts: an index written without them
+    int32_t n_intv = 0;
+    ok = ok && rd(&n_intv, 4) && n_intv >= 0 && fseeko(f, (off_t)n_intv * 8, SEEK_CUR) == 0;
+  }
+  uint64_t no_coor = 0;
+  ok = ok && rd(&no_coor, 8);                                 // (optional in the format; samtools writes it -- without it the count is not known)
+  fclose(f);
+  if (!ok) return false;
+  n = total + no_coor;
+  return true;
+}
+
 // the header walker: from the block at `start` to the end of the file, or (end_coff != 0) to the share's end -- the block at
 // end_coff is included when end_uoff > 0 (its first end_uoff bytes are the share's; trim_ = the rest)
 void BgzfFeed::walk_from(size_t start, uint64_t end_coff, uint32_t end_uoff) {

@@ -30,6 +30,10 @@ class BgzfFeed {
   // Virtual offsets (coffset << 16 | uoffset) of record starts named by the .bai next to `path` (linear index + bin chunk
   // starts), ascending and distinct; empty when there is no usable index.
   static std::vector<uint64_t> split_points(const std::string &path);
+  // the number of records of an indexed BAM from the index's metadata pseudo-bins (bin 37450 of every reference: mapped /
+  // placed-unmapped records) and the count of unplaced records behind the last reference -- what `samtools idxstats` adds up.
+  // false: no index, or one written without them
+  static bool indexed_records(const std::string &path, uint64_t &n);
   // inflated bytes at the end of the share's last block that belong to the next share (known once next() has said `last`)
   uint32_t tail_trim() const { return trim_; }
   const std::string &path() const { return path_; }

@@ -778,8 +778,16 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   // Reads the per-read state is sized for at the start (it grows geometrically beyond): a record of 150 bases with qualities
   // and a few tags takes 90 - 110 bytes of a level-6 BAM, 60 - 70 without qualities.  (The first sizing was file bytes / 48:
   // 124 GB of device memory and seconds of set-up for a 57 GB file of 5.4e8 reads.)
+  // An index beside the file knows the count (the metadata pseudo-bins `samtools idxstats` reads): the state is then sized for
+  // what the file holds -- a 30 x genome at 60 - 70 bytes a read is not under-sized and grown, the synthetic 57 GB file is not
+  // over-sized by a fifth (70 -> 59 GB of device memory).  A stale index costs what a wrong guess costs: the state grows.
   static const char *env_hint = getenv("STRL_READS_HINT");
-  const uint64_t reads_hint = env_hint ? strtoull(env_hint, nullptr, 10) : feed.file_bytes() / 88 / (size_t)G;
+  uint64_t indexed = 0;
+  const bool have_count = !env_hint && !getenv("STRL_NO_INDEX_COUNT") && BgzfFeed::indexed_records(bam, indexed) && indexed > 0;
+  const uint64_t reads_hint = env_hint     ? strtoull(env_hint, nullptr, 10)
+                              : have_count ? (G > 1 ? (indexed + indexed / 20) / (uint64_t)G + 65536 : indexed + indexed / 256 + 65536)
+                                           : feed.file_bytes() / 88 / (size_t)G;
+  if (verbose && have_count) fprintf(stderr, "[strling] %llu records by the index's counts\n", (unsigned long long)indexed);
   // Shares of the file, one per context: [cut[g], cut[g + 1]) in virtual offsets, every cut a record start the .bai names
   // (the one nearest to g / G of the bytes behind the header).  extract.nim:308-329 is one loop over the file in file order;
   // the shares are gathered in that order afterwards (strl_ctxs_extract_gather), so nothing downstream can tell.
@@ -2545,6 +2553,12 @@ int main(int argc, char **argv) {
   if (cmd == "_region") return region_main(argc, argv);
   if (cmd == "_shares") return shares_main(argc, argv);
   if (cmd == "_codec") return codec_main(argc, argv);
+  if (cmd == "_indexed_records") {     // (tests) the record count the index beside a BAM gives, or "unknown"
+    uint64_t n = 0;
+    if (argc > 2 && BgzfFeed::indexed_records(argv[2], n)) printf("%llu\n", (unsigned long long)n);
+    else printf("unknown\n");
+    return 0;
+  }
   if (cmd == "pull_region")
     quit("[strling] `%s` is not part of this build (the MI355X path covers index, extract, merge and call; see DESIGN.md section 9)", cmd.c_str());
   fputs(top, stdout);

@@ -55,3 +55,20 @@ def test_index_windows_and_regions_match_oracle(ctx, oracle, n_bases, seed, p):
     exp_words = oracle_window_words(oracle, seq.decode(), p)
     assert np.array_equal(words, exp_words), np.nonzero(words != exp_words)[0][:10]
     assert ctx.index_regions(seq) == oracle.index_chrom(seq.upper(), p)
+
+
+def test_indexed_records_needs_the_metadata_bins(tmp_path):
+    """an index written without the pseudo-bin 37450 (older tools) or without the trailing n_no_coor gives no count: the CLI then
+    sizes by the file's bytes as before"""
+    import struct
+    import subprocess
+    from strling_amd import build
+    bam = str(tmp_path / "x.bam")
+    open(bam, "wb").write(b"")
+    plain = b"BAI\1" + struct.pack("<i", 1) + struct.pack("<i", 1) + struct.pack("<IiQQ", 4681, 1, 100 << 16, 200 << 16) + struct.pack("<iQ", 1, 100 << 16)
+    meta = b"BAI\1" + struct.pack("<i", 2) + struct.pack("<i", 2) + struct.pack("<IiQQ", 4681, 1, 100 << 16, 200 << 16) + struct.pack("<IiQQQQ", 37450, 2, 100 << 16, 200 << 16, 7, 2) + \
+        struct.pack("<iQ", 1, 100 << 16) + struct.pack("<ii", 0, 0)                     # a second reference without records
+    for data, want in ((plain, "unknown"), (plain + struct.pack("<Q", 5), "unknown"), (meta, "unknown"), (meta + struct.pack("<Q", 5), "14"), (meta[:40], "unknown")):
+        open(bam + ".bai", "wb").write(data)
+        r = subprocess.run([build.CLI, "_indexed_records", bam], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.strip() == want, (want, r.stdout, r.stderr)

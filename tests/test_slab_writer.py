@@ -1,5 +1,6 @@
 """The whole-genome sized BAM writer (bamio.write_bam_slabs + tools/bamgen/bamgen.c: test / bench infrastructure) against the
 plain Python writer: same record bytes, an index that says the same thing, slabs that can be regenerated alone."""
+import os
 import struct
 import zlib
 
@@ -37,6 +38,11 @@ def _bai_abs(path, at):
         bins = {}
         for _ in range(n_bin):
             b, nc = struct.unpack_from("<Ii", d, o); o += 8
+            if b == 37450:                                   # the metadata pseudo-bin: (file span), (n_mapped, n_unmapped)
+                v0, v1, n_map, n_unm = struct.unpack_from("<QQQQ", d, o); o += 32
+                assert nc == 2
+                bins[b] = [[ab(v0), ab(v1)], [n_map, n_unm]]
+                continue
             ch = []
             for _ in range(nc):
                 v0, v1 = struct.unpack_from("<QQ", d, o); o += 16
@@ -48,8 +54,9 @@ def _bai_abs(path, at):
         n_intv = struct.unpack_from("<i", d, o)[0]; o += 4
         lin = [ab(v) if v else None for v in struct.unpack_from(f"<{n_intv}Q", d, o)]; o += 8 * n_intv
         refs.append((bins, lin))
+    no_coor = struct.unpack_from("<Q", d, o)[0]; o += 8
     assert o == len(d)
-    return refs
+    return refs, no_coor
 
 
 def test_slab_file_equals_the_python_writer(tmp_path):
@@ -64,11 +71,23 @@ def test_slab_file_equals_the_python_writer(tmp_path):
     rb, at_b = _inflate(b)
     assert ra == rb                                                    # header + every record, byte for byte
     assert open(tmp_path / "slab.str").read() == open(tmp_path / "plain.str").read()
-    ia, ib = _bai_abs(a + ".bai", at_a), _bai_abs(b + ".bai", at_b)
+    (ia, no_coor_a), (ib, no_coor_b) = _bai_abs(a + ".bai", at_a), _bai_abs(b + ".bai", at_b)
     assert len(ia) == len(ib) == 2 * n_slabs
     for (bins_a, lin_a), (bins_b, lin_b) in zip(ia, ib):
-        assert bins_a == bins_b
+        assert bins_a == bins_b                                        # (the metadata pseudo-bin 37450 with them: span and counts)
         assert [x for x in lin_a] == [x for x in lin_b]
+    # the counts `samtools idxstats` reads: mapped + placed-unmapped per reference, the unplaced tail -- and the CLI's sum of them
+    assert no_coor_a == no_coor_b == int((rec.tid < 0).sum())
+    for t, (bins_a, _) in enumerate(ia):
+        sel = rec.tid == t
+        assert bins_a[37450][1] == [int((sel & ((rec.flag & 4) == 0)).sum()), int((sel & ((rec.flag & 4) != 0)).sum())]
+    import subprocess
+    from strling_amd import build
+    for path in (a, b):
+        r = subprocess.run([build.CLI, "_indexed_records", path], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.strip() == str(rec.n), (r.stdout, r.stderr)
+    os.remove(b + ".bai")
+    assert subprocess.run([build.CLI, "_indexed_records", b], capture_output=True, text=True).stdout.strip() == "unknown"
 
 
 def test_a_slab_regenerates_alone_and_quals_aux_keep_the_fields(tmp_path):
