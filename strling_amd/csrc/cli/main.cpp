@@ -780,7 +780,7 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   // 124 GB of device memory and seconds of set-up for a 57 GB file of 5.4e8 reads.)
   // An index beside the file knows the count (the metadata pseudo-bins `samtools idxstats` reads): the state is then sized for
   // what the file holds -- a 30 x genome at 60 - 70 bytes a read is not under-sized and grown, the synthetic 57 GB file is not
-  // over-sized by a fifth (70 -> 59 GB of device memory).  A stale index costs what a wrong guess costs: the state grows.
+  // over-sized by a fifth (71.6 -> 60.5 GB of device memory).  A stale index costs what a wrong guess costs: the state grows.
   static const char *env_hint = getenv("STRL_READS_HINT");
   uint64_t indexed = 0;
   const bool have_count = !env_hint && !getenv("STRL_NO_INDEX_COUNT") && BgzfFeed::indexed_records(bam, indexed) && indexed > 0;

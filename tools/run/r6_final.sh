@@ -4,18 +4,18 @@
 # replicas on the one device, and the front end's kernel trace (as it runs, and with every launch alone on the device)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R && export TMPDIR=/tmp
-O=gpurun_out/r6s; mkdir -p $O
+O=gpurun_out/r6u; mkdir -p $O
 CLI=$R/strling_amd/lib/strling
 timeout 2400 python -m pytest tests -q -m gpu > $O/gpu_tests_final.txt 2>&1; grep -E 'passed|failed' $O/gpu_tests_final.txt | tail -2
 timeout 2400 python bench.py > $O/bench_default_full_size.json 2> $O/bench_default_full_size.err
 python - <<'PY'
 import json
 try:
-    j = json.loads(open('gpurun_out/r6s/bench_default_full_size.json').read().strip().splitlines()[-1]); e = j['end_to_end']
+    j = json.loads(open('gpurun_out/r6u/bench_default_full_size.json').read().strip().splitlines()[-1]); e = j['end_to_end']
     print('bench: value', j['value'], 'ms', j['ms_per_step'], 'frac', j['roofline']['frac'], 'traffic', j['roofline']['traffic'], '| e2e reads', e['reads'], 'extract_s', e.get('extract_s'), 'first', e.get('first_run_wall_s'), 'call', e.get('call_s'), 'merge', e.get('merge_s'), 'x+c', e.get('extract_plus_call_s'), 'check', (e.get('check') or {}).get('ok'), (e.get('check') or {}).get('slabs'), 'vs cpu', e.get('vs_cpu_baseline_e2e_wall'), e.get('vs_cpu_baseline_e2e_extract_plus_call'))
     for r in e['runs']: print('  run', r['wall_s'], r['loop_s'], r['outside_the_loop'][:330])
 except Exception as ex:
-    print('bench failed', ex); print(open('gpurun_out/r6s/bench_default_full_size.err').read()[-1500:])
+    print('bench failed', ex); print(open('gpurun_out/r6u/bench_default_full_size.err').read()[-1500:])
 PY
 B=$(ls /tmp/e2e_268435456_6.bam /dev/shm/e2e_268435456_6.bam 2>/dev/null | head -1); S=${B%.bam}.str
 if [ -n "$B" ]; then
