@@ -179,9 +179,15 @@ bool BamReader::load_index(const std::string &bam_path, std::string &err) {
   if (!f && bam_path.size() > 4) f = fopen((bam_path.substr(0, bam_path.size() - 4) + ".bai").c_str(), "rb");
   if (!f) { err = "no .bai index next to " + bam_path; return false; }
   auto rd = [&](void *p, size_t n) { return fread(p, 1, n, f) == n; };
+  fseeko(f, 0, SEEK_END);
+  const uint64_t f_size = (uint64_t)std::max<off_t>(ftello(f), 0);
+  fseeko(f, 0, SEEK_SET);
+  auto left = [&]() -> uint64_t { const off_t at = ftello(f); return at < 0 || (uint64_t)at > f_size ? 0 : f_size - (uint64_t)at; };
   char magic[4];
   int32_t n_ref = 0;
-  bool ok = rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && n_ref >= 0;
+  // (counts the file cannot hold -- a reference takes 8 bytes at least, an interval 8 -- are a corrupt index, not allocations)
+  bool ok = rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && n_ref >= 0 && (uint64_t)n_ref * 8 <= left();
+  if (!ok) n_ref = 0;
   lin_.assign((size_t)std::max(n_ref, 0), {});
   ref_beg_.assign((size_t)std::max(n_ref, 0), 0);
   for (int32_t r = 0; ok && r < n_ref; ++r) {
@@ -199,7 +205,7 @@ bool BamReader::load_index(const std::string &bam_path, std::string &err) {
       }
     }
     int32_t n_intv = 0;
-    ok = ok && rd(&n_intv, 4) && n_intv >= 0;
+    ok = ok && rd(&n_intv, 4) && n_intv >= 0 && (uint64_t)n_intv * 8 <= left();
     if (ok) {
       lin_[(size_t)r].resize((size_t)n_intv);
       ok = n_intv == 0 || rd(lin_[(size_t)r].data(), (size_t)n_intv * 8);

@@ -133,6 +133,10 @@ std::vector<uint64_t> BgzfFeed::split_points(const std::string &path) {
   if (!f && path.size() > 4) f = fopen((path.substr(0, path.size() - 4) + ".bai").c_str(), "rb");
   if (!f) return v;
   auto rd = [&](void *p, size_t n) { return fread(p, 1, n, f) == n; };
+  fseeko(f, 0, SEEK_END);
+  const uint64_t f_size = (uint64_t)std::max<off_t>(ftello(f), 0);
+  fseeko(f, 0, SEEK_SET);
+  auto left = [&]() -> uint64_t { const off_t at = ftello(f); return at < 0 || (uint64_t)at > f_size ? 0 : f_size - (uint64_t)at; };
   char magic[4];
   int32_t n_ref = 0;
   bool ok = rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && n_ref >= 0;
@@ -143,14 +147,14 @@ std::vector<uint64_t> BgzfFeed::split_points(const std::string &path) {
     for (int32_t k = 0; ok && k < n_bin; ++k) {
       uint32_t bin = 0;
       int32_t n_chunk = 0;
-      ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0 && n_chunk < (1 << 28);
+      ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0 && (uint64_t)n_chunk * 16 <= left();      // (a count the file cannot hold: not an allocation)
       if (!ok) break;
       buf.resize((size_t)n_chunk * 2);
       ok = n_chunk == 0 || rd(buf.data(), (size_t)n_chunk * 16);
       if (ok && bin != 37450) for (int32_t c = 0; c < n_chunk; ++c) v.push_back(buf[(size_t)c * 2]);   // 37450: the metadata pseudo-bin
     }
     int32_t n_intv = 0;
-    ok = ok && rd(&n_intv, 4) && n_intv >= 0;
+    ok = ok && rd(&n_intv, 4) && n_intv >= 0 && (uint64_t)n_intv * 8 <= left();
     if (ok && n_intv) {
       buf.resize((size_t)n_intv);
       ok = rd(buf.data(), (size_t)n_intv * 8);
@@ -170,6 +174,10 @@ bool BgzfFeed::indexed_records(const std::string &path, uint64_t &n) {
   if (!f && path.size() > 4) f = fopen((path.substr(0, path.size() - 4) + ".bai").c_str(), "rb");
   if (!f) return false;
   auto rd = [&](void *p, size_t k) { return fread(p, 1, k, f) == k; };
+  fseeko(f, 0, SEEK_END);
+  const uint64_t f_size = (uint64_t)std::max<off_t>(ftello(f), 0);
+  fseeko(f, 0, SEEK_SET);
+  auto left = [&]() -> uint64_t { const off_t at = ftello(f); return at < 0 || (uint64_t)at > f_size ? 0 : f_size - (uint64_t)at; };
   char magic[4];
   int32_t n_ref = 0;
   bool ok = rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && n_ref >= 0;
@@ -182,7 +190,7 @@ bool BgzfFeed::indexed_records(const std::string &path, uint64_t &n) {
     for (int32_t k = 0; ok && k < n_bin; ++k) {
       uint32_t bin = 0;
       int32_t n_chunk = 0;
-      ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0 && n_chunk < (1 << 28);
+      ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0 && (uint64_t)n_chunk * 16 <= left();      // (a count the file cannot hold: not an allocation)
       if (!ok) break;
       buf.resize((size_t)n_chunk * 2);
       ok = n_chunk == 0 || rd(buf.data(), (size_t)n_chunk * 16);
@@ -193,7 +201,7 @@ bool BgzfFeed::indexed_records(const std::string &path, uint64_t &n) {
     }
     if (ok && n_bin > 0 && !meta) ok = false;                 // a reference with records and no counts: an index written without them
     int32_t n_intv = 0;
-    ok = ok && rd(&n_intv, 4) && n_intv >= 0 && fseeko(f, (off_t)n_intv * 8, SEEK_CUR) == 0;
+    ok = ok && rd(&n_intv, 4) && n_intv >= 0 && (uint64_t)n_intv * 8 <= left() && fseeko(f, (off_t)n_intv * 8, SEEK_CUR) == 0;
   }
   uint64_t no_coor = 0;
   ok = ok && rd(&no_coor, 8);                                 // (optional in the format; samtools writes it -- without it the count is not known)

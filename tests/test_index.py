@@ -72,3 +72,31 @@ def test_indexed_records_needs_the_metadata_bins(tmp_path):
         open(bam + ".bai", "wb").write(data)
         r = subprocess.run([build.CLI, "_indexed_records", bam], capture_output=True, text=True)
         assert r.returncode == 0 and r.stdout.strip() == want, (want, r.stdout, r.stderr)
+
+
+def test_an_index_with_counts_the_file_cannot_hold_is_corrupt_not_an_allocation(tmp_path):
+    """n_ref / n_chunk / n_intv of a .bai are trusted only as far as the file's size goes: the three parsers (record counts, share
+    cuts, region reads) say unknown / corrupt at once instead of reserving gigabytes"""
+    import struct
+    import subprocess
+    import time
+    from strling_amd import bamio, build, synth
+    rec, _ = synth.synth_wgs_30x(1, 400, seed=3, procs=1)
+    bam = str(tmp_path / "x.bam")
+    bamio.write_bam(bam, rec, level=1)
+    good = open(bam + ".bai", "rb").read()
+    hostile = [b"BAI\1" + struct.pack("<i", 0x7fffffff),                                             # references
+               b"BAI\1" + struct.pack("<ii", 1, 1) + struct.pack("<Ii", 4681, 0x0fffffff),             # chunks of a bin
+               b"BAI\1" + struct.pack("<ii", 1, 0) + struct.pack("<i", 0x7fffffff)]                    # intervals
+    for data in hostile:
+        open(bam + ".bai", "wb").write(data)
+        t0 = time.time()
+        r = subprocess.run([build.CLI, "_indexed_records", bam], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.strip() == "unknown"
+        r = subprocess.run([build.CLI, "_shares", bam, "4"], capture_output=True, text=True)
+        assert r.returncode in (0, 1) and "bad_alloc" not in r.stderr, r.stderr
+        r = subprocess.run([build.CLI, "_region", bam, "0", "0", "1000"], capture_output=True, text=True)
+        assert r.returncode != 0 and "bad_alloc" not in r.stderr and "corrupt .bai" in r.stderr, r.stderr
+        assert time.time() - t0 < 5
+    open(bam + ".bai", "wb").write(good)
+    assert subprocess.run([build.CLI, "_indexed_records", bam], capture_output=True, text=True).stdout.strip() == str(rec.n)
