@@ -815,6 +815,9 @@ int strl_bin_peek(const char *path, strl_bin_info *info) {
   if (!ok || n < 0) { set_error("truncated bin header"); return STRL_ERR_FORMAT; }
   info->n_reads = n;
   info->qnames_bytes = (uint64_t)sz - fixed - (uint64_t)info->header_len - 4;
+  // (callers size their arrays from n_reads: a record is 15 bytes at the very least -- a count the file cannot hold is refused
+  // here, not allocated for and then found wrong by the read, unpack.nim:130-131)
+  if ((uint64_t)n * 15 > info->qnames_bytes) { set_error("[strling] expected %d got fewer: the file holds %llu bytes of records", n, (unsigned long long)info->qnames_bytes); return STRL_ERR_FORMAT; }
   return STRL_OK;
 }
 

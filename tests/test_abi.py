@@ -288,3 +288,24 @@ def test_bin_reader_parts_on_small_files_equal_sequential(tmp_path, capfd, monke
             linked += "records parsed into place" in err
             assert np.array_equal(b["treads"], t) and np.array_equal(b["qname_off"], qo) and b["qnames"] == qn, (seed, K)
     assert linked >= cases * 0.8, (linked, cases)
+
+
+def test_bin_header_count_the_file_cannot_hold_is_refused_by_the_peek(tmp_path):
+    """callers size their arrays from the header's read count (strl_bin_peek): 2^31 - 1 reads in a 17 KB file is a format error
+    there, not a 64 GB allocation followed by the reader's `expected N got M`"""
+    import ctypes as C
+    t = np.zeros(3, api.TREAD_DTYPE)
+    t["repeat"] = b"AC"; t["qname_id"] = np.arange(3)
+    path = str(tmp_path / "few.bin")
+    hdr = "@HD\tVN:1.6\n"
+    api.bin_write(path, 0.8, 40, np.zeros(4096, np.uint32), hdr, t, np.array([0, 2, 4, 6], np.uint64), b"aabbcc")
+    info = api.BinInfo()
+    assert api.load().strl_bin_peek(path.encode(), C.byref(info)) == 0 and info.n_reads == 3
+    raw = bytearray(open(path, "rb").read())
+    at = 3 + 2 + 9 + 4 + 1 + 4096 * 4 + 4 + len(hdr)
+    assert int.from_bytes(raw[at:at + 4], "little") == 3
+    raw[at:at + 4] = (0x7fffffff).to_bytes(4, "little")
+    open(path, "wb").write(raw)
+    assert api.load().strl_bin_peek(path.encode(), C.byref(info)) != 0 and b"expected 2147483647" in api.load().strl_last_error()
+    with pytest.raises(api.StrlingError):
+        api.bin_read(path)
