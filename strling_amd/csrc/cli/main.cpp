@@ -1302,7 +1302,20 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   const double t_pair = secs(tp0, now());
   fprintf(stderr, "[strling] writing binary file:%s\n", bin.c_str());
   const auto tw0 = now();
-  CHECK(strl_bin_write(bin.c_str(), (float)p, min_mapq, frag, feed.header_text().data(), (int32_t)feed.header_text().size(), treads_p, nt, qoff_p, names_p));
+  // The rings the .bin is not written out of go back meanwhile: un-registering page-locked memory the DMA engines have used
+  // is ~0.1 s per GB (profiles/r06/exit_where.log) whoever does it -- this thread beside the writer's, or the kernel behind
+  // the process' last line, on the caller's clock.  (STRL_NO_EARLY_UNPIN=1: left to the exit.)
+  std::thread early_unpin;
+  if (!getenv("STRL_NO_EARLY_UNPIN"))
+    early_unpin = std::thread([&] {
+      for (size_t k = 0; k < pin.size(); ++k) {
+        if (pin[k] && (void *)pin[k] != (void *)treads_p && (void *)pin[k] != (void *)qoff_p) { strl_pinned_free(pin[k]); pin[k] = nullptr; }
+        if (pin_meta[k]) { strl_pinned_free(pin_meta[k]); pin_meta[k] = nullptr; }
+      }
+    });
+  const int bin_rc = strl_bin_write(bin.c_str(), (float)p, min_mapq, frag, feed.header_text().data(), (int32_t)feed.header_text().size(), treads_p, nt, qoff_p, names_p);
+  if (early_unpin.joinable()) early_unpin.join();
+  CHECK(bin_rc);
   const double t_write = secs(tw0, now());
   fprintf(stderr, "[strling] finished extraction\n");
   if (verbose) {
