@@ -2024,6 +2024,8 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
                    {&c->p_key0, p_max * 8, 0, {}}, {&c->p_key1, p_max * 8, 0, {}}, {&c->p_val0, p_max * 4, 0, {}}, {&c->p_val1, p_max * 4, 0, {}},
                    {&c->p_emit, (size_t)p_ecap * sizeof(strl_tread), 0, {}}, {&c->treads, (size_t)p_ecap * sizeof(strl_tread) + 64, 0, {}}, {&c->sort_scratch, p_sb, 0, {}}};
     const int dev = c->device;
+    int least = 0, greatest = 0;          // (numerically: least >= greatest; equal where the device has one level)
+    STRL_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));      // (in front of the threads: nothing may return between their start and their join)
     std::vector<std::thread> th;
     for (Want &w : want)
       th.emplace_back([&w, dev] {
@@ -2032,8 +2034,6 @@ int strl_front_begin(strl_ctx *c, int32_t n_ref, uint64_t first_record_offset, u
         w.rc = w.b->reserve(w.bytes);
         if (w.rc) w.err = strl_last_error();
       });
-    int least = 0, greatest = 0;          // (numerically: least >= greatest; equal where the device has one level)
-    STRL_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     for (int k = 0; k < 4; ++k)
       th.emplace_back([&pre_st, &pre_st_rc, k, dev, least, greatest] {
         hipError_t e = hipSetDevice(dev);
