@@ -783,7 +783,8 @@ static int extract_front(const Args &a, const std::string &bam, const std::strin
   // over-sized by a fifth (71.6 -> 60.5 GB of device memory).  A stale index costs what a wrong guess costs: the state grows.
   static const char *env_hint = getenv("STRL_READS_HINT");
   uint64_t indexed = 0;
-  const bool have_count = !env_hint && !getenv("STRL_NO_INDEX_COUNT") && BgzfFeed::indexed_records(bam, indexed) && indexed > 0;
+  // (a count of more records than the file has bytes is not believed: the state would be allocated for it)
+  const bool have_count = !env_hint && !getenv("STRL_NO_INDEX_COUNT") && BgzfFeed::indexed_records(bam, indexed) && indexed > 0 && indexed <= feed.file_bytes();
   const uint64_t reads_hint = env_hint     ? strtoull(env_hint, nullptr, 10)
                               : have_count ? (G > 1 ? (indexed + indexed / 20) / (uint64_t)G + 65536 : indexed + indexed / 256 + 65536)
                                            : feed.file_bytes() / 88 / (size_t)G;
